@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py - EKF updates/sec of the MI355X measurement-update path.
+
+One "step" = one measurement update of every filter in the batch (B independent
+filters per GPU; filters shard across GPUs with no collective - SURVEY.md 8e).
+Workload = BASELINE.json's metric point: state dim 250, 80 features (M = 160),
+fp64, XIVO row sparsity, inputs resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0). See DESIGN.md section "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD datasheet). 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz
+
+
+def f_alg(N, M):
+    """Reference as-coded flops of UpdateJosephForm."""
+    return 4.0 * N ** 3 + 8.0 * M * N ** 2 + 4.0 * M ** 2 * N + M ** 3 / 3.0
+
+
+def cpu_baseline(N, F, seconds=12.0):
+    """Times the CPU path on a bounded sample of the same workload (rank 0, N=1 only).
+    Prefers oracle/_ref (Eigen 3.3.9, the reference's own arithmetic, 1 thread like
+    the reference's singleton estimator); falls back to the numpy oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from xivo_amd import synth
+    P, H, inn, dR = synth.s_level(N, F, 2, seed=12345)
+    M = 2 * F
+    try:
+        import ref_binding
+        ref = ref_binding.load()
+    except Exception:
+        ref = None
+    if ref is not None:
+        fn = lambda b: ref.update_joseph(H[b], P[b], inn[b], dR[b])
+        kind, what, cores = "port", "oracle/_ref: Eigen-3.3.9 expression-faithful driver of estimator.cpp:1257-1288, -O3, 1 thread", 1
+    else:
+        import xivo_oracle as orc
+        try:
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(1)
+        except Exception:
+            pass
+        fn = lambda b: orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        kind, what, cores = "port", "oracle/xivo_oracle.py numpy restatement, BLAS pinned to 1 thread", 1
+    fn(0)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn(n & 1)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "updates/s", "cores": cores, "kind": kind,
+            "sample": f"{n} updates of (N={N}, M={M}) in {dt:.1f}s; {what}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="filters per GPU")
+    ap.add_argument("--state-dim", type=int, default=250)
+    ap.add_argument("--features", type=int, default=80)
+    ap.add_argument("--level", choices=["S", "G"], default="S",
+                    help="S: dense H resident (UpdateJosephForm only); G: + Jacobians, gating, stacking")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from xivo_amd import synth
+    from xivo_amd.lib import Context, FLAG_PROFILE, load_library
+
+    N, F, B = args.state_dim, args.features, args.batch
+    M = 2 * F
+    flags = 0 if args.no_profile else FLAG_PROFILE
+    ctx = Context(N, M, B, device=local_rank, flags=flags)
+
+    # synthetic inputs: 64 distinct seeded filters per rank, tiled to the batch
+    uniq = min(B, 64)
+    P, H, inn, dR = synth.s_level(N, F, uniq, seed=1000 + rank)
+    reps = (B + uniq - 1) // uniq
+    tile = lambda a: np.concatenate([a] * reps, axis=0)[:B]
+    ctx.upload_P(tile(P))
+    ctx.set_measurements(tile(H), tile(inn), tile(dR))
+    ctx.snapshot_P()
+
+    def step():
+        ctx.update_joseph(B)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    ctx.timer_begin()
+    for _ in range(args.steps):
+        step()
+    gpu_ms = ctx.timer_end()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    status = ctx.get_status(check=False)
+    prof = ctx.profile_get() if flags else {}
+    peak_meas = ctx.bench_mfma_peak() if rank == 0 else None
+
+    if rank == 0:
+        updates = world * B * args.steps
+        value = updates / dt
+        lib = load_library()
+        import ctypes as C
+
+        def tile_of(r, c):
+            bm, bn = C.c_int(), C.c_int()
+            lib.xivo_hip_gemm_tile(r, c, C.byref(bm), C.byref(bn))
+            return f"gemm_nt_f64_kernel<{bm.value // 32},{bn.value // 32}>"
+
+        # group stages by the kernel instantiation rocprofv3 would report them under
+        shape = {"gemm_HP": (M, N), "gemm_S": (M, M), "gemm_KH_I": (N, N), "gemm_AP": (N, N), "gemm_Pnew": (N, N)}
+        groups = {}
+        for name, st in prof.items():
+            if st["launches"] == 0:
+                continue
+            kname = tile_of(*shape[name]) if name in shape else name
+            g = groups.setdefault(kname, {"ms": 0.0, "launches": 0, "flops": 0.0, "stages": []})
+            g["ms"] += st["ms"]; g["launches"] += st["launches"]
+            g["flops"] += st["flops_per_launch"] * st["launches"]; g["stages"].append(name)
+        roofline = None
+        if groups:
+            dom = max(groups, key=lambda k: groups[k]["ms"])
+            g = groups[dom]
+            achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "stages": g["stages"],
+                        "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                        "avg_launch_ms": g["ms"] / g["launches"], "launches": g["launches"],
+                        "traffic": None,
+                        "mfma_peak_measured_tflops": peak_meas,
+                        "pipeline_f_alg_tflops": f_alg(N, M) * value / world / 1e12,
+                        "pipeline_frac": f_alg(N, M) * value / world / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+        out = {
+            "metric": "EKF updates/sec (state dim 250, 80 feats) @1 GPU; % MFMA roofline",
+            "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"S-level UpdateJosephForm: state dim {N}, {F} features (M={M}), "
+                                   f"XIVO row sparsity, P/H/inn/R resident in HBM",
+                       "filters_per_gpu": B, "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
+                       "gpu_event_ms_per_step": gpu_ms / args.steps,
+                       "not_spd_filters": int((status != 0).sum())},
+            "roofline": roofline,
+            "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, F)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

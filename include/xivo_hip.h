@@ -1,0 +1,208 @@
+/* xivo_hip.h - C ABI of the MI355X-native EKF measurement-update path for XIVO.
+ *
+ * Drop-in boundary for the reference's private hot path (the reference has no
+ * FFI of its own - SURVEY.md section 8b): each entry point below names the
+ * reference member function / lines it replaces, relative to /root/reference.
+ *
+ * Conventions
+ *  - plain C, no exceptions, no aborts: every call returns XIVO_HIP_OK (0) or a
+ *    negative status (the reference LOG(FATAL)s / throws instead,
+ *    src/estimator.cpp:121,587,821,844 - the C++ adapter in
+ *    xivo_amd/host/estimator_hip.h converts a non-zero status back to that).
+ *  - all matrices are column-major double (common/alias.h:11, Eigen default),
+ *    with an explicit leading dimension where the caller owns the buffer.
+ *  - batch-first: a context holds `batch_max` independent filters (the
+ *    reference is one singleton filter per process, src/estimator.cpp:26);
+ *    "b0, nb" = first filter and number of filters a call touches.
+ *  - the covariance P of every filter is device resident; host edits of P go
+ *    through the xivo_hip_p_* calls (mirrors of the host edits listed in
+ *    SURVEY.md a17) or through upload/download.
+ *  - a context is single threaded (like the reference's estimator); different
+ *    contexts may be driven from different host threads / processes (one per GPU).
+ *  - host pointers are borrowed for the duration of the call only.
+ */
+#ifndef XIVO_HIP_H_
+#define XIVO_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xivo_hip_ctx xivo_hip_ctx;
+
+enum {
+  XIVO_HIP_OK = 0,
+  XIVO_HIP_ERR_INVALID = -1,     /* bad argument / size                         */
+  XIVO_HIP_ERR_HIP = -2,         /* a HIP runtime call failed                   */
+  XIVO_HIP_ERR_NOT_SPD = -3,     /* S = HPH^T + R not positive definite         */
+  XIVO_HIP_ERR_NOMEM = -4,
+  XIVO_HIP_ERR_UNSUPPORTED = -5  /* size outside what the kernels are built for */
+};
+
+/* flags for xivo_hip_create / stacking */
+enum {
+  XIVO_HIP_FLAG_NONE = 0u,
+  /* Feature::FillJacobianBlock writes the group-translation block over the
+   * group-rotation block (src/feature.cpp:675-676). Default = reproduce it;
+   * this flag gives the evidently intended full row (as src/update.cpp:326). */
+  XIVO_HIP_FLAG_FIX_GROUP_BLOCK = 1u,
+  /* record HIP events around every kernel launch (per-stage timing) */
+  XIVO_HIP_FLAG_PROFILE = 2u,
+  /* compute every tile of P+ instead of the lower triangle + mirror (A/B knob) */
+  XIVO_HIP_FLAG_FULL_PNEW = 4u
+};
+
+/* camera models implemented on device (common/camera_pinhole.h,
+ * common/camera_equidist.h, common/camera_radtan.h, common/camera_atan.h) */
+enum { XIVO_CAM_PINHOLE = 0, XIVO_CAM_ATAN = 1, XIVO_CAM_RADTAN = 2, XIVO_CAM_EQUI = 3 };
+
+/* Error-state layout (src/core.h:40-105). N is a run-time value here
+ * (kFullSize is a compile-time constant in the reference). */
+typedef struct {
+  int N;              /* kFullSize                                           */
+  int group_begin;    /* kGroupBegin  (23 in the default build)              */
+  int n_groups;       /* kMaxGroup                                           */
+  int feature_begin;  /* kFeatureBegin = group_begin + 6*n_groups            */
+  int n_features;     /* kMaxFeature                                         */
+} xivo_layout;
+
+typedef struct {
+  int model;          /* XIVO_CAM_*                                          */
+  int rows, cols;
+  double fx, fy, cx, cy;
+  double d[5];        /* EQUI: k0..k3 ; RADTAN: p1,p2,k1,k2,k3(order of the
+                         reference ctor) ; ATAN: w                            */
+} xivo_cam;
+
+/* Nominal poses one filter needs for Feature::ComputeJacobian
+ * (src/update.cpp:24-32 passes X_.Rsb, X_.Tsb, X_.Rbc, X_.Tbc). 3x3 matrices
+ * are column-major. */
+typedef struct {
+  double Rsb[9], Tsb[3];
+  double Rbc[9], Tbc[3];
+} xivo_pose_in;
+
+/* One group anchor (src/group.h:41-107): pose + state slot `sind`. */
+typedef struct {
+  double Rsb[9], Tsb[3];
+} xivo_group_in;
+
+/* One in-state feature (src/feature.h:74-232). */
+typedef struct {
+  double x[3];        /* (X/Z, Y/Z, log Z) in the reference camera frame, feature.h:258-262 */
+  double xp[2];       /* last tracked pixel, Feature::back()                 */
+  int ref_sind;       /* ref_->sind(): slot of the reference group           */
+  int sind;           /* feature slot                                        */
+} xivo_feat_in;
+
+/* One out-of-state (MSCKF) feature with k observations from in-state groups
+ * (src/oos.cpp:8-89). */
+#define XIVO_OOS_MAX_OBS 16
+typedef struct {
+  double Xs[3];                       /* cache_.Xs, src/oos.cpp:17           */
+  int n_obs;
+  int group_sind[XIVO_OOS_MAX_OBS];   /* obs.g->sind()                       */
+  double xp[XIVO_OOS_MAX_OBS][2];     /* obs.xp                              */
+} xivo_oos_in;
+
+/* ---- lifetime -------------------------------------------------------- */
+int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_max, unsigned flags);
+void xivo_hip_destroy(xivo_hip_ctx* ctx);
+const char* xivo_hip_strerror(int status);
+int xivo_hip_sync(xivo_hip_ctx* ctx);
+int xivo_hip_set_flags(xivo_hip_ctx* ctx, unsigned flags);
+
+/* ---- covariance residency (Estimator::P_, src/estimator.h:423; a17) --- */
+int xivo_hip_upload_P(xivo_hip_ctx* ctx, int b0, int nb, const double* P, long stride, int ld);
+int xivo_hip_download_P(xivo_hip_ctx* ctx, int b0, int nb, double* P, long stride, int ld);
+/* BackupState / RestoreState P part (src/estimator.cpp:1413-1414,1434-1435) */
+int xivo_hip_snapshot_P(xivo_hip_ctx* ctx);
+int xivo_hip_restore_P(xivo_hip_ctx* ctx);
+/* P.block(off,0,len,N)=0; P.block(0,off,N,len)=0 (src/estimator.cpp:757-759,781-783,1476-1477; src/update.cpp:299-315) */
+int xivo_hip_p_zero_rc(xivo_hip_ctx* ctx, int b, int off, int len);
+/* copy rows+cols [src,src+len) onto [dst,dst+len) (AddGroupToState, src/estimator.cpp:808-816) */
+int xivo_hip_p_copy_rc(xivo_hip_ctx* ctx, int b, int dst, int src, int len);
+/* P.block<3,3>(off,off) = P3 (Feature::FillCovarianceBlock, src/feature.cpp:753-760) */
+int xivo_hip_p_set_block3(xivo_hip_ctx* ctx, int b, int off, const double* P3);
+/* diag(P) (FindNewRefGroup reads it, src/estimator.cpp:1394-1407) */
+int xivo_hip_p_diag(xivo_hip_ctx* ctx, int b, double* diag_out);
+
+/* ---- S-level: dense H / inn / diagR given (Estimator::H_, inn_, diagR_) -- */
+/* stage measurements of filters [b0,b0+nb): H is M x N (ldh), inn and diagR
+ * have M entries. M may differ between calls, M <= M_max. */
+int xivo_hip_set_measurements(xivo_hip_ctx* ctx, int b0, int nb, int M,
+                              const double* H, long strideH, int ldh,
+                              const double* inn, long strideInn,
+                              const double* diagR, long strideR);
+/* Estimator::UpdateJosephForm (src/estimator.cpp:1257-1288) for filters [0,B):
+ * S = HPH^T + R, K^T = S^-1 HP, dx = K inn, P <- (KH-I)P(KH-I)^T + K R K^T,
+ * on the resident P with the staged measurements. Asynchronous on the
+ * context's stream. */
+int xivo_hip_update_joseph(xivo_hip_ctx* ctx, int B);
+/* err_ (dx) of filters [b0,b0+nb) after the update (before AbsorbError) */
+int xivo_hip_get_err(xivo_hip_ctx* ctx, int b0, int nb, double* err, long stride);
+/* per-filter factorisation status of the last update (0 = ok) ; returns
+ * XIVO_HIP_ERR_NOT_SPD if any is non-zero */
+int xivo_hip_get_status(xivo_hip_ctx* ctx, int b0, int nb, int* status);
+/* Estimator::MHGating numeric core on dense rows (src/update.cpp:60-96):
+ * rows 2f,2f+1 of the staged H are feature f's J. Writes the inlier mask and
+ * Mahalanobis distances; rejected rows are then neutralised in the staged
+ * measurements so that a following xivo_hip_update_joseph equals the
+ * reference's FilterUpdate over the inliers only. */
+int xivo_hip_mh_gate_dense(xivo_hip_ctx* ctx, int B, int F, double R, double mh_thresh,
+                           double mh_mult, int min_inliers,
+                           unsigned char* inlier_mask_out, double* mh_dist_out);
+
+/* ---- G-level: features + poses given, Jacobians built on device -------- */
+int xivo_hip_set_layout(xivo_hip_ctx* ctx, const xivo_layout* layout, const xivo_cam* cam);
+int xivo_hip_set_scene(xivo_hip_ctx* ctx, int b0, int nb, int F,
+                       const xivo_pose_in* poses, const xivo_group_in* groups /* nb x n_groups */,
+                       const xivo_feat_in* feats /* nb x F */);
+/* Estimator::ComputeInstateJacobians (src/update.cpp:24-32) =
+ * Feature::ComputeJacobian x F (src/feature.cpp:542-656) */
+int xivo_hip_jacobians_instate(xivo_hip_ctx* ctx, int B);
+/* compact per-feature result: J blocks 2x21 ([Wsb Tsb Wbc Tbc Wg Tg x], row-major 2 x 21) + inn (2) */
+int xivo_hip_get_jacobians(xivo_hip_ctx* ctx, int b0, int nb, double* J2x21, double* inn2);
+/* Estimator::MHGating (src/update.cpp:50-116) on the compact Jacobians (full
+ * J row, as the reference gates with f->J()). */
+int xivo_hip_mh_gate(xivo_hip_ctx* ctx, int B, double R, double mh_thresh, double mh_mult,
+                     int min_inliers, unsigned char* inlier_mask_out, double* mh_dist_out);
+/* Estimator::FilterUpdate stacking (src/update.cpp:129-138) through
+ * Feature::FillJacobianBlock (src/feature.cpp:658-684): in-state inlier rows
+ * first, then any OOS rows appended by xivo_hip_oos_project. */
+int xivo_hip_stack(xivo_hip_ctx* ctx, int B, double R);
+/* Feature::ComputeOOSJacobian (src/oos.cpp:8-89) + SlowGivens
+ * (src/helpers.cpp:13-23): per feature (2k-3) projected rows appended after
+ * the in-state rows with diagR = Roos. rows_out[b] = total OOS rows. */
+int xivo_hip_oos_project(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xivo_oos_in* feats,
+                         double Roos, int* rows_out);
+/* jac -> gate -> stack -> UpdateJosephForm in one call (Estimator::UpdateStep's
+ * numeric core, src/manager.cpp:72-104) */
+int xivo_hip_filter_update(xivo_hip_ctx* ctx, int B, double R, double mh_thresh, double mh_mult,
+                           int min_inliers, int use_gating);
+int xivo_hip_get_H(xivo_hip_ctx* ctx, int b, int* M_out, double* H, int ldh, double* inn, double* diagR);
+
+/* ---- covariance propagation tail (src/rk4.cpp:92-102, src/estimator.cpp:590) */
+/* P_mm <- Pmm_new ; P_ms <- Phi P_ms ; P_sm <- P_sm Phi^T. Phi and Pmm_new
+ * are nm x nm (nm = 23 = kMotionSize), one pair per filter. */
+int xivo_hip_propagate_cov(xivo_hip_ctx* ctx, int b0, int nb, int nm, const double* Phi,
+                           const double* Pmm_new);
+
+/* ---- measurement helpers (bench.py / tests only) ----------------------- */
+int xivo_hip_timer_begin(xivo_hip_ctx* ctx);
+int xivo_hip_timer_end(xivo_hip_ctx* ctx, float* ms_out);
+/* per-stage accumulated GPU time (ms) and launch counts since the last reset;
+ * needs XIVO_HIP_FLAG_PROFILE. names_out[i] points to static strings. */
+#define XIVO_HIP_MAX_STAGES 16
+int xivo_hip_profile_reset(xivo_hip_ctx* ctx);
+int xivo_hip_profile_get(xivo_hip_ctx* ctx, int* n_stages, const char** names_out,
+                         float* ms_out, int* launches_out, double* flops_per_launch_out);
+/* fp64 MFMA issue-rate microbenchmark (TFLOP/s of v_mfma_f64_16x16x4_f64) */
+int xivo_hip_bench_mfma_peak(xivo_hip_ctx* ctx, double* tflops_out);
+/* tile the batched GEMM picks for an (rows x cols) output, for DESIGN.md/tests */
+void xivo_hip_gemm_tile(int rows, int cols, int* bm, int* bn);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XIVO_HIP_H_ */

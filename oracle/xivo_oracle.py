@@ -1,0 +1,512 @@
+"""CPU oracle: a numpy restatement of XIVO's EKF measurement-update hot path.
+
+TEST INFRASTRUCTURE ONLY. Nothing in the product path (xivo_amd/, include/)
+may import, call or link this file; only tests/, __graft_entry__.smoke() and
+bench.py's `cpu_baseline` leg use it, and only as the checker.
+
+Every function restates one piece of the reference (paths relative to
+/root/reference) in plain float64 numpy, keeping the reference's expression
+order where that is observable. Pinning (see tests/test_oracle_pinned.py and
+tests/golden/):
+  * the restatement is validated against oracle/_ref/libxivo_ref_*.so, which is
+    compiled from the reference's OWN sources where they lie (Eigen 3.3.9 LDLT /
+    LLT / FullPivLU, Sophus, src/helpers.cpp verbatim, common/project.h and the
+    common/camera_*.h headers verbatim) plus an expression-faithful driver
+    (oracle/ref/xivo_ref.cpp) for the member functions that cannot be compiled
+    (they live in Estimator/Feature TUs that need OpenCV);
+  * golden vectors generated from that library are committed under
+    tests/golden/ (script: tests/golden/make_golden.py);
+  * the reference's own known-answer test `GivensSub`
+    (src/test/unittest_givens.cpp:15-37) and its finite-difference Jacobian
+    checks (src/test/unittest_jacobians_instate.cpp, ..._oos.cpp) are re-run
+    against these functions.
+The reference has NO test for UpdateJosephForm / MHGating / FilterUpdate /
+Propagate; for those the pin is the Eigen-built driver above, not a reference
+golden vector (stated in DESIGN.md).
+"""
+import math
+import numpy as np
+
+# ----------------------------------------------------------------------------
+# a16: error-state layout (src/core.h:40-105, default build: no online calib)
+# ----------------------------------------------------------------------------
+WSB, TSB, VSB, BG, BA, WBC, TBC, WSG = 0, 3, 6, 9, 12, 15, 18, 21
+K_MOTION = 23
+
+
+class Layout:
+    """kGroupBegin / kFeatureBegin / kFullSize (src/core.h:87-105) as run-time values."""
+
+    def __init__(self, n_groups, n_features, N=None, group_begin=K_MOTION):
+        self.group_begin = group_begin
+        self.n_groups = n_groups
+        self.feature_begin = group_begin + 6 * n_groups
+        self.n_features = n_features
+        full = self.feature_begin + 3 * n_features
+        self.N = full if N is None else N   # N > full: trailing zero slots (estimator.cpp:757-759)
+        assert self.N >= full
+
+
+# ----------------------------------------------------------------------------
+# a1: Estimator::UpdateJosephForm (src/estimator.cpp:1257-1288)
+# ----------------------------------------------------------------------------
+def update_joseph(H, P, inn, diagR):
+    """Returns (err, P_new, K_scaled). Expression order as the reference:
+    S=(H P) H^T; +R; K^T = S^-1 (H P); err = K inn; A = K H - I;
+    P = (A P) A^T; K *= sqrt(R) column-wise; P += K K^T."""
+    H = np.asarray(H, dtype=np.float64)
+    P = np.asarray(P, dtype=np.float64)
+    S = (H @ P) @ H.T                                   # :1259
+    S[np.diag_indices_from(S)] += diagR                 # :1261-1263
+    Kt = np.linalg.solve(S, H @ P)                      # :1266 (Eigen: pivoted LDL^T)
+    K = Kt.T
+    err = K @ inn                                       # :1267
+    A = K @ H                                           # :1276
+    A[np.diag_indices_from(A)] -= 1.0                   # :1277-1279
+    Pn = (A @ P) @ A.T                                  # :1280
+    Ks = K * np.sqrt(diagR)[None, :]                    # :1282-1286
+    Pn = Pn + Ks @ Ks.T                                 # :1287
+    return err, Pn, Ks
+
+
+F_ALG = lambda N, M: 4.0 * N ** 3 + 8.0 * M * N ** 2 + 4.0 * M ** 2 * N + M ** 3 / 3.0
+
+
+# ----------------------------------------------------------------------------
+# a6: Estimator::MHGating numeric core (src/update.cpp:60-96)
+# ----------------------------------------------------------------------------
+def mh_distances(J, P, inn, R):
+    """J: [F, 2, N], inn: [F, 2] -> d[F]; S = J P J^T + R I2; d = r^T S.llt().solve(r)."""
+    F = J.shape[0]
+    d = np.empty(F)
+    for i in range(F):
+        S = (J[i] @ P) @ J[i].T                          # :65
+        S[0, 0] += R                                     # :66
+        S[1, 1] += R                                     # :67
+        # Eigen LLT reads the lower triangle only
+        l00 = math.sqrt(S[0, 0]); l10 = S[1, 0] / l00; l11 = math.sqrt(S[1, 1] - l10 * l10)
+        y0 = inn[i, 0] / l00; y1 = (inn[i, 1] - l10 * y0) / l11
+        x1 = y1 / l11; x0 = (y0 - l10 * x1) / l00
+        d[i] = inn[i, 0] * x0 + inn[i, 1] * x1           # :68
+    return d
+
+
+def mh_gate(dist, thresh, mult, min_inliers):
+    """Threshold-relaxation loop (src/update.cpp:72-96). Returns (mask, num_rejected
+    accumulated over relaxations - the reference's counting quirk -, final thresh)."""
+    F = len(dist)
+    if min_inliers <= 0:                                 # loop body never runs
+        return np.zeros(F, dtype=bool), 0, -1.0
+    inliers = []
+    rejected = 0
+    used = thresh
+    th = thresh
+    mask = np.zeros(F, dtype=bool)
+    guard = 0
+    while len(inliers) < min_inliers:                    # :73
+        inliers = []
+        mask[:] = False
+        for i in range(F):
+            if dist[i] < th:                             # :84
+                inliers.append(i); mask[i] = True
+            else:
+                rejected += 1                            # :87
+        used = th
+        th *= mult                                       # :94
+        guard += 1
+        if len(inliers) == F or guard > 4096:
+            break
+    return mask, rejected, used
+
+
+# ----------------------------------------------------------------------------
+# SO3 helpers (thirdparty/sophus/sophus/so3.hpp hat / exp)
+# ----------------------------------------------------------------------------
+def hat(w):
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def so3_exp(w):
+    """Rodrigues formula (matches Sophus::SO3::exp to rounding; used for test scene
+    generation and ComposeMotion, never for parity-critical values)."""
+    th = np.linalg.norm(w)
+    Wm = hat(w)
+    if th < 1e-10:
+        return np.eye(3) + Wm + 0.5 * Wm @ Wm
+    return np.eye(3) + math.sin(th) / th * Wm + (1 - math.cos(th)) / (th * th) * Wm @ Wm
+
+
+# ----------------------------------------------------------------------------
+# cameras (common/camera_pinhole.h:17-37, camera_equidist.h:23-95,
+# camera_radtan.h:23-90, camera_atan.h:22-67) - Project(xc, &jac)
+# ----------------------------------------------------------------------------
+CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
+
+
+def camera_project(cam, xc):
+    fx, fy, cx, cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    x, y = float(xc[0]), float(xc[1])
+    model = cam["model"]
+    d = cam.get("d", [])
+    if model == CAM_PINHOLE:
+        return np.array([fx * x + cx, fy * y + cy]), np.array([[fx, 0.0], [0.0, fy]])
+    if model == CAM_EQUI:
+        k0, k1, k2, k3 = d[:4]
+        n2 = x * x + y * y; n = math.sqrt(n2); n3 = n2 + 1
+        th = math.atan2(n, 1.0); phi = math.atan2(y, x)
+        th2 = th * th; th3 = th2 * th; th4 = th3 * th; th5 = th3 * th2; th6 = th5 * th
+        th7 = th5 * th2; th8 = th7 * th; th9 = th7 * th2
+        r = th + k0 * th3 + k1 * th5 + k2 * th7 + k3 * th9
+        c, s = math.cos(phi), math.sin(phi)
+        xp = np.array([fx * r * c + cx, fy * r * s + cy])
+        dphi_dx, dphi_dy = -y / n2, x / n2
+        dth_dx, dth_dy = x / n3 / n, y / n3 / n
+        dr = 1 + k0 * 3 * th2 + k1 * 5 * th4 + k2 * 7 * th6 + k3 * 9 * th8
+        J = np.array([[fx * c * dr * dth_dx - fx * r * s * dphi_dx, fx * c * dr * dth_dy - fx * r * s * dphi_dy],
+                      [fy * s * dr * dth_dx + fy * r * c * dphi_dx, fy * s * dr * dth_dy + fy * r * c * dphi_dy]])
+        return xp, J
+    if model == CAM_RADTAN:
+        p1, p2, k1, k2, k3 = d[:5]
+        t2 = x * x; t3 = y * y; t4 = k1 * x * 2.0; t5 = k1 * y * 2.0; t6 = p1 * x * 2.0; t7 = p2 * y * 2.0
+        t8 = t2 * 3.0; t9 = t3 * 3.0; t10 = t6 * y; t11 = t7 * x; t12 = t2 + t3; t13 = t3 + t8; t14 = t2 + t9
+        t15 = t12 * t12; t16 = t12 * t12 * t12; t17 = k1 * t12
+        t22 = k2 * t12 * x * 4.0; t23 = k2 * t12 * y * 4.0; t18 = k2 * t15; t19 = k3 * t16
+        t20 = p1 * t14; t21 = p2 * t13; t24 = k3 * t15 * x * 6.0; t25 = k3 * t15 * y * 6.0
+        t26 = t4 + t22 + t24; t27 = t5 + t23 + t25; t28 = t17 + t18 + t19 + 1.0
+        t29 = t28 * x; t30 = t28 * y; t31 = t10 + t21 + t29; t32 = t11 + t20 + t30
+        xp = np.array([cx + fx * t31, cy + fy * t32])
+        J = np.array([[fx * (t28 + p2 * x * 6.0 + p1 * y * 2.0 + t26 * x), fx * (t6 + t7 + t27 * x)],
+                      [fy * (t6 + t7 + t26 * y), fy * (t28 + p2 * x * 2.0 + p1 * y * 6.0 + t27 * y)]])
+        return xp, J
+    if model == CAM_ATAN:
+        w = d[0]
+        invw = 1.0 / w; w2 = 2.0 * math.tan(w * 0.5)
+        R = math.sqrt(x * x + y * y)
+        singular = R < 0.0001 or w == 0
+        f = 1.0 if singular else invw * math.atan(w2 * R) / R
+        xp = np.array([fx * f * x + cx, fy * f * y + cy])
+        if singular:
+            J = np.array([[fx, 0.0], [0.0, fy]])
+        else:
+            a = w2 * R
+            df_dR = invw * (1.0 / (1 + a * a) * a - math.atan(a)) / R / R
+            dfx, dfy = df_dR * x / R, df_dR * y / R
+            J = np.array([[fx * f + fx * x * dfx, fx * x * dfy], [fy * y * dfx, fy * f + fy * y * dfy]])
+        return xp, J
+    raise ValueError("unknown camera model")
+
+
+def project(Xc):
+    """common/project.h:11-24"""
+    X, Y, Z = Xc
+    return np.array([X / Z, Y / Z]), np.array([[1 / Z, 0, -X / (Z * Z)], [0, 1 / Z, -Y / (Z * Z)]])
+
+
+def unproject_logz(x):
+    """common/project.h:79-95"""
+    z = math.exp(x[2])
+    return np.array([x[0] * z, x[1] * z, z]), np.array([[z, 0, x[0] * z], [0, z, x[1] * z], [0, 0, z]])
+
+
+# ----------------------------------------------------------------------------
+# a4: Feature::ComputeJacobian (src/feature.cpp:542-656)
+# ----------------------------------------------------------------------------
+def compute_jacobian(x, xp_meas, Rsbr, Tsbr, Rsb, Tsb, Rbc, Tbc, cam, layout, ref_sind, sind,
+                     return_cache=False):
+    """Returns (J [2 x N], inn [2], blocks [7,2,3]) for one in-state feature."""
+    Rsb_t, Rbc_t = Rsb.T, Rbc.T
+    Xc, dXc_dx = unproject_logz(x)                       # :555 (Xc(&cache_.dXc_dx), feature.cpp:98-105)
+    Xbr = Rbc @ Xc + Tbc                                 # :556
+    Xs = Rsbr @ Xbr + Tsbr                               # :557
+    Xb = Rsb_t @ (Xs - Tsb)                              # :558
+    Xcn = Rbc_t @ (Xb - Tbc)                             # :559
+    dXbr_dXc = Rbc                                       # :562
+    dXbr_dWbc = -Rbc @ hat(Xc)                           # :564
+    dXs_dXbr = Rsbr                                      # :567
+    dXs_dWsbr = -Rsbr @ hat(Xbr)                         # :569
+    dXb_dXs = Rsb_t                                      # :572
+    dXb_dTsb = -Rsb_t                                    # :573
+    dXb_dWsb = hat(Xb)                                   # :574
+    dXcn_dXb = Rbc_t                                     # :577
+    dXcn_dTbc = -Rbc_t + dXcn_dXb @ dXb_dXs @ dXs_dXbr @ np.eye(3)          # :578-579
+    dXcn_dWbc = hat(Xcn) + dXcn_dXb @ dXb_dXs @ dXs_dXbr @ dXbr_dWbc        # :580-581
+    dXcn_dTsb = dXcn_dXb @ dXb_dTsb                      # :584
+    dXcn_dWsb = dXcn_dXb @ dXb_dWsb                      # :585
+    dXcn_dTsbr = dXcn_dXb @ dXb_dXs @ np.eye(3)          # :586
+    dXcn_dWsbr = dXcn_dXb @ dXb_dXs @ dXs_dWsbr          # :587
+    dXcn_dXs = dXcn_dXb @ dXb_dXs                        # :588
+    dXcn_dx = dXcn_dXs @ dXs_dXbr @ dXbr_dXc @ dXc_dx    # :589
+    xcn, dxcn_dXcn = project(Xcn)                        # :611
+    xp, dxp_dxcn = camera_project(cam, xcn)              # :617
+    dxp_dXcn = dxp_dxcn @ dxcn_dXcn                      # :620
+    blocks = np.stack([dxp_dXcn @ dXcn_dWsb, dxp_dXcn @ dXcn_dTsb, dxp_dXcn @ dXcn_dWbc,
+                       dxp_dXcn @ dXcn_dTbc, dxp_dXcn @ dXcn_dWsbr, dxp_dXcn @ dXcn_dTsbr,
+                       dxp_dXcn @ dXcn_dx])              # :623-645
+    goff = layout.group_begin + 6 * ref_sind             # :639
+    foff = layout.feature_begin + 3 * sind               # :640
+    J = np.zeros((2, layout.N))
+    for b, off in enumerate([WSB, TSB, WBC, TBC, goff, goff + 3, foff]):
+        J[:, off:off + 3] = blocks[b]
+    inn = np.asarray(xp_meas, dtype=np.float64) - xp     # :654
+    if return_cache:
+        cache = dict(Xc=Xc, Xbr=Xbr, Xs=Xs, Xb=Xb, Xcn=Xcn, dXcn_dWsb=dXcn_dWsb, dXcn_dTsb=dXcn_dTsb,
+                     dXcn_dWbc=dXcn_dWbc, dXcn_dTbc=dXcn_dTbc, dXcn_dWsbr=dXcn_dWsbr,
+                     dXcn_dTsbr=dXcn_dTsbr, dXcn_dx=dXcn_dx, dXcn_dXs=dXcn_dXs, xp=xp)
+        return J, inn, blocks, cache
+    return J, inn, blocks
+
+
+# ----------------------------------------------------------------------------
+# a3: Feature::FillJacobianBlock (src/feature.cpp:658-684), a2: FilterUpdate
+# stacking (src/update.cpp:129-138)
+# ----------------------------------------------------------------------------
+def fill_jacobian_block(H, row, J, layout, ref_sind, sind, fix_group_block=False):
+    for off in (WSB, TSB, WBC, TBC):                     # :659-662
+        H[row:row + 2, off:off + 3] = J[:, off:off + 3]
+    goff = layout.group_begin + 6 * ref_sind             # :672
+    foff = layout.feature_begin + 3 * sind               # :673
+    H[row:row + 2, goff:goff + 3] = J[:, goff:goff + 3]              # :675
+    if fix_group_block:
+        H[row:row + 2, goff + 3:goff + 6] = J[:, goff + 3:goff + 6]
+    else:
+        H[row:row + 2, goff:goff + 3] = J[:, goff + 3:goff + 6]      # :676 (the quirk)
+    H[row:row + 2, foff:foff + 3] = J[:, foff:foff + 3]              # :677
+
+
+def stack_measurements(Js, inns, ref_sinds, sinds, layout, R, fix_group_block=False):
+    """Rows for the features given, in the order given (update.cpp:129-138)."""
+    F = len(Js)
+    H = np.zeros((2 * F, layout.N))                      # :130
+    inn = np.zeros(2 * F)
+    diagR = np.empty(2 * F)
+    for i in range(F):
+        fill_jacobian_block(H, 2 * i, Js[i], layout, ref_sinds[i], sinds[i], fix_group_block)   # :135
+        inn[2 * i:2 * i + 2] = inns[i]                   # :136
+        diagR[2 * i:2 * i + 2] = R                       # :137
+    return H, inn, diagR
+
+
+def neutralise_rows(H, inn, diagR, mask_rows):
+    """The device keeps rejected features' rows in place but neutral (H row 0,
+    inn 0, diagR 1); algebraically identical to not stacking them."""
+    H = H.copy(); inn = inn.copy(); diagR = diagR.copy()
+    H[~mask_rows] = 0.0; inn[~mask_rows] = 0.0; diagR[~mask_rows] = 1.0
+    return H, inn, diagR
+
+
+# ----------------------------------------------------------------------------
+# Eigen::FullPivLU<MatrixXd>::kernel()
+# (thirdparty/eigen/Eigen/src/LU/FullPivLU.h:490-580 computeInPlace, :619-699 kernel)
+# ----------------------------------------------------------------------------
+def fullpivlu_kernel(Ain):
+    lu = np.array(Ain, dtype=np.float64, order="F")
+    rows, cols = lu.shape
+    size = min(rows, cols)
+    colsT = list(range(size))
+    nonzero = size
+    maxpivot = 0.0
+    for k in range(size):
+        corner = np.abs(lu[k:, k:])
+        # Eigen's visitor walks column-major and keeps the first maximum
+        flat = corner.flatten(order="F")
+        idx = int(np.argmax(flat))
+        big = flat[idx]
+        br, bc = idx % (rows - k) + k, idx // (rows - k) + k
+        if big == 0.0:
+            nonzero = k
+            for i in range(k, size):
+                colsT[i] = i
+            break
+        maxpivot = max(maxpivot, big)
+        colsT[k] = bc
+        if k != br:
+            lu[[k, br], :] = lu[[br, k], :]
+        if k != bc:
+            lu[:, [k, bc]] = lu[:, [bc, k]]
+        if k < rows - 1:
+            lu[k + 1:, k] /= lu[k, k]
+        if k < size - 1:
+            lu[k + 1:, k + 1:] -= np.outer(lu[k + 1:, k], lu[k, k + 1:])
+    q = list(range(cols))
+    for k in range(size):
+        q[k], q[colsT[k]] = q[colsT[k]], q[k]
+    thr = maxpivot * (np.finfo(np.float64).eps * size)
+    piv = [i for i in range(nonzero) if abs(lu[i, i]) > thr]
+    rank = len(piv)
+    dimker = cols - rank
+    if dimker == 0:
+        return np.zeros((cols, 1)), rank
+    m = np.zeros((rank, cols))
+    for i in range(rank):
+        m[i, i:] = lu[piv[i], i:]
+    for i in range(rank):
+        m[i, :i] = 0.0
+    for i in range(rank):
+        if piv[i] != i:
+            m[:, [i, piv[i]]] = m[:, [piv[i], i]]
+    for c in range(rank, cols):
+        for i in range(rank - 1, -1, -1):
+            s = m[i, c] - m[i, i + 1:rank] @ m[i + 1:rank, c]
+            m[i, c] = s / m[i, i]
+    for i in range(rank - 1, -1, -1):
+        if piv[i] != i:
+            m[:, [i, piv[i]]] = m[:, [piv[i], i]]
+    ker = np.zeros((cols, dimker))
+    for i in range(rank):
+        ker[q[i], :] = -m[i, rank:]
+    for k in range(dimker):
+        ker[q[rank + k], k] = 1.0
+    return ker, rank
+
+
+def slow_givens(Hf, Hx):
+    """src/helpers.cpp:13-23: A = FullPivLU(Hf^T).kernel(); Hx <- A^T Hx."""
+    A, _ = fullpivlu_kernel(Hf.T)
+    return A.T @ Hx, A
+
+
+# a10: givens / Givens (src/helpers.cpp:27-75, G&VL Alg. 5.1.3, eps guard common/alias.h:80)
+EPS_ALIAS = float(np.float32(1e-4))
+
+
+def givens(a, b):
+    if abs(b) < EPS_ALIAS:
+        c, s = 1.0, 0.0
+    elif abs(b) > abs(a):
+        t = -a / b; s = 1 / math.sqrt(1 + t * t); c = s * t
+    else:
+        t = -b / a; c = 1 / math.sqrt(1 + t * t); s = c * t
+    return np.array([[c, s], [-s, c]])
+
+
+def givens_eliminate(x, Hx, Hf, effective_rows=-1):
+    x = x.copy(); Hx = Hx.copy(); Hf = Hf.copy()
+    rows = Hf.shape[0] if effective_rows == -1 else effective_rows
+    cols = Hf.shape[1]
+    for c in range(cols):
+        for r in range(rows - 2, c - 1, -1):
+            Gt = givens(Hf[r, c], Hf[r + 1, c]).T
+            Hf[r:r + 2, :] = Gt @ Hf[r:r + 2, :]
+            # NB the reference rotates only the first `cols` columns of Hx (helpers.cpp:64)
+            Hx[r:r + 2, :cols] = Gt @ Hx[r:r + 2, :cols]
+            x[r:r + 2] = Gt @ x[r:r + 2]
+    for r in range(rows - cols):
+        x[r] = x[r + cols]; Hx[r] = Hx[r + cols]; Hf[r] = Hf[r + cols]
+    return rows - cols, x, Hx, Hf
+
+
+# ----------------------------------------------------------------------------
+# a8/a9: Feature::ComputeOOSJacobian(+Internal) (src/oos.cpp:8-89)
+# ----------------------------------------------------------------------------
+def oos_jacobian_internal(Xs, Rsb, Tsb, Rbc, Tbc, xp_obs, cam, layout, g_sind):
+    """One observation: returns (Hf 2x3, Hx 2xN, inn 2) (src/oos.cpp:39-89)."""
+    Rsb_t, Rbc_t = Rsb.T, Rbc.T
+    Xb = Rsb_t @ (Xs - Tsb)                              # :52
+    dXb_dXs = Rsb_t; dXb_dTsb = -Rsb_t; dXb_dWsb = hat(Xb)
+    Xcn = Rbc_t @ (Xb - Tbc)                             # :58
+    dXcn_dXb = Rbc_t; dXcn_dWbc = hat(Xcn); dXcn_dTbc = -Rbc_t
+    xcn, dxcn_dXcn = project(Xcn)                        # :66
+    xp, dxp_dxcn = camera_project(cam, xcn)              # :68
+    dxp_dXcn = dxp_dxcn @ dxcn_dXcn                      # :70
+    inn = np.asarray(xp_obs, dtype=np.float64) - xp      # :72
+    Hf = dxp_dXcn @ dXcn_dXb @ dXb_dXs                   # :74-75
+    Hx = np.zeros((2, layout.N))                         # :77
+    goff = layout.group_begin + 6 * g_sind
+    Hx[:, goff:goff + 3] = dxp_dXcn @ dXcn_dXb @ dXb_dWsb        # :78-79
+    Hx[:, goff + 3:goff + 6] = dxp_dXcn @ dXcn_dXb @ dXb_dTsb    # :80-81
+    Hx[:, WBC:WBC + 3] = dxp_dXcn @ dXcn_dWbc            # :82-83
+    Hx[:, TBC:TBC + 3] = dxp_dXcn @ dXcn_dTbc            # :84-85
+    return Hf, Hx, inn
+
+
+def oos_jacobian(Xs, obs, groups_R, groups_T, Rbc, Tbc, cam, layout):
+    """ComputeOOSJacobian on the 2k live rows (the reference passes the
+    whole 2*kMaxGroup buffer, oos.cpp:28 - dead code there; this repo and the
+    oracle project only the live rows). obs = [(g_sind, xp), ...].
+    Returns (Hx' [(2k-rank) x N], inn' [(2k-rank)], A)."""
+    k = len(obs)
+    Hf = np.zeros((2 * k, 3)); Hx = np.zeros((2 * k, layout.N)); r = np.zeros(2 * k)
+    for c, (g, xp) in enumerate(obs):
+        hf, hx, inn = oos_jacobian_internal(Xs, groups_R[g], groups_T[g], Rbc, Tbc, xp, cam, layout, g)
+        Hf[2 * c:2 * c + 2] = hf; Hx[2 * c:2 * c + 2] = hx; r[2 * c:2 * c + 2] = inn
+    Hxp, A = slow_givens(Hf, Hx)                         # :27-28
+    rp = A.T @ r                                         # :29
+    return Hxp, rp, A
+
+
+# ----------------------------------------------------------------------------
+# a12/a14: covariance part of RK4Step (src/rk4.cpp:35-103) and
+# ComputeMotionJacobianAt (src/estimator.cpp:615-704), default build
+# ----------------------------------------------------------------------------
+def motion_jacobian(Rsb, bg, ba, gyro, accel, g_vec, Cg=None, Ca=None):
+    Cg = np.eye(3) if Cg is None else Cg
+    Ca = np.eye(3) if Ca is None else Ca
+    gyro_calib = Cg @ gyro - bg
+    accel_calib = Ca @ accel - ba
+    F = np.zeros((K_MOTION, K_MOTION)); G = np.zeros((K_MOTION, 12))
+    dW_dW = -hat(gyro_calib)
+    dV_dW = -Rsb @ hat(accel_calib)
+    dV_dba = -Rsb
+    dV_dWsg = -Rsb @ hat(g_vec)
+    for j in range(3):
+        F[WSB + j, BG + j] = -1; F[TSB + j, VSB + j] = 1
+        for i in range(3):
+            F[WSB + i, WSB + j] = dW_dW[i, j]
+            F[VSB + i, WSB + j] = dV_dW[i, j]
+            F[VSB + i, BA + j] = dV_dba[i, j]
+            if j < 2:
+                F[VSB + i, WSG + j] = dV_dWsg[i, j]
+    for j in range(3):
+        G[WSB + j, j] = -1; G[BG + j, 6 + j] = 1; G[BA + j, 9 + j] = 1
+        for i in range(3):
+            G[VSB + i, 3 + j] = -Rsb[i, j]
+    return F, G
+
+
+def rk4_cov_tail(P, FK, PK, dt, Qmodel=None):
+    """P_mm += PK dt; Phi = I + FK dt; P_ms <- Phi P_ms; P_sm <- P_sm Phi^T
+    (src/rk4.cpp:92-102); optionally P_mm += Qmodel (src/estimator.cpp:590)."""
+    P = P.copy()
+    nm = FK.shape[0]
+    Phi = np.eye(nm) + FK * dt
+    P[:nm, :nm] = P[:nm, :nm] + PK * dt
+    P[:nm, nm:] = Phi @ P[:nm, nm:]
+    P[nm:, :nm] = P[nm:, :nm] @ Phi.T
+    if Qmodel is not None:
+        P[:nm, :nm] += Qmodel
+    return P, Phi
+
+
+def rk4_step_cov(P, Fs, Gs, Qimu, dt):
+    """Covariance/transition part of RK4Step given the 4 stage Jacobians
+    (F_i, G_i) evaluated along the mean trajectory (src/rk4.cpp:49-96)."""
+    h = 0.5 * dt
+    nm = Fs[0].shape[0]
+    P0 = P[:nm, :nm]
+    q = lambda F, G, Pm: F @ Pm + Pm @ F.T + G @ Qimu @ G.T
+    FK1 = Fs[0]; PK1 = q(Fs[0], Gs[0], P0)
+    FK2 = Fs[1] + Fs[1] @ FK1 * h; PK2 = q(Fs[1], Gs[1], P0 + h * PK1)
+    FK3 = Fs[2] + Fs[2] @ FK2 * h; PK3 = q(Fs[2], Gs[2], P0 + h * PK2)
+    FK4 = Fs[3] + Fs[3] @ FK3 * dt; PK4 = q(Fs[3], Gs[3], P0 + dt * PK3)
+    FK = (FK1 + 2.0 * (FK2 + FK3) + FK4) / 6.0
+    PK = (PK1 + 2.0 * (PK2 + PK3) + PK4) / 6.0
+    return FK, PK
+
+
+# ----------------------------------------------------------------------------
+# a17: host edits of P_ (src/estimator.cpp:754-846, 1382-1389, 1474-1478;
+# src/feature.cpp:753-760)
+# ----------------------------------------------------------------------------
+def p_zero_rc(P, off, n):
+    P = P.copy(); P[off:off + n, :] = 0; P[:, off:off + n] = 0; return P
+
+
+def p_copy_rc(P, dst, src, n):
+    P = P.copy()
+    P[dst:dst + n, :] = P[src:src + n, :]               # rows first (estimator.cpp:808-809)
+    P[:, dst:dst + n] = P[:, src:src + n]               # then columns (:810-811)
+    return P
+
+
+def p_set_block3(P, off, P3):
+    P = P.copy(); P[off:off + 3, off:off + 3] = P3; return P

@@ -1,0 +1,692 @@
+// C ABI of the MI355X EKF measurement-update path (include/xivo_hip.h).
+// Host-side orchestration only: owns the device buffers of a batch of filters,
+// sequences the kernels of gemm_f64.hip / chol_trsm.hip / ekf_kernels.hip on one
+// HIP stream, never throws and never aborts.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/xivo_hip.h"
+#include "common.h"
+#include "ekf_kernels.h"
+
+using namespace xivo_hip;
+
+namespace {
+
+enum Stage : int {
+  ST_JAC = 0, ST_GATE, ST_STACK, ST_HP, ST_S, ST_CHOL, ST_TRSM, ST_KH, ST_AP, ST_PNEW, ST_OTHER, ST_COUNT
+};
+const char* kStageNames[ST_COUNT] = {"jac_instate", "mh_gate", "stack_H", "gemm_HP", "gemm_S", "chol_S",
+                                     "trsm_gain", "gemm_KH_I", "gemm_AP", "gemm_Pnew", "other"};
+
+struct EventPair { hipEvent_t a, b; int stage; };
+
+}  // namespace
+
+struct xivo_hip_ctx {
+  int device = 0;
+  int N = 0, Np = 0, Mmax = 0, Mpmax = 0, Bmax = 0;
+  unsigned flags = 0;
+  hipStream_t stream = nullptr;
+  // per-filter device buffers
+  double *P = nullptr, *Psnap = nullptr, *H = nullptr, *HT = nullptr, *HP = nullptr, *S = nullptr;
+  double *K = nullptr, *A = nullptr, *T = nullptr, *invD = nullptr, *inn = nullptr, *diagR = nullptr;
+  double *err = nullptr, *staging = nullptr, *scratch = nullptr;
+  int* status = nullptr;
+  size_t staging_elems = 0;
+  long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0;
+  int M = 0, Mp = 0;  // rows currently staged
+  // G-level
+  xivo_layout lay{};
+  xivo_cam cam{};
+  bool have_layout = false;
+  int Fmax = 0, F = 0;
+  xivo_pose_in* poses = nullptr;
+  xivo_group_in* groups = nullptr;
+  xivo_feat_in* feats = nullptr;
+  double *J = nullptr, *finn = nullptr, *dist = nullptr;
+  unsigned char* mask = nullptr;
+  int* rows_instate = nullptr;
+  xivo_oos_in* oos = nullptr;
+  int oos_cap = 0;
+  int* oos_rows = nullptr;
+  // timing
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  std::vector<EventPair> pool;
+  size_t pool_used = 0;
+  float stage_ms[ST_COUNT] = {0};
+  int stage_launches[ST_COUNT] = {0};
+  double stage_flops[ST_COUNT] = {0};
+};
+
+namespace {
+
+#define HIP_TRY(expr)                              \
+  do {                                             \
+    hipError_t e_ = (expr);                        \
+    if (e_ != hipSuccess) return XIVO_HIP_ERR_HIP; \
+  } while (0)
+
+template <class T>
+int dev_alloc(T** p, size_t n) {
+  if (n == 0) { *p = nullptr; return XIVO_HIP_OK; }
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) return XIVO_HIP_ERR_NOMEM;
+  e = hipMemset(*p, 0, n * sizeof(T));
+  return e == hipSuccess ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
+}
+
+struct StageTimer {
+  xivo_hip_ctx* c; EventPair* ep = nullptr;
+  StageTimer(xivo_hip_ctx* ctx, int stage, double flops) : c(ctx) {
+    if (!(c->flags & XIVO_HIP_FLAG_PROFILE)) return;
+    if (c->pool_used >= c->pool.size()) {
+      EventPair np; np.stage = stage;
+      if (hipEventCreate(&np.a) != hipSuccess || hipEventCreate(&np.b) != hipSuccess) return;
+      c->pool.push_back(np);
+    }
+    ep = &c->pool[c->pool_used++];
+    ep->stage = stage;
+    c->stage_launches[stage]++;
+    c->stage_flops[stage] = flops;
+    hipEventRecord(ep->a, c->stream);
+  }
+  ~StageTimer() { if (ep) hipEventRecord(ep->b, c->stream); }
+};
+
+int collect_profile(xivo_hip_ctx* c) {
+  if (c->pool_used == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < c->pool_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->pool[i].a, c->pool[i].b) == hipSuccess) c->stage_ms[c->pool[i].stage] += ms;
+  }
+  c->pool_used = 0;
+  return XIVO_HIP_OK;
+}
+
+MeasBuffers meas_buffers(xivo_hip_ctx* c) {
+  MeasBuffers mb;
+  mb.H = c->H; mb.strideH = c->sH; mb.ldh = c->Mpmax;
+  mb.HT = c->HT; mb.strideHT = c->sHT; mb.ldht = c->Np;
+  mb.inn = c->inn; mb.strideInn = c->Mpmax;
+  mb.diagR = c->diagR; mb.strideR = c->Mpmax;
+  return mb;
+}
+
+SceneBuffers scene_buffers(xivo_hip_ctx* c) {
+  SceneBuffers sb;
+  sb.poses = c->poses; sb.groups = c->groups; sb.feats = c->feats;
+  sb.J = c->J; sb.finn = c->finn; sb.mask = c->mask; sb.dist = c->dist;
+  sb.Fmax = c->Fmax; sb.F = c->F;
+  return sb;
+}
+
+int ensure_staging(xivo_hip_ctx* c, size_t elems) {
+  if (elems <= c->staging_elems) return XIVO_HIP_OK;
+  if (c->staging) hipFree(c->staging);
+  c->staging = nullptr; c->staging_elems = 0;
+  if (hipMalloc((void**)&c->staging, elems * sizeof(double)) != hipSuccess) return XIVO_HIP_ERR_NOMEM;
+  c->staging_elems = elems;
+  return XIVO_HIP_OK;
+}
+
+// copy nb host matrices (rows x cols, leading dim ld, `stride` elements apart)
+// into a packed device staging area (ld = rows)
+int h2d_packed(xivo_hip_ctx* c, double* dst, const double* src, int nb, int rows, int cols, long stride, int ld) {
+  if (ld == rows) {
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)rows * cols * sizeof(double), src, (size_t)stride * sizeof(double),
+                             (size_t)rows * cols * sizeof(double), nb, hipMemcpyHostToDevice, c->stream));
+  } else {
+    for (int b = 0; b < nb; ++b)
+      HIP_TRY(hipMemcpy2DAsync(dst + (size_t)b * rows * cols, (size_t)rows * sizeof(double), src + (size_t)b * stride,
+                               (size_t)ld * sizeof(double), (size_t)rows * sizeof(double), cols,
+                               hipMemcpyHostToDevice, c->stream));
+  }
+  return XIVO_HIP_OK;
+}
+
+int d2h_packed(xivo_hip_ctx* c, double* dst, const double* src, int nb, int rows, int cols, long stride, int ld) {
+  if (ld == rows) {
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)stride * sizeof(double), src, (size_t)rows * cols * sizeof(double),
+                             (size_t)rows * cols * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    for (int b = 0; b < nb; ++b)
+      HIP_TRY(hipMemcpy2DAsync(dst + (size_t)b * stride, (size_t)ld * sizeof(double), src + (size_t)b * rows * cols,
+                               (size_t)rows * sizeof(double), (size_t)rows * sizeof(double), cols,
+                               hipMemcpyDeviceToHost, c->stream));
+  }
+  return XIVO_HIP_OK;
+}
+
+bool bad_range(xivo_hip_ctx* c, int b0, int nb) { return !c || b0 < 0 || nb < 0 || b0 + nb > c->Bmax; }
+
+int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0, long sA0, int lda0,
+         const double* B0, long sB0, int ldb0, int K0, const double* A1, long sA1, int lda1, const double* B1,
+         long sB1, int ldb1, int K1, const double* scale1, long sScale1, double* C, long sC, int ldc, int epi,
+         const double* diag, long sDiag, int lower_only) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.seg[0] = GemmSeg{A0, B0, nullptr, sA0, sB0, 0, lda0, ldb0, K0};
+  g.nseg = 1;
+  if (A1) {
+    g.seg[1] = GemmSeg{A1, B1, scale1, sA1, sB1, sScale1, lda1, ldb1, K1};
+    g.nseg = 2;
+  }
+  g.C = C; g.strideC = sC; g.ldc = ldc; g.Mp = rows; g.Np = cols;
+  g.diag = diag; g.strideDiag = sDiag; g.epilogue = epi; g.lower_only = lower_only; g.batch = B;
+  const double flops = 2.0 * rows * cols * (double)(K0 + (A1 ? K1 : 0)) * B;
+  StageTimer st(c, stage, flops);
+  return launch_gemm_nt_f64(g, c->stream) == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* xivo_hip_strerror(int s) {
+  switch (s) {
+    case XIVO_HIP_OK: return "ok";
+    case XIVO_HIP_ERR_INVALID: return "invalid argument";
+    case XIVO_HIP_ERR_HIP: return "HIP runtime error";
+    case XIVO_HIP_ERR_NOT_SPD: return "innovation covariance S is not positive definite";
+    case XIVO_HIP_ERR_NOMEM: return "out of device memory";
+    case XIVO_HIP_ERR_UNSUPPORTED: return "size not supported by the compiled kernels";
+    default: return "unknown status";
+  }
+}
+
+void xivo_hip_destroy(xivo_hip_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
+                  c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
+                  c->mask, c->rows_instate, c->oos, c->oos_rows};
+  for (void* p : ptrs) if (p) hipFree(p);
+  for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+  if (c->t0) hipEventDestroy(c->t0);
+  if (c->t1) hipEventDestroy(c->t1);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_max, unsigned flags) {
+  if (!out || N <= 0 || M_max <= 0 || batch_max <= 0) return XIVO_HIP_ERR_INVALID;
+  *out = nullptr;
+  if (round_up16(M_max) / 16 > 24) return XIVO_HIP_ERR_UNSUPPORTED;  // trsm register budget
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return XIVO_HIP_ERR_HIP;
+  HIP_TRY(hipSetDevice(device));
+  xivo_hip_ctx* c = new (std::nothrow) xivo_hip_ctx();
+  if (!c) return XIVO_HIP_ERR_NOMEM;
+  c->device = device; c->N = N; c->Np = round_up16(N); c->Mmax = M_max; c->Mpmax = round_up16(M_max);
+  c->Bmax = batch_max; c->flags = flags;
+  const size_t B = batch_max;
+  const size_t Np = c->Np, Mp = c->Mpmax;
+  c->sP = (long)(Np * Np); c->sH = (long)(Mp * Np); c->sHT = (long)(Np * Mp); c->sS = (long)(Mp * Mp);
+  c->sK = (long)(Np * Mp); c->sInvD = (long)(Mp / 16 * 512);
+  int rc = XIVO_HIP_OK;
+  auto A = [&](auto** p, size_t n) { if (rc == XIVO_HIP_OK) rc = dev_alloc(p, n); };
+  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return XIVO_HIP_ERR_HIP; }
+  A(&c->P, B * c->sP); A(&c->H, B * c->sH); A(&c->HT, B * c->sHT); A(&c->HP, B * c->sH);
+  A(&c->S, B * c->sS); A(&c->K, B * c->sK); A(&c->A, B * c->sP); A(&c->T, B * c->sP);
+  A(&c->invD, B * c->sInvD); A(&c->inn, B * Mp); A(&c->diagR, B * Mp); A(&c->err, B * Np);
+  A(&c->status, B); A(&c->scratch, B * Np);
+  if (rc == XIVO_HIP_OK && hipEventCreate(&c->t0) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
+  if (rc == XIVO_HIP_OK && hipEventCreate(&c->t1) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
+  if (rc != XIVO_HIP_OK) { xivo_hip_destroy(c); return rc; }
+  *out = c;
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_sync(xivo_hip_ctx* c) {
+  if (!c) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_set_flags(xivo_hip_ctx* c, unsigned flags) {
+  if (!c) return XIVO_HIP_ERR_INVALID;
+  c->flags = flags;
+  return XIVO_HIP_OK;
+}
+
+// ------------------------------------------------------------------ P residency
+int xivo_hip_upload_P(xivo_hip_ctx* c, int b0, int nb, const double* P, long stride, int ld) {
+  if (bad_range(c, b0, nb) || !P || ld < c->N) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const int N = c->N;
+  int rc = ensure_staging(c, (size_t)nb * N * N);
+  if (rc) return rc;
+  rc = h2d_packed(c, c->staging, P, nb, N, N, stride, ld);
+  if (rc) return rc;
+  if (launch_unpack_P(c->staging, c->P + (long)b0 * c->sP, N, c->Np, c->Np, c->sP, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // host buffer is only borrowed for the call
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_download_P(xivo_hip_ctx* c, int b0, int nb, double* P, long stride, int ld) {
+  if (bad_range(c, b0, nb) || !P || ld < c->N) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const int N = c->N;
+  int rc = ensure_staging(c, (size_t)nb * N * N);
+  if (rc) return rc;
+  if (launch_pack_P(c->P + (long)b0 * c->sP, c->staging, N, c->Np, c->sP, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  rc = d2h_packed(c, P, c->staging, nb, N, N, stride, ld);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_snapshot_P(xivo_hip_ctx* c) {
+  if (!c) return XIVO_HIP_ERR_INVALID;
+  if (!c->Psnap) {
+    if (hipMalloc((void**)&c->Psnap, (size_t)c->Bmax * c->sP * sizeof(double)) != hipSuccess) return XIVO_HIP_ERR_NOMEM;
+  }
+  HIP_TRY(hipMemcpyAsync(c->Psnap, c->P, (size_t)c->Bmax * c->sP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_restore_P(xivo_hip_ctx* c) {
+  if (!c || !c->Psnap) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipMemcpyAsync(c->P, c->Psnap, (size_t)c->Bmax * c->sP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_p_zero_rc(xivo_hip_ctx* c, int b, int off, int len) {
+  if (bad_range(c, b, 1) || off < 0 || len < 0 || off + len > c->N) return XIVO_HIP_ERR_INVALID;
+  return launch_p_zero_rc(c->P + (long)b * c->sP, c->Np, c->Np, off, len, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+int xivo_hip_p_copy_rc(xivo_hip_ctx* c, int b, int dst, int src, int len) {
+  if (bad_range(c, b, 1) || dst < 0 || src < 0 || len < 0 || dst + len > c->N || src + len > c->N) return XIVO_HIP_ERR_INVALID;
+  return launch_p_copy_rc(c->P + (long)b * c->sP, c->Np, c->Np, dst, src, len, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+int xivo_hip_p_set_block3(xivo_hip_ctx* c, int b, int off, const double* P3) {
+  if (bad_range(c, b, 1) || !P3 || off < 0 || off + 3 > c->N) return XIVO_HIP_ERR_INVALID;
+  double* dst = c->P + (long)b * c->sP + off + (long)off * c->Np;
+  HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->Np * sizeof(double), P3, 3 * sizeof(double), 3 * sizeof(double), 3,
+                           hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_p_diag(xivo_hip_ctx* c, int b, double* out) {
+  if (bad_range(c, b, 1) || !out) return XIVO_HIP_ERR_INVALID;
+  if (launch_p_diag(c->P + (long)b * c->sP, c->Np, c->N, c->scratch, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY(hipMemcpyAsync(out, c->scratch, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+// ------------------------------------------------------------------ S-level
+int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const double* H, long strideH, int ldh,
+                              const double* inn, long strideInn, const double* diagR, long strideR) {
+  if (bad_range(c, b0, nb) || !H || !inn || !diagR || M <= 0 || M > c->Mmax || ldh < M) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const int N = c->N;
+  const size_t per = (size_t)M * N + 2 * (size_t)M;
+  int rc = ensure_staging(c, (size_t)nb * per);
+  if (rc) return rc;
+  double* sH = c->staging;
+  double* sInn = sH + (size_t)nb * M * N;
+  double* sR = sInn + (size_t)nb * M;
+  rc = h2d_packed(c, sH, H, nb, M, N, strideH, ldh);
+  if (rc) return rc;
+  rc = h2d_packed(c, sInn, inn, nb, M, 1, strideInn, M);
+  if (rc) return rc;
+  rc = h2d_packed(c, sR, diagR, nb, M, 1, strideR, M);
+  if (rc) return rc;
+  MeasBuffers mb = meas_buffers(c);
+  mb.H += (long)b0 * mb.strideH; mb.HT += (long)b0 * mb.strideHT;
+  mb.inn += (long)b0 * mb.strideInn; mb.diagR += (long)b0 * mb.strideR;
+  c->M = M; c->Mp = round_up16(M);
+  // clear up to the allocated row count so stale rows of a previous, larger M vanish
+  if (launch_unpack_meas(sH, sInn, sR, mb, M, c->Mpmax, N, c->Np, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_update_joseph(xivo_hip_ctx* c, int B) {
+  if (!c || B <= 0 || B > c->Bmax || c->Mp <= 0) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
+  int rc;
+  // HP = H * P  (estimator.cpp:1259 first product; P symmetric => B operand = P rows)
+  rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+            c->HP, c->sH, ldh, EPI_NONE, nullptr, 0, 0);
+  if (rc) return rc;
+  // S = HP * H^T + diag(R)  (estimator.cpp:1259-1263)
+  rc = gemm(c, ST_S, B, Mp, Mp, c->HP, c->sH, ldh, c->H, c->sH, ldh, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+            c->S, c->sS, lds, EPI_ADD_DIAG, c->diagR, c->Mpmax, 0);
+  if (rc) return rc;
+  {  // S = L L^T
+    CholArgs a; a.S = c->S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = c->invD; a.strideInvD = c->sInvD;
+    a.status = c->status; a.batch = B;
+    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B);
+    if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
+    TrsmArgs a; a.LU = c->S; a.strideLU = c->sS; a.ldlu = lds; a.invD = c->invD; a.strideInvD = c->sInvD;
+    a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh; a.K = c->K; a.strideK = c->sK; a.ldk = Np;
+    a.inn = c->inn; a.strideInn = c->Mpmax; a.err = c->err; a.strideErr = Np; a.Mp = Mp; a.Np = Np; a.batch = B;
+    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B);
+    if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  // A = K * H - I  (estimator.cpp:1276-1279)
+  rc = gemm(c, ST_KH, B, Np, Np, c->K, c->sK, Np, c->HT, c->sHT, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+            c->A, c->sP, Np, EPI_SUB_IDENT, nullptr, 0, 0);
+  if (rc) return rc;
+  // T = A * P  (estimator.cpp:1280, left product)
+  rc = gemm(c, ST_AP, B, Np, Np, c->A, c->sP, Np, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+            c->T, c->sP, Np, EPI_NONE, nullptr, 0, 0);
+  if (rc) return rc;
+  // P = T * A^T + K diag(R) K^T  (estimator.cpp:1280-1287, fused)
+  rc = gemm(c, ST_PNEW, B, Np, Np, c->T, c->sP, Np, c->A, c->sP, Np, Np, c->K, c->sK, Np, c->K, c->sK, Np, Mp, c->diagR,
+            c->Mpmax, c->P, c->sP, Np, EPI_NONE, nullptr, 0, (c->flags & XIVO_HIP_FLAG_FULL_PNEW) ? 0 : 1);
+  return rc;
+}
+
+int xivo_hip_get_err(xivo_hip_ctx* c, int b0, int nb, double* err, long stride) {
+  if (bad_range(c, b0, nb) || !err || stride < c->N) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipMemcpy2DAsync(err, (size_t)stride * sizeof(double), c->err + (long)b0 * c->Np, (size_t)c->Np * sizeof(double),
+                           (size_t)c->N * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_get_status(xivo_hip_ctx* c, int b0, int nb, int* status) {
+  if (bad_range(c, b0, nb) || !status) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipMemcpyAsync(status, c->status + b0, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < nb; ++i) if (status[i]) return XIVO_HIP_ERR_NOT_SPD;
+  return XIVO_HIP_OK;
+}
+
+static int ensure_gate_buffers(xivo_hip_ctx* c, int F) {
+  if (F <= c->Fmax && c->mask) return XIVO_HIP_OK;
+  const int Fm = F > c->Mpmax / 2 ? F : c->Mpmax / 2;
+  void* olds[] = {c->feats, c->J, c->finn, c->dist, c->mask};
+  for (void* p : olds) if (p) hipFree(p);
+  c->feats = nullptr; c->J = nullptr; c->finn = nullptr; c->dist = nullptr; c->mask = nullptr;
+  const size_t B = c->Bmax;
+  int rc = dev_alloc(&c->feats, B * Fm);
+  if (!rc) rc = dev_alloc(&c->J, B * Fm * 42);
+  if (!rc) rc = dev_alloc(&c->finn, B * Fm * 2);
+  if (!rc) rc = dev_alloc(&c->dist, B * Fm);
+  if (!rc) rc = dev_alloc(&c->mask, B * Fm);
+  if (!rc && !c->rows_instate) rc = dev_alloc(&c->rows_instate, B);
+  if (!rc) c->Fmax = Fm;
+  return rc;
+}
+
+int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_thresh, double mh_mult,
+                           int min_inliers, unsigned char* mask_out, double* dist_out) {
+  if (!c || B <= 0 || B > c->Bmax || F <= 0 || 2 * F > c->M) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensure_gate_buffers(c, F);
+  if (rc) return rc;
+  const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
+  rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+            c->HP, c->sH, ldh, EPI_NONE, nullptr, 0, 0);
+  if (rc) return rc;
+  GateDenseArgs a;
+  a.H = c->H; a.strideH = c->sH; a.ldh = ldh; a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh;
+  a.Hw = c->H; a.HTw = c->HT; a.strideHT = c->sHT; a.ldht = Np;
+  a.inn = c->inn; a.strideInn = c->Mpmax; a.diagR = c->diagR; a.strideR = c->Mpmax;
+  a.mask = c->mask; a.dist = c->dist; a.F = F; a.Np = Np; a.batch = B;
+  a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;
+  {
+    StageTimer st(c, ST_GATE, 0.0);
+    if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  if (mask_out) HIP_TRY(hipMemcpyAsync(mask_out, c->mask, (size_t)B * F, hipMemcpyDeviceToHost, c->stream));
+  if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, c->dist, (size_t)B * F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (mask_out || dist_out) HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+// ------------------------------------------------------------------ G-level
+int xivo_hip_set_layout(xivo_hip_ctx* c, const xivo_layout* lay, const xivo_cam* cam) {
+  if (!c || !lay || !cam) return XIVO_HIP_ERR_INVALID;
+  if (lay->N != c->N || lay->group_begin < 21 || lay->n_groups <= 0 || lay->n_features <= 0 ||
+      lay->feature_begin < lay->group_begin + 6 * lay->n_groups ||
+      lay->feature_begin + 3 * lay->n_features > lay->N)
+    return XIVO_HIP_ERR_INVALID;
+  if (cam->model < XIVO_CAM_PINHOLE || cam->model > XIVO_CAM_EQUI) return XIVO_HIP_ERR_INVALID;
+  c->lay = *lay; c->cam = *cam; c->have_layout = true;
+  if (!c->poses) {
+    int rc = dev_alloc(&c->poses, (size_t)c->Bmax);
+    if (!rc) rc = dev_alloc(&c->groups, (size_t)c->Bmax * lay->n_groups);
+    if (rc) return rc;
+  }
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_set_scene(xivo_hip_ctx* c, int b0, int nb, int F, const xivo_pose_in* poses,
+                       const xivo_group_in* groups, const xivo_feat_in* feats) {
+  if (bad_range(c, b0, nb) || !c->have_layout || F <= 0 || 2 * F > c->Mmax || !poses || !groups || !feats)
+    return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensure_gate_buffers(c, F);
+  if (rc) return rc;
+  for (long i = 0; i < (long)nb * F; ++i) {
+    const xivo_feat_in& f = feats[i];
+    if (f.ref_sind < 0 || f.ref_sind >= c->lay.n_groups || f.sind < 0 || f.sind >= c->lay.n_features)
+      return XIVO_HIP_ERR_INVALID;
+  }
+  c->F = F;
+  HIP_TRY(hipMemcpyAsync(c->poses + b0, poses, (size_t)nb * sizeof(xivo_pose_in), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->groups + (size_t)b0 * c->lay.n_groups, groups,
+                         (size_t)nb * c->lay.n_groups * sizeof(xivo_group_in), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpy2DAsync(c->feats + (size_t)b0 * c->Fmax, (size_t)c->Fmax * sizeof(xivo_feat_in), feats,
+                           (size_t)F * sizeof(xivo_feat_in), (size_t)F * sizeof(xivo_feat_in), nb,
+                           hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_jacobians_instate(xivo_hip_ctx* c, int B) {
+  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
+  StageTimer st(c, ST_JAC, 0.0);
+  return launch_jac_instate(scene_buffers(c), c->lay, c->cam, B, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+int xivo_hip_get_jacobians(xivo_hip_ctx* c, int b0, int nb, double* J, double* inn) {
+  if (bad_range(c, b0, nb) || c->F <= 0) return XIVO_HIP_ERR_INVALID;
+  const size_t F = c->F, Fm = c->Fmax;
+  if (J) HIP_TRY(hipMemcpy2DAsync(J, F * 42 * sizeof(double), c->J + (size_t)b0 * Fm * 42, Fm * 42 * sizeof(double),
+                                  F * 42 * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+  if (inn) HIP_TRY(hipMemcpy2DAsync(inn, F * 2 * sizeof(double), c->finn + (size_t)b0 * Fm * 2, Fm * 2 * sizeof(double),
+                                    F * 2 * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+static int gate_impl(xivo_hip_ctx* c, int B, double R, double th, double mult, int min_inl, int use_gating) {
+  GateArgs a;
+  a.sb = scene_buffers(c); a.lay = c->lay; a.P = c->P; a.strideP = c->sP; a.ldp = c->Np;
+  a.R = R; a.thresh = th; a.mult = mult; a.min_inliers = min_inl; a.batch = B; a.use_gating = use_gating;
+  StageTimer st(c, ST_GATE, 0.0);
+  return launch_gate_sparse(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double mh_mult, int min_inliers,
+                     unsigned char* mask_out, double* dist_out) {
+  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
+  int rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
+  if (rc) return rc;
+  const size_t F = c->F, Fm = c->Fmax;
+  if (mask_out) HIP_TRY(hipMemcpy2DAsync(mask_out, F, c->mask, Fm, F, B, hipMemcpyDeviceToHost, c->stream));
+  if (dist_out) HIP_TRY(hipMemcpy2DAsync(dist_out, F * sizeof(double), c->dist, Fm * sizeof(double), F * sizeof(double), B,
+                                         hipMemcpyDeviceToHost, c->stream));
+  if (mask_out || dist_out) HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
+  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
+  StackArgs a;
+  a.sb = scene_buffers(c); a.lay = c->lay; a.mb = meas_buffers(c);
+  a.Mp = c->Mpmax; a.Np = c->Np; a.batch = B; a.R = R;
+  a.fix_group_block = (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK) ? 1 : 0;
+  a.rows_instate = c->rows_instate;
+  c->M = 2 * c->F; c->Mp = round_up16(c->M);
+  StageTimer st(c, ST_STACK, 0.0);
+  return launch_stack(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_oos_in* feats, double Roos,
+                         int* rows_out) {
+  if (bad_range(c, b0, nb) || !c->have_layout || n_oos <= 0 || !feats || b0 != 0) return XIVO_HIP_ERR_INVALID;
+  int max_rows = 0;
+  for (int b = 0; b < nb; ++b) {
+    int rows = 0;
+    for (int o = 0; o < n_oos; ++o) {
+      const xivo_oos_in& f = feats[(size_t)b * n_oos + o];
+      if (f.n_obs < 2 || f.n_obs > XIVO_OOS_MAX_OBS) return XIVO_HIP_ERR_INVALID;
+      for (int q = 0; q < f.n_obs; ++q)
+        if (f.group_sind[q] < 0 || f.group_sind[q] >= c->lay.n_groups) return XIVO_HIP_ERR_INVALID;
+      rows += 2 * f.n_obs - 3;
+    }
+    if (rows > max_rows) max_rows = rows;
+  }
+  if (c->M + max_rows > c->Mmax) return XIVO_HIP_ERR_INVALID;
+  if (n_oos * nb > c->oos_cap) {
+    if (c->oos) hipFree(c->oos);
+    c->oos = nullptr; c->oos_cap = 0;
+    int rc = dev_alloc(&c->oos, (size_t)n_oos * c->Bmax);
+    if (rc) return rc;
+    c->oos_cap = n_oos * c->Bmax;
+  }
+  if (!c->oos_rows) { int rc = dev_alloc(&c->oos_rows, (size_t)c->Bmax); if (rc) return rc; }
+  HIP_TRY(hipMemcpyAsync(c->oos, feats, (size_t)nb * n_oos * sizeof(xivo_oos_in), hipMemcpyHostToDevice, c->stream));
+  OosArgs a;
+  a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
+  a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
+  a.rows_out = c->oos_rows;
+  {
+    StageTimer st(c, ST_OTHER, 0.0);
+    if (launch_oos(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  if (rows_out) HIP_TRY(hipMemcpyAsync(rows_out, c->oos_rows, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->M += max_rows; c->Mp = round_up16(c->M);
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, double mh_mult, int min_inliers,
+                           int use_gating) {
+  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
+  int rc = xivo_hip_jacobians_instate(c, B);
+  if (rc) return rc;
+  // Estimator::OutlierRejection only gates when F > min_required_inliers_ (src/manager.cpp:635)
+  const int gate = use_gating && c->F > min_inliers;
+  rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, gate);
+  if (rc) return rc;
+  rc = xivo_hip_stack(c, B, R);
+  if (rc) return rc;
+  return xivo_hip_update_joseph(c, B);
+}
+
+int xivo_hip_get_H(xivo_hip_ctx* c, int b, int* M_out, double* H, int ldh, double* inn, double* diagR) {
+  if (bad_range(c, b, 1) || c->M <= 0) return XIVO_HIP_ERR_INVALID;
+  const int M = c->M;
+  if (M_out) *M_out = M;
+  if (H) {
+    if (ldh < M) return XIVO_HIP_ERR_INVALID;
+    HIP_TRY(hipMemcpy2DAsync(H, (size_t)ldh * sizeof(double), c->H + (long)b * c->sH, (size_t)c->Mpmax * sizeof(double),
+                             (size_t)M * sizeof(double), c->N, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (inn) HIP_TRY(hipMemcpyAsync(inn, c->inn + (long)b * c->Mpmax, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (diagR) HIP_TRY(hipMemcpyAsync(diagR, c->diagR + (long)b * c->Mpmax, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+// ------------------------------------------------------------------ propagation tail
+int xivo_hip_propagate_cov(xivo_hip_ctx* c, int b0, int nb, int nm, const double* Phi, const double* Pmm) {
+  if (bad_range(c, b0, nb) || nm <= 0 || nm > 32 || nm > c->N || !Phi || !Pmm) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  const size_t per = (size_t)nm * nm;
+  int rc = ensure_staging(c, 2 * per * nb);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->staging, Phi, per * nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->staging + per * nb, Pmm, per * nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  {
+    StageTimer st(c, ST_OTHER, 0.0);
+    if (launch_propagate_cov(c->P, c->sP, c->Np, c->N, c->Np, nm, c->staging, c->staging + per * nb, b0, nb, c->stream))
+      return XIVO_HIP_ERR_HIP;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+// ------------------------------------------------------------------ timing
+int xivo_hip_timer_begin(xivo_hip_ctx* c) {
+  if (!c) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipEventRecord(c->t0, c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_timer_end(xivo_hip_ctx* c, float* ms) {
+  if (!c || !ms) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipEventRecord(c->t1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->t1));
+  HIP_TRY(hipEventElapsedTime(ms, c->t0, c->t1));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_profile_reset(xivo_hip_ctx* c) {
+  if (!c) return XIVO_HIP_ERR_INVALID;
+  int rc = collect_profile(c);
+  for (int i = 0; i < ST_COUNT; ++i) { c->stage_ms[i] = 0.f; c->stage_launches[i] = 0; c->stage_flops[i] = 0.0; }
+  return rc;
+}
+
+int xivo_hip_profile_get(xivo_hip_ctx* c, int* n, const char** names, float* ms, int* launches, double* flops) {
+  if (!c || !n) return XIVO_HIP_ERR_INVALID;
+  int rc = collect_profile(c);
+  if (rc) return rc;
+  *n = ST_COUNT;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    if (names) names[i] = kStageNames[i];
+    if (ms) ms[i] = c->stage_ms[i];
+    if (launches) launches[i] = c->stage_launches[i];
+    if (flops) flops[i] = c->stage_flops[i];
+  }
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_bench_mfma_peak(xivo_hip_ctx* c, double* tflops) {
+  if (!c || !tflops) return XIVO_HIP_ERR_INVALID;
+  const int iters = 2000;
+  if (launch_mfma_peak(c->scratch, 10, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY(hipEventRecord(c->t0, c->stream));
+  if (launch_mfma_peak(c->scratch, iters, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY(hipEventRecord(c->t1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->t1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->t0, c->t1));
+  const double flops = 2.0 * 16 * 16 * 4 * 8.0 * iters * 4.0 /*waves*/ * 256 * 8 /*blocks*/;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  return XIVO_HIP_OK;
+}
+
+void xivo_hip_gemm_tile(int rows, int cols, int* bm, int* bn) {
+  int wm, wn;
+  gemm_pick_tile(round_up16(rows), round_up16(cols), &wm, &wn);
+  if (bm) *bm = 32 * wm;
+  if (bn) *bn = 32 * wn;
+}
+
+}  // extern "C"

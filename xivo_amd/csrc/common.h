@@ -1,0 +1,95 @@
+// Shared declarations for the MI355X (gfx950) EKF measurement-update kernels.
+//
+// All device matrices are column-major fp64 (the reference's Eigen layout,
+// /root/reference/common/alias.h:11, CMakeLists.txt:42) with every dimension
+// padded to a multiple of 16 (the v_mfma_f64_16x16x4_f64 tile) and zero filled
+// in the pad, so no kernel needs element-level bounds checks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xivo_hip {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+static inline int round_up16(int x) { return (x + 15) & ~15; }
+
+// ---------------------------------------------------------------------------
+// Batched "NT" GEMM:  C[i + j*ldc] (+)= sum_k A[i + k*lda] * B[j + k*ldb]
+// i.e. C = A * B^T with both operands stored with the OUTPUT index contiguous.
+// Up to two K-segments are summed into one output tile (used for
+// P+ = T*A^T + K*diag(R)*K^T, estimator.cpp:1280-1287, in a single pass).
+// ---------------------------------------------------------------------------
+struct GemmSeg {
+  const double* A;      // [rows_out x K], leading dim lda
+  const double* B;      // [cols_out x K], leading dim ldb
+  const double* scale;  // optional per-k scale applied to B (nullptr = none)
+  long strideA, strideB, strideScale;  // per-filter strides (elements)
+  int lda, ldb, K;      // K multiple of 16
+};
+
+enum GemmEpilogue : int {
+  EPI_NONE = 0,
+  EPI_ADD_DIAG = 1,   // C[i][i] += diag[i]      (S = HPH^T + R, estimator.cpp:1261-1263)
+  EPI_SUB_IDENT = 2,  // C[i][i] -= 1            (KH - I,       estimator.cpp:1276-1279)
+  EPI_SUB_C0 = 3,     // C = acc - C0            (unused by default path)
+};
+
+struct GemmArgs {
+  GemmSeg seg[2];
+  int nseg;
+  double* C;
+  long strideC;
+  int ldc;
+  int Mp, Np;          // output rows / cols (multiples of 16)
+  const double* diag;  // EPI_ADD_DIAG
+  long strideDiag;
+  int epilogue;
+  int lower_only;      // 1: skip tiles strictly above the diagonal and mirror-store
+  int batch;
+  int tiles_m, tiles_n;
+};
+
+// launches on `stream`; returns hipError_t as int
+int launch_gemm_nt_f64(const GemmArgs& args, hipStream_t stream);
+// tile actually chosen for (Mp, Np) - exposed for tests / DESIGN.md
+void gemm_pick_tile(int Mp, int Np, int* WM, int* WN);
+
+// ---------------------------------------------------------------------------
+// Batched Cholesky (one workgroup per filter) + register-resident TRSM.
+// ---------------------------------------------------------------------------
+struct CholArgs {
+  double* S;        // [Mp x Mp] in: S (lower triangle read); out: L in lower, L^T in upper
+  long strideS;
+  int lds;
+  int Mp;           // multiple of 16
+  double* invD;     // [Mp/16][2][256]: inv(L_jj) col-major, then its transpose
+  long strideInvD;
+  int* status;      // per filter: 0 ok, else 1 + first non-positive pivot index
+  int batch;
+};
+int launch_chol_f64(const CholArgs& args, hipStream_t stream);
+
+struct TrsmArgs {
+  const double* LU;    // from chol: L lower, L^T upper
+  long strideLU;
+  int ldlu;
+  const double* invD;
+  long strideInvD;
+  const double* HP;    // RHS [Mp x Np] col-major
+  long strideHP;
+  int ldhp;
+  double* K;           // out: gain [Np x Mp] col-major (estimator.cpp:1265-1266)
+  long strideK;
+  int ldk;
+  const double* inn;   // [Mp]
+  long strideInn;
+  double* err;         // out: dx = K * inn [Np]  (estimator.cpp:1267)
+  long strideErr;
+  int Mp, Np;
+  int batch;
+};
+int launch_trsm_f64(const TrsmArgs& args, hipStream_t stream);
+
+}  // namespace xivo_hip

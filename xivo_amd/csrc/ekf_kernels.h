@@ -1,0 +1,85 @@
+// Launchers of the EKF-specific (non-GEMM) kernels. See ekf_kernels.hip.
+#pragma once
+#include "common.h"
+#include "../../include/xivo_hip.h"
+
+namespace xivo_hip {
+
+// raw (n x n, ld = n, contiguous per filter) <-> padded (ld = ldp) covariance
+int launch_unpack_P(const double* raw, double* P, int N, int Np, int ldp, long strideP, int batch,
+                    hipStream_t s);
+int launch_pack_P(const double* P, double* raw, int N, int ldp, long strideP, int batch, hipStream_t s);
+
+// raw H (M x N, ld = M), inn (M), diagR (M)  ->  padded H (Mp x Np, ld ldh),
+// H^T (Np x Mp, ld ldht), inn (Mp, zero pad), diagR (Mp, pad = 1)
+struct MeasBuffers {
+  double* H; long strideH; int ldh;
+  double* HT; long strideHT; int ldht;
+  double* inn; long strideInn;
+  double* diagR; long strideR;
+};
+int launch_unpack_meas(const double* rawH, const double* rawInn, const double* rawR, MeasBuffers mb,
+                       int M, int Mp, int N, int Np, int batch, hipStream_t s);
+
+// P edits
+int launch_p_zero_rc(double* P, int ldp, int Np, int off, int len, hipStream_t s);
+int launch_p_copy_rc(double* P, int ldp, int Np, int dst, int src, int len, hipStream_t s);
+int launch_p_diag(const double* P, int ldp, int N, double* out, hipStream_t s);
+
+// dense-row Mahalanobis gating (update.cpp:60-96) + neutralising rejected rows
+struct GateDenseArgs {
+  const double* H; long strideH; int ldh;       // candidate rows (J of feature f = rows 2f, 2f+1)
+  const double* HP; long strideHP; int ldhp;    // H * P of the same rows
+  double* Hw; double* HTw; long strideHT; int ldht;  // H / H^T to neutralise
+  double* inn; long strideInn;
+  double* diagR; long strideR;
+  unsigned char* mask; double* dist;            // [batch x F]
+  int F, Np, batch;
+  double R, thresh, mult; int min_inliers;
+};
+int launch_gate_dense(const GateDenseArgs& a, hipStream_t s);
+
+// G-level kernels
+struct SceneBuffers {
+  const xivo_pose_in* poses;     // [batch]
+  const xivo_group_in* groups;   // [batch x n_groups]
+  const xivo_feat_in* feats;     // [batch x Fmax]
+  double* J;                     // [batch x Fmax x 42]  (2 x 21 row-major)
+  double* finn;                  // [batch x Fmax x 2]
+  unsigned char* mask;           // [batch x Fmax]
+  double* dist;                  // [batch x Fmax]
+  int Fmax, F;
+};
+int launch_jac_instate(const SceneBuffers& sb, const xivo_layout& lay, const xivo_cam& cam, int batch,
+                       hipStream_t s);
+struct GateArgs {
+  SceneBuffers sb; xivo_layout lay;
+  const double* P; long strideP; int ldp;
+  double R, thresh, mult; int min_inliers; int batch; int use_gating;
+};
+int launch_gate_sparse(const GateArgs& a, hipStream_t s);
+struct StackArgs {
+  SceneBuffers sb; xivo_layout lay; MeasBuffers mb;
+  int Mp, Np, batch; double R; int fix_group_block;
+  int* rows_instate;   // [batch] out: 2 * F (rows reserved for in-state features)
+};
+int launch_stack(const StackArgs& a, hipStream_t s);
+
+// OOS (MSCKF) rows: oos.cpp:39-89 + helpers.cpp:13-23
+struct OosArgs {
+  const xivo_oos_in* feats; int n_oos;          // [batch x n_oos]
+  const xivo_pose_in* poses; const xivo_group_in* groups;
+  xivo_layout lay; xivo_cam cam; MeasBuffers mb;
+  int row0;            // first free row (after the in-state rows)
+  int Mp, Np, batch; double Roos;
+  int* rows_out;       // [batch]
+};
+int launch_oos(const OosArgs& a, hipStream_t s);
+
+// propagation tail (rk4.cpp:92-102)
+int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm, const double* Phi,
+                         const double* Pmm, int b0, int nb, hipStream_t s);
+
+int launch_mfma_peak(double* sink, int iters, hipStream_t s);
+
+}  // namespace xivo_hip

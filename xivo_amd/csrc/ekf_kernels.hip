@@ -1,0 +1,723 @@
+// EKF-specific kernels around the batched GEMM / Cholesky core (gfx950).
+//
+//  jac_instate_kernel   Feature::ComputeJacobian           src/feature.cpp:542-656
+//  gate_sparse_kernel   Estimator::MHGating                src/update.cpp:50-116
+//  gate_dense_kernel    same numeric core on dense J rows  src/update.cpp:60-96
+//  stack_kernel         FilterUpdate stacking + Feature::FillJacobianBlock
+//                                                          src/update.cpp:129-138, src/feature.cpp:658-684
+//  oos_kernel           ComputeOOSJacobian(+Internal) + SlowGivens
+//                                                          src/oos.cpp:8-89, src/helpers.cpp:13-23
+//  propagate_cov_kernel covariance cross-block tail        src/rk4.cpp:92-102
+//  p_* kernels          host edits of P_
+// (all paths relative to /root/reference). These are HBM/L2-bound byte movers
+// or tiny per-feature 3x3 chains: one thread / one wave64 per feature, wave
+// reductions for the chi-square gating, no MFMA.
+#include "ekf_kernels.h"
+#include "camera_device.h"
+
+namespace xivo_hip {
+
+namespace {
+
+// ---------------------------------------------------------------- pack/unpack
+__global__ void unpack_P_kernel(const double* __restrict__ raw, double* __restrict__ P, int N, int Np,
+                                int ldp, long strideP) {
+  const int f = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)Np * Np) return;
+  const int i = (int)(e % Np), j = (int)(e / Np);
+  double v = 0.0;
+  if (i < N && j < N) v = raw[(long)f * N * N + i + (long)j * N];
+  P[(long)f * strideP + i + (long)j * ldp] = v;
+}
+
+__global__ void pack_P_kernel(const double* __restrict__ P, double* __restrict__ raw, int N, int ldp,
+                              long strideP) {
+  const int f = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)N * N) return;
+  const int i = (int)(e % N), j = (int)(e / N);
+  raw[(long)f * N * N + e] = P[(long)f * strideP + i + (long)j * ldp];
+}
+
+__global__ void unpack_meas_kernel(const double* __restrict__ rawH, const double* __restrict__ rawInn,
+                                   const double* __restrict__ rawR, MeasBuffers mb, int M, int Mp, int N,
+                                   int Np) {
+  const int f = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tot = (long)Mp * Np;
+  if (e < tot) {
+    {  // H: m fastest
+      const int m = (int)(e % Mp), n = (int)(e / Mp);
+      double v = 0.0;
+      if (m < M && n < N) v = rawH[(long)f * M * N + m + (long)n * M];
+      mb.H[(long)f * mb.strideH + m + (long)n * mb.ldh] = v;
+    }
+    {  // H^T: n fastest
+      const int n = (int)(e % Np), m = (int)(e / Np);
+      double v = 0.0;
+      if (m < M && n < N) v = rawH[(long)f * M * N + m + (long)n * M];
+      mb.HT[(long)f * mb.strideHT + n + (long)m * mb.ldht] = v;
+    }
+  }
+  if (e < Mp) {
+    mb.inn[(long)f * mb.strideInn + e] = e < M ? rawInn[(long)f * M + e] : 0.0;
+    mb.diagR[(long)f * mb.strideR + e] = e < M ? rawR[(long)f * M + e] : 1.0;
+  }
+}
+
+// ---------------------------------------------------------------- P edits
+__global__ void p_zero_rc_kernel(double* P, int ldp, int Np, int off, int len) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Np) return;
+  for (int r = 0; r < len; ++r) {
+    P[(off + r) + (long)t * ldp] = 0.0;
+    P[t + (long)(off + r) * ldp] = 0.0;
+  }
+}
+// rows first, then columns - the order of Estimator::AddGroupToState
+// (src/estimator.cpp:808-816); phase selects which.
+__global__ void p_copy_rc_kernel(double* P, int ldp, int Np, int dst, int src, int len, int phase) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Np) return;
+  for (int r = 0; r < len; ++r) {
+    if (phase == 0) P[(dst + r) + (long)t * ldp] = P[(src + r) + (long)t * ldp];
+    else P[t + (long)(dst + r) * ldp] = P[t + (long)(src + r) * ldp];
+  }
+}
+__global__ void p_diag_kernel(const double* P, int ldp, int N, double* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < N) out[t] = P[t + (long)t * ldp];
+}
+
+// ---------------------------------------------------------------- gating core
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// d = res^T (S.llt().solve(res)) for 2x2 S given by its lower triangle
+// (src/update.cpp:65-69; Eigen LLT reads the lower triangle)
+__device__ __forceinline__ double mh_dist_2x2(double s00, double s10, double s11, double r0, double r1) {
+  const double l00 = sqrt(s00);
+  const double l10 = s10 / l00;
+  const double l11 = sqrt(s11 - l10 * l10);
+  const double y0 = r0 / l00;
+  const double y1 = (r1 - l10 * y0) / l11;
+  const double x1 = y1 / l11;
+  const double x0 = (y0 - l10 * x1) / l00;
+  return r0 * x0 + r1 * x1;
+}
+
+// threshold relaxation loop of src/update.cpp:73-96, run by one wave over the
+// F distances in LDS. Returns the threshold that was in force when the loop
+// exited (inlier <=> dist < thresh).
+__device__ double relax_threshold(const double* sdist, int F, double thresh, double mult, int min_inliers,
+                                  int lane) {
+  if (min_inliers <= 0) return -1.0;  // loop body never runs: no inliers (update.cpp:73)
+  for (int it = 0; it < 4096; ++it) {
+    int cnt = 0;
+    for (int f0 = 0; f0 < F; f0 += 64) {
+      const int f = f0 + lane;
+      const bool in = (f < F) && (sdist[f] < thresh);
+      cnt += __popcll(__ballot(in));
+    }
+    if (cnt >= min_inliers || cnt == F) return thresh;
+    thresh *= mult;
+  }
+  return thresh;
+}
+
+__global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
+  const int filt = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ double sdist[];  // F doubles + 1
+  const double* H = a.H + (long)filt * a.strideH;
+  const double* HP = a.HP + (long)filt * a.strideHP;
+  double* inn = a.inn + (long)filt * a.strideInn;
+  for (int f = wave; f < a.F; f += 4) {
+    double s00 = 0, s10 = 0, s11 = 0;
+    for (int n = lane; n < a.Np; n += 64) {
+      const d2 hp = *reinterpret_cast<const d2*>(HP + 2 * f + (long)n * a.ldhp);
+      const d2 h = *reinterpret_cast<const d2*>(H + 2 * f + (long)n * a.ldh);
+      s00 = fma(hp[0], h[0], s00);
+      s10 = fma(hp[1], h[0], s10);
+      s11 = fma(hp[1], h[1], s11);
+    }
+    s00 = wave_sum(s00) + a.R;
+    s10 = wave_sum(s10);
+    s11 = wave_sum(s11) + a.R;
+    if (lane == 0) sdist[f] = mh_dist_2x2(s00, s10, s11, inn[2 * f], inn[2 * f + 1]);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const double th = relax_threshold(sdist, a.F, a.thresh, a.mult, a.min_inliers, lane);
+    if (lane == 0) sdist[a.F] = th;
+  }
+  __syncthreads();
+  const double th = sdist[a.F];
+  for (int f = tid; f < a.F; f += 256) {
+    const bool in = sdist[f] < th;
+    a.mask[(long)filt * a.F + f] = in ? 1 : 0;
+    a.dist[(long)filt * a.F + f] = sdist[f];
+    if (!in) {
+      inn[2 * f] = 0.0; inn[2 * f + 1] = 0.0;
+      double* dr = a.diagR + (long)filt * a.strideR;
+      dr[2 * f] = 1.0; dr[2 * f + 1] = 1.0;
+    }
+  }
+  // neutralise rejected rows of H / H^T
+  double* Hw = a.Hw + (long)filt * a.strideH;
+  double* HTw = a.HTw + (long)filt * a.strideHT;
+  for (int f = 0; f < a.F; ++f) {
+    if (sdist[f] < th) continue;
+    for (int n = tid; n < a.Np; n += 256) {
+      Hw[2 * f + (long)n * a.ldh] = 0.0;
+      Hw[2 * f + 1 + (long)n * a.ldh] = 0.0;
+      HTw[n + (long)(2 * f) * a.ldht] = 0.0;
+      HTw[n + (long)(2 * f + 1) * a.ldht] = 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 3x3 helpers (row-major m[i][j])
+struct M3 { double m[3][3]; };
+struct V3 { double v[3]; };
+
+__device__ __forceinline__ M3 m3_from_colmajor(const double* p) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = p[i + 3 * j];
+  return r;
+}
+__device__ __forceinline__ M3 m3_t(const M3& a) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[j][i];
+  return r;
+}
+__device__ __forceinline__ M3 m3_mul(const M3& a, const M3& b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+  return r;
+}
+__device__ __forceinline__ M3 m3_neg(const M3& a) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = -a.m[i][j];
+  return r;
+}
+__device__ __forceinline__ M3 m3_add(const M3& a, const M3& b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][j] + b.m[i][j];
+  return r;
+}
+__device__ __forceinline__ V3 m3_mulv(const M3& a, const V3& x) {
+  V3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r.v[i] = a.m[i][0] * x.v[0] + a.m[i][1] * x.v[1] + a.m[i][2] * x.v[2];
+  return r;
+}
+// SO3::hat (sophus/so3.hpp): [0 -z y; z 0 -x; -y x 0]
+__device__ __forceinline__ M3 hat(const V3& w) {
+  M3 r;
+  r.m[0][0] = 0; r.m[0][1] = -w.v[2]; r.m[0][2] = w.v[1];
+  r.m[1][0] = w.v[2]; r.m[1][1] = 0; r.m[1][2] = -w.v[0];
+  r.m[2][0] = -w.v[1]; r.m[2][1] = w.v[0]; r.m[2][2] = 0;
+  return r;
+}
+// 2x3 = (2x3) * (3x3)
+__device__ __forceinline__ void m23_mul(const double a[2][3], const M3& b, double out[2][3]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[i][j] = a[i][0] * b.m[0][j] + a[i][1] * b.m[1][j] + a[i][2] * b.m[2][j];
+}
+
+// project(Xcn) with Jacobian (common/project.h:11-24) then Camera::Project;
+// returns dxp_dXcn = dxp_dxcn * dxcn_dXcn (feature.cpp:611-620, oos.cpp:66-70)
+__device__ __forceinline__ void project_pixel(const xivo_cam& cam, const V3& Xcn, double xp[2],
+                                              double dxp_dXcn[2][3]) {
+  const double X = Xcn.v[0], Y = Xcn.v[1], Z = Xcn.v[2];
+  const double xcn0 = X / Z, xcn1 = Y / Z;
+  const double d[2][3] = {{1 / Z, 0, -X / (Z * Z)}, {0, 1 / Z, -Y / (Z * Z)}};
+  double Jc[2][2];
+  camera_project(cam, xcn0, xcn1, xp, Jc);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dxp_dXcn[i][j] = Jc[i][0] * d[0][j] + Jc[i][1] * d[1][j];
+}
+
+// ---------------------------------------------------------------- in-state Jacobian
+// One thread per (filter, feature). Output J is 2 x 21 row-major with block
+// order [Wsb Tsb Wbc Tbc Wsbr Tsbr x] (the 7 structural non-zero blocks of
+// Feature::J_, feature.cpp:623-645).
+__global__ void jac_instate_kernel(SceneBuffers sb, xivo_layout lay, xivo_cam cam, int batch) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= batch * sb.F) return;
+  const int filt = t / sb.F, f = t % sb.F;
+  const xivo_pose_in& pose = sb.poses[filt];
+  const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+  const xivo_group_in& grp = sb.groups[(long)filt * lay.n_groups + ft.ref_sind];
+
+  const M3 Rsb = m3_from_colmajor(pose.Rsb), Rbc = m3_from_colmajor(pose.Rbc);
+  const M3 Rsb_t = m3_t(Rsb), Rbc_t = m3_t(Rbc);
+  const M3 Rsbr = m3_from_colmajor(grp.Rsb);
+  const V3 Tsb{{pose.Tsb[0], pose.Tsb[1], pose.Tsb[2]}}, Tbc{{pose.Tbc[0], pose.Tbc[1], pose.Tbc[2]}};
+  const V3 Tsbr{{grp.Tsb[0], grp.Tsb[1], grp.Tsb[2]}};
+
+  // Xc = unproject_logz(x_) (project.h:79-95, feature.cpp:98-105)
+  const double z = exp(ft.x[2]);
+  const V3 Xc{{ft.x[0] * z, ft.x[1] * z, z}};
+  M3 dXc_dx;
+  dXc_dx.m[0][0] = z; dXc_dx.m[0][1] = 0; dXc_dx.m[0][2] = ft.x[0] * z;
+  dXc_dx.m[1][0] = 0; dXc_dx.m[1][1] = z; dXc_dx.m[1][2] = ft.x[1] * z;
+  dXc_dx.m[2][0] = 0; dXc_dx.m[2][1] = 0; dXc_dx.m[2][2] = z;
+
+  // feature.cpp:556-560
+  V3 Xbr = m3_mulv(Rbc, Xc);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Xbr.v[i] += Tbc.v[i];
+  V3 Xs = m3_mulv(Rsbr, Xbr);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Xs.v[i] += Tsbr.v[i];
+  V3 dXs;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dXs.v[i] = Xs.v[i] - Tsb.v[i];
+  const V3 Xb = m3_mulv(Rsb_t, dXs);
+  V3 dXb;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dXb.v[i] = Xb.v[i] - Tbc.v[i];
+  const V3 Xcn = m3_mulv(Rbc_t, dXb);
+
+  // feature.cpp:563-590 (products associated left to right as Eigen does)
+  const M3 dXbr_dWbc = m3_mul(m3_neg(Rbc), hat(Xc));
+  const M3 dXs_dWsbr = m3_mul(m3_neg(Rsbr), hat(Xbr));
+  const M3 dXb_dWsb = hat(Xb);
+  const M3 dXcn_dXs = m3_mul(Rbc_t, Rsb_t);                 // dXcn_dXb * dXb_dXs
+  const M3 dXcn_dXbr = m3_mul(dXcn_dXs, Rsbr);              // ... * dXs_dXbr
+  const M3 dXcn_dTbc = m3_add(m3_neg(Rbc_t), dXcn_dXbr);    // :579-580 (dXbr_dTbc = I)
+  const M3 dXcn_dWbc = m3_add(hat(Xcn), m3_mul(dXcn_dXbr, dXbr_dWbc));  // :581-582
+  const M3 dXcn_dTsb = m3_mul(Rbc_t, m3_neg(Rsb_t));        // :585
+  const M3 dXcn_dWsb = m3_mul(Rbc_t, dXb_dWsb);             // :586
+  const M3 dXcn_dTsbr = dXcn_dXs;                           // :587 (dXs_dTsbr = I)
+  const M3 dXcn_dWsbr = m3_mul(dXcn_dXs, dXs_dWsbr);        // :588
+  const M3 dXcn_dx = m3_mul(m3_mul(dXcn_dXbr, Rbc), dXc_dx);  // :590
+
+  double xp[2], dxp_dXcn[2][3];
+  project_pixel(cam, Xcn, xp, dxp_dXcn);
+
+  double blk[7][2][3];
+  m23_mul(dxp_dXcn, dXcn_dWsb, blk[0]);
+  m23_mul(dxp_dXcn, dXcn_dTsb, blk[1]);
+  m23_mul(dxp_dXcn, dXcn_dWbc, blk[2]);
+  m23_mul(dxp_dXcn, dXcn_dTbc, blk[3]);
+  m23_mul(dxp_dXcn, dXcn_dWsbr, blk[4]);
+  m23_mul(dxp_dXcn, dXcn_dTsbr, blk[5]);
+  m23_mul(dxp_dXcn, dXcn_dx, blk[6]);
+
+  double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
+#pragma unroll
+  for (int b = 0; b < 7; ++b)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) J[i * 21 + 3 * b + j] = blk[b][i][j];
+  double* inn = sb.finn + ((long)filt * sb.Fmax + f) * 2;
+  inn[0] = ft.xp[0] - xp[0];   // feature.cpp:654-655
+  inn[1] = ft.xp[1] - xp[1];
+}
+
+// column of the error state that compact-J column c (0..20) maps to
+__device__ __forceinline__ int jcol(const xivo_layout& lay, const xivo_feat_in& ft, int c) {
+  const int b = c / 3, o = c % 3;
+  switch (b) {
+    case 0: return 0 + o;    // Index::Wsb  (core.h:41)
+    case 1: return 3 + o;    // Index::Tsb
+    case 2: return 15 + o;   // Index::Wbc
+    case 3: return 18 + o;   // Index::Tbc
+    case 4: return lay.group_begin + 6 * ft.ref_sind + o;
+    case 5: return lay.group_begin + 6 * ft.ref_sind + 3 + o;
+    default: return lay.feature_begin + 3 * ft.sind + o;
+  }
+}
+
+// One workgroup per filter; a wave64 per feature computes S = J P J^T + R I2
+// from the 21 x 21 sub-block of P the feature touches (J is structurally
+// sparse), reduces it across lanes, and the 2x2 LLT gives the Mahalanobis
+// distance. Then one wave runs the threshold-relaxation loop.
+__global__ __launch_bounds__(256) void gate_sparse_kernel(GateArgs a) {
+  const int filt = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ double sdist[];
+  const SceneBuffers& sb = a.sb;
+  const double* P = a.P + (long)filt * a.strideP;
+  if (a.use_gating) {
+    for (int f = wave; f < sb.F; f += 4) {
+      const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+      const double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
+      const double* inn = sb.finn + ((long)filt * sb.Fmax + f) * 2;
+      double v = 0.0;
+      const int ra = lane % 21, rc = lane / 21;  // lanes 0..41 active: (P J^T)(a, c)
+      if (lane < 42) {
+        const int ia = jcol(a.lay, ft, ra);
+        for (int b = 0; b < 21; ++b) {
+          const int ib = jcol(a.lay, ft, b);
+          v = fma(P[ia + (long)ib * a.ldp], J[rc * 21 + b], v);
+        }
+      }
+      const double j0 = lane < 42 ? J[ra] : 0.0, j1 = lane < 42 ? J[21 + ra] : 0.0;
+      double s00 = (lane < 21) ? j0 * v : 0.0;
+      double s10 = (lane < 21) ? j1 * v : 0.0;
+      double s11 = (lane >= 21 && lane < 42) ? j1 * v : 0.0;
+      s00 = wave_sum(s00) + a.R;
+      s10 = wave_sum(s10);
+      s11 = wave_sum(s11) + a.R;
+      if (lane == 0) sdist[f] = mh_dist_2x2(s00, s10, s11, inn[0], inn[1]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const double th = relax_threshold(sdist, sb.F, a.thresh, a.mult, a.min_inliers, lane);
+      if (lane == 0) sdist[sb.F] = th;
+    }
+    __syncthreads();
+  }
+  const double th = a.use_gating ? sdist[sb.F] : 0.0;
+  for (int f = tid; f < sb.F; f += 256) {
+    const bool in = a.use_gating ? (sdist[f] < th) : true;
+    sb.mask[(long)filt * sb.Fmax + f] = in ? 1 : 0;
+    sb.dist[(long)filt * sb.Fmax + f] = a.use_gating ? sdist[f] : 0.0;
+  }
+}
+
+// Stack H (and H^T), inn, diagR for one filter: rows 2f, 2f+1 belong to feature
+// f; a rejected feature keeps its two rows but they are neutral (H row = 0,
+// inn = 0, diagR = 1), which is algebraically the reference's "row not stacked".
+__global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
+  const int filt = blockIdx.x, tid = threadIdx.x;
+  const SceneBuffers& sb = a.sb;
+  double* H = a.mb.H + (long)filt * a.mb.strideH;
+  double* HT = a.mb.HT + (long)filt * a.mb.strideHT;
+  // H_.setZero(total_size, N) (update.cpp:130)
+  for (int n = 0; n < a.Np; ++n)
+    for (int m = tid; m < a.Mp; m += 256) H[m + (long)n * a.mb.ldh] = 0.0;
+  for (int m = 0; m < a.Mp; ++m)
+    for (int n = tid; n < a.Np; n += 256) HT[n + (long)m * a.mb.ldht] = 0.0;
+  double* inn = a.mb.inn + (long)filt * a.mb.strideInn;
+  double* dR = a.mb.diagR + (long)filt * a.mb.strideR;
+  for (int m = tid; m < a.Mp; m += 256) { inn[m] = 0.0; dR[m] = 1.0; }
+  __syncthreads();
+  for (int f = tid; f < sb.F; f += 256) {
+    if (!sb.mask[(long)filt * sb.Fmax + f]) continue;
+    const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+    const double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
+    const double* fi = sb.finn + ((long)filt * sb.Fmax + f) * 2;
+    for (int b = 0; b < 7; ++b) {
+      // Feature::FillJacobianBlock: the group-rotation block is overwritten by the
+      // group-translation block and goff+3.. stays zero (feature.cpp:675-676)
+      int src = b;
+      if (!a.fix_group_block) {
+        if (b == 4) src = 5;
+        else if (b == 5) continue;
+      }
+      for (int o = 0; o < 3; ++o) {
+        const int col = jcol(a.lay, ft, 3 * b + o);
+        for (int i = 0; i < 2; ++i) {
+          const double v = J[i * 21 + 3 * src + o];
+          H[(2 * f + i) + (long)col * a.mb.ldh] = v;
+          HT[col + (long)(2 * f + i) * a.mb.ldht] = v;
+        }
+      }
+    }
+    inn[2 * f] = fi[0]; inn[2 * f + 1] = fi[1];      // update.cpp:136
+    dR[2 * f] = a.R; dR[2 * f + 1] = a.R;            // update.cpp:137
+  }
+  if (tid == 0 && a.rows_instate) a.rows_instate[filt] = 2 * sb.F;
+}
+
+// ---------------------------------------------------------------- OOS / MSCKF rows
+// One wave64 per (filter, OOS feature). Lane 0 runs Eigen's FullPivLU on the
+// 3 x 2k matrix Hf^T exactly as FullPivLU::computeInPlace / kernel() do
+// (thirdparty/eigen/Eigen/src/LU/FullPivLU.h:490-580, 619-699) so that the
+// null-space basis A - which is NOT orthonormal - matches SlowGivens
+// (helpers.cpp:13-23) and not merely its span; lanes then form A^T Hx, A^T r.
+constexpr int OOS_R = 2 * XIVO_OOS_MAX_OBS;  // max rows 2k
+
+__global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
+  const int filt = blockIdx.y, o = blockIdx.x, lane = threadIdx.x;
+  const xivo_oos_in& ft = a.feats[(long)filt * a.n_oos + o];
+  const xivo_pose_in& pose = a.poses[filt];
+  const int k = ft.n_obs, R2 = 2 * k;
+  __shared__ double sHf[OOS_R][3];
+  __shared__ double sHx[OOS_R][12];   // per row: [Wg(3) Tg(3) Wbc(3) Tbc(3)]
+  __shared__ double sInn[OOS_R];
+  __shared__ double sLU[3][OOS_R];
+  __shared__ double sA[OOS_R][OOS_R]; // kernel basis, 2k x dimker
+  __shared__ int sQ[OOS_R];
+  __shared__ int sRank;
+  __shared__ int sRow0;
+
+  // row offset of this feature = row0 + sum_{o' < o} (2 k_o' - 3)  (rank 3 assumed for the
+  // reservation; rows beyond the actual kernel dimension stay neutral)
+  if (lane == 0) {
+    int r = a.row0;
+    for (int q = 0; q < o; ++q) {
+      const int kq = a.feats[(long)filt * a.n_oos + q].n_obs;
+      r += kq >= 2 ? 2 * kq - 3 : 0;
+    }
+    sRow0 = r;
+    if (o == a.n_oos - 1 && a.rows_out) a.rows_out[filt] = r + (k >= 2 ? 2 * k - 3 : 0) - a.row0;
+  }
+  // per-observation Jacobians (oos.cpp:39-89), one lane per observation
+  if (lane < k) {
+    const xivo_group_in& g = a.groups[(long)filt * a.lay.n_groups + ft.group_sind[lane]];
+    const M3 Rsb = m3_from_colmajor(g.Rsb), Rbc = m3_from_colmajor(pose.Rbc);
+    const M3 Rsb_t = m3_t(Rsb), Rbc_t = m3_t(Rbc);
+    V3 d;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d.v[i] = ft.Xs[i] - g.Tsb[i];
+    const V3 Xb = m3_mulv(Rsb_t, d);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d.v[i] = Xb.v[i] - pose.Tbc[i];
+    const V3 Xcn = m3_mulv(Rbc_t, d);
+    double xp[2], dxp_dXcn[2][3];
+    project_pixel(a.cam, Xcn, xp, dxp_dXcn);
+    double t1[2][3], out[2][3];
+    m23_mul(dxp_dXcn, Rbc_t, t1);                 // dxp_dXcn * dXcn_dXb
+    m23_mul(t1, Rsb_t, out);                      // * dXb_dXs -> Hf        (oos.cpp:74-75)
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) sHf[2 * lane + i][j] = out[i][j];
+    m23_mul(t1, hat(Xb), out);                    // * dXb_dWsb -> goff     (oos.cpp:78-79)
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) sHx[2 * lane + i][j] = out[i][j];
+    m23_mul(t1, m3_neg(Rsb_t), out);              // * dXb_dTsb -> goff + 3 (oos.cpp:80-81)
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) sHx[2 * lane + i][3 + j] = out[i][j];
+    m23_mul(dxp_dXcn, hat(Xcn), out);             // dXcn_dWbc              (oos.cpp:82-83)
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) sHx[2 * lane + i][6 + j] = out[i][j];
+    m23_mul(dxp_dXcn, m3_neg(Rbc_t), out);        // dXcn_dTbc              (oos.cpp:84-85)
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) sHx[2 * lane + i][9 + j] = out[i][j];
+    sInn[2 * lane] = ft.xp[lane][0] - xp[0];      // oos.cpp:72
+    sInn[2 * lane + 1] = ft.xp[lane][1] - xp[1];
+  }
+  __syncthreads();
+
+  // FullPivLU of Hf^T (3 x 2k) by lane 0
+  if (lane == 0) {
+    const int rows = 3, cols = R2, size = rows < cols ? rows : cols;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < cols; ++j) sLU[i][j] = sHf[j][i];
+    int colsT[3] = {0, 1, 2};
+    int nonzero = size;
+    double maxpivot = 0.0;
+    for (int kk = 0; kk < size; ++kk) {
+      // biggest |.| in the bottom-right corner; Eigen's maxCoeff visitor scans
+      // column-major and keeps the FIRST maximum
+      int br = kk, bc = kk; double big = -1.0;
+      for (int j = kk; j < cols; ++j)
+        for (int i = kk; i < rows; ++i) {
+          const double s = fabs(sLU[i][j]);
+          if (s > big) { big = s; br = i; bc = j; }
+        }
+      if (big == 0.0) {
+        nonzero = kk;
+        for (int i = kk; i < size; ++i) colsT[i] = i;
+        break;
+      }
+      if (big > maxpivot) maxpivot = big;
+      colsT[kk] = bc;
+      if (kk != br) for (int j = 0; j < cols; ++j) { const double t = sLU[kk][j]; sLU[kk][j] = sLU[br][j]; sLU[br][j] = t; }
+      if (kk != bc) for (int i = 0; i < rows; ++i) { const double t = sLU[i][kk]; sLU[i][kk] = sLU[i][bc]; sLU[i][bc] = t; }
+      if (kk < rows - 1) for (int i = kk + 1; i < rows; ++i) sLU[i][kk] /= sLU[kk][kk];
+      if (kk < size - 1)
+        for (int i = kk + 1; i < rows; ++i)
+          for (int j = kk + 1; j < cols; ++j) sLU[i][j] -= sLU[i][kk] * sLU[kk][j];
+    }
+    // m_q: identity with transposition (k, colsT[k]) applied on the right, k ascending
+    for (int j = 0; j < cols; ++j) sQ[j] = j;
+    for (int kk = 0; kk < size; ++kk) { const int t = sQ[kk]; sQ[kk] = sQ[colsT[kk]]; sQ[colsT[kk]] = t; }
+    // rank with Eigen's default threshold eps * diagonalSize (FullPivLU.h threshold())
+    const double thr = maxpivot * (2.220446049250313e-16 * size);
+    int piv[3]; int p = 0;
+    for (int i = 0; i < nonzero; ++i) if (fabs(sLU[i][i]) > thr) piv[p++] = i;
+    const int rank = p, dimker = cols - rank;
+    sRank = rank;
+    // trapezoid m (rank x cols), FullPivLU.h:660-672
+    double m[3][OOS_R];
+    for (int i = 0; i < rank; ++i) {
+      for (int j = 0; j < cols; ++j) m[i][j] = (j < i) ? 0.0 : sLU[piv[i]][j];
+    }
+    for (int i = 0; i < rank; ++i) for (int j = 0; j < i; ++j) m[i][j] = 0.0;
+    for (int i = 0; i < rank; ++i)
+      if (piv[i] != i) for (int r = 0; r < rank; ++r) { const double t = m[r][i]; m[r][i] = m[r][piv[i]]; m[r][piv[i]] = t; }
+    // upper-triangular solve m[:, :rank] X = m[:, rank:]
+    for (int c = rank; c < cols; ++c)
+      for (int i = rank - 1; i >= 0; --i) {
+        double s = m[i][c];
+        for (int j = i + 1; j < rank; ++j) s -= m[i][j] * m[j][c];
+        m[i][c] = s / m[i][i];
+      }
+    for (int i = rank - 1; i >= 0; --i)
+      if (piv[i] != i) for (int r = 0; r < rank; ++r) { const double t = m[r][i]; m[r][i] = m[r][piv[i]]; m[r][piv[i]] = t; }
+    for (int i = 0; i < rank; ++i) for (int c = 0; c < dimker; ++c) sA[sQ[i]][c] = -m[i][rank + c];
+    for (int i = rank; i < cols; ++i) for (int c = 0; c < dimker; ++c) sA[sQ[i]][c] = 0.0;
+    for (int c = 0; c < dimker; ++c) sA[sQ[rank + c]][c] = 1.0;
+  }
+  __syncthreads();
+
+  // Hx <- A^T Hx, inn <- A^T inn (helpers.cpp:20, oos.cpp:29); lane r owns output row r
+  const int dimker = R2 - sRank;
+  const int nrows_res = k >= 2 ? 2 * k - 3 : 0;  // rows reserved for this feature
+  if (lane < nrows_res) {
+    const int row = sRow0 + lane;
+    double* H = a.mb.H + (long)filt * a.mb.strideH;
+    double* HT = a.mb.HT + (long)filt * a.mb.strideHT;
+    double* inn = a.mb.inn + (long)filt * a.mb.strideInn;
+    double* dR = a.mb.diagR + (long)filt * a.mb.strideR;
+    if (lane < dimker && row < a.Mp) {
+      double rr = 0.0;
+      for (int j = 0; j < R2; ++j) rr += sA[j][lane] * sInn[j];
+      for (int ob = 0; ob < k; ++ob) {
+        const int goff = a.lay.group_begin + 6 * ft.group_sind[ob];
+        for (int c = 0; c < 12; ++c) {
+          const double v = sA[2 * ob][lane] * sHx[2 * ob][c] + sA[2 * ob + 1][lane] * sHx[2 * ob + 1][c];
+          const int col = c < 6 ? goff + c : (c < 9 ? 15 + (c - 6) : 18 + (c - 9));
+          const double nv = H[row + (long)col * a.mb.ldh] + v;
+          H[row + (long)col * a.mb.ldh] = nv;
+          HT[col + (long)row * a.mb.ldht] = nv;
+        }
+      }
+      inn[row] = rr;
+      dR[row] = a.Roos;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- propagation tail
+// P_mm <- Pmm_new ; P_ms <- Phi P_ms ; P_sm <- P_sm Phi^T (rk4.cpp:92-102). One
+// workgroup per filter, Phi in LDS; thread j owns structure column / row j.
+__global__ __launch_bounds__(256) void propagate_cov_kernel(double* Pall, long strideP, int ldp, int N, int nm,
+                                                            const double* Phi_all, const double* Pmm_all,
+                                                            int b0) {
+  const int filt = b0 + blockIdx.x, tid = threadIdx.x;
+  double* P = Pall + (long)filt * strideP;
+  const double* Phi = Phi_all + (long)blockIdx.x * nm * nm;
+  const double* Pmm = Pmm_all + (long)blockIdx.x * nm * nm;
+  extern __shared__ double sPhi[];  // nm*nm, column-major
+  for (int e = tid; e < nm * nm; e += 256) sPhi[e] = Phi[e];
+  __syncthreads();
+  constexpr int MAXM = 32;
+  for (int j = nm + tid; j < N; j += 256) {
+    double col[MAXM], row[MAXM];
+    for (int k = 0; k < nm; ++k) { col[k] = P[k + (long)j * ldp]; row[k] = P[j + (long)k * ldp]; }
+    for (int i = 0; i < nm; ++i) {
+      double s = 0.0, t = 0.0;
+      for (int k = 0; k < nm; ++k) {
+        s = fma(sPhi[i + k * nm], col[k], s);   // (Phi P_ms)(i, j)
+        t = fma(row[k], sPhi[i + k * nm], t);   // (P_sm Phi^T)(j, i)
+      }
+      P[i + (long)j * ldp] = s;
+      P[j + (long)i * ldp] = t;
+    }
+  }
+  for (int e = tid; e < nm * nm; e += 256) P[(e % nm) + (long)(e / nm) * ldp] = Pmm[e];
+}
+
+// ---------------------------------------------------------------- fp64 MFMA issue-rate probe
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters) {
+  d4 acc[8];
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) sink[0] = s;
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH() return (int)hipGetLastError()
+
+int launch_unpack_P(const double* raw, double* P, int N, int Np, int ldp, long strideP, int batch,
+                    hipStream_t s) {
+  dim3 grid((unsigned)(((long)Np * Np + 255) / 256), batch);
+  hipLaunchKernelGGL(unpack_P_kernel, grid, dim3(256), 0, s, raw, P, N, Np, ldp, strideP);
+  CHECK_LAUNCH();
+}
+int launch_pack_P(const double* P, double* raw, int N, int ldp, long strideP, int batch, hipStream_t s) {
+  dim3 grid((unsigned)(((long)N * N + 255) / 256), batch);
+  hipLaunchKernelGGL(pack_P_kernel, grid, dim3(256), 0, s, P, raw, N, ldp, strideP);
+  CHECK_LAUNCH();
+}
+int launch_unpack_meas(const double* rawH, const double* rawInn, const double* rawR, MeasBuffers mb, int M,
+                       int Mp, int N, int Np, int batch, hipStream_t s) {
+  dim3 grid((unsigned)(((long)Mp * Np + 255) / 256), batch);
+  hipLaunchKernelGGL(unpack_meas_kernel, grid, dim3(256), 0, s, rawH, rawInn, rawR, mb, M, Mp, N, Np);
+  CHECK_LAUNCH();
+}
+int launch_p_zero_rc(double* P, int ldp, int Np, int off, int len, hipStream_t s) {
+  hipLaunchKernelGGL(p_zero_rc_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, P, ldp, Np, off, len);
+  CHECK_LAUNCH();
+}
+int launch_p_copy_rc(double* P, int ldp, int Np, int dst, int src, int len, hipStream_t s) {
+  hipLaunchKernelGGL(p_copy_rc_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, P, ldp, Np, dst, src, len, 0);
+  hipLaunchKernelGGL(p_copy_rc_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, P, ldp, Np, dst, src, len, 1);
+  CHECK_LAUNCH();
+}
+int launch_p_diag(const double* P, int ldp, int N, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(p_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, s, P, ldp, N, out);
+  CHECK_LAUNCH();
+}
+int launch_gate_dense(const GateDenseArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(gate_dense_kernel, dim3(a.batch), dim3(256), (a.F + 1) * sizeof(double), s, a);
+  CHECK_LAUNCH();
+}
+int launch_jac_instate(const SceneBuffers& sb, const xivo_layout& lay, const xivo_cam& cam, int batch,
+                       hipStream_t s) {
+  const int tot = batch * sb.F;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(jac_instate_kernel, dim3((tot + 127) / 128), dim3(128), 0, s, sb, lay, cam, batch);
+  CHECK_LAUNCH();
+}
+int launch_gate_sparse(const GateArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(gate_sparse_kernel, dim3(a.batch), dim3(256), (a.sb.F + 1) * sizeof(double), s, a);
+  CHECK_LAUNCH();
+}
+int launch_stack(const StackArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(stack_kernel, dim3(a.batch), dim3(256), 0, s, a);
+  CHECK_LAUNCH();
+}
+int launch_oos(const OosArgs& a, hipStream_t s) {
+  if (a.n_oos <= 0) return 0;
+  hipLaunchKernelGGL(oos_kernel, dim3(a.n_oos, a.batch), dim3(64), 0, s, a);
+  CHECK_LAUNCH();
+}
+int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm, const double* Phi,
+                         const double* Pmm, int b0, int nb, hipStream_t s) {
+  (void)Np;
+  if (nm > 32) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(propagate_cov_kernel, dim3(nb), dim3(256), nm * nm * sizeof(double), s, P, strideP, ldp, N,
+                     nm, Phi, Pmm, b0);
+  CHECK_LAUNCH();
+}
+int launch_mfma_peak(double* sink, int iters, hipStream_t s) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * 8), dim3(256), 0, s, sink, iters);
+  CHECK_LAUNCH();
+}
+
+}  // namespace xivo_hip

@@ -1,0 +1,337 @@
+"""ctypes binding of include/xivo_hip.h (test / bench plumbing only)."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+OOS_MAX_OBS = 16
+
+FLAG_FIX_GROUP_BLOCK = 1
+FLAG_PROFILE = 2
+FLAG_FULL_PNEW = 4
+CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
+
+
+class XivoHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"xivo_hip status {status}: {msg}")
+        self.status = status
+
+
+class Layout(C.Structure):
+    _fields_ = [("N", C.c_int), ("group_begin", C.c_int), ("n_groups", C.c_int),
+                ("feature_begin", C.c_int), ("n_features", C.c_int)]
+
+
+class Cam(C.Structure):
+    _fields_ = [("model", C.c_int), ("rows", C.c_int), ("cols", C.c_int),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("d", C.c_double * 5)]
+
+
+# numpy dtypes mirroring the C structs (all naturally aligned, no padding surprises:
+# sizes are asserted against ctypes below)
+pose_dtype = np.dtype([("Rsb", "f8", 9), ("Tsb", "f8", 3), ("Rbc", "f8", 9), ("Tbc", "f8", 3)])
+group_dtype = np.dtype([("Rsb", "f8", 9), ("Tsb", "f8", 3)])
+feat_dtype = np.dtype([("x", "f8", 3), ("xp", "f8", 2), ("ref_sind", "i4"), ("sind", "i4")])
+oos_dtype = np.dtype([("Xs", "f8", 3), ("n_obs", "i4"), ("group_sind", "i4", OOS_MAX_OBS),
+                      ("_pad", "i4"), ("xp", "f8", (OOS_MAX_OBS, 2))])
+
+
+class _OosC(C.Structure):
+    _fields_ = [("Xs", C.c_double * 3), ("n_obs", C.c_int), ("group_sind", C.c_int * OOS_MAX_OBS),
+                ("xp", (C.c_double * 2) * OOS_MAX_OBS)]
+
+
+assert oos_dtype.itemsize == C.sizeof(_OosC), (oos_dtype.itemsize, C.sizeof(_OosC))
+assert feat_dtype.itemsize == 48 and pose_dtype.itemsize == 192 and group_dtype.itemsize == 96
+
+
+def lib_path():
+    return os.path.join(_HERE, "libxivo_hip.so")
+
+
+_LIB = None
+
+_SIGS = {
+    "xivo_hip_create": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint],
+    "xivo_hip_sync": [C.c_void_p],
+    "xivo_hip_set_flags": [C.c_void_p, C.c_uint],
+    "xivo_hip_upload_P": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int],
+    "xivo_hip_download_P": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int],
+    "xivo_hip_snapshot_P": [C.c_void_p],
+    "xivo_hip_restore_P": [C.c_void_p],
+    "xivo_hip_p_zero_rc": [C.c_void_p, C.c_int, C.c_int, C.c_int],
+    "xivo_hip_p_copy_rc": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
+    "xivo_hip_p_set_block3": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "xivo_hip_p_diag": [C.c_void_p, C.c_int, C.c_void_p],
+    "xivo_hip_set_measurements": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int,
+                                  C.c_void_p, C.c_long, C.c_void_p, C.c_long],
+    "xivo_hip_update_joseph": [C.c_void_p, C.c_int],
+    "xivo_hip_get_err": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long],
+    "xivo_hip_get_status": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "xivo_hip_mh_gate_dense": [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                               C.c_void_p, C.c_void_p],
+    "xivo_hip_set_layout": [C.c_void_p, C.POINTER(Layout), C.POINTER(Cam)],
+    "xivo_hip_set_scene": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "xivo_hip_jacobians_instate": [C.c_void_p, C.c_int],
+    "xivo_hip_get_jacobians": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "xivo_hip_mh_gate": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p,
+                         C.c_void_p],
+    "xivo_hip_stack": [C.c_void_p, C.c_int, C.c_double],
+    "xivo_hip_oos_project": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p],
+    "xivo_hip_filter_update": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int],
+    "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    "xivo_hip_propagate_cov": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "xivo_hip_timer_begin": [C.c_void_p],
+    "xivo_hip_timer_end": [C.c_void_p, C.POINTER(C.c_float)],
+    "xivo_hip_profile_reset": [C.c_void_p],
+    "xivo_hip_profile_get": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_float),
+                             C.POINTER(C.c_int), C.POINTER(C.c_double)],
+    "xivo_hip_bench_mfma_peak": [C.c_void_p, C.POINTER(C.c_double)],
+}
+# every symbol include/xivo_hip.h declares (tests check the library exports them all)
+ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile"])
+
+
+def load_library():
+    """Load libxivo_hip.so; raises (no fallback) if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP extension is the product; there is no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.xivo_hip_destroy.argtypes = [C.c_void_p]
+    lib.xivo_hip_destroy.restype = None
+    lib.xivo_hip_strerror.argtypes = [C.c_int]
+    lib.xivo_hip_strerror.restype = C.c_char_p
+    lib.xivo_hip_gemm_tile.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.xivo_hip_gemm_tile.restype = None
+    _LIB = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """A batch of `batch` independent filters with state dim N on one GPU.
+
+    Matrices cross this boundary as numpy arrays shaped [batch, cols, rows]
+    C-contiguous == column-major [rows x cols] per filter (Eigen's layout); the
+    helpers below take/return [batch, rows, cols] arrays and do the transposes.
+    """
+
+    def __init__(self, N, M_max, batch, device=0, flags=0):
+        self.lib = load_library()
+        self.N, self.M_max, self.batch = int(N), int(M_max), int(batch)
+        h = C.c_void_p()
+        self._check(self.lib.xivo_hip_create(C.byref(h), device, N, M_max, batch, flags))
+        self.h = h
+        self.flags = flags
+
+    def _check(self, rc):
+        if rc != 0:
+            raise XivoHipError(rc, self.lib.xivo_hip_strerror(rc).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.xivo_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._check(self.lib.xivo_hip_sync(self.h))
+
+    def set_flags(self, flags):
+        self._check(self.lib.xivo_hip_set_flags(self.h, flags))
+        self.flags = flags
+
+    # ---- P ---------------------------------------------------------------
+    def upload_P(self, P, b0=0):
+        P = np.asarray(P, dtype=np.float64)
+        nb = P.shape[0]
+        Pc = _f64(np.transpose(P, (0, 2, 1)))  # column-major per filter
+        self._check(self.lib.xivo_hip_upload_P(self.h, b0, nb, _ptr(Pc), self.N * self.N, self.N))
+
+    def download_P(self, b0=0, nb=None):
+        nb = self.batch - b0 if nb is None else nb
+        out = np.empty((nb, self.N, self.N), dtype=np.float64)
+        self._check(self.lib.xivo_hip_download_P(self.h, b0, nb, _ptr(out), self.N * self.N, self.N))
+        return np.transpose(out, (0, 2, 1)).copy()
+
+    def snapshot_P(self):
+        self._check(self.lib.xivo_hip_snapshot_P(self.h))
+
+    def restore_P(self):
+        self._check(self.lib.xivo_hip_restore_P(self.h))
+
+    def p_zero_rc(self, b, off, length):
+        self._check(self.lib.xivo_hip_p_zero_rc(self.h, b, off, length))
+
+    def p_copy_rc(self, b, dst, src, length):
+        self._check(self.lib.xivo_hip_p_copy_rc(self.h, b, dst, src, length))
+
+    def p_set_block3(self, b, off, P3):
+        P3c = _f64(np.asarray(P3).T)
+        self._check(self.lib.xivo_hip_p_set_block3(self.h, b, off, _ptr(P3c)))
+
+    def p_diag(self, b):
+        out = np.empty(self.N)
+        self._check(self.lib.xivo_hip_p_diag(self.h, b, _ptr(out)))
+        return out
+
+    # ---- S-level ------------------------------------------------------------
+    def set_measurements(self, H, inn, diagR, b0=0):
+        H = np.asarray(H, dtype=np.float64)
+        nb, M, N = H.shape
+        assert N == self.N
+        Hc = _f64(np.transpose(H, (0, 2, 1)))
+        inn = _f64(inn)
+        dR = _f64(diagR)
+        self._check(self.lib.xivo_hip_set_measurements(self.h, b0, nb, M, _ptr(Hc), M * N, M, _ptr(inn), M,
+                                                       _ptr(dR), M))
+
+    def update_joseph(self, B=None):
+        self._check(self.lib.xivo_hip_update_joseph(self.h, self.batch if B is None else B))
+
+    def get_err(self, b0=0, nb=None):
+        nb = self.batch - b0 if nb is None else nb
+        out = np.empty((nb, self.N))
+        self._check(self.lib.xivo_hip_get_err(self.h, b0, nb, _ptr(out), self.N))
+        return out
+
+    def get_status(self, b0=0, nb=None, check=True):
+        nb = self.batch - b0 if nb is None else nb
+        out = np.zeros(nb, dtype=np.int32)
+        rc = self.lib.xivo_hip_get_status(self.h, b0, nb, _ptr(out))
+        if check:
+            self._check(rc)
+        return out
+
+    def mh_gate_dense(self, F, R, thresh, mult, min_inliers, B=None):
+        B = self.batch if B is None else B
+        mask = np.zeros((B, F), dtype=np.uint8)
+        dist = np.zeros((B, F))
+        self._check(self.lib.xivo_hip_mh_gate_dense(self.h, B, F, R, thresh, mult, min_inliers, _ptr(mask),
+                                                    _ptr(dist)))
+        return mask.astype(bool), dist
+
+    # ---- G-level ------------------------------------------------------------
+    def set_layout(self, N, group_begin, n_groups, feature_begin, n_features, cam):
+        lay = Layout(N, group_begin, n_groups, feature_begin, n_features)
+        self.layout = lay
+        c = Cam()
+        c.model, c.rows, c.cols = cam["model"], cam.get("rows", 480), cam.get("cols", 640)
+        c.fx, c.fy, c.cx, c.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+        d = list(cam.get("d", [])) + [0.0] * 5
+        for i in range(5):
+            c.d[i] = d[i]
+        self._check(self.lib.xivo_hip_set_layout(self.h, C.byref(lay), C.byref(c)))
+
+    def set_scene(self, poses, groups, feats, b0=0):
+        poses = np.ascontiguousarray(poses, dtype=pose_dtype)
+        groups = np.ascontiguousarray(groups, dtype=group_dtype)
+        feats = np.ascontiguousarray(feats, dtype=feat_dtype)
+        nb, F = feats.shape
+        self.F = F
+        self._check(self.lib.xivo_hip_set_scene(self.h, b0, nb, F, _ptr(poses), _ptr(groups), _ptr(feats)))
+
+    def jacobians_instate(self, B=None):
+        self._check(self.lib.xivo_hip_jacobians_instate(self.h, self.batch if B is None else B))
+
+    def get_jacobians(self, b0=0, nb=None):
+        nb = self.batch - b0 if nb is None else nb
+        J = np.empty((nb, self.F, 2, 21))
+        inn = np.empty((nb, self.F, 2))
+        self._check(self.lib.xivo_hip_get_jacobians(self.h, b0, nb, _ptr(J), _ptr(inn)))
+        return J, inn
+
+    def mh_gate(self, R, thresh, mult, min_inliers, B=None):
+        B = self.batch if B is None else B
+        mask = np.zeros((B, self.F), dtype=np.uint8)
+        dist = np.zeros((B, self.F))
+        self._check(self.lib.xivo_hip_mh_gate(self.h, B, R, thresh, mult, min_inliers, _ptr(mask), _ptr(dist)))
+        return mask.astype(bool), dist
+
+    def stack(self, R, B=None):
+        self._check(self.lib.xivo_hip_stack(self.h, self.batch if B is None else B, R))
+
+    def oos_project(self, feats, Roos):
+        feats = np.ascontiguousarray(feats, dtype=oos_dtype)
+        nb, n_oos = feats.shape
+        rows = np.zeros(nb, dtype=np.int32)
+        self._check(self.lib.xivo_hip_oos_project(self.h, 0, nb, n_oos, _ptr(feats), Roos, _ptr(rows)))
+        return rows
+
+    def filter_update(self, R, thresh, mult, min_inliers, use_gating=True, B=None):
+        self._check(self.lib.xivo_hip_filter_update(self.h, self.batch if B is None else B, R, thresh, mult,
+                                                    min_inliers, int(use_gating)))
+
+    def get_H(self, b):
+        M = C.c_int()
+        self._check(self.lib.xivo_hip_get_H(self.h, b, C.byref(M), None, 0, None, None))
+        M = M.value
+        H = np.empty((self.N, M))
+        inn = np.empty(M)
+        dR = np.empty(M)
+        self._check(self.lib.xivo_hip_get_H(self.h, b, None, _ptr(H), M, _ptr(inn), _ptr(dR)))
+        return H.T.copy(), inn, dR
+
+    def propagate_cov(self, Phi, Pmm, b0=0):
+        Phi = np.asarray(Phi, dtype=np.float64)
+        nb, nm, _ = Phi.shape
+        Phic = _f64(np.transpose(Phi, (0, 2, 1)))
+        Pmmc = _f64(np.transpose(np.asarray(Pmm, dtype=np.float64), (0, 2, 1)))
+        self._check(self.lib.xivo_hip_propagate_cov(self.h, b0, nb, nm, _ptr(Phic), _ptr(Pmmc)))
+
+    # ---- timing ---------------------------------------------------------------
+    def timer_begin(self):
+        self._check(self.lib.xivo_hip_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._check(self.lib.xivo_hip_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_reset(self):
+        self._check(self.lib.xivo_hip_profile_reset(self.h))
+
+    def profile_get(self):
+        n = C.c_int()
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        launches = (C.c_int * 16)()
+        flops = (C.c_double * 16)()
+        self._check(self.lib.xivo_hip_profile_get(self.h, C.byref(n), names, ms, launches, flops))
+        return {names[i].decode(): {"ms": ms[i], "launches": launches[i], "flops_per_launch": flops[i]}
+                for i in range(n.value)}
+
+    def bench_mfma_peak(self):
+        t = C.c_double()
+        self._check(self.lib.xivo_hip_bench_mfma_peak(self.h, C.byref(t)))
+        return t.value
