@@ -1,0 +1,232 @@
+// oracle/_ref driver - TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Built by oracle/ref/Makefile against the reference's OWN sources where they
+// lie under /root/reference: vendored Eigen 3.3.9 (LDLT, LLT, FullPivLU, dense
+// products), Sophus (SO3::hat/exp), src/helpers.cpp (included verbatim, the way
+// the reference's own unit test does - src/test/unittest_givens.cpp:1 - so the
+// file-static givens() is reachable), common/project.h and the four
+// common/camera_*.h models. The Estimator / Feature member functions themselves
+// cannot be compiled here (their TUs pull OpenCV via common/utils.h:17), so each
+// is re-stated below against the same Eigen types with the reference's exact
+// expression sequence, citing the lines it follows.
+#include "helpers.cpp"  // /root/reference/src/helpers.cpp
+
+#include "Eigen/Cholesky"
+#include "Eigen/LU"
+#include "camera_atan.h"
+#include "camera_equidist.h"
+#include "camera_pinhole.h"
+#include "camera_radtan.h"
+#include "project.h"
+
+using namespace xivo;
+
+namespace {
+using MapMat = Eigen::Map<const MatX>;
+using MapMatW = Eigen::Map<MatX>;
+using MapVec = Eigen::Map<const VecX>;
+using MapVecW = Eigen::Map<VecX>;
+
+struct CamCfg { int model; int rows, cols; double fx, fy, cx, cy; double d[5]; };
+
+Vec2 cam_project(const CamCfg& c, const Vec2& xc, Mat2* jac) {
+  switch (c.model) {
+    case 0: return PinholeCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy).Project(xc, jac);
+    case 1: return ATANCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy, c.d[0]).Project(xc, jac);
+    case 2: return RadialTangentialCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy, c.d[0], c.d[1], c.d[2], c.d[3], c.d[4]).Project(xc, jac);
+    default: return EquidistantCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy, c.d[0], c.d[1], c.d[2], c.d[3]).Project(xc, jac);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+// Estimator::UpdateJosephForm, src/estimator.cpp:1257-1288 (members -> locals)
+void ref_update_joseph(int N, int M, const double* H, const double* P, const double* inn, const double* diagR,
+                       double* err_out, double* P_out) {
+  MatX H_ = MapMat(H, M, N), P_ = MapMat(P, N, N);
+  VecX inn_ = MapVec(inn, M), diagR_ = MapVec(diagR, M), err_ = VecX::Zero(N);
+  MatX S_, K_, I_KH_;
+  S_ = H_ * P_ * H_.transpose();
+  for (int i = 0; i < diagR_.size(); ++i) S_(i, i) += diagR_(i);
+  K_.setZero(err_.size(), H_.rows());
+  K_.transpose() = S_.ldlt().solve(H_ * P_);
+  err_ = K_ * inn_;
+  I_KH_ = K_ * H_;
+  for (int i = 0; i < err_.size(); ++i) I_KH_(i, i) -= 1;
+  P_ = I_KH_ * P_ * I_KH_.transpose();
+  int kr = K_.rows(), kc = K_.cols();
+  for (int i = 0; i < kc; ++i) K_.block(0, i, kr, 1) *= sqrt(diagR_(i));
+  P_.noalias() += K_ * K_.transpose();
+  (MapVecW(err_out, N)) = err_;
+  (MapMatW(P_out, N, N)) = P_;
+}
+
+// Estimator::MHGating distances, src/update.cpp:60-70. J: F blocks of 2 x N col-major
+void ref_mh_distances(int F, int N, const double* J, const double* P, const double* inn, double R, double* dist) {
+  MatX P_ = MapMat(P, N, N);
+  for (int f = 0; f < F; ++f) {
+    Eigen::Matrix<double, 2, Eigen::Dynamic> Jf = Eigen::Map<const Eigen::Matrix<double, 2, Eigen::Dynamic>>(J + (size_t)f * 2 * N, 2, N);
+    Vec2 res(inn[2 * f], inn[2 * f + 1]);
+    Mat2 S = Jf * P_ * Jf.transpose();
+    S(0, 0) += R;
+    S(1, 1) += R;
+    dist[f] = res.dot(S.llt().solve(res));
+  }
+}
+
+// Feature::ComputeJacobian, src/feature.cpp:542-656 (default build). 3x3 inputs col-major.
+// Outputs: J (2 x N col-major), inn (2), cache = [Xc Xs Xcn | dXcn_d{Wsb,Tsb,Wbc,Tbc,Wsbr,Tsbr,Xs}] = 9 + 7*9
+void ref_compute_jacobian(const double* x, const double* xp_meas, const double* Rsbr_, const double* Tsbr_,
+                          const double* Rsb_, const double* Tsb_, const double* Rbc_, const double* Tbc_,
+                          const CamCfg* cam, int N, int group_begin, int feature_begin, int ref_sind, int sind,
+                          double* J_out, double* inn_out, double* cache_out) {
+  Mat3 Rsb = Eigen::Map<const Mat3>(Rsb_), Rbc = Eigen::Map<const Mat3>(Rbc_), Rsbr = Eigen::Map<const Mat3>(Rsbr_);
+  Vec3 Tsb = Eigen::Map<const Vec3>(Tsb_), Tbc = Eigen::Map<const Vec3>(Tbc_), Tsbr = Eigen::Map<const Vec3>(Tsbr_);
+  Vec3 x_ = Eigen::Map<const Vec3>(x);
+  Mat3 Rsb_t = Rsb.transpose(), Rbc_t = Rbc.transpose();
+  Mat3 dXc_dx;
+  Vec3 Xc = unproject_logz(x_, &dXc_dx);
+  Vec3 Xbr = Rbc * Xc + Tbc;
+  Vec3 Xs = Rsbr * Xbr + Tsbr;
+  Vec3 Xb = Rsb_t * (Xs - Tsb);
+  Vec3 Xcn = Rbc_t * (Xb - Tbc);
+  Mat3 dXbr_dXc = Rbc, dXbr_dTbc = Mat3::Identity(), dXbr_dWbc = -Rbc * SO3::hat(Xc);
+  Mat3 dXs_dXbr = Rsbr, dXs_dTsbr = Mat3::Identity(), dXs_dWsbr = -Rsbr * SO3::hat(Xbr);
+  Mat3 dXb_dXs = Rsb_t, dXb_dTsb = -Rsb_t, dXb_dWsb = SO3::hat(Xb);
+  Mat3 dXcn_dXb = Rbc_t;
+  Mat3 dXcn_dTbc = -Rbc_t + dXcn_dXb * dXb_dXs * dXs_dXbr * dXbr_dTbc;
+  Mat3 dXcn_dWbc = SO3::hat(Xcn) + dXcn_dXb * dXb_dXs * dXs_dXbr * dXbr_dWbc;
+  Mat3 dXcn_dTsb = dXcn_dXb * dXb_dTsb;
+  Mat3 dXcn_dWsb = dXcn_dXb * dXb_dWsb;
+  Mat3 dXcn_dTsbr = dXcn_dXb * dXb_dXs * dXs_dTsbr;
+  Mat3 dXcn_dWsbr = dXcn_dXb * dXb_dXs * dXs_dWsbr;
+  Mat3 dXcn_dXs = dXcn_dXb * dXb_dXs;
+  Mat3 dXcn_dx = dXcn_dXs * dXs_dXbr * dXbr_dXc * dXc_dx;
+  Mat23 dxcn_dXcn;
+  Vec2 xcn = project(Xcn, &dxcn_dXcn);
+  Mat2 dxp_dxcn;
+  Vec2 xp = cam_project(*cam, xcn, &dxp_dxcn);
+  Mat23 dxp_dXcn = dxp_dxcn * dxcn_dXcn;
+  Eigen::Matrix<double, 2, Eigen::Dynamic> J = Eigen::Matrix<double, 2, Eigen::Dynamic>::Zero(2, N);
+  J.block<2, 3>(0, 0) = dxp_dXcn * dXcn_dWsb;
+  J.block<2, 3>(0, 3) = dxp_dXcn * dXcn_dTsb;
+  J.block<2, 3>(0, 15) = dxp_dXcn * dXcn_dWbc;
+  J.block<2, 3>(0, 18) = dxp_dXcn * dXcn_dTbc;
+  int goff = group_begin + 6 * ref_sind, foff = feature_begin + 3 * sind;
+  J.block<2, 3>(0, goff) = dxp_dXcn * dXcn_dWsbr;
+  J.block<2, 3>(0, goff + 3) = dxp_dXcn * dXcn_dTsbr;
+  J.block<2, 3>(0, foff) = dxp_dXcn * dXcn_dx;
+  Eigen::Map<Eigen::Matrix<double, 2, Eigen::Dynamic>>(J_out, 2, N) = J;
+  inn_out[0] = xp_meas[0] - xp(0);
+  inn_out[1] = xp_meas[1] - xp(1);
+  if (cache_out) {
+    (Eigen::Map<Vec3>(cache_out + 0)) = Xc; (Eigen::Map<Vec3>(cache_out + 3)) = Xs; (Eigen::Map<Vec3>(cache_out + 6)) = Xcn;
+    const Mat3* ms[7] = {&dXcn_dWsb, &dXcn_dTsb, &dXcn_dWbc, &dXcn_dTbc, &dXcn_dWsbr, &dXcn_dTsbr, &dXcn_dXs};
+    for (int i = 0; i < 7; ++i) Eigen::Map<Mat3>(cache_out + 9 + 9 * i) = *ms[i];
+  }
+}
+
+// Feature::FillJacobianBlock, src/feature.cpp:658-684 on a col-major H (ldh rows)
+void ref_fill_jacobian_block(double* H, int M, int N, int offset, const double* J, int group_begin, int feature_begin,
+                             int ref_sind, int sind) {
+  MapMatW Hm(H, M, N);
+  Eigen::Map<const Eigen::Matrix<double, 2, Eigen::Dynamic>> J_(J, 2, N);
+  Hm.block<2, 3>(offset, 0) = J_.block<2, 3>(0, 0);
+  Hm.block<2, 3>(offset, 3) = J_.block<2, 3>(0, 3);
+  Hm.block<2, 3>(offset, 15) = J_.block<2, 3>(0, 15);
+  Hm.block<2, 3>(offset, 18) = J_.block<2, 3>(0, 18);
+  int goff = group_begin + 6 * ref_sind, foff = feature_begin + 3 * sind;
+  Hm.block<2, 3>(offset, goff) = J_.block<2, 3>(0, goff);
+  Hm.block<2, 3>(offset, goff) = J_.block<2, 3>(0, goff + 3);
+  Hm.block<2, 3>(offset, foff) = J_.block<2, 3>(0, foff);
+}
+
+// Feature::ComputeOOSJacobianInternal, src/oos.cpp:39-89 for one observation.
+void ref_oos_internal(const double* Xs_, const double* Rsb_, const double* Tsb_, const double* Rbc_, const double* Tbc_,
+                      const double* xp_obs, const CamCfg* cam, int N, int group_begin, int g_sind, double* Hf_out /*2x3 col-major*/,
+                      double* Hx_out /*2xN col-major*/, double* inn_out) {
+  Vec3 Xs = Eigen::Map<const Vec3>(Xs_), Tsb = Eigen::Map<const Vec3>(Tsb_), Tbc = Eigen::Map<const Vec3>(Tbc_);
+  Mat3 Rsb = Eigen::Map<const Mat3>(Rsb_), Rbc = Eigen::Map<const Mat3>(Rbc_);
+  int goff = group_begin + 6 * g_sind;
+  Mat3 Rsb_t = Rsb.transpose(), Rbc_t = Rbc.transpose();
+  Vec3 Xb = Rsb_t * (Xs - Tsb);
+  Mat3 dXb_dXs = Rsb_t, dXb_dTsb = -Rsb_t, dXb_dWsb = SO3::hat(Xb);
+  Vec3 Xcn = Rbc_t * (Xb - Tbc);
+  Mat3 dXcn_dXb = Rbc_t, dXcn_dWbc = SO3::hat(Xcn), dXcn_dTbc = -Rbc_t;
+  Mat23 dxcn_dXcn;
+  Vec2 xcn = project(Xcn, &dxcn_dXcn);
+  Mat2 dxp_dxcn;
+  Vec2 xp = cam_project(*cam, xcn, &dxp_dxcn);
+  Mat23 dxp_dXcn = dxp_dxcn * dxcn_dXcn;
+  inn_out[0] = xp_obs[0] - xp(0);
+  inn_out[1] = xp_obs[1] - xp(1);
+  (Eigen::Map<Mat23>(Hf_out)) = dxp_dXcn * dXcn_dXb * dXb_dXs;
+  Eigen::Matrix<double, 2, Eigen::Dynamic> Hx = Eigen::Matrix<double, 2, Eigen::Dynamic>::Zero(2, N);
+  Hx.block<2, 3>(0, goff) = dxp_dXcn * dXcn_dXb * dXb_dWsb;
+  Hx.block<2, 3>(0, goff + 3) = dxp_dXcn * dXcn_dXb * dXb_dTsb;
+  Hx.block<2, 3>(0, 15) = dxp_dXcn * dXcn_dWbc;
+  Hx.block<2, 3>(0, 18) = dxp_dXcn * dXcn_dTbc;
+  Eigen::Map<Eigen::Matrix<double, 2, Eigen::Dynamic>>(Hx_out, 2, N) = Hx;
+}
+
+// xivo::SlowGivens (the real one, src/helpers.cpp:13-23) + inn <- A^T inn (src/oos.cpp:29).
+// Hf: R x 3, Hx: R x N, inn: R (col-major). Returns rows of the projected system.
+int ref_slow_givens(int R, int N, const double* Hf, const double* Hx, const double* inn, double* Hx_out, double* inn_out,
+                    double* A_out, int* A_cols) {
+  MatX Hf_ = MapMat(Hf, R, 3), Hx_ = MapMat(Hx, R, N), A;
+  VecX inn_ = MapVec(inn, R);
+  int rows = SlowGivens(Hf_, Hx_, A);
+  VecX r = A.transpose() * inn_;
+  (MapMatW(Hx_out, rows, N)) = Hx_;
+  (MapVecW(inn_out, rows)) = r;
+  if (A_out) MapMatW(A_out, A.rows(), A.cols()) = A;
+  if (A_cols) *A_cols = (int)A.cols();
+  return rows;
+}
+
+// file-static xivo::givens (src/helpers.cpp:27-46); G col-major 2x2
+void ref_givens(double a, double b, double* G) { (Eigen::Map<Mat2>(G)) = givens(a, b); }
+
+// xivo::Givens (the real one, src/helpers.cpp:48-75)
+int ref_Givens(int R, int N, double* x, double* Hx, double* Hf, int effective_rows) {
+  VecX x_ = MapVec(x, R);
+  MatX Hx_ = MapMat(Hx, R, N), Hf_ = MapMat(Hf, R, 3);
+  int rows = Givens(x_, Hx_, Hf_, effective_rows);
+  (MapVecW(x, R)) = x_; (MapMatW(Hx, R, N)) = Hx_; (MapMatW(Hf, R, 3)) = Hf_;
+  return rows;
+}
+
+// Eigen::FullPivLU<MatX>(A).kernel() for an r x c matrix; returns kernel columns
+int ref_fullpivlu_kernel(int r, int c, const double* A, double* ker_out, int* rank_out) {
+  MatX A_ = MapMat(A, r, c);
+  Eigen::FullPivLU<MatX> lu(A_);
+  MatX k = lu.kernel();
+  (MapMatW(ker_out, k.rows(), k.cols())) = k;
+  if (rank_out) *rank_out = (int)lu.rank();
+  return (int)k.cols();
+}
+
+// camera Project through the reference's own model classes
+void ref_camera_project(const CamCfg* cam, const double* xc, double* xp, double* jac /*2x2 col-major*/) {
+  Mat2 J = Mat2::Zero();
+  Vec2 p = cam_project(*cam, Vec2(xc[0], xc[1]), &J);
+  xp[0] = p(0); xp[1] = p(1);
+  (Eigen::Map<Mat2>(jac)) = J;
+}
+
+// covariance tail of RK4Step, src/rk4.cpp:89-102 (+ Qmodel, src/estimator.cpp:590)
+void ref_rk4_cov_tail(int N, int nm, double* P, const double* FK, const double* PK, double dt, const double* Qmodel) {
+  MapMatW P_(P, N, N);
+  MatX F_ = MatX::Identity(nm, nm);
+  F_ = F_ + MapMat(FK, nm, nm) * dt;
+  P_.block(0, 0, nm, nm) = P_.block(0, 0, nm, nm) + MapMat(PK, nm, nm) * dt;
+  P_.block(0, nm, nm, N - nm) = F_ * P_.block(0, nm, nm, N - nm);
+  P_.block(nm, 0, N - nm, nm) = P_.block(nm, 0, N - nm, nm) * F_.transpose();
+  if (Qmodel) P_.block(0, 0, nm, nm).noalias() += MapMat(Qmodel, nm, nm);
+}
+
+// Sophus::SO3::exp
+void ref_so3_exp(const double* w, double* R) { (Eigen::Map<Mat3>(R)) = SO3::exp(Eigen::Map<const Vec3>(w)).matrix(); }
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+"""ctypes loader of oracle/_ref/libxivo_ref_*.so (TEST INFRASTRUCTURE ONLY).
+
+The library is the reference's own arithmetic (Eigen 3.3.9 / Sophus / helpers.cpp /
+camera headers compiled from /root/reference where they lie, see oracle/ref/). It is
+built in the authoring container and travels prebuilt to the GPU box; load() returns
+None-raising errors if it is absent so callers can skip."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class CamCfg(C.Structure):
+    _fields_ = [("model", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("fx", C.c_double), ("fy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("d", C.c_double * 5)]
+
+
+def _cam(cam):
+    c = CamCfg()
+    c.model, c.rows, c.cols = cam["model"], cam.get("rows", 480), cam.get("cols", 640)
+    c.fx, c.fy, c.cx, c.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    d = list(cam.get("d", [])) + [0.0] * 5
+    for i in range(5):
+        c.d[i] = d[i]
+    return c
+
+
+def _has_avx512():
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    need = ("avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl")
+    return all(f in flags for f in need)
+
+
+def _F(a):  # column-major copy
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Ref:
+    def __init__(self, path):
+        self.path = path
+        self.lib = C.CDLL(path)
+        self.lib.ref_slow_givens.restype = C.c_int
+        self.lib.ref_Givens.restype = C.c_int
+        self.lib.ref_fullpivlu_kernel.restype = C.c_int
+
+    def update_joseph(self, H, P, inn, diagR):
+        M, N = H.shape
+        Hf, Pf = _F(H), _F(P)
+        err = np.empty(N); Pout = np.empty((N, N), order="F")
+        self.lib.ref_update_joseph(C.c_int(N), C.c_int(M), _p(Hf), _p(Pf), _p(np.ascontiguousarray(inn, dtype=np.float64)),
+                                   _p(np.ascontiguousarray(diagR, dtype=np.float64)), _p(err), _p(Pout))
+        return err, np.ascontiguousarray(Pout)
+
+    def mh_distances(self, J, P, inn, R):
+        F, _, N = J.shape
+        Jc = np.ascontiguousarray(np.transpose(J, (0, 2, 1)), dtype=np.float64)  # each 2 x N col-major
+        d = np.empty(F)
+        self.lib.ref_mh_distances(C.c_int(F), C.c_int(N), _p(Jc), _p(_F(P)), _p(np.ascontiguousarray(inn, dtype=np.float64)),
+                                  C.c_double(R), _p(d))
+        return d
+
+    def compute_jacobian(self, x, xp_meas, Rsbr, Tsbr, Rsb, Tsb, Rbc, Tbc, cam, layout, ref_sind, sind):
+        N = layout.N
+        J = np.empty((2, N), order="F"); inn = np.empty(2); cache = np.empty(9 + 63)
+        c = _cam(cam)
+        v = lambda a: _p(np.ascontiguousarray(a, dtype=np.float64))
+        Rs = [_F(Rsbr), _F(Rsb), _F(Rbc)]
+        self.lib.ref_compute_jacobian(v(x), v(xp_meas), _p(Rs[0]), v(Tsbr), _p(Rs[1]), v(Tsb), _p(Rs[2]), v(Tbc),
+                                      C.byref(c), C.c_int(N), C.c_int(layout.group_begin), C.c_int(layout.feature_begin),
+                                      C.c_int(ref_sind), C.c_int(sind), _p(J), _p(inn), _p(cache))
+        names = ["dXcn_dWsb", "dXcn_dTsb", "dXcn_dWbc", "dXcn_dTbc", "dXcn_dWsbr", "dXcn_dTsbr", "dXcn_dXs"]
+        cd = dict(Xc=cache[0:3].copy(), Xs=cache[3:6].copy(), Xcn=cache[6:9].copy())
+        for i, n in enumerate(names):
+            cd[n] = cache[9 + 9 * i:18 + 9 * i].reshape(3, 3).T.copy()
+        return np.ascontiguousarray(J), inn, cd
+
+    def fill_jacobian_block(self, H, row, J, layout, ref_sind, sind):
+        M, N = H.shape
+        Hf = _F(H)
+        self.lib.ref_fill_jacobian_block(_p(Hf), C.c_int(M), C.c_int(N), C.c_int(row), _p(_F(J)),
+                                         C.c_int(layout.group_begin), C.c_int(layout.feature_begin),
+                                         C.c_int(ref_sind), C.c_int(sind))
+        H[...] = Hf
+
+    def oos_internal(self, Xs, Rsb, Tsb, Rbc, Tbc, xp_obs, cam, layout, g_sind):
+        N = layout.N
+        Hf = np.empty((2, 3), order="F"); Hx = np.empty((2, N), order="F"); inn = np.empty(2)
+        c = _cam(cam)
+        v = lambda a: _p(np.ascontiguousarray(a, dtype=np.float64))
+        R1, R2 = _F(Rsb), _F(Rbc)
+        self.lib.ref_oos_internal(v(Xs), _p(R1), v(Tsb), _p(R2), v(Tbc), v(xp_obs), C.byref(c), C.c_int(N),
+                                  C.c_int(layout.group_begin), C.c_int(g_sind), _p(Hf), _p(Hx), _p(inn))
+        return np.ascontiguousarray(Hf), np.ascontiguousarray(Hx), inn
+
+    def slow_givens(self, Hf, Hx, inn):
+        R, N = Hx.shape
+        Hxo = np.empty((R, N), order="F"); ro = np.empty(R); A = np.empty((R, R), order="F"); ac = C.c_int()
+        rows = self.lib.ref_slow_givens(C.c_int(R), C.c_int(N), _p(_F(Hf)), _p(_F(Hx)),
+                                        _p(np.ascontiguousarray(inn, dtype=np.float64)), _p(Hxo), _p(ro), _p(A), C.byref(ac))
+        Hxo = np.ndarray((rows, N), dtype=np.float64, buffer=Hxo.data, order="F").copy()
+        A = np.ndarray((R, ac.value), dtype=np.float64, buffer=A.data, order="F").copy()
+        return np.ascontiguousarray(Hxo), ro[:rows].copy(), np.ascontiguousarray(A)
+
+    def givens(self, a, b):
+        G = np.empty((2, 2), order="F")
+        self.lib.ref_givens(C.c_double(a), C.c_double(b), _p(G))
+        return np.ascontiguousarray(G)
+
+    def Givens(self, x, Hx, Hf, effective_rows=-1):
+        R, N = Hx.shape
+        xf = np.ascontiguousarray(x, dtype=np.float64).copy(); Hxf = _F(Hx).copy(order="F"); Hff = _F(Hf).copy(order="F")
+        rows = self.lib.ref_Givens(C.c_int(R), C.c_int(N), _p(xf), _p(Hxf), _p(Hff), C.c_int(effective_rows))
+        return rows, xf, np.ascontiguousarray(Hxf), np.ascontiguousarray(Hff)
+
+    def fullpivlu_kernel(self, A):
+        r, c = A.shape
+        ker = np.empty((c, c), order="F"); rank = C.c_int()
+        k = self.lib.ref_fullpivlu_kernel(C.c_int(r), C.c_int(c), _p(_F(A)), _p(ker), C.byref(rank))
+        ker = np.ndarray((c, k), dtype=np.float64, buffer=ker.data, order="F").copy()
+        return np.ascontiguousarray(ker), rank.value
+
+    def camera_project(self, cam, xc):
+        c = _cam(cam)
+        xp = np.empty(2); J = np.empty((2, 2), order="F")
+        self.lib.ref_camera_project(C.byref(c), _p(np.ascontiguousarray(xc, dtype=np.float64)), _p(xp), _p(J))
+        return xp, np.ascontiguousarray(J)
+
+    def rk4_cov_tail(self, P, FK, PK, dt, Qmodel=None):
+        N = P.shape[0]; nm = FK.shape[0]
+        Pf = _F(P).copy(order="F")
+        q = _p(_F(Qmodel)) if Qmodel is not None else None
+        Qf = _F(Qmodel) if Qmodel is not None else None
+        self.lib.ref_rk4_cov_tail(C.c_int(N), C.c_int(nm), _p(Pf), _p(_F(FK)), _p(_F(PK)), C.c_double(dt),
+                                  _p(Qf) if Qf is not None else None)
+        return np.ascontiguousarray(Pf)
+
+    def so3_exp(self, w):
+        R = np.empty((3, 3), order="F")
+        self.lib.ref_so3_exp(_p(np.ascontiguousarray(w, dtype=np.float64)), _p(R))
+        return np.ascontiguousarray(R)
+
+
+_REF = None
+
+
+def load():
+    """Returns the Ref wrapper; raises FileNotFoundError if oracle/_ref was never built."""
+    global _REF
+    if _REF is not None:
+        return _REF
+    v = "v4" if _has_avx512() else "v3"
+    path = os.path.join(_HERE, "_ref", f"libxivo_ref_{v}.so")
+    if not os.path.exists(path):
+        path = os.path.join(_HERE, "_ref", "libxivo_ref_v3.so")
+    if not os.path.exists(path):
+        raise FileNotFoundError("oracle/_ref not built (needs /root/reference; run oracle/ref/Makefile)")
+    _REF = Ref(path)
+    return _REF

@@ -1,0 +1,210 @@
+"""Pins the numpy oracle (oracle/xivo_oracle.py) BEFORE it is trusted as the checker:
+ 1. the reference's own known-answer test GivensSub (src/test/unittest_givens.cpp:15-37);
+ 2. the reference's finite-difference Jacobian checks, re-run on the restatement
+    (src/test/unittest_jacobians_instate.cpp:28-29 tol 9e-4, ..._oos.cpp tol 1e-5);
+ 3. committed golden vectors generated from oracle/_ref - the reference's own Eigen /
+    Sophus / helpers.cpp / camera arithmetic (tests/golden/make_golden.py);
+ 4. live comparison against oracle/_ref when the prebuilt library is present."""
+import os
+
+import numpy as np
+import pytest
+
+import xivo_oracle as orc
+from xivo_amd import synth
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+CAMS = {"pinhole": synth.PINHOLE, "equi": synth.EQUI, "radtan": synth.RADTAN, "atan": synth.ATAN}
+
+
+def lay_from(a):
+    N, gb, ng, fb, nf = [int(v) for v in a]
+    lay = orc.Layout(ng, nf, N=N, group_begin=gb)
+    assert lay.feature_begin == fb
+    return lay
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - b) / max(np.linalg.norm(b), 1e-300)
+
+
+# ---- 1. reference KAT -------------------------------------------------------------
+def test_givens_sub_kat():
+    tol = 5e-4
+    v1 = np.array([0.9134, 0.6324]); G1 = orc.givens(*v1); y1 = G1.T @ v1
+    assert abs(abs(y1[0]) - 1.1110) < tol and abs(y1[1]) < tol
+    assert abs(abs(G1[0, 0]) - 0.8222) < tol and abs(abs(G1[0, 1]) - 0.5692) < tol
+    assert abs(abs(G1[1, 0]) - 0.5692) < tol and abs(abs(G1[1, 1]) - 0.8222) < tol
+    v2 = np.array([0.1270, 1.1109]); G2 = orc.givens(*v2); y2 = G2.T @ v2
+    assert abs(abs(y2[0]) - 1.1181) < tol and abs(y2[1]) < tol
+    assert abs(abs(G2[0, 0]) - 0.1136) < tol and abs(abs(G2[0, 1]) - 0.9935) < tol
+
+
+# ---- 2. finite-difference checks of the Jacobian chain ------------------------------
+def _scene(seed=0, cam=synth.PINHOLE):
+    sc = synth.g_level(3, 4, 4, 1, seed=seed, cam=cam)
+    lay = orc.Layout(3, 4)
+    i = 1
+    r = int(sc["ref"][0, i])
+    return dict(x=sc["x"][0, i].copy(), Rsbr=sc["gR"][0, r].copy(), Tsbr=sc["gT"][0, r].copy(), Rsb=sc["Rsb"][0].copy(),
+                Tsb=sc["Tsb"][0].copy(), Rbc=sc["Rbc"][0].copy(), Tbc=sc["Tbc"][0].copy(), lay=lay, ref=r, sind=i)
+
+
+def _xcn(s):
+    _, _, _, c = orc.compute_jacobian(s["x"], [0, 0], s["Rsbr"], s["Tsbr"], s["Rsb"], s["Tsb"], s["Rbc"], s["Tbc"],
+                                      synth.PINHOLE, s["lay"], s["ref"], s["sind"], return_cache=True)
+    return c
+
+
+@pytest.mark.parametrize("which", ["Wsb", "Tsb", "Wbc", "Tbc", "Wsbr", "Tsbr", "x"])
+def test_instate_chain_finite_difference(which):
+    """As unittest_jacobians_instate.cpp: forward differences (delta 1e-6) of Xcn
+    w.r.t. each error-state block vs the analytic cache entry, tol 9e-4."""
+    s = _scene(3)
+    c0 = _xcn(s)
+    ana = c0["dXcn_d" + which]
+    delta = 1e-6
+    num = np.zeros((3, 3))
+    for j in range(3):
+        p = dict(s)
+        d = np.zeros(3); d[j] = delta
+        if which == "Wsb": p["Rsb"] = s["Rsb"] @ orc.so3_exp(d)
+        elif which == "Wbc": p["Rbc"] = s["Rbc"] @ orc.so3_exp(d)
+        elif which == "Wsbr": p["Rsbr"] = s["Rsbr"] @ orc.so3_exp(d)
+        elif which == "Tsb": p["Tsb"] = s["Tsb"] + d
+        elif which == "Tbc": p["Tbc"] = s["Tbc"] + d
+        elif which == "Tsbr": p["Tsbr"] = s["Tsbr"] + d
+        else: p["x"] = s["x"] + d
+        num[:, j] = (_xcn(p)["Xcn"] - c0["Xcn"]) / delta
+    assert np.abs(num - ana).max() < 9e-4
+
+
+def test_oos_chain_finite_difference():
+    """As unittest_jacobians_oos.cpp: d(xp)/d(group pose, Wbc, Tbc, Xs), tol 1e-5 (relative here)."""
+    s = _scene(4)
+    lay = s["lay"]; cam = synth.PINHOLE
+    Xs = _xcn(s)["Xs"]
+    f = lambda Xs_, R, T, Rbc, Tbc: orc.oos_jacobian_internal(Xs_, R, T, Rbc, Tbc, [0, 0], cam, lay, 1)
+    Hf, Hx, inn0 = f(Xs, s["Rsb"], s["Tsb"], s["Rbc"], s["Tbc"])
+    delta = 1e-7
+    goff = lay.group_begin + 6
+    for j in range(3):
+        d = np.zeros(3); d[j] = delta
+        num = -(f(Xs + d, s["Rsb"], s["Tsb"], s["Rbc"], s["Tbc"])[2] - inn0) / delta
+        assert np.abs(num - Hf[:, j]).max() < 1e-5 * max(1, np.abs(Hf).max())
+        num = -(f(Xs, s["Rsb"] @ orc.so3_exp(d), s["Tsb"], s["Rbc"], s["Tbc"])[2] - inn0) / delta
+        assert np.abs(num - Hx[:, goff + j]).max() < 1e-4 * max(1, np.abs(Hx).max())
+        num = -(f(Xs, s["Rsb"], s["Tsb"] + d, s["Rbc"], s["Tbc"])[2] - inn0) / delta
+        assert np.abs(num - Hx[:, goff + 3 + j]).max() < 1e-4 * max(1, np.abs(Hx).max())
+        num = -(f(Xs, s["Rsb"], s["Tsb"], s["Rbc"], s["Tbc"] + d)[2] - inn0) / delta
+        assert np.abs(num - Hx[:, orc.TBC + j]).max() < 1e-4 * max(1, np.abs(Hx).max())
+
+
+# ---- 3. golden vectors from the Eigen-built reference driver -------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_golden_update_joseph(tag):
+    err, Pn, _ = orc.update_joseph(G[f"uj_{tag}_H"], G[f"uj_{tag}_P"], G[f"uj_{tag}_inn"], G[f"uj_{tag}_dR"])
+    assert rel(err, G[f"uj_{tag}_err"]) < 1e-10
+    assert rel(Pn, G[f"uj_{tag}_Pn"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_golden_cameras(name):
+    for i, xc in enumerate(G["cam_xc"]):
+        xp, J = orc.camera_project(CAMS[name], xc)
+        assert rel(xp, G[f"cam_{name}_xp"][i]) < 1e-13
+        assert np.abs(J - G[f"cam_{name}_J"][i]).max() < 1e-10 * max(1.0, np.abs(J).max())
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_golden_jacobian_fill_and_gating(name):
+    lay = lay_from(G["lay"])
+    k = lambda s: G[f"jac_{name}_{s}"]
+    Js, inns = [], []
+    for i in range(10):
+        r, s = int(k("ref")[i]), int(k("sind")[i])
+        J, inn, _ = orc.compute_jacobian(k("x")[i], k("xp")[i], k("gR")[r], k("gT")[r], k("Rsb"), k("Tsb"), k("Rbc"),
+                                         k("Tbc"), CAMS[name], lay, r, s)
+        assert rel(J, k("J")[i]) < 1e-12 and np.abs(inn - k("inn")[i]).max() < 1e-9
+        Js.append(J); inns.append(inn)
+    H, inn, dR = orc.stack_measurements(Js, inns, k("ref"), k("sind"), lay, 2.25)
+    assert rel(H, k("H")) < 1e-12          # includes the FillJacobianBlock quirk (feature.cpp:675-676)
+    goff = lay.group_begin + 6 * int(k("ref")[0])
+    assert np.all(H[0:2, goff + 3:goff + 6] == 0) and np.any(Js[0][:, goff + 3:goff + 6] != 0)
+    d = orc.mh_distances(np.array(Js), k("P"), np.array(inns), 2.25)
+    assert rel(d, k("dist")) < 1e-9
+
+
+def test_golden_oos_and_slow_givens():
+    lay = lay_from(G["oos_lay"])
+    obs = [(c, G["oos_xp"][c]) for c in range(5)]
+    for c in range(5):
+        hf, hx, inn = orc.oos_jacobian_internal(G["oos_Xs"], G["oos_gR"][c], G["oos_gT"][c], G["oos_Rbc"], G["oos_Tbc"],
+                                                G["oos_xp"][c], synth.PINHOLE, lay, c)
+        assert rel(hf, G["oos_Hf"][2 * c:2 * c + 2]) < 1e-12
+        assert rel(hx, G["oos_Hx"][2 * c:2 * c + 2]) < 1e-12
+        assert np.abs(inn - G["oos_r"][2 * c:2 * c + 2]).max() < 1e-9
+    Hxp, rp, A = orc.oos_jacobian(G["oos_Xs"], obs, G["oos_gR"], G["oos_gT"], G["oos_Rbc"], G["oos_Tbc"], synth.PINHOLE, lay)
+    assert A.shape == G["oos_A"].shape == (10, 7)
+    assert rel(A, G["oos_A"]) < 1e-11       # the SAME (non-orthonormal) basis as Eigen's FullPivLU::kernel
+    assert rel(Hxp, G["oos_Hxp"]) < 1e-11 and rel(rp, G["oos_rp"]) < 1e-11
+    assert np.abs(A.T @ G["oos_Hf"]).max() < 1e-9 * np.abs(G["oos_Hf"]).max()
+
+
+@pytest.mark.parametrize("tag", ["full", "def"])
+def test_golden_fullpivlu_kernel(tag):
+    ker, rank = orc.fullpivlu_kernel(G[f"lu_{tag}_A"])
+    assert rank == int(G[f"lu_{tag}_rank"]) and ker.shape == G[f"lu_{tag}_ker"].shape
+    assert np.abs(ker - G[f"lu_{tag}_ker"]).max() < 1e-12
+
+
+def test_golden_givens_elimination():
+    rows, x, Hx, Hf = orc.givens_eliminate(G["giv_x"], G["giv_Hx"], G["giv_Hf"])
+    assert rows == int(G["giv_rows"])
+    assert rel(x, G["giv_xo"]) < 1e-12 and rel(Hx, G["giv_Hxo"]) < 1e-12
+    assert np.abs(Hf - G["giv_Hfo"]).max() < 1e-12   # eliminated block: ~0, compare absolutely
+
+
+def test_golden_propagation_tail_and_so3():
+    Pn, _ = orc.rk4_cov_tail(G["prop_P"], G["prop_FK"], G["prop_PK"], float(G["prop_dt"]), G["prop_Q"])
+    assert rel(Pn, G["prop_Pn"]) < 1e-13
+    for w, R in zip(G["so3_w"], G["so3_R"]):
+        assert np.abs(orc.so3_exp(w) - R).max() < 1e-12
+
+
+# ---- 4. live against oracle/_ref (prebuilt library travels with the repo) ---------------
+def _ref():
+    import ref_binding
+    try:
+        return ref_binding.load()
+    except (FileNotFoundError, OSError):
+        pytest.skip("oracle/_ref not built")
+
+
+@pytest.mark.parametrize("N,F", [(150, 50), (250, 80), (203, 30)])
+def test_live_update_joseph_vs_ref(N, F):
+    ref = _ref()
+    P, H, inn, dR = synth.s_level(N, F, 1, seed=N + F)
+    e1, P1 = ref.update_joseph(H[0], P[0], inn[0], dR[0])
+    e2, P2, _ = orc.update_joseph(H[0], P[0], inn[0], dR[0])
+    assert rel(e2, e1) < 1e-9 and rel(P2, P1) < 1e-11
+
+
+def test_live_fullpivlu_random_shapes():
+    ref = _ref()
+    rng = np.random.default_rng(5)
+    for k in range(2, 9):
+        A = rng.normal(size=(3, 2 * k))
+        k1, r1 = ref.fullpivlu_kernel(A)
+        k2, r2 = orc.fullpivlu_kernel(A)
+        assert r1 == r2 and np.abs(k1 - k2).max() < 1e-11
+
+
+def test_mh_gate_loop_semantics():
+    d = np.array([1.0, 7.0, 3.0, 9.0, 100.0, 6.5])
+    m, rej, th = orc.mh_gate(d, 5.991, 1.1, 2)
+    assert m.tolist() == [True, False, True, False, False, False] and rej == 4 and th == 5.991
+    # needs two relaxations to reach 4 inliers: 5.991 -> 6.59 -> 7.25
+    m, rej, th = orc.mh_gate(d, 5.991, 1.1, 4)
+    assert m.sum() == 4 and rej == 4 + 3 + 2 and abs(th - 5.991 * 1.1 * 1.1) < 1e-12
+    assert orc.mh_gate(d, 5.991, 1.1, 0)[0].sum() == 0   # loop never entered (update.cpp:73)
