@@ -143,13 +143,14 @@ def main():
         lib = load_library()
         import ctypes as C
 
-        def tile_of(r, c):
+        def tile_of(r, c, sym=0):
             bm, bn = C.c_int(), C.c_int()
-            lib.xivo_hip_gemm_tile(r, c, C.byref(bm), C.byref(bn))
+            lib.xivo_hip_gemm_tile(r, c, sym, C.byref(bm), C.byref(bn))
             return f"gemm_nt_f64_kernel<{bm.value // 32},{bn.value // 32}>"
 
         # group stages by the kernel instantiation rocprofv3 would report them under
-        shape = {"gemm_HP": (M, N), "gemm_S": (M, M), "gemm_KH_I": (N, N), "gemm_AP": (N, N), "gemm_Pnew": (N, N)}
+        shape = {"gemm_HP": (M, N, 0), "gemm_S": (M, M, 1), "gemm_KH_I": (N, N, 0), "gemm_AP": (N, N, 0),
+                 "gemm_Pnew": (N, N, 1)}
         groups = {}
         for name, st in prof.items():
             if st["launches"] == 0:

@@ -197,10 +197,12 @@ int xivo_hip_timer_end(xivo_hip_ctx* ctx, float* ms_out);
 int xivo_hip_profile_reset(xivo_hip_ctx* ctx);
 int xivo_hip_profile_get(xivo_hip_ctx* ctx, int* n_stages, const char** names_out,
                          float* ms_out, int* launches_out, double* flops_per_launch_out);
-/* fp64 MFMA issue-rate microbenchmark (TFLOP/s of v_mfma_f64_16x16x4_f64) */
-int xivo_hip_bench_mfma_peak(xivo_hip_ctx* ctx, double* tflops_out);
-/* tile the batched GEMM picks for an (rows x cols) output, for DESIGN.md/tests */
-void xivo_hip_gemm_tile(int rows, int cols, int* bm, int* bn);
+/* fp64 MFMA issue-rate microbenchmark of v_mfma_f64_16x16x4_f64; out4 = {TFLOP/s full chip,
+ * cycles per MFMA (1 wave/SIMD), sustained clock GHz (lower bound), TFLOP/s 1 wave/SIMD} */
+int xivo_hip_bench_mfma_peak(xivo_hip_ctx* ctx, double* out4);
+/* tile the batched GEMM picks for an (rows x cols) output (symmetric = lower
+ * triangle + mirror mode), for DESIGN.md/tests */
+void xivo_hip_gemm_tile(int rows, int cols, int symmetric, int* bm, int* bn);
 
 #ifdef __cplusplus
 }

@@ -24,10 +24,12 @@ def test_strerror_and_tile_query_need_no_gpu(built):
     assert lib.xivo_hip_strerror(0) == b"ok"
     assert b"positive definite" in lib.xivo_hip_strerror(-3)
     bm, bn = ctypes.c_int(), ctypes.c_int()
-    lib.xivo_hip_gemm_tile(250, 250, ctypes.byref(bm), ctypes.byref(bn))
+    lib.xivo_hip_gemm_tile(250, 250, 0, ctypes.byref(bm), ctypes.byref(bn))
     assert (bm.value, bn.value) == (128, 128)
-    lib.xivo_hip_gemm_tile(160, 250, ctypes.byref(bm), ctypes.byref(bn))
+    lib.xivo_hip_gemm_tile(160, 250, 0, ctypes.byref(bm), ctypes.byref(bn))
     assert (bm.value, bn.value) == (160, 128)
+    lib.xivo_hip_gemm_tile(160, 160, 1, ctypes.byref(bm), ctypes.byref(bn))
+    assert (bm.value, bn.value) == (128, 128)
 
 
 def test_no_product_code_touches_the_oracle():

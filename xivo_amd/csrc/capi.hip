@@ -31,7 +31,7 @@ struct xivo_hip_ctx {
   unsigned flags = 0;
   hipStream_t stream = nullptr;
   // per-filter device buffers
-  double *P = nullptr, *Psnap = nullptr, *H = nullptr, *HT = nullptr, *HP = nullptr, *S = nullptr;
+  double *P = nullptr, *Psnap = nullptr, *H = nullptr, *HT = nullptr, *HP = nullptr, *PHT = nullptr, *S = nullptr;
   double *K = nullptr, *A = nullptr, *T = nullptr, *invD = nullptr, *inn = nullptr, *diagR = nullptr;
   double *err = nullptr, *staging = nullptr, *scratch = nullptr;
   int* status = nullptr;
@@ -163,10 +163,18 @@ int d2h_packed(xivo_hip_ctx* c, double* dst, const double* src, int nb, int rows
 
 bool bad_range(xivo_hip_ctx* c, int b0, int nb) { return !c || b0 < 0 || nb < 0 || b0 + nb > c->Bmax; }
 
+struct GemmExtra {
+  int epi = EPI_NONE;
+  const double* diag = nullptr; long sDiag = 0;
+  const double* msub = nullptr; long sMsub = 0; int ldmsub = 0;
+  double* C2 = nullptr; long sC2 = 0; int ldc2 = 0;
+  int lower_only = 0;
+};
+
 int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0, long sA0, int lda0,
          const double* B0, long sB0, int ldb0, int K0, const double* A1, long sA1, int lda1, const double* B1,
-         long sB1, int ldb1, int K1, const double* scale1, long sScale1, double* C, long sC, int ldc, int epi,
-         const double* diag, long sDiag, int lower_only) {
+         long sB1, int ldb1, int K1, const double* scale1, long sScale1, double* C, long sC, int ldc,
+         const GemmExtra& x) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.seg[0] = GemmSeg{A0, B0, nullptr, sA0, sB0, 0, lda0, ldb0, K0};
@@ -176,7 +184,9 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
     g.nseg = 2;
   }
   g.C = C; g.strideC = sC; g.ldc = ldc; g.Mp = rows; g.Np = cols;
-  g.diag = diag; g.strideDiag = sDiag; g.epilogue = epi; g.lower_only = lower_only; g.batch = B;
+  g.C2 = x.C2; g.strideC2 = x.sC2; g.ldc2 = x.ldc2;
+  g.diag = x.diag; g.strideDiag = x.sDiag; g.Msub = x.msub; g.strideMsub = x.sMsub; g.ldmsub = x.ldmsub;
+  g.epilogue = x.epi; g.lower_only = x.lower_only; g.batch = B;
   const double flops = 2.0 * rows * cols * (double)(K0 + (A1 ? K1 : 0)) * B;
   StageTimer st(c, stage, flops);
   return launch_gemm_nt_f64(g, c->stream) == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
@@ -202,7 +212,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
+  void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->oos, c->oos_rows};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -231,7 +241,7 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   int rc = XIVO_HIP_OK;
   auto A = [&](auto** p, size_t n) { if (rc == XIVO_HIP_OK) rc = dev_alloc(p, n); };
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return XIVO_HIP_ERR_HIP; }
-  A(&c->P, B * c->sP); A(&c->H, B * c->sH); A(&c->HT, B * c->sHT); A(&c->HP, B * c->sH);
+  A(&c->P, B * c->sP); A(&c->H, B * c->sH); A(&c->HT, B * c->sHT); A(&c->HP, B * c->sH); A(&c->PHT, B * c->sK);
   A(&c->S, B * c->sS); A(&c->K, B * c->sK); A(&c->A, B * c->sP); A(&c->T, B * c->sP);
   A(&c->invD, B * c->sInvD); A(&c->inn, B * Mp); A(&c->diagR, B * Mp); A(&c->err, B * Np);
   A(&c->status, B); A(&c->scratch, B * Np);
@@ -359,14 +369,19 @@ int xivo_hip_update_joseph(xivo_hip_ctx* c, int B) {
   HIP_TRY(hipSetDevice(c->device));
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
   int rc;
-  // HP = H * P  (estimator.cpp:1259 first product; P symmetric => B operand = P rows)
-  rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-            c->HP, c->sH, ldh, EPI_NONE, nullptr, 0, 0);
-  if (rc) return rc;
-  // S = HP * H^T + diag(R)  (estimator.cpp:1259-1263)
-  rc = gemm(c, ST_S, B, Mp, Mp, c->HP, c->sH, ldh, c->H, c->sH, ldh, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-            c->S, c->sS, lds, EPI_ADD_DIAG, c->diagR, c->Mpmax, 0);
-  if (rc) return rc;
+  const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0;
+  {  // HP = H * P and its transpose PH^T (estimator.cpp:1259 first product; P symmetric => B operand = P rows)
+    GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
+    rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              c->HP, c->sH, ldh, x);
+    if (rc) return rc;
+  }
+  {  // S = HP * H^T + diag(R)  (estimator.cpp:1259-1263); lower triangle + mirror
+    GemmExtra x; x.epi = EPI_ADD_DIAG; x.diag = c->diagR; x.sDiag = c->Mpmax; x.lower_only = full ? 0 : 1;
+    rc = gemm(c, ST_S, B, Mp, Mp, c->HP, c->sH, ldh, c->H, c->sH, ldh, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              c->S, c->sS, lds, x);
+    if (rc) return rc;
+  }
   {  // S = L L^T
     CholArgs a; a.S = c->S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = c->invD; a.strideInvD = c->sInvD;
     a.status = c->status; a.batch = B;
@@ -375,22 +390,29 @@ int xivo_hip_update_joseph(xivo_hip_ctx* c, int B) {
   }
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
     TrsmArgs a; a.LU = c->S; a.strideLU = c->sS; a.ldlu = lds; a.invD = c->invD; a.strideInvD = c->sInvD;
-    a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh; a.K = c->K; a.strideK = c->sK; a.ldk = Np;
+    a.PHT = c->PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = c->K; a.strideK = c->sK; a.ldk = Np;
     a.inn = c->inn; a.strideInn = c->Mpmax; a.err = c->err; a.strideErr = Np; a.Mp = Mp; a.Np = Np; a.batch = B;
     StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B);
     if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
-  // A = K * H - I  (estimator.cpp:1276-1279)
-  rc = gemm(c, ST_KH, B, Np, Np, c->K, c->sK, Np, c->HT, c->sHT, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-            c->A, c->sP, Np, EPI_SUB_IDENT, nullptr, 0, 0);
-  if (rc) return rc;
-  // T = A * P  (estimator.cpp:1280, left product)
-  rc = gemm(c, ST_AP, B, Np, Np, c->A, c->sP, Np, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-            c->T, c->sP, Np, EPI_NONE, nullptr, 0, 0);
-  if (rc) return rc;
-  // P = T * A^T + K diag(R) K^T  (estimator.cpp:1280-1287, fused)
-  rc = gemm(c, ST_PNEW, B, Np, Np, c->T, c->sP, Np, c->A, c->sP, Np, Np, c->K, c->sK, Np, c->K, c->sK, Np, Mp, c->diagR,
-            c->Mpmax, c->P, c->sP, Np, EPI_NONE, nullptr, 0, (c->flags & XIVO_HIP_FLAG_FULL_PNEW) ? 0 : 1);
+  {  // A = K * H - I  (estimator.cpp:1276-1279)
+    GemmExtra x; x.epi = EPI_SUB_IDENT;
+    rc = gemm(c, ST_KH, B, Np, Np, c->K, c->sK, Np, c->HT, c->sHT, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              c->A, c->sP, Np, x);
+    if (rc) return rc;
+  }
+  {  // T = A * P = K * (HP) - P  (estimator.cpp:1280, left product; distributes over the already
+     // formed HP, 2MN^2 instead of 2N^3 flops, same value up to rounding)
+    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = c->P; x.sMsub = c->sP; x.ldmsub = Np;
+    rc = gemm(c, ST_AP, B, Np, Np, c->K, c->sK, Np, c->PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              c->T, c->sP, Np, x);
+    if (rc) return rc;
+  }
+  {  // P = T * A^T + K diag(R) K^T  (estimator.cpp:1280-1287, fused; lower triangle + mirror)
+    GemmExtra x; x.lower_only = full ? 0 : 1;
+    rc = gemm(c, ST_PNEW, B, Np, Np, c->T, c->sP, Np, c->A, c->sP, Np, Np, c->K, c->sK, Np, c->K, c->sK, Np, Mp, c->diagR,
+              c->Mpmax, c->P, c->sP, Np, x);
+  }
   return rc;
 }
 
@@ -437,7 +459,7 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
   if (rc) return rc;
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
   rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-            c->HP, c->sH, ldh, EPI_NONE, nullptr, 0, 0);
+            c->HP, c->sH, ldh, GemmExtra());
   if (rc) return rc;
   GateDenseArgs a;
   a.H = c->H; a.strideH = c->sH; a.ldh = ldh; a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh;
@@ -667,24 +689,39 @@ int xivo_hip_profile_get(xivo_hip_ctx* c, int* n, const char** names, float* ms,
   return XIVO_HIP_OK;
 }
 
-int xivo_hip_bench_mfma_peak(xivo_hip_ctx* c, double* tflops) {
-  if (!c || !tflops) return XIVO_HIP_ERR_INVALID;
+int xivo_hip_bench_mfma_peak(xivo_hip_ctx* c, double* out4) {
+  // out4[0] = TFLOP/s with the chip full (8 workgroups / CU)
+  // out4[1] = shader cycles per MFMA per SIMD, one wave per SIMD (256 workgroups)
+  // out4[2] = sustained shader clock (GHz) during the full-chip run
+  // out4[3] = TFLOP/s with one wave per SIMD
+  if (!c || !out4) return XIVO_HIP_ERR_INVALID;
   const int iters = 2000;
-  if (launch_mfma_peak(c->scratch, 10, c->stream)) return XIVO_HIP_ERR_HIP;
-  HIP_TRY(hipEventRecord(c->t0, c->stream));
-  if (launch_mfma_peak(c->scratch, iters, c->stream)) return XIVO_HIP_ERR_HIP;
-  HIP_TRY(hipEventRecord(c->t1, c->stream));
-  HIP_TRY(hipEventSynchronize(c->t1));
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, c->t0, c->t1));
-  const double flops = 2.0 * 16 * 16 * 4 * 8.0 * iters * 4.0 /*waves*/ * 256 * 8 /*blocks*/;
-  *tflops = flops / (ms * 1e-3) / 1e12;
+  double res[2][2];
+  for (int mode = 0; mode < 2; ++mode) {
+    const int blocks = mode == 0 ? 256 * 8 : 256;
+    if (launch_mfma_peak(c->scratch, 10, blocks, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY(hipEventRecord(c->t0, c->stream));
+    if (launch_mfma_peak(c->scratch, iters, blocks, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY(hipEventRecord(c->t1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->t1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->t0, c->t1));
+    double cyc = 0.0;
+    HIP_TRY(hipMemcpy(&cyc, c->scratch + 1, sizeof(double), hipMemcpyDeviceToHost));
+    const double flops = 2.0 * 16 * 16 * 4 * 8.0 * iters * 4.0 /*waves*/ * blocks;
+    res[mode][0] = flops / (ms * 1e-3) / 1e12;
+    res[mode][1] = cyc;
+    if (mode == 0) out4[2] = cyc / (ms * 1e-3) / 1e9;  // cycles of one resident wave / wall time (lower bound)
+  }
+  out4[0] = res[0][0];
+  out4[3] = res[1][0];
+  out4[1] = res[1][1] / (8.0 * iters);
   return XIVO_HIP_OK;
 }
 
-void xivo_hip_gemm_tile(int rows, int cols, int* bm, int* bn) {
+void xivo_hip_gemm_tile(int rows, int cols, int symmetric, int* bm, int* bn) {
   int wm, wn;
-  gemm_pick_tile(round_up16(rows), round_up16(cols), &wm, &wn);
+  gemm_pick_tile(round_up16(rows), round_up16(cols), symmetric, &wm, &wn);
   if (bm) *bm = 32 * wm;
   if (bn) *bn = 32 * wn;
 }

@@ -5,10 +5,12 @@
 // pivoted LDL^T; S = HPH^T + R is SPD, so an un-pivoted blocked Cholesky is the
 // same linear map up to rounding (tests assert 1e-8 on dx, 1e-6 on P).
 //
-// chol_f64_kernel : one 256-thread workgroup per filter, left-looking, 16x16
-//   blocks (the v_mfma_f64_16x16x4_f64 tile). The diagonal block is factored in
-//   registers by one wave (row per lane, v_readlane broadcasts); its explicit
-//   inverse is kept so every panel / triangular-solve step is an MFMA.
+// chol_f64_kernel : one wave64 per filter, left-looking, 16x16 blocks (the
+//   v_mfma_f64_16x16x4_f64 tile). The diagonal block is factored in registers
+//   (row per lane, v_readlane broadcasts); its explicit inverse is kept so every
+//   panel / triangular-solve step is an MFMA. The factorisation is latency
+//   bound, so throughput comes from many filters resident per CU, not from
+//   widening one filter.
 //   Output: L in the lower triangle, L^T mirrored into the upper triangle (so
 //   the backward solve also reads its A operand with the lane index contiguous).
 // trsm_f64_kernel : each wave64 owns 16 right-hand-side columns and keeps the
@@ -33,47 +35,46 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void chol_f64_kernel(CholArgs g) {
+// One wave64 per filter (no cross-wave barriers; many filters resident per CU so
+// the serial 16x16 diagonal factorisations of different filters overlap).
+__global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
   const int filt = blockIdx.x;
   if (filt >= g.batch) return;
-  double* __restrict__ S = g.S + (long)filt * g.strideS;
+  double* S = g.S + (long)filt * g.strideS;
   double* invD = g.invD + (long)filt * g.strideInvD;
   const long ld = g.lds;
   const int nb = g.Mp / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x;
   const int li = lane & 15, lg = lane >> 4;
 
-  __shared__ double sP[4][16 * 17];
+  __shared__ double sP[16 * 17];
   __shared__ double sInv[2][256];
-  __shared__ int sStatus;
-  if (tid == 0) sStatus = 0;
+  int bad = 0;
 
   for (int j = 0; j < nb; ++j) {
-    // ---- 1. partial sums of the diagonal block: sum_{k<j} L_jk L_jk^T, k split over waves
+    // ---- 1. diagonal block update: sum_{k<j} L_jk L_jk^T (two accumulators for ILP)
     {
-      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-      for (int k = wave; k < j; k += 4) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double a = S[(16 * j + li) + (long)(16 * k + 4 * s + lg) * ld];
-          acc = mfma(a, a, acc);
-        }
+      d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+      for (int k = 0; k < j; ++k) {
+        const double a0 = S[(16 * j + li) + (long)(16 * k + 0 + lg) * ld];
+        const double a1 = S[(16 * j + li) + (long)(16 * k + 4 + lg) * ld];
+        const double a2 = S[(16 * j + li) + (long)(16 * k + 8 + lg) * ld];
+        const double a3 = S[(16 * j + li) + (long)(16 * k + 12 + lg) * ld];
+        acc0 = mfma(a0, a0, acc0);
+        acc1 = mfma(a1, a1, acc1);
+        acc0 = mfma(a2, a2, acc0);
+        acc1 = mfma(a3, a3, acc1);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sP[wave][li * 17 + lg + 4 * r] = acc[r];
+      for (int r = 0; r < 4; ++r) sP[li * 17 + lg + 4 * r] = acc0[r] + acc1[r];
     }
     __syncthreads();
 
-    // ---- 2. wave 0: factor the 16x16 diagonal block in registers, invert it
-    if (wave == 0) {
+    // ---- 2. factor the 16x16 diagonal block in registers (row li per lane), invert it
+    {
       double x[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        double v = S[(16 * j + li) + (long)(16 * j + c) * ld];
-        v -= sP[0][li * 17 + c] + sP[1][li * 17 + c] + sP[2][li * 17 + c] + sP[3][li * 17 + c];
-        x[c] = v;
-      }
-      int bad = 0;
+      for (int c = 0; c < 16; ++c) x[c] = S[(16 * j + li) + (long)(16 * j + c) * ld] - sP[li * 17 + c];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         double dcc = readlane_d(x[c], c);
@@ -90,7 +91,6 @@ __global__ __launch_bounds__(256) void chol_f64_kernel(CholArgs g) {
           x[q] = fma(-x[c], lqc, x[q]);
         }
       }
-      if (bad && lane == 0 && sStatus == 0) sStatus = bad;
       // inverse: lane jj solves L y = e_jj
       double y[16];
 #pragma unroll
@@ -117,40 +117,54 @@ __global__ __launch_bounds__(256) void chol_f64_kernel(CholArgs g) {
       }
     }
     __syncthreads();
-    // publish inverse blocks (coalesced)
-    for (int e = tid; e < 512; e += 256) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
+    for (int e = lane; e < 512; e += 64) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
 
-    // ---- 3. panel: L_ij^T = inv(L_jj) * (S_ij^T - sum_k L_jk L_ik^T), i > j
-    for (int i = j + 1 + wave; i < nb; i += 4) {
-      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    // ---- 3. panel: L_ij^T = inv(L_jj) * (S_ij^T - sum_k L_jk L_ik^T), i > j; two rows in flight
+    for (int i = j + 1; i < nb; i += 2) {
+      const bool two = (i + 1 < nb);
+      const int i2 = two ? i + 1 : i;
+      d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
       for (int k = 0; k < j; ++k) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const long col = (long)(16 * k + 4 * s + lg) * ld;
           const double a = S[(16 * j + li) + col];
-          const double b = S[(16 * i + li) + col];
-          acc = mfma(a, b, acc);
+          const double b1 = S[(16 * i + li) + col];
+          const double b2 = S[(16 * i2 + li) + col];
+          accA = mfma(a, b1, accA);
+          accB = mfma(a, b2, accB);
         }
       }
-      d4 rhs;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rhs[r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] - acc[r];
-      d4 out = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) out = mfma(sInv[0][li + (4 * s + lg) * 16], rhs[s], out);
+      d4 rhsA, rhsB;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] = out[r];   // L(i-block, j-block)
-        S[(16 * j + lg + 4 * r) + (long)(16 * i + li) * ld] = out[r];   // L^T mirrored to upper
+        rhsA[r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] - accA[r];
+        rhsB[r] = S[(16 * i2 + li) + (long)(16 * j + lg + 4 * r) * ld] - accB[r];
+      }
+      d4 outA = d4{0.0, 0.0, 0.0, 0.0}, outB = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double iv = sInv[0][li + (4 * s + lg) * 16];
+        outA = mfma(iv, rhsA[s], outA);
+        outB = mfma(iv, rhsB[s], outB);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] = outA[r];   // L(i-block, j-block)
+        S[(16 * j + lg + 4 * r) + (long)(16 * i + li) * ld] = outA[r];   // L^T mirrored to upper
+        if (two) {
+          S[(16 * i2 + li) + (long)(16 * j + lg + 4 * r) * ld] = outB[r];
+          S[(16 * j + lg + 4 * r) + (long)(16 * i2 + li) * ld] = outB[r];
+        }
       }
     }
     __syncthreads();
   }
-  if (tid == 0) g.status[filt] = sStatus;
+  if (lane == 0) g.status[filt] = bad;
 }
 
-template <int NBM>
-__global__ __launch_bounds__(256) void trsm_f64_kernel(TrsmArgs g) {
+template <int NBM, int WPE>
+__global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
   const int chunks = (g.Np + 63) / 64;
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
@@ -165,7 +179,7 @@ __global__ __launch_bounds__(256) void trsm_f64_kernel(TrsmArgs g) {
 
   const double* __restrict__ LU = g.LU + (long)filt * g.strideLU;
   const double* __restrict__ invD = g.invD + (long)filt * g.strideInvD;
-  const double* __restrict__ HP = g.HP + (long)filt * g.strideHP;
+  const double* __restrict__ PHT = g.PHT + (long)filt * g.stridePHT;
   const long ld = g.ldlu;
 
   d4 X[NBM];
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(256) void trsm_f64_kernel(TrsmArgs g) {
     X[i] = d4{0.0, 0.0, 0.0, 0.0};
     if (i < nb) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) X[i][r] = HP[(16 * i + lg + 4 * r) + (long)(c0 + li) * g.ldhp];
+      for (int r = 0; r < 4; ++r) X[i][r] = PHT[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldpht];
     }
   }
 
@@ -241,7 +255,8 @@ template <int NBM>
 int launch_trsm_t(const TrsmArgs& g, hipStream_t stream) {
   const int chunks = (g.Np + 63) / 64;
   const int grid = ((g.batch + 7) / 8) * 8 * chunks;
-  hipLaunchKernelGGL((trsm_f64_kernel<NBM>), dim3(grid), dim3(256), 0, stream, g);
+  constexpr int WPE = NBM <= 6 ? 6 : (NBM <= 10 ? 4 : (NBM <= 14 ? 3 : (NBM <= 20 ? 2 : 1)));
+  hipLaunchKernelGGL((trsm_f64_kernel<NBM, WPE>), dim3(grid), dim3(256), 0, stream, g);
   return (int)hipGetLastError();
 }
 
@@ -249,7 +264,7 @@ int launch_trsm_t(const TrsmArgs& g, hipStream_t stream) {
 
 int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
-  hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(256), 0, stream, g);
+  hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
   return (int)hipGetLastError();
 }
 
@@ -257,10 +272,10 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
   const int nb = g.Mp / 16;
   if (nb <= 4) return launch_trsm_t<4>(g, stream);
-  if (nb <= 8) return launch_trsm_t<8>(g, stream);
-  if (nb <= 12) return launch_trsm_t<12>(g, stream);
-  if (nb <= 16) return launch_trsm_t<16>(g, stream);
-  if (nb <= 20) return launch_trsm_t<20>(g, stream);
+  if (nb <= 7) return launch_trsm_t<7>(g, stream);
+  if (nb <= 10) return launch_trsm_t<10>(g, stream);
+  if (nb <= 14) return launch_trsm_t<14>(g, stream);
+  if (nb <= 19) return launch_trsm_t<19>(g, stream);
   if (nb <= 24) return launch_trsm_t<24>(g, stream);
   return (int)hipErrorInvalidValue;
 }

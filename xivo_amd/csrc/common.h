@@ -33,7 +33,8 @@ enum GemmEpilogue : int {
   EPI_NONE = 0,
   EPI_ADD_DIAG = 1,   // C[i][i] += diag[i]      (S = HPH^T + R, estimator.cpp:1261-1263)
   EPI_SUB_IDENT = 2,  // C[i][i] -= 1            (KH - I,       estimator.cpp:1276-1279)
-  EPI_SUB_C0 = 3,     // C = acc - C0            (unused by default path)
+  EPI_SUB_MAT = 3,    // C = acc - Msub          (T = K(HP) - P,  estimator.cpp:1280)
+  EPI_ADD_MAT = 4,    // C = acc + Msub          (Phi P Phi^T + Q)
 };
 
 struct GemmArgs {
@@ -43,8 +44,14 @@ struct GemmArgs {
   long strideC;
   int ldc;
   int Mp, Np;          // output rows / cols (multiples of 16)
+  double* C2;          // optional second output = C^T (ldc2), e.g. PH^T next to HP
+  long strideC2;
+  int ldc2;
   const double* diag;  // EPI_ADD_DIAG
   long strideDiag;
+  const double* Msub;  // EPI_SUB_MAT / EPI_ADD_MAT operand, same shape as C
+  long strideMsub;
+  int ldmsub;
   int epilogue;
   int lower_only;      // 1: skip tiles strictly above the diagonal and mirror-store
   int batch;
@@ -54,7 +61,7 @@ struct GemmArgs {
 // launches on `stream`; returns hipError_t as int
 int launch_gemm_nt_f64(const GemmArgs& args, hipStream_t stream);
 // tile actually chosen for (Mp, Np) - exposed for tests / DESIGN.md
-void gemm_pick_tile(int Mp, int Np, int* WM, int* WN);
+void gemm_pick_tile(int Mp, int Np, int lower_only, int* WM, int* WN);
 
 // ---------------------------------------------------------------------------
 // Batched Cholesky (one workgroup per filter) + register-resident TRSM.
@@ -77,9 +84,9 @@ struct TrsmArgs {
   int ldlu;
   const double* invD;
   long strideInvD;
-  const double* HP;    // RHS [Mp x Np] col-major
-  long strideHP;
-  int ldhp;
+  const double* PHT;   // RHS transposed: (HP)^T = P H^T, [Np x Mp] col-major
+  long stridePHT;
+  int ldpht;
   double* K;           // out: gain [Np x Mp] col-major (estimator.cpp:1265-1266)
   long strideK;
   int ldk;

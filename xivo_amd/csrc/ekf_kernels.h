@@ -80,6 +80,6 @@ int launch_oos(const OosArgs& a, hipStream_t s);
 int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm, const double* Phi,
                          const double* Pmm, int b0, int nb, hipStream_t s);
 
-int launch_mfma_peak(double* sink, int iters, hipStream_t s);
+int launch_mfma_peak(double* sink, int iters, int blocks, hipStream_t s);
 
 }  // namespace xivo_hip

@@ -634,11 +634,15 @@ __global__ __launch_bounds__(256) void propagate_cov_kernel(double* Pall, long s
 }
 
 // ---------------------------------------------------------------- fp64 MFMA issue-rate probe
+// Every wave issues `iters` x 8 independent v_mfma_f64_16x16x4_f64; wave 0 of
+// block 0 also reports the shader-clock cycles it spent (s_memtime), so the
+// host can separate "cycles per MFMA" from "sustained clock".
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters) {
   d4 acc[8];
   const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  const long long t0 = clock64();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
@@ -646,6 +650,8 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters)
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  const long long t1 = clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) sink[1] = (double)(t1 - t0);
   if (s == 12345.678) sink[0] = s;
 }
 
@@ -715,8 +721,8 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
                      nm, Phi, Pmm, b0);
   CHECK_LAUNCH();
 }
-int launch_mfma_peak(double* sink, int iters, hipStream_t s) {
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * 8), dim3(256), 0, s, sink, iters);
+int launch_mfma_peak(double* sink, int iters, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, sink, iters);
   CHECK_LAUNCH();
 }
 

@@ -113,7 +113,7 @@ def load_library():
     lib.xivo_hip_destroy.restype = None
     lib.xivo_hip_strerror.argtypes = [C.c_int]
     lib.xivo_hip_strerror.restype = C.c_char_p
-    lib.xivo_hip_gemm_tile.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.xivo_hip_gemm_tile.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.xivo_hip_gemm_tile.restype = None
     _LIB = lib
     return lib
@@ -332,6 +332,7 @@ class Context:
                 for i in range(n.value)}
 
     def bench_mfma_peak(self):
-        t = C.c_double()
-        self._check(self.lib.xivo_hip_bench_mfma_peak(self.h, C.byref(t)))
-        return t.value
+        t = (C.c_double * 4)()
+        self._check(self.lib.xivo_hip_bench_mfma_peak(self.h, t))
+        return {"tflops_full_chip": t[0], "cycles_per_mfma_1wave_per_simd": t[1],
+                "clock_ghz_lower_bound_full_chip": t[2], "tflops_1wave_per_simd": t[3]}
