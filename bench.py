@@ -68,11 +68,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="filters per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="filters per GPU")
     ap.add_argument("--state-dim", type=int, default=250)
     ap.add_argument("--features", type=int, default=80)
-    ap.add_argument("--level", choices=["S", "G"], default="S",
-                    help="S: dense H resident (UpdateJosephForm only); G: + Jacobians, gating, stacking")
+    ap.add_argument("--no-gating", action="store_true",
+                    help="time UpdateJosephForm only (default: MH gating + UpdateJosephForm, one 'update' of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -105,8 +105,13 @@ def main():
     ctx.set_measurements(tile(H), tile(inn), tile(dR))
     ctx.snapshot_P()
 
+    R_VIS, MH_THRESH, MH_MULT, MIN_INL = 2.25, 5.991, 1.1, 5   # cfg/tumvi_cam0.json / estimator.cpp:366-369
+
     def step():
-        ctx.update_joseph(B)
+        if args.no_gating:
+            ctx.update_joseph(B)
+        else:
+            ctx.update_dense_gated(F, R_VIS, MH_THRESH, MH_MULT, MIN_INL, B)
 
     def barrier():
         ctx.sync()
@@ -156,6 +161,8 @@ def main():
             if st["launches"] == 0:
                 continue
             kname = tile_of(*shape[name]) if name in shape else name
+            if name == "gemm_S" and M <= 176:
+                kname = "gemm_sym_f64_kernel<8>"   # whole triangle in one workgroup (block-list kernel)
             g = groups.setdefault(kname, {"ms": 0.0, "launches": 0, "flops": 0.0, "stages": []})
             g["ms"] += st["ms"]; g["launches"] += st["launches"]
             g["flops"] += st["flops_per_launch"] * st["launches"]; g["stages"].append(name)
@@ -177,8 +184,8 @@ def main():
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"S-level UpdateJosephForm: state dim {N}, {F} features (M={M}), "
-                                   f"XIVO row sparsity, P/H/inn/R resident in HBM",
+            "config": {"workload": ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
+                                   f": state dim {N}, {F} features (M={M}), XIVO row sparsity, P/H/inn/R resident in HBM",
                        "filters_per_gpu": B, "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
                        "gpu_event_ms_per_step": gpu_ms / args.steps,
                        "not_spd_filters": int((status != 0).sum())},

@@ -49,7 +49,10 @@ enum {
   /* record HIP events around every kernel launch (per-stage timing) */
   XIVO_HIP_FLAG_PROFILE = 2u,
   /* compute every tile of P+ instead of the lower triangle + mirror (A/B knob) */
-  XIVO_HIP_FLAG_FULL_PNEW = 4u
+  XIVO_HIP_FLAG_FULL_PNEW = 4u,
+  /* symmetric products through the rectangular-tile kernel (strip-balanced 128x128
+   * tiles) instead of the block-list kernel (A/B knob) */
+  XIVO_HIP_FLAG_TILE_SYM = 8u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,
@@ -152,6 +155,14 @@ int xivo_hip_get_status(xivo_hip_ctx* ctx, int b0, int nb, int* status);
 int xivo_hip_mh_gate_dense(xivo_hip_ctx* ctx, int B, int F, double R, double mh_thresh,
                            double mh_mult, int min_inliers,
                            unsigned char* inlier_mask_out, double* mh_dist_out);
+
+/* FilterUpdate on dense candidate rows in one pass: HP = H P once, Mahalanobis gating of
+ * features 0..F-1 from (HP)_f H_f^T + R (skipped when F <= min_inliers, src/manager.cpp:635),
+ * rejected rows neutralised, then UpdateJosephForm. xivo_hip_get_gate returns the mask /
+ * distances of that pass ([B x F]). */
+int xivo_hip_update_dense_gated(xivo_hip_ctx* ctx, int B, int F, double R, double mh_thresh,
+                                double mh_mult, int min_inliers);
+int xivo_hip_get_gate(xivo_hip_ctx* ctx, int B, int F, unsigned char* inlier_mask_out, double* mh_dist_out);
 
 /* ---- G-level: features + poses given, Jacobians built on device -------- */
 int xivo_hip_set_layout(xivo_hip_ctx* ctx, const xivo_layout* layout, const xivo_cam* cam);

@@ -1,0 +1,50 @@
+"""The C++ adapter (xivo_amd/host/estimator_hip.h) keeps the reference's member-function
+surface: ComputeInstateJacobians -> MHGating -> FilterUpdate (src/manager.cpp:72-104).
+Reads like the reference flow; checked against the oracle flow over inliers only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import xivo_oracle as orc
+from helpers import rel_fro, TOL_P, TOL_DX
+from scene_util import scene_arrays, oracle_jacobians, spd
+from xivo_amd import synth
+from xivo_amd.lib import Cam, Layout
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_update_step_through_cpp_adapter(built, flags):
+    lib = C.CDLL(os.path.join(ROOT, "xivo_amd", "libxivo_host.so"))
+    cam = synth.EQUI
+    ng, nf, F = 6, 16, 16
+    sc = synth.g_level(ng, nf, F, 1, seed=77, cam=cam)
+    lay = orc.Layout(ng, nf)
+    poses, groups, feats, xp = scene_arrays(sc, cam)
+    feats["xp"][0, [3, 9]] += 60.0; xp[0, [3, 9]] += 60.0
+    P = spd(lay.N, 5) * 1e-4
+    Pio = np.asfortranarray(P.copy())
+    err = np.zeros(lay.N); mask = np.zeros(F, dtype=np.uint8); nrej = C.c_int(); msg = C.create_string_buffer(256)
+    clay = Layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf)
+    ccam = Cam(); ccam.model, ccam.rows, ccam.cols = cam["model"], cam["rows"], cam["cols"]
+    ccam.fx, ccam.fy, ccam.cx, ccam.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    for i, v in enumerate(cam["d"]):
+        ccam.d[i] = v
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.xivo_host_selftest_update_step(C.byref(clay), C.byref(ccam), C.c_uint(flags), F, p(poses), p(groups), p(feats),
+                                            p(Pio), C.c_double(2.25), C.c_double(5.991), C.c_double(1.1), 5, p(err),
+                                            p(mask), C.byref(nrej), msg, 256)
+    assert rc == 0, msg.value
+    Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, 0)
+    d = orc.mh_distances(Js, P, inns, 2.25)
+    m, rej, _ = orc.mh_gate(d, 5.991, 1.1, 5)
+    assert np.array_equal(mask.astype(bool), m) and nrej.value == rej and (~m).sum() == 2
+    idx = np.nonzero(m)[0]
+    H, inn, dR = orc.stack_measurements(Js[idx], inns[idx], sc["ref"][0][idx], sc["sind"][0][idx], lay, 2.25,
+                                        fix_group_block=bool(flags & 1))
+    e_ref, P_ref, _ = orc.update_joseph(H, P, inn, dR)
+    assert rel_fro(np.ascontiguousarray(Pio), P_ref) < TOL_P and rel_fro(err, e_ref) < TOL_DX

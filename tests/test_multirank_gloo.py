@@ -1,0 +1,51 @@
+"""world_size-2 gloo test of the N>1 path of bench.py: filters shard with no data-path
+collective; the only communication is the barrier and the max-over-ranks timing."""
+import os
+import socket
+
+import pytest
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from xivo_amd.shard import shard_range, max_over_ranks, sum_over_ranks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(11, world, rank)
+    dist.barrier()
+    tmax = max_over_ranks(dist, 1.0 + rank)           # rank 1 is "slower"
+    total = sum_over_ranks(dist, hi - lo)
+    q.put((rank, lo, hi, tmax, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_timing():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps: p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps: p.join(60)
+    assert [(r[1], r[2]) for r in res] == [(0, 6), (6, 11)]       # disjoint, covering, sizes differ by <= 1
+    assert all(r[3] == 2.0 for r in res)                           # max over ranks
+    assert all(r[4] == 11 for r in res)                            # every filter owned exactly once
+
+
+def test_shard_range_properties():
+    from xivo_amd.shard import shard_range, sequence_to_gpu
+    for n in (0, 1, 7, 8, 1024, 1027):
+        for w in (1, 2, 4, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert [sequence_to_gpu(s, 8) for s in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]

@@ -100,3 +100,68 @@ def test_not_spd_is_reported_not_fatal(built):
         assert st[0] == 0 and st[1] != 0
         with pytest.raises(XivoHipError):
             ctx.get_status()
+
+
+def _gating_case(N, F, B, seed):
+    """Dense rows small enough that S_f ~ R, plus a few wild innovations per filter."""
+    P, H, inn, dR = synth.s_level(N, F, B, seed=seed)
+    H *= 0.01
+    rng = np.random.default_rng(seed)
+    for b in range(B):
+        bad = rng.choice(F, size=3 + b, replace=False)
+        inn[b].reshape(F, 2)[bad] += rng.choice([-1, 1], size=(len(bad), 2)) * rng.uniform(8, 30, size=(len(bad), 2))
+    return P, H, inn, dR
+
+
+def _oracle_gate(P, H, inn, R, thresh, mult, min_inl):
+    F = H.shape[0] // 2
+    J = H.reshape(F, 2, -1)
+    d = orc.mh_distances(J, P, inn.reshape(F, 2), R)
+    return orc.mh_gate(d, thresh, mult, min_inl)[0], d
+
+
+def test_mh_gate_dense_matches_oracle(built):
+    N, F, B = 150, 50, 4
+    P, H, inn, dR = _gating_case(N, F, B, 21)
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
+        mask, dist = ctx.mh_gate_dense(F, 2.25, 5.991, 1.1, 5)
+        ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+    for b in range(B):
+        m, d = _oracle_gate(P[b], H[b], inn[b], 2.25, 5.991, 1.1, 5)
+        assert rel_fro(dist[b], d) < 1e-9 and np.array_equal(mask[b], m) and (~m).sum() >= 3
+        rows = np.repeat(m, 2)
+        e_ref, P_ref, _ = orc.update_joseph(H[b][rows], P[b], inn[b][rows], dR[b][rows])   # rejected rows not stacked
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+@pytest.mark.parametrize("N,F", [(150, 50), (250, 80)])
+def test_update_dense_gated_single_pass(built, N, F):
+    B = 3
+    P, H, inn, dR = _gating_case(N, F, B, 33)
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
+        ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5)
+        mask, dist = ctx.get_gate(F)
+        err = ctx.get_err(); Pn = ctx.download_P()
+        assert (ctx.get_status() == 0).all()
+    for b in range(B):
+        m, d = _oracle_gate(P[b], H[b], inn[b], 2.25, 5.991, 1.1, 5)
+        assert rel_fro(dist[b], d) < 1e-9 and np.array_equal(mask[b], m)
+        rows = np.repeat(m, 2)
+        e_ref, P_ref, _ = orc.update_joseph(H[b][rows], P[b], inn[b][rows], dR[b][rows])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+def test_gating_skipped_when_too_few_features(built):
+    """F <= min_required_inliers_: OutlierRejection does not gate (src/manager.cpp:635)."""
+    N, F, B = 64, 4, 2
+    P, H, inn, dR = _gating_case(N, F, B, 5)
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
+        ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5)
+        err = ctx.get_err(); Pn = ctx.download_P()
+    for b in range(B):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX

@@ -3,6 +3,7 @@
 // sequences the kernels of gemm_f64.hip / chol_trsm.hip / ekf_kernels.hip on one
 // HIP stream, never throws and never aborts.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -38,6 +39,7 @@ struct xivo_hip_ctx {
   size_t staging_elems = 0;
   long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0;
   int M = 0, Mp = 0;  // rows currently staged
+  int chunk = 0;      // filters per pipeline pass (0 = whole batch)
   // G-level
   xivo_layout lay{};
   xivo_cam cam{};
@@ -189,10 +191,14 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   g.epilogue = x.epi; g.lower_only = x.lower_only; g.batch = B;
   const double flops = 2.0 * rows * cols * (double)(K0 + (A1 ? K1 : 0)) * B;
   StageTimer st(c, stage, flops);
-  return launch_gemm_nt_f64(g, c->stream) == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
+  const bool sym = g.lower_only && rows == cols && gemm_sym_supported(rows) && !g.C2 && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
+  const int rc = sym ? launch_gemm_sym_f64(g, c->stream) : launch_gemm_nt_f64(g, c->stream);
+  return rc == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
 }
 
 }  // namespace
+
+static int ensure_gate_buffers(xivo_hip_ctx* c, int F);
 
 extern "C" {
 
@@ -234,6 +240,7 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   if (!c) return XIVO_HIP_ERR_NOMEM;
   c->device = device; c->N = N; c->Np = round_up16(N); c->Mmax = M_max; c->Mpmax = round_up16(M_max);
   c->Bmax = batch_max; c->flags = flags;
+  if (const char* e = getenv("XIVO_HIP_CHUNK")) c->chunk = atoi(e);
   const size_t B = batch_max;
   const size_t Np = c->Np, Mp = c->Mpmax;
   c->sP = (long)(Np * Np); c->sH = (long)(Mp * Np); c->sHT = (long)(Np * Mp); c->sS = (long)(Mp * Mp);
@@ -364,56 +371,123 @@ int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   return XIVO_HIP_OK;
 }
 
-int xivo_hip_update_joseph(xivo_hip_ctx* c, int B) {
-  if (!c || B <= 0 || B > c->Bmax || c->Mp <= 0) return XIVO_HIP_ERR_INVALID;
-  HIP_TRY(hipSetDevice(c->device));
+// One pass of the update pipeline over filters [b0, b0 + B).
+struct GateParams { int F; double R, thresh, mult; int min_inliers; };
+
+static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams* gate = nullptr) {
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
+  const double* H = c->H + (long)b0 * c->sH;
+  const double* HT = c->HT + (long)b0 * c->sHT;
+  double* P = c->P + (long)b0 * c->sP;
+  double* HP = c->HP + (long)b0 * c->sH;
+  double* PHT = c->PHT + (long)b0 * c->sK;
+  double* S = c->S + (long)b0 * c->sS;
+  double* K = c->K + (long)b0 * c->sK;
+  double* A = c->A + (long)b0 * c->sP;
+  double* T = c->T + (long)b0 * c->sP;
+  double* invD = c->invD + (long)b0 * c->sInvD;
+  const double* inn = c->inn + (long)b0 * c->Mpmax;
+  const double* diagR = c->diagR + (long)b0 * c->Mpmax;
   int rc;
   const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0;
   {  // HP = H * P and its transpose PH^T (estimator.cpp:1259 first product; P symmetric => B operand = P rows)
-    GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
-    rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-              c->HP, c->sH, ldh, x);
+    GemmExtra x; x.C2 = PHT; x.sC2 = c->sK; x.ldc2 = Np;
+    rc = gemm(c, ST_HP, B, Mp, Np, H, c->sH, ldh, P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              HP, c->sH, ldh, x);
     if (rc) return rc;
   }
+  if (gate) {  // Estimator::MHGating on the rows just multiplied (update.cpp:60-96): S_f = (HP)_f H_f^T + R
+    GateDenseArgs a;
+    a.H = H; a.strideH = c->sH; a.ldh = ldh; a.HP = HP; a.strideHP = c->sH; a.ldhp = ldh;
+    a.Hw = c->H + (long)b0 * c->sH; a.HTw = c->HT + (long)b0 * c->sHT; a.strideHT = c->sHT; a.ldht = Np;
+    a.HPw = HP; a.PHTw = PHT; a.PHTr = PHT;
+    a.inn = c->inn + (long)b0 * c->Mpmax; a.strideInn = c->Mpmax; a.diagR = c->diagR + (long)b0 * c->Mpmax;
+    a.strideR = c->Mpmax; a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
+    a.F = gate->F; a.Np = Np; a.batch = B;
+    a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
+    StageTimer st(c, ST_GATE, 0.0);
+    if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
   {  // S = HP * H^T + diag(R)  (estimator.cpp:1259-1263); lower triangle + mirror
-    GemmExtra x; x.epi = EPI_ADD_DIAG; x.diag = c->diagR; x.sDiag = c->Mpmax; x.lower_only = full ? 0 : 1;
-    rc = gemm(c, ST_S, B, Mp, Mp, c->HP, c->sH, ldh, c->H, c->sH, ldh, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-              c->S, c->sS, lds, x);
+    GemmExtra x; x.epi = EPI_ADD_DIAG; x.diag = diagR; x.sDiag = c->Mpmax; x.lower_only = full ? 0 : 1;
+    rc = gemm(c, ST_S, B, Mp, Mp, HP, c->sH, ldh, H, c->sH, ldh, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              S, c->sS, lds, x);
     if (rc) return rc;
   }
   {  // S = L L^T
-    CholArgs a; a.S = c->S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = c->invD; a.strideInvD = c->sInvD;
-    a.status = c->status; a.batch = B;
+    CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
+    a.status = c->status + b0; a.batch = B;
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B);
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
-    TrsmArgs a; a.LU = c->S; a.strideLU = c->sS; a.ldlu = lds; a.invD = c->invD; a.strideInvD = c->sInvD;
-    a.PHT = c->PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = c->K; a.strideK = c->sK; a.ldk = Np;
-    a.inn = c->inn; a.strideInn = c->Mpmax; a.err = c->err; a.strideErr = Np; a.Mp = Mp; a.Np = Np; a.batch = B;
+    TrsmArgs a; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
+    a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
+    a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
+    a.batch = B;
     StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B);
     if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // A = K * H - I  (estimator.cpp:1276-1279)
     GemmExtra x; x.epi = EPI_SUB_IDENT;
-    rc = gemm(c, ST_KH, B, Np, Np, c->K, c->sK, Np, c->HT, c->sHT, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-              c->A, c->sP, Np, x);
+    rc = gemm(c, ST_KH, B, Np, Np, K, c->sK, Np, HT, c->sHT, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              A, c->sP, Np, x);
     if (rc) return rc;
   }
   {  // T = A * P = K * (HP) - P  (estimator.cpp:1280, left product; distributes over the already
      // formed HP, 2MN^2 instead of 2N^3 flops, same value up to rounding)
-    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = c->P; x.sMsub = c->sP; x.ldmsub = Np;
-    rc = gemm(c, ST_AP, B, Np, Np, c->K, c->sK, Np, c->PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-              c->T, c->sP, Np, x);
+    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np;
+    rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              T, c->sP, Np, x);
     if (rc) return rc;
   }
   {  // P = T * A^T + K diag(R) K^T  (estimator.cpp:1280-1287, fused; lower triangle + mirror)
     GemmExtra x; x.lower_only = full ? 0 : 1;
-    rc = gemm(c, ST_PNEW, B, Np, Np, c->T, c->sP, Np, c->A, c->sP, Np, Np, c->K, c->sK, Np, c->K, c->sK, Np, Mp, c->diagR,
-              c->Mpmax, c->P, c->sP, Np, x);
+    rc = gemm(c, ST_PNEW, B, Np, Np, T, c->sP, Np, A, c->sP, Np, Np, K, c->sK, Np, K, c->sK, Np, Mp, diagR,
+              c->Mpmax, P, c->sP, Np, x);
   }
   return rc;
+}
+
+int xivo_hip_update_joseph(xivo_hip_ctx* c, int B) {
+  if (!c || B <= 0 || B > c->Bmax || c->Mp <= 0) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  // Filters are independent, so the batch is walked in chunks whose intermediates
+  // (HP, PH^T, S, K, A, T: ~2.7 MB per filter at N=250/M=160) stay resident in the
+  // 256 MiB Infinity Cache between consecutive kernels instead of round-tripping HBM.
+  const int chunk = c->chunk > 0 ? c->chunk : B;
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = B - b0 < chunk ? B - b0 : chunk;
+    int rc = update_joseph_range(c, b0, nb);
+    if (rc) return rc;
+  }
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_update_dense_gated(xivo_hip_ctx* c, int B, int F, double R, double mh_thresh, double mh_mult,
+                                int min_inliers) {
+  if (!c || B <= 0 || B > c->Bmax || c->Mp <= 0 || F <= 0 || 2 * F > c->M) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensure_gate_buffers(c, F);
+  if (rc) return rc;
+  GateParams gp{F, R, mh_thresh, mh_mult, min_inliers};
+  // Estimator::OutlierRejection only gates when F > min_required_inliers_ (src/manager.cpp:635)
+  const GateParams* g = F > min_inliers ? &gp : nullptr;
+  const int chunk = c->chunk > 0 ? c->chunk : B;
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = B - b0 < chunk ? B - b0 : chunk;
+    rc = update_joseph_range(c, b0, nb, g);
+    if (rc) return rc;
+  }
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_get_gate(xivo_hip_ctx* c, int B, int F, unsigned char* mask_out, double* dist_out) {
+  if (!c || B <= 0 || B > c->Bmax || F <= 0 || !c->mask) return XIVO_HIP_ERR_INVALID;
+  if (mask_out) HIP_TRY(hipMemcpyAsync(mask_out, c->mask, (size_t)B * F, hipMemcpyDeviceToHost, c->stream));
+  if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, c->dist, (size_t)B * F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
 }
 
 int xivo_hip_get_err(xivo_hip_ctx* c, int b0, int nb, double* err, long stride) {
@@ -458,12 +532,15 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
   int rc = ensure_gate_buffers(c, F);
   if (rc) return rc;
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
-  rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-            c->HP, c->sH, ldh, GemmExtra());
+  {
+    GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
+    rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              c->HP, c->sH, ldh, x);
+  }
   if (rc) return rc;
   GateDenseArgs a;
   a.H = c->H; a.strideH = c->sH; a.ldh = ldh; a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh;
-  a.Hw = c->H; a.HTw = c->HT; a.strideHT = c->sHT; a.ldht = Np;
+  a.Hw = c->H; a.HTw = c->HT; a.strideHT = c->sHT; a.ldht = Np; a.HPw = nullptr; a.PHTw = nullptr; a.PHTr = c->PHT;
   a.inn = c->inn; a.strideInn = c->Mpmax; a.diagR = c->diagR; a.strideR = c->Mpmax;
   a.mask = c->mask; a.dist = c->dist; a.F = F; a.Np = Np; a.batch = B;
   a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;

@@ -251,6 +251,135 @@ __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
 }
 
+// LDS-resident variant: the workgroup (8 waves = 128 right-hand-side columns) first
+// copies the whole factor into LDS - the 45..55 lower 16x16 blocks of L, with
+// inv(L_kk) sitting in the diagonal slots - and then every A operand of the
+// forward AND the backward substitution is a conflict-free ds_read_b64 (blocks are
+// stored column-major with a leading dimension of 17 so that both L_ik and its
+// transpose read without bank conflicts). No barrier after the initial copy.
+template <int NBM>
+__global__ __launch_bounds__(512, 2) void trsm_lds_f64_kernel(TrsmArgs g) {
+  constexpr int BLK = 16 * 17;
+  extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
+  const int chunks = (g.Np + 127) / 128;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int filt = (slot / chunks) * 8 + xcd;
+  const int chunk = slot % chunks;
+  if (filt >= g.batch) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int nb = g.Mp / 16;
+  const double* __restrict__ LU = g.LU + (long)filt * g.strideLU;
+  const double* __restrict__ invD = g.invD + (long)filt * g.strideInvD;
+  const double* __restrict__ PHT = g.PHT + (long)filt * g.stridePHT;
+  const long ld = g.ldlu;
+
+  // cooperative copy: block (i,k), i >= k at slot i(i+1)/2 + k
+  const int nblk = nb * (nb + 1) / 2;
+  for (int e = tid; e < nblk * 128; e += 512) {       // 128 = 256 elements / 2 per thread-load
+    const int t = e >> 7, w = e & 127;
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;            // block row of slot t (nb <= 24: a few iterations)
+    const int k = t - i * (i + 1) / 2;
+    const int r = (w & 7) * 2, c = w >> 3;             // rows r, r+1 of column c
+    d2 v;
+    if (i == k) v = *reinterpret_cast<const d2*>(invD + (long)k * 512 + r + 16 * c);
+    else v = *reinterpret_cast<const d2*>(LU + (16 * i + r) + (long)(16 * k + c) * ld);
+    sL[t * BLK + r + 17 * c] = v[0];
+    sL[t * BLK + r + 1 + 17 * c] = v[1];
+  }
+  const int c0 = chunk * 128 + wave * 16;
+  const bool live = c0 < g.Np;
+
+  d4 X[NBM];
+#pragma unroll
+  for (int i = 0; i < NBM; ++i) {
+    X[i] = d4{0.0, 0.0, 0.0, 0.0};
+    if (live && i < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[i][r] = PHT[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldpht];
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+
+  // forward: L Y = HP
+#pragma unroll
+  for (int k = 0; k < NBM; ++k) {
+    if (k < nb) {
+      const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
+      d4 t = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t = mfma(Dk[li + 17 * (4 * s + lg)], X[k][s], t);
+      X[k] = t;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = k + 1; i < NBM; ++i) {
+          if (i < nb) {
+            const double a = sL[(i * (i + 1) / 2 + k) * BLK + li + 17 * (4 * s + lg)];
+            X[i] = mfma(-a, t[s], X[i]);
+          }
+        }
+      }
+    }
+  }
+  // backward: L^T K^T = Y
+#pragma unroll
+  for (int k = NBM - 1; k >= 0; --k) {
+    if (k < nb) {
+      const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
+      d4 t = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t = mfma(Dk[(4 * s + lg) + 17 * li], X[k][s], t);
+      X[k] = t;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+          const double a = sL[(k * (k + 1) / 2 + i) * BLK + (4 * s + lg) + 17 * li];   // (L_ki)^T
+          X[i] = mfma(-a, t[s], X[i]);
+        }
+      }
+    }
+  }
+
+  double* __restrict__ K = g.K + (long)filt * g.strideK;
+  const double* __restrict__ inn = g.inn + (long)filt * g.strideInn;
+  double part = 0.0;
+#pragma unroll
+  for (int i = 0; i < NBM; ++i) {
+    if (i < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + lg + 4 * r;
+        K[(c0 + li) + (long)m * g.ldk] = X[i][r];
+        part = fma(X[i][r], inn[m], part);
+      }
+    }
+  }
+  part += __shfl_xor(part, 16);
+  part += __shfl_xor(part, 32);
+  if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
+}
+
+template <int NBM>
+int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
+  const int nb = g.Mp / 16;
+  const int chunks = (g.Np + 127) / 128;
+  const int grid = ((g.batch + 7) / 8) * 8 * chunks;
+  const size_t lds = (size_t)nb * (nb + 1) / 2 * 16 * 17 * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_lds_f64_kernel<NBM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((trsm_lds_f64_kernel<NBM>), dim3(grid), dim3(512), lds, stream, g);
+  return (int)hipGetLastError();
+}
+
 template <int NBM>
 int launch_trsm_t(const TrsmArgs& g, hipStream_t stream) {
   const int chunks = (g.Np + 63) / 64;
@@ -271,6 +400,10 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
 int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
   const int nb = g.Mp / 16;
+  // whole factor in LDS (nb(nb+1)/2 blocks of 16x17 doubles) when it fits 160 KiB
+  if (nb <= 6) return launch_trsm_lds_t<6>(g, stream);
+  if (nb <= 10) return launch_trsm_lds_t<10>(g, stream);
+  if (nb <= 11) return launch_trsm_lds_t<11>(g, stream);
   if (nb <= 4) return launch_trsm_t<4>(g, stream);
   if (nb <= 7) return launch_trsm_t<7>(g, stream);
   if (nb <= 10) return launch_trsm_t<10>(g, stream);

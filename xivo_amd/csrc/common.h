@@ -100,3 +100,14 @@ struct TrsmArgs {
 int launch_trsm_f64(const TrsmArgs& args, hipStream_t stream);
 
 }  // namespace xivo_hip
+
+namespace xivo_hip {
+// Row-group partition of the lower triangle for the symmetric GEMM kernel.
+struct SymGroups {
+  int n;          // number of groups (<= 8)
+  int r0[8], r1[8];  // block rows [r0, r1) of each group
+};
+// symmetric (lower triangle + mirror) product for outputs of at most 16 blocks (256)
+int launch_gemm_sym_f64(const GemmArgs& args, hipStream_t stream);
+bool gemm_sym_supported(int Mp);
+}  // namespace xivo_hip

@@ -31,6 +31,8 @@ struct GateDenseArgs {
   const double* H; long strideH; int ldh;       // candidate rows (J of feature f = rows 2f, 2f+1)
   const double* HP; long strideHP; int ldhp;    // H * P of the same rows
   double* Hw; double* HTw; long strideHT; int ldht;  // H / H^T to neutralise
+  double* HPw; double* PHTw;                         // optional: HP / (HP)^T rows to neutralise too
+  const double* PHTr;                                // (HP)^T = P H^T of the candidate rows [Np x Mp]
   double* inn; long strideInn;
   double* diagR; long strideR;
   unsigned char* mask; double* dist;            // [batch x F]

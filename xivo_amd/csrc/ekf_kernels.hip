@@ -136,14 +136,21 @@ __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
   const double* H = a.H + (long)filt * a.strideH;
   const double* HP = a.HP + (long)filt * a.strideHP;
   double* inn = a.inn + (long)filt * a.strideInn;
+  // S_f = (HP)_f H_f^T + R I2 from the TRANSPOSED copies (P H^T and H^T are [Np x Mp] with
+  // the state index contiguous), so every lane streams four contiguous columns.
+  const double* PHT = a.PHTr + (long)filt * a.strideHT;
+  const double* HT = a.HTw + (long)filt * a.strideHT;
   for (int f = wave; f < a.F; f += 4) {
     double s00 = 0, s10 = 0, s11 = 0;
+    const double* p0 = PHT + (long)(2 * f) * a.ldht;
+    const double* p1 = p0 + a.ldht;
+    const double* h0 = HT + (long)(2 * f) * a.ldht;
+    const double* h1 = h0 + a.ldht;
     for (int n = lane; n < a.Np; n += 64) {
-      const d2 hp = *reinterpret_cast<const d2*>(HP + 2 * f + (long)n * a.ldhp);
-      const d2 h = *reinterpret_cast<const d2*>(H + 2 * f + (long)n * a.ldh);
-      s00 = fma(hp[0], h[0], s00);
-      s10 = fma(hp[1], h[0], s10);
-      s11 = fma(hp[1], h[1], s11);
+      const double hp0 = p0[n], hp1 = p1[n], hh0 = h0[n], hh1 = h1[n];
+      s00 = fma(hp0, hh0, s00);
+      s10 = fma(hp1, hh0, s10);
+      s11 = fma(hp1, hh1, s11);
     }
     s00 = wave_sum(s00) + a.R;
     s10 = wave_sum(s10);
@@ -177,6 +184,14 @@ __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
       Hw[2 * f + 1 + (long)n * a.ldh] = 0.0;
       HTw[n + (long)(2 * f) * a.ldht] = 0.0;
       HTw[n + (long)(2 * f + 1) * a.ldht] = 0.0;
+      if (a.HPw) {
+        double* HPw = a.HPw + (long)filt * a.strideHP;
+        double* PHTw = a.PHTw + (long)filt * a.strideHT;
+        HPw[2 * f + (long)n * a.ldhp] = 0.0;
+        HPw[2 * f + 1 + (long)n * a.ldhp] = 0.0;
+        PHTw[n + (long)(2 * f) * a.ldht] = 0.0;
+        PHTw[n + (long)(2 * f + 1) * a.ldht] = 0.0;
+      }
     }
   }
 }

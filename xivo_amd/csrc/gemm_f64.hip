@@ -34,9 +34,7 @@ namespace xivo_hip {
 
 namespace {
 
-constexpr int BK = 16;
-
-template <int WM, int WN, bool STRIP>
+template <int WM, int WN, int BK, bool STRIP>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, const int m0, const int n0,
                                           double* smem) {
   static_assert(!STRIP || (WM == 4 && WN == 4), "strip mapping is defined for 128x128 tiles");
@@ -86,11 +84,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     }
   }
 
-  const int steps0 = g.seg[0].K / BK;
-  const int steps1 = g.nseg > 1 ? g.seg[1].K / BK : 0;
+  const int steps0 = (g.seg[0].K + BK - 1) / BK;
+  const int steps1 = g.nseg > 1 ? (g.seg[1].K + BK - 1) / BK : 0;
   const int nsteps = steps0 + steps1;
 
-  d2 ra[WM], rb[WN];
+  constexpr int RA = WM * BK / 16, RB = WN * BK / 16;   // 16-byte loads per thread per panel
+  d2 ra[RA], rb[RB];
 
   auto load_global = [&](int t) {
     const int s = t < steps0 ? 0 : 1;
@@ -99,22 +98,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     const double* Ab = sg.A + (long)filt * sg.strideA;
     const double* Bb = sg.B + (long)filt * sg.strideB;
 #pragma unroll
-    for (int r = 0; r < WM; ++r) {
+    for (int r = 0; r < RA; ++r) {
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WM), p = idx % (16 * WM);
       const int row = m0 + 2 * p;
       d2 v = d2{0.0, 0.0};
-      if (row < g.Mp) v = *reinterpret_cast<const d2*>(Ab + row + (long)(k0 + k) * sg.lda);
+      if (row < g.Mp && k0 + k < sg.K) v = *reinterpret_cast<const d2*>(Ab + row + (long)(k0 + k) * sg.lda);
       ra[r] = v;
     }
 #pragma unroll
-    for (int r = 0; r < WN; ++r) {
+    for (int r = 0; r < RB; ++r) {
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WN), p = idx % (16 * WN);
       const int col = n0 + 2 * p;
       d2 v = d2{0.0, 0.0};
-      if (col < g.Np) v = *reinterpret_cast<const d2*>(Bb + col + (long)(k0 + k) * sg.ldb);
-      if (sg.scale) {
+      if (col < g.Np && k0 + k < sg.K) v = *reinterpret_cast<const d2*>(Bb + col + (long)(k0 + k) * sg.ldb);
+      if (sg.scale && k0 + k < sg.K) {
         const double sc = sg.scale[(long)filt * sg.strideScale + k0 + k];
         v *= sc;
       }
@@ -124,13 +123,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
 
   auto store_lds = [&]() {
 #pragma unroll
-    for (int r = 0; r < WM; ++r) {
+    for (int r = 0; r < RA; ++r) {
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WM), p = idx % (16 * WM);
       *reinterpret_cast<d2*>(As + k * LDAS + 2 * p) = ra[r];
     }
 #pragma unroll
-    for (int r = 0; r < WN; ++r) {
+    for (int r = 0; r < RB; ++r) {
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WN), p = idx % (16 * WN);
       *reinterpret_cast<d2*>(Bs + k * LDBS + 2 * p) = rb[r];
@@ -201,8 +200,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   }
 }
 
+// k-panel depth: 32 where two workgroups' LDS (2 x BK x (BM+BN+32) doubles) still fit
+// the CU's 160 KiB - twice the bytes in flight per workgroup and half the barriers -
+// else 16. K segments that are not a multiple of 32 are handled by zero-filling.
+template <int WM, int WN>
+constexpr int pick_bk() {
+  return (WM * WN <= 16 && 2 * 32 * (32 * WM + 32 * WN + 32) * 8 <= 160 * 1024) ? 32 : 16;   // larger tiles: registers
+}
+
 template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
+  constexpr int BK = pick_bk<WM, WN>();
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int LDAS = BM + 16, LDBS = BN + 16;
   __shared__ __attribute__((aligned(16))) double smem[BK * (LDAS + LDBS)];
@@ -220,11 +228,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   if (g.lower_only && n0 >= m0 + BM) return;  // tile strictly above the diagonal
   if constexpr (WM == 4 && WN == 4) {
     if (g.lower_only && m0 == n0) {
-      gemm_tile<WM, WN, true>(g, filt, m0, n0, smem);
+      gemm_tile<WM, WN, BK, true>(g, filt, m0, n0, smem);
       return;
     }
   }
-  gemm_tile<WM, WN, false>(g, filt, m0, n0, smem);
+  gemm_tile<WM, WN, BK, false>(g, filt, m0, n0, smem);
 }
 
 template <int WM, int WN>

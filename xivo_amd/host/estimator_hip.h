@@ -1,0 +1,152 @@
+// C++ host adapter: the reference's Estimator / Feature hot-path surface on top
+// of the C ABI (include/xivo_hip.h).
+//
+// The reference exposes this path only as member functions of its singleton
+// `Estimator` and of `Feature` (src/estimator.h:261-313, src/feature.h:134-188).
+// This header keeps those names, argument meanings and error behaviour so that
+// the calling code of src/manager.cpp:72-104 (ComputeInstateJacobians ->
+// OutlierRejection/MHGating -> FilterUpdate) reads the same. It runs in the
+// "plumbing" mode of SURVEY.md 8b: the host members P_, H_, inn_, diagR_, err_
+// stay authoritative, every call uploads what the device needs and downloads
+// what the reference would have left in its members. (The throughput path is
+// the batched C ABI itself; this adapter is the drop-in for one filter.)
+//
+// Matrix type: a minimal column-major `MatX` with Eigen's memory layout
+// (Eigen::MatrixXd::data() can be passed wherever MatX::data() is). Inside the
+// reference tree the same adapter compiles with `using MatX = Eigen::MatrixXd`.
+#pragma once
+#include <cmath>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/xivo_hip.h"
+
+namespace xivo {
+namespace hip {
+
+using number_t = double;  // common/alias.h:11
+
+struct VecX {
+  std::vector<number_t> v;
+  VecX() = default;
+  explicit VecX(int n) : v(n, 0.0) {}
+  int size() const { return (int)v.size(); }
+  int rows() const { return (int)v.size(); }
+  void setZero(int n) { v.assign(n, 0.0); }
+  void resize(int n) { v.resize(n); }
+  number_t& operator()(int i) { return v[i]; }
+  number_t operator()(int i) const { return v[i]; }
+  number_t* data() { return v.data(); }
+  const number_t* data() const { return v.data(); }
+};
+
+struct MatX {  // column-major, like Eigen's default (CMakeLists.txt:42)
+  std::vector<number_t> v;
+  int r = 0, c = 0;
+  MatX() = default;
+  MatX(int rows, int cols) : v((size_t)rows * cols, 0.0), r(rows), c(cols) {}
+  int rows() const { return r; }
+  int cols() const { return c; }
+  void setZero(int rows, int cols) { r = rows; c = cols; v.assign((size_t)rows * cols, 0.0); }
+  number_t& operator()(int i, int j) { return v[(size_t)j * r + i]; }
+  number_t operator()(int i, int j) const { return v[(size_t)j * r + i]; }
+  number_t* data() { return v.data(); }
+  const number_t* data() const { return v.data(); }
+};
+
+struct Vec2 { number_t v[2] = {0, 0}; number_t& operator()(int i) { return v[i]; } number_t operator()(int i) const { return v[i]; } };
+struct Vec3 { number_t v[3] = {0, 0, 0}; number_t& operator()(int i) { return v[i]; } number_t operator()(int i) const { return v[i]; } };
+struct Mat3 {  // column-major 3x3
+  number_t v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  number_t& operator()(int i, int j) { return v[3 * j + i]; }
+  number_t operator()(int i, int j) const { return v[3 * j + i]; }
+};
+
+enum class FeatureStatus { INSTATE, GAUGE, REJECTED_BY_FILTER };  // subset of src/core.h used on this path
+
+// Group anchor (src/group.h:41-107): pose + state slot.
+struct Group {
+  Mat3 Rsb_; Vec3 Tsb_; int sind_ = -1;
+  const Mat3& Rsb() const { return Rsb_; }
+  const Vec3& Tsb() const { return Tsb_; }
+  int sind() const { return sind_; }
+};
+using GroupPtr = Group*;
+
+class Estimator;
+
+// Feature (src/feature.h:74-232): the members the hot path reads and writes.
+class Feature {
+ public:
+  Vec3 x_;                 // (X/Z, Y/Z, log Z), feature.h:258-262
+  Vec2 back_;              // last tracked pixel
+  GroupPtr ref_ = nullptr;
+  int sind_ = -1;
+  FeatureStatus status_ = FeatureStatus::INSTATE;
+
+  const Vec2& back() const { return back_; }
+  GroupPtr ref() const { return ref_; }
+  int sind() const { return sind_; }
+  FeatureStatus status() const { return status_; }
+  void SetStatus(FeatureStatus s) { status_ = s; }
+  // J(): 2 x kFullSize row pair, inn(): innovation (feature.h:187-188 accessors)
+  const MatX& J() const { return J_; }
+  const Vec2& inn() const { return inn_; }
+  // Feature::FillJacobianBlock (src/feature.cpp:658-684), including the
+  // group-block overwrite of :675-676 unless the estimator was created with
+  // XIVO_HIP_FLAG_FIX_GROUP_BLOCK.
+  void FillJacobianBlock(MatX& H, int offset) const;
+
+ private:
+  friend class Estimator;
+  MatX J_;
+  Vec2 inn_;
+  const Estimator* owner_ = nullptr;
+};
+using FeaturePtr = Feature*;
+
+// Estimator: the hot-path members and methods of src/estimator.h:261-313,423-509.
+class Estimator {
+ public:
+  Estimator(const xivo_layout& layout, const xivo_cam& cam, int max_features, unsigned flags = 0, int device = 0);
+  ~Estimator();
+  Estimator(const Estimator&) = delete;
+  Estimator& operator=(const Estimator&) = delete;
+
+  // ---- members with the reference's names (src/estimator.h:423-509) ----
+  MatX P_, H_, K_;         // K_ holds K*sqrt(R) after UpdateJosephForm, as in the reference (estimator.cpp:1282-1286)
+  VecX inn_, diagR_, err_;
+  number_t R_ = 2.25;      // visual_meas_std^2 (estimator.cpp:334-335)
+  number_t MH_thresh_ = 5.991, MH_thresh_multipler_ = 1.1;  // estimator.cpp:366-369
+  int min_required_inliers_ = 5;
+  bool use_MH_gating_ = true;
+  int num_mh_rejected_ = 0;
+  // nominal state pieces ComputeInstateJacobians passes down (update.cpp:27-28)
+  Mat3 Rsb_, Rbc_; Vec3 Tsb_, Tbc_;
+  std::vector<FeaturePtr> instate_features_;
+  std::vector<FeaturePtr> in_current_ekf_update_;
+  std::vector<GroupPtr> groups_;   // indexed by slot `sind`
+
+  // ---- methods with the reference's names ----
+  void UpdateJosephForm();                 // src/estimator.cpp:1257-1288
+  void ComputeInstateJacobians();          // src/update.cpp:24-32
+  std::vector<FeaturePtr> MHGating();      // src/update.cpp:50-116
+  void FilterUpdate();                     // src/update.cpp:120-153 (AbsorbError is left to the caller)
+  // host edits of P_ stay plain host code on the authoritative host copy
+
+  const xivo_layout& layout() const { return lay_; }
+  unsigned flags() const { return flags_; }
+
+ private:
+  void Check(int status, const char* what) const;
+  xivo_hip_ctx* ctx_ = nullptr;
+  xivo_layout lay_;
+  xivo_cam cam_;
+  unsigned flags_;
+  int max_features_;
+};
+
+}  // namespace hip
+}  // namespace xivo

@@ -72,6 +72,8 @@ _SIGS = {
     "xivo_hip_get_status": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_mh_gate_dense": [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                                C.c_void_p, C.c_void_p],
+    "xivo_hip_update_dense_gated": [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int],
+    "xivo_hip_get_gate": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_set_layout": [C.c_void_p, C.POINTER(Layout), C.POINTER(Cam)],
     "xivo_hip_set_scene": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_jacobians_instate": [C.c_void_p, C.c_int],
@@ -239,6 +241,17 @@ class Context:
         dist = np.zeros((B, F))
         self._check(self.lib.xivo_hip_mh_gate_dense(self.h, B, F, R, thresh, mult, min_inliers, _ptr(mask),
                                                     _ptr(dist)))
+        return mask.astype(bool), dist
+
+    def update_dense_gated(self, F, R, thresh, mult, min_inliers, B=None):
+        self._check(self.lib.xivo_hip_update_dense_gated(self.h, self.batch if B is None else B, F, R, thresh, mult,
+                                                         min_inliers))
+
+    def get_gate(self, F, B=None):
+        B = self.batch if B is None else B
+        mask = np.zeros((B, F), dtype=np.uint8)
+        dist = np.zeros((B, F))
+        self._check(self.lib.xivo_hip_get_gate(self.h, B, F, _ptr(mask), _ptr(dist)))
         return mask.astype(bool), dist
 
     # ---- G-level ------------------------------------------------------------
