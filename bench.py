@@ -166,6 +166,14 @@ def main():
             g = groups.setdefault(kname, {"ms": 0.0, "launches": 0, "flops": 0.0, "stages": []})
             g["ms"] += st["ms"]; g["launches"] += st["launches"]
             g["flops"] += st["flops_per_launch"] * st["launches"]; g["stages"].append(name)
+        pmc = {}
+        try:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+            if cands:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
+                pmc["_file"] = "profiles/" + cands[-1]
+        except Exception:
+            pmc = {}
         roofline = None
         if groups:
             dom = max(groups, key=lambda k: groups[k]["ms"])
@@ -175,7 +183,11 @@ def main():
                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                         "avg_launch_ms": g["ms"] / g["launches"], "launches": g["launches"],
-                        "traffic": None,
+                        # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of the
+                        # same command (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE); null if absent
+                        "traffic": (lambda e: (e.get("hbm_read_bytes_per_launch", 0) + e.get("hbm_write_bytes_per_launch", 0))
+                                    if e and args.batch == 4096 else None)(pmc.get(dom.replace("<", "<").replace(",", ", "))),
+                        "traffic_source": pmc.get("_file"),
                         "mfma_peak_measured_tflops": peak_meas,
                         "pipeline_f_alg_tflops": f_alg(N, M) * value / world / 1e12,
                         "pipeline_frac": f_alg(N, M) * value / world / 1e12 / FP64_MFMA_PEAK_TFLOPS}
