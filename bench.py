@@ -75,6 +75,7 @@ def main():
                     help="time UpdateJosephForm only (default: MH gating + UpdateJosephForm, one 'update' of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="extra XIVO_HIP_FLAG_* bits (A/B knobs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,7 +94,7 @@ def main():
 
     N, F, B = args.state_dim, args.features, args.batch
     M = 2 * F
-    flags = 0 if args.no_profile else FLAG_PROFILE
+    flags = (0 if args.no_profile else FLAG_PROFILE) | args.flags
     ctx = Context(N, M, B, device=local_rank, flags=flags)
 
     # synthetic inputs: 64 distinct seeded filters per rank, tiled to the batch
@@ -139,7 +140,7 @@ def main():
         dt = float(t.item())
 
     status = ctx.get_status(check=False)
-    prof = ctx.profile_get() if flags else {}
+    prof = ctx.profile_get() if (flags & FLAG_PROFILE) else {}
     peak_meas = ctx.bench_mfma_peak() if rank == 0 else None
 
     if rank == 0:

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void trsm_lds_f64_kernel(TrsmArgs g) {
   const int filt = (slot / chunks) * 8 + xcd;
   const int chunk = slot % chunks;
   if (filt >= g.batch) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int nb = g.Mp / 16;
   const double* __restrict__ LU = g.LU + (long)filt * g.strideLU;

@@ -28,13 +28,20 @@
 // block rows {w, 7-w} of the 8x8 block grid, i.e. exactly 9 of the 36
 // lower-triangle blocks each, so the triangle costs 9/16 of a full tile instead
 // of the 16/16 its busiest wave would otherwise pay.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace xivo_hip {
 
 namespace {
 
-template <int WM, int WN, int BK, bool STRIP>
+// FAST: the tile is interior (every 16x16 block in range and wanted), so slot activity is a
+// compile-time property - for strip tiles together with the compile-time wave index WAVE - and
+// the MFMA loop is straight-line code. Otherwise each slot is guarded by a wave-uniform bit
+// (hipcc turns those guards into a chain of scalar branches: ~2 taken branches per MFMA,
+// which is what made half-empty diagonal tiles SLOWER than full ones).
+template <int WM, int WN, int BK, bool STRIP, bool FAST, int WAVE>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, const int m0, const int n0,
                                           double* smem) {
   static_assert(!STRIP || (WM == 4 && WN == 4), "strip mapping is defined for 128x128 tiles");
@@ -47,7 +54,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   double* Bs = smem + BK * LDAS;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  // readfirstlane: tells the compiler the wave index (and everything derived from it: the slot
+  // activity mask, strip rows) is wave-uniform -> SGPRs and scalar branches instead of exec masking
+  const int wave = (STRIP && FAST) ? WAVE : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int wr = wave & 1, wc = wave >> 1;
 
@@ -67,6 +77,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     if (g.lower_only && J0 > I0) on = false;   // block strictly above the diagonal
     if (on) active |= 1u << q;
   }
+  active = __builtin_amdgcn_readfirstlane(active);
+  // compile-time activity of slot q on the FAST path
+  auto fast_on = [&](int q) -> bool { return !STRIP || slot_b(q) <= arow(slot_a(q)); };
+  auto is_on = [&](int q) -> bool { return FAST ? fast_on(q) : (active & (1u << q)) != 0; };
 
   // Accumulators start at 0, or at -/+Msub for C = acc -/+ Msub (T = K(HP) - P): the
   // loads are issued here, ahead of the first k-panel, instead of serialising
@@ -75,7 +89,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-    if ((g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT) && (active & (1u << q))) {
+    if ((g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT) && is_on(q)) {
       const double* Ms = g.Msub + (long)filt * g.strideMsub;
       const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
       const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;
@@ -91,48 +105,87 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   constexpr int RA = WM * BK / 16, RB = WN * BK / 16;   // 16-byte loads per thread per panel
   d2 ra[RA], rb[RB];
 
-  auto load_global = [&](int t) {
-    const int s = t < steps0 ? 0 : 1;
-    const GemmSeg& sg = g.seg[s];
-    const int k0 = (s ? t - steps0 : t) * BK;
-    const double* Ab = sg.A + (long)filt * sg.strideA;
-    const double* Bb = sg.B + (long)filt * sg.strideB;
+  // Branch-free panel loads: every per-thread quantity that does not change from one
+  // k-step to the next (element offset inside the panel, row validity) is computed once
+  // per K-segment; out-of-range rows / k-columns are read from a clamped (always valid)
+  // address and zeroed with a select, so the loop body is load + select, no exec masking.
+  int eoffA[RA], eoffB[RB];
+  unsigned okA = 0, okB = 0;
+  const double* segA = nullptr;
+  const double* segB = nullptr;
+  const double* segS = nullptr;
+  int seg_lda = 0, seg_ldb = 0, seg_K = 0;
+  auto setup_seg = [&](int sidx) {
+    const GemmSeg& sg = g.seg[sidx];
+    segA = sg.A + (long)filt * sg.strideA;
+    segB = sg.B + (long)filt * sg.strideB;
+    segS = sg.scale ? sg.scale + (long)filt * sg.strideScale : nullptr;
+    seg_lda = sg.lda; seg_ldb = sg.ldb; seg_K = sg.K;
+    okA = 0; okB = 0;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WM), p = idx % (16 * WM);
       const int row = m0 + 2 * p;
-      d2 v = d2{0.0, 0.0};
-      if (row < g.Mp && k0 + k < sg.K) v = *reinterpret_cast<const d2*>(Ab + row + (long)(k0 + k) * sg.lda);
-      ra[r] = v;
+      const bool ok = row < g.Mp;
+      eoffA[r] = (ok ? row : 0) + k * sg.lda;
+      if (ok) okA |= 1u << r;
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WN), p = idx % (16 * WN);
       const int col = n0 + 2 * p;
-      d2 v = d2{0.0, 0.0};
-      if (col < g.Np && k0 + k < sg.K) v = *reinterpret_cast<const d2*>(Bb + col + (long)(k0 + k) * sg.ldb);
-      if (sg.scale && k0 + k < sg.K) {
-        const double sc = sg.scale[(long)filt * sg.strideScale + k0 + k];
-        v *= sc;
-      }
-      rb[r] = v;
+      const bool ok = col < g.Np;
+      eoffB[r] = (ok ? col : 0) + k * sg.ldb;
+      if (ok) okB |= 1u << r;
+    }
+  };
+
+  // Issue only: nothing below consumes the loaded registers, so the loads stay in flight
+  // under the MFMA block; masking (row validity, k-tail) and the optional per-k scale are
+  // applied in store_lds, one k-step later.
+  int pend_k0 = 0, pend_K = 0;
+  const double* pend_S = nullptr;
+  auto load_global = [&](int t) {
+    if (t == 0) setup_seg(0);
+    else if (t == steps0) setup_seg(1);
+    const int k0 = (t < steps0 ? t : t - steps0) * BK;
+    const bool tail = k0 + BK > seg_K;            // only the last, partial k-step of a segment
+    const double* Ab = segA + (long)k0 * seg_lda;
+    const double* Bb = segB + (long)k0 * seg_ldb;
+    pend_k0 = k0; pend_K = seg_K; pend_S = segS;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int k = (tid + 256 * r) / (16 * WM);
+      const bool kin = !tail || (k0 + k < seg_K);
+      ra[r] = *reinterpret_cast<const d2*>(Ab + (kin ? eoffA[r] : eoffA[r] - k * seg_lda));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int k = (tid + 256 * r) / (16 * WN);
+      const bool kin = !tail || (k0 + k < seg_K);
+      rb[r] = *reinterpret_cast<const d2*>(Bb + (kin ? eoffB[r] : eoffB[r] - k * seg_ldb));
     }
   };
 
   auto store_lds = [&]() {
+    const bool tail = pend_k0 + BK > pend_K;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WM), p = idx % (16 * WM);
-      *reinterpret_cast<d2*>(As + k * LDAS + 2 * p) = ra[r];
+      const bool keep = ((okA >> r) & 1u) && (!tail || pend_k0 + k < pend_K);
+      *reinterpret_cast<d2*>(As + k * LDAS + 2 * p) = keep ? ra[r] : d2{0.0, 0.0};
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WN), p = idx % (16 * WN);
-      *reinterpret_cast<d2*>(Bs + k * LDBS + 2 * p) = rb[r];
+      const bool keep = ((okB >> r) & 1u) && (!tail || pend_k0 + k < pend_K);
+      d2 v = keep ? rb[r] : d2{0.0, 0.0};
+      if (pend_S) v *= pend_S[pend_k0 + k < pend_K ? pend_k0 + k : pend_K - 1];
+      *reinterpret_cast<d2*>(Bs + k * LDBS + 2 * p) = v;
     }
   };
 
@@ -150,7 +203,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       for (int x = 0; x < NB; ++x) bb[x] = Bs[(4 * s + lg) * LDBS + 16 * bcol(x) + li];
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
-        if (active & (1u << q))
+        if (is_on(q))
           acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[slot_b(q)], a[slot_a(q)], acc[q], 0, 0, 0);
       }
     }
@@ -165,7 +218,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   const bool need_t = g.lower_only || C2b;
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
-    if (!(active & (1u << q))) continue;
+    if (!is_on(q)) continue;
     const int I0 = m0 + 16 * arow(slot_a(q)), J0 = n0 + 16 * bcol(slot_b(q));
     const int i = I0 + li;
     d4 v = acc[q];
@@ -200,12 +253,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   }
 }
 
-// k-panel depth: 32 where two workgroups' LDS (2 x BK x (BM+BN+32) doubles) still fit
-// the CU's 160 KiB - twice the bytes in flight per workgroup and half the barriers -
-// else 16. K segments that are not a multiple of 32 are handled by zero-filling.
+// k-panel depth (a template knob; K segments that are not a multiple of it are zero-filled).
 template <int WM, int WN>
 constexpr int pick_bk() {
-  return (WM * WN <= 16 && 2 * 32 * (32 * WM + 32 * WN + 32) * 8 <= 160 * 1024) ? 32 : 16;   // larger tiles: registers
+  return 16;   // 32 measured neutral on MI355X and costs 32 more staging VGPRs
 }
 
 template <int WM, int WN>
@@ -226,13 +277,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   if (g.lower_only && n0 >= m0 + BM) return;  // tile strictly above the diagonal
+  const bool inside = (m0 + BM <= g.Mp) && (n0 + BN <= g.Np);
   if constexpr (WM == 4 && WN == 4) {
-    if (g.lower_only && m0 == n0) {
-      gemm_tile<WM, WN, BK, true>(g, filt, m0, n0, smem);
+    if (g.lower_only == 1 && m0 == n0) {
+      if (inside) {
+        const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        if (w == 0) gemm_tile<WM, WN, BK, true, true, 0>(g, filt, m0, n0, smem);
+        else if (w == 1) gemm_tile<WM, WN, BK, true, true, 1>(g, filt, m0, n0, smem);
+        else if (w == 2) gemm_tile<WM, WN, BK, true, true, 2>(g, filt, m0, n0, smem);
+        else gemm_tile<WM, WN, BK, true, true, 3>(g, filt, m0, n0, smem);
+      } else {
+        gemm_tile<WM, WN, BK, true, false, -1>(g, filt, m0, n0, smem);
+      }
       return;
     }
   }
-  gemm_tile<WM, WN, BK, false>(g, filt, m0, n0, smem);
+  // interior tile with every block wanted (for lower_only: strictly below the diagonal)
+  if (inside && (!g.lower_only || n0 + BN <= m0)) gemm_tile<WM, WN, BK, false, true, -1>(g, filt, m0, n0, smem);
+  else gemm_tile<WM, WN, BK, false, false, -1>(g, filt, m0, n0, smem);
 }
 
 template <int WM, int WN>
@@ -279,7 +341,10 @@ void gemm_pick_tile(int Mp, int Np, int lower_only, int* WM, int* WN) {
   *WN = wn;
 }
 
-int launch_gemm_nt_f64(const GemmArgs& a, hipStream_t stream) {
+int launch_gemm_nt_f64(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
+  static const bool no_strip = getenv("XIVO_HIP_NO_STRIP") != nullptr;   // A/B knob
+  if (no_strip && a.lower_only) a.lower_only = 2;
   int wm, wn;
   gemm_pick_tile(a.Mp, a.Np, a.lower_only, &wm, &wn);
 #define XIVO_GEMM_CASE(M_, N_) \

@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_f64_kernel(GemmArgs g, SymGro
     scol[q] = __builtin_amdgcn_readfirstlane(t < total ? t - base : 0);
   }
 
+  active = __builtin_amdgcn_readfirstlane(active);
+
   d4 acc[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
