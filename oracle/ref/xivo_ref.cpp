@@ -230,3 +230,133 @@ void ref_rk4_cov_tail(int N, int nm, double* P, const double* FK, const double* 
 void ref_so3_exp(const double* w, double* R) { (Eigen::Map<Mat3>(R)) = SO3::exp(Eigen::Map<const Vec3>(w)).matrix(); }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Estimator::RK4Step (src/rk4.cpp:35-103) with ComposeMotion (src/estimator.cpp:598-613)
+// and ComputeMotionJacobianAt (src/estimator.cpp:615-704), default build, restated line
+// by line on the reference's own types (Sophus SO3 incl. normalize(), Eigen dense).
+// state = [Rsb(9, col-major) Tsb(3) Vsb(3) bg(3) ba(3) Rsg(9)] in/out; P is N x N in/out.
+// ---------------------------------------------------------------------------
+namespace {
+struct RefState { SO3 Rsb; Vec3 Tsb, Vsb, bg, ba; SO3 Rsg; };
+struct RefProp {
+  RefState X_;
+  MatX P_, F_, G_, Qimu_;
+  Vec3 g_, slope_gyro_, slope_accel_;
+  Mat3 Cg, Ca;
+  void ComposeMotion(RefState& X, const Vec3& V, const Eigen::Matrix<double, 6, 1>& gyro_accel, double dt) {
+    Vec3 gyro = gyro_accel.head<3>();
+    Vec3 accel = gyro_accel.tail<3>();
+    Vec3 gyro_calib = Cg * gyro - X.bg;
+    Vec3 accel_calib = Ca * accel - X.ba;
+    X.Tsb += V * dt;
+    X.Vsb += (X.Rsb * accel_calib + X.Rsg * g_) * dt;
+    X.Rsb *= SO3::exp(gyro_calib * dt);
+    X.Rsb.normalize();
+  }
+  void ComputeMotionJacobianAt(const RefState& X, const Eigen::Matrix<double, 6, 1>& gyro_accel) {
+    Vec3 gyro = gyro_accel.head<3>();
+    Vec3 accel = gyro_accel.tail<3>();
+    Vec3 gyro_calib = Cg * gyro - X.bg;
+    Vec3 accel_calib = Ca * accel - X.ba;
+    Mat3 Rsb = X.Rsb.matrix();
+    Mat3 dWsb_dWsb = -SO3::hat(gyro_calib);
+    Mat3 dV_dWsb = -Rsb * SO3::hat(accel_calib);
+    Mat3 dV_dba = -Rsb;
+    Mat3 dV_dWsg = -Rsb * SO3::hat(g_);
+    F_.setZero(23, 23);
+    for (int j = 0; j < 3; ++j) {
+      F_(0 + j, 9 + j) = -1;
+      F_(3 + j, 6 + j) = 1;
+      for (int i = 0; i < 3; ++i) {
+        F_(0 + i, 0 + j) = dWsb_dWsb(i, j);
+        F_(6 + i, 0 + j) = dV_dWsb(i, j);
+        F_(6 + i, 12 + j) = dV_dba(i, j);
+        if (j < 2) F_(6 + i, 21 + j) = dV_dWsg(i, j);
+      }
+    }
+    G_.setZero(23, 12);
+    for (int j = 0; j < 3; ++j) {
+      G_(0 + j, j) = -1;
+      G_(9 + j, 6 + j) = 1;
+      G_(12 + j, 9 + j) = 1;
+      for (int i = 0; i < 3; ++i) G_(6 + i, 3 + j) = -Rsb(i, j);
+    }
+  }
+  void RK4Step(const Vec3& gyro0, const Vec3& accel0, double dt) {
+    const int kMotionSize = 23;
+    const int kFullSize = (int)P_.rows();
+    double halfstep = 0.5 * dt;
+    RefState X0;
+    Vec3 K1, K2, K3, K4;
+    MatX FK1, FK2, FK3, FK4, PK1, PK2, PK3, PK4;
+    Eigen::Matrix<double, 6, 1> slope;
+    slope << slope_gyro_, slope_accel_;
+    Eigen::Matrix<double, 6, 1> gyro_accel, gyro_accel0;
+    gyro_accel0 << gyro0, accel0;
+    X0 = X_;
+    K1 = X0.Vsb;
+    ComputeMotionJacobianAt(X0, gyro_accel0);
+    FK1 = F_;
+    MatX P0 = P_.block(0, 0, kMotionSize, kMotionSize);
+    PK1 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+    X0 = X_;
+    gyro_accel = gyro_accel0 + halfstep * slope;
+    ComposeMotion(X0, 0.5 * K1, gyro_accel, halfstep);
+    K2 = X0.Vsb;
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    FK2 = F_ + F_ * FK1 * halfstep;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) + halfstep * PK1;
+    PK2 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+    X0 = X_;
+    gyro_accel = gyro_accel0 + halfstep * slope;
+    ComposeMotion(X0, 0.5 * K2, gyro_accel, halfstep);
+    K3 = X0.Vsb;
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    FK3 = F_ + F_ * FK2 * halfstep;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) + halfstep * PK2;
+    PK3 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+    X0 = X_;
+    gyro_accel = gyro_accel0 + halfstep * slope;
+    ComposeMotion(X0, K3, gyro_accel, dt);
+    K4 = X0.Vsb;
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    FK4 = F_ + F_ * FK3 * dt;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) + dt * PK3;
+    PK4 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+    Vec3 Ktot = (K1 + 2.0 * (K2 + K3) + K4) / 6.0;
+    MatX FK = (FK1 + 2.0 * (FK2 + FK3) + FK4) / 6.0;
+    MatX PK = (PK1 + 2.0 * (PK2 + PK3) + PK4) / 6.0;
+    gyro_accel = gyro_accel0 + dt * slope;
+    ComposeMotion(X_, Ktot, gyro_accel, dt);
+    F_.setIdentity(kMotionSize, kMotionSize);
+    F_ = F_ + FK * dt;
+    P_.block(0, 0, kMotionSize, kMotionSize) = P_.block(0, 0, kMotionSize, kMotionSize) + PK * dt;
+    P_.block(0, kMotionSize, kMotionSize, kFullSize - kMotionSize) =
+        F_ * P_.block(0, kMotionSize, kMotionSize, kFullSize - kMotionSize);
+    P_.block(kMotionSize, 0, kFullSize - kMotionSize, kMotionSize) =
+        P_.block(kMotionSize, 0, kFullSize - kMotionSize, kMotionSize) * F_.transpose();
+  }
+};
+}  // namespace
+
+extern "C" void ref_rk4_step(int N, double* state30, double* P, const double* gyro0, const double* accel0,
+                             const double* slope_gyro, const double* slope_accel, double dt, const double* Qimu,
+                             const double* g_vec) {
+  RefProp r;
+  Mat3 R0 = Eigen::Map<const Mat3>(state30), Rg = Eigen::Map<const Mat3>(state30 + 21);
+  r.X_.Rsb = SO3(Eigen::Quaterniond(R0));
+  r.X_.Rsg = SO3(Eigen::Quaterniond(Rg));
+  r.X_.Tsb = Eigen::Map<const Vec3>(state30 + 9); r.X_.Vsb = Eigen::Map<const Vec3>(state30 + 12);
+  r.X_.bg = Eigen::Map<const Vec3>(state30 + 15); r.X_.ba = Eigen::Map<const Vec3>(state30 + 18);
+  r.P_ = MapMat(P, N, N);
+  r.Qimu_ = MapMat(Qimu, 12, 12);
+  r.g_ = Eigen::Map<const Vec3>(g_vec);
+  r.slope_gyro_ = Eigen::Map<const Vec3>(slope_gyro); r.slope_accel_ = Eigen::Map<const Vec3>(slope_accel);
+  r.Cg.setIdentity(); r.Ca.setIdentity();
+  r.RK4Step(Eigen::Map<const Vec3>(gyro0), Eigen::Map<const Vec3>(accel0), dt);
+  Eigen::Map<Mat3> Ro(state30);
+  Ro = r.X_.Rsb.matrix();
+  (Eigen::Map<Vec3>(state30 + 9)) = r.X_.Tsb; (Eigen::Map<Vec3>(state30 + 12)) = r.X_.Vsb;
+  (MapMatW(P, N, N)) = r.P_;
+}

@@ -142,6 +142,19 @@ class Ref:
                                   _p(Qf) if Qf is not None else None)
         return np.ascontiguousarray(Pf)
 
+    def rk4_step(self, X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec):
+        """X: oracle MotionState. Returns (Rsb, Tsb, Vsb, P_new)."""
+        N = P.shape[0]
+        st = np.concatenate([_F(X.Rsb).reshape(-1, order="F"), X.Tsb, X.Vsb, X.bg, X.ba, _F(X.Rsg).reshape(-1, order="F")])
+        st = np.ascontiguousarray(st, dtype=np.float64)
+        Pf = _F(P).copy(order="F")
+        v = lambda a: _p(np.ascontiguousarray(a, dtype=np.float64))
+        Qf = _F(Qimu)
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (gyro0, accel0, slope_gyro, slope_accel, g_vec)]
+        self.lib.ref_rk4_step(C.c_int(N), _p(st), _p(Pf), _p(keep[0]), _p(keep[1]), _p(keep[2]), _p(keep[3]), C.c_double(dt),
+                              _p(Qf), _p(keep[4]))
+        return st[0:9].reshape(3, 3).T.copy(), st[9:12].copy(), st[12:15].copy(), np.ascontiguousarray(Pf)
+
     def so3_exp(self, w):
         R = np.empty((3, 3), order="F")
         self.lib.ref_so3_exp(_p(np.ascontiguousarray(w, dtype=np.float64)), _p(R))

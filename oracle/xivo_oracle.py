@@ -510,3 +510,108 @@ def p_copy_rc(P, dst, src, n):
 
 def p_set_block3(P, off, P3):
     P = P.copy(); P[off:off + 3, off:off + 3] = P3; return P
+
+
+# ----------------------------------------------------------------------------
+# a11-a14: Estimator::Propagate with the RK4 / Prince-Dormand integrators
+# (src/estimator.cpp:539-704, src/rk4.cpp:5-103, src/princedormand.cpp:7-221),
+# default build (no online IMU calibration: Cg = Ca = I unless given).
+# Both integrators are the same stage recursion with different tableaux, incl.
+# the reference's own conventions (ComposeMotion is handed a_ij-weighted
+# velocities AND the shortened step; RK4's 4th stage samples the IMU at the half
+# step, rk4.cpp:77-79).
+# ----------------------------------------------------------------------------
+class MotionState:
+    """The part of `State` (src/core.h:117-180) that Propagate touches."""
+
+    def __init__(self, Rsb, Tsb, Vsb, bg, ba, Rsg):
+        self.Rsb, self.Tsb, self.Vsb = np.array(Rsb, float), np.array(Tsb, float), np.array(Vsb, float)
+        self.bg, self.ba, self.Rsg = np.array(bg, float), np.array(ba, float), np.array(Rsg, float)
+
+    def copy(self):
+        return MotionState(self.Rsb, self.Tsb, self.Vsb, self.bg, self.ba, self.Rsg)
+
+
+def compose_motion(X, V, gyro, accel, dt, g_vec, Cg=None, Ca=None):
+    """src/estimator.cpp:598-613 (in place)."""
+    Cg = np.eye(3) if Cg is None else Cg
+    Ca = np.eye(3) if Ca is None else Ca
+    gyro_calib = Cg @ gyro - X.bg
+    accel_calib = Ca @ accel - X.ba
+    X.Tsb = X.Tsb + V * dt                                                  # :608
+    X.Vsb = X.Vsb + (X.Rsb @ accel_calib + X.Rsg @ g_vec) * dt              # :609
+    X.Rsb = X.Rsb @ so3_exp(gyro_calib * dt)                                # :610 (normalize(): no-op to rounding)
+
+
+RK4_TABLEAU = dict(
+    a=[[], [0.5], [0.0, 0.5], [0.0, 0.0, 1.0]],
+    c_step=[0.0, 0.5, 0.5, 1.0],
+    c_imu=[0.0, 0.5, 0.5, 0.5],        # rk4.cpp:77: the 4th stage re-uses the half-step IMU sample
+    b=[1 / 6.0, 2 / 6.0, 2 / 6.0, 1 / 6.0])
+PD_TABLEAU = dict(
+    a=[[], [2 / 9.0], [1 / 12.0, 3 / 12.0], [55 / 324.0, -75 / 324.0, 200 / 324.0],
+       [83 / 330.0, -195 / 330.0, 305 / 330.0, 27 / 330.0],
+       [-19 / 28.0, 63 / 28.0, 4 / 28.0, -108 / 28.0, 88 / 28.0],
+       [38 / 400.0, 0.0, 240 / 400.0, -243 / 400.0, 330 / 400.0, 35 / 400.0]],
+    c_step=[0.0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1.0, 1.0],
+    c_imu=[0.0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1.0, 1.0],
+    b=[0.0862, 0.0, 0.6660, -0.7857, 0.9570, 0.0965, -0.0200])       # princedormand.cpp:195-200
+
+
+def integrator_step(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, Cg=None, Ca=None):
+    """One RK4Step (rk4.cpp:35-103) / PrinceDormandStep (princedormand.cpp:85-221).
+    Returns (X_new, P_new)."""
+    nm = K_MOTION
+    Pmm = P[:nm, :nm]
+    Ks, FKs, PKs = [], [], []
+    for i in range(len(tab["b"])):
+        X0 = X.copy()
+        ga = np.concatenate([gyro0, accel0]) + np.concatenate([slope_gyro, slope_accel]) * (tab["c_imu"][i] * dt)
+        if i > 0:
+            V = sum(a * K for a, K in zip(tab["a"][i], Ks))
+            compose_motion(X0, V, ga[:3], ga[3:], tab["c_step"][i] * dt, g_vec, Cg, Ca)
+        F, G = motion_jacobian(X0.Rsb, X0.bg, X0.ba, ga[:3], ga[3:], g_vec, Cg, Ca)
+        Ks.append(X0.Vsb.copy())
+        if i == 0:
+            FK = F.copy(); P0 = Pmm.copy()
+        else:
+            FK = F + F @ sum(a * f for a, f in zip(tab["a"][i], FKs)) * dt
+            P0 = Pmm + sum(a * p for a, p in zip(tab["a"][i], PKs)) * dt
+        FKs.append(FK)
+        PKs.append(F @ P0 + P0 @ F.T + G @ Qimu @ G.T)
+    Kt = sum(b * K for b, K in zip(tab["b"], Ks))
+    FK = sum(b * f for b, f in zip(tab["b"], FKs))
+    PK = sum(b * p for b, p in zip(tab["b"], PKs))
+    Xn = X.copy()
+    compose_motion(Xn, Kt, gyro0 + slope_gyro * dt, accel0 + slope_accel * dt, dt, g_vec, Cg, Ca)
+    Pn, _ = rk4_cov_tail(P, FK, PK, dt)
+    return Xn, Pn
+
+
+def integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, stepsize=0.002, Cg=None, Ca=None):
+    """Fixed sub-stepping with the half-step tail trick (rk4.cpp:13-32, princedormand.cpp:62-81)."""
+    if stepsize < 0:
+        return integrator_step(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, Cg, Ca)
+    total = 0.0
+    gyro, accel = np.array(gyro0, float), np.array(accel0, float)
+    while total < dt:
+        h = stepsize
+        if total + h > dt:
+            h = dt - total
+        elif total + h + 0.5 * h > dt:
+            h = 0.5 * h
+        X, P = integrator_step(X, P, gyro, accel, slope_gyro, slope_accel, h, Qimu, g_vec, tab, Cg, Ca)
+        gyro = gyro + slope_gyro * h
+        accel = accel + slope_accel * h
+        total += h
+    return X, P
+
+
+def propagate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, Qmodel, g_vec, method="RK4", stepsize=0.002):
+    """Estimator::Propagate's integration + P_mm += Qmodel (estimator.cpp:580-590); the IMU
+    slope bookkeeping of :556-575 is the caller's."""
+    tab = RK4_TABLEAU if method == "RK4" else PD_TABLEAU
+    X, P = integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, stepsize)
+    P = P.copy()
+    P[:K_MOTION, :K_MOTION] += Qmodel
+    return X, P

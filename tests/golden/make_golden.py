@@ -96,6 +96,18 @@ def main():
     Q = np.diag(rng.uniform(1e-6, 1e-4, nm))
     g["prop_P"], g["prop_FK"], g["prop_PK"], g["prop_Q"], g["prop_dt"] = P, FK, PK, Q, np.array(0.002)
     g["prop_Pn"] = ref.rk4_cov_tail(P, FK, PK, 0.002, Q)
+    # --- RK4Step (rk4.cpp:35-103) incl. ComposeMotion / ComputeMotionJacobianAt, line-faithful driver
+    N = 41
+    A = rng.uniform(-1, 1, size=(N, N)); P = A @ A.T / N * 1e-3 + 1e-6 * np.eye(N)
+    X = orc.MotionState(orc.so3_exp([0.1, -0.2, 0.3]), [0.1, 0.2, 0.3], [0.5, -0.1, 0.2], [0.01, 0.02, -0.01],
+                        [0.05, -0.02, 0.03], orc.so3_exp([0.01, 0.02, 0.0]))
+    gv = np.array([0.0, 0.0, -9.8]); Qi = np.diag([1e-4] * 3 + [1e-3] * 3 + [1e-6] * 3 + [1e-5] * 3)
+    gy, ac = np.array([0.1, 0.2, -0.1]), np.array([0.3, 0.1, 9.7])
+    sg, sa = np.array([1.0, -2.0, 0.5]), np.array([0.2, 0.1, -0.3])
+    R1, T1, V1, P1 = ref.rk4_step(X, P, gy, ac, sg, sa, 0.002, Qi, gv)
+    for k, v in dict(P=P, Rsb=X.Rsb, Tsb=X.Tsb, Vsb=X.Vsb, bg=X.bg, ba=X.ba, Rsg=X.Rsg, g=gv, Qimu=Qi, gyro=gy, accel=ac, sg=sg,
+                     sa=sa, dt=np.array(0.002), Rn=R1, Tn=T1, Vn=V1, Pn=P1).items():
+        g[f"rk4_{k}"] = v
     # --- Sophus SO3::exp
     w = rng.normal(size=(4, 3)) * 0.5
     g["so3_w"] = w

@@ -48,3 +48,37 @@ def test_update_step_through_cpp_adapter(built, flags):
                                         fix_group_block=bool(flags & 1))
     e_ref, P_ref, _ = orc.update_joseph(H, P, inn, dR)
     assert rel_fro(np.ascontiguousarray(Pio), P_ref) < TOL_P and rel_fro(err, e_ref) < TOL_DX
+
+
+@pytest.mark.parametrize("method,visual", [("RK4", False), ("RK4", True), ("PD", False)])
+def test_propagate_through_cpp_adapter(built, method, visual):
+    """Estimator::Propagate (estimator.cpp:539-592): host stages + device covariance tail."""
+    lib = C.CDLL(os.path.join(ROOT, "xivo_amd", "libxivo_host.so"))
+    N = 203
+    rng = np.random.default_rng(8)
+    P = spd(N, 3) * 1e-3
+    X = orc.MotionState(orc.so3_exp([0.1, -0.2, 0.3]), [0.1, 0.2, 0.3], [0.5, -0.1, 0.2], [0.01, 0.02, -0.01],
+                        [0.05, -0.02, 0.03], orc.so3_exp([0.01, 0.02, 0.0]))
+    gv = np.array([0.0, 0.0, -9.8])
+    Qi = np.diag([1e-4] * 3 + [1e-3] * 3 + [1e-6] * 3 + [1e-5] * 3); Qm = np.diag(rng.uniform(1e-9, 1e-7, 23))
+    last_g, last_a = np.array([0.1, 0.2, -0.1]), np.array([0.3, 0.1, 9.7])
+    curr_g, curr_a = np.array([0.12, 0.19, -0.08]), np.array([0.31, 0.12, 9.69])
+    slope_g, slope_a = np.array([1.0, -2.0, 0.5]), np.array([0.2, 0.1, -0.3])   # from the previous IMU sample
+    dt = 0.005
+    if visual:
+        sg, sa = slope_g, slope_a
+    else:
+        sg, sa = (curr_g - last_g) / dt, (curr_a - last_a) / dt
+    Xe, Pe = orc.propagate(X, P, last_g, last_a, sg, sa, dt, Qi, Qm, gv, method=method)
+    st = np.concatenate([X.Rsb.T.reshape(-1), X.Tsb, X.Vsb, X.bg, X.ba, X.Rsg.T.reshape(-1)]).copy()
+    imu = np.concatenate([last_g, last_a, curr_g, curr_a, slope_g, slope_a]).copy()
+    Pio = np.asfortranarray(P.copy()); msg = C.create_string_buffer(256)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    Qif, Qmf = np.asfortranarray(Qi), np.asfortranarray(Qm)
+    rc = lib.xivo_host_selftest_propagate(N, int(method == "RK4"), int(visual), C.c_double(dt), C.c_double(0.002), p(st), p(Pio),
+                                          p(imu), p(Qif), p(Qmf), p(gv), msg, 256)
+    assert rc == 0, msg.value
+    assert np.abs(st[0:9].reshape(3, 3).T - Xe.Rsb).max() < 1e-13
+    assert np.abs(st[9:12] - Xe.Tsb).max() < 1e-14 and np.abs(st[12:15] - Xe.Vsb).max() < 1e-13
+    assert rel_fro(np.ascontiguousarray(Pio), Pe) < 1e-12          # accumulated-Phi tail == per-sub-step tails
+    assert np.allclose(imu[12:15], sg) and np.allclose(imu[15:18], sa)

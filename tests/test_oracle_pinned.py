@@ -208,3 +208,48 @@ def test_mh_gate_loop_semantics():
     m, rej, th = orc.mh_gate(d, 5.991, 1.1, 4)
     assert m.sum() == 4 and rej == 4 + 3 + 2 and abs(th - 5.991 * 1.1 * 1.1) < 1e-12
     assert orc.mh_gate(d, 5.991, 1.1, 0)[0].sum() == 0   # loop never entered (update.cpp:73)
+
+
+# ---- propagation (a11-a14) ------------------------------------------------------------
+def _rk4_inputs():
+    X = orc.MotionState(G["rk4_Rsb"], G["rk4_Tsb"], G["rk4_Vsb"], G["rk4_bg"], G["rk4_ba"], G["rk4_Rsg"])
+    return X, G["rk4_P"], G["rk4_gyro"], G["rk4_accel"], G["rk4_sg"], G["rk4_sa"], float(G["rk4_dt"]), G["rk4_Qimu"], G["rk4_g"]
+
+
+def test_golden_rk4_step():
+    """Tableau form of the oracle == line-by-line RK4Step on Sophus/Eigen (rk4.cpp:35-103)."""
+    X, P, gy, ac, sg, sa, dt, Qi, gv = _rk4_inputs()
+    Xn, Pn = orc.integrator_step(X, P, gy, ac, sg, sa, dt, Qi, gv, orc.RK4_TABLEAU)
+    assert np.abs(Xn.Rsb - G["rk4_Rn"]).max() < 1e-14 and np.abs(Xn.Tsb - G["rk4_Tn"]).max() < 1e-15
+    assert np.abs(Xn.Vsb - G["rk4_Vn"]).max() < 1e-15 and rel(Pn, G["rk4_Pn"]) < 1e-14
+
+
+def test_prince_dormand_consistent_with_rk4():
+    """Both integrators solve the same ODE: on one 2 ms step they agree to O(h^4)."""
+    X, P, gy, ac, sg, sa, dt, Qi, gv = _rk4_inputs()
+    Xa, Pa = orc.integrator_step(X, P, gy, ac, sg, sa, dt, Qi, gv, orc.RK4_TABLEAU)
+    Xb, Pb = orc.integrator_step(X, P, gy, ac, sg, sa, dt, Qi, gv, orc.PD_TABLEAU)
+    assert np.abs(Xa.Rsb - Xb.Rsb).max() < 1e-8 and np.abs(Xa.Vsb - Xb.Vsb).max() < 1e-6
+    assert rel(Pb, Pa) < 1e-3
+    # Dormand-Prince weights of princedormand.cpp:195-200 sum to 1 (to the 4 printed digits)
+    assert abs(sum(orc.PD_TABLEAU["b"]) - 1.0) < 1e-3 and abs(sum(orc.RK4_TABLEAU["b"]) - 1.0) < 1e-15
+
+
+def test_substepping_half_step_trick():
+    """rk4.cpp:19-31: dt = 5 ms at stepsize 2 ms -> steps 2, 2, 1 ms; 4.5 ms -> 2, 1 (half), 1.5 ms."""
+    X, P, gy, ac, sg, sa, _, Qi, gv = _rk4_inputs()
+    calls = []
+    real = orc.integrator_step
+
+    def spy(X_, P_, g_, a_, sg_, sa_, h, *rest):
+        calls.append(round(h, 6))
+        return real(X_, P_, g_, a_, sg_, sa_, h, *rest)
+    orc.integrator_step = spy
+    try:
+        orc.integrate(X, P, gy, ac, sg, sa, 0.005, Qi, gv, orc.RK4_TABLEAU, 0.002)
+        assert calls == [0.002, 0.002, 0.001]
+        calls.clear()
+        orc.integrate(X, P, gy, ac, sg, sa, 0.0045, Qi, gv, orc.RK4_TABLEAU, 0.002)
+        assert calls == [0.002, 0.001, 0.0015]
+    finally:
+        orc.integrator_step = real

@@ -1,6 +1,7 @@
 // Implementation of the reference-shaped adapter (estimator_hip.h) over the C ABI.
 #include "estimator_hip.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace xivo {
@@ -144,6 +145,184 @@ void Estimator::FilterUpdate() {
   UpdateJosephForm();                                           // :141
 }
 
+// ---------------------------------------------------------------------------
+// Propagation: host stages + device tail
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int NM = 23;   // kMotionSize (src/core.h)
+struct M23 {             // column-major 23x23
+  double v[NM * NM];
+  M23() { std::memset(v, 0, sizeof(v)); }
+  double& operator()(int i, int j) { return v[j * NM + i]; }
+  double operator()(int i, int j) const { return v[j * NM + i]; }
+};
+M23 mul(const M23& a, const M23& b) {
+  M23 c;
+  for (int j = 0; j < NM; ++j)
+    for (int k = 0; k < NM; ++k) {
+      const double bkj = b(k, j);
+      if (bkj == 0.0) continue;
+      for (int i = 0; i < NM; ++i) c(i, j) += a(i, k) * bkj;
+    }
+  return c;
+}
+M23 transpose(const M23& a) { M23 c; for (int i = 0; i < NM; ++i) for (int j = 0; j < NM; ++j) c(i, j) = a(j, i); return c; }
+M23 axpby(double alpha, const M23& a, double beta, const M23& b) { M23 c; for (int e = 0; e < NM * NM; ++e) c.v[e] = alpha * a.v[e] + beta * b.v[e]; return c; }
+Vec3 mulv(const Mat3& R, const Vec3& x) { Vec3 r; for (int i = 0; i < 3; ++i) r(i) = R(i, 0) * x(0) + R(i, 1) * x(1) + R(i, 2) * x(2); return r; }
+Mat3 mulm(const Mat3& a, const Mat3& b) { Mat3 c; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j); return c; }
+Mat3 hat3(const Vec3& w) { Mat3 m; m(0,0)=0; m(0,1)=-w(2); m(0,2)=w(1); m(1,0)=w(2); m(1,1)=0; m(1,2)=-w(0); m(2,0)=-w(1); m(2,1)=w(0); m(2,2)=0; return m; }
+Mat3 so3_exp(const Vec3& w) {   // Sophus::SO3::exp (Rodrigues)
+  const double th = std::sqrt(w(0) * w(0) + w(1) * w(1) + w(2) * w(2));
+  Mat3 W = hat3(w), W2 = mulm(W, W), R;
+  const double a = th < 1e-10 ? 1.0 : std::sin(th) / th, b = th < 1e-10 ? 0.5 : (1 - std::cos(th)) / (th * th);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = (i == j) + a * W(i, j) + b * W2(i, j);
+  return R;
+}
+struct MState { Mat3 Rsb; Vec3 Tsb, Vsb, bg, ba; Mat3 Rsg; };
+struct Tableau { int S; double a[7][7]; double c_step[7], c_imu[7], b[7]; };
+const Tableau kRK4 = {4, {{0}, {0.5}, {0, 0.5}, {0, 0, 1.0}}, {0, 0.5, 0.5, 1.0}, {0, 0.5, 0.5, 0.5},
+                      {1 / 6.0, 2 / 6.0, 2 / 6.0, 1 / 6.0}};                                   // src/rk4.cpp:35-96
+const Tableau kPD = {7,
+                     {{0}, {2 / 9.0}, {1 / 12.0, 3 / 12.0}, {55 / 324.0, -75 / 324.0, 200 / 324.0},
+                      {83 / 330.0, -195 / 330.0, 305 / 330.0, 27 / 330.0},
+                      {-19 / 28.0, 63 / 28.0, 4 / 28.0, -108 / 28.0, 88 / 28.0},
+                      {38 / 400.0, 0, 240 / 400.0, -243 / 400.0, 330 / 400.0, 35 / 400.0}},
+                     {0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1, 1}, {0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1, 1},
+                     {0.0862, 0, 0.6660, -0.7857, 0.9570, 0.0965, -0.0200}};                   // src/princedormand.cpp:85-200
+
+// Estimator::ComposeMotion (src/estimator.cpp:598-613), Cg = Ca = I (default build)
+void ComposeMotion(MState& X, const Vec3& V, const Vec3& gyro, const Vec3& accel, double dt, const Vec3& g) {
+  Vec3 gc, ac;
+  for (int i = 0; i < 3; ++i) { gc(i) = gyro(i) - X.bg(i); ac(i) = accel(i) - X.ba(i); }
+  const Vec3 Ra = mulv(X.Rsb, ac), Rg = mulv(X.Rsg, g);
+  Vec3 w;
+  for (int i = 0; i < 3; ++i) { X.Tsb(i) += V(i) * dt; X.Vsb(i) += (Ra(i) + Rg(i)) * dt; w(i) = gc(i) * dt; }
+  X.Rsb = mulm(X.Rsb, so3_exp(w));
+}
+// Estimator::ComputeMotionJacobianAt (src/estimator.cpp:615-704) -> dense F (23x23), G (23x12)
+void MotionJacobian(const MState& X, const Vec3& gyro, const Vec3& accel, const Vec3& g, M23& F, double G[NM][12]) {
+  Vec3 gc, ac;
+  for (int i = 0; i < 3; ++i) { gc(i) = gyro(i) - X.bg(i); ac(i) = accel(i) - X.ba(i); }
+  const Mat3 hg = hat3(gc), ha = hat3(ac), hgr = hat3(g);
+  const Mat3 dV_dW = mulm(X.Rsb, ha), dV_dWsg = mulm(X.Rsb, hgr);
+  F = M23();
+  std::memset(G, 0, sizeof(double) * NM * 12);
+  for (int j = 0; j < 3; ++j) {
+    F(0 + j, 9 + j) = -1; F(3 + j, 6 + j) = 1;
+    for (int i = 0; i < 3; ++i) {
+      F(0 + i, 0 + j) = -hg(i, j);
+      F(6 + i, 0 + j) = -dV_dW(i, j);
+      F(6 + i, 12 + j) = -X.Rsb(i, j);
+      if (j < 2) F(6 + i, 21 + j) = -dV_dWsg(i, j);
+    }
+    G[0 + j][j] = -1; G[9 + j][6 + j] = 1; G[12 + j][9 + j] = 1;
+    for (int i = 0; i < 3; ++i) G[6 + i][3 + j] = -X.Rsb(i, j);
+  }
+}
+// one RK4Step / PrinceDormandStep on the motion block; Phi_out = I + FK dt
+void IntegratorStep(const Tableau& tb, MState& X, M23& Pmm, M23& Phi_out, const Vec3& gyro0, const Vec3& accel0,
+                    const Vec3& sg, const Vec3& sa, double dt, const MatX& Qimu, const Vec3& g) {
+  Vec3 Ks[7]; M23 FKs[7], PKs[7];
+  for (int i = 0; i < tb.S; ++i) {
+    MState X0 = X;
+    Vec3 gy, ac;
+    for (int c = 0; c < 3; ++c) { gy(c) = gyro0(c) + sg(c) * tb.c_imu[i] * dt; ac(c) = accel0(c) + sa(c) * tb.c_imu[i] * dt; }
+    M23 Fs, Ps;
+    if (i > 0) {
+      Vec3 V;
+      for (int j = 0; j < i; ++j) {
+        for (int c = 0; c < 3; ++c) V(c) += tb.a[i][j] * Ks[j](c);
+        Fs = axpby(1.0, Fs, tb.a[i][j], FKs[j]);
+        Ps = axpby(1.0, Ps, tb.a[i][j], PKs[j]);
+      }
+      ComposeMotion(X0, V, gy, ac, tb.c_step[i] * dt, g);
+    }
+    M23 F; double G[NM][12];
+    MotionJacobian(X0, gy, ac, g, F, G);
+    Ks[i] = X0.Vsb;
+    FKs[i] = i == 0 ? F : axpby(1.0, F, dt, mul(F, Fs));
+    const M23 P0 = i == 0 ? Pmm : axpby(1.0, Pmm, dt, Ps);
+    const M23 FP = mul(F, P0);
+    M23 GQG;
+    for (int r = 0; r < NM; ++r)
+      for (int c = 0; c < NM; ++c) {
+        double s = 0;
+        for (int p = 0; p < 12; ++p) {
+          if (G[r][p] == 0.0) continue;
+          for (int q = 0; q < 12; ++q) s += G[r][p] * Qimu(p, q) * G[c][q];
+        }
+        GQG(r, c) = s;
+      }
+    PKs[i] = axpby(1.0, axpby(1.0, FP, 1.0, mul(P0, transpose(F))), 1.0, GQG);
+  }
+  Vec3 K; M23 FK, PK;
+  for (int i = 0; i < tb.S; ++i) {
+    for (int c = 0; c < 3; ++c) K(c) += tb.b[i] * Ks[i](c);
+    FK = axpby(1.0, FK, tb.b[i], FKs[i]);
+    PK = axpby(1.0, PK, tb.b[i], PKs[i]);
+  }
+  Vec3 gy, ac;
+  for (int c = 0; c < 3; ++c) { gy(c) = gyro0(c) + sg(c) * dt; ac(c) = accel0(c) + sa(c) * dt; }
+  ComposeMotion(X, K, gy, ac, dt, g);
+  Pmm = axpby(1.0, Pmm, dt, PK);
+  Phi_out = M23();
+  for (int i = 0; i < NM; ++i) Phi_out(i, i) = 1.0;
+  Phi_out = axpby(1.0, Phi_out, dt, FK);
+}
+}  // namespace
+
+void Estimator::Propagate(bool visual_meas, number_t dt) {
+  if (dt == 0) return;                                    // estimator.cpp:551-556
+  Vec3 accel0, gyro0;
+  if (!visual_meas) {                                     // :558-568
+    for (int i = 0; i < 3; ++i) {
+      slope_accel_(i) = (curr_accel_(i) - last_accel_(i)) / dt;
+      slope_gyro_(i) = (curr_gyro_(i) - last_gyro_(i)) / dt;
+    }
+    accel0 = last_accel_; gyro0 = last_gyro_;
+    last_accel_ = curr_accel_; last_gyro_ = curr_gyro_;
+  } else {                                                // :569-575
+    accel0 = last_accel_; gyro0 = last_gyro_;
+    for (int i = 0; i < 3; ++i) {
+      last_accel_(i) = accel0(i) + slope_accel_(i) * dt;
+      last_gyro_(i) = gyro0(i) + slope_gyro_(i) * dt;
+    }
+  }
+  const Tableau* tb;
+  if (integration_method_ == "PrinceDormand") tb = &kPD;
+  else if (integration_method_ == "RK4") tb = &kRK4;
+  else throw std::runtime_error("Unknown integration method");        // LOG(FATAL), estimator.cpp:587
+  const int N = lay_.N;
+  MState X{Rsb_, Tsb_, Vsb_, bg_, ba_, Rsg_};
+  M23 Pmm, PhiAcc;
+  for (int i = 0; i < NM; ++i) { PhiAcc(i, i) = 1.0; for (int j = 0; j < NM; ++j) Pmm(i, j) = P_(i, j); }
+  auto one = [&](const Vec3& gy, const Vec3& ac, double h) {
+    M23 Phi;
+    IntegratorStep(*tb, X, Pmm, Phi, gy, ac, slope_gyro_, slope_accel_, h, Qimu_, g_);
+    PhiAcc = mul(Phi, PhiAcc);
+  };
+  if (stepsize_ < 0) {
+    one(gyro0, accel0, dt);
+  } else {                                                // rk4.cpp:16-31 / princedormand.cpp:62-81
+    number_t total = 0;
+    Vec3 gy = gyro0, ac = accel0;
+    while (total < dt) {
+      number_t h = stepsize_;
+      if (total + h > dt) h = dt - total;
+      else if (total + h + 0.5 * h > dt) h = 0.5 * h;     // half step trick
+      one(gy, ac, h);
+      for (int i = 0; i < 3; ++i) { gy(i) += slope_gyro_(i) * h; ac(i) += slope_accel_(i) * h; }
+      total += h;
+    }
+  }
+  for (int i = 0; i < NM; ++i) for (int j = 0; j < NM; ++j) Pmm(i, j) += Qmodel_(i, j);   // estimator.cpp:590
+  Rsb_ = X.Rsb; Tsb_ = X.Tsb; Vsb_ = X.Vsb;
+  // device: P_mm <- Pmm ; P_ms <- Phi P_ms ; P_sm <- P_sm Phi^T  (src/rk4.cpp:92-102, accumulated)
+  Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "upload_P");
+  Check(xivo_hip_propagate_cov(ctx_, 0, 1, NM, PhiAcc.v, Pmm.v), "propagate_cov");
+  Check(xivo_hip_download_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "download_P");
+}
+
 }  // namespace hip
 }  // namespace xivo
 
@@ -188,6 +367,38 @@ extern "C" int xivo_host_selftest_update_step(const xivo_layout* lay, const xivo
     std::memcpy(err_out, est.err_.data(), sizeof(double) * N);
     for (int i = 0; i < F; ++i) inlier_mask_out[i] = fs[i].status() != FeatureStatus::REJECTED_BY_FILTER;
     *num_mh_rejected_out = est.num_mh_rejected_;
+    return 0;
+  } catch (const std::exception& e) {
+    if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }
+    return -1;
+  }
+}
+
+// state30 = [Rsb(9 col-major) Tsb Vsb bg ba Rsg(9)] in/out; imu18 = [last_gyro last_accel curr_gyro curr_accel slope_gyro slope_accel]
+extern "C" int xivo_host_selftest_propagate(int N, int use_rk4, int visual_meas, double dt, double stepsize, double* state30,
+                                            double* P_inout, double* imu18, const double* Qimu, const double* Qmodel,
+                                            const double* g_vec, char* msg, int msg_len) {
+  using namespace xivo::hip;
+  try {
+    xivo_layout lay{N, 23, 1, 29, (N - 29) / 3 > 0 ? (N - 29) / 3 : 1};
+    xivo_cam cam{}; cam.model = XIVO_CAM_PINHOLE; cam.fx = cam.fy = 500; cam.cx = cam.cy = 250; cam.rows = cam.cols = 500;
+    Estimator est(lay, cam, 1, 0);
+    std::memcpy(est.P_.data(), P_inout, sizeof(double) * N * N);
+    std::memcpy(est.Rsb_.v, state30, 72); std::memcpy(est.Tsb_.v, state30 + 9, 24); std::memcpy(est.Vsb_.v, state30 + 12, 24);
+    std::memcpy(est.bg_.v, state30 + 15, 24); std::memcpy(est.ba_.v, state30 + 18, 24); std::memcpy(est.Rsg_.v, state30 + 21, 72);
+    std::memcpy(est.last_gyro_.v, imu18, 24); std::memcpy(est.last_accel_.v, imu18 + 3, 24);
+    std::memcpy(est.curr_gyro_.v, imu18 + 6, 24); std::memcpy(est.curr_accel_.v, imu18 + 9, 24);
+    std::memcpy(est.slope_gyro_.v, imu18 + 12, 24); std::memcpy(est.slope_accel_.v, imu18 + 15, 24);
+    std::memcpy(est.g_.v, g_vec, 24);
+    est.Qimu_.setZero(12, 12); std::memcpy(est.Qimu_.data(), Qimu, sizeof(double) * 144);
+    est.Qmodel_.setZero(23, 23); std::memcpy(est.Qmodel_.data(), Qmodel, sizeof(double) * 529);
+    est.integration_method_ = use_rk4 ? "RK4" : "PrinceDormand";
+    est.stepsize_ = stepsize;
+    est.Propagate(visual_meas != 0, dt);
+    std::memcpy(P_inout, est.P_.data(), sizeof(double) * N * N);
+    std::memcpy(state30, est.Rsb_.v, 72); std::memcpy(state30 + 9, est.Tsb_.v, 24); std::memcpy(state30 + 12, est.Vsb_.v, 24);
+    std::memcpy(imu18, est.last_gyro_.v, 24); std::memcpy(imu18 + 3, est.last_accel_.v, 24);
+    std::memcpy(imu18 + 12, est.slope_gyro_.v, 24); std::memcpy(imu18 + 15, est.slope_accel_.v, 24);
     return 0;
   } catch (const std::exception& e) {
     if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }

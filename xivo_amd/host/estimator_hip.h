@@ -129,7 +129,22 @@ class Estimator {
   std::vector<FeaturePtr> in_current_ekf_update_;
   std::vector<GroupPtr> groups_;   // indexed by slot `sind`
 
+  // ---- propagation members (src/estimator.h: X_, g_, Qimu_, Qmodel_, slope_*, last_/curr_ IMU) ----
+  Vec3 Vsb_, bg_, ba_;     // X_.Vsb, X_.bg, X_.ba (Rsb_/Tsb_/Rbc_/Tbc_ above are the rest of X_)
+  Mat3 Rsg_;               // X_.Rsg
+  Vec3 g_;                 // gravity, src/estimator.cpp:g_
+  MatX Qimu_, Qmodel_;     // 12x12, 23x23 (src/estimator.cpp:590)
+  Vec3 slope_accel_, slope_gyro_, last_accel_, last_gyro_, curr_accel_, curr_gyro_;
+  std::string integration_method_ = "PrinceDormand";   // cfg/tumvi_cam0.json:14
+  number_t stepsize_ = 0.002;                          // RK4.stepsize / PrinceDormand.stepsize
+
   // ---- methods with the reference's names ----
+  // Estimator::Propagate (src/estimator.cpp:539-592). `dt` = curr_time_ - last_time_, which the
+  // reference takes from its message timestamps. The 23x23 stage arithmetic (RK4Step,
+  // PrinceDormandStep, ComputeMotionJacobianAt, ComposeMotion) runs on the host exactly as in
+  // the reference; the O(23 x N) cross-covariance tail (src/rk4.cpp:92-102) and P_mm += Qmodel
+  // run on the device, once per call, with the sub-step transitions accumulated.
+  void Propagate(bool visual_meas, number_t dt);
   void UpdateJosephForm();                 // src/estimator.cpp:1257-1288
   void ComputeInstateJacobians();          // src/update.cpp:24-32
   std::vector<FeaturePtr> MHGating();      // src/update.cpp:50-116
