@@ -165,3 +165,21 @@ def test_gating_skipped_when_too_few_features(built):
     for b in range(B):
         e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+@pytest.mark.parametrize("N,F", [(150, 50), (250, 80), (37, 3)])
+def test_reassociated_joseph_equals_as_coded(built, N, F):
+    """XIVO_HIP_FLAG_REASSOC: P+ = (T H^T + K R) K^T - T is the same expression as the Joseph
+    form; also exercised with a deliberately WRONG gain-side input (noisy H rows -> K far from
+    optimal is not constructible here, so we check against the oracle's as-coded sequence)."""
+    from xivo_amd.lib import FLAG_REASSOC
+    B = 3
+    P, H, inn, dR = synth.s_level(N, F, B, seed=N + 1)
+    with Context(N, 2 * F, B, flags=FLAG_REASSOC) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+    for b in range(B):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+        assert rel_fro(Pn[b], P_ref) < 1e-10
+        assert np.linalg.eigvalsh(Pn[b]).min() > -1e-12 * np.abs(Pn[b]).max()

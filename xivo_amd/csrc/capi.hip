@@ -169,6 +169,7 @@ struct GemmExtra {
   int epi = EPI_NONE;
   const double* diag = nullptr; long sDiag = 0;
   const double* msub = nullptr; long sMsub = 0; int ldmsub = 0;
+  const double* mcol = nullptr; long sMcol = 0;
   double* C2 = nullptr; long sC2 = 0; int ldc2 = 0;
   int lower_only = 0;
 };
@@ -188,10 +189,12 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   g.C = C; g.strideC = sC; g.ldc = ldc; g.Mp = rows; g.Np = cols;
   g.C2 = x.C2; g.strideC2 = x.sC2; g.ldc2 = x.ldc2;
   g.diag = x.diag; g.strideDiag = x.sDiag; g.Msub = x.msub; g.strideMsub = x.sMsub; g.ldmsub = x.ldmsub;
+  g.McolScale = x.mcol; g.strideMcol = x.sMcol;
   g.epilogue = x.epi; g.lower_only = x.lower_only; g.batch = B;
   const double flops = 2.0 * rows * cols * (double)(K0 + (A1 ? K1 : 0)) * B;
   StageTimer st(c, stage, flops);
-  const bool sym = g.lower_only && rows == cols && gemm_sym_supported(rows) && !g.C2 && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
+  const bool sym = g.lower_only && rows == cols && gemm_sym_supported(rows) && !g.C2 &&
+                   (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG) && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
   const int rc = sym ? launch_gemm_sym_f64(g, c->stream) : launch_gemm_nt_f64(g, c->stream);
   return rc == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
 }
@@ -427,6 +430,26 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.batch = B;
     StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B);
     if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  if (c->flags & XIVO_HIP_FLAG_REASSOC) {
+    {  // T = K (HP) - P
+      GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np;
+      rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+                T, c->sP, Np, x);
+      if (rc) return rc;
+    }
+    {  // G = T H^T + K diag(R)   [Np x Mp, kept in the (unused) A buffer]
+      GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = K; x.sMsub = c->sK; x.ldmsub = Np; x.mcol = diagR; x.sMcol = c->Mpmax;
+      rc = gemm(c, ST_KH, B, Np, Mp, T, c->sP, Np, H, c->sH, ldh, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+                A, c->sP, Np, x);
+      if (rc) return rc;
+    }
+    {  // P+ = G K^T - T   (lower triangle + mirror)
+      GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
+      rc = gemm(c, ST_PNEW, B, Np, Np, A, c->sP, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+                P, c->sP, Np, x);
+    }
+    return rc;
   }
   {  // A = K * H - I  (estimator.cpp:1276-1279)
     GemmExtra x; x.epi = EPI_SUB_IDENT;

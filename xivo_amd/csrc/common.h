@@ -52,10 +52,13 @@ struct GemmArgs {
   const double* Msub;  // EPI_SUB_MAT / EPI_ADD_MAT operand, same shape as C
   long strideMsub;
   int ldmsub;
+  const double* McolScale;  // optional per-column scale of Msub (K diag(R))
+  long strideMcol;
   int epilogue;
   int lower_only;      // 1: skip tiles strictly above the diagonal and mirror-store
   int batch;
   int tiles_m, tiles_n;
+  int debug_skip;      // experiments only (XIVO_HIP_SKIP): 1 skip diagonal tiles, 2 skip off-diagonal tiles
 };
 
 // launches on `stream`; returns hipError_t as int

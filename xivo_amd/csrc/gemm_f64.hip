@@ -28,6 +28,7 @@
 // block rows {w, 7-w} of the 8x8 block grid, i.e. exactly 9 of the 36
 // lower-triangle blocks each, so the triangle costs 9/16 of a full tile instead
 // of the 16/16 its busiest wave would otherwise pay.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -94,7 +95,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
       const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[q][r] = sgn * Ms[i + (long)(J0 + lg + 4 * r) * g.ldmsub];
+      for (int r = 0; r < 4; ++r) {
+        const int j = J0 + lg + 4 * r;
+        double v = sgn * Ms[i + (long)j * g.ldmsub];
+        if (g.McolScale) v *= g.McolScale[(long)filt * g.strideMcol + j];
+        acc[q][r] = v;
+      }
     }
   }
 
@@ -272,11 +278,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
   const int filt = (slot / nt) * 8 + xcd;
-  const int tile = slot % nt;
+  // Rotate the tile order from filter to filter: the dispatcher hands consecutive workgroups of an
+  // XCD to its CUs round-robin, so a fixed order pins every "tile 1" to the same quarter of the CUs -
+  // with unequal tiles (symmetric outputs: full, strip and skipped tiles) that serialised the heavy
+  // tiles on 8 of 32 CUs (measured: one off-diagonal tile per filter cost as much as all four).
+  const int tile = (slot + slot / nt) % nt;
   if (filt >= g.batch) return;
   const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   if (g.lower_only && n0 >= m0 + BM) return;  // tile strictly above the diagonal
+  if (g.debug_skip == 1 && m0 == n0) return;   // experiment: skip diagonal tiles
+  if (g.debug_skip == 2 && m0 != n0) return;   // experiment: skip off-diagonal tiles
   const bool inside = (m0 + BM <= g.Mp) && (n0 + BN <= g.Np);
   if constexpr (WM == 4 && WN == 4) {
     if (g.lower_only == 1 && m0 == n0) {
@@ -293,7 +305,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     }
   }
   // interior tile with every block wanted (for lower_only: strictly below the diagonal)
-  if (inside && (!g.lower_only || n0 + BN <= m0)) gemm_tile<WM, WN, BK, false, true, -1>(g, filt, m0, n0, smem);
+  // lower_only == 2: diagonal tiles are computed in full (dense FAST path) and only stored as
+  // lower triangle + mirror
+  if (inside && (!g.lower_only || n0 + BN <= m0 || g.lower_only == 2)) gemm_tile<WM, WN, BK, false, true, -1>(g, filt, m0, n0, smem);
   else gemm_tile<WM, WN, BK, false, false, -1>(g, filt, m0, n0, smem);
 }
 
@@ -327,26 +341,48 @@ int pick_w(int dim) {
 }  // namespace
 
 void gemm_pick_tile(int Mp, int Np, int lower_only, int* WM, int* WN) {
+  if (const char* e = getenv("XIVO_HIP_TILE")) {   // A/B knob: "wm,wn" for square outputs > 176
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && Mp == Np && Mp > 176 && !lower_only) { *WM = a; *WN = b; return; }
+  }
   if (lower_only && Mp > 64) {  // symmetric output: square 128x128 tiles (strip-balanced diagonals)
     *WM = 4;
     *WN = 4;
     return;
   }
-  int wm = pick_w(Mp), wn = pick_w(Np);
-  // accumulator budget: WM*WN <= 20 (160 VGPRs of accumulators)
-  while (wm * wn > 20 || (wm == 4 && wn == 5)) {   // <4,5> spills; <5,4> does not
-    if (wn >= wm) --wn; else --wm;
+  // among the instantiated wave tiles minimise (padded MFMA work) x (1 + 0.5 (1/WM + 1/WN)) - the
+  // second factor stands for operand bytes and per-k-step overhead per flop, which fall with the
+  // tile size; ties go to the larger tile. <4,5> is not built (spills), <5,4> is.
+  static const int cand[][2] = {{2, 2}, {2, 3}, {2, 4}, {2, 5}, {3, 2}, {3, 3}, {3, 4}, {3, 5},
+                                {4, 2}, {4, 3}, {4, 4}, {5, 2}, {5, 3}, {5, 4}};
+  double best_cost = -1;
+  int bw = 2, bn = 2;
+  for (const auto& c : cand) {
+    const long pr = ((Mp + 32 * c[0] - 1) / (32 * c[0])) * 32L * c[0];
+    const long pc = ((Np + 32 * c[1] - 1) / (32 * c[1])) * 32L * c[1];
+    const double cost = (double)pr * pc * (1.0 + 0.5 * (1.0 / c[0] + 1.0 / c[1]));
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && c[0] * c[1] > bw * bn)) {
+      best_cost = cost; bw = c[0]; bn = c[1];
+    }
   }
-  *WM = wm;
-  *WN = wn;
+  *WM = bw;
+  *WN = bn;
 }
 
 int launch_gemm_nt_f64(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
   static const bool no_strip = getenv("XIVO_HIP_NO_STRIP") != nullptr;   // A/B knob
   if (no_strip && a.lower_only) a.lower_only = 2;
+  static const int dbg_skip = getenv("XIVO_HIP_SKIP") ? atoi(getenv("XIVO_HIP_SKIP")) : 0;
+  a.debug_skip = a.lower_only ? dbg_skip : 0;
   int wm, wn;
   gemm_pick_tile(a.Mp, a.Np, a.lower_only, &wm, &wn);
+  // accumulators initialised from memory (T = K(HP) - P): the 64 extra loads per lane sit in the
+  // tile prologue; the narrower 128x64 tile (3 instead of 2 workgroups per CU) hides them
+  // (measured 0.54 vs 0.72 ms per 1024 filters at N=250)
+  if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
+      !getenv("XIVO_HIP_TILE"))
+    wn = 2;
 #define XIVO_GEMM_CASE(M_, N_) \
   if (wm == M_ && wn == N_) return launch_t<M_, N_>(a, stream);
   XIVO_GEMM_CASE(2, 2) XIVO_GEMM_CASE(2, 3) XIVO_GEMM_CASE(2, 4) XIVO_GEMM_CASE(2, 5)

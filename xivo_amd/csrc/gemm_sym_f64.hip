@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_f64_kernel(GemmArgs g, SymGro
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
   const int filt = (slot / ng) * 8 + xcd;
-  const int grp = slot % ng;
+  const int grp = (slot + slot / ng) % ng;   // rotate so unequal groups spread over all CUs
   if (filt >= g.batch) return;
   const int r0 = sg.r0[grp], r1 = sg.r1[grp];
   const int nrows = r1 - r0, ncols = r1;               // in 16-blocks

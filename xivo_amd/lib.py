@@ -9,6 +9,8 @@ OOS_MAX_OBS = 16
 FLAG_FIX_GROUP_BLOCK = 1
 FLAG_PROFILE = 2
 FLAG_FULL_PNEW = 4
+FLAG_TILE_SYM = 8
+FLAG_REASSOC = 16
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
 
