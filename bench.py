@@ -97,13 +97,14 @@ def main():
     flags = (0 if args.no_profile else FLAG_PROFILE) | args.flags
     ctx = Context(N, M, B, device=local_rank, flags=flags)
 
-    # synthetic inputs: 64 distinct seeded filters per rank, tiled to the batch
+    # synthetic inputs: 64 distinct seeded filters per rank, tiled over the batch block by block
+    # (keeps host memory and upload time small; every filter still does the full work)
     uniq = min(B, 64)
     P, H, inn, dR = synth.s_level(N, F, uniq, seed=1000 + rank)
-    reps = (B + uniq - 1) // uniq
-    tile = lambda a: np.concatenate([a] * reps, axis=0)[:B]
-    ctx.upload_P(tile(P))
-    ctx.set_measurements(tile(H), tile(inn), tile(dR))
+    for b0 in range(0, B, uniq):
+        nb = min(uniq, B - b0)
+        ctx.upload_P(P[:nb], b0=b0)
+        ctx.set_measurements(H[:nb], inn[:nb], dR[:nb], b0=b0)
     ctx.snapshot_P()
 
     R_VIS, MH_THRESH, MH_MULT, MIN_INL = 2.25, 5.991, 1.1, 5   # cfg/tumvi_cam0.json / estimator.cpp:366-369

@@ -188,3 +188,47 @@ def test_propagation_tail(built):
         got = ctx.download_P()
     for b in range(B):
         assert rel_fro(got[b], exp[b]) < 1e-14
+
+
+def test_config3_full_size_instate_plus_oos(built):
+    """BASELINE.json config 3 at full size: N=251 (8 groups, 60 in-state features -> 120 rows)
+    + 20 OOS features seen from k=5 groups (7 projected rows each -> 140 rows), M=260."""
+    cam = synth.PINHOLE
+    ng, nf, F, B, n_oos, k = 8, 60, 60, 2, 20, 5
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 6, cam, M_max=2 * F + n_oos * (2 * k - 3))
+    assert lay.N == 251
+    rng = np.random.default_rng(19)
+    oos = np.zeros((B, n_oos), dtype=oos_dtype)
+    obs_all = {}
+    for b in range(B):
+        for o in range(n_oos):
+            Xs = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(3, 6)])
+            gs = rng.permutation(ng)[:k]
+            oos[b, o]["Xs"] = Xs; oos[b, o]["n_obs"] = k
+            obs = []
+            for q, g in enumerate(gs):
+                _, _, inn = orc.oos_jacobian_internal(Xs, sc["gR"][b, g], sc["gT"][b, g], sc["Rbc"][b], sc["Tbc"][b], [0, 0],
+                                                      cam, lay, int(g))
+                pix = -inn + rng.normal(0, 1.0, 2)
+                oos[b, o]["group_sind"][q] = g; oos[b, o]["xp"][q] = pix
+                obs.append((int(g), pix))
+            obs_all[b, o] = (Xs, obs)
+    P = np.array([spd(lay.N, 70 + b) * 1e-4 for b in range(B)])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
+        ctx.jacobians_instate(); ctx.mh_gate(R_VIS, MH, MULT, 5); ctx.stack(R_VIS)
+        rows = ctx.oos_project(oos, 3.5 ** 2)
+        ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+        assert (ctx.get_status() == 0).all()
+    assert rows.tolist() == [140] * B
+    for b in range(B):
+        Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, b)
+        H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][b], sc["sind"][b], lay, R_VIS)
+        for o in range(n_oos):
+            Xs, obs = obs_all[b, o]
+            Hxp, rp, _ = orc.oos_jacobian(Xs, obs, sc["gR"][b], sc["gT"][b], sc["Rbc"][b], sc["Tbc"][b], cam, lay)
+            H = np.vstack([H, Hxp]); inn = np.concatenate([inn, rp]); dR = np.concatenate([dR, np.full(len(rp), 3.5 ** 2)])
+        assert H.shape == (260, 251)
+        e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX

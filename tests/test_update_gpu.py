@@ -183,3 +183,37 @@ def test_reassociated_joseph_equals_as_coded(built, N, F):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
         assert rel_fro(Pn[b], P_ref) < 1e-10
         assert np.linalg.eigvalsh(Pn[b]).min() > -1e-12 * np.abs(Pn[b]).max()
+
+
+def test_size_independent_properties_at_full_batch(built):
+    """Properties that need no oracle, on a full-size batch (N=250, M=160, 512 filters):
+    P+ symmetric PSD, P+ <= P in the Loewner order along H's rows (information only adds),
+    zero innovation -> zero dx, and linearity of dx in the innovation."""
+    N, F, B = 250, 80, 512
+    P1, H1, inn1, dR1 = synth.s_level(N, F, 8, seed=77)
+    tile = lambda a: np.concatenate([a] * (B // 8), axis=0)
+    P, H, dR = tile(P1), tile(H1), tile(dR1)
+    inn = tile(inn1).copy()
+    inn[1::3] *= 2.0          # every third filter: doubled innovation
+    inn[2::3] = 0.0           # every third filter: zero innovation
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+        assert (ctx.get_status() == 0).all()
+    assert np.array_equal(Pn, np.transpose(Pn, (0, 2, 1)))
+    assert np.all(err[2::3] == 0.0)
+    # linearity in the innovation: filters b (x1 class, b % 3 == 0) and b2 (x2 class, b2 % 3 == 1)
+    # built from the same source filter (b % 8 == b2 % 8)
+    checked = 0
+    for b in range(0, 96, 3):
+        b2 = next(c for c in range(b + 1, B) if c % 8 == b % 8 and c % 3 == 1)
+        assert rel_fro(err[b2], 2.0 * err[b]) < 1e-12
+        checked += 1
+    assert checked == 32
+    for b in range(0, B, 61):
+        w = np.linalg.eigvalsh(Pn[b])
+        assert w.min() > -1e-12 * w.max()
+        HPH_before = np.einsum("ij,jk,ik->i", H[b], P[b], H[b]); HPH_after = np.einsum("ij,jk,ik->i", H[b], Pn[b], H[b])
+        assert np.all(HPH_after <= HPH_before * (1 + 1e-9))
+    # covariance update does not depend on the innovation
+    assert rel_fro(Pn[1], Pn[9]) < 1e-13 and rel_fro(Pn[0], Pn[8]) == 0.0

@@ -251,17 +251,17 @@ __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
 }
 
-// LDS-resident variant: the workgroup (8 waves = 128 right-hand-side columns) first
+// LDS-resident variant: the workgroup (16 waves = 256 right-hand-side columns) first
 // copies the whole factor into LDS - the 45..55 lower 16x16 blocks of L, with
 // inv(L_kk) sitting in the diagonal slots - and then every A operand of the
 // forward AND the backward substitution is a conflict-free ds_read_b64 (blocks are
 // stored column-major with a leading dimension of 17 so that both L_ik and its
 // transpose read without bank conflicts). No barrier after the initial copy.
 template <int NBM>
-__global__ __launch_bounds__(512, 2) void trsm_lds_f64_kernel(TrsmArgs g) {
+__global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr int BLK = 16 * 17;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
-  const int chunks = (g.Np + 127) / 128;
+  const int chunks = (g.Np + 255) / 256;
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
   const int filt = (slot / chunks) * 8 + xcd;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void trsm_lds_f64_kernel(TrsmArgs g) {
 
   // cooperative copy: block (i,k), i >= k at slot i(i+1)/2 + k
   const int nblk = nb * (nb + 1) / 2;
-  for (int e = tid; e < nblk * 128; e += 512) {       // 128 = 256 elements / 2 per thread-load
+  for (int e = tid; e < nblk * 128; e += 1024) {      // 128 = 256 elements / 2 per thread-load
     const int t = e >> 7, w = e & 127;
     int i = 0;
     while ((i + 1) * (i + 2) / 2 <= t) ++i;            // block row of slot t (nb <= 24: a few iterations)
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void trsm_lds_f64_kernel(TrsmArgs g) {
     sL[t * BLK + r + 17 * c] = v[0];
     sL[t * BLK + r + 1 + 17 * c] = v[1];
   }
-  const int c0 = chunk * 128 + wave * 16;
+  const int c0 = chunk * 256 + wave * 16;
   const bool live = c0 < g.Np;
 
   d4 X[NBM];
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void trsm_lds_f64_kernel(TrsmArgs g) {
 template <int NBM>
 int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
   const int nb = g.Mp / 16;
-  const int chunks = (g.Np + 127) / 128;
+  const int chunks = (g.Np + 255) / 256;
   const int grid = ((g.batch + 7) / 8) * 8 * chunks;
   const size_t lds = (size_t)nb * (nb + 1) / 2 * 16 * 17 * sizeof(double);
   static bool attr_set = false;
@@ -376,7 +376,7 @@ int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((trsm_lds_f64_kernel<NBM>), dim3(grid), dim3(512), lds, stream, g);
+  hipLaunchKernelGGL((trsm_lds_f64_kernel<NBM>), dim3(grid), dim3(1024), lds, stream, g);
   return (int)hipGetLastError();
 }
 
