@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="filters per GPU")
     ap.add_argument("--state-dim", type=int, default=250)
     ap.add_argument("--features", type=int, default=80)
+    ap.add_argument("--level", choices=["S", "G"], default="S",
+                    help="S (default, the BASELINE metric point): dense H rows resident; G: feature-level path at the "
+                         "constructible layout N=251 (8 groups, 60 features): Jacobians + sparse gating + stacking + update")
     ap.add_argument("--no-gating", action="store_true",
                     help="time UpdateJosephForm only (default: MH gating + UpdateJosephForm, one 'update' of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,24 +96,59 @@ def main():
     from xivo_amd.lib import Context, FLAG_PROFILE, load_library
 
     N, F, B = args.state_dim, args.features, args.batch
-    M = 2 * F
+    R_VIS, MH_THRESH, MH_MULT, MIN_INL = 2.25, 5.991, 1.1, 5   # cfg/tumvi_cam0.json / estimator.cpp:366-369
     flags = (0 if args.no_profile else FLAG_PROFILE) | args.flags
-    ctx = Context(N, M, B, device=local_rank, flags=flags)
-
-    # synthetic inputs: 64 distinct seeded filters per rank, tiled over the batch block by block
-    # (keeps host memory and upload time small; every filter still does the full work)
     uniq = min(B, 64)
-    P, H, inn, dR = synth.s_level(N, F, uniq, seed=1000 + rank)
-    for b0 in range(0, B, uniq):
-        nb = min(uniq, B - b0)
-        ctx.upload_P(P[:nb], b0=b0)
-        ctx.set_measurements(H[:nb], inn[:nb], dR[:nb], b0=b0)
+    if args.level == "G":
+        # layout-faithful scene (SURVEY 8d "G-level"): 8 groups, 60 in-state features -> N = 23 + 48 + 180 = 251
+        ng, nf, F = 8, 60, 60
+        N = 23 + 6 * ng + 3 * nf
+        uniq = min(B, 16)
+        from xivo_amd.lib import pose_dtype, group_dtype, feat_dtype
+        sc = synth.g_level(ng, nf, F, uniq, seed=2000 + rank, cam=synth.EQUI)
+        poses = np.zeros(uniq, dtype=pose_dtype); groups = np.zeros((uniq, ng), dtype=group_dtype)
+        feats = np.zeros((uniq, F), dtype=feat_dtype)
+        cmaj = lambda R: np.asarray(R).T.reshape(-1)
+        for b in range(uniq):
+            poses[b]["Rsb"], poses[b]["Tsb"] = cmaj(sc["Rsb"][b]), sc["Tsb"][b]
+            poses[b]["Rbc"], poses[b]["Tbc"] = cmaj(sc["Rbc"][b]), sc["Tbc"][b]
+            for g_ in range(ng):
+                groups[b, g_]["Rsb"], groups[b, g_]["Tsb"] = cmaj(sc["gR"][b, g_]), sc["gT"][b, g_]
+            feats["x"][b] = sc["x"][b]; feats["ref_sind"][b] = sc["ref"][b]; feats["sind"][b] = sc["sind"][b]
+        M = 2 * F
+        ctx = Context(N, M, B, device=local_rank, flags=flags)
+        ctx.set_layout(N, 23, ng, 23 + 6 * ng, nf, synth.EQUI)
+        rngP = np.random.default_rng(3000 + rank)
+        A_ = rngP.uniform(-1, 1, size=(uniq, N, N))
+        P = (A_ @ np.transpose(A_, (0, 2, 1)) / N + 1e-3 * np.eye(N)[None]) * 1e-4
+        # measured pixel = predicted pixel + N(0, 1.5^2): the prediction comes from the device itself
+        # (first pass with xp = 0 gives inn = -xp_pred), so no CPU model of the camera is involved
+        for b0 in range(0, B, uniq):
+            nb = min(uniq, B - b0)
+            ctx.upload_P(P[:nb], b0=b0)
+            ctx.set_scene(poses[:nb], groups[:nb], feats[:nb], b0=b0)
+        ctx.jacobians_instate(uniq)
+        _, inn0 = ctx.get_jacobians(0, uniq)
+        feats["xp"] = -inn0 + sc["pix_noise"]
+        for b0 in range(0, B, uniq):
+            nb = min(uniq, B - b0)
+            ctx.set_scene(poses[:nb], groups[:nb], feats[:nb], b0=b0)
+    else:
+        M = 2 * F
+        ctx = Context(N, M, B, device=local_rank, flags=flags)
+        # synthetic inputs: 64 distinct seeded filters per rank, tiled over the batch block by block
+        # (keeps host memory and upload time small; every filter still does the full work)
+        P, H, inn, dR = synth.s_level(N, F, uniq, seed=1000 + rank)
+        for b0 in range(0, B, uniq):
+            nb = min(uniq, B - b0)
+            ctx.upload_P(P[:nb], b0=b0)
+            ctx.set_measurements(H[:nb], inn[:nb], dR[:nb], b0=b0)
     ctx.snapshot_P()
 
-    R_VIS, MH_THRESH, MH_MULT, MIN_INL = 2.25, 5.991, 1.1, 5   # cfg/tumvi_cam0.json / estimator.cpp:366-369
-
     def step():
-        if args.no_gating:
+        if args.level == "G":
+            ctx.filter_update(R_VIS, MH_THRESH, MH_MULT, MIN_INL, not args.no_gating, B)
+        elif args.no_gating:
             ctx.update_joseph(B)
         else:
             ctx.update_dense_gated(F, R_VIS, MH_THRESH, MH_MULT, MIN_INL, B)
@@ -165,6 +203,8 @@ def main():
             kname = tile_of(*shape[name]) if name in shape else name
             if name == "gemm_S" and M <= 176:
                 kname = "gemm_sym_f64_kernel<8>"   # whole triangle in one workgroup (block-list kernel)
+            if name == "gemm_AP" and kname == "gemm_nt_f64_kernel<4,4>":
+                kname = "gemm_nt_f64_kernel<4,2>"  # accumulator-initialised GEMMs run on the 128x64 tile
             g = groups.setdefault(kname, {"ms": 0.0, "launches": 0, "flops": 0.0, "stages": []})
             g["ms"] += st["ms"]; g["launches"] += st["launches"]
             g["flops"] += st["flops_per_launch"] * st["launches"]; g["stages"].append(name)
@@ -188,8 +228,12 @@ def main():
                         # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of the
                         # same command (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE); null if absent
                         "traffic": (lambda e: (e.get("hbm_read_bytes_per_launch", 0) + e.get("hbm_write_bytes_per_launch", 0))
-                                    if e and args.batch == 4096 else None)(pmc.get(dom.replace("<", "<").replace(",", ", "))),
+                                    if e and args.batch == 4096 else None)(pmc.get(dom.replace(",", ", "))),
                         "traffic_source": pmc.get("_file"),
+                        # from the same PMC passes: flops the MFMA pipe really executed per launch (symmetry and
+                        # K(HP) - P skip work the reference's as-coded count includes) and pipe busy %
+                        "executed_mfma_flops_per_launch": (pmc.get(dom.replace(",", ", ")) or {}).get("executed_mfma_f64_flops_per_launch"),
+                        "mfma_busy_pct_pmc": (pmc.get(dom.replace(",", ", ")) or {}).get("mfma_busy_pct"),
                         "mfma_peak_measured_tflops": peak_meas,
                         "pipeline_f_alg_tflops": f_alg(N, M) * value / world / 1e12,
                         "pipeline_frac": f_alg(N, M) * value / world / 1e12 / FP64_MFMA_PEAK_TFLOPS}
@@ -198,7 +242,8 @@ def main():
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
+            "config": {"workload": ("feature-level: Jacobians + " if args.level == "G" else "") +
+                                   ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
                                    f": state dim {N}, {F} features (M={M}), XIVO row sparsity, P/H/inn/R resident in HBM",
                        "filters_per_gpu": B, "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
                        "gpu_event_ms_per_step": gpu_ms / args.steps,

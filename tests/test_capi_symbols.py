@@ -43,3 +43,38 @@ def test_no_product_code_touches_the_oracle():
                     if re.search(r"xivo_oracle|ref_binding|oracle/", txt) and "no reference to the oracle" not in txt:
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_create_without_gpu_fails_loudly_not_fatally(built):
+    """No CPU fallback: on a box without a GPU the product reports an error status
+    (and the Python binding raises) instead of computing something else."""
+    import subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import ctypes as C\n"
+        "from xivo_amd.lib import load_library, Context, XivoHipError\n"
+        "lib = load_library()\n"
+        "h = C.c_void_p()\n"
+        "rc = lib.xivo_hip_create(C.byref(h), 0, 64, 16, 2, 0)\n"
+        "if rc == 0:\n"
+        "    lib.xivo_hip_destroy(h); print('HAS_GPU')\n"
+        "else:\n"
+        "    assert rc < 0 and h.value is None\n"
+        "    try:\n"
+        "        Context(64, 16, 2); print('NO_RAISE')\n"
+        "    except XivoHipError as e:\n"
+        "        print('RAISED', e.status)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "HAS_GPU" in out.stdout or "RAISED" in out.stdout
+
+
+def test_invalid_arguments_return_status_codes(built):
+    from xivo_amd.lib import load_library
+    lib = load_library()
+    h = ctypes.c_void_p()
+    assert lib.xivo_hip_create(None, 0, 64, 16, 2, 0) == -1
+    assert lib.xivo_hip_create(ctypes.byref(h), 0, 0, 16, 2, 0) == -1
+    assert lib.xivo_hip_create(ctypes.byref(h), 0, 64, 16 * 30, 2, 0) == -5      # M beyond the solver's register budget
+    assert lib.xivo_hip_sync(None) == -1 and lib.xivo_hip_update_joseph(None, 1) == -1
+    lib.xivo_hip_destroy(None)   # no-op

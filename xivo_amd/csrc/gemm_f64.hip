@@ -341,6 +341,10 @@ int pick_w(int dim) {
 }  // namespace
 
 void gemm_pick_tile(int Mp, int Np, int lower_only, int* WM, int* WN) {
+  if (const char* e = getenv("XIVO_HIP_TILE_RECT")) {   // A/B knob for non-square outputs
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && Mp != Np) { *WM = a; *WN = b; return; }
+  }
   if (const char* e = getenv("XIVO_HIP_TILE")) {   // A/B knob: "wm,wn" for square outputs > 176
     int a = 0, b = 0;
     if (sscanf(e, "%d,%d", &a, &b) == 2 && Mp == Np && Mp > 176 && !lower_only) { *WM = a; *WN = b; return; }
