@@ -615,3 +615,86 @@ def propagate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, Qmodel, g_
     P = P.copy()
     P[:K_MOTION, :K_MOTION] += Qmodel
     return X, P
+
+
+# ----------------------------------------------------------------------------
+# a15: Estimator::AbsorbError (src/estimator.cpp:875-921) with State::operator+=
+# (src/core.h:135-165), SO3xR3::operator+= (src/group.h:25-29), Feature::UpdateState
+# (src/feature.h:220). The periodic SO3 re-normalisation (kEnforceSO3Freq) is a
+# no-op to rounding on orthonormal inputs and is omitted.
+# ----------------------------------------------------------------------------
+def absorb_error(st, err, layout, upd_groups, upd_feats):
+    """st: dict with Rsb,Tsb,Vsb,bg,ba,Rbc,Tbc,Rsg, gR [G,3,3], gT [G,3], x [F,3], sind [F] (modified in place)."""
+    st["Rsb"] = st["Rsb"] @ so3_exp(err[WSB:WSB + 3])
+    st["Tsb"] = st["Tsb"] + err[TSB:TSB + 3]
+    st["Vsb"] = st["Vsb"] + err[VSB:VSB + 3]
+    st["bg"] = st["bg"] + err[BG:BG + 3]
+    st["ba"] = st["ba"] + err[BA:BA + 3]
+    st["Rbc"] = st["Rbc"] @ so3_exp(err[WBC:WBC + 3])
+    st["Tbc"] = st["Tbc"] + err[TBC:TBC + 3]
+    st["Rsg"] = st["Rsg"] @ so3_exp(np.array([err[WSG], err[WSG + 1], 0.0]))
+    for g in upd_groups:                                           # estimator.cpp:897-905
+        off = layout.group_begin + 6 * g
+        st["gR"][g] = st["gR"][g] @ so3_exp(err[off:off + 3])
+        st["gT"][g] = st["gT"][g] + err[off + 3:off + 6]
+    for i in upd_feats:                                            # :906-912
+        off = layout.feature_begin + 3 * int(st["sind"][i])
+        st["x"][i] = st["x"][i] + err[off:off + 3]
+
+
+# ----------------------------------------------------------------------------
+# a7: Estimator::OnePointRANSAC (src/update.cpp:213-393), numeric core for one filter.
+# ----------------------------------------------------------------------------
+def one_point_ransac(st, P, xp, cam, layout, R, ransac_thresh, ransac_chi2, gauge_group, instate_groups,
+                     in_current_ekf_update=()):
+    """st as in absorb_error plus ref [F]. All F features are the MH inliers handed in.
+    Returns dict(inliers=sorted feature indices kept, rejected=..., chi2={feature: distance},
+    low=low-innovation mask, err=dx of the partial update, P_partial=P after it).
+    The hypothesis loop of :238-258 draws k but never uses it: the low-innovation set is
+    simply {f : |xp - pred| < ransac_thresh} (pred == the prediction of ComputeJacobian)."""
+    import copy
+    F = len(xp)
+
+    def jac_all(s):
+        out = []
+        for i in range(F):
+            r = int(s["ref"][i])
+            out.append(compute_jacobian(s["x"][i], xp[i], s["gR"][r], s["gT"][r], s["Rsb"], s["Tsb"], s["Rbc"], s["Tbc"],
+                                        cam, layout, r, int(s["sind"][i]))[:2])
+        return out
+    J0 = jac_all(st)
+    low = np.array([np.linalg.norm(J0[i][1]) < ransac_thresh for i in range(F)])         # :245-249
+    res = dict(low=low, chi2={}, err=None, P_partial=None)
+    if low.all():                                                                          # :263-265
+        res.update(inliers=list(range(F)), rejected=[])
+        return res
+    s2 = copy.deepcopy(st)                                                                 # BackupState :283
+    P2 = P.copy()
+    active_groups = sorted(set(int(g) for g in st["ref"]))
+    groups_low = sorted(set(int(st["ref"][i]) for i in range(F) if low[i]))
+    if low.any():
+        if gauge_group not in groups_low:                                                  # :292-301
+            cov = [sum(P2[layout.group_begin + 6 * g + d, layout.group_begin + 6 * g + d] for d in range(6)) for g in groups_low]
+            tmpref = groups_low[int(np.argmin(cov))]                                       # FindNewRefGroup, estimator.cpp:1394-1407
+            P2 = p_zero_rc(P2, layout.group_begin + 6 * tmpref, 6)
+        for i in range(F):                                                                 # :304-310
+            if not low[i]:
+                P2 = p_zero_rc(P2, layout.feature_begin + 3 * int(st["sind"][i]), 3)
+        for g in active_groups:                                                            # :311-317
+            if g not in groups_low:
+                P2 = p_zero_rc(P2, layout.group_begin + 6 * g, 6)
+        idx = [i for i in range(F) if low[i]]
+        H = np.vstack([J0[i][0] for i in idx])                                             # :326 full J rows (no FillJacobianBlock)
+        inn = np.concatenate([J0[i][1] for i in idx])
+        err, P2, _ = update_joseph(H, P2, inn, np.full(len(inn), R))                       # :332
+        absorb_error(s2, err, layout, instate_groups, in_current_ekf_update)              # :333
+        res["err"], res["P_partial"] = err, P2
+    kept, rejected = [i for i in range(F) if low[i]], []
+    J1 = jac_all(s2)                                                                       # :348 (at the updated state)
+    for i in range(F):
+        if not low[i]:
+            d = mh_distances(J1[i][0][None], P2, J1[i][1][None], R)[0]                     # :352-356
+            res["chi2"][i] = d
+            (kept if d < ransac_chi2 else rejected).append(i)
+    res.update(inliers=sorted(kept), rejected=rejected)                                    # state restored by the caller's copy
+    return res

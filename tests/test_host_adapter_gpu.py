@@ -82,3 +82,34 @@ def test_propagate_through_cpp_adapter(built, method, visual):
     assert np.abs(st[9:12] - Xe.Tsb).max() < 1e-14 and np.abs(st[12:15] - Xe.Vsb).max() < 1e-13
     assert rel_fro(np.ascontiguousarray(Pio), Pe) < 1e-12          # accumulated-Phi tail == per-sub-step tails
     assert np.allclose(imu[12:15], sg) and np.allclose(imu[15:18], sa)
+
+
+def test_one_point_ransac_through_cpp_adapter(built):
+    """Estimator::OnePointRANSAC (update.cpp:213-393) as a composition over the device pieces."""
+    lib = C.CDLL(os.path.join(ROOT, "xivo_amd", "libxivo_host.so"))
+    cam = synth.PINHOLE
+    ng, nf, F = 4, 12, 12
+    sc = synth.g_level(ng, nf, F, 1, seed=5, cam=cam)
+    lay = orc.Layout(ng, nf)
+    poses, groups, feats, xp = scene_arrays(sc, cam)
+    feats["xp"][0, [2, 7]] += [6.0, -5.0]; xp[0, [2, 7]] += [6.0, -5.0]
+    feats["xp"][0, 9] += 90.0; xp[0, 9] += 90.0
+    P = spd(lay.N, 1) * 1e-4
+    st = dict(Rsb=sc["Rsb"][0], Tsb=sc["Tsb"][0], Vsb=np.zeros(3), bg=np.zeros(3), ba=np.zeros(3), Rbc=sc["Rbc"][0],
+              Tbc=sc["Tbc"][0], Rsg=np.eye(3), gR=sc["gR"][0].copy(), gT=sc["gT"][0].copy(), x=sc["x"][0].copy(),
+              sind=sc["sind"][0], ref=sc["ref"][0])
+    exp = orc.one_point_ransac(st, P, xp[0], cam, lay, 2.25, 5.0, 5.89, 0, list(range(ng)))
+    assert (~exp["low"]).sum() == 3 and len(exp["rejected"]) == 2      # the scenario exercises rescue and rejection
+    clay = Layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf)
+    ccam = Cam(); ccam.model, ccam.rows, ccam.cols = cam["model"], cam["rows"], cam["cols"]
+    ccam.fx, ccam.fy, ccam.cx, ccam.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    kept = np.zeros(F, dtype=np.uint8); chi2 = np.zeros(F); nrej = C.c_int(); rerr = C.c_double(); msg = C.create_string_buffer(256)
+    Pf = np.asfortranarray(P)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.xivo_host_selftest_ransac(C.byref(clay), C.byref(ccam), F, p(poses), p(groups), p(feats), p(Pf), C.c_double(2.25),
+                                       C.c_double(5.0), C.c_double(5.89), 0, p(kept), p(chi2), C.byref(nrej), C.byref(rerr), msg, 256)
+    assert rc == 0, msg.value
+    assert sorted(np.nonzero(kept)[0].tolist()) == exp["inliers"] and nrej.value == len(exp["rejected"])
+    for i, d in exp["chi2"].items():
+        assert abs(chi2[i] - d) < 1e-7 * max(1.0, d)
+    assert rerr.value == 0.0          # RestoreState: P_ and the nominal state are bit-identical to the backup

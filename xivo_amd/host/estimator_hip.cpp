@@ -146,6 +146,130 @@ void Estimator::FilterUpdate() {
 }
 
 // ---------------------------------------------------------------------------
+// AbsorbError and OnePointRANSAC (compositions; the heavy parts run on the device)
+// ---------------------------------------------------------------------------
+namespace {
+Mat3 mul3(const Mat3& a, const Mat3& b) { Mat3 c; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j); return c; }
+Mat3 exp3(double wx, double wy, double wz) {   // SO3_from_rotvec / SO3::exp (src/helpers.cpp:374-378)
+  const double th = std::sqrt(wx * wx + wy * wy + wz * wz);
+  Mat3 W; W(0,0)=0; W(0,1)=-wz; W(0,2)=wy; W(1,0)=wz; W(1,1)=0; W(1,2)=-wx; W(2,0)=-wy; W(2,1)=wx; W(2,2)=0;
+  const Mat3 W2 = mul3(W, W);
+  const double a = th < 1e-10 ? 1.0 : std::sin(th) / th, b = th < 1e-10 ? 0.5 : (1 - std::cos(th)) / (th * th);
+  Mat3 R;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = (i == j) + a * W(i, j) + b * W2(i, j);
+  return R;
+}
+void zero_rc(MatX& P, int off, int len) {
+  const int n = P.rows();
+  for (int r = 0; r < len; ++r) for (int t = 0; t < n; ++t) { P(off + r, t) = 0.0; P(t, off + r) = 0.0; }
+}
+}  // namespace
+
+void Estimator::AbsorbError() {
+  // State::operator+= (src/core.h:135-165); the every-50-calls SO3 re-normalisation is a no-op
+  // to rounding on orthonormal inputs and is omitted.
+  Rsb_ = mul3(Rsb_, exp3(err_(0), err_(1), err_(2)));
+  for (int i = 0; i < 3; ++i) { Tsb_(i) += err_(3 + i); Vsb_(i) += err_(6 + i); bg_(i) += err_(9 + i); ba_(i) += err_(12 + i); Tbc_(i) += err_(18 + i); }
+  Rbc_ = mul3(Rbc_, exp3(err_(15), err_(16), err_(17)));
+  Rsg_ = mul3(Rsg_, exp3(err_(21), err_(22), 0.0));
+  for (Group* g : instate_groups_) {                                   // estimator.cpp:897-905
+    const int off = lay_.group_begin + 6 * g->sind();
+    g->Rsb_ = mul3(g->Rsb_, exp3(err_(off), err_(off + 1), err_(off + 2)));
+    for (int i = 0; i < 3; ++i) g->Tsb_(i) += err_(off + 3 + i);
+  }
+  for (Feature* f : in_current_ekf_update_) {                          // :906-912
+    const int off = lay_.feature_begin + 3 * f->sind();
+    for (int i = 0; i < 3; ++i) f->x_(i) += err_(off + i);
+  }
+  err_.setZero(err_.size());                                            // :920
+}
+
+std::vector<FeaturePtr> Estimator::OnePointRANSAC(const std::vector<FeaturePtr>& mh_inliers) {
+  if (mh_inliers.empty()) return mh_inliers;
+  const int n = (int)mh_inliers.size(), size = lay_.N;
+  // update.cpp:238-258: the hypothesis index k is drawn but never used, so the maximal
+  // low-innovation set is {f : |xp - Predict| < ransac_thresh_}; inn() == xp - Predict at this state.
+  std::vector<bool> low(n);
+  int n_low = 0;
+  for (int i = 0; i < n; ++i) {
+    const Vec2& r = mh_inliers[i]->inn();
+    low[i] = std::sqrt(r(0) * r(0) + r(1) * r(1)) < ransac_thresh_;
+    n_low += low[i];
+  }
+  ransac_chi2_.assign(n, -1.0);
+  num_oneptransac_rejected_ = 0;
+  if (n_low == n) return mh_inliers;                                    // :263-265
+  // BackupState (estimator.cpp:1410-1449)
+  const MatX P0 = P_;
+  const Mat3 Rsb0 = Rsb_, Rbc0 = Rbc_, Rsg0 = Rsg_;
+  const Vec3 Tsb0 = Tsb_, Vsb0 = Vsb_, bg0 = bg_, ba0 = ba_, Tbc0 = Tbc_;
+  std::vector<Group> g0; for (Group* g : groups_) g0.push_back(g ? *g : Group());
+  std::vector<Vec3> x0; for (Feature* f : mh_inliers) x0.push_back(f->x_);
+  const std::vector<FeaturePtr> instate0 = instate_features_;
+
+  std::vector<Group*> groups_low, active;
+  auto has = [](const std::vector<Group*>& v, Group* g) { for (Group* q : v) if (q == g) return true; return false; };
+  for (int i = 0; i < n; ++i) {
+    if (!has(active, mh_inliers[i]->ref())) active.push_back(mh_inliers[i]->ref());
+    if (low[i] && !has(groups_low, mh_inliers[i]->ref())) groups_low.push_back(mh_inliers[i]->ref());
+  }
+  if (n_low > 0) {
+    if (!has(groups_low, gauge_group_ptr_)) {                           // :292-301, FindNewRefGroup estimator.cpp:1394-1407
+      Group* best = nullptr; double bestc = 0;
+      for (Group* g : groups_low) {
+        double c = 0; const int off = lay_.group_begin + 6 * g->sind();
+        for (int d = 0; d < 6; ++d) c += P_(off + d, off + d);
+        if (!best || c < bestc) { best = g; bestc = c; }
+      }
+      zero_rc(P_, lay_.group_begin + 6 * best->sind(), 6);
+    }
+    for (int i = 0; i < n; ++i)                                         // :304-310
+      if (!low[i]) zero_rc(P_, lay_.feature_begin + 3 * mh_inliers[i]->sind(), 3);
+    for (Group* g : active)                                             // :311-317
+      if (!has(groups_low, g)) zero_rc(P_, lay_.group_begin + 6 * g->sind(), 6);
+    H_.setZero(2 * n_low, size); inn_.setZero(2 * n_low); diagR_.resize(2 * n_low);
+    int c = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!low[i]) continue;
+      const MatX& J = mh_inliers[i]->J();
+      for (int j = 0; j < size; ++j) { H_(2 * c, j) = J(0, j); H_(2 * c + 1, j) = J(1, j); }   // :326 full row
+      inn_(2 * c) = mh_inliers[i]->inn()(0); inn_(2 * c + 1) = mh_inliers[i]->inn()(1);
+      diagR_(2 * c) = R_; diagR_(2 * c + 1) = R_;
+      ++c;
+    }
+    UpdateJosephForm();                                                 // :332
+    AbsorbError();                                                      // :333
+  }
+  // rescue high-innovation measurements (:338-377): Jacobians at the updated state + chi-square, on the device
+  std::vector<FeaturePtr> hi;
+  for (int i = 0; i < n; ++i) if (!low[i]) hi.push_back(mh_inliers[i]);
+  instate_features_ = hi;
+  ComputeInstateJacobians();
+  Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)size * size, size), "upload_P");
+  std::vector<unsigned char> mask(hi.size());
+  std::vector<double> dist(hi.size());
+  Check(xivo_hip_mh_gate(ctx_, 1, R_, ransac_Chi2_, 1.0, 0, mask.data(), dist.data()), "mh_gate");
+  std::vector<FeaturePtr> output;
+  for (int i = 0; i < n; ++i) if (low[i]) output.push_back(mh_inliers[i]);
+  int h = 0;
+  for (int i = 0; i < n; ++i) {
+    if (low[i]) continue;
+    ransac_chi2_[i] = dist[h];
+    if (dist[h] < ransac_Chi2_) output.push_back(mh_inliers[i]);        // :357-358
+    else { mh_inliers[i]->SetStatus(FeatureStatus::REJECTED_BY_FILTER); ++num_oneptransac_rejected_; }   // :364-367
+    ++h;
+  }
+  // RestoreState + re-compute Jacobians at the original state (:383-387)
+  P_ = P0; Rsb_ = Rsb0; Rbc_ = Rbc0; Rsg_ = Rsg0; Tsb_ = Tsb0; Vsb_ = Vsb0; bg_ = bg0; ba_ = ba0; Tbc_ = Tbc0;
+  for (size_t g = 0; g < groups_.size(); ++g) if (groups_[g]) *groups_[g] = g0[g];
+  for (int i = 0; i < n; ++i) mh_inliers[i]->x_ = x0[i];
+  instate_features_ = mh_inliers;
+  ComputeInstateJacobians();
+  instate_features_ = instate0;
+  return output;
+}
+
+// ---------------------------------------------------------------------------
 // Propagation: host stages + device tail
 // ---------------------------------------------------------------------------
 namespace {
@@ -399,6 +523,50 @@ extern "C" int xivo_host_selftest_propagate(int N, int use_rk4, int visual_meas,
     std::memcpy(state30, est.Rsb_.v, 72); std::memcpy(state30 + 9, est.Tsb_.v, 24); std::memcpy(state30 + 12, est.Vsb_.v, 24);
     std::memcpy(imu18, est.last_gyro_.v, 24); std::memcpy(imu18 + 3, est.last_accel_.v, 24);
     std::memcpy(imu18 + 12, est.slope_gyro_.v, 24); std::memcpy(imu18 + 15, est.slope_accel_.v, 24);
+    return 0;
+  } catch (const std::exception& e) {
+    if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }
+    return -1;
+  }
+}
+
+extern "C" int xivo_host_selftest_ransac(const xivo_layout* lay, const xivo_cam* cam, int F, const xivo_pose_in* pose,
+                                         const xivo_group_in* groups, const xivo_feat_in* feats, const double* P_in, double R,
+                                         double ransac_thresh, double ransac_chi2, int gauge_group,
+                                         unsigned char* kept_out, double* chi2_out, int* num_rejected_out,
+                                         double* restore_err_out, char* msg, int msg_len) {
+  using namespace xivo::hip;
+  try {
+    Estimator est(*lay, *cam, F, 0);
+    const int N = lay->N;
+    std::memcpy(est.P_.data(), P_in, sizeof(double) * N * N);
+    std::memcpy(est.Rsb_.v, pose->Rsb, 72); std::memcpy(est.Tsb_.v, pose->Tsb, 24);
+    std::memcpy(est.Rbc_.v, pose->Rbc, 72); std::memcpy(est.Tbc_.v, pose->Tbc, 24);
+    est.R_ = R; est.ransac_thresh_ = ransac_thresh; est.ransac_Chi2_ = ransac_chi2;
+    std::vector<Group> gs(lay->n_groups);
+    for (int g = 0; g < lay->n_groups; ++g) {
+      std::memcpy(gs[g].Rsb_.v, groups[g].Rsb, 72); std::memcpy(gs[g].Tsb_.v, groups[g].Tsb, 24);
+      gs[g].sind_ = g; est.groups_[g] = &gs[g]; est.instate_groups_.push_back(&gs[g]);
+    }
+    est.gauge_group_ptr_ = &gs[gauge_group];
+    std::vector<Feature> fs(F);
+    std::vector<FeaturePtr> all;
+    for (int i = 0; i < F; ++i) {
+      std::memcpy(fs[i].x_.v, feats[i].x, 24); std::memcpy(fs[i].back_.v, feats[i].xp, 16);
+      fs[i].ref_ = &gs[feats[i].ref_sind]; fs[i].sind_ = feats[i].sind;
+      all.push_back(&fs[i]);
+    }
+    est.instate_features_ = all;
+    est.ComputeInstateJacobians();
+    std::vector<FeaturePtr> out = est.OnePointRANSAC(all);
+    for (int i = 0; i < F; ++i) { kept_out[i] = 0; chi2_out[i] = est.ransac_chi2_.empty() ? -1.0 : est.ransac_chi2_[i]; }
+    for (FeaturePtr f : out) kept_out[f - &fs[0]] = 1;
+    *num_rejected_out = est.num_oneptransac_rejected_;
+    double e = 0;
+    for (int i = 0; i < N * N; ++i) e = std::fmax(e, std::fabs(est.P_.data()[i] - P_in[i]));
+    for (int i = 0; i < 9; ++i) e = std::fmax(e, std::fabs(est.Rsb_.v[i] - pose->Rsb[i]));
+    for (int g = 0; g < lay->n_groups; ++g) for (int i = 0; i < 3; ++i) e = std::fmax(e, std::fabs(gs[g].Tsb_.v[i] - groups[g].Tsb[i]));
+    *restore_err_out = e;
     return 0;
   } catch (const std::exception& e) {
     if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }

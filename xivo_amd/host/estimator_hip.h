@@ -149,6 +149,16 @@ class Estimator {
   void ComputeInstateJacobians();          // src/update.cpp:24-32
   std::vector<FeaturePtr> MHGating();      // src/update.cpp:50-116
   void FilterUpdate();                     // src/update.cpp:120-153 (AbsorbError is left to the caller)
+  void AbsorbError();                      // src/estimator.cpp:875-921 (host, O(N))
+  // Estimator::OnePointRANSAC (src/update.cpp:213-393): a composition of the pieces above -
+  // low-innovation set, BackupState, P row/col zeroing, partial UpdateJosephForm on the full J
+  // rows, AbsorbError, re-Jacobians + chi-square rescue on the device, RestoreState.
+  std::vector<FeaturePtr> OnePointRANSAC(const std::vector<FeaturePtr>& mh_inliers);
+  number_t ransac_thresh_ = 5, ransac_Chi2_ = 5.89;        // src/estimator.cpp:132-134
+  GroupPtr gauge_group_ptr_ = nullptr;
+  std::vector<GroupPtr> instate_groups_;   // groups AbsorbError retracts (src/manager.cpp:103)
+  int num_oneptransac_rejected_ = 0;
+  std::vector<number_t> ransac_chi2_;      // chi-square distances of the rescue step (for tests/diagnostics)
   // host edits of P_ stay plain host code on the authoritative host copy
 
   const xivo_layout& layout() const { return lay_; }
