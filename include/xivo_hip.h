@@ -120,6 +120,8 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
 void xivo_hip_destroy(xivo_hip_ctx* ctx);
 const char* xivo_hip_strerror(int status);
 int xivo_hip_sync(xivo_hip_ctx* ctx);
+/* number of visible HIP devices (0 if none / on error) */
+int xivo_hip_device_count(void);
 int xivo_hip_set_flags(xivo_hip_ctx* ctx, unsigned flags);
 
 /* ---- covariance residency (Estimator::P_, src/estimator.h:423; a17) --- */

@@ -262,6 +262,12 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   return XIVO_HIP_OK;
 }
 
+int xivo_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
 int xivo_hip_sync(xivo_hip_ctx* c) {
   if (!c) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipStreamSynchronize(c->stream));

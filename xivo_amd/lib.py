@@ -95,7 +95,7 @@ _SIGS = {
     "xivo_hip_bench_mfma_peak": [C.c_void_p, C.POINTER(C.c_double)],
 }
 # every symbol include/xivo_hip.h declares (tests check the library exports them all)
-ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile"])
+ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile", "xivo_hip_device_count"])
 
 
 def load_library():
@@ -113,6 +113,8 @@ def load_library():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.xivo_hip_device_count.argtypes = []
+    lib.xivo_hip_device_count.restype = C.c_int
     lib.xivo_hip_destroy.argtypes = [C.c_void_p]
     lib.xivo_hip_destroy.restype = None
     lib.xivo_hip_strerror.argtypes = [C.c_int]
