@@ -113,3 +113,98 @@ def test_one_point_ransac_through_cpp_adapter(built):
     for i, d in exp["chi2"].items():
         assert abs(chi2[i] - d) < 1e-7 * max(1.0, d)
     assert rerr.value == 0.0          # RestoreState: P_ and the nominal state are bit-identical to the backup
+
+
+def test_multi_frame_sequence_replay(built):
+    """Four camera frames of one filter through the adapter - IMU propagation (Dormand-Prince), Jacobians,
+    MH gating, stacking with the FillJacobianBlock quirk, Joseph update, AbsorbError, state feedback -
+    against the same flow assembled from the oracle pieces. Parity is asserted on the final P and state."""
+    from xivo_amd.lib import group_dtype, feat_dtype
+    lib = C.CDLL(os.path.join(ROOT, "xivo_amd", "libxivo_host.so"))
+    cam = synth.PINHOLE
+    ng, nf, F, T, n_imu, dt = 4, 10, 10, 4, 4, 0.0025
+    sc = synth.g_level(ng, nf, F, 1, seed=31, cam=cam)
+    lay = orc.Layout(ng, nf); N = lay.N
+    rng = np.random.default_rng(4)
+    P0 = spd(N, 9) * 1e-4
+    gv = np.array([0.0, 0.0, -9.8])
+    Rsg = orc.so3_exp([0.01, -0.02, 0.0])
+    st = dict(Rsb=sc["Rsb"][0].copy(), Tsb=sc["Tsb"][0].copy(), Vsb=np.array([0.02, -0.01, 0.01]), bg=np.array([1e-3, -2e-3, 1e-3]),
+              ba=np.array([0.02, 0.01, -0.01]), Rbc=sc["Rbc"][0].copy(), Tbc=sc["Tbc"][0].copy(), Rsg=Rsg, gR=sc["gR"][0].copy(),
+              gT=sc["gT"][0].copy(), x=sc["x"][0].copy(), sind=sc["sind"][0], ref=sc["ref"][0])
+    hover = -(st["Rsb"].T @ Rsg @ gv) + st["ba"]
+    imu = np.empty((T, n_imu, 6))
+    imu[..., :3] = st["bg"] + rng.normal(0, 0.02, size=(T, n_imu, 3))
+    imu[..., 3:] = hover + rng.normal(0, 0.05, size=(T, n_imu, 3))
+    pix = np.empty((T, F, 2))
+    for t in range(T):
+        for i in range(F):
+            Xcn = sc["Xcn"][0, i]
+            pix[t, i] = orc.camera_project(cam, Xcn[:2] / Xcn[2])[0] + rng.normal(0, 1.0, 2)
+    pix[1, 3] += 70.0                                    # one gross outlier in frame 1
+    Qi = np.diag([1e-4] * 3 + [1e-3] * 3 + [1e-6] * 3 + [1e-5] * 3); Qm = np.diag(rng.uniform(1e-9, 1e-7, 23))
+
+    # ---- oracle flow
+    s = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+    P = P0.copy()
+    last_g, last_a = imu[0, 0, :3].copy(), imu[0, 0, 3:].copy()
+    sg, sa = np.zeros(3), np.zeros(3)
+    alive = np.ones(F, dtype=bool)
+    n_inl = []
+
+    def prop(dtv, g0, a0):
+        nonlocal P
+        X = orc.MotionState(s["Rsb"], s["Tsb"], s["Vsb"], s["bg"], s["ba"], s["Rsg"])
+        Xn, P = orc.propagate(X, P, g0, a0, sg, sa, dtv, Qi, Qm, gv, method="PD")
+        s["Rsb"], s["Tsb"], s["Vsb"] = Xn.Rsb, Xn.Tsb, Xn.Vsb
+    for t in range(T):
+        for k in range(n_imu):
+            cg, ca = imu[t, k, :3], imu[t, k, 3:]
+            if t == 0 and k == 0:
+                continue
+            sg, sa = (cg - last_g) / dt, (ca - last_a) / dt
+            prop(dt, last_g, last_a)
+            last_g, last_a = cg.copy(), ca.copy()
+        prop(0.5 * dt, last_g, last_a)
+        last_g, last_a = last_g + sg * 0.5 * dt, last_a + sa * 0.5 * dt
+        idx = [i for i in range(F) if alive[i]]
+        JI = [orc.compute_jacobian(s["x"][i], pix[t, i], s["gR"][int(s["ref"][i])], s["gT"][int(s["ref"][i])], s["Rsb"], s["Tsb"],
+                                   s["Rbc"], s["Tbc"], cam, lay, int(s["ref"][i]), int(s["sind"][i]))[:2] for i in idx]
+        Js = np.array([j for j, _ in JI]); inns = np.array([r for _, r in JI])
+        m = orc.mh_gate(orc.mh_distances(Js, P, inns, 2.25), 5.991, 1.1, 5)[0] if len(idx) > 5 else np.ones(len(idx), bool)
+        keep = [idx[q] for q in range(len(idx)) if m[q]]
+        n_inl.append(len(keep))
+        H, inn, dR = orc.stack_measurements(Js[m], inns[m], [s["ref"][i] for i in keep], [s["sind"][i] for i in keep], lay, 2.25)
+        err, P, _ = orc.update_joseph(H, P, inn, dR)
+        orc.absorb_error(s, err, lay, list(range(ng)), keep)
+        for q, i in enumerate(idx):
+            if not m[q]:
+                alive[i] = False
+                P = orc.p_zero_rc(P, lay.feature_begin + 3 * int(s["sind"][i]), 3)
+    assert n_inl[1] == F - 1 and not alive[3]
+
+    # ---- adapter flow
+    _, groups, feats, _ = scene_arrays(sc, cam)
+    state30 = np.concatenate([st["Rsb"].T.reshape(-1), st["Tsb"], st["Vsb"], st["bg"], st["ba"], Rsg.T.reshape(-1)]).copy()
+    Pio = np.asfortranarray(P0.copy()); inl = np.zeros(T, dtype=np.int32); msg = C.create_string_buffer(256)
+    clay = Layout(N, lay.group_begin, ng, lay.feature_begin, nf)
+    ccam = Cam(); ccam.model, ccam.rows, ccam.cols = cam["model"], cam["rows"], cam["cols"]
+    ccam.fx, ccam.fy, ccam.cx, ccam.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    g_io = np.ascontiguousarray(groups[0]); f_io = np.ascontiguousarray(feats[0])
+    Rbc_cm = np.ascontiguousarray(st["Rbc"].T.reshape(-1)); Tbc = np.ascontiguousarray(st["Tbc"])
+    imu_c, pix_c = np.ascontiguousarray(imu), np.ascontiguousarray(pix)
+    Qif, Qmf = np.asfortranarray(Qi), np.asfortranarray(Qm)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.xivo_host_selftest_sequence(C.byref(clay), C.byref(ccam), F, T, n_imu, C.c_double(dt), p(imu_c), p(pix_c), p(state30),
+                                         p(g_io), p(f_io), p(Rbc_cm), p(Tbc), p(Pio), p(Qif), p(Qmf), p(gv), 0, C.c_double(2.25),
+                                         p(inl), msg, 256)
+    assert rc == 0, msg.value
+    assert inl.tolist() == n_inl
+    assert rel_fro(np.ascontiguousarray(Pio), P) < TOL_P
+    assert np.abs(state30[0:9].reshape(3, 3).T - s["Rsb"]).max() < 1e-9
+    assert np.abs(state30[9:12] - s["Tsb"]).max() < 1e-9 and np.abs(state30[12:15] - s["Vsb"]).max() < 1e-9
+    assert np.abs(state30[15:18] - s["bg"]).max() < 1e-10 and np.abs(state30[18:21] - s["ba"]).max() < 1e-10
+    for g_ in range(ng):
+        assert np.abs(np.asarray(g_io[g_]["Tsb"]) - s["gT"][g_]).max() < 1e-9
+    for i in range(F):
+        assert np.abs(np.asarray(f_io[i]["x"]) - s["x"][i]).max() < 1e-8

@@ -573,3 +573,78 @@ extern "C" int xivo_host_selftest_ransac(const xivo_layout* lay, const xivo_cam*
     return -1;
   }
 }
+
+// Multi-frame replay of the per-frame numeric flow of the reference for ONE filter:
+//   per frame: `n_imu` x Propagate(false) + Propagate(true) (src/estimator.cpp:475-592,1122),
+//   ComputeInstateJacobians -> MHGating -> FilterUpdate -> AbsorbError (src/manager.cpp:72-104, update.cpp:145).
+// imu: [n_frames][n_imu][6] (gyro, accel) samples, dt_imu between them; pixels: [n_frames][F][2].
+// Outputs the final P, the final nominal motion state (30), group poses and feature states.
+extern "C" int xivo_host_selftest_sequence(const xivo_layout* lay, const xivo_cam* cam, int F, int n_frames, int n_imu,
+                                           double dt_imu, const double* imu, const double* pixels, double* state30,
+                                           xivo_group_in* groups_io, xivo_feat_in* feats_io, const double* Rbc,
+                                           const double* Tbc, double* P_inout, const double* Qimu, const double* Qmodel,
+                                           const double* g_vec, int use_rk4, double R, int* inliers_per_frame, char* msg,
+                                           int msg_len) {
+  using namespace xivo::hip;
+  try {
+    Estimator est(*lay, *cam, F, 0);
+    const int N = lay->N;
+    std::memcpy(est.P_.data(), P_inout, sizeof(double) * N * N);
+    std::memcpy(est.Rsb_.v, state30, 72); std::memcpy(est.Tsb_.v, state30 + 9, 24); std::memcpy(est.Vsb_.v, state30 + 12, 24);
+    std::memcpy(est.bg_.v, state30 + 15, 24); std::memcpy(est.ba_.v, state30 + 18, 24); std::memcpy(est.Rsg_.v, state30 + 21, 72);
+    std::memcpy(est.Rbc_.v, Rbc, 72); std::memcpy(est.Tbc_.v, Tbc, 24);
+    std::memcpy(est.g_.v, g_vec, 24);
+    est.Qimu_.setZero(12, 12); std::memcpy(est.Qimu_.data(), Qimu, sizeof(double) * 144);
+    est.Qmodel_.setZero(23, 23); std::memcpy(est.Qmodel_.data(), Qmodel, sizeof(double) * 529);
+    est.integration_method_ = use_rk4 ? "RK4" : "PrinceDormand";
+    est.R_ = R;
+    std::vector<Group> gs(lay->n_groups);
+    for (int g = 0; g < lay->n_groups; ++g) {
+      std::memcpy(gs[g].Rsb_.v, groups_io[g].Rsb, 72); std::memcpy(gs[g].Tsb_.v, groups_io[g].Tsb, 24);
+      gs[g].sind_ = g; est.groups_[g] = &gs[g]; est.instate_groups_.push_back(&gs[g]);
+    }
+    std::vector<Feature> fs(F);
+    for (int i = 0; i < F; ++i) {
+      std::memcpy(fs[i].x_.v, feats_io[i].x, 24);
+      fs[i].ref_ = &gs[feats_io[i].ref_sind]; fs[i].sind_ = feats_io[i].sind;
+    }
+    std::memcpy(est.last_gyro_.v, imu, 24); std::memcpy(est.last_accel_.v, imu + 3, 24);
+    for (int t = 0; t < n_frames; ++t) {
+      for (int k = 0; k < n_imu; ++k) {
+        const double* s = imu + ((size_t)t * n_imu + k) * 6;
+        std::memcpy(est.curr_gyro_.v, s, 24); std::memcpy(est.curr_accel_.v, s + 3, 24);
+        if (t == 0 && k == 0) continue;                 // the first sample only seeds last_*
+        est.Propagate(false, dt_imu);
+      }
+      est.Propagate(true, 0.5 * dt_imu);                // the image arrives half an IMU period later
+      est.instate_features_.clear();
+      for (int i = 0; i < F; ++i) {
+        if (fs[i].status() == FeatureStatus::REJECTED_BY_FILTER) continue;   // removed from the state by the caller
+        std::memcpy(fs[i].back_.v, pixels + ((size_t)t * F + i) * 2, 16);
+        est.instate_features_.push_back(&fs[i]);
+      }
+      est.ComputeInstateJacobians();
+      std::vector<FeaturePtr> inl = ((int)est.instate_features_.size() > est.min_required_inliers_)
+                                        ? est.MHGating() : est.instate_features_;
+      inliers_per_frame[t] = (int)inl.size();
+      est.in_current_ekf_update_ = inl;
+      est.FilterUpdate();
+      est.AbsorbError();
+      // RemoveFeatureFromState for rejected ones (src/estimator.cpp:762-783): host edit of the authoritative P_
+      for (int i = 0; i < F; ++i)
+        if (fs[i].status() == FeatureStatus::REJECTED_BY_FILTER) {
+          const int off = lay->feature_begin + 3 * fs[i].sind();
+          for (int r = 0; r < 3; ++r) for (int q = 0; q < N; ++q) { est.P_(off + r, q) = 0.0; est.P_(q, off + r) = 0.0; }
+        }
+    }
+    std::memcpy(P_inout, est.P_.data(), sizeof(double) * N * N);
+    std::memcpy(state30, est.Rsb_.v, 72); std::memcpy(state30 + 9, est.Tsb_.v, 24); std::memcpy(state30 + 12, est.Vsb_.v, 24);
+    std::memcpy(state30 + 15, est.bg_.v, 24); std::memcpy(state30 + 18, est.ba_.v, 24); std::memcpy(state30 + 21, est.Rsg_.v, 72);
+    for (int g = 0; g < lay->n_groups; ++g) { std::memcpy(groups_io[g].Rsb, gs[g].Rsb_.v, 72); std::memcpy(groups_io[g].Tsb, gs[g].Tsb_.v, 24); }
+    for (int i = 0; i < F; ++i) std::memcpy(feats_io[i].x, fs[i].x_.v, 24);
+    return 0;
+  } catch (const std::exception& e) {
+    if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }
+    return -1;
+  }
+}
