@@ -21,11 +21,11 @@ namespace xivo_hip {
 
 namespace {
 
-constexpr int NS = 18;        // slots per wave -> up to 72 blocks per workgroup
+constexpr int NS_MAX = 18;    // slots per wave -> up to 72 blocks per workgroup
 constexpr int ROWS_MAX = 12;  // block rows per group
 constexpr int COLS_MAX = 16;  // block cols (output <= 256)
 
-template <int BK>
+template <int BK, int NS>
 __global__ __launch_bounds__(256, 2) void gemm_sym_f64_kernel(GemmArgs g, SymGroups sg) {
   constexpr int RA_MAX = ROWS_MAX * BK / 32, RB_MAX = COLS_MAX * BK / 32;   // 16-byte loads per thread per panel
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -184,7 +184,7 @@ int launch_gemm_sym_f64(const GemmArgs& a, hipStream_t stream) {
   const int nb = a.Mp / 16;
   if (!gemm_sym_supported(a.Mp) || a.Mp != a.Np) return (int)hipErrorInvalidValue;
   // cut block rows into groups of <= 4*NS blocks and <= 2*RA_MAX rows, as evenly as possible
-  const int cap = 4 * NS, total = nb * (nb + 1) / 2;
+  const int cap = 4 * NS_MAX, total = nb * (nb + 1) / 2;
   int ngroups = (total + cap - 1) / cap;
   SymGroups sg;
   for (;; ++ngroups) {
@@ -203,7 +203,15 @@ int launch_gemm_sym_f64(const GemmArgs& a, hipStream_t stream) {
     }
     if (ok && r == nb) { sg.n = gi; break; }
   }
-  static const int bk = getenv("XIVO_HIP_SYM_BK") ? atoi(getenv("XIVO_HIP_SYM_BK")) : 8;   // 8: no spills (220 VGPRs)
+  static const int bk_env = getenv("XIVO_HIP_SYM_BK") ? atoi(getenv("XIVO_HIP_SYM_BK")) : 0;   // A/B knob
+  // panel depth: 16 when <= 14 slots per wave suffice (252 VGPRs, no spills; 0.258 vs 0.273 ms for the
+  // 160x160 S), else 8 (with 18 slots BK = 16 spills)
+  int max_blocks0 = 0;
+  for (int gi = 0; gi < sg.n; ++gi) {
+    const int cnt = sg.r1[gi] * (sg.r1[gi] + 1) / 2 - sg.r0[gi] * (sg.r0[gi] + 1) / 2;
+    if (cnt > max_blocks0) max_blocks0 = cnt;
+  }
+  const int bk = bk_env ? bk_env : (max_blocks0 <= 56 ? 16 : 8);
   int max_lds = 0;
   for (int gi = 0; gi < sg.n; ++gi) {
     const int nr = sg.r1[gi] - sg.r0[gi], nc = sg.r1[gi];
@@ -213,8 +221,18 @@ int launch_gemm_sym_f64(const GemmArgs& a, hipStream_t stream) {
     if (bytes > max_lds) max_lds = bytes;
   }
   const int grid = ((a.batch + 7) / 8) * 8 * sg.n;
-  if (bk == 8) hipLaunchKernelGGL(gemm_sym_f64_kernel<8>, dim3(grid), dim3(256), max_lds, stream, a, sg);
-  else hipLaunchKernelGGL(gemm_sym_f64_kernel<16>, dim3(grid), dim3(256), max_lds, stream, a, sg);
+  // slots per wave actually needed by the largest group: 14 (<= 56 blocks, e.g. the 160x160 S) frees
+  // 32 accumulator VGPRs, which is what lets the BK = 16 panel depth run without spills
+  int max_blocks = 0;
+  for (int gi = 0; gi < sg.n; ++gi) {
+    const int cnt = sg.r1[gi] * (sg.r1[gi] + 1) / 2 - sg.r0[gi] * (sg.r0[gi] + 1) / 2;
+    if (cnt > max_blocks) max_blocks = cnt;
+  }
+  const bool small = max_blocks <= 56;
+  if (small && bk == 16) hipLaunchKernelGGL((gemm_sym_f64_kernel<16, 14>), dim3(grid), dim3(256), max_lds, stream, a, sg);
+  else if (small) hipLaunchKernelGGL((gemm_sym_f64_kernel<8, 14>), dim3(grid), dim3(256), max_lds, stream, a, sg);
+  else if (bk == 16) hipLaunchKernelGGL((gemm_sym_f64_kernel<16, 18>), dim3(grid), dim3(256), max_lds, stream, a, sg);
+  else hipLaunchKernelGGL((gemm_sym_f64_kernel<8, 18>), dim3(grid), dim3(256), max_lds, stream, a, sg);
   return (int)hipGetLastError();
 }
 
