@@ -59,7 +59,13 @@ enum {
    * is never formed and both products contract over M instead of N: 2.5x fewer flops in
    * the covariance stage. Rounding differs from the as-coded order at the 1e-13 level
    * (tests); opt-in because the reference codes the congruence form. */
-  XIVO_HIP_FLAG_REASSOC = 16u
+  XIVO_HIP_FLAG_REASSOC = 16u,
+  /* BASELINE.json config 4: the three covariance products of the Joseph update (KH - I, (KH-I)P,
+   * P+ = T A^T + K R K^T) run on the fp32 MFMA (v_mfma_f32_16x16x4_f32, 3x the fp64 issue rate) with
+   * fp32 accumulation; operands and results stay fp64 in HBM. HP, S, the factorisation, the gain and dx
+   * stay fp64 because their error is amplified by cond(S). Stated tolerance: 5e-5 relative Frobenius on
+   * P+ (measured 1.4e-5 at N=400/M=300, 5e-6 at N=250/M=160), dx unchanged (1e-8). */
+  XIVO_HIP_FLAG_FP32_COV = 32u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,

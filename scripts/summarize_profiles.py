@@ -56,6 +56,7 @@ for k, disp in m.items():
     busy = sum(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for c in disp.values())
     gui = sum(c.get("GRBM_GUI_ACTIVE", 0) for c in disp.values())          # summed over the 8 XCDs
     mops = sum(c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) for c in disp.values())
+    mops32 = sum(c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) for c in disp.values())
     us = sum(md.get(i, 0) for i in disp)
     s = summary.setdefault(k, {})
     s["launches_profiled"] = n
@@ -63,6 +64,7 @@ for k, disp in m.items():
     # 1024 SIMDs; GRBM_GUI_ACTIVE is per XCD (x8) -> chip cycles = gui / 8
     s["mfma_busy_pct"] = 100.0 * busy / (gui / 8.0 * 1024) if gui else None
     s["executed_mfma_f64_flops_per_launch"] = mops * 512.0 / n if n else None
+    s["executed_mfma_f32_flops_per_launch"] = mops32 * 512.0 / n if n else None
     s["shader_clock_ghz"] = (gui / 8.0) / (us * 1e3) if us else None
 for nm, key, scale in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0)):
     for k, disp in counters(nm).items():

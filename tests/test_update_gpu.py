@@ -217,3 +217,27 @@ def test_size_independent_properties_at_full_batch(built):
         assert np.all(HPH_after <= HPH_before * (1 + 1e-9))
     # covariance update does not depend on the innovation
     assert rel_fro(Pn[1], Pn[9]) < 1e-13 and rel_fro(Pn[0], Pn[8]) == 0.0
+
+
+TOL_P_FP32 = 5e-5   # stated tolerance of XIVO_HIP_FLAG_FP32_COV (config 4): relative Frobenius on P+
+
+
+@pytest.mark.parametrize("N,F,dense", [(400, 150, False), (400, 150, True), (250, 80, False), (150, 50, False), (37, 3, False)])
+def test_fp32_covariance_products_config4(built, N, F, dense):
+    """BASELINE.json config 4 (state dim 400, 150 features): the Joseph covariance products on the fp32
+    MFMA. dx must stay at the fp64 tolerance (the gain path is fp64); P+ within the stated 5e-5."""
+    from xivo_amd.lib import FLAG_FP32_COV
+    B = 3
+    P, H, inn, dR = synth.s_level(N, F, B, seed=N + 2 * F, dense=dense)
+    with Context(N, 2 * F, B, flags=FLAG_FP32_COV) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+        assert (ctx.get_status() == 0).all()
+    worst = 0.0
+    for b in range(B):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(err[b], e_ref) < TOL_DX
+        worst = max(worst, rel_fro(Pn[b], P_ref))
+        assert np.array_equal(Pn[b], Pn[b].T)
+    assert worst < TOL_P_FP32, worst
+    print("fp32 covariance products: worst rel. Frobenius error on P+ = %.2e at N=%d" % (worst, N))

@@ -172,6 +172,7 @@ struct GemmExtra {
   const double* mcol = nullptr; long sMcol = 0;
   double* C2 = nullptr; long sC2 = 0; int ldc2 = 0;
   int lower_only = 0;
+  int fp32 = 0;
 };
 
 int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0, long sA0, int lda0,
@@ -190,10 +191,10 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   g.C2 = x.C2; g.strideC2 = x.sC2; g.ldc2 = x.ldc2;
   g.diag = x.diag; g.strideDiag = x.sDiag; g.Msub = x.msub; g.strideMsub = x.sMsub; g.ldmsub = x.ldmsub;
   g.McolScale = x.mcol; g.strideMcol = x.sMcol;
-  g.epilogue = x.epi; g.lower_only = x.lower_only; g.batch = B;
+  g.epilogue = x.epi; g.lower_only = x.lower_only; g.batch = B; g.fp32 = x.fp32;
   const double flops = 2.0 * rows * cols * (double)(K0 + (A1 ? K1 : 0)) * B;
   StageTimer st(c, stage, flops);
-  const bool sym = g.lower_only && rows == cols && gemm_sym_supported(rows) && !g.C2 &&
+  const bool sym = g.lower_only && rows == cols && gemm_sym_supported(rows) && !g.C2 && !g.fp32 &&
                    (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG) && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
   const int rc = sym ? launch_gemm_sym_f64(g, c->stream) : launch_gemm_nt_f64(g, c->stream);
   return rc == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
@@ -399,6 +400,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   const double* diagR = c->diagR + (long)b0 * c->Mpmax;
   int rc;
   const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0;
+  const int f32 = (c->flags & XIVO_HIP_FLAG_FP32_COV) ? 1 : 0;
   {  // HP = H * P and its transpose PH^T (estimator.cpp:1259 first product; P symmetric => B operand = P rows)
     GemmExtra x; x.C2 = PHT; x.sC2 = c->sK; x.ldc2 = Np;
     rc = gemm(c, ST_HP, B, Mp, Np, H, c->sH, ldh, P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
@@ -458,20 +460,20 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     return rc;
   }
   {  // A = K * H - I  (estimator.cpp:1276-1279)
-    GemmExtra x; x.epi = EPI_SUB_IDENT;
+    GemmExtra x; x.epi = EPI_SUB_IDENT; x.fp32 = f32;
     rc = gemm(c, ST_KH, B, Np, Np, K, c->sK, Np, HT, c->sHT, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               A, c->sP, Np, x);
     if (rc) return rc;
   }
   {  // T = A * P = K * (HP) - P  (estimator.cpp:1280, left product; distributes over the already
      // formed HP, 2MN^2 instead of 2N^3 flops, same value up to rounding)
-    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np;
+    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.fp32 = f32;
     rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               T, c->sP, Np, x);
     if (rc) return rc;
   }
   {  // P = T * A^T + K diag(R) K^T  (estimator.cpp:1280-1287, fused; lower triangle + mirror)
-    GemmExtra x; x.lower_only = full ? 0 : 1;
+    GemmExtra x; x.lower_only = full ? 0 : 1; x.fp32 = f32;
     rc = gemm(c, ST_PNEW, B, Np, Np, T, c->sP, Np, A, c->sP, Np, Np, K, c->sK, Np, K, c->sK, Np, Mp, diagR,
               c->Mpmax, P, c->sP, Np, x);
   }

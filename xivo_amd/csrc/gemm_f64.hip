@@ -37,22 +37,48 @@ namespace xivo_hip {
 
 namespace {
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Compute-type traits: fp64 (default, the reference's arithmetic) or fp32 MFMA with fp32 accumulation
+// (XIVO_HIP_FLAG_FP32_COV: BASELINE.json config 4, covariance products only). Operands stay fp64 in HBM
+// and are rounded to fp32 when they are written to LDS; results are widened on store.
+template <typename CT> struct Cx;
+template <> struct Cx<double> {
+  typedef d4 acc_t; typedef d2 pair_t;
+  static __device__ __forceinline__ acc_t zero() { return d4{0.0, 0.0, 0.0, 0.0}; }
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  // C/D row of accumulator register r for lane group lg (cdna_hip_programming.md section 3: f64 differs)
+  static __device__ __forceinline__ int crow(int lg, int r) { return lg + 4 * r; }
+  static __device__ __forceinline__ pair_t cvt(d2 v) { return v; }
+};
+template <> struct Cx<float> {
+  typedef f4 acc_t; typedef f2 pair_t;
+  static __device__ __forceinline__ acc_t zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int lg, int r) { return 4 * lg + r; }
+  static __device__ __forceinline__ pair_t cvt(d2 v) { return pair_t{(float)v[0], (float)v[1]}; }
+};
+
 // FAST: the tile is interior (every 16x16 block in range and wanted), so slot activity is a
 // compile-time property - for strip tiles together with the compile-time wave index WAVE - and
 // the MFMA loop is straight-line code. Otherwise each slot is guarded by a wave-uniform bit
 // (hipcc turns those guards into a chain of scalar branches: ~2 taken branches per MFMA,
 // which is what made half-empty diagonal tiles SLOWER than full ones).
-template <int WM, int WN, int BK, bool STRIP, bool FAST, int WAVE>
+template <typename CT, int WM, int WN, int BK, bool STRIP, bool FAST, int WAVE>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, const int m0, const int n0,
-                                          double* smem) {
+                                          double* smem_raw) {
+  typedef typename Cx<CT>::acc_t acc_t;
+  typedef typename Cx<CT>::pair_t pair_t;
+  CT* smem = reinterpret_cast<CT*>(smem_raw);
   static_assert(!STRIP || (WM == 4 && WN == 4), "strip mapping is defined for 128x128 tiles");
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int LDAS = BM + 16, LDBS = BN + 16;
   constexpr int NS = WM * WN;                 // accumulator slots per wave
   constexpr int NA = STRIP ? 2 : WM;          // A fragments per k-slice
   constexpr int NB = STRIP ? 2 * WN : WN;     // B fragments per k-slice
-  double* As = smem;
-  double* Bs = smem + BK * LDAS;
+  CT* As = smem;
+  CT* Bs = smem + BK * LDAS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,20 +112,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   // Accumulators start at 0, or at -/+Msub for C = acc -/+ Msub (T = K(HP) - P): the
   // loads are issued here, ahead of the first k-panel, instead of serialising
   // behind the stores of the epilogue.
-  d4 acc[NS];
+  acc_t acc[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
-    acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    acc[q] = Cx<CT>::zero();
     if ((g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT) && is_on(q)) {
       const double* Ms = g.Msub + (long)filt * g.strideMsub;
       const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
       const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = J0 + lg + 4 * r;
+        const int j = J0 + Cx<CT>::crow(lg, r);
         double v = sgn * Ms[i + (long)j * g.ldmsub];
         if (g.McolScale) v *= g.McolScale[(long)filt * g.strideMcol + j];
-        acc[q][r] = v;
+        acc[q][r] = (CT)v;
       }
     }
   }
@@ -182,7 +208,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WM), p = idx % (16 * WM);
       const bool keep = ((okA >> r) & 1u) && (!tail || pend_k0 + k < pend_K);
-      *reinterpret_cast<d2*>(As + k * LDAS + 2 * p) = keep ? ra[r] : d2{0.0, 0.0};
+      *reinterpret_cast<pair_t*>(As + k * LDAS + 2 * p) = Cx<CT>::cvt(keep ? ra[r] : d2{0.0, 0.0});
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -191,7 +217,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       const bool keep = ((okB >> r) & 1u) && (!tail || pend_k0 + k < pend_K);
       d2 v = keep ? rb[r] : d2{0.0, 0.0};
       if (pend_S) v *= pend_S[pend_k0 + k < pend_K ? pend_k0 + k : pend_K - 1];
-      *reinterpret_cast<d2*>(Bs + k * LDBS + 2 * p) = v;
+      *reinterpret_cast<pair_t*>(Bs + k * LDBS + 2 * p) = Cx<CT>::cvt(v);
     }
   };
 
@@ -202,7 +228,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     if (t + 1 < nsteps) load_global(t + 1);
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
-      double a[NA], bb[NB];
+      CT a[NA], bb[NB];
 #pragma unroll
       for (int x = 0; x < NA; ++x) a[x] = As[(4 * s + lg) * LDAS + 16 * arow(x) + li];
 #pragma unroll
@@ -210,7 +236,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         if (is_on(q))
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[slot_b(q)], a[slot_a(q)], acc[q], 0, 0, 0);
+          acc[q] = Cx<CT>::mfma(bb[slot_b(q)], a[slot_a(q)], acc[q]);
       }
     }
     __syncthreads();
@@ -220,17 +246,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   double* Cb = g.C + (long)filt * g.strideC;
   double* C2b = g.C2 ? g.C2 + (long)filt * g.strideC2 : nullptr;
   const double* dg = g.diag ? g.diag + (long)filt * g.strideDiag : nullptr;
-  double* Tw = smem + wave * (16 * 17);  // per-wave 16x16 transpose pad (main-loop LDS is free now)
+  double* Tw = smem_raw + wave * (16 * 17);  // per-wave 16x16 transpose pad (main-loop LDS is free now)
   const bool need_t = g.lower_only || C2b;
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     if (!is_on(q)) continue;
     const int I0 = m0 + 16 * arow(slot_a(q)), J0 = n0 + 16 * bcol(slot_b(q));
     const int i = I0 + li;
-    d4 v = acc[q];
+    double v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int j = J0 + lg + 4 * r;
+      const int j = J0 + Cx<CT>::crow(lg, r);
+      v[r] = (double)acc[q][r];
       if (g.epilogue == EPI_ADD_DIAG) {
         if (i == j) v[r] += dg[i];
       } else if (g.epilogue == EPI_SUB_IDENT) {
@@ -239,9 +266,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int j = J0 + lg + 4 * r;
+      const int jl = Cx<CT>::crow(lg, r);
+      const int j = J0 + jl;
       if (!g.lower_only || i >= j) Cb[i + (long)j * g.ldc] = v[r];
-      if (need_t) Tw[(lg + 4 * r) * 17 + li] = v[r];   // T[j_local][i_local]
+      if (need_t) Tw[jl * 17 + li] = v[r];   // T[j_local][i_local]
     }
     if (need_t) {
       // The lower triangle is authoritative and is mirrored, so a symmetric result is
@@ -259,13 +287,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   }
 }
 
-// k-panel depth (a template knob; K segments that are not a multiple of it are zero-filled).
 template <int WM, int WN>
 constexpr int pick_bk() {
   return 16;   // 32 measured neutral on MI355X and costs 32 more staging VGPRs
 }
 
-template <int WM, int WN>
+template <int WM, int WN, typename CT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   constexpr int BK = pick_bk<WM, WN>();
   constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -294,12 +321,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     if (g.lower_only == 1 && m0 == n0) {
       if (inside) {
         const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        if (w == 0) gemm_tile<WM, WN, BK, true, true, 0>(g, filt, m0, n0, smem);
-        else if (w == 1) gemm_tile<WM, WN, BK, true, true, 1>(g, filt, m0, n0, smem);
-        else if (w == 2) gemm_tile<WM, WN, BK, true, true, 2>(g, filt, m0, n0, smem);
-        else gemm_tile<WM, WN, BK, true, true, 3>(g, filt, m0, n0, smem);
+        if (w == 0) gemm_tile<CT, WM, WN, BK, true, true, 0>(g, filt, m0, n0, smem);
+        else if (w == 1) gemm_tile<CT, WM, WN, BK, true, true, 1>(g, filt, m0, n0, smem);
+        else if (w == 2) gemm_tile<CT, WM, WN, BK, true, true, 2>(g, filt, m0, n0, smem);
+        else gemm_tile<CT, WM, WN, BK, true, true, 3>(g, filt, m0, n0, smem);
       } else {
-        gemm_tile<WM, WN, BK, true, false, -1>(g, filt, m0, n0, smem);
+        gemm_tile<CT, WM, WN, BK, true, false, -1>(g, filt, m0, n0, smem);
       }
       return;
     }
@@ -307,8 +334,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   // interior tile with every block wanted (for lower_only: strictly below the diagonal)
   // lower_only == 2: diagonal tiles are computed in full (dense FAST path) and only stored as
   // lower triangle + mirror
-  if (inside && (!g.lower_only || n0 + BN <= m0 || g.lower_only == 2)) gemm_tile<WM, WN, BK, false, true, -1>(g, filt, m0, n0, smem);
-  else gemm_tile<WM, WN, BK, false, false, -1>(g, filt, m0, n0, smem);
+  if (inside && (!g.lower_only || n0 + BN <= m0 || g.lower_only == 2)) gemm_tile<CT, WM, WN, BK, false, true, -1>(g, filt, m0, n0, smem);
+  else gemm_tile<CT, WM, WN, BK, false, false, -1>(g, filt, m0, n0, smem);
 }
 
 template <int WM, int WN>
@@ -319,7 +346,8 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
   const int groups = (g.batch + 7) / 8;
   const int grid = groups * 8 * g.tiles_m * g.tiles_n;
   if (grid <= 0) return 0;
-  hipLaunchKernelGGL((gemm_nt_f64_kernel<WM, WN>), dim3(grid), dim3(256), 0, stream, g);
+  if (g.fp32) hipLaunchKernelGGL((gemm_nt_f64_kernel<WM, WN, float>), dim3(grid), dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_nt_f64_kernel<WM, WN, double>), dim3(grid), dim3(256), 0, stream, g);
   return (int)hipGetLastError();
 }
 

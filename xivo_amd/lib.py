@@ -11,6 +11,7 @@ FLAG_PROFILE = 2
 FLAG_FULL_PNEW = 4
 FLAG_TILE_SYM = 8
 FLAG_REASSOC = 16
+FLAG_FP32_COV = 32
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
 
