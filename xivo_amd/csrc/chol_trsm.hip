@@ -18,6 +18,8 @@
 //   (row = (lane>>4) + 4*reg, col = lane&15) is exactly the B-operand layout of
 //   the four k-slices of the next MFMA, so forward and backward substitution
 //   chain with no data movement at all; dx = K*inn falls out as a lane reduce.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace xivo_hip {
@@ -364,6 +366,165 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
 }
 
+// Streaming variant for factors that do not fit LDS (M > 176): the workgroup (8 waves = 128
+// right-hand-side columns, X in registers as above) walks the block columns of L; the column panel
+// of step k+1 - inv(L_kk) plus the blocks L_ik, i > k (forward) or L_ki^T, i < k (backward, read
+// from the mirrored upper triangle) - is fetched global -> registers while step k's MFMAs run and
+// lands in the other half of a double-buffered LDS panel; one barrier per step.
+template <int NBM>
+__global__ __launch_bounds__(512) void trsm_stream_f64_kernel(TrsmArgs g) {
+  constexpr int BLK = 16 * 17;
+  constexpr int PL = (NBM * 128 + 511) / 512;          // d2 loads per thread per panel
+  extern __shared__ __attribute__((aligned(16))) double sL[];   // [2][NBM][16 x 17]
+  const int chunks = (g.Np + 127) / 128;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int filt = (slot / chunks) * 8 + xcd;
+  const int chunk = slot % chunks;
+  if (filt >= g.batch) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int nb = g.Mp / 16;
+  const double* __restrict__ LU = g.LU + (long)filt * g.strideLU;
+  const double* __restrict__ invD = g.invD + (long)filt * g.strideInvD;
+  const double* __restrict__ PHT = g.PHT + (long)filt * g.stridePHT;
+  const long ld = g.ldlu;
+  const int c0 = chunk * 128 + wave * 16;
+  const bool live = c0 < g.Np;
+
+  d4 X[NBM];
+#pragma unroll
+  for (int i = 0; i < NBM; ++i) {
+    X[i] = d4{0.0, 0.0, 0.0, 0.0};
+    if (live && i < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[i][r] = PHT[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldpht];
+    }
+  }
+
+  // panel of step k: slot j holds block (row-block j of the column); forward: j >= k, backward: j <= k.
+  // slot k itself holds inv(L_kk) (forward) / inv(L_kk)^T (backward). All blocks are read with the
+  // lane index contiguous (the upper triangle holds L^T) and stored [row + 17 * col].
+  d2 pr[PL];
+  auto panel_load = [&](int k, bool fwd) {
+    const int j0 = fwd ? k : 0, nj = fwd ? nb - k : k + 1;
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+      const int e = tid + 512 * u;
+      d2 v = d2{0.0, 0.0};
+      if (e < nj * 128) {
+        const int j = j0 + (e >> 7), w = e & 127;
+        const int r = (w & 7) * 2, c = w >> 3;
+        if (j == k) v = *reinterpret_cast<const d2*>(invD + (long)k * 512 + (fwd ? 0 : 256) + r + 16 * c);
+        else v = *reinterpret_cast<const d2*>(LU + (16 * j + r) + (long)(16 * k + c) * ld);
+      }
+      pr[u] = v;
+    }
+  };
+  auto panel_store = [&](int k, bool fwd, double* buf) {
+    const int j0 = fwd ? k : 0, nj = fwd ? nb - k : k + 1;
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+      const int e = tid + 512 * u;
+      if (e < nj * 128) {
+        const int j = j0 + (e >> 7), w = e & 127;
+        const int r = (w & 7) * 2, c = w >> 3;
+        buf[j * BLK + r + 17 * c] = pr[u][0];
+        buf[j * BLK + r + 1 + 17 * c] = pr[u][1];
+      }
+    }
+  };
+  double* buf0 = sL;
+  double* buf1 = sL + NBM * BLK;
+
+  // ---- forward: L Y = HP
+  panel_load(0, true);
+  panel_store(0, true, buf0);
+#pragma unroll
+  for (int k = 0; k < NBM; ++k) {
+    if (k < nb) {
+      __syncthreads();
+      const double* cur = (k & 1) ? buf1 : buf0;
+      double* nxt = (k & 1) ? buf0 : buf1;
+      if (k + 1 < nb) panel_load(k + 1, true);
+      if (live) {
+        d4 t = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) t = mfma(cur[k * BLK + li + 17 * (4 * s + lg)], X[k][s], t);
+        X[k] = t;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int i = k + 1; i < NBM; ++i) {
+            if (i < nb) X[i] = mfma(-cur[i * BLK + li + 17 * (4 * s + lg)], t[s], X[i]);
+          }
+        }
+      }
+      if (k + 1 < nb) panel_store(k + 1, true, nxt);
+    }
+  }
+  // ---- backward: L^T K^T = Y  (panels of column k of the upper triangle = rows of L^T)
+  __syncthreads();
+  panel_load(nb - 1, false);
+  panel_store(nb - 1, false, buf0);
+  int par = 0;
+#pragma unroll
+  for (int k = NBM - 1; k >= 0; --k) {
+    if (k < nb) {
+      __syncthreads();
+      const double* cur = par ? buf1 : buf0;
+      double* nxt = par ? buf0 : buf1;
+      par ^= 1;
+      if (k > 0) panel_load(k - 1, false);
+      if (live) {
+        d4 t = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) t = mfma(cur[k * BLK + li + 17 * (4 * s + lg)], X[k][s], t);
+        X[k] = t;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int i = 0; i < k; ++i) X[i] = mfma(-cur[i * BLK + li + 17 * (4 * s + lg)], t[s], X[i]);
+        }
+      }
+      if (k > 0) panel_store(k - 1, false, nxt);
+    }
+  }
+  if (!live) return;
+  double* __restrict__ K = g.K + (long)filt * g.strideK;
+  const double* __restrict__ inn = g.inn + (long)filt * g.strideInn;
+  double part = 0.0;
+#pragma unroll
+  for (int i = 0; i < NBM; ++i) {
+    if (i < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + lg + 4 * r;
+        K[(c0 + li) + (long)m * g.ldk] = X[i][r];
+        part = fma(X[i][r], inn[m], part);
+      }
+    }
+  }
+  part += __shfl_xor(part, 16);
+  part += __shfl_xor(part, 32);
+  if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
+}
+
+template <int NBM>
+int launch_trsm_stream_t(const TrsmArgs& g, hipStream_t stream) {
+  const int chunks = (g.Np + 127) / 128;
+  const int grid = ((g.batch + 7) / 8) * 8 * chunks;
+  const size_t lds = (size_t)2 * NBM * 16 * 17 * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_stream_f64_kernel<NBM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((trsm_stream_f64_kernel<NBM>), dim3(grid), dim3(512), lds, stream, g);
+  return (int)hipGetLastError();
+}
+
 template <int NBM>
 int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
   const int nb = g.Mp / 16;
@@ -404,6 +565,13 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   if (nb <= 6) return launch_trsm_lds_t<6>(g, stream);
   if (nb <= 10) return launch_trsm_lds_t<10>(g, stream);
   if (nb <= 11) return launch_trsm_lds_t<11>(g, stream);
+  // larger factors: stream the factor through a double-buffered LDS panel
+  static const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;   // A/B knob
+  if (!no_stream) {
+    if (nb <= 14) return launch_trsm_stream_t<14>(g, stream);
+    if (nb <= 19) return launch_trsm_stream_t<19>(g, stream);
+    if (nb <= 24) return launch_trsm_stream_t<24>(g, stream);
+  }
   if (nb <= 4) return launch_trsm_t<4>(g, stream);
   if (nb <= 7) return launch_trsm_t<7>(g, stream);
   if (nb <= 10) return launch_trsm_t<10>(g, stream);
