@@ -12,6 +12,9 @@ pytestmark = pytest.mark.gpu
 
 CASES = [  # (N, F) -> M = 2F ; BASELINE.json configs + TUM-VI default build + ragged sizes
     (150, 50), (250, 80), (400, 150), (203, 30), (251, 130), (37, 3), (64, 8), (100, 1),
+    (100, 192),   # M = 384 = the largest factor the solver is built for (24 blocks); M > N is legal
+    (176, 88),    # Mp = Np = 176: the largest single-workgroup triangle of the block-list kernel
+    (192, 96),    # first size that falls back to strip tiles / the streamed solve
 ]
 
 

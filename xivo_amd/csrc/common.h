@@ -59,7 +59,6 @@ struct GemmArgs {
   int batch;
   int tiles_m, tiles_n;
   int fp32;            // 1: fp32 MFMA with fp32 accumulation for this product (operands/results stay fp64 in HBM)
-  int debug_skip;      // experiments only (XIVO_HIP_SKIP): 1 skip diagonal tiles, 2 skip off-diagonal tiles
 };
 
 // launches on `stream`; returns hipError_t as int

@@ -314,8 +314,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   if (g.lower_only && n0 >= m0 + BM) return;  // tile strictly above the diagonal
-  if (g.debug_skip == 1 && m0 == n0) return;   // experiment: skip diagonal tiles
-  if (g.debug_skip == 2 && m0 != n0) return;   // experiment: skip off-diagonal tiles
   const bool inside = (m0 + BM <= g.Mp) && (n0 + BN <= g.Np);
   if constexpr (WM == 4 && WN == 4) {
     if (g.lower_only == 1 && m0 == n0) {
@@ -405,8 +403,6 @@ int launch_gemm_nt_f64(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
   static const bool no_strip = getenv("XIVO_HIP_NO_STRIP") != nullptr;   // A/B knob
   if (no_strip && a.lower_only) a.lower_only = 2;
-  static const int dbg_skip = getenv("XIVO_HIP_SKIP") ? atoi(getenv("XIVO_HIP_SKIP")) : 0;
-  a.debug_skip = a.lower_only ? dbg_skip : 0;
   int wm, wn;
   gemm_pick_tile(a.Mp, a.Np, a.lower_only, &wm, &wn);
   // accumulators initialised from memory (T = K(HP) - P): the 64 extra loads per lane sit in the
