@@ -223,7 +223,11 @@ def main():
         def tile_of(r, c, sym=0):
             bm, bn = C.c_int(), C.c_int()
             lib.xivo_hip_gemm_tile(r, c, sym, C.byref(bm), C.byref(bn))
-            return f"gemm_nt_f64_kernel<{bm.value // 32},{bn.value // 32}>"
+            return f"gemm_nt_f64_kernel<{bm.value // 32},{bn.value // 32},double>"
+
+        def norm(k):   # rocprofv3 prints template arguments with spaces; the block-list kernel has one instantiation per size class
+            k = k.replace(" ", "")
+            return "gemm_sym_f64_kernel" if k.startswith("gemm_sym_f64_kernel") else k
 
         # group stages by the kernel instantiation rocprofv3 would report them under
         shape = {"gemm_HP": (M, N, 0), "gemm_S": (M, M, 1), "gemm_KH_I": (N, N, 0), "gemm_AP": (N, N, 0),
@@ -234,17 +238,18 @@ def main():
                 continue
             kname = tile_of(*shape[name]) if name in shape else name
             if name == "gemm_S" and M <= 176:
-                kname = "gemm_sym_f64_kernel<8>"   # whole triangle in one workgroup (block-list kernel)
-            if name == "gemm_AP" and kname == "gemm_nt_f64_kernel<4,4>":
-                kname = "gemm_nt_f64_kernel<4,2>"  # accumulator-initialised GEMMs run on the 128x64 tile
+                kname = "gemm_sym_f64_kernel"   # whole triangle in one workgroup (block-list kernel)
+            if name == "gemm_AP" and kname == "gemm_nt_f64_kernel<4,4,double>":
+                kname = "gemm_nt_f64_kernel<4,2,double>"  # accumulator-initialised GEMMs run on the 128x64 tile
             g = groups.setdefault(kname, {"ms": 0.0, "launches": 0, "flops": 0.0, "stages": []})
             g["ms"] += st["ms"]; g["launches"] += st["launches"]
             g["flops"] += st["flops_per_launch"] * st["launches"]; g["stages"].append(name)
         pmc = {}
         try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+            import re
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_pmc_summary\.json", f))
             if cands:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
+                pmc = {norm(k): v for k, v in json.load(open(os.path.join(ROOT, "profiles", cands[-1]))).items()}
                 pmc["_file"] = "profiles/" + cands[-1]
         except Exception:
             pmc = {}
@@ -260,12 +265,12 @@ def main():
                         # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of the
                         # same command (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE); null if absent
                         "traffic": (lambda e: (e.get("hbm_read_bytes_per_launch", 0) + e.get("hbm_write_bytes_per_launch", 0))
-                                    if e and args.batch == 4096 else None)(pmc.get(dom.replace(",", ", "))),
+                                    if e and args.batch == 4096 else None)(pmc.get(norm(dom))),
                         "traffic_source": pmc.get("_file"),
                         # from the same PMC passes: flops the MFMA pipe really executed per launch (symmetry and
                         # K(HP) - P skip work the reference's as-coded count includes) and pipe busy %
-                        "executed_mfma_flops_per_launch": (pmc.get(dom.replace(",", ", ")) or {}).get("executed_mfma_f64_flops_per_launch"),
-                        "mfma_busy_pct_pmc": (pmc.get(dom.replace(",", ", ")) or {}).get("mfma_busy_pct"),
+                        "executed_mfma_flops_per_launch": (pmc.get(norm(dom)) or {}).get("executed_mfma_f64_flops_per_launch"),
+                        "mfma_busy_pct_pmc": (pmc.get(norm(dom)) or {}).get("mfma_busy_pct"),
                         "mfma_peak_measured_tflops": peak_meas,
                         "pipeline_f_alg_tflops": f_alg(N, M) * value / world / 1e12,
                         "pipeline_frac": f_alg(N, M) * value / world / 1e12 / FP64_MFMA_PEAK_TFLOPS}

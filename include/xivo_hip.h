@@ -96,6 +96,10 @@ typedef struct {
 typedef struct {
   double Rsb[9], Tsb[3];
   double Rbc[9], Tbc[3];
+  /* rest of the nominal motion state (src/core.h:117-130): not read by the Jacobians, but
+   * retracted by xivo_hip_absorb_error so the whole State can stay device resident */
+  double Vsb[3], bg[3], ba[3];
+  double Rsg[9];
 } xivo_pose_in;
 
 /* One group anchor (src/group.h:41-107): pose + state slot `sind`. */
@@ -207,6 +211,14 @@ int xivo_hip_oos_project(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xiv
 int xivo_hip_filter_update(xivo_hip_ctx* ctx, int B, double R, double mh_thresh, double mh_mult,
                            int min_inliers, int use_gating);
 int xivo_hip_get_H(xivo_hip_ctx* ctx, int b, int* M_out, double* H, int ldh, double* inn, double* diagR);
+/* Estimator::AbsorbError (src/estimator.cpp:875-921) on the device-resident nominal state of filters
+ * [0,B): X += dx via State::operator+= (src/core.h:135-165: SO3 exp on Rsb, Rbc, Rsg), every group slot
+ * += dx segment (src/group.h:25-29), every feature that was an inlier of the last gating / stacking pass
+ * x += dx segment (src/feature.h:220); then dx = 0. (no host round trip of the state.) */
+int xivo_hip_absorb_error(xivo_hip_ctx* ctx, int B);
+/* download the resident scene (any pointer may be NULL) */
+int xivo_hip_get_scene(xivo_hip_ctx* ctx, int b0, int nb, xivo_pose_in* poses, xivo_group_in* groups,
+                       xivo_feat_in* feats);
 
 /* ---- covariance propagation tail (src/rk4.cpp:92-102, src/estimator.cpp:590) */
 /* P_mm <- Pmm_new ; P_ms <- Phi P_ms ; P_sm <- P_sm Phi^T. Phi and Pmm_new

@@ -232,3 +232,65 @@ def test_config3_full_size_instate_plus_oos(built):
         assert H.shape == (260, 251)
         e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+def test_resident_frames_with_device_absorb_error(built):
+    """three frames of (Jacobians -> MHGating -> stack -> UpdateJosephForm -> AbsorbError)
+    with P, dx and the nominal state (pose, groups, features) never leaving the device; only new pixel
+    measurements are fed in. Oracle: the same loop on the host (estimator.cpp:875-921 for the retraction)."""
+    cam = synth.RADTAN
+    B, ng, nf = 3, 5, 14
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, nf, B, 9, cam)
+    rng = np.random.default_rng(4)
+    extra = dict(Vsb=rng.normal(size=(B, 3)), bg=rng.normal(size=(B, 3)) * 1e-2, ba=rng.normal(size=(B, 3)) * 1e-2,
+                 Rsg=np.array([orc.so3_exp(rng.normal(size=3) * 0.05) for _ in range(B)]))
+    for b in range(B):
+        poses[b]["Vsb"] = extra["Vsb"][b]; poses[b]["bg"] = extra["bg"][b]; poses[b]["ba"] = extra["ba"][b]
+        poses[b]["Rsg"] = extra["Rsg"][b].T.reshape(-1)
+    feats["xp"][1, 5] += 60.0; xp[1, 5] += 60.0      # one outlier, rejected in every frame
+    P0 = np.array([spd(lay.N, 70 + b) * 1e-4 for b in range(B)])
+    frames = [xp, xp + rng.normal(size=xp.shape) * 0.7, xp + rng.normal(size=xp.shape) * 0.7]
+    with ctx:
+        ctx.upload_P(P0); ctx.set_scene(poses, groups, feats)
+        masks = []
+        for k, meas in enumerate(frames):
+            if k:                                    # only the pixels change; x / poses stay as the device left them
+                _, _, fcur = ctx.get_scene()
+                fcur["xp"] = meas
+                pcur, gcur, _ = ctx.get_scene()
+                ctx.set_scene(pcur, gcur, fcur)
+            ctx.filter_update(R_VIS, MH, MULT, 5, True)
+            masks.append(ctx.get_gate(nf)[0].copy())
+            ctx.absorb_error()
+        assert np.abs(ctx.get_err()).max() == 0.0     # err_.setZero()
+        P = ctx.download_P()
+        pose_d, group_d, feat_d = ctx.get_scene()
+    for b in range(B):
+        st = dict(Rsb=sc["Rsb"][b].copy(), Tsb=sc["Tsb"][b].copy(), Rbc=sc["Rbc"][b].copy(), Tbc=sc["Tbc"][b].copy(),
+                  Vsb=extra["Vsb"][b].copy(), bg=extra["bg"][b].copy(), ba=extra["ba"][b].copy(), Rsg=extra["Rsg"][b].copy(),
+                  gR=sc["gR"][b].copy(), gT=sc["gT"][b].copy(), x=sc["x"][b].copy(), sind=sc["sind"][b], ref=sc["ref"][b])
+        Pb = P0[b].copy()
+        for k, meas in enumerate(frames):
+            Js, inns = [], []
+            for i in range(nf):
+                r = int(st["ref"][i])
+                J, inn, _ = orc.compute_jacobian(st["x"][i], meas[b, i], st["gR"][r], st["gT"][r], st["Rsb"], st["Tsb"],
+                                                 st["Rbc"], st["Tbc"], cam, lay, r, int(st["sind"][i]))
+                Js.append(J); inns.append(inn)
+            Js, inns = np.array(Js), np.array(inns)
+            m, _, _ = orc.mh_gate(orc.mh_distances(Js, Pb, inns, R_VIS), MH, MULT, 5)
+            assert np.array_equal(masks[k][b], m)
+            H, inn, dR = orc.stack_measurements(Js[m], inns[m], st["ref"][m], st["sind"][m], lay, R_VIS)
+            dx, Pb, _ = orc.update_joseph(H, Pb, inn, dR)
+            orc.absorb_error(st, dx, lay, range(ng), np.nonzero(m)[0])
+        assert not masks[0][1, 5]
+        assert rel_fro(P[b], Pb) < TOL_P
+        cmT = lambda v: np.asarray(v).reshape(3, 3).T
+        for name in ("Rsb", "Rbc", "Rsg"):
+            assert np.abs(cmT(pose_d[b][name]) - st[name]).max() < 1e-9, name
+        for name in ("Tsb", "Tbc", "Vsb", "bg", "ba"):
+            assert np.abs(pose_d[b][name] - st[name]).max() < 1e-9, name
+        for g in range(ng):
+            assert np.abs(cmT(group_d[b, g]["Rsb"]) - st["gR"][g]).max() < 1e-9
+            assert np.abs(group_d[b, g]["Tsb"] - st["gT"][g]).max() < 1e-9
+        assert np.abs(feat_d[b]["x"] - st["x"]).max() < 1e-9

@@ -50,6 +50,7 @@ struct xivo_hip_ctx {
   xivo_feat_in* feats = nullptr;
   double *J = nullptr, *finn = nullptr, *dist = nullptr;
   unsigned char* mask = nullptr;
+  int gate_sparse_last = 0;   // mask/dist row stride: Fmax after the layout-faithful gate, F after the dense one
   int* rows_instate = nullptr;
   xivo_oos_in* oos = nullptr;
   int oos_cap = 0;
@@ -417,6 +418,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.F = gate->F; a.Np = Np; a.batch = B;
     a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
     StageTimer st(c, ST_GATE, 0.0);
+    c->gate_sparse_last = 0;
     if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // S = HP * H^T + diag(R)  (estimator.cpp:1259-1263); lower triangle + mirror
@@ -515,8 +517,12 @@ int xivo_hip_update_dense_gated(xivo_hip_ctx* c, int B, int F, double R, double 
 
 int xivo_hip_get_gate(xivo_hip_ctx* c, int B, int F, unsigned char* mask_out, double* dist_out) {
   if (!c || B <= 0 || B > c->Bmax || F <= 0 || !c->mask) return XIVO_HIP_ERR_INVALID;
-  if (mask_out) HIP_TRY(hipMemcpyAsync(mask_out, c->mask, (size_t)B * F, hipMemcpyDeviceToHost, c->stream));
-  if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, c->dist, (size_t)B * F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  // the dense gate packs [B][F]; the layout-faithful gate (xivo_hip_mh_gate / filter_update) strides by Fmax
+  const size_t ld = c->gate_sparse_last ? (size_t)c->Fmax : (size_t)F;
+  if (c->gate_sparse_last && F != c->F) return XIVO_HIP_ERR_INVALID;
+  if (mask_out) HIP_TRY(hipMemcpy2DAsync(mask_out, F, c->mask, ld, F, B, hipMemcpyDeviceToHost, c->stream));
+  if (dist_out) HIP_TRY(hipMemcpy2DAsync(dist_out, F * sizeof(double), c->dist, ld * sizeof(double), F * sizeof(double), B,
+                                         hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return XIVO_HIP_OK;
 }
@@ -577,6 +583,7 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
   a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;
   {
     StageTimer st(c, ST_GATE, 0.0);
+    c->gate_sparse_last = 0;
     if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   if (mask_out) HIP_TRY(hipMemcpyAsync(mask_out, c->mask, (size_t)B * F, hipMemcpyDeviceToHost, c->stream));
@@ -647,6 +654,7 @@ static int gate_impl(xivo_hip_ctx* c, int B, double R, double th, double mult, i
   a.sb = scene_buffers(c); a.lay = c->lay; a.P = c->P; a.strideP = c->sP; a.ldp = c->Np;
   a.R = R; a.thresh = th; a.mult = mult; a.min_inliers = min_inl; a.batch = B; a.use_gating = use_gating;
   StageTimer st(c, ST_GATE, 0.0);
+  c->gate_sparse_last = 1;
   return launch_gate_sparse(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 
@@ -726,6 +734,29 @@ int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, d
   rc = xivo_hip_stack(c, B, R);
   if (rc) return rc;
   return xivo_hip_update_joseph(c, B);
+}
+
+int xivo_hip_absorb_error(xivo_hip_ctx* c, int B) {
+  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0 || !c->mask) return XIVO_HIP_ERR_INVALID;
+  AbsorbArgs a;
+  a.poses = c->poses; a.groups = c->groups; a.feats = c->feats; a.mask = c->mask; a.err = c->err; a.strideErr = c->Np;
+  a.lay = c->lay; a.F = c->F; a.Fmax = c->Fmax; a.batch = B;
+  StageTimer st(c, ST_OTHER, 0.0);
+  return launch_absorb_error(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+int xivo_hip_get_scene(xivo_hip_ctx* c, int b0, int nb, xivo_pose_in* poses, xivo_group_in* groups, xivo_feat_in* feats) {
+  if (bad_range(c, b0, nb) || !c->have_layout || !c->poses) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  if (poses) HIP_TRY(hipMemcpyAsync(poses, c->poses + b0, (size_t)nb * sizeof(xivo_pose_in), hipMemcpyDeviceToHost, c->stream));
+  if (groups) HIP_TRY(hipMemcpyAsync(groups, c->groups + (size_t)b0 * c->lay.n_groups,
+                                     (size_t)nb * c->lay.n_groups * sizeof(xivo_group_in), hipMemcpyDeviceToHost, c->stream));
+  if (feats && c->F > 0)
+    HIP_TRY(hipMemcpy2DAsync(feats, (size_t)c->F * sizeof(xivo_feat_in), c->feats + (size_t)b0 * c->Fmax,
+                             (size_t)c->Fmax * sizeof(xivo_feat_in), (size_t)c->F * sizeof(xivo_feat_in), nb,
+                             hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
 }
 
 int xivo_hip_get_H(xivo_hip_ctx* c, int b, int* M_out, double* H, int ldh, double* inn, double* diagR) {

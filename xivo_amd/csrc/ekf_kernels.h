@@ -67,6 +67,13 @@ struct StackArgs {
 };
 int launch_stack(const StackArgs& a, hipStream_t s);
 
+// AbsorbError on the resident scene (estimator.cpp:875-921)
+struct AbsorbArgs {
+  xivo_pose_in* poses; xivo_group_in* groups; xivo_feat_in* feats; const unsigned char* mask;
+  double* err; long strideErr; xivo_layout lay; int F, Fmax, batch;
+};
+int launch_absorb_error(const AbsorbArgs& a, hipStream_t s);
+
 // OOS (MSCKF) rows: oos.cpp:39-89 + helpers.cpp:13-23
 struct OosArgs {
   const xivo_oos_in* feats; int n_oos;          // [batch x n_oos]

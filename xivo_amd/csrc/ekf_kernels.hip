@@ -464,6 +464,56 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   if (tid == 0 && a.rows_instate) a.rows_instate[filt] = 2 * sb.F;
 }
 
+// ---------------------------------------------------------------- AbsorbError
+// SO3::exp (Rodrigues), as SO3_from_rotvec (src/helpers.cpp:374-378)
+__device__ __forceinline__ M3 so3_exp_dev(double wx, double wy, double wz) {
+  const double th = sqrt(wx * wx + wy * wy + wz * wz);
+  const V3 w{{wx, wy, wz}};
+  const M3 W = hat(w), W2 = m3_mul(W, W);
+  const double a = th < 1e-10 ? 1.0 : sin(th) / th, b = th < 1e-10 ? 0.5 : (1.0 - cos(th)) / (th * th);
+  M3 R;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R.m[i][j] = (i == j ? 1.0 : 0.0) + a * W.m[i][j] + b * W2.m[i][j];
+  return R;
+}
+__device__ __forceinline__ void rot_retract(double* Rcm, double wx, double wy, double wz) {   // R <- R exp(w), column-major storage
+  const M3 R = m3_mul(m3_from_colmajor(Rcm), so3_exp_dev(wx, wy, wz));
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rcm[i + 3 * j] = R.m[i][j];
+}
+// One workgroup per filter; thread 0 retracts the motion state, threads 1.. the group slots and features.
+__global__ __launch_bounds__(256) void absorb_error_kernel(AbsorbArgs a) {
+  const int filt = blockIdx.x, tid = threadIdx.x;
+  double* err = a.err + (long)filt * a.strideErr;
+  if (tid == 0) {                                        // State::operator+= (core.h:135-165)
+    xivo_pose_in& X = a.poses[filt];
+    rot_retract(X.Rsb, err[0], err[1], err[2]);
+    rot_retract(X.Rbc, err[15], err[16], err[17]);
+    rot_retract(X.Rsg, err[21], err[22], 0.0);
+    for (int i = 0; i < 3; ++i) {
+      X.Tsb[i] += err[3 + i]; X.Vsb[i] += err[6 + i]; X.bg[i] += err[9 + i]; X.ba[i] += err[12 + i]; X.Tbc[i] += err[18 + i];
+    }
+  }
+  for (int g = tid; g < a.lay.n_groups; g += 256) {      // SO3xR3::operator+= (group.h:25-29); empty slots have dx = 0
+    xivo_group_in& G = a.groups[(long)filt * a.lay.n_groups + g];
+    const int off = a.lay.group_begin + 6 * g;
+    rot_retract(G.Rsb, err[off], err[off + 1], err[off + 2]);
+    for (int i = 0; i < 3; ++i) G.Tsb[i] += err[off + 3 + i];
+  }
+  for (int f = tid; f < a.F; f += 256) {                 // Feature::UpdateState for in_current_ekf_update_ (estimator.cpp:906-912)
+    if (!a.mask[(long)filt * a.Fmax + f]) continue;
+    xivo_feat_in& ft = a.feats[(long)filt * a.Fmax + f];
+    const int off = a.lay.feature_begin + 3 * ft.sind;
+    for (int i = 0; i < 3; ++i) ft.x[i] += err[off + i];
+  }
+  __syncthreads();
+  for (int n = tid; n < a.lay.N; n += 256) err[n] = 0.0;  // err_.setZero() (estimator.cpp:920)
+}
+
 // ---------------------------------------------------------------- OOS / MSCKF rows
 // One wave64 per (filter, OOS feature). Lane 0 runs Eigen's FullPivLU on the
 // 3 x 2k matrix Hf^T exactly as FullPivLU::computeInPlace / kernel() do
@@ -721,6 +771,10 @@ int launch_gate_sparse(const GateArgs& a, hipStream_t s) {
 }
 int launch_stack(const StackArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(stack_kernel, dim3(a.batch), dim3(256), 0, s, a);
+  CHECK_LAUNCH();
+}
+int launch_absorb_error(const AbsorbArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(absorb_error_kernel, dim3(a.batch), dim3(256), 0, s, a);
   CHECK_LAUNCH();
 }
 int launch_oos(const OosArgs& a, hipStream_t s) {

@@ -66,6 +66,8 @@ void Estimator::ComputeInstateJacobians() {
   xivo_pose_in pose;
   std::memcpy(pose.Rsb, Rsb_.v, sizeof(pose.Rsb)); std::memcpy(pose.Tsb, Tsb_.v, sizeof(pose.Tsb));
   std::memcpy(pose.Rbc, Rbc_.v, sizeof(pose.Rbc)); std::memcpy(pose.Tbc, Tbc_.v, sizeof(pose.Tbc));
+  std::memcpy(pose.Vsb, Vsb_.v, sizeof(pose.Vsb)); std::memcpy(pose.bg, bg_.v, sizeof(pose.bg));
+  std::memcpy(pose.ba, ba_.v, sizeof(pose.ba)); std::memcpy(pose.Rsg, Rsg_.v, sizeof(pose.Rsg));
   std::vector<xivo_group_in> gs(lay_.n_groups);
   for (int g = 0; g < lay_.n_groups; ++g) {
     Mat3 I; Vec3 z;

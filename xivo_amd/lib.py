@@ -34,7 +34,8 @@ class Cam(C.Structure):
 
 # numpy dtypes mirroring the C structs (all naturally aligned, no padding surprises:
 # sizes are asserted against ctypes below)
-pose_dtype = np.dtype([("Rsb", "f8", 9), ("Tsb", "f8", 3), ("Rbc", "f8", 9), ("Tbc", "f8", 3)])
+pose_dtype = np.dtype([("Rsb", "f8", 9), ("Tsb", "f8", 3), ("Rbc", "f8", 9), ("Tbc", "f8", 3),
+                       ("Vsb", "f8", 3), ("bg", "f8", 3), ("ba", "f8", 3), ("Rsg", "f8", 9)])
 group_dtype = np.dtype([("Rsb", "f8", 9), ("Tsb", "f8", 3)])
 feat_dtype = np.dtype([("x", "f8", 3), ("xp", "f8", 2), ("ref_sind", "i4"), ("sind", "i4")])
 oos_dtype = np.dtype([("Xs", "f8", 3), ("n_obs", "i4"), ("group_sind", "i4", OOS_MAX_OBS),
@@ -47,7 +48,7 @@ class _OosC(C.Structure):
 
 
 assert oos_dtype.itemsize == C.sizeof(_OosC), (oos_dtype.itemsize, C.sizeof(_OosC))
-assert feat_dtype.itemsize == 48 and pose_dtype.itemsize == 192 and group_dtype.itemsize == 96
+assert feat_dtype.itemsize == 48 and pose_dtype.itemsize == 336 and group_dtype.itemsize == 96
 
 
 def lib_path():
@@ -86,6 +87,8 @@ _SIGS = {
     "xivo_hip_stack": [C.c_void_p, C.c_int, C.c_double],
     "xivo_hip_oos_project": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p],
     "xivo_hip_filter_update": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int],
+    "xivo_hip_absorb_error": [C.c_void_p, C.c_int],
+    "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_propagate_cov": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_timer_begin": [C.c_void_p],
@@ -309,6 +312,17 @@ class Context:
     def filter_update(self, R, thresh, mult, min_inliers, use_gating=True, B=None):
         self._check(self.lib.xivo_hip_filter_update(self.h, self.batch if B is None else B, R, thresh, mult,
                                                     min_inliers, int(use_gating)))
+
+    def absorb_error(self, B=None):
+        self._check(self.lib.xivo_hip_absorb_error(self.h, self.batch if B is None else B))
+
+    def get_scene(self, b0=0, nb=None):
+        nb = self.batch - b0 if nb is None else nb
+        poses = np.zeros(nb, dtype=pose_dtype)
+        groups = np.zeros((nb, self.layout.n_groups), dtype=group_dtype)
+        feats = np.zeros((nb, self.F), dtype=feat_dtype)
+        self._check(self.lib.xivo_hip_get_scene(self.h, b0, nb, _ptr(poses), _ptr(groups), _ptr(feats)))
+        return poses, groups, feats
 
     def get_H(self, b):
         M = C.c_int()
