@@ -211,6 +211,7 @@ def main():
     dt = max_over_ranks(dist, dt)
 
     status = ctx.get_status(check=False)
+    sparse_path = ctx.last_path() == 1
     prof = ctx.profile_get() if (flags & FLAG_PROFILE) else {}
     peak_meas = ctx.bench_mfma_peak() if rank == 0 else None
 
@@ -237,7 +238,9 @@ def main():
             if st["launches"] == 0:
                 continue
             kname = tile_of(*shape[name]) if name in shape else name
-            if name == "gemm_S" and M <= 176:
+            if sparse_path and name in ("gemm_HP", "gemm_S", "gemm_KH_I"):
+                kname = {"gemm_HP": "ell_mul_kernel<0>", "gemm_S": "ell_mul_kernel<1>", "gemm_KH_I": "ell_mul_kernel<2>"}[name]
+            elif name == "gemm_S" and M <= 176:
                 kname = "gemm_sym_f64_kernel"   # whole triangle in one workgroup (block-list kernel)
             if name == "gemm_AP" and kname == "gemm_nt_f64_kernel<4,4,double>":
                 kname = "gemm_nt_f64_kernel<4,2,double>"  # accumulator-initialised GEMMs run on the 128x64 tile
@@ -283,6 +286,8 @@ def main():
                                    ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
                                    f": state dim {N}, {F} features (M={M}), XIVO row sparsity, P/H/inn/R resident in HBM",
                        "filters_per_gpu": B, "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
+                       "pipeline": "sparse-H (row-pair compressed H, re-associated Joseph form)" if sparse_path
+                                   else "dense as-coded",
                        "gpu_event_ms_per_step": gpu_ms / args.steps,
                        "not_spd_filters": int((status != 0).sum())},
             "roofline": roofline,

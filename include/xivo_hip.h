@@ -65,7 +65,14 @@ enum {
    * fp32 accumulation; operands and results stay fp64 in HBM. HP, S, the factorisation, the gain and dx
    * stay fp64 because their error is amplified by cond(S). Stated tolerance: 5e-5 relative Frobenius on
    * P+ (measured 1.4e-5 at N=400/M=300, 5e-6 at N=250/M=160), dx unchanged (1e-8). */
-  XIVO_HIP_FLAG_FP32_COV = 32u
+  XIVO_HIP_FLAG_FP32_COV = 32u,
+  /* By default the update exploits the row sparsity of H: when every row pair of every filter of the
+   * call has at most 16 columns shared by most pairs + 12 private non-zero columns (true for the stacked
+   * in-state Jacobians of src/update.cpp:129-138: 21 per pair), H P, S and the H-products of the
+   * covariance stage skip the structural zeros (exact: the skipped terms are 0 * x) and the covariance
+   * stage uses the re-associated Joseph expression above. A denser H (OOS rows, arbitrary input) takes the
+   * as-coded dense path automatically. This flag forces the dense as-coded path for any H. */
+  XIVO_HIP_FLAG_DENSE_H = 64u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,
@@ -241,6 +248,8 @@ int xivo_hip_bench_mfma_peak(xivo_hip_ctx* ctx, double* out4);
 /* tile the batched GEMM picks for an (rows x cols) output (symmetric = lower
  * triangle + mirror mode), for DESIGN.md/tests */
 void xivo_hip_gemm_tile(int rows, int cols, int symmetric, int* bm, int* bn);
+/* which path the last update call took: 0 = dense as-coded, 1 = sparse-H (row-pair compressed) */
+int xivo_hip_last_path(xivo_hip_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ import pytest
 import xivo_oracle as orc
 from helpers import rel_fro, TOL_P, TOL_DX
 from xivo_amd import synth
-from xivo_amd.lib import Context, FLAG_FULL_PNEW
+from xivo_amd.lib import Context, FLAG_FULL_PNEW, FLAG_DENSE_H
 
 pytestmark = pytest.mark.gpu
 
@@ -19,14 +19,19 @@ CASES = [  # (N, F) -> M = 2F ; BASELINE.json configs + TUM-VI default build + r
 
 
 @pytest.mark.parametrize("N,F", CASES)
-@pytest.mark.parametrize("dense", [False, True])
-def test_update_joseph_matches_oracle(built, N, F, dense):
+@pytest.mark.parametrize("kind", ["sparse", "dense", "sparse_forced_dense"])
+def test_update_joseph_matches_oracle(built, N, F, kind):
+    """kind: XIVO row sparsity -> sparse-H pipeline (ell.h); dense H -> as-coded dense pipeline picked
+    automatically; the same sparse H with XIVO_HIP_FLAG_DENSE_H -> as-coded dense pipeline."""
     B = 5
+    dense = kind == "dense"
     P, H, inn, dR = synth.s_level(N, F, B, seed=N * 7 + F, dense=dense)
-    with Context(N, 2 * F, B) as ctx:
+    with Context(N, 2 * F, B, flags=FLAG_DENSE_H if kind == "sparse_forced_dense" else 0) as ctx:
         ctx.upload_P(P)
         ctx.set_measurements(H, inn, dR)
         ctx.update_joseph()
+        # dense H with 2 features on a 37-dim state still fits the compressed form (<= 28 columns)
+        assert ctx.last_path() == (1 if kind == "sparse" or (dense and N <= 28) else 0)
         err = ctx.get_err()
         Pn = ctx.download_P()
         assert (ctx.get_status() == 0).all()
@@ -123,10 +128,11 @@ def _oracle_gate(P, H, inn, R, thresh, mult, min_inl):
     return orc.mh_gate(d, thresh, mult, min_inl)[0], d
 
 
-def test_mh_gate_dense_matches_oracle(built):
+@pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])
+def test_mh_gate_dense_matches_oracle(built, flags):
     N, F, B = 150, 50, 4
     P, H, inn, dR = _gating_case(N, F, B, 21)
-    with Context(N, 2 * F, B) as ctx:
+    with Context(N, 2 * F, B, flags=flags) as ctx:
         ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
         mask, dist = ctx.mh_gate_dense(F, 2.25, 5.991, 1.1, 5)
         ctx.update_joseph()
@@ -139,11 +145,12 @@ def test_mh_gate_dense_matches_oracle(built):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
 
 
+@pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])
 @pytest.mark.parametrize("N,F", [(150, 50), (250, 80)])
-def test_update_dense_gated_single_pass(built, N, F):
+def test_update_dense_gated_single_pass(built, N, F, flags):
     B = 3
     P, H, inn, dR = _gating_case(N, F, B, 33)
-    with Context(N, 2 * F, B) as ctx:
+    with Context(N, 2 * F, B, flags=flags) as ctx:
         ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
         ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5)
         mask, dist = ctx.get_gate(F)
@@ -244,3 +251,43 @@ def test_fp32_covariance_products_config4(built, N, F, dense):
         assert np.array_equal(Pn[b], Pn[b].T)
     assert worst < TOL_P_FP32, worst
     print("fp32 covariance products: worst rel. Frobenius error on P+ = %.2e at N=%d" % (worst, N))
+
+
+def test_mixed_batch_falls_back_to_dense_path(built):
+    """One filter with a dense H in the batch: the whole call takes the as-coded dense pipeline."""
+    N, F, B = 150, 50, 4
+    P, H, inn, dR = synth.s_level(N, F, B, seed=77)
+    H[2] = synth.s_level(N, F, 1, seed=78, dense=True)[1][0]
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        assert ctx.last_path() == 0
+        ctx.upload_P(P); ctx.update_joseph(B=2)          # filters 0..1 alone are sparse
+        assert ctx.last_path() == 1
+        err = ctx.get_err(0, 2); Pn = ctx.download_P(0, 2)
+    for b in range(2):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+def test_sparse_path_with_structural_zero_in_common_column(built):
+    """A feature whose Jacobian has exact zeros in the shared pose columns, an all-zero row pair in the middle,
+    and a pair with 13 private columns (does not fit -> dense fallback for that batch)."""
+    N, F, B = 120, 20, 2
+    P, H, inn, dR = synth.s_level(N, F, B, seed=5)
+    H[:, 6:8, 0:6] = 0.0          # feature 3: no dependence on the sensor pose
+    H[:, 10:12, :] = 0.0          # feature 5: empty pair
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        assert ctx.last_path() == 1
+        err = ctx.get_err(); Pn = ctx.download_P()
+        for b in range(B):
+            e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+            assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+        H2 = H.copy()
+        H2[1, 4, 60:73] = 1.0     # 13 extra private columns in one row
+        ctx.upload_P(P); ctx.set_measurements(H2, inn, dR); ctx.update_joseph()
+        assert ctx.last_path() == 0
+        err = ctx.get_err(); Pn = ctx.download_P()
+        for b in range(B):
+            e_ref, P_ref, _ = orc.update_joseph(H2[b], P[b], inn[b], dR[b])
+            assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX

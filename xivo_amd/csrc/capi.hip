@@ -11,6 +11,7 @@
 #include "../../include/xivo_hip.h"
 #include "common.h"
 #include "ekf_kernels.h"
+#include "ell.h"
 
 using namespace xivo_hip;
 
@@ -36,6 +37,10 @@ struct xivo_hip_ctx {
   double *K = nullptr, *A = nullptr, *T = nullptr, *invD = nullptr, *inn = nullptr, *diagR = nullptr;
   double *err = nullptr, *staging = nullptr, *scratch = nullptr;
   int* status = nullptr;
+  // row-pair compressed H (ell.h) + host mirror of the per-filter "does not fit" flag
+  EllBuffers ell{};
+  std::vector<int> ell_over_h;
+  int last_path = 0;
   size_t staging_elems = 0;
   long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0;
   int M = 0, Mp = 0;  // rows currently staged
@@ -225,7 +230,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
-                  c->mask, c->rows_instate, c->oos, c->oos_rows};
+                  c->mask, c->rows_instate, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.over};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
@@ -257,6 +262,9 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   A(&c->S, B * c->sS); A(&c->K, B * c->sK); A(&c->A, B * c->sP); A(&c->T, B * c->sP);
   A(&c->invD, B * c->sInvD); A(&c->inn, B * Mp); A(&c->diagR, B * Mp); A(&c->err, B * Np);
   A(&c->status, B); A(&c->scratch, B * Np);
+  c->ell.pairs_max = (int)(Mp / 2);
+  A(&c->ell.idx, B * c->ell.stride_idx()); A(&c->ell.val, B * c->ell.stride_val()); A(&c->ell.nc, B); A(&c->ell.over, B);
+  c->ell_over_h.assign(B, 1);
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t0) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t1) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc != XIVO_HIP_OK) { xivo_hip_destroy(c); return rc; }
@@ -378,12 +386,103 @@ int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   c->M = M; c->Mp = round_up16(M);
   // clear up to the allocated row count so stale rows of a previous, larger M vanish
   if (launch_unpack_meas(sH, sInn, sR, mb, M, c->Mpmax, N, c->Np, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  {  // row-pair compressed form of the same rows + which filters fit it
+    EllBuffers e = c->ell;
+    e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.over += b0;
+    if (launch_ell_build(mb.HT, mb.strideHT, mb.ldht, c->Np, c->Mpmax, e, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(c->ell_over_h.data() + b0, e.over, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return XIVO_HIP_OK;
 }
 
 // One pass of the update pipeline over filters [b0, b0 + B).
 struct GateParams { int F; double R, thresh, mult; int min_inliers; };
+
+// Sparse-H pipeline (ell.h): H P, S and T H^T skip the structural zeros of H on the vector ALU; the
+// factorisation, the gain and the two N x N x M covariance products stay on the MFMA kernels.
+//   HP = H P (+ P H^T)            ell_mul<HP>      estimator.cpp:1259
+//   [MH gating]                   gate_ell         update.cpp:60-96
+//   S = (HP) H^T + R              ell_mul<S>       estimator.cpp:1259-1263
+//   S = L L^T, K^T = S^-1 HP, dx  chol, trsm       estimator.cpp:1265-1267
+//   T = K (HP) - P = (KH - I) P   gemm (MFMA)      estimator.cpp:1276-1280 (left product)
+//   G = T H^T + K R               ell_mul<G>
+//   P+ = G K^T - T                gemm (MFMA)      = T (KH-I)^T + K R K^T, estimator.cpp:1280-1287
+static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams* gate) {
+  const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
+  double* P = c->P + (long)b0 * c->sP;
+  double* HP = c->HP + (long)b0 * c->sH;
+  double* PHT = c->PHT + (long)b0 * c->sK;
+  double* S = c->S + (long)b0 * c->sS;
+  double* K = c->K + (long)b0 * c->sK;
+  double* G = c->A + (long)b0 * c->sP;
+  double* T = c->T + (long)b0 * c->sP;
+  double* invD = c->invD + (long)b0 * c->sInvD;
+  double* inn = c->inn + (long)b0 * c->Mpmax;
+  double* diagR = c->diagR + (long)b0 * c->Mpmax;
+  const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0;
+  const int f32 = 0;
+  EllBuffers e = c->ell;
+  e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.over += b0;
+  const double nnz_flops = 2.0 * Mp * 21.0;   // per contiguous-index value: 21 structural non-zeros per row
+  int rc;
+  {
+    EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
+    a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B;
+    StageTimer st(c, ST_HP, nnz_flops * Np * B);
+    if (launch_ell_mul(ELL_HP, a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  if (gate) {
+    GateEllArgs a{}; a.ell = e;
+    a.H = c->H + (long)b0 * c->sH; a.strideH = c->sH; a.ldh = ldh;
+    a.HT = c->HT + (long)b0 * c->sHT; a.strideHT = c->sHT; a.ldht = Np; a.HP = HP; a.PHT = PHT;
+    a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
+    a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
+    a.F = gate->F; a.Np = Np; a.batch = B;
+    a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
+    StageTimer st(c, ST_GATE, 0.0);
+    c->gate_sparse_last = 0;
+    if (launch_gate_ell(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  {
+    EllMulArgs a{}; a.ell = e; a.Src = HP; a.strideSrc = c->sH; a.ldsrc = ldh; a.out = S; a.strideOut = c->sS; a.ldo = lds;
+    a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B;
+    StageTimer st(c, ST_S, nnz_flops * Mp * B);
+    if (launch_ell_mul(ELL_S, a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  {
+    CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
+    a.status = c->status + b0; a.batch = B;
+    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B);
+    if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  {
+    TrsmArgs a; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
+    a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
+    a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
+    a.batch = B;
+    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B);
+    if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  {  // T = K (HP) - P
+    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.fp32 = f32;
+    rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              T, c->sP, Np, x);
+    if (rc) return rc;
+  }
+  {  // G = T H^T + K diag(R)   [Np x Mp, in the A buffer]
+    EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sP; a.ldo = Np;
+    a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B;
+    StageTimer st(c, ST_KH, nnz_flops * Np * B);
+    if (launch_ell_mul(ELL_G, a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  {  // P+ = G K^T - T   (lower triangle + mirror)
+    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1; x.fp32 = f32;
+    rc = gemm(c, ST_PNEW, B, Np, Np, G, c->sP, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              P, c->sP, Np, x);
+  }
+  return rc;
+}
 
 static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams* gate = nullptr) {
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
@@ -402,6 +501,11 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   int rc;
   const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0;
   const int f32 = (c->flags & XIVO_HIP_FLAG_FP32_COV) ? 1 : 0;
+  // the fp32 covariance mode (config 4) is defined on the as-coded products: dense path
+  bool sparse = !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV));
+  for (int b = b0; sparse && b < b0 + B; ++b) sparse = c->ell_over_h[b] == 0;
+  c->last_path = sparse ? 1 : 0;
+  if (sparse) return update_sparse_range(c, b0, B, gate);
   {  // HP = H * P and its transpose PH^T (estimator.cpp:1259 first product; P symmetric => B operand = P rows)
     GemmExtra x; x.C2 = PHT; x.sC2 = c->sK; x.ldc2 = Np;
     rc = gemm(c, ST_HP, B, Mp, Np, H, c->sH, ldh, P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
@@ -417,6 +521,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.strideR = c->Mpmax; a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
     a.F = gate->F; a.Np = Np; a.batch = B;
     a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
+    a.ell = c->ell; a.have_ell = 0;
     StageTimer st(c, ST_GATE, 0.0);
     c->gate_sparse_last = 0;
     if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
@@ -515,6 +620,8 @@ int xivo_hip_update_dense_gated(xivo_hip_ctx* c, int B, int F, double R, double 
   return XIVO_HIP_OK;
 }
 
+int xivo_hip_last_path(xivo_hip_ctx* c) { return c ? c->last_path : -1; }
+
 int xivo_hip_get_gate(xivo_hip_ctx* c, int B, int F, unsigned char* mask_out, double* dist_out) {
   if (!c || B <= 0 || B > c->Bmax || F <= 0 || !c->mask) return XIVO_HIP_ERR_INVALID;
   // the dense gate packs [B][F]; the layout-faithful gate (xivo_hip_mh_gate / filter_update) strides by Fmax
@@ -581,6 +688,7 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
   a.inn = c->inn; a.strideInn = c->Mpmax; a.diagR = c->diagR; a.strideR = c->Mpmax;
   a.mask = c->mask; a.dist = c->dist; a.F = F; a.Np = Np; a.batch = B;
   a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;
+  a.ell = c->ell; a.have_ell = 1;
   {
     StageTimer st(c, ST_GATE, 0.0);
     c->gate_sparse_last = 0;
@@ -679,6 +787,8 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   a.fix_group_block = (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK) ? 1 : 0;
   a.rows_instate = c->rows_instate;
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
+  a.ell = c->ell; a.emit_ell = 1;
+  for (int b = 0; b < B; ++b) c->ell_over_h[b] = 0;
   StageTimer st(c, ST_STACK, 0.0);
   return launch_stack(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
@@ -719,6 +829,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   if (rows_out) HIP_TRY(hipMemcpyAsync(rows_out, c->oos_rows, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->M += max_rows; c->Mp = round_up16(c->M);
+  for (int b = b0; b < b0 + nb; ++b) c->ell_over_h[b] = 1;   // OOS rows are dense over the group blocks: dense path
   return XIVO_HIP_OK;
 }
 

@@ -1,6 +1,7 @@
 // Launchers of the EKF-specific (non-GEMM) kernels. See ekf_kernels.hip.
 #pragma once
 #include "common.h"
+#include "ell.h"
 #include "../../include/xivo_hip.h"
 
 namespace xivo_hip {
@@ -38,6 +39,7 @@ struct GateDenseArgs {
   unsigned char* mask; double* dist;            // [batch x F]
   int F, Np, batch;
   double R, thresh, mult; int min_inliers;
+  EllBuffers ell; int have_ell;                 // also zero the rejected pairs of the compressed form (ell.h)
 };
 int launch_gate_dense(const GateDenseArgs& a, hipStream_t s);
 
@@ -64,6 +66,7 @@ struct StackArgs {
   SceneBuffers sb; xivo_layout lay; MeasBuffers mb;
   int Mp, Np, batch; double R; int fix_group_block;
   int* rows_instate;   // [batch] out: 2 * F (rows reserved for in-state features)
+  EllBuffers ell; int emit_ell;   // also emit the row-pair compressed form (ell.h)
 };
 int launch_stack(const StackArgs& a, hipStream_t s);
 

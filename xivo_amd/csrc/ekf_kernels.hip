@@ -14,6 +14,7 @@
 // reductions for the chi-square gating, no MFMA.
 #include "ekf_kernels.h"
 #include "camera_device.h"
+#include "gate_device.h"
 
 namespace xivo_hip {
 
@@ -90,45 +91,6 @@ __global__ void p_diag_kernel(const double* P, int ldp, int N, double* out) {
   if (t < N) out[t] = P[t + (long)t * ldp];
 }
 
-// ---------------------------------------------------------------- gating core
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// d = res^T (S.llt().solve(res)) for 2x2 S given by its lower triangle
-// (src/update.cpp:65-69; Eigen LLT reads the lower triangle)
-__device__ __forceinline__ double mh_dist_2x2(double s00, double s10, double s11, double r0, double r1) {
-  const double l00 = sqrt(s00);
-  const double l10 = s10 / l00;
-  const double l11 = sqrt(s11 - l10 * l10);
-  const double y0 = r0 / l00;
-  const double y1 = (r1 - l10 * y0) / l11;
-  const double x1 = y1 / l11;
-  const double x0 = (y0 - l10 * x1) / l00;
-  return r0 * x0 + r1 * x1;
-}
-
-// threshold relaxation loop of src/update.cpp:73-96, run by one wave over the
-// F distances in LDS. Returns the threshold that was in force when the loop
-// exited (inlier <=> dist < thresh).
-__device__ double relax_threshold(const double* sdist, int F, double thresh, double mult, int min_inliers,
-                                  int lane) {
-  if (min_inliers <= 0) return -1.0;  // loop body never runs: no inliers (update.cpp:73)
-  for (int it = 0; it < 4096; ++it) {
-    int cnt = 0;
-    for (int f0 = 0; f0 < F; f0 += 64) {
-      const int f = f0 + lane;
-      const bool in = (f < F) && (sdist[f] < thresh);
-      cnt += __popcll(__ballot(in));
-    }
-    if (cnt >= min_inliers || cnt == F) return thresh;
-    thresh *= mult;
-  }
-  return thresh;
-}
-
 __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
   const int filt = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -172,6 +134,10 @@ __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
       inn[2 * f] = 0.0; inn[2 * f + 1] = 0.0;
       double* dr = a.diagR + (long)filt * a.strideR;
       dr[2 * f] = 1.0; dr[2 * f + 1] = 1.0;
+      if (a.have_ell) {
+        double* ev = a.ell.val + (long)filt * a.ell.stride_val() + (long)f * ELL_W * 2;
+        for (int t = 0; t < 2 * ELL_W; ++t) ev[t] = 0.0;
+      }
     }
   }
   // neutralise rejected rows of H / H^T
@@ -462,6 +428,40 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
     dR[2 * f] = a.R; dR[2 * f + 1] = a.R;            // update.cpp:137
   }
   if (tid == 0 && a.rows_instate) a.rows_instate[filt] = 2 * sb.F;
+  if (!a.emit_ell) return;
+  // row-pair compressed form: the 12 sensor pose / extrinsics columns are the common slots, the
+  // group and feature blocks the private ones (ell.h)
+  int* eidx = a.ell.idx + (long)filt * a.ell.stride_idx();
+  double* eval = a.ell.val + (long)filt * a.ell.stride_val();
+  if (tid == 0) { a.ell.nc[filt] = 12; a.ell.over[filt] = 0; }
+  for (int p = tid; p < a.Mp / 2; p += 256) {
+    int* pi = eidx + (long)p * ELL_W;
+    double* pv = eval + (long)p * ELL_W * 2;
+    const bool on = p < sb.F && sb.mask[(long)filt * sb.Fmax + p];
+    const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + (p < sb.F ? p : 0)];
+    const double* J = sb.J + ((long)filt * sb.Fmax + (p < sb.F ? p : 0)) * 42;
+    for (int t = 0; t < ELL_CW; ++t) {
+      pi[t] = t < 12 ? jcol(a.lay, ft, t) : 0;
+      pv[2 * t] = (on && t < 12) ? J[t] : 0.0;
+      pv[2 * t + 1] = (on && t < 12) ? J[21 + t] : 0.0;
+    }
+    int t = ELL_CW;
+    if (on) {
+      for (int b = 4; b < 7; ++b) {
+        int src = b;
+        if (!a.fix_group_block) {
+          if (b == 4) src = 5;
+          else if (b == 5) continue;
+        }
+        for (int o = 0; o < 3; ++o, ++t) {
+          pi[t] = jcol(a.lay, ft, 3 * b + o);
+          pv[2 * t] = J[3 * src + o];
+          pv[2 * t + 1] = J[21 + 3 * src + o];
+        }
+      }
+    }
+    for (; t < ELL_W; ++t) { pi[t] = -1; pv[2 * t] = 0.0; pv[2 * t + 1] = 0.0; }
+  }
 }
 
 // ---------------------------------------------------------------- AbsorbError

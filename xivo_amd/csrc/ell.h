@@ -1,0 +1,74 @@
+// Row-pair compressed measurement Jacobian ("ELL" form of H) and the kernels that use it.
+//
+// The stacked H of Estimator::FilterUpdate (src/update.cpp:129-138) has two rows per feature, and
+// Feature::FillJacobianBlock (src/feature.cpp:658-684) writes only seven 2x3 blocks into each row
+// pair: 21 of the N columns (18 with the overwrite of :675-676). The reference multiplies H as a
+// dense Eigen matrix (src/estimator.cpp:1259-1280); every term it adds for a structurally zero entry
+// is an exact 0 * x = 0, so skipping those terms changes nothing but the summation order.
+//
+// Layout per filter, per row pair p (rows 2p, 2p+1), ELL_W = ELL_CW + ELL_PW slots:
+//   slots [0, ELL_CW)      "common" columns: slot t names the SAME state column in every pair of the
+//                          filter (the sensor pose / extrinsics blocks every feature touches); a value
+//                          may be 0; unused slots have idx 0 and value 0
+//   slots [ELL_CW, ELL_W)  "private" columns of the pair in ascending order (group anchor + feature
+//                          blocks); unused slots have idx -1
+//   val[slot] = (H[2p][idx], H[2p+1][idx])
+// A filter whose H does not fit (some pair has more than ELL_PW private columns: dense H, OOS rows)
+// gets over[filter] = 1 and is updated by the dense kernels instead.
+#pragma once
+#include "common.h"
+
+namespace xivo_hip {
+
+constexpr int ELL_CW = 16, ELL_PW = 12, ELL_W = ELL_CW + ELL_PW;
+
+struct EllBuffers {
+  int* idx;        // [batch][pairs_max][ELL_W]
+  double* val;     // [batch][pairs_max][ELL_W][2]
+  int* nc;         // [batch] number of common slots in use
+  int* over;       // [batch] 1: does not fit
+  int pairs_max;   // Mpmax / 2
+  __host__ __device__ long stride_idx() const { return (long)pairs_max * ELL_W; }
+  __host__ __device__ long stride_val() const { return (long)pairs_max * ELL_W * 2; }
+};
+
+// Build the ELL form from the dense transposed copy H^T [Np x Mp] (column n contiguous).
+int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, EllBuffers e, int batch,
+                     hipStream_t s);
+
+// out[x + ldo * m] = sum_slots val[m][slot] * Src[x + lds * idx[m][slot]]  (+ epilogue), x in [0, X)
+enum EllMode : int {
+  ELL_HP = 0,   // Src = P (symmetric): out = P H^T [Np x Mp], out2 = H P [Mp x Np]      (estimator.cpp:1259)
+  ELL_S = 1,    // Src = HP [Mp x Np] : out = S = (HP) H^T + diag(R), stored transposed  (estimator.cpp:1259-1263)
+  ELL_G = 2,    // Src = T  [Np x Np] : out = T H^T + K diag(R)  [Np x Mp]               (re-associated :1280-1287)
+};
+struct EllMulArgs {
+  EllBuffers ell;
+  const double* Src; long strideSrc; int ldsrc;
+  double* out; long strideOut; int ldo;
+  double* out2; long strideOut2; int ldo2;      // ELL_HP only
+  const double* diagR; long strideR;            // ELL_S, ELL_G
+  const double* K; long strideK; int ldk;       // ELL_G
+  int X;        // extent of the contiguous index (Np for HP/G, Mp for S)
+  int Mp;       // rows of H in use (multiple of 16)
+  int batch;
+};
+int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s);
+
+// Estimator::MHGating numeric core (src/update.cpp:60-96) on the ELL rows: S_f = H_f (P H_f^T) + R I2
+// from the already formed P H^T, threshold relaxation, then neutralisation of the rejected pairs
+// (ELL values, H / H^T / HP / P H^T rows = 0, inn = 0, diagR = 1).
+struct GateEllArgs {
+  EllBuffers ell;
+  double* H; long strideH; int ldh;        // dense copies kept consistent for xivo_hip_get_H
+  double* HT; long strideHT; int ldht;
+  double* HP; double* PHT;                 // same shapes / strides as H / HT
+  double* inn; long strideInn;
+  double* diagR; long strideR;
+  unsigned char* mask; double* dist;       // [batch x F]
+  int F, Np, batch;
+  double R, thresh, mult; int min_inliers;
+};
+int launch_gate_ell(const GateEllArgs& a, hipStream_t s);
+
+}  // namespace xivo_hip

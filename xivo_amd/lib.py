@@ -12,6 +12,7 @@ FLAG_FULL_PNEW = 4
 FLAG_TILE_SYM = 8
 FLAG_REASSOC = 16
 FLAG_FP32_COV = 32
+FLAG_DENSE_H = 64
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
 
@@ -87,6 +88,7 @@ _SIGS = {
     "xivo_hip_stack": [C.c_void_p, C.c_int, C.c_double],
     "xivo_hip_oos_project": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p],
     "xivo_hip_filter_update": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int],
+    "xivo_hip_last_path": [C.c_void_p],
     "xivo_hip_absorb_error": [C.c_void_p, C.c_int],
     "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
@@ -312,6 +314,10 @@ class Context:
     def filter_update(self, R, thresh, mult, min_inliers, use_gating=True, B=None):
         self._check(self.lib.xivo_hip_filter_update(self.h, self.batch if B is None else B, R, thresh, mult,
                                                     min_inliers, int(use_gating)))
+
+    def last_path(self):
+        """0: dense as-coded pipeline, 1: sparse-H (row-pair compressed) pipeline."""
+        return int(self.lib.xivo_hip_last_path(self.h))
 
     def absorb_error(self, B=None):
         self._check(self.lib.xivo_hip_absorb_error(self.h, self.batch if B is None else B))
