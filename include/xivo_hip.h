@@ -72,7 +72,13 @@ enum {
    * covariance stage skip the structural zeros (exact: the skipped terms are 0 * x) and the covariance
    * stage uses the re-associated Joseph expression above. A denser H (OOS rows, arbitrary input) takes the
    * as-coded dense path automatically. This flag forces the dense as-coded path for any H. */
-  XIVO_HIP_FLAG_DENSE_H = 64u
+  XIVO_HIP_FLAG_DENSE_H = 64u,
+  /* In the sparse-H pipeline P+ = -T + G K^T with -T = P - K(HP) (fp64) and the Joseph correction
+   * G K^T, G = T H^T + K R, which is O(eps * cond(S)) relative to P because K is the gain of this very S.
+   * By default that correction PRODUCT runs on the fp32 MFMA (G itself - a cancellation - and -T stay
+   * fp64): its rounding adds <= 1e-7 |G K^T| to P+, orders of magnitude below the fp64 rounding of -T.
+   * This flag keeps the correction product in fp64 as well. */
+  XIVO_HIP_FLAG_FP64_CORR = 128u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,

@@ -291,3 +291,23 @@ def test_sparse_path_with_structural_zero_in_common_column(built):
         for b in range(B):
             e_ref, P_ref, _ = orc.update_joseph(H2[b], P[b], inn[b], dR[b])
             assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+@pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (400, 150)])
+def test_fp32_correction_product_is_invisible(built, N, F):
+    """Sparse-H pipeline: P+ = -T + G K^T with the correction product G K^T on the fp32 MFMA (default) vs in
+    fp64 (XIVO_HIP_FLAG_FP64_CORR). G is the O(eps) residual of the gain equation, so the two agree to ~1e-15
+    relative and both sit at the fp64 rounding level from the oracle - far inside TOL_P."""
+    from xivo_amd.lib import FLAG_FP64_CORR
+    B = 3
+    P, H, inn, dR = synth.s_level(N, F, B, seed=91)
+    outs = []
+    for flags in (0, FLAG_FP64_CORR):
+        with Context(N, 2 * F, B, flags=flags) as ctx:
+            ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+            assert ctx.last_path() == 1
+            outs.append(ctx.download_P())
+    assert rel_fro(outs[0], outs[1]) < 1e-12
+    for b in range(B):
+        _, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(outs[0][b], P_ref) < 1e-10

@@ -39,10 +39,10 @@ struct xivo_hip_ctx {
   int* status = nullptr;
   // row-pair compressed H (ell.h) + host mirror of the per-filter "does not fit" flag
   EllBuffers ell{};
-  std::vector<int> ell_over_h;
+  std::vector<int> ell_over_h, ell_nc_h;
   int last_path = 0;
   size_t staging_elems = 0;
-  long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0;
+  long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0, sA = 0;   // sA: A buffer, max(N x N, N x M)
   int M = 0, Mp = 0;  // rows currently staged
   int chunk = 0;      // filters per pipeline pass (0 = whole batch)
   // G-level
@@ -254,17 +254,17 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   const size_t B = batch_max;
   const size_t Np = c->Np, Mp = c->Mpmax;
   c->sP = (long)(Np * Np); c->sH = (long)(Mp * Np); c->sHT = (long)(Np * Mp); c->sS = (long)(Mp * Mp);
-  c->sK = (long)(Np * Mp); c->sInvD = (long)(Mp / 16 * 512);
+  c->sK = (long)(Np * Mp); c->sInvD = (long)(Mp / 16 * 512); c->sA = c->sP > c->sK ? c->sP : c->sK;
   int rc = XIVO_HIP_OK;
   auto A = [&](auto** p, size_t n) { if (rc == XIVO_HIP_OK) rc = dev_alloc(p, n); };
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return XIVO_HIP_ERR_HIP; }
   A(&c->P, B * c->sP); A(&c->H, B * c->sH); A(&c->HT, B * c->sHT); A(&c->HP, B * c->sH); A(&c->PHT, B * c->sK);
-  A(&c->S, B * c->sS); A(&c->K, B * c->sK); A(&c->A, B * c->sP); A(&c->T, B * c->sP);
+  A(&c->S, B * c->sS); A(&c->K, B * c->sK); A(&c->A, B * c->sA); A(&c->T, B * c->sP);
   A(&c->invD, B * c->sInvD); A(&c->inn, B * Mp); A(&c->diagR, B * Mp); A(&c->err, B * Np);
   A(&c->status, B); A(&c->scratch, B * Np);
   c->ell.pairs_max = (int)(Mp / 2);
   A(&c->ell.idx, B * c->ell.stride_idx()); A(&c->ell.val, B * c->ell.stride_val()); A(&c->ell.nc, B); A(&c->ell.over, B);
-  c->ell_over_h.assign(B, 1);
+  c->ell_over_h.assign(B, 1); c->ell_nc_h.assign(B, ELL_CW);
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t0) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t1) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc != XIVO_HIP_OK) { xivo_hip_destroy(c); return rc; }
@@ -391,6 +391,7 @@ int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
     e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.over += b0;
     if (launch_ell_build(mb.HT, mb.strideHT, mb.ldht, c->Np, c->Mpmax, e, nb, c->stream)) return XIVO_HIP_ERR_HIP;
     HIP_TRY(hipMemcpyAsync(c->ell_over_h.data() + b0, e.over, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ell_nc_h.data() + b0, e.nc, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return XIVO_HIP_OK;
@@ -415,7 +416,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   double* PHT = c->PHT + (long)b0 * c->sK;
   double* S = c->S + (long)b0 * c->sS;
   double* K = c->K + (long)b0 * c->sK;
-  double* G = c->A + (long)b0 * c->sP;
+  double* G = c->A + (long)b0 * c->sA;
   double* T = c->T + (long)b0 * c->sP;
   double* invD = c->invD + (long)b0 * c->sInvD;
   double* inn = c->inn + (long)b0 * c->Mpmax;
@@ -424,11 +425,13 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   const int f32 = 0;
   EllBuffers e = c->ell;
   e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.over += b0;
+  int nc_max = 0;
+  for (int b = b0; b < b0 + B; ++b) nc_max = c->ell_nc_h[b] > nc_max ? c->ell_nc_h[b] : nc_max;
   const double nnz_flops = 2.0 * Mp * 21.0;   // per contiguous-index value: 21 structural non-zeros per row
   int rc;
   {
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
-    a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B;
+    a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.cols = Np;
     StageTimer st(c, ST_HP, nnz_flops * Np * B);
     if (launch_ell_mul(ELL_HP, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
@@ -445,8 +448,9 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (launch_gate_ell(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {
-    EllMulArgs a{}; a.ell = e; a.Src = HP; a.strideSrc = c->sH; a.ldsrc = ldh; a.out = S; a.strideOut = c->sS; a.ldo = lds;
-    a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B;
+    EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
+    a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
+    a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max;
     StageTimer st(c, ST_S, nnz_flops * Mp * B);
     if (launch_ell_mul(ELL_S, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
@@ -471,14 +475,15 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (rc) return rc;
   }
   {  // G = T H^T + K diag(R)   [Np x Mp, in the A buffer]
-    EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sP; a.ldo = Np;
-    a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B;
+    EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sA; a.ldo = Np;
+    a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.cols = Np;
     StageTimer st(c, ST_KH, nnz_flops * Np * B);
     if (launch_ell_mul(ELL_G, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // P+ = G K^T - T   (lower triangle + mirror)
-    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1; x.fp32 = f32;
-    rc = gemm(c, ST_PNEW, B, Np, Np, G, c->sP, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
+    x.fp32 = (c->flags & XIVO_HIP_FLAG_FP64_CORR) ? 0 : 1;   // correction product on the fp32 MFMA, T added in fp64
+    rc = gemm(c, ST_PNEW, B, Np, Np, G, c->sA, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               P, c->sP, Np, x);
   }
   return rc;
@@ -788,7 +793,7 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   a.rows_instate = c->rows_instate;
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
   a.ell = c->ell; a.emit_ell = 1;
-  for (int b = 0; b < B; ++b) c->ell_over_h[b] = 0;
+  for (int b = 0; b < B; ++b) { c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12; }
   StageTimer st(c, ST_STACK, 0.0);
   return launch_stack(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
         }
       }
     }
-    for (; t < ELL_W; ++t) { pi[t] = -1; pv[2 * t] = 0.0; pv[2 * t + 1] = 0.0; }
+    for (; t < ELL_W; ++t) { pi[t] = 0; pv[2 * t] = 0.0; pv[2 * t + 1] = 0.0; }
   }
 }
 

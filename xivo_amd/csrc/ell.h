@@ -11,7 +11,7 @@
 //                          filter (the sensor pose / extrinsics blocks every feature touches); a value
 //                          may be 0; unused slots have idx 0 and value 0
 //   slots [ELL_CW, ELL_W)  "private" columns of the pair in ascending order (group anchor + feature
-//                          blocks); unused slots have idx -1
+//                          blocks); unused slots have idx 0 and value 0
 //   val[slot] = (H[2p][idx], H[2p+1][idx])
 // A filter whose H does not fit (some pair has more than ELL_PW private columns: dense H, OOS rows)
 // gets over[filter] = 1 and is updated by the dense kernels instead.
@@ -39,18 +39,24 @@ int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, 
 // out[x + ldo * m] = sum_slots val[m][slot] * Src[x + lds * idx[m][slot]]  (+ epilogue), x in [0, X)
 enum EllMode : int {
   ELL_HP = 0,   // Src = P (symmetric): out = P H^T [Np x Mp], out2 = H P [Mp x Np]      (estimator.cpp:1259)
-  ELL_S = 1,    // Src = HP [Mp x Np] : out = S = (HP) H^T + diag(R), stored transposed  (estimator.cpp:1259-1263)
+  ELL_S = 1,    // Src = P H^T [Np x Mp] (tile form) or HP [Mp x Np] (gather form): out = S = (HP) H^T + diag(R)
+                //                                                                 (estimator.cpp:1259-1263)
   ELL_G = 2,    // Src = T  [Np x Np] : out = T H^T + K diag(R)  [Np x Mp]               (re-associated :1280-1287)
 };
 struct EllMulArgs {
   EllBuffers ell;
   const double* Src; long strideSrc; int ldsrc;
+  int cols;     // number of source columns a slot index can name (Np)
+  const double* SrcAlt; long strideSrcAlt; int ldsrcAlt;   // ELL_S: H P [Mp x Np] for the gather fallback (may be null if the tile form fits)
   double* out; long strideOut; int ldo;
   double* out2; long strideOut2; int ldo2;      // ELL_HP only
   const double* diagR; long strideR;            // ELL_S, ELL_G
   const double* K; long strideK; int ldk;       // ELL_G
   int X;        // extent of the contiguous index (Np for HP/G, Mp for S)
   int Mp;       // rows of H in use (multiple of 16)
+  int dbg;
+  int rb_per_wg; // set by the launcher: 16-row blocks one workgroup walks
+  int nc_max;   // upper bound of nc over the filters of the launch (host mirror)
   int batch;
 };
 int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s);

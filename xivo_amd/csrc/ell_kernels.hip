@@ -3,6 +3,7 @@
 // columns of the source matrix, 512 B per wave load; no MFMA (a row pair has 21 non-zeros).
 #include "ell.h"
 #include "gate_device.h"
+#include <stdlib.h>
 
 namespace xivo_hip {
 
@@ -75,87 +76,174 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const double* __restrict
       pos += __popcll(m);
     }
     if (pos > ELL_PW) { if (lane == 0) e.over[filt] = 1; }
-    else if (lane >= pos && lane < ELL_PW) { pi[ELL_CW + lane] = -1; pv[2 * (ELL_CW + lane)] = 0.0; pv[2 * (ELL_CW + lane) + 1] = 0.0; }
+    else if (lane >= pos && lane < ELL_PW) { pi[ELL_CW + lane] = 0; pv[2 * (ELL_CW + lane)] = 0.0; pv[2 * (ELL_CW + lane) + 1] = 0.0; }
   }
 }
 
 // ---------------------------------------------------------------- out = H_ell (x) Src
-// Workgroup = (filter, block of 8 row pairs = 16 rows of H, chunk of 256 values of the contiguous
-// index). The workgroups of one filter share an XCD so the source columns they re-read hit its L2.
-// The common columns are loaded once per lane and reused by the 8 pairs.
-template <int MODE>
+// Workgroup = (filter, chunk of 256 values of the contiguous index, range of 16-row blocks of H).
+// For a big batch one workgroup walks ALL row blocks of its chunk, so every source element is
+// fetched from HBM by exactly one workgroup (its re-reads - a group block is shared by the features
+// anchored to it - hit L1/L2) and the common columns are loaded once; for a small batch the row blocks
+// are spread over workgroups instead (latency mode). Slot indices / values are wave-uniform scalar loads.
+template <int MODE, int CWU>
 __global__ __launch_bounds__(256) void ell_mul_kernel(EllMulArgs a) {
   const int xchunks = (a.X + 255) / 256;
-  const int per = (a.Mp / 16) * xchunks;
+  const int nrb = a.Mp / 16;
+  const int rsplit = (nrb + a.rb_per_wg - 1) / a.rb_per_wg;
+  const int per = rsplit * xchunks;
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
   const int filt = (slot / per) * 8 + xcd;
   if (filt >= a.batch) return;
   const int sub = slot % per;
-  const int rb = sub / xchunks, xc = sub % xchunks;
+  const int rs = sub / xchunks, xc = sub % xchunks;
   const int x = xc * 256 + threadIdx.x;
   const bool live = x < a.X;
   const int xs = live ? x : 0;
-  const int* __restrict__ idx = a.ell.idx + (long)filt * a.ell.stride_idx() + (long)rb * 8 * ELL_W;
-  const double* __restrict__ val = a.ell.val + (long)filt * a.ell.stride_val() + (long)rb * 8 * ELL_W * 2;
   const double* __restrict__ Src = a.Src + (long)filt * a.strideSrc + xs;
-  const int nc = a.ell.nc[filt];
+  const int* __restrict__ idx0 = a.ell.idx + (long)filt * a.ell.stride_idx();
+  const double* __restrict__ val0 = a.ell.val + (long)filt * a.ell.stride_val();
 
-  double cm[ELL_CW];
+  // branch-free on purpose: unused slots name column 0 with value 0, so every load below is
+  // unconditional and a pair's loads are all in flight together
+  double cm[CWU];
 #pragma unroll
-  for (int t = 0; t < ELL_CW; ++t) cm[t] = t < nc ? Src[(long)idx[t] * a.ldsrc] : 0.0;
+  for (int t = 0; t < CWU; ++t) cm[t] = Src[(long)idx0[t] * a.ldsrc];
 
-  double acc[8][2];
+  const double* __restrict__ dR = a.diagR + (long)filt * a.strideR;
+  const double* __restrict__ K = a.K + (long)filt * a.strideK + xs;
+  double* __restrict__ out = a.out + (long)filt * a.strideOut + xs;
+  double* __restrict__ out2 = a.out2 + (long)filt * a.strideOut2 + (long)xs * a.ldo2;
+  const int p_end = 8 * min(nrb, (rs + 1) * a.rb_per_wg);
+  // runtime loop over row pairs, two per trip: bounds the loads in flight (24 per lane) and the registers
+#pragma unroll 2
+  for (int p = 8 * rs * a.rb_per_wg; p < p_end; ++p) {
+    const int* __restrict__ pi = idx0 + (long)p * ELL_W + ELL_CW;
+    const double* __restrict__ pv = val0 + (long)p * ELL_W * 2;
+    double sv[ELL_PW];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int* __restrict__ pi = idx + p * ELL_W;
-    const double* __restrict__ pv = val + p * ELL_W * 2;
+    for (int t = 0; t < ELL_PW; ++t) sv[t] = Src[(long)pi[t] * a.ldsrc];
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-    for (int t = 0; t < ELL_CW; ++t) {
-      if (t < nc) { a0 = fma(pv[2 * t], cm[t], a0); a1 = fma(pv[2 * t + 1], cm[t], a1); }
-    }
+    for (int t = 0; t < CWU; ++t) { a0 = fma(pv[2 * t], cm[t], a0); a1 = fma(pv[2 * t + 1], cm[t], a1); }
 #pragma unroll
-    for (int t = ELL_CW; t < ELL_W; ++t) {
-      const int k = pi[t];
-      if (k >= 0) {
-        const double s = Src[(long)k * a.ldsrc];
-        a0 = fma(pv[2 * t], s, a0); a1 = fma(pv[2 * t + 1], s, a1);
-      }
+    for (int t = 0; t < ELL_PW; ++t) {
+      a0 = fma(pv[2 * (ELL_CW + t)], sv[t], a0); a1 = fma(pv[2 * (ELL_CW + t) + 1], sv[t], a1);
     }
-    acc[p][0] = a0; acc[p][1] = a1;
+    if (!live) continue;
+    const int m = 2 * p;
+    if (MODE == ELL_HP) {
+      out[(long)m * a.ldo] = a0;
+      out[(long)(m + 1) * a.ldo] = a1;
+      *reinterpret_cast<d2*>(out2 + m) = d2{a0, a1};
+    } else if (MODE == ELL_S) {
+      out[(long)m * a.ldo] = a0 + (x == m ? dR[m] : 0.0);
+      out[(long)(m + 1) * a.ldo] = a1 + (x == m + 1 ? dR[m + 1] : 0.0);
+    } else {
+      out[(long)m * a.ldo] = fma(K[(long)m * a.ldk], dR[m], a0);
+      out[(long)(m + 1) * a.ldo] = fma(K[(long)(m + 1) * a.ldk], dR[m + 1], a1);
+    }
   }
-  if (!live) return;
-  const int m0 = rb * 16;
-  double* __restrict__ out = a.out + (long)filt * a.strideOut + x;
-  if (MODE == ELL_HP) {
-    double* __restrict__ out2 = a.out2 + (long)filt * a.strideOut2 + m0 + (long)x * a.ldo2;
+}
+
+// ---------------------------------------------------------------- tile-in-LDS variant
+// The gather form above re-fetches a source column once per row pair that names it (a group block is
+// shared by the features anchored to it, and the 12 pose columns by everybody): ~4x the size of the
+// source per filter, served by L2 / Infinity Cache. Here a workgroup first parks an XC-wide slab of
+// the source (all columns x XC values of the contiguous index) in LDS - each source element leaves HBM
+// exactly once - and then its waves walk the row pairs of the filter gathering from LDS. Slot indices
+// and values are wave-uniform SCALAR loads: the arrays are read through constant-address-space pointers
+// (they were written by an earlier kernel), otherwise the stores of the loop would demote them to
+// per-lane vector loads.
+//   XC = 64: lane = x, both rows of the pair per lane (one workgroup of 16 waves per CU, slab <= 158 KB)
+//   XC = 32: lanes 0..31 row 2p, lanes 32..63 row 2p+1 (for wider sources)
+// LDS slab: [cols][XC + 1] doubles (odd pitch: the transposing load of ELL_S writes column-wise).
+typedef __attribute__((address_space(4))) const double ell_cdouble;
+typedef __attribute__((address_space(4))) const int ell_cint;
+
+template <int MODE, int CWU, int XC>
+__global__ __launch_bounds__(1024) void ell_tile_kernel(EllMulArgs a) {
+  constexpr int LD = XC + 1;
+  extern __shared__ __attribute__((aligned(16))) double tile[];
+  const int xchunks = (a.X + XC - 1) / XC;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int filt = (slot / xchunks) * 8 + xcd;
+  if (filt >= a.batch) return;
+  const int x0 = (slot % xchunks) * XC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const double* __restrict__ Src = a.Src + (long)filt * a.strideSrc;
+  const int cols = a.cols;
+  if (MODE == ELL_S) {
+    // source = P H^T [cols x Mp] (column j contiguous over the state index): slab[k][jj] = PHT[k, x0 + jj]
+    for (int jj = wave; jj < XC; jj += nw) {
+      const bool ok = x0 + jj < a.X;
+      const double* __restrict__ col = Src + (long)(x0 + jj) * a.ldsrc;
+      for (int k0 = 0; k0 < cols; k0 += 64 * 8) {
+        double r[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      out[(long)(m0 + 2 * p) * a.ldo] = acc[p][0];
-      out[(long)(m0 + 2 * p + 1) * a.ldo] = acc[p][1];
-      *reinterpret_cast<d2*>(out2 + 2 * p) = d2{acc[p][0], acc[p][1]};
-    }
-  } else if (MODE == ELL_S) {
-    const double* __restrict__ dR = a.diagR + (long)filt * a.strideR;
+        for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; r[u] = (ok && k < cols) ? col[k] : 0.0; }
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 2 * p + i;
-        out[(long)m * a.ldo] = acc[p][i] + (x == m ? dR[m] : 0.0);
+        for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; if (k < cols) tile[k * LD + jj] = r[u]; }
       }
     }
   } else {
-    const double* __restrict__ dR = a.diagR + (long)filt * a.strideR;
-    const double* __restrict__ K = a.K + (long)filt * a.strideK + x;
+    // source [X x cols], contiguous index first: slab[k][xx] = Src[x0 + xx, k]
+    const int xx = tid % XC, kq = tid / XC, kstep = blockDim.x / XC;
+    const bool ok = x0 + xx < a.X;
+    const double* __restrict__ row = Src + x0 + xx;
+    for (int k0 = 0; k0 < cols; k0 += kstep * 8) {
+      double r[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+      for (int u = 0; u < 8; ++u) { const int k = k0 + kq + kstep * u; r[u] = (ok && k < cols) ? row[(long)k * a.ldsrc] : 0.0; }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 2 * p + i;
-        out[(long)m * a.ldo] = fma(K[(long)m * a.ldk], dR[m], acc[p][i]);
-      }
+      for (int u = 0; u < 8; ++u) { const int k = k0 + kq + kstep * u; if (k < cols) tile[k * LD + xx] = r[u]; }
+    }
+  }
+  __syncthreads();
+  if (a.dbg == 1) return;
+
+  const int xx = lane % XC, half = lane / XC;
+  const int x = x0 + xx;
+  const bool live = x < a.X;
+  ell_cint* idx0 = (ell_cint*)(a.ell.idx + (long)filt * a.ell.stride_idx());
+  ell_cdouble* val0 = (ell_cdouble*)(a.ell.val + (long)filt * a.ell.stride_val());
+  ell_cdouble* dR = (ell_cdouble*)(a.diagR + (long)filt * a.strideR);
+  const double* __restrict__ K = a.K + (long)filt * a.strideK + (live ? x : 0);
+  double* __restrict__ out = a.out + (long)filt * a.strideOut + (live ? x : 0);
+  const double* __restrict__ my = tile + xx;
+
+  double cm[CWU];
+#pragma unroll
+  for (int t = 0; t < CWU; ++t) cm[t] = my[idx0[t] * LD];
+
+  const int pairs = a.dbg == 2 ? 16 : a.Mp / 2;
+#pragma unroll 2
+  for (int p = wave; p < pairs; p += nw) {
+    const int pe = a.dbg == 3 ? 0 : p;
+    ell_cint* pi = idx0 + (long)pe * ELL_W + ELL_CW;
+    ell_cdouble* pv = val0 + (long)pe * ELL_W * 2;
+    double sv[ELL_PW];
+#pragma unroll
+    for (int t = 0; t < ELL_PW; ++t) sv[t] = my[pi[t] * LD];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < CWU; ++t) { a0 = fma(pv[2 * t], cm[t], a0); a1 = fma(pv[2 * t + 1], cm[t], a1); }
+#pragma unroll
+    for (int t = 0; t < ELL_PW; ++t) {
+      a0 = fma(pv[2 * (ELL_CW + t)], sv[t], a0); a1 = fma(pv[2 * (ELL_CW + t) + 1], sv[t], a1);
+    }
+    if (!live) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (XC == 32 && i != half) continue;      // XC = 32: each half-wave stores its own row
+      const int m = 2 * p + i;
+      const double acc = i ? a1 : a0;
+      if (MODE == ELL_HP) out[(long)m * a.ldo] = acc;
+      else if (MODE == ELL_S) out[(long)m * a.ldo] = acc + (x == m ? dR[m] : 0.0);
+      else out[(long)m * a.ldo] = fma(K[(long)m * a.ldk], dR[m], acc);
     }
   }
 }
@@ -177,7 +265,6 @@ __global__ __launch_bounds__(256) void gate_ell_kernel(GateEllArgs a) {
     double s00 = 0, s10 = 0, s11 = 0;
     for (int t = 0; t < ELL_W; ++t) {
       const int k = pi[t];
-      if (k < 0) break;
       const double v0 = pv[2 * t], v1 = pv[2 * t + 1];
       const double p0 = c0[k], p1 = c1[k];
       s00 = fma(v0, p0, s00);
@@ -234,16 +321,66 @@ int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, 
   CHECK_LAUNCH();
 }
 
-int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s) {
-  if (a.batch <= 0) return 0;
-  const int xchunks = (a.X + 255) / 256;
-  const int per = (a.Mp / 16) * xchunks;
-  const int grid = ((a.batch + 7) / 8) * 8 * per;
-  switch (mode) {
-    case ELL_HP: hipLaunchKernelGGL((ell_mul_kernel<ELL_HP>), dim3(grid), dim3(256), 0, s, a); break;
-    case ELL_S: hipLaunchKernelGGL((ell_mul_kernel<ELL_S>), dim3(grid), dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((ell_mul_kernel<ELL_G>), dim3(grid), dim3(256), 0, s, a); break;
+template <int MODE, int CWU, int XC>
+static int launch_ell_tile_t(const EllMulArgs& a, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
   }
+  const int xchunks = (a.X + XC - 1) / XC;
+  const int grid = ((a.batch + 7) / 8) * 8 * xchunks;
+  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC>), dim3(grid), dim3(1024), lds, s, a);
+  return (int)hipGetLastError();
+}
+template <int MODE>
+static int launch_ell_tile_m(const EllMulArgs& a, hipStream_t s, bool* done) {
+  const size_t lds64 = (size_t)a.cols * 65 * sizeof(double), lds32 = (size_t)a.cols * 33 * sizeof(double);
+  const size_t cap = 158 * 1024;
+  const bool n12 = a.nc_max <= 12;
+  *done = true;
+  if (lds64 <= cap) return n12 ? launch_ell_tile_t<MODE, 12, 64>(a, lds64, s) : launch_ell_tile_t<MODE, ELL_CW, 64>(a, lds64, s);
+  if (lds32 <= cap) return n12 ? launch_ell_tile_t<MODE, 12, 32>(a, lds32, s) : launch_ell_tile_t<MODE, ELL_CW, 32>(a, lds32, s);
+  *done = false;
+  return 0;
+}
+
+int launch_ell_mul(int mode, const EllMulArgs& a_in, hipStream_t s) {
+  if (a_in.batch <= 0) return 0;
+  EllMulArgs a = a_in;
+  {
+    if (const char* e = getenv("XIVO_HIP_ELL_DBG")) a.dbg = atoi(e);
+    static const bool no_tile = getenv("XIVO_HIP_ELL_GATHER") != nullptr;   // A/B knob: force the gather form
+    if (!no_tile) {
+      bool done = false;
+      const int rc = mode == ELL_HP ? launch_ell_tile_m<ELL_HP>(a, s, &done)
+                     : (mode == ELL_S ? launch_ell_tile_m<ELL_S>(a, s, &done) : launch_ell_tile_m<ELL_G>(a, s, &done));
+      if (done) return rc;
+    }
+  }
+  if (mode == ELL_S) {   // the gather form reads H P [Mp x Np]; only the tile form can use P H^T
+    a.Src = a.SrcAlt; a.strideSrc = a.strideSrcAlt; a.ldsrc = a.ldsrcAlt;
+  }
+  const int xchunks = (a.X + 255) / 256;
+  const int nrb = a.Mp / 16;
+  // big batch: one workgroup per (filter, chunk) walks all row blocks; small batch: spread them
+  a.rb_per_wg = (long)a.batch * xchunks >= 2048 ? nrb : ((long)a.batch * xchunks >= 512 ? (nrb + 1) / 2 : 1);
+  if (const char* e = getenv("XIVO_HIP_ELL_RB")) a.rb_per_wg = atoi(e) > 0 ? atoi(e) : a.rb_per_wg;   // A/B knob
+  const int rsplit = (nrb + a.rb_per_wg - 1) / a.rb_per_wg;
+  const int grid = ((a.batch + 7) / 8) * 8 * rsplit * xchunks;
+  // common slots actually in use, rounded to the instantiated widths
+#define ELL_LAUNCH(MODE)                                                                                  \
+  do {                                                                                                    \
+    if (a.nc_max <= 12) hipLaunchKernelGGL((ell_mul_kernel<MODE, 12>), dim3(grid), dim3(256), 0, s, a);   \
+    else hipLaunchKernelGGL((ell_mul_kernel<MODE, ELL_CW>), dim3(grid), dim3(256), 0, s, a);              \
+  } while (0)
+  switch (mode) {
+    case ELL_HP: ELL_LAUNCH(ELL_HP); break;
+    case ELL_S: ELL_LAUNCH(ELL_S); break;
+    default: ELL_LAUNCH(ELL_G); break;
+  }
+#undef ELL_LAUNCH
   CHECK_LAUNCH();
 }
 

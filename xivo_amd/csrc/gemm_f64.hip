@@ -112,11 +112,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   // Accumulators start at 0, or at -/+Msub for C = acc -/+ Msub (T = K(HP) - P): the
   // loads are issued here, ahead of the first k-panel, instead of serialising
   // behind the stores of the epilogue.
+  // fp32 products keep Msub in fp64: it is added to the widened accumulators in the epilogue
+  // (loaded after the main loop, when the staging registers are dead) instead of being rounded
+  // to fp32 here.
+  constexpr bool LATE_MSUB = sizeof(CT) == 4;
   acc_t acc[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     acc[q] = Cx<CT>::zero();
-    if ((g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT) && is_on(q)) {
+    if (!LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT) && is_on(q)) {
       const double* Ms = g.Msub + (long)filt * g.strideMsub;
       const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
       const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;
@@ -242,6 +246,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     __syncthreads();
   }
 
+  double msv[LATE_MSUB ? NS : 1][4];
+  if (LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT)) {
+    const double* Ms = g.Msub + (long)filt * g.strideMsub;
+    const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (!is_on(q)) continue;
+      const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = J0 + Cx<CT>::crow(lg, r);
+        double v = sgn * Ms[i + (long)j * g.ldmsub];
+        if (g.McolScale) v *= g.McolScale[(long)filt * g.strideMcol + j];
+        msv[LATE_MSUB ? q : 0][r] = v;
+      }
+    }
+  }
+
   // Epilogue. acc[q][r] = C[i = I0 + li][j = J0 + lg + 4r]
   double* Cb = g.C + (long)filt * g.strideC;
   double* C2b = g.C2 ? g.C2 + (long)filt * g.strideC2 : nullptr;
@@ -258,6 +280,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     for (int r = 0; r < 4; ++r) {
       const int j = J0 + Cx<CT>::crow(lg, r);
       v[r] = (double)acc[q][r];
+      if (LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT)) v[r] += msv[LATE_MSUB ? q : 0][r];
       if (g.epilogue == EPI_ADD_DIAG) {
         if (i == j) v[r] += dg[i];
       } else if (g.epilogue == EPI_SUB_IDENT) {
