@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD datasheet). 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz
 
 
@@ -221,29 +222,16 @@ def main():
         lib = load_library()
         import ctypes as C
 
-        def tile_of(r, c, sym=0):
-            bm, bn = C.c_int(), C.c_int()
-            lib.xivo_hip_gemm_tile(r, c, sym, C.byref(bm), C.byref(bn))
-            return f"gemm_nt_f64_kernel<{bm.value // 32},{bn.value // 32},double>"
-
         def norm(k):   # rocprofv3 prints template arguments with spaces; the block-list kernel has one instantiation per size class
             k = k.replace(" ", "")
             return "gemm_sym_f64_kernel" if k.startswith("gemm_sym_f64_kernel") else k
 
-        # group stages by the kernel instantiation rocprofv3 would report them under
-        shape = {"gemm_HP": (M, N, 0), "gemm_S": (M, M, 1), "gemm_KH_I": (N, N, 0), "gemm_AP": (N, N, 0),
-                 "gemm_Pnew": (N, N, 1)}
+        # group stages by the kernel instantiation the library reports for them (= the rocprofv3 kernel name)
         groups = {}
         for name, st in prof.items():
             if st["launches"] == 0:
                 continue
-            kname = tile_of(*shape[name]) if name in shape else name
-            if sparse_path and name in ("gemm_HP", "gemm_S", "gemm_KH_I"):
-                kname = {"gemm_HP": "ell_mul_kernel<0>", "gemm_S": "ell_mul_kernel<1>", "gemm_KH_I": "ell_mul_kernel<2>"}[name]
-            elif name == "gemm_S" and M <= 176:
-                kname = "gemm_sym_f64_kernel"   # whole triangle in one workgroup (block-list kernel)
-            if name == "gemm_AP" and kname == "gemm_nt_f64_kernel<4,4,double>":
-                kname = "gemm_nt_f64_kernel<4,2,double>"  # accumulator-initialised GEMMs run on the 128x64 tile
+            kname = norm(st["kernel"] or name)
             g = groups.setdefault(kname, {"ms": 0.0, "launches": 0, "flops": 0.0, "stages": []})
             g["ms"] += st["ms"]; g["launches"] += st["launches"]
             g["flops"] += st["flops_per_launch"] * st["launches"]; g["stages"].append(name)
@@ -260,10 +248,20 @@ def main():
         if groups:
             dom = max(groups, key=lambda k: groups[k]["ms"])
             g = groups[dom]
-            achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": dom, "stages": g["stages"],
-                        "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            Np_, Mp_ = (N + 15) // 16 * 16, (M + 15) // 16 * 16
+            # algorithmic HBM bytes per filter of the sparse-H (VALU, HBM-bound) stages: source once + output once
+            ell_bytes = {"gemm_HP": 8 * (Np_ * Np_ + Np_ * Mp_), "gemm_S": 8 * (Np_ * Mp_ + Mp_ * Mp_),
+                         "gemm_KH_I": 8 * (Np_ * Np_ + 2 * Np_ * Mp_)}
+            if dom.startswith("ell_"):
+                nbytes = sum(ell_bytes[st_] * B * prof[st_]["launches"] for st_ in g["stages"])
+                achieved = nbytes / (g["ms"] * 1e-3) / 1e9
+                bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
+            else:
+                achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                bound, peak, unit = "mfma", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"
+            roofline = {"bound": bound, "kernel": dom, "stages": g["stages"],
+                        "achieved": achieved, "peak": peak, "unit": unit,
+                        "frac": achieved / peak,
                         "avg_launch_ms": g["ms"] / g["launches"], "launches": g["launches"],
                         # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of the
                         # same command (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE); null if absent

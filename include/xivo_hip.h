@@ -256,6 +256,9 @@ int xivo_hip_bench_mfma_peak(xivo_hip_ctx* ctx, double* out4);
 void xivo_hip_gemm_tile(int rows, int cols, int symmetric, int* bm, int* bn);
 /* which path the last update call took: 0 = dense as-coded, 1 = sparse-H (row-pair compressed) */
 int xivo_hip_last_path(xivo_hip_ctx* ctx);
+/* kernel instantiation the last launch of profile stage `stage` ran (index as in xivo_hip_profile_get; needs
+ * XIVO_HIP_FLAG_PROFILE), spelled as rocprofv3 --kernel-trace prints it minus spaces; "" if none */
+const char* xivo_hip_stage_kernel(xivo_hip_ctx* ctx, int stage);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,7 @@ struct xivo_hip_ctx {
   float stage_ms[ST_COUNT] = {0};
   int stage_launches[ST_COUNT] = {0};
   double stage_flops[ST_COUNT] = {0};
+  char stage_kernel[ST_COUNT][64] = {{0}};   // kernel instantiation of the stage's last launch (as rocprofv3 names it)
 };
 
 namespace {
@@ -88,8 +89,9 @@ int dev_alloc(T** p, size_t n) {
 
 struct StageTimer {
   xivo_hip_ctx* c; EventPair* ep = nullptr;
-  StageTimer(xivo_hip_ctx* ctx, int stage, double flops) : c(ctx) {
+  StageTimer(xivo_hip_ctx* ctx, int stage, double flops, const char* kernel = nullptr) : c(ctx) {
     if (!(c->flags & XIVO_HIP_FLAG_PROFILE)) return;
+    if (kernel) { strncpy(c->stage_kernel[stage], kernel, 63); c->stage_kernel[stage][63] = 0; }
     if (c->pool_used >= c->pool.size()) {
       EventPair np; np.stage = stage;
       if (hipEventCreate(&np.a) != hipSuccess || hipEventCreate(&np.b) != hipSuccess) return;
@@ -199,9 +201,11 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   g.McolScale = x.mcol; g.strideMcol = x.sMcol;
   g.epilogue = x.epi; g.lower_only = x.lower_only; g.batch = B; g.fp32 = x.fp32;
   const double flops = 2.0 * rows * cols * (double)(K0 + (A1 ? K1 : 0)) * B;
-  StageTimer st(c, stage, flops);
   const bool sym = g.lower_only && rows == cols && gemm_sym_supported(rows) && !g.C2 && !g.fp32 &&
                    (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG) && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
+  char label[64] = "gemm_sym_f64_kernel";
+  if (!sym) gemm_kernel_label(g, label, sizeof(label));
+  StageTimer st(c, stage, flops, label);
   const int rc = sym ? launch_gemm_sym_f64(g, c->stream) : launch_gemm_nt_f64(g, c->stream);
   return rc == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
 }
@@ -432,7 +436,8 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
     a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.cols = Np;
-    StageTimer st(c, ST_HP, nnz_flops * Np * B);
+    char label[64]; ell_kernel_label(ELL_HP, a, label, sizeof(label));
+    StageTimer st(c, ST_HP, nnz_flops * Np * B, label);
     if (launch_ell_mul(ELL_HP, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   if (gate) {
@@ -443,7 +448,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
     a.F = gate->F; a.Np = Np; a.batch = B;
     a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
-    StageTimer st(c, ST_GATE, 0.0);
+    StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
     c->gate_sparse_last = 0;
     if (launch_gate_ell(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
@@ -451,13 +456,14 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max;
-    StageTimer st(c, ST_S, nnz_flops * Mp * B);
+    char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
+    StageTimer st(c, ST_S, nnz_flops * Mp * B, label);
     if (launch_ell_mul(ELL_S, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {
     CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B;
-    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B);
+    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, "chol_f64_kernel");
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {
@@ -465,11 +471,14 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
-    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B);
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
+    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label);
     if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
-  {  // T = K (HP) - P
+  {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
+     // triangle is computed and mirrored (XIVO_HIP_FLAG_FULL_PNEW: all of it)
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.fp32 = f32;
+    x.lower_only = (full || getenv("XIVO_HIP_T_FULL")) ? 0 : 1;
     rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               T, c->sP, Np, x);
     if (rc) return rc;
@@ -477,7 +486,8 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {  // G = T H^T + K diag(R)   [Np x Mp, in the A buffer]
     EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sA; a.ldo = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.cols = Np;
-    StageTimer st(c, ST_KH, nnz_flops * Np * B);
+    char label[64]; ell_kernel_label(ELL_G, a, label, sizeof(label));
+    StageTimer st(c, ST_KH, nnz_flops * Np * B, label);
     if (launch_ell_mul(ELL_G, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // P+ = G K^T - T   (lower triangle + mirror)
@@ -527,7 +537,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.F = gate->F; a.Np = Np; a.batch = B;
     a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
     a.ell = c->ell; a.have_ell = 0;
-    StageTimer st(c, ST_GATE, 0.0);
+    StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
     c->gate_sparse_last = 0;
     if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
@@ -540,7 +550,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {  // S = L L^T
     CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B;
-    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B);
+    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, "chol_f64_kernel");
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
@@ -548,7 +558,8 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
-    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B);
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
+    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label);
     if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   if (c->flags & XIVO_HIP_FLAG_REASSOC) {
@@ -627,6 +638,10 @@ int xivo_hip_update_dense_gated(xivo_hip_ctx* c, int B, int F, double R, double 
 
 int xivo_hip_last_path(xivo_hip_ctx* c) { return c ? c->last_path : -1; }
 
+const char* xivo_hip_stage_kernel(xivo_hip_ctx* c, int stage) {
+  return (c && stage >= 0 && stage < ST_COUNT) ? c->stage_kernel[stage] : "";
+}
+
 int xivo_hip_get_gate(xivo_hip_ctx* c, int B, int F, unsigned char* mask_out, double* dist_out) {
   if (!c || B <= 0 || B > c->Bmax || F <= 0 || !c->mask) return XIVO_HIP_ERR_INVALID;
   // the dense gate packs [B][F]; the layout-faithful gate (xivo_hip_mh_gate / filter_update) strides by Fmax
@@ -695,7 +710,7 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
   a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;
   a.ell = c->ell; a.have_ell = 1;
   {
-    StageTimer st(c, ST_GATE, 0.0);
+    StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
     c->gate_sparse_last = 0;
     if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
@@ -747,7 +762,7 @@ int xivo_hip_set_scene(xivo_hip_ctx* c, int b0, int nb, int F, const xivo_pose_i
 
 int xivo_hip_jacobians_instate(xivo_hip_ctx* c, int B) {
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
-  StageTimer st(c, ST_JAC, 0.0);
+  StageTimer st(c, ST_JAC, 0.0, "jac_instate_kernel");
   return launch_jac_instate(scene_buffers(c), c->lay, c->cam, B, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 
@@ -766,7 +781,7 @@ static int gate_impl(xivo_hip_ctx* c, int B, double R, double th, double mult, i
   GateArgs a;
   a.sb = scene_buffers(c); a.lay = c->lay; a.P = c->P; a.strideP = c->sP; a.ldp = c->Np;
   a.R = R; a.thresh = th; a.mult = mult; a.min_inliers = min_inl; a.batch = B; a.use_gating = use_gating;
-  StageTimer st(c, ST_GATE, 0.0);
+  StageTimer st(c, ST_GATE, 0.0, "gate_sparse_kernel");
   c->gate_sparse_last = 1;
   return launch_gate_sparse(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
@@ -794,7 +809,7 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
   a.ell = c->ell; a.emit_ell = 1;
   for (int b = 0; b < B; ++b) { c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12; }
-  StageTimer st(c, ST_STACK, 0.0);
+  StageTimer st(c, ST_STACK, 0.0, "stack_kernel");
   return launch_stack(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 

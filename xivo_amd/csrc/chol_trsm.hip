@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <stdio.h>
 
 namespace xivo_hip {
 
@@ -579,6 +580,14 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   if (nb <= 19) return launch_trsm_t<19>(g, stream);
   if (nb <= 24) return launch_trsm_t<24>(g, stream);
   return (int)hipErrorInvalidValue;
+}
+
+void trsm_kernel_label(int Mp, char* buf, size_t n) {
+  const int nb = Mp / 16;
+  const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
+  if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11));
+  else if (!no_stream) snprintf(buf, n, "trsm_stream_f64_kernel<%d>", nb <= 14 ? 14 : (nb <= 19 ? 19 : 24));
+  else snprintf(buf, n, "trsm_f64_kernel");
 }
 
 }  // namespace xivo_hip

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 namespace xivo_hip {
 
@@ -63,6 +64,8 @@ struct GemmArgs {
 
 // launches on `stream`; returns hipError_t as int
 int launch_gemm_nt_f64(const GemmArgs& args, hipStream_t stream);
+// name of the kernel instantiation launch_gemm_nt_f64 runs for these arguments (as rocprofv3 prints it, no spaces)
+void gemm_kernel_label(const GemmArgs& args, char* buf, size_t n);
 // tile actually chosen for (Mp, Np) - exposed for tests / DESIGN.md
 void gemm_pick_tile(int Mp, int Np, int lower_only, int* WM, int* WN);
 
@@ -101,6 +104,7 @@ struct TrsmArgs {
   int batch;
 };
 int launch_trsm_f64(const TrsmArgs& args, hipStream_t stream);
+void trsm_kernel_label(int Mp, char* buf, size_t n);
 
 }  // namespace xivo_hip
 

@@ -54,12 +54,13 @@ struct EllMulArgs {
   const double* K; long strideK; int ldk;       // ELL_G
   int X;        // extent of the contiguous index (Np for HP/G, Mp for S)
   int Mp;       // rows of H in use (multiple of 16)
-  int dbg;
   int rb_per_wg; // set by the launcher: 16-row blocks one workgroup walks
   int nc_max;   // upper bound of nc over the filters of the launch (host mirror)
   int batch;
 };
 int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s);
+// name of the kernel instantiation launch_ell_mul runs for these arguments
+void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n);
 
 // Estimator::MHGating numeric core (src/update.cpp:60-96) on the ELL rows: S_f = H_f (P H_f^T) + R I2
 // from the already formed P H^T, threshold relaxation, then neutralisation of the rejected pairs

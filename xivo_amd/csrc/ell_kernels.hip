@@ -3,6 +3,7 @@
 // columns of the source matrix, 512 B per wave load; no MFMA (a row pair has 21 non-zeros).
 #include "ell.h"
 #include "gate_device.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace xivo_hip {
@@ -147,24 +148,29 @@ __global__ __launch_bounds__(256) void ell_mul_kernel(EllMulArgs a) {
   }
 }
 
-// ---------------------------------------------------------------- tile-in-LDS variant
+// ---------------------------------------------------------------- slab-in-LDS variant
 // The gather form above re-fetches a source column once per row pair that names it (a group block is
 // shared by the features anchored to it, and the 12 pose columns by everybody): ~4x the size of the
 // source per filter, served by L2 / Infinity Cache. Here a workgroup first parks an XC-wide slab of
 // the source (all columns x XC values of the contiguous index) in LDS - each source element leaves HBM
-// exactly once - and then its waves walk the row pairs of the filter gathering from LDS. Slot indices
-// and values are wave-uniform SCALAR loads: the arrays are read through constant-address-space pointers
-// (they were written by an earlier kernel), otherwise the stores of the loop would demote them to
-// per-lane vector loads.
-//   XC = 64: lane = x, both rows of the pair per lane (one workgroup of 16 waves per CU, slab <= 158 KB)
-//   XC = 32: lanes 0..31 row 2p, lanes 32..63 row 2p+1 (for wider sources)
-// LDS slab: [cols][XC + 1] doubles (odd pitch: the transposing load of ELL_S writes column-wise).
+// exactly once - together with the slot VALUES of all row pairs of the filter, and then its waves
+// walk the pairs: lane = x gathers the pair's private columns from the slab (ds_read_b64), the
+// coefficients arrive as wave-uniform ds_read_b128 broadcasts (one (row 2p, row 2p+1) pair each)
+// and the slot indices as scalar loads. (Coefficients as scalar loads serialise on the ~100 SGPRs
+// and miss the scalar cache - 38 KB per slab; measured 3x slower.)
+//   XC = 64: lane = x, both rows of the pair per lane     XC = 32: half-waves take one row each
+// LDS: slab[cols][XC] doubles, element (k, x) at k * XC + (x ^ (k & 15)) - the XOR keeps both the
+// row-wise loads and the transposing load of ELL_S (lanes = k) conflict-free without a pad column;
+// then ops[pairs][CWU + ELL_PW][2].
 typedef __attribute__((address_space(4))) const double ell_cdouble;
 typedef __attribute__((address_space(4))) const int ell_cint;
 
+// threads per workgroup: the S instantiation does not fit the 128-VGPR budget of 16 waves per CU
+constexpr int ell_tile_threads(int mode) { return mode == ELL_S ? 512 : 1024; }
+
 template <int MODE, int CWU, int XC>
-__global__ __launch_bounds__(1024) void ell_tile_kernel(EllMulArgs a) {
-  constexpr int LD = XC + 1;
+__global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMulArgs a) {
+  constexpr int NSLOT = CWU + ELL_PW;
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int xchunks = (a.X + XC - 1) / XC;
   const int b = blockIdx.x;
@@ -176,6 +182,15 @@ __global__ __launch_bounds__(1024) void ell_tile_kernel(EllMulArgs a) {
   const int nw = blockDim.x >> 6;
   const double* __restrict__ Src = a.Src + (long)filt * a.strideSrc;
   const int cols = a.cols;
+  const int pairs = a.Mp / 2;
+  double* ops = tile + (long)cols * XC;
+  {  // coefficients of every pair of the filter: coalesced 16-byte loads -> LDS
+    const d2* __restrict__ gv = reinterpret_cast<const d2*>(a.ell.val + (long)filt * a.ell.stride_val());
+    for (int e = tid; e < pairs * NSLOT; e += blockDim.x) {
+      const int p = e / NSLOT, t = e % NSLOT;
+      *reinterpret_cast<d2*>(ops + 2 * e) = gv[p * ELL_W + (t < CWU ? t : ELL_CW + (t - CWU))];
+    }
+  }
   if (MODE == ELL_S) {
     // source = P H^T [cols x Mp] (column j contiguous over the state index): slab[k][jj] = PHT[k, x0 + jj]
     for (int jj = wave; jj < XC; jj += nw) {
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(1024) void ell_tile_kernel(EllMulArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; r[u] = (ok && k < cols) ? col[k] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; if (k < cols) tile[k * LD + jj] = r[u]; }
+        for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; if (k < cols) tile[k * XC + (jj ^ (k & 15))] = r[u]; }
       }
     }
   } else {
@@ -199,42 +214,36 @@ __global__ __launch_bounds__(1024) void ell_tile_kernel(EllMulArgs a) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int k = k0 + kq + kstep * u; r[u] = (ok && k < cols) ? row[(long)k * a.ldsrc] : 0.0; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int k = k0 + kq + kstep * u; if (k < cols) tile[k * LD + xx] = r[u]; }
+      for (int u = 0; u < 8; ++u) { const int k = k0 + kq + kstep * u; if (k < cols) tile[k * XC + (xx ^ (k & 15))] = r[u]; }
     }
   }
   __syncthreads();
-  if (a.dbg == 1) return;
 
   const int xx = lane % XC, half = lane / XC;
   const int x = x0 + xx;
   const bool live = x < a.X;
   ell_cint* idx0 = (ell_cint*)(a.ell.idx + (long)filt * a.ell.stride_idx());
-  ell_cdouble* val0 = (ell_cdouble*)(a.ell.val + (long)filt * a.ell.stride_val());
   ell_cdouble* dR = (ell_cdouble*)(a.diagR + (long)filt * a.strideR);
   const double* __restrict__ K = a.K + (long)filt * a.strideK + (live ? x : 0);
   double* __restrict__ out = a.out + (long)filt * a.strideOut + (live ? x : 0);
-  const double* __restrict__ my = tile + xx;
+  auto slab = [&](int k) -> double { return tile[k * XC + (xx ^ (k & 15))]; };
 
   double cm[CWU];
 #pragma unroll
-  for (int t = 0; t < CWU; ++t) cm[t] = my[idx0[t] * LD];
+  for (int t = 0; t < CWU; ++t) cm[t] = slab(idx0[t]);
 
-  const int pairs = a.dbg == 2 ? 16 : a.Mp / 2;
 #pragma unroll 2
   for (int p = wave; p < pairs; p += nw) {
-    const int pe = a.dbg == 3 ? 0 : p;
-    ell_cint* pi = idx0 + (long)pe * ELL_W + ELL_CW;
-    ell_cdouble* pv = val0 + (long)pe * ELL_W * 2;
+    ell_cint* pi = idx0 + (long)p * ELL_W + ELL_CW;
+    const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT;
     double sv[ELL_PW];
 #pragma unroll
-    for (int t = 0; t < ELL_PW; ++t) sv[t] = my[pi[t] * LD];
+    for (int t = 0; t < ELL_PW; ++t) sv[t] = slab(pi[t]);
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-    for (int t = 0; t < CWU; ++t) { a0 = fma(pv[2 * t], cm[t], a0); a1 = fma(pv[2 * t + 1], cm[t], a1); }
+    for (int t = 0; t < CWU; ++t) { const d2 v = pv[t]; a0 = fma(v[0], cm[t], a0); a1 = fma(v[1], cm[t], a1); }
 #pragma unroll
-    for (int t = 0; t < ELL_PW; ++t) {
-      a0 = fma(pv[2 * (ELL_CW + t)], sv[t], a0); a1 = fma(pv[2 * (ELL_CW + t) + 1], sv[t], a1);
-    }
+    for (int t = 0; t < ELL_PW; ++t) { const d2 v = pv[CWU + t]; a0 = fma(v[0], sv[t], a0); a1 = fma(v[1], sv[t], a1); }
     if (!live) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -331,18 +340,37 @@ static int launch_ell_tile_t(const EllMulArgs& a, size_t lds, hipStream_t s) {
   }
   const int xchunks = (a.X + XC - 1) / XC;
   const int grid = ((a.batch + 7) / 8) * 8 * xchunks;
-  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC>), dim3(grid), dim3(1024), lds, s, a);
+  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC>), dim3(grid), dim3(ell_tile_threads(MODE)), lds, s, a);
   return (int)hipGetLastError();
 }
+// which form / instantiation the launcher picks: xc = 64 / 32 (slab form) or 0 (gather form)
+static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, size_t* lds) {
+  static const bool no_tile = getenv("XIVO_HIP_ELL_GATHER") != nullptr;   // A/B knob: force the gather form
+  *cwu = a.nc_max <= 12 ? 12 : ELL_CW;
+  const size_t ops = (size_t)(a.Mp / 2) * (*cwu + ELL_PW) * 2 * sizeof(double);
+  const size_t lds64 = (size_t)a.cols * 64 * sizeof(double) + ops, lds32 = (size_t)a.cols * 32 * sizeof(double) + ops;
+  const size_t cap = 160 * 1024;
+  *xc = 0; *lds = 0;
+  if (no_tile) return;
+  if (lds64 <= cap) { *xc = 64; *lds = lds64; }
+  else if (lds32 <= cap) { *xc = 32; *lds = lds32; }
+}
+
+void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n) {
+  int xc, cwu; size_t lds;
+  ell_pick(a, &xc, &cwu, &lds);
+  if (xc) snprintf(buf, n, "ell_tile_kernel<%d,%d,%d>", mode, cwu, xc);
+  else snprintf(buf, n, "ell_mul_kernel<%d,%d>", mode, cwu);
+}
+
 template <int MODE>
 static int launch_ell_tile_m(const EllMulArgs& a, hipStream_t s, bool* done) {
-  const size_t lds64 = (size_t)a.cols * 65 * sizeof(double), lds32 = (size_t)a.cols * 33 * sizeof(double);
-  const size_t cap = 158 * 1024;
-  const bool n12 = a.nc_max <= 12;
-  *done = true;
-  if (lds64 <= cap) return n12 ? launch_ell_tile_t<MODE, 12, 64>(a, lds64, s) : launch_ell_tile_t<MODE, ELL_CW, 64>(a, lds64, s);
-  if (lds32 <= cap) return n12 ? launch_ell_tile_t<MODE, 12, 32>(a, lds32, s) : launch_ell_tile_t<MODE, ELL_CW, 32>(a, lds32, s);
-  *done = false;
+  int xc, cwu; size_t lds;
+  ell_pick(a, &xc, &cwu, &lds);
+  *done = xc != 0;
+  const bool n12 = cwu == 12;
+  if (xc == 64) return n12 ? launch_ell_tile_t<MODE, 12, 64>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 64>(a, lds, s);
+  if (xc == 32) return n12 ? launch_ell_tile_t<MODE, 12, 32>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 32>(a, lds, s);
   return 0;
 }
 
@@ -350,9 +378,7 @@ int launch_ell_mul(int mode, const EllMulArgs& a_in, hipStream_t s) {
   if (a_in.batch <= 0) return 0;
   EllMulArgs a = a_in;
   {
-    if (const char* e = getenv("XIVO_HIP_ELL_DBG")) a.dbg = atoi(e);
-    static const bool no_tile = getenv("XIVO_HIP_ELL_GATHER") != nullptr;   // A/B knob: force the gather form
-    if (!no_tile) {
+    {
       bool done = false;
       const int rc = mode == ELL_HP ? launch_ell_tile_m<ELL_HP>(a, s, &done)
                      : (mode == ELL_S ? launch_ell_tile_m<ELL_S>(a, s, &done) : launch_ell_tile_m<ELL_G>(a, s, &done));

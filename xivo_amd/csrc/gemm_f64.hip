@@ -422,18 +422,20 @@ void gemm_pick_tile(int Mp, int Np, int lower_only, int* WM, int* WN) {
   *WN = bn;
 }
 
+static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out);
+
+void gemm_kernel_label(const GemmArgs& a, char* buf, size_t n) {
+  int wm, wn;
+  pick_for(a, &wm, &wn);
+  snprintf(buf, n, "gemm_nt_f64_kernel<%d,%d,%s>", wm, wn, a.fp32 ? "float" : "double");
+}
+
 int launch_gemm_nt_f64(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
   static const bool no_strip = getenv("XIVO_HIP_NO_STRIP") != nullptr;   // A/B knob
   if (no_strip && a.lower_only) a.lower_only = 2;
   int wm, wn;
-  gemm_pick_tile(a.Mp, a.Np, a.lower_only, &wm, &wn);
-  // accumulators initialised from memory (T = K(HP) - P): the 64 extra loads per lane sit in the
-  // tile prologue; the narrower 128x64 tile (3 instead of 2 workgroups per CU) hides them
-  // (measured 0.54 vs 0.72 ms per 1024 filters at N=250)
-  if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
-      !getenv("XIVO_HIP_TILE"))
-    wn = 2;
+  pick_for(a, &wm, &wn);
 #define XIVO_GEMM_CASE(M_, N_) \
   if (wm == M_ && wn == N_) return launch_t<M_, N_>(a, stream);
   XIVO_GEMM_CASE(2, 2) XIVO_GEMM_CASE(2, 3) XIVO_GEMM_CASE(2, 4) XIVO_GEMM_CASE(2, 5)
@@ -442,6 +444,18 @@ int launch_gemm_nt_f64(const GemmArgs& a_in, hipStream_t stream) {
   XIVO_GEMM_CASE(5, 2) XIVO_GEMM_CASE(5, 3) XIVO_GEMM_CASE(5, 4)
 #undef XIVO_GEMM_CASE
   return (int)hipErrorInvalidValue;
+}
+
+static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
+  int wm, wn;
+  gemm_pick_tile(a.Mp, a.Np, a.lower_only, &wm, &wn);
+  // accumulators initialised from memory (T = K(HP) - P): the 64 extra loads per lane sit in the
+  // tile prologue; the narrower 128x64 tile (3 instead of 2 workgroups per CU) hides them
+  // (measured 0.54 vs 0.72 ms per 1024 filters at N=250)
+  if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
+      !getenv("XIVO_HIP_TILE"))
+    wn = 2;
+  *wm_out = wm; *wn_out = wn;
 }
 
 }  // namespace xivo_hip
