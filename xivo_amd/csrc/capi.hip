@@ -200,7 +200,9 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   g.diag = x.diag; g.strideDiag = x.sDiag; g.Msub = x.msub; g.strideMsub = x.sMsub; g.ldmsub = x.ldmsub;
   g.McolScale = x.mcol; g.strideMcol = x.sMcol;
   g.epilogue = x.epi; g.lower_only = x.lower_only; g.batch = B; g.fp32 = x.fp32;
-  const double flops = 2.0 * rows * cols * (double)(K0 + (A1 ? K1 : 0)) * B;
+  // algorithmic flops of the product: a symmetric output needs its lower triangle only
+  const double outs = x.lower_only ? 0.5 * rows * (cols + 1.0) : (double)rows * cols;
+  const double flops = 2.0 * outs * (double)(K0 + (A1 ? K1 : 0)) * B;
   const bool sym = g.lower_only && rows == cols && gemm_sym_supported(rows) && !g.C2 && !g.fp32 &&
                    (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG) && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
   char label[64] = "gemm_sym_f64_kernel";

@@ -166,6 +166,156 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
   if (lane == 0) g.status[filt] = bad;
 }
 
+// Register-resident variant for factors of at most NB <= 12 block rows (M <= 192): one workgroup of
+// four waves per filter, wave w owns the block rows i = w (mod 4) and keeps every L_ik it has produced
+// in registers, in the MFMA operand layout (the C layout of L_ik^T, see above, IS that layout). S is
+// read from HBM exactly once and L written once; the left-looking kernel above re-reads L_ik from
+// global for every later column (3x the bytes of S with thousands of filters in flight: it was
+// HBM-bound at 4.8 TB/s) and runs its whole dependency chain in one wave (178 us for one filter).
+// Per block column j (owner wave = j mod 4):
+//   A  owner : diagonal update sum_k L_jk L_jk^T from its registers -> LDS pad
+//   B  owner : factor + invert the 16x16 block in registers (as above) -> LDS / global; publishes the
+//              row panel L_jk, k < j, in LDS
+//   C  all   : own rows i > j:  L_ij^T = inv(L_jj) (S_ij^T - sum_k L_jk L_ik^T), kept + stored
+// with one barrier after A and one after B.
+template <int NB>
+__global__ __launch_bounds__(256) void chol_reg_f64_kernel(CholArgs g, int mirror) {
+  constexpr int RW = NB / 4;
+  const int filt = blockIdx.x;
+  if (filt >= g.batch) return;
+  double* S = g.S + (long)filt * g.strideS;
+  double* invD = g.invD + (long)filt * g.strideInvD;
+  const long ld = g.lds;
+  const int nb = g.Mp / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+
+  __shared__ double sP[16 * 17];
+  __shared__ double sInv[2][256];
+  __shared__ __attribute__((aligned(16))) double sRow[(NB - 1) * 256];   // [k][lane][4]
+  __shared__ int sBad;
+  if (tid == 0) sBad = 0;
+
+  d4 L[RW][NB];   // L[ii][k] = block (i = wave + 4 ii, k); only k < i is ever touched
+
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j >= nb) break;
+    constexpr int dummy = 0; (void)dummy;
+    const int owner = j & 3, jj = j >> 2;
+    // S_ij for the rows this wave will finish in phase C (in flight across phases A and B)
+    d4 sreg[RW];
+#pragma unroll
+    for (int ii = 0; ii < RW; ++ii) {
+      const int i = wave + 4 * ii;
+      if (4 * ii + 3 > j && i > j && i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sreg[ii][r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld];
+      }
+    }
+    double x[16];
+    if (wave == owner) {
+      d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < j; ++k) {
+        const d4 a = L[jj][k];
+        acc0 = mfma(a[0], a[0], acc0);
+        acc1 = mfma(a[1], a[1], acc1);
+        acc0 = mfma(a[2], a[2], acc0);
+        acc1 = mfma(a[3], a[3], acc1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sP[li * 17 + lg + 4 * r] = acc0[r] + acc1[r];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = S[(16 * j + li) + (long)(16 * j + c) * ld];
+    }
+    __syncthreads();
+    if (wave == owner) {
+      int bad = 0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] -= sP[li * 17 + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        double dcc = readlane_d(x[c], c);
+        if (!(dcc > 0.0)) {
+          if (!bad) bad = 1 + 16 * j + c;
+          dcc = 1.0;
+        }
+        const double d = sqrt(dcc);
+        const double rd = 1.0 / d;
+        x[c] = (li == c) ? d : x[c] * rd;
+#pragma unroll
+        for (int q = c + 1; q < 16; ++q) {
+          const double lqc = readlane_d(x[c], q);
+          x[q] = fma(-x[c], lqc, x[q]);
+        }
+      }
+      double y[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double acc = (li == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+          const double lik = readlane_d(x[k], i);
+          acc = fma(-lik, y[k], acc);
+        }
+        const double lii = readlane_d(x[i], i);
+        y[i] = acc / lii;
+      }
+      if (lg == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (c <= li) {
+            S[(16 * j + li) + (long)(16 * j + c) * ld] = x[c];
+            S[(16 * j + c) + (long)(16 * j + li) * ld] = x[c];
+          }
+          sInv[0][c + li * 16] = y[c];   // inv(L)(c, li)
+          sInv[1][li + c * 16] = y[c];   // inv(L)^T(li, c)
+        }
+      }
+      if (bad && lane == 0 && sBad == 0) sBad = bad;
+      // publish the row panel of block row j
+#pragma unroll
+      for (int k = 0; k < j; ++k) *reinterpret_cast<d4*>(&sRow[(k * 64 + lane) * 4]) = L[jj][k];
+    }
+    __syncthreads();
+    if (wave == owner)
+      for (int e = lane; e < 512; e += 64) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
+#pragma unroll
+    for (int ii = 0; ii < RW; ++ii) {
+      const int i = wave + 4 * ii;
+      if (4 * ii + 3 > j && i > j && i < nb) {
+        d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+          if (k < 4 * ii + 3) {
+            const d4 a = *reinterpret_cast<const d4*>(&sRow[(k * 64 + lane) * 4]);
+            const d4 bb = L[ii][k];
+            accA = mfma(a[0], bb[0], accA);
+            accB = mfma(a[1], bb[1], accB);
+            accA = mfma(a[2], bb[2], accA);
+            accB = mfma(a[3], bb[3], accB);
+          }
+        }
+        d4 rhs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rhs[r] = sreg[ii][r] - (accA[r] + accB[r]);
+        d4 out = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) out = mfma(sInv[0][li + (4 * s4 + lg) * 16], rhs[s4], out);
+        L[ii][j] = out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] = out[r];                 // L(i-block, j-block)
+          if (mirror) S[(16 * j + lg + 4 * r) + (long)(16 * i + li) * ld] = out[r];     // L^T for the streamed solve
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) g.status[filt] = sBad;
+}
+
 template <int NBM, int WPE>
 __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
   const int chunks = (g.Np + 63) / 64;
@@ -555,6 +705,18 @@ int launch_trsm_t(const TrsmArgs& g, hipStream_t stream) {
 
 int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
+  static const bool old_kernel = getenv("XIVO_HIP_CHOL_WAVE") != nullptr;   // A/B knob: one wave per filter
+  const int nb = g.Mp / 16;
+  // the four-wave kernel wins on latency (113 vs 178 us for one 160 x 160 factor); with thousands of filters
+  // the one-wave kernel keeps 16 dependency chains per CU in flight instead of 3 and is faster (0.76 vs 1.19 ms / 4096)
+  static const bool reg_always = getenv("XIVO_HIP_CHOL_REG") != nullptr;   // A/B knob
+  if (!old_kernel && nb <= 12 && (g.batch < 1024 || reg_always)) {
+    const int mirror = nb > 11 ? 1 : 0;   // only the streamed solve (nb >= 12) reads the mirrored upper triangle
+    if (nb <= 4) hipLaunchKernelGGL(chol_reg_f64_kernel<4>, dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    else if (nb <= 8) hipLaunchKernelGGL(chol_reg_f64_kernel<8>, dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    else hipLaunchKernelGGL(chol_reg_f64_kernel<12>, dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
   return (int)hipGetLastError();
 }
