@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <utility>
 #include <stdio.h>
 
 namespace xivo_hip {
@@ -166,6 +167,15 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
   if (lane == 0) g.status[filt] = bad;
 }
 
+template <class F, int... Js>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Js...>) {
+  (f(std::integral_constant<int, Js>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 // Register-resident variant for factors of at most NB <= 12 block rows (M <= 192): one workgroup of
 // four waves per filter, wave w owns the block rows i = w (mod 4) and keeps every L_ik it has produced
 // in registers, in the MFMA operand layout (the C layout of L_ik^T, see above, IS that layout). S is
@@ -173,11 +183,11 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
 // global for every later column (3x the bytes of S with thousands of filters in flight: it was
 // HBM-bound at 4.8 TB/s) and runs its whole dependency chain in one wave (178 us for one filter).
 // Per block column j (owner wave = j mod 4):
-//   A  owner : diagonal update sum_k L_jk L_jk^T from its registers -> LDS pad
-//   B  owner : factor + invert the 16x16 block in registers (as above) -> LDS / global; publishes the
-//              row panel L_jk, k < j, in LDS
+//   A  owner : diagonal update sum_k L_jk L_jk^T from its registers; factor + invert the 16x16 block
+//              spread over all 64 lanes (column broadcasts by ds_bpermute, no sqrt / divide in the
+//              chain) -> LDS / global; publishes the row panel L_jk, k < j, in LDS
 //   C  all   : own rows i > j:  L_ij^T = inv(L_jj) (S_ij^T - sum_k L_jk L_ik^T), kept + stored
-// with one barrier after A and one after B.
+// with one barrier between A and C and one after C.
 template <int NB>
 __global__ __launch_bounds__(256) void chol_reg_f64_kernel(CholArgs g, int mirror) {
   constexpr int RW = NB / 4;
@@ -190,19 +200,29 @@ __global__ __launch_bounds__(256) void chol_reg_f64_kernel(CholArgs g, int mirro
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
 
-  __shared__ double sP[16 * 17];
   __shared__ double sInv[2][256];
   __shared__ __attribute__((aligned(16))) double sRow[(NB - 1) * 256];   // [k][lane][4]
   __shared__ int sBad;
   if (tid == 0) sBad = 0;
 
   d4 L[RW][NB];   // L[ii][k] = block (i = wave + 4 ii, k); only k < i is ever touched
-
+  // the diagonal blocks this wave will factor, fetched up front (their latency would otherwise sit in
+  // the serial chain of every column): x-layout, element r = S[row li][col lg + 4 r] of block (jd, jd)
+  d4 sdiag[RW];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    if (j >= nb) break;
-    constexpr int dummy = 0; (void)dummy;
-    const int owner = j & 3, jj = j >> 2;
+  for (int ii = 0; ii < RW; ++ii) {
+    const int jd = wave + 4 * ii;
+    if (jd < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sdiag[ii][r] = S[(16 * jd + li) + (long)(16 * jd + lg + 4 * r) * ld];
+    }
+  }
+
+  // compile-time column index: every L[][] subscript below is a constant, so the factor stays in registers
+  static_for<NB>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (j < nb) {
+    constexpr int owner = j & 3, jj = j >> 2;
     // S_ij for the rows this wave will finish in phase C (in flight across phases A and B)
     d4 sreg[RW];
 #pragma unroll
@@ -213,7 +233,9 @@ __global__ __launch_bounds__(256) void chol_reg_f64_kernel(CholArgs g, int mirro
         for (int r = 0; r < 4; ++r) sreg[ii][r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld];
       }
     }
-    double x[16];
+    // diagonal block in the 64-lane layout x[r] = X[row li][col lg + 4 r] - which is what the MFMA
+    // accumulators of the (symmetric) update already are, so no transpose through LDS
+    d4 x;
     if (wave == owner) {
       d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -225,50 +247,60 @@ __global__ __launch_bounds__(256) void chol_reg_f64_kernel(CholArgs g, int mirro
         acc1 = mfma(a[3], a[3], acc1);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sP[li * 17 + lg + 4 * r] = acc0[r] + acc1[r];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) x[c] = S[(16 * j + li) + (long)(16 * j + c) * ld];
+      for (int r = 0; r < 4; ++r) x[r] = sdiag[jj][r] - (acc0[r] + acc1[r]);
     }
-    __syncthreads();
     if (wave == owner) {
       int bad = 0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) x[c] -= sP[li * 17 + c];
+      double rdv[16];   // 1 / L_cc (wave-uniform)
+      // right-looking Cholesky of the 16x16 block: step c broadcasts column c with ds_bpermute
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        double dcc = readlane_d(x[c], c);
+        const int lgc = c & 3, rc = c >> 2;
+        double dcc = readlane_d(x[rc], c + 16 * lgc);
         if (!(dcc > 0.0)) {
           if (!bad) bad = 1 + 16 * j + c;
           dcc = 1.0;
         }
-        const double d = sqrt(dcc);
-        const double rd = 1.0 / d;
-        x[c] = (li == c) ? d : x[c] * rd;
+        // rd = dcc^-1/2: hardware estimate + two Newton steps; d = dcc * rd with one correction
+        double rd = __builtin_amdgcn_rsq(dcc);
+        const double hx = 0.5 * dcc;
+        rd = rd * fma(-hx * rd, rd, 1.5);
+        rd = rd * fma(-hx * rd, rd, 1.5);
+        double d = dcc * rd;
+        d = fma(fma(-d, d, dcc), 0.5 * rd, d);
+        rdv[c] = rd;
+        if (lg == lgc) x[rc] = (li == c) ? d : x[rc] * rd;
+        const double lqc = __shfl(x[rc], li + 16 * lgc);            // L[my row][c]
 #pragma unroll
-        for (int q = c + 1; q < 16; ++q) {
-          const double lqc = readlane_d(x[c], q);
-          x[q] = fma(-x[c], lqc, x[q]);
+        for (int r = rc; r < 4; ++r) {
+          const int p = lg + 4 * r;                                  // my column
+          const double lpc = __shfl(x[rc], p + 16 * lgc);            // L[p][c]
+          if (p > c && li > c) x[r] = fma(-lqc, lpc, x[r]);
         }
       }
+      // inverse: lane li solves L y = e_li; L[i][k] is a readlane away, 1 / L[i][i] is rdv[i]
       double y[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         double acc = (li == i) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < i; ++k) {
-          const double lik = readlane_d(x[k], i);
+          const double lik = readlane_d(x[k >> 2], i + 16 * (k & 3));
           acc = fma(-lik, y[k], acc);
         }
-        const double lii = readlane_d(x[i], i);
-        y[i] = acc / lii;
+        y[i] = acc * rdv[i];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = lg + 4 * r;
+        if (c <= li) {
+          S[(16 * j + li) + (long)(16 * j + c) * ld] = x[r];
+          S[(16 * j + c) + (long)(16 * j + li) * ld] = x[r];
+        }
       }
       if (lg == 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          if (c <= li) {
-            S[(16 * j + li) + (long)(16 * j + c) * ld] = x[c];
-            S[(16 * j + c) + (long)(16 * j + li) * ld] = x[c];
-          }
           sInv[0][c + li * 16] = y[c];   // inv(L)(c, li)
           sInv[1][li + c * 16] = y[c];   // inv(L)^T(li, c)
         }
@@ -311,8 +343,9 @@ __global__ __launch_bounds__(256) void chol_reg_f64_kernel(CholArgs g, int mirro
         }
       }
     }
-  }
-  __syncthreads();
+    __syncthreads();   // sInv / sRow are rewritten by the next owner
+    }
+  });
   if (tid == 0) g.status[filt] = sBad;
 }
 
@@ -707,10 +740,9 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
   static const bool old_kernel = getenv("XIVO_HIP_CHOL_WAVE") != nullptr;   // A/B knob: one wave per filter
   const int nb = g.Mp / 16;
-  // the four-wave kernel wins on latency (113 vs 178 us for one 160 x 160 factor); with thousands of filters
-  // the one-wave kernel keeps 16 dependency chains per CU in flight instead of 3 and is faster (0.76 vs 1.19 ms / 4096)
-  static const bool reg_always = getenv("XIVO_HIP_CHOL_REG") != nullptr;   // A/B knob
-  if (!old_kernel && nb <= 12 && (g.batch < 1024 || reg_always)) {
+  // measured at M = 160: one factor 78 us (one-wave kernel 178 us); 4096 factors 0.75 ms (0.76 ms), with a third
+  // of the HBM traffic
+  if (!old_kernel && nb <= 12) {
     const int mirror = nb > 11 ? 1 : 0;   // only the streamed solve (nb >= 12) reads the mirrored upper triangle
     if (nb <= 4) hipLaunchKernelGGL(chol_reg_f64_kernel<4>, dim3(g.batch), dim3(256), 0, stream, g, mirror);
     else if (nb <= 8) hipLaunchKernelGGL(chol_reg_f64_kernel<8>, dim3(g.batch), dim3(256), 0, stream, g, mirror);
