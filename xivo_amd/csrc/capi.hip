@@ -41,6 +41,9 @@ struct xivo_hip_ctx {
   EllBuffers ell{};
   std::vector<int> ell_over_h, ell_nc_h;
   int last_path = 0;
+  // dense H / H^T of the stacked rows: written eagerly by set_measurements, lazily after xivo_hip_stack
+  bool dense_valid = true;
+  double stack_R = 0.0; int stack_B = 0;
   size_t staging_elems = 0;
   long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0, sA = 0;   // sA: A buffer, max(N x N, N x M)
   int M = 0, Mp = 0;  // rows currently staged
@@ -215,6 +218,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
 }  // namespace
 
 static int ensure_gate_buffers(xivo_hip_ctx* c, int F);
+static int ensure_dense(xivo_hip_ctx* c);
 
 extern "C" {
 
@@ -389,7 +393,7 @@ int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   MeasBuffers mb = meas_buffers(c);
   mb.H += (long)b0 * mb.strideH; mb.HT += (long)b0 * mb.strideHT;
   mb.inn += (long)b0 * mb.strideInn; mb.diagR += (long)b0 * mb.strideR;
-  c->M = M; c->Mp = round_up16(M);
+  c->M = M; c->Mp = round_up16(M); c->dense_valid = true;
   // clear up to the allocated row count so stale rows of a previous, larger M vanish
   if (launch_unpack_meas(sH, sInn, sR, mb, M, c->Mpmax, N, c->Np, nb, c->stream)) return XIVO_HIP_ERR_HIP;
   {  // row-pair compressed form of the same rows + which filters fit it
@@ -444,8 +448,8 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   if (gate) {
     GateEllArgs a{}; a.ell = e;
-    a.H = c->H + (long)b0 * c->sH; a.strideH = c->sH; a.ldh = ldh;
-    a.HT = c->HT + (long)b0 * c->sHT; a.strideHT = c->sHT; a.ldht = Np; a.HP = HP; a.PHT = PHT;
+    a.H = c->dense_valid ? c->H + (long)b0 * c->sH : nullptr; a.strideH = c->sH; a.ldh = ldh;
+    a.HT = c->dense_valid ? c->HT + (long)b0 * c->sHT : nullptr; a.strideHT = c->sHT; a.ldht = Np; a.HP = HP; a.PHT = PHT;
     a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
     a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
     a.F = gate->F; a.Np = Np; a.batch = B;
@@ -523,6 +527,8 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   for (int b = b0; sparse && b < b0 + B; ++b) sparse = c->ell_over_h[b] == 0;
   c->last_path = sparse ? 1 : 0;
   if (sparse) return update_sparse_range(c, b0, B, gate);
+  rc = ensure_dense(c);
+  if (rc) return rc;
   {  // HP = H * P and its transpose PH^T (estimator.cpp:1259 first product; P symmetric => B operand = P rows)
     GemmExtra x; x.C2 = PHT; x.sC2 = c->sK; x.ldc2 = Np;
     rc = gemm(c, ST_HP, B, Mp, Np, H, c->sH, ldh, P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
@@ -801,18 +807,32 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
   return XIVO_HIP_OK;
 }
 
-int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
-  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
+static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense) {
   StackArgs a;
   a.sb = scene_buffers(c); a.lay = c->lay; a.mb = meas_buffers(c);
   a.Mp = c->Mpmax; a.Np = c->Np; a.batch = B; a.R = R;
   a.fix_group_block = (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK) ? 1 : 0;
   a.rows_instate = c->rows_instate;
-  c->M = 2 * c->F; c->Mp = round_up16(c->M);
-  a.ell = c->ell; a.emit_ell = 1;
-  for (int b = 0; b < B; ++b) { c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12; }
+  a.ell = c->ell; a.emit_ell = 1; a.write_dense = write_dense;
   StageTimer st(c, ST_STACK, 0.0, "stack_kernel");
   return launch_stack(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+// the dense copies of the stacked rows, for the consumers that need them (dense pipeline, OOS rows, get_H)
+static int ensure_dense(xivo_hip_ctx* c) {
+  if (c->dense_valid) return XIVO_HIP_OK;
+  c->dense_valid = true;
+  return stack_impl(c, c->stack_B, c->stack_R, 1);
+}
+
+int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
+  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
+  c->M = 2 * c->F; c->Mp = round_up16(c->M);
+  for (int b = 0; b < B; ++b) { c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12; }
+  // the sparse-H pipeline reads only the compressed rows: skip the 2 x Mp x Np dense zero-fill + scatter
+  const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
+  c->dense_valid = dense != 0; c->stack_R = R; c->stack_B = B;
+  return stack_impl(c, B, R, dense);
 }
 
 int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_oos_in* feats, double Roos,
@@ -831,6 +851,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
     if (rows > max_rows) max_rows = rows;
   }
   if (c->M + max_rows > c->Mmax) return XIVO_HIP_ERR_INVALID;
+  { int rcd = ensure_dense(c); if (rcd) return rcd; }
   if (n_oos * nb > c->oos_cap) {
     if (c->oos) hipFree(c->oos);
     c->oos = nullptr; c->oos_cap = 0;
@@ -898,6 +919,7 @@ int xivo_hip_get_H(xivo_hip_ctx* c, int b, int* M_out, double* H, int ldh, doubl
   if (M_out) *M_out = M;
   if (H) {
     if (ldh < M) return XIVO_HIP_ERR_INVALID;
+    { int rcd = ensure_dense(c); if (rcd) return rcd; }
     HIP_TRY(hipMemcpy2DAsync(H, (size_t)ldh * sizeof(double), c->H + (long)b * c->sH, (size_t)c->Mpmax * sizeof(double),
                              (size_t)M * sizeof(double), c->N, hipMemcpyDeviceToHost, c->stream));
   }

@@ -67,6 +67,7 @@ struct StackArgs {
   int Mp, Np, batch; double R; int fix_group_block;
   int* rows_instate;   // [batch] out: 2 * F (rows reserved for in-state features)
   EllBuffers ell; int emit_ell;   // also emit the row-pair compressed form (ell.h)
+  int write_dense;                // 0: only inn / diagR / ELL (the dense H, H^T are materialised on demand)
 };
 int launch_stack(const StackArgs& a, hipStream_t s);
 

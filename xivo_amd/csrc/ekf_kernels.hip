@@ -394,10 +394,12 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   double* H = a.mb.H + (long)filt * a.mb.strideH;
   double* HT = a.mb.HT + (long)filt * a.mb.strideHT;
   // H_.setZero(total_size, N) (update.cpp:130)
-  for (int n = 0; n < a.Np; ++n)
-    for (int m = tid; m < a.Mp; m += 256) H[m + (long)n * a.mb.ldh] = 0.0;
-  for (int m = 0; m < a.Mp; ++m)
-    for (int n = tid; n < a.Np; n += 256) HT[n + (long)m * a.mb.ldht] = 0.0;
+  if (a.write_dense) {
+    for (int n = 0; n < a.Np; ++n)
+      for (int m = tid; m < a.Mp; m += 256) H[m + (long)n * a.mb.ldh] = 0.0;
+    for (int m = 0; m < a.Mp; ++m)
+      for (int n = tid; n < a.Np; n += 256) HT[n + (long)m * a.mb.ldht] = 0.0;
+  }
   double* inn = a.mb.inn + (long)filt * a.mb.strideInn;
   double* dR = a.mb.diagR + (long)filt * a.mb.strideR;
   for (int m = tid; m < a.Mp; m += 256) { inn[m] = 0.0; dR[m] = 1.0; }
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
         const int col = jcol(a.lay, ft, 3 * b + o);
         for (int i = 0; i < 2; ++i) {
           const double v = J[i * 21 + 3 * src + o];
+          if (!a.write_dense) continue;
           H[(2 * f + i) + (long)col * a.mb.ldh] = v;
           HT[col + (long)(2 * f + i) * a.mb.ldht] = v;
         }

@@ -300,20 +300,22 @@ __global__ __launch_bounds__(256) void gate_ell_kernel(GateEllArgs a) {
       for (int t = 0; t < 2 * ELL_W; ++t) val[(long)f * ELL_W * 2 + t] = 0.0;
     }
   }
-  double* H = a.H + (long)filt * a.strideH;
-  double* HT = a.HT + (long)filt * a.strideHT;
+  double* H = a.H ? a.H + (long)filt * a.strideH : nullptr;       // dense copies, when they are materialised
+  double* HT = a.HT ? a.HT + (long)filt * a.strideHT : nullptr;
   double* HP = a.HP + (long)filt * a.strideH;
   for (int f = 0; f < a.F; ++f) {
     if (sdist[f] < th) continue;
     for (int n = tid; n < a.Np; n += 256) {
-      H[2 * f + (long)n * a.ldh] = 0.0;
-      H[2 * f + 1 + (long)n * a.ldh] = 0.0;
-      HP[2 * f + (long)n * a.ldh] = 0.0;
-      HP[2 * f + 1 + (long)n * a.ldh] = 0.0;
-      HT[n + (long)(2 * f) * a.ldht] = 0.0;
-      HT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
+      if (H) {
+        H[2 * f + (long)n * a.ldh] = 0.0;
+        H[2 * f + 1 + (long)n * a.ldh] = 0.0;
+        HT[n + (long)(2 * f) * a.ldht] = 0.0;
+        HT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
+      }
       PHT[n + (long)(2 * f) * a.ldht] = 0.0;
       PHT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
+      HP[2 * f + (long)n * a.ldh] = 0.0;          // read by the gather form of ELL_S only
+      HP[2 * f + 1 + (long)n * a.ldh] = 0.0;
     }
   }
 }
