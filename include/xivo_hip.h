@@ -259,6 +259,8 @@ int xivo_hip_last_path(xivo_hip_ctx* ctx);
 /* kernel instantiation the last launch of profile stage `stage` ran (index as in xivo_hip_profile_get; needs
  * XIVO_HIP_FLAG_PROFILE), spelled as rocprofv3 --kernel-trace prints it minus spaces; "" if none */
 const char* xivo_hip_stage_kernel(xivo_hip_ctx* ctx, int stage);
+/* algorithmic HBM bytes of that launch: every input and every output of the stage once */
+double xivo_hip_stage_bytes(xivo_hip_ctx* ctx, int stage);
 
 #ifdef __cplusplus
 }

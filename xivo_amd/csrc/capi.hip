@@ -70,6 +70,7 @@ struct xivo_hip_ctx {
   float stage_ms[ST_COUNT] = {0};
   int stage_launches[ST_COUNT] = {0};
   double stage_flops[ST_COUNT] = {0};
+  double stage_bytes[ST_COUNT] = {0};         // algorithmic HBM bytes of the stage's last launch (inputs once + outputs once)
   char stage_kernel[ST_COUNT][64] = {{0}};   // kernel instantiation of the stage's last launch (as rocprofv3 names it)
 };
 
@@ -92,8 +93,9 @@ int dev_alloc(T** p, size_t n) {
 
 struct StageTimer {
   xivo_hip_ctx* c; EventPair* ep = nullptr;
-  StageTimer(xivo_hip_ctx* ctx, int stage, double flops, const char* kernel = nullptr) : c(ctx) {
+  StageTimer(xivo_hip_ctx* ctx, int stage, double flops, const char* kernel = nullptr, double bytes = 0.0) : c(ctx) {
     if (!(c->flags & XIVO_HIP_FLAG_PROFILE)) return;
+    c->stage_bytes[stage] = bytes;
     if (kernel) { strncpy(c->stage_kernel[stage], kernel, 63); c->stage_kernel[stage][63] = 0; }
     if (c->pool_used >= c->pool.size()) {
       EventPair np; np.stage = stage;
@@ -210,7 +212,9 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
                    (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG) && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
   char label[64] = "gemm_sym_f64_kernel";
   if (!sym) gemm_kernel_label(g, label, sizeof(label));
-  StageTimer st(c, stage, flops, label);
+  const double bytes = 8.0 * B * ((double)rows * K0 + (double)cols * K0 + (A1 ? ((double)rows + cols) * K1 : 0.0) +
+                                  (x.msub ? outs : 0.0) + (double)rows * cols + (x.C2 ? (double)rows * cols : 0.0));
+  StageTimer st(c, stage, flops, label, bytes);
   const int rc = sym ? launch_gemm_sym_f64(g, c->stream) : launch_gemm_nt_f64(g, c->stream);
   return rc == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
 }
@@ -443,7 +447,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
     a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.cols = Np;
     char label[64]; ell_kernel_label(ELL_HP, a, label, sizeof(label));
-    StageTimer st(c, ST_HP, nnz_flops * Np * B, label);
+    StageTimer st(c, ST_HP, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
     if (launch_ell_mul(ELL_HP, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   if (gate) {
@@ -463,13 +467,14 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max;
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
-    StageTimer st(c, ST_S, nnz_flops * Mp * B, label);
+    StageTimer st(c, ST_S, nnz_flops * Mp * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     if (launch_ell_mul(ELL_S, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {
     CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B;
-    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, "chol_f64_kernel");
+    char clabel[64]; chol_kernel_label(Mp, clabel, sizeof(clabel));
+    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {
@@ -478,7 +483,8 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
-    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label);
+    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
     if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
@@ -493,7 +499,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sA; a.ldo = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.cols = Np;
     char label[64]; ell_kernel_label(ELL_G, a, label, sizeof(label));
-    StageTimer st(c, ST_KH, nnz_flops * Np * B, label);
+    StageTimer st(c, ST_KH, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + 2.0 * Np * Mp));
     if (launch_ell_mul(ELL_G, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // P+ = G K^T - T   (lower triangle + mirror)
@@ -558,7 +564,8 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {  // S = L L^T
     CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B;
-    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, "chol_f64_kernel");
+    char clabel[64]; chol_kernel_label(Mp, clabel, sizeof(clabel));
+    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
@@ -567,7 +574,8 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
-    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label);
+    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
     if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   if (c->flags & XIVO_HIP_FLAG_REASSOC) {
@@ -645,6 +653,10 @@ int xivo_hip_update_dense_gated(xivo_hip_ctx* c, int B, int F, double R, double 
 }
 
 int xivo_hip_last_path(xivo_hip_ctx* c) { return c ? c->last_path : -1; }
+
+double xivo_hip_stage_bytes(xivo_hip_ctx* c, int stage) {
+  return (c && stage >= 0 && stage < ST_COUNT) ? c->stage_bytes[stage] : 0.0;
+}
 
 const char* xivo_hip_stage_kernel(xivo_hip_ctx* c, int stage) {
   return (c && stage >= 0 && stage < ST_COUNT) ? c->stage_kernel[stage] : "";

@@ -776,6 +776,12 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   return (int)hipErrorInvalidValue;
 }
 
+void chol_kernel_label(int Mp, char* buf, size_t n) {
+  const int nb = Mp / 16;
+  if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12) snprintf(buf, n, "chol_f64_kernel");
+  else snprintf(buf, n, "chol_reg_f64_kernel<%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : 12));
+}
+
 void trsm_kernel_label(int Mp, char* buf, size_t n) {
   const int nb = Mp / 16;
   const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;

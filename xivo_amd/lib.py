@@ -91,6 +91,7 @@ _SIGS = {
     "xivo_hip_filter_update": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int],
     "xivo_hip_last_path": [C.c_void_p],
     "xivo_hip_stage_kernel": [C.c_void_p, C.c_int],
+    "xivo_hip_stage_bytes": [C.c_void_p, C.c_int],
     "xivo_hip_absorb_error": [C.c_void_p, C.c_int],
     "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
@@ -130,6 +131,7 @@ def load_library():
     lib.xivo_hip_gemm_tile.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.xivo_hip_gemm_tile.restype = None
     lib.xivo_hip_stage_kernel.restype = C.c_char_p
+    lib.xivo_hip_stage_bytes.restype = C.c_double
     _LIB = lib
     return lib
 
@@ -370,7 +372,8 @@ class Context:
         flops = (C.c_double * 16)()
         self._check(self.lib.xivo_hip_profile_get(self.h, C.byref(n), names, ms, launches, flops))
         return {names[i].decode(): {"ms": ms[i], "launches": launches[i], "flops_per_launch": flops[i],
-                                    "kernel": self.lib.xivo_hip_stage_kernel(self.h, i).decode()}
+                                    "kernel": self.lib.xivo_hip_stage_kernel(self.h, i).decode(),
+                                    "bytes_per_launch": self.lib.xivo_hip_stage_bytes(self.h, i)}
                 for i in range(n.value)}
 
     def bench_mfma_peak(self):
