@@ -54,6 +54,7 @@ struct EllMulArgs {
   const double* K; long strideK; int ldk;       // ELL_G
   int X;        // extent of the contiguous index (Np for HP/G, Mp for S)
   int Mp;       // rows of H in use (multiple of 16)
+  int slabs_per_wg; // set by the launcher (slab form): consecutive slabs one workgroup streams
   int rb_per_wg; // set by the launcher: 16-row blocks one workgroup walks
   int nc_max;   // upper bound of nc over the filters of the launch (host mirror)
   int batch;

@@ -165,95 +165,149 @@ __global__ __launch_bounds__(256) void ell_mul_kernel(EllMulArgs a) {
 typedef __attribute__((address_space(4))) const double ell_cdouble;
 typedef __attribute__((address_space(4))) const int ell_cint;
 
-// threads per workgroup: the S instantiation does not fit the 128-VGPR budget of 16 waves per CU
+// threads per workgroup: 16 waves (128 VGPRs each) walk the pairs fastest; the S instantiation (transposing
+// prefetch, 40 doubles per thread) needs the 256-VGPR budget of 8 waves
 constexpr int ell_tile_threads(int mode) { return mode == ELL_S ? 512 : 1024; }
 
 template <int MODE, int CWU, int XC>
 __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMulArgs a) {
   constexpr int NSLOT = CWU + ELL_PW;
+  constexpr int NT = ell_tile_threads(MODE), NW = NT / 64;
+  // slab elements per thread held in registers while the previous slab is being consumed
+  // covers every cols the LDS can hold (XC = 64: <= 272; XC = 32: <= 528)
+  // (prefetching under the pair walk pays for ELL_S only: at 16 waves per CU the 128-VGPR budget of the other
+  //  two modes cannot hold a slab share next to the walk without spilling - measured slower)
+  constexpr bool PF = MODE == ELL_S;
+  constexpr int RN = PF ? 40 : 8;
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int xchunks = (a.X + XC - 1) / XC;
+  const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;     // workgroups per filter
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
-  const int filt = (slot / xchunks) * 8 + xcd;
+  const int filt = (slot / wgs) * 8 + xcd;
   if (filt >= a.batch) return;
-  const int x0 = (slot % xchunks) * XC;
+  const int s_begin = (slot % wgs) * a.slabs_per_wg;
+  const int s_end = min(xchunks, s_begin + a.slabs_per_wg);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = blockDim.x >> 6;
   const double* __restrict__ Src = a.Src + (long)filt * a.strideSrc;
   const int cols = a.cols;
   const int pairs = a.Mp / 2;
   double* ops = tile + (long)cols * XC;
-  {  // coefficients of every pair of the filter: coalesced 16-byte loads -> LDS
+  {  // coefficients of every pair of the filter: coalesced 16-byte loads -> LDS, once per workgroup
     const d2* __restrict__ gv = reinterpret_cast<const d2*>(a.ell.val + (long)filt * a.ell.stride_val());
-    for (int e = tid; e < pairs * NSLOT; e += blockDim.x) {
+    for (int e = tid; e < pairs * NSLOT; e += NT) {
       const int p = e / NSLOT, t = e % NSLOT;
       *reinterpret_cast<d2*>(ops + 2 * e) = gv[p * ELL_W + (t < CWU ? t : ELL_CW + (t - CWU))];
     }
   }
-  if (MODE == ELL_S) {
-    // source = P H^T [cols x Mp] (column j contiguous over the state index): slab[k][jj] = PHT[k, x0 + jj]
-    for (int jj = wave; jj < XC; jj += nw) {
-      const bool ok = x0 + jj < a.X;
-      const double* __restrict__ col = Src + (long)(x0 + jj) * a.ldsrc;
-      for (int k0 = 0; k0 < cols; k0 += 64 * 8) {
-        double r[8];
+  // The slab of step s+1 is fetched into registers while the pairs are walked over the slab of step s
+  // (one workgroup per CU owns the LDS, so nothing else would hide the HBM latency of the next slab).
+  //   ELL_S : source = P H^T [cols x Mp], column j contiguous over the state index: slab[k][jj] = PHT[k, x0 + jj];
+  //           thread (wave, lane) fetches column jj = wave + NW q, rows k = lane + 64 u
+  //   else  : source [X x cols], contiguous index first: slab[k][xx] = Src[x0 + xx, k];
+  //           thread fetches xx = tid % XC, k = tid / XC + (NT / XC) u
+  double r[RN];
+  auto fetch = [&](int sidx) {
+    const int x0 = sidx * XC;
+    if (MODE == ELL_S) {
+      constexpr int KU = RN / (XC / NW);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; r[u] = (ok && k < cols) ? col[k] : 0.0; }
+      for (int q = 0; q < XC / NW; ++q) {
+        const int jj = wave + NW * q;
+        const bool ok = x0 + jj < a.X;
+        const double* __restrict__ col = Src + (long)(x0 + (ok ? jj : 0)) * a.ldsrc;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; if (k < cols) tile[k * XC + (jj ^ (k & 15))] = r[u]; }
+        for (int u = 0; u < KU; ++u) { const int k = lane + 64 * u; r[q * KU + u] = (ok && k < cols) ? col[k] : 0.0; }
+      }
+    } else {
+      // uniform 64-bit base (+ u * step, scalar) and one 32-bit per-lane byte offset: no per-load address VGPRs.
+      // cols is a multiple of 16 and NT / XC divides 16, so "k < cols" is the same for every lane of a step
+      const int xx = tid % XC, kq = tid / XC;
+      const bool ok = x0 + xx < a.X;
+      const unsigned voff = ((unsigned)(ok ? xx : 0) + (unsigned)kq * (unsigned)a.ldsrc) * 8u;
+      const char* base = reinterpret_cast<const char*>(Src + x0);
+      const size_t step = (size_t)(NT / XC) * (size_t)a.ldsrc * 8u;
+      const int nu = cols / (NT / XC);
+#pragma unroll
+      for (int u = 0; u < RN; ++u) {
+        double v = 0.0;
+        if (u < nu) v = *reinterpret_cast<const double*>(base + (size_t)u * step + voff);
+        r[u] = ok ? v : 0.0;
       }
     }
-  } else {
-    // source [X x cols], contiguous index first: slab[k][xx] = Src[x0 + xx, k]
-    const int xx = tid % XC, kq = tid / XC, kstep = blockDim.x / XC;
-    const bool ok = x0 + xx < a.X;
-    const double* __restrict__ row = Src + x0 + xx;
-    for (int k0 = 0; k0 < cols; k0 += kstep * 8) {
-      double r[8];
+  };
+  auto park = [&]() {
+    if (MODE == ELL_S) {
+      constexpr int KU = RN / (XC / NW);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int k = k0 + kq + kstep * u; r[u] = (ok && k < cols) ? row[(long)k * a.ldsrc] : 0.0; }
+      for (int q = 0; q < XC / NW; ++q) {
+        const int jj = wave + NW * q;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int k = k0 + kq + kstep * u; if (k < cols) tile[k * XC + (xx ^ (k & 15))] = r[u]; }
+        for (int u = 0; u < KU; ++u) { const int k = lane + 64 * u; if (k < cols) tile[k * XC + (jj ^ (k & 15))] = r[q * KU + u]; }
+      }
+    } else {
+      const int xx = tid % XC, kq = tid / XC;
+#pragma unroll
+      for (int u = 0; u < RN; ++u) { const int k = kq + (NT / XC) * u; if (k < cols) tile[k * XC + (xx ^ (k & 15))] = r[u]; }
     }
-  }
-  __syncthreads();
+  };
 
   const int xx = lane % XC, half = lane / XC;
-  const int x = x0 + xx;
-  const bool live = x < a.X;
   ell_cint* idx0 = (ell_cint*)(a.ell.idx + (long)filt * a.ell.stride_idx());
   ell_cdouble* dR = (ell_cdouble*)(a.diagR + (long)filt * a.strideR);
-  const double* __restrict__ K = a.K + (long)filt * a.strideK + (live ? x : 0);
-  double* __restrict__ out = a.out + (long)filt * a.strideOut + (live ? x : 0);
   auto slab = [&](int k) -> double { return tile[k * XC + (xx ^ (k & 15))]; };
 
-  double cm[CWU];
+  if (PF) fetch(s_begin);
+  for (int sidx = s_begin; sidx < s_end; ++sidx) {
+    if (PF) {
+      park();
+    } else {
+      // straight copy, 8 loads in flight per thread
+      const int x0 = sidx * XC;
+      const int xq = tid % XC, kq = tid / XC;
+      const bool ok = x0 + xq < a.X;
+      const double* __restrict__ row = Src + x0 + (ok ? xq : 0);
+      for (int k0 = 0; k0 < cols; k0 += (NT / XC) * 8) {
 #pragma unroll
-  for (int t = 0; t < CWU; ++t) cm[t] = slab(idx0[t]);
-
-#pragma unroll 2
-  for (int p = wave; p < pairs; p += nw) {
-    ell_cint* pi = idx0 + (long)p * ELL_W + ELL_CW;
-    const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT;
-    double sv[ELL_PW];
+        for (int u = 0; u < 8; ++u) { const int k = k0 + kq + (NT / XC) * u; r[u] = (ok && k < cols) ? row[(long)k * a.ldsrc] : 0.0; }
 #pragma unroll
-    for (int t = 0; t < ELL_PW; ++t) sv[t] = slab(pi[t]);
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int t = 0; t < CWU; ++t) { const d2 v = pv[t]; a0 = fma(v[0], cm[t], a0); a1 = fma(v[1], cm[t], a1); }
-#pragma unroll
-    for (int t = 0; t < ELL_PW; ++t) { const d2 v = pv[CWU + t]; a0 = fma(v[0], sv[t], a0); a1 = fma(v[1], sv[t], a1); }
-    if (!live) continue;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (XC == 32 && i != half) continue;      // XC = 32: each half-wave stores its own row
-      const int m = 2 * p + i;
-      const double acc = i ? a1 : a0;
-      if (MODE == ELL_HP) out[(long)m * a.ldo] = acc;
-      else if (MODE == ELL_S) out[(long)m * a.ldo] = acc + (x == m ? dR[m] : 0.0);
-      else out[(long)m * a.ldo] = fma(K[(long)m * a.ldk], dR[m], acc);
+        for (int u = 0; u < 8; ++u) { const int k = k0 + kq + (NT / XC) * u; if (k < cols) tile[k * XC + (xq ^ (k & 15))] = r[u]; }
+      }
     }
+    __syncthreads();
+    if (PF && sidx + 1 < s_end) fetch(sidx + 1);
+
+    const int x = sidx * XC + xx;
+    const bool live = x < a.X;
+    const double* __restrict__ K = a.K + (long)filt * a.strideK + (live ? x : 0);
+    double* __restrict__ out = a.out + (long)filt * a.strideOut + (live ? x : 0);
+    double cm[CWU];
+#pragma unroll
+    for (int t = 0; t < CWU; ++t) cm[t] = slab(idx0[t]);
+#pragma unroll 2
+    for (int p = wave; p < pairs; p += NW) {
+      ell_cint* pi = idx0 + (long)p * ELL_W + ELL_CW;
+      const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT;
+      double sv[ELL_PW];
+#pragma unroll
+      for (int t = 0; t < ELL_PW; ++t) sv[t] = slab(pi[t]);
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < CWU; ++t) { const d2 v = pv[t]; a0 = fma(v[0], cm[t], a0); a1 = fma(v[1], cm[t], a1); }
+#pragma unroll
+      for (int t = 0; t < ELL_PW; ++t) { const d2 v = pv[CWU + t]; a0 = fma(v[0], sv[t], a0); a1 = fma(v[1], sv[t], a1); }
+      if (!live) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (XC == 32 && i != half) continue;      // XC = 32: each half-wave stores its own row
+        const int m = 2 * p + i;
+        const double acc = i ? a1 : a0;
+        if (MODE == ELL_HP) out[(long)m * a.ldo] = acc;
+        else if (MODE == ELL_S) out[(long)m * a.ldo] = acc + (x == m ? dR[m] : 0.0);
+        else out[(long)m * a.ldo] = fma(K[(long)m * a.ldk], dR[m], acc);
+      }
+    }
+    __syncthreads();   // the slab is overwritten by the next step
   }
 }
 
@@ -333,15 +387,21 @@ int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, 
 }
 
 template <int MODE, int CWU, int XC>
-static int launch_ell_tile_t(const EllMulArgs& a, size_t lds, hipStream_t s) {
+static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  EllMulArgs a = a_in;
   const int xchunks = (a.X + XC - 1) / XC;
-  const int grid = ((a.batch + 7) / 8) * 8 * xchunks;
+  // big batch: one workgroup streams all slabs of its filter (next slab prefetched under the pair walk,
+  // coefficients staged once); small batch: one workgroup per slab (latency)
+  a.slabs_per_wg = (MODE == ELL_S && a.batch >= 1024) ? xchunks : 1;
+  if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
+  const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
+  const int grid = ((a.batch + 7) / 8) * 8 * wgs;
   hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC>), dim3(grid), dim3(ell_tile_threads(MODE)), lds, s, a);
   return (int)hipGetLastError();
 }
