@@ -177,7 +177,8 @@ __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMul
   // covers every cols the LDS can hold (XC = 64: <= 272; XC = 32: <= 528)
   // (prefetching under the pair walk pays for ELL_S only: at 16 waves per CU the 128-VGPR budget of the other
   //  two modes cannot hold a slab share next to the walk without spilling - measured slower)
-  constexpr bool PF = MODE == ELL_S;
+  constexpr bool PF = MODE == ELL_S && XC == 64 && CWU == 12;
+  constexpr int UNR = (PF || (CWU == 12 && XC == 64)) ? 2 : 1;   // pairs in flight per wave (register budget)
   constexpr int RN = PF ? 40 : 8;
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int xchunks = (a.X + XC - 1) / XC;
@@ -261,6 +262,18 @@ __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMul
   for (int sidx = s_begin; sidx < s_end; ++sidx) {
     if (PF) {
       park();
+    } else if (MODE == ELL_S) {
+      const int x0 = sidx * XC;
+      for (int jj = wave; jj < XC; jj += NW) {
+        const bool ok = x0 + jj < a.X;
+        const double* __restrict__ col = Src + (long)(x0 + (ok ? jj : 0)) * a.ldsrc;
+        for (int k0 = 0; k0 < cols; k0 += 64 * 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; r[u] = (ok && k < cols) ? col[k] : 0.0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; if (k < cols) tile[k * XC + (jj ^ (k & 15))] = r[u]; }
+        }
+      }
     } else {
       // straight copy, 8 loads in flight per thread
       const int x0 = sidx * XC;
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMul
     double cm[CWU];
 #pragma unroll
     for (int t = 0; t < CWU; ++t) cm[t] = slab(idx0[t]);
-#pragma unroll 2
+#pragma unroll UNR
     for (int p = wave; p < pairs; p += NW) {
       ell_cint* pi = idx0 + (long)p * ELL_W + ELL_CW;
       const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT;
@@ -398,7 +411,7 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   const int xchunks = (a.X + XC - 1) / XC;
   // big batch: one workgroup streams all slabs of its filter (next slab prefetched under the pair walk,
   // coefficients staged once); small batch: one workgroup per slab (latency)
-  a.slabs_per_wg = (MODE == ELL_S && a.batch >= 1024) ? xchunks : 1;
+  a.slabs_per_wg = (MODE == ELL_S && XC == 64 && CWU == 12 && a.batch >= 1024) ? xchunks : 1;
   if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
   const int grid = ((a.batch + 7) / 8) * 8 * wgs;
