@@ -224,6 +224,33 @@ int xivo_hip_oos_project(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xiv
 int xivo_hip_filter_update(xivo_hip_ctx* ctx, int B, double R, double mh_thresh, double mh_mult,
                            int min_inliers, int use_gating);
 int xivo_hip_get_H(xivo_hip_ctx* ctx, int b, int* M_out, double* H, int ldh, double* inn, double* diagR);
+/* ---- the step just before the path - depth sub-filter + candidate scoring ----
+ * Feature::SubfilterUpdate (src/feature.cpp:246-297): one 3x3 EKF step per feature that is tracked but not
+ * in the state yet, against the resident sensor pose / anchor groups (xivo_hip_set_scene), followed by
+ * Criteria::Candidate / CandidateStrict (src/options.cpp:10-33) and Feature::score (src/feature.cpp:133-142),
+ * which decide who is moved into the state. Embarrassingly parallel: one thread per (filter, feature). */
+enum { XIVO_FEAT_INITIALIZING = 0, XIVO_FEAT_READY = 1 };
+typedef struct {
+  double x[3];            /* in/out: (X/Z, Y/Z, log Z) in the anchor camera frame (src/feature.h:258-262) */
+  double P[9];            /* in/out: 3x3 covariance, column-major */
+  double xp[2];           /* in: tracked pixel in the current frame */
+  double outlier_counter; /* in/out */
+  double score;           /* out: -P(2,2) */
+  int ref_sind;           /* in: anchor group slot */
+  int status;             /* in/out: XIVO_FEAT_INITIALIZING / XIVO_FEAT_READY */
+  int init_counter;       /* in/out */
+  int candidate;          /* out: bit 0 Criteria::Candidate, bit 1 Criteria::CandidateStrict */
+} xivo_subfilter_feat;
+typedef struct {
+  double Rtri, MH_thresh;           /* SubfilterOptions (src/options.h:25-32): 3.5, 5.991 */
+  int ready_steps;                  /* 5 */
+  double min_depth, max_depth;      /* cfg min_depth / max_depth: 0.05, 5.0 */
+  double max_subfilter_outlier;     /* 0.01 */
+} xivo_subfilter_opts;
+/* feats: host array [nb x n] (filter-major), updated in place */
+int xivo_hip_subfilter_update(xivo_hip_ctx* ctx, int b0, int nb, int n, xivo_subfilter_feat* feats,
+                              const xivo_subfilter_opts* opts);
+
 /* Estimator::AbsorbError (src/estimator.cpp:875-921) on the device-resident nominal state of filters
  * [0,B): X += dx via State::operator+= (src/core.h:135-165: SO3 exp on Rsb, Rbc, Rsg), every group slot
  * += dx segment (src/group.h:25-29), every feature that was an inlier of the last gating / stacking pass

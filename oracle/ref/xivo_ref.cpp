@@ -227,6 +227,51 @@ void ref_rk4_cov_tail(int N, int nm, double* P, const double* FK, const double* 
 }
 
 // Sophus::SO3::exp
+// Feature::SubfilterUpdate, src/feature.cpp:246-297 (default build: log-depth), restated on the same Eigen /
+// Sophus types with the identical expression sequence. x (3), P (3x3 col-major), counters in/out.
+// Returns the new status (0 INITIALIZING, 1 READY).
+int ref_subfilter_update(double* x, double* P, const double* xp_meas, const double* Rsb_, const double* Tsb_,
+                         const double* Rbc_, const double* Tbc_, const double* Rsbr_, const double* Tsbr_,
+                         const CamCfg* cam, double Rtri, double MH_thresh, int ready_steps, int* init_counter,
+                         double* outlier_counter) {
+  const Mat3 Rsb = Eigen::Map<const Mat3>(Rsb_), Rbc = Eigen::Map<const Mat3>(Rbc_), Rsbr = Eigen::Map<const Mat3>(Rsbr_);
+  const Vec3 Tsb = Eigen::Map<const Vec3>(Tsb_), Tbc = Eigen::Map<const Vec3>(Tbc_), Tsbr = Eigen::Map<const Vec3>(Tsbr_);
+  const SE3 gsb = SE3(SO3(Rsb), Tsb), gbc = SE3(SO3(Rbc), Tbc), gref = SE3(SO3(Rsbr), Tsbr);
+  Vec3 x_ = Eigen::Map<const Vec3>(x);
+  Mat3 P_ = Eigen::Map<const Mat3>(P);
+  (*init_counter)++;
+  Mat3 dXc_dx;
+  Vec3 Xc = unproject_logz(x_, &dXc_dx);
+  SE3 gtot = (gsb * gbc).inverse() * gref * gbc;
+  Vec3 Xcn = gtot * Xc;
+  Mat3 dXcn_dXc = gtot.so3().matrix();
+  Mat23 dxcn_dXcn;
+  Vec2 xcn = project(Xcn, &dxcn_dXcn);
+  Mat2 dxp_dxcn;
+  Vec2 xp = cam_project(*cam, xcn, &dxp_dxcn);
+  Mat23 H = dxp_dxcn * dxcn_dXcn * dXcn_dXc * dXc_dx;
+  const Vec2 xpm = Eigen::Map<const Vec2>(xp_meas);
+  Vec2 inn = xpm - xp;
+  Mat2 S = H * P_ * H.transpose();
+  S(0, 0) += Rtri;
+  S(1, 1) += Rtri;
+  double ratio{inn.dot(S.ldlt().solve(inn)) / MH_thresh};
+  if (ratio > 1) {
+    S(0, 0) += Rtri * (ratio - 1);
+    S(1, 1) += Rtri * (ratio - 1);
+    *outlier_counter += sqrt(ratio);
+  } else {
+    *outlier_counter = 0;
+  }
+  Eigen::Matrix<double, 3, 2> K = P_ * H.transpose() * S.inverse();
+  x_ += K * inn;
+  Mat3 I_KH = Mat3::Identity() - K * H;
+  P_ = I_KH * P_ * I_KH.transpose() + K * Rtri * K.transpose();
+  (Eigen::Map<Vec3>(x)) = x_;
+  (Eigen::Map<Mat3>(P)) = P_;
+  return *init_counter > ready_steps ? 1 : 0;
+}
+
 void ref_so3_exp(const double* w, double* R) { (Eigen::Map<Mat3>(R)) = SO3::exp(Eigen::Map<const Vec3>(w)).matrix(); }
 
 }  // extern "C"

@@ -82,6 +82,20 @@ class Ref:
             cd[n] = cache[9 + 9 * i:18 + 9 * i].reshape(3, 3).T.copy()
         return np.ascontiguousarray(J), inn, cd
 
+    def subfilter_update(self, x, P, xp_meas, Rsb, Tsb, Rbc, Tbc, Rsbr, Tsbr, cam, Rtri, MH_thresh, ready_steps,
+                         init_counter, outlier_counter):
+        """Feature::SubfilterUpdate. Returns (x, P, status, init_counter, outlier_counter)."""
+        x = np.array(x, dtype=np.float64); Pf = _F(np.array(P, dtype=np.float64))
+        ic = C.c_int(init_counter); oc = C.c_double(outlier_counter)
+        c = _cam(cam)
+        v = lambda a: _p(np.ascontiguousarray(a, dtype=np.float64))
+        Rs = [_F(Rsb), _F(Rbc), _F(Rsbr)]
+        self.lib.ref_subfilter_update.restype = C.c_int
+        st = self.lib.ref_subfilter_update(_p(x), _p(Pf), v(xp_meas), _p(Rs[0]), v(Tsb), _p(Rs[1]), v(Tbc), _p(Rs[2]),
+                                           v(Tsbr), C.byref(c), C.c_double(Rtri), C.c_double(MH_thresh),
+                                           C.c_int(ready_steps), C.byref(ic), C.byref(oc))
+        return x, np.ascontiguousarray(Pf), int(st), ic.value, oc.value
+
     def fill_jacobian_block(self, H, row, J, layout, ref_sind, sind):
         M, N = H.shape
         Hf = _F(H)

@@ -643,6 +643,59 @@ def absorb_error(st, err, layout, upd_groups, upd_feats):
 
 
 # ----------------------------------------------------------------------------
+# Feature::SubfilterUpdate (src/feature.cpp:246-297) - the 3x3 depth sub-filter of a feature
+# that is not in the state yet - and the candidate tests / score that decide who enters the state
+# (src/options.cpp:10-33, src/feature.cpp:133-142).
+# ----------------------------------------------------------------------------
+FEAT_INITIALIZING, FEAT_READY = 0, 1
+
+
+def subfilter_update(x, P, xp_meas, Rsb, Tsb, Rbc, Tbc, Rsbr, Tsbr, cam, Rtri=3.5, MH_thresh=5.991, ready_steps=5,
+                     init_counter=0, outlier_counter=0.0):
+    """Returns (x, P, status, init_counter, outlier_counter). 3x3 matrices row-major [i, j]."""
+    x = np.asarray(x, dtype=np.float64); P = np.asarray(P, dtype=np.float64)
+    init_counter += 1                                              # :256
+    z = math.exp(x[2])                                             # unproject_logz, common/project.h:80-95
+    Xc = np.array([x[0] * z, x[1] * z, z])
+    dXc_dx = np.array([[z, 0, x[0] * z], [0, z, x[1] * z], [0, 0, z]])
+    # gtot = (gsb * gbc)^-1 * ref.gsb * gbc  (:260)
+    Rsc, Tsc = Rsb @ Rbc, Rsb @ Tbc + Tsb
+    Rrc, Trc = Rsbr @ Rbc, Rsbr @ Tbc + Tsbr
+    Rtot, Ttot = Rsc.T @ Rrc, Rsc.T @ (Trc - Tsc)
+    Xcn = Rtot @ Xc + Ttot                                         # :261
+    dxcn_dXcn = np.array([[1 / Xcn[2], 0, -Xcn[0] / Xcn[2] ** 2], [0, 1 / Xcn[2], -Xcn[1] / Xcn[2] ** 2]])
+    xp, dxp_dxcn = camera_project(cam, Xcn[:2] / Xcn[2])          # :264-267
+    H = ((dxp_dxcn @ dxcn_dXcn) @ Rtot) @ dXc_dx                   # :269 (left to right)
+    inn = np.asarray(xp_meas, dtype=np.float64) - xp
+    S = H @ P @ H.T
+    S[0, 0] += Rtri; S[1, 1] += Rtri                               # :273-275
+    ratio = float(inn @ np.linalg.solve(S, inn)) / MH_thresh       # :277 (Eigen: LDLT)
+    if ratio > 1:                                                  # :279-285
+        S[0, 0] += Rtri * (ratio - 1); S[1, 1] += Rtri * (ratio - 1)
+        outlier_counter += math.sqrt(ratio)
+    else:
+        outlier_counter = 0.0
+    K = P @ H.T @ np.linalg.inv(S)                                 # :287
+    x = x + K @ inn
+    I_KH = np.eye(3) - K @ H
+    P = I_KH @ P @ I_KH.T + K * Rtri @ K.T                         # :291 (Rtri, not the inflated S)
+    status = FEAT_READY if init_counter > ready_steps else FEAT_INITIALIZING   # :293-297
+    return x, P, status, init_counter, outlier_counter
+
+
+def candidate_flags(x, status, outlier_counter, zmin=0.05, zmax=5.0, max_subfilter_outlier=0.01):
+    """(Criteria::Candidate, Criteria::CandidateStrict), src/options.cpp:10-33."""
+    zed = math.exp(x[2])                                           # Feature::z(), feature.cpp:120-126
+    ok = outlier_counter < max_subfilter_outlier and zmin < zed < zmax
+    return (status in (FEAT_READY, FEAT_INITIALIZING)) and ok, status == FEAT_READY and ok
+
+
+def feature_score(P):
+    """Feature::score(), src/feature.cpp:133-142: confidence in depth."""
+    return -float(np.asarray(P)[2, 2])
+
+
+# ----------------------------------------------------------------------------
 # a7: Estimator::OnePointRANSAC (src/update.cpp:213-393), numeric core for one filter.
 # ----------------------------------------------------------------------------
 def one_point_ransac(st, P, xp, cam, layout, R, ransac_thresh, ransac_chi2, gauge_group, instate_groups,

@@ -112,6 +112,36 @@ def main():
     w = rng.normal(size=(4, 3)) * 0.5
     g["so3_w"] = w
     g["so3_R"] = np.array([ref.so3_exp(v) for v in w])
+    # --- Feature::SubfilterUpdate (feature.cpp:246-297), 4 cameras x 3 features x 3 consecutive frames
+    #     (feature 2 gets a wild pixel in frame 1: the ratio > 1 branch)
+    rs = np.random.default_rng(2024)
+    for name, cam in cams.items():
+        sc = synth.g_level(3, 3, 3, 1, seed=31, cam=cam)
+        xs, Ps, stats, ics, ocs, xp_frames = [], [], [], [], [], []
+        x = sc["x"][0] + rs.normal(size=(3, 3)) * np.array([0.01, 0.01, 0.15])
+        g[f"sub_{name}_x0"] = x.copy()
+        P = np.array([np.diag([1e-4, 1e-4, 0.25]) for _ in range(3)])
+        ic = np.zeros(3, dtype=np.int64); oc = np.zeros(3)
+        for fr in range(3):
+            xp = np.empty((3, 2))
+            for i in range(3):
+                Xcn = sc["Xcn"][0, i]
+                xp[i] = orc.camera_project(cam, Xcn[:2] / Xcn[2])[0] + rs.normal(size=2) * 0.8
+            if fr == 1:
+                xp[2] += 25.0
+            xp_frames.append(xp)
+            st = np.zeros(3, dtype=np.int64)
+            for i in range(3):
+                r = int(sc["ref"][0, i])
+                x[i], P[i], st[i], ic[i], oc[i] = ref.subfilter_update(
+                    x[i], P[i], xp[i], sc["Rsb"][0], sc["Tsb"][0], sc["Rbc"][0], sc["Tbc"][0], sc["gR"][0, r], sc["gT"][0, r],
+                    cam, 3.5, 5.991, 1, int(ic[i]), float(oc[i]))
+            xs.append(x.copy()); Ps.append(P.copy()); stats.append(st.copy()); ics.append(ic.copy()); ocs.append(oc.copy())
+        g[f"sub_{name}_xp"] = np.array(xp_frames)
+        g[f"sub_{name}_x"] = np.array(xs); g[f"sub_{name}_P"] = np.array(Ps)
+        g[f"sub_{name}_status"] = np.array(stats); g[f"sub_{name}_ic"] = np.array(ics); g[f"sub_{name}_oc"] = np.array(ocs)
+        for k in ("Rsb", "Tsb", "Rbc", "Tbc", "gR", "gT", "ref"):
+            g[f"sub_{name}_{k}"] = sc[k][0]
     out = os.path.join(ROOT, "tests", "golden", "golden_v1.npz")
     np.savez_compressed(out, **g)
     print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")

@@ -294,3 +294,45 @@ def test_resident_frames_with_device_absorb_error(built):
             assert np.abs(cmT(group_d[b, g]["Rsb"]) - st["gR"][g]).max() < 1e-9
             assert np.abs(group_d[b, g]["Tsb"] - st["gT"][g]).max() < 1e-9
         assert np.abs(feat_d[b]["x"] - st["x"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_subfilter_update_and_candidates(built, name):
+    """SURVEY 8f.2: Feature::SubfilterUpdate + Criteria::Candidate(Strict) + Feature::score for a batch of
+    not-yet-in-state features, three consecutive frames on the device vs the oracle (golden-pinned restatement)."""
+    from xivo_amd.lib import subfilter_dtype
+    cam = CAMS[name]
+    B, ng, nfeat = 3, 4, 9
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nfeat, nfeat, B, 17, cam)
+    rng = np.random.default_rng(8)
+    sub = np.zeros((B, nfeat), dtype=subfilter_dtype)
+    x0 = sc["x"] + rng.normal(size=sc["x"].shape) * np.array([0.01, 0.01, 0.15])
+    P0 = np.diag([1e-4, 1e-4, 0.25])
+    for b in range(B):
+        for i in range(nfeat):
+            sub[b, i]["x"] = x0[b, i]; sub[b, i]["P"] = P0.T.reshape(-1); sub[b, i]["ref_sind"] = sc["ref"][b, i]
+    frames = [xp + rng.normal(size=xp.shape) * 0.8 for _ in range(3)]
+    frames[1][0, 4] += 25.0           # wild pixel: ratio > 1 branch
+    frames[2][1, 2] -= 40.0
+    ref_state = [[dict(x=x0[b, i].copy(), P=P0.copy(), ic=0, oc=0.0, st=0) for i in range(nfeat)] for b in range(B)]
+    with ctx:
+        ctx.set_scene(poses, groups, feats)
+        for fr in range(3):
+            sub["xp"] = frames[fr]
+            sub = ctx.subfilter_update(sub, ready_steps=1)
+            for b in range(B):
+                for i in range(nfeat):
+                    s = ref_state[b][i]; r = int(sc["ref"][b, i])
+                    s["x"], s["P"], s["st"], s["ic"], s["oc"] = orc.subfilter_update(
+                        s["x"], s["P"], frames[fr][b, i], sc["Rsb"][b], sc["Tsb"][b], sc["Rbc"][b], sc["Tbc"][b],
+                        sc["gR"][b, r], sc["gT"][b, r], cam, 3.5, 5.991, 1, s["ic"], s["oc"])
+                    d = sub[b, i]
+                    assert np.abs(d["x"] - s["x"]).max() < 1e-10
+                    assert rel_fro(d["P"].reshape(3, 3).T, s["P"]) < 1e-9
+                    assert d["status"] == s["st"] and d["init_counter"] == s["ic"]
+                    assert abs(d["outlier_counter"] - s["oc"]) < 1e-9 * max(1.0, s["oc"])
+                    cand, strict = orc.candidate_flags(s["x"], s["st"], s["oc"])
+                    assert d["candidate"] == (1 if cand else 0) | (2 if strict else 0)
+                    assert abs(d["score"] - orc.feature_score(s["P"])) < 1e-12
+    assert any(ref_state[b][i]["oc"] > 0 for b in range(B) for i in range(nfeat))   # the inflated-S branch ran
+    assert (sub["status"] == 1).all()

@@ -5,6 +5,7 @@
  3. committed golden vectors generated from oracle/_ref - the reference's own Eigen /
     Sophus / helpers.cpp / camera arithmetic (tests/golden/make_golden.py);
  4. live comparison against oracle/_ref when the prebuilt library is present."""
+import math
 import os
 
 import numpy as np
@@ -253,3 +254,39 @@ def test_substepping_half_step_trick():
         assert calls == [0.002, 0.001, 0.0015]
     finally:
         orc.integrator_step = real
+
+
+# ---- depth sub-filter (Feature::SubfilterUpdate, src/feature.cpp:246-297) ----
+SUB_CAMS = {"pinhole": synth.PINHOLE, "equi": synth.EQUI, "radtan": synth.RADTAN, "atan": synth.ATAN}
+
+
+@pytest.mark.parametrize("name", list(SUB_CAMS))
+def test_golden_subfilter_update(name):
+    """numpy restatement vs the Eigen/Sophus driver of the reference expression sequence: three consecutive frames,
+    three features, incl. the ratio > 1 (inflated S, outlier counter) branch and the INITIALIZING -> READY switch."""
+    cam = SUB_CAMS[name]
+    k = lambda s: G[f"sub_{name}_{s}"]
+    x = k("x0").copy(); P = np.array([np.diag([1e-4, 1e-4, 0.25]) for _ in range(3)])
+    ic = [0, 0, 0]; oc = [0.0, 0.0, 0.0]
+    saw_outlier = False
+    for fr in range(3):
+        for i in range(3):
+            r = int(k("ref")[i])
+            x[i], P[i], st, ic[i], oc[i] = orc.subfilter_update(x[i], P[i], k("xp")[fr, i], k("Rsb"), k("Tsb"), k("Rbc"), k("Tbc"),
+                                                                k("gR")[r], k("gT")[r], cam, 3.5, 5.991, 1, ic[i], oc[i])
+            assert st == k("status")[fr, i] and ic[i] == k("ic")[fr, i]
+            assert abs(oc[i] - k("oc")[fr, i]) < 1e-9 * max(1.0, oc[i])
+            saw_outlier |= oc[i] > 0
+        assert np.abs(x - k("x")[fr]).max() < 1e-11 and rel(P, k("P")[fr]) < 1e-9
+    assert saw_outlier and k("status")[0].max() == 0 and k("status")[2].min() == 1
+
+
+def test_candidate_flags_and_score():
+    """Criteria::Candidate / CandidateStrict (src/options.cpp:10-33), Feature::score (src/feature.cpp:133-142)."""
+    x = np.array([0.1, -0.2, math.log(2.0)])
+    assert orc.candidate_flags(x, orc.FEAT_INITIALIZING, 0.0) == (True, False)
+    assert orc.candidate_flags(x, orc.FEAT_READY, 0.0) == (True, True)
+    assert orc.candidate_flags(x, orc.FEAT_READY, 0.02) == (False, False)              # outlier counter too high
+    assert orc.candidate_flags(np.array([0, 0, math.log(6.0)]), orc.FEAT_READY, 0.0) == (False, False)   # beyond max_depth
+    assert orc.candidate_flags(np.array([0, 0, math.log(0.01)]), orc.FEAT_READY, 0.0) == (False, False)  # below min_depth
+    assert orc.feature_score(np.diag([1.0, 2.0, 0.3])) == -0.3

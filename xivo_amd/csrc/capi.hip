@@ -63,6 +63,8 @@ struct xivo_hip_ctx {
   xivo_oos_in* oos = nullptr;
   int oos_cap = 0;
   int* oos_rows = nullptr;
+  xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
+  size_t sub_cap = 0;
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
   std::vector<EventPair> pool;
@@ -244,7 +246,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
-                  c->mask, c->rows_instate, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.over};
+                  c->mask, c->rows_instate, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.over, c->sub};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
@@ -900,6 +902,31 @@ int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, d
   rc = xivo_hip_stack(c, B, R);
   if (rc) return rc;
   return xivo_hip_update_joseph(c, B);
+}
+
+int xivo_hip_subfilter_update(xivo_hip_ctx* c, int b0, int nb, int n, xivo_subfilter_feat* feats,
+                              const xivo_subfilter_opts* opts) {
+  if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || n <= 0 || !feats || !opts) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  for (size_t i = 0; i < (size_t)nb * n; ++i)
+    if (feats[i].ref_sind < 0 || feats[i].ref_sind >= c->lay.n_groups) return XIVO_HIP_ERR_INVALID;
+  const size_t bytes = (size_t)nb * n * sizeof(xivo_subfilter_feat);
+  if (bytes > c->sub_cap) {
+    if (c->sub) hipFree(c->sub);
+    c->sub = nullptr; c->sub_cap = 0;
+    if (hipMalloc((void**)&c->sub, bytes) != hipSuccess) return XIVO_HIP_ERR_NOMEM;
+    c->sub_cap = bytes;
+  }
+  HIP_TRY(hipMemcpyAsync(c->sub, feats, bytes, hipMemcpyHostToDevice, c->stream));
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "subfilter_kernel");
+    if (launch_subfilter(c->sub, n, c->poses + b0, c->groups + (size_t)b0 * c->lay.n_groups, c->lay.n_groups, c->cam,
+                         *opts, nb, c->stream))
+      return XIVO_HIP_ERR_HIP;
+  }
+  HIP_TRY(hipMemcpyAsync(feats, c->sub, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
 }
 
 int xivo_hip_absorb_error(xivo_hip_ctx* c, int B) {

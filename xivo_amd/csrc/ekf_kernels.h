@@ -71,6 +71,10 @@ struct StackArgs {
 };
 int launch_stack(const StackArgs& a, hipStream_t s);
 
+// Feature::SubfilterUpdate + candidate tests (feature.cpp:246-297, options.cpp:10-33)
+int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses, const xivo_group_in* groups,
+                     int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s);
+
 // AbsorbError on the resident scene (estimator.cpp:875-921)
 struct AbsorbArgs {
   xivo_pose_in* poses; xivo_group_in* groups; xivo_feat_in* feats; const unsigned char* mask;

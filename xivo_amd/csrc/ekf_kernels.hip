@@ -467,6 +467,114 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- depth sub-filter
+// One thread per (filter, feature): every product below is 3x3 / 2x3 / 2x2 and is written in the
+// reference's association order (feature.cpp:246-297).
+__global__ void subfilter_kernel(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses,
+                                 const xivo_group_in* groups, int n_groups, xivo_cam cam, xivo_subfilter_opts o,
+                                 int batch) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= batch * n) return;
+  const int filt = t / n;
+  xivo_subfilter_feat& f = feats[t];
+  const xivo_pose_in& pose = poses[filt];
+  const xivo_group_in& grp = groups[(long)filt * n_groups + f.ref_sind];
+  const M3 Rsb = m3_from_colmajor(pose.Rsb), Rbc = m3_from_colmajor(pose.Rbc), Rsbr = m3_from_colmajor(grp.Rsb);
+  const V3 Tsb{{pose.Tsb[0], pose.Tsb[1], pose.Tsb[2]}}, Tbc{{pose.Tbc[0], pose.Tbc[1], pose.Tbc[2]}};
+  const V3 Tsbr{{grp.Tsb[0], grp.Tsb[1], grp.Tsb[2]}};
+  const int init_counter = f.init_counter + 1;                                   // :256
+  // Xc(&dXc_dx): unproject_logz (project.h:80-95)
+  const double z = exp(f.x[2]);
+  const V3 Xc{{f.x[0] * z, f.x[1] * z, z}};
+  M3 dXc_dx;
+  dXc_dx.m[0][0] = z; dXc_dx.m[0][1] = 0; dXc_dx.m[0][2] = f.x[0] * z;
+  dXc_dx.m[1][0] = 0; dXc_dx.m[1][1] = z; dXc_dx.m[1][2] = f.x[1] * z;
+  dXc_dx.m[2][0] = 0; dXc_dx.m[2][1] = 0; dXc_dx.m[2][2] = z;
+  // gtot = (gsb * gbc)^-1 * ref.gsb * gbc   (:260)
+  const M3 Rsc = m3_mul(Rsb, Rbc), Rrc = m3_mul(Rsbr, Rbc);
+  V3 Tsc = m3_mulv(Rsb, Tbc), Trc = m3_mulv(Rsbr, Tbc);
+  V3 dT;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { Tsc.v[i] += Tsb.v[i]; Trc.v[i] += Tsbr.v[i]; dT.v[i] = Trc.v[i] - Tsc.v[i]; }
+  const M3 Rsc_t = m3_t(Rsc);
+  const M3 Rtot = m3_mul(Rsc_t, Rrc);
+  const V3 Ttot = m3_mulv(Rsc_t, dT);
+  V3 Xcn = m3_mulv(Rtot, Xc);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Xcn.v[i] += Ttot.v[i];                              // :261
+  double xp[2], dxp_dXcn[2][3];
+  project_pixel(cam, Xcn, xp, dxp_dXcn);                                          // :263-267 (dxp_dxcn * dxcn_dXcn)
+  double tmp[2][3], H[2][3];
+  m23_mul(dxp_dXcn, Rtot, tmp);
+  m23_mul(tmp, dXc_dx, H);                                                        // :269
+  const double inn0 = f.xp[0] - xp[0], inn1 = f.xp[1] - xp[1];
+  M3 P = m3_from_colmajor(f.P);
+  // S = H P H^T + Rtri I  (:272-275)
+  double HPm[2][3];
+  m23_mul(H, P, HPm);
+  double S[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) S[i][j] = HPm[i][0] * H[j][0] + HPm[i][1] * H[j][1] + HPm[i][2] * H[j][2];
+  S[0][0] += o.Rtri; S[1][1] += o.Rtri;
+  // ratio = inn . S^-1 inn / MH_thresh  (:277; 2x2 LDL^T without the pivot search, same value to rounding)
+  double outlier = f.outlier_counter;
+  {
+    const double l10 = S[1][0] / S[0][0], d1 = S[1][1] - l10 * S[0][1];
+    const double y1 = inn1 - l10 * inn0;
+    const double s1 = y1 / d1, s0 = (inn0 - S[0][1] * s1) / S[0][0];
+    const double ratio = (inn0 * s0 + inn1 * s1) / o.MH_thresh;
+    if (ratio > 1) {                                                              // :279-285
+      S[0][0] += o.Rtri * (ratio - 1); S[1][1] += o.Rtri * (ratio - 1);
+      outlier += sqrt(ratio);
+    } else {
+      outlier = 0.0;
+    }
+  }
+  // K = P H^T S^-1 (:287; Eigen's 2x2 inverse = adjugate / determinant)
+  const double det = S[0][0] * S[1][1] - S[0][1] * S[1][0], idet = 1.0 / det;
+  const double Si[2][2] = {{S[1][1] * idet, -S[0][1] * idet}, {-S[1][0] * idet, S[0][0] * idet}};
+  double PHt[3][2], K[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) PHt[i][j] = P.m[i][0] * H[j][0] + P.m[i][1] * H[j][1] + P.m[i][2] * H[j][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) K[i][j] = PHt[i][0] * Si[0][j] + PHt[i][1] * Si[1][j];
+  double xn[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xn[i] = f.x[i] + (K[i][0] * inn0 + K[i][1] * inn1);   // :289
+  M3 A;                                                                           // I - K H (:290)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) A.m[i][j] = (i == j ? 1.0 : 0.0) - (K[i][0] * H[0][j] + K[i][1] * H[1][j]);
+  const M3 AP = m3_mul(A, P);
+  M3 Pn;                                                                          // :291
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      Pn.m[i][j] = (AP.m[i][0] * A.m[j][0] + AP.m[i][1] * A.m[j][1] + AP.m[i][2] * A.m[j][2]) +
+                   ((K[i][0] * o.Rtri) * K[j][0] + (K[i][1] * o.Rtri) * K[j][1]);
+  const int status = init_counter > o.ready_steps ? XIVO_FEAT_READY : XIVO_FEAT_INITIALIZING;   // :293-297
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f.x[i] = xn[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) f.P[i + 3 * j] = Pn.m[i][j];
+  }
+  f.outlier_counter = outlier; f.init_counter = init_counter; f.status = status;
+  // Criteria::Candidate / CandidateStrict (options.cpp:10-33), Feature::score (feature.cpp:133-142)
+  const double zed = exp(xn[2]);
+  const bool ok = outlier < o.max_subfilter_outlier && zed > o.min_depth && zed < o.max_depth;
+  f.candidate = (ok ? 1 : 0) | ((ok && status == XIVO_FEAT_READY) ? 2 : 0);
+  f.score = -Pn.m[2][2];
+}
+
 // ---------------------------------------------------------------- AbsorbError
 // SO3::exp (Rodrigues), as SO3_from_rotvec (src/helpers.cpp:374-378)
 __device__ __forceinline__ M3 so3_exp_dev(double wx, double wy, double wz) {
@@ -774,6 +882,14 @@ int launch_gate_sparse(const GateArgs& a, hipStream_t s) {
 }
 int launch_stack(const StackArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(stack_kernel, dim3(a.batch), dim3(256), 0, s, a);
+  CHECK_LAUNCH();
+}
+int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses, const xivo_group_in* groups,
+                     int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s) {
+  const int tot = batch * n;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(subfilter_kernel, dim3((tot + 127) / 128), dim3(128), 0, s, feats, n, poses, groups, n_groups, cam,
+                     o, batch);
   CHECK_LAUNCH();
 }
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s) {

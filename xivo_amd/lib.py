@@ -50,6 +50,11 @@ class _OosC(C.Structure):
 
 
 assert oos_dtype.itemsize == C.sizeof(_OosC), (oos_dtype.itemsize, C.sizeof(_OosC))
+subfilter_dtype = np.dtype([("x", "f8", 3), ("P", "f8", 9), ("xp", "f8", 2), ("outlier_counter", "f8"), ("score", "f8"),
+                            ("ref_sind", "i4"), ("status", "i4"), ("init_counter", "i4"), ("candidate", "i4")])
+subfilter_opts_dtype = np.dtype([("Rtri", "f8"), ("MH_thresh", "f8"), ("ready_steps", "i4"), ("_pad", "i4"),
+                                 ("min_depth", "f8"), ("max_depth", "f8"), ("max_subfilter_outlier", "f8")])
+assert subfilter_dtype.itemsize == 144 and subfilter_opts_dtype.itemsize == 48
 assert feat_dtype.itemsize == 48 and pose_dtype.itemsize == 336 and group_dtype.itemsize == 96
 
 
@@ -93,6 +98,7 @@ _SIGS = {
     "xivo_hip_stage_kernel": [C.c_void_p, C.c_int],
     "xivo_hip_stage_bytes": [C.c_void_p, C.c_int],
     "xivo_hip_absorb_error": [C.c_void_p, C.c_int],
+    "xivo_hip_subfilter_update": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_propagate_cov": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
@@ -323,6 +329,17 @@ class Context:
     def last_path(self):
         """0: dense as-coded pipeline, 1: sparse-H (row-pair compressed) pipeline."""
         return int(self.lib.xivo_hip_last_path(self.h))
+
+    def subfilter_update(self, feats, Rtri=3.5, MH_thresh=5.991, ready_steps=5, min_depth=0.05, max_depth=5.0,
+                         max_subfilter_outlier=0.01, b0=0):
+        """feats: [nb, n] array of subfilter_dtype (P column-major); returns the updated copy."""
+        feats = np.ascontiguousarray(feats, dtype=subfilter_dtype).copy()
+        nb, n = feats.shape
+        o = np.zeros(1, dtype=subfilter_opts_dtype)
+        o["Rtri"], o["MH_thresh"], o["ready_steps"] = Rtri, MH_thresh, ready_steps
+        o["min_depth"], o["max_depth"], o["max_subfilter_outlier"] = min_depth, max_depth, max_subfilter_outlier
+        self._check(self.lib.xivo_hip_subfilter_update(self.h, b0, nb, n, _ptr(feats), _ptr(o)))
+        return feats
 
     def absorb_error(self, B=None):
         self._check(self.lib.xivo_hip_absorb_error(self.h, self.batch if B is None else B))
