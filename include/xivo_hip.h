@@ -251,6 +251,18 @@ typedef struct {
 int xivo_hip_subfilter_update(xivo_hip_ctx* ctx, int b0, int nb, int n, xivo_subfilter_feat* feats,
                               const xivo_subfilter_opts* opts);
 
+/* ---- orthonormal Givens elimination and QR measurement compression ----
+ * Batched xivo::Givens (src/helpers.cpp:48-75) and xivo::QR (src/helpers.cpp:78-101) on host arrays, nb
+ * independent problems of identical shape, column-major, leading dimension = rows.
+ *  Givens: eliminates Hf [rows x nf] with the rotations of G&VL Alg. 5.1.3 (the reference's givens(), eps guard
+ *          1e-4f), rotates x and - as the reference codes it, helpers.cpp:64 - only the first nf columns of
+ *          Hx [rows x nx]; then strips the first nf rows. rows_out[b] = rows - nf.
+ *  QR:     triangularises Hx [rows x nx] (all columns rotated), rotates x; rows_out[b] = rows (the caller keeps
+ *          the top block). effective_rows = -1: all rows. */
+int xivo_hip_givens(xivo_hip_ctx* ctx, int nb, int rows, int nx, int nf, double* x, double* Hx, double* Hf,
+                    int effective_rows, int* rows_out);
+int xivo_hip_qr(xivo_hip_ctx* ctx, int nb, int rows, int nx, double* x, double* Hx, int effective_rows, int* rows_out);
+
 /* Estimator::AbsorbError (src/estimator.cpp:875-921) on the device-resident nominal state of filters
  * [0,B): X += dx via State::operator+= (src/core.h:135-165: SO3 exp on Rsb, Rbc, Rsg), every group slot
  * += dx segment (src/group.h:25-29), every feature that was an inlier of the last gating / stacking pass

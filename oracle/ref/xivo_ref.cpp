@@ -197,6 +197,15 @@ int ref_Givens(int R, int N, double* x, double* Hx, double* Hf, int effective_ro
   return rows;
 }
 
+// xivo::QR (src/helpers.cpp:78-101)
+int ref_QR(int R, int N, double* x, double* Hx, int effective_rows) {
+  VecX x_ = MapVec(x, R);
+  MatX Hx_ = MapMat(Hx, R, N);
+  int rows = QR(x_, Hx_, effective_rows);
+  (MapVecW(x, R)) = x_; (MapMatW(Hx, R, N)) = Hx_;
+  return rows;
+}
+
 // Eigen::FullPivLU<MatX>(A).kernel() for an r x c matrix; returns kernel columns
 int ref_fullpivlu_kernel(int r, int c, const double* A, double* ker_out, int* rank_out) {
   MatX A_ = MapMat(A, r, c);

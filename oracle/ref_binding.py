@@ -134,6 +134,12 @@ class Ref:
         rows = self.lib.ref_Givens(C.c_int(R), C.c_int(N), _p(xf), _p(Hxf), _p(Hff), C.c_int(effective_rows))
         return rows, xf, np.ascontiguousarray(Hxf), np.ascontiguousarray(Hff)
 
+    def QR(self, x, Hx, effective_rows=-1):
+        R, N = Hx.shape
+        xf = np.ascontiguousarray(x, dtype=np.float64).copy(); Hxf = _F(Hx).copy(order="F")
+        rows = self.lib.ref_QR(C.c_int(R), C.c_int(N), _p(xf), _p(Hxf), C.c_int(effective_rows))
+        return rows, xf, np.ascontiguousarray(Hxf)
+
     def fullpivlu_kernel(self, A):
         r, c = A.shape
         ker = np.empty((c, c), order="F"); rank = C.c_int()

@@ -395,6 +395,20 @@ def givens_eliminate(x, Hx, Hf, effective_rows=-1):
     return rows - cols, x, Hx, Hf
 
 
+def qr_compress(x, Hx, effective_rows=-1):
+    """xivo::QR (src/helpers.cpp:78-101): Givens triangularisation of the first `rows` rows of Hx (all columns
+    rotated, unlike Givens above), residual rotated along; returns (rows, x, Hx) - the caller keeps the top block."""
+    x = x.copy(); Hx = Hx.copy()
+    rows = Hx.shape[0] if effective_rows == -1 else effective_rows
+    cols = Hx.shape[1]
+    for c in range(cols):
+        for r in range(rows - 2, c - 1, -1):
+            Gt = givens(Hx[r, c], Hx[r + 1, c]).T
+            Hx[r:r + 2, :] = Gt @ Hx[r:r + 2, :]
+            x[r:r + 2] = Gt @ x[r:r + 2]
+    return rows, x, Hx
+
+
 # ----------------------------------------------------------------------------
 # a8/a9: Feature::ComputeOOSJacobian(+Internal) (src/oos.cpp:8-89)
 # ----------------------------------------------------------------------------

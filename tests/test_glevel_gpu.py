@@ -336,3 +336,35 @@ def test_subfilter_update_and_candidates(built, name):
                     assert abs(d["score"] - orc.feature_score(s["P"])) < 1e-12
     assert any(ref_state[b][i]["oc"] > 0 for b in range(B) for i in range(nfeat))   # the inflated-S branch ran
     assert (sub["status"] == 1).all()
+
+
+@pytest.mark.parametrize("rows,nx,eff", [(8, 60, -1), (32, 107, -1), (20, 60, 14), (6, 3, -1)])
+def test_device_givens_matches_reference_semantics(built, rows, nx, eff):
+    """xivo::Givens (src/helpers.cpp:48-75) batched on the device, including what the reference actually codes:
+    only the first 3 columns of Hx are rotated (helpers.cpp:64) and the first 3 rows are stripped."""
+    rng = np.random.default_rng(rows + nx)
+    nb = 5
+    x = rng.normal(size=(nb, rows)); Hx = rng.normal(size=(nb, rows, nx)); Hf = rng.normal(size=(nb, rows, 3))
+    Hf[1, 3, 0] = 0.0; Hf[1, 4, 0] = 1e-6        # |b| < eps branch of givens()
+    with Context(8, 2, 1) as ctx:
+        ro, xd, Hxd, Hfd = ctx.givens(x, Hx, Hf, eff)
+    for b in range(nb):
+        r, xo, Hxo, Hfo = orc.givens_eliminate(x[b], Hx[b], Hf[b], eff)
+        assert ro[b] == r
+        assert np.abs(xd[b] - xo).max() < 1e-12 and np.abs(Hxd[b] - Hxo).max() < 1e-12 and np.abs(Hfd[b] - Hfo).max() < 1e-12
+
+
+@pytest.mark.parametrize("rows,nx,eff", [(12, 5, -1), (40, 21, -1), (200, 130, -1), (90, 70, 80)])
+def test_device_qr_compression(built, rows, nx, eff):
+    """xivo::QR (src/helpers.cpp:78-101): measurement compression, all columns rotated; nx > 64 exercises the
+    multi-chunk column ownership."""
+    rng = np.random.default_rng(rows * 7 + nx)
+    nb = 3
+    x = rng.normal(size=(nb, rows)); Hx = rng.normal(size=(nb, rows, nx))
+    with Context(8, 2, 1) as ctx:
+        ro, xd, Hxd = ctx.qr(x, Hx, eff)
+    for b in range(nb):
+        r, xo, Hxo = orc.qr_compress(x[b], Hx[b], eff)
+        assert ro[b] == r
+        assert np.abs(xd[b] - xo).max() < 1e-10 and np.abs(Hxd[b] - Hxo).max() < 1e-10
+        assert np.abs(np.tril(Hxd[b][:r], -1)).max() < 1e-10

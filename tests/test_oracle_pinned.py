@@ -290,3 +290,18 @@ def test_candidate_flags_and_score():
     assert orc.candidate_flags(np.array([0, 0, math.log(6.0)]), orc.FEAT_READY, 0.0) == (False, False)   # beyond max_depth
     assert orc.candidate_flags(np.array([0, 0, math.log(0.01)]), orc.FEAT_READY, 0.0) == (False, False)  # below min_depth
     assert orc.feature_score(np.diag([1.0, 2.0, 0.3])) == -0.3
+
+
+@pytest.mark.parametrize("rows,cols,eff", [(12, 5, -1), (40, 21, -1), (30, 7, 20)])
+def test_live_qr_compress_vs_ref(rows, cols, eff):
+    """xivo::QR (src/helpers.cpp:78-101) of the reference itself (helpers.cpp compiled verbatim) vs the restatement;
+    the result is upper-trapezoidal and the rotations are orthonormal (norms preserved)."""
+    rng = np.random.default_rng(rows * 100 + cols)
+    x = rng.normal(size=rows); Hx = rng.normal(size=(rows, cols))
+    r0, x0, H0 = _ref().QR(x, Hx, eff)
+    r1, x1, H1 = orc.qr_compress(x, Hx, eff)
+    assert r0 == r1 == (rows if eff == -1 else eff)
+    assert np.abs(x0 - x1).max() < 1e-12 and np.abs(H0 - H1).max() < 1e-12
+    n = r1
+    assert np.abs(np.tril(H1[:n], -1)).max() < 1e-12
+    assert abs(np.linalg.norm(H1[:n]) - np.linalg.norm(Hx[:n])) < 1e-10 and abs(np.linalg.norm(x1[:n]) - np.linalg.norm(x[:n])) < 1e-10

@@ -904,6 +904,44 @@ int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, d
   return xivo_hip_update_joseph(c, B);
 }
 
+static int givens_impl(xivo_hip_ctx* c, int nb, int rows, int nx, int nf, double* x, double* Hx, double* Hf,
+                       int effective_rows, int* rows_out, int qr) {
+  if (!c || nb <= 0 || rows < 2 || nx <= 0 || !x || !Hx || (!qr && (!Hf || nf <= 0 || nf > 64)) || (qr && nx > 512))
+    return XIVO_HIP_ERR_INVALID;
+  const int eff = effective_rows < 0 ? rows : effective_rows;
+  // the reference CHECKs these (helpers.cpp:49-53, 79-84); here they are an error code
+  if (eff > rows || eff < 2 || (qr ? eff <= nx : eff < nf)) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t ex = (size_t)nb * rows, ehx = (size_t)nb * rows * nx, ehf = qr ? 0 : (size_t)nb * rows * nf;
+  int rc = ensure_staging(c, ex + ehx + ehf);
+  if (rc) return rc;
+  double* dx = c->staging; double* dHx = dx + ex; double* dHf = dHx + ehx;
+  HIP_TRY(hipMemcpyAsync(dx, x, ex * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(dHx, Hx, ehx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (!qr) HIP_TRY(hipMemcpyAsync(dHf, Hf, ehf * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  GivensArgs a; a.x = dx; a.Hx = dHx; a.Hf = qr ? nullptr : dHf; a.rows = rows; a.nx = nx; a.nf = nf; a.eff = effective_rows;
+  a.batch = nb; a.qr = qr;
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "givens_kernel");
+    if (launch_givens(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  HIP_TRY(hipMemcpyAsync(x, dx, ex * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(Hx, dHx, ehx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (!qr) HIP_TRY(hipMemcpyAsync(Hf, dHf, ehf * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (rows_out) for (int b = 0; b < nb; ++b) rows_out[b] = qr ? eff : eff - nf;
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_givens(xivo_hip_ctx* c, int nb, int rows, int nx, int nf, double* x, double* Hx, double* Hf,
+                    int effective_rows, int* rows_out) {
+  return givens_impl(c, nb, rows, nx, nf, x, Hx, Hf, effective_rows, rows_out, 0);
+}
+
+int xivo_hip_qr(xivo_hip_ctx* c, int nb, int rows, int nx, double* x, double* Hx, int effective_rows, int* rows_out) {
+  return givens_impl(c, nb, rows, nx, 0, x, Hx, nullptr, effective_rows, rows_out, 1);
+}
+
 int xivo_hip_subfilter_update(xivo_hip_ctx* c, int b0, int nb, int n, xivo_subfilter_feat* feats,
                               const xivo_subfilter_opts* opts) {
   if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || n <= 0 || !feats || !opts) return XIVO_HIP_ERR_INVALID;

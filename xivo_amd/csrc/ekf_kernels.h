@@ -75,6 +75,13 @@ int launch_stack(const StackArgs& a, hipStream_t s);
 int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses, const xivo_group_in* groups,
                      int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s);
 
+// xivo::Givens / xivo::QR (helpers.cpp:27-101), one wave per problem, in place
+struct GivensArgs {
+  double* x; double* Hx; double* Hf;   // per problem: x [rows], Hx [rows x nx], Hf [rows x nf] (null for QR)
+  int rows, nx, nf, eff, batch, qr;
+};
+int launch_givens(const GivensArgs& a, hipStream_t s);
+
 // AbsorbError on the resident scene (estimator.cpp:875-921)
 struct AbsorbArgs {
   xivo_pose_in* poses; xivo_group_in* groups; xivo_feat_in* feats; const unsigned char* mask;

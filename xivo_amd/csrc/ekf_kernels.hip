@@ -575,6 +575,82 @@ __global__ void subfilter_kernel(xivo_subfilter_feat* feats, int n, const xivo_p
   f.score = -Pn.m[2][2];
 }
 
+// ---------------------------------------------------------------- Givens / QR
+// givens(a, b), helpers.cpp:27-46 (G&VL Alg. 5.1.3; eps = 1e-4f, common/alias.h:80): G = [c s; -s c]
+__device__ __forceinline__ void givens_cs(double a, double b, double& c, double& s) {
+  const double eps = (double)1e-4f;
+  if (fabs(b) < eps) { c = 1.0; s = 0.0; return; }
+  if (fabs(b) > fabs(a)) { const double t = -a / b; s = 1.0 / sqrt(1.0 + t * t); c = s * t; }
+  else { const double t = -b / a; c = 1.0 / sqrt(1.0 + t * t); s = c * t; }
+}
+
+// One wave per problem. The rotations of one column sweep run bottom-up and each touches rows (r, r+1): every
+// lane owns the matrix columns j = lane (mod 64) and carries the current row r+1 of its columns in registers,
+// so within a sweep each element is loaded once and stored once, and the pivot pair (a, b) of the sweep's
+// column comes from its owner lane by a shuffle - no lane ever reads what another lane wrote.
+//   qr = 0  xivo::Givens: pivots from Hf [rows x nf]; rotated: Hf (all nf columns), Hx (only its first nf
+//           columns - helpers.cpp:64 as coded), x; then rows 0.. are replaced by rows nf.. (helpers.cpp:69-73)
+//   qr = 1  xivo::QR: pivots from Hx; rotated: Hx (all nx columns), x (helpers.cpp:78-101)
+__global__ __launch_bounds__(64) void givens_kernel(GivensArgs a) {
+  constexpr int MAXC = 8;                                  // column chunks of 64: nx <= 512 for QR
+  const int prob = blockIdx.x, lane = threadIdx.x;
+  double* x = a.x + (long)prob * a.rows;
+  double* Hx = a.Hx + (long)prob * a.rows * a.nx;
+  double* P = a.qr ? Hx : a.Hf + (long)prob * a.rows * a.nf;   // pivot matrix
+  const int pc = a.qr ? a.nx : a.nf;                            // pivot / elimination columns
+  const int rows = a.eff < 0 ? a.rows : a.eff;
+  const long ld = a.rows;
+  const int nchunk = (pc + 63) / 64;
+  for (int c = 0; c < pc && c < rows - 1; ++c) {
+    const int owner = c & 63, och = c >> 6;
+    // carries: row r+1 of the columns this lane owns, in the pivot matrix and (Givens) in Hx, and of x
+    double cp[MAXC], chx = 0.0, cx = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) { const int j = lane + 64 * q; cp[q] = (q < nchunk && j < pc) ? P[(rows - 1) + ld * j] : 0.0; }
+    if (!a.qr && lane < a.nf && lane < a.nx) chx = Hx[(rows - 1) + ld * lane];
+    if (lane == 0) cx = x[rows - 1];
+    for (int r = rows - 2; r >= c; --r) {
+      double pa = 0.0, pb = 0.0;
+#pragma unroll
+      for (int q = 0; q < MAXC; ++q) if (q == och) { pa = P[r + ld * c]; pb = cp[q]; }   // meaningful on the owner lane only
+      pa = __shfl(pa, owner); pb = __shfl(pb, owner);
+      double cs, sn;
+      givens_cs(pa, pb, cs, sn);
+      // Gt = givens(a, b)^T = [c -s; s c]:  row_r <- c row_r - s row_r+1 ;  row_r+1 <- s row_r + c row_r+1
+#pragma unroll
+      for (int q = 0; q < MAXC; ++q) {
+        const int j = lane + 64 * q;
+        if (q < nchunk && j < pc) {
+          const double top = P[r + ld * j], bot = cp[q];
+          P[(r + 1) + ld * j] = sn * top + cs * bot;
+          cp[q] = cs * top - sn * bot;
+        }
+      }
+      if (!a.qr && lane < a.nf && lane < a.nx) {
+        const double top = Hx[r + ld * lane], bot = chx;
+        Hx[(r + 1) + ld * lane] = sn * top + cs * bot;
+        chx = cs * top - sn * bot;
+      }
+      if (lane == 0) {
+        const double top = x[r], bot = cx;
+        x[r + 1] = sn * top + cs * bot;
+        cx = cs * top - sn * bot;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) { const int j = lane + 64 * q; if (q < nchunk && j < pc) P[c + ld * j] = cp[q]; }
+    if (!a.qr && lane < a.nf && lane < a.nx) Hx[c + ld * lane] = chx;
+    if (lane == 0) x[c] = cx;
+  }
+  if (!a.qr) {   // strip the first nf rows (helpers.cpp:69-73); increasing r reads rows not yet overwritten
+    for (int r = 0; r < rows - a.nf; ++r) {
+      for (int j = lane; j < a.nx; j += 64) Hx[r + ld * j] = Hx[(r + a.nf) + ld * j];
+      if (lane < a.nf) P[r + ld * lane] = P[(r + a.nf) + ld * lane];
+      if (lane == 0) x[r] = x[r + a.nf];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- AbsorbError
 // SO3::exp (Rodrigues), as SO3_from_rotvec (src/helpers.cpp:374-378)
 __device__ __forceinline__ M3 so3_exp_dev(double wx, double wy, double wz) {
@@ -890,6 +966,11 @@ int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* pose
   if (tot <= 0) return 0;
   hipLaunchKernelGGL(subfilter_kernel, dim3((tot + 127) / 128), dim3(128), 0, s, feats, n, poses, groups, n_groups, cam,
                      o, batch);
+  CHECK_LAUNCH();
+}
+int launch_givens(const GivensArgs& a, hipStream_t s) {
+  if (a.batch <= 0) return 0;
+  hipLaunchKernelGGL(givens_kernel, dim3(a.batch), dim3(64), 0, s, a);
   CHECK_LAUNCH();
 }
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s) {

@@ -98,6 +98,9 @@ _SIGS = {
     "xivo_hip_stage_kernel": [C.c_void_p, C.c_int],
     "xivo_hip_stage_bytes": [C.c_void_p, C.c_int],
     "xivo_hip_absorb_error": [C.c_void_p, C.c_int],
+    "xivo_hip_givens": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                        C.c_void_p],
+    "xivo_hip_qr": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "xivo_hip_subfilter_update": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
@@ -340,6 +343,26 @@ class Context:
         o["min_depth"], o["max_depth"], o["max_subfilter_outlier"] = min_depth, max_depth, max_subfilter_outlier
         self._check(self.lib.xivo_hip_subfilter_update(self.h, b0, nb, n, _ptr(feats), _ptr(o)))
         return feats
+
+    def givens(self, x, Hx, Hf, effective_rows=-1):
+        """Batched xivo::Givens. x [nb, rows], Hx [nb, rows, nx], Hf [nb, rows, nf] (row-major numpy views of the
+        matrices); returns (rows_out, x, Hx, Hf)."""
+        nb, rows, nx = Hx.shape
+        nf = Hf.shape[2]
+        xd = np.ascontiguousarray(x, dtype=np.float64).copy()
+        Hxd = np.ascontiguousarray(np.transpose(Hx, (0, 2, 1)), dtype=np.float64).copy()   # column-major per problem
+        Hfd = np.ascontiguousarray(np.transpose(Hf, (0, 2, 1)), dtype=np.float64).copy()
+        ro = np.zeros(nb, dtype=np.int32)
+        self._check(self.lib.xivo_hip_givens(self.h, nb, rows, nx, nf, _ptr(xd), _ptr(Hxd), _ptr(Hfd), effective_rows, _ptr(ro)))
+        return ro, xd, np.transpose(Hxd, (0, 2, 1)).copy(), np.transpose(Hfd, (0, 2, 1)).copy()
+
+    def qr(self, x, Hx, effective_rows=-1):
+        nb, rows, nx = Hx.shape
+        xd = np.ascontiguousarray(x, dtype=np.float64).copy()
+        Hxd = np.ascontiguousarray(np.transpose(Hx, (0, 2, 1)), dtype=np.float64).copy()
+        ro = np.zeros(nb, dtype=np.int32)
+        self._check(self.lib.xivo_hip_qr(self.h, nb, rows, nx, _ptr(xd), _ptr(Hxd), effective_rows, _ptr(ro)))
+        return ro, xd, np.transpose(Hxd, (0, 2, 1)).copy()
 
     def absorb_error(self, B=None):
         self._check(self.lib.xivo_hip_absorb_error(self.h, self.batch if B is None else B))
