@@ -39,7 +39,7 @@ struct xivo_hip_ctx {
   int* status = nullptr;
   // row-pair compressed H (ell.h) + host mirror of the per-filter "does not fit" flag
   EllBuffers ell{};
-  std::vector<int> ell_over_h, ell_nc_h;
+  std::vector<int> ell_over_h, ell_nc_h, ell_pw_h;
   int last_path = 0;
   // dense H / H^T of the stacked rows: written eagerly by set_measurements, lazily after xivo_hip_stack
   bool dense_valid = true;
@@ -246,7 +246,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
-                  c->mask, c->rows_instate, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.over, c->sub};
+                  c->mask, c->rows_instate, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
@@ -279,8 +279,8 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   A(&c->invD, B * c->sInvD); A(&c->inn, B * Mp); A(&c->diagR, B * Mp); A(&c->err, B * Np);
   A(&c->status, B); A(&c->scratch, B * Np);
   c->ell.pairs_max = (int)(Mp / 2);
-  A(&c->ell.idx, B * c->ell.stride_idx()); A(&c->ell.val, B * c->ell.stride_val()); A(&c->ell.nc, B); A(&c->ell.over, B);
-  c->ell_over_h.assign(B, 1); c->ell_nc_h.assign(B, ELL_CW);
+  A(&c->ell.idx, B * c->ell.stride_idx()); A(&c->ell.val, B * c->ell.stride_val()); A(&c->ell.nc, B); A(&c->ell.pw, B); A(&c->ell.over, B);
+  c->ell_over_h.assign(B, 1); c->ell_nc_h.assign(B, ELL_CW); c->ell_pw_h.assign(B, ELL_PW);
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t0) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t1) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc != XIVO_HIP_OK) { xivo_hip_destroy(c); return rc; }
@@ -404,10 +404,11 @@ int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   if (launch_unpack_meas(sH, sInn, sR, mb, M, c->Mpmax, N, c->Np, nb, c->stream)) return XIVO_HIP_ERR_HIP;
   {  // row-pair compressed form of the same rows + which filters fit it
     EllBuffers e = c->ell;
-    e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.over += b0;
+    e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.pw += b0; e.over += b0;
     if (launch_ell_build(mb.HT, mb.strideHT, mb.ldht, c->Np, c->Mpmax, e, nb, c->stream)) return XIVO_HIP_ERR_HIP;
     HIP_TRY(hipMemcpyAsync(c->ell_over_h.data() + b0, e.over, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(c->ell_nc_h.data() + b0, e.nc, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ell_pw_h.data() + b0, e.pw, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return XIVO_HIP_OK;
@@ -440,14 +441,16 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0;
   const int f32 = 0;
   EllBuffers e = c->ell;
-  e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.over += b0;
+  e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.pw += b0; e.over += b0;
   int nc_max = 0;
   for (int b = b0; b < b0 + B; ++b) nc_max = c->ell_nc_h[b] > nc_max ? c->ell_nc_h[b] : nc_max;
+  int pw_max = 1;
+  for (int b = b0; b < b0 + B; ++b) pw_max = c->ell_pw_h[b] > pw_max ? c->ell_pw_h[b] : pw_max;
   const double nnz_flops = 2.0 * Mp * 21.0;   // per contiguous-index value: 21 structural non-zeros per row
   int rc;
   {
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
-    a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.cols = Np;
+    a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
     char label[64]; ell_kernel_label(ELL_HP, a, label, sizeof(label));
     StageTimer st(c, ST_HP, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
     if (launch_ell_mul(ELL_HP, a, c->stream)) return XIVO_HIP_ERR_HIP;
@@ -467,7 +470,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {
     EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
-    a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max;
+    a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max;
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
     StageTimer st(c, ST_S, nnz_flops * Mp * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     if (launch_ell_mul(ELL_S, a, c->stream)) return XIVO_HIP_ERR_HIP;
@@ -499,7 +502,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   {  // G = T H^T + K diag(R)   [Np x Mp, in the A buffer]
     EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sA; a.ldo = Np;
-    a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.cols = Np;
+    a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
     char label[64]; ell_kernel_label(ELL_G, a, label, sizeof(label));
     StageTimer st(c, ST_KH, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + 2.0 * Np * Mp));
     if (launch_ell_mul(ELL_G, a, c->stream)) return XIVO_HIP_ERR_HIP;
@@ -842,7 +845,10 @@ static int ensure_dense(xivo_hip_ctx* c) {
 int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
-  for (int b = 0; b < B; ++b) { c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12; }
+  for (int b = 0; b < B; ++b) {
+    c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12;
+    c->ell_pw_h[b] = (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK) ? 9 : 6;   // group block(s) + feature block
+  }
   // the sparse-H pipeline reads only the compressed rows: skip the 2 x Mp x Np dense zero-fill + scatter
   const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
   c->dense_valid = dense != 0; c->stack_R = R; c->stack_B = B;

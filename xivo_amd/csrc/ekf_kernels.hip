@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   // group and feature blocks the private ones (ell.h)
   int* eidx = a.ell.idx + (long)filt * a.ell.stride_idx();
   double* eval = a.ell.val + (long)filt * a.ell.stride_val();
-  if (tid == 0) { a.ell.nc[filt] = 12; a.ell.over[filt] = 0; }
+  if (tid == 0) { a.ell.nc[filt] = 12; a.ell.over[filt] = 0; a.ell.pw[filt] = a.fix_group_block ? 9 : 6; }
   for (int p = tid; p < a.Mp / 2; p += 256) {
     int* pi = eidx + (long)p * ELL_W;
     double* pv = eval + (long)p * ELL_W * 2;

@@ -26,6 +26,7 @@ struct EllBuffers {
   int* idx;        // [batch][pairs_max][ELL_W]
   double* val;     // [batch][pairs_max][ELL_W][2]
   int* nc;         // [batch] number of common slots in use
+  int* pw;         // [batch] largest number of private slots any pair uses
   int* over;       // [batch] 1: does not fit
   int pairs_max;   // Mpmax / 2
   __host__ __device__ long stride_idx() const { return (long)pairs_max * ELL_W; }
@@ -57,6 +58,7 @@ struct EllMulArgs {
   int slabs_per_wg; // set by the launcher (slab form): consecutive slabs one workgroup streams
   int rb_per_wg; // set by the launcher: 16-row blocks one workgroup walks
   int nc_max;   // upper bound of nc over the filters of the launch (host mirror)
+  int pw_max;   // upper bound of pw (0 = unknown -> ELL_PW)
   int batch;
 };
 int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s);

@@ -22,10 +22,10 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const double* __restrict
   int* occ = sh;
   int* nonempty = sh + Np;
   __shared__ int ccols[ELL_CW];
-  __shared__ int s_nc, s_ne;
+  __shared__ int s_nc, s_ne, s_pw;
   const double* HT = HTall + (long)filt * strideHT;
   for (int p = tid; p < pairs; p += 256) nonempty[p] = 0;
-  if (tid == 0) { e.over[filt] = 0; s_ne = 0; }
+  if (tid == 0) { e.over[filt] = 0; s_ne = 0; s_pw = 0; }
   __syncthreads();
   for (int n = tid; n < Np; n += 256) {
     int c = 0;
@@ -76,9 +76,12 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const double* __restrict
       if (nz && my < ELL_PW) { pi[ELL_CW + my] = n; pv[2 * (ELL_CW + my)] = a; pv[2 * (ELL_CW + my) + 1] = b; }
       pos += __popcll(m);
     }
+    if (lane == 0) atomicMax(&s_pw, pos);
     if (pos > ELL_PW) { if (lane == 0) e.over[filt] = 1; }
     else if (lane >= pos && lane < ELL_PW) { pi[ELL_CW + lane] = 0; pv[2 * (ELL_CW + lane)] = 0.0; pv[2 * (ELL_CW + lane) + 1] = 0.0; }
   }
+  __syncthreads();
+  if (tid == 0) e.pw[filt] = s_pw;
 }
 
 // ---------------------------------------------------------------- out = H_ell (x) Src
@@ -169,9 +172,9 @@ typedef __attribute__((address_space(4))) const int ell_cint;
 // prefetch, 40 doubles per thread) needs the 256-VGPR budget of 8 waves
 constexpr int ell_tile_threads(int mode) { return mode == ELL_S ? 512 : 1024; }
 
-template <int MODE, int CWU, int XC>
+template <int MODE, int CWU, int XC, int PWU>
 __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMulArgs a) {
-  constexpr int NSLOT = CWU + ELL_PW;
+  constexpr int NSLOT = CWU + PWU;   // PWU: private slots actually walked (9 for XIVO's group + feature blocks)
   constexpr int NT = ell_tile_threads(MODE), NW = NT / 64;
   // slab elements per thread held in registers while the previous slab is being consumed
   // covers every cols the LDS can hold (XC = 64: <= 272; XC = 32: <= 528)
@@ -301,14 +304,14 @@ __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMul
     for (int p = wave; p < pairs; p += NW) {
       ell_cint* pi = idx0 + (long)p * ELL_W + ELL_CW;
       const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT;
-      double sv[ELL_PW];
+      double sv[PWU];
 #pragma unroll
-      for (int t = 0; t < ELL_PW; ++t) sv[t] = slab(pi[t]);
+      for (int t = 0; t < PWU; ++t) sv[t] = slab(pi[t]);
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll
       for (int t = 0; t < CWU; ++t) { const d2 v = pv[t]; a0 = fma(v[0], cm[t], a0); a1 = fma(v[1], cm[t], a1); }
 #pragma unroll
-      for (int t = 0; t < ELL_PW; ++t) { const d2 v = pv[CWU + t]; a0 = fma(v[0], sv[t], a0); a1 = fma(v[1], sv[t], a1); }
+      for (int t = 0; t < PWU; ++t) { const d2 v = pv[CWU + t]; a0 = fma(v[0], sv[t], a0); a1 = fma(v[1], sv[t], a1); }
       if (!live) continue;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -399,11 +402,11 @@ int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, 
   CHECK_LAUNCH();
 }
 
-template <int MODE, int CWU, int XC>
+template <int MODE, int CWU, int XC, int PWU>
 static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC, PWU>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -415,37 +418,43 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
   const int grid = ((a.batch + 7) / 8) * 8 * wgs;
-  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC>), dim3(grid), dim3(ell_tile_threads(MODE)), lds, s, a);
+  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU>), dim3(grid), dim3(ell_tile_threads(MODE)), lds, s, a);
   return (int)hipGetLastError();
 }
 // which form / instantiation the launcher picks: xc = 64 / 32 (slab form) or 0 (gather form)
-static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, size_t* lds) {
+static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, int* pwu, size_t* lds) {
   static const bool no_tile = getenv("XIVO_HIP_ELL_GATHER") != nullptr;   // A/B knob: force the gather form
   *cwu = a.nc_max <= 12 ? 12 : ELL_CW;
-  const size_t ops = (size_t)(a.Mp / 2) * (*cwu + ELL_PW) * 2 * sizeof(double);
+  *pwu = (*cwu == 12 && a.pw_max > 0 && a.pw_max <= 9) ? 9 : ELL_PW;
+  const size_t ops = (size_t)(a.Mp / 2) * (*cwu + *pwu) * 2 * sizeof(double);
   const size_t lds64 = (size_t)a.cols * 64 * sizeof(double) + ops, lds32 = (size_t)a.cols * 32 * sizeof(double) + ops;
   const size_t cap = 160 * 1024;
   *xc = 0; *lds = 0;
   if (no_tile) return;
-  if (lds64 <= cap) { *xc = 64; *lds = lds64; }
-  else if (lds32 <= cap) { *xc = 32; *lds = lds32; }
+  if (lds64 <= cap) { *xc = 64; *lds = lds64; return; }
+  // the 9-slot walk is instantiated for XC = 64 only
+  *pwu = ELL_PW;
+  const size_t lds32b = (size_t)a.cols * 32 * sizeof(double) + (size_t)(a.Mp / 2) * (*cwu + ELL_PW) * 2 * sizeof(double);
+  if (lds32b <= cap) { *xc = 32; *lds = lds32b; }
+  (void)lds32;
 }
 
 void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n) {
-  int xc, cwu; size_t lds;
-  ell_pick(a, &xc, &cwu, &lds);
-  if (xc) snprintf(buf, n, "ell_tile_kernel<%d,%d,%d>", mode, cwu, xc);
+  int xc, cwu, pwu; size_t lds;
+  ell_pick(a, &xc, &cwu, &pwu, &lds);
+  if (xc) snprintf(buf, n, "ell_tile_kernel<%d,%d,%d,%d>", mode, cwu, xc, pwu);
   else snprintf(buf, n, "ell_mul_kernel<%d,%d>", mode, cwu);
 }
 
 template <int MODE>
 static int launch_ell_tile_m(const EllMulArgs& a, hipStream_t s, bool* done) {
-  int xc, cwu; size_t lds;
-  ell_pick(a, &xc, &cwu, &lds);
+  int xc, cwu, pwu; size_t lds;
+  ell_pick(a, &xc, &cwu, &pwu, &lds);
   *done = xc != 0;
   const bool n12 = cwu == 12;
-  if (xc == 64) return n12 ? launch_ell_tile_t<MODE, 12, 64>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 64>(a, lds, s);
-  if (xc == 32) return n12 ? launch_ell_tile_t<MODE, 12, 32>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 32>(a, lds, s);
+  if (xc == 64 && pwu == 9) return launch_ell_tile_t<MODE, 12, 64, 9>(a, lds, s);
+  if (xc == 64) return n12 ? launch_ell_tile_t<MODE, 12, 64, ELL_PW>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 64, ELL_PW>(a, lds, s);
+  if (xc == 32) return n12 ? launch_ell_tile_t<MODE, 12, 32, ELL_PW>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 32, ELL_PW>(a, lds, s);
   return 0;
 }
 
