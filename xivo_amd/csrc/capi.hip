@@ -188,6 +188,7 @@ struct GemmExtra {
   double* C2 = nullptr; long sC2 = 0; int ldc2 = 0;
   int lower_only = 0;
   int fp32 = 0;
+  int a_f32 = 0;   // first operand stored as float
 };
 
 int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0, long sA0, int lda0,
@@ -196,10 +197,10 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
          const GemmExtra& x) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
-  g.seg[0] = GemmSeg{A0, B0, nullptr, sA0, sB0, 0, lda0, ldb0, K0};
+  g.seg[0] = GemmSeg{A0, B0, nullptr, sA0, sB0, 0, lda0, ldb0, K0, x.a_f32};
   g.nseg = 1;
   if (A1) {
-    g.seg[1] = GemmSeg{A1, B1, scale1, sA1, sB1, sScale1, lda1, ldb1, K1};
+    g.seg[1] = GemmSeg{A1, B1, scale1, sA1, sB1, sScale1, lda1, ldb1, K1, 0};
     g.nseg = 2;
   }
   g.C = C; g.strideC = sC; g.ldc = ldc; g.Mp = rows; g.Np = cols;
@@ -214,7 +215,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
                    (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG) && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
   char label[64] = "gemm_sym_f64_kernel";
   if (!sym) gemm_kernel_label(g, label, sizeof(label));
-  const double bytes = 8.0 * B * ((double)rows * K0 + (double)cols * K0 + (A1 ? ((double)rows + cols) * K1 : 0.0) +
+  const double bytes = 8.0 * B * ((double)rows * K0 * (x.a_f32 ? 0.5 : 1.0) + (double)cols * K0 + (A1 ? ((double)rows + cols) * K1 : 0.0) +
                                   (x.msub ? outs : 0.0) + (double)rows * cols + (x.C2 ? (double)rows * cols : 0.0));
   StageTimer st(c, stage, flops, label, bytes);
   const int rc = sym ? launch_gemm_sym_f64(g, c->stream) : launch_gemm_nt_f64(g, c->stream);
@@ -500,17 +501,23 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
               T, c->sP, Np, x);
     if (rc) return rc;
   }
+  bool g_f32 = false;
   {  // G = T H^T + K diag(R)   [Np x Mp, in the A buffer]
     EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sA; a.ldo = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
-    char label[64]; ell_kernel_label(ELL_G, a, label, sizeof(label));
-    StageTimer st(c, ST_KH, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + 2.0 * Np * Mp));
-    if (launch_ell_mul(ELL_G, a, c->stream)) return XIVO_HIP_ERR_HIP;
+    // G only ever feeds the fp32 correction product: keep it in HBM as float (slab form only)
+    g_f32 = !(c->flags & XIVO_HIP_FLAG_FP64_CORR) && ell_uses_slab_form(a);
+    if (g_f32) a.strideOut = 2 * c->sA;
+    const int gmode = g_f32 ? ELL_GF : ELL_G;
+    char label[64]; ell_kernel_label(gmode, a, label, sizeof(label));
+    StageTimer st(c, ST_KH, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (g_f32 ? 1.5 : 2.0) * Np * Mp));
+    if (launch_ell_mul(gmode, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // P+ = G K^T - T   (lower triangle + mirror)
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
     x.fp32 = (c->flags & XIVO_HIP_FLAG_FP64_CORR) ? 0 : 1;   // correction product on the fp32 MFMA, T added in fp64
-    rc = gemm(c, ST_PNEW, B, Np, Np, G, c->sA, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+    x.a_f32 = g_f32 ? 1 : 0;
+    rc = gemm(c, ST_PNEW, B, Np, Np, G, g_f32 ? 2 * c->sA : c->sA, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               P, c->sP, Np, x);
   }
   return rc;

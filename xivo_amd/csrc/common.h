@@ -28,6 +28,7 @@ struct GemmSeg {
   const double* scale;  // optional per-k scale applied to B (nullptr = none)
   long strideA, strideB, strideScale;  // per-filter strides (elements)
   int lda, ldb, K;      // K multiple of 16
+  int a_f32;            // 1: A is stored as float (same lda / stride in ELEMENTS) - fp32 products only
 };
 
 enum GemmEpilogue : int {

@@ -43,6 +43,7 @@ enum EllMode : int {
   ELL_S = 1,    // Src = P H^T [Np x Mp] (tile form) or HP [Mp x Np] (gather form): out = S = (HP) H^T + diag(R)
                 //                                                                 (estimator.cpp:1259-1263)
   ELL_G = 2,    // Src = T  [Np x Np] : out = T H^T + K diag(R)  [Np x Mp]               (re-associated :1280-1287)
+  ELL_GF = 3,   // ELL_G with the result stored as float (slab form only; strideOut / ldo in float elements)
 };
 struct EllMulArgs {
   EllBuffers ell;
@@ -64,6 +65,8 @@ struct EllMulArgs {
 int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s);
 // name of the kernel instantiation launch_ell_mul runs for these arguments
 void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n);
+// true when launch_ell_mul will run the slab-in-LDS form for these arguments
+bool ell_uses_slab_form(const EllMulArgs& a);
 
 // Estimator::MHGating numeric core (src/update.cpp:60-96) on the ELL rows: S_f = H_f (P H_f^T) + R I2
 // from the already formed P H^T, threshold relaxation, then neutralisation of the rejected pairs

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMul
     const bool live = x < a.X;
     const double* __restrict__ K = a.K + (long)filt * a.strideK + (live ? x : 0);
     double* __restrict__ out = a.out + (long)filt * a.strideOut + (live ? x : 0);
+    float* __restrict__ outf = reinterpret_cast<float*>(a.out) + (long)filt * a.strideOut + (live ? x : 0);
     double cm[CWU];
 #pragma unroll
     for (int t = 0; t < CWU; ++t) cm[t] = slab(idx0[t]);
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMul
         const double acc = i ? a1 : a0;
         if (MODE == ELL_HP) out[(long)m * a.ldo] = acc;
         else if (MODE == ELL_S) out[(long)m * a.ldo] = acc + (x == m ? dR[m] : 0.0);
+        else if (MODE == ELL_GF) outf[(long)m * a.ldo] = (float)fma(K[(long)m * a.ldk], dR[m], acc);
         else out[(long)m * a.ldo] = fma(K[(long)m * a.ldk], dR[m], acc);
       }
     }
@@ -439,6 +441,12 @@ static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, int* pwu, size_t* l
   (void)lds32;
 }
 
+bool ell_uses_slab_form(const EllMulArgs& a) {
+  int xc, cwu, pwu; size_t lds;
+  ell_pick(a, &xc, &cwu, &pwu, &lds);
+  return xc != 0;
+}
+
 void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n) {
   int xc, cwu, pwu; size_t lds;
   ell_pick(a, &xc, &cwu, &pwu, &lds);
@@ -465,7 +473,8 @@ int launch_ell_mul(int mode, const EllMulArgs& a_in, hipStream_t s) {
     {
       bool done = false;
       const int rc = mode == ELL_HP ? launch_ell_tile_m<ELL_HP>(a, s, &done)
-                     : (mode == ELL_S ? launch_ell_tile_m<ELL_S>(a, s, &done) : launch_ell_tile_m<ELL_G>(a, s, &done));
+                     : (mode == ELL_S ? launch_ell_tile_m<ELL_S>(a, s, &done)
+                     : (mode == ELL_GF ? launch_ell_tile_m<ELL_GF>(a, s, &done) : launch_ell_tile_m<ELL_G>(a, s, &done)));
       if (done) return rc;
     }
   }

@@ -150,13 +150,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   const double* segA = nullptr;
   const double* segB = nullptr;
   const double* segS = nullptr;
-  int seg_lda = 0, seg_ldb = 0, seg_K = 0;
+  int seg_lda = 0, seg_ldb = 0, seg_K = 0, seg_af32 = 0;
   auto setup_seg = [&](int sidx) {
     const GemmSeg& sg = g.seg[sidx];
     segA = sg.A + (long)filt * sg.strideA;
     segB = sg.B + (long)filt * sg.strideB;
     segS = sg.scale ? sg.scale + (long)filt * sg.strideScale : nullptr;
-    seg_lda = sg.lda; seg_ldb = sg.ldb; seg_K = sg.K;
+    seg_lda = sg.lda; seg_ldb = sg.ldb; seg_K = sg.K; seg_af32 = sg.a_f32;
+    if (sizeof(CT) == 4 && sg.a_f32) segA = reinterpret_cast<const double*>(reinterpret_cast<const float*>(sg.A) + (long)filt * sg.strideA);
     okA = 0; okB = 0;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
@@ -181,7 +182,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   // Issue only: nothing below consumes the loaded registers, so the loads stay in flight
   // under the MFMA block; masking (row validity, k-tail) and the optional per-k scale are
   // applied in store_lds, one k-step later.
-  int pend_k0 = 0, pend_K = 0;
+  int pend_k0 = 0, pend_K = 0, pend_af32 = 0;
   const double* pend_S = nullptr;
   auto load_global = [&](int t) {
     if (t == 0) setup_seg(0);
@@ -190,12 +191,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     const bool tail = k0 + BK > seg_K;            // only the last, partial k-step of a segment
     const double* Ab = segA + (long)k0 * seg_lda;
     const double* Bb = segB + (long)k0 * seg_ldb;
-    pend_k0 = k0; pend_K = seg_K; pend_S = segS;
+    pend_k0 = k0; pend_K = seg_K; pend_S = segS; pend_af32 = seg_af32;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int k = (tid + 256 * r) / (16 * WM);
       const bool kin = !tail || (k0 + k < seg_K);
-      ra[r] = *reinterpret_cast<const d2*>(Ab + (kin ? eoffA[r] : eoffA[r] - k * seg_lda));
+      const long eo = kin ? eoffA[r] : eoffA[r] - k * seg_lda;
+      if (sizeof(CT) == 4 && seg_af32) {   // A kept in HBM as float (it only ever feeds this fp32 product):
+        // issue-only 8-byte load of the float pair, bits parked in ra[r][0]; unpacked in store_lds
+        ra[r][0] = *reinterpret_cast<const double*>(reinterpret_cast<const float*>(segA) + (long)k0 * seg_lda + eo);
+      } else {
+        ra[r] = *reinterpret_cast<const d2*>(Ab + eo);
+      }
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -212,7 +219,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WM), p = idx % (16 * WM);
       const bool keep = ((okA >> r) & 1u) && (!tail || pend_k0 + k < pend_K);
-      *reinterpret_cast<pair_t*>(As + k * LDAS + 2 * p) = Cx<CT>::cvt(keep ? ra[r] : d2{0.0, 0.0});
+      if (sizeof(CT) == 4 && pend_af32) {
+        const double bits = keep ? ra[r][0] : 0.0;      // +0.0 is also two float zeros
+        *reinterpret_cast<double*>(As + k * LDAS + 2 * p) = bits;
+      } else {
+        *reinterpret_cast<pair_t*>(As + k * LDAS + 2 * p) = Cx<CT>::cvt(keep ? ra[r] : d2{0.0, 0.0});
+      }
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
