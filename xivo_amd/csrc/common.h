@@ -58,6 +58,7 @@ struct GemmArgs {
   long strideMcol;
   int epilogue;
   int lower_only;      // 1: skip tiles strictly above the diagonal and mirror-store
+  int no_mirror;       // with lower_only: store the lower triangle only (the reader knows the matrix is symmetric)
   int batch;
   int tiles_m, tiles_n;
   int fp32;            // 1: fp32 MFMA with fp32 accumulation for this product (operands/results stay fp64 in HBM)

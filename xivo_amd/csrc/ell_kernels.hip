@@ -172,7 +172,7 @@ typedef __attribute__((address_space(4))) const int ell_cint;
 // prefetch, 40 doubles per thread) needs the 256-VGPR budget of 8 waves
 constexpr int ell_tile_threads(int mode) { return mode == ELL_S ? 512 : 1024; }
 
-template <int MODE, int CWU, int XC, int PWU>
+template <int MODE, int CWU, int XC, int PWU, bool SL>
 __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMulArgs a) {
   constexpr int NSLOT = CWU + PWU;   // PWU: private slots actually walked (9 for XIVO's group + feature blocks)
   constexpr int NT = ell_tile_threads(MODE), NW = NT / 64;
@@ -276,6 +276,42 @@ __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMul
 #pragma unroll
           for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; if (k < cols) tile[k * XC + (jj ^ (k & 15))] = r[u]; }
         }
+      }
+    } else if (SL) {
+      // symmetric source, lower triangle authoritative (element (i, j), i >= j, at i + ld j):
+      //   columns k < x0        : rows x0.. are below the diagonal -> direct, lanes = x
+      //   columns k >= x0 + XC  : (x, k) lives at (k, x) -> for one x the k run is contiguous: lanes = k
+      //   the XC x XC block on the diagonal: both passes, each keeps its half
+      const int x0 = sidx * XC;
+      const int xq = tid % XC, kq = tid / XC;
+      const bool okx = x0 + xq < a.X;
+      const double* __restrict__ row = Src + x0 + (okx ? xq : 0);
+      const int kd_end = min(cols, x0 + XC);
+      for (int k0 = 0; k0 < kd_end; k0 += (NT / XC) * 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + kq + (NT / XC) * u; r[u] = (okx && k < kd_end) ? row[(long)k * a.ldsrc] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + kq + (NT / XC) * u;
+          if (k < kd_end && (k < x0 || x0 + xq >= k)) tile[k * XC + (xq ^ (k & 15))] = r[u];
+        }
+      }
+      for (int jj = wave; jj < XC; jj += NW) {
+        const int xr = x0 + jj;                       // source row = stored column xr, rows k > xr
+        const bool ok = xr < a.X;
+        const double* __restrict__ col = Src + (long)(ok ? xr : 0) * a.ldsrc;
+        for (int k0 = x0; k0 < cols; k0 += 64 * 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; r[u] = (ok && k < cols) ? col[k] : 0.0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 + lane + 64 * u;
+            if (k < cols && k > xr) tile[k * XC + (jj ^ (k & 15))] = r[u];
+          }
+        }
+      }
+      if (x0 + XC > a.X) {   // ragged last slab: rows beyond X are zero
+        for (int e = tid; e < cols * XC; e += NT) { const int k = e / XC, xx2 = e % XC; if (x0 + xx2 >= a.X) tile[k * XC + (xx2 ^ (k & 15))] = 0.0; }
       }
     } else {
       // straight copy, 8 loads in flight per thread
@@ -404,11 +440,11 @@ int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, 
   CHECK_LAUNCH();
 }
 
-template <int MODE, int CWU, int XC, int PWU>
+template <int MODE, int CWU, int XC, int PWU, bool SL = false>
 static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC, PWU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC, PWU, SL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -420,7 +456,7 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
   const int grid = ((a.batch + 7) / 8) * 8 * wgs;
-  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU>), dim3(grid), dim3(ell_tile_threads(MODE)), lds, s, a);
+  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU, SL>), dim3(grid), dim3(ell_tile_threads(MODE)), lds, s, a);
   return (int)hipGetLastError();
 }
 // which form / instantiation the launcher picks: xc = 64 / 32 (slab form) or 0 (gather form)
@@ -447,10 +483,16 @@ bool ell_uses_slab_form(const EllMulArgs& a) {
   return xc != 0;
 }
 
+bool ell_accepts_lower_source(const EllMulArgs& a) {
+  int xc, cwu, pwu; size_t lds;
+  ell_pick(a, &xc, &cwu, &pwu, &lds);
+  return xc == 64 && cwu == 12;
+}
+
 void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n) {
   int xc, cwu, pwu; size_t lds;
   ell_pick(a, &xc, &cwu, &pwu, &lds);
-  if (xc) snprintf(buf, n, "ell_tile_kernel<%d,%d,%d,%d>", mode, cwu, xc, pwu);
+  if (xc) snprintf(buf, n, "ell_tile_kernel<%d,%d,%d,%d,%s>", mode, cwu, xc, pwu, a.src_lower ? "true" : "false");
   else snprintf(buf, n, "ell_mul_kernel<%d,%d>", mode, cwu);
 }
 
@@ -460,6 +502,14 @@ static int launch_ell_tile_m(const EllMulArgs& a, hipStream_t s, bool* done) {
   ell_pick(a, &xc, &cwu, &pwu, &lds);
   *done = xc != 0;
   const bool n12 = cwu == 12;
+  if (a.src_lower) {   // symmetric lower-only source: instantiated for the G modes at XC = 64, 12 common slots
+    if constexpr (MODE == ELL_G || MODE == ELL_GF) {
+      if (xc == 64 && n12) return pwu == 9 ? launch_ell_tile_t<MODE, 12, 64, 9, true>(a, lds, s)
+                                          : launch_ell_tile_t<MODE, 12, 64, ELL_PW, true>(a, lds, s);
+    }
+    *done = true;
+    return (int)hipErrorInvalidValue;
+  }
   if (xc == 64 && pwu == 9) return launch_ell_tile_t<MODE, 12, 64, 9>(a, lds, s);
   if (xc == 64) return n12 ? launch_ell_tile_t<MODE, 12, 64, ELL_PW>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 64, ELL_PW>(a, lds, s);
   if (xc == 32) return n12 ? launch_ell_tile_t<MODE, 12, 32, ELL_PW>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 32, ELL_PW>(a, lds, s);

@@ -281,7 +281,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   double* C2b = g.C2 ? g.C2 + (long)filt * g.strideC2 : nullptr;
   const double* dg = g.diag ? g.diag + (long)filt * g.strideDiag : nullptr;
   double* Tw = smem_raw + wave * (16 * 17);  // per-wave 16x16 transpose pad (main-loop LDS is free now)
-  const bool need_t = g.lower_only || C2b;
+  const bool need_t = (g.lower_only && !g.no_mirror) || C2b;
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     if (!is_on(q)) continue;
@@ -315,7 +315,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       for (int r = 0; r < 4; ++r) {
         const double t = Tw[li * 17 + lg + 4 * r];   // element (i2 = I0 + lg + 4r, j2 = J0 + li)
         const int i2 = I0 + lg + 4 * r, j2 = J0 + li;
-        if (g.lower_only && i2 > j2) Cb[j2 + (long)i2 * g.ldc] = t;
+        if (g.lower_only && !g.no_mirror && i2 > j2) Cb[j2 + (long)i2 * g.ldc] = t;
         if (C2b) C2b[j2 + (long)i2 * g.ldc2] = t;
       }
     }
