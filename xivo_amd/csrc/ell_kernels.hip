@@ -374,21 +374,19 @@ __global__ __launch_bounds__(256) void gate_ell_kernel(GateEllArgs a) {
   double* val = a.ell.val + (long)filt * a.ell.stride_val();
   double* PHT = a.PHT + (long)filt * a.strideHT;
   double* inn = a.inn + (long)filt * a.strideInn;
-  for (int f = tid; f < a.F; f += 256) {
-    const int* pi = idx + (long)f * ELL_W;
-    const double* pv = val + (long)f * ELL_W * 2;
+  // one wave per feature, one lane per slot: the 2 x 28 gathers of a feature are one round trip
+  for (int f = wave; f < a.F; f += 4) {
     const double* c0 = PHT + (long)(2 * f) * a.ldht;      // P J0^T
     const double* c1 = c0 + a.ldht;                       // P J1^T
     double s00 = 0, s10 = 0, s11 = 0;
-    for (int t = 0; t < ELL_W; ++t) {
-      const int k = pi[t];
-      const double v0 = pv[2 * t], v1 = pv[2 * t + 1];
+    if (lane < ELL_W) {
+      const int k = idx[(long)f * ELL_W + lane];
+      const double v0 = val[((long)f * ELL_W + lane) * 2], v1 = val[((long)f * ELL_W + lane) * 2 + 1];
       const double p0 = c0[k], p1 = c1[k];
-      s00 = fma(v0, p0, s00);
-      s10 = fma(v1, p0, s10);
-      s11 = fma(v1, p1, s11);
+      s00 = v0 * p0; s10 = v1 * p0; s11 = v1 * p1;
     }
-    sdist[f] = mh_dist_2x2(s00 + a.R, s10, s11 + a.R, inn[2 * f], inn[2 * f + 1]);
+    s00 = wave_sum(s00); s10 = wave_sum(s10); s11 = wave_sum(s11);
+    if (lane == 0) sdist[f] = mh_dist_2x2(s00 + a.R, s10, s11 + a.R, inn[2 * f], inn[2 * f + 1]);
   }
   __syncthreads();
   if (wave == 0) {
