@@ -480,7 +480,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {
     CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B;
-    char clabel[64]; chol_kernel_label(Mp, clabel, sizeof(clabel));
+    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
@@ -588,7 +588,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {  // S = L L^T
     CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B;
-    char clabel[64]; chol_kernel_label(Mp, clabel, sizeof(clabel));
+    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }

@@ -188,8 +188,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 //              chain) -> LDS / global; publishes the row panel L_jk, k < j, in LDS
 //   C  all   : own rows i > j:  L_ij^T = inv(L_jj) (S_ij^T - sum_k L_jk L_ik^T), kept + stored
 // with one barrier between A and C and one after C.
-template <int NB>
-__global__ __launch_bounds__(256) void chol_reg_f64_kernel(CholArgs g, int mirror) {
+// MINB = workgroups per CU the register budget is cut for: 3 (168 VGPRs, a few spills) is faster for thousands of
+// factors (0.67 vs 0.75 ms / 4096 at M = 160), 2 (212 VGPRs) for a single one (76 vs 82 us)
+template <int NB, int MINB>
+__global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror) {
   constexpr int RW = NB / 4;
   const int filt = blockIdx.x;
   if (filt >= g.batch) return;
@@ -744,9 +746,11 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   // of the HBM traffic
   if (!old_kernel && nb <= 12) {
     const int mirror = nb > 11 ? 1 : 0;   // only the streamed solve (nb >= 12) reads the mirrored upper triangle
-    if (nb <= 4) hipLaunchKernelGGL(chol_reg_f64_kernel<4>, dim3(g.batch), dim3(256), 0, stream, g, mirror);
-    else if (nb <= 8) hipLaunchKernelGGL(chol_reg_f64_kernel<8>, dim3(g.batch), dim3(256), 0, stream, g, mirror);
-    else hipLaunchKernelGGL(chol_reg_f64_kernel<12>, dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    const bool many = g.batch >= 512;
+    if (nb <= 4) hipLaunchKernelGGL((chol_reg_f64_kernel<4, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    else if (nb <= 8) hipLaunchKernelGGL((chol_reg_f64_kernel<8, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    else if (many) hipLaunchKernelGGL((chol_reg_f64_kernel<12, 3>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    else hipLaunchKernelGGL((chol_reg_f64_kernel<12, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
@@ -776,10 +780,10 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   return (int)hipErrorInvalidValue;
 }
 
-void chol_kernel_label(int Mp, char* buf, size_t n) {
+void chol_kernel_label(int Mp, int batch, char* buf, size_t n) {
   const int nb = Mp / 16;
   if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12) snprintf(buf, n, "chol_f64_kernel");
-  else snprintf(buf, n, "chol_reg_f64_kernel<%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : 12));
+  else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : 12), (nb > 8 && batch >= 512) ? 3 : 2);
 }
 
 void trsm_kernel_label(int Mp, char* buf, size_t n) {

@@ -85,7 +85,7 @@ struct CholArgs {
   int batch;
 };
 int launch_chol_f64(const CholArgs& args, hipStream_t stream);
-void chol_kernel_label(int Mp, char* buf, size_t n);
+void chol_kernel_label(int Mp, int batch, char* buf, size_t n);
 
 struct TrsmArgs {
   const double* LU;    // from chol: L lower, L^T upper

@@ -366,7 +366,8 @@ __global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMul
 }
 
 // ---------------------------------------------------------------- gating on ELL rows
-__global__ __launch_bounds__(256) void gate_ell_kernel(GateEllArgs a) {
+__global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
+  const int nt = blockDim.x, nwv = nt >> 6;   // 256 threads for a big batch, 1024 when few filters must finish fast
   const int filt = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ double sdist[];  // F doubles + 1
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void gate_ell_kernel(GateEllArgs a) {
   double* PHT = a.PHT + (long)filt * a.strideHT;
   double* inn = a.inn + (long)filt * a.strideInn;
   // one wave per feature, one lane per slot: the 2 x 28 gathers of a feature are one round trip
-  for (int f = wave; f < a.F; f += 4) {
+  for (int f = wave; f < a.F; f += nwv) {
     const double* c0 = PHT + (long)(2 * f) * a.ldht;      // P J0^T
     const double* c1 = c0 + a.ldht;                       // P J1^T
     double s00 = 0, s10 = 0, s11 = 0;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void gate_ell_kernel(GateEllArgs a) {
   }
   __syncthreads();
   const double th = sdist[a.F];
-  for (int f = tid; f < a.F; f += 256) {
+  for (int f = tid; f < a.F; f += nt) {
     const bool in = sdist[f] < th;
     a.mask[(long)filt * a.F + f] = in ? 1 : 0;
     a.dist[(long)filt * a.F + f] = sdist[f];
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void gate_ell_kernel(GateEllArgs a) {
   double* HP = a.HP + (long)filt * a.strideH;
   for (int f = 0; f < a.F; ++f) {
     if (sdist[f] < th) continue;
-    for (int n = tid; n < a.Np; n += 256) {
+    for (int n = tid; n < a.Np; n += nt) {
       if (H) {
         H[2 * f + (long)n * a.ldh] = 0.0;
         H[2 * f + 1 + (long)n * a.ldh] = 0.0;
@@ -553,7 +554,7 @@ int launch_ell_mul(int mode, const EllMulArgs& a_in, hipStream_t s) {
 
 int launch_gate_ell(const GateEllArgs& a, hipStream_t s) {
   if (a.batch <= 0) return 0;
-  hipLaunchKernelGGL(gate_ell_kernel, dim3(a.batch), dim3(256), (size_t)(a.F + 1) * sizeof(double), s, a);
+  hipLaunchKernelGGL(gate_ell_kernel, dim3(a.batch), dim3(a.batch < 256 ? 1024 : 256), (size_t)(a.F + 1) * sizeof(double), s, a);
   CHECK_LAUNCH();
 }
 
