@@ -170,19 +170,26 @@ typedef __attribute__((address_space(4))) const int ell_cint;
 
 // threads per workgroup: 16 waves (128 VGPRs each) walk the pairs fastest; the S instantiation (transposing
 // prefetch, 40 doubles per thread) needs the 256-VGPR budget of 8 waves
-constexpr int ell_tile_threads(int mode) { return mode == ELL_S ? 512 : 1024; }
+// prefetch variant (next slab fetched into registers under the pair walk): the hot configuration only
+constexpr bool ell_tile_pf(int mode, int cwu, int xc, int pwu, bool sl) {
+  // (tried for the P H^T and G instantiations too, at 8 waves / 256 VGPRs: 0.83 -> 0.92 and 0.88 -> 1.79 ms)
+  return !sl && xc == 64 && cwu == 12 && mode == ELL_S && pwu >= 0;
+}
+constexpr int ell_tile_threads(int mode, int cwu, int xc, int pwu, bool sl) {
+  return (mode == ELL_S || ell_tile_pf(mode, cwu, xc, pwu, sl)) ? 512 : 1024;
+}
 
 template <int MODE, int CWU, int XC, int PWU, bool SL>
-__global__ __launch_bounds__(ell_tile_threads(MODE)) void ell_tile_kernel(EllMulArgs a) {
+__global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU, SL)) void ell_tile_kernel(EllMulArgs a) {
   constexpr int NSLOT = CWU + PWU;   // PWU: private slots actually walked (9 for XIVO's group + feature blocks)
-  constexpr int NT = ell_tile_threads(MODE), NW = NT / 64;
+  constexpr int NT = ell_tile_threads(MODE, CWU, XC, PWU, SL), NW = NT / 64;
   // slab elements per thread held in registers while the previous slab is being consumed
   // covers every cols the LDS can hold (XC = 64: <= 272; XC = 32: <= 528)
   // (prefetching under the pair walk pays for ELL_S only: at 16 waves per CU the 128-VGPR budget of the other
   //  two modes cannot hold a slab share next to the walk without spilling - measured slower)
-  constexpr bool PF = MODE == ELL_S && XC == 64 && CWU == 12;
+  constexpr bool PF = ell_tile_pf(MODE, CWU, XC, PWU, SL);
   constexpr int UNR = (PF || (CWU == 12 && XC == 64)) ? 2 : 1;   // pairs in flight per wave (register budget)
-  constexpr int RN = PF ? 40 : 8;
+  constexpr int RN = PF ? (MODE == ELL_S ? 40 : 34) : 8;
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int xchunks = (a.X + XC - 1) / XC;
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;     // workgroups per filter
@@ -451,11 +458,11 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   const int xchunks = (a.X + XC - 1) / XC;
   // big batch: one workgroup streams all slabs of its filter (next slab prefetched under the pair walk,
   // coefficients staged once); small batch: one workgroup per slab (latency)
-  a.slabs_per_wg = (MODE == ELL_S && XC == 64 && CWU == 12 && a.batch >= 1024) ? xchunks : 1;
+  a.slabs_per_wg = (ell_tile_pf(MODE, CWU, XC, PWU, SL) && a.batch >= 1024) ? xchunks : 1;
   if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
   const int grid = ((a.batch + 7) / 8) * 8 * wgs;
-  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU, SL>), dim3(grid), dim3(ell_tile_threads(MODE)), lds, s, a);
+  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU, SL>), dim3(grid), dim3(ell_tile_threads(MODE, CWU, XC, PWU, SL)), lds, s, a);
   return (int)hipGetLastError();
 }
 // which form / instantiation the launcher picks: xc = 64 / 32 (slab form) or 0 (gather form)
