@@ -258,22 +258,27 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     __syncthreads();
   }
 
-  double msv[LATE_MSUB ? NS : 1][4];
-  if (LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT)) {
+  // fp32 products: Msub (fp64) is added in the epilogue, fetched through a small ring a few slots ahead of
+  // the stores (holding all of it would cost 128 VGPRs and the third workgroup per CU)
+  constexpr int MSD = 4;
+  double msring[LATE_MSUB ? MSD : 1][4];
+  const bool late_ms = LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT);
+  auto load_ms = [&](int q) {
+    if (q >= NS || !is_on(q)) return;
     const double* Ms = g.Msub + (long)filt * g.strideMsub;
     const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;
+    const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
 #pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      if (!is_on(q)) continue;
-      const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = J0 + Cx<CT>::crow(lg, r);
-        double v = sgn * Ms[i + (long)j * g.ldmsub];
-        if (g.McolScale) v *= g.McolScale[(long)filt * g.strideMcol + j];
-        msv[LATE_MSUB ? q : 0][r] = v;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int j = J0 + Cx<CT>::crow(lg, r);
+      double v = sgn * Ms[i + (long)j * g.ldmsub];
+      if (g.McolScale) v *= g.McolScale[(long)filt * g.strideMcol + j];
+      msring[LATE_MSUB ? q % MSD : 0][r] = v;
     }
+  };
+  if (late_ms) {
+#pragma unroll
+    for (int q = 0; q < MSD - 1; ++q) load_ms(q);
   }
 
   // Epilogue. acc[q][r] = C[i = I0 + li][j = J0 + lg + 4r]
@@ -284,6 +289,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   const bool need_t = (g.lower_only && !g.no_mirror) || C2b;
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
+    if (late_ms) load_ms(q + MSD - 1);
     if (!is_on(q)) continue;
     const int I0 = m0 + 16 * arow(slot_a(q)), J0 = n0 + 16 * bcol(slot_b(q));
     const int i = I0 + li;
@@ -292,7 +298,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     for (int r = 0; r < 4; ++r) {
       const int j = J0 + Cx<CT>::crow(lg, r);
       v[r] = (double)acc[q][r];
-      if (LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT)) v[r] += msv[LATE_MSUB ? q : 0][r];
+      if (late_ms) v[r] += msring[LATE_MSUB ? q % MSD : 0][r];
       if (g.epilogue == EPI_ADD_DIAG) {
         if (i == j) v[r] += dg[i];
       } else if (g.epilogue == EPI_SUB_IDENT) {
@@ -328,7 +334,7 @@ constexpr int pick_bk() {
 }
 
 template <int WM, int WN, typename CT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (sizeof(CT) == 4 && WM * WN <= 16) ? 3 : 2) void gemm_nt_f64_kernel(GemmArgs g) {
   constexpr int BK = pick_bk<WM, WN>();
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int LDAS = BM + 16, LDBS = BN + 16;
