@@ -502,7 +502,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
      // triangle is computed and mirrored (XIVO_HIP_FLAG_FULL_PNEW: all of it)
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.fp32 = f32;
-    x.lower_only = (full || getenv("XIVO_HIP_T_FULL")) ? 0 : 1;
+    x.lower_only = (full || getenv("XIVO_HIP_T_FULL")) ? 0 : (getenv("XIVO_HIP_T_RECT") ? 2 : 1);
     // the only reader of T's upper triangle is ell<G>, whose slab loader can also fetch (x, k), x < k, from (k, x):
     // measured T 1.74 -> 1.57 ms but ell<G> 0.92 -> 1.39 ms per 4096 (two-pattern loader), so T stays mirrored;
     // A/B knob XIVO_HIP_T_LOWER
