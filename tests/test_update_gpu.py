@@ -311,3 +311,24 @@ def test_fp32_correction_product_is_invisible(built, N, F):
     for b in range(B):
         _, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
         assert rel_fro(outs[0][b], P_ref) < 1e-10
+
+
+def test_profile_reports_kernels_bytes_and_path(built):
+    """What bench.py builds its roofline from: per-stage kernel names (as rocprofv3 spells them, minus spaces),
+    algorithmic flops / bytes and which pipeline ran."""
+    from xivo_amd.lib import FLAG_PROFILE
+    N, F, B = 250, 80, 16
+    P, H, inn, dR = synth.s_level(N, F, B, seed=1)
+    for flags, path, hp_kernel in ((FLAG_PROFILE, 1, "ell_tile_kernel<0,12,64,9,false>"),
+                                   (FLAG_PROFILE | FLAG_DENSE_H, 0, "gemm_nt_f64_kernel<5,4,double>")):
+        with Context(N, 2 * F, B, flags=flags) as ctx:
+            ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
+            ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5)
+            prof = ctx.profile_get()
+            assert ctx.last_path() == path
+        assert prof["gemm_HP"]["kernel"] == hp_kernel
+        for st in ("gemm_HP", "gemm_S", "chol_S", "trsm_gain", "gemm_AP", "gemm_Pnew"):
+            assert prof[st]["launches"] == 1 and prof[st]["ms"] > 0 and prof[st]["kernel"]
+            assert prof[st]["bytes_per_launch"] > 0 and prof[st]["flops_per_launch"] > 0
+        assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<12")
+        assert prof["trsm_gain"]["kernel"] == "trsm_lds_f64_kernel<10>"
