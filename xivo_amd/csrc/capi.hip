@@ -494,20 +494,10 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
     if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
-  bool t_lower = false, t_lower_ok = false;
-  {  // is ell<G> going to run in its slab form? (only that loader understands a lower-only T)
-    EllMulArgs q{}; q.cols = Np; q.Mp = Mp; q.nc_max = nc_max; q.pw_max = pw_max; q.X = Np; q.batch = B;
-    t_lower_ok = ell_accepts_lower_source(q);
-  }
   {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
      // triangle is computed and mirrored (XIVO_HIP_FLAG_FULL_PNEW: all of it)
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.fp32 = f32;
-    x.lower_only = (full || getenv("XIVO_HIP_T_FULL")) ? 0 : (getenv("XIVO_HIP_T_RECT") ? 2 : 1);
-    // the only reader of T's upper triangle is ell<G>, whose slab loader can also fetch (x, k), x < k, from (k, x):
-    // measured T 1.74 -> 1.57 ms but ell<G> 0.92 -> 1.39 ms per 4096 (two-pattern loader), so T stays mirrored;
-    // A/B knob XIVO_HIP_T_LOWER
-    t_lower = x.lower_only && getenv("XIVO_HIP_T_LOWER") && t_lower_ok;
-    x.no_mirror = t_lower ? 1 : 0;
+    x.lower_only = (full || getenv("XIVO_HIP_T_FULL")) ? 0 : 1;
     rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               T, c->sP, Np, x);
     if (rc) return rc;
@@ -516,7 +506,6 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {  // G = T H^T + K diag(R)   [Np x Mp, in the A buffer]
     EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sA; a.ldo = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
-    a.src_lower = t_lower ? 1 : 0;
     // G only ever feeds the fp32 correction product: keep it in HBM as float (slab form only)
     g_f32 = !(c->flags & XIVO_HIP_FLAG_FP64_CORR) && ell_uses_slab_form(a);
     if (g_f32) a.strideOut = 2 * c->sA;

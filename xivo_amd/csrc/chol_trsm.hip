@@ -192,7 +192,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // factors (0.67 vs 0.75 ms / 4096 at M = 160), 2 (212 VGPRs) for a single one (76 vs 82 us)
 template <int NB, int MINB>
 __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror) {
-  constexpr int RW = NB / 4;
+  constexpr int RW = (NB + 3) / 4;
   const int filt = blockIdx.x;
   if (filt >= g.batch) return;
   double* S = g.S + (long)filt * g.strideS;
@@ -744,11 +744,18 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   const int nb = g.Mp / 16;
   // measured at M = 160: one factor 78 us (one-wave kernel 178 us); 4096 factors 0.75 ms (0.76 ms), with a third
   // of the HBM traffic
-  if (!old_kernel && nb <= 12) {
+  // The register kernel is 170-200 KB of straight-line code executed once per factor. On some MI355X nodes of the
+  // pool it runs 2.6x slower (1.77 vs 0.67 ms per 4096 factors; the large-code GEMM variants lose ~10 % on the same
+  // nodes, the small looping kernels nothing), which makes it a liability for throughput: big batches use the
+  // compact one-wave kernel (0.76 / 0.80 ms on fast / slow nodes), small ones the register kernel (76 vs 178 us).
+  static const bool reg_always = getenv("XIVO_HIP_CHOL_REG") != nullptr;   // A/B knob
+  if (!old_kernel && nb <= 12 && (g.batch < 512 || reg_always)) {
     const int mirror = nb > 11 ? 1 : 0;   // only the streamed solve (nb >= 12) reads the mirrored upper triangle
     const bool many = g.batch >= 512;
     if (nb <= 4) hipLaunchKernelGGL((chol_reg_f64_kernel<4, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     else if (nb <= 8) hipLaunchKernelGGL((chol_reg_f64_kernel<8, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    else if (nb <= 10 && many) hipLaunchKernelGGL((chol_reg_f64_kernel<10, 3>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    else if (nb <= 10) hipLaunchKernelGGL((chol_reg_f64_kernel<10, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     else if (many) hipLaunchKernelGGL((chol_reg_f64_kernel<12, 3>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     else hipLaunchKernelGGL((chol_reg_f64_kernel<12, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     return (int)hipGetLastError();
@@ -782,8 +789,8 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
 
 void chol_kernel_label(int Mp, int batch, char* buf, size_t n) {
   const int nb = Mp / 16;
-  if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12) snprintf(buf, n, "chol_f64_kernel");
-  else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : 12), (nb > 8 && batch >= 512) ? 3 : 2);
+  if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12 || (batch >= 512 && !getenv("XIVO_HIP_CHOL_REG"))) snprintf(buf, n, "chol_f64_kernel");
+  else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)), (nb > 8 && batch >= 512) ? 3 : 2);
 }
 
 void trsm_kernel_label(int Mp, char* buf, size_t n) {

@@ -49,7 +49,6 @@ struct EllMulArgs {
   EllBuffers ell;
   const double* Src; long strideSrc; int ldsrc;
   int cols;     // number of source columns a slot index can name (Np)
-  int src_lower; // ELL_HP / ELL_G(F), slab form: the source is symmetric and only its lower triangle is stored
   const double* SrcAlt; long strideSrcAlt; int ldsrcAlt;   // ELL_S: H P [Mp x Np] for the gather fallback (may be null if the tile form fits)
   double* out; long strideOut; int ldo;
   double* out2; long strideOut2; int ldo2;      // ELL_HP only
@@ -68,8 +67,6 @@ int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s);
 void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n);
 // true when launch_ell_mul will run the slab-in-LDS form for these arguments
 bool ell_uses_slab_form(const EllMulArgs& a);
-// true when the slab form that will run can read a symmetric source stored as its lower triangle only
-bool ell_accepts_lower_source(const EllMulArgs& a);
 
 // Estimator::MHGating numeric core (src/update.cpp:60-96) on the ELL rows: S_f = H_f (P H_f^T) + R I2
 // from the already formed P H^T, threshold relaxation, then neutralisation of the rejected pairs

@@ -171,23 +171,23 @@ typedef __attribute__((address_space(4))) const int ell_cint;
 // threads per workgroup: 16 waves (128 VGPRs each) walk the pairs fastest; the S instantiation (transposing
 // prefetch, 40 doubles per thread) needs the 256-VGPR budget of 8 waves
 // prefetch variant (next slab fetched into registers under the pair walk): the hot configuration only
-constexpr bool ell_tile_pf(int mode, int cwu, int xc, int pwu, bool sl) {
+constexpr bool ell_tile_pf(int mode, int cwu, int xc, int pwu) {
   // (tried for the P H^T and G instantiations too, at 8 waves / 256 VGPRs: 0.83 -> 0.92 and 0.88 -> 1.79 ms)
-  return !sl && xc == 64 && cwu == 12 && mode == ELL_S && pwu >= 0;
+  return xc == 64 && cwu == 12 && mode == ELL_S && pwu >= 0;
 }
-constexpr int ell_tile_threads(int mode, int cwu, int xc, int pwu, bool sl) {
-  return (mode == ELL_S || ell_tile_pf(mode, cwu, xc, pwu, sl)) ? 512 : 1024;
+constexpr int ell_tile_threads(int mode, int cwu, int xc, int pwu) {
+  return (mode == ELL_S || ell_tile_pf(mode, cwu, xc, pwu)) ? 512 : 1024;
 }
 
-template <int MODE, int CWU, int XC, int PWU, bool SL>
-__global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU, SL)) void ell_tile_kernel(EllMulArgs a) {
+template <int MODE, int CWU, int XC, int PWU>
+__global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile_kernel(EllMulArgs a) {
   constexpr int NSLOT = CWU + PWU;   // PWU: private slots actually walked (9 for XIVO's group + feature blocks)
-  constexpr int NT = ell_tile_threads(MODE, CWU, XC, PWU, SL), NW = NT / 64;
+  constexpr int NT = ell_tile_threads(MODE, CWU, XC, PWU), NW = NT / 64;
   // slab elements per thread held in registers while the previous slab is being consumed
   // covers every cols the LDS can hold (XC = 64: <= 272; XC = 32: <= 528)
   // (prefetching under the pair walk pays for ELL_S only: at 16 waves per CU the 128-VGPR budget of the other
   //  two modes cannot hold a slab share next to the walk without spilling - measured slower)
-  constexpr bool PF = ell_tile_pf(MODE, CWU, XC, PWU, SL);
+  constexpr bool PF = ell_tile_pf(MODE, CWU, XC, PWU);
   constexpr int UNR = (PF || (CWU == 12 && XC == 64)) ? 2 : 1;   // pairs in flight per wave (register budget)
   constexpr int RN = PF ? (MODE == ELL_S ? 40 : 34) : 8;
   extern __shared__ __attribute__((aligned(16))) double tile[];
@@ -283,42 +283,6 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU, SL)) void ell_
 #pragma unroll
           for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; if (k < cols) tile[k * XC + (jj ^ (k & 15))] = r[u]; }
         }
-      }
-    } else if (SL) {
-      // symmetric source, lower triangle authoritative (element (i, j), i >= j, at i + ld j):
-      //   columns k < x0        : rows x0.. are below the diagonal -> direct, lanes = x
-      //   columns k >= x0 + XC  : (x, k) lives at (k, x) -> for one x the k run is contiguous: lanes = k
-      //   the XC x XC block on the diagonal: both passes, each keeps its half
-      const int x0 = sidx * XC;
-      const int xq = tid % XC, kq = tid / XC;
-      const bool okx = x0 + xq < a.X;
-      const double* __restrict__ row = Src + x0 + (okx ? xq : 0);
-      const int kd_end = min(cols, x0 + XC);
-      for (int k0 = 0; k0 < kd_end; k0 += (NT / XC) * 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = k0 + kq + (NT / XC) * u; r[u] = (okx && k < kd_end) ? row[(long)k * a.ldsrc] : 0.0; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = k0 + kq + (NT / XC) * u;
-          if (k < kd_end && (k < x0 || x0 + xq >= k)) tile[k * XC + (xq ^ (k & 15))] = r[u];
-        }
-      }
-      for (int jj = wave; jj < XC; jj += NW) {
-        const int xr = x0 + jj;                       // source row = stored column xr, rows k > xr
-        const bool ok = xr < a.X;
-        const double* __restrict__ col = Src + (long)(ok ? xr : 0) * a.ldsrc;
-        for (int k0 = x0; k0 < cols; k0 += 64 * 8) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { const int k = k0 + lane + 64 * u; r[u] = (ok && k < cols) ? col[k] : 0.0; }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int k = k0 + lane + 64 * u;
-            if (k < cols && k > xr) tile[k * XC + (jj ^ (k & 15))] = r[u];
-          }
-        }
-      }
-      if (x0 + XC > a.X) {   // ragged last slab: rows beyond X are zero
-        for (int e = tid; e < cols * XC; e += NT) { const int k = e / XC, xx2 = e % XC; if (x0 + xx2 >= a.X) tile[k * XC + (xx2 ^ (k & 15))] = 0.0; }
       }
     } else {
       // straight copy, 8 loads in flight per thread
@@ -446,11 +410,11 @@ int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, 
   CHECK_LAUNCH();
 }
 
-template <int MODE, int CWU, int XC, int PWU, bool SL = false>
+template <int MODE, int CWU, int XC, int PWU>
 static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC, PWU, SL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC, PWU>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -458,11 +422,11 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   const int xchunks = (a.X + XC - 1) / XC;
   // big batch: one workgroup streams all slabs of its filter (next slab prefetched under the pair walk,
   // coefficients staged once); small batch: one workgroup per slab (latency)
-  a.slabs_per_wg = (ell_tile_pf(MODE, CWU, XC, PWU, SL) && a.batch >= 1024) ? xchunks : 1;
+  a.slabs_per_wg = (ell_tile_pf(MODE, CWU, XC, PWU) && a.batch >= 1024) ? xchunks : 1;
   if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
   const int grid = ((a.batch + 7) / 8) * 8 * wgs;
-  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU, SL>), dim3(grid), dim3(ell_tile_threads(MODE, CWU, XC, PWU, SL)), lds, s, a);
+  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU>), dim3(grid), dim3(ell_tile_threads(MODE, CWU, XC, PWU)), lds, s, a);
   return (int)hipGetLastError();
 }
 // which form / instantiation the launcher picks: xc = 64 / 32 (slab form) or 0 (gather form)
@@ -489,16 +453,10 @@ bool ell_uses_slab_form(const EllMulArgs& a) {
   return xc != 0;
 }
 
-bool ell_accepts_lower_source(const EllMulArgs& a) {
-  int xc, cwu, pwu; size_t lds;
-  ell_pick(a, &xc, &cwu, &pwu, &lds);
-  return xc == 64 && cwu == 12;
-}
-
 void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n) {
   int xc, cwu, pwu; size_t lds;
   ell_pick(a, &xc, &cwu, &pwu, &lds);
-  if (xc) snprintf(buf, n, "ell_tile_kernel<%d,%d,%d,%d,%s>", mode, cwu, xc, pwu, a.src_lower ? "true" : "false");
+  if (xc) snprintf(buf, n, "ell_tile_kernel<%d,%d,%d,%d>", mode, cwu, xc, pwu);
   else snprintf(buf, n, "ell_mul_kernel<%d,%d>", mode, cwu);
 }
 
@@ -508,14 +466,6 @@ static int launch_ell_tile_m(const EllMulArgs& a, hipStream_t s, bool* done) {
   ell_pick(a, &xc, &cwu, &pwu, &lds);
   *done = xc != 0;
   const bool n12 = cwu == 12;
-  if (a.src_lower) {   // symmetric lower-only source: instantiated for the G modes at XC = 64, 12 common slots
-    if constexpr (MODE == ELL_G || MODE == ELL_GF) {
-      if (xc == 64 && n12) return pwu == 9 ? launch_ell_tile_t<MODE, 12, 64, 9, true>(a, lds, s)
-                                          : launch_ell_tile_t<MODE, 12, 64, ELL_PW, true>(a, lds, s);
-    }
-    *done = true;
-    return (int)hipErrorInvalidValue;
-  }
   if (xc == 64 && pwu == 9) return launch_ell_tile_t<MODE, 12, 64, 9>(a, lds, s);
   if (xc == 64) return n12 ? launch_ell_tile_t<MODE, 12, 64, ELL_PW>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 64, ELL_PW>(a, lds, s);
   if (xc == 32) return n12 ? launch_ell_tile_t<MODE, 12, 32, ELL_PW>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 32, ELL_PW>(a, lds, s);

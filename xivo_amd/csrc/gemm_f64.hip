@@ -473,13 +473,6 @@ static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
   if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
       !getenv("XIVO_HIP_TILE"))
     wn = 2;
-  // symmetric output with memory-initialised fp64 accumulators (T = K(HP) - P, lower + mirror): rectangular
-  // 128x64 tiles, diagonal-crossing tiles computed in full (lower_only == 2) - more MFMA work than the strip
-  // tiles (6/8 vs ~4.5/8 of the square) but three workgroups per CU; A/B knob XIVO_HIP_T_RECT
-  if (a.lower_only == 2 && (a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT) && !a.fp32 && a.Mp == a.Np &&
-      a.Mp > 128 && getenv("XIVO_HIP_T_RECT")) {
-    wm = 4; wn = 2;
-  }
   *wm_out = wm; *wn_out = wn;
 }
 
