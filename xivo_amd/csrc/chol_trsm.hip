@@ -747,7 +747,9 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   // The register kernel is 170-200 KB of straight-line code executed once per factor. On some MI355X nodes of the
   // pool it runs 2.6x slower (1.77 vs 0.67 ms per 4096 factors; the large-code GEMM variants lose ~10 % on the same
   // nodes, the small looping kernels nothing), which makes it a liability for throughput: big batches use the
-  // compact one-wave kernel (0.76 / 0.80 ms on fast / slow nodes), small ones the register kernel (76 vs 178 us).
+  // compact one-wave kernel (0.71-0.76 / 0.80 ms on fast / slow nodes), small ones the register kernel (76 vs 178 us).
+  // (A looped twin of the register kernel - runtime column loop, constant subscripts under uniform guards, 25 KB -
+  //  keeps all 21 blocks live around the diagonal code and spills: 1.42 ms / 102 us. Not kept.)
   static const bool reg_always = getenv("XIVO_HIP_CHOL_REG") != nullptr;   // A/B knob
   if (!old_kernel && nb <= 12 && (g.batch < 512 || reg_always)) {
     const int mirror = nb > 11 ? 1 : 0;   // only the streamed solve (nb >= 12) reads the mirrored upper triangle
