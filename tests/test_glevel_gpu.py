@@ -83,28 +83,34 @@ def test_stacking_with_and_without_fill_quirk(built, fix):
         assert np.array_equal(got[b][2], dR)
 
 
+@pytest.mark.parametrize("flags,path", [(0, 1), (FLAG_FIX_GROUP_BLOCK, 1), (64, 0)])   # 64 = XIVO_HIP_FLAG_DENSE_H
 @pytest.mark.parametrize("name,N", [("pinhole", None), ("equi", 251)])
-def test_filter_update_equals_reference_over_inliers_only(built, name, N):
+def test_filter_update_equals_reference_over_inliers_only(built, name, N, flags, path):
     """jac -> gate -> stack -> UpdateJosephForm on device == the reference flow where
-    rejected features are simply not stacked (update.cpp:105-141)."""
+    rejected features are simply not stacked (update.cpp:105-141); through the compressed rows emitted by the
+    stack kernel (with and without the FillJacobianBlock quirk) and through the dense pipeline."""
     cam = CAMS[name]
     ng, nf, F, B = (8, 60, 60, 3) if N else (5, 14, 14, 3)
-    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 4, cam, N=N)
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 4, cam, N=N, flags=flags)
     feats["xp"][1, [0, 5]] += 55.0; xp[1, [0, 5]] += 55.0
     P = np.array([spd(lay.N, 30 + b) * 1e-4 for b in range(B)])
     with ctx:
         ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
         ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)
+        assert ctx.last_path() == path
         err = ctx.get_err(); Pn = ctx.download_P()
         assert (ctx.get_status() == 0).all()
+    rejected = 0
     for b in range(B):
         Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, b)
         m, _, _ = orc.mh_gate(orc.mh_distances(Js, P[b], inns, R_VIS), MH, MULT, 5)
         idx = np.nonzero(m)[0]
-        H, inn, dR = orc.stack_measurements(Js[idx], inns[idx], sc["ref"][b][idx], sc["sind"][b][idx], lay, R_VIS)
+        rejected += int((~m).sum())
+        H, inn, dR = orc.stack_measurements(Js[idx], inns[idx], sc["ref"][b][idx], sc["sind"][b][idx], lay, R_VIS,
+                                            fix_group_block=bool(flags & FLAG_FIX_GROUP_BLOCK))
         e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
-    assert (~m).sum() == 0 or True
+    assert rejected >= 2
 
 
 def test_oos_rows_match_slow_givens(built):
