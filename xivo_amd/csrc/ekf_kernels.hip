@@ -8,6 +8,10 @@
 //  oos_kernel           ComputeOOSJacobian(+Internal) + SlowGivens
 //                                                          src/oos.cpp:8-89, src/helpers.cpp:13-23
 //  propagate_cov_kernel covariance cross-block tail        src/rk4.cpp:92-102
+//  subfilter_kernel     Feature::SubfilterUpdate + Criteria::Candidate(Strict) + Feature::score
+//                                                          src/feature.cpp:246-297,133-142, src/options.cpp:10-33
+//  absorb_error_kernel  Estimator::AbsorbError             src/estimator.cpp:875-921
+//  givens_kernel        xivo::Givens / xivo::QR            src/helpers.cpp:27-101
 //  p_* kernels          host edits of P_
 // (all paths relative to /root/reference). These are HBM/L2-bound byte movers
 // or tiny per-feature 3x3 chains: one thread / one wave64 per feature, wave

@@ -84,12 +84,11 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const double* __restrict
   if (tid == 0) e.pw[filt] = s_pw;
 }
 
-// ---------------------------------------------------------------- out = H_ell (x) Src
-// Workgroup = (filter, chunk of 256 values of the contiguous index, range of 16-row blocks of H).
-// For a big batch one workgroup walks ALL row blocks of its chunk, so every source element is
-// fetched from HBM by exactly one workgroup (its re-reads - a group block is shared by the features
-// anchored to it - hit L1/L2) and the common columns are loaded once; for a small batch the row blocks
-// are spread over workgroups instead (latency mode). Slot indices / values are wave-uniform scalar loads.
+// ---------------------------------------------------------------- out = H_ell (x) Src, gather form
+// Fallback for sources too wide for the slab form below (more than ~528 columns). Workgroup = (filter, chunk of
+// 256 values of the contiguous index, range of 16-row blocks of H); every lane streams the columns its pair
+// names straight from L2 / Infinity Cache (a group block is re-fetched by every feature anchored to it: ~4x
+// the size of the source per filter). Slot indices / values are wave-uniform scalar loads.
 template <int MODE, int CWU>
 __global__ __launch_bounds__(256) void ell_mul_kernel(EllMulArgs a) {
   const int xchunks = (a.X + 255) / 256;
