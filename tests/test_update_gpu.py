@@ -15,6 +15,7 @@ CASES = [  # (N, F) -> M = 2F ; BASELINE.json configs + TUM-VI default build + r
     (100, 192),   # M = 384 = the largest factor the solver is built for (24 blocks); M > N is legal
     (176, 88),    # Mp = Np = 176: the largest single-workgroup triangle of the block-list kernel
     (192, 96),    # first size that falls back to strip tiles / the streamed solve
+    (600, 20),    # source too wide for the LDS slab: gather form of the compressed-row kernels
 ]
 
 
