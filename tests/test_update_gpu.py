@@ -333,3 +333,32 @@ def test_profile_reports_kernels_bytes_and_path(built):
             assert prof[st]["bytes_per_launch"] > 0 and prof[st]["flops_per_launch"] > 0
         assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<10")   # B = 16: the latency kernel
         assert prof["trsm_gain"]["kernel"] == "trsm_lds_f64_kernel<10>"
+
+
+@pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])
+def test_ill_conditioned_innovation_covariance(built, flags):
+    """cond(S) ~ 1e7 (P with eigenvalues over 8 decades, R = 1e-6): the gain carries ~1e-7 relative error, which
+    is exactly what the Joseph correction term is for. Both pipelines must stay inside the tolerances and report
+    SPD factors; the sparse pipeline forms that correction on the fp32 MFMA."""
+    N, F, B = 150, 40, 3
+    rng = np.random.default_rng(3)
+    _, H, inn, _ = synth.s_level(N, F, B, seed=5)
+    H *= 0.05
+    P = np.empty((B, N, N))
+    for b in range(B):
+        Q, _ = np.linalg.qr(rng.normal(size=(N, N)))
+        P[b] = (Q * np.logspace(-8, 0, N)) @ Q.T
+        P[b] = 0.5 * (P[b] + P[b].T)
+    dR = np.full((B, 2 * F), 1e-6)
+    with Context(N, 2 * F, B, flags=flags) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        assert (ctx.get_status() == 0).all()
+        err = ctx.get_err(); Pn = ctx.download_P()
+    for b in range(B):
+        S = H[b] @ P[b] @ H[b].T + np.diag(dR[b])
+        assert np.linalg.cond(S) > 1e6
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P
+        assert rel_fro(err[b], e_ref) < 1e-6     # dx inherits cond(S) * eps from ANY solver; 1e-8 is for cond ~ 1e3
+        w = np.linalg.eigvalsh(Pn[b])
+        assert w.min() > -1e-9 * w.max()
