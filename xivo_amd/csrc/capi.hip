@@ -457,18 +457,6 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     StageTimer st(c, ST_HP, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
     if (launch_ell_mul(ELL_HP, a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
-  if (gate) {
-    GateEllArgs a{}; a.ell = e;
-    a.H = c->dense_valid ? c->H + (long)b0 * c->sH : nullptr; a.strideH = c->sH; a.ldh = ldh;
-    a.HT = c->dense_valid ? c->HT + (long)b0 * c->sHT : nullptr; a.strideHT = c->sHT; a.ldht = Np; a.HP = HP; a.PHT = PHT;
-    a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
-    a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
-    a.F = gate->F; a.Np = Np; a.batch = B;
-    a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
-    StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
-    c->gate_sparse_last = 0;
-    if (launch_gate_ell(a, c->stream)) return XIVO_HIP_ERR_HIP;
-  }
   {
     EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
@@ -476,6 +464,19 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
     StageTimer st(c, ST_S, nnz_flops * Mp * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     if (launch_ell_mul(ELL_S, a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  if (gate) {
+    GateEllArgs a{}; a.ell = e;
+    a.H = c->dense_valid ? c->H + (long)b0 * c->sH : nullptr; a.strideH = c->sH; a.ldh = ldh;
+    a.HT = c->dense_valid ? c->HT + (long)b0 * c->sHT : nullptr; a.strideHT = c->sHT; a.ldht = Np; a.HP = HP; a.PHT = PHT;
+    a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
+    a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
+    a.F = gate->F; a.Np = Np; a.batch = B;
+    a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.from_S = 1;   // distances from the diagonal blocks of S
+    a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
+    StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
+    c->gate_sparse_last = 0;
+    if (launch_gate_ell(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {
     CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;

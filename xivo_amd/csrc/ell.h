@@ -81,6 +81,9 @@ struct GateEllArgs {
   unsigned char* mask; double* dist;       // [batch x F]
   int F, Np, batch;
   double R, thresh, mult; int min_inliers;
+  // from_S: S = H P H^T + diag(R) of ALL candidate rows is already formed (ell<S>); the 2x2 blocks S_f are read
+  // off its diagonal and the rows / columns of the rejected pairs are then decoupled in place (0, unit diagonal)
+  double* S; long strideS; int lds; int Mp; int from_S;
 };
 int launch_gate_ell(const GateEllArgs& a, hipStream_t s);
 

@@ -345,8 +345,18 @@ __global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
   double* val = a.ell.val + (long)filt * a.ell.stride_val();
   double* PHT = a.PHT + (long)filt * a.strideHT;
   double* inn = a.inn + (long)filt * a.strideInn;
+  double* Sm = a.from_S ? a.S + (long)filt * a.strideS : nullptr;
+  if (a.from_S) {
+    const double* dr0 = a.diagR + (long)filt * a.strideR;
+    for (int f = tid; f < a.F; f += nt) {
+      const double s00 = Sm[2 * f + (long)(2 * f) * a.lds] - dr0[2 * f] + a.R;
+      const double s10 = Sm[2 * f + 1 + (long)(2 * f) * a.lds];
+      const double s11 = Sm[2 * f + 1 + (long)(2 * f + 1) * a.lds] - dr0[2 * f + 1] + a.R;
+      sdist[f] = mh_dist_2x2(s00, s10, s11, inn[2 * f], inn[2 * f + 1]);
+    }
+  }
   // one wave per feature, one lane per slot: the 2 x 28 gathers of a feature are one round trip
-  for (int f = wave; f < a.F; f += nwv) {
+  for (int f = wave; f < (a.from_S ? 0 : a.F); f += nwv) {
     const double* c0 = PHT + (long)(2 * f) * a.ldht;      // P J0^T
     const double* c1 = c0 + a.ldht;                       // P J1^T
     double s00 = 0, s10 = 0, s11 = 0;
@@ -393,6 +403,24 @@ __global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
       PHT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
       HP[2 * f + (long)n * a.ldh] = 0.0;          // read by the gather form of ELL_S only
       HP[2 * f + 1 + (long)n * a.ldh] = 0.0;
+    }
+    if (Sm) {
+      for (int jx = tid; jx < a.Mp; jx += nt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = 2 * f + i;
+          Sm[r + (long)jx * a.lds] = 0.0;
+          Sm[jx + (long)r * a.lds] = 0.0;
+        }
+      }
+    }
+  }
+  if (Sm) {
+    __syncthreads();
+    for (int f = tid; f < a.F; f += nt) {
+      if (sdist[f] < th) continue;
+      Sm[2 * f + (long)(2 * f) * a.lds] = 1.0;
+      Sm[2 * f + 1 + (long)(2 * f + 1) * a.lds] = 1.0;
     }
   }
 }
