@@ -3,9 +3,6 @@
 // columns of the source matrix, 512 B per wave load; no MFMA (a row pair has 21 non-zeros).
 #include "ell.h"
 #include "gate_device.h"
-#ifndef XIVO_ELL_SCALAR_COMMON
-#define XIVO_ELL_SCALAR_COMMON 0
-#endif
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -184,8 +181,6 @@ constexpr int ell_tile_threads(int mode, int cwu, int xc, int pwu) {
 template <int MODE, int CWU, int XC, int PWU>
 __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile_kernel(EllMulArgs a) {
   constexpr int NSLOT = CWU + PWU;   // PWU: private slots actually walked (9 for XIVO's group + feature blocks)
-  // experiment: coefficients of the common slots as scalar loads (48 SGPRs per pair), private ones from LDS
-  constexpr bool SCALAR_COMMON = XIVO_ELL_SCALAR_COMMON;
   constexpr int NT = ell_tile_threads(MODE, CWU, XC, PWU), NW = NT / 64;
   // slab elements per thread held in registers while the previous slab is being consumed
   // covers every cols the LDS can hold (XC = 64: <= 272; XC = 32: <= 528)
@@ -269,7 +264,6 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
 
   const int xx = lane % XC, half = lane / XC;
   ell_cint* idx0 = (ell_cint*)(a.ell.idx + (long)filt * a.ell.stride_idx());
-  ell_cdouble* cv = (ell_cdouble*)(a.ell.val + (long)filt * a.ell.stride_val());   // coefficients, scalar path
   ell_cdouble* dR = (ell_cdouble*)(a.diagR + (long)filt * a.strideR);
   auto slab = [&](int k) -> double { return tile[k * XC + (xx ^ (k & 15))]; };
 
@@ -322,10 +316,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
       for (int t = 0; t < PWU; ++t) sv[t] = slab(pi[t]);
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-      for (int t = 0; t < CWU; ++t) {
-        if (SCALAR_COMMON) { a0 = fma(cv[(long)p * ELL_W * 2 + 2 * t], cm[t], a0); a1 = fma(cv[(long)p * ELL_W * 2 + 2 * t + 1], cm[t], a1); }
-        else { const d2 v = pv[t]; a0 = fma(v[0], cm[t], a0); a1 = fma(v[1], cm[t], a1); }
-      }
+      for (int t = 0; t < CWU; ++t) { const d2 v = pv[t]; a0 = fma(v[0], cm[t], a0); a1 = fma(v[1], cm[t], a1); }
 #pragma unroll
       for (int t = 0; t < PWU; ++t) { const d2 v = pv[CWU + t]; a0 = fma(v[0], sv[t], a0); a1 = fma(v[1], sv[t], a1); }
       if (!live) continue;
