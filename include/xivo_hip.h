@@ -251,6 +251,28 @@ typedef struct {
 int xivo_hip_subfilter_update(xivo_hip_ctx* ctx, int b0, int nb, int n, xivo_subfilter_feat* feats,
                               const xivo_subfilter_opts* opts);
 
+/* ---- Estimator::Propagate on the device-resident state ----
+ * For filters [b0, b0 + nb): integrates the nominal motion state (Rsb, Tsb, Vsb, bg, ba, Rsg of the resident
+ * xivo_pose_in, xivo_hip_set_scene) over dt with RK4Step (src/rk4.cpp:35-103) or PrinceDormandStep
+ * (src/princedormand.cpp:85-221) under the fixed sub-stepping of src/rk4.cpp:13-32 (stepsize < 0: one step),
+ * ComposeMotion (src/estimator.cpp:598-613) and ComputeMotionJacobianAt (src/estimator.cpp:615-704, default build:
+ * no online IMU calibration), accumulates the sub-step transitions, then applies the covariance tail
+ * (src/rk4.cpp:92-102) and P_mm += Qmodel (src/estimator.cpp:590) to the resident P. The IMU sample is modelled as
+ * the reference does between two messages: value at the start + slope * t (src/estimator.cpp:556-575). */
+typedef struct {
+  double gyro[3], accel[3];              /* last_gyro_, last_accel_ */
+  double slope_gyro[3], slope_accel[3];  /* (curr - last) / dt */
+  double dt;
+} xivo_imu_in;
+typedef struct {
+  double Qimu[144];    /* 12 x 12, column-major (gyro, accel, gyro-bias, accel-bias noise) */
+  double Qmodel[529];  /* 23 x 23, column-major */
+  double g[3];         /* gravity in the spatial frame before Rsg */
+  int method;          /* 0: RK4, 1: PrinceDormand */
+  double stepsize;     /* cfg integration stepsize (0.002); < 0: a single step of length dt */
+} xivo_prop_opts;
+int xivo_hip_propagate(xivo_hip_ctx* ctx, int b0, int nb, const xivo_imu_in* imu, const xivo_prop_opts* opts);
+
 /* ---- orthonormal Givens elimination and QR measurement compression ----
  * Batched xivo::Givens (src/helpers.cpp:48-75) and xivo::QR (src/helpers.cpp:78-101) on host arrays, nb
  * independent problems of identical shape, column-major, leading dimension = rows.

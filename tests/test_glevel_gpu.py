@@ -374,3 +374,105 @@ def test_device_qr_compression(built, rows, nx, eff):
         assert ro[b] == r
         assert np.abs(xd[b] - xo).max() < 1e-10 and np.abs(Hxd[b] - Hxo).max() < 1e-10
         assert np.abs(np.tril(Hxd[b][:r], -1)).max() < 1e-10
+
+
+@pytest.mark.parametrize("method,dt,stepsize", [("RK4", 0.005, 0.002), ("PrinceDormand", 0.0045, 0.002), ("RK4", 0.003, -1.0),
+                                                ("PrinceDormand", 0.01, 0.002)])
+def test_device_propagate_state_and_covariance(built, method, dt, stepsize):
+    """Estimator::Propagate entirely on the device (nominal motion state of the resident scene + P): RK4Step /
+    PrinceDormandStep with the reference's sub-stepping, ComposeMotion, ComputeMotionJacobianAt, covariance tail and
+    + Qmodel, vs the oracle (pinned against the line-faithful Sophus/Eigen RK4Step, golden rk4_*)."""
+    from xivo_amd.lib import imu_dtype
+    cam = synth.PINHOLE
+    B, ng, nf = 4, 3, 6
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, nf, B, 21, cam)
+    rng = np.random.default_rng(12)
+    N = lay.N
+    st = []
+    for b in range(B):
+        X = orc.MotionState(sc["Rsb"][b], sc["Tsb"][b], rng.normal(size=3) * 0.5, rng.normal(size=3) * 0.01,
+                            rng.normal(size=3) * 0.05, orc.so3_exp(np.array([0.02, -0.03, 0.0])))
+        st.append(X)
+        poses[b]["Vsb"] = X.Vsb; poses[b]["bg"] = X.bg; poses[b]["ba"] = X.ba; poses[b]["Rsg"] = X.Rsg.T.reshape(-1)
+    P = np.array([spd(N, 50 + b) * 1e-3 for b in range(B)])
+    imu = np.zeros(B, dtype=imu_dtype)
+    imu["gyro"] = rng.normal(size=(B, 3)) * 0.3; imu["accel"] = rng.normal(size=(B, 3)) + np.array([0, 0, 9.8])
+    imu["slope_gyro"] = rng.normal(size=(B, 3)) * 5.0; imu["slope_accel"] = rng.normal(size=(B, 3)) * 20.0
+    imu["dt"] = dt * (1.0 + 0.1 * np.arange(B))        # a different sub-step pattern per filter
+    Qi = np.diag(rng.uniform(1e-6, 1e-4, 12)); A = rng.normal(size=(23, 23)) * 1e-4; Qm = A @ A.T
+    g = np.array([0.0, 0.0, -9.796])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
+        ctx.propagate(imu, Qi, Qm, g, method=method, stepsize=stepsize)
+        Pn = ctx.download_P()
+        pose_d, _, _ = ctx.get_scene()
+    for b in range(B):
+        Xr, Pr = orc.propagate(st[b], P[b], imu["gyro"][b], imu["accel"][b], imu["slope_gyro"][b], imu["slope_accel"][b],
+                               float(imu["dt"][b]), Qi, Qm, g, method=method, stepsize=stepsize)
+        assert rel_fro(Pn[b], Pr) < 1e-11
+        assert np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - Xr.Rsb).max() < 1e-12
+        assert np.abs(pose_d[b]["Tsb"] - Xr.Tsb).max() < 1e-12 and np.abs(pose_d[b]["Vsb"] - Xr.Vsb).max() < 1e-12
+        assert np.array_equal(pose_d[b]["bg"], st[b].bg) and np.array_equal(pose_d[b]["ba"], st[b].ba)
+
+
+def test_resident_full_frame_loop(built):
+    """The whole per-frame EKF loop with nothing but the IMU sample and the pixels crossing the boundary:
+    Propagate -> ComputeInstateJacobians -> MHGating -> FilterUpdate -> AbsorbError, three frames, state and P
+    resident on the device (src/estimator.cpp:539-592, src/manager.cpp:72-104, src/estimator.cpp:875-921)."""
+    from xivo_amd.lib import imu_dtype
+    cam = synth.EQUI
+    B, ng, nf = 2, 4, 10
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, nf, B, 33, cam)
+    rng = np.random.default_rng(6)
+    N = lay.N
+    ref = []
+    for b in range(B):
+        X = orc.MotionState(sc["Rsb"][b], sc["Tsb"][b], rng.normal(size=3) * 0.05, rng.normal(size=3) * 1e-3,
+                            rng.normal(size=3) * 1e-2, np.eye(3))
+        poses[b]["Vsb"] = X.Vsb; poses[b]["bg"] = X.bg; poses[b]["ba"] = X.ba; poses[b]["Rsg"] = X.Rsg.T.reshape(-1)
+        ref.append(dict(X=X, P=spd(N, 80 + b) * 1e-4, gR=sc["gR"][b].copy(), gT=sc["gT"][b].copy(), x=sc["x"][b].copy()))
+    P0 = np.array([r["P"] for r in ref])
+    Qi = np.eye(12) * 1e-6; Qm = np.eye(23) * 1e-8; g = np.array([0.0, 0.0, -9.8])
+    frames = []
+    for k in range(3):
+        imu = np.zeros(B, dtype=imu_dtype)
+        imu["gyro"] = rng.normal(size=(B, 3)) * 0.02; imu["accel"] = rng.normal(size=(B, 3)) * 0.05 + np.array([0, 0, 9.8])
+        imu["slope_gyro"] = rng.normal(size=(B, 3)); imu["slope_accel"] = rng.normal(size=(B, 3))
+        imu["dt"] = 0.005
+        frames.append((imu, xp + rng.normal(size=xp.shape) * 0.6))
+    with ctx:
+        ctx.upload_P(P0); ctx.set_scene(poses, groups, feats)
+        for imu, meas in frames:
+            ctx.propagate(imu, Qi, Qm, g, method="RK4", stepsize=0.002)
+            pcur, gcur, fcur = ctx.get_scene()
+            fcur["xp"] = meas
+            ctx.set_scene(pcur, gcur, fcur)
+            ctx.filter_update(R_VIS, MH, MULT, 5, True)
+            ctx.absorb_error()
+        Pn = ctx.download_P()
+        pose_d, group_d, feat_d = ctx.get_scene()
+    for b in range(B):
+        r = ref[b]
+        for imu, meas in frames:
+            r["X"], r["P"] = orc.propagate(r["X"], r["P"], imu["gyro"][b], imu["accel"][b], imu["slope_gyro"][b],
+                                           imu["slope_accel"][b], 0.005, Qi, Qm, g, method="RK4", stepsize=0.002)
+            Js, inns = [], []
+            for i in range(nf):
+                rr = int(sc["ref"][b, i])
+                J, inn, _ = orc.compute_jacobian(r["x"][i], meas[b, i], r["gR"][rr], r["gT"][rr], r["X"].Rsb, r["X"].Tsb,
+                                                 sc["Rbc"][b], sc["Tbc"][b], cam, lay, rr, int(sc["sind"][b, i]))
+                Js.append(J); inns.append(inn)
+            Js, inns = np.array(Js), np.array(inns)
+            m, _, _ = orc.mh_gate(orc.mh_distances(Js, r["P"], inns, R_VIS), MH, MULT, 5)
+            H, inn, dR = orc.stack_measurements(Js[m], inns[m], sc["ref"][b][m], sc["sind"][b][m], lay, R_VIS)
+            dx, r["P"], _ = orc.update_joseph(H, r["P"], inn, dR)
+            stt = dict(Rsb=r["X"].Rsb, Tsb=r["X"].Tsb, Vsb=r["X"].Vsb, bg=r["X"].bg, ba=r["X"].ba, Rbc=sc["Rbc"][b].copy(),
+                       Tbc=sc["Tbc"][b].copy(), Rsg=r["X"].Rsg, gR=r["gR"], gT=r["gT"], x=r["x"], sind=sc["sind"][b])
+            orc.absorb_error(stt, dx, lay, range(ng), np.nonzero(m)[0])
+            r["X"] = orc.MotionState(stt["Rsb"], stt["Tsb"], stt["Vsb"], stt["bg"], stt["ba"], stt["Rsg"])
+            sc["Rbc"][b], sc["Tbc"][b] = stt["Rbc"], stt["Tbc"]
+        assert rel_fro(Pn[b], r["P"]) < TOL_P
+        assert np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - r["X"].Rsb).max() < 1e-9
+        assert np.abs(pose_d[b]["Tsb"] - r["X"].Tsb).max() < 1e-9 and np.abs(pose_d[b]["Vsb"] - r["X"].Vsb).max() < 1e-9
+        assert np.abs(pose_d[b]["bg"] - r["X"].bg).max() < 1e-10 and np.abs(pose_d[b]["ba"] - r["X"].ba).max() < 1e-10
+        assert np.abs(feat_d[b]["x"] - r["x"]).max() < 1e-9

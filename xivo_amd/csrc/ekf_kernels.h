@@ -75,6 +75,18 @@ int launch_stack(const StackArgs& a, hipStream_t s);
 int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses, const xivo_group_in* groups,
                      int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s);
 
+// Estimator::Propagate state + covariance stages (rk4.cpp, princedormand.cpp, estimator.cpp:598-704): one wave per
+// filter; writes the accumulated transition Phi and the new P_mm (23 x 23 each, column-major) for the tail kernel
+struct PropStateArgs {
+  xivo_pose_in* poses; const xivo_imu_in* imu;      // [nb] each (poses already offset to b0)
+  const double* Qimu; const double* Qmodel;         // device copies
+  double g[3]; int method; double stepsize;
+  const double* P; long strideP; int ldp;           // resident covariance (offset to b0)
+  double* Phi_out; double* Pmm_out;                 // [nb][529]
+  int batch;
+};
+int launch_propagate_state(const PropStateArgs& a, hipStream_t s);
+
 // xivo::Givens / xivo::QR (helpers.cpp:27-101), one wave per problem, in place
 struct GivensArgs {
   double* x; double* Hx; double* Hf;   // per problem: x [rows], Hx [rows x nx], Hf [rows x nf] (null for QR)

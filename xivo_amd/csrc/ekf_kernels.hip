@@ -889,6 +889,210 @@ __global__ __launch_bounds__(256) void propagate_cov_kernel(double* Pall, long s
   for (int e = tid; e < nm * nm; e += 256) P[(e % nm) + (long)(e / nm) * ldp] = Pmm[e];
 }
 
+// ---------------------------------------------------------------- propagation: state + covariance stages
+// Runge-Kutta tableaus as the reference codes them: RK4Step (rk4.cpp:35-103; the 4th stage re-uses the half-step
+// IMU sample, :77) and PrinceDormandStep (princedormand.cpp:85-221, weights :195-200).
+struct RkTableau { int ns; double a[7][6]; double c_step[7]; double c_imu[7]; double b[7]; };
+__constant__ RkTableau kTableau[2] = {
+    {4,
+     {{0}, {0.5}, {0.0, 0.5}, {0.0, 0.0, 1.0}},
+     {0.0, 0.5, 0.5, 1.0},
+     {0.0, 0.5, 0.5, 0.5},
+     {1 / 6.0, 2 / 6.0, 2 / 6.0, 1 / 6.0}},
+    {7,
+     {{0},
+      {2 / 9.0},
+      {1 / 12.0, 3 / 12.0},
+      {55 / 324.0, -75 / 324.0, 200 / 324.0},
+      {83 / 330.0, -195 / 330.0, 305 / 330.0, 27 / 330.0},
+      {-19 / 28.0, 63 / 28.0, 4 / 28.0, -108 / 28.0, 88 / 28.0},
+      {38 / 400.0, 0.0, 240 / 400.0, -243 / 400.0, 330 / 400.0, 35 / 400.0}},
+     {0.0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1.0, 1.0},
+     {0.0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1.0, 1.0},
+     {0.0862, 0.0, 0.6660, -0.7857, 0.9570, 0.0965, -0.0200}}};
+
+struct MotionRegs { M3 Rsb, Rsg; V3 Tsb, Vsb, bg, ba; };
+
+// ComposeMotion, estimator.cpp:598-613 (default build: Cg = Ca = I)
+__device__ __forceinline__ void compose_motion_dev(MotionRegs& X, const V3& V, const V3& gyro, const V3& accel, double dt,
+                                                   const V3& g) {
+  V3 gc, ac;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { gc.v[i] = gyro.v[i] - X.bg.v[i]; ac.v[i] = accel.v[i] - X.ba.v[i]; }
+  const V3 Ra = m3_mulv(X.Rsb, ac), Rg = m3_mulv(X.Rsg, g);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    X.Tsb.v[i] += V.v[i] * dt;                                   // :608
+    X.Vsb.v[i] += (Ra.v[i] + Rg.v[i]) * dt;                      // :609
+  }
+  X.Rsb = m3_mul(X.Rsb, so3_exp_dev(gc.v[0] * dt, gc.v[1] * dt, gc.v[2] * dt));   // :610
+}
+
+// One wave per filter. All 64 lanes carry the (tiny) nominal state redundantly; the 23 x 23 matrices live in LDS,
+// column-major with leading dimension 23, and every matrix operation is spread element-wise over the lanes.
+__global__ __launch_bounds__(64) void propagate_state_kernel(PropStateArgs a) {
+  constexpr int NM = 23, NN = NM * NM, NG = NM * 12;
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x, filt = blockIdx.x;
+  const RkTableau& tab = kTableau[a.method ? 1 : 0];
+  const int ns = tab.ns;
+  double* Pmm = sm;            // P_mm at the start of the sub-step
+  double* Phi = Pmm + NN;      // accumulated transition
+  double* F = Phi + NN;
+  double* P0 = F + NN;
+  double* S1 = P0 + NN;        // scratch
+  double* S2 = S1 + NN;
+  double* GQG = S2 + NN;
+  double* G = GQG + NN;        // 23 x 12
+  double* GQ = G + NG;
+  double* Q = GQ + NG;         // 12 x 12
+  double* FKs = Q + 144;       // [ns][NN]
+  double* PKs = FKs + ns * NN;
+  auto E = [](int i, int j) { return i + NM * j; };
+
+  const double* Pg = a.P + (long)filt * a.strideP;
+  for (int e = lane; e < NN; e += 64) {
+    const int i = e % NM, j = e / NM;
+    Pmm[e] = Pg[i + (long)j * a.ldp];
+    Phi[e] = i == j ? 1.0 : 0.0;
+  }
+  for (int e = lane; e < 144; e += 64) Q[e] = a.Qimu[e];
+  xivo_pose_in& pose = a.poses[filt];
+  MotionRegs X;
+  X.Rsb = m3_from_colmajor(pose.Rsb); X.Rsg = m3_from_colmajor(pose.Rsg);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { X.Tsb.v[i] = pose.Tsb[i]; X.Vsb.v[i] = pose.Vsb[i]; X.bg.v[i] = pose.bg[i]; X.ba.v[i] = pose.ba[i]; }
+  const xivo_imu_in im = a.imu[filt];
+  V3 gyro{{im.gyro[0], im.gyro[1], im.gyro[2]}}, accel{{im.accel[0], im.accel[1], im.accel[2]}};
+  const V3 sg{{im.slope_gyro[0], im.slope_gyro[1], im.slope_gyro[2]}}, sa{{im.slope_accel[0], im.slope_accel[1], im.slope_accel[2]}};
+  const V3 gv{{a.g[0], a.g[1], a.g[2]}};
+  __syncthreads();
+
+  double total = 0.0;
+  const double dt = im.dt;
+  // fixed sub-stepping with the half-step tail trick (rk4.cpp:13-32, princedormand.cpp:62-81)
+  while (total < dt || a.stepsize < 0) {
+    double h = a.stepsize;
+    if (a.stepsize < 0) h = dt;
+    else if (total + h > dt) h = dt - total;
+    else if (total + h + 0.5 * h > dt) h = 0.5 * h;
+
+    V3 Ks[7];
+    for (int st = 0; st < ns; ++st) {
+      MotionRegs X0 = X;
+      const double ti = tab.c_imu[st] * h;
+      V3 gi, ai;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gi.v[i] = gyro.v[i] + sg.v[i] * ti; ai.v[i] = accel.v[i] + sa.v[i] * ti; }
+      if (st > 0) {
+        V3 V{{0, 0, 0}};
+        for (int q = 0; q < st; ++q)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) V.v[i] += tab.a[st][q] * Ks[q].v[i];
+        compose_motion_dev(X0, V, gi, ai, tab.c_step[st] * h, gv);
+      }
+      Ks[st] = X0.Vsb;
+      // ComputeMotionJacobianAt (estimator.cpp:615-704): F (23 x 23), G (23 x 12)
+      V3 gc, ac;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gc.v[i] = gi.v[i] - X0.bg.v[i]; ac.v[i] = ai.v[i] - X0.ba.v[i]; }
+      const M3 dW_dW = m3_neg(hat(gc));
+      const M3 dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));
+      const M3 dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));
+      for (int e = lane; e < NN; e += 64) F[e] = 0.0;
+      for (int e = lane; e < NG; e += 64) G[e] = 0.0;
+      __syncthreads();
+      if (lane < 9) {
+        const int i = lane / 3, j = lane % 3;
+        F[E(0 + i, 0 + j)] = dW_dW.m[i][j];          // Wsb <- Wsb
+        F[E(6 + i, 0 + j)] = dV_dW.m[i][j];          // Vsb <- Wsb
+        F[E(6 + i, 12 + j)] = -X0.Rsb.m[i][j];       // Vsb <- ba
+        if (j < 2) F[E(6 + i, 21 + j)] = dV_dWsg.m[i][j];   // Vsb <- Wsg (2 dof)
+        G[(6 + i) + NM * (3 + j)] = -X0.Rsb.m[i][j]; // Vsb <- accel noise
+        if (i == j) {
+          F[E(0 + i, 9 + i)] = -1.0;                 // Wsb <- bg
+          F[E(3 + i, 6 + i)] = 1.0;                  // Tsb <- Vsb
+          G[(0 + i) + NM * i] = -1.0;                // Wsb <- gyro noise
+          G[(9 + i) + NM * (6 + i)] = 1.0;           // bg  <- gyro-bias noise
+          G[(12 + i) + NM * (9 + i)] = 1.0;          // ba  <- accel-bias noise
+        }
+      }
+      __syncthreads();
+      // FK_st = F + F (sum_q a_q FK_q) h ;  P0 = Pmm + (sum_q a_q PK_q) h   (rk4.cpp:49-88)
+      for (int e = lane; e < NN; e += 64) {
+        double sf = 0.0, sp = 0.0;
+        for (int q = 0; q < st; ++q) { sf += tab.a[st][q] * FKs[q * NN + e]; sp += tab.a[st][q] * PKs[q * NN + e]; }
+        S1[e] = sf;
+        P0[e] = Pmm[e] + sp * h;
+      }
+      __syncthreads();
+      for (int e = lane; e < NN; e += 64) {
+        const int i = e % NM, j = e / NM;
+        double fk = 0.0;
+        if (st > 0) for (int k = 0; k < NM; ++k) fk = fma(F[E(i, k)], S1[E(k, j)], fk);
+        FKs[st * NN + e] = F[e] + fk * h;
+      }
+      // G Q G^T
+      for (int e = lane; e < NG; e += 64) {
+        const int i = e % NM, j = e / NM;
+        double v = 0.0;
+        for (int k = 0; k < 12; ++k) v = fma(G[i + NM * k], Q[k + 12 * j], v);
+        GQ[e] = v;
+      }
+      __syncthreads();
+      for (int e = lane; e < NN; e += 64) {
+        const int i = e % NM, j = e / NM;
+        double v = 0.0, fp = 0.0, pf = 0.0;
+        for (int k = 0; k < 12; ++k) v = fma(GQ[i + NM * k], G[j + NM * k], v);
+        for (int k = 0; k < NM; ++k) { fp = fma(F[E(i, k)], P0[E(k, j)], fp); pf = fma(P0[E(i, k)], F[E(j, k)], pf); }
+        PKs[st * NN + e] = (fp + pf) + v;            // F P0 + P0 F^T + G Q G^T
+      }
+      __syncthreads();
+    }
+    // combine the stages
+    V3 Kt{{0, 0, 0}};
+    for (int q = 0; q < ns; ++q)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Kt.v[i] += tab.b[q] * Ks[q].v[i];
+    V3 ge, ae;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ge.v[i] = gyro.v[i] + sg.v[i] * h; ae.v[i] = accel.v[i] + sa.v[i] * h; }
+    compose_motion_dev(X, Kt, ge, ae, h, gv);
+    for (int e = lane; e < NN; e += 64) {
+      double fk = 0.0, pk = 0.0;
+      for (int q = 0; q < ns; ++q) { fk += tab.b[q] * FKs[q * NN + e]; pk += tab.b[q] * PKs[q * NN + e]; }
+      Pmm[e] += pk * h;                              // rk4.cpp:92-93
+      S1[e] = ((e % NM) == (e / NM) ? 1.0 : 0.0) + fk * h;   // Phi_step = I + FK h
+    }
+    __syncthreads();
+    for (int e = lane; e < NN; e += 64) {            // Phi <- Phi_step Phi
+      const int i = e % NM, j = e / NM;
+      double v = 0.0;
+      for (int k = 0; k < NM; ++k) v = fma(S1[E(i, k)], Phi[E(k, j)], v);
+      S2[e] = v;
+    }
+    __syncthreads();
+    for (int e = lane; e < NN; e += 64) Phi[e] = S2[e];
+    __syncthreads();
+    gyro = ge; accel = ae;                           // rk4.cpp:27-28
+    total += h;
+    if (a.stepsize < 0) break;
+  }
+  // P_mm += Qmodel (estimator.cpp:590); results for the tail kernel; nominal state back
+  for (int e = lane; e < NN; e += 64) {
+    a.Pmm_out[(long)filt * NN + e] = Pmm[e] + a.Qmodel[e];
+    a.Phi_out[(long)filt * NN + e] = Phi[e];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pose.Tsb[i] = X.Tsb.v[i]; pose.Vsb[i] = X.Vsb.v[i];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pose.Rsb[i + 3 * j] = X.Rsb.m[i][j];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- fp64 MFMA issue-rate probe
 // Every wave issues `iters` x 8 independent v_mfma_f64_16x16x4_f64; wave 0 of
 // block 0 also reports the shader-clock cycles it spent (s_memtime), so the
@@ -992,6 +1196,19 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
   if (nm > 32) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(propagate_cov_kernel, dim3(nb), dim3(256), nm * nm * sizeof(double), s, P, strideP, ldp, N,
                      nm, Phi, Pmm, b0);
+  CHECK_LAUNCH();
+}
+int launch_propagate_state(const PropStateArgs& a, hipStream_t s) {
+  if (a.batch <= 0) return 0;
+  const int ns = a.method ? 7 : 4;
+  const size_t lds = (size_t)(7 * 529 + 2 * 276 + 144 + 2 * ns * 529) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(propagate_state_kernel, dim3(a.batch), dim3(64), lds, s, a);
   CHECK_LAUNCH();
 }
 int launch_mfma_peak(double* sink, int iters, int blocks, hipStream_t s) {

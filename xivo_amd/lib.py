@@ -50,6 +50,10 @@ class _OosC(C.Structure):
 
 
 assert oos_dtype.itemsize == C.sizeof(_OosC), (oos_dtype.itemsize, C.sizeof(_OosC))
+imu_dtype = np.dtype([("gyro", "f8", 3), ("accel", "f8", 3), ("slope_gyro", "f8", 3), ("slope_accel", "f8", 3), ("dt", "f8")])
+prop_opts_dtype = np.dtype([("Qimu", "f8", 144), ("Qmodel", "f8", 529), ("g", "f8", 3), ("method", "i4"), ("_pad", "i4"),
+                            ("stepsize", "f8")])
+assert imu_dtype.itemsize == 104 and prop_opts_dtype.itemsize == (144 + 529 + 3) * 8 + 16
 subfilter_dtype = np.dtype([("x", "f8", 3), ("P", "f8", 9), ("xp", "f8", 2), ("outlier_counter", "f8"), ("score", "f8"),
                             ("ref_sind", "i4"), ("status", "i4"), ("init_counter", "i4"), ("candidate", "i4")])
 subfilter_opts_dtype = np.dtype([("Rtri", "f8"), ("MH_thresh", "f8"), ("ready_steps", "i4"), ("_pad", "i4"),
@@ -98,6 +102,7 @@ _SIGS = {
     "xivo_hip_stage_kernel": [C.c_void_p, C.c_int],
     "xivo_hip_stage_bytes": [C.c_void_p, C.c_int],
     "xivo_hip_absorb_error": [C.c_void_p, C.c_int],
+    "xivo_hip_propagate": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_givens": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                         C.c_void_p],
     "xivo_hip_qr": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
@@ -363,6 +368,15 @@ class Context:
         ro = np.zeros(nb, dtype=np.int32)
         self._check(self.lib.xivo_hip_qr(self.h, nb, rows, nx, _ptr(xd), _ptr(Hxd), effective_rows, _ptr(ro)))
         return ro, xd, np.transpose(Hxd, (0, 2, 1)).copy()
+
+    def propagate(self, imu, Qimu, Qmodel, g, method="RK4", stepsize=0.002, b0=0):
+        """imu: [nb] array of imu_dtype; Qimu 12x12, Qmodel 23x23 (numpy row-major, symmetric or not)."""
+        imu = np.ascontiguousarray(imu, dtype=imu_dtype)
+        o = np.zeros(1, dtype=prop_opts_dtype)
+        o["Qimu"] = np.asarray(Qimu, dtype=np.float64).T.reshape(-1)
+        o["Qmodel"] = np.asarray(Qmodel, dtype=np.float64).T.reshape(-1)
+        o["g"] = g; o["method"] = 0 if method == "RK4" else 1; o["stepsize"] = stepsize
+        self._check(self.lib.xivo_hip_propagate(self.h, b0, len(imu), _ptr(imu), _ptr(o)))
 
     def absorb_error(self, B=None):
         self._check(self.lib.xivo_hip_absorb_error(self.h, self.batch if B is None else B))
