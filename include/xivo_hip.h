@@ -271,7 +271,9 @@ typedef struct {
   int method;          /* 0: RK4, 1: PrinceDormand */
   double stepsize;     /* cfg integration stepsize (0.002); < 0: a single step of length dt */
 } xivo_prop_opts;
-int xivo_hip_propagate(xivo_hip_ctx* ctx, int b0, int nb, const xivo_imu_in* imu, const xivo_prop_opts* opts);
+/* imu: [nb][n_imu] - the n_imu samples of each filter since its last call (one Estimator::Propagate each, in order);
+ * their transitions are accumulated on chip and the O(23 N) cross-covariance tail is applied once. */
+int xivo_hip_propagate(xivo_hip_ctx* ctx, int b0, int nb, int n_imu, const xivo_imu_in* imu, const xivo_prop_opts* opts);
 
 /* ---- orthonormal Givens elimination and QR measurement compression ----
  * Batched xivo::Givens (src/helpers.cpp:48-75) and xivo::QR (src/helpers.cpp:78-101) on host arrays, nb

@@ -476,3 +476,39 @@ def test_resident_full_frame_loop(built):
         assert np.abs(pose_d[b]["Tsb"] - r["X"].Tsb).max() < 1e-9 and np.abs(pose_d[b]["Vsb"] - r["X"].Vsb).max() < 1e-9
         assert np.abs(pose_d[b]["bg"] - r["X"].bg).max() < 1e-10 and np.abs(pose_d[b]["ba"] - r["X"].ba).max() < 1e-10
         assert np.abs(feat_d[b]["x"] - r["x"]).max() < 1e-9
+
+
+def test_device_propagate_several_imu_samples_in_one_call(built):
+    """Five IMU samples per filter in one xivo_hip_propagate call == five Estimator::Propagate calls in a row (each
+    adds Qmodel); the cross-covariance tail is applied once with the accumulated transition."""
+    from xivo_amd.lib import imu_dtype
+    cam = synth.PINHOLE
+    B, ng, nf, K = 3, 3, 6, 5
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, nf, B, 22, cam)
+    rng = np.random.default_rng(13)
+    st = []
+    for b in range(B):
+        X = orc.MotionState(sc["Rsb"][b], sc["Tsb"][b], rng.normal(size=3) * 0.3, rng.normal(size=3) * 0.01,
+                            rng.normal(size=3) * 0.05, np.eye(3))
+        st.append(X)
+        poses[b]["Vsb"] = X.Vsb; poses[b]["bg"] = X.bg; poses[b]["ba"] = X.ba; poses[b]["Rsg"] = X.Rsg.T.reshape(-1)
+    P = np.array([spd(lay.N, 60 + b) * 1e-3 for b in range(B)])
+    imu = np.zeros((B, K), dtype=imu_dtype)
+    imu["gyro"] = rng.normal(size=(B, K, 3)) * 0.3; imu["accel"] = rng.normal(size=(B, K, 3)) + np.array([0, 0, 9.8])
+    imu["slope_gyro"] = rng.normal(size=(B, K, 3)) * 5.0; imu["slope_accel"] = rng.normal(size=(B, K, 3)) * 20.0
+    imu["dt"] = 0.005
+    Qi = np.diag(rng.uniform(1e-6, 1e-4, 12)); A = rng.normal(size=(23, 23)) * 1e-4; Qm = A @ A.T
+    g = np.array([0.0, 0.0, -9.796])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
+        ctx.propagate(imu, Qi, Qm, g, method="RK4", stepsize=0.002)
+        Pn = ctx.download_P()
+        pose_d, _, _ = ctx.get_scene()
+    for b in range(B):
+        Xr, Pr = st[b], P[b]
+        for k in range(K):
+            Xr, Pr = orc.propagate(Xr, Pr, imu["gyro"][b, k], imu["accel"][b, k], imu["slope_gyro"][b, k],
+                                   imu["slope_accel"][b, k], 0.005, Qi, Qm, g, method="RK4", stepsize=0.002)
+        assert rel_fro(Pn[b], Pr) < 1e-11
+        assert np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - Xr.Rsb).max() < 1e-12
+        assert np.abs(pose_d[b]["Tsb"] - Xr.Tsb).max() < 1e-12 and np.abs(pose_d[b]["Vsb"] - Xr.Vsb).max() < 1e-12

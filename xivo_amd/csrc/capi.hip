@@ -1039,24 +1039,24 @@ int xivo_hip_propagate_cov(xivo_hip_ctx* c, int b0, int nb, int nm, const double
   return XIVO_HIP_OK;
 }
 
-int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, const xivo_imu_in* imu, const xivo_prop_opts* o) {
-  if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || !imu || !o || c->N < 23 || c->lay.group_begin < 23)
+int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_imu_in* imu, const xivo_prop_opts* o) {
+  if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || !imu || !o || n_imu <= 0 || c->N < 23 || c->lay.group_begin < 23)
     return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
-  for (int b = 0; b < nb; ++b)
+  for (size_t b = 0; b < (size_t)nb * n_imu; ++b)
     if (!(imu[b].dt > 0.0) || (o->stepsize >= 0 && o->stepsize < 1e-6)) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   const size_t per = 529;
-  const size_t imu_d = ((size_t)nb * sizeof(xivo_imu_in) + 7) / 8;      // in doubles
+  const size_t imu_d = ((size_t)nb * n_imu * sizeof(xivo_imu_in) + 7) / 8;      // in doubles
   int rc = ensure_staging(c, 2 * per * nb + 144 + 529 + imu_d);
   if (rc) return rc;
   double* dPhi = c->staging; double* dPmm = dPhi + per * nb; double* dQi = dPmm + per * nb; double* dQm = dQi + 144;
   xivo_imu_in* dImu = reinterpret_cast<xivo_imu_in*>(dQm + 529);
   HIP_TRY(hipMemcpyAsync(dQi, o->Qimu, 144 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(dQm, o->Qmodel, 529 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(dImu, imu, (size_t)nb * sizeof(xivo_imu_in), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(dImu, imu, (size_t)nb * n_imu * sizeof(xivo_imu_in), hipMemcpyHostToDevice, c->stream));
   PropStateArgs a;
-  a.poses = c->poses + b0; a.imu = dImu; a.Qimu = dQi; a.Qmodel = dQm;
+  a.poses = c->poses + b0; a.imu = dImu; a.n_imu = n_imu; a.Qimu = dQi; a.Qmodel = dQm;
   a.g[0] = o->g[0]; a.g[1] = o->g[1]; a.g[2] = o->g[2]; a.method = o->method; a.stepsize = o->stepsize;
   a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
   {

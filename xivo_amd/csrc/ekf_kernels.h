@@ -78,7 +78,8 @@ int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* pose
 // Estimator::Propagate state + covariance stages (rk4.cpp, princedormand.cpp, estimator.cpp:598-704): one wave per
 // filter; writes the accumulated transition Phi and the new P_mm (23 x 23 each, column-major) for the tail kernel
 struct PropStateArgs {
-  xivo_pose_in* poses; const xivo_imu_in* imu;      // [nb] each (poses already offset to b0)
+  xivo_pose_in* poses; const xivo_imu_in* imu;      // [nb] / [nb][n_imu] (poses already offset to b0)
+  int n_imu;
   const double* Qimu; const double* Qmodel;         // device copies
   double g[3]; int method; double stepsize;
   const double* P; long strideP; int ldp;           // resident covariance (offset to b0)

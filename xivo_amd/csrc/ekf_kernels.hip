@@ -889,6 +889,38 @@ __global__ __launch_bounds__(256) void propagate_cov_kernel(double* Pall, long s
   for (int e = tid; e < nm * nm; e += 256) P[(e % nm) + (long)(e / nm) * ldp] = Pmm[e];
 }
 
+// Compile-time motion size (the default build's 23): col / row stay in registers (with a run-time nm the two
+// arrays are indexed dynamically and live in scratch: 1.83 ms per 4096 filters at N = 251 instead of 0.2).
+template <int NM>
+__global__ __launch_bounds__(256) void propagate_cov_fixed_kernel(double* Pall, long strideP, int ldp, int N,
+                                                                  const double* Phi_all, const double* Pmm_all, int b0) {
+  const int filt = b0 + blockIdx.x, tid = threadIdx.x;
+  double* P = Pall + (long)filt * strideP;
+  const double* Phi = Phi_all + (long)blockIdx.x * NM * NM;
+  const double* Pmm = Pmm_all + (long)blockIdx.x * NM * NM;
+  __shared__ double sPhi[NM * NM];  // column-major
+  for (int e = tid; e < NM * NM; e += 256) sPhi[e] = Phi[e];
+  __syncthreads();
+  for (int j = NM + tid; j < N; j += 256) {
+    double col[NM], row[NM];
+#pragma unroll
+    for (int k = 0; k < NM; ++k) { col[k] = P[k + (long)j * ldp]; row[k] = P[j + (long)k * ldp]; }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      double s = 0.0, t = 0.0;
+#pragma unroll
+      for (int k = 0; k < NM; ++k) {
+        const double ph = sPhi[i + k * NM];
+        s = fma(ph, col[k], s);   // (Phi P_ms)(i, j)
+        t = fma(row[k], ph, t);   // (P_sm Phi^T)(j, i)
+      }
+      P[i + (long)j * ldp] = s;
+      P[j + (long)i * ldp] = t;
+    }
+  }
+  for (int e = tid; e < NM * NM; e += 256) P[(e % NM) + (long)(e / NM) * ldp] = Pmm[e];
+}
+
 // ---------------------------------------------------------------- propagation: state + covariance stages
 // Runge-Kutta tableaus as the reference codes them: RK4Step (rk4.cpp:35-103; the 4th stage re-uses the half-step
 // IMU sample, :77) and PrinceDormandStep (princedormand.cpp:85-221, weights :195-200).
@@ -928,12 +960,14 @@ __device__ __forceinline__ void compose_motion_dev(MotionRegs& X, const V3& V, c
   X.Rsb = m3_mul(X.Rsb, so3_exp_dev(gc.v[0] * dt, gc.v[1] * dt, gc.v[2] * dt));   // :610
 }
 
-// One wave per filter. All 64 lanes carry the (tiny) nominal state redundantly; the 23 x 23 matrices live in LDS,
-// column-major with leading dimension 23, and every matrix operation is spread element-wise over the lanes.
-__global__ __launch_bounds__(64) void propagate_state_kernel(PropStateArgs a) {
-  constexpr int NM = 23, NN = NM * NM, NG = NM * 12;
+// One workgroup of 256 threads per filter. Every thread carries the (tiny) nominal state redundantly; the 23 x 23
+// matrices live in LDS, column-major with leading dimension 23, and every matrix operation is spread element-wise
+// over the threads. F = dX'/dX has non-zero rows only for Wsb, Tsb, Vsb (rows 0..8: the biases, extrinsics and
+// gravity are constants of the motion model), so F M, M F^T and (I + FK h) Phi are 9-row / 9-column products.
+__global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
+  constexpr int NM = 23, NN = NM * NM, NG = NM * 12, NT = 256, FR = 9;   // FR: rows of F that are not identically zero
   extern __shared__ double sm[];
-  const int lane = threadIdx.x, filt = blockIdx.x;
+  const int lane = threadIdx.x, filt = blockIdx.x;   // `lane`: thread index in the workgroup
   const RkTableau& tab = kTableau[a.method ? 1 : 0];
   const int ns = tab.ns;
   double* Pmm = sm;            // P_mm at the start of the sub-step
@@ -946,28 +980,32 @@ __global__ __launch_bounds__(64) void propagate_state_kernel(PropStateArgs a) {
   double* G = GQG + NN;        // 23 x 12
   double* GQ = G + NG;
   double* Q = GQ + NG;         // 12 x 12
-  double* FKs = Q + 144;       // [ns][NN]
+  double* sKs = Q + 144;       // [7][3] stage velocities (in LDS: a register array indexed by the stage lives in scratch)
+  double* FKs = sKs + 24;      // [ns][NN]
   double* PKs = FKs + ns * NN;
   auto E = [](int i, int j) { return i + NM * j; };
 
   const double* Pg = a.P + (long)filt * a.strideP;
-  for (int e = lane; e < NN; e += 64) {
+  for (int e = lane; e < NN; e += NT) {
     const int i = e % NM, j = e / NM;
     Pmm[e] = Pg[i + (long)j * a.ldp];
     Phi[e] = i == j ? 1.0 : 0.0;
   }
-  for (int e = lane; e < 144; e += 64) Q[e] = a.Qimu[e];
+  for (int e = lane; e < 144; e += NT) Q[e] = a.Qimu[e];
   xivo_pose_in& pose = a.poses[filt];
   MotionRegs X;
   X.Rsb = m3_from_colmajor(pose.Rsb); X.Rsg = m3_from_colmajor(pose.Rsg);
 #pragma unroll
   for (int i = 0; i < 3; ++i) { X.Tsb.v[i] = pose.Tsb[i]; X.Vsb.v[i] = pose.Vsb[i]; X.bg.v[i] = pose.bg[i]; X.ba.v[i] = pose.ba[i]; }
-  const xivo_imu_in im = a.imu[filt];
-  V3 gyro{{im.gyro[0], im.gyro[1], im.gyro[2]}}, accel{{im.accel[0], im.accel[1], im.accel[2]}};
-  const V3 sg{{im.slope_gyro[0], im.slope_gyro[1], im.slope_gyro[2]}}, sa{{im.slope_accel[0], im.slope_accel[1], im.slope_accel[2]}};
   const V3 gv{{a.g[0], a.g[1], a.g[2]}};
   __syncthreads();
 
+  // one Estimator::Propagate per IMU sample; the transitions of all samples are accumulated in Phi so that the
+  // O(23 N) cross-covariance tail runs once per call instead of once per sample
+  for (int smp = 0; smp < a.n_imu; ++smp) {
+  const xivo_imu_in im = a.imu[(long)filt * a.n_imu + smp];
+  V3 gyro{{im.gyro[0], im.gyro[1], im.gyro[2]}}, accel{{im.accel[0], im.accel[1], im.accel[2]}};
+  const V3 sg{{im.slope_gyro[0], im.slope_gyro[1], im.slope_gyro[2]}}, sa{{im.slope_accel[0], im.slope_accel[1], im.slope_accel[2]}};
   double total = 0.0;
   const double dt = im.dt;
   // fixed sub-stepping with the half-step tail trick (rk4.cpp:13-32, princedormand.cpp:62-81)
@@ -977,7 +1015,6 @@ __global__ __launch_bounds__(64) void propagate_state_kernel(PropStateArgs a) {
     else if (total + h > dt) h = dt - total;
     else if (total + h + 0.5 * h > dt) h = 0.5 * h;
 
-    V3 Ks[7];
     for (int st = 0; st < ns; ++st) {
       MotionRegs X0 = X;
       const double ti = tab.c_imu[st] * h;
@@ -988,10 +1025,10 @@ __global__ __launch_bounds__(64) void propagate_state_kernel(PropStateArgs a) {
         V3 V{{0, 0, 0}};
         for (int q = 0; q < st; ++q)
 #pragma unroll
-          for (int i = 0; i < 3; ++i) V.v[i] += tab.a[st][q] * Ks[q].v[i];
+          for (int i = 0; i < 3; ++i) V.v[i] += tab.a[st][q] * sKs[3 * q + i];
         compose_motion_dev(X0, V, gi, ai, tab.c_step[st] * h, gv);
       }
-      Ks[st] = X0.Vsb;
+      if (lane < 3) sKs[3 * st + lane] = lane == 0 ? X0.Vsb.v[0] : (lane == 1 ? X0.Vsb.v[1] : X0.Vsb.v[2]);   // visible after the barriers below
       // ComputeMotionJacobianAt (estimator.cpp:615-704): F (23 x 23), G (23 x 12)
       V3 gc, ac;
 #pragma unroll
@@ -999,52 +1036,69 @@ __global__ __launch_bounds__(64) void propagate_state_kernel(PropStateArgs a) {
       const M3 dW_dW = m3_neg(hat(gc));
       const M3 dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));
       const M3 dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));
-      for (int e = lane; e < NN; e += 64) F[e] = 0.0;
-      for (int e = lane; e < NG; e += 64) G[e] = 0.0;
+      for (int e = lane; e < NN; e += NT) F[e] = 0.0;
+      for (int e = lane; e < NG; e += NT) G[e] = 0.0;
       __syncthreads();
-      if (lane < 9) {
-        const int i = lane / 3, j = lane % 3;
-        F[E(0 + i, 0 + j)] = dW_dW.m[i][j];          // Wsb <- Wsb
-        F[E(6 + i, 0 + j)] = dV_dW.m[i][j];          // Vsb <- Wsb
-        F[E(6 + i, 12 + j)] = -X0.Rsb.m[i][j];       // Vsb <- ba
-        if (j < 2) F[E(6 + i, 21 + j)] = dV_dWsg.m[i][j];   // Vsb <- Wsg (2 dof)
-        G[(6 + i) + NM * (3 + j)] = -X0.Rsb.m[i][j]; // Vsb <- accel noise
-        if (i == j) {
-          F[E(0 + i, 9 + i)] = -1.0;                 // Wsb <- bg
-          F[E(3 + i, 6 + i)] = 1.0;                  // Tsb <- Vsb
-          G[(0 + i) + NM * i] = -1.0;                // Wsb <- gyro noise
-          G[(9 + i) + NM * (6 + i)] = 1.0;           // bg  <- gyro-bias noise
-          G[(12 + i) + NM * (9 + i)] = 1.0;          // ba  <- accel-bias noise
+      // (compile-time i, j: a run-time subscript into the 3x3 register matrices would push them to scratch)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (lane != 3 * i + j) continue;
+          F[E(0 + i, 0 + j)] = dW_dW.m[i][j];          // Wsb <- Wsb
+          F[E(6 + i, 0 + j)] = dV_dW.m[i][j];          // Vsb <- Wsb
+          F[E(6 + i, 12 + j)] = -X0.Rsb.m[i][j];       // Vsb <- ba
+          if (j < 2) F[E(6 + i, 21 + j)] = dV_dWsg.m[i][j];   // Vsb <- Wsg (2 dof)
+          G[(6 + i) + NM * (3 + j)] = -X0.Rsb.m[i][j]; // Vsb <- accel noise
+          if (i == j) {
+            F[E(0 + i, 9 + i)] = -1.0;                 // Wsb <- bg
+            F[E(3 + i, 6 + i)] = 1.0;                  // Tsb <- Vsb
+            G[(0 + i) + NM * i] = -1.0;                // Wsb <- gyro noise
+            G[(9 + i) + NM * (6 + i)] = 1.0;           // bg  <- gyro-bias noise
+            G[(12 + i) + NM * (9 + i)] = 1.0;          // ba  <- accel-bias noise
+          }
         }
       }
       __syncthreads();
       // FK_st = F + F (sum_q a_q FK_q) h ;  P0 = Pmm + (sum_q a_q PK_q) h   (rk4.cpp:49-88)
-      for (int e = lane; e < NN; e += 64) {
+      for (int e = lane; e < NN; e += NT) {
         double sf = 0.0, sp = 0.0;
         for (int q = 0; q < st; ++q) { sf += tab.a[st][q] * FKs[q * NN + e]; sp += tab.a[st][q] * PKs[q * NN + e]; }
         S1[e] = sf;
         P0[e] = Pmm[e] + sp * h;
       }
       __syncthreads();
-      for (int e = lane; e < NN; e += 64) {
+      for (int e = lane; e < NN; e += NT) {
         const int i = e % NM, j = e / NM;
         double fk = 0.0;
-        if (st > 0) for (int k = 0; k < NM; ++k) fk = fma(F[E(i, k)], S1[E(k, j)], fk);
+        if (st > 0 && i < FR) {
+#pragma unroll
+          for (int k = 0; k < NM; ++k) fk = fma(F[E(i, k)], S1[E(k, j)], fk);
+        }
         FKs[st * NN + e] = F[e] + fk * h;
       }
       // G Q G^T
-      for (int e = lane; e < NG; e += 64) {
+      for (int e = lane; e < NG; e += NT) {
         const int i = e % NM, j = e / NM;
         double v = 0.0;
+#pragma unroll
         for (int k = 0; k < 12; ++k) v = fma(G[i + NM * k], Q[k + 12 * j], v);
         GQ[e] = v;
       }
       __syncthreads();
-      for (int e = lane; e < NN; e += 64) {
+      for (int e = lane; e < NN; e += NT) {
         const int i = e % NM, j = e / NM;
         double v = 0.0, fp = 0.0, pf = 0.0;
+#pragma unroll
         for (int k = 0; k < 12; ++k) v = fma(GQ[i + NM * k], G[j + NM * k], v);
-        for (int k = 0; k < NM; ++k) { fp = fma(F[E(i, k)], P0[E(k, j)], fp); pf = fma(P0[E(i, k)], F[E(j, k)], pf); }
+        if (i < FR) {
+#pragma unroll
+          for (int k = 0; k < NM; ++k) fp = fma(F[E(i, k)], P0[E(k, j)], fp);
+        }
+        if (j < FR) {
+#pragma unroll
+          for (int k = 0; k < NM; ++k) pf = fma(P0[E(i, k)], F[E(j, k)], pf);
+        }
         PKs[st * NN + e] = (fp + pf) + v;            // F P0 + P0 F^T + G Q G^T
       }
       __syncthreads();
@@ -1053,34 +1107,41 @@ __global__ __launch_bounds__(64) void propagate_state_kernel(PropStateArgs a) {
     V3 Kt{{0, 0, 0}};
     for (int q = 0; q < ns; ++q)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) Kt.v[i] += tab.b[q] * Ks[q].v[i];
+      for (int i = 0; i < 3; ++i) Kt.v[i] += tab.b[q] * sKs[3 * q + i];
     V3 ge, ae;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { ge.v[i] = gyro.v[i] + sg.v[i] * h; ae.v[i] = accel.v[i] + sa.v[i] * h; }
     compose_motion_dev(X, Kt, ge, ae, h, gv);
-    for (int e = lane; e < NN; e += 64) {
+    for (int e = lane; e < NN; e += NT) {
       double fk = 0.0, pk = 0.0;
       for (int q = 0; q < ns; ++q) { fk += tab.b[q] * FKs[q * NN + e]; pk += tab.b[q] * PKs[q * NN + e]; }
       Pmm[e] += pk * h;                              // rk4.cpp:92-93
       S1[e] = ((e % NM) == (e / NM) ? 1.0 : 0.0) + fk * h;   // Phi_step = I + FK h
     }
     __syncthreads();
-    for (int e = lane; e < NN; e += 64) {            // Phi <- Phi_step Phi
+    for (int e = lane; e < NN; e += NT) {            // Phi <- Phi_step Phi (rows >= FR of Phi_step are identity rows)
       const int i = e % NM, j = e / NM;
-      double v = 0.0;
-      for (int k = 0; k < NM; ++k) v = fma(S1[E(i, k)], Phi[E(k, j)], v);
+      double v = Phi[e];
+      if (i < FR) {
+        v = 0.0;
+#pragma unroll
+        for (int k = 0; k < NM; ++k) v = fma(S1[E(i, k)], Phi[E(k, j)], v);
+      }
       S2[e] = v;
     }
     __syncthreads();
-    for (int e = lane; e < NN; e += 64) Phi[e] = S2[e];
+    for (int e = lane; e < NN; e += NT) Phi[e] = S2[e];
     __syncthreads();
     gyro = ge; accel = ae;                           // rk4.cpp:27-28
     total += h;
     if (a.stepsize < 0) break;
   }
-  // P_mm += Qmodel (estimator.cpp:590); results for the tail kernel; nominal state back
-  for (int e = lane; e < NN; e += 64) {
-    a.Pmm_out[(long)filt * NN + e] = Pmm[e] + a.Qmodel[e];
+  for (int e = lane; e < NN; e += NT) Pmm[e] += a.Qmodel[e];    // P_mm += Qmodel (estimator.cpp:590), per Propagate
+  __syncthreads();
+  }
+  // results for the tail kernel; nominal state back
+  for (int e = lane; e < NN; e += NT) {
+    a.Pmm_out[(long)filt * NN + e] = Pmm[e];
     a.Phi_out[(long)filt * NN + e] = Phi[e];
   }
   if (lane == 0) {
@@ -1194,6 +1255,10 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
                          const double* Pmm, int b0, int nb, hipStream_t s) {
   (void)Np;
   if (nm > 32) return (int)hipErrorInvalidValue;
+  if (nm == 23) {
+    hipLaunchKernelGGL(propagate_cov_fixed_kernel<23>, dim3(nb), dim3(256), 0, s, P, strideP, ldp, N, Phi, Pmm, b0);
+    CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(propagate_cov_kernel, dim3(nb), dim3(256), nm * nm * sizeof(double), s, P, strideP, ldp, N,
                      nm, Phi, Pmm, b0);
   CHECK_LAUNCH();
@@ -1201,14 +1266,14 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s) {
   if (a.batch <= 0) return 0;
   const int ns = a.method ? 7 : 4;
-  const size_t lds = (size_t)(7 * 529 + 2 * 276 + 144 + 2 * ns * 529) * sizeof(double);
+  const size_t lds = (size_t)(7 * 529 + 2 * 276 + 144 + 24 + 2 * ns * 529) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(propagate_state_kernel, dim3(a.batch), dim3(64), lds, s, a);
+  hipLaunchKernelGGL(propagate_state_kernel, dim3(a.batch), dim3(256), lds, s, a);
   CHECK_LAUNCH();
 }
 int launch_mfma_peak(double* sink, int iters, int blocks, hipStream_t s) {

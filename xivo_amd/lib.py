@@ -102,7 +102,7 @@ _SIGS = {
     "xivo_hip_stage_kernel": [C.c_void_p, C.c_int],
     "xivo_hip_stage_bytes": [C.c_void_p, C.c_int],
     "xivo_hip_absorb_error": [C.c_void_p, C.c_int],
-    "xivo_hip_propagate": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "xivo_hip_propagate": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_givens": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                         C.c_void_p],
     "xivo_hip_qr": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
@@ -370,13 +370,17 @@ class Context:
         return ro, xd, np.transpose(Hxd, (0, 2, 1)).copy()
 
     def propagate(self, imu, Qimu, Qmodel, g, method="RK4", stepsize=0.002, b0=0):
-        """imu: [nb] array of imu_dtype; Qimu 12x12, Qmodel 23x23 (numpy row-major, symmetric or not)."""
+        """imu: [nb] or [nb, n_imu] array of imu_dtype (the samples since the last call, in order); Qimu 12x12,
+        Qmodel 23x23 (numpy row-major)."""
         imu = np.ascontiguousarray(imu, dtype=imu_dtype)
+        if imu.ndim == 1:
+            imu = imu[:, None]
+        imu = np.ascontiguousarray(imu)
         o = np.zeros(1, dtype=prop_opts_dtype)
         o["Qimu"] = np.asarray(Qimu, dtype=np.float64).T.reshape(-1)
         o["Qmodel"] = np.asarray(Qmodel, dtype=np.float64).T.reshape(-1)
         o["g"] = g; o["method"] = 0 if method == "RK4" else 1; o["stepsize"] = stepsize
-        self._check(self.lib.xivo_hip_propagate(self.h, b0, len(imu), _ptr(imu), _ptr(o)))
+        self._check(self.lib.xivo_hip_propagate(self.h, b0, imu.shape[0], imu.shape[1], _ptr(imu), _ptr(o)))
 
     def absorb_error(self, B=None):
         self._check(self.lib.xivo_hip_absorb_error(self.h, self.batch if B is None else B))
