@@ -975,9 +975,8 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
   double* F = Phi + NN;
   double* P0 = F + NN;
   double* S1 = P0 + NN;        // scratch
-  double* S2 = S1 + NN;
-  double* GQG = S2 + NN;
-  double* G = GQG + NN;        // 23 x 12
+  double* S2 = P0;             // (P0 is dead once the stages of a sub-step are combined)
+  double* G = S1 + NN;         // 23 x 12
   double* GQ = G + NG;
   double* Q = GQ + NG;         // 12 x 12
   double* sKs = Q + 144;       // [7][3] stage velocities (in LDS: a register array indexed by the stage lives in scratch)
@@ -1266,7 +1265,7 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s) {
   if (a.batch <= 0) return 0;
   const int ns = a.method ? 7 : 4;
-  const size_t lds = (size_t)(7 * 529 + 2 * 276 + 144 + 24 + 2 * ns * 529) * sizeof(double);
+  const size_t lds = (size_t)(5 * 529 + 2 * 276 + 144 + 24 + 2 * ns * 529) * sizeof(double);   // RK4: 59 KB, DP: 110 KB
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
