@@ -125,7 +125,8 @@ typedef struct {
   double x[3];        /* (X/Z, Y/Z, log Z) in the reference camera frame, feature.h:258-262 */
   double xp[2];       /* last tracked pixel, Feature::back()                 */
   int ref_sind;       /* ref_->sind(): slot of the reference group           */
-  int sind;           /* feature slot                                        */
+  int sind;           /* feature slot; -1 = absent entry: contributes no rows, is never an inlier
+                         (filters of one batch may hold different numbers of features)      */
 } xivo_feat_in;
 
 /* One out-of-state (MSCKF) feature with k observations from in-state groups
@@ -295,6 +296,41 @@ int xivo_hip_absorb_error(xivo_hip_ctx* ctx, int B);
 /* download the resident scene (any pointer may be NULL) */
 int xivo_hip_get_scene(xivo_hip_ctx* ctx, int b0, int nb, xivo_pose_in* poses, xivo_group_in* groups,
                        xivo_feat_in* feats);
+
+/* ---- resident state edits between updates, batched over filters ----
+ * The reference edits X_/P_ one filter at a time on the host (the functions cited per kind). A sequence driver that
+ * keeps thousands of filters resident cannot afford one launch per edit, so a whole frame's edits of all filters go
+ * down in one call: ops must be grouped by filter with non-decreasing `b`; the ops of one filter are applied in
+ * array order by one workgroup, different filters run concurrently. Offsets are error-state indices. */
+enum {
+  XIVO_EDIT_P_ZERO_RC = 0,     /* i0 = off, i1 = len             : as xivo_hip_p_zero_rc                              */
+  XIVO_EDIT_P_COPY_RC = 1,     /* i0 = dst, i1 = src, i2 = len   : as xivo_hip_p_copy_rc                              */
+  XIVO_EDIT_P_SET_BLOCK3 = 2,  /* i0 = off, v[0..8] = P3         : as xivo_hip_p_set_block3                           */
+  /* Estimator::AddGroupToState (src/estimator.cpp:801-816), i0 = group slot: resident group[i0] <- current (Rsb,Tsb),
+   * P rows then columns of the slot <- those of Wsb, then of Tsb */
+  XIVO_EDIT_ADD_GROUP = 3,
+  /* Estimator::RemoveGroupFromState (src/estimator.cpp:745-759), i0 = group slot */
+  XIVO_EDIT_REMOVE_GROUP = 4,
+  /* Estimator::AddFeatureToState (src/estimator.cpp:820-846) + Feature::FillCovarianceBlock (src/feature.cpp:753-760):
+   * i0 = position j in the resident feature list, i1 = feature slot sind, i2 = anchor group slot,
+   * v[0..2] = x, v[3..4] = xp, v[5..13] = the feature's own 3x3 covariance (column-major) */
+  XIVO_EDIT_ADD_FEATURE = 5,
+  /* Estimator::RemoveFeatureFromState (src/estimator.cpp:762-783), i0 = position j: its slot's rows/cols are zeroed
+   * and the entry becomes absent (sind = -1) */
+  XIVO_EDIT_REMOVE_FEATURE = 6,
+  /* new tracked pixel of the feature at position i0 (Feature::back()), v[0..1] = xp */
+  XIVO_EDIT_SET_XP = 7
+};
+typedef struct {
+  int b;             /* filter */
+  int kind;          /* XIVO_EDIT_* */
+  int i0, i1, i2;
+  int reserved;
+  double v[14];
+} xivo_edit_op;
+/* F = length of the resident feature list the ops index (positions 0..F-1; entries never written are absent).
+ * F <= M_max / 2. Sets the list length used by the following Jacobian / gating / update calls. */
+int xivo_hip_edit_batch(xivo_hip_ctx* ctx, int F, int n_ops, const xivo_edit_op* ops);
 
 /* ---- covariance propagation tail (src/rk4.cpp:92-102, src/estimator.cpp:590) */
 /* P_mm <- Pmm_new ; P_ms <- Phi P_ms ; P_sm <- P_sm Phi^T. Phi and Pmm_new

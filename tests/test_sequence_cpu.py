@@ -1,0 +1,129 @@
+"""Host side of the image-free sequence driver: the point-cloud world / IMU simulator, the IMU message
+bookkeeping, the csv / trajectory formats, and the runner's life-cycle decisions against the oracle backend. No GPU."""
+import numpy as np
+
+import xivo_oracle as orc
+from seq_oracle import OracleBackend
+from xivo_amd import formats, pcw, sequence
+
+K = np.array([[275.0, 0, 320.0], [0, 275.0, 240.0], [0, 0, 1.0]])
+
+
+def test_pcw_track_ids_follow_visibility():
+    """ids start at 10000 (counter0, src/feature.h), are kept while a point stays in the image, dropped when it leaves,
+    and a point that comes back is a new track (scripts/point_cloud_world.py:64-99)."""
+    w = pcw.RandomPCW(npts=400, seed=3)
+    Rbc = pcw.so3_exp(np.array([-1.57079633, 0, 0]))
+    ids0, m0 = w.generate_measurements(Rbc, np.zeros(3), K, 640, 480, 0.0)
+    assert len(ids0) > 5 and ids0.min() == 10000 and np.array_equal(np.sort(ids0), 10000 + np.arange(len(ids0)))
+    assert np.all(m0[:, 2] > 0) and np.all((m0[:, 0] >= 0) & (m0[:, 0] <= 640) & (m0[:, 1] >= 0) & (m0[:, 1] <= 480))
+    ids1, _ = w.generate_measurements(Rbc, np.array([0.01, 0, 0]), K, 640, 480, 0.0)
+    common = np.intersect1d(ids0, ids1)
+    assert len(common) >= len(ids0) - 3                       # a small step keeps nearly every track
+    # look away, then back: every point gets a fresh id
+    w.generate_measurements(Rbc @ pcw.so3_exp(np.array([0, np.pi, 0])), np.zeros(3), K, 640, 480, 0.0)
+    ids3, _ = w.generate_measurements(Rbc, np.zeros(3), K, 640, 480, 0.0)
+    assert len(ids3) == len(ids0) and ids3.min() > ids1.max()
+    # same seed, same stream
+    w2 = pcw.RandomPCW(npts=400, seed=3)
+    ids0b, m0b = w2.generate_measurements(Rbc, np.zeros(3), K, 640, 480, 0.0)
+    assert np.array_equal(ids0, ids0b) and np.array_equal(m0, m0b)
+
+
+def test_imu_sim_is_consistent_with_the_filters_motion_model():
+    """Noise-free IMU samples of the analytic trajectory, pushed through ImuFeeder and the oracle's Estimator::Propagate
+    (Dormand-Prince, the reference's sub-stepping), reproduce the ground truth: ties the simulator's accelerometer /
+    gyro conventions to src/estimator.cpp:598-613."""
+    cfg = sequence.SequenceConfig()
+    for motion in ("lissajous", "trefoil"):
+        s = pcw.TrajectorySim(motion, noise_accel=0, noise_gyro=0)
+        a0, g0 = s.meas(0.0)
+        fd = sequence.ImuFeeder(1, 0.0, [g0], [a0])
+        X = orc.MotionState(np.eye(3), np.zeros(3), s.vel(0), np.zeros(3), np.zeros(3), np.eye(3))
+        P = cfg.P_init()[:23, :23]
+        for k in range(1, 201):
+            t = k * 0.0025
+            a, g = s.meas(t)
+            fd.imu(t, np.array([g]), np.array([a]))
+            r = fd.take()[0, 0]
+            X, P = orc.propagate(X, P, r["gyro"], r["accel"], r["slope_gyro"], r["slope_accel"], float(r["dt"]),
+                                 cfg.Qimu_matrix(), cfg.Qmodel_matrix(), cfg.gravity, method="PD", stepsize=0.002)
+        R, T = s.gsb(0.5)
+        assert np.abs(X.Rsb - R).max() < 1e-4 and np.abs(X.Tsb - T).max() < 2e-3 and np.abs(X.Vsb - s.vel(0.5)).max() < 5e-3
+
+
+def test_imu_feeder_mirrors_propagate_bookkeeping():
+    """src/estimator.cpp:548-575: an IMU message integrates from the last sample with the slope to the new one; a
+    camera message extrapolates along the last slope, and nothing is propagated when timestamps coincide."""
+    fd = sequence.ImuFeeder(2, 0.0, np.zeros((2, 3)), np.ones((2, 3)))
+    fd.imu(0.01, np.full((2, 3), 0.2), np.full((2, 3), 3.0))
+    fd.visual(0.01)                                              # dt == 0: no record
+    fd.visual(0.015)                                             # extrapolation
+    fd.imu(0.02, np.full((2, 3), 0.1), np.full((2, 3), 1.0))
+    rec = fd.take()
+    assert rec.shape == (2, 3) and fd.take() is None
+    assert np.allclose(rec["dt"][0], [0.01, 0.005, 0.005])
+    assert np.allclose(rec["gyro"][0, 0], 0.0) and np.allclose(rec["slope_gyro"][0, 0], 20.0)
+    assert np.allclose(rec["gyro"][0, 1], 0.2) and np.allclose(rec["slope_gyro"][0, 1], 20.0)      # same slope
+    assert np.allclose(rec["gyro"][0, 2], 0.3)                                                       # 0.2 + 20 * 0.005
+    assert np.allclose(rec["slope_gyro"][0, 2], (0.1 - 0.3) / 0.005)
+    assert np.allclose(rec["accel"][1, 2], 3.0 + 200.0 * 0.005)
+
+
+def test_csv_and_trajectory_formats(tmp_path):
+    """EuRoC / TUM-VI csv as DataLoader reads it (src/loader.cpp:14-60) and the `ts Tsb Wsb` dump of src/app/vio.cpp."""
+    rng = np.random.default_rng(0)
+    ts = (np.arange(20) * 5_000_000 + 1_520_000_000_000_000_000).astype(np.int64)
+    gyro, accel = rng.normal(size=(20, 3)), rng.normal(size=(20, 3))
+    o = rng.permutation(20)
+    formats.write_imu_csv(str(tmp_path / "imu0"), ts[o], gyro[o], accel[o])
+    ts2, g2, a2 = formats.read_imu_csv(str(tmp_path / "imu0"))
+    assert np.array_equal(ts2, ts) and np.array_equal(g2, gyro) and np.array_equal(a2, accel)    # sorted, lossless
+    cam = tmp_path / "cam0"
+    cam.mkdir()
+    (cam / "data.csv").write_text("#timestamp [ns],filename\n%d,b.png\n%d,a.png\n" % (ts[4], ts[0]))
+    cts, paths = formats.read_cam_csv(str(cam))
+    assert list(cts) == [ts[0], ts[4]] and paths[0].endswith("data/a.png")
+    ev = formats.merge_streams(ts, cts)
+    assert ev[0][:2] == (int(ts[0]), 0) and ev[1][:2] == (int(ts[0]), 1)     # IMU first at equal stamps
+    assert [e[0] for e in ev] == sorted(e[0] for e in ev) and len(ev) == 22
+    T, W = rng.normal(size=(20, 3)), rng.normal(size=(20, 3)) * 0.1
+    formats.write_trajectory(str(tmp_path / "traj.txt"), ts, T, W)
+    ts3, T3, W3 = formats.read_trajectory(str(tmp_path / "traj.txt"))
+    assert np.array_equal(ts3, ts) and np.allclose(T3, T, rtol=1e-8) and np.allclose(W3, W, rtol=1e-8)
+    # ATE: invariant to a rigid motion of the estimate when aligned, not otherwise
+    R = pcw.so3_exp(np.array([0.3, -0.2, 0.5]))
+    moved = T @ R.T + np.array([1.0, 2.0, 3.0])
+    assert formats.ate_rmse(moved, T) < 1e-12 and formats.ate_rmse(moved, T, align=False) > 1.0
+    assert abs(formats.ate_rmse(T + np.array([0.0, 0.0, 0.1]) * (np.arange(20) % 2)[:, None], T, align=False)
+               - 0.1 / np.sqrt(2)) < 1e-12
+
+
+def test_sequence_runner_tracks_ground_truth_with_the_oracle_backend():
+    """Two point-cloud-world sequences (different worlds / curves) through the runner with the oracle backend: the slot
+    book-keeping stays consistent with the resident scene, the estimate follows ground truth, and the as-coded
+    FillJacobianBlock (group rotation block dropped, src/feature.cpp:675-676) tracks far worse than the full row."""
+    B = 2
+    res = {}
+    for fix in (True, False):
+        cfg = sequence.SequenceConfig(fix_group_block=fix)
+        worlds = [pcw.RandomPCW(seed=b) for b in range(B)]
+        sims = [pcw.TrajectorySim("lissajous" if b % 2 == 0 else "trefoil", seed=100 + b) for b in range(B)]
+        out = sequence.run_pcw(OracleBackend, cfg, worlds, sims, total_time=1.6)
+        res[fix] = [formats.ate_rmse(out["Tsb"][:, b], out["gt_Tsb"][:, b], align=False) for b in range(B)]
+        assert len(out["ts"]) == 40 and out["ts"][1] == 40_000_000
+        for b, bk in enumerate(out["runner"].books):
+            st = out["backend"].st[b]
+            held = {j for j in range(cfg.n_features) if bk.feat_id[j] >= 0}
+            assert held == set(np.nonzero(st["sind"] >= 0)[0]) and len(held) > 10
+            for j in held:
+                assert st["ref"][j] == bk.feat_ref[j] and bk.group_refs[bk.feat_ref[j]] > 0
+            assert sum(r for r in bk.group_refs if r > 0) == len(held)
+            # covariance of free slots is zero, of used slots not
+            P = st["P"]
+            for j in range(cfg.n_features):
+                d = P[113 + 3 * j, 113 + 3 * j]
+                assert (d > 0) == (j in held)
+            assert np.allclose(P, P.T, atol=1e-9) and np.linalg.eigvalsh(P).min() > -1e-9
+    assert max(res[True]) < 0.08, res
+    assert min(res[False]) > 3 * max(res[True]), res

@@ -1,0 +1,184 @@
+"""Resident-state edits, ragged batches and whole sequences through the C ABI vs the oracle."""
+import numpy as np
+import pytest
+
+import xivo_oracle as orc
+from seq_oracle import OracleBackend
+from xivo_amd import formats, pcw, sequence
+from xivo_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_fro(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _start(cfg, B, seed):
+    rng = np.random.default_rng(seed)
+    sims = [pcw.TrajectorySim("lissajous", seed=seed + b) for b in range(B)]
+    poses = sequence.initial_poses(cfg, sims, t0=0.3 + 0.1 * seed)
+    P0 = []
+    for b in range(B):
+        A = rng.uniform(-1, 1, size=(cfg.N, cfg.N))
+        P = A @ A.T / cfg.N * 1e-3 + 1e-5 * np.eye(cfg.N)
+        P0.append(0.5 * (P + P.T))
+    return poses, np.array(P0), rng
+
+
+def _random_ops(cfg, B, rng, n):
+    ops = []
+    for _ in range(n):
+        b = int(rng.integers(B)); k = int(rng.integers(8))
+        g = int(rng.integers(cfg.n_groups)); j = int(rng.integers(cfg.n_features))
+        if k == L.EDIT_P_ZERO_RC:
+            off = int(rng.integers(cfg.N - 6)); ops.append(sequence._op(b, k, off, int(rng.integers(1, 7))))
+        elif k == L.EDIT_P_COPY_RC:
+            ops.append(sequence._op(b, k, int(rng.integers(23, cfg.N - 6)), int(rng.integers(0, 17)), int(rng.integers(1, 7))))
+        elif k == L.EDIT_P_SET_BLOCK3:
+            A = rng.normal(size=(3, 3)); ops.append(sequence._op(b, k, int(rng.integers(cfg.N - 3)), v=(A @ A.T).reshape(-1)))
+        elif k in (L.EDIT_ADD_GROUP, L.EDIT_REMOVE_GROUP):
+            ops.append(sequence._op(b, k, g))
+        elif k == L.EDIT_ADD_FEATURE:
+            A = rng.normal(size=(3, 3)) * 0.1
+            v = np.concatenate([rng.normal(size=3) * 0.3, rng.uniform(0, 400, 2), (A @ A.T).reshape(-1)])
+            ops.append(sequence._op(b, k, j, int(rng.integers(cfg.n_features)), g, v=v))
+        else:
+            ops.append(sequence._op(b, k, j, v=rng.uniform(0, 400, 2)))
+    return np.array(ops, dtype=L.edit_dtype)
+
+
+def test_edit_batch_matches_the_reference_edits_bit_for_bit(built):
+    """Random mixes of every XIVO_EDIT_* kind over several filters in one call == the host edits of
+    src/estimator.cpp:745-846 / src/feature.cpp:753-760 applied one by one (copies and zero fills: exact)."""
+    cfg = sequence.SequenceConfig(n_groups=6, n_features=12)
+    B = 5
+    poses, P0, rng = _start(cfg, B, 1)
+    hb = sequence.HipBackend(cfg, B, poses, P0)
+    ob = OracleBackend(cfg, B, poses, P0)
+    try:
+        for rnd in range(3):
+            ops = _random_ops(cfg, B, rng, 60)
+            ops = ops[np.argsort(ops["b"], kind="stable")]
+            hb.edit(ops); ob.edit(ops)
+            Pd = hb.covariance()
+            pose_d, group_d, feat_d = hb.scene()
+            for b in range(B):
+                s = ob.st[b]
+                assert np.array_equal(Pd[b], s["P"]), (rnd, b)
+                assert np.array_equal(feat_d[b]["sind"], s["sind"])
+                on = s["sind"] >= 0
+                assert np.array_equal(feat_d[b]["x"][on], s["x"][on]) and np.array_equal(feat_d[b]["ref_sind"][on], s["ref"][on])
+                assert np.array_equal(feat_d[b]["xp"][on], s["xp"][on])
+                assert np.array_equal(group_d[b]["Rsb"].reshape(-1, 3, 3).transpose(0, 2, 1), s["gR"])
+                assert np.array_equal(group_d[b]["Tsb"], s["gT"])
+    finally:
+        hb.close()
+
+
+def test_edit_batch_rejects_bad_ops(built):
+    cfg = sequence.SequenceConfig(n_groups=4, n_features=8)
+    poses, P0, _ = _start(cfg, 2, 2)
+    hb = sequence.HipBackend(cfg, 2, poses, P0)
+    try:
+        bad = [sequence._op(2, L.EDIT_REMOVE_GROUP, 0), sequence._op(0, L.EDIT_ADD_GROUP, 4),
+               sequence._op(0, L.EDIT_ADD_FEATURE, 8, 0, 0), sequence._op(0, L.EDIT_ADD_FEATURE, 0, 8, 0),
+               sequence._op(0, L.EDIT_P_ZERO_RC, cfg.N - 2, 3), sequence._op(0, 99, 0),
+               sequence._op(0, L.EDIT_P_COPY_RC, 0, cfg.N - 1, 2)]
+        for o in bad:
+            with pytest.raises(L.XivoHipError):
+                hb.ctx.edit_batch(cfg.n_features, np.array([o], dtype=L.edit_dtype))
+        # ops must be grouped by filter: the raw entry point refuses a descending filter index
+        two = np.array([sequence._op(1, L.EDIT_REMOVE_GROUP, 0), sequence._op(0, L.EDIT_REMOVE_GROUP, 0)], dtype=L.edit_dtype)
+        rc = hb.ctx.lib.xivo_hip_edit_batch(hb.ctx.h, cfg.n_features, 2, two.ctypes.data)
+        assert rc == -1
+        hb.ctx.edit_batch(cfg.n_features, np.zeros(0, dtype=L.edit_dtype))      # empty list is fine
+    finally:
+        hb.close()
+
+
+def test_ragged_batch_filter_update(built):
+    """Filters of one call hold different numbers of features (absent entries, sind = -1): 0, fewer than
+    min_inliers (no gating, src/manager.cpp:635), and a full list with gross outliers that gating must reject."""
+    cfg = sequence.SequenceConfig(n_groups=5, n_features=14, fix_group_block=False)
+    B = 4
+    present = [0, 3, 9, 14]
+    poses, P0, rng = _start(cfg, B, 3)
+    hb = sequence.HipBackend(cfg, B, poses, P0)
+    ob = OracleBackend(cfg, B, poses, P0)
+    try:
+        ops = []
+        fx, cx, cy = cfg.cam["fx"], cfg.cam["cx"], cfg.cam["cy"]
+        for b in range(B):
+            for g in range(2):
+                ops.append(sequence._op(b, L.EDIT_ADD_GROUP, g))
+            slots = rng.permutation(cfg.n_features)[:present[b]]
+            for q, j in enumerate(slots):
+                xp = rng.uniform([80, 60], [560, 420])
+                x = [(xp[0] - cx) / fx, (xp[1] - cy) / fx, np.log(rng.uniform(1.0, 6.0))]
+                noise = rng.normal(size=2) * (400.0 if q % 5 == 4 else 1.0)      # every 5th: gross outlier
+                A = rng.normal(size=(3, 3)) * 0.01
+                ops.append(sequence._op(b, L.EDIT_ADD_FEATURE, int(j), int(j), q % 2,
+                                        v=np.concatenate([x, xp + noise, (A @ A.T + 1e-5 * np.eye(3)).reshape(-1)])))
+        ops = np.array(ops, dtype=L.edit_dtype)
+        hb.edit(ops); ob.edit(ops)
+        md = hb.update(); mo = ob.update()
+        assert np.array_equal(md, mo)
+        assert md[0].sum() == 0 and md[1].sum() == 3 and md[3].sum() < 14
+        Pd = hb.covariance(); Rd, Td = hb.poses(); Ro, To = ob.poses()
+        _, _, feat_d = hb.scene()
+        assert np.array_equal(Pd[0], ob.st[0]["P"])              # nothing to update: P untouched, bit for bit
+        for b in range(B):
+            assert rel_fro(Pd[b], ob.st[b]["P"]) < 1e-10
+            assert np.abs(Td[b] - To[b]).max() < 1e-10 and np.abs(Rd[b] - Ro[b]).max() < 1e-10
+            on = ob.st[b]["sind"] >= 0
+            assert np.abs(feat_d[b]["x"][on] - ob.st[b]["x"][on]).max(initial=0) < 1e-10
+    finally:
+        hb.close()
+
+
+@pytest.mark.parametrize("fix", [True, False])
+def test_sequences_device_vs_oracle(built, fix):
+    """Three point-cloud-world sequences for 14 camera frames (224 IMU samples): the device-resident run and the oracle
+    run take identical life-cycle decisions (same inlier masks every frame) and end in the same state / covariance."""
+    B = 3
+    cfg = sequence.SequenceConfig(fix_group_block=fix)
+    runs = {}
+    for name, factory in (("hip", sequence.HipBackend), ("oracle", OracleBackend)):
+        worlds = [pcw.RandomPCW(seed=10 + b) for b in range(B)]
+        sims = [pcw.TrajectorySim("trefoil" if b == 1 else "lissajous", seed=200 + b) for b in range(B)]
+        runs[name] = sequence.run_pcw(factory, cfg, worlds, sims, total_time=0.56)
+    h, o = runs["hip"], runs["oracle"]
+    try:
+        for bh, bo in zip(h["runner"].books, o["runner"].books):
+            assert bh.feat_id == bo.feat_id and bh.feat_ref == bo.feat_ref and bh.group_refs == bo.group_refs
+        assert h["runner"].n_rejected == o["runner"].n_rejected
+        assert np.abs(h["Tsb"] - o["Tsb"]).max() < 1e-8 and np.abs(h["Wsb"] - o["Wsb"]).max() < 1e-8
+        Pd = h["backend"].covariance()
+        for b in range(B):
+            assert rel_fro(Pd[b], o["backend"].st[b]["P"]) < 1e-6
+        assert min(bk.n_instate() for bk in h["runner"].books) > 10
+    finally:
+        h["backend"].close()
+
+
+def test_many_sequences_track_ground_truth(built, tmp_path):
+    """48 sequences (different worlds, curves, noise seeds) for 2.4 s on one context: every estimate stays finite and
+    close to ground truth; the trajectory dump round-trips (src/app/vio.cpp:101-106 format)."""
+    B = 48
+    cfg = sequence.SequenceConfig()
+    worlds = [pcw.RandomPCW(seed=b) for b in range(B)]
+    sims = [pcw.TrajectorySim("lissajous" if b % 2 == 0 else "trefoil", rate=0.08 + 0.001 * b, seed=300 + b) for b in range(B)]
+    out = sequence.run_pcw(sequence.HipBackend, cfg, worlds, sims, total_time=2.4)
+    try:
+        assert np.isfinite(out["Tsb"]).all() and np.isfinite(out["Wsb"]).all()
+        ate = np.array([formats.ate_rmse(out["Tsb"][:, b], out["gt_Tsb"][:, b], align=False) for b in range(B)])
+        print('ATE', np.round(np.sort(ate), 3))
+        assert np.median(ate) < 0.08 and ate.max() < 0.5, ate
+        P = out["backend"].covariance()
+        assert np.isfinite(P).all() and all(np.linalg.eigvalsh(0.5 * (P[b] + P[b].T)).min() > -1e-9 for b in range(0, B, 8))
+        formats.write_trajectory(str(tmp_path / "t.txt"), out["ts"], out["Tsb"][:, 0], out["Wsb"][:, 0])
+        ts, T, W = formats.read_trajectory(str(tmp_path / "t.txt"))
+        assert np.array_equal(ts, out["ts"]) and np.allclose(T, out["Tsb"][:, 0], rtol=1e-8, atol=1e-12)
+    finally:
+        out["backend"].close()

@@ -64,6 +64,7 @@ struct xivo_hip_ctx {
   int oos_cap = 0;
   int* oos_rows = nullptr;
   xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
+  void* edit_buf = nullptr; size_t edit_cap = 0;   // device copy of the ops of xivo_hip_edit_batch
   size_t sub_cap = 0;
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -248,7 +249,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
-                  c->mask, c->rows_instate, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub};
+                  c->mask, c->rows_instate, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
@@ -719,6 +720,9 @@ static int ensure_gate_buffers(xivo_hip_ctx* c, int F) {
   if (!rc) rc = dev_alloc(&c->dist, B * Fm);
   if (!rc) rc = dev_alloc(&c->mask, B * Fm);
   if (!rc && !c->rows_instate) rc = dev_alloc(&c->rows_instate, B);
+  // every entry starts absent (sind = -1) and masked out until a scene / edit writes it
+  if (!rc && hipMemsetAsync(c->feats, 0xFF, B * Fm * sizeof(xivo_feat_in), c->stream) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
+  if (!rc && hipMemsetAsync(c->mask, 0, B * Fm, c->stream) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (!rc) c->Fmax = Fm;
   return rc;
 }
@@ -780,6 +784,7 @@ int xivo_hip_set_scene(xivo_hip_ctx* c, int b0, int nb, int F, const xivo_pose_i
   if (rc) return rc;
   for (long i = 0; i < (long)nb * F; ++i) {
     const xivo_feat_in& f = feats[i];
+    if (f.sind == -1) continue;   // absent entry
     if (f.ref_sind < 0 || f.ref_sind >= c->lay.n_groups || f.sind < 0 || f.sind >= c->lay.n_features)
       return XIVO_HIP_ERR_INVALID;
   }
@@ -989,6 +994,61 @@ int xivo_hip_absorb_error(xivo_hip_ctx* c, int B) {
   a.lay = c->lay; a.F = c->F; a.Fmax = c->Fmax; a.batch = B;
   StageTimer st(c, ST_OTHER, 0.0);
   return launch_absorb_error(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+int xivo_hip_edit_batch(xivo_hip_ctx* c, int F, int n_ops, const xivo_edit_op* ops) {
+  if (!c || !c->have_layout || !c->poses || F <= 0 || 2 * F > c->Mmax || n_ops < 0 || (n_ops > 0 && !ops))
+    return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensure_gate_buffers(c, F);
+  if (rc) return rc;
+  const xivo_layout& L = c->lay;
+  std::vector<int> wg_filter, wg_begin;
+  for (int o = 0; o < n_ops; ++o) {
+    const xivo_edit_op& e = ops[o];
+    if (e.b < 0 || e.b >= c->Bmax || (o > 0 && e.b < ops[o - 1].b)) return XIVO_HIP_ERR_INVALID;
+    bool ok = false;
+    switch (e.kind) {
+      case XIVO_EDIT_P_ZERO_RC: ok = e.i0 >= 0 && e.i1 >= 0 && e.i0 + e.i1 <= c->N; break;
+      case XIVO_EDIT_P_COPY_RC: ok = e.i0 >= 0 && e.i1 >= 0 && e.i2 >= 0 && e.i0 + e.i2 <= c->N && e.i1 + e.i2 <= c->N; break;
+      case XIVO_EDIT_P_SET_BLOCK3: ok = e.i0 >= 0 && e.i0 + 3 <= c->N; break;
+      case XIVO_EDIT_ADD_GROUP: case XIVO_EDIT_REMOVE_GROUP: ok = e.i0 >= 0 && e.i0 < L.n_groups; break;
+      case XIVO_EDIT_ADD_FEATURE:
+        ok = e.i0 >= 0 && e.i0 < F && e.i1 >= 0 && e.i1 < L.n_features && e.i2 >= 0 && e.i2 < L.n_groups; break;
+      case XIVO_EDIT_REMOVE_FEATURE: case XIVO_EDIT_SET_XP: ok = e.i0 >= 0 && e.i0 < F; break;
+      default: ok = false;
+    }
+    if (!ok) return XIVO_HIP_ERR_INVALID;
+    if (o == 0 || e.b != ops[o - 1].b) { wg_filter.push_back(e.b); wg_begin.push_back(o); }
+  }
+  c->F = F;
+  if (n_ops == 0) return XIVO_HIP_OK;
+  wg_begin.push_back(n_ops);
+  const int n_wg = (int)wg_filter.size();
+  const size_t bytes_ops = (size_t)n_ops * sizeof(xivo_edit_op);
+  const size_t bytes = bytes_ops + (size_t)(2 * n_wg + 1) * sizeof(int);
+  if (bytes > c->edit_cap) {
+    if (c->edit_buf) hipFree(c->edit_buf);
+    c->edit_buf = nullptr; c->edit_cap = 0;
+    const size_t cap = bytes * 2;
+    if (hipMalloc(&c->edit_buf, cap) != hipSuccess) return XIVO_HIP_ERR_NOMEM;
+    c->edit_cap = cap;
+  }
+  char* d = (char*)c->edit_buf;
+  HIP_TRY(hipMemcpyAsync(d, ops, bytes_ops, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d + bytes_ops, wg_filter.data(), (size_t)n_wg * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d + bytes_ops + (size_t)n_wg * sizeof(int), wg_begin.data(), (size_t)(n_wg + 1) * sizeof(int),
+                         hipMemcpyHostToDevice, c->stream));
+  EditArgs a;
+  a.ops = (const xivo_edit_op*)d; a.wg_filter = (const int*)(d + bytes_ops); a.wg_begin = a.wg_filter + n_wg;
+  a.P = c->P; a.strideP = c->sP; a.ldp = c->Np; a.Np = c->Np; a.lay = L;
+  a.poses = c->poses; a.groups = c->groups; a.feats = c->feats; a.Fmax = c->Fmax;
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "edit_batch_kernel");
+    if (launch_edit_batch(a, n_wg, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors above are pageable staging
+  return XIVO_HIP_OK;
 }
 
 int xivo_hip_get_scene(xivo_hip_ctx* c, int b0, int nb, xivo_pose_in* poses, xivo_group_in* groups, xivo_feat_in* feats) {

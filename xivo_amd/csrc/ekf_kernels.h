@@ -102,6 +102,15 @@ struct AbsorbArgs {
 };
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s);
 
+// batched resident edits (xivo_hip_edit_batch): wg_filter[w] = filter of workgroup w, its ops are
+// ops[wg_begin[w] .. wg_begin[w + 1])
+struct EditArgs {
+  const xivo_edit_op* ops; const int* wg_filter; const int* wg_begin;
+  double* P; long strideP; int ldp, Np; xivo_layout lay;
+  xivo_pose_in* poses; xivo_group_in* groups; xivo_feat_in* feats; int Fmax;
+};
+int launch_edit_batch(const EditArgs& a, int n_wg, hipStream_t s);
+
 // OOS (MSCKF) rows: oos.cpp:39-89 + helpers.cpp:13-23
 struct OosArgs {
   const xivo_oos_in* feats; int n_oos;          // [batch x n_oos]

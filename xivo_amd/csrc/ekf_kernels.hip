@@ -257,6 +257,13 @@ __global__ void jac_instate_kernel(SceneBuffers sb, xivo_layout lay, xivo_cam ca
   const int filt = t / sb.F, f = t % sb.F;
   const xivo_pose_in& pose = sb.poses[filt];
   const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+  if (ft.sind < 0) {   // absent entry (ragged batches): no Jacobian, no innovation
+    double* J0 = sb.J + ((long)filt * sb.Fmax + f) * 42;
+    for (int i = 0; i < 42; ++i) J0[i] = 0.0;
+    sb.finn[((long)filt * sb.Fmax + f) * 2] = 0.0;
+    sb.finn[((long)filt * sb.Fmax + f) * 2 + 1] = 0.0;
+    return;
+  }
   const xivo_group_in& grp = sb.groups[(long)filt * lay.n_groups + ft.ref_sind];
 
   const M3 Rsb = m3_from_colmajor(pose.Rsb), Rbc = m3_from_colmajor(pose.Rbc);
@@ -351,9 +358,23 @@ __global__ __launch_bounds__(256) void gate_sparse_kernel(GateArgs a) {
   extern __shared__ double sdist[];
   const SceneBuffers& sb = a.sb;
   const double* P = a.P + (long)filt * a.strideP;
-  if (a.use_gating) {
+  // entries present in this filter (sind >= 0); Estimator::OutlierRejection gates only when there are more
+  // than min_required_inliers_ of them (src/manager.cpp:635)
+  __shared__ int s_present;
+  if (tid == 0) s_present = 0;
+  __syncthreads();
+  {
+    int cnt = 0;
+    for (int f = tid; f < sb.F; f += 256) cnt += sb.feats[(long)filt * sb.Fmax + f].sind >= 0 ? 1 : 0;
+    if (cnt) atomicAdd(&s_present, cnt);
+  }
+  __syncthreads();
+  const int present = s_present;
+  const bool gating = a.use_gating && present > a.min_inliers;
+  if (gating) {
     for (int f = wave; f < sb.F; f += 4) {
       const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+      if (ft.sind < 0) { if (lane == 0) sdist[f] = __builtin_inf(); continue; }
       const double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
       const double* inn = sb.finn + ((long)filt * sb.Fmax + f) * 2;
       double v = 0.0;
@@ -376,16 +397,17 @@ __global__ __launch_bounds__(256) void gate_sparse_kernel(GateArgs a) {
     }
     __syncthreads();
     if (wave == 0) {
-      const double th = relax_threshold(sdist, sb.F, a.thresh, a.mult, a.min_inliers, lane);
+      const double th = relax_threshold(sdist, sb.F, a.thresh, a.mult, a.min_inliers, lane, present);
       if (lane == 0) sdist[sb.F] = th;
     }
     __syncthreads();
   }
-  const double th = a.use_gating ? sdist[sb.F] : 0.0;
+  const double th = gating ? sdist[sb.F] : 0.0;
   for (int f = tid; f < sb.F; f += 256) {
-    const bool in = a.use_gating ? (sdist[f] < th) : true;
+    const bool here = sb.feats[(long)filt * sb.Fmax + f].sind >= 0;
+    const bool in = gating ? (sdist[f] < th) : here;
     sb.mask[(long)filt * sb.Fmax + f] = in ? 1 : 0;
-    sb.dist[(long)filt * sb.Fmax + f] = a.use_gating ? sdist[f] : 0.0;
+    sb.dist[(long)filt * sb.Fmax + f] = (gating && here) ? sdist[f] : 0.0;
   }
 }
 
@@ -676,6 +698,82 @@ __device__ __forceinline__ void rot_retract(double* Rcm, double wx, double wy, d
 #pragma unroll
     for (int j = 0; j < 3; ++j) Rcm[i + 3 * j] = R.m[i][j];
 }
+// ---------------------------------------------------------------- batched resident edits (xivo_hip_edit_batch)
+__device__ __forceinline__ void edit_zero_rc(double* P, int ldp, int Np, int off, int len, int tid) {
+  for (int t = tid; t < Np; t += 256)
+    for (int r = 0; r < len; ++r) {
+      P[(off + r) + (long)t * ldp] = 0.0;
+      P[t + (long)(off + r) * ldp] = 0.0;
+    }
+  __syncthreads();
+}
+// rows, then columns (which re-read the rows just written): the order of src/estimator.cpp:808-816
+__device__ __forceinline__ void edit_copy_rc(double* P, int ldp, int Np, int dst, int src, int len, int tid) {
+  for (int t = tid; t < Np; t += 256)
+    for (int r = 0; r < len; ++r) P[(dst + r) + (long)t * ldp] = P[(src + r) + (long)t * ldp];
+  __syncthreads();
+  for (int t = tid; t < Np; t += 256)
+    for (int r = 0; r < len; ++r) P[t + (long)(dst + r) * ldp] = P[t + (long)(src + r) * ldp];
+  __syncthreads();
+}
+// One workgroup per filter that has ops; its ops run in array order.
+__global__ __launch_bounds__(256) void edit_batch_kernel(EditArgs a) {
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int filt = a.wg_filter[w];
+  double* P = a.P + (long)filt * a.strideP;
+  xivo_feat_in* feats = a.feats + (long)filt * a.Fmax;
+  xivo_group_in* groups = a.groups + (long)filt * a.lay.n_groups;
+  const xivo_pose_in& X = a.poses[filt];
+  for (int o = a.wg_begin[w]; o < a.wg_begin[w + 1]; ++o) {
+    const xivo_edit_op& op = a.ops[o];
+    switch (op.kind) {
+      case XIVO_EDIT_P_ZERO_RC: edit_zero_rc(P, a.ldp, a.Np, op.i0, op.i1, tid); break;
+      case XIVO_EDIT_P_COPY_RC: edit_copy_rc(P, a.ldp, a.Np, op.i0, op.i1, op.i2, tid); break;
+      case XIVO_EDIT_P_SET_BLOCK3:
+        if (tid < 9) P[(op.i0 + tid % 3) + (long)(op.i0 + tid / 3) * a.ldp] = op.v[tid];
+        __syncthreads();
+        break;
+      case XIVO_EDIT_ADD_GROUP: {
+        if (tid < 9) groups[op.i0].Rsb[tid] = X.Rsb[tid];
+        else if (tid < 12) groups[op.i0].Tsb[tid - 9] = X.Tsb[tid - 9];
+        const int off = a.lay.group_begin + 6 * op.i0;
+        edit_copy_rc(P, a.ldp, a.Np, off, 0, 3, tid);       // Index::Wsb
+        edit_copy_rc(P, a.ldp, a.Np, off + 3, 3, 3, tid);   // Index::Tsb
+        break;
+      }
+      case XIVO_EDIT_REMOVE_GROUP: edit_zero_rc(P, a.ldp, a.Np, a.lay.group_begin + 6 * op.i0, 6, tid); break;
+      case XIVO_EDIT_ADD_FEATURE: {
+        if (tid == 0) {
+          xivo_feat_in& f = feats[op.i0];
+          f.x[0] = op.v[0]; f.x[1] = op.v[1]; f.x[2] = op.v[2];
+          f.xp[0] = op.v[3]; f.xp[1] = op.v[4];
+          f.sind = op.i1; f.ref_sind = op.i2;
+        }
+        const int off = a.lay.feature_begin + 3 * op.i1;
+        edit_zero_rc(P, a.ldp, a.Np, off, 3, tid);
+        if (tid < 9) P[(off + tid % 3) + (long)(off + tid / 3) * a.ldp] = op.v[5 + tid];
+        __syncthreads();
+        break;
+      }
+      case XIVO_EDIT_REMOVE_FEATURE: {
+        const int sind = feats[op.i0].sind;
+        __syncthreads();
+        if (sind >= 0) {
+          edit_zero_rc(P, a.ldp, a.Np, a.lay.feature_begin + 3 * sind, 3, tid);
+          if (tid == 0) feats[op.i0].sind = -1;
+          __syncthreads();
+        }
+        break;
+      }
+      case XIVO_EDIT_SET_XP:
+        if (tid < 2) feats[op.i0].xp[tid] = op.v[tid];
+        __syncthreads();
+        break;
+      default: break;
+    }
+  }
+}
+
 // One workgroup per filter; thread 0 retracts the motion state, threads 1.. the group slots and features.
 __global__ __launch_bounds__(256) void absorb_error_kernel(AbsorbArgs a) {
   const int filt = blockIdx.x, tid = threadIdx.x;
@@ -698,6 +796,7 @@ __global__ __launch_bounds__(256) void absorb_error_kernel(AbsorbArgs a) {
   for (int f = tid; f < a.F; f += 256) {                 // Feature::UpdateState for in_current_ekf_update_ (estimator.cpp:906-912)
     if (!a.mask[(long)filt * a.Fmax + f]) continue;
     xivo_feat_in& ft = a.feats[(long)filt * a.Fmax + f];
+    if (ft.sind < 0) continue;
     const int off = a.lay.feature_begin + 3 * ft.sind;
     for (int i = 0; i < 3; ++i) ft.x[i] += err[off + i];
   }
@@ -1240,6 +1339,10 @@ int launch_givens(const GivensArgs& a, hipStream_t s) {
   if (a.batch <= 0) return 0;
   hipLaunchKernelGGL(givens_kernel, dim3(a.batch), dim3(64), 0, s, a);
   CHECK_LAUNCH();
+}
+int launch_edit_batch(const EditArgs& a, int n_wg, hipStream_t s) {
+  hipLaunchKernelGGL(edit_batch_kernel, dim3(n_wg), dim3(256), 0, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(absorb_error_kernel, dim3(a.batch), dim3(256), 0, s, a);

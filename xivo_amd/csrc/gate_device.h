@@ -27,8 +27,10 @@ __device__ __forceinline__ double mh_dist_2x2(double s00, double s10, double s11
 // threshold relaxation loop of src/update.cpp:73-96, run by one wave over the
 // F distances in LDS. Returns the threshold that was in force when the loop
 // exited (inlier <=> dist < thresh).
+// `present` = number of real entries among the F (absent ones carry +inf and can never become inliers).
 __device__ inline double relax_threshold(const double* sdist, int F, double thresh, double mult, int min_inliers,
-                                  int lane) {
+                                  int lane, int present = -1) {
+  if (present < 0) present = F;
   if (min_inliers <= 0) return -1.0;  // loop body never runs: no inliers (update.cpp:73)
   for (int it = 0; it < 4096; ++it) {
     int cnt = 0;
@@ -37,7 +39,7 @@ __device__ inline double relax_threshold(const double* sdist, int F, double thre
       const bool in = (f < F) && (sdist[f] < thresh);
       cnt += __popcll(__ballot(in));
     }
-    if (cnt >= min_inliers || cnt == F) return thresh;
+    if (cnt >= min_inliers || cnt >= present) return thresh;
     thresh *= mult;
   }
   return thresh;

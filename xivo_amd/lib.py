@@ -58,6 +58,12 @@ subfilter_dtype = np.dtype([("x", "f8", 3), ("P", "f8", 9), ("xp", "f8", 2), ("o
                             ("ref_sind", "i4"), ("status", "i4"), ("init_counter", "i4"), ("candidate", "i4")])
 subfilter_opts_dtype = np.dtype([("Rtri", "f8"), ("MH_thresh", "f8"), ("ready_steps", "i4"), ("_pad", "i4"),
                                  ("min_depth", "f8"), ("max_depth", "f8"), ("max_subfilter_outlier", "f8")])
+# xivo_edit_op (include/xivo_hip.h): one resident-state edit of one filter
+edit_dtype = np.dtype([("b", "i4"), ("kind", "i4"), ("i0", "i4"), ("i1", "i4"), ("i2", "i4"), ("reserved", "i4"),
+                       ("v", "f8", 14)])
+assert edit_dtype.itemsize == 136
+EDIT_P_ZERO_RC, EDIT_P_COPY_RC, EDIT_P_SET_BLOCK3, EDIT_ADD_GROUP, EDIT_REMOVE_GROUP, EDIT_ADD_FEATURE, \
+    EDIT_REMOVE_FEATURE, EDIT_SET_XP = range(8)
 assert subfilter_dtype.itemsize == 144 and subfilter_opts_dtype.itemsize == 48
 assert feat_dtype.itemsize == 48 and pose_dtype.itemsize == 336 and group_dtype.itemsize == 96
 
@@ -107,6 +113,7 @@ _SIGS = {
                         C.c_void_p],
     "xivo_hip_qr": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "xivo_hip_subfilter_update": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "xivo_hip_edit_batch": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_propagate_cov": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
@@ -384,6 +391,14 @@ class Context:
 
     def absorb_error(self, B=None):
         self._check(self.lib.xivo_hip_absorb_error(self.h, self.batch if B is None else B))
+
+    def edit_batch(self, F, ops):
+        """ops: array of edit_dtype; sorted by filter here (stable, so the per-filter order is kept)."""
+        ops = np.ascontiguousarray(ops, dtype=edit_dtype)
+        if ops.size:
+            ops = np.ascontiguousarray(ops[np.argsort(ops["b"], kind="stable")])
+        self.F = F
+        self._check(self.lib.xivo_hip_edit_batch(self.h, F, int(ops.size), _ptr(ops) if ops.size else None))
 
     def get_scene(self, b0=0, nb=None):
         nb = self.batch - b0 if nb is None else nb
