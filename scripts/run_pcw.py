@@ -1,0 +1,59 @@
+"""Run B point-cloud-world sequences at once on one MI355X (BASELINE configs 1 / 5 surrogate: TUM-VI sizes, N = 203,
+<= 30 features) and report tracking error + where the time goes. Mirrors scripts/pyxivo_pcw.py's options."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xivo_amd import formats, pcw, sequence  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-sequences", type=int, default=256)
+    ap.add_argument("-npts", type=int, default=1000)
+    ap.add_argument("-total_time", type=float, default=2.0)
+    ap.add_argument("-imu_dt", type=float, default=0.0025)
+    ap.add_argument("-vision_dt", type=float, default=0.04)
+    ap.add_argument("-noise_vision_std", type=float, default=1.0)
+    ap.add_argument("-integration_method", default="PrinceDormand")
+    ap.add_argument("-as_coded_group_block", action="store_true", help="reproduce src/feature.cpp:675-676")
+    ap.add_argument("-dump", default="", help="directory for per-sequence `ts Tsb Wsb` trajectories")
+    a = ap.parse_args()
+    B = a.sequences
+    cfg = sequence.SequenceConfig(integration_method=a.integration_method, fix_group_block=not a.as_coded_group_block)
+    worlds = [pcw.RandomPCW(npts=a.npts, seed=b) for b in range(B)]
+    sims = [pcw.TrajectorySim("lissajous" if b % 2 == 0 else "trefoil", rate=0.08 + 0.04 * (b % 7) / 7, seed=1000 + b)
+            for b in range(B)]
+    timers = {}
+    t0 = time.perf_counter()
+    out = sequence.run_pcw(sequence.HipBackend, cfg, worlds, sims, total_time=a.total_time, imu_dt=a.imu_dt,
+                           vision_dt=a.vision_dt, noise_vision_std=a.noise_vision_std, timers=timers)
+    wall = time.perf_counter() - t0
+    out["backend"].close()
+    frames = len(out["ts"])
+    ate = np.array([formats.ate_rmse(out["Tsb"][:, b], out["gt_Tsb"][:, b], align=False) for b in range(B)])
+    dev = sum(timers.get(k, 0.0) for k in ("propagate", "edit", "update"))
+    r = out["runner"]
+    print(json.dumps({
+        "sequences": B, "frames_per_sequence": frames, "imu_samples_per_frame": int(round(a.vision_dt / a.imu_dt)),
+        "N": cfg.N, "max_features": cfg.n_features, "integration": a.integration_method,
+        "ate_m": {"median": float(np.median(ate)), "p90": float(np.quantile(ate, 0.9)), "max": float(ate.max())},
+        "updates": r.n_updates, "mh_rejected": r.n_rejected,
+        "wall_s": wall, "device_path_s": dev,
+        "phase_s": {k: round(v, 4) for k, v in sorted(timers.items())},
+        "device_frames_per_s": B * frames / dev if dev > 0 else None,
+        "ms_per_frame_per_batch": {k: round(1e3 * timers.get(k, 0.0) / frames, 3) for k in ("propagate", "edit", "update")},
+    }))
+    if a.dump:
+        os.makedirs(a.dump, exist_ok=True)
+        for b in range(B):
+            formats.write_trajectory(os.path.join(a.dump, "seq%04d.txt" % b), out["ts"], out["Tsb"][:, b], out["Wsb"][:, b])
+
+
+if __name__ == "__main__":
+    main()

@@ -1059,37 +1059,52 @@ __device__ __forceinline__ void compose_motion_dev(MotionRegs& X, const V3& V, c
   X.Rsb = m3_mul(X.Rsb, so3_exp_dev(gc.v[0] * dt, gc.v[1] * dt, gc.v[2] * dt));   // :610
 }
 
-// One workgroup of 256 threads per filter. Every thread carries the (tiny) nominal state redundantly; the 23 x 23
-// matrices live in LDS, column-major with leading dimension 23, and every matrix operation is spread element-wise
-// over the threads. F = dX'/dX has non-zero rows only for Wsb, Tsb, Vsb (rows 0..8: the biases, extrinsics and
-// gravity are constants of the motion model), so F M, M F^T and (I + FK h) Phi are 9-row / 9-column products.
+// One workgroup of 256 threads per filter. Every thread carries the (tiny) nominal state redundantly, hence also the
+// entries of the motion Jacobians: F = dX'/dX (23 x 23) has non-zero rows only for Wsb, Tsb, Vsb (rows 0..8: biases,
+// extrinsics and gravity are constants of the motion model) and at most 8 non-zeros in a row - dW/dW, dW/dbg = -I,
+// dT/dV = I, dV/dW, dV/dba = -Rsb, dV/dWsg (estimator.cpp:615-704) - and G (23 x 12) is four 3 x 3 blocks
+// (-I, -Rsb, I, I). Neither is ever materialised: F M, M F^T and G Q G^T are formed from the register copies with the
+// structural zeros skipped (exact: the skipped terms are 0 * x, and the surviving terms are summed in the same
+// ascending-k order as the dense product), so a stage costs ~0.1 of the dense 9-row products and three barriers.
+// The 23 x 23 matrices live in LDS (column-major, ld 23); FK keeps its 9 non-zero rows only ([i + 9 j]).
+// Work split of the product phase, by wave: waves 0..2 own the row blocks Wsb / Tsb / Vsb of F: lanes 0..22 form
+// column j of F P0, lanes 32..54 column j of F S (S = sum a_q FK_q) and from it FK of the stage; wave 3: lanes 0..22
+// row i of P0 F^T, lanes 32..43 row r of the 12 x 12 support of G Q G^T.
 __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
-  constexpr int NM = 23, NN = NM * NM, NG = NM * 12, NT = 256, FR = 9;   // FR: rows of F that are not identically zero
+  constexpr int NM = 23, NN = NM * NM, NT = 256, FR = 9, NF = FR * NM;   // FR: rows of F that are not identically zero
   extern __shared__ double sm[];
   const int lane = threadIdx.x, filt = blockIdx.x;   // `lane`: thread index in the workgroup
+  const int wave = lane >> 6, wl = lane & 63;
   const RkTableau& tab = kTableau[a.method ? 1 : 0];
   const int ns = tab.ns;
   double* Pmm = sm;            // P_mm at the start of the sub-step
   double* Phi = Pmm + NN;      // accumulated transition
-  double* F = Phi + NN;
-  double* P0 = F + NN;
-  double* S1 = P0 + NN;        // scratch
-  double* S2 = P0;             // (P0 is dead once the stages of a sub-step are combined)
-  double* G = S1 + NN;         // 23 x 12
-  double* GQ = G + NG;
-  double* Q = GQ + NG;         // 12 x 12
-  double* sKs = Q + 144;       // [7][3] stage velocities (in LDS: a register array indexed by the stage lives in scratch)
-  double* FKs = sKs + 24;      // [ns][NN]
-  double* PKs = FKs + ns * NN;
-  auto E = [](int i, int j) { return i + NM * j; };
+  double* P0 = Phi + NN;
+  double* S1 = P0 + NN;        // 23 x 23 scratch whose rows >= 9 stay zero: sum a_q FK_q, later I + FK h
+  double* FPs = S1 + NN;       // [9 x 23]  F P0          ([i + 9 j])
+  double* PFs = FPs + NF;      // [23 x 9]  P0 F^T        ([i + 23 j])
+  double* GQG = PFs + NF;      // [12 x 12] support of G Q G^T: rows / cols (Wsb, Vsb, bg, ba)
+  double* Q = GQG + 144;       // 12 x 12
+  double* GQc = Q + 144;       // [12 x 12] the non-zero rows of G Q
+  double* sKs = GQc + 144;     // [7][3] stage velocities (in LDS: a register array indexed by the stage lives in scratch)
+  double* FKs = sKs + 24;      // [ns][9 x 23]
+  double* PKs = FKs + ns * NF; // [ns][23 x 23]
 
   const double* Pg = a.P + (long)filt * a.strideP;
   for (int e = lane; e < NN; e += NT) {
     const int i = e % NM, j = e / NM;
     Pmm[e] = Pg[i + (long)j * a.ldp];
     Phi[e] = i == j ? 1.0 : 0.0;
+    S1[e] = 0.0;
   }
-  for (int e = lane; e < 144; e += NT) Q[e] = a.Qimu[e];
+  for (int e = lane; e < 144; e += NT) {
+    const double q = a.Qimu[e];
+    Q[e] = q;
+    // rows of G Q that do not depend on the state: Wsb rows = -Q[0:3,:], bg rows = Q[6:9,:], ba rows = Q[9:12,:]
+    const int r = e % 12;
+    if (r < 3) GQc[e] = -q;
+    else if (r >= 6) GQc[e] = q;
+  }
   xivo_pose_in& pose = a.poses[filt];
   MotionRegs X;
   X.Rsb = m3_from_colmajor(pose.Rsb); X.Rsg = m3_from_colmajor(pose.Rsg);
@@ -1127,77 +1142,127 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
         compose_motion_dev(X0, V, gi, ai, tab.c_step[st] * h, gv);
       }
       if (lane < 3) sKs[3 * st + lane] = lane == 0 ? X0.Vsb.v[0] : (lane == 1 ? X0.Vsb.v[1] : X0.Vsb.v[2]);   // visible after the barriers below
-      // ComputeMotionJacobianAt (estimator.cpp:615-704): F (23 x 23), G (23 x 12)
+      // ComputeMotionJacobianAt (estimator.cpp:615-704): the blocks of F and G, in registers
       V3 gc, ac;
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gc.v[i] = gi.v[i] - X0.bg.v[i]; ac.v[i] = ai.v[i] - X0.ba.v[i]; }
-      const M3 dW_dW = m3_neg(hat(gc));
-      const M3 dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));
-      const M3 dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));
-      for (int e = lane; e < NN; e += NT) F[e] = 0.0;
-      for (int e = lane; e < NG; e += NT) G[e] = 0.0;
-      __syncthreads();
-      // (compile-time i, j: a run-time subscript into the 3x3 register matrices would push them to scratch)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (lane != 3 * i + j) continue;
-          F[E(0 + i, 0 + j)] = dW_dW.m[i][j];          // Wsb <- Wsb
-          F[E(6 + i, 0 + j)] = dV_dW.m[i][j];          // Vsb <- Wsb
-          F[E(6 + i, 12 + j)] = -X0.Rsb.m[i][j];       // Vsb <- ba
-          if (j < 2) F[E(6 + i, 21 + j)] = dV_dWsg.m[i][j];   // Vsb <- Wsg (2 dof)
-          G[(6 + i) + NM * (3 + j)] = -X0.Rsb.m[i][j]; // Vsb <- accel noise
-          if (i == j) {
-            F[E(0 + i, 9 + i)] = -1.0;                 // Wsb <- bg
-            F[E(3 + i, 6 + i)] = 1.0;                  // Tsb <- Vsb
-            G[(0 + i) + NM * i] = -1.0;                // Wsb <- gyro noise
-            G[(9 + i) + NM * (6 + i)] = 1.0;           // bg  <- gyro-bias noise
-            G[(12 + i) + NM * (9 + i)] = 1.0;          // ba  <- accel-bias noise
-          }
-        }
-      }
-      __syncthreads();
-      // FK_st = F + F (sum_q a_q FK_q) h ;  P0 = Pmm + (sum_q a_q PK_q) h   (rk4.cpp:49-88)
+      const M3 dW_dW = m3_neg(hat(gc));                           // Wsb <- Wsb ; Wsb <- bg is -I
+      const M3 dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));           // Vsb <- Wsb
+      const M3 dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));         // Vsb <- Wsg (first 2 columns)
+      const M3 nR = m3_neg(X0.Rsb);                               // Vsb <- ba, and G's Vsb <- accel-noise block
+
+      // -- phase A: S = sum_q a_q FK_q (rows < 9), P0 = Pmm + (sum_q a_q PK_q) h (rk4.cpp:49-88); Vsb rows of G Q
       for (int e = lane; e < NN; e += NT) {
-        double sf = 0.0, sp = 0.0;
-        for (int q = 0; q < st; ++q) { sf += tab.a[st][q] * FKs[q * NN + e]; sp += tab.a[st][q] * PKs[q * NN + e]; }
-        S1[e] = sf;
+        double sp = 0.0;
+        for (int q = 0; q < st; ++q) sp += tab.a[st][q] * PKs[q * NN + e];
         P0[e] = Pmm[e] + sp * h;
       }
-      __syncthreads();
-      for (int e = lane; e < NN; e += NT) {
-        const int i = e % NM, j = e / NM;
-        double fk = 0.0;
-        if (st > 0 && i < FR) {
-#pragma unroll
-          for (int k = 0; k < NM; ++k) fk = fma(F[E(i, k)], S1[E(k, j)], fk);
-        }
-        FKs[st * NN + e] = F[e] + fk * h;
+      for (int e = lane; e < NF; e += NT) {
+        double sf = 0.0;
+        for (int q = 0; q < st; ++q) sf += tab.a[st][q] * FKs[q * NF + e];
+        S1[(e % FR) + NM * (e / FR)] = sf;
       }
-      // G Q G^T
-      for (int e = lane; e < NG; e += NT) {
-        const int i = e % NM, j = e / NM;
-        double v = 0.0;
+      if (lane >= 64 && lane < 76) {                              // (G Q)[Vsb_i, l] = sum_k -Rsb[i][k] Q[3 + k, l]
+        const int l = lane - 64;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) v = fma(G[i + NM * k], Q[k + 12 * j], v);
-        GQ[e] = v;
+        for (int i = 0; i < 3; ++i) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v = fma(nR.m[i][k], Q[(3 + k) + 12 * l], v);
+          GQc[(3 + i) + 12 * l] = v;
+        }
       }
       __syncthreads();
+
+      // -- phase B: the structured products
+      if (wave < 3) {
+        const bool fk_task = wl >= 32;
+        const int j = fk_task ? wl - 32 : wl;
+        if (j < NM) {
+          const double* M = (fk_task ? S1 : P0) + NM * j;         // column j
+          double o[3], f[3];                                      // o = (F M)[block rows, j], f = F[block rows, j]
+          if (wave == 0) {                                        // Wsb rows: k = 0..2 (dW/dW), k = 9 + i (-1)
+            const double m0 = M[0], m1 = M[1], m2 = M[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              double v = fma(dW_dW.m[i][0], m0, 0.0);
+              v = fma(dW_dW.m[i][1], m1, v);
+              v = fma(dW_dW.m[i][2], m2, v);
+              o[i] = fma(-1.0, M[9 + i], v);
+              f[i] = j == 0 ? dW_dW.m[i][0] : (j == 1 ? dW_dW.m[i][1] : (j == 2 ? dW_dW.m[i][2] : (j == 9 + i ? -1.0 : 0.0)));
+            }
+          } else if (wave == 1) {                                 // Tsb rows: k = 6 + i (1)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { o[i] = fma(1.0, M[6 + i], 0.0); f[i] = j == 6 + i ? 1.0 : 0.0; }
+          } else {                                                // Vsb rows: k = 0..2, 12..14, 21..22
+            const double m0 = M[0], m1 = M[1], m2 = M[2], m12 = M[12], m13 = M[13], m14 = M[14], m21 = M[21], m22 = M[22];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              double v = fma(dV_dW.m[i][0], m0, 0.0);
+              v = fma(dV_dW.m[i][1], m1, v);
+              v = fma(dV_dW.m[i][2], m2, v);
+              v = fma(nR.m[i][0], m12, v);
+              v = fma(nR.m[i][1], m13, v);
+              v = fma(nR.m[i][2], m14, v);
+              v = fma(dV_dWsg.m[i][0], m21, v);
+              o[i] = fma(dV_dWsg.m[i][1], m22, v);
+              f[i] = j == 0 ? dV_dW.m[i][0] : (j == 1 ? dV_dW.m[i][1] : (j == 2 ? dV_dW.m[i][2] :
+                     (j == 12 ? nR.m[i][0] : (j == 13 ? nR.m[i][1] : (j == 14 ? nR.m[i][2] :
+                     (j == 21 ? dV_dWsg.m[i][0] : (j == 22 ? dV_dWsg.m[i][1] : 0.0)))))));
+            }
+          }
+          if (fk_task) {                                          // FK_st = F + F S h
+#pragma unroll
+            for (int i = 0; i < 3; ++i) FKs[st * NF + (3 * wave + i) + FR * j] = f[i] + o[i] * h;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) FPs[(3 * wave + i) + FR * j] = o[i];
+          }
+        }
+      } else if (wl < NM) {                                       // (P0 F^T)[i, 0..8] = sum_k P0[i, k] F[j, k]
+        const int i = wl;
+        const double p0 = P0[i], p1 = P0[i + NM], p2 = P0[i + NM * 2];
+        const double p12 = P0[i + NM * 12], p13 = P0[i + NM * 13], p14 = P0[i + NM * 14];
+        const double p21 = P0[i + NM * 21], p22 = P0[i + NM * 22];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          double v = fma(p0, dW_dW.m[j][0], 0.0);
+          v = fma(p1, dW_dW.m[j][1], v);
+          v = fma(p2, dW_dW.m[j][2], v);
+          PFs[i + NM * j] = fma(P0[i + NM * (9 + j)], -1.0, v);
+          PFs[i + NM * (3 + j)] = fma(P0[i + NM * (6 + j)], 1.0, 0.0);
+          double w = fma(p0, dV_dW.m[j][0], 0.0);
+          w = fma(p1, dV_dW.m[j][1], w);
+          w = fma(p2, dV_dW.m[j][2], w);
+          w = fma(p12, nR.m[j][0], w);
+          w = fma(p13, nR.m[j][1], w);
+          w = fma(p14, nR.m[j][2], w);
+          w = fma(p21, dV_dWsg.m[j][0], w);
+          PFs[i + NM * (6 + j)] = fma(p22, dV_dWsg.m[j][1], w);
+        }
+      } else if (wl >= 32 && wl < 44) {                           // (G Q G^T)[r, :] on the 12 x 12 support
+        const int r = wl - 32;
+        const double g3 = GQc[r + 12 * 3], g4 = GQc[r + 12 * 4], g5 = GQc[r + 12 * 5];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          GQG[r + 12 * j] = fma(GQc[r + 12 * j], -1.0, 0.0);     // Wsb columns: G[Wsb_j, j] = -1
+          double v = fma(g3, nR.m[j][0], 0.0);                    // Vsb columns: G[Vsb_j, 3..5] = -Rsb[j][:]
+          v = fma(g4, nR.m[j][1], v);
+          GQG[r + 12 * (3 + j)] = fma(g5, nR.m[j][2], v);
+          GQG[r + 12 * (6 + j)] = GQc[r + 12 * (6 + j)];          // bg, ba columns: +1
+          GQG[r + 12 * (9 + j)] = GQc[r + 12 * (9 + j)];
+        }
+      }
+      __syncthreads();
+
+      // -- phase C: PK_st = F P0 + P0 F^T + G Q G^T
       for (int e = lane; e < NN; e += NT) {
         const int i = e % NM, j = e / NM;
-        double v = 0.0, fp = 0.0, pf = 0.0;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) v = fma(GQ[i + NM * k], G[j + NM * k], v);
-        if (i < FR) {
-#pragma unroll
-          for (int k = 0; k < NM; ++k) fp = fma(F[E(i, k)], P0[E(k, j)], fp);
-        }
-        if (j < FR) {
-#pragma unroll
-          for (int k = 0; k < NM; ++k) pf = fma(P0[E(i, k)], F[E(j, k)], pf);
-        }
-        PKs[st * NN + e] = (fp + pf) + v;            // F P0 + P0 F^T + G Q G^T
+        const int ci = i < 3 ? i : ((i >= 6 && i < 15) ? i - 3 : -1), cj = j < 3 ? j : ((j >= 6 && j < 15) ? j - 3 : -1);
+        const double fp = i < FR ? FPs[i + FR * j] : 0.0;
+        const double pf = j < FR ? PFs[i + NM * j] : 0.0;
+        const double v = (ci >= 0 && cj >= 0) ? GQG[ci + 12 * cj] : 0.0;
+        PKs[st * NN + e] = (fp + pf) + v;
       }
       __syncthreads();
     }
@@ -1211,24 +1276,26 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
     for (int i = 0; i < 3; ++i) { ge.v[i] = gyro.v[i] + sg.v[i] * h; ae.v[i] = accel.v[i] + sa.v[i] * h; }
     compose_motion_dev(X, Kt, ge, ae, h, gv);
     for (int e = lane; e < NN; e += NT) {
-      double fk = 0.0, pk = 0.0;
-      for (int q = 0; q < ns; ++q) { fk += tab.b[q] * FKs[q * NN + e]; pk += tab.b[q] * PKs[q * NN + e]; }
+      double pk = 0.0;
+      for (int q = 0; q < ns; ++q) pk += tab.b[q] * PKs[q * NN + e];
       Pmm[e] += pk * h;                              // rk4.cpp:92-93
-      S1[e] = ((e % NM) == (e / NM) ? 1.0 : 0.0) + fk * h;   // Phi_step = I + FK h
+    }
+    for (int e = lane; e < NF; e += NT) {
+      const int i = e % FR, j = e / FR;
+      double fk = 0.0;
+      for (int q = 0; q < ns; ++q) fk += tab.b[q] * FKs[q * NF + e];
+      S1[i + NM * j] = (i == j ? 1.0 : 0.0) + fk * h;   // rows < 9 of Phi_step = I + FK h (the others are identity rows)
     }
     __syncthreads();
-    for (int e = lane; e < NN; e += NT) {            // Phi <- Phi_step Phi (rows >= FR of Phi_step are identity rows)
-      const int i = e % NM, j = e / NM;
-      double v = Phi[e];
-      if (i < FR) {
-        v = 0.0;
+    for (int e = lane; e < NF; e += NT) {            // Phi <- Phi_step Phi
+      const int i = e % FR, j = e / FR;
+      double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < NM; ++k) v = fma(S1[E(i, k)], Phi[E(k, j)], v);
-      }
-      S2[e] = v;
+      for (int k = 0; k < NM; ++k) v = fma(S1[i + NM * k], Phi[k + NM * j], v);
+      FPs[e] = v;
     }
     __syncthreads();
-    for (int e = lane; e < NN; e += NT) Phi[e] = S2[e];
+    for (int e = lane; e < NF; e += NT) Phi[(e % FR) + NM * (e / FR)] = FPs[e];
     __syncthreads();
     gyro = ge; accel = ae;                           // rk4.cpp:27-28
     total += h;
@@ -1368,7 +1435,7 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s) {
   if (a.batch <= 0) return 0;
   const int ns = a.method ? 7 : 4;
-  const size_t lds = (size_t)(5 * 529 + 2 * 276 + 144 + 24 + 2 * ns * 529) * sizeof(double);   // RK4: 59 KB, DP: 110 KB
+  const size_t lds = (size_t)(4 * 529 + 2 * 207 + 3 * 144 + 24 + ns * (207 + 529)) * sizeof(double);   // RK4: 47 KB, DP: 65 KB
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

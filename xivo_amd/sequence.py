@@ -161,6 +161,9 @@ class HipBackend:
         self.ctx.absorb_error()
         return mask
 
+    def sync(self):
+        self.ctx.sync()
+
     def poses(self):
         p, _, _ = self.ctx.get_scene()
         return p["Rsb"].reshape(-1, 3, 3).transpose(0, 2, 1).copy(), p["Tsb"].copy()
@@ -210,6 +213,17 @@ class SequenceRunner:
         self.books = [_Book(cfg.n_groups, cfg.n_features) for _ in range(B)]
         self.n_updates = 0
         self.n_rejected = 0
+        self.timers = None       # set to {} to accumulate wall seconds per phase (adds a device sync per phase)
+
+    def _tick(self, name, t0):
+        if self.timers is None:
+            return 0.0
+        import time
+        if name not in ("host_pre", "host_post") and hasattr(self.be, "sync"):
+            self.be.sync()
+        t1 = time.perf_counter()
+        self.timers[name] = self.timers.get(name, 0.0) + (t1 - t0)
+        return t1
 
     def _discard_empty_groups(self, b, ops):
         bk = self.books[b]
@@ -220,9 +234,12 @@ class SequenceRunner:
 
     def frame(self, imu, tracks):
         """imu: [B x K] xivo_imu_in records or None; tracks: per filter (ids [n], xp_and_depths [n x 3])."""
+        import time
         cfg, be = self.cfg, self.be
+        t0 = time.perf_counter()
         if imu is not None:
             be.propagate(imu)
+        t0 = self._tick("propagate", t0) or t0
         # --- before the update: tracker-dropped features leave, tracked ones get their new pixel
         ops = []
         for b in range(self.B):
@@ -239,9 +256,13 @@ class SequenceRunner:
                     ops.append(_op(b, L.EDIT_REMOVE_FEATURE, j))
                     bk.drop_feature(j)
             self._discard_empty_groups(b, ops)
-        be.edit(np.array(ops, dtype=L.edit_dtype))
+        ops = np.array(ops, dtype=L.edit_dtype)
+        t0 = self._tick("host_pre", t0) or t0
+        be.edit(ops)
+        t0 = self._tick("edit", t0) or t0
         # --- measurement update on the tracked in-state features (every filter, ragged)
         mask = be.update()
+        t0 = self._tick("update", t0) or t0
         self.n_updates += sum(1 for bk in self.books if bk.n_instate() > 0)
         # --- after the update: MH-rejected features leave, then new features enter with a new group
         ops = []
@@ -273,7 +294,10 @@ class SequenceRunner:
                 ops.append(_op(b, L.EDIT_ADD_FEATURE, j, j, g, v=np.concatenate([x, meas[k, :2], P3])))
                 bk.feat_id[j] = int(ids[k]); bk.feat_ref[j] = g; bk.id2slot[int(ids[k])] = j
                 bk.group_refs[g] += 1
-        be.edit(np.array(ops, dtype=L.edit_dtype))
+        ops = np.array(ops, dtype=L.edit_dtype)
+        t0 = self._tick("host_post", t0) or t0
+        be.edit(ops)
+        self._tick("edit", t0)
         return mask
 
 
@@ -292,7 +316,8 @@ def initial_poses(cfg, sims, t0=0.0):
     return poses
 
 
-def run_pcw(backend_factory, cfg, worlds, sims, total_time=4.0, imu_dt=0.0025, vision_dt=0.04, noise_vision_std=1.0):
+def run_pcw(backend_factory, cfg, worlds, sims, total_time=4.0, imu_dt=0.0025, vision_dt=0.04, noise_vision_std=1.0,
+            timers=None):
     """The loop of scripts/pyxivo_pcw.py:117-163 for B = len(sims) sequences at once.
     -> dict(ts [n] ns, Tsb [n x B x 3], Wsb [n x B x 3], gt_Tsb [n x B x 3], runner, backend)"""
     B = len(sims)
@@ -302,6 +327,7 @@ def run_pcw(backend_factory, cfg, worlds, sims, total_time=4.0, imu_dt=0.0025, v
     P0 = np.repeat(cfg.P_init()[None], B, axis=0)
     be = backend_factory(cfg, B, poses0, P0)
     runner = SequenceRunner(be, cfg, B)
+    runner.timers = timers
     m0 = [s.meas(0.0) for s in sims]
     feeder = ImuFeeder(B, 0.0, [m[1] for m in m0], [m[0] for m in m0])
     n_imu = int(round(total_time / imu_dt)); every = int(round(vision_dt / imu_dt))
