@@ -18,10 +18,11 @@ using namespace xivo_hip;
 namespace {
 
 enum Stage : int {
-  ST_JAC = 0, ST_GATE, ST_STACK, ST_HP, ST_S, ST_CHOL, ST_TRSM, ST_KH, ST_AP, ST_PNEW, ST_OTHER, ST_COUNT
+  ST_JAC = 0, ST_GATE, ST_STACK, ST_HP, ST_S, ST_CHOL, ST_TRSM, ST_KH, ST_AP, ST_PNEW, ST_OTHER, ST_PROP_STATE, ST_PROP_TAIL, ST_COUNT
 };
 const char* kStageNames[ST_COUNT] = {"jac_instate", "mh_gate", "stack_H", "gemm_HP", "gemm_S", "chol_S",
-                                     "trsm_gain", "gemm_KH_I", "gemm_AP", "gemm_Pnew", "other"};
+                                     "trsm_gain", "gemm_KH_I", "gemm_AP", "gemm_Pnew", "other", "propagate_state",
+                                     "propagate_tail"};
 
 struct EventPair { hipEvent_t a, b; int stage; };
 
@@ -1120,8 +1121,13 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   a.g[0] = o->g[0]; a.g[1] = o->g[1]; a.g[2] = o->g[2]; a.method = o->method; a.stepsize = o->stepsize;
   a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
   {
-    StageTimer st(c, ST_OTHER, 0.0, "propagate_state_kernel");
+    StageTimer st(c, ST_PROP_STATE, 0.0, "propagate_state_kernel");
     if (launch_propagate_state(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  {
+    // tail: reads and writes the 23 rows and 23 columns of P that change (+ Phi, P_mm)
+    StageTimer st(c, ST_PROP_TAIL, 0.0, "propagate_cov_fixed_kernel<23>",
+                  (double)nb * (4.0 * 23 * c->N + 2.0 * 529) * sizeof(double));
     if (launch_propagate_cov(c->P, c->sP, c->Np, c->N, c->Np, 23, dPhi, dPmm, b0, nb, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));   // imu / opts are borrowed host memory

@@ -989,32 +989,68 @@ __global__ __launch_bounds__(256) void propagate_cov_kernel(double* Pall, long s
 }
 
 // Compile-time motion size (the default build's 23): col / row stay in registers (with a run-time nm the two
-// arrays are indexed dynamically and live in scratch: 1.83 ms per 4096 filters at N = 251 instead of 0.2).
+// arrays are indexed dynamically and live in scratch). One workgroup per filter, one thread per state column j >= NM.
+// The row block P_ms (NM x (N - NM): NM contiguous doubles per column, columns ldp apart) goes through LDS so that
+// HBM sees each 8 NM-byte run once, in lane order, on the way in and on the way out; the column block P_sm is
+// coalesced as it lies. Phi sits in LDS with an even leading dimension so that one 16-byte broadcast read feeds two
+// output rows (4 FMAs). Bound: HBM - 4 x 8 NM (N - NM) bytes per filter.
 template <int NM>
 __global__ __launch_bounds__(256) void propagate_cov_fixed_kernel(double* Pall, long strideP, int ldp, int N,
                                                                   const double* Phi_all, const double* Pmm_all, int b0) {
+  constexpr int LP = NM + 1;        // even: rows (i, i + 1), i even, of one Phi column are 16-byte aligned
+  static_assert(LP % 2 == 0, "NM must be odd");
   const int filt = b0 + blockIdx.x, tid = threadIdx.x;
   double* P = Pall + (long)filt * strideP;
   const double* Phi = Phi_all + (long)blockIdx.x * NM * NM;
   const double* Pmm = Pmm_all + (long)blockIdx.x * NM * NM;
-  __shared__ double sPhi[NM * NM];  // column-major
-  for (int e = tid; e < NM * NM; e += 256) sPhi[e] = Phi[e];
-  __syncthreads();
-  for (int j = NM + tid; j < N; j += 256) {
-    double col[NM], row[NM];
-#pragma unroll
-    for (int k = 0; k < NM; ++k) { col[k] = P[k + (long)j * ldp]; row[k] = P[j + (long)k * ldp]; }
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      double s = 0.0, t = 0.0;
-#pragma unroll
-      for (int k = 0; k < NM; ++k) {
-        const double ph = sPhi[i + k * NM];
-        s = fma(ph, col[k], s);   // (Phi P_ms)(i, j)
-        t = fma(row[k], ph, t);   // (P_sm Phi^T)(j, i)
+  __shared__ __attribute__((aligned(16))) double sPhi[LP * NM];   // column-major, row NM = 0
+  __shared__ double sBlk[NM * 256];                                // [k + NM * (j - j0)]
+  for (int e = tid; e < NM * NM; e += 256) sPhi[(e % NM) + LP * (e / NM)] = Phi[e];
+  if (tid < NM) sPhi[NM + LP * tid] = 0.0;
+  for (int j0 = NM; j0 < N; j0 += 256) {
+    const int nc = N - j0 < 256 ? N - j0 : 256;
+    __syncthreads();                                // sPhi ready / previous chunk written back
+    {
+      int k = tid % NM, jj = tid / NM;              // element e = tid + 256 m  <->  (k, jj)
+      for (int e = tid; e < NM * nc; e += 256) {
+        sBlk[e] = P[k + (long)(j0 + jj) * ldp];
+        k += 256 % NM; jj += 256 / NM;
+        if (k >= NM) { k -= NM; ++jj; }
       }
-      P[i + (long)j * ldp] = s;
-      P[j + (long)i * ldp] = t;
+    }
+    __syncthreads();
+    if (tid < nc) {
+      const int j = j0 + tid;
+      double col[NM], row[NM];
+#pragma unroll
+      for (int k = 0; k < NM; ++k) { col[k] = sBlk[k + NM * tid]; row[k] = P[j + (long)k * ldp]; }
+#pragma unroll
+      for (int i = 0; i < NM; i += 2) {
+        double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+          const double2 ph = *reinterpret_cast<const double2*>(&sPhi[i + LP * k]);
+          s0 = fma(ph.x, col[k], s0);   // (Phi P_ms)(i, j)
+          t0 = fma(row[k], ph.x, t0);   // (P_sm Phi^T)(j, i)
+          s1 = fma(ph.y, col[k], s1);
+          t1 = fma(row[k], ph.y, t1);
+        }
+        sBlk[i + NM * tid] = s0;
+        P[j + (long)i * ldp] = t0;
+        if (i + 1 < NM) {
+          sBlk[i + 1 + NM * tid] = s1;
+          P[j + (long)(i + 1) * ldp] = t1;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      int k = tid % NM, jj = tid / NM;
+      for (int e = tid; e < NM * nc; e += 256) {
+        P[k + (long)(j0 + jj) * ldp] = sBlk[e];
+        k += 256 % NM; jj += 256 / NM;
+        if (k >= NM) { k -= NM; ++jj; }
+      }
     }
   }
   for (int e = tid; e < NM * NM; e += 256) P[(e % NM) + (long)(e / NM) * ldp] = Pmm[e];
@@ -1042,41 +1078,68 @@ __constant__ RkTableau kTableau[2] = {
      {0.0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1.0, 1.0},
      {0.0862, 0.0, 0.6660, -0.7857, 0.9570, 0.0965, -0.0200}}};
 
-struct MotionRegs { M3 Rsb, Rsg; V3 Tsb, Vsb, bg, ba; };
+// exp(hat(w)) for the per-stage rotation increments (|w| = |gyro| * step, a few mrad): sin(t)/t and (1 - cos t)/t^2 as
+// even Taylor series in t^2 - for |w| <= 0.25 the truncation is < 1e-20, below the rounding of the sin / cos route -
+// which removes sqrt, sin, cos and two divisions from the serial chain every stage waits for.
+__device__ __forceinline__ M3 so3_exp_small(double wx, double wy, double wz) {
+  const double t2 = wx * wx + wy * wy + wz * wz;
+  if (t2 > 0.0625) return so3_exp_dev(wx, wy, wz);
+  const double a = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, 1.0 / 6227020800.0, -1.0 / 39916800.0), 1.0 / 362880.0),
+                                                 -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+  const double b = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, 1.0 / 87178291200.0, -1.0 / 479001600.0), 1.0 / 3628800.0),
+                                                 -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0), 0.5);
+  const V3 w{{wx, wy, wz}};
+  const M3 W = hat(w), W2 = m3_mul(W, W);
+  M3 R;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R.m[i][j] = (i == j ? 1.0 : 0.0) + a * W.m[i][j] + b * W2.m[i][j];
+  return R;
+}
+
+struct MotionRegs { M3 Rsb; V3 Tsb, Vsb, bg, ba; };   // Rsg is a constant of Propagate: its product Rsg g is passed separately
 
 // ComposeMotion, estimator.cpp:598-613 (default build: Cg = Ca = I)
 __device__ __forceinline__ void compose_motion_dev(MotionRegs& X, const V3& V, const V3& gyro, const V3& accel, double dt,
-                                                   const V3& g) {
+                                                   const V3& Rg) {
   V3 gc, ac;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { gc.v[i] = gyro.v[i] - X.bg.v[i]; ac.v[i] = accel.v[i] - X.ba.v[i]; }
-  const V3 Ra = m3_mulv(X.Rsb, ac), Rg = m3_mulv(X.Rsg, g);
+  const V3 Ra = m3_mulv(X.Rsb, ac);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     X.Tsb.v[i] += V.v[i] * dt;                                   // :608
     X.Vsb.v[i] += (Ra.v[i] + Rg.v[i]) * dt;                      // :609
   }
-  X.Rsb = m3_mul(X.Rsb, so3_exp_dev(gc.v[0] * dt, gc.v[1] * dt, gc.v[2] * dt));   // :610
+  X.Rsb = m3_mul(X.Rsb, so3_exp_small(gc.v[0] * dt, gc.v[1] * dt, gc.v[2] * dt));   // :610
 }
 
-// One workgroup of 256 threads per filter. Every thread carries the (tiny) nominal state redundantly, hence also the
-// entries of the motion Jacobians: F = dX'/dX (23 x 23) has non-zero rows only for Wsb, Tsb, Vsb (rows 0..8: biases,
-// extrinsics and gravity are constants of the motion model) and at most 8 non-zeros in a row - dW/dW, dW/dbg = -I,
-// dT/dV = I, dV/dW, dV/dba = -Rsb, dV/dWsg (estimator.cpp:615-704) - and G (23 x 12) is four 3 x 3 blocks
-// (-I, -Rsb, I, I). Neither is ever materialised: F M, M F^T and G Q G^T are formed from the register copies with the
-// structural zeros skipped (exact: the skipped terms are 0 * x, and the surviving terms are summed in the same
-// ascending-k order as the dense product), so a stage costs ~0.1 of the dense 9-row products and three barriers.
+// One workgroup of 256 threads per filter; every wave carries the (tiny) nominal state. Structure exploited:
+//  * The nominal state of stage st - ComposeMotion of the sub-step's start state with the interpolated IMU sample
+//    (rk4.cpp:49-88) - feeds the covariance stages only through Rsb(st), the bias-corrected gyro / accel and the stage
+//    velocity K_st, and none of these depends on another stage (only Tsb does, through the a_ij-weighted velocities,
+//    and Tsb enters no Jacobian). So the serial chain of ns ComposeMotion + ComputeMotionJacobianAt evaluations
+//    (estimator.cpp:598-704) collapses to a pre-pass in which wave w evaluates stages w, w + 4 and publishes the
+//    Jacobian blocks (36 numbers) and K_st in LDS, followed by one ComposeMotion for the sub-step itself.
+//  * F = dX'/dX (23 x 23) has non-zero rows only for Wsb, Tsb, Vsb and at most 8 non-zeros in a row - dW/dW,
+//    dW/dbg = -I, dT/dV = I, dV/dW, dV/dba = -Rsb, dV/dWsg - and G (23 x 12) is four 3 x 3 blocks (-I, -Rsb, I, I).
+//    Neither is materialised: F M, M F^T and G Q G^T are formed from register copies of the 36 numbers with the
+//    structural zeros skipped (exact: the skipped terms are 0 * x, the surviving ones are summed in the same
+//    ascending-k order as the dense product).
+//  * NS (stages) is a template parameter: the tableau-weighted sums are unrolled, all LDS loads of a sum are in
+//    flight together, and coefficients of stages not yet computed are the tableau's zeros times finite stale values.
 // The 23 x 23 matrices live in LDS (column-major, ld 23); FK keeps its 9 non-zero rows only ([i + 9 j]).
-// Work split of the product phase, by wave: waves 0..2 own the row blocks Wsb / Tsb / Vsb of F: lanes 0..22 form
-// column j of F P0, lanes 32..54 column j of F S (S = sum a_q FK_q) and from it FK of the stage; wave 3: lanes 0..22
-// row i of P0 F^T, lanes 32..43 row r of the 12 x 12 support of G Q G^T.
-__global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
+// Product phase by wave: waves 0..2 own the row blocks Wsb / Tsb / Vsb of F: lanes 0..22 form column j of F P0,
+// lanes 32..54 column j of F S (S = sum a_q FK_q) and from it FK of the stage; wave 3: lanes 0..22 row i of P0 F^T,
+// lanes 32..43 row r of the 12 x 12 support of G Q G^T.
+template <int NS>
+__global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a) {
   constexpr int NM = 23, NN = NM * NM, NT = 256, FR = 9, NF = FR * NM;   // FR: rows of F that are not identically zero
   extern __shared__ double sm[];
   const int lane = threadIdx.x, filt = blockIdx.x;   // `lane`: thread index in the workgroup
   const int wave = lane >> 6, wl = lane & 63;
-  const RkTableau& tab = kTableau[a.method ? 1 : 0];
-  const int ns = tab.ns;
+  const RkTableau& tab = kTableau[NS == 4 ? 0 : 1];
   double* Pmm = sm;            // P_mm at the start of the sub-step
   double* Phi = Pmm + NN;      // accumulated transition
   double* P0 = Phi + NN;
@@ -1086,9 +1149,10 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
   double* GQG = PFs + NF;      // [12 x 12] support of G Q G^T: rows / cols (Wsb, Vsb, bg, ba)
   double* Q = GQG + 144;       // 12 x 12
   double* GQc = Q + 144;       // [12 x 12] the non-zero rows of G Q
-  double* sKs = GQc + 144;     // [7][3] stage velocities (in LDS: a register array indexed by the stage lives in scratch)
-  double* FKs = sKs + 24;      // [ns][9 x 23]
-  double* PKs = FKs + ns * NF; // [ns][23 x 23]
+  double* sKs = GQc + 144;     // [NS][3] stage velocities
+  double* Jms = sKs + 24;      // [NS][4][3 x 3] row-major: dW/dW, dV/dW, -Rsb, dV/dWsg of every stage
+  double* FKs = Jms + NS * 36; // [NS][9 x 23]
+  double* PKs = FKs + NS * NF; // [NS][23 x 23]
 
   const double* Pg = a.P + (long)filt * a.strideP;
   for (int e = lane; e < NN; e += NT) {
@@ -1097,6 +1161,7 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
     Phi[e] = i == j ? 1.0 : 0.0;
     S1[e] = 0.0;
   }
+  for (int e = lane; e < NS * (NF + NN); e += NT) FKs[e] = 0.0;   // finite values under the tableau's zero coefficients
   for (int e = lane; e < 144; e += NT) {
     const double q = a.Qimu[e];
     Q[e] = q;
@@ -1107,10 +1172,11 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
   }
   xivo_pose_in& pose = a.poses[filt];
   MotionRegs X;
-  X.Rsb = m3_from_colmajor(pose.Rsb); X.Rsg = m3_from_colmajor(pose.Rsg);
+  X.Rsb = m3_from_colmajor(pose.Rsb);
 #pragma unroll
   for (int i = 0; i < 3; ++i) { X.Tsb.v[i] = pose.Tsb[i]; X.Vsb.v[i] = pose.Vsb[i]; X.bg.v[i] = pose.bg[i]; X.ba.v[i] = pose.ba[i]; }
   const V3 gv{{a.g[0], a.g[1], a.g[2]}};
+  const V3 Rg = m3_mulv(m3_from_colmajor(pose.Rsg), gv);   // Rsg g (estimator.cpp:609)
   __syncthreads();
 
   // one Estimator::Propagate per IMU sample; the transitions of all samples are accumulated in Phi so that the
@@ -1128,51 +1194,89 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
     else if (total + h > dt) h = dt - total;
     else if (total + h + 0.5 * h > dt) h = 0.5 * h;
 
-    for (int st = 0; st < ns; ++st) {
+    // -- nominal pre-pass: wave w evaluates stages w, w + 4
+    for (int st = wave; st < NS; st += 4) {
       MotionRegs X0 = X;
       const double ti = tab.c_imu[st] * h;
       V3 gi, ai;
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gi.v[i] = gyro.v[i] + sg.v[i] * ti; ai.v[i] = accel.v[i] + sa.v[i] * ti; }
       if (st > 0) {
-        V3 V{{0, 0, 0}};
-        for (int q = 0; q < st; ++q)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) V.v[i] += tab.a[st][q] * sKs[3 * q + i];
-        compose_motion_dev(X0, V, gi, ai, tab.c_step[st] * h, gv);
+        const V3 V0{{0, 0, 0}};   // the a_ij-weighted velocities only move Tsb, which no Jacobian reads
+        compose_motion_dev(X0, V0, gi, ai, tab.c_step[st] * h, Rg);
       }
-      if (lane < 3) sKs[3 * st + lane] = lane == 0 ? X0.Vsb.v[0] : (lane == 1 ? X0.Vsb.v[1] : X0.Vsb.v[2]);   // visible after the barriers below
-      // ComputeMotionJacobianAt (estimator.cpp:615-704): the blocks of F and G, in registers
+      // ComputeMotionJacobianAt (estimator.cpp:615-704): the blocks of F and G
       V3 gc, ac;
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gc.v[i] = gi.v[i] - X0.bg.v[i]; ac.v[i] = ai.v[i] - X0.ba.v[i]; }
-      const M3 dW_dW = m3_neg(hat(gc));                           // Wsb <- Wsb ; Wsb <- bg is -I
-      const M3 dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));           // Vsb <- Wsb
-      const M3 dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));         // Vsb <- Wsg (first 2 columns)
-      const M3 nR = m3_neg(X0.Rsb);                               // Vsb <- ba, and G's Vsb <- accel-noise block
+      const M3 w_dW_dW = m3_neg(hat(gc));                         // Wsb <- Wsb ; Wsb <- bg is -I
+      const M3 w_dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));         // Vsb <- Wsb
+      const M3 w_dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));       // Vsb <- Wsg (first 2 columns)
+      const M3 w_nR = m3_neg(X0.Rsb);                             // Vsb <- ba, and G's Vsb <- accel-noise block
+      if (wl == 0) {
+        double* Jm = Jms + st * 36;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          sKs[3 * st + i] = X0.Vsb.v[i];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            Jm[3 * i + j] = w_dW_dW.m[i][j]; Jm[9 + 3 * i + j] = w_dV_dW.m[i][j];
+            Jm[18 + 3 * i + j] = w_nR.m[i][j]; Jm[27 + 3 * i + j] = w_dV_dWsg.m[i][j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // the sub-step of the nominal state itself (every wave keeps its own copy)
+    V3 ge, ae;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ge.v[i] = gyro.v[i] + sg.v[i] * h; ae.v[i] = accel.v[i] + sa.v[i] * h; }
+    {
+      V3 Kt{{0, 0, 0}};
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Kt.v[i] += tab.b[q] * sKs[3 * q + i];
+      compose_motion_dev(X, Kt, ge, ae, h, Rg);
+    }
 
+    for (int st = 0; st < NS; ++st) {
+      const double* Jm = Jms + st * 36;
       // -- phase A: S = sum_q a_q FK_q (rows < 9), P0 = Pmm + (sum_q a_q PK_q) h (rk4.cpp:49-88); Vsb rows of G Q
+      double aq[NS - 1];
+#pragma unroll
+      for (int q = 0; q < NS - 1; ++q) aq[q] = tab.a[st][q];
       for (int e = lane; e < NN; e += NT) {
         double sp = 0.0;
-        for (int q = 0; q < st; ++q) sp += tab.a[st][q] * PKs[q * NN + e];
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q) sp += aq[q] * PKs[q * NN + e];
         P0[e] = Pmm[e] + sp * h;
       }
-      for (int e = lane; e < NF; e += NT) {
+      if (lane < NF) {
         double sf = 0.0;
-        for (int q = 0; q < st; ++q) sf += tab.a[st][q] * FKs[q * NF + e];
-        S1[(e % FR) + NM * (e / FR)] = sf;
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q) sf += aq[q] * FKs[q * NF + lane];
+        S1[(lane % FR) + NM * (lane / FR)] = sf;
       }
-      if (lane >= 64 && lane < 76) {                              // (G Q)[Vsb_i, l] = sum_k -Rsb[i][k] Q[3 + k, l]
-        const int l = lane - 64;
+      if (lane >= 224 && lane < 236) {                            // (G Q)[Vsb_i, l] = sum_k -Rsb[i][k] Q[3 + k, l]
+        const int l = lane - 224;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           double v = 0.0;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) v = fma(nR.m[i][k], Q[(3 + k) + 12 * l], v);
+          for (int k = 0; k < 3; ++k) v = fma(Jm[18 + 3 * i + k], Q[(3 + k) + 12 * l], v);
           GQc[(3 + i) + 12 * l] = v;
         }
       }
       __syncthreads();
+      auto ldm = [&](int blk) {                                   // one published 3 x 3 block into registers
+        M3 r;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) r.m[i][j] = Jm[9 * blk + 3 * i + j];
+        return r;
+      };
 
       // -- phase B: the structured products
       if (wave < 3) {
@@ -1182,6 +1286,7 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
           const double* M = (fk_task ? S1 : P0) + NM * j;         // column j
           double o[3], f[3];                                      // o = (F M)[block rows, j], f = F[block rows, j]
           if (wave == 0) {                                        // Wsb rows: k = 0..2 (dW/dW), k = 9 + i (-1)
+            const M3 dW_dW = ldm(0);
             const double m0 = M[0], m1 = M[1], m2 = M[2];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -1195,6 +1300,7 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) { o[i] = fma(1.0, M[6 + i], 0.0); f[i] = j == 6 + i ? 1.0 : 0.0; }
           } else {                                                // Vsb rows: k = 0..2, 12..14, 21..22
+            const M3 dV_dW = ldm(1), nR = ldm(2), dV_dWsg = ldm(3);
             const double m0 = M[0], m1 = M[1], m2 = M[2], m12 = M[12], m13 = M[13], m14 = M[14], m21 = M[21], m22 = M[22];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -1221,6 +1327,7 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
         }
       } else if (wl < NM) {                                       // (P0 F^T)[i, 0..8] = sum_k P0[i, k] F[j, k]
         const int i = wl;
+        const M3 dW_dW = ldm(0), dV_dW = ldm(1), nR = ldm(2), dV_dWsg = ldm(3);
         const double p0 = P0[i], p1 = P0[i + NM], p2 = P0[i + NM * 2];
         const double p12 = P0[i + NM * 12], p13 = P0[i + NM * 13], p14 = P0[i + NM * 14];
         const double p21 = P0[i + NM * 21], p22 = P0[i + NM * 22];
@@ -1242,6 +1349,7 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
         }
       } else if (wl >= 32 && wl < 44) {                           // (G Q G^T)[r, :] on the 12 x 12 support
         const int r = wl - 32;
+        const M3 nR = ldm(2);
         const double g3 = GQc[r + 12 * 3], g4 = GQc[r + 12 * 4], g5 = GQc[r + 12 * 5];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -1267,35 +1375,29 @@ __global__ __launch_bounds__(256) void propagate_state_kernel(PropStateArgs a) {
       __syncthreads();
     }
     // combine the stages
-    V3 Kt{{0, 0, 0}};
-    for (int q = 0; q < ns; ++q)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) Kt.v[i] += tab.b[q] * sKs[3 * q + i];
-    V3 ge, ae;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { ge.v[i] = gyro.v[i] + sg.v[i] * h; ae.v[i] = accel.v[i] + sa.v[i] * h; }
-    compose_motion_dev(X, Kt, ge, ae, h, gv);
     for (int e = lane; e < NN; e += NT) {
       double pk = 0.0;
-      for (int q = 0; q < ns; ++q) pk += tab.b[q] * PKs[q * NN + e];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) pk += tab.b[q] * PKs[q * NN + e];
       Pmm[e] += pk * h;                              // rk4.cpp:92-93
     }
-    for (int e = lane; e < NF; e += NT) {
-      const int i = e % FR, j = e / FR;
+    if (lane < NF) {
+      const int i = lane % FR, j = lane / FR;
       double fk = 0.0;
-      for (int q = 0; q < ns; ++q) fk += tab.b[q] * FKs[q * NF + e];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) fk += tab.b[q] * FKs[q * NF + lane];
       S1[i + NM * j] = (i == j ? 1.0 : 0.0) + fk * h;   // rows < 9 of Phi_step = I + FK h (the others are identity rows)
     }
     __syncthreads();
-    for (int e = lane; e < NF; e += NT) {            // Phi <- Phi_step Phi
-      const int i = e % FR, j = e / FR;
+    if (lane < NF) {                                 // Phi <- Phi_step Phi
+      const int i = lane % FR, j = lane / FR;
       double v = 0.0;
 #pragma unroll
       for (int k = 0; k < NM; ++k) v = fma(S1[i + NM * k], Phi[k + NM * j], v);
-      FPs[e] = v;
+      FPs[lane] = v;
     }
     __syncthreads();
-    for (int e = lane; e < NF; e += NT) Phi[(e % FR) + NM * (e / FR)] = FPs[e];
+    if (lane < NF) Phi[(lane % FR) + NM * (lane / FR)] = FPs[lane];
     __syncthreads();
     gyro = ge; accel = ae;                           // rk4.cpp:27-28
     total += h;
@@ -1432,18 +1534,23 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
                      nm, Phi, Pmm, b0);
   CHECK_LAUNCH();
 }
-int launch_propagate_state(const PropStateArgs& a, hipStream_t s) {
-  if (a.batch <= 0) return 0;
-  const int ns = a.method ? 7 : 4;
-  const size_t lds = (size_t)(4 * 529 + 2 * 207 + 3 * 144 + 24 + ns * (207 + 529)) * sizeof(double);   // RK4: 47 KB, DP: 65 KB
+template <int NS>
+static int launch_propagate_state_ns(const PropStateArgs& a, hipStream_t s) {
+  // LDS: 4 matrices, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, stage velocities, per stage 36 Jacobian entries +
+  // FK (9 rows) + PK: RK4 49 KB (3 workgroups per CU), Dormand-Prince 67 KB (2 per CU)
+  const size_t lds = (size_t)(4 * 529 + 2 * 207 + 3 * 144 + 24 + NS * (36 + 207 + 529)) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel<NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(propagate_state_kernel, dim3(a.batch), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(propagate_state_kernel<NS>, dim3(a.batch), dim3(256), lds, s, a);
   CHECK_LAUNCH();
+}
+int launch_propagate_state(const PropStateArgs& a, hipStream_t s) {
+  if (a.batch <= 0) return 0;
+  return a.method ? launch_propagate_state_ns<7>(a, s) : launch_propagate_state_ns<4>(a, s);
 }
 int launch_mfma_peak(double* sink, int iters, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, sink, iters);

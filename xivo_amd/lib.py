@@ -69,7 +69,8 @@ assert feat_dtype.itemsize == 48 and pose_dtype.itemsize == 336 and group_dtype.
 
 
 def lib_path():
-    return os.path.join(_HERE, "libxivo_hip.so")
+    # XIVO_HIP_LIBRARY: A/B timing of experimental builds in one process pool (scripts only)
+    return os.environ.get("XIVO_HIP_LIBRARY") or os.path.join(_HERE, "libxivo_hip.so")
 
 
 _LIB = None
