@@ -376,9 +376,10 @@ def test_device_qr_compression(built, rows, nx, eff):
         assert np.abs(np.tril(Hxd[b][:r], -1)).max() < 1e-10
 
 
-@pytest.mark.parametrize("method,dt,stepsize", [("RK4", 0.005, 0.002), ("PrinceDormand", 0.0045, 0.002), ("RK4", 0.003, -1.0),
-                                                ("PrinceDormand", 0.01, 0.002)])
-def test_device_propagate_state_and_covariance(built, method, dt, stepsize):
+@pytest.mark.parametrize("method,dt,stepsize,gyro_scale", [("RK4", 0.005, 0.002, 0.3), ("PrinceDormand", 0.0045, 0.002, 0.3),
+                                                           ("RK4", 0.003, -1.0, 0.3), ("PrinceDormand", 0.01, 0.002, 0.3),
+                                                           ("RK4", 0.1, -1.0, 9.0), ("PrinceDormand", 0.1, 0.05, 9.0)])
+def test_device_propagate_state_and_covariance(built, method, dt, stepsize, gyro_scale):
     """Estimator::Propagate entirely on the device (nominal motion state of the resident scene + P): RK4Step /
     PrinceDormandStep with the reference's sub-stepping, ComposeMotion, ComputeMotionJacobianAt, covariance tail and
     + Qmodel, vs the oracle (pinned against the line-faithful Sophus/Eigen RK4Step, golden rk4_*)."""
@@ -396,7 +397,9 @@ def test_device_propagate_state_and_covariance(built, method, dt, stepsize):
         poses[b]["Vsb"] = X.Vsb; poses[b]["bg"] = X.bg; poses[b]["ba"] = X.ba; poses[b]["Rsg"] = X.Rsg.T.reshape(-1)
     P = np.array([spd(N, 50 + b) * 1e-3 for b in range(B)])
     imu = np.zeros(B, dtype=imu_dtype)
-    imu["gyro"] = rng.normal(size=(B, 3)) * 0.3; imu["accel"] = rng.normal(size=(B, 3)) + np.array([0, 0, 9.8])
+    # gyro_scale 9: rotation increments of ~1 rad per stage - the device takes the halve-and-square route of
+    # so3_exp_small where the oracle evaluates sin / cos
+    imu["gyro"] = rng.normal(size=(B, 3)) * gyro_scale; imu["accel"] = rng.normal(size=(B, 3)) + np.array([0, 0, 9.8])
     imu["slope_gyro"] = rng.normal(size=(B, 3)) * 5.0; imu["slope_accel"] = rng.normal(size=(B, 3)) * 20.0
     imu["dt"] = dt * (1.0 + 0.1 * np.arange(B))        # a different sub-step pattern per filter
     Qi = np.diag(rng.uniform(1e-6, 1e-4, 12)); A = rng.normal(size=(23, 23)) * 1e-4; Qm = A @ A.T

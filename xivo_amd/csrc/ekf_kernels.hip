@@ -1080,10 +1080,13 @@ __constant__ RkTableau kTableau[2] = {
 
 // exp(hat(w)) for the per-stage rotation increments (|w| = |gyro| * step, a few mrad): sin(t)/t and (1 - cos t)/t^2 as
 // even Taylor series in t^2 - for |w| <= 0.25 the truncation is < 1e-20, below the rounding of the sin / cos route -
-// which removes sqrt, sin, cos and two divisions from the serial chain every stage waits for.
+// which removes sqrt, sin, cos and two divisions (and their registers) from the chain every stage waits for. A larger
+// increment (a single 0.1 s step of a fast spin) is halved until it is small and the result squared back:
+// exp(w) = exp(w / 2^n)^(2^n), each squaring costing one rounding of a rotation matrix.
 __device__ __forceinline__ M3 so3_exp_small(double wx, double wy, double wz) {
-  const double t2 = wx * wx + wy * wy + wz * wz;
-  if (t2 > 0.0625) return so3_exp_dev(wx, wy, wz);
+  double t2 = wx * wx + wy * wy + wz * wz;
+  int halvings = 0;                         // scaling and squaring for the (unusual) large increment
+  while (t2 > 0.0625 && halvings < 64) { wx *= 0.5; wy *= 0.5; wz *= 0.5; t2 *= 0.25; ++halvings; }
   const double a = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, 1.0 / 6227020800.0, -1.0 / 39916800.0), 1.0 / 362880.0),
                                                  -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
   const double b = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, 1.0 / 87178291200.0, -1.0 / 479001600.0), 1.0 / 3628800.0),
@@ -1095,6 +1098,7 @@ __device__ __forceinline__ M3 so3_exp_small(double wx, double wy, double wz) {
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) R.m[i][j] = (i == j ? 1.0 : 0.0) + a * W.m[i][j] + b * W2.m[i][j];
+  for (; halvings > 0; --halvings) R = m3_mul(R, R);
   return R;
 }
 
