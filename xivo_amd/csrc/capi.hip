@@ -65,6 +65,7 @@ struct xivo_hip_ctx {
   int oos_cap = 0;
   int* oos_rows = nullptr;
   xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
+  std::vector<char> hstage;                        // host staging of d2h_rows
   void* edit_buf = nullptr; size_t edit_cap = 0;   // device copy of the ops of xivo_hip_edit_batch
   size_t sub_cap = 0;
   // timing
@@ -141,6 +142,24 @@ SceneBuffers scene_buffers(xivo_hip_ctx* c) {
   sb.J = c->J; sb.finn = c->finn; sb.mask = c->mask; sb.dist = c->dist;
   sb.Fmax = c->Fmax; sb.F = c->F;
   return sb;
+}
+
+// Device -> host copy of `rows` rows of `width` bytes (device pitch dpitch, host pitch hpitch). hipMemcpy2D issues one
+// small DMA per row - 13 ms for 2048 rows of 30 bytes - so short rows come over as one contiguous block and are
+// repacked on the host.
+int d2h_rows(xivo_hip_ctx* c, void* dst, size_t hpitch, const void* src, size_t dpitch, size_t width, size_t rows) {
+  if (rows == 0 || width == 0) return XIVO_HIP_OK;
+  if (width == dpitch && width == hpitch) {
+    HIP_TRY(hipMemcpyAsync(dst, src, width * rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return XIVO_HIP_OK;
+  }
+  const size_t span = dpitch * (rows - 1) + width;
+  if (c->hstage.size() < span) c->hstage.resize(span);
+  HIP_TRY(hipMemcpyAsync(c->hstage.data(), src, span, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (size_t r = 0; r < rows; ++r) memcpy((char*)dst + r * hpitch, c->hstage.data() + r * dpitch, width);
+  return XIVO_HIP_OK;
 }
 
 int ensure_staging(xivo_hip_ctx* c, size_t elems) {
@@ -683,20 +702,19 @@ int xivo_hip_get_gate(xivo_hip_ctx* c, int B, int F, unsigned char* mask_out, do
   // the dense gate packs [B][F]; the layout-faithful gate (xivo_hip_mh_gate / filter_update) strides by Fmax
   const size_t ld = c->gate_sparse_last ? (size_t)c->Fmax : (size_t)F;
   if (c->gate_sparse_last && F != c->F) return XIVO_HIP_ERR_INVALID;
-  if (mask_out) HIP_TRY(hipMemcpy2DAsync(mask_out, F, c->mask, ld, F, B, hipMemcpyDeviceToHost, c->stream));
-  if (dist_out) HIP_TRY(hipMemcpy2DAsync(dist_out, F * sizeof(double), c->dist, ld * sizeof(double), F * sizeof(double), B,
-                                         hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (mask_out) { int rc = d2h_rows(c, mask_out, F, c->mask, ld, F, B); if (rc) return rc; }
+  if (dist_out) {
+    int rc = d2h_rows(c, dist_out, F * sizeof(double), c->dist, ld * sizeof(double), F * sizeof(double), B);
+    if (rc) return rc;
+  }
   return XIVO_HIP_OK;
 }
 
 int xivo_hip_get_err(xivo_hip_ctx* c, int b0, int nb, double* err, long stride) {
   if (bad_range(c, b0, nb) || !err || stride < c->N) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
-  HIP_TRY(hipMemcpy2DAsync(err, (size_t)stride * sizeof(double), c->err + (long)b0 * c->Np, (size_t)c->Np * sizeof(double),
-                           (size_t)c->N * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return XIVO_HIP_OK;
+  return d2h_rows(c, err, (size_t)stride * sizeof(double), c->err + (long)b0 * c->Np, (size_t)c->Np * sizeof(double),
+                  (size_t)c->N * sizeof(double), nb);
 }
 
 int xivo_hip_get_status(xivo_hip_ctx* c, int b0, int nb, int* status) {
@@ -809,11 +827,16 @@ int xivo_hip_jacobians_instate(xivo_hip_ctx* c, int B) {
 int xivo_hip_get_jacobians(xivo_hip_ctx* c, int b0, int nb, double* J, double* inn) {
   if (bad_range(c, b0, nb) || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   const size_t F = c->F, Fm = c->Fmax;
-  if (J) HIP_TRY(hipMemcpy2DAsync(J, F * 42 * sizeof(double), c->J + (size_t)b0 * Fm * 42, Fm * 42 * sizeof(double),
-                                  F * 42 * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
-  if (inn) HIP_TRY(hipMemcpy2DAsync(inn, F * 2 * sizeof(double), c->finn + (size_t)b0 * Fm * 2, Fm * 2 * sizeof(double),
-                                    F * 2 * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (J) {
+    int rc = d2h_rows(c, J, F * 42 * sizeof(double), c->J + (size_t)b0 * Fm * 42, Fm * 42 * sizeof(double),
+                      F * 42 * sizeof(double), nb);
+    if (rc) return rc;
+  }
+  if (inn) {
+    int rc = d2h_rows(c, inn, F * 2 * sizeof(double), c->finn + (size_t)b0 * Fm * 2, Fm * 2 * sizeof(double),
+                      F * 2 * sizeof(double), nb);
+    if (rc) return rc;
+  }
   return XIVO_HIP_OK;
 }
 
@@ -832,10 +855,11 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
   int rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
   if (rc) return rc;
   const size_t F = c->F, Fm = c->Fmax;
-  if (mask_out) HIP_TRY(hipMemcpy2DAsync(mask_out, F, c->mask, Fm, F, B, hipMemcpyDeviceToHost, c->stream));
-  if (dist_out) HIP_TRY(hipMemcpy2DAsync(dist_out, F * sizeof(double), c->dist, Fm * sizeof(double), F * sizeof(double), B,
-                                         hipMemcpyDeviceToHost, c->stream));
-  if (mask_out || dist_out) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (mask_out) { rc = d2h_rows(c, mask_out, F, c->mask, Fm, F, B); if (rc) return rc; }
+  if (dist_out) {
+    rc = d2h_rows(c, dist_out, F * sizeof(double), c->dist, Fm * sizeof(double), F * sizeof(double), B);
+    if (rc) return rc;
+  }
   return XIVO_HIP_OK;
 }
 
@@ -1058,11 +1082,12 @@ int xivo_hip_get_scene(xivo_hip_ctx* c, int b0, int nb, xivo_pose_in* poses, xiv
   if (poses) HIP_TRY(hipMemcpyAsync(poses, c->poses + b0, (size_t)nb * sizeof(xivo_pose_in), hipMemcpyDeviceToHost, c->stream));
   if (groups) HIP_TRY(hipMemcpyAsync(groups, c->groups + (size_t)b0 * c->lay.n_groups,
                                      (size_t)nb * c->lay.n_groups * sizeof(xivo_group_in), hipMemcpyDeviceToHost, c->stream));
-  if (feats && c->F > 0)
-    HIP_TRY(hipMemcpy2DAsync(feats, (size_t)c->F * sizeof(xivo_feat_in), c->feats + (size_t)b0 * c->Fmax,
-                             (size_t)c->Fmax * sizeof(xivo_feat_in), (size_t)c->F * sizeof(xivo_feat_in), nb,
-                             hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (feats && c->F > 0) {
+    int rc = d2h_rows(c, feats, (size_t)c->F * sizeof(xivo_feat_in), c->feats + (size_t)b0 * c->Fmax,
+                      (size_t)c->Fmax * sizeof(xivo_feat_in), (size_t)c->F * sizeof(xivo_feat_in), nb);
+    if (rc) return rc;
+  }
   return XIVO_HIP_OK;
 }
 
