@@ -107,6 +107,11 @@ def main():
     ap.add_argument("--level", choices=["S", "G"], default="S",
                     help="S (default, the BASELINE metric point): dense H rows resident; G: feature-level path at the "
                          "constructible layout N=251 (8 groups, 60 features): Jacobians + sparse gating + stacking + update")
+    ap.add_argument("--propagate-samples", type=int, default=0,
+                    help="level G only: every step also integrates this many IMU samples (Estimator::Propagate, 2.5 ms each "
+                         "at 2 ms sub-steps) before the update and absorbs the error after it - the whole per-frame loop "
+                         "(SURVEY 8d: the metric with propagation); 16 samples = 32 Runge-Kutta sub-steps per update")
+    ap.add_argument("--integrator", choices=["RK4", "PrinceDormand"], default="RK4")
     ap.add_argument("--no-gating", action="store_true",
                     help="time UpdateJosephForm only (default: MH gating + UpdateJosephForm, one 'update' of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,9 +187,25 @@ def main():
             ctx.upload_P(P[:nb], b0=b0)
             ctx.set_measurements(H[:nb], inn[:nb], dR[:nb], b0=b0)
     ctx.snapshot_P()
+    frame = args.level == "G" and args.propagate_samples > 0
+    if frame:
+        # a sensor at rest: the accelerometer reads -g in the body frame, so the nominal state stays where the scene
+        # was generated while P is propagated (Qimu / Qmodel of cfg/tumvi_cam0.json's order of magnitude)
+        from xivo_amd.lib import imu_dtype
+        p_all, _, _ = ctx.get_scene()
+        Rsb = p_all["Rsb"].reshape(B, 3, 3).transpose(0, 2, 1)
+        imu = np.zeros((B, args.propagate_samples), dtype=imu_dtype)
+        imu["accel"] = (np.transpose(Rsb, (0, 2, 1)) @ np.array([0.0, 0.0, 9.8]))[:, None, :]
+        imu["dt"] = 0.0025
+        Qimu = np.diag(np.repeat([1e-6, 1e-4, 1e-10, 1e-10], 3)); Qmodel = np.eye(23) * 1e-10
+        grav = np.array([0.0, 0.0, -9.8])
 
     def step():
-        if args.level == "G":
+        if frame:
+            ctx.propagate(imu, Qimu, Qmodel, grav, method=args.integrator, stepsize=0.002)
+            ctx.filter_update(R_VIS, MH_THRESH, MH_MULT, MIN_INL, not args.no_gating, B)
+            ctx.absorb_error(B)
+        elif args.level == "G":
             ctx.filter_update(R_VIS, MH_THRESH, MH_MULT, MIN_INL, not args.no_gating, B)
         elif args.no_gating:
             ctx.update_joseph(B)
@@ -285,7 +306,9 @@ def main():
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("feature-level: Jacobians + " if args.level == "G" else "") +
+            "config": {"workload": (f"whole frame: Propagate ({args.propagate_samples} IMU samples, {args.integrator}) + AbsorbError + "
+                                    if frame else "") +
+                                   ("feature-level: Jacobians + " if args.level == "G" else "") +
                                    ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
                                    f": state dim {N}, {F} features (M={M}), XIVO row sparsity, P/H/inn/R resident in HBM",
                        "filters_per_gpu": B, "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
