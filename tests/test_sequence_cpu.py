@@ -127,3 +127,25 @@ def test_sequence_runner_tracks_ground_truth_with_the_oracle_backend():
             assert np.allclose(P, P.T, atol=1e-9) and np.linalg.eigvalsh(P).min() > -1e-9
     assert max(res[True]) < 0.08, res
     assert min(res[False]) > 3 * max(res[True]), res
+
+
+def test_reference_cfg_schema_is_read(tmp_path):
+    """pyxivo-style construction reads the reference's estimator cfg schema (// comments, "X", "P", "Qmodel", "Qimu",
+    "camera_cfg", integrator block): src/estimator.cpp:257-330 semantics for the matrices."""
+    import os
+    from xivo_amd import pyxivo
+    here = os.path.dirname(os.path.abspath(__file__))
+    c = pyxivo.config_from_cfg(pyxivo.load_json_with_comments(os.path.join(here, "golden", "pcw_like_cfg.json")))
+    assert c.integration_method == "PrinceDormand" and c.stepsize == 0.002 and c.min_inliers == 5
+    assert c.cam["model"] == 0 and c.cam["fx"] == 275.0 and c.cam["cols"] == 640
+    assert np.allclose(c.Wbc, [-1.57079633, 0, 0]) and np.allclose(c.gravity, [0, 0, -9.8])
+    P = c.P_init()
+    assert P.shape == (203, 203) and P[0, 0] == 0.001 and P[6, 6] == 0.5 and P[9, 9] == 1e-10 and P[23:, 23:].max() == 0
+    Qm = c.Qmodel_matrix()
+    assert Qm[0, 0] == 1e-4 and Qm[6, 6] == 0.0            # only Wsb / Wbc / Wsg are read, then squared
+    assert np.allclose(np.diag(c.Qimu_matrix()), np.repeat([25e-6, 25e-4, 0, 0], 3))
+    cfg2 = {"camera_cfg": {"model": "equidistant", "rows": 512, "cols": 512, "fx": 190.0, "fy": 191.0, "cx": 254.0, "cy": 256.0,
+                           "k0123": [1e-3, 2e-3, 3e-3, 4e-3]}, "X": {"Wbc": [[1, 0, 0], [0, 0, 1], [0, -1, 0]]}}
+    c2 = pyxivo.config_from_cfg(cfg2)
+    assert c2.cam["model"] == 3 and c2.cam["d"] == [1e-3, 2e-3, 3e-3, 4e-3]
+    assert np.allclose(c2.Wbc, [-np.pi / 2, 0, 0])          # a matrix Wbc is converted to the rotation vector

@@ -182,3 +182,61 @@ def test_many_sequences_track_ground_truth(built, tmp_path):
         assert np.array_equal(ts, out["ts"]) and np.allclose(T, out["Tsb"][:, 0], rtol=1e-8, atol=1e-12)
     finally:
         out["backend"].close()
+
+
+def test_pyxivo_style_estimator_runs_the_reference_client_loop(built):
+    """The loop of scripts/pyxivo_pcw.py:133-163 against xivo_amd.pyxivo.Estimator (one filter): IMU packets first at
+    equal stamps, VisualMeasPointCloud with (ids, x, y, depth), accessors in pyxivo's shapes. The batched driver
+    (run_pcw, B = 1) issues the same device calls, so both end in the same pose."""
+    import os
+    from xivo_amd import pyxivo
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = pyxivo.config_from_cfg(pyxivo.load_json_with_comments(os.path.join(here, "golden", "pcw_like_cfg.json")))
+    imu = pcw.TrajectorySim("lissajous", seed=41)
+    cfg.X0["Vsb"] = imu.vel(0.0)
+    vision = pcw.RandomPCW(seed=5)
+    K = np.array([[275.0, 0, 320.0], [0, 275.0, 240.0], [0, 0, 1.0]])
+    Rbc = pcw.so3_exp(cfg.Wbc)
+    est = pyxivo.Estimator(cfg, "", "lissajous", False)
+    est.InitWithSimDepths()
+    with pytest.raises(NotImplementedError):
+        est.VisualMeas(0, "img.png")
+    total, imu_dt, vis_dt = 0.8, 0.0025, 0.04
+    packets = [(k * imu_dt, 0) for k in range(int(round(total / imu_dt)))] + [(k * vis_dt, 1) for k in range(int(round(total / vis_dt)))]
+    packets.sort(key=lambda p: (round(p[0] * 1e9), p[1]))
+    try:
+        for t, kind in packets:
+            ts = int(round(t * 1e9))
+            if kind == 0:
+                accel, gyro = imu.meas(t)
+                est.InertialMeas(ts, gyro[0], gyro[1], gyro[2], accel[0], accel[1], accel[2])
+            else:
+                Rsb, Tsb = imu.gsb(t)
+                ids, meas = vision.generate_measurements(Rsb @ Rbc, Rsb @ cfg.Tbc + Tsb, K, 640, 480, 1.0)   # cfg extrinsics, as read_cfg_data does
+                est.VisualMeasPointCloud(ts, ids, meas)
+                gsb = est.gsb()                       # pose right after the camera update
+        assert gsb.shape == (3, 4) and est.gsc().shape == (3, 4) and est.Pstate().shape == (9, 9) and est.P().shape == (203, 203)
+        assert est.VisionInitialized() and est.now() == int(round((total - imu_dt) * 1e9))    # the last message was an IMU one
+        n = est.num_instate_features()
+        assert 10 < n <= 30 and est.InstateFeatureIDs().shape == (n,) and est.InstateFeaturePositions().shape == (n, 3)
+        assert est.InstateFeatureIDs().min() >= 10000 and len(set(est.InstateFeatureIDs())) == n
+        assert est.InstateGroupPoses().shape == (est.num_instate_groups(), 7) and est.InstateGroupCovs().shape == (6 * est.num_instate_groups(), 6)
+        assert set(est.InstateFeatureRefGroups()) <= set(est.InstateGroupIDs())
+        assert np.allclose(np.linalg.norm(est.InstateGroupPoses()[:, :4], axis=1), 1.0, atol=1e-9)
+        # in-state landmarks sit on points of the simulated world (the filter's map is consistent with the world)
+        Xs = est.InstateFeaturePositions()
+        d = np.linalg.norm(Xs[:, None, :] - vision.Xs[None], axis=2).min(axis=1)
+        assert np.median(d) < 0.4, d      # (log-depth prior std 0.1: ~10 % of a 3..10 m range along the ray)
+        Rt, Tt = imu.gsb(total - vis_dt)
+        assert np.linalg.norm(gsb[:, 3] - Tt) < 0.1 and np.abs(gsb[:, :3] - Rt).max() < 0.02
+        # same sequence through the batched driver
+        sims = [pcw.TrajectorySim("lissajous", seed=41)]; worlds = [pcw.RandomPCW(seed=5)]
+        cfg_b = pyxivo.config_from_cfg(pyxivo.load_json_with_comments(os.path.join(here, "golden", "pcw_like_cfg.json")))
+        out = sequence.run_pcw(sequence.HipBackend, cfg_b, worlds, sims, total_time=total)
+        try:
+            # (not bit for bit: the client's integer-nanosecond stamps give dt = 0.0025 to the last ulp only)
+            assert np.abs(out["Tsb"][-1, 0] - gsb[:, 3]).max() < 1e-9
+        finally:
+            out["backend"].close()
+    finally:
+        est.close()

@@ -78,6 +78,7 @@ class SequenceConfig:
         self.cam = dict(model=L_CAM_PINHOLE, rows=480, cols=640, fx=275.0, fy=275.0, cx=320.0, cy=240.0, d=[])
         self.Wbc, self.Tbc = np.array([-1.57079633, 0.0, 0.0]), np.zeros(3)
         self.gravity = np.array([0.0, 0.0, -9.8])
+        self.X0 = None                  # cfg "X" (initial nominal state) when the filter does not start from ground truth
         self.P0 = dict(Wsb=0.001, Tsb=0.001, Vsb=0.5, bg=1e-10, ba=1e-10, Wbc=1e-10, Tbc=1e-10, Wsg=1e-10)
         self.Qmodel = dict(Wsb=0.01, Wbc=0.0, Wsg=0.0)
         self.Qimu = dict(gyro=5e-3, accel=5e-2, gyro_bias=0.0, accel_bias=0.0)
@@ -183,6 +184,7 @@ class _Book:
 
     def __init__(self, n_groups, n_features):
         self.group_refs = [-1] * n_groups        # -1: free slot, else number of in-state features anchored there
+        self.group_gen = [0] * n_groups          # how many groups have lived in the slot (tells a re-used slot apart)
         self.feat_id = [-1] * n_features         # track id held by feature slot j (-1: free)
         self.feat_ref = [-1] * n_features
         self.id2slot = {}
@@ -288,7 +290,7 @@ class SequenceRunner:
                 continue
             g = gfree[0]
             ops.append(_op(b, L.EDIT_ADD_GROUP, g))
-            bk.group_refs[g] = 0
+            bk.group_refs[g] = 0; bk.group_gen[g] += 1
             for j, k in zip(free, cand):
                 x = [(meas[k, 0] - cx) / fx, (meas[k, 1] - cy) / fy, np.log(meas[k, 2])]   # Feature::Initialize, feature.cpp:144-150
                 ops.append(_op(b, L.EDIT_ADD_FEATURE, j, j, g, v=np.concatenate([x, meas[k, :2], P3])))
