@@ -332,6 +332,11 @@ typedef struct {
  * F <= M_max / 2. Sets the list length used by the following Jacobian / gating / update calls. */
 int xivo_hip_edit_batch(xivo_hip_ctx* ctx, int F, int n_ops, const xivo_edit_op* ops);
 
+/* New tracked pixels of a whole frame in one dense array (what the tracker hands over per camera frame; replaces one
+ * XIVO_EDIT_SET_XP op per feature): xp is [nb][F][2]; a NaN pair leaves that entry's pixel untouched (feature not
+ * tracked in this frame / absent entry). Sets the list length F like xivo_hip_edit_batch. */
+int xivo_hip_set_pixels(xivo_hip_ctx* ctx, int b0, int nb, int F, const double* xp);
+
 /* ---- covariance propagation tail (src/rk4.cpp:92-102, src/estimator.cpp:590) */
 /* P_mm <- Pmm_new ; P_ms <- Phi P_ms ; P_sm <- P_sm Phi^T. Phi and Pmm_new
  * are nm x nm (nm = 23 = kMotionSize), one pair per filter. */

@@ -69,6 +69,12 @@ class OracleBackend:
             else:
                 raise ValueError(k)
 
+    def set_pixels(self, xp):
+        """include/xivo_hip.h xivo_hip_set_pixels: NaN pairs leave the entry untouched"""
+        for b, s in enumerate(self.st):
+            ok = ~np.isnan(xp[b]).any(axis=1)
+            s["xp"][ok] = xp[b][ok]
+
     def update(self):
         c, lay = self.cfg, self.lay
         R = c.visual_meas_std ** 2

@@ -76,6 +76,32 @@ def test_edit_batch_matches_the_reference_edits_bit_for_bit(built):
         hb.close()
 
 
+def test_set_pixels_dense_frame_upload(built):
+    """xivo_hip_set_pixels: one [B x F x 2] array per frame, NaN pairs leave an entry as it is."""
+    cfg = sequence.SequenceConfig(n_groups=4, n_features=8)
+    B = 3
+    poses, P0, rng = _start(cfg, B, 4)
+    hb = sequence.HipBackend(cfg, B, poses, P0)
+    try:
+        ops = [sequence._op(b, L.EDIT_ADD_FEATURE, j, j, 0, v=np.concatenate([[0.1, 0.2, 0.3], [100.0 + j, 50.0 + b], np.eye(3).reshape(-1)]))
+               for b in range(B) for j in range(0, 8, 2)]
+        hb.edit(np.array(ops, dtype=L.edit_dtype))
+        xp = np.full((B, 8, 2), np.nan)
+        xp[:, 0] = [[11.0, 12.0], [21.0, 22.0], [31.0, 32.0]]
+        xp[1, 4] = [5.5, np.nan]                 # half a pair is no pair
+        xp[2, 6] = [7.0, 8.0]
+        xp[0, 1] = [1.0, 1.0]                    # absent entry: the pixel is stored but the entry stays absent
+        hb.set_pixels(xp)
+        _, _, f = hb.scene()
+        assert np.array_equal(f["xp"][:, 0], xp[:, 0]) and np.array_equal(f["xp"][2, 6], [7.0, 8.0])
+        assert np.array_equal(f["xp"][1, 4], [104.0, 51.0]) and np.array_equal(f["xp"][0, 2], [102.0, 50.0])
+        assert f["sind"][0, 1] == -1 and np.array_equal(f["sind"][:, 0], [0, 0, 0])
+        with pytest.raises(L.XivoHipError):
+            hb.ctx.set_pixels(np.zeros((B + 1, 8, 2)))
+    finally:
+        hb.close()
+
+
 def test_edit_batch_rejects_bad_ops(built):
     cfg = sequence.SequenceConfig(n_groups=4, n_features=8)
     poses, P0, _ = _start(cfg, 2, 2)

@@ -1076,6 +1076,21 @@ int xivo_hip_edit_batch(xivo_hip_ctx* c, int F, int n_ops, const xivo_edit_op* o
   return XIVO_HIP_OK;
 }
 
+int xivo_hip_set_pixels(xivo_hip_ctx* c, int b0, int nb, int F, const double* xp) {
+  if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || F <= 0 || 2 * F > c->Mmax || !xp) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensure_gate_buffers(c, F);
+  if (rc) return rc;
+  rc = ensure_staging(c, (size_t)nb * F * 2);
+  if (rc) return rc;
+  c->F = F;
+  HIP_TRY(hipMemcpyAsync(c->staging, xp, (size_t)nb * F * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (launch_set_pixels(c->feats + (size_t)b0 * c->Fmax, c->Fmax, F, c->staging, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY(hipStreamSynchronize(c->stream));   // xp is borrowed host memory
+  return XIVO_HIP_OK;
+}
+
 int xivo_hip_get_scene(xivo_hip_ctx* c, int b0, int nb, xivo_pose_in* poses, xivo_group_in* groups, xivo_feat_in* feats) {
   if (bad_range(c, b0, nb) || !c->have_layout || !c->poses) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;

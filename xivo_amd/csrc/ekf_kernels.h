@@ -110,6 +110,7 @@ struct EditArgs {
   xivo_pose_in* poses; xivo_group_in* groups; xivo_feat_in* feats; int Fmax;
 };
 int launch_edit_batch(const EditArgs& a, int n_wg, hipStream_t s);
+int launch_set_pixels(xivo_feat_in* feats /* already offset to b0 */, int Fmax, int F, const double* xp, int nb, hipStream_t s);
 
 // OOS (MSCKF) rows: oos.cpp:39-89 + helpers.cpp:13-23
 struct OosArgs {

@@ -716,6 +716,15 @@ __device__ __forceinline__ void edit_copy_rc(double* P, int ldp, int Np, int dst
     for (int r = 0; r < len; ++r) P[t + (long)(dst + r) * ldp] = P[t + (long)(src + r) * ldp];
   __syncthreads();
 }
+// xivo_hip_set_pixels: one thread per (filter, list entry)
+__global__ void set_pixels_kernel(xivo_feat_in* feats, int Fmax, int F, const double* xp, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double u = xp[2 * t], v = xp[2 * t + 1];
+  if (u != u || v != v) return;   // NaN: not tracked in this frame
+  xivo_feat_in& f = feats[(long)(t / F) * Fmax + (t % F)];
+  f.xp[0] = u; f.xp[1] = v;
+}
 // One workgroup per filter that has ops; its ops run in array order.
 __global__ __launch_bounds__(256) void edit_batch_kernel(EditArgs a) {
   const int w = blockIdx.x, tid = threadIdx.x;
@@ -1512,6 +1521,11 @@ int launch_givens(const GivensArgs& a, hipStream_t s) {
   if (a.batch <= 0) return 0;
   hipLaunchKernelGGL(givens_kernel, dim3(a.batch), dim3(64), 0, s, a);
   CHECK_LAUNCH();
+}
+int launch_set_pixels(xivo_feat_in* feats, int Fmax, int F, const double* xp, int nb, hipStream_t s) {
+  const int n = nb * F;
+  hipLaunchKernelGGL(set_pixels_kernel, dim3((n + 255) / 256), dim3(256), 0, s, feats, Fmax, F, xp, n);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int launch_edit_batch(const EditArgs& a, int n_wg, hipStream_t s) {
   hipLaunchKernelGGL(edit_batch_kernel, dim3(n_wg), dim3(256), 0, s, a);

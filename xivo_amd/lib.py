@@ -115,6 +115,7 @@ _SIGS = {
     "xivo_hip_qr": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "xivo_hip_subfilter_update": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_edit_batch": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "xivo_hip_set_pixels": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_propagate_cov": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
@@ -400,6 +401,13 @@ class Context:
             ops = np.ascontiguousarray(ops[np.argsort(ops["b"], kind="stable")])
         self.F = F
         self._check(self.lib.xivo_hip_edit_batch(self.h, F, int(ops.size), _ptr(ops) if ops.size else None))
+
+    def set_pixels(self, xp, b0=0):
+        """xp: [nb, F, 2], NaN = leave the entry's pixel as it is"""
+        xp = np.ascontiguousarray(xp, dtype=np.float64)
+        nb, F = xp.shape[:2]
+        self.F = F
+        self._check(self.lib.xivo_hip_set_pixels(self.h, b0, nb, F, _ptr(xp)))
 
     def get_scene(self, b0=0, nb=None):
         nb = self.batch - b0 if nb is None else nb

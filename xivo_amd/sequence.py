@@ -2,7 +2,7 @@
 
 Runs B independent visual-inertial sequences at once on one GPU context: for every camera frame the IMU samples since the
 last frame go down in one `xivo_hip_propagate` call, the frame's state edits of all filters in one `xivo_hip_edit_batch`
-call, then `xivo_hip_filter_update` (Jacobians -> MH gating -> stacking -> Joseph update) and `xivo_hip_absorb_error`.
+call and its pixels in one `xivo_hip_set_pixels` call, then `xivo_hip_filter_update` (Jacobians -> MH gating -> stacking -> Joseph update) and `xivo_hip_absorb_error`.
 State, covariance, groups and features never leave the device; the host keeps only the slot book-keeping
 (`gsel_` / `fsel_` of src/estimator.h:496-503) and decides who enters and leaves the state.
 
@@ -155,6 +155,9 @@ class HipBackend:
     def edit(self, ops):
         self.ctx.edit_batch(self.F, ops)
 
+    def set_pixels(self, xp):
+        self.ctx.set_pixels(xp)
+
     def update(self):
         c = self.cfg
         self.ctx.filter_update(c.visual_meas_std ** 2, c.MH_thresh, c.MH_adjust_factor, c.min_inliers, True)
@@ -244,6 +247,7 @@ class SequenceRunner:
         t0 = self._tick("propagate", t0) or t0
         # --- before the update: tracker-dropped features leave, tracked ones get their new pixel
         ops = []
+        xp = np.full((self.B, cfg.n_features, 2), np.nan)     # the frame's pixels of the tracked in-state features
         for b in range(self.B):
             bk = self.books[b]
             ids, meas = tracks[b]
@@ -253,7 +257,7 @@ class SequenceRunner:
                 if fid < 0:
                     continue
                 if fid in pos:
-                    ops.append(_op(b, L.EDIT_SET_XP, j, v=meas[pos[fid], :2]))
+                    xp[b, j] = meas[pos[fid], :2]
                 else:
                     ops.append(_op(b, L.EDIT_REMOVE_FEATURE, j))
                     bk.drop_feature(j)
@@ -261,6 +265,7 @@ class SequenceRunner:
         ops = np.array(ops, dtype=L.edit_dtype)
         t0 = self._tick("host_pre", t0) or t0
         be.edit(ops)
+        be.set_pixels(xp)
         t0 = self._tick("edit", t0) or t0
         # --- measurement update on the tracked in-state features (every filter, ragged)
         mask = be.update()
