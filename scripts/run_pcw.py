@@ -24,35 +24,56 @@ def main():
     ap.add_argument("-as_coded_group_block", action="store_true", help="reproduce src/feature.cpp:675-676")
     ap.add_argument("-dump", default="", help="directory for per-sequence `ts Tsb Wsb` trajectories")
     a = ap.parse_args()
-    B = a.sequences
+    # BASELINE config 5: under torch.distributed.run, sequence s runs on rank s mod world (one rank per GPU, no data-path
+    # collective; the ranks only meet to add up the report)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    from xivo_amd.shard import sequence_to_gpu
+    mine = [s_ for s_ in range(a.sequences) if sequence_to_gpu(s_, world) == rank]
+    B = len(mine)
     cfg = sequence.SequenceConfig(integration_method=a.integration_method, fix_group_block=not a.as_coded_group_block)
-    worlds = [pcw.RandomPCW(npts=a.npts, seed=b) for b in range(B)]
+    worlds = [pcw.RandomPCW(npts=a.npts, seed=b) for b in mine]
     sims = [pcw.TrajectorySim("lissajous" if b % 2 == 0 else "trefoil", rate=0.08 + 0.04 * (b % 7) / 7, seed=1000 + b)
-            for b in range(B)]
+            for b in mine]
     timers = {}
+    device = int(os.environ.get("LOCAL_RANK", 0))
     t0 = time.perf_counter()
-    out = sequence.run_pcw(sequence.HipBackend, cfg, worlds, sims, total_time=a.total_time, imu_dt=a.imu_dt,
-                           vision_dt=a.vision_dt, noise_vision_std=a.noise_vision_std, timers=timers)
+    out = sequence.run_pcw(lambda c_, B_, p_, P_: sequence.HipBackend(c_, B_, p_, P_, device=device), cfg, worlds, sims,
+                           total_time=a.total_time, imu_dt=a.imu_dt, vision_dt=a.vision_dt,
+                           noise_vision_std=a.noise_vision_std, timers=timers)
     wall = time.perf_counter() - t0
     out["backend"].close()
     frames = len(out["ts"])
     ate = np.array([formats.ate_rmse(out["Tsb"][:, b], out["gt_Tsb"][:, b], align=False) for b in range(B)])
     dev = sum(timers.get(k, 0.0) for k in ("propagate", "edit", "update"))
     r = out["runner"]
+    if a.dump:
+        os.makedirs(a.dump, exist_ok=True)
+        for k, b in enumerate(mine):
+            formats.write_trajectory(os.path.join(a.dump, "seq%04d.txt" % b), out["ts"], out["Tsb"][:, k], out["Wsb"][:, k])
+    n_upd, n_rej = r.n_updates, r.n_rejected
+    if dist is not None:
+        parts = [None] * world
+        dist.all_gather_object(parts, (ate.tolist(), wall, dev, n_upd, n_rej))
+        ate = np.array(sum((p_[0] for p_ in parts), []))
+        wall, dev = max(p_[1] for p_ in parts), max(p_[2] for p_ in parts)      # whole job = slowest rank
+        n_upd, n_rej = sum(p_[3] for p_ in parts), sum(p_[4] for p_ in parts)
+        B = a.sequences
+    if rank != 0:
+        return
     print(json.dumps({
-        "sequences": B, "frames_per_sequence": frames, "imu_samples_per_frame": int(round(a.vision_dt / a.imu_dt)),
+        "sequences": B, "n_gpus": world, "frames_per_sequence": frames, "imu_samples_per_frame": int(round(a.vision_dt / a.imu_dt)),
         "N": cfg.N, "max_features": cfg.n_features, "integration": a.integration_method,
         "ate_m": {"median": float(np.median(ate)), "p90": float(np.quantile(ate, 0.9)), "max": float(ate.max())},
-        "updates": r.n_updates, "mh_rejected": r.n_rejected,
+        "updates": n_upd, "mh_rejected": n_rej,
         "wall_s": wall, "device_path_s": dev,
         "phase_s": {k: round(v, 4) for k, v in sorted(timers.items())},
         "device_frames_per_s": B * frames / dev if dev > 0 else None,
         "ms_per_frame_per_batch": {k: round(1e3 * timers.get(k, 0.0) / frames, 3) for k in ("propagate", "edit", "update")},
     }))
-    if a.dump:
-        os.makedirs(a.dump, exist_ok=True)
-        for b in range(B):
-            formats.write_trajectory(os.path.join(a.dump, "seq%04d.txt" % b), out["ts"], out["Tsb"][:, b], out["Wsb"][:, b])
 
 
 if __name__ == "__main__":

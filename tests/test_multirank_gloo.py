@@ -49,3 +49,50 @@ def test_shard_range_properties():
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
     assert [sequence_to_gpu(s, 8) for s in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+
+
+def _seq_worker(rank, world, port, q):
+    """BASELINE config 5 shape: sequence s runs on rank s mod world (scripts/run_pcw.py); here with the oracle backend."""
+    import numpy as np
+    import torch.distributed as dist
+    from seq_oracle import OracleBackend
+    from xivo_amd import pcw, sequence
+    from xivo_amd.shard import sequence_to_gpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = [s for s in range(3) if sequence_to_gpu(s, world) == rank]
+    cfg = sequence.SequenceConfig(n_groups=4, n_features=8)
+    out = sequence.run_pcw(OracleBackend, cfg, [pcw.RandomPCW(npts=300, seed=s) for s in mine],
+                           [pcw.TrajectorySim(seed=50 + s) for s in mine], total_time=0.12)
+    parts = [None] * world
+    dist.all_gather_object(parts, {s: out["Tsb"][:, k].tolist() for k, s in enumerate(mine)})
+    q.put((rank, parts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sequences_shard_over_ranks_without_data_exchange():
+    """Three sequences over two ranks (s mod world) give exactly the trajectories of one process running all three:
+    the path shards by sequence, the ranks only meet to collect the report."""
+    torch = pytest.importorskip("torch")
+    import numpy as np
+    import torch.multiprocessing as mp
+    from seq_oracle import OracleBackend
+    from xivo_amd import pcw, sequence
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_seq_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps: p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps: p.join(60)
+    merged = {}
+    for part in res[0][1]:
+        merged.update(part)
+    assert sorted(merged) == [0, 1, 2] and res[0][1] == res[1][1]
+    assert sorted(res[0][1][0]) == [0, 2] and sorted(res[0][1][1]) == [1]
+    cfg = sequence.SequenceConfig(n_groups=4, n_features=8)
+    one = sequence.run_pcw(OracleBackend, cfg, [pcw.RandomPCW(npts=300, seed=s) for s in range(3)],
+                           [pcw.TrajectorySim(seed=50 + s) for s in range(3)], total_time=0.12)
+    for s in range(3):
+        assert np.array_equal(np.array(merged[s]), one["Tsb"][:, s])
