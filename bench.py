@@ -112,6 +112,9 @@ def main():
                          "at 2 ms sub-steps) before the update and absorbs the error after it - the whole per-frame loop "
                          "(SURVEY 8d: the metric with propagation); 16 samples = 32 Runge-Kutta sub-steps per update")
     ap.add_argument("--integrator", choices=["RK4", "PrinceDormand"], default="RK4")
+    ap.add_argument("--oos", type=int, default=0,
+                    help="level G only (BASELINE config 3): this many out-of-state (MSCKF) features, each seen from 5 in-state "
+                         "groups, are null-space projected (src/oos.cpp) and appended: 7 rows each, M = 120 + 7 n")
     ap.add_argument("--no-gating", action="store_true",
                     help="time UpdateJosephForm only (default: MH gating + UpdateJosephForm, one 'update' of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,7 +161,7 @@ def main():
             for g_ in range(ng):
                 groups[b, g_]["Rsb"], groups[b, g_]["Tsb"] = cmaj(sc["gR"][b, g_]), sc["gT"][b, g_]
             feats["x"][b] = sc["x"][b]; feats["ref_sind"][b] = sc["ref"][b]; feats["sind"][b] = sc["sind"][b]
-        M = 2 * F
+        M = 2 * F + 7 * args.oos
         ctx = Context(N, M, B, device=device, flags=flags)
         ctx.set_layout(N, 23, ng, 23 + 6 * ng, nf, synth.EQUI)
         rngP = np.random.default_rng(3000 + rank)
@@ -187,6 +190,25 @@ def main():
             ctx.upload_P(P[:nb], b0=b0)
             ctx.set_measurements(H[:nb], inn[:nb], dR[:nb], b0=b0)
     ctx.snapshot_P()
+    oos_on = args.level == "G" and args.oos > 0
+    if oos_on:
+        # OOS features: landmarks near the in-state ones (world position from the scene's own anchors), each observed
+        # from 5 groups; their pixels only set the innovation, the work per update does not depend on them
+        from xivo_amd.lib import oos_dtype
+        rngo = np.random.default_rng(4000 + rank)
+        oos_u = np.zeros((uniq, args.oos), dtype=oos_dtype)
+        for b in range(uniq):
+            for o in range(args.oos):
+                i = o % F; r = int(sc["ref"][b, i]); x = sc["x"][b, i]; z = np.exp(x[2])
+                Xc = np.array([x[0] * z, x[1] * z, z])
+                oos_u[b, o]["Xs"] = sc["gR"][b, r] @ (sc["Rbc"][b] @ Xc + sc["Tbc"][b]) + sc["gT"][b, r] + rngo.normal(0, 0.05, 3)
+                oos_u[b, o]["n_obs"] = 5
+                oos_u[b, o]["group_sind"][:5] = rngo.permutation(ng)[:5]
+                oos_u[b, o]["xp"][:5] = np.array([synth.EQUI["cx"], synth.EQUI["cy"]]) + rngo.normal(0, 40.0, (5, 2))
+        oos_all = np.tile(oos_u, (-(-B // uniq), 1))[:B]
+        ctx.jacobians_instate(B); ctx.mh_gate(R_VIS, MH_THRESH, MH_MULT, MIN_INL, B, want=False); ctx.stack(R_VIS, B)
+        rows = ctx.oos_project(oos_all, 3.5 ** 2)         # uploads the list once; the timed steps project it resident
+        assert (rows == 7 * args.oos).all()
     frame = args.level == "G" and args.propagate_samples > 0
     if frame:
         # a sensor at rest: the accelerometer reads -g in the body frame, so the nominal state stays where the scene
@@ -205,6 +227,12 @@ def main():
             ctx.propagate(imu, Qimu, Qmodel, grav, method=args.integrator, stepsize=0.002)
             ctx.filter_update(R_VIS, MH_THRESH, MH_MULT, MIN_INL, not args.no_gating, B)
             ctx.absorb_error(B)
+        elif oos_on:
+            ctx.jacobians_instate(B)
+            ctx.mh_gate(R_VIS, MH_THRESH, MH_MULT, MIN_INL, B, want=False)
+            ctx.stack(R_VIS, B)
+            ctx.oos_project((B, args.oos), 3.5 ** 2, want_rows=False)
+            ctx.update_joseph(B)
         elif args.level == "G":
             ctx.filter_update(R_VIS, MH_THRESH, MH_MULT, MIN_INL, not args.no_gating, B)
         elif args.no_gating:
@@ -308,6 +336,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"whole frame: Propagate ({args.propagate_samples} IMU samples, {args.integrator}) + AbsorbError + "
                                     if frame else "") +
+                                   (f"{args.oos} OOS features (null-space projected, 7 rows each) + " if oos_on else "") +
                                    ("feature-level: Jacobians + " if args.level == "G" else "") +
                                    ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
                                    f": state dim {N}, {F} features (M={M}), XIVO row sparsity, P/H/inn/R resident in HBM",

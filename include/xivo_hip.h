@@ -217,7 +217,8 @@ int xivo_hip_mh_gate(xivo_hip_ctx* ctx, int B, double R, double mh_thresh, doubl
 int xivo_hip_stack(xivo_hip_ctx* ctx, int B, double R);
 /* Feature::ComputeOOSJacobian (src/oos.cpp:8-89) + SlowGivens
  * (src/helpers.cpp:13-23): per feature (2k-3) projected rows appended after
- * the in-state rows with diagR = Roos. rows_out[b] = total OOS rows. */
+ * the in-state rows with diagR = Roos. rows_out[b] = total OOS rows. feats == NULL projects the list of the
+ * previous call again (it stays resident; same nb and n_oos) - for a caller that re-linearises without new tracks. */
 int xivo_hip_oos_project(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xivo_oos_in* feats,
                          double Roos, int* rows_out);
 /* jac -> gate -> stack -> UpdateJosephForm in one call (Estimator::UpdateStep's

@@ -63,6 +63,7 @@ struct xivo_hip_ctx {
   int* rows_instate = nullptr;
   xivo_oos_in* oos = nullptr;
   int oos_cap = 0;
+  int oos_nb = 0, oos_n = 0, oos_max_rows = 0;   // shape of the resident OOS list (xivo_hip_oos_project with feats == NULL)
   int* oos_rows = nullptr;
   xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
   std::vector<char> hstage;                        // host staging of d2h_rows
@@ -896,9 +897,11 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
 
 int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_oos_in* feats, double Roos,
                          int* rows_out) {
-  if (bad_range(c, b0, nb) || !c->have_layout || n_oos <= 0 || !feats || b0 != 0) return XIVO_HIP_ERR_INVALID;
-  int max_rows = 0;
-  for (int b = 0; b < nb; ++b) {
+  if (bad_range(c, b0, nb) || !c->have_layout || n_oos <= 0 || b0 != 0) return XIVO_HIP_ERR_INVALID;
+  // feats == NULL: the list uploaded by the previous call is still resident (same nb, n_oos) - project it again
+  if (!feats && (!c->oos || c->oos_nb != nb || c->oos_n != n_oos)) return XIVO_HIP_ERR_INVALID;
+  int max_rows = feats ? 0 : c->oos_max_rows;
+  for (int b = 0; feats && b < nb; ++b) {
     int rows = 0;
     for (int o = 0; o < n_oos; ++o) {
       const xivo_oos_in& f = feats[(size_t)b * n_oos + o];
@@ -914,12 +917,16 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   if (n_oos * nb > c->oos_cap) {
     if (c->oos) hipFree(c->oos);
     c->oos = nullptr; c->oos_cap = 0;
+    if (!feats) return XIVO_HIP_ERR_INVALID;
     int rc = dev_alloc(&c->oos, (size_t)n_oos * c->Bmax);
     if (rc) return rc;
     c->oos_cap = n_oos * c->Bmax;
   }
   if (!c->oos_rows) { int rc = dev_alloc(&c->oos_rows, (size_t)c->Bmax); if (rc) return rc; }
-  HIP_TRY(hipMemcpyAsync(c->oos, feats, (size_t)nb * n_oos * sizeof(xivo_oos_in), hipMemcpyHostToDevice, c->stream));
+  if (feats) {
+    HIP_TRY(hipMemcpyAsync(c->oos, feats, (size_t)nb * n_oos * sizeof(xivo_oos_in), hipMemcpyHostToDevice, c->stream));
+    c->oos_nb = nb; c->oos_n = n_oos; c->oos_max_rows = max_rows;
+  }
   OosArgs a;
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
   a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;

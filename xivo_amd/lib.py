@@ -322,8 +322,11 @@ class Context:
         self._check(self.lib.xivo_hip_get_jacobians(self.h, b0, nb, _ptr(J), _ptr(inn)))
         return J, inn
 
-    def mh_gate(self, R, thresh, mult, min_inliers, B=None):
+    def mh_gate(self, R, thresh, mult, min_inliers, B=None, want=True):
         B = self.batch if B is None else B
+        if not want:      # mask / distances stay on the device (read them with get_gate)
+            self._check(self.lib.xivo_hip_mh_gate(self.h, B, R, thresh, mult, min_inliers, None, None))
+            return None
         mask = np.zeros((B, self.F), dtype=np.uint8)
         dist = np.zeros((B, self.F))
         self._check(self.lib.xivo_hip_mh_gate(self.h, B, R, thresh, mult, min_inliers, _ptr(mask), _ptr(dist)))
@@ -332,11 +335,17 @@ class Context:
     def stack(self, R, B=None):
         self._check(self.lib.xivo_hip_stack(self.h, self.batch if B is None else B, R))
 
-    def oos_project(self, feats, Roos):
-        feats = np.ascontiguousarray(feats, dtype=oos_dtype)
-        nb, n_oos = feats.shape
-        rows = np.zeros(nb, dtype=np.int32)
-        self._check(self.lib.xivo_hip_oos_project(self.h, 0, nb, n_oos, _ptr(feats), Roos, _ptr(rows)))
+    def oos_project(self, feats, Roos, want_rows=True):
+        """feats: [nb, n_oos] oos_dtype, or a (nb, n_oos) tuple to project the resident list of the last call again"""
+        if isinstance(feats, tuple):
+            nb, n_oos = feats
+            ptr = None
+        else:
+            feats = np.ascontiguousarray(feats, dtype=oos_dtype)
+            nb, n_oos = feats.shape
+            ptr = _ptr(feats)
+        rows = np.zeros(nb, dtype=np.int32) if want_rows else None
+        self._check(self.lib.xivo_hip_oos_project(self.h, 0, nb, n_oos, ptr, Roos, _ptr(rows) if want_rows else None))
         return rows
 
     def filter_update(self, R, thresh, mult, min_inliers, use_gating=True, B=None):
