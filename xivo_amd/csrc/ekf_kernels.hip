@@ -1154,15 +1154,17 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
   const int wave = lane >> 6, wl = lane & 63;
   const RkTableau& tab = kTableau[NS == 4 ? 0 : 1];
   double* Pmm = sm;            // P_mm at the start of the sub-step
-  double* Phi = Pmm + NN;      // accumulated transition
-  double* P0 = Phi + NN;
+  double* PhiA = Pmm + NN;     // rows < 9 of the accumulated transition ([i + 9 j]; the other rows stay identity rows),
+  double* PhiB = PhiA + NF;    // double buffered
+  double* P0 = PhiB + NF;
   double* S1 = P0 + NN;        // 23 x 23 scratch whose rows >= 9 stay zero: sum a_q FK_q, later I + FK h
   double* FPs = S1 + NN;       // [9 x 23]  F P0          ([i + 9 j])
   double* PFs = FPs + NF;      // [23 x 9]  P0 F^T        ([i + 23 j])
   double* GQG = PFs + NF;      // [12 x 12] support of G Q G^T: rows / cols (Wsb, Vsb, bg, ba)
   double* Q = GQG + 144;       // 12 x 12
   double* GQc = Q + 144;       // [12 x 12] the non-zero rows of G Q
-  double* sKs = GQc + 144;     // [NS][3] stage velocities
+  double* zero = GQc + 144;    // one 0.0 (target of the structurally absent terms of phase C) + pad
+  double* sKs = zero + 2;      // [NS][3] stage velocities
   double* Jms = sKs + 24;      // [NS][4][3 x 3] row-major: dW/dW, dV/dW, -Rsb, dV/dWsg of every stage
   double* FKs = Jms + NS * 36; // [NS][9 x 23]
   double* PKs = FKs + NS * NF; // [NS][23 x 23]
@@ -1171,8 +1173,24 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
   for (int e = lane; e < NN; e += NT) {
     const int i = e % NM, j = e / NM;
     Pmm[e] = Pg[i + (long)j * a.ldp];
-    Phi[e] = i == j ? 1.0 : 0.0;
     S1[e] = 0.0;
+  }
+  if (lane < NF) PhiA[lane] = (lane % FR) == (lane / FR) ? 1.0 : 0.0;
+  if (lane == 0) zero[0] = 0.0;
+  double* Phi = PhiA;
+  double* PhiN = PhiB;
+  // this thread's elements e = lane + 256 m of the 23 x 23 matrices: Qmodel entries and the LDS offsets (from sm) of
+  // the three terms of PK(e) = (F P0)(e) + (P0 F^T)(e) + (G Q G^T)(e); structurally absent terms point at `zero`
+  double qm[3];
+  int oFP[3], oPF[3], oG[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int e = lane + NT * m, i = e % NM, j = e / NM;
+    const int ci = i < 3 ? i : ((i >= 6 && i < 15) ? i - 3 : -1), cj = j < 3 ? j : ((j >= 6 && j < 15) ? j - 3 : -1);
+    qm[m] = e < NN ? a.Qmodel[e] : 0.0;
+    oFP[m] = i < FR ? (int)(FPs - sm) + i + FR * j : (int)(zero - sm);
+    oPF[m] = j < FR ? (int)(PFs - sm) + i + NM * j : (int)(zero - sm);
+    oG[m] = (ci >= 0 && cj >= 0) ? (int)(GQG - sm) + ci + 12 * cj : (int)(zero - sm);
   }
   for (int e = lane; e < NS * (NF + NN); e += NT) FKs[e] = 0.0;   // finite values under the tableau's zero coefficients
   for (int e = lane; e < 144; e += NT) {
@@ -1194,8 +1212,10 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
 
   // one Estimator::Propagate per IMU sample; the transitions of all samples are accumulated in Phi so that the
   // O(23 N) cross-covariance tail runs once per call instead of once per sample
+  xivo_imu_in im_next = a.imu[(long)filt * a.n_imu];
   for (int smp = 0; smp < a.n_imu; ++smp) {
-  const xivo_imu_in im = a.imu[(long)filt * a.n_imu + smp];
+  const xivo_imu_in im = im_next;
+  if (smp + 1 < a.n_imu) im_next = a.imu[(long)filt * a.n_imu + smp + 1];   // in flight while this sample is integrated
   V3 gyro{{im.gyro[0], im.gyro[1], im.gyro[2]}}, accel{{im.accel[0], im.accel[1], im.accel[2]}};
   const V3 sg{{im.slope_gyro[0], im.slope_gyro[1], im.slope_gyro[2]}}, sa{{im.slope_accel[0], im.slope_accel[1], im.slope_accel[2]}};
   double total = 0.0;
@@ -1253,17 +1273,23 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
       compose_motion_dev(X, Kt, ge, ae, h, Rg);
     }
 
-    for (int st = 0; st < NS; ++st) {
+    // phase A of stage st: S = sum_q a_q FK_q (rows < 9), P0 = Pmm + (sum_q a_q PK_q) h (rk4.cpp:49-88), Vsb rows of G Q.
+    // It runs once before the stage loop for stage 0 and otherwise fused behind phase C of the stage before, whose
+    // thread owns the same elements: two barriers per stage.
+    auto phase_a = [&](int st) {
       const double* Jm = Jms + st * 36;
-      // -- phase A: S = sum_q a_q FK_q (rows < 9), P0 = Pmm + (sum_q a_q PK_q) h (rk4.cpp:49-88); Vsb rows of G Q
       double aq[NS - 1];
 #pragma unroll
       for (int q = 0; q < NS - 1; ++q) aq[q] = tab.a[st][q];
-      for (int e = lane; e < NN; e += NT) {
-        double sp = 0.0;
 #pragma unroll
-        for (int q = 0; q < NS - 1; ++q) sp += aq[q] * PKs[q * NN + e];
-        P0[e] = Pmm[e] + sp * h;
+      for (int m = 0; m < 3; ++m) {
+        const int e = lane + NT * m;
+        if (e < NN) {
+          double sp = 0.0;
+#pragma unroll
+          for (int q = 0; q < NS - 1; ++q) sp += aq[q] * PKs[q * NN + e];
+          P0[e] = Pmm[e] + sp * h;
+        }
       }
       if (lane < NF) {
         double sf = 0.0;
@@ -1281,7 +1307,11 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
           GQc[(3 + i) + 12 * l] = v;
         }
       }
-      __syncthreads();
+    };
+    phase_a(0);
+    __syncthreads();
+    for (int st = 0; st < NS; ++st) {
+      const double* Jm = Jms + st * 36;
       auto ldm = [&](int blk) {                                   // one published 3 x 3 block into registers
         M3 r;
 #pragma unroll
@@ -1360,8 +1390,9 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
           w = fma(p21, dV_dWsg.m[j][0], w);
           PFs[i + NM * (6 + j)] = fma(p22, dV_dWsg.m[j][1], w);
         }
-      } else if (wl >= 32 && wl < 44) {                           // (G Q G^T)[r, :] on the 12 x 12 support
-        const int r = wl - 32;
+      }
+      if (wave == 1 && wl < 12) {                                 // (G Q G^T)[r, :] on the 12 x 12 support (wave 1's F rows are trivial)
+        const int r = wl;
         const M3 nR = ldm(2);
         const double g3 = GQc[r + 12 * 3], g4 = GQc[r + 12 * 4], g5 = GQc[r + 12 * 5];
 #pragma unroll
@@ -1376,23 +1407,25 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
       }
       __syncthreads();
 
-      // -- phase C: PK_st = F P0 + P0 F^T + G Q G^T
-      for (int e = lane; e < NN; e += NT) {
-        const int i = e % NM, j = e / NM;
-        const int ci = i < 3 ? i : ((i >= 6 && i < 15) ? i - 3 : -1), cj = j < 3 ? j : ((j >= 6 && j < 15) ? j - 3 : -1);
-        const double fp = i < FR ? FPs[i + FR * j] : 0.0;
-        const double pf = j < FR ? PFs[i + NM * j] : 0.0;
-        const double v = (ci >= 0 && cj >= 0) ? GQG[ci + 12 * cj] : 0.0;
-        PKs[st * NN + e] = (fp + pf) + v;
+      // -- phase C: PK_st = F P0 + P0 F^T + G Q G^T, then phase A of the next stage
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int e = lane + NT * m;
+        if (e < NN) PKs[st * NN + e] = (sm[oFP[m]] + sm[oPF[m]]) + sm[oG[m]];
       }
+      if (st + 1 < NS) phase_a(st + 1);
       __syncthreads();
     }
     // combine the stages
-    for (int e = lane; e < NN; e += NT) {
-      double pk = 0.0;
 #pragma unroll
-      for (int q = 0; q < NS; ++q) pk += tab.b[q] * PKs[q * NN + e];
-      Pmm[e] += pk * h;                              // rk4.cpp:92-93
+    for (int m = 0; m < 3; ++m) {
+      const int e = lane + NT * m;
+      if (e < NN) {
+        double pk = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) pk += tab.b[q] * PKs[q * NN + e];
+        Pmm[e] += pk * h;                            // rk4.cpp:92-93
+      }
     }
     if (lane < NF) {
       const int i = lane % FR, j = lane / FR;
@@ -1402,27 +1435,31 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
       S1[i + NM * j] = (i == j ? 1.0 : 0.0) + fk * h;   // rows < 9 of Phi_step = I + FK h (the others are identity rows)
     }
     __syncthreads();
-    if (lane < NF) {                                 // Phi <- Phi_step Phi
-      const int i = lane % FR, j = lane / FR;
+    if (lane < NF) {                                 // Phi <- Phi_step Phi; rows >= 9 of Phi are identity rows: their
+      const int i = lane % FR, j = lane / FR;        // terms of the k-sum are 0 except S1(i, j) * 1 at k = j
       double v = 0.0;
 #pragma unroll
-      for (int k = 0; k < NM; ++k) v = fma(S1[i + NM * k], Phi[k + NM * j], v);
-      FPs[lane] = v;
+      for (int k = 0; k < FR; ++k) v = fma(S1[i + NM * k], Phi[k + FR * j], v);
+      if (j >= FR) v = fma(S1[i + NM * j], 1.0, v);
+      PhiN[lane] = v;
     }
-    __syncthreads();
-    if (lane < NF) Phi[(lane % FR) + NM * (lane / FR)] = FPs[lane];
-    __syncthreads();
+    { double* t = Phi; Phi = PhiN; PhiN = t; }       // (next read of Phi / write of S1 lies behind the pre-pass barrier)
     gyro = ge; accel = ae;                           // rk4.cpp:27-28
     total += h;
     if (a.stepsize < 0) break;
   }
-  for (int e = lane; e < NN; e += NT) Pmm[e] += a.Qmodel[e];    // P_mm += Qmodel (estimator.cpp:590), per Propagate
-  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {                      // P_mm += Qmodel (estimator.cpp:590), per Propagate; own elements only
+    const int e = lane + NT * m;
+    if (e < NN) Pmm[e] += qm[m];
   }
+  }
+  __syncthreads();
   // results for the tail kernel; nominal state back
   for (int e = lane; e < NN; e += NT) {
+    const int i = e % NM, j = e / NM;
     a.Pmm_out[(long)filt * NN + e] = Pmm[e];
-    a.Phi_out[(long)filt * NN + e] = Phi[e];
+    a.Phi_out[(long)filt * NN + e] = i < FR ? Phi[i + FR * j] : (i == j ? 1.0 : 0.0);
   }
   if (lane == 0) {
 #pragma unroll
@@ -1556,7 +1593,7 @@ template <int NS>
 static int launch_propagate_state_ns(const PropStateArgs& a, hipStream_t s) {
   // LDS: 4 matrices, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, stage velocities, per stage 36 Jacobian entries +
   // FK (9 rows) + PK: RK4 49 KB (3 workgroups per CU), Dormand-Prince 67 KB (2 per CU)
-  const size_t lds = (size_t)(4 * 529 + 2 * 207 + 3 * 144 + 24 + NS * (36 + 207 + 529)) * sizeof(double);
+  const size_t lds = (size_t)(3 * 529 + 4 * 207 + 3 * 144 + 2 + 24 + NS * (36 + 207 + 529)) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel<NS>),
