@@ -1128,7 +1128,7 @@ __device__ __forceinline__ void compose_motion_dev(MotionRegs& X, const V3& V, c
   X.Rsb = m3_mul(X.Rsb, so3_exp_small(gc.v[0] * dt, gc.v[1] * dt, gc.v[2] * dt));   // :610
 }
 
-// One workgroup of 256 threads per filter; every wave carries the (tiny) nominal state. Structure exploited:
+// One workgroup of 256 threads per filter; the (tiny) nominal state lives in LDS. Structure exploited:
 //  * The nominal state of stage st - ComposeMotion of the sub-step's start state with the interpolated IMU sample
 //    (rk4.cpp:49-88) - feeds the covariance stages only through Rsb(st), the bias-corrected gyro / accel and the stage
 //    velocity K_st, and none of these depends on another stage (only Tsb does, through the a_ij-weighted velocities,
@@ -1164,7 +1164,9 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
   double* Q = GQG + 144;       // 12 x 12
   double* GQc = Q + 144;       // [12 x 12] the non-zero rows of G Q
   double* zero = GQc + 144;    // one 0.0 (target of the structurally absent terms of phase C) + pad
-  double* sKs = zero + 2;      // [NS][3] stage velocities
+  double* nom = zero + 2;      // nominal state + IMU sample, resident in LDS between their few uses (70 VGPRs otherwise):
+                               // Rsb[9] row-major, Tsb, Vsb, bg, ba, Rsg g, gyro, accel, slope_gyro, slope_accel (3 each)
+  double* sKs = nom + 36;      // [NS][3] stage velocities
   double* Jms = sKs + 24;      // [NS][4][3 x 3] row-major: dW/dW, dV/dW, -Rsb, dV/dWsg of every stage
   double* FKs = Jms + NS * 36; // [NS][9 x 23]
   double* PKs = FKs + NS * NF; // [NS][23 x 23]
@@ -1202,24 +1204,45 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
     else if (r >= 6) GQc[e] = q;
   }
   xivo_pose_in& pose = a.poses[filt];
-  MotionRegs X;
-  X.Rsb = m3_from_colmajor(pose.Rsb);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { X.Tsb.v[i] = pose.Tsb[i]; X.Vsb.v[i] = pose.Vsb[i]; X.bg.v[i] = pose.bg[i]; X.ba.v[i] = pose.ba[i]; }
   const V3 gv{{a.g[0], a.g[1], a.g[2]}};
-  const V3 Rg = m3_mulv(m3_from_colmajor(pose.Rsg), gv);   // Rsg g (estimator.cpp:609)
+  if (lane == 0) {
+    const V3 Rg0 = m3_mulv(m3_from_colmajor(pose.Rsg), gv);   // Rsg g (estimator.cpp:609)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) nom[3 * i + j] = pose.Rsb[i + 3 * j];
+      nom[9 + i] = pose.Tsb[i]; nom[12 + i] = pose.Vsb[i]; nom[15 + i] = pose.bg[i]; nom[18 + i] = pose.ba[i];
+      nom[21 + i] = Rg0.v[i];
+    }
+  }
+  auto load_nominal = [&](MotionRegs& X, V3& Rg) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) X.Rsb.m[i][j] = nom[3 * i + j];
+      X.Tsb.v[i] = nom[9 + i]; X.Vsb.v[i] = nom[12 + i]; X.bg.v[i] = nom[15 + i]; X.ba.v[i] = nom[18 + i];
+      Rg.v[i] = nom[21 + i];
+    }
+  };
   __syncthreads();
 
   // one Estimator::Propagate per IMU sample; the transitions of all samples are accumulated in Phi so that the
   // O(23 N) cross-covariance tail runs once per call instead of once per sample
-  xivo_imu_in im_next = a.imu[(long)filt * a.n_imu];
+  // lanes 0..2 carry one component each of the next IMU sample (loaded one sample ahead: its latency hides behind
+  // the integration of the current one)
+  const xivo_imu_in* imu_f = a.imu + (long)filt * a.n_imu;
+  const int c3 = lane < 3 ? lane : 0;
+  double n_g = imu_f[0].gyro[c3], n_a = imu_f[0].accel[c3], n_sg = imu_f[0].slope_gyro[c3], n_sa = imu_f[0].slope_accel[c3];
+  double n_dt = imu_f[0].dt;
   for (int smp = 0; smp < a.n_imu; ++smp) {
-  const xivo_imu_in im = im_next;
-  if (smp + 1 < a.n_imu) im_next = a.imu[(long)filt * a.n_imu + smp + 1];   // in flight while this sample is integrated
-  V3 gyro{{im.gyro[0], im.gyro[1], im.gyro[2]}}, accel{{im.accel[0], im.accel[1], im.accel[2]}};
-  const V3 sg{{im.slope_gyro[0], im.slope_gyro[1], im.slope_gyro[2]}}, sa{{im.slope_accel[0], im.slope_accel[1], im.slope_accel[2]}};
+  if (lane < 3) { nom[24 + lane] = n_g; nom[27 + lane] = n_a; nom[30 + lane] = n_sg; nom[33 + lane] = n_sa; }
+  const double dt = n_dt;
+  if (smp + 1 < a.n_imu) {
+    const xivo_imu_in& nx = imu_f[smp + 1];
+    n_g = nx.gyro[c3]; n_a = nx.accel[c3]; n_sg = nx.slope_gyro[c3]; n_sa = nx.slope_accel[c3]; n_dt = nx.dt;
+  }
+  __syncthreads();
   double total = 0.0;
-  const double dt = im.dt;
   // fixed sub-stepping with the half-step tail trick (rk4.cpp:13-32, princedormand.cpp:62-81)
   while (total < dt || a.stepsize < 0) {
     double h = a.stepsize;
@@ -1229,11 +1252,12 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
 
     // -- nominal pre-pass: wave w evaluates stages w, w + 4
     for (int st = wave; st < NS; st += 4) {
-      MotionRegs X0 = X;
+      MotionRegs X0; V3 Rg;
+      load_nominal(X0, Rg);
       const double ti = tab.c_imu[st] * h;
       V3 gi, ai;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { gi.v[i] = gyro.v[i] + sg.v[i] * ti; ai.v[i] = accel.v[i] + sa.v[i] * ti; }
+      for (int i = 0; i < 3; ++i) { gi.v[i] = nom[24 + i] + nom[30 + i] * ti; ai.v[i] = nom[27 + i] + nom[33 + i] * ti; }
       if (st > 0) {
         const V3 V0{{0, 0, 0}};   // the a_ij-weighted velocities only move Tsb, which no Jacobian reads
         compose_motion_dev(X0, V0, gi, ai, tab.c_step[st] * h, Rg);
@@ -1260,19 +1284,28 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
       }
     }
     __syncthreads();
-    // the sub-step of the nominal state itself (every wave keeps its own copy)
-    V3 ge, ae;
+    // the sub-step of the nominal state itself: wave 0, while the others start on phase A of stage 0
+    if (wave == 0) {
+      MotionRegs X; V3 Rg;
+      load_nominal(X, Rg);
+      V3 ge, ae, Kt{{0, 0, 0}};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { ge.v[i] = gyro.v[i] + sg.v[i] * h; ae.v[i] = accel.v[i] + sa.v[i] * h; }
-    {
-      V3 Kt{{0, 0, 0}};
+      for (int i = 0; i < 3; ++i) { ge.v[i] = nom[24 + i] + nom[30 + i] * h; ae.v[i] = nom[27 + i] + nom[33 + i] * h; }
 #pragma unroll
       for (int q = 0; q < NS; ++q)
 #pragma unroll
         for (int i = 0; i < 3; ++i) Kt.v[i] += tab.b[q] * sKs[3 * q + i];
       compose_motion_dev(X, Kt, ge, ae, h, Rg);
+      if (wl == 0) {                                 // (the next readers of nom sit behind the barriers of the stage loop)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) nom[3 * i + j] = X.Rsb.m[i][j];
+          nom[9 + i] = X.Tsb.v[i]; nom[12 + i] = X.Vsb.v[i];
+          nom[24 + i] = ge.v[i]; nom[27 + i] = ae.v[i];   // rk4.cpp:27-28: the next sub-step starts from the interpolated sample
+        }
+      }
     }
-
     // phase A of stage st: S = sum_q a_q FK_q (rows < 9), P0 = Pmm + (sum_q a_q PK_q) h (rk4.cpp:49-88), Vsb rows of G Q.
     // It runs once before the stage loop for stage 0 and otherwise fused behind phase C of the stage before, whose
     // thread owns the same elements: two barriers per stage.
@@ -1444,7 +1477,6 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
       PhiN[lane] = v;
     }
     { double* t = Phi; Phi = PhiN; PhiN = t; }       // (next read of Phi / write of S1 lies behind the pre-pass barrier)
-    gyro = ge; accel = ae;                           // rk4.cpp:27-28
     total += h;
     if (a.stepsize < 0) break;
   }
@@ -1464,9 +1496,9 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      pose.Tsb[i] = X.Tsb.v[i]; pose.Vsb[i] = X.Vsb.v[i];
+      pose.Tsb[i] = nom[9 + i]; pose.Vsb[i] = nom[12 + i];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) pose.Rsb[i + 3 * j] = X.Rsb.m[i][j];
+      for (int j = 0; j < 3; ++j) pose.Rsb[i + 3 * j] = nom[3 * i + j];
     }
   }
 }
@@ -1593,7 +1625,7 @@ template <int NS>
 static int launch_propagate_state_ns(const PropStateArgs& a, hipStream_t s) {
   // LDS: 4 matrices, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, stage velocities, per stage 36 Jacobian entries +
   // FK (9 rows) + PK: RK4 49 KB (3 workgroups per CU), Dormand-Prince 67 KB (2 per CU)
-  const size_t lds = (size_t)(3 * 529 + 4 * 207 + 3 * 144 + 2 + 24 + NS * (36 + 207 + 529)) * sizeof(double);
+  const size_t lds = (size_t)(3 * 529 + 4 * 207 + 3 * 144 + 2 + 36 + 24 + NS * (36 + 207 + 529)) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel<NS>),
