@@ -1168,7 +1168,8 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
                                // Rsb[9] row-major, Tsb, Vsb, bg, ba, Rsg g, gyro, accel, slope_gyro, slope_accel (3 each)
   double* sKs = nom + 36;      // [NS][3] stage velocities
   double* Jms = sKs + 24;      // [NS][4][3 x 3] row-major: dW/dW, dV/dW, -Rsb, dV/dWsg of every stage
-  double* FKs = Jms + NS * 36; // [NS][9 x 23]
+  double* F9s = Jms + NS * 36; // [NS][9 x 23] the non-zero rows of F per stage, dense ([i + 9 j]): the F term of FK = F + F S h
+  double* FKs = F9s + NS * NF; // [NS][9 x 23]
   double* PKs = FKs + NS * NF; // [NS][23 x 23]
 
   const double* Pg = a.P + (long)filt * a.strideP;
@@ -1195,6 +1196,10 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
     oG[m] = (ci >= 0 && cj >= 0) ? (int)(GQG - sm) + ci + 12 * cj : (int)(zero - sm);
   }
   for (int e = lane; e < NS * (NF + NN); e += NT) FKs[e] = 0.0;   // finite values under the tableau's zero coefficients
+  for (int e = lane; e < NS * NF; e += NT) {                      // the constant entries of F: dWsb/dbg = -I, dTsb/dVsb = I
+    const int i = (e % NF) % FR, j = (e % NF) / FR;
+    F9s[e] = (i < 3 && j == 9 + i) ? -1.0 : ((i >= 3 && i < 6 && j == 3 + i) ? 1.0 : 0.0);
+  }
   for (int e = lane; e < 144; e += NT) {
     const double q = a.Qimu[e];
     Q[e] = q;
@@ -1272,6 +1277,7 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
       const M3 w_nR = m3_neg(X0.Rsb);                             // Vsb <- ba, and G's Vsb <- accel-noise block
       if (wl == 0) {
         double* Jm = Jms + st * 36;
+        double* F9 = F9s + st * NF;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           sKs[3 * st + i] = X0.Vsb.v[i];
@@ -1279,6 +1285,10 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
           for (int j = 0; j < 3; ++j) {
             Jm[3 * i + j] = w_dW_dW.m[i][j]; Jm[9 + 3 * i + j] = w_dV_dW.m[i][j];
             Jm[18 + 3 * i + j] = w_nR.m[i][j]; Jm[27 + 3 * i + j] = w_dV_dWsg.m[i][j];
+            F9[i + FR * j] = w_dW_dW.m[i][j];                     // Wsb <- Wsb
+            F9[(6 + i) + FR * j] = w_dV_dW.m[i][j];               // Vsb <- Wsb
+            F9[(6 + i) + FR * (12 + j)] = w_nR.m[i][j];           // Vsb <- ba
+            if (j < 2) F9[(6 + i) + FR * (21 + j)] = w_dV_dWsg.m[i][j];   // Vsb <- Wsg
           }
         }
       }
@@ -1360,7 +1370,7 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
         const int j = fk_task ? wl - 32 : wl;
         if (j < NM) {
           const double* M = (fk_task ? S1 : P0) + NM * j;         // column j
-          double o[3], f[3];                                      // o = (F M)[block rows, j], f = F[block rows, j]
+          double o[3];                                            // o = (F M)[block rows, j]
           if (wave == 0) {                                        // Wsb rows: k = 0..2 (dW/dW), k = 9 + i (-1)
             const M3 dW_dW = ldm(0);
             const double m0 = M[0], m1 = M[1], m2 = M[2];
@@ -1370,11 +1380,10 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
               v = fma(dW_dW.m[i][1], m1, v);
               v = fma(dW_dW.m[i][2], m2, v);
               o[i] = fma(-1.0, M[9 + i], v);
-              f[i] = j == 0 ? dW_dW.m[i][0] : (j == 1 ? dW_dW.m[i][1] : (j == 2 ? dW_dW.m[i][2] : (j == 9 + i ? -1.0 : 0.0)));
             }
           } else if (wave == 1) {                                 // Tsb rows: k = 6 + i (1)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { o[i] = fma(1.0, M[6 + i], 0.0); f[i] = j == 6 + i ? 1.0 : 0.0; }
+            for (int i = 0; i < 3; ++i) o[i] = fma(1.0, M[6 + i], 0.0);
           } else {                                                // Vsb rows: k = 0..2, 12..14, 21..22
             const M3 dV_dW = ldm(1), nR = ldm(2), dV_dWsg = ldm(3);
             const double m0 = M[0], m1 = M[1], m2 = M[2], m12 = M[12], m13 = M[13], m14 = M[14], m21 = M[21], m22 = M[22];
@@ -1388,14 +1397,11 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
               v = fma(nR.m[i][2], m14, v);
               v = fma(dV_dWsg.m[i][0], m21, v);
               o[i] = fma(dV_dWsg.m[i][1], m22, v);
-              f[i] = j == 0 ? dV_dW.m[i][0] : (j == 1 ? dV_dW.m[i][1] : (j == 2 ? dV_dW.m[i][2] :
-                     (j == 12 ? nR.m[i][0] : (j == 13 ? nR.m[i][1] : (j == 14 ? nR.m[i][2] :
-                     (j == 21 ? dV_dWsg.m[i][0] : (j == 22 ? dV_dWsg.m[i][1] : 0.0)))))));
             }
           }
           if (fk_task) {                                          // FK_st = F + F S h
 #pragma unroll
-            for (int i = 0; i < 3; ++i) FKs[st * NF + (3 * wave + i) + FR * j] = f[i] + o[i] * h;
+            for (int i = 0; i < 3; ++i) FKs[st * NF + (3 * wave + i) + FR * j] = F9s[st * NF + (3 * wave + i) + FR * j] + o[i] * h;
           } else {
 #pragma unroll
             for (int i = 0; i < 3; ++i) FPs[(3 * wave + i) + FR * j] = o[i];
@@ -1624,8 +1630,8 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
 template <int NS>
 static int launch_propagate_state_ns(const PropStateArgs& a, hipStream_t s) {
   // LDS: 4 matrices, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, stage velocities, per stage 36 Jacobian entries +
-  // FK (9 rows) + PK: RK4 49 KB (3 workgroups per CU), Dormand-Prince 67 KB (2 per CU)
-  const size_t lds = (size_t)(3 * 529 + 4 * 207 + 3 * 144 + 2 + 36 + 24 + NS * (36 + 207 + 529)) * sizeof(double);
+  // F, FK (9 rows each) + PK: RK4 54 KB, Dormand-Prince 78 KB (2 workgroups per CU either way: 210 / 229 VGPRs)
+  const size_t lds = (size_t)(3 * 529 + 4 * 207 + 3 * 144 + 2 + 36 + 24 + NS * (36 + 2 * 207 + 529)) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel<NS>),
