@@ -22,6 +22,8 @@ def main():
     ap.add_argument("-noise_vision_std", type=float, default=1.0)
     ap.add_argument("-integration_method", default="PrinceDormand")
     ap.add_argument("-as_coded_group_block", action="store_true", help="reproduce src/feature.cpp:675-676")
+    ap.add_argument("-host", default="python", choices=["python", "cpp"],
+                    help="host side of the frame loop: xivo_amd/sequence.py or xivo::hip::BatchEstimator (C++)")
     ap.add_argument("-dump", default="", help="directory for per-sequence `ts Tsb Wsb` trajectories")
     a = ap.parse_args()
     # BASELINE config 5: under torch.distributed.run, sequence s runs on rank s mod world (one rank per GPU, no data-path
@@ -41,11 +43,22 @@ def main():
     timers = {}
     device = int(os.environ.get("LOCAL_RANK", 0))
     t0 = time.perf_counter()
-    out = sequence.run_pcw(lambda c_, B_, p_, P_: sequence.HipBackend(c_, B_, p_, P_, device=device), cfg, worlds, sims,
-                           total_time=a.total_time, imu_dt=a.imu_dt, vision_dt=a.vision_dt,
-                           noise_vision_std=a.noise_vision_std, timers=timers)
+    if a.host == "cpp":
+        out = sequence.run_pcw_cpp(cfg, worlds, sims, total_time=a.total_time, imu_dt=a.imu_dt, vision_dt=a.vision_dt,
+                                   noise_vision_std=a.noise_vision_std, device=device)
+        st = out["estimator"].stats()
+        timers = {"host_cpp_lifecycle": st["host_seconds"]}
+
+        class _R:      # the report below reads these two counters
+            n_updates, n_rejected = st["updates"], st["mh_rejected"]
+        out["runner"] = _R
+        out["estimator"].close()
+    else:
+        out = sequence.run_pcw(lambda c_, B_, p_, P_: sequence.HipBackend(c_, B_, p_, P_, device=device), cfg, worlds, sims,
+                               total_time=a.total_time, imu_dt=a.imu_dt, vision_dt=a.vision_dt,
+                               noise_vision_std=a.noise_vision_std, timers=timers)
+        out["backend"].close()
     wall = time.perf_counter() - t0
-    out["backend"].close()
     frames = len(out["ts"])
     ate = np.array([formats.ate_rmse(out["Tsb"][:, b], out["gt_Tsb"][:, b], align=False) for b in range(B)])
     dev = sum(timers.get(k, 0.0) for k in ("propagate", "edit", "update"))
@@ -66,7 +79,7 @@ def main():
         return
     print(json.dumps({
         "sequences": B, "n_gpus": world, "frames_per_sequence": frames, "imu_samples_per_frame": int(round(a.vision_dt / a.imu_dt)),
-        "N": cfg.N, "max_features": cfg.n_features, "integration": a.integration_method,
+        "N": cfg.N, "max_features": cfg.n_features, "integration": a.integration_method, "host": a.host,
         "ate_m": {"median": float(np.median(ate)), "p90": float(np.quantile(ate, 0.9)), "max": float(ate.max())},
         "updates": n_upd, "mh_rejected": n_rej,
         "wall_s": wall, "device_path_s": dev,

@@ -266,3 +266,29 @@ def test_pyxivo_style_estimator_runs_the_reference_client_loop(built):
             out["backend"].close()
     finally:
         est.close()
+
+
+def test_cpp_batch_estimator_equals_python_runner(built):
+    """xivo::hip::BatchEstimator (C++ host side: IMU bookkeeping, slot book-keeping, edit lists) fed the same messages
+    as the Python runner takes the same decisions every frame - identical slot books - and ends in the same state (the
+    only arithmetic on the host is the feature initialisation, log() of libm vs numpy: last-ulp differences)."""
+    B = 4
+    cfg = sequence.SequenceConfig()
+    mk = lambda: ([pcw.RandomPCW(seed=20 + b) for b in range(B)],
+                  [pcw.TrajectorySim("trefoil" if b % 2 else "lissajous", seed=400 + b) for b in range(B)])
+    w1, s1 = mk()
+    py = sequence.run_pcw(sequence.HipBackend, cfg, w1, s1, total_time=1.0)
+    w2, s2 = mk()
+    cp = sequence.run_pcw_cpp(cfg, w2, s2, total_time=1.0)
+    try:
+        assert np.array_equal(py["ts"], cp["ts"])
+        for b in range(B):
+            fid, fref, gref = cp["estimator"].book(b)
+            bk = py["runner"].books[b]
+            assert list(fid) == bk.feat_id and list(fref) == bk.feat_ref and list(gref) == bk.group_refs
+        st = cp["estimator"].stats()
+        assert st["updates"] == py["runner"].n_updates and st["mh_rejected"] == py["runner"].n_rejected
+        assert np.abs(py["Tsb"] - cp["Tsb"]).max() < 1e-10 and np.abs(py["Wsb"] - cp["Wsb"]).max() < 1e-10
+        assert 0 < st["host_seconds"] < 1.0
+    finally:
+        py["backend"].close(); cp["estimator"].close()

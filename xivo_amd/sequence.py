@@ -357,3 +357,31 @@ def run_pcw(backend_factory, cfg, worlds, sims, total_time=4.0, imu_dt=0.0025, v
             gt_T.append(np.array([s.gsb(t)[1] for s in sims]))
     return dict(ts=np.array(ts), Tsb=np.array(est_T), Wsb=np.array(est_W), gt_Tsb=np.array(gt_T), runner=runner,
                 backend=be)
+
+
+def run_pcw_cpp(cfg, worlds, sims, total_time=4.0, imu_dt=0.0025, vision_dt=0.04, noise_vision_std=1.0, device=0):
+    """run_pcw with the C++ host side: the same messages go to xivo::hip::BatchEstimator (xivo_amd/host/batch_estimator.h)
+    through its InertialMeas / VisualMeasPointCloud entry points instead of ImuFeeder + SequenceRunner.
+    -> dict(ts, Tsb, Wsb, gt_Tsb, estimator)"""
+    from .batch import BatchEstimator
+    B = len(sims)
+    K = np.array([[cfg.cam["fx"], 0, cfg.cam["cx"]], [0, cfg.cam["fy"], cfg.cam["cy"]], [0, 0, 1.0]])
+    Rbc = so3_exp(cfg.Wbc)
+    est = BatchEstimator(cfg, B, initial_poses(cfg, sims), cfg.P_init(), device=device)
+    n_imu = int(round(total_time / imu_dt)); every = int(round(vision_dt / imu_dt))
+    ts, est_T, est_W, gt_T = [], [], [], []
+    for k in range(n_imu):
+        t = k * imu_dt
+        m = [s.meas(t) for s in sims]
+        est.InertialMeas(t, np.array([x[1] for x in m]), np.array([x[0] for x in m]))
+        if k % every == 0:
+            tracks = []
+            for b in range(B):
+                Rsb, Tsb = sims[b].gsb(t)
+                tracks.append(worlds[b].generate_measurements(Rsb @ Rbc, Rsb @ cfg.Tbc + Tsb, K, cfg.cam["cols"],
+                                                              cfg.cam["rows"], noise_vision_std))
+            est.VisualMeasPointCloud(t, tracks)
+            R, T = est.gsb()
+            ts.append(int(round(t * 1e9))); est_T.append(T); est_W.append(np.array([so3_log(r) for r in R]))
+            gt_T.append(np.array([s.gsb(t)[1] for s in sims]))
+    return dict(ts=np.array(ts), Tsb=np.array(est_T), Wsb=np.array(est_W), gt_Tsb=np.array(gt_T), estimator=est)
