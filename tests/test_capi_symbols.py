@@ -78,3 +78,14 @@ def test_invalid_arguments_return_status_codes(built):
     assert lib.xivo_hip_create(ctypes.byref(h), 0, 64, 16 * 30, 2, 0) == -5      # M beyond the solver's register budget
     assert lib.xivo_hip_sync(None) == -1 and lib.xivo_hip_update_joseph(None, 1) == -1
     lib.xivo_hip_destroy(None)   # no-op
+
+
+def test_host_library_exports_the_batch_estimator(built):
+    """libxivo_host.so (C++ side: adapter + xivo::hip::BatchEstimator) loads next to the C ABI and exports the entry
+    points xivo_amd/batch.py binds (no compute call without a GPU)."""
+    from xivo_amd import batch
+    host = batch.load_host_library()
+    for name in ("xivo_batch_create", "xivo_batch_destroy", "xivo_batch_imu", "xivo_batch_visual", "xivo_batch_poses",
+                 "xivo_batch_book", "xivo_batch_stats", "xivo_batch_ctx", "xivo_host_selftest_update_step"):
+        assert hasattr(host, name), name
+    assert batch.batch_cfg_dtype.itemsize == 5600      # struct xivo_batch_cfg (host/batch_estimator.cpp)
