@@ -24,8 +24,29 @@ def main():
     ap.add_argument("-as_coded_group_block", action="store_true", help="reproduce src/feature.cpp:675-676")
     ap.add_argument("-host", default="python", choices=["python", "cpp"],
                     help="host side of the frame loop: xivo_amd/sequence.py or xivo::hip::BatchEstimator (C++)")
+    ap.add_argument("-vectorized", action="store_true",
+                    help="thousands of sequences: vectorised simulators + the C++ host side (xivo_amd.sequence.run_pcw_batch)")
     ap.add_argument("-dump", default="", help="directory for per-sequence `ts Tsb Wsb` trajectories")
     a = ap.parse_args()
+    if a.vectorized:
+        cfg = sequence.SequenceConfig(integration_method=a.integration_method, fix_group_block=not a.as_coded_group_block)
+        tm = {}
+        t0 = time.perf_counter()
+        out = sequence.run_pcw_batch(cfg, a.sequences, total_time=a.total_time, imu_dt=a.imu_dt, vision_dt=a.vision_dt,
+                                     noise_vision_std=a.noise_vision_std, npts=a.npts, timers=tm)
+        wall = time.perf_counter() - t0
+        st = out["estimator"].stats(); out["estimator"].close()
+        frames = len(out["ts"])
+        ate = np.sqrt(np.mean(np.sum((out["Tsb"] - out["gt_Tsb"]) ** 2, axis=2), axis=0))
+        print(json.dumps({
+            "sequences": a.sequences, "frames_per_sequence": frames, "N": cfg.N, "integration": a.integration_method,
+            "host": "cpp, vectorised simulators",
+            "ate_m": {"median": float(np.median(ate)), "p90": float(np.quantile(ate, 0.9)), "max": float(ate.max())},
+            "updates": st["updates"], "mh_rejected": st["mh_rejected"], "wall_s": wall, "simulator_s": tm.get("sim", 0.0),
+            "frame_calls_s": tm.get("frame", 0.0), "host_cpp_lifecycle_s": st["host_seconds"],
+            "frames_per_s_in_frame_calls": a.sequences * frames / tm["frame"],
+            "ms_per_frame_of_all_sequences": 1e3 * tm["frame"] / frames}))
+        return
     # BASELINE config 5: under torch.distributed.run, sequence s runs on rank s mod world (one rank per GPU, no data-path
     # collective; the ranks only meet to add up the report)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))

@@ -149,3 +149,27 @@ def test_reference_cfg_schema_is_read(tmp_path):
     c2 = pyxivo.config_from_cfg(cfg2)
     assert c2.cam["model"] == 3 and c2.cam["d"] == [1e-3, 2e-3, 3e-3, 4e-3]
     assert np.allclose(c2.Wbc, [-np.pi / 2, 0, 0])          # a matrix Wbc is converted to the rotation vector
+
+
+def test_batch_simulators_equal_the_scalar_ones():
+    """BatchTrajectorySim / BatchPCW (numpy over the sequence axis, what feeds thousands of filters) reproduce
+    TrajectorySim / RandomPCW sequence by sequence: poses, velocities, noise-free IMU samples, track ids and pixels."""
+    motion, rate = ["lissajous", "trefoil", "lissajous"], [0.1, 0.08, 0.12]
+    bs = pcw.BatchTrajectorySim(motion, rate, noise_accel=0, noise_gyro=0)
+    for b, (m, r) in enumerate(zip(motion, rate)):
+        s = pcw.TrajectorySim(m, rate=r, noise_accel=0, noise_gyro=0)
+        for t in (0.0, 0.37, 1.9):
+            R, T = s.gsb(t); Rb, Tb = bs.gsb(t)
+            a, g = s.meas(t); ab, gb = bs.meas(t)
+            assert np.abs(R - Rb[b]).max() < 1e-14 and np.abs(T - Tb[b]).max() < 1e-13
+            assert np.abs(a - ab[b]).max() < 1e-12 and np.abs(g - gb[b]).max() < 1e-13
+            assert np.abs(s.vel(t) - bs.vel(t)[b]).max() < 1e-13
+    w = pcw.RandomPCW(npts=300, seed=4)
+    bw = pcw.BatchPCW(2, Xs=np.stack([w.Xs, w.Xs[::-1]]))
+    Rbc = pcw.so3_exp(np.array([-1.57079633, 0, 0]))
+    for step in range(5):
+        Rsc = Rbc @ pcw.so3_exp(np.array([0, 0.35 * step, 0])); Tsc = np.array([0.1 * step, 0, 0])
+        ids, m = w.generate_measurements(Rsc, Tsc, K, 640, 480, 0.0)
+        off, bi, bm = bw.generate(np.stack([Rsc, Rsc]), np.stack([Tsc, Tsc]), K, 640, 480, 0.0)
+        assert np.array_equal(bi[:off[1]], ids) and np.allclose(bm[:off[1]], m, atol=1e-12)
+        assert off[2] - off[1] == len(ids)                     # the mirrored world sees the same points

@@ -292,3 +292,17 @@ def test_cpp_batch_estimator_equals_python_runner(built):
         assert 0 < st["host_seconds"] < 1.0
     finally:
         py["backend"].close(); cp["estimator"].close()
+
+
+def test_vectorised_batch_run_tracks_ground_truth(built):
+    """256 sequences through the vectorised simulators and xivo::hip::BatchEstimator: every trajectory follows its
+    ground truth."""
+    cfg = sequence.SequenceConfig()
+    out = sequence.run_pcw_batch(cfg, 256, total_time=1.6)
+    try:
+        ate = np.sqrt(np.mean(np.sum((out["Tsb"] - out["gt_Tsb"]) ** 2, axis=2), axis=0))
+        assert np.isfinite(ate).all() and np.median(ate) < 0.05 and ate.max() < 0.3, np.sort(ate)[-5:]
+        st = out["estimator"].stats()
+        assert st["updates"] >= 256 * 38
+    finally:
+        out["estimator"].close()

@@ -14,6 +14,8 @@ namespace xivo {
 namespace hip {
 
 namespace {
+// a microsecond of book-keeping per filter: a handful of threads is all the loop can use (256 made it 8x slower)
+constexpr int kThreads = 8;
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -140,17 +142,21 @@ void BatchEstimator::VisualMeasPointCloud(double t, const int* off, const int64_
   }
   // --- before the update: tracker-dropped features leave (ProcessTracks, src/manager.cpp:152-169), tracked ones get
   // their new pixel
-  std::vector<xivo_edit_op> ops;
   const double nan = std::numeric_limits<double>::quiet_NaN();
   std::fill(xp_.begin(), xp_.end(), nan);
   // which track carries each in-state feature: the <= kMaxFeature in-state ids sorted once per filter, one binary
   // search per track (a frame brings ~10^2 tracks per filter, most of them not in the state)
-  std::vector<std::pair<int64_t, int>> instate;      // (id, slot), ascending id
-  std::vector<int> slot_track(F);
   in_state_.assign((size_t)off[B_], 0);
+  per_.resize(B_);
+  // (filters are independent: the per-filter book-keeping runs over the host cores, every filter filling its own op
+  // list; the lists are then joined in filter order, which xivo_hip_edit_batch requires anyway)
+#pragma omp parallel for schedule(static) num_threads(kThreads) if (B_ >= 512)
   for (int b = 0; b < B_; ++b) {
+    std::vector<xivo_edit_op>& ops = per_[b];
+    ops.clear();
+    std::vector<std::pair<int64_t, int>> instate;      // (id, slot), ascending id
+    std::vector<int> slot_track(F);
     Book& bk = books_[b];
-    instate.clear();
     for (int j = 0; j < F; ++j) if (bk.feat_id[j] >= 0) instate.emplace_back(bk.feat_id[j], j);
     std::sort(instate.begin(), instate.end());
     std::fill(slot_track.begin(), slot_track.end(), -1);
@@ -172,6 +178,8 @@ void BatchEstimator::VisualMeasPointCloud(double t, const int* off, const int64_
     DiscardEmptyGroups(b, ops);
     for (int j = 0; j < F; ++j) slot_track_all_[(size_t)b * F + j] = slot_track[j];
   }
+  std::vector<xivo_edit_op> ops;
+  for (int b = 0; b < B_; ++b) ops.insert(ops.end(), per_[b].begin(), per_[b].end());
   host_s_ += now_s() - t0;
   Check(xivo_hip_edit_batch(ctx_, F, (int)ops.size(), ops.empty() ? nullptr : ops.data()), "edit_batch");
   Check(xivo_hip_set_pixels(ctx_, 0, B_, F, xp_.data()), "set_pixels");
@@ -183,18 +191,21 @@ void BatchEstimator::VisualMeasPointCloud(double t, const int* off, const int64_
   t0 = now_s();
   for (int b = 0; b < B_; ++b) n_updates_ += books_[b].id2slot.empty() ? 0 : 1;
   // --- after the update: MH-rejected features leave (src/update.cpp:105-113), new ones enter with a new group
-  ops.clear();
   const double fx = cfg_.cam.fx, fy = cfg_.cam.fy, cx = cfg_.cam.cx, cy = cfg_.cam.cy;
   const double sd[3] = {cfg_.initial_std_x / fx, cfg_.initial_std_y / fx, cfg_.initial_std_z};
-  std::vector<int> free_slots, order;
+  long rejected = 0;
+#pragma omp parallel for schedule(static) reduction(+ : rejected) num_threads(kThreads) if (B_ >= 512)
   for (int b = 0; b < B_; ++b) {
+    std::vector<xivo_edit_op>& ops = per_[b];
+    ops.clear();
+    std::vector<int> free_slots, order;
     Book& bk = books_[b];
     for (int j = 0; j < F; ++j)
       if (bk.feat_id[j] >= 0 && !mask_[(size_t)b * F + j]) {
         ops.push_back(make_op(b, XIVO_EDIT_REMOVE_FEATURE, j));
         in_state_[slot_track_all_[(size_t)b * F + j]] = 0;      // its track is a candidate again right away
         DropFeature(bk, j);
-        ++n_rejected_;
+        ++rejected;
       }
     DiscardEmptyGroups(b, ops);
     free_slots.clear();
@@ -224,6 +235,9 @@ void BatchEstimator::VisualMeasPointCloud(double t, const int* off, const int64_
       bk.group_refs[g] += 1;
     }
   }
+  n_rejected_ += rejected;
+  ops.clear();
+  for (int b = 0; b < B_; ++b) ops.insert(ops.end(), per_[b].begin(), per_[b].end());
   host_s_ += now_s() - t0;
   Check(xivo_hip_edit_batch(ctx_, F, (int)ops.size(), ops.empty() ? nullptr : ops.data()), "edit_batch");
   if (mask_out) std::memcpy(mask_out, mask_.data(), mask_.size());

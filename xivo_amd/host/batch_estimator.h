@@ -88,6 +88,7 @@ class BatchEstimator {
   std::vector<unsigned char> mask_;
   std::vector<double> xp_;
   std::vector<unsigned char> in_state_;   // per track of the current frame: is it an in-state feature
+  std::vector<std::vector<xivo_edit_op>> per_;   // per filter: the edit ops of the current phase
   std::vector<int> slot_track_all_;       // [B][F] track index of each in-state feature in the current frame
 };
 

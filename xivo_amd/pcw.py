@@ -137,3 +137,93 @@ class TrajectorySim:
         accel = a_b - Rsb.T @ self.grav_s + self.bias_accel + self.noise_accel * self.rng.standard_normal(3)
         gyro = w_b + self.bias_gyro + self.noise_gyro * self.rng.standard_normal(3)
         return accel, gyro
+
+
+# ---- the same two simulators for B sequences at once (numpy over the sequence axis): what feeds thousands of
+# ---- filters per frame; formulas identical to RandomPCW / TrajectorySim above (tests compare them)
+def so3_exp_batch(w):
+    """w: [B, 3] -> [B, 3, 3]"""
+    th = np.linalg.norm(w, axis=1)
+    W = np.zeros((w.shape[0], 3, 3))
+    W[:, 0, 1], W[:, 0, 2], W[:, 1, 0], W[:, 1, 2], W[:, 2, 0], W[:, 2, 1] = -w[:, 2], w[:, 1], w[:, 2], -w[:, 0], -w[:, 1], w[:, 0]
+    small = th < 1e-9
+    ths = np.where(small, 1.0, th)
+    a = np.where(small, 1.0, np.sin(ths) / ths)
+    b = np.where(small, 0.5, (1.0 - np.cos(ths)) / (ths * ths))
+    return np.eye(3)[None] + a[:, None, None] * W + b[:, None, None] * (W @ W), W, th
+
+
+class BatchTrajectorySim:
+    """B trajectories: motion[b] in {"lissajous", "trefoil"}, rate[b]; one noise stream for all."""
+
+    def __init__(self, motion, rate, rot_amp=0.2, noise_accel=1e-4, noise_gyro=1e-5, grav_s=(0, 0, -9.8), seed=1):
+        self.is_tre = np.array([m == "trefoil" for m in motion])
+        self.rate = np.asarray(rate, dtype=float)
+        self.B = len(self.rate)
+        self.rot_amp = float(rot_amp)
+        self.rot_w = np.array([0.3, 0.4, 0.1]) * 3.0
+        self.noise_accel, self.noise_gyro = noise_accel, noise_gyro
+        self.grav_s = np.asarray(grav_s, dtype=float)
+        self.rng = np.random.default_rng(seed)
+        self.p0 = self._curve(np.zeros(self.B))[0]
+
+    def _curve(self, s):
+        c2, s2, c3, s3, c7, s7 = np.cos(2 * s), np.sin(2 * s), np.cos(3 * s), np.sin(3 * s), np.cos(7 * s), np.sin(7 * s)
+        pl = np.stack([4 * c3, 0.1 * s7, 4 * s2], 1)
+        dl = np.stack([-12 * s3, 0.7 * c7, 8 * c2], 1)
+        al = np.stack([-36 * c3, -4.9 * s7, -16 * s2], 1)
+        pt = np.stack([(4 + c3) * c2, (4 + c3) * s2, s3], 1)
+        dt = np.stack([-3 * s3 * c2 - 2 * (4 + c3) * s2, -3 * s3 * s2 + 2 * (4 + c3) * c2, 3 * c3], 1)
+        at = np.stack([12 * s2 * s3 - 9 * c2 * c3 - 4 * c2 * (c3 + 4), -4 * s2 * (c3 + 4) - 12 * c2 * s3 - 9 * c3 * s2, -9 * s3], 1)
+        m = self.is_tre[:, None]
+        return np.where(m, pt, pl), np.where(m, dt, dl), np.where(m, at, al)
+
+    def gsb(self, t):
+        w = np.tile(self.rot_amp * np.sin(self.rot_w * t), (self.B, 1))
+        R, _, _ = so3_exp_batch(w)
+        return R, self._curve(self.rate * t)[0] - self.p0
+
+    def vel(self, t):
+        return self.rate[:, None] * self._curve(self.rate * t)[1]
+
+    def meas(self, t):
+        """-> (accel [B, 3], gyro [B, 3])"""
+        w = np.tile(self.rot_amp * np.sin(self.rot_w * t), (self.B, 1))
+        wd = self.rot_amp * self.rot_w * np.cos(self.rot_w * t)
+        R, W, th = so3_exp_batch(w)
+        a_s = (self.rate ** 2)[:, None] * self._curve(self.rate * t)[2]
+        Jr = _right_jacobian(w[0])                       # the orientation profile is shared by all sequences
+        accel = np.einsum("bji,bj->bi", R, a_s - self.grav_s) + self.noise_accel * self.rng.standard_normal((self.B, 3))
+        gyro = (Jr @ wd)[None] + self.noise_gyro * self.rng.standard_normal((self.B, 3))
+        return accel, gyro
+
+
+class BatchPCW:
+    """B point-cloud worlds with RandomPCW's track-id semantics; generate() returns the concatenated track lists in the
+    layout xivo::hip::BatchEstimator::VisualMeasPointCloud takes (offsets, ids, (x, y, depth) rows)."""
+
+    def __init__(self, B, npts=1000, xlim=(-10, 10), ylim=(-10, 10), zlim=(-5, 5), seed=0, Xs=None):
+        self.rng = np.random.default_rng(seed)
+        lo = np.array([xlim[0], ylim[0], zlim[0]], dtype=float); hi = np.array([xlim[1], ylim[1], zlim[1]], dtype=float)
+        self.Xs = self.rng.uniform(lo, hi, size=(B, npts, 3)) if Xs is None else np.asarray(Xs, dtype=float)
+        self.ids = np.full(self.Xs.shape[:2], -1, dtype=np.int64)
+        self.next_pt_id = np.full(self.Xs.shape[0], 10000, dtype=np.int64)
+
+    def generate(self, Rsc, Tsc, K, imw, imh, noise_px_std):
+        Xc = np.einsum("bpj,bji->bpi", self.Xs - Tsc[:, None, :], Rsc)       # Rsc^T (Xs - Tsc)
+        front = Xc[..., 2] > 0
+        z = np.where(front, Xc[..., 2], 1.0)
+        u = K[0, 0] * Xc[..., 0] / z + K[0, 2]
+        v = K[1, 1] * Xc[..., 1] / z + K[1, 2]
+        vis = front & (u >= 0) & (v >= 0) & (u <= imw) & (v <= imh)
+        noise = noise_px_std * self.rng.standard_normal(u.shape + (2,))
+        new = vis & (self.ids < 0)
+        rank = np.cumsum(new, axis=1) - 1                                     # order of appearance inside a world
+        self.ids = np.where(new, self.next_pt_id[:, None] + rank, self.ids)
+        self.next_pt_id = self.next_pt_id + new.sum(axis=1)
+        self.ids = np.where(vis, self.ids, -1)
+        off = np.zeros(self.Xs.shape[0] + 1, dtype=np.int32)
+        off[1:] = np.cumsum(vis.sum(axis=1))
+        sel = np.nonzero(vis)                                                 # row-major: sequences in order, points ascending
+        meas = np.stack([u[sel] + noise[sel][:, 0], v[sel] + noise[sel][:, 1], Xc[..., 2][sel]], axis=1)
+        return off, self.ids[sel].copy(), np.ascontiguousarray(meas)

@@ -385,3 +385,46 @@ def run_pcw_cpp(cfg, worlds, sims, total_time=4.0, imu_dt=0.0025, vision_dt=0.04
             ts.append(int(round(t * 1e9))); est_T.append(T); est_W.append(np.array([so3_log(r) for r in R]))
             gt_T.append(np.array([s.gsb(t)[1] for s in sims]))
     return dict(ts=np.array(ts), Tsb=np.array(est_T), Wsb=np.array(est_W), gt_Tsb=np.array(gt_T), estimator=est)
+
+
+def run_pcw_batch(cfg, B, total_time=2.0, imu_dt=0.0025, vision_dt=0.04, noise_vision_std=1.0, npts=1000, seed=0, device=0,
+                  timers=None):
+    """Thousands of sequences end to end: the vectorised simulators of xivo_amd/pcw.py (BatchTrajectorySim, BatchPCW) feed
+    xivo::hip::BatchEstimator message by message. -> dict(ts, Tsb [n x B x 3], gt_Tsb, estimator)"""
+    import time
+    from .batch import BatchEstimator
+    from .pcw import BatchPCW, BatchTrajectorySim
+    motion = ["lissajous" if b % 2 == 0 else "trefoil" for b in range(B)]
+    rate = 0.08 + 0.04 * (np.arange(B) % 7) / 7
+    sim = BatchTrajectorySim(motion, rate, seed=seed + 1)
+    world = BatchPCW(B, npts=npts, seed=seed)
+    K = np.array([[cfg.cam["fx"], 0, cfg.cam["cx"]], [0, cfg.cam["fy"], cfg.cam["cy"]], [0, 0, 1.0]])
+    Rbc = so3_exp(cfg.Wbc)
+    poses = np.zeros(B, dtype=L.pose_dtype)
+    R0, T0 = sim.gsb(0.0)
+    poses["Rsb"] = R0.transpose(0, 2, 1).reshape(B, 9); poses["Tsb"] = T0; poses["Vsb"] = sim.vel(0.0)
+    poses["Rbc"] = Rbc.T.reshape(-1); poses["Tbc"] = cfg.Tbc; poses["Rsg"] = np.eye(3).reshape(-1)
+    est = BatchEstimator(cfg, B, poses, cfg.P_init(), device=device)
+    host = est.host
+    n_imu = int(round(total_time / imu_dt)); every = int(round(vision_dt / imu_dt))
+    ts, est_T, gt_T = [], [], []
+    tm = timers if timers is not None else {}
+    for k in range(n_imu):
+        t = k * imu_dt
+        t0 = time.perf_counter()
+        accel, gyro = sim.meas(t)
+        tm["sim"] = tm.get("sim", 0.0) + time.perf_counter() - t0
+        est.InertialMeas(t, gyro, accel)
+        if k % every == 0:
+            t0 = time.perf_counter()
+            Rsb, Tsb = sim.gsb(t)
+            off, ids, meas = world.generate(Rsb @ Rbc, np.einsum("bij,j->bi", Rsb, cfg.Tbc) + Tsb, K, cfg.cam["cols"],
+                                            cfg.cam["rows"], noise_vision_std)
+            t1 = time.perf_counter()
+            tm["sim"] = tm.get("sim", 0.0) + t1 - t0
+            mask = np.zeros((B, cfg.n_features), dtype=np.uint8)
+            if host.xivo_batch_visual(est.h, float(t), off.ctypes.data, ids.ctypes.data, meas.ctypes.data, mask.ctypes.data) != 0:
+                raise RuntimeError("VisualMeasPointCloud failed")
+            tm["frame"] = tm.get("frame", 0.0) + time.perf_counter() - t1
+            ts.append(int(round(t * 1e9))); est_T.append(est.poses()["Tsb"].copy()); gt_T.append(Tsb)
+    return dict(ts=np.array(ts), Tsb=np.array(est_T), gt_Tsb=np.array(gt_T), estimator=est)
