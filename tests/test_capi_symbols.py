@@ -35,7 +35,7 @@ def test_strerror_and_tile_query_need_no_gpu(built):
 def test_no_product_code_touches_the_oracle():
     """The product path must never import / link the oracle or a CPU fallback."""
     bad = []
-    for base in ("xivo_amd", "include"):
+    for base in ("xivo_amd", "include", "scripts"):
         for dp, _, fns in os.walk(os.path.join(ROOT, base)):
             for fn in fns:
                 if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):

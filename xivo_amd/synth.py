@@ -91,3 +91,27 @@ def g_level(n_groups, n_features, F, batch, seed=0, cam=PINHOLE, N=None, pix_noi
     out["n_groups"], out["n_features"], out["F"] = n_groups, n_features, F
     out["N"] = 23 + 6 * n_groups + 3 * n_features if N is None else N
     return out
+
+
+def scene_structs(sc):
+    """A g_level scene as the C-ABI struct arrays (poses, groups, feats; column-major 3x3), without pixels: the timing
+    scripts and bench.py take the predicted pixels from the device itself (jacobians with xp = 0 give inn = -prediction)."""
+    from .lib import feat_dtype, group_dtype, pose_dtype
+    B, F = sc["x"].shape[:2]
+    G = sc["gR"].shape[1]
+    poses = np.zeros(B, dtype=pose_dtype); groups = np.zeros((B, G), dtype=group_dtype); feats = np.zeros((B, F), dtype=feat_dtype)
+    cm = lambda R: np.asarray(R).T.reshape(-1)
+    for b in range(B):
+        poses[b]["Rsb"], poses[b]["Tsb"] = cm(sc["Rsb"][b]), sc["Tsb"][b]
+        poses[b]["Rbc"], poses[b]["Tbc"] = cm(sc["Rbc"][b]), sc["Tbc"][b]
+        poses[b]["Rsg"] = np.eye(3).reshape(-1)
+        for g in range(G):
+            groups[b, g]["Rsb"], groups[b, g]["Tsb"] = cm(sc["gR"][b, g]), sc["gT"][b, g]
+    feats["x"] = sc["x"]; feats["ref_sind"] = sc["ref"]; feats["sind"] = sc["sind"]
+    return poses, groups, feats
+
+
+def spd_covariance(N, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    A = rng.uniform(-1, 1, size=(N, N))
+    return (A @ A.T / N + 1e-3 * np.eye(N)) * scale
