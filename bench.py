@@ -23,6 +23,9 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD datasheet). 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz
 
 
+DEFAULT_BATCH = 16384
+
+
 def f_alg(N, M):
     """Reference as-coded flops of UpdateJosephForm."""
     return 4.0 * N ** 3 + 8.0 * M * N ** 2 + 4.0 * M ** 2 * N + M ** 3 / 3.0
@@ -101,7 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="filters per GPU")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH,
+                    help="filters per GPU (16384 x ~4 MB of resident matrices = 64 GB of the 288 GB; 4096: -4 %% throughput)")
     ap.add_argument("--state-dim", type=int, default=250)
     ap.add_argument("--features", type=int, default=80)
     ap.add_argument("--level", choices=["S", "G"], default="S",
@@ -294,6 +298,9 @@ def main():
                 pmc["_file"] = "profiles/" + cands[-1]
         except Exception:
             pmc = {}
+        # filters per launch of the profiled command (per-launch counters only compare at the same batch)
+        m_ = __import__("re").search(r"--batch\s+(\d+)", str((pmc.get("_notes") or {}).get("command", "")))
+        pmc_batch = int(m_.group(1)) if m_ else DEFAULT_BATCH
         roofline = None
         if groups:
             dom = max(groups, key=lambda k: groups[k]["ms"])
@@ -317,7 +324,7 @@ def main():
                         # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of the
                         # same command (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE); null if absent
                         "traffic": (lambda e: (e.get("hbm_read_bytes_per_launch", 0) + e.get("hbm_write_bytes_per_launch", 0))
-                                    if e and args.batch == 4096 else None)(pmc.get(norm(dom))),
+                                    if e and args.batch == pmc_batch else None)(pmc.get(norm(dom))),
                         "traffic_source": pmc.get("_file"),
                         # from the same PMC passes: flops the MFMA pipe really executed per launch (symmetry and
                         # K(HP) - P skip work the reference's as-coded count includes) and pipe busy %
