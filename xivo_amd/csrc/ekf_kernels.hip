@@ -1147,7 +1147,10 @@ __device__ __forceinline__ void compose_motion_dev(MotionRegs& X, const V3& V, c
 // lanes 32..54 column j of F S (S = sum a_q FK_q) and from it FK of the stage; wave 3: lanes 0..22 row i of P0 F^T,
 // lanes 32..43 row r of the 12 x 12 support of G Q G^T.
 template <int NS>
-__global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a) {
+// RK4: 3 workgroups per CU (LDS 50 KB each). The kernel is bound by the latency of one workgroup's serial chain, so a
+// third resident workgroup pays for the 40 VGPRs that spill at the 168-register budget (2.47 -> 2.22 ms per 16 samples
+// x 4096 filters); Dormand-Prince (68 KB) stays at 2.
+__global__ __launch_bounds__(256, NS == 4 ? 3 : 2) void propagate_state_kernel(PropStateArgs a) {
   constexpr int NM = 23, NN = NM * NM, NT = 256, FR = 9, NF = FR * NM;   // FR: rows of F that are not identically zero
   extern __shared__ double sm[];
   const int lane = threadIdx.x, filt = blockIdx.x;   // `lane`: thread index in the workgroup
@@ -1168,8 +1171,8 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
                                // Rsb[9] row-major, Tsb, Vsb, bg, ba, Rsg g, gyro, accel, slope_gyro, slope_accel (3 each)
   double* sKs = nom + 36;      // [NS][3] stage velocities
   double* Jms = sKs + 24;      // [NS][4][3 x 3] row-major: dW/dW, dV/dW, -Rsb, dV/dWsg of every stage
-  double* F9s = Jms + NS * 36; // [NS][9 x 23] the non-zero rows of F per stage, dense ([i + 9 j]): the F term of FK = F + F S h
-  double* FKs = F9s + NS * NF; // [NS][9 x 23]
+  double* F9 = Jms + NS * 36;  // [9 x 23] the non-zero rows of F of the current stage, dense ([i + 9 j]): the F term of FK = F + F S h
+  double* FKs = F9 + NF;       // [NS][9 x 23]
   double* PKs = FKs + NS * NF; // [NS][23 x 23]
 
   const double* Pg = a.P + (long)filt * a.strideP;
@@ -1196,9 +1199,9 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
     oG[m] = (ci >= 0 && cj >= 0) ? (int)(GQG - sm) + ci + 12 * cj : (int)(zero - sm);
   }
   for (int e = lane; e < NS * (NF + NN); e += NT) FKs[e] = 0.0;   // finite values under the tableau's zero coefficients
-  for (int e = lane; e < NS * NF; e += NT) {                      // the constant entries of F: dWsb/dbg = -I, dTsb/dVsb = I
-    const int i = (e % NF) % FR, j = (e % NF) / FR;
-    F9s[e] = (i < 3 && j == 9 + i) ? -1.0 : ((i >= 3 && i < 6 && j == 3 + i) ? 1.0 : 0.0);
+  if (lane < NF) {                                                // the constant entries of F: dWsb/dbg = -I, dTsb/dVsb = I
+    const int i = lane % FR, j = lane / FR;
+    F9[lane] = (i < 3 && j == 9 + i) ? -1.0 : ((i >= 3 && i < 6 && j == 3 + i) ? 1.0 : 0.0);
   }
   for (int e = lane; e < 144; e += NT) {
     const double q = a.Qimu[e];
@@ -1277,7 +1280,6 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
       const M3 w_nR = m3_neg(X0.Rsb);                             // Vsb <- ba, and G's Vsb <- accel-noise block
       if (wl == 0) {
         double* Jm = Jms + st * 36;
-        double* F9 = F9s + st * NF;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           sKs[3 * st + i] = X0.Vsb.v[i];
@@ -1285,10 +1287,6 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
           for (int j = 0; j < 3; ++j) {
             Jm[3 * i + j] = w_dW_dW.m[i][j]; Jm[9 + 3 * i + j] = w_dV_dW.m[i][j];
             Jm[18 + 3 * i + j] = w_nR.m[i][j]; Jm[27 + 3 * i + j] = w_dV_dWsg.m[i][j];
-            F9[i + FR * j] = w_dW_dW.m[i][j];                     // Wsb <- Wsb
-            F9[(6 + i) + FR * j] = w_dV_dW.m[i][j];               // Vsb <- Wsb
-            F9[(6 + i) + FR * (12 + j)] = w_nR.m[i][j];           // Vsb <- ba
-            if (j < 2) F9[(6 + i) + FR * (21 + j)] = w_dV_dWsg.m[i][j];   // Vsb <- Wsg
           }
         }
       }
@@ -1339,6 +1337,13 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
 #pragma unroll
         for (int q = 0; q < NS - 1; ++q) sf += aq[q] * FKs[q * NF + lane];
         S1[(lane % FR) + NM * (lane / FR)] = sf;
+      }
+      if (lane >= 64 && lane < 97) {                              // the stage's 33 state-dependent entries of F into its dense rows
+        const int l = lane - 64, blk = l < 27 ? l / 9 : 3, m = l - 9 * blk;
+        const int i = blk < 3 ? m / 3 : m / 2, j = blk < 3 ? m % 3 : m % 2;
+        // blocks: dW/dW -> rows 0..2, cols 0..2 ; dV/dW -> rows 6..8, cols 0..2 ; -Rsb -> rows 6..8, cols 12..14 ; dV/dWsg -> cols 21..22
+        const int row = blk == 0 ? i : 6 + i, col = blk < 2 ? j : (blk == 2 ? 12 + j : 21 + j);
+        F9[row + FR * col] = Jm[9 * blk + 3 * i + j];
       }
       if (lane >= 224 && lane < 236) {                            // (G Q)[Vsb_i, l] = sum_k -Rsb[i][k] Q[3 + k, l]
         const int l = lane - 224;
@@ -1401,7 +1406,7 @@ __global__ __launch_bounds__(256, 2) void propagate_state_kernel(PropStateArgs a
           }
           if (fk_task) {                                          // FK_st = F + F S h
 #pragma unroll
-            for (int i = 0; i < 3; ++i) FKs[st * NF + (3 * wave + i) + FR * j] = F9s[st * NF + (3 * wave + i) + FR * j] + o[i] * h;
+            for (int i = 0; i < 3; ++i) FKs[st * NF + (3 * wave + i) + FR * j] = F9[(3 * wave + i) + FR * j] + o[i] * h;
           } else {
 #pragma unroll
             for (int i = 0; i < 3; ++i) FPs[(3 * wave + i) + FR * j] = o[i];
@@ -1630,8 +1635,8 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
 template <int NS>
 static int launch_propagate_state_ns(const PropStateArgs& a, hipStream_t s) {
   // LDS: 4 matrices, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, stage velocities, per stage 36 Jacobian entries +
-  // F, FK (9 rows each) + PK: RK4 54 KB, Dormand-Prince 78 KB (2 workgroups per CU either way: 210 / 229 VGPRs)
-  const size_t lds = (size_t)(3 * 529 + 4 * 207 + 3 * 144 + 2 + 36 + 24 + NS * (36 + 2 * 207 + 529)) * sizeof(double);
+  // FK (9 rows) + PK: RK4 50 KB (3 workgroups per CU), Dormand-Prince 68 KB (2)
+  const size_t lds = (size_t)(3 * 529 + 5 * 207 + 3 * 144 + 2 + 36 + 24 + NS * (36 + 207 + 529)) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel<NS>),
