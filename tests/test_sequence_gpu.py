@@ -306,3 +306,21 @@ def test_vectorised_batch_run_tracks_ground_truth(built):
         assert st["updates"] >= 256 * 38
     finally:
         out["estimator"].close()
+
+
+@pytest.mark.parametrize("extra", [[], ["-host", "cpp"], ["-vectorized"], ["-integration_method", "RK4", "-as_coded_group_block"]])
+def test_run_pcw_cli(built, extra, tmp_path):
+    """scripts/run_pcw.py end to end (the three host sides, both integrators): one JSON report line, sane tracking error."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "scripts", "run_pcw.py"), "-sequences", "6", "-total_time", "0.6"] + extra
+    if "-vectorized" not in extra:
+        cmd += ["-dump", str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["sequences"] == 6 and rep["frames_per_sequence"] == 15 and rep["updates"] >= 6 * 13
+    assert rep["ate_m"]["max"] < 0.2
+    if "-vectorized" not in extra:
+        ts, T, W = formats.read_trajectory(str(tmp_path / "seq0003.txt"))
+        assert len(ts) == 15 and ts[1] == 40_000_000 and np.isfinite(T).all() and np.isfinite(W).all()
