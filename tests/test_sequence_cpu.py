@@ -173,3 +173,85 @@ def test_batch_simulators_equal_the_scalar_ones():
         off, bi, bm = bw.generate(np.stack([Rsc, Rsc]), np.stack([Tsc, Tsc]), K, 640, 480, 0.0)
         assert np.array_equal(bi[:off[1]], ids) and np.allclose(bm[:off[1]], m, atol=1e-12)
         assert off[2] - off[1] == len(ids)                     # the mirrored world sees the same points
+
+
+class _ShadowBackend:
+    """Backend double for the life-cycle fuzz test: applies the edit ops to a shadow copy of the resident slot state,
+    asserting each op is legal where it stands, and answers `update` with random gating outcomes."""
+
+    def __init__(self, cfg, B, seed):
+        self.cfg, self.B = cfg, B
+        self.rng = np.random.default_rng(seed)
+        self.sind = np.full((B, cfg.n_features), -1); self.ref = np.full((B, cfg.n_features), -1)
+        self.group_on = np.zeros((B, cfg.n_groups), dtype=bool)
+        self.xp_set = np.zeros((B, cfg.n_features), dtype=bool)
+        self.n_ops = 0
+
+    def propagate(self, imu):
+        assert imu.shape[0] == self.B and (imu["dt"] > 0).all()
+
+    def edit(self, ops):
+        from xivo_amd import lib as L
+        assert (np.diff(ops["b"]) >= 0).all() if len(ops) else True        # grouped by filter, as the C ABI requires
+        for o in ops:
+            b, k, i0, i1, i2 = int(o["b"]), int(o["kind"]), int(o["i0"]), int(o["i1"]), int(o["i2"])
+            self.n_ops += 1
+            if k == L.EDIT_ADD_GROUP:
+                assert not self.group_on[b, i0]; self.group_on[b, i0] = True
+            elif k == L.EDIT_REMOVE_GROUP:
+                assert self.group_on[b, i0] and not (self.ref[b][self.sind[b] >= 0] == i0).any()   # no feature left on it
+                self.group_on[b, i0] = False
+            elif k == L.EDIT_ADD_FEATURE:
+                assert self.sind[b, i0] < 0 and not (self.sind[b] == i1).any() and self.group_on[b, i2]
+                assert np.isfinite(o["v"]).all() and o["v"][5] > 0 and o["v"][13] > 0
+                self.sind[b, i0] = i1; self.ref[b, i0] = i2
+            elif k == L.EDIT_REMOVE_FEATURE:
+                assert self.sind[b, i0] >= 0
+                self.sind[b, i0] = -1; self.ref[b, i0] = -1
+            else:
+                raise AssertionError("unexpected op kind %d" % k)
+
+    def set_pixels(self, xp):
+        ok = ~np.isnan(xp).any(axis=2)
+        assert not (ok & (self.sind < 0)).any()            # pixels only for entries that are in the state
+        self.xp_set = ok
+
+    def update(self):
+        present = self.sind >= 0
+        assert (self.xp_set == present).all()              # every in-state feature got this frame's pixel
+        return present & (self.rng.uniform(size=present.shape) > 0.15)      # 15 % rejected by "gating"
+
+    def poses(self):
+        return np.repeat(np.eye(3)[None], self.B, axis=0), np.zeros((self.B, 3))
+
+
+def test_life_cycle_fuzz_against_a_shadow_of_the_resident_slots():
+    """Random track sets (tracks appear, vanish and come back, depths in and out of range) and random gating outcomes:
+    every op the runner emits is legal in the order it is emitted, the books equal the shadow state after every frame,
+    group slots are reclaimed, and the state is kept as full as the tracks allow."""
+    cfg = sequence.SequenceConfig(n_groups=4, n_features=9, min_new_features=2)
+    B = 5
+    be = _ShadowBackend(cfg, B, 7)
+    runner = sequence.SequenceRunner(be, cfg, B)
+    rng = np.random.default_rng(11)
+    pool = [np.arange(100 * b, 100 * b + 40) for b in range(B)]
+    full = 0
+    for frame in range(120):
+        tracks = []
+        for b in range(B):
+            ids = np.sort(rng.choice(pool[b], size=int(rng.integers(0, 25)), replace=False))
+            depth = rng.uniform(0.01, 14.0, size=len(ids))       # some outside [min_depth, max_depth]
+            tracks.append((ids, np.column_stack([rng.uniform(0, 640, len(ids)), rng.uniform(0, 480, len(ids)), depth])))
+        imu = np.zeros((B, 2), dtype=sequence.L.imu_dtype); imu["dt"] = 0.02
+        runner.frame(imu, tracks)
+        for b, bk in enumerate(runner.books):
+            held = {j for j in range(cfg.n_features) if bk.feat_id[j] >= 0}
+            assert held == set(np.nonzero(be.sind[b] >= 0)[0])
+            assert [bk.feat_ref[j] for j in sorted(held)] == list(be.ref[b][sorted(held)])
+            assert [r >= 0 for r in bk.group_refs] == list(be.group_on[b])
+            assert all(r != 0 for r in bk.group_refs)             # empty groups are discarded in the same frame
+            assert sum(r for r in bk.group_refs if r > 0) == len(held) == len(bk.id2slot)
+            ids_now = set(int(i) for i in tracks[b][0])
+            assert all(bk.feat_id[j] in ids_now for j in held)    # nothing in the state that the tracker dropped
+            full += len(held) == cfg.n_features
+    assert be.n_ops > 2000 and full > 20 and runner.n_rejected > 100
