@@ -324,3 +324,28 @@ def test_run_pcw_cli(built, extra, tmp_path):
     if "-vectorized" not in extra:
         ts, T, W = formats.read_trajectory(str(tmp_path / "seq0003.txt"))
         assert len(ts) == 15 and ts[1] == 40_000_000 and np.isfinite(T).all() and np.isfinite(W).all()
+
+
+def test_cpp_batch_estimator_equals_python_runner_under_rejections(built):
+    """Same comparison with a gate far tighter than the innovation statistics (chi-square threshold 0.02 instead of
+    5.991; with cfg/pcw.json's process noise the predicted uncertainty, ~11 px, dominates S and the distances of good
+    features are ~0.04): MH gating now rejects features every frame (they leave the state and are candidates again at
+    once) - the paths a well-tuned run never takes."""
+    B = 4
+    cfg = sequence.SequenceConfig(MH_thresh=0.02)
+    mk = lambda: ([pcw.RandomPCW(seed=60 + b) for b in range(B)],
+                  [pcw.TrajectorySim("trefoil" if b % 2 else "lissajous", seed=500 + b) for b in range(B)])
+    w1, s1 = mk()
+    py = sequence.run_pcw(sequence.HipBackend, cfg, w1, s1, total_time=1.0)
+    w2, s2 = mk()
+    cp = sequence.run_pcw_cpp(cfg, w2, s2, total_time=1.0)
+    try:
+        st = cp["estimator"].stats()
+        assert py["runner"].n_rejected > 50 and st["mh_rejected"] == py["runner"].n_rejected
+        for b in range(B):
+            fid, fref, gref = cp["estimator"].book(b)
+            bk = py["runner"].books[b]
+            assert list(fid) == bk.feat_id and list(fref) == bk.feat_ref and list(gref) == bk.group_refs
+        assert np.abs(py["Tsb"] - cp["Tsb"]).max() < 1e-9
+    finally:
+        py["backend"].close(); cp["estimator"].close()
