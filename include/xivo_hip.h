@@ -170,6 +170,16 @@ int xivo_hip_set_measurements(xivo_hip_ctx* ctx, int b0, int nb, int M,
                               const double* H, long strideH, int ldh,
                               const double* inn, long strideInn,
                               const double* diagR, long strideR);
+/* The same hand-over for measurements that are already in device memory (a device-side producer, or a caller that
+ * keeps its Eigen buffers in pinned / managed memory): dH is M x N column-major per filter (leading dimension ldh,
+ * filters strideH elements apart), dInn / dR have M entries. This is the per-frame device work of the S-level
+ * boundary - H_ changes with every camera frame (src/update.cpp:129-138): one batched launch builds the row-pair
+ * compressed rows (each element of H read once); padded dense copies are materialised only for filters whose rows
+ * do not fit the compressed form. The device buffers are read during the call only. */
+int xivo_hip_set_measurements_device(xivo_hip_ctx* ctx, int b0, int nb, int M,
+                                     const double* dH, long strideH, int ldh,
+                                     const double* dInn, long strideInn,
+                                     const double* dR, long strideR);
 /* Estimator::UpdateJosephForm (src/estimator.cpp:1257-1288) for filters [0,B):
  * S = HPH^T + R, K^T = S^-1 HP, dx = K inn, P <- (KH-I)P(KH-I)^T + K R K^T,
  * on the resident P with the staged measurements. Asynchronous on the

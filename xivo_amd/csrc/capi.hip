@@ -44,6 +44,7 @@ struct xivo_hip_ctx {
   int last_path = 0;
   // dense H / H^T of the stacked rows: written eagerly by set_measurements, lazily after xivo_hip_stack
   bool dense_valid = true;
+  bool dense_from_ell = false;   // the stacked rows came in through set_measurements (compressed rows are the source)
   double stack_R = 0.0; int stack_B = 0;
   size_t staging_elems = 0;
   long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0, sA = 0;   // sA: A buffer, max(N x N, N x M)
@@ -402,6 +403,37 @@ int xivo_hip_p_diag(xivo_hip_ctx* c, int b, double* out) {
 }
 
 // ------------------------------------------------------------------ S-level
+// Hand-over of dense measurements that already live in device memory (dH: M x N column-major per filter): ONE
+// launch builds the row-pair compressed rows of the whole range; the padded dense copies are written only for
+// the filters that do not fit it (they take the dense pipeline) and otherwise rebuilt from the compressed rows
+// on demand (ensure_dense).
+static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const double* dH, long strideH, int ldh,
+                              const double* dInn, long strideInn, const double* dR, long strideR) {
+  const int N = c->N;
+  MeasBuffers mb = meas_buffers(c);
+  mb.H += (long)b0 * mb.strideH; mb.HT += (long)b0 * mb.strideHT;
+  mb.inn += (long)b0 * mb.strideInn; mb.diagR += (long)b0 * mb.strideR;
+  c->M = M; c->Mp = round_up16(M);
+  EllBuffers e = c->ell;
+  e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.pw += b0; e.over += b0;
+  {
+    StageTimer st(c, ST_STACK, 0.0, "meas_compress_kernel", 8.0 * nb * ((double)M * N + 4.0 * M) + (double)nb * c->ell.pairs_max * ELL_W * 20.0);
+    // clear up to the allocated row count so stale rows of a previous, larger M vanish
+    if (launch_meas_compress(dH, strideH, ldh, dInn, strideInn, dR, strideR, M, N, c->Np, c->Mpmax, e, mb.inn, mb.strideInn,
+                             mb.diagR, mb.strideR, nb, c->stream))
+      return XIVO_HIP_ERR_HIP;
+  }
+  HIP_TRY(hipMemcpyAsync(c->ell_over_h.data() + b0, e.over, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->ell_nc_h.data() + b0, e.nc, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->ell_pw_h.data() + b0, e.pw, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  bool any_over = false;
+  for (int b = b0; b < b0 + nb && !any_over; ++b) any_over = c->ell_over_h[b] != 0;
+  if (any_over && launch_unpack_meas(dH, strideH, ldh, e.over, mb, M, c->Mpmax, N, c->Np, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  c->dense_valid = false; c->dense_from_ell = true;
+  return XIVO_HIP_OK;
+}
+
 int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const double* H, long strideH, int ldh,
                               const double* inn, long strideInn, const double* diagR, long strideR) {
   if (bad_range(c, b0, nb) || !H || !inn || !diagR || M <= 0 || M > c->Mmax || ldh < M) return XIVO_HIP_ERR_INVALID;
@@ -420,22 +452,18 @@ int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   if (rc) return rc;
   rc = h2d_packed(c, sR, diagR, nb, M, 1, strideR, M);
   if (rc) return rc;
-  MeasBuffers mb = meas_buffers(c);
-  mb.H += (long)b0 * mb.strideH; mb.HT += (long)b0 * mb.strideHT;
-  mb.inn += (long)b0 * mb.strideInn; mb.diagR += (long)b0 * mb.strideR;
-  c->M = M; c->Mp = round_up16(M); c->dense_valid = true;
-  // clear up to the allocated row count so stale rows of a previous, larger M vanish
-  if (launch_unpack_meas(sH, sInn, sR, mb, M, c->Mpmax, N, c->Np, nb, c->stream)) return XIVO_HIP_ERR_HIP;
-  {  // row-pair compressed form of the same rows + which filters fit it
-    EllBuffers e = c->ell;
-    e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.pw += b0; e.over += b0;
-    if (launch_ell_build(mb.HT, mb.strideHT, mb.ldht, c->Np, c->Mpmax, e, nb, c->stream)) return XIVO_HIP_ERR_HIP;
-    HIP_TRY(hipMemcpyAsync(c->ell_over_h.data() + b0, e.over, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->ell_nc_h.data() + b0, e.nc, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->ell_pw_h.data() + b0, e.pw, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  }
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  rc = stage_measurements(c, b0, nb, M, sH, (long)M * N, M, sInn, M, sR, M);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));   // host buffers are only borrowed for the call
   return XIVO_HIP_OK;
+}
+
+int xivo_hip_set_measurements_device(xivo_hip_ctx* c, int b0, int nb, int M, const double* dH, long strideH, int ldh,
+                                     const double* dInn, long strideInn, const double* dR, long strideR) {
+  if (bad_range(c, b0, nb) || !dH || !dInn || !dR || M <= 0 || M > c->Mmax || ldh < M || strideH < 0) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  return stage_measurements(c, b0, nb, M, dH, strideH, ldh, dInn, strideInn, dR, strideR);
 }
 
 // One pass of the update pipeline over filters [b0, b0 + B).
@@ -753,6 +781,8 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
   HIP_TRY(hipSetDevice(c->device));
   int rc = ensure_gate_buffers(c, F);
   if (rc) return rc;
+  rc = ensure_dense(c);
+  if (rc) return rc;
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
   {
     GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
@@ -879,6 +909,11 @@ static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense) {
 static int ensure_dense(xivo_hip_ctx* c) {
   if (c->dense_valid) return XIVO_HIP_OK;
   c->dense_valid = true;
+  if (c->dense_from_ell) {   // S-level hand-over: the compressed rows are the source (filters that do not fit hold dense rows already)
+    StageTimer st(c, ST_STACK, 0.0, "ell_to_dense_kernel");
+    return launch_ell_to_dense(c->ell, c->H, c->sH, c->Mpmax, c->HT, c->sHT, c->Np, c->Mpmax, c->Np, c->Bmax, c->stream)
+               ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+  }
   return stack_impl(c, c->stack_B, c->stack_R, 1);
 }
 
@@ -891,7 +926,7 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   }
   // the sparse-H pipeline reads only the compressed rows: skip the 2 x Mp x Np dense zero-fill + scatter
   const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
-  c->dense_valid = dense != 0; c->stack_R = R; c->stack_B = B;
+  c->dense_valid = dense != 0; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B;
   return stack_impl(c, B, R, dense);
 }
 

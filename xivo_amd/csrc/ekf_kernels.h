@@ -19,7 +19,7 @@ struct MeasBuffers {
   double* inn; long strideInn;
   double* diagR; long strideR;
 };
-int launch_unpack_meas(const double* rawH, const double* rawInn, const double* rawR, MeasBuffers mb,
+int launch_unpack_meas(const double* rawH, long strideRaw, int ldraw, const int* only_if, MeasBuffers mb,
                        int M, int Mp, int N, int Np, int batch, hipStream_t s);
 
 // P edits

@@ -45,29 +45,26 @@ __global__ void pack_P_kernel(const double* __restrict__ P, double* __restrict__
   raw[(long)f * N * N + e] = P[(long)f * strideP + i + (long)j * ldp];
 }
 
-__global__ void unpack_meas_kernel(const double* __restrict__ rawH, const double* __restrict__ rawInn,
-                                   const double* __restrict__ rawR, MeasBuffers mb, int M, int Mp, int N,
-                                   int Np) {
+// dense padded H / H^T of the filters that do NOT fit the row-pair compressed form (only_if[f] != 0; null: all)
+__global__ void unpack_meas_kernel(const double* __restrict__ rawH, long strideRaw, int ldraw,
+                                   const int* __restrict__ only_if, MeasBuffers mb, int M, int Mp, int N, int Np) {
   const int f = blockIdx.y;
+  if (only_if && !only_if[f]) return;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long tot = (long)Mp * Np;
   if (e < tot) {
     {  // H: m fastest
       const int m = (int)(e % Mp), n = (int)(e / Mp);
       double v = 0.0;
-      if (m < M && n < N) v = rawH[(long)f * M * N + m + (long)n * M];
+      if (m < M && n < N) v = rawH[(long)f * strideRaw + m + (long)n * ldraw];
       mb.H[(long)f * mb.strideH + m + (long)n * mb.ldh] = v;
     }
     {  // H^T: n fastest
       const int n = (int)(e % Np), m = (int)(e / Np);
       double v = 0.0;
-      if (m < M && n < N) v = rawH[(long)f * M * N + m + (long)n * M];
+      if (m < M && n < N) v = rawH[(long)f * strideRaw + m + (long)n * ldraw];
       mb.HT[(long)f * mb.strideHT + n + (long)m * mb.ldht] = v;
     }
-  }
-  if (e < Mp) {
-    mb.inn[(long)f * mb.strideInn + e] = e < M ? rawInn[(long)f * M + e] : 0.0;
-    mb.diagR[(long)f * mb.strideR + e] = e < M ? rawR[(long)f * M + e] : 1.0;
   }
 }
 
@@ -1551,10 +1548,10 @@ int launch_pack_P(const double* P, double* raw, int N, int ldp, long strideP, in
   hipLaunchKernelGGL(pack_P_kernel, grid, dim3(256), 0, s, P, raw, N, ldp, strideP);
   CHECK_LAUNCH();
 }
-int launch_unpack_meas(const double* rawH, const double* rawInn, const double* rawR, MeasBuffers mb, int M,
+int launch_unpack_meas(const double* rawH, long strideRaw, int ldraw, const int* only_if, MeasBuffers mb, int M,
                        int Mp, int N, int Np, int batch, hipStream_t s) {
   dim3 grid((unsigned)(((long)Mp * Np + 255) / 256), batch);
-  hipLaunchKernelGGL(unpack_meas_kernel, grid, dim3(256), 0, s, rawH, rawInn, rawR, mb, M, Mp, N, Np);
+  hipLaunchKernelGGL(unpack_meas_kernel, grid, dim3(256), 0, s, rawH, strideRaw, ldraw, only_if, mb, M, Mp, N, Np);
   CHECK_LAUNCH();
 }
 int launch_p_zero_rc(double* P, int ldp, int Np, int off, int len, hipStream_t s) {

@@ -33,9 +33,15 @@ struct EllBuffers {
   __host__ __device__ long stride_val() const { return (long)pairs_max * ELL_W * 2; }
 };
 
-// Build the ELL form from the dense transposed copy H^T [Np x Mp] (column n contiguous).
-int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, EllBuffers e, int batch,
-                     hipStream_t s);
+// Hand-over of a dense H [M x N, column-major, leading dimension ldh] resident in device memory: builds the
+// row-pair compressed form (+ nc / pw / over per filter) in one pass over the matrix, one launch for the batch,
+// and copies inn / diagR into the padded working vectors (rows [M, Mp_clear) neutral).
+int launch_meas_compress(const double* H, long strideH, int ldh, const double* inn, long strideInn,
+                         const double* diagR, long strideR, int M, int N, int Np, int Mp_clear, EllBuffers e,
+                         double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s);
+// dense padded H / H^T of the filters that fit the compressed form (over = 0), rebuilt from it
+int launch_ell_to_dense(EllBuffers e, double* H, long strideH, int ldh, double* HT, long strideHT, int ldht, int Mp,
+                        int Np, int batch, hipStream_t s);
 
 // out[x + ldo * m] = sum_slots val[m][slot] * Src[x + lds * idx[m][slot]]  (+ epilogue), x in [0, X)
 enum EllMode : int {

@@ -10,78 +10,160 @@ namespace xivo_hip {
 
 namespace {
 
-// ---------------------------------------------------------------- build from dense H^T
-// One workgroup per filter. Phase A: per state column, in how many row pairs it is non-zero.
-// Columns used by more than half of the non-empty pairs become the "common" slots (ascending, at most
-// ELL_CW). Phase B: one wave per pair compacts the remaining non-zero columns in ascending order.
-__global__ __launch_bounds__(256) void ell_build_kernel(const double* __restrict__ HTall, long strideHT, int ldht,
-                                                        int Np, int Mp, EllBuffers e) {
-  extern __shared__ int sh[];           // [Np] occupancy -> common slot + 1 ; then [pairs] non-empty flags
-  const int filt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pairs = Mp / 2;
-  int* occ = sh;
-  int* nonempty = sh + Np;
+// ---------------------------------------------------------------- hand-over of a dense H
+// Estimator::FilterUpdate hands UpdateJosephForm a dense H_ (M x N, column-major: src/update.cpp:129-138,
+// src/estimator.h:496). One workgroup per filter turns it into the row-pair compressed form in a single
+// pass over the matrix (each element leaves HBM once, 16-byte loads, lanes = row pairs so that a column
+// of H is one contiguous run across the workgroup):
+//   pass 1  thread p walks the columns n = 0..N-1 of its row pair (UNR loads in flight), appends the
+//           non-zero (n, H[2p][n], H[2p+1][n]) to its list in LDS and the wave counts, per column, the
+//           pairs that use it (ballot + popcount, one LDS row per wave - no atomics)
+//   common  columns used by more than half of the non-empty pairs become the "common" slots (ascending,
+//           at most ELL_CW) - one wave, ballot prefix sums
+//   pass 2  thread p walks its list (ascending n): common columns go to their slot, the rest are packed
+//           into the private slots; unused slots get (idx 0, value 0). Every thread writes one contiguous
+//           112-byte index row and one 448-byte value row (merged into full lines by the L2).
+// Rows [M, Mp_clear) are cleared (stale rows of a previous, larger M), inn / diagR copied with the
+// neutral padding (0 / 1).
+struct MeasCompressArgs {
+  const double* H; long strideH; int ldh;
+  const double* inn; long strideInn;
+  const double* diagR; long strideR;
+  int M, N, Np;
+  int pairs_clear;                       // Mp_clear / 2
+  EllBuffers ell;
+  double* inn_out; long strideInnOut;
+  double* R_out; long strideROut;
+  int list_ld;                           // pairs rounded up to a multiple of 4 (LDS list row length)
+};
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void meas_compress_kernel(MeasCompressArgs a) {
+  constexpr int UNR = 16;
+  extern __shared__ __attribute__((aligned(16))) double csh[];
+  // LDS: lst_v[ELL_W][list_ld] d2 | lst_n[ELL_W][list_ld] int | occw[nw][Np] int | cslot[Np] int
+  const int filt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int pairs = (a.M + 1) / 2;
+  d2* lst_v = reinterpret_cast<d2*>(csh);
+  int* lst_n = reinterpret_cast<int*>(lst_v + ELL_W * a.list_ld);
+  int* occw = lst_n + ELL_W * a.list_ld;
+  int* cslot = occw + nw * a.Np;
   __shared__ int ccols[ELL_CW];
-  __shared__ int s_nc, s_ne, s_pw;
-  const double* HT = HTall + (long)filt * strideHT;
-  for (int p = tid; p < pairs; p += 256) nonempty[p] = 0;
-  if (tid == 0) { e.over[filt] = 0; s_ne = 0; s_pw = 0; }
-  __syncthreads();
-  for (int n = tid; n < Np; n += 256) {
-    int c = 0;
-    for (int p = 0; p < pairs; ++p) {
-      const bool nz = HT[n + (long)(2 * p) * ldht] != 0.0 || HT[n + (long)(2 * p + 1) * ldht] != 0.0;
-      if (nz) { ++c; nonempty[p] = 1; }
+  __shared__ int s_nc, s_pw, s_ne[4];
+  const double* __restrict__ H = a.H + (long)filt * a.strideH;
+  if (tid == 0) { s_pw = 0; a.ell.over[filt] = 0; }
+  const bool mine = tid < pairs;
+  const bool second = 2 * tid + 1 < a.M;          // M odd: the last pair has one row only
+  const double* __restrict__ hp = H + (mine ? 2 * tid : 0);
+  int cnt = 0;
+  for (int n0 = 0; n0 < a.N; n0 += UNR) {
+    d2 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int n = n0 + u < a.N ? n0 + u : a.N - 1;
+      const double* q = hp + (long)n * a.ldh;
+      if (ALIGNED) v[u] = *reinterpret_cast<const d2*>(q);
+      else { v[u][0] = q[0]; v[u][1] = second ? q[1] : 0.0; }
     }
-    occ[n] = c;
+    int mycount = 0;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const bool in = mine && n0 + u < a.N;
+      if (!second) v[u][1] = 0.0;
+      const bool nz = in && (v[u][0] != 0.0 || v[u][1] != 0.0);
+      const int c = __popcll(__ballot(nz));
+      if (lane == u) mycount = c;
+      if (nz) {
+        if (cnt < ELL_W) { lst_v[cnt * a.list_ld + tid] = v[u]; lst_n[cnt * a.list_ld + tid] = n0 + u; }
+        ++cnt;
+      }
+    }
+    if (lane < UNR && n0 + lane < a.Np) occw[wave * a.Np + n0 + lane] = mycount;
+  }
+  for (int n = a.N + (UNR - a.N % UNR) % UNR + tid; n < a.Np; n += blockDim.x)   // pad columns never visited above
+    for (int w = 0; w < nw; ++w) occw[w * a.Np + n] = 0;
+  {
+    const int ne_w = __popcll(__ballot(cnt > 0));
+    if (lane == 0) s_ne[wave] = ne_w;
   }
   __syncthreads();
-  for (int p = tid; p < pairs; p += 256)
-    if (nonempty[p]) atomicAdd(&s_ne, 1);
-  __syncthreads();
-  if (tid == 0) {
-    int nc = 0;
-    const int ne = s_ne;
-    for (int n = 0; n < Np; ++n) {
-      const bool common = ne > 0 && 2 * occ[n] > ne && nc < ELL_CW;
-      if (common) ccols[nc] = n;
-      occ[n] = common ? ++nc : 0;        // slot + 1, 0 = private
+  if (wave == 0) {
+    int ne = 0;
+    for (int w = 0; w < nw; ++w) ne += s_ne[w];
+    int base = 0;
+    for (int n0 = 0; n0 < a.Np; n0 += 64) {
+      const int n = n0 + lane;
+      int occ = 0;
+      if (n < a.Np) for (int w = 0; w < nw; ++w) occ += occw[w * a.Np + n];
+      const bool flag = n < a.N && ne > 0 && 2 * occ > ne;
+      const unsigned long long m = __ballot(flag);
+      const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
+      const bool common = flag && rank < ELL_CW;
+      if (n < a.Np) cslot[n] = common ? rank + 1 : 0;
+      if (common) ccols[rank] = n;
+      base += __popcll(m);
     }
-    s_nc = nc;
-    e.nc[filt] = nc;
+    if (lane == 0) { const int nc = base < ELL_CW ? base : ELL_CW; s_nc = nc; a.ell.nc[filt] = nc; }
   }
   __syncthreads();
   const int nc = s_nc;
-  int* idx = e.idx + (long)filt * e.stride_idx();
-  double* val = e.val + (long)filt * e.stride_val();
-  for (int p = wave; p < pairs; p += 4) {
-    const double* h0 = HT + (long)(2 * p) * ldht;
-    const double* h1 = h0 + ldht;
-    int* pi = idx + (long)p * ELL_W;
-    double* pv = val + (long)p * ELL_W * 2;
-    if (lane < ELL_CW) {
-      const int k = lane < nc ? ccols[lane] : 0;
-      pi[lane] = k;
-      pv[2 * lane] = lane < nc ? h0[k] : 0.0;
-      pv[2 * lane + 1] = lane < nc ? h1[k] : 0.0;
-    }
+  if (tid < a.pairs_clear) {
+    int* pi = a.ell.idx + (long)filt * a.ell.stride_idx() + (long)tid * ELL_W;
+    d2* pv = reinterpret_cast<d2*>(a.ell.val + (long)filt * a.ell.stride_val()) + (long)tid * ELL_W;
+    unsigned cmask = 0;
     int pos = 0;
-    for (int n0 = 0; n0 < Np; n0 += 64) {
-      const int n = n0 + lane;
-      double a = 0.0, b = 0.0;
-      bool nz = false;
-      if (n < Np && occ[n] == 0) { a = h0[n]; b = h1[n]; nz = (a != 0.0) || (b != 0.0); }
-      const unsigned long long m = __ballot(nz);
-      const int my = pos + __popcll(m & ((1ull << lane) - 1ull));
-      if (nz && my < ELL_PW) { pi[ELL_CW + my] = n; pv[2 * (ELL_CW + my)] = a; pv[2 * (ELL_CW + my) + 1] = b; }
-      pos += __popcll(m);
+    const int walk = cnt < ELL_W ? cnt : ELL_W;
+    for (int k = 0; k < walk; ++k) {
+      const int n = lst_n[k * a.list_ld + tid];
+      const d2 v = lst_v[k * a.list_ld + tid];
+      const int cs = cslot[n];
+      if (cs) { pv[cs - 1] = v; cmask |= 1u << (cs - 1); }
+      else {
+        if (pos < ELL_PW) { pi[ELL_CW + pos] = n; pv[ELL_CW + pos] = v; }
+        ++pos;
+      }
     }
-    if (lane == 0) atomicMax(&s_pw, pos);
-    if (pos > ELL_PW) { if (lane == 0) e.over[filt] = 1; }
-    else if (lane >= pos && lane < ELL_PW) { pi[ELL_CW + lane] = 0; pv[2 * (ELL_CW + lane)] = 0.0; pv[2 * (ELL_CW + lane) + 1] = 0.0; }
+    if (cnt > ELL_W) pos = ELL_PW + 1;            // list overflow: more than 28 non-zero columns cannot fit
+#pragma unroll
+    for (int t = 0; t < ELL_CW; ++t) {
+      pi[t] = t < nc ? ccols[t] : 0;
+      if (!((cmask >> t) & 1u)) pv[t] = d2{0.0, 0.0};
+    }
+    for (int t = pos; t < ELL_PW; ++t) { pi[ELL_CW + t] = 0; pv[ELL_CW + t] = d2{0.0, 0.0}; }
+    if (pos > ELL_PW) a.ell.over[filt] = 1;
+    atomicMax(&s_pw, pos);
+  }
+  for (int m = tid; m < 2 * a.pairs_clear; m += blockDim.x) {
+    a.inn_out[(long)filt * a.strideInnOut + m] = m < a.M ? a.inn[(long)filt * a.strideInn + m] : 0.0;
+    a.R_out[(long)filt * a.strideROut + m] = m < a.M ? a.diagR[(long)filt * a.strideR + m] : 1.0;
   }
   __syncthreads();
-  if (tid == 0) e.pw[filt] = s_pw;
+  if (tid == 0) a.ell.pw[filt] = s_pw;
+}
+
+// Dense H / H^T (padded, both zero filled) of the filters whose rows fit the compressed form, rebuilt from it
+// on demand (dense pipeline, xivo_hip_get_H); filters with over = 1 already hold their dense rows.
+__global__ __launch_bounds__(256) void ell_to_dense_kernel(EllBuffers e, double* Hall, long strideH, int ldh,
+                                                           double* HTall, long strideHT, int ldht, int Mp, int Np) {
+  const int filt = blockIdx.x, tid = threadIdx.x;
+  if (e.over[filt]) return;
+  double* H = Hall + (long)filt * strideH;
+  double* HT = HTall + (long)filt * strideHT;
+  for (long i = tid; i < (long)Mp * Np; i += 256) {
+    H[(i % Mp) + (i / Mp) * ldh] = 0.0;
+    HT[(i % Np) + (i / Np) * ldht] = 0.0;
+  }
+  __syncthreads();
+  const int* idx = e.idx + (long)filt * e.stride_idx();
+  const double* val = e.val + (long)filt * e.stride_val();
+  for (int i = tid; i < (Mp / 2) * ELL_W; i += 256) {
+    const int p = i / ELL_W, n = idx[i];
+    const double v0 = val[2 * (long)i], v1 = val[2 * (long)i + 1];
+    if (v0 != 0.0 || v1 != 0.0) {     // unused slots name column 0 with value 0
+      H[2 * p + (long)n * ldh] = v0; H[2 * p + 1 + (long)n * ldh] = v1;
+      HT[n + (long)(2 * p) * ldht] = v0; HT[n + (long)(2 * p + 1) * ldht] = v1;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- out = H_ell (x) Src, gather form
@@ -429,11 +511,35 @@ __global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
 
 #define CHECK_LAUNCH() return (int)hipGetLastError()
 
-int launch_ell_build(const double* HT, long strideHT, int ldht, int Np, int Mp, EllBuffers e, int batch,
-                     hipStream_t s) {
+int launch_meas_compress(const double* H, long strideH, int ldh, const double* inn, long strideInn,
+                         const double* diagR, long strideR, int M, int N, int Np, int Mp_clear, EllBuffers e,
+                         double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s) {
   if (batch <= 0) return 0;
-  const size_t lds = (size_t)(Np + Mp / 2) * sizeof(int);
-  hipLaunchKernelGGL(ell_build_kernel, dim3(batch), dim3(256), lds, s, HT, strideHT, ldht, Np, Mp, e);
+  MeasCompressArgs a;
+  a.H = H; a.strideH = strideH; a.ldh = ldh; a.inn = inn; a.strideInn = strideInn; a.diagR = diagR; a.strideR = strideR;
+  a.M = M; a.N = N; a.Np = Np; a.pairs_clear = Mp_clear / 2; a.ell = e;
+  a.inn_out = inn_out; a.strideInnOut = strideInnOut; a.R_out = R_out; a.strideROut = strideROut;
+  const int nt = ((a.pairs_clear + 63) / 64) * 64;
+  if (nt > 256) return (int)hipErrorInvalidValue;
+  a.list_ld = (nt + 3) & ~3;
+  const size_t lds = (size_t)ELL_W * a.list_ld * (sizeof(d2) + sizeof(int)) + (size_t)(nt / 64 + 1) * Np * sizeof(int);
+  // 16-byte loads need an even leading dimension / stride and an aligned base
+  const bool aligned = (ldh % 2 == 0) && (strideH % 2 == 0) && ((reinterpret_cast<uintptr_t>(H) & 15u) == 0) && (M % 2 == 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&meas_compress_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&meas_compress_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (aligned) hipLaunchKernelGGL(meas_compress_kernel<true>, dim3(batch), dim3(nt), lds, s, a);
+  else hipLaunchKernelGGL(meas_compress_kernel<false>, dim3(batch), dim3(nt), lds, s, a);
+  CHECK_LAUNCH();
+}
+
+int launch_ell_to_dense(EllBuffers e, double* H, long strideH, int ldh, double* HT, long strideHT, int ldht, int Mp,
+                        int Np, int batch, hipStream_t s) {
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(ell_to_dense_kernel, dim3(batch), dim3(256), 0, s, e, H, strideH, ldh, HT, strideHT, ldht, Mp, Np);
   CHECK_LAUNCH();
 }
 

@@ -89,6 +89,8 @@ _SIGS = {
     "xivo_hip_p_diag": [C.c_void_p, C.c_int, C.c_void_p],
     "xivo_hip_set_measurements": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int,
                                   C.c_void_p, C.c_long, C.c_void_p, C.c_long],
+    "xivo_hip_set_measurements_device": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int,
+                                         C.c_void_p, C.c_long, C.c_void_p, C.c_long],
     "xivo_hip_update_joseph": [C.c_void_p, C.c_int],
     "xivo_hip_get_err": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long],
     "xivo_hip_get_status": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -255,6 +257,14 @@ class Context:
         dR = _f64(diagR)
         self._check(self.lib.xivo_hip_set_measurements(self.h, b0, nb, M, _ptr(Hc), M * N, M, _ptr(inn), M,
                                                        _ptr(dR), M))
+
+    def set_measurements_device(self, dH, dinn, dR, M, nb, b0=0, strideH=None, ldh=None):
+        """Hand-over of measurements that already live in device memory: dH / dinn / dR are device addresses
+        (ints, e.g. torch tensor .data_ptr()) of nb column-major M x N matrices and M-vectors."""
+        ldh = M if ldh is None else ldh
+        strideH = ldh * self.N if strideH is None else strideH
+        self._check(self.lib.xivo_hip_set_measurements_device(self.h, b0, nb, M, C.c_void_p(dH), strideH, ldh,
+                                                              C.c_void_p(dinn), M, C.c_void_p(dR), M))
 
     def update_joseph(self, B=None):
         self._check(self.lib.xivo_hip_update_joseph(self.h, self.batch if B is None else B))
