@@ -4,7 +4,13 @@
 One "step" = one measurement update of every filter in the batch (B independent
 filters per GPU; filters shard across GPUs with no collective - SURVEY.md 8e).
 Workload = BASELINE.json's metric point: state dim 250, 80 features (M = 160),
-fp64, XIVO row sparsity, inputs resident in HBM before the timed region.
+fp64, XIVO row sparsity, inputs resident in HBM before the timed region. Every
+step hands the dense H / inn / diagR of every filter over again (H changes with
+every camera frame, src/update.cpp:129-138): the dense -> row-pair compression is
+inside the timed step. `value` is the ALL-fp64 rate (XIVO_HIP_FLAG_FP64_CORR); the
+rate with the Joseph correction product on the fp32 MFMA is reported next to it.
+
+`python bench.py --gpus N` without a launcher spawns its N ranks itself.
 
 Prints ONE JSON line (rank 0). See DESIGN.md section "Measurement".
 """
@@ -99,6 +105,44 @@ def _cpu_worker(arg):
     return n, time.perf_counter() - t0
 
 
+def parity_check(ctx, step, B, uniq, F, P, H, inn, dR, gate, no_gating):
+    """Runs ONE step from the initial covariance and compares P+ / dx of 8 filters spread over the batch with the
+    oracle (numpy restatement of src/update.cpp:60-96 + src/estimator.cpp:1257-1288) on the same inputs.
+    Tolerances = BASELINE.json north_star: 1e-6 relative Frobenius on P, 1e-8 on dx."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import xivo_oracle as orc
+    R, th, mult, min_inl = gate
+    ctx.restore_P()
+    step()
+    picks = sorted({b for b in (0, 7, 8, B // 2 - 1, B // 2 + 3, B - 9, B - 8, B - 1) if 0 <= b < B})
+    worst_P = worst_dx = 0.0
+    mask_equal = True
+    for b in picks:
+        u = b % uniq
+        Pn = ctx.download_P(b0=b, nb=1)[0]
+        err = ctx.get_err(b0=b, nb=1)[0]
+        rows = np.ones(2 * F, dtype=bool)
+        if not no_gating and F > min_inl:
+            d = orc.mh_distances(H[u].reshape(F, 2, -1), P[u], inn[u].reshape(F, 2), R)
+            m = orc.mh_gate(d, th, mult, min_inl)[0]
+            rows = np.repeat(m, 2)
+        e_ref, P_ref, _ = orc.update_joseph(H[u][rows], P[u], inn[u][rows], dR[u][rows])
+        worst_P = max(worst_P, float(np.linalg.norm(Pn - P_ref) / np.linalg.norm(P_ref)))
+        worst_dx = max(worst_dx, float(np.linalg.norm(err - e_ref) / np.linalg.norm(e_ref)))
+    if not no_gating and F > min_inl:
+        gm, _ = ctx.get_gate(F, B)
+        for b in picks:
+            u = b % uniq
+            d = orc.mh_distances(H[u].reshape(F, 2, -1), P[u], inn[u].reshape(F, 2), R)
+            mask_equal = mask_equal and bool(np.array_equal(gm[b], orc.mh_gate(d, th, mult, min_inl)[0]))
+    ok = worst_P < 1e-6 and worst_dx < 1e-8 and mask_equal
+    out = {"ok": bool(ok), "filters": picks, "rel_fro_P_max": worst_P, "rel_dx_max": worst_dx,
+           "inlier_masks_equal": mask_equal, "tol": {"P": 1e-6, "dx": 1e-8}, "checker": "oracle/xivo_oracle.py"}
+    if not ok:
+        raise AssertionError(f"bench parity check failed: {out}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +168,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra XIVO_HIP_FLAG_* bits (A/B knobs)")
+    ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the second timed loop (fp32 correction product)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction path only, no device work (CPU-box test of --gpus N)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher (one rank per GPU, LOCAL_RANK -> hipSetDevice, gloo control plane)
+        from xivo_amd.shard import spawn_ranks
+        sys.exit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -138,8 +191,31 @@ def main():
         dist_mod.init_process_group(backend="gloo")
         dist = dist_mod
 
+    if args.dry_run:
+        # launcher / rendezvous / reductions only: every rank "processes" its filters in no time
+        from xivo_amd.shard import max_over_ranks, gather_over_ranks
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.001 * (1 + rank))
+        dt_rank = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        dt = max_over_ranks(dist, dt_rank)
+        per_rank = gather_over_ranks(dist, args.batch * args.steps / dt_rank)
+        if rank == 0:
+            print(json.dumps({"metric": "EKF updates/sec (state dim 250, 80 feats) @1 GPU; % MFMA roofline", "dry_run": True,
+                              "value": None, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                              "per_rank_updates_per_s": per_rank, "ranks_reporting": len(per_rank)}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     from xivo_amd import synth
-    from xivo_amd.lib import Context, FLAG_PROFILE, load_library
+    from xivo_amd.lib import Context, FLAG_PROFILE, FLAG_FP64_CORR, load_library
 
     # one rank per GPU; the modulo only matters when more ranks than GPUs are launched (smoke-testing the
     # N>1 path on a 1-GPU box) - on the 8-GPU node it is the identity
@@ -147,7 +223,8 @@ def main():
     device = local_rank % ndev
     N, F, B = args.state_dim, args.features, args.batch
     R_VIS, MH_THRESH, MH_MULT, MIN_INL = 2.25, 5.991, 1.1, 5   # cfg/tumvi_cam0.json / estimator.cpp:366-369
-    flags = (0 if args.no_profile else FLAG_PROFILE) | args.flags
+    base_flags = (0 if args.no_profile else FLAG_PROFILE) | args.flags
+    flags = base_flags | FLAG_FP64_CORR      # headline: every product in fp64
     uniq = min(B, 64)
     if args.level == "G":
         # layout-faithful scene (SURVEY 8d "G-level"): 8 groups, 60 in-state features -> N = 23 + 48 + 180 = 251
@@ -192,7 +269,16 @@ def main():
         for b0 in range(0, B, uniq):
             nb = min(uniq, B - b0)
             ctx.upload_P(P[:nb], b0=b0)
-            ctx.set_measurements(H[:nb], inn[:nb], dR[:nb], b0=b0)
+        # the stacked measurements of every filter, dense and column-major as Estimator::H_ / inn_ / diagR_ are
+        # (src/estimator.h:496-509), resident in HBM before the timed region (torch: device memory plumbing only)
+        import torch
+        tdev = torch.device(f"cuda:{device}")
+        reps = -(-B // uniq)
+        tile = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(tdev).repeat((reps,) + (1,) * (a.ndim - 1))[:B].contiguous()
+        dH, dinn, dRd = tile(np.transpose(H, (0, 2, 1))), tile(inn), tile(dR)
+        torch.cuda.synchronize(tdev)
+        hand_over = lambda: ctx.set_measurements_device(dH.data_ptr(), dinn.data_ptr(), dRd.data_ptr(), M, B)
+        hand_over()
     ctx.snapshot_P()
     oos_on = args.level == "G" and args.oos > 0
     if oos_on:
@@ -240,8 +326,10 @@ def main():
         elif args.level == "G":
             ctx.filter_update(R_VIS, MH_THRESH, MH_MULT, MIN_INL, not args.no_gating, B)
         elif args.no_gating:
+            hand_over()
             ctx.update_joseph(B)
         else:
+            hand_over()       # H changes every frame: the dense -> row-pair compression is part of the step
             ctx.update_dense_gated(F, R_VIS, MH_THRESH, MH_MULT, MIN_INL, B)
 
     def barrier():
@@ -250,23 +338,47 @@ def main():
             dist.barrier()
             ctx.sync()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.profile_reset()
-    t0 = time.perf_counter()
-    ctx.timer_begin()
-    for _ in range(args.steps):
-        step()
-    gpu_ms = ctx.timer_end()
-    barrier()
-    dt = time.perf_counter() - t0
-    from xivo_amd.shard import max_over_ranks
-    dt = max_over_ranks(dist, dt)
+    from xivo_amd.shard import max_over_ranks, gather_over_ranks
 
+    def timed(nwarm):
+        """W untimed steps, then exactly K steps between barrier + device sync on both sides."""
+        for _ in range(nwarm):
+            step()
+        barrier()
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        ctx.timer_begin()
+        for _ in range(args.steps):
+            step()
+        gpu_ms_ = ctx.timer_end()
+        barrier()
+        dt_rank_ = time.perf_counter() - t0
+        return dt_rank_, gpu_ms_, (ctx.profile_get() if (flags & FLAG_PROFILE) else {})
+
+    # ---- headline: every product of the update in fp64 (XIVO_HIP_FLAG_FP64_CORR)
+    dt_rank, gpu_ms, prof = timed(args.warmup)
+    dt = max_over_ranks(dist, dt_rank)
+    per_rank = gather_over_ranks(dist, B * args.steps / dt_rank)
     status = ctx.get_status(check=False)
     sparse_path = ctx.last_path() == 1
-    prof = ctx.profile_get() if (flags & FLAG_PROFILE) else {}
+
+    # ---- second figure: default library mode - the Joseph correction product G K^T on the fp32 MFMA
+    mixed = None
+    if not args.no_mixed and sparse_path and not (args.flags & FLAG_FP64_CORR):
+        ctx.set_flags(base_flags)
+        ctx.restore_P()
+        dt_m, gpu_ms_m, prof_m = timed(min(args.warmup, 2))
+        dt_m = max_over_ranks(dist, dt_m)
+        mixed = {"value": world * B * args.steps / dt_m, "ms_per_step": dt_m / args.steps * 1e3,
+                 "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof_m.items() if v["launches"]}}
+        ctx.set_flags(flags)
+
+    # ---- parity at the benchmarked batch: one step from the initial P, filters spread over the launch
+    # (first / last, both sides of an XCD group of 8, mid batch) against the oracle - checker only, outside the timing
+    parity = None
+    if args.level == "S" and not args.no_parity_check and rank == 0:
+        parity = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating)
+
     peak_meas = ctx.bench_mfma_peak() if rank == 0 else None
 
     if rank == 0:
@@ -350,8 +462,20 @@ def main():
                        "filters_per_gpu": B, "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
                        "pipeline": "sparse-H (row-pair compressed H, re-associated Joseph form)" if sparse_path
                                    else "dense as-coded",
+                       "hand_over": ("dense H/inn/diagR (column-major, resident in HBM) -> row-pair compressed rows, "
+                                     "every step, inside the timed region (stage stack_H)") if args.level == "S" else
+                                    "Jacobians -> compressed rows on device every step",
+                       "precision": {"value": "all fp64: storage, every product, factorisation, solve (XIVO_HIP_FLAG_FP64_CORR)",
+                                     "value_mixed": "library default: identical, except the Joseph correction product G K^T "
+                                                    "(G = T H^T + K R = O(eps cond(S)) residual) on v_mfma_f32_16x16x4_f32; "
+                                                    "G itself and -T stay fp64"},
                        "gpu_event_ms_per_step": gpu_ms / args.steps,
                        "not_spd_filters": int((status != 0).sum())},
+            "value_mixed": mixed["value"] if mixed else None,
+            "mixed": mixed,
+            "per_rank_updates_per_s": per_rank,
+            "per_rank_min_max": [min(per_rank), max(per_rank)],
+            "parity_check": parity,
             "roofline": roofline,
             "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
         }

@@ -27,7 +27,12 @@ def main():
     ap.add_argument("-vectorized", action="store_true",
                     help="thousands of sequences: vectorised simulators + the C++ host side (xivo_amd.sequence.run_pcw_batch)")
     ap.add_argument("-dump", default="", help="directory for per-sequence `ts Tsb Wsb` trajectories")
+    ap.add_argument("-gpus", type=int, default=1,
+                    help="BASELINE config 5 without a launcher: spawn this many ranks (one per GPU), sequence s on rank s mod gpus")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from xivo_amd.shard import spawn_ranks
+        sys.exit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], a.gpus))
     if a.vectorized:
         cfg = sequence.SequenceConfig(integration_method=a.integration_method, fix_group_block=not a.as_coded_group_block)
         tm = {}

@@ -96,3 +96,25 @@ def test_sequences_shard_over_ranks_without_data_exchange():
                            [pcw.TrajectorySim(seed=50 + s) for s in range(3)], total_time=0.12)
     for s in range(3):
         assert np.array_equal(np.array(merged[s]), one["Tsb"][:, s])
+
+
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* on 127.0.0.1), they rendezvous over gloo, rank 0 prints one JSON line with n_gpus = 2 and one
+    rate per rank. --dry-run = the launcher / barrier / reduction path without device work (no GPU on this box)."""
+    import json
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["dry_run"] is True
+    assert len(out["per_rank_updates_per_s"]) == 2
+    # the job time is the slower rank's (rank 1 sleeps twice as long per step in the dry path)
+    assert out["ms_per_step"] >= 2.0
