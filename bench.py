@@ -270,14 +270,10 @@ def main():
             nb = min(uniq, B - b0)
             ctx.upload_P(P[:nb], b0=b0)
         # the stacked measurements of every filter, dense and column-major as Estimator::H_ / inn_ / diagR_ are
-        # (src/estimator.h:496-509), resident in HBM before the timed region (torch: device memory plumbing only)
-        import torch
-        tdev = torch.device(f"cuda:{device}")
-        reps = -(-B // uniq)
-        tile = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(tdev).repeat((reps,) + (1,) * (a.ndim - 1))[:B].contiguous()
-        dH, dinn, dRd = tile(np.transpose(H, (0, 2, 1))), tile(inn), tile(dR)
-        torch.cuda.synchronize(tdev)
-        hand_over = lambda: ctx.set_measurements_device(dH.data_ptr(), dinn.data_ptr(), dRd.data_ptr(), M, B)
+        # (src/estimator.h:496-509), resident in HBM before the timed region
+        dH = ctx.device_array(np.transpose(H, (0, 2, 1)), total=B)
+        dinn, dRd = ctx.device_array(inn, total=B), ctx.device_array(dR, total=B)
+        hand_over = lambda: ctx.set_measurements_device(dH, dinn, dRd, M, B)
         hand_over()
     ctx.snapshot_P()
     oos_on = args.level == "G" and args.oos > 0

@@ -355,6 +355,11 @@ int xivo_hip_propagate_cov(xivo_hip_ctx* ctx, int b0, int nb, int nm, const doub
                            const double* Pmm_new);
 
 /* ---- measurement helpers (bench.py / tests only) ----------------------- */
+/* device buffers on the context's GPU for inputs that are "already resident" (what xivo_hip_set_measurements_device is
+ * handed): allocate, upload `bytes` from the host and replicate that block until `total_bytes` are filled, free. */
+int xivo_hip_dev_alloc(xivo_hip_ctx* ctx, size_t bytes, void** out);
+int xivo_hip_dev_free(xivo_hip_ctx* ctx, void* p);
+int xivo_hip_dev_upload(xivo_hip_ctx* ctx, void* dst, const void* src, size_t bytes, size_t total_bytes);
 int xivo_hip_timer_begin(xivo_hip_ctx* ctx);
 int xivo_hip_timer_end(xivo_hip_ctx* ctx, float* ms_out);
 /* per-stage accumulated GPU time (ms) and launch counts since the last reset;

@@ -12,9 +12,8 @@ from xivo_amd.lib import Context
 pytestmark = pytest.mark.gpu
 
 
-def _dev(arrs):
-    import torch
-    return [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in arrs]
+def _dev(ctx, arrs):
+    return [ctx.device_array(a) for a in arrs]
 
 
 @pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (64, 8), (203, 30)])
@@ -22,13 +21,13 @@ def test_device_entry_equals_host_entry(built, N, F):
     B, M = 6, 2 * F
     P, H, inn, dR = synth.s_level(N, F, B, seed=5 * N + F)
     Hc = np.ascontiguousarray(np.transpose(H, (0, 2, 1)))       # column-major M x N per filter
-    dH, dinn, dRd = _dev([Hc, inn, dR])
     outs = []
     for dev in (False, True):
         with Context(N, M, B) as ctx:
             ctx.upload_P(P)
             if dev:
-                ctx.set_measurements_device(dH.data_ptr(), dinn.data_ptr(), dRd.data_ptr(), M, B)
+                dH, dinn, dRd = _dev(ctx, [Hc, inn, dR])
+                ctx.set_measurements_device(dH, dinn, dRd, M, B)
             else:
                 ctx.set_measurements(H, inn, dR)
             ctx.update_joseph()
@@ -43,7 +42,6 @@ def test_device_entry_equals_host_entry(built, N, F):
 def test_device_entry_strided_and_repeated(built):
     """leading dimension > M, filters further apart than one matrix, hand-over repeated with new rows (stale rows of
     a larger M must vanish)."""
-    import torch
     N, B = 100, 4
     with Context(N, 40, B) as ctx:
         for F in (20, 7):
@@ -51,10 +49,9 @@ def test_device_entry_strided_and_repeated(built):
             P, H, inn, dR = synth.s_level(N, F, B, seed=F)
             buf = np.full((B, N + 3, ldh), 7.0)
             buf[:, :N, :M] = np.transpose(H, (0, 2, 1))
-            dH = torch.from_numpy(buf).to("cuda:0")
-            dinn, dRd = _dev([inn, dR])
+            dH, dinn, dRd = _dev(ctx, [buf, inn, dR])
             ctx.upload_P(P)
-            ctx.set_measurements_device(dH.data_ptr(), dinn.data_ptr(), dRd.data_ptr(), M, B, strideH=(N + 3) * ldh, ldh=ldh)
+            ctx.set_measurements_device(dH, dinn, dRd, M, B, strideH=(N + 3) * ldh, ldh=ldh)
             ctx.update_joseph()
             Pn, err = ctx.download_P(), ctx.get_err()
             for b in range(B):
@@ -118,18 +115,19 @@ def test_gated_update_after_device_handover_is_repeatable(built):
     P, H, inn, dR = synth.s_level(N, F, B, seed=9)
     inn[:, :6] *= 40.0            # a few certain outliers
     Hc = np.ascontiguousarray(np.transpose(H, (0, 2, 1)))
-    dH, dinn, dRd = _dev([Hc, inn, dR])
     res = []
     with Context(N, M, B) as ctx:
+        dH, dinn, dRd = _dev(ctx, [Hc, inn, dR])
         for _ in range(2):
             ctx.upload_P(P)
-            ctx.set_measurements_device(dH.data_ptr(), dinn.data_ptr(), dRd.data_ptr(), M, B)
+            ctx.set_measurements_device(dH, dinn, dRd, M, B)
             ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5)
             mask, _ = ctx.get_gate(F)
             res.append((ctx.download_P(), ctx.get_err(), mask))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][2], res[1][2])
-    assert not res[0][2][:, :3].any()
     for b in range(B):
+        d = orc.mh_distances(H[b].reshape(F, 2, -1), P[b], inn[b].reshape(F, 2), 2.25)
+        assert np.array_equal(res[0][2][b], orc.mh_gate(d, 5.991, 1.1, 5)[0]) and not res[0][2][b].all()
         keep = np.repeat(res[0][2][b], 2)
         e_ref, P_ref, _ = orc.update_joseph(H[b][keep], P[b], inn[b][keep], dR[b][keep])
         assert rel_fro(res[0][0][b], P_ref) < TOL_P and rel_fro(res[0][1][b], e_ref) < TOL_DX

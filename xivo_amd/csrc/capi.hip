@@ -3,6 +3,7 @@
 // sequences the kernels of gemm_f64.hip / chol_trsm.hip / ekf_kernels.hip on one
 // HIP stream, never throws and never aborts.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
@@ -83,10 +84,15 @@ struct xivo_hip_ctx {
 
 namespace {
 
+// XIVO_HIP_DEBUG=1: name the failing runtime call on stderr (the C ABI itself only returns a status)
+static bool debug_on() { static const bool on = getenv("XIVO_HIP_DEBUG") != nullptr; return on; }
 #define HIP_TRY(expr)                              \
   do {                                             \
     hipError_t e_ = (expr);                        \
-    if (e_ != hipSuccess) return XIVO_HIP_ERR_HIP; \
+    if (e_ != hipSuccess) {                        \
+      if (debug_on()) fprintf(stderr, "xivo_hip: %s -> %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return XIVO_HIP_ERR_HIP;                     \
+    }                                              \
   } while (0)
 
 template <class T>
@@ -419,9 +425,8 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   {
     StageTimer st(c, ST_STACK, 0.0, "meas_compress_kernel", 8.0 * nb * ((double)M * N + 4.0 * M) + (double)nb * c->ell.pairs_max * ELL_W * 20.0);
     // clear up to the allocated row count so stale rows of a previous, larger M vanish
-    if (launch_meas_compress(dH, strideH, ldh, dInn, strideInn, dR, strideR, M, N, c->Np, c->Mpmax, e, mb.inn, mb.strideInn,
-                             mb.diagR, mb.strideR, nb, c->stream))
-      return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_meas_compress(dH, strideH, ldh, dInn, strideInn, dR, strideR, M, N, c->Np, c->Mpmax, e, mb.inn,
+                                             mb.strideInn, mb.diagR, mb.strideR, nb, c->stream));
   }
   HIP_TRY(hipMemcpyAsync(c->ell_over_h.data() + b0, e.over, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(c->ell_nc_h.data() + b0, e.nc, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -429,7 +434,8 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   HIP_TRY(hipStreamSynchronize(c->stream));
   bool any_over = false;
   for (int b = b0; b < b0 + nb && !any_over; ++b) any_over = c->ell_over_h[b] != 0;
-  if (any_over && launch_unpack_meas(dH, strideH, ldh, e.over, mb, M, c->Mpmax, N, c->Np, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  if (debug_on()) fprintf(stderr, "xivo_hip: hand-over b0=%d nb=%d M=%d any_over=%d nc0=%d pw0=%d\n", b0, nb, M, (int)any_over, c->ell_nc_h[b0], c->ell_pw_h[b0]);
+  if (any_over) HIP_TRY((hipError_t)launch_unpack_meas(dH, strideH, ldh, e.over, mb, M, c->Mpmax, N, c->Np, nb, c->stream));
   c->dense_valid = false; c->dense_from_ell = true;
   return XIVO_HIP_OK;
 }
@@ -1213,6 +1219,36 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
     if (launch_propagate_cov(c->P, c->sP, c->Np, c->N, c->Np, 23, dPhi, dPmm, b0, nb, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));   // imu / opts are borrowed host memory
+  return XIVO_HIP_OK;
+}
+
+// ------------------------------------------------------------------ device buffers for resident inputs (bench / tests)
+int xivo_hip_dev_alloc(xivo_hip_ctx* c, size_t bytes, void** out) {
+  if (!c || !out || bytes == 0) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  *out = nullptr;
+  return hipMalloc(out, bytes) == hipSuccess ? XIVO_HIP_OK : XIVO_HIP_ERR_NOMEM;
+}
+
+int xivo_hip_dev_free(xivo_hip_ctx* c, void* p) {
+  if (!c) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (p) HIP_TRY(hipFree(p));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_dev_upload(xivo_hip_ctx* c, void* dst, const void* src, size_t bytes, size_t total_bytes) {
+  if (!c || !dst || !src || bytes == 0 || total_bytes < bytes) return XIVO_HIP_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  // replicate the uploaded block over the rest of the buffer (doubling device-to-device copies)
+  for (size_t have = bytes; have < total_bytes;) {
+    const size_t n = have < total_bytes - have ? have : total_bytes - have;
+    HIP_TRY(hipMemcpyAsync((char*)dst + have, dst, n, hipMemcpyDeviceToDevice, c->stream));
+    have += n;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return XIVO_HIP_OK;
 }
 

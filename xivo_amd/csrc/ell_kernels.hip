@@ -526,11 +526,14 @@ int launch_meas_compress(const double* H, long strideH, int ldh, const double* i
   // 16-byte loads need an even leading dimension / stride and an aligned base
   const bool aligned = (ldh % 2 == 0) && (strideH % 2 == 0) && ((reinterpret_cast<uintptr_t>(H) & 15u) == 0) && (M % 2 == 0);
   static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&meas_compress_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&meas_compress_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (!attr_set) {   // dynamic + the kernel's 96 bytes of static LDS must fit the 160 KiB of a CU
+    const int cap = 160 * 1024 - 256;
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&meas_compress_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&meas_compress_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
     attr_set = true;
   }
+  if (lds > (size_t)(160 * 1024 - 256)) return (int)hipErrorInvalidValue;
   if (aligned) hipLaunchKernelGGL(meas_compress_kernel<true>, dim3(batch), dim3(nt), lds, s, a);
   else hipLaunchKernelGGL(meas_compress_kernel<false>, dim3(batch), dim3(nt), lds, s, a);
   CHECK_LAUNCH();

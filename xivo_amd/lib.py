@@ -121,6 +121,9 @@ _SIGS = {
     "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_get_H": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "xivo_hip_propagate_cov": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "xivo_hip_dev_alloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
+    "xivo_hip_dev_free": [C.c_void_p, C.c_void_p],
+    "xivo_hip_dev_upload": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t],
     "xivo_hip_timer_begin": [C.c_void_p],
     "xivo_hip_timer_end": [C.c_void_p, C.POINTER(C.c_float)],
     "xivo_hip_profile_reset": [C.c_void_p],
@@ -191,6 +194,9 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for p in getattr(self, "_dev_bufs", []):
+                self.lib.xivo_hip_dev_free(self.h, p)
+            self._dev_bufs = []
             self.lib.xivo_hip_destroy(self.h)
             self.h = None
 
@@ -265,6 +271,19 @@ class Context:
         strideH = ldh * self.N if strideH is None else strideH
         self._check(self.lib.xivo_hip_set_measurements_device(self.h, b0, nb, M, C.c_void_p(dH), strideH, ldh,
                                                               C.c_void_p(dinn), M, C.c_void_p(dR), M))
+
+    def device_array(self, a, total=None):
+        """Device copy of the numpy array `a` on this context's GPU (bench / tests: inputs that are already resident);
+        total = number of leading-axis entries the buffer holds, `a` is repeated to fill it. Returns the address."""
+        a = np.ascontiguousarray(a)
+        total = a.shape[0] if total is None else total
+        per = a.nbytes // a.shape[0]
+        p = C.c_void_p()
+        self._check(self.lib.xivo_hip_dev_alloc(self.h, per * total, C.byref(p)))
+        self._dev_bufs = getattr(self, "_dev_bufs", []) + [p]
+        n0 = min(a.shape[0], total)
+        self._check(self.lib.xivo_hip_dev_upload(self.h, p, _ptr(a), per * n0, per * total))
+        return p.value
 
     def update_joseph(self, B=None):
         self._check(self.lib.xivo_hip_update_joseph(self.h, self.batch if B is None else B))
