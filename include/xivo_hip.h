@@ -24,6 +24,8 @@
 #ifndef XIVO_HIP_H_
 #define XIVO_HIP_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif

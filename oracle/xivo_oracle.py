@@ -634,11 +634,53 @@ def propagate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, Qmodel, g_
 # ----------------------------------------------------------------------------
 # a15: Estimator::AbsorbError (src/estimator.cpp:875-921) with State::operator+=
 # (src/core.h:135-165), SO3xR3::operator+= (src/group.h:25-29), Feature::UpdateState
-# (src/feature.h:220). The periodic SO3 re-normalisation (kEnforceSO3Freq) is a
-# no-op to rounding on orthonormal inputs and is omitted.
+# (src/feature.h:220). Every kEnforceSO3Freq = 50 calls (State::counter, core.h:120-122,154-162) Rsb and Rbc are
+# re-normalised (Sophus SO3::normalize: unit quaternion) and Rsg <- exp(log(Rsg) with z zeroed).
 # ----------------------------------------------------------------------------
+ENFORCE_SO3_FREQ = 50
+
+
+def rot_to_quat(R):
+    """(w, x, y, z) of a rotation matrix (Shepperd), normalised."""
+    t = np.trace(R)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = math.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s]
+    elif R[1, 1] > R[2, 2]:
+        s = math.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s]
+    else:
+        s = math.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s]
+    q = np.array(q)
+    return q / np.linalg.norm(q)
+
+
+def quat_to_rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def so3_log_quat(q):
+    """Sophus SO3::logAndTheta on the unit quaternion (thirdparty/sophus/sophus/so3.hpp)."""
+    w, v = q[0], np.asarray(q[1:])
+    n2 = float(v @ v)
+    if n2 < 1e-20:
+        k = 2.0 / w - 2.0 / 3.0 * n2 / (w ** 3)
+    else:
+        n = math.sqrt(n2)
+        k = (math.pi / n if w > 0 else -math.pi / n) if abs(w) < 1e-10 else 2.0 * math.atan(n / w) / n
+    return k * v
+
+
 def absorb_error(st, err, layout, upd_groups, upd_feats):
-    """st: dict with Rsb,Tsb,Vsb,bg,ba,Rbc,Tbc,Rsg, gR [G,3,3], gT [G,3], x [F,3], sind [F] (modified in place)."""
+    """st: dict with Rsb,Tsb,Vsb,bg,ba,Rbc,Tbc,Rsg, gR [G,3,3], gT [G,3], x [F,3], sind [F] (modified in place);
+    st["counter"] (created at 0) is State::counter."""
     st["Rsb"] = st["Rsb"] @ so3_exp(err[WSB:WSB + 3])
     st["Tsb"] = st["Tsb"] + err[TSB:TSB + 3]
     st["Vsb"] = st["Vsb"] + err[VSB:VSB + 3]
@@ -647,6 +689,12 @@ def absorb_error(st, err, layout, upd_groups, upd_feats):
     st["Rbc"] = st["Rbc"] @ so3_exp(err[WBC:WBC + 3])
     st["Tbc"] = st["Tbc"] + err[TBC:TBC + 3]
     st["Rsg"] = st["Rsg"] @ so3_exp(np.array([err[WSG], err[WSG + 1], 0.0]))
+    st["counter"] = st.get("counter", 0) + 1                       # core.h:154-162
+    if st["counter"] % ENFORCE_SO3_FREQ == 0:
+        st["Rsb"] = quat_to_rot(rot_to_quat(st["Rsb"]))
+        st["Rbc"] = quat_to_rot(rot_to_quat(st["Rbc"]))
+        w = so3_log_quat(rot_to_quat(st["Rsg"]))
+        st["Rsg"] = so3_exp(np.array([w[0], w[1], 0.0]))
     for g in upd_groups:                                           # estimator.cpp:897-905
         off = layout.group_begin + 6 * g
         st["gR"][g] = st["gR"][g] @ so3_exp(err[off:off + 3])

@@ -240,10 +240,12 @@ def test_config3_full_size_instate_plus_oos(built):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
 
 
-def test_resident_frames_with_device_absorb_error(built):
-    """three frames of (Jacobians -> MHGating -> stack -> UpdateJosephForm -> AbsorbError)
+@pytest.mark.parametrize("nframes", [3, 52])
+def test_resident_frames_with_device_absorb_error(built, nframes):
+    """frames of (Jacobians -> MHGating -> stack -> UpdateJosephForm -> AbsorbError)
     with P, dx and the nominal state (pose, groups, features) never leaving the device; only new pixel
-    measurements are fed in. Oracle: the same loop on the host (estimator.cpp:875-921 for the retraction)."""
+    measurements are fed in. Oracle: the same loop on the host (estimator.cpp:875-921 for the retraction).
+    52 frames cross State::counter % 50 == 0: the periodic SO3 re-normalisation / Rsg projection of core.h:154-162."""
     cam = synth.RADTAN
     B, ng, nf = 3, 5, 14
     sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, nf, B, 9, cam)
@@ -255,7 +257,7 @@ def test_resident_frames_with_device_absorb_error(built):
         poses[b]["Rsg"] = extra["Rsg"][b].T.reshape(-1)
     feats["xp"][1, 5] += 60.0; xp[1, 5] += 60.0      # one outlier, rejected in every frame
     P0 = np.array([spd(lay.N, 70 + b) * 1e-4 for b in range(B)])
-    frames = [xp, xp + rng.normal(size=xp.shape) * 0.7, xp + rng.normal(size=xp.shape) * 0.7]
+    frames = [xp] + [xp + rng.normal(size=xp.shape) * 0.7 for _ in range(nframes - 1)]
     with ctx:
         ctx.upload_P(P0); ctx.set_scene(poses, groups, feats)
         masks = []

@@ -1,5 +1,7 @@
 """Host side of the image-free sequence driver: the point-cloud world / IMU simulator, the IMU message
 bookkeeping, the csv / trajectory formats, and the runner's life-cycle decisions against the oracle backend. No GPU."""
+import os
+
 import numpy as np
 
 import xivo_oracle as orc
@@ -126,7 +128,9 @@ def test_sequence_runner_tracks_ground_truth_with_the_oracle_backend():
                 assert (d > 0) == (j in held)
             assert np.allclose(P, P.T, atol=1e-9) and np.linalg.eigvalsh(P).min() > -1e-9
     assert max(res[True]) < 0.08, res
-    assert min(res[False]) > 3 * max(res[True]), res
+    # (with the reference's initial covariance - cfg "P" are standard deviations, src/estimator.cpp:304 - the as-coded
+    #  stacking is only moderately worse over 1.6 s; with a 1000x looser prior it used to lose the track)
+    assert np.mean(res[False]) > np.mean(res[True]), res
 
 
 def test_reference_cfg_schema_is_read(tmp_path):
@@ -140,7 +144,9 @@ def test_reference_cfg_schema_is_read(tmp_path):
     assert c.cam["model"] == 0 and c.cam["fx"] == 275.0 and c.cam["cols"] == 640
     assert np.allclose(c.Wbc, [-1.57079633, 0, 0]) and np.allclose(c.gravity, [0, 0, -9.8])
     P = c.P_init()
-    assert P.shape == (203, 203) and P[0, 0] == 0.001 and P[6, 6] == 0.5 and P[9, 9] == 1e-10 and P[23:, 23:].max() == 0
+    # cfg "P" holds standard deviations: the matrix is squared (src/estimator.cpp:304); free slots keep the unit diagonal
+    assert P.shape == (203, 203) and P[0, 0] == 1e-3 * 1e-3 and P[6, 6] == 0.25 and P[9, 9] == 1e-10 * 1e-10
+    assert np.array_equal(P[23:, 23:], np.eye(180))
     Qm = c.Qmodel_matrix()
     assert Qm[0, 0] == 1e-4 and Qm[6, 6] == 0.0            # only Wsb / Wbc / Wsg are read, then squared
     assert np.allclose(np.diag(c.Qimu_matrix()), np.repeat([25e-6, 25e-4, 0, 0], 3))
@@ -255,3 +261,79 @@ def test_life_cycle_fuzz_against_a_shadow_of_the_resident_slots():
             assert all(bk.feat_id[j] in ids_now for j in held)    # nothing in the state that the tracker dropped
             full += len(held) == cfg.n_features
     assert be.n_ops > 2000 and full > 20 and runner.n_rejected > 100
+
+
+# ---------------------------------------------------------------- cfg semantics pinned against the reference's loader
+def test_P_init_matches_reference_cfg_loading():
+    """src/estimator.cpp:257-304: P_ = identity with the motion blocks scaled by cfg "P", then `P_ *= P_`: the cfg numbers
+    are standard deviations, unused group / feature slots keep a unit diagonal."""
+    import numpy as np
+    from xivo_amd import pyxivo
+    here = os.path.dirname(os.path.abspath(__file__))
+    c = pyxivo.config_from_cfg(pyxivo.load_json_with_comments(os.path.join(here, "golden", "pcw_like_cfg.json")))
+    P = c.P_init()
+    d = np.diag(P)
+    assert np.count_nonzero(P - np.diag(d)) == 0
+    # restatement of the reference's loader on the same numbers
+    ref = np.ones(c.N)
+    ref[0:3], ref[3:6], ref[6:9], ref[9:12], ref[12:15], ref[15:18], ref[18:21], ref[21:23] = 1e-3, 1e-3, 0.5, 1e-10, 1e-10, 1e-10, 1e-10, 1e-10
+    Pref = np.diag(ref); Pref = Pref @ Pref                          # P_ *= P_
+    assert np.allclose(P, Pref, rtol=1e-15, atol=0)
+    assert d[0] == 1e-3 * 1e-3 and d[6] == 0.25 and d[9] == 1e-10 * 1e-10 and d[23] == 1.0 and d[-1] == 1.0
+    # "Tbc" as a 3-vector (src/estimator.cpp:266-271)
+    cfg = pyxivo.load_json_with_comments(os.path.join(here, "golden", "pcw_like_cfg.json"))
+    cfg["P"]["Tbc"] = [1e-3, 2e-3, 3e-3]
+    d2 = np.diag(pyxivo.config_from_cfg(cfg).P_init())
+    assert np.allclose(d2[18:21], [1e-6, 4e-6, 9e-6])
+    # Qmodel / Qimu are squared the same way (:313-330)
+    assert np.diag(c.Qmodel_matrix())[0] == 1e-4 and np.isclose(np.diag(c.Qimu_matrix())[3], 2.5e-3)
+
+
+def test_initial_feature_std_uses_the_reference_focal_length():
+    """Camera::GetFocalLength() = 0.5 sqrt(fx^2 + fy^2) (src/camera_manager.cpp:56), not fx (src/estimator.cpp:351-352)."""
+    from xivo_amd import sequence
+    c = sequence.SequenceConfig()
+    c.cam = dict(c.cam, fx=300.0, fy=400.0)
+    assert c.focal_length() == 250.0
+    c2 = sequence.SequenceConfig()
+    assert abs(c2.focal_length() - 275.0 * 0.5 * 2 ** 0.5) < 1e-12
+
+
+def test_imu_feeder_skips_repeated_and_old_timestamps():
+    """Estimator::Propagate returns on dt == 0 without touching last_ / slope_ (src/estimator.cpp:550-555)."""
+    import warnings
+    import numpy as np
+    from xivo_amd.sequence import ImuFeeder
+    f = ImuFeeder(2, 0.0, np.zeros((2, 3)), np.zeros((2, 3)))
+    f.imu(0.01, np.ones((2, 3)), np.ones((2, 3)))
+    slope = f.slope_gyro.copy(); last = f.last_gyro.copy()
+    f.imu(0.01, 5 * np.ones((2, 3)), 5 * np.ones((2, 3)))           # repeated timestamp: skipped
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        f.imu(0.005, 7 * np.ones((2, 3)), 7 * np.ones((2, 3)))      # older than the filter time: skipped with a warning
+        assert len(w) == 1
+    assert np.array_equal(f.slope_gyro, slope) and np.array_equal(f.last_gyro, last) and np.all(f.t == 0.01)
+    recs = f.take()
+    assert recs.shape == (2, 1) and np.all(np.isfinite(recs["slope_gyro"])) and np.all(recs["dt"] > 0)
+
+
+def test_oracle_absorb_error_enforces_so3_every_50_calls():
+    """State::operator+= (src/core.h:154-162): every kEnforceSO3Freq = 50 absorbs Rsb / Rbc are re-normalised and the z
+    component of log(Rsg) is zeroed - composing xy-only increments builds up a z rotation at second order."""
+    import numpy as np
+    import xivo_oracle as orc
+    from types import SimpleNamespace
+    lay = SimpleNamespace(group_begin=23, feature_begin=29)
+    st = dict(Rsb=np.eye(3), Tsb=np.zeros(3), Vsb=np.zeros(3), bg=np.zeros(3), ba=np.zeros(3), Rbc=np.eye(3), Tbc=np.zeros(3),
+              Rsg=np.eye(3), gR=np.eye(3)[None].copy(), gT=np.zeros((1, 3)), x=np.zeros((0, 3)), sind=np.zeros(0, dtype=int))
+    rng = np.random.default_rng(0)
+    zs = []
+    for k in range(100):
+        err = np.zeros(32)
+        err[21:23] = rng.normal(0, 0.05, 2)
+        orc.absorb_error(st, err, lay, [], [])
+        zs.append(orc.so3_log_quat(orc.rot_to_quat(st["Rsg"]))[2])
+    assert st["counter"] == 100
+    assert abs(zs[48]) > 1e-6                         # second-order z drift has built up ...
+    assert abs(zs[49]) < 1e-15 and abs(zs[99]) < 1e-15   # ... and is projected out on calls 50 and 100
+    assert np.allclose(st["Rsg"] @ st["Rsg"].T, np.eye(3), atol=1e-14)

@@ -57,6 +57,7 @@ struct xivo_hip_ctx {
   bool have_layout = false;
   int Fmax = 0, F = 0;
   xivo_pose_in* poses = nullptr;
+  int* absorb_count = nullptr;   // State::counter of every filter (src/core.h:120-122)
   xivo_group_in* groups = nullptr;
   xivo_feat_in* feats = nullptr;
   double *J = nullptr, *finn = nullptr, *dist = nullptr;
@@ -219,6 +220,7 @@ struct GemmExtra {
   int fp32 = 0;
   int a_f32 = 0;   // first operand stored as float
   int no_mirror = 0;
+  const int* skip = nullptr;   // per-filter status: non-zero = leave the output of that filter untouched
 };
 
 int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0, long sA0, int lda0,
@@ -238,6 +240,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   g.diag = x.diag; g.strideDiag = x.sDiag; g.Msub = x.msub; g.strideMsub = x.sMsub; g.ldmsub = x.ldmsub;
   g.McolScale = x.mcol; g.strideMcol = x.sMcol;
   g.epilogue = x.epi; g.lower_only = x.lower_only; g.no_mirror = x.no_mirror; g.batch = B; g.fp32 = x.fp32;
+  g.skip_status = x.skip;
   // algorithmic flops of the product: a symmetric output needs its lower triangle only
   const double outs = x.lower_only ? 0.5 * rows * (cols + 1.0) : (double)rows * cols;
   const double flops = 2.0 * outs * (double)(K0 + (A1 ? K1 : 0)) * B;
@@ -277,7 +280,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
-                  c->mask, c->rows_instate, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf};
+                  c->mask, c->rows_instate, c->absorb_count, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
@@ -326,12 +329,14 @@ int xivo_hip_device_count(void) {
 }
 
 int xivo_hip_sync(xivo_hip_ctx* c) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return XIVO_HIP_OK;
 }
 
 int xivo_hip_set_flags(xivo_hip_ctx* c, unsigned flags) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c) return XIVO_HIP_ERR_INVALID;
   c->flags = flags;
   return XIVO_HIP_OK;
@@ -339,6 +344,7 @@ int xivo_hip_set_flags(xivo_hip_ctx* c, unsigned flags) {
 
 // ------------------------------------------------------------------ P residency
 int xivo_hip_upload_P(xivo_hip_ctx* c, int b0, int nb, const double* P, long stride, int ld) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !P || ld < c->N) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   HIP_TRY(hipSetDevice(c->device));
@@ -353,6 +359,7 @@ int xivo_hip_upload_P(xivo_hip_ctx* c, int b0, int nb, const double* P, long str
 }
 
 int xivo_hip_download_P(xivo_hip_ctx* c, int b0, int nb, double* P, long stride, int ld) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !P || ld < c->N) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   HIP_TRY(hipSetDevice(c->device));
@@ -367,6 +374,7 @@ int xivo_hip_download_P(xivo_hip_ctx* c, int b0, int nb, double* P, long stride,
 }
 
 int xivo_hip_snapshot_P(xivo_hip_ctx* c) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c) return XIVO_HIP_ERR_INVALID;
   if (!c->Psnap) {
     if (hipMalloc((void**)&c->Psnap, (size_t)c->Bmax * c->sP * sizeof(double)) != hipSuccess) return XIVO_HIP_ERR_NOMEM;
@@ -376,22 +384,26 @@ int xivo_hip_snapshot_P(xivo_hip_ctx* c) {
 }
 
 int xivo_hip_restore_P(xivo_hip_ctx* c) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->Psnap) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipMemcpyAsync(c->P, c->Psnap, (size_t)c->Bmax * c->sP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return XIVO_HIP_OK;
 }
 
 int xivo_hip_p_zero_rc(xivo_hip_ctx* c, int b, int off, int len) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b, 1) || off < 0 || len < 0 || off + len > c->N) return XIVO_HIP_ERR_INVALID;
   return launch_p_zero_rc(c->P + (long)b * c->sP, c->Np, c->Np, off, len, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 
 int xivo_hip_p_copy_rc(xivo_hip_ctx* c, int b, int dst, int src, int len) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b, 1) || dst < 0 || src < 0 || len < 0 || dst + len > c->N || src + len > c->N) return XIVO_HIP_ERR_INVALID;
   return launch_p_copy_rc(c->P + (long)b * c->sP, c->Np, c->Np, dst, src, len, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 
 int xivo_hip_p_set_block3(xivo_hip_ctx* c, int b, int off, const double* P3) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b, 1) || !P3 || off < 0 || off + 3 > c->N) return XIVO_HIP_ERR_INVALID;
   double* dst = c->P + (long)b * c->sP + off + (long)off * c->Np;
   HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->Np * sizeof(double), P3, 3 * sizeof(double), 3 * sizeof(double), 3,
@@ -401,6 +413,7 @@ int xivo_hip_p_set_block3(xivo_hip_ctx* c, int b, int off, const double* P3) {
 }
 
 int xivo_hip_p_diag(xivo_hip_ctx* c, int b, double* out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b, 1) || !out) return XIVO_HIP_ERR_INVALID;
   if (launch_p_diag(c->P + (long)b * c->sP, c->Np, c->N, c->scratch, c->stream)) return XIVO_HIP_ERR_HIP;
   HIP_TRY(hipMemcpyAsync(out, c->scratch, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -442,6 +455,7 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
 
 int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const double* H, long strideH, int ldh,
                               const double* inn, long strideInn, const double* diagR, long strideR) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !H || !inn || !diagR || M <= 0 || M > c->Mmax || ldh < M) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   HIP_TRY(hipSetDevice(c->device));
@@ -466,6 +480,7 @@ int xivo_hip_set_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
 
 int xivo_hip_set_measurements_device(xivo_hip_ctx* c, int b0, int nb, int M, const double* dH, long strideH, int ldh,
                                      const double* dInn, long strideInn, const double* dR, long strideR) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !dH || !dInn || !dR || M <= 0 || M > c->Mmax || ldh < M || strideH < 0) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   HIP_TRY(hipSetDevice(c->device));
@@ -575,6 +590,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
     x.fp32 = (c->flags & XIVO_HIP_FLAG_FP64_CORR) ? 0 : 1;   // correction product on the fp32 MFMA, T added in fp64
     x.a_f32 = g_f32 ? 1 : 0;
+    x.skip = c->status + b0;   // S not positive definite: P of that filter stays the prior (reported through xivo_hip_get_status)
     rc = gemm(c, ST_PNEW, B, Np, Np, G, g_f32 ? 2 * c->sA : c->sA, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               P, c->sP, Np, x);
   }
@@ -663,6 +679,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     }
     {  // P+ = G K^T - T   (lower triangle + mirror)
       GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
+      x.skip = c->status + b0;
       rc = gemm(c, ST_PNEW, B, Np, Np, A, c->sP, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
                 P, c->sP, Np, x);
     }
@@ -683,6 +700,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   {  // P = T * A^T + K diag(R) K^T  (estimator.cpp:1280-1287, fused; lower triangle + mirror)
     GemmExtra x; x.lower_only = full ? 0 : 1; x.fp32 = f32;
+    x.skip = c->status + b0;
     rc = gemm(c, ST_PNEW, B, Np, Np, T, c->sP, Np, A, c->sP, Np, Np, K, c->sK, Np, K, c->sK, Np, Mp, diagR,
               c->Mpmax, P, c->sP, Np, x);
   }
@@ -690,6 +708,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
 }
 
 int xivo_hip_update_joseph(xivo_hip_ctx* c, int B) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || B <= 0 || B > c->Bmax || c->Mp <= 0) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   // Filters are independent, so the batch is walked in chunks whose intermediates
@@ -706,6 +725,7 @@ int xivo_hip_update_joseph(xivo_hip_ctx* c, int B) {
 
 int xivo_hip_update_dense_gated(xivo_hip_ctx* c, int B, int F, double R, double mh_thresh, double mh_mult,
                                 int min_inliers) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || B <= 0 || B > c->Bmax || c->Mp <= 0 || F <= 0 || 2 * F > c->M) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   int rc = ensure_gate_buffers(c, F);
@@ -733,6 +753,7 @@ const char* xivo_hip_stage_kernel(xivo_hip_ctx* c, int stage) {
 }
 
 int xivo_hip_get_gate(xivo_hip_ctx* c, int B, int F, unsigned char* mask_out, double* dist_out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || B <= 0 || B > c->Bmax || F <= 0 || !c->mask) return XIVO_HIP_ERR_INVALID;
   // the dense gate packs [B][F]; the layout-faithful gate (xivo_hip_mh_gate / filter_update) strides by Fmax
   const size_t ld = c->gate_sparse_last ? (size_t)c->Fmax : (size_t)F;
@@ -746,6 +767,7 @@ int xivo_hip_get_gate(xivo_hip_ctx* c, int B, int F, unsigned char* mask_out, do
 }
 
 int xivo_hip_get_err(xivo_hip_ctx* c, int b0, int nb, double* err, long stride) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !err || stride < c->N) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   return d2h_rows(c, err, (size_t)stride * sizeof(double), c->err + (long)b0 * c->Np, (size_t)c->Np * sizeof(double),
@@ -753,6 +775,7 @@ int xivo_hip_get_err(xivo_hip_ctx* c, int b0, int nb, double* err, long stride) 
 }
 
 int xivo_hip_get_status(xivo_hip_ctx* c, int b0, int nb, int* status) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !status) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   HIP_TRY(hipMemcpyAsync(status, c->status + b0, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -783,6 +806,7 @@ static int ensure_gate_buffers(xivo_hip_ctx* c, int F) {
 
 int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_thresh, double mh_mult,
                            int min_inliers, unsigned char* mask_out, double* dist_out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || B <= 0 || B > c->Bmax || F <= 0 || 2 * F > c->M) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   int rc = ensure_gate_buffers(c, F);
@@ -816,6 +840,7 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
 
 // ------------------------------------------------------------------ G-level
 int xivo_hip_set_layout(xivo_hip_ctx* c, const xivo_layout* lay, const xivo_cam* cam) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !lay || !cam) return XIVO_HIP_ERR_INVALID;
   if (lay->N != c->N || lay->group_begin < 21 || lay->n_groups <= 0 || lay->n_features <= 0 ||
       lay->feature_begin < lay->group_begin + 6 * lay->n_groups ||
@@ -825,6 +850,7 @@ int xivo_hip_set_layout(xivo_hip_ctx* c, const xivo_layout* lay, const xivo_cam*
   c->lay = *lay; c->cam = *cam; c->have_layout = true;
   if (!c->poses) {
     int rc = dev_alloc(&c->poses, (size_t)c->Bmax);
+    if (!rc) rc = dev_alloc(&c->absorb_count, (size_t)c->Bmax);
     if (!rc) rc = dev_alloc(&c->groups, (size_t)c->Bmax * lay->n_groups);
     if (rc) return rc;
   }
@@ -833,6 +859,7 @@ int xivo_hip_set_layout(xivo_hip_ctx* c, const xivo_layout* lay, const xivo_cam*
 
 int xivo_hip_set_scene(xivo_hip_ctx* c, int b0, int nb, int F, const xivo_pose_in* poses,
                        const xivo_group_in* groups, const xivo_feat_in* feats) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !c->have_layout || F <= 0 || 2 * F > c->Mmax || !poses || !groups || !feats)
     return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
@@ -856,12 +883,14 @@ int xivo_hip_set_scene(xivo_hip_ctx* c, int b0, int nb, int F, const xivo_pose_i
 }
 
 int xivo_hip_jacobians_instate(xivo_hip_ctx* c, int B) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   StageTimer st(c, ST_JAC, 0.0, "jac_instate_kernel");
   return launch_jac_instate(scene_buffers(c), c->lay, c->cam, B, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 
 int xivo_hip_get_jacobians(xivo_hip_ctx* c, int b0, int nb, double* J, double* inn) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   const size_t F = c->F, Fm = c->Fmax;
   if (J) {
@@ -888,6 +917,7 @@ static int gate_impl(xivo_hip_ctx* c, int B, double R, double th, double mult, i
 
 int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double mh_mult, int min_inliers,
                      unsigned char* mask_out, double* dist_out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   int rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
   if (rc) return rc;
@@ -924,6 +954,7 @@ static int ensure_dense(xivo_hip_ctx* c) {
 }
 
 int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
   for (int b = 0; b < B; ++b) {
@@ -938,6 +969,7 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
 
 int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_oos_in* feats, double Roos,
                          int* rows_out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !c->have_layout || n_oos <= 0 || b0 != 0) return XIVO_HIP_ERR_INVALID;
   // feats == NULL: the list uploaded by the previous call is still resident (same nb, n_oos) - project it again
   if (!feats && (!c->oos || c->oos_nb != nb || c->oos_n != n_oos)) return XIVO_HIP_ERR_INVALID;
@@ -985,6 +1017,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
 
 int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, double mh_mult, int min_inliers,
                            int use_gating) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   int rc = xivo_hip_jacobians_instate(c, B);
   if (rc) return rc;
@@ -1028,15 +1061,18 @@ static int givens_impl(xivo_hip_ctx* c, int nb, int rows, int nx, int nf, double
 
 int xivo_hip_givens(xivo_hip_ctx* c, int nb, int rows, int nx, int nf, double* x, double* Hx, double* Hf,
                     int effective_rows, int* rows_out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   return givens_impl(c, nb, rows, nx, nf, x, Hx, Hf, effective_rows, rows_out, 0);
 }
 
 int xivo_hip_qr(xivo_hip_ctx* c, int nb, int rows, int nx, double* x, double* Hx, int effective_rows, int* rows_out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   return givens_impl(c, nb, rows, nx, 0, x, Hx, nullptr, effective_rows, rows_out, 1);
 }
 
 int xivo_hip_subfilter_update(xivo_hip_ctx* c, int b0, int nb, int n, xivo_subfilter_feat* feats,
                               const xivo_subfilter_opts* opts) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || n <= 0 || !feats || !opts) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   for (size_t i = 0; i < (size_t)nb * n; ++i)
@@ -1061,15 +1097,17 @@ int xivo_hip_subfilter_update(xivo_hip_ctx* c, int b0, int nb, int n, xivo_subfi
 }
 
 int xivo_hip_absorb_error(xivo_hip_ctx* c, int B) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0 || !c->mask) return XIVO_HIP_ERR_INVALID;
   AbsorbArgs a;
   a.poses = c->poses; a.groups = c->groups; a.feats = c->feats; a.mask = c->mask; a.err = c->err; a.strideErr = c->Np;
-  a.lay = c->lay; a.F = c->F; a.Fmax = c->Fmax; a.batch = B;
+  a.lay = c->lay; a.F = c->F; a.Fmax = c->Fmax; a.batch = B; a.counter = c->absorb_count; a.status = c->status;
   StageTimer st(c, ST_OTHER, 0.0);
   return launch_absorb_error(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 
 int xivo_hip_edit_batch(xivo_hip_ctx* c, int F, int n_ops, const xivo_edit_op* ops) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || !c->poses || F <= 0 || 2 * F > c->Mmax || n_ops < 0 || (n_ops > 0 && !ops))
     return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
@@ -1125,6 +1163,7 @@ int xivo_hip_edit_batch(xivo_hip_ctx* c, int F, int n_ops, const xivo_edit_op* o
 }
 
 int xivo_hip_set_pixels(xivo_hip_ctx* c, int b0, int nb, int F, const double* xp) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || F <= 0 || 2 * F > c->Mmax || !xp) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   HIP_TRY(hipSetDevice(c->device));
@@ -1140,6 +1179,7 @@ int xivo_hip_set_pixels(xivo_hip_ctx* c, int b0, int nb, int F, const double* xp
 }
 
 int xivo_hip_get_scene(xivo_hip_ctx* c, int b0, int nb, xivo_pose_in* poses, xivo_group_in* groups, xivo_feat_in* feats) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !c->have_layout || !c->poses) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   if (poses) HIP_TRY(hipMemcpyAsync(poses, c->poses + b0, (size_t)nb * sizeof(xivo_pose_in), hipMemcpyDeviceToHost, c->stream));
@@ -1155,6 +1195,7 @@ int xivo_hip_get_scene(xivo_hip_ctx* c, int b0, int nb, xivo_pose_in* poses, xiv
 }
 
 int xivo_hip_get_H(xivo_hip_ctx* c, int b, int* M_out, double* H, int ldh, double* inn, double* diagR) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b, 1) || c->M <= 0) return XIVO_HIP_ERR_INVALID;
   const int M = c->M;
   if (M_out) *M_out = M;
@@ -1172,6 +1213,7 @@ int xivo_hip_get_H(xivo_hip_ctx* c, int b, int* M_out, double* H, int ldh, doubl
 
 // ------------------------------------------------------------------ propagation tail
 int xivo_hip_propagate_cov(xivo_hip_ctx* c, int b0, int nb, int nm, const double* Phi, const double* Pmm) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || nm <= 0 || nm > 32 || nm > c->N || !Phi || !Pmm) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   const size_t per = (size_t)nm * nm;
@@ -1189,6 +1231,7 @@ int xivo_hip_propagate_cov(xivo_hip_ctx* c, int b0, int nb, int nm, const double
 }
 
 int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_imu_in* imu, const xivo_prop_opts* o) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || !imu || !o || n_imu <= 0 || c->N < 23 || c->lay.group_begin < 23)
     return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
@@ -1224,6 +1267,7 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
 
 // ------------------------------------------------------------------ device buffers for resident inputs (bench / tests)
 int xivo_hip_dev_alloc(xivo_hip_ctx* c, size_t bytes, void** out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !out || bytes == 0) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   *out = nullptr;
@@ -1231,6 +1275,7 @@ int xivo_hip_dev_alloc(xivo_hip_ctx* c, size_t bytes, void** out) {
 }
 
 int xivo_hip_dev_free(xivo_hip_ctx* c, void* p) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1239,6 +1284,7 @@ int xivo_hip_dev_free(xivo_hip_ctx* c, void* p) {
 }
 
 int xivo_hip_dev_upload(xivo_hip_ctx* c, void* dst, const void* src, size_t bytes, size_t total_bytes) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !dst || !src || bytes == 0 || total_bytes < bytes) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -1254,12 +1300,14 @@ int xivo_hip_dev_upload(xivo_hip_ctx* c, void* dst, const void* src, size_t byte
 
 // ------------------------------------------------------------------ timing
 int xivo_hip_timer_begin(xivo_hip_ctx* c) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipEventRecord(c->t0, c->stream));
   return XIVO_HIP_OK;
 }
 
 int xivo_hip_timer_end(xivo_hip_ctx* c, float* ms) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !ms) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipEventRecord(c->t1, c->stream));
   HIP_TRY(hipEventSynchronize(c->t1));
@@ -1268,6 +1316,7 @@ int xivo_hip_timer_end(xivo_hip_ctx* c, float* ms) {
 }
 
 int xivo_hip_profile_reset(xivo_hip_ctx* c) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c) return XIVO_HIP_ERR_INVALID;
   int rc = collect_profile(c);
   for (int i = 0; i < ST_COUNT; ++i) { c->stage_ms[i] = 0.f; c->stage_launches[i] = 0; c->stage_flops[i] = 0.0; }
@@ -1275,6 +1324,7 @@ int xivo_hip_profile_reset(xivo_hip_ctx* c) {
 }
 
 int xivo_hip_profile_get(xivo_hip_ctx* c, int* n, const char** names, float* ms, int* launches, double* flops) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !n) return XIVO_HIP_ERR_INVALID;
   int rc = collect_profile(c);
   if (rc) return rc;
@@ -1289,6 +1339,7 @@ int xivo_hip_profile_get(xivo_hip_ctx* c, int* n, const char** names, float* ms,
 }
 
 int xivo_hip_bench_mfma_peak(xivo_hip_ctx* c, double* out4) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   // out4[0] = TFLOP/s with the chip full (8 workgroups / CU)
   // out4[1] = shader cycles per MFMA per SIMD, one wave per SIMD (256 workgroups)
   // out4[2] = sustained shader clock (GHz) during the full-chip run

@@ -62,6 +62,8 @@ struct GemmArgs {
   int batch;
   int tiles_m, tiles_n;
   int fp32;            // 1: fp32 MFMA with fp32 accumulation for this product (operands/results stay fp64 in HBM)
+  const int* skip_status;  // optional [batch]: filters with a non-zero entry are left untouched (S not positive definite:
+                           // the final covariance product must not overwrite P with the garbage of a failed factorisation)
 };
 
 // launches on `stream`; returns hipError_t as int

@@ -99,6 +99,8 @@ int launch_givens(const GivensArgs& a, hipStream_t s);
 struct AbsorbArgs {
   xivo_pose_in* poses; xivo_group_in* groups; xivo_feat_in* feats; const unsigned char* mask;
   double* err; long strideErr; xivo_layout lay; int F, Fmax, batch;
+  const int* status;   // [batch] factorisation status of the update that produced err: non-zero -> nothing is absorbed, err <- 0
+  int* counter;   // [batch] State::counter (core.h:120-122): absorbs so far, drives the periodic SO3 re-normalisation
 };
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s);
 

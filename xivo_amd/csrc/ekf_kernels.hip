@@ -695,6 +695,54 @@ __device__ __forceinline__ void rot_retract(double* Rcm, double wx, double wy, d
 #pragma unroll
     for (int j = 0; j < 3; ++j) Rcm[i + 3 * j] = R.m[i][j];
 }
+// The periodic re-normalisation of State::operator+= (src/core.h:154-162, every kEnforceSO3Freq = 50 absorbs):
+// Sophus SO3::normalize() on Rsb / Rbc (unit quaternion; here: matrix -> quaternion -> normalise -> matrix, which
+// also re-orthonormalises the stored matrix) and Rsg <- exp(log(Rsg) with its z component zeroed).
+__device__ __forceinline__ void rot_to_quat(const M3& R, double q[4]) {   // (w, x, y, z), Shepperd's branch on the largest diagonal term
+  const double t = R.m[0][0] + R.m[1][1] + R.m[2][2];
+  if (t > 0.0) {
+    const double s = sqrt(t + 1.0) * 2.0;
+    q[0] = 0.25 * s; q[1] = (R.m[2][1] - R.m[1][2]) / s; q[2] = (R.m[0][2] - R.m[2][0]) / s; q[3] = (R.m[1][0] - R.m[0][1]) / s;
+  } else if (R.m[0][0] > R.m[1][1] && R.m[0][0] > R.m[2][2]) {
+    const double s = sqrt(1.0 + R.m[0][0] - R.m[1][1] - R.m[2][2]) * 2.0;
+    q[0] = (R.m[2][1] - R.m[1][2]) / s; q[1] = 0.25 * s; q[2] = (R.m[0][1] + R.m[1][0]) / s; q[3] = (R.m[0][2] + R.m[2][0]) / s;
+  } else if (R.m[1][1] > R.m[2][2]) {
+    const double s = sqrt(1.0 + R.m[1][1] - R.m[0][0] - R.m[2][2]) * 2.0;
+    q[0] = (R.m[0][2] - R.m[2][0]) / s; q[1] = (R.m[0][1] + R.m[1][0]) / s; q[2] = 0.25 * s; q[3] = (R.m[1][2] + R.m[2][1]) / s;
+  } else {
+    const double s = sqrt(1.0 + R.m[2][2] - R.m[0][0] - R.m[1][1]) * 2.0;
+    q[0] = (R.m[1][0] - R.m[0][1]) / s; q[1] = (R.m[0][2] + R.m[2][0]) / s; q[2] = (R.m[1][2] + R.m[2][1]) / s; q[3] = 0.25 * s;
+  }
+  const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] *= n; q[1] *= n; q[2] *= n; q[3] *= n;
+}
+__device__ __forceinline__ void quat_to_colmajor(const double q[4], double* Rcm) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  Rcm[0] = 1.0 - 2.0 * (y * y + z * z); Rcm[3] = 2.0 * (x * y - w * z);       Rcm[6] = 2.0 * (x * z + w * y);
+  Rcm[1] = 2.0 * (x * y + w * z);       Rcm[4] = 1.0 - 2.0 * (x * x + z * z); Rcm[7] = 2.0 * (y * z - w * x);
+  Rcm[2] = 2.0 * (x * z - w * y);       Rcm[5] = 2.0 * (y * z + w * x);       Rcm[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+__device__ __forceinline__ void rot_normalize(double* Rcm) {
+  double q[4];
+  rot_to_quat(m3_from_colmajor(Rcm), q);
+  quat_to_colmajor(q, Rcm);
+}
+__device__ __forceinline__ void rot_zero_log_z(double* Rcm) {   // Sophus SO3::log on the unit quaternion, z <- 0, exp
+  double q[4];
+  rot_to_quat(m3_from_colmajor(Rcm), q);
+  const double n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3], w = q[0];
+  double k;
+  if (n2 < 1e-20) k = 2.0 / w - 2.0 / 3.0 * n2 / (w * w * w);
+  else {
+    const double n = sqrt(n2);
+    k = fabs(w) < 1e-10 ? (w > 0.0 ? 3.141592653589793 / n : -3.141592653589793 / n) : 2.0 * atan(n / w) / n;
+  }
+  const M3 R = so3_exp_dev(k * q[1], k * q[2], 0.0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rcm[i + 3 * j] = R.m[i][j];
+}
 // ---------------------------------------------------------------- batched resident edits (xivo_hip_edit_batch)
 __device__ __forceinline__ void edit_zero_rc(double* P, int ldp, int Np, int off, int len, int tid) {
   for (int t = tid; t < Np; t += 256)
@@ -784,6 +832,10 @@ __global__ __launch_bounds__(256) void edit_batch_kernel(EditArgs a) {
 __global__ __launch_bounds__(256) void absorb_error_kernel(AbsorbArgs a) {
   const int filt = blockIdx.x, tid = threadIdx.x;
   double* err = a.err + (long)filt * a.strideErr;
+  if (a.status && a.status[filt]) {                      // S was not positive definite: K / dx of that filter are meaningless
+    for (int n = tid; n < a.lay.N; n += 256) err[n] = 0.0;
+    return;
+  }
   if (tid == 0) {                                        // State::operator+= (core.h:135-165)
     xivo_pose_in& X = a.poses[filt];
     rot_retract(X.Rsb, err[0], err[1], err[2]);
@@ -791,6 +843,11 @@ __global__ __launch_bounds__(256) void absorb_error_kernel(AbsorbArgs a) {
     rot_retract(X.Rsg, err[21], err[22], 0.0);
     for (int i = 0; i < 3; ++i) {
       X.Tsb[i] += err[3 + i]; X.Vsb[i] += err[6 + i]; X.bg[i] += err[9 + i]; X.ba[i] += err[12 + i]; X.Tbc[i] += err[18 + i];
+    }
+    if (a.counter && ++a.counter[filt] % 50 == 0) {      // kEnforceSO3Freq (core.h:111,154-162)
+      rot_normalize(X.Rsb);
+      rot_normalize(X.Rbc);
+      rot_zero_log_z(X.Rsg);
     }
   }
   for (int g = tid; g < a.lay.n_groups; g += 256) {      // SO3xR3::operator+= (group.h:25-29); empty slots have dx = 0

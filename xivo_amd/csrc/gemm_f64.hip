@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256, (sizeof(CT) == 4 && WM * WN <= 16) ? 3 : 2) vo
   // tiles on 8 of 32 CUs (measured: one off-diagonal tile per filter cost as much as all four).
   const int tile = (slot + slot / nt) % nt;
   if (filt >= g.batch) return;
+  if (g.skip_status && g.skip_status[filt]) return;
   const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   if (g.lower_only && n0 >= m0 + BM) return;  // tile strictly above the diagonal

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_f64_kernel(GemmArgs g, SymGro
   const int filt = (slot / ng) * 8 + xcd;
   const int grp = (slot + slot / ng) % ng;   // rotate so unequal groups spread over all CUs
   if (filt >= g.batch) return;
+  if (g.skip_status && g.skip_status[filt]) return;
   const int r0 = sg.r0[grp], r1 = sg.r1[grp];
   const int nrows = r1 - r0, ncols = r1;               // in 16-blocks
   const int LDAS = 16 * (nrows + 1 + (nrows & 1));     // LDAS/16 odd -> k-rows alternate bank halves

@@ -1,5 +1,6 @@
 // See batch_estimator.h. Decision for decision the frame loop of xivo_amd/sequence.py (SequenceRunner.frame, ImuFeeder).
 #include "batch_estimator.h"
+#include <stdio.h>
 
 #include <algorithm>
 #include <chrono>
@@ -73,6 +74,13 @@ void BatchEstimator::InertialMeas(double t, const double* gyro, const double* ac
     return;
   }
   const double dt = t - t_;
+  if (!(dt > 0.0)) {
+    // Estimator::Propagate returns on dt == 0 with last_ / slope_ untouched (src/estimator.cpp:550-555); a message from
+    // the past is skipped the same way
+    if (dt < 0.0) fprintf(stderr, "xivo::hip::BatchEstimator: IMU message older than the filter time skipped\n");
+    host_s_ += now_s() - t0;
+    return;
+  }
   std::vector<xivo_imu_in> rec(B_);
   for (int b = 0; b < B_; ++b) {
     xivo_imu_in& r = rec[b];
@@ -185,14 +193,22 @@ void BatchEstimator::VisualMeasPointCloud(double t, const int* off, const int64_
   Check(xivo_hip_set_pixels(ctx_, 0, B_, F, xp_.data()), "set_pixels");
   // --- measurement update on the tracked in-state features (src/manager.cpp:72-104), ragged over the filters
   const double R = cfg_.visual_meas_std * cfg_.visual_meas_std;
-  Check(xivo_hip_filter_update(ctx_, B_, R, cfg_.MH_thresh, cfg_.MH_adjust_factor, cfg_.min_inliers, 1), "filter_update");
+  Check(xivo_hip_filter_update(ctx_, B_, R, cfg_.MH_thresh, cfg_.MH_adjust_factor, cfg_.min_inliers, cfg_.use_MH_gating), "filter_update");
   Check(xivo_hip_get_gate(ctx_, B_, F, mask_.data(), nullptr), "get_gate");
+  // a filter whose S was not positive definite keeps its prior P and absorbs nothing (the device skips both); it is
+  // counted and reported here - the reference's pivoted LDL^T cannot fail, so there is no reference behaviour to mirror
+  status_.resize(B_);
+  const int st = xivo_hip_get_status(ctx_, 0, B_, status_.data());
+  if (st == XIVO_HIP_ERR_NOT_SPD) { for (int b = 0; b < B_; ++b) n_not_spd_ += status_[b] != 0; }
+  else Check(st, "get_status");
   Check(xivo_hip_absorb_error(ctx_, B_), "absorb_error");
   t0 = now_s();
   for (int b = 0; b < B_; ++b) n_updates_ += books_[b].id2slot.empty() ? 0 : 1;
   // --- after the update: MH-rejected features leave (src/update.cpp:105-113), new ones enter with a new group
   const double fx = cfg_.cam.fx, fy = cfg_.cam.fy, cx = cfg_.cam.cx, cy = cfg_.cam.cy;
-  const double sd[3] = {cfg_.initial_std_x / fx, cfg_.initial_std_y / fx, cfg_.initial_std_z};
+  // Camera::GetFocalLength() = 0.5 sqrt(fx^2 + fy^2) (src/camera_manager.cpp:56, src/estimator.cpp:351-352)
+  const double fl = 0.5 * std::sqrt(fx * fx + fy * fy);
+  const double sd[3] = {cfg_.initial_std_x / fl, cfg_.initial_std_y / fl, cfg_.initial_std_z};
   long rejected = 0;
 #pragma omp parallel for schedule(static) reduction(+ : rejected) num_threads(kThreads) if (B_ >= 512)
   for (int b = 0; b < B_; ++b) {
@@ -257,7 +273,7 @@ struct xivo_batch_cfg {   // flat mirror of xivo::hip::BatchConfig
   int n_groups, n_features;
   xivo_cam cam;
   double visual_meas_std, MH_thresh, MH_adjust_factor;
-  int min_inliers, min_new_features, fix_group_block, reserved;
+  int min_inliers, min_new_features, fix_group_block, disable_MH_gating;   // cfg use_MH_gating = false
   double initial_std_x, initial_std_y, initial_std_z, min_depth, max_depth;
   xivo_prop_opts prop;
 };
@@ -268,6 +284,7 @@ int xivo_batch_create(const xivo_batch_cfg* c, int B, int device, const xivo_pos
     cfg.n_groups = c->n_groups; cfg.n_features = c->n_features; cfg.cam = c->cam;
     cfg.visual_meas_std = c->visual_meas_std; cfg.MH_thresh = c->MH_thresh; cfg.MH_adjust_factor = c->MH_adjust_factor;
     cfg.min_inliers = c->min_inliers; cfg.min_new_features = c->min_new_features; cfg.fix_group_block = c->fix_group_block;
+    cfg.use_MH_gating = c->disable_MH_gating ? 0 : 1;
     cfg.initial_std_x = c->initial_std_x; cfg.initial_std_y = c->initial_std_y; cfg.initial_std_z = c->initial_std_z;
     cfg.min_depth = c->min_depth; cfg.max_depth = c->max_depth; cfg.prop = c->prop;
     *out = new xivo::hip::BatchEstimator(cfg, B, device, poses0, P0);
@@ -299,6 +316,7 @@ void xivo_batch_stats(void* h, long* n_updates, long* n_rejected, double* host_s
   auto* e = static_cast<xivo::hip::BatchEstimator*>(h);
   *n_updates = e->n_updates(); *n_rejected = e->n_rejected(); *host_seconds = e->host_seconds();
 }
+long xivo_batch_not_spd(void* h) { return static_cast<xivo::hip::BatchEstimator*>(h)->n_not_spd(); }
 void* xivo_batch_ctx(void* h) { return static_cast<xivo::hip::BatchEstimator*>(h)->ctx(); }
 
 }  // extern "C"

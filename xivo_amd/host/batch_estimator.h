@@ -29,6 +29,7 @@ struct BatchConfig {
   double visual_meas_std = 1.0;
   double MH_thresh = 5.991, MH_adjust_factor = 1.1;
   int min_inliers = 5;
+  int use_MH_gating = 1;                            // cfg use_MH_gating (src/estimator.cpp:364)
   double initial_std_x = 1.0, initial_std_y = 1.0, initial_std_z = 0.1;   // pixels, pixels, log-depth (estimator.cpp:349-353)
   double min_depth = 0.05, max_depth = 10.0;
   int min_new_features = 3;                         // open a new group only when this many feature slots are free
@@ -58,6 +59,7 @@ class BatchEstimator {
   const BatchConfig& cfg() const { return cfg_; }
   xivo_hip_ctx* ctx() { return ctx_; }
   long n_updates() const { return n_updates_; }
+  long n_not_spd() const { return n_not_spd_; }   // updates skipped because S was not positive definite
   long n_rejected() const { return n_rejected_; }
   double host_seconds() const { return host_s_; }   // time spent in the host-side life cycle (not in C-ABI calls)
 
@@ -83,7 +85,8 @@ class BatchEstimator {
   double t_ = 0.0;
   std::vector<double> last_gyro_, last_accel_, slope_gyro_, slope_accel_;   // [B][3]
   std::vector<std::vector<xivo_imu_in>> pending_;   // [message][B]
-  long n_updates_ = 0, n_rejected_ = 0;
+  long n_updates_ = 0, n_rejected_ = 0, n_not_spd_ = 0;
+  std::vector<int> status_;
   double host_s_ = 0.0;
   std::vector<unsigned char> mask_;
   std::vector<double> xp_;

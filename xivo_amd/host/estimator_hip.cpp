@@ -167,13 +167,57 @@ void zero_rc(MatX& P, int off, int len) {
 }
 }  // namespace
 
+namespace {
+// unit quaternion (w, x, y, z) of a rotation matrix (Shepperd), and back: Sophus SO3::normalize() on the
+// reference's quaternion storage = this round trip on the matrix storage used here
+void rot_to_quat(const Mat3& R, number_t q[4]) {
+  const number_t t = R(0, 0) + R(1, 1) + R(2, 2);
+  if (t > 0.0) {
+    const number_t s = std::sqrt(t + 1.0) * 2.0;
+    q[0] = 0.25 * s; q[1] = (R(2, 1) - R(1, 2)) / s; q[2] = (R(0, 2) - R(2, 0)) / s; q[3] = (R(1, 0) - R(0, 1)) / s;
+  } else if (R(0, 0) > R(1, 1) && R(0, 0) > R(2, 2)) {
+    const number_t s = std::sqrt(1.0 + R(0, 0) - R(1, 1) - R(2, 2)) * 2.0;
+    q[0] = (R(2, 1) - R(1, 2)) / s; q[1] = 0.25 * s; q[2] = (R(0, 1) + R(1, 0)) / s; q[3] = (R(0, 2) + R(2, 0)) / s;
+  } else if (R(1, 1) > R(2, 2)) {
+    const number_t s = std::sqrt(1.0 + R(1, 1) - R(0, 0) - R(2, 2)) * 2.0;
+    q[0] = (R(0, 2) - R(2, 0)) / s; q[1] = (R(0, 1) + R(1, 0)) / s; q[2] = 0.25 * s; q[3] = (R(1, 2) + R(2, 1)) / s;
+  } else {
+    const number_t s = std::sqrt(1.0 + R(2, 2) - R(0, 0) - R(1, 1)) * 2.0;
+    q[0] = (R(1, 0) - R(0, 1)) / s; q[1] = (R(0, 2) + R(2, 0)) / s; q[2] = (R(1, 2) + R(2, 1)) / s; q[3] = 0.25 * s;
+  }
+  const number_t n = 1.0 / std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) q[i] *= n;
+}
+Mat3 quat_to_rot(const number_t q[4]) {
+  const number_t w = q[0], x = q[1], y = q[2], z = q[3];
+  Mat3 R;
+  R(0, 0) = 1 - 2 * (y * y + z * z); R(0, 1) = 2 * (x * y - w * z);     R(0, 2) = 2 * (x * z + w * y);
+  R(1, 0) = 2 * (x * y + w * z);     R(1, 1) = 1 - 2 * (x * x + z * z); R(1, 2) = 2 * (y * z - w * x);
+  R(2, 0) = 2 * (x * z - w * y);     R(2, 1) = 2 * (y * z + w * x);     R(2, 2) = 1 - 2 * (x * x + y * y);
+  return R;
+}
+}  // namespace
+
 void Estimator::AbsorbError() {
-  // State::operator+= (src/core.h:135-165); the every-50-calls SO3 re-normalisation is a no-op
-  // to rounding on orthonormal inputs and is omitted.
+  // State::operator+= (src/core.h:135-165)
   Rsb_ = mul3(Rsb_, exp3(err_(0), err_(1), err_(2)));
   for (int i = 0; i < 3; ++i) { Tsb_(i) += err_(3 + i); Vsb_(i) += err_(6 + i); bg_(i) += err_(9 + i); ba_(i) += err_(12 + i); Tbc_(i) += err_(18 + i); }
   Rbc_ = mul3(Rbc_, exp3(err_(15), err_(16), err_(17)));
   Rsg_ = mul3(Rsg_, exp3(err_(21), err_(22), 0.0));
+  if (++absorb_counter_ % 50 == 0) {   // kEnforceSO3Freq (src/core.h:111,154-162)
+    number_t q[4];
+    rot_to_quat(Rsb_, q); Rsb_ = quat_to_rot(q);
+    rot_to_quat(Rbc_, q); Rbc_ = quat_to_rot(q);
+    rot_to_quat(Rsg_, q);              // Wsg = Rsg.log(); Wsg(2) = 0; Rsg = exp(Wsg)   (Sophus SO3::log on the quaternion)
+    const number_t n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3], w = q[0];
+    number_t k;
+    if (n2 < 1e-20) k = 2.0 / w - 2.0 / 3.0 * n2 / (w * w * w);
+    else {
+      const number_t n = std::sqrt(n2);
+      k = std::fabs(w) < 1e-10 ? (w > 0.0 ? M_PI / n : -M_PI / n) : 2.0 * std::atan(n / w) / n;
+    }
+    Rsg_ = exp3(k * q[1], k * q[2], 0.0);
+  }
   for (Group* g : instate_groups_) {                                   // estimator.cpp:897-905
     const int off = lay_.group_begin + 6 * g->sind();
     g->Rsb_ = mul3(g->Rsb_, exp3(err_(off), err_(off + 1), err_(off + 2)));

@@ -158,6 +158,7 @@ class Estimator {
   GroupPtr gauge_group_ptr_ = nullptr;
   std::vector<GroupPtr> instate_groups_;   // groups AbsorbError retracts (src/manager.cpp:103)
   int num_oneptransac_rejected_ = 0;
+  int absorb_counter_ = 0;                 // State::counter (src/core.h:120-122)
   std::vector<number_t> ransac_chi2_;      // chi-square distances of the rescue step (for tests/diagnostics)
   // host edits of P_ stay plain host code on the authoritative host copy
 

@@ -48,7 +48,8 @@ def config_from_cfg(cfg):
         c.gravity = np.asarray(cfg["gravity"], dtype=float)
     for k in c.P0:
         if k in cfg.get("P", {}):
-            c.P0[k] = float(cfg["P"][k])
+            v = np.asarray(cfg["P"][k], dtype=float).reshape(-1)
+            c.P0[k] = v[:3] if (k == "Tbc" and v.size == 3) else float(v[0])      # "Tbc": scalar or 3-vector (estimator.cpp:266-271)
     for k in c.Qmodel:
         if k in cfg.get("Qmodel", {}):
             c.Qmodel[k] = float(cfg["Qmodel"][k])
@@ -63,6 +64,10 @@ def config_from_cfg(cfg):
     c.MH_thresh = float(cfg.get("MH_thresh", c.MH_thresh))
     c.MH_adjust_factor = float(cfg.get("MH_adjust_factor", c.MH_adjust_factor))
     c.min_inliers = int(cfg.get("min_inliers", c.min_inliers))
+    c.use_MH_gating = bool(cfg.get("use_MH_gating", c.use_MH_gating))
+    c.use_1pt_RANSAC = bool(cfg.get("use_1pt_RANSAC", c.use_1pt_RANSAC))
+    c.ransac_thresh = float(cfg.get("1pt_RANSAC_thresh", c.ransac_thresh))
+    c.ransac_Chi2 = float(cfg.get("1pt_RANSAC_Chi2", c.ransac_Chi2))
     for k in ("initial_std_x", "initial_std_y", "initial_std_z", "min_depth", "max_depth"):
         if k in cfg:
             setattr(c, k, float(cfg[k]))

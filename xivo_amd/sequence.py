@@ -39,6 +39,13 @@ class ImuFeeder:
     def imu(self, t, gyro, accel):
         """one IMU message per filter at time t (visual_meas == false branch, :558-567)"""
         dt = t - self.t
+        if np.all(dt <= 0):
+            # Estimator::Propagate returns early on dt == 0 and leaves last_ / slope_ untouched (src/estimator.cpp:550-555);
+            # a message from the past (dt < 0) is skipped the same way, with a warning
+            if np.any(dt < 0):
+                import warnings
+                warnings.warn("IMU message older than the filter time: skipped")
+            return
         rec = np.zeros(self.t.shape[0], dtype=L.imu_dtype)
         self.slope_gyro = (gyro - self.last_gyro) / dt[:, None]
         self.slope_accel = (accel - self.last_accel) / dt[:, None]
@@ -85,6 +92,9 @@ class SequenceConfig:
         self.integration_method, self.stepsize = "PrinceDormand", 0.002
         self.visual_meas_std = 1.0
         self.MH_thresh, self.MH_adjust_factor, self.min_inliers = 5.991, 1.1, 5
+        self.use_MH_gating = True       # cfg use_MH_gating (src/estimator.cpp:364)
+        self.use_1pt_RANSAC = False     # cfg use_1pt_RANSAC (off in cfg/pcw.json, cfg/tumvi_cam0.json)
+        self.ransac_thresh, self.ransac_Chi2 = 5.0, 5.89       # 1pt_RANSAC_thresh / 1pt_RANSAC_Chi2 defaults (estimator.cpp:132-134)
         self.initial_std_x = self.initial_std_y = 1.0      # pixels, divided by the focal length (estimator.cpp:351-352)
         self.initial_std_z = 0.10
         self.min_depth, self.max_depth = 0.05, 10.0
@@ -103,14 +113,21 @@ class SequenceConfig:
         return 23 + 6 * self.n_groups + 3 * self.n_features
 
     def P_init(self):
-        """P_ = identity blocks scaled by cfg "P" (src/estimator.cpp:257-271); group / feature slots start at zero"""
-        P = np.zeros((self.N, self.N))
-        d = np.zeros(23)
+        """Estimator ctor, src/estimator.cpp:257-304: P_ = identity (kFullSize - unused group / feature slots keep a
+        unit diagonal until a remove op zeroes them), the motion blocks scaled by cfg "P" - which are STANDARD
+        DEVIATIONS: the whole matrix is then squared (`P_ *= P_`, :304). "Tbc" may be a scalar or a 3-vector (:266-271)."""
+        P = np.eye(self.N)
+        d = np.ones(23)
         p = self.P0
         d[0:3], d[3:6], d[6:9], d[9:12], d[12:15] = p["Wsb"], p["Tsb"], p["Vsb"], p["bg"], p["ba"]
-        d[15:18], d[18:21], d[21:23] = p["Wbc"], p["Tbc"], p["Wsg"]
-        P[:23, :23] = np.diag(d)
+        d[15:18], d[18:21], d[21:23] = p["Wbc"], np.asarray(p["Tbc"], dtype=float).reshape(-1)[:3], p["Wsg"]
+        P[:23, :23] = np.diag(d * d)
         return P
+
+    def focal_length(self):
+        """Camera::GetFocalLength() = 0.5 sqrt(fx^2 + fy^2) (src/camera_manager.cpp:56) - what the initial feature
+        std in pixels is divided by (src/estimator.cpp:351-352); NOT fx: 0.707 fx for a square pixel."""
+        return 0.5 * float(np.hypot(self.cam["fx"], self.cam["fy"]))
 
     def Qmodel_matrix(self):
         """src/estimator.cpp:313-318: only the Wsb, Wbc and Wsg blocks are read from cfg "Qmodel", then squared"""
@@ -160,8 +177,11 @@ class HipBackend:
 
     def update(self):
         c = self.cfg
-        self.ctx.filter_update(c.visual_meas_std ** 2, c.MH_thresh, c.MH_adjust_factor, c.min_inliers, True)
+        self.ctx.filter_update(c.visual_meas_std ** 2, c.MH_thresh, c.MH_adjust_factor, c.min_inliers, bool(c.use_MH_gating))
         mask, _ = self.ctx.get_gate(self.F)
+        # a filter whose S was not positive definite keeps its prior P and absorbs nothing (device side); surfaced here
+        self.last_status = self.ctx.get_status(check=False)
+        self.n_not_spd = getattr(self, "n_not_spd", 0) + int((self.last_status != 0).sum())
         self.ctx.absorb_error()
         return mask
 
@@ -274,7 +294,8 @@ class SequenceRunner:
         # --- after the update: MH-rejected features leave, then new features enter with a new group
         ops = []
         fx, fy, cx, cy = cfg.cam["fx"], cfg.cam["fy"], cfg.cam["cx"], cfg.cam["cy"]
-        std = np.array([cfg.initial_std_x / fx, cfg.initial_std_y / fx, cfg.initial_std_z])
+        fl = cfg.focal_length()
+        std = np.array([cfg.initial_std_x / fl, cfg.initial_std_y / fl, cfg.initial_std_z])
         P3 = np.diag(std * std).T.reshape(-1)
         for b in range(self.B):
             bk = self.books[b]
