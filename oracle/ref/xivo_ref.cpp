@@ -391,13 +391,112 @@ struct RefProp {
     P_.block(kMotionSize, 0, kFullSize - kMotionSize, kMotionSize) =
         P_.block(kMotionSize, 0, kFullSize - kMotionSize, kMotionSize) * F_.transpose();
   }
-};
-}  // namespace
+  // Estimator::PrinceDormandStep, src/princedormand.cpp:85-221 (same members; the function-local statics are locals)
+  void PrinceDormandStep(const Vec3& gyro0, const Vec3& accel0, double dt) {
+    const int kMotionSize = 23;
+    const int kFullSize = (int)P_.rows();
+    const double r_9 = 1.0 / 9.0, r_2_9 = 2.0 / 9.0, r_12 = 1.0 / 12.0, r_324 = 1.0 / 324.0, r_330 = 1.0 / 330.0,
+                 r_28 = 1.0 / 28.0, r_400 = 1.0 / 400.0;
+    RefState X0;
+    Vec3 K1, K2, K3, K4, K5, K6, K7;
+    MatX FK1, FK2, FK3, FK4, FK5, FK6, FK7;
+    MatX PK1, PK2, PK3, PK4, PK5, PK6, PK7;
+    double step;
+    Eigen::Matrix<double, 6, 1> slope;
+    slope << slope_gyro_, slope_accel_;
+    Eigen::Matrix<double, 6, 1> gyro_accel0, gyro_accel;
+    gyro_accel0 << gyro0, accel0;
 
-extern "C" void ref_rk4_step(int N, double* state30, double* P, const double* gyro0, const double* accel0,
-                             const double* slope_gyro, const double* slope_accel, double dt, const double* Qimu,
-                             const double* g_vec) {
-  RefProp r;
+    X0 = X_;
+    K1 = X0.Vsb;
+    ComputeMotionJacobianAt(X0, gyro_accel0);
+    FK1 = F_;
+    MatX P0 = P_.block(0, 0, kMotionSize, kMotionSize);
+    PK1 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+
+    X0 = X_;
+    step = r_2_9 * dt;
+    gyro_accel = gyro_accel0 + slope * step;
+    ComposeMotion(X0, r_2_9 * (K1), gyro_accel, step);
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    K2 = X0.Vsb;
+    FK2 = F_ + F_ * r_2_9 * (FK1)*dt;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) + r_2_9 * (PK1)*dt;
+    PK2 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+
+    X0 = X_;
+    step = 3.0 * r_9 * dt;
+    gyro_accel = gyro_accel0 + slope * step;
+    ComposeMotion(X0, r_12 * (K1 + 3.0 * K2), gyro_accel, step);
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    K3 = X0.Vsb;
+    FK3 = F_ + F_ * r_12 * (FK1 + 3.0 * FK2) * dt;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) + r_12 * (PK1 + 3.0 * PK2) * dt;
+    PK3 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+
+    X0 = X_;
+    step = 5.0 * r_9 * dt;
+    gyro_accel = gyro_accel0 + slope * step;
+    ComposeMotion(X0, r_324 * (55.0 * K1 - 75.0 * K2 + 200.0 * K3), gyro_accel, step);
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    K4 = X0.Vsb;
+    FK4 = F_ + F_ * r_324 * (55.0 * FK1 - 75.0 * FK2 + 200.0 * FK3) * dt;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) + r_324 * (55.0 * PK1 - 75.0 * PK2 + 200.0 * PK3) * dt;
+    PK4 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+
+    X0 = X_;
+    step = 6.0 * r_9 * dt;
+    gyro_accel = gyro_accel0 + slope * step;
+    ComposeMotion(X0, r_330 * (83.0 * K1 - 195.0 * K2 + 305.0 * K3 + 27.0 * K4), gyro_accel, step);
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    K5 = X0.Vsb;
+    FK5 = F_ + F_ * r_330 * (83.0 * FK1 - 195.0 * FK2 + 305.0 * FK3 + 27.0 * FK4) * dt;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) + r_330 * (83.0 * PK1 - 195.0 * PK2 + 305.0 * PK3 + 27.0 * PK4) * dt;
+    PK5 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+
+    X0 = X_;
+    step = dt;
+    gyro_accel = gyro_accel0 + slope * step;
+    ComposeMotion(X0, r_28 * (-19.0 * K1 + 63.0 * K2 + 4.0 * K3 - 108.0 * K4 + 88.0 * K5), gyro_accel, step);
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    K6 = X0.Vsb;
+    FK6 = F_ + F_ * r_28 * (-19.0 * FK1 + 63.0 * FK2 + 4.0 * FK3 - 108.0 * FK4 + 88.0 * FK5) * dt;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) +
+         r_28 * (-19.0 * PK1 + 63.0 * PK2 + 4.0 * PK3 - 108.0 * PK4 + 88.0 * PK5) * dt;
+    PK6 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+
+    X0 = X_;
+    step = dt;
+    gyro_accel = gyro_accel0 + slope * step;
+    ComposeMotion(X0, r_400 * (38.0 * K1 + 240.0 * K3 - 243.0 * K4 + 330.0 * K5 + 35.0 * K6), gyro_accel, step);
+    ComputeMotionJacobianAt(X0, gyro_accel);
+    K7 = X0.Vsb;
+    FK7 = F_ + F_ * r_400 * (38.0 * FK1 + 240.0 * FK3 - 243.0 * FK4 + 330.0 * FK5 + 35.0 * FK6) * dt;
+    P0 = P_.block(0, 0, kMotionSize, kMotionSize) +
+         r_400 * (38.0 * PK1 + 240.0 * PK3 - 243.0 * PK4 + 330.0 * PK5 + 35.0 * PK6) * dt;
+    PK7 = F_ * P0 + P0 * F_.transpose() + G_ * Qimu_ * G_.transpose();
+
+    MatX K, FK, PK;
+    K = 0.0862 * K1 + 0.6660 * K3 - 0.7857 * K4 + 0.9570 * K5 + 0.0965 * K6 - 0.0200 * K7;
+    FK = 0.0862 * FK1 + 0.6660 * FK3 - 0.7857 * FK4 + 0.9570 * FK5 + 0.0965 * FK6 - 0.0200 * FK7;
+    PK = 0.0862 * PK1 + 0.6660 * PK3 - 0.7857 * PK4 + 0.9570 * PK5 + 0.0965 * PK6 - 0.0200 * PK7;
+
+    gyro_accel = gyro_accel0 + slope * dt;
+    ComposeMotion(X_, K, gyro_accel, dt);
+
+    F_.setIdentity(kMotionSize, kMotionSize);
+    F_ = F_ + FK * dt;
+
+    P_.block(0, 0, kMotionSize, kMotionSize).noalias() += PK * dt;
+    P_.block(0, kMotionSize, kMotionSize, kFullSize - kMotionSize) =
+        F_ * P_.block(0, kMotionSize, kMotionSize, kFullSize - kMotionSize);
+    P_.block(kMotionSize, 0, kFullSize - kMotionSize, kMotionSize) =
+        P_.block(kMotionSize, 0, kFullSize - kMotionSize, kMotionSize) * F_.transpose();
+  }
+};
+
+void load_prop(RefProp& r, int N, const double* state30, const double* P, const double* slope_gyro, const double* slope_accel,
+               const double* Qimu, const double* g_vec) {
   Mat3 R0 = Eigen::Map<const Mat3>(state30), Rg = Eigen::Map<const Mat3>(state30 + 21);
   r.X_.Rsb = SO3(Eigen::Quaterniond(R0));
   r.X_.Rsg = SO3(Eigen::Quaterniond(Rg));
@@ -408,9 +507,109 @@ extern "C" void ref_rk4_step(int N, double* state30, double* P, const double* gy
   r.g_ = Eigen::Map<const Vec3>(g_vec);
   r.slope_gyro_ = Eigen::Map<const Vec3>(slope_gyro); r.slope_accel_ = Eigen::Map<const Vec3>(slope_accel);
   r.Cg.setIdentity(); r.Ca.setIdentity();
-  r.RK4Step(Eigen::Map<const Vec3>(gyro0), Eigen::Map<const Vec3>(accel0), dt);
+}
+void store_prop(const RefProp& r, int N, double* state30, double* P) {
   Eigen::Map<Mat3> Ro(state30);
   Ro = r.X_.Rsb.matrix();
   (Eigen::Map<Vec3>(state30 + 9)) = r.X_.Tsb; (Eigen::Map<Vec3>(state30 + 12)) = r.X_.Vsb;
   (MapMatW(P, N, N)) = r.P_;
+}
+}  // namespace
+
+extern "C" void ref_pd_step(int N, double* state30, double* P, const double* gyro0, const double* accel0,
+                            const double* slope_gyro, const double* slope_accel, double dt, const double* Qimu,
+                            const double* g_vec) {
+  RefProp r;
+  load_prop(r, N, state30, P, slope_gyro, slope_accel, Qimu, g_vec);
+  r.PrinceDormandStep(Eigen::Map<const Vec3>(gyro0), Eigen::Map<const Vec3>(accel0), dt);
+  store_prop(r, N, state30, P);
+}
+
+// Estimator::OnePointRANSAC, src/update.cpp:213-393, numeric core up to and including the partial update (:238-332):
+// the low-innovation set (the hypothesis index k of :240-244 is drawn but never used, so the set is
+// {f : |xp - Predict| < ransac_thresh_}; xp - Predict == inn at the state the Jacobians were taken at), the temporary
+// reference group (FindNewRefGroup, src/estimator.cpp:1394-1407), the zeroing of P (:299-316), the stacking of the
+// FULL rows J() (:320-330) and UpdateJosephForm (:332). The caller continues with AbsorbError / ComputeJacobian /
+// the chi-square rescue through the functions above.
+//   J: F blocks of 2 x N (col-major), inn: F x 2, sind / ref: feature and anchor-group slots, gauge: slot of
+//   gauge_group_ptr_ (-1: none in the state). Outputs: low[F] (0/1), err[N], P_out (P after zeroing + update; = P if
+//   no update ran). Returns the number of low-innovation inliers, or -1 when all are (early return of :263-265).
+extern "C" int ref_one_point_ransac_core(int N, int F, const double* J, const double* inn, const double* P, const int* sind,
+                                         const int* ref, int gauge, int group_begin, int feature_begin, double R,
+                                         double ransac_thresh, int* low, double* err_out, double* P_out) {
+  const int kGroupBegin = group_begin, kFeatureBegin = feature_begin, kGroupSize = 6, kFeatureSize = 3;
+  MatX P_ = MapMat(P, N, N);
+  const int size = N;
+  std::vector<bool> is_low_innovation_inlier;
+  std::vector<int> groups_with_low_inn_inlier, active_groups;
+  int n_low = 0;
+  for (int i = 0; i < F; ++i) {
+    Vec2 res(inn[2 * i], inn[2 * i + 1]);
+    const bool in = res.norm() < ransac_thresh;                                      // :246-249
+    is_low_innovation_inlier.push_back(in);
+    low[i] = in ? 1 : 0;
+    n_low += in;
+    if (std::find(active_groups.begin(), active_groups.end(), ref[i]) == active_groups.end()) active_groups.push_back(ref[i]);
+    if (in && std::find(groups_with_low_inn_inlier.begin(), groups_with_low_inn_inlier.end(), ref[i]) == groups_with_low_inn_inlier.end())
+      groups_with_low_inn_inlier.push_back(ref[i]);
+  }
+  (MapMatW(P_out, N, N)) = P_;
+  for (int i = 0; i < N; ++i) err_out[i] = 0.0;
+  if (n_low == F) return -1;                                                         // :263-265
+  if (n_low > 0) {
+    if (std::find(groups_with_low_inn_inlier.begin(), groups_with_low_inn_inlier.end(), gauge) == groups_with_low_inn_inlier.end()) {
+      // FindNewRefGroup: std::min_element over the candidates by the summed 6 diagonal entries (first minimum wins).
+      // The reference iterates an unordered_set of pointers; here the candidates are visited in ascending slot order.
+      std::vector<int> candidates = groups_with_low_inn_inlier;
+      std::sort(candidates.begin(), candidates.end());
+      auto git = std::min_element(candidates.begin(), candidates.end(), [&](int g1, int g2) -> bool {
+        int offset1 = kGroupBegin + 6 * g1, offset2 = kGroupBegin + 6 * g2;
+        number_t cov1{0}, cov2{0};
+        for (int i = 0; i < 6; ++i) { cov1 += P_(offset1 + i, offset1 + i); cov2 += P_(offset2 + i, offset2 + i); }
+        return cov1 < cov2;
+      });
+      int offset = kGroupBegin + kGroupSize * (*git);
+      P_.block(offset, 0, kGroupSize, size).setZero();
+      P_.block(0, offset, size, kGroupSize).setZero();
+    }
+    for (int i = 0; i < F; ++i) {
+      if (!is_low_innovation_inlier[i]) {
+        int offset = kFeatureBegin + kFeatureSize * sind[i];
+        P_.block(offset, 0, kFeatureSize, size).setZero();
+        P_.block(0, offset, size, kFeatureSize).setZero();
+      }
+    }
+    for (int g : active_groups) {
+      if (std::find(groups_with_low_inn_inlier.begin(), groups_with_low_inn_inlier.end(), g) == groups_with_low_inn_inlier.end()) {
+        int offset = kGroupBegin + kGroupSize * g;
+        P_.block(offset, 0, kGroupSize, size).setZero();
+        P_.block(0, offset, size, kGroupSize).setZero();
+      }
+    }
+    MatX H_; VecX inn_, diagR_;
+    H_.setZero(2 * n_low, size);
+    inn_.setZero(2 * n_low);
+    diagR_.resize(2 * n_low);
+    int f_cnt = 0;
+    for (int i = 0; i < F; ++i) {
+      if (is_low_innovation_inlier[i]) {
+        H_.block(2 * f_cnt, 0, 2, size) = Eigen::Map<const Eigen::Matrix<double, 2, Eigen::Dynamic>>(J + (size_t)i * 2 * N, 2, N);
+        inn_.segment<2>(2 * f_cnt) = Vec2(inn[2 * i], inn[2 * i + 1]);
+        diagR_.segment<2>(2 * f_cnt) << R, R;
+        f_cnt++;
+      }
+    }
+    std::vector<double> Pin(P_.data(), P_.data() + (size_t)N * N);
+    ref_update_joseph(N, 2 * n_low, H_.data(), Pin.data(), inn_.data(), diagR_.data(), err_out, P_out);
+  }
+  return n_low;
+}
+
+extern "C" void ref_rk4_step(int N, double* state30, double* P, const double* gyro0, const double* accel0,
+                             const double* slope_gyro, const double* slope_accel, double dt, const double* Qimu,
+                             const double* g_vec) {
+  RefProp r;
+  load_prop(r, N, state30, P, slope_gyro, slope_accel, Qimu, g_vec);
+  r.RK4Step(Eigen::Map<const Vec3>(gyro0), Eigen::Map<const Vec3>(accel0), dt);
+  store_prop(r, N, state30, P);
 }

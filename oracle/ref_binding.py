@@ -175,6 +175,35 @@ class Ref:
                               _p(Qf), _p(keep[4]))
         return st[0:9].reshape(3, 3).T.copy(), st[9:12].copy(), st[12:15].copy(), np.ascontiguousarray(Pf)
 
+    def pd_step(self, X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec):
+        """Estimator::PrinceDormandStep (src/princedormand.cpp:85-221) restated on Sophus / Eigen. Returns (Rsb, Tsb, Vsb, P_new)."""
+        return self._step(self.lib.ref_pd_step, X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec)
+
+    def _step(self, fn, X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec):
+        N = P.shape[0]
+        st = np.concatenate([_F(X.Rsb).reshape(-1, order="F"), X.Tsb, X.Vsb, X.bg, X.ba, _F(X.Rsg).reshape(-1, order="F")])
+        st = np.ascontiguousarray(st, dtype=np.float64)
+        Pf = _F(P).copy(order="F")
+        Qf = _F(Qimu)
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (gyro0, accel0, slope_gyro, slope_accel, g_vec)]
+        fn(C.c_int(N), _p(st), _p(Pf), _p(keep[0]), _p(keep[1]), _p(keep[2]), _p(keep[3]), C.c_double(dt), _p(Qf), _p(keep[4]))
+        return st[0:9].reshape(3, 3).T.copy(), st[9:12].copy(), st[12:15].copy(), np.ascontiguousarray(Pf)
+
+    def one_point_ransac_core(self, J, inn, P, sind, ref, gauge, layout, R, ransac_thresh):
+        """Estimator::OnePointRANSAC (src/update.cpp:238-332): low-innovation set, temporary reference group, zeroing of
+        P, stacking of the full rows, UpdateJosephForm. J: [F, 2, N], inn: [F, 2]. Returns (n_low or -1, low mask, err,
+        P after zeroing + update)."""
+        F, _, N = J.shape
+        Jc = np.ascontiguousarray(np.stack([_F(J[i]).reshape(-1, order="F") for i in range(F)]))
+        innc = np.ascontiguousarray(inn, dtype=np.float64)
+        sind = np.ascontiguousarray(sind, dtype=np.int32); ref = np.ascontiguousarray(ref, dtype=np.int32)
+        low = np.zeros(F, dtype=np.int32); err = np.zeros(N); Pout = np.zeros((N, N), order="F")
+        self.lib.ref_one_point_ransac_core.restype = C.c_int
+        n = self.lib.ref_one_point_ransac_core(C.c_int(N), C.c_int(F), _p(Jc), _p(innc), _p(_F(P)), _p(sind), _p(ref),
+                                               C.c_int(int(gauge)), C.c_int(layout.group_begin), C.c_int(layout.feature_begin),
+                                               C.c_double(R), C.c_double(ransac_thresh), _p(low), _p(err), _p(Pout))
+        return n, low.astype(bool), err, np.ascontiguousarray(Pout)
+
     def so3_exp(self, w):
         R = np.empty((3, 3), order="F")
         self.lib.ref_so3_exp(_p(np.ascontiguousarray(w, dtype=np.float64)), _p(R))

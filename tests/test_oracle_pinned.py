@@ -305,3 +305,112 @@ def test_live_qr_compress_vs_ref(rows, cols, eff):
     n = r1
     assert np.abs(np.tril(H1[:n], -1)).max() < 1e-12
     assert abs(np.linalg.norm(H1[:n]) - np.linalg.norm(Hx[:n])) < 1e-10 and abs(np.linalg.norm(x1[:n]) - np.linalg.norm(x[:n])) < 1e-10
+
+
+# ---- round 2 pins: golden_v2.npz (tests/golden/make_golden_v2.py) ------------------------------------------------
+G2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v2.npz"))
+
+
+def _pd_inputs(tag):
+    g = lambda k: G2[f"pd_{tag}_{k}"]
+    X = orc.MotionState(g("Rsb"), g("Tsb"), g("Vsb"), g("bg"), g("ba"), g("Rsg"))
+    return X, g("P"), g("gyro"), g("accel"), g("sg"), g("sa"), float(g("dt")), g("Qimu"), g("g")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_golden_prince_dormand_step(tag):
+    """Tableau form of the oracle == line-by-line PrinceDormandStep on Sophus / Eigen (src/princedormand.cpp:85-221):
+    the 7 stages, the printed 4-digit combination weights (:195-200), ComposeMotion incl. normalize(), the covariance tail."""
+    X, P, gy, ac, sg, sa, dt, Qi, gv = _pd_inputs(tag)
+    Xn, Pn = orc.integrator_step(X, P, gy, ac, sg, sa, dt, Qi, gv, orc.PD_TABLEAU)
+    g = lambda k: G2[f"pd_{tag}_{k}"]
+    assert np.abs(Xn.Rsb - g("Rn")).max() < 1e-14 and np.abs(Xn.Tsb - g("Tn")).max() < 1e-15
+    assert np.abs(Xn.Vsb - g("Vn")).max() < 1e-15 and rel(Pn, g("Pn")) < 1e-14
+
+
+def test_live_prince_dormand_and_rk4_steps_vs_ref():
+    ref = _ref()
+    rng = np.random.default_rng(9)
+    for k in range(4):
+        N = 29 + 6 * k
+        A = rng.uniform(-1, 1, size=(N, N)); P = A @ A.T / N * 1e-3 + 1e-6 * np.eye(N)
+        X = orc.MotionState(orc.so3_exp(rng.normal(size=3) * 0.4), rng.normal(size=3), rng.normal(size=3),
+                            rng.normal(size=3) * 0.01, rng.normal(size=3) * 0.05, orc.so3_exp([0.02, -0.01, 0.0]))
+        gy, ac = rng.normal(size=3) * (1 + 3 * k), np.array([0.2, -0.1, 9.7]) + rng.normal(size=3)
+        sg, sa = rng.normal(size=3) * 5, rng.normal(size=3)
+        Qi = np.diag(rng.uniform(1e-6, 1e-3, 12)); gv = np.array([0.0, 0.0, -9.8]); dt = 0.001 * (1 + k)
+        for tab, fn in ((orc.PD_TABLEAU, ref.pd_step), (orc.RK4_TABLEAU, ref.rk4_step)):
+            R1, T1, V1, P1 = fn(X, P, gy, ac, sg, sa, dt, Qi, gv)
+            Xn, Pn = orc.integrator_step(X, P, gy, ac, sg, sa, dt, Qi, gv, tab)
+            assert np.abs(Xn.Rsb - R1).max() < 1e-13 and np.abs(Xn.Tsb - T1).max() < 1e-14 and np.abs(Xn.Vsb - V1).max() < 1e-13
+            assert rel(Pn, P1) < 1e-13
+
+
+def _ransac_state(tag):
+    g = lambda k: G2[f"rs_{tag}_in_{k}"]
+    st = dict(Rsb=g("Rsb").copy(), Tsb=g("Tsb").copy(), Vsb=np.zeros(3), bg=np.zeros(3), ba=np.zeros(3), Rbc=g("Rbc").copy(),
+              Tbc=g("Tbc").copy(), Rsg=np.eye(3), gR=g("gR").copy(), gT=g("gT").copy(), x=g("x").copy(), sind=g("sind"), ref=g("ref"))
+    return st, g("P"), g("xp"), lay_from(g("lay")), float(g("R")), float(g("thresh")), float(g("chi2")), int(g("gauge"))
+
+
+@pytest.mark.parametrize("tag,cam", [("pin", "pinhole"), ("rad", "radtan"), ("tmp", "equi")])
+def test_golden_one_point_ransac(tag, cam):
+    """The oracle's OnePointRANSAC (src/update.cpp:213-393) against the flow run on the reference's arithmetic: Eigen core
+    up to the partial UpdateJosephForm (low-innovation set, FindNewRefGroup, P zeroing, full-row stacking), Sophus exp in
+    AbsorbError, ComputeJacobian at the updated state, 2x2 LLT chi-square rescue. 'tmp': gauge group without a
+    low-innovation inlier -> temporary reference group path (:292-301)."""
+    st, P, xp, lay, R, th, c2, gauge = _ransac_state(tag)
+    ng = lay.n_groups
+    out = orc.one_point_ransac(st, P, xp, CAMS[cam], lay, R, th, c2, gauge, range(ng))
+    assert np.array_equal(out["low"], G2[f"rs_{tag}_low"]) and out["low"].sum() == int(G2[f"rs_{tag}_n_low"])
+    assert rel(out["err"], G2[f"rs_{tag}_err"]) < 1e-9 and rel(out["P_partial"], G2[f"rs_{tag}_P_partial"]) < 1e-11
+    chi = G2[f"rs_{tag}_chi"]
+    for i, d in out["chi2"].items():
+        assert abs(d - chi[i]) < 1e-7 * max(1.0, chi[i])
+    assert sorted(out["chi2"]) == list(np.nonzero(~G2[f"rs_{tag}_low"])[0])
+    assert out["inliers"] == list(G2[f"rs_{tag}_kept"])
+    assert len(out["rejected"]) >= 1 and len(out["inliers"]) > out["low"].sum()      # something rescued, something rejected
+
+
+def test_live_one_point_ransac_core_vs_ref():
+    ref = _ref()
+    for seed in range(6):
+        cam = [synth.PINHOLE, synth.EQUI, synth.RADTAN][seed % 3]
+        ng, nf = 4, 11
+        sc = synth.g_level(ng, nf, nf, 1, seed=100 + seed, cam=cam)
+        lay = orc.Layout(ng, nf)
+        rng = np.random.default_rng(seed)
+        A = rng.uniform(-1, 1, size=(lay.N, lay.N)); P = (A @ A.T / lay.N + 1e-3 * np.eye(lay.N)) * 1e-4
+        xp = np.array([orc.camera_project(cam, sc["Xcn"][0, i][:2] / sc["Xcn"][0, i][2])[0] for i in range(nf)])
+        xp += rng.normal(size=xp.shape) * 1.2
+        st = dict(Rsb=sc["Rsb"][0], Tsb=sc["Tsb"][0], Vsb=np.zeros(3), bg=np.zeros(3), ba=np.zeros(3), Rbc=sc["Rbc"][0],
+                  Tbc=sc["Tbc"][0], Rsg=np.eye(3), gR=sc["gR"][0].copy(), gT=sc["gT"][0].copy(), x=sc["x"][0].copy(),
+                  sind=sc["sind"][0], ref=sc["ref"][0])
+        gauge = -1 if seed % 2 else 0
+        out = orc.one_point_ransac(st, P, xp, cam, lay, 1.0, 1.8, 5.89, gauge, range(ng))
+        J = []; inn = []
+        for i in range(nf):
+            r = int(st["ref"][i])
+            Ji, ii, _ = ref.compute_jacobian(st["x"][i], xp[i], st["gR"][r], st["gT"][r], st["Rsb"], st["Tsb"], st["Rbc"], st["Tbc"],
+                                             cam, lay, r, int(st["sind"][i]))
+            J.append(Ji); inn.append(ii)
+        n, low, err, P2 = ref.one_point_ransac_core(np.array(J), np.array(inn), P, st["sind"], st["ref"], gauge, lay, 1.0, 1.8)
+        assert np.array_equal(low, out["low"])
+        if n == -1:
+            assert out["low"].all()
+        elif n > 0:
+            assert rel(out["err"], err) < 1e-9 and rel(out["P_partial"], P2) < 1e-11
+
+
+@pytest.mark.parametrize("tag", ["150", "250"])
+def test_golden_update_joseph_at_baseline_sizes(tag):
+    """a1 at BASELINE.json's synthetic sizes (150, 50) and (250, 80) against the Eigen driver's LDLT / dense products."""
+    import hashlib
+    N, F, seed = [int(v) for v in G2[f"ujb_{tag}_seed"]]
+    P, H, inn, dR = synth.s_level(N, F, 1, seed=seed)
+    h = hashlib.sha256()
+    for a in (P[0], H[0], inn[0], dR[0]):
+        h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), G2[f"ujb_{tag}_sha"]), "synthetic input generator drifted"
+    err, Pn, _ = orc.update_joseph(H[0], P[0], inn[0], dR[0])
+    assert rel(err, G2[f"ujb_{tag}_err"]) < 1e-9 and rel(Pn, G2[f"ujb_{tag}_Pn"]) < 1e-11
