@@ -233,6 +233,21 @@ int xivo_hip_stack(xivo_hip_ctx* ctx, int B, double R);
  * previous call again (it stays resident; same nb and n_oos) - for a caller that re-linearises without new tracks. */
 int xivo_hip_oos_project(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xivo_oos_in* feats,
                          double Roos, int* rows_out);
+/* Estimator::OnePointRANSAC (src/update.cpp:213-393) for filters [0,B) on the resident state; call after
+ * xivo_hip_jacobians_instate + xivo_hip_mh_gate (the MH inliers are the input set, as OutlierRejection hands them over,
+ * src/manager.cpp:629-650). Low-innovation set {|inn| < ransac_thresh} (the hypothesis loop of :238-258 never uses its
+ * random index), BackupState on the device, P rows/cols of non-members zeroed (+ a temporary reference group when
+ * gauge_group[b] holds no low-innovation inlier, FindNewRefGroup), partial UpdateJosephForm on the full rows J() +
+ * AbsorbError, Jacobians at the updated state, chi-square rescue with ransac_chi2, RestoreState, Jacobians at the
+ * original state. The resulting inlier set REPLACES the MH mask: a following xivo_hip_stack / xivo_hip_update_joseph /
+ * xivo_hip_absorb_error runs on it.
+ *   gauge_group   host [B]: slot of gauge_group_ptr_, -1 = none (NULL: none for every filter)
+ *   absorb_groups host [B]: bit g = group slot g is in instate_groups_ when the partial update is absorbed (that list is
+ *                 the previous frame's, src/manager.cpp:103); NULL = every slot
+ *   inlier_mask_out / chi2_out [B x F], n_rejected_out [B]: host, any may be NULL. chi2 is 0 for features not tested. */
+int xivo_hip_one_point_ransac(xivo_hip_ctx* ctx, int B, double R, double ransac_thresh, double ransac_chi2,
+                              const int* gauge_group, const unsigned long long* absorb_groups,
+                              unsigned char* inlier_mask_out, double* chi2_out, int* n_rejected_out);
 /* jac -> gate -> stack -> UpdateJosephForm in one call (Estimator::UpdateStep's
  * numeric core, src/manager.cpp:72-104) */
 int xivo_hip_filter_update(xivo_hip_ctx* ctx, int B, double R, double mh_thresh, double mh_mult,

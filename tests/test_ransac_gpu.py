@@ -1,0 +1,104 @@
+"""Estimator::OnePointRANSAC (src/update.cpp:213-393) as ONE batched entry point on the resident state
+(xivo_hip_one_point_ransac) against the oracle restatement, which is pinned to the reference's Eigen / Sophus arithmetic
+(tests/test_oracle_pinned.py::test_golden_one_point_ransac). 64 filters of one call, ragged: different numbers of
+present features, of outliers, gauge groups with and without a low-innovation inlier, filters where every inlier is
+low-innovation (early return) and where none is (rescue against the prior)."""
+import numpy as np
+import pytest
+
+import xivo_oracle as orc
+from helpers import rel_fro, TOL_P, TOL_DX
+from scene_util import scene_arrays, spd
+from xivo_amd import synth
+from xivo_amd.lib import Context, FLAG_FIX_GROUP_BLOCK
+
+pytestmark = pytest.mark.gpu
+R_VIS, MH, MULT = 1.0, 5.991, 1.1
+THRESH, CHI2 = 2.0, 5.89
+
+
+def _state(sc, b, xp_b):
+    return dict(Rsb=sc["Rsb"][b].copy(), Tsb=sc["Tsb"][b].copy(), Vsb=np.zeros(3), bg=np.zeros(3), ba=np.zeros(3),
+                Rbc=sc["Rbc"][b].copy(), Tbc=sc["Tbc"][b].copy(), Rsg=np.eye(3), gR=sc["gR"][b].copy(), gT=sc["gT"][b].copy(),
+                x=sc["x"][b].copy(), sind=sc["sind"][b], ref=sc["ref"][b])
+
+
+def _sub(st, idx):
+    s = dict(st)
+    s["x"], s["sind"], s["ref"] = st["x"][idx], st["sind"][idx], st["ref"][idx]
+    return s
+
+
+@pytest.mark.parametrize("flags", [0, FLAG_FIX_GROUP_BLOCK])
+def test_batched_ransac_matches_oracle(built, flags):
+    cam = synth.RADTAN
+    B, ng, nf = 64, 5, 14
+    sc = synth.g_level(ng, nf, nf, B, seed=77, cam=cam)
+    lay = orc.Layout(ng, nf, N=sc["N"])
+    rng = np.random.default_rng(5)
+    poses, groups, feats, xp = scene_arrays(sc, cam)
+    xp = xp + rng.normal(size=xp.shape) * 0.3
+    gauge = np.zeros(B, dtype=np.int32)
+    for b in range(B):
+        kind = b % 8
+        n_present = [14, 14, 9, 14, 6, 14, 14, 11][kind]
+        feats["sind"][b, n_present:] = -1                      # ragged: absent entries
+        if kind in (0, 2, 5, 7):                               # a few high-innovation features, one hopeless
+            far = rng.choice(n_present, size=3 + b % 2, replace=False)
+            xp[b, far[:-1]] += rng.choice([-1, 1], size=(len(far) - 1, 2)) * rng.uniform(2.0, 4.0, size=(len(far) - 1, 2))
+            xp[b, far[-1]] += 35.0
+        elif kind == 3:                                        # nothing is low-innovation: rescue against the prior
+            xp[b, :n_present] += rng.choice([-1, 1], size=(n_present, 2)) * rng.uniform(2.5, 3.5, size=(n_present, 2))
+        # kinds 1, 4, 6: everything low-innovation (early return)
+        gauge[b] = -1 if kind in (2, 7) else int(rng.integers(0, ng))
+    feats["xp"] = xp
+    P = np.array([spd(lay.N, 300 + b) * 1e-4 for b in range(B)])
+    with Context(lay.N, 2 * nf, B, flags=flags) as ctx:
+        ctx.set_layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf, cam)
+        ctx.upload_P(P)
+        ctx.set_scene(poses, groups, feats)
+        ctx.jacobians_instate()
+        mh_mask, _ = ctx.mh_gate(R_VIS, MH, MULT, 5)
+        J0, inn0 = ctx.get_jacobians()
+        keep, chi, nrej = ctx.one_point_ransac(R_VIS, THRESH, CHI2, gauge=gauge)
+        # RestoreState: covariance, nominal state and Jacobians are exactly what they were
+        assert np.array_equal(ctx.download_P(), P)
+        p2, g2, _ = ctx.get_scene()
+        assert np.array_equal(p2["Rsb"], poses["Rsb"]) and np.array_equal(g2["Tsb"], groups["Tsb"])
+        J1, inn1 = ctx.get_jacobians()
+        assert np.array_equal(J0, J1) and np.array_equal(inn0, inn1)
+        # the RANSAC inlier set is what the following update stacks and absorbs
+        ctx.stack(R_VIS)
+        ctx.update_joseph()
+        Pn, err = ctx.download_P(), ctx.get_err()
+    seen = dict(early=0, partial=0, prior=0, tmpref=0, rejected=0, rescued=0)
+    for b in range(B):
+        idx = np.nonzero(mh_mask[b])[0]                        # OnePointRANSAC is handed the MH inliers
+        st = _state(sc, b, xp[b])
+        out = orc.one_point_ransac(_sub(st, idx), P[b], xp[b][idx], cam, lay, R_VIS, THRESH, CHI2, int(gauge[b]), range(ng))
+        exp = np.zeros(nf, dtype=bool); exp[idx[out["inliers"]]] = True
+        assert np.array_equal(keep[b], exp), b
+        assert nrej[b] == len(out["rejected"])
+        for i, d in out["chi2"].items():
+            assert abs(chi[b, idx[i]] - d) < 1e-7 * max(1.0, d), (b, i)
+        low = out["low"]
+        seen["early"] += low.all(); seen["prior"] += (not low.any()); seen["partial"] += (low.any() and not low.all())
+        seen["tmpref"] += (low.any() and not low.all() and gauge[b] not in set(st["ref"][idx][low]))
+        seen["rejected"] += len(out["rejected"]); seen["rescued"] += len(out["inliers"]) - int(low.sum())
+        # the update that follows, on the RANSAC inliers (as-coded or full-row stacking per the context flag)
+        fix = bool(flags & FLAG_FIX_GROUP_BLOCK)
+        Js, inns = [], []
+        for i in np.nonzero(exp)[0]:
+            r = int(st["ref"][i])
+            Jf, innf, _ = orc.compute_jacobian(st["x"][i], xp[b, i], st["gR"][r], st["gT"][r], st["Rsb"], st["Tsb"], st["Rbc"], st["Tbc"],
+                                               cam, lay, r, int(st["sind"][i]))
+            Js.append(Jf); inns.append(innf)
+        if Js:
+            kept = np.nonzero(exp)[0]
+            H, inn, dR = orc.stack_measurements(np.array(Js), np.array(inns), st["ref"][kept], st["sind"][kept], lay, R_VIS,
+                                                fix_group_block=fix)
+            e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+            assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+    # the batch really exercises every branch
+    assert seen["early"] >= 8 and seen["partial"] >= 16 and seen["prior"] >= 4 and seen["tmpref"] >= 4
+    assert seen["rejected"] >= 16 and seen["rescued"] >= 8, seen

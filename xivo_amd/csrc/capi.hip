@@ -58,6 +58,13 @@ struct xivo_hip_ctx {
   int Fmax = 0, F = 0;
   xivo_pose_in* poses = nullptr;
   int* absorb_count = nullptr;   // State::counter of every filter (src/core.h:120-122)
+  // OnePointRANSAC scratch (allocated on first use): BackupState copies, selection results
+  double* Prs = nullptr; xivo_pose_in* poses_rs = nullptr; xivo_group_in* groups_rs = nullptr;
+  unsigned char *rs_low = nullptr, *rs_lowkeep = nullptr, *rs_keep = nullptr;
+  unsigned long long *rs_zg = nullptr, *rs_gmask = nullptr;
+  int *rs_state = nullptr, *rs_gauge = nullptr, *rs_nrej = nullptr;
+  double* rs_chi = nullptr;
+  int rs_Fmax = 0;
   xivo_group_in* groups = nullptr;
   xivo_feat_in* feats = nullptr;
   double *J = nullptr, *finn = nullptr, *dist = nullptr;
@@ -280,7 +287,8 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
-                  c->mask, c->rows_instate, c->absorb_count, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf};
+                  c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
@@ -930,11 +938,12 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
   return XIVO_HIP_OK;
 }
 
-static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense) {
+static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigned char* mask_override = nullptr, int full_rows = 0) {
   StackArgs a;
   a.sb = scene_buffers(c); a.lay = c->lay; a.mb = meas_buffers(c);
+  if (mask_override) a.sb.mask = mask_override;
   a.Mp = c->Mpmax; a.Np = c->Np; a.batch = B; a.R = R;
-  a.fix_group_block = (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK) ? 1 : 0;
+  a.fix_group_block = (full_rows || (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK)) ? 1 : 0;
   a.rows_instate = c->rows_instate;
   a.ell = c->ell; a.emit_ell = 1; a.write_dense = write_dense;
   StageTimer st(c, ST_STACK, 0.0, "stack_kernel");
@@ -1012,6 +1021,95 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->M += max_rows; c->Mp = round_up16(c->M);
   for (int b = b0; b < b0 + nb; ++b) c->ell_over_h[b] = 1;   // OOS rows are dense over the group blocks: dense path
+  return XIVO_HIP_OK;
+}
+
+// Estimator::OnePointRANSAC (src/update.cpp:213-393) for filters [0,B) on the resident state, after
+// xivo_hip_jacobians_instate + xivo_hip_mh_gate (the MH inlier mask is the input set):
+//   select (low-innovation set, temporary reference group)                       :238-301   ransac_select_kernel
+//   BackupState: P, nominal state, groups                                        :283       device-to-device copies
+//   zero P rows / cols of non-members                                            :299-316   ransac_zero_kernel
+//   partial update on the FULL rows J() of the low-innovation set + AbsorbError  :320-333   stack (full rows) + update + absorb
+//   re-Jacobians at the updated state, chi-square rescue                         :343-369   jac_instate + ransac_rescue_kernel
+//   RestoreState, re-Jacobians at the original state                             :383-387
+// The resulting inlier set replaces the MH mask (what xivo_hip_stack / xivo_hip_absorb_error read afterwards).
+int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_thresh, double ransac_chi2,
+                              const int* gauge_group, const unsigned long long* absorb_groups,
+                              unsigned char* inlier_mask_out, double* chi2_out, int* n_rejected_out) {
+  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0 || !c->mask || !c->poses) return XIVO_HIP_ERR_INVALID;
+  if (c->lay.n_groups > 64) return XIVO_HIP_ERR_UNSUPPORTED;
+  const size_t Bm = c->Bmax, ng = c->lay.n_groups;
+  if (!c->Prs || c->rs_Fmax != c->Fmax) {
+    void* olds[] = {c->rs_low, c->rs_lowkeep, c->rs_keep, c->rs_chi};
+    for (void* p : olds) if (p) hipFree(p);
+    c->rs_low = c->rs_lowkeep = c->rs_keep = nullptr; c->rs_chi = nullptr;
+    int rc = XIVO_HIP_OK;
+    auto A = [&](auto** p, size_t n) { if (rc == XIVO_HIP_OK && !*p) rc = dev_alloc(p, n); };
+    A(&c->Prs, Bm * c->sP); A(&c->poses_rs, Bm); A(&c->groups_rs, Bm * ng);
+    A(&c->rs_low, Bm * c->Fmax); A(&c->rs_lowkeep, Bm * c->Fmax); A(&c->rs_keep, Bm * c->Fmax); A(&c->rs_chi, Bm * c->Fmax);
+    A(&c->rs_zg, Bm); A(&c->rs_gmask, Bm); A(&c->rs_state, Bm); A(&c->rs_gauge, Bm); A(&c->rs_nrej, Bm);
+    if (rc) return rc;
+    c->rs_Fmax = c->Fmax;
+  }
+  if (gauge_group) HIP_TRY(hipMemcpyAsync(c->rs_gauge, gauge_group, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  else HIP_TRY(hipMemsetAsync(c->rs_gauge, 0xFF, (size_t)B * sizeof(int), c->stream));
+  if (absorb_groups) HIP_TRY(hipMemcpyAsync(c->rs_gmask, absorb_groups, (size_t)B * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+  RansacArgs a;
+  a.sb = scene_buffers(c); a.lay = c->lay; a.P = c->P; a.strideP = c->sP; a.ldp = c->Np; a.Np = c->Np;
+  a.R = R; a.thresh = ransac_thresh; a.chi2 = ransac_chi2; a.gauge = c->rs_gauge;
+  a.low = c->rs_low; a.low_keep = c->rs_lowkeep; a.zero_groups = c->rs_zg; a.state = c->rs_state;
+  a.keep = c->rs_keep; a.chi = c->rs_chi; a.n_rejected = c->rs_nrej; a.batch = B;
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "ransac_select_kernel");
+    if (launch_ransac_select(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  // the low-innovation set as select found it (filters with nothing to update get an all-neutral stacking mask)
+  HIP_TRY(hipMemcpyAsync(c->rs_lowkeep, c->rs_low, (size_t)B * c->Fmax, hipMemcpyDeviceToDevice, c->stream));
+  // BackupState (src/estimator.cpp:1410-1428)
+  HIP_TRY(hipMemcpyAsync(c->Prs, c->P, (size_t)B * c->sP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->poses_rs, c->poses, (size_t)B * sizeof(xivo_pose_in), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->groups_rs, c->groups, (size_t)B * ng * sizeof(xivo_group_in), hipMemcpyDeviceToDevice, c->stream));
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "ransac_zero_kernel");
+    if (launch_ransac_zero(a, c->P, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  // partial update: H_ rows = the full J() of the low-innovation inliers (:326 - no FillJacobianBlock), R_ on the diagonal
+  c->M = 2 * c->F; c->Mp = round_up16(c->M);
+  for (int b = 0; b < B; ++b) { c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12; c->ell_pw_h[b] = 9; }
+  const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
+  c->dense_valid = dense != 0; c->dense_from_ell = true; c->stack_R = R; c->stack_B = B;
+  int rc = stack_impl(c, B, R, dense, c->rs_low, 1);
+  if (rc) return rc;
+  rc = xivo_hip_update_joseph(c, B);
+  if (rc) return rc;
+  {  // AbsorbError (:333): in_current_ekf_update_ is empty at this point of Estimator::UpdateStep (cleared at
+     // src/manager.cpp:28, filled after OutlierRejection), so no feature state moves; State::counter is restored with X_
+    AbsorbArgs ab;
+    ab.poses = c->poses; ab.groups = c->groups; ab.feats = c->feats; ab.mask = nullptr; ab.err = c->err; ab.strideErr = c->Np;
+    ab.lay = c->lay; ab.F = c->F; ab.Fmax = c->Fmax; ab.batch = B; ab.counter = nullptr; ab.status = c->status;
+    ab.group_mask = absorb_groups ? c->rs_gmask : nullptr;
+    StageTimer st(c, ST_OTHER, 0.0, "absorb_error_kernel");
+    if (launch_absorb_error(ab, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  rc = xivo_hip_jacobians_instate(c, B);                                   // :348 at the updated state
+  if (rc) return rc;
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "ransac_rescue_kernel");
+    if (launch_ransac_rescue(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  // RestoreState + Jacobians at the original state (:383-387)
+  HIP_TRY(hipMemcpyAsync(c->P, c->Prs, (size_t)B * c->sP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->poses, c->poses_rs, (size_t)B * sizeof(xivo_pose_in), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->groups, c->groups_rs, (size_t)B * ng * sizeof(xivo_group_in), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->mask, c->rs_keep, (size_t)B * c->Fmax, hipMemcpyDeviceToDevice, c->stream));
+  rc = xivo_hip_jacobians_instate(c, B);
+  if (rc) return rc;
+  c->gate_sparse_last = 1;
+  const size_t F = c->F, Fm = c->Fmax;
+  if (inlier_mask_out) { rc = d2h_rows(c, inlier_mask_out, F, c->mask, Fm, F, B); if (rc) return rc; }
+  if (chi2_out) { rc = d2h_rows(c, chi2_out, F * sizeof(double), c->rs_chi, Fm * sizeof(double), F * sizeof(double), B); if (rc) return rc; }
+  if (n_rejected_out) HIP_TRY(hipMemcpyAsync(n_rejected_out, c->rs_nrej, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));   // gauge_group / absorb_groups are borrowed host memory
   return XIVO_HIP_OK;
 }
 

@@ -100,9 +100,27 @@ struct AbsorbArgs {
   xivo_pose_in* poses; xivo_group_in* groups; xivo_feat_in* feats; const unsigned char* mask;
   double* err; long strideErr; xivo_layout lay; int F, Fmax, batch;
   const int* status;   // [batch] factorisation status of the update that produced err: non-zero -> nothing is absorbed, err <- 0
+  const unsigned long long* group_mask;   // optional [batch]: bit g = group slot g is in instate_groups_ (null: every slot)
   int* counter;   // [batch] State::counter (core.h:120-122): absorbs so far, drives the periodic SO3 re-normalisation
 };
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s);
+
+// Estimator::OnePointRANSAC on the resident state (update.cpp:213-393): selection, P zeroing, rescue test
+struct RansacArgs {
+  SceneBuffers sb; xivo_layout lay;
+  const double* P; long strideP; int ldp; int Np;
+  double R, thresh, chi2;
+  const int* gauge;                 // [batch] slot of gauge_group_ptr_ (-1: none), may be null
+  unsigned char* low;               // [batch x Fmax] out: low-innovation set (all 0 for filters in state 0 / 2)
+  const unsigned char* low_keep;    // rescue: the set select found (a copy - `low` doubles as the stacking mask)
+  unsigned long long* zero_groups;  // [batch] out
+  int* state;                       // [batch] out: 0 nothing to do, 1 partial update + rescue, 2 rescue against the prior
+  unsigned char* keep; double* chi; int* n_rejected;   // rescue outputs
+  int batch;
+};
+int launch_ransac_select(const RansacArgs& a, hipStream_t s);
+int launch_ransac_zero(const RansacArgs& a, double* P, hipStream_t s);
+int launch_ransac_rescue(const RansacArgs& a, hipStream_t s);
 
 // batched resident edits (xivo_hip_edit_batch): wg_filter[w] = filter of workgroup w, its ops are
 // ops[wg_begin[w] .. wg_begin[w + 1])

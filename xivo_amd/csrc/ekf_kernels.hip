@@ -345,6 +345,29 @@ __device__ __forceinline__ int jcol(const xivo_layout& lay, const xivo_feat_in& 
   }
 }
 
+// res^T (J P J^T + R I2)^-1 res of one feature by one wave64 (src/update.cpp:60-70, :352-356): the 21 x 21 sub-block of
+// P the full row J touches, reduced across lanes, 2x2 LLT. The value is valid in every lane.
+__device__ __forceinline__ double feature_chi2(const double* P, int ldp, const xivo_layout& lay, const xivo_feat_in& ft,
+                                               const double* J, const double* inn, double R, int lane) {
+  double v = 0.0;
+  const int ra = lane % 21, rc = lane / 21;  // lanes 0..41 active: (P J^T)(a, c)
+  if (lane < 42) {
+    const int ia = jcol(lay, ft, ra);
+    for (int b = 0; b < 21; ++b) {
+      const int ib = jcol(lay, ft, b);
+      v = fma(P[ia + (long)ib * ldp], J[rc * 21 + b], v);
+    }
+  }
+  const double j0 = lane < 42 ? J[ra] : 0.0, j1 = lane < 42 ? J[21 + ra] : 0.0;
+  double s00 = (lane < 21) ? j0 * v : 0.0;
+  double s10 = (lane < 21) ? j1 * v : 0.0;
+  double s11 = (lane >= 21 && lane < 42) ? j1 * v : 0.0;
+  s00 = wave_sum(s00) + R;
+  s10 = wave_sum(s10);
+  s11 = wave_sum(s11) + R;
+  return mh_dist_2x2(s00, s10, s11, inn[0], inn[1]);
+}
+
 // One workgroup per filter; a wave64 per feature computes S = J P J^T + R I2
 // from the 21 x 21 sub-block of P the feature touches (J is structurally
 // sparse), reduces it across lanes, and the 2x2 LLT gives the Mahalanobis
@@ -374,23 +397,8 @@ __global__ __launch_bounds__(256) void gate_sparse_kernel(GateArgs a) {
       if (ft.sind < 0) { if (lane == 0) sdist[f] = __builtin_inf(); continue; }
       const double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
       const double* inn = sb.finn + ((long)filt * sb.Fmax + f) * 2;
-      double v = 0.0;
-      const int ra = lane % 21, rc = lane / 21;  // lanes 0..41 active: (P J^T)(a, c)
-      if (lane < 42) {
-        const int ia = jcol(a.lay, ft, ra);
-        for (int b = 0; b < 21; ++b) {
-          const int ib = jcol(a.lay, ft, b);
-          v = fma(P[ia + (long)ib * a.ldp], J[rc * 21 + b], v);
-        }
-      }
-      const double j0 = lane < 42 ? J[ra] : 0.0, j1 = lane < 42 ? J[21 + ra] : 0.0;
-      double s00 = (lane < 21) ? j0 * v : 0.0;
-      double s10 = (lane < 21) ? j1 * v : 0.0;
-      double s11 = (lane >= 21 && lane < 42) ? j1 * v : 0.0;
-      s00 = wave_sum(s00) + a.R;
-      s10 = wave_sum(s10);
-      s11 = wave_sum(s11) + a.R;
-      if (lane == 0) sdist[f] = mh_dist_2x2(s00, s10, s11, inn[0], inn[1]);
+      const double d = feature_chi2(P, a.ldp, a.lay, ft, J, inn, a.R, lane);
+      if (lane == 0) sdist[f] = d;
     }
     __syncthreads();
     if (wave == 0) {
@@ -850,13 +858,15 @@ __global__ __launch_bounds__(256) void absorb_error_kernel(AbsorbArgs a) {
       rot_zero_log_z(X.Rsg);
     }
   }
+  const unsigned long long gmask = a.group_mask ? a.group_mask[filt] : ~0ull;   // instate_groups_ (estimator.cpp:897)
   for (int g = tid; g < a.lay.n_groups; g += 256) {      // SO3xR3::operator+= (group.h:25-29); empty slots have dx = 0
+    if (g < 64 && !((gmask >> g) & 1ull)) continue;
     xivo_group_in& G = a.groups[(long)filt * a.lay.n_groups + g];
     const int off = a.lay.group_begin + 6 * g;
     rot_retract(G.Rsb, err[off], err[off + 1], err[off + 2]);
     for (int i = 0; i < 3; ++i) G.Tsb[i] += err[off + 3 + i];
   }
-  for (int f = tid; f < a.F; f += 256) {                 // Feature::UpdateState for in_current_ekf_update_ (estimator.cpp:906-912)
+  for (int f = tid; f < (a.mask ? a.F : 0); f += 256) {  // Feature::UpdateState for in_current_ekf_update_ (estimator.cpp:906-912)
     if (!a.mask[(long)filt * a.Fmax + f]) continue;
     xivo_feat_in& ft = a.feats[(long)filt * a.Fmax + f];
     if (ft.sind < 0) continue;
@@ -1568,6 +1578,116 @@ __global__ __launch_bounds__(256, NS == 4 ? 3 : 2) void propagate_state_kernel(P
   }
 }
 
+// ---------------------------------------------------------------- Estimator::OnePointRANSAC (src/update.cpp:213-393)
+// select: the low-innovation set among the MH inliers (:238-258 - the hypothesis index k is drawn but never used, so
+// the maximal set is {f : |xp - Predict| < ransac_thresh_}; xp - Predict is the innovation of the Jacobian pass), the
+// groups that hold one, the temporary reference group when gauge_group_ptr_ holds none (FindNewRefGroup,
+// src/estimator.cpp:1394-1407: smallest summed 6 diagonal entries of P, ascending slot order) and what has to be
+// zeroed in P (:299-316). state: 0 = every MH inlier is low-innovation (or there is none): nothing to do (:263-265);
+// 1 = partial update + rescue; 2 = no low-innovation inlier: rescue against the prior (:287 guard).
+__global__ __launch_bounds__(64) void ransac_select_kernel(RansacArgs a) {
+  const int filt = blockIdx.x, lane = threadIdx.x;
+  const SceneBuffers& sb = a.sb;
+  const double* P = a.P + (long)filt * a.strideP;
+  unsigned long long active = 0, withlow = 0;
+  int n_mh = 0, n_low = 0;
+  for (int f0 = 0; f0 < sb.F; f0 += 64) {
+    const int f = f0 + lane;
+    bool mh = false, low = false;
+    int ref = 0;
+    if (f < sb.F) {
+      const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+      mh = sb.mask[(long)filt * sb.Fmax + f] && ft.sind >= 0;
+      ref = mh ? ft.ref_sind : 0;
+      const double r0 = sb.finn[((long)filt * sb.Fmax + f) * 2], r1 = sb.finn[((long)filt * sb.Fmax + f) * 2 + 1];
+      low = mh && sqrt(r0 * r0 + r1 * r1) < a.thresh;
+      a.low[(long)filt * sb.Fmax + f] = low ? 1 : 0;
+    }
+    n_mh += __popcll(__ballot(mh));
+    n_low += __popcll(__ballot(low));
+    unsigned long long ma = mh ? 1ull << ref : 0ull, ml = low ? 1ull << ref : 0ull;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      ma |= __shfl_xor(ma, o);
+      ml |= __shfl_xor(ml, o);
+    }
+    active |= ma; withlow |= ml;
+  }
+  int state = 1;
+  unsigned long long zg = 0;
+  if (n_mh == 0 || n_low == n_mh) state = 0;
+  else if (n_low == 0) state = 2;
+  if (state == 1) {
+    const int gauge = a.gauge ? a.gauge[filt] : -1;
+    if (gauge < 0 || gauge >= 64 || !((withlow >> gauge) & 1ull)) {
+      double best = __builtin_inf();
+      int arg = -1;
+      for (int g = 0; g < a.lay.n_groups; ++g) {                    // wave-uniform loop
+        if (!((withlow >> g) & 1ull)) continue;
+        const int off = a.lay.group_begin + 6 * g;
+        double cov = 0.0;
+        for (int i = 0; i < 6; ++i) cov += P[(off + i) + (long)(off + i) * a.ldp];
+        if (cov < best) { best = cov; arg = g; }
+      }
+      if (arg >= 0) zg |= 1ull << arg;
+    }
+    zg |= active & ~withlow;
+  } else {
+    // nothing is updated for this filter: an all-neutral measurement set leaves P and the state untouched
+    for (int f = lane; f < sb.F; f += 64) a.low[(long)filt * sb.Fmax + f] = 0;
+  }
+  if (lane == 0) { a.state[filt] = state; a.zero_groups[filt] = zg; }
+}
+
+// P rows / columns of the MH inliers outside the low-innovation set and of the groups named by select (:299-316)
+__global__ __launch_bounds__(256) void ransac_zero_kernel(RansacArgs a, double* Pall) {
+  const int filt = blockIdx.x, tid = threadIdx.x;
+  if (a.state[filt] != 1) return;
+  const SceneBuffers& sb = a.sb;
+  double* P = Pall + (long)filt * a.strideP;
+  const unsigned long long zg = a.zero_groups[filt];
+  for (int g = 0; g < a.lay.n_groups; ++g) {
+    if (!((zg >> g) & 1ull)) continue;
+    const int off = a.lay.group_begin + 6 * g;
+    for (int t = tid; t < a.Np; t += 256)
+      for (int r = 0; r < 6; ++r) { P[(off + r) + (long)t * a.ldp] = 0.0; P[t + (long)(off + r) * a.ldp] = 0.0; }
+  }
+  for (int f = 0; f < sb.F; ++f) {
+    const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+    if (!(sb.mask[(long)filt * sb.Fmax + f] && ft.sind >= 0) || a.low[(long)filt * sb.Fmax + f]) continue;
+    const int off = a.lay.feature_begin + 3 * ft.sind;
+    for (int t = tid; t < a.Np; t += 256)
+      for (int r = 0; r < 3; ++r) { P[(off + r) + (long)t * a.ldp] = 0.0; P[t + (long)(off + r) * a.ldp] = 0.0; }
+  }
+}
+
+// rescue (:343-369): chi-square test of every MH inlier outside the low-innovation set with the Jacobians re-taken at
+// the partially updated state against the partially updated P; the final inlier mask replaces the MH mask.
+__global__ __launch_bounds__(256) void ransac_rescue_kernel(RansacArgs a) {
+  const int filt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const SceneBuffers& sb = a.sb;
+  const double* P = a.P + (long)filt * a.strideP;
+  const int state = a.state[filt];
+  __shared__ int s_rej;
+  if (tid == 0) s_rej = 0;
+  __syncthreads();
+  for (int f = wave; f < sb.F; f += 4) {
+    const long e = (long)filt * sb.Fmax + f;
+    const xivo_feat_in& ft = sb.feats[e];
+    const bool mh = sb.mask[e] && ft.sind >= 0;
+    double d = 0.0;
+    bool keep = mh;
+    if (mh && state != 0 && !a.low_keep[e]) {
+      d = feature_chi2(P, a.ldp, a.lay, ft, sb.J + e * 42, sb.finn + e * 2, a.R, lane);
+      keep = d < a.chi2;
+      if (!keep && lane == 0) atomicAdd(&s_rej, 1);
+    }
+    if (lane == 0) { a.keep[e] = keep ? 1 : 0; a.chi[e] = d; }
+  }
+  __syncthreads();
+  if (tid == 0) a.n_rejected[filt] = s_rej;
+}
+
 // ---------------------------------------------------------------- fp64 MFMA issue-rate probe
 // Every wave issues `iters` x 8 independent v_mfma_f64_16x16x4_f64; wave 0 of
 // block 0 also reports the shader-clock cycles it spent (s_memtime), so the
@@ -1664,6 +1784,18 @@ int launch_set_pixels(xivo_feat_in* feats, int Fmax, int F, const double* xp, in
 int launch_edit_batch(const EditArgs& a, int n_wg, hipStream_t s) {
   hipLaunchKernelGGL(edit_batch_kernel, dim3(n_wg), dim3(256), 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int launch_ransac_select(const RansacArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(ransac_select_kernel, dim3(a.batch), dim3(64), 0, s, a);
+  CHECK_LAUNCH();
+}
+int launch_ransac_zero(const RansacArgs& a, double* P, hipStream_t s) {
+  hipLaunchKernelGGL(ransac_zero_kernel, dim3(a.batch), dim3(256), 0, s, a, P);
+  CHECK_LAUNCH();
+}
+int launch_ransac_rescue(const RansacArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(ransac_rescue_kernel, dim3(a.batch), dim3(256), 0, s, a);
+  CHECK_LAUNCH();
 }
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(absorb_error_kernel, dim3(a.batch), dim3(256), 0, s, a);

@@ -106,6 +106,8 @@ _SIGS = {
                          C.c_void_p],
     "xivo_hip_stack": [C.c_void_p, C.c_int, C.c_double],
     "xivo_hip_oos_project": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p],
+    "xivo_hip_one_point_ransac": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p],
     "xivo_hip_filter_update": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int],
     "xivo_hip_last_path": [C.c_void_p],
     "xivo_hip_stage_kernel": [C.c_void_p, C.c_int],
@@ -376,6 +378,19 @@ class Context:
         rows = np.zeros(nb, dtype=np.int32) if want_rows else None
         self._check(self.lib.xivo_hip_oos_project(self.h, 0, nb, n_oos, ptr, Roos, _ptr(rows) if want_rows else None))
         return rows
+
+    def one_point_ransac(self, R, ransac_thresh, ransac_chi2, gauge=None, absorb_groups=None, B=None):
+        """Estimator::OnePointRANSAC on the resident state (after jacobians_instate + mh_gate). gauge: [B] group slots
+        (-1 none); absorb_groups: [B] uint64 masks of instate_groups_ (None: every slot).
+        Returns (inlier mask [B, F], chi-square of the rescue test [B, F], rejected per filter [B])."""
+        B = self.batch if B is None else B
+        F = self.F
+        mask = np.zeros((B, F), dtype=np.uint8); chi = np.zeros((B, F)); nrej = np.zeros(B, dtype=np.int32)
+        g = None if gauge is None else np.ascontiguousarray(gauge, dtype=np.int32)
+        ag = None if absorb_groups is None else np.ascontiguousarray(absorb_groups, dtype=np.uint64)
+        self._check(self.lib.xivo_hip_one_point_ransac(self.h, B, R, ransac_thresh, ransac_chi2, None if g is None else _ptr(g),
+                                                       None if ag is None else _ptr(ag), _ptr(mask), _ptr(chi), _ptr(nrej)))
+        return mask.astype(bool), chi, nrej
 
     def filter_update(self, R, thresh, mult, min_inliers, use_gating=True, B=None):
         self._check(self.lib.xivo_hip_filter_update(self.h, self.batch if B is None else B, R, thresh, mult,
