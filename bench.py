@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--oos", type=int, default=0,
                     help="level G only (BASELINE config 3): this many out-of-state (MSCKF) features, each seen from 5 in-state "
                          "groups, are null-space projected (src/oos.cpp) and appended: 7 rows each, M = 120 + 7 n")
+    ap.add_argument("--ransac", action="store_true",
+                    help="level G only: OnePointRANSAC (src/update.cpp:213-393) between MH gating and the update - backup, "
+                         "partial update on the low-innovation set, absorb, re-Jacobians, chi-square rescue, restore")
     ap.add_argument("--no-gating", action="store_true",
                     help="time UpdateJosephForm only (default: MH gating + UpdateJosephForm, one 'update' of SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -319,6 +322,12 @@ def main():
             ctx.stack(R_VIS, B)
             ctx.oos_project((B, args.oos), 3.5 ** 2, want_rows=False)
             ctx.update_joseph(B)
+        elif args.level == "G" and args.ransac:
+            ctx.jacobians_instate(B)
+            ctx.mh_gate(R_VIS, MH_THRESH, MH_MULT, MIN_INL, B, want=False)
+            ctx.one_point_ransac(R_VIS, 2.0, 5.89, B=B, want=False)       # 1pt_RANSAC_thresh of cfg/pcw.json is 1.5 px
+            ctx.stack(R_VIS, B)
+            ctx.update_joseph(B)
         elif args.level == "G":
             ctx.filter_update(R_VIS, MH_THRESH, MH_MULT, MIN_INL, not args.no_gating, B)
         elif args.no_gating:
@@ -453,6 +462,7 @@ def main():
                                     if frame else "") +
                                    (f"{args.oos} OOS features (null-space projected, 7 rows each) + " if oos_on else "") +
                                    ("feature-level: Jacobians + " if args.level == "G" else "") +
+                                   ("OnePointRANSAC + " if (args.level == "G" and args.ransac) else "") +
                                    ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
                                    f": state dim {N}, {F} features (M={M}), XIVO row sparsity, P/H/inn/R resident in HBM",
                        "filters_per_gpu": B, "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",

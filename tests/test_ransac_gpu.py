@@ -37,7 +37,7 @@ def test_batched_ransac_matches_oracle(built, flags):
     lay = orc.Layout(ng, nf, N=sc["N"])
     rng = np.random.default_rng(5)
     poses, groups, feats, xp = scene_arrays(sc, cam)
-    xp = xp + rng.normal(size=xp.shape) * 0.3
+    xp = xp - sc["pix_noise"] + rng.normal(size=xp.shape) * 0.3       # 0.3 px noise: low-innovation unless moved below
     gauge = np.zeros(B, dtype=np.int32)
     for b in range(B):
         kind = b % 8

@@ -379,15 +379,19 @@ class Context:
         self._check(self.lib.xivo_hip_oos_project(self.h, 0, nb, n_oos, ptr, Roos, _ptr(rows) if want_rows else None))
         return rows
 
-    def one_point_ransac(self, R, ransac_thresh, ransac_chi2, gauge=None, absorb_groups=None, B=None):
+    def one_point_ransac(self, R, ransac_thresh, ransac_chi2, gauge=None, absorb_groups=None, B=None, want=True):
         """Estimator::OnePointRANSAC on the resident state (after jacobians_instate + mh_gate). gauge: [B] group slots
         (-1 none); absorb_groups: [B] uint64 masks of instate_groups_ (None: every slot).
         Returns (inlier mask [B, F], chi-square of the rescue test [B, F], rejected per filter [B])."""
         B = self.batch if B is None else B
         F = self.F
-        mask = np.zeros((B, F), dtype=np.uint8); chi = np.zeros((B, F)); nrej = np.zeros(B, dtype=np.int32)
         g = None if gauge is None else np.ascontiguousarray(gauge, dtype=np.int32)
         ag = None if absorb_groups is None else np.ascontiguousarray(absorb_groups, dtype=np.uint64)
+        if not want:      # results stay on the device (the inlier mask is read by the following stack / absorb)
+            self._check(self.lib.xivo_hip_one_point_ransac(self.h, B, R, ransac_thresh, ransac_chi2, None if g is None else _ptr(g),
+                                                           None if ag is None else _ptr(ag), None, None, None))
+            return None
+        mask = np.zeros((B, F), dtype=np.uint8); chi = np.zeros((B, F)); nrej = np.zeros(B, dtype=np.int32)
         self._check(self.lib.xivo_hip_one_point_ransac(self.h, B, R, ransac_thresh, ransac_chi2, None if g is None else _ptr(g),
                                                        None if ag is None else _ptr(ag), _ptr(mask), _ptr(chi), _ptr(nrej)))
         return mask.astype(bool), chi, nrej

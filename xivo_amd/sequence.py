@@ -177,7 +177,18 @@ class HipBackend:
 
     def update(self):
         c = self.cfg
-        self.ctx.filter_update(c.visual_meas_std ** 2, c.MH_thresh, c.MH_adjust_factor, c.min_inliers, bool(c.use_MH_gating))
+        R = c.visual_meas_std ** 2
+        if c.use_1pt_RANSAC:
+            # Estimator::OutlierRejection with use_1pt_RANSAC (src/manager.cpp:629-650): MH gating, then OnePointRANSAC on
+            # its inliers; the update runs on what RANSAC keeps. (No gauge group / previous-frame group list in this
+            # simplified life cycle: temporary reference group every time, every slot absorbed.)
+            self.ctx.jacobians_instate()
+            self.ctx.mh_gate(R, c.MH_thresh, c.MH_adjust_factor, c.min_inliers if c.use_MH_gating else 1 << 30, want=False)
+            self.ctx.one_point_ransac(R, c.ransac_thresh, c.ransac_Chi2, want=False)
+            self.ctx.stack(R)
+            self.ctx.update_joseph()
+        else:
+            self.ctx.filter_update(R, c.MH_thresh, c.MH_adjust_factor, c.min_inliers, bool(c.use_MH_gating))
         mask, _ = self.ctx.get_gate(self.F)
         # a filter whose S was not positive definite keeps its prior P and absorbs nothing (device side); surfaced here
         self.last_status = self.ctx.get_status(check=False)
