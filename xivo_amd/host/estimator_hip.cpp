@@ -53,10 +53,21 @@ void Estimator::UpdateJosephForm() {
         "set_measurements");
   Check(xivo_hip_update_joseph(ctx_, 1), "update_joseph");
   err_.setZero(N);
+  int st = 0;
+  const int rc = xivo_hip_get_status(ctx_, 0, 1, &st);
+  if (rc == XIVO_HIP_ERR_NOT_SPD) {
+    // S = HPH^T + R was not positive definite. The reference's pivoted LDL^T (src/estimator.cpp:1266) cannot fail, so
+    // there is no behaviour to mirror; the device left its P untouched (the final product skips such a filter) and the
+    // host copy P_ - still the prior, nothing has been downloaded - stays authoritative: the measurement is dropped
+    // (err_ = 0), counted, and the filter carries on. BackupState/RestoreState (src/estimator.cpp:1410-1449) is not needed.
+    ++num_not_spd_;
+    last_update_ok_ = false;
+    return;
+  }
+  Check(rc, "get_status");
+  last_update_ok_ = true;
   Check(xivo_hip_get_err(ctx_, 0, 1, err_.data(), N), "get_err");
   Check(xivo_hip_download_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "download_P");
-  int st = 0;
-  Check(xivo_hip_get_status(ctx_, 0, 1, &st), "UpdateJosephForm (S = HPH^T + R)");
 }
 
 void Estimator::ComputeInstateJacobians() {
@@ -64,22 +75,22 @@ void Estimator::ComputeInstateJacobians() {
   if (F == 0) return;
   if (F > max_features_) throw std::runtime_error("more in-state features than the context was created for");
   xivo_pose_in pose;
-  std::memcpy(pose.Rsb, Rsb_.v, sizeof(pose.Rsb)); std::memcpy(pose.Tsb, Tsb_.v, sizeof(pose.Tsb));
-  std::memcpy(pose.Rbc, Rbc_.v, sizeof(pose.Rbc)); std::memcpy(pose.Tbc, Tbc_.v, sizeof(pose.Tbc));
-  std::memcpy(pose.Vsb, Vsb_.v, sizeof(pose.Vsb)); std::memcpy(pose.bg, bg_.v, sizeof(pose.bg));
-  std::memcpy(pose.ba, ba_.v, sizeof(pose.ba)); std::memcpy(pose.Rsg, Rsg_.v, sizeof(pose.Rsg));
+  std::memcpy(pose.Rsb, Rsb_.data(), sizeof(pose.Rsb)); std::memcpy(pose.Tsb, Tsb_.data(), sizeof(pose.Tsb));
+  std::memcpy(pose.Rbc, Rbc_.data(), sizeof(pose.Rbc)); std::memcpy(pose.Tbc, Tbc_.data(), sizeof(pose.Tbc));
+  std::memcpy(pose.Vsb, Vsb_.data(), sizeof(pose.Vsb)); std::memcpy(pose.bg, bg_.data(), sizeof(pose.bg));
+  std::memcpy(pose.ba, ba_.data(), sizeof(pose.ba)); std::memcpy(pose.Rsg, Rsg_.data(), sizeof(pose.Rsg));
   std::vector<xivo_group_in> gs(lay_.n_groups);
   for (int g = 0; g < lay_.n_groups; ++g) {
-    Mat3 I; Vec3 z;
+    const Mat3 I = Identity3(); const Vec3 z;
     const Group* gp = groups_[g];
-    std::memcpy(gs[g].Rsb, gp ? gp->Rsb_.v : I.v, sizeof(gs[g].Rsb));
-    std::memcpy(gs[g].Tsb, gp ? gp->Tsb_.v : z.v, sizeof(gs[g].Tsb));
+    std::memcpy(gs[g].Rsb, gp ? gp->Rsb_.data() : I.data(), sizeof(gs[g].Rsb));
+    std::memcpy(gs[g].Tsb, gp ? gp->Tsb_.data() : z.data(), sizeof(gs[g].Tsb));
   }
   std::vector<xivo_feat_in> fs(F);
   for (int i = 0; i < F; ++i) {
     const Feature* f = instate_features_[i];
-    std::memcpy(fs[i].x, f->x_.v, sizeof(fs[i].x));
-    std::memcpy(fs[i].xp, f->back_.v, sizeof(fs[i].xp));
+    std::memcpy(fs[i].x, f->x_.data(), sizeof(fs[i].x));
+    std::memcpy(fs[i].xp, f->back_.data(), sizeof(fs[i].xp));
     fs[i].ref_sind = f->ref_->sind();
     fs[i].sind = f->sind_;
   }
@@ -510,17 +521,17 @@ extern "C" int xivo_host_selftest_update_step(const xivo_layout* lay, const xivo
     Estimator est(*lay, *cam, F, flags);
     const int N = lay->N;
     std::memcpy(est.P_.data(), P_inout, sizeof(double) * N * N);
-    std::memcpy(est.Rsb_.v, pose->Rsb, 72); std::memcpy(est.Tsb_.v, pose->Tsb, 24);
-    std::memcpy(est.Rbc_.v, pose->Rbc, 72); std::memcpy(est.Tbc_.v, pose->Tbc, 24);
+    std::memcpy(est.Rsb_.data(), pose->Rsb, 72); std::memcpy(est.Tsb_.data(), pose->Tsb, 24);
+    std::memcpy(est.Rbc_.data(), pose->Rbc, 72); std::memcpy(est.Tbc_.data(), pose->Tbc, 24);
     est.R_ = R; est.MH_thresh_ = mh_thresh; est.MH_thresh_multipler_ = mh_mult; est.min_required_inliers_ = min_inliers;
     std::vector<Group> gs(lay->n_groups);
     for (int g = 0; g < lay->n_groups; ++g) {
-      std::memcpy(gs[g].Rsb_.v, groups[g].Rsb, 72); std::memcpy(gs[g].Tsb_.v, groups[g].Tsb, 24);
+      std::memcpy(gs[g].Rsb_.data(), groups[g].Rsb, 72); std::memcpy(gs[g].Tsb_.data(), groups[g].Tsb, 24);
       gs[g].sind_ = g; est.groups_[g] = &gs[g];
     }
     std::vector<Feature> fs(F);
     for (int i = 0; i < F; ++i) {
-      std::memcpy(fs[i].x_.v, feats[i].x, 24); std::memcpy(fs[i].back_.v, feats[i].xp, 16);
+      std::memcpy(fs[i].x_.data(), feats[i].x, 24); std::memcpy(fs[i].back_.data(), feats[i].xp, 16);
       fs[i].ref_ = &gs[feats[i].ref_sind]; fs[i].sind_ = feats[i].sind;
       est.instate_features_.push_back(&fs[i]);
     }
@@ -554,21 +565,21 @@ extern "C" int xivo_host_selftest_propagate(int N, int use_rk4, int visual_meas,
     xivo_cam cam{}; cam.model = XIVO_CAM_PINHOLE; cam.fx = cam.fy = 500; cam.cx = cam.cy = 250; cam.rows = cam.cols = 500;
     Estimator est(lay, cam, 1, 0);
     std::memcpy(est.P_.data(), P_inout, sizeof(double) * N * N);
-    std::memcpy(est.Rsb_.v, state30, 72); std::memcpy(est.Tsb_.v, state30 + 9, 24); std::memcpy(est.Vsb_.v, state30 + 12, 24);
-    std::memcpy(est.bg_.v, state30 + 15, 24); std::memcpy(est.ba_.v, state30 + 18, 24); std::memcpy(est.Rsg_.v, state30 + 21, 72);
-    std::memcpy(est.last_gyro_.v, imu18, 24); std::memcpy(est.last_accel_.v, imu18 + 3, 24);
-    std::memcpy(est.curr_gyro_.v, imu18 + 6, 24); std::memcpy(est.curr_accel_.v, imu18 + 9, 24);
-    std::memcpy(est.slope_gyro_.v, imu18 + 12, 24); std::memcpy(est.slope_accel_.v, imu18 + 15, 24);
-    std::memcpy(est.g_.v, g_vec, 24);
+    std::memcpy(est.Rsb_.data(), state30, 72); std::memcpy(est.Tsb_.data(), state30 + 9, 24); std::memcpy(est.Vsb_.data(), state30 + 12, 24);
+    std::memcpy(est.bg_.data(), state30 + 15, 24); std::memcpy(est.ba_.data(), state30 + 18, 24); std::memcpy(est.Rsg_.data(), state30 + 21, 72);
+    std::memcpy(est.last_gyro_.data(), imu18, 24); std::memcpy(est.last_accel_.data(), imu18 + 3, 24);
+    std::memcpy(est.curr_gyro_.data(), imu18 + 6, 24); std::memcpy(est.curr_accel_.data(), imu18 + 9, 24);
+    std::memcpy(est.slope_gyro_.data(), imu18 + 12, 24); std::memcpy(est.slope_accel_.data(), imu18 + 15, 24);
+    std::memcpy(est.g_.data(), g_vec, 24);
     est.Qimu_.setZero(12, 12); std::memcpy(est.Qimu_.data(), Qimu, sizeof(double) * 144);
     est.Qmodel_.setZero(23, 23); std::memcpy(est.Qmodel_.data(), Qmodel, sizeof(double) * 529);
     est.integration_method_ = use_rk4 ? "RK4" : "PrinceDormand";
     est.stepsize_ = stepsize;
     est.Propagate(visual_meas != 0, dt);
     std::memcpy(P_inout, est.P_.data(), sizeof(double) * N * N);
-    std::memcpy(state30, est.Rsb_.v, 72); std::memcpy(state30 + 9, est.Tsb_.v, 24); std::memcpy(state30 + 12, est.Vsb_.v, 24);
-    std::memcpy(imu18, est.last_gyro_.v, 24); std::memcpy(imu18 + 3, est.last_accel_.v, 24);
-    std::memcpy(imu18 + 12, est.slope_gyro_.v, 24); std::memcpy(imu18 + 15, est.slope_accel_.v, 24);
+    std::memcpy(state30, est.Rsb_.data(), 72); std::memcpy(state30 + 9, est.Tsb_.data(), 24); std::memcpy(state30 + 12, est.Vsb_.data(), 24);
+    std::memcpy(imu18, est.last_gyro_.data(), 24); std::memcpy(imu18 + 3, est.last_accel_.data(), 24);
+    std::memcpy(imu18 + 12, est.slope_gyro_.data(), 24); std::memcpy(imu18 + 15, est.slope_accel_.data(), 24);
     return 0;
   } catch (const std::exception& e) {
     if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }
@@ -586,19 +597,19 @@ extern "C" int xivo_host_selftest_ransac(const xivo_layout* lay, const xivo_cam*
     Estimator est(*lay, *cam, F, 0);
     const int N = lay->N;
     std::memcpy(est.P_.data(), P_in, sizeof(double) * N * N);
-    std::memcpy(est.Rsb_.v, pose->Rsb, 72); std::memcpy(est.Tsb_.v, pose->Tsb, 24);
-    std::memcpy(est.Rbc_.v, pose->Rbc, 72); std::memcpy(est.Tbc_.v, pose->Tbc, 24);
+    std::memcpy(est.Rsb_.data(), pose->Rsb, 72); std::memcpy(est.Tsb_.data(), pose->Tsb, 24);
+    std::memcpy(est.Rbc_.data(), pose->Rbc, 72); std::memcpy(est.Tbc_.data(), pose->Tbc, 24);
     est.R_ = R; est.ransac_thresh_ = ransac_thresh; est.ransac_Chi2_ = ransac_chi2;
     std::vector<Group> gs(lay->n_groups);
     for (int g = 0; g < lay->n_groups; ++g) {
-      std::memcpy(gs[g].Rsb_.v, groups[g].Rsb, 72); std::memcpy(gs[g].Tsb_.v, groups[g].Tsb, 24);
+      std::memcpy(gs[g].Rsb_.data(), groups[g].Rsb, 72); std::memcpy(gs[g].Tsb_.data(), groups[g].Tsb, 24);
       gs[g].sind_ = g; est.groups_[g] = &gs[g]; est.instate_groups_.push_back(&gs[g]);
     }
     est.gauge_group_ptr_ = &gs[gauge_group];
     std::vector<Feature> fs(F);
     std::vector<FeaturePtr> all;
     for (int i = 0; i < F; ++i) {
-      std::memcpy(fs[i].x_.v, feats[i].x, 24); std::memcpy(fs[i].back_.v, feats[i].xp, 16);
+      std::memcpy(fs[i].x_.data(), feats[i].x, 24); std::memcpy(fs[i].back_.data(), feats[i].xp, 16);
       fs[i].ref_ = &gs[feats[i].ref_sind]; fs[i].sind_ = feats[i].sind;
       all.push_back(&fs[i]);
     }
@@ -610,8 +621,8 @@ extern "C" int xivo_host_selftest_ransac(const xivo_layout* lay, const xivo_cam*
     *num_rejected_out = est.num_oneptransac_rejected_;
     double e = 0;
     for (int i = 0; i < N * N; ++i) e = std::fmax(e, std::fabs(est.P_.data()[i] - P_in[i]));
-    for (int i = 0; i < 9; ++i) e = std::fmax(e, std::fabs(est.Rsb_.v[i] - pose->Rsb[i]));
-    for (int g = 0; g < lay->n_groups; ++g) for (int i = 0; i < 3; ++i) e = std::fmax(e, std::fabs(gs[g].Tsb_.v[i] - groups[g].Tsb[i]));
+    for (int i = 0; i < 9; ++i) e = std::fmax(e, std::fabs(est.Rsb_.data()[i] - pose->Rsb[i]));
+    for (int g = 0; g < lay->n_groups; ++g) for (int i = 0; i < 3; ++i) e = std::fmax(e, std::fabs(gs[g].Tsb_.data()[i] - groups[g].Tsb[i]));
     *restore_err_out = e;
     return 0;
   } catch (const std::exception& e) {
@@ -636,29 +647,29 @@ extern "C" int xivo_host_selftest_sequence(const xivo_layout* lay, const xivo_ca
     Estimator est(*lay, *cam, F, 0);
     const int N = lay->N;
     std::memcpy(est.P_.data(), P_inout, sizeof(double) * N * N);
-    std::memcpy(est.Rsb_.v, state30, 72); std::memcpy(est.Tsb_.v, state30 + 9, 24); std::memcpy(est.Vsb_.v, state30 + 12, 24);
-    std::memcpy(est.bg_.v, state30 + 15, 24); std::memcpy(est.ba_.v, state30 + 18, 24); std::memcpy(est.Rsg_.v, state30 + 21, 72);
-    std::memcpy(est.Rbc_.v, Rbc, 72); std::memcpy(est.Tbc_.v, Tbc, 24);
-    std::memcpy(est.g_.v, g_vec, 24);
+    std::memcpy(est.Rsb_.data(), state30, 72); std::memcpy(est.Tsb_.data(), state30 + 9, 24); std::memcpy(est.Vsb_.data(), state30 + 12, 24);
+    std::memcpy(est.bg_.data(), state30 + 15, 24); std::memcpy(est.ba_.data(), state30 + 18, 24); std::memcpy(est.Rsg_.data(), state30 + 21, 72);
+    std::memcpy(est.Rbc_.data(), Rbc, 72); std::memcpy(est.Tbc_.data(), Tbc, 24);
+    std::memcpy(est.g_.data(), g_vec, 24);
     est.Qimu_.setZero(12, 12); std::memcpy(est.Qimu_.data(), Qimu, sizeof(double) * 144);
     est.Qmodel_.setZero(23, 23); std::memcpy(est.Qmodel_.data(), Qmodel, sizeof(double) * 529);
     est.integration_method_ = use_rk4 ? "RK4" : "PrinceDormand";
     est.R_ = R;
     std::vector<Group> gs(lay->n_groups);
     for (int g = 0; g < lay->n_groups; ++g) {
-      std::memcpy(gs[g].Rsb_.v, groups_io[g].Rsb, 72); std::memcpy(gs[g].Tsb_.v, groups_io[g].Tsb, 24);
+      std::memcpy(gs[g].Rsb_.data(), groups_io[g].Rsb, 72); std::memcpy(gs[g].Tsb_.data(), groups_io[g].Tsb, 24);
       gs[g].sind_ = g; est.groups_[g] = &gs[g]; est.instate_groups_.push_back(&gs[g]);
     }
     std::vector<Feature> fs(F);
     for (int i = 0; i < F; ++i) {
-      std::memcpy(fs[i].x_.v, feats_io[i].x, 24);
+      std::memcpy(fs[i].x_.data(), feats_io[i].x, 24);
       fs[i].ref_ = &gs[feats_io[i].ref_sind]; fs[i].sind_ = feats_io[i].sind;
     }
-    std::memcpy(est.last_gyro_.v, imu, 24); std::memcpy(est.last_accel_.v, imu + 3, 24);
+    std::memcpy(est.last_gyro_.data(), imu, 24); std::memcpy(est.last_accel_.data(), imu + 3, 24);
     for (int t = 0; t < n_frames; ++t) {
       for (int k = 0; k < n_imu; ++k) {
         const double* s = imu + ((size_t)t * n_imu + k) * 6;
-        std::memcpy(est.curr_gyro_.v, s, 24); std::memcpy(est.curr_accel_.v, s + 3, 24);
+        std::memcpy(est.curr_gyro_.data(), s, 24); std::memcpy(est.curr_accel_.data(), s + 3, 24);
         if (t == 0 && k == 0) continue;                 // the first sample only seeds last_*
         est.Propagate(false, dt_imu);
       }
@@ -666,7 +677,7 @@ extern "C" int xivo_host_selftest_sequence(const xivo_layout* lay, const xivo_ca
       est.instate_features_.clear();
       for (int i = 0; i < F; ++i) {
         if (fs[i].status() == FeatureStatus::REJECTED_BY_FILTER) continue;   // removed from the state by the caller
-        std::memcpy(fs[i].back_.v, pixels + ((size_t)t * F + i) * 2, 16);
+        std::memcpy(fs[i].back_.data(), pixels + ((size_t)t * F + i) * 2, 16);
         est.instate_features_.push_back(&fs[i]);
       }
       est.ComputeInstateJacobians();
@@ -684,10 +695,10 @@ extern "C" int xivo_host_selftest_sequence(const xivo_layout* lay, const xivo_ca
         }
     }
     std::memcpy(P_inout, est.P_.data(), sizeof(double) * N * N);
-    std::memcpy(state30, est.Rsb_.v, 72); std::memcpy(state30 + 9, est.Tsb_.v, 24); std::memcpy(state30 + 12, est.Vsb_.v, 24);
-    std::memcpy(state30 + 15, est.bg_.v, 24); std::memcpy(state30 + 18, est.ba_.v, 24); std::memcpy(state30 + 21, est.Rsg_.v, 72);
-    for (int g = 0; g < lay->n_groups; ++g) { std::memcpy(groups_io[g].Rsb, gs[g].Rsb_.v, 72); std::memcpy(groups_io[g].Tsb, gs[g].Tsb_.v, 24); }
-    for (int i = 0; i < F; ++i) std::memcpy(feats_io[i].x, fs[i].x_.v, 24);
+    std::memcpy(state30, est.Rsb_.data(), 72); std::memcpy(state30 + 9, est.Tsb_.data(), 24); std::memcpy(state30 + 12, est.Vsb_.data(), 24);
+    std::memcpy(state30 + 15, est.bg_.data(), 24); std::memcpy(state30 + 18, est.ba_.data(), 24); std::memcpy(state30 + 21, est.Rsg_.data(), 72);
+    for (int g = 0; g < lay->n_groups; ++g) { std::memcpy(groups_io[g].Rsb, gs[g].Rsb_.data(), 72); std::memcpy(groups_io[g].Tsb, gs[g].Tsb_.data(), 24); }
+    for (int i = 0; i < F; ++i) std::memcpy(feats_io[i].x, fs[i].x_.data(), 24);
     return 0;
   } catch (const std::exception& e) {
     if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }

@@ -11,9 +11,10 @@
 // what the reference would have left in its members. (The throughput path is
 // the batched C ABI itself; this adapter is the drop-in for one filter.)
 //
-// Matrix type: a minimal column-major `MatX` with Eigen's memory layout
-// (Eigen::MatrixXd::data() can be passed wherever MatX::data() is). Inside the
-// reference tree the same adapter compiles with `using MatX = Eigen::MatrixXd`.
+// Matrix types: minimal column-major `MatX` / `VecX` / `Vec2` / `Vec3` / `Mat3` with Eigen's memory layout and the
+// subset of Eigen's interface the adapter uses (operator(), rows(), cols(), data(), setZero, resize). With
+// -DXIVO_HIP_USE_EIGEN they are the reference's own aliases (common/alias.h) instead - the build a maintainer uses
+// inside the reference tree; tests/test_boundary_cpu.py compiles both.
 #pragma once
 #include <cmath>
 #include <memory>
@@ -26,6 +27,22 @@
 namespace xivo {
 namespace hip {
 
+#ifdef XIVO_HIP_USE_EIGEN
+}  // namespace hip
+}  // namespace xivo
+// Inside the reference tree: the reference's own matrix aliases (common/alias.h: Eigen 3.3.9 + Sophus, column-major
+// double; the tree is built with -DEIGEN_INITIALIZE_MATRICES_BY_ZERO, CMakeLists.txt:43). tests/test_boundary_cpu.py
+// compiles this adapter that way against /root/reference's headers.
+#include "alias.h"
+namespace xivo {
+namespace hip {
+using ::xivo::number_t;
+using ::xivo::MatX;
+using ::xivo::VecX;
+using ::xivo::Vec2;
+using ::xivo::Vec3;
+using ::xivo::Mat3;
+#else
 using number_t = double;  // common/alias.h:11
 
 struct VecX {
@@ -56,19 +73,26 @@ struct MatX {  // column-major, like Eigen's default (CMakeLists.txt:42)
   const number_t* data() const { return v.data(); }
 };
 
-struct Vec2 { number_t v[2] = {0, 0}; number_t& operator()(int i) { return v[i]; } number_t operator()(int i) const { return v[i]; } };
-struct Vec3 { number_t v[3] = {0, 0, 0}; number_t& operator()(int i) { return v[i]; } number_t operator()(int i) const { return v[i]; } };
+// fixed-size types: zero-initialised like the reference's Eigen build (EIGEN_INITIALIZE_MATRICES_BY_ZERO)
+struct Vec2 { number_t v[2] = {0, 0}; number_t& operator()(int i) { return v[i]; } number_t operator()(int i) const { return v[i]; }
+              number_t* data() { return v; } const number_t* data() const { return v; } };
+struct Vec3 { number_t v[3] = {0, 0, 0}; number_t& operator()(int i) { return v[i]; } number_t operator()(int i) const { return v[i]; }
+              number_t* data() { return v; } const number_t* data() const { return v; } };
 struct Mat3 {  // column-major 3x3
-  number_t v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  number_t v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   number_t& operator()(int i, int j) { return v[3 * j + i]; }
   number_t operator()(int i, int j) const { return v[3 * j + i]; }
+  number_t* data() { return v; }
+  const number_t* data() const { return v; }
 };
+#endif
+inline Mat3 Identity3() { Mat3 I; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) I(i, j) = i == j ? 1.0 : 0.0; return I; }
 
 enum class FeatureStatus { INSTATE, GAUGE, REJECTED_BY_FILTER };  // subset of src/core.h used on this path
 
 // Group anchor (src/group.h:41-107): pose + state slot.
 struct Group {
-  Mat3 Rsb_; Vec3 Tsb_; int sind_ = -1;
+  Mat3 Rsb_ = Identity3(); Vec3 Tsb_; int sind_ = -1;
   const Mat3& Rsb() const { return Rsb_; }
   const Vec3& Tsb() const { return Tsb_; }
   int sind() const { return sind_; }
@@ -124,14 +148,14 @@ class Estimator {
   bool use_MH_gating_ = true;
   int num_mh_rejected_ = 0;
   // nominal state pieces ComputeInstateJacobians passes down (update.cpp:27-28)
-  Mat3 Rsb_, Rbc_; Vec3 Tsb_, Tbc_;
+  Mat3 Rsb_ = Identity3(), Rbc_ = Identity3(); Vec3 Tsb_, Tbc_;
   std::vector<FeaturePtr> instate_features_;
   std::vector<FeaturePtr> in_current_ekf_update_;
   std::vector<GroupPtr> groups_;   // indexed by slot `sind`
 
   // ---- propagation members (src/estimator.h: X_, g_, Qimu_, Qmodel_, slope_*, last_/curr_ IMU) ----
   Vec3 Vsb_, bg_, ba_;     // X_.Vsb, X_.bg, X_.ba (Rsb_/Tsb_/Rbc_/Tbc_ above are the rest of X_)
-  Mat3 Rsg_;               // X_.Rsg
+  Mat3 Rsg_ = Identity3(); // X_.Rsg
   Vec3 g_;                 // gravity, src/estimator.cpp:g_
   MatX Qimu_, Qmodel_;     // 12x12, 23x23 (src/estimator.cpp:590)
   Vec3 slope_accel_, slope_gyro_, last_accel_, last_gyro_, curr_accel_, curr_gyro_;
@@ -159,6 +183,8 @@ class Estimator {
   std::vector<GroupPtr> instate_groups_;   // groups AbsorbError retracts (src/manager.cpp:103)
   int num_oneptransac_rejected_ = 0;
   int absorb_counter_ = 0;                 // State::counter (src/core.h:120-122)
+  int num_not_spd_ = 0;                    // updates dropped because S was not positive definite (P_ kept, err_ = 0)
+  bool last_update_ok_ = true;
   std::vector<number_t> ransac_chi2_;      // chi-square distances of the rescue step (for tests/diagnostics)
   // host edits of P_ stay plain host code on the authoritative host copy
 
