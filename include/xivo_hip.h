@@ -233,6 +233,15 @@ int xivo_hip_stack(xivo_hip_ctx* ctx, int B, double R);
  * previous call again (it stays resident; same nb and n_oos) - for a caller that re-linearises without new tracks. */
 int xivo_hip_oos_project(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xivo_oos_in* feats,
                          double Roos, int* rows_out);
+/* Measurement compression (use_compression_ / compression_trigger_ratio_, src/estimator.h:399-402 - parsed by the
+ * reference, src/estimator.cpp:115-117, but never acted on; xivo::QR, src/helpers.cpp:77-101 "QR-based measurement
+ * compression"): call after xivo_hip_oos_project. For every filter whose OOS block has more than trigger_ratio (>= 1;
+ * reference default 1.5) times as many rows as non-zero columns, the block is replaced by the triangular factor of its
+ * QR decomposition (Householder reflections on the device; the rows only touch the extrinsics and group columns, so
+ * the 2k-3 rows of every OOS feature collapse to at most 6 + 6 n_groups rows in total). Orthogonal row operations with
+ * isotropic noise leave S^-1-weighted quantities - K, dx, P+ - unchanged to rounding. rows_out[b] (host, may be NULL) =
+ * OOS rows of filter b afterwards; the stacked row count M shrinks to in-state rows + the largest of them. */
+int xivo_hip_compress_oos(xivo_hip_ctx* ctx, int B, double trigger_ratio, int* rows_out);
 /* Estimator::OnePointRANSAC (src/update.cpp:213-393) for filters [0,B) on the resident state; call after
  * xivo_hip_jacobians_instate + xivo_hip_mh_gate (the MH inliers are the input set, as OutlierRejection hands them over,
  * src/manager.cpp:629-650). Low-innovation set {|inn| < ransac_thresh} (the hypothesis loop of :238-258 never uses its

@@ -196,9 +196,13 @@ def test_propagation_tail(built):
         assert rel_fro(got[b], exp[b]) < 1e-14
 
 
-def test_config3_full_size_instate_plus_oos(built):
+@pytest.mark.parametrize("compress", [False, True])
+def test_config3_full_size_instate_plus_oos(built, compress):
     """BASELINE.json config 3 at full size: N=251 (8 groups, 60 in-state features -> 120 rows)
-    + 20 OOS features seen from k=5 groups (7 projected rows each -> 140 rows), M=260."""
+    + 20 OOS features seen from k=5 groups (7 projected rows each -> 140 rows), M=260.
+    compress: the 140 OOS rows (non-zero only over the 6 extrinsics + 48 group columns) are replaced by the 54-row
+    triangular factor of their QR decomposition before the update (measurement compression, src/estimator.h:399-402,
+    src/helpers.cpp:77-101): M = 174; K, dx, P+ are unchanged to rounding."""
     cam = synth.PINHOLE
     ng, nf, F, B, n_oos, k = 8, 60, 60, 2, 20, 5
     sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 6, cam, M_max=2 * F + n_oos * (2 * k - 3))
@@ -224,6 +228,23 @@ def test_config3_full_size_instate_plus_oos(built):
         ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
         ctx.jacobians_instate(); ctx.mh_gate(R_VIS, MH, MULT, 5); ctx.stack(R_VIS)
         rows = ctx.oos_project(oos, 3.5 ** 2)
+        if compress:
+            Hfull = [ctx.get_H(b) for b in range(B)]
+            crow = ctx.compress_oos(1.5)
+            assert crow.tolist() == [54] * B
+            for b in range(B):
+                Hc, ic, rc_ = ctx.get_H(b)
+                Hf, if_, rf = Hfull[b]
+                assert Hc.shape[0] == 174 and np.array_equal(Hc[:120], Hf[:120]) and np.array_equal(ic[:120], if_[:120])
+                A, C = Hf[120:], Hc[120:]
+                assert np.all(rc_[120:] == 3.5 ** 2)
+                # an orthogonal transform of the block: same Gram matrix, same H^T r; upper-trapezoidal over its columns
+                assert rel_fro(C.T @ C, A.T @ A) < 1e-12 and rel_fro(C.T @ ic[120:], A.T @ if_[120:]) < 1e-12
+                cols = np.nonzero(np.abs(A).sum(0))[0]
+                assert len(cols) == 54 and np.array_equal(np.nonzero(np.abs(C).sum(0))[0], cols)
+                assert np.count_nonzero(np.tril(C[:, cols], -1)) == 0
+                # the retained energy of the residual: ||Q1^T r|| <= ||r||
+                assert np.linalg.norm(ic[120:]) <= np.linalg.norm(if_[120:]) * (1 + 1e-12)
         ctx.update_joseph()
         err = ctx.get_err(); Pn = ctx.download_P()
         assert (ctx.get_status() == 0).all()
@@ -517,3 +538,49 @@ def test_device_propagate_several_imu_samples_in_one_call(built):
         assert rel_fro(Pn[b], Pr) < 1e-11
         assert np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - Xr.Rsb).max() < 1e-12
         assert np.abs(pose_d[b]["Tsb"] - Xr.Tsb).max() < 1e-12 and np.abs(pose_d[b]["Vsb"] - Xr.Vsb).max() < 1e-12
+
+
+def test_oos_compression_trigger_and_ragged_blocks(built):
+    """compression_trigger_ratio: a block with fewer than ratio x (non-zero columns) rows is left alone; filters of one
+    call hold different numbers of OOS observations; the compressed update equals the oracle's uncompressed one."""
+    cam = synth.EQUI
+    ng, nf, F, B, n_oos = 4, 10, 10, 3, 12
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 12, cam, M_max=2 * F + n_oos * 5)
+    rng = np.random.default_rng(3)
+    oos = np.zeros((B, n_oos), dtype=oos_dtype)
+    obs_all = {}
+    kk = {0: 4, 1: 3, 2: 2}                       # observations per OOS feature: 5 / 3 / 1 projected rows each
+    for b in range(B):
+        for o in range(n_oos):
+            k = kk[b]
+            Xs = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(3, 6)])
+            gs = rng.permutation(ng)[:k]
+            oos[b, o]["Xs"] = Xs; oos[b, o]["n_obs"] = k
+            obs = []
+            for q, g in enumerate(gs):
+                _, _, inn = orc.oos_jacobian_internal(Xs, sc["gR"][b, g], sc["gT"][b, g], sc["Rbc"][b], sc["Tbc"][b], [0, 0], cam, lay, int(g))
+                pix = -inn + rng.normal(0, 1.0, 2)
+                oos[b, o]["group_sind"][q] = g; oos[b, o]["xp"][q] = pix
+                obs.append((int(g), pix))
+            obs_all[b, o] = (Xs, obs)
+    P = np.array([spd(lay.N, 90 + b) * 1e-4 for b in range(B)])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
+        ctx.jacobians_instate(); ctx.mh_gate(R_VIS, MH, MULT, 5); ctx.stack(R_VIS)
+        rows = ctx.oos_project(oos, 3.5 ** 2)
+        assert rows.tolist() == [60, 36, 12]
+        crow = ctx.compress_oos(1.5)
+        # 30 non-zero columns (6 + 24): 60 > 45 compresses to 30 rows; 36 and 12 rows stay (36 < 45)
+        assert crow.tolist() == [30, 36, 12]
+        ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+        assert (ctx.get_status() == 0).all()
+    for b in range(B):
+        Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, b)
+        H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][b], sc["sind"][b], lay, R_VIS)
+        for o in range(n_oos):
+            Xs, obs = obs_all[b, o]
+            Hxp, rp, _ = orc.oos_jacobian(Xs, obs, sc["gR"][b], sc["gT"][b], sc["Rbc"][b], sc["Tbc"][b], cam, lay)
+            H = np.vstack([H, Hxp]); inn = np.concatenate([inn, rp]); dR = np.concatenate([dR, np.full(len(rp), 3.5 ** 2)])
+        e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX

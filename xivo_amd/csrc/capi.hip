@@ -73,6 +73,8 @@ struct xivo_hip_ctx {
   int* rows_instate = nullptr;
   xivo_oos_in* oos = nullptr;
   int oos_cap = 0;
+  int oos_row0 = -1;   // first row of the OOS block of the last xivo_hip_oos_project (-1: none since the last stacking)
+  double oos_R = 0.0;
   int oos_nb = 0, oos_n = 0, oos_max_rows = 0;   // shape of the resident OOS list (xivo_hip_oos_project with feats == NULL)
   int* oos_rows = nullptr;
   xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
@@ -972,7 +974,7 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   }
   // the sparse-H pipeline reads only the compressed rows: skip the 2 x Mp x Np dense zero-fill + scatter
   const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
-  c->dense_valid = dense != 0; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B;
+  c->dense_valid = dense != 0; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B; c->oos_row0 = -1;
   return stack_impl(c, B, R, dense);
 }
 
@@ -1012,6 +1014,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   OosArgs a;
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
   a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
+  c->oos_row0 = c->M; c->oos_R = Roos;
   a.rows_out = c->oos_rows;
   {
     StageTimer st(c, ST_OTHER, 0.0);
@@ -1110,6 +1113,33 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   if (chi2_out) { rc = d2h_rows(c, chi2_out, F * sizeof(double), c->rs_chi, Fm * sizeof(double), F * sizeof(double), B); if (rc) return rc; }
   if (n_rejected_out) HIP_TRY(hipMemcpyAsync(n_rejected_out, c->rs_nrej, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));   // gauge_group / absorb_groups are borrowed host memory
+  return XIVO_HIP_OK;
+}
+
+// Measurement compression of the OOS rows appended by the last xivo_hip_oos_project (use_compression_ /
+// compression_trigger_ratio_, src/estimator.h:399-402; xivo::QR, src/helpers.cpp:77-101): per filter, when the block
+// has more than trigger_ratio times as many rows as non-zero columns, it is replaced by the triangular factor of its QR
+// decomposition (oos_compress_kernel) and the row count of the stacked measurement shrinks accordingly.
+int xivo_hip_compress_oos(xivo_hip_ctx* c, int B, double trigger_ratio, int* rows_out) {
+  if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->oos_row0 < 0 || !c->oos_rows || B != c->oos_nb || !(trigger_ratio >= 1.0))
+    return XIVO_HIP_ERR_INVALID;
+  OosCompressArgs a;
+  a.lay = c->lay; a.mb = meas_buffers(c); a.row0 = c->oos_row0; a.rows = c->oos_rows; a.rows_out = c->oos_rows;
+  a.ratio = trigger_ratio; a.Roos = c->oos_R; a.batch = B;
+  int rc;
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "oos_compress_kernel");
+    rc = launch_oos_compress(a, c->oos_max_rows, c->stream);
+  }
+  if (rc > 0) return XIVO_HIP_ERR_HIP;
+  std::vector<int> rows(B);
+  HIP_TRY(hipMemcpyAsync(rows.data(), c->oos_rows, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int mx = 0;
+  for (int b = 0; b < B; ++b) mx = rows[b] > mx ? rows[b] : mx;
+  // (rc == -1: block larger than the built kernels - rows are left as they are, which is always valid)
+  c->M = c->oos_row0 + mx; c->Mp = round_up16(c->M); c->oos_max_rows = mx;
+  if (rows_out) memcpy(rows_out, rows.data(), (size_t)B * sizeof(int));
   return XIVO_HIP_OK;
 }
 

@@ -143,6 +143,18 @@ struct OosArgs {
 };
 int launch_oos(const OosArgs& a, hipStream_t s);
 
+// measurement compression of the appended OOS rows (estimator.h:399-402, helpers.cpp:77-101)
+struct OosCompressArgs {
+  xivo_layout lay; MeasBuffers mb;
+  int row0;              // first OOS row
+  const int* rows;       // [batch] OOS rows of each filter (as written by launch_oos)
+  int* rows_out;         // [batch] rows after compression (may alias rows)
+  double ratio, Roos;
+  int batch;
+};
+// returns -1 (nothing launched) when the block is larger than the built instantiations
+int launch_oos_compress(const OosCompressArgs& a, int rows_max, hipStream_t s);
+
 // propagation tail (rk4.cpp:92-102)
 int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm, const double* Phi,
                          const double* Pmm, int b0, int nb, hipStream_t s);

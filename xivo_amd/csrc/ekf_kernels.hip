@@ -1578,6 +1578,166 @@ __global__ __launch_bounds__(256, NS == 4 ? 3 : 2) void propagate_state_kernel(P
   }
 }
 
+// ---------------------------------------------------------------- measurement compression of the OOS rows
+// use_compression_ / compression_trigger_ratio_ (src/estimator.h:399-402) and xivo::QR (src/helpers.cpp:77-101, "QR-based
+// measurement compression") are parsed / defined but never run by the reference's pipeline. Here the block of
+// null-space-projected OOS rows appended under the in-state rows (rows [row0, row0 + rows_b) of the stacked H) is
+// replaced by the triangular factor of its QR decomposition whenever it has more than `ratio` times as many rows as
+// non-zero columns: the rows only touch the camera-extrinsics and group columns, so 7 rows per feature collapse to at
+// most 6 + 6 * n_groups rows for the whole block. Orthogonal row operations with isotropic noise Roos leave the update
+// (S, K, dx, P+) unchanged to rounding (tests compare against the uncompressed oracle update and check
+// Hc^T Hc = H^T H, Hc^T rc = H^T r).
+// One workgroup of four waves per filter: lane = candidate column (CPL columns per lane: [Wbc Tbc | group slots], the
+// residual rides along as one more column), wave w keeps rows [w RW, (w + 1) RW) of its columns in registers.
+// Householder reflections column by column (a column that is zero from the pivot row down is skipped), v broadcast
+// from the pivot lane with v_readlane, the per-column dot products reduced over the four waves through LDS: two
+// barriers per column, no dynamic register indexing (the row loops are unrolled and predicated on r >= pivot row).
+template <int RW, int CPL>
+__global__ __launch_bounds__(256) void oos_compress_kernel(OosCompressArgs a) {
+  const int filt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rows = a.rows[filt];
+  const int ncand = 6 + 6 * a.lay.n_groups;            // candidate columns; column index ncand = the residual
+  double* H = a.mb.H + (long)filt * a.mb.strideH;
+  double* HT = a.mb.HT + (long)filt * a.mb.strideHT;
+  double* inn = a.mb.inn + (long)filt * a.mb.strideInn;
+  double* dR = a.mb.diagR + (long)filt * a.mb.strideR;
+  __shared__ double sdot[4][64 * CPL];
+  __shared__ double ssum[4], spiv[4];
+  auto col_of = [&](int jj) -> int { return jj < 6 ? 15 + jj : a.lay.group_begin + (jj - 6); };
+  double v[CPL][RW];
+  // rows this wave holds, as a VECTOR value (a scalar one makes the compiler keep RW row predicates in SGPRs)
+  int nloc;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(nloc) : "s"(rows - wave * RW));
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int jj = lane + 64 * q;
+    // column jj of the block: contiguous over the rows (H is column-major); the residual is one more column
+    const double* src = jj < ncand ? H + (a.row0 + wave * RW) + (long)col_of(jj) * a.mb.ldh : inn + (a.row0 + wave * RW);
+    const bool have = jj <= ncand;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) v[q][rr] = (have && rr < nloc) ? src[rr] : 0.0;
+  }
+  // trigger: rows > ratio * (non-zero candidate columns)
+  __shared__ unsigned long long smask[4][CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    bool any = false;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) any = any || v[q][rr] != 0.0;
+    const unsigned long long m = __ballot(any && lane + 64 * q < ncand);
+    if (lane == 0) smask[wave][q] = m;
+  }
+  __syncthreads();
+  int nzc = 0;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) nzc += __popcll(smask[0][q] | smask[1][q] | smask[2][q] | smask[3][q]);
+  if (!((double)rows > a.ratio * (double)nzc) || rows <= 1) {
+    if (tid == 0) a.rows_out[filt] = rows;
+    return;
+  }
+  __shared__ double scol[4][RW];   // column j of this wave's rows, broadcast source (LDS broadcast instead of RW v_readlane
+                                   // pairs: those landed in ~100 SGPRs at once and spilled)
+  int p = 0;   // pivot row = number of reflections applied so far
+  for (int j = 0; j < ncand && p < rows; ++j) {
+    const int jl = j & 63, jq = j >> 6;
+    // pivot row relative to this wave's first row, kept in a VECTOR register on purpose: as a scalar, the compiler
+    // hoists the 2 RW row predicates of the unrolled loops into SGPRs and spills them
+    int pl;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(pl) : "s"(p - wave * RW));
+    // the owner lane publishes column j; squared norm from the pivot row down + the pivot element
+    if (lane == jl) {
+      double s = 0.0, x0 = 0.0;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        if (q != jq) continue;
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+          const double e = v[q][rr];
+          scol[wave][rr] = e;
+          if (rr >= pl) s = fma(e, e, s);
+          if (rr == pl) x0 = e;
+        }
+      }
+      ssum[wave] = s; spiv[wave] = x0;
+    }
+    __syncthreads();
+    const double stot = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    const double xp = spiv[p / RW];       // the wave that owns row p
+    if (stot == 0.0) { __syncthreads(); continue; }       // nothing below the pivot row in this column
+    const double nrm = sqrt(stot);
+    const double alpha = xp > 0.0 ? -nrm : nrm;
+    const double beta = 1.0 / (stot - xp * alpha);        // H = I - beta v v^T, v = x - alpha e_p
+    // dot products v^T A[:, c] over this wave's rows
+    double dot[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) dot[q] = 0.0;
+    int pl2;   // a fresh copy per loop: shared predicates would be kept as 2 RW 64-bit lane masks in SGPRs
+    asm volatile("v_mov_b32 %0, %1" : "=v"(pl2) : "v"(pl));
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      double vr = scol[wave][rr];
+      if (rr == pl2) vr -= alpha;
+      if (rr < pl2) vr = 0.0;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) dot[q] = fma(vr, v[q][rr], dot[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) sdot[wave][lane + 64 * q] = dot[q];
+    __syncthreads();
+    double w[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int c = lane + 64 * q;
+      w[q] = beta * (sdot[0][c] + sdot[1][c] + sdot[2][c] + sdot[3][c]);
+    }
+    int pl3;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(pl3) : "v"(pl));
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      double vr = scol[wave][rr];
+      if (rr == pl3) vr -= alpha;
+      if (rr < pl3) vr = 0.0;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        double e = fma(-vr, w[q], v[q][rr]);
+        if (q == jq && lane == jl && rr >= pl3) e = rr == pl3 ? alpha : 0.0;    // the reflected column, exactly
+        v[q][rr] = e;
+      }
+    }
+    ++p;
+  }
+  // rows [0, p): the triangular factor; rows [p, rows): exactly neutral
+  int pl;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(pl) : "s"(p - wave * RW));
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int jj = lane + 64 * q;
+    if (jj < ncand) {
+      const int col = col_of(jj);
+      double* hd = H + (a.row0 + wave * RW) + (long)col * a.mb.ldh;
+      double* ht = HT + col + (long)(a.row0 + wave * RW) * a.mb.ldht;
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        if (rr < nloc) {
+          const double x = rr < pl ? v[q][rr] : 0.0;
+          hd[rr] = x;
+          *ht = x;
+        }
+        ht += a.mb.ldht;
+      }
+    } else if (jj == ncand) {
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        if (rr < nloc) {
+          inn[a.row0 + wave * RW + rr] = rr < pl ? v[q][rr] : 0.0;
+          dR[a.row0 + wave * RW + rr] = rr < pl ? a.Roos : 1.0;
+        }
+      }
+    }
+  }
+  if (tid == 0) a.rows_out[filt] = p;
+}
+
 // ---------------------------------------------------------------- Estimator::OnePointRANSAC (src/update.cpp:213-393)
 // select: the low-innovation set among the MH inliers (:238-258 - the hypothesis index k is drawn but never used, so
 // the maximal set is {f : |xp - Predict| < ransac_thresh_}; xp - Predict is the innovation of the Jacobian pass), the
@@ -1784,6 +1944,14 @@ int launch_set_pixels(xivo_feat_in* feats, int Fmax, int F, const double* xp, in
 int launch_edit_batch(const EditArgs& a, int n_wg, hipStream_t s) {
   hipLaunchKernelGGL(edit_batch_kernel, dim3(n_wg), dim3(256), 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int launch_oos_compress(const OosCompressArgs& a, int rows_max, hipStream_t s) {
+  const int ncols = 6 + 6 * a.lay.n_groups + 1;      // candidates + the residual column
+  if (ncols <= 64 && rows_max <= 144) hipLaunchKernelGGL((oos_compress_kernel<36, 1>), dim3(a.batch), dim3(256), 0, s, a);
+  else if (ncols <= 64 && rows_max <= 256) hipLaunchKernelGGL((oos_compress_kernel<64, 1>), dim3(a.batch), dim3(256), 0, s, a);
+  else if (ncols <= 128 && rows_max <= 144) hipLaunchKernelGGL((oos_compress_kernel<36, 2>), dim3(a.batch), dim3(256), 0, s, a);
+  else return -1;                                     // not built for this size: the caller leaves the rows as they are
+  CHECK_LAUNCH();
 }
 int launch_ransac_select(const RansacArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(ransac_select_kernel, dim3(a.batch), dim3(64), 0, s, a);

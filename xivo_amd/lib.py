@@ -106,6 +106,7 @@ _SIGS = {
                          C.c_void_p],
     "xivo_hip_stack": [C.c_void_p, C.c_int, C.c_double],
     "xivo_hip_oos_project": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p],
+    "xivo_hip_compress_oos": [C.c_void_p, C.c_int, C.c_double, C.c_void_p],
     "xivo_hip_one_point_ransac": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p],
     "xivo_hip_filter_update": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int],
@@ -377,6 +378,13 @@ class Context:
             ptr = _ptr(feats)
         rows = np.zeros(nb, dtype=np.int32) if want_rows else None
         self._check(self.lib.xivo_hip_oos_project(self.h, 0, nb, n_oos, ptr, Roos, _ptr(rows) if want_rows else None))
+        return rows
+
+    def compress_oos(self, trigger_ratio=1.5, B=None, want_rows=True):
+        """QR measurement compression of the OOS rows appended by oos_project (estimator.h:399-402)."""
+        B = self.batch if B is None else B
+        rows = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.xivo_hip_compress_oos(self.h, B, trigger_ratio, _ptr(rows) if want_rows else None))
         return rows
 
     def one_point_ransac(self, R, ransac_thresh, ransac_chi2, gauge=None, absorb_groups=None, B=None, want=True):
