@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--oos", type=int, default=0,
                     help="level G only (BASELINE config 3): this many out-of-state (MSCKF) features, each seen from 5 in-state "
                          "groups, are null-space projected (src/oos.cpp) and appended: 7 rows each, M = 120 + 7 n")
+    ap.add_argument("--no-compression", action="store_true", help="--oos: keep all 7 n projected rows (no QR measurement compression)")
     ap.add_argument("--ransac", action="store_true",
                     help="level G only: OnePointRANSAC (src/update.cpp:213-393) between MH gating and the update - backup, "
                          "partial update on the low-innovation set, absorb, re-Jacobians, chi-square rescue, restore")
@@ -321,6 +322,8 @@ def main():
             ctx.mh_gate(R_VIS, MH_THRESH, MH_MULT, MIN_INL, B, want=False)
             ctx.stack(R_VIS, B)
             ctx.oos_project((B, args.oos), 3.5 ** 2, want_rows=False)
+            if not args.no_compression:      # measurement compression (estimator.h:399-402): 140 OOS rows -> 54
+                ctx.compress_oos(1.5, B, want_rows=False)
             ctx.update_joseph(B)
         elif args.level == "G" and args.ransac:
             ctx.jacobians_instate(B)
@@ -460,7 +463,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"whole frame: Propagate ({args.propagate_samples} IMU samples, {args.integrator}) + AbsorbError + "
                                     if frame else "") +
-                                   (f"{args.oos} OOS features (null-space projected, 7 rows each) + " if oos_on else "") +
+                                   (f"{args.oos} OOS features (null-space projected, 7 rows each" +
+                                    ("" if args.no_compression else ", QR-compressed to 54 rows") + ") + " if oos_on else "") +
                                    ("feature-level: Jacobians + " if args.level == "G" else "") +
                                    ("OnePointRANSAC + " if (args.level == "G" and args.ransac) else "") +
                                    ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
