@@ -560,14 +560,14 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (launch_gate_ell(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {
-    CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
+    CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B;
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {
-    TrsmArgs a; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
+    TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
@@ -638,7 +638,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (rc) return rc;
   }
   if (gate) {  // Estimator::MHGating on the rows just multiplied (update.cpp:60-96): S_f = (HP)_f H_f^T + R
-    GateDenseArgs a;
+    GateDenseArgs a{};
     a.H = H; a.strideH = c->sH; a.ldh = ldh; a.HP = HP; a.strideHP = c->sH; a.ldhp = ldh;
     a.Hw = c->H + (long)b0 * c->sH; a.HTw = c->HT + (long)b0 * c->sHT; a.strideHT = c->sHT; a.ldht = Np;
     a.HPw = HP; a.PHTw = PHT; a.PHTr = PHT;
@@ -658,14 +658,14 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (rc) return rc;
   }
   {  // S = L L^T
-    CholArgs a; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
+    CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B;
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
-    TrsmArgs a; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
+    TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
@@ -830,7 +830,7 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
               c->HP, c->sH, ldh, x);
   }
   if (rc) return rc;
-  GateDenseArgs a;
+  GateDenseArgs a{};
   a.H = c->H; a.strideH = c->sH; a.ldh = ldh; a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh;
   a.Hw = c->H; a.HTw = c->HT; a.strideHT = c->sHT; a.ldht = Np; a.HPw = nullptr; a.PHTw = nullptr; a.PHTr = c->PHT;
   a.inn = c->inn; a.strideInn = c->Mpmax; a.diagR = c->diagR; a.strideR = c->Mpmax;
@@ -917,7 +917,7 @@ int xivo_hip_get_jacobians(xivo_hip_ctx* c, int b0, int nb, double* J, double* i
 }
 
 static int gate_impl(xivo_hip_ctx* c, int B, double R, double th, double mult, int min_inl, int use_gating) {
-  GateArgs a;
+  GateArgs a{};
   a.sb = scene_buffers(c); a.lay = c->lay; a.P = c->P; a.strideP = c->sP; a.ldp = c->Np;
   a.R = R; a.thresh = th; a.mult = mult; a.min_inliers = min_inl; a.batch = B; a.use_gating = use_gating;
   StageTimer st(c, ST_GATE, 0.0, "gate_sparse_kernel");
@@ -941,7 +941,7 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
 }
 
 static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigned char* mask_override = nullptr, int full_rows = 0) {
-  StackArgs a;
+  StackArgs a{};
   a.sb = scene_buffers(c); a.lay = c->lay; a.mb = meas_buffers(c);
   if (mask_override) a.sb.mask = mask_override;
   a.Mp = c->Mpmax; a.Np = c->Np; a.batch = B; a.R = R;
@@ -1011,7 +1011,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
     HIP_TRY(hipMemcpyAsync(c->oos, feats, (size_t)nb * n_oos * sizeof(xivo_oos_in), hipMemcpyHostToDevice, c->stream));
     c->oos_nb = nb; c->oos_n = n_oos; c->oos_max_rows = max_rows;
   }
-  OosArgs a;
+  OosArgs a{};
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
   a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
   c->oos_row0 = c->M; c->oos_R = Roos;
@@ -1057,7 +1057,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   if (gauge_group) HIP_TRY(hipMemcpyAsync(c->rs_gauge, gauge_group, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
   else HIP_TRY(hipMemsetAsync(c->rs_gauge, 0xFF, (size_t)B * sizeof(int), c->stream));
   if (absorb_groups) HIP_TRY(hipMemcpyAsync(c->rs_gmask, absorb_groups, (size_t)B * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-  RansacArgs a;
+  RansacArgs a{};
   a.sb = scene_buffers(c); a.lay = c->lay; a.P = c->P; a.strideP = c->sP; a.ldp = c->Np; a.Np = c->Np;
   a.R = R; a.thresh = ransac_thresh; a.chi2 = ransac_chi2; a.gauge = c->rs_gauge;
   a.low = c->rs_low; a.low_keep = c->rs_lowkeep; a.zero_groups = c->rs_zg; a.state = c->rs_state;
@@ -1087,7 +1087,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   if (rc) return rc;
   {  // AbsorbError (:333): in_current_ekf_update_ is empty at this point of Estimator::UpdateStep (cleared at
      // src/manager.cpp:28, filled after OutlierRejection), so no feature state moves; State::counter is restored with X_
-    AbsorbArgs ab;
+    AbsorbArgs ab{};
     ab.poses = c->poses; ab.groups = c->groups; ab.feats = c->feats; ab.mask = nullptr; ab.err = c->err; ab.strideErr = c->Np;
     ab.lay = c->lay; ab.F = c->F; ab.Fmax = c->Fmax; ab.batch = B; ab.counter = nullptr; ab.status = c->status;
     ab.group_mask = absorb_groups ? c->rs_gmask : nullptr;
@@ -1123,7 +1123,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
 int xivo_hip_compress_oos(xivo_hip_ctx* c, int B, double trigger_ratio, int* rows_out) {
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->oos_row0 < 0 || !c->oos_rows || B != c->oos_nb || !(trigger_ratio >= 1.0))
     return XIVO_HIP_ERR_INVALID;
-  OosCompressArgs a;
+  OosCompressArgs a{};
   a.lay = c->lay; a.mb = meas_buffers(c); a.row0 = c->oos_row0; a.rows = c->oos_rows; a.rows_out = c->oos_rows;
   a.ratio = trigger_ratio; a.Roos = c->oos_R; a.batch = B;
   int rc;
@@ -1173,7 +1173,7 @@ static int givens_impl(xivo_hip_ctx* c, int nb, int rows, int nx, int nf, double
   HIP_TRY(hipMemcpyAsync(dx, x, ex * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(dHx, Hx, ehx * sizeof(double), hipMemcpyHostToDevice, c->stream));
   if (!qr) HIP_TRY(hipMemcpyAsync(dHf, Hf, ehf * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  GivensArgs a; a.x = dx; a.Hx = dHx; a.Hf = qr ? nullptr : dHf; a.rows = rows; a.nx = nx; a.nf = nf; a.eff = effective_rows;
+  GivensArgs a{}; a.x = dx; a.Hx = dHx; a.Hf = qr ? nullptr : dHf; a.rows = rows; a.nx = nx; a.nf = nf; a.eff = effective_rows;
   a.batch = nb; a.qr = qr;
   {
     StageTimer st(c, ST_OTHER, 0.0, "givens_kernel");
@@ -1227,7 +1227,7 @@ int xivo_hip_subfilter_update(xivo_hip_ctx* c, int b0, int nb, int n, xivo_subfi
 int xivo_hip_absorb_error(xivo_hip_ctx* c, int B) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0 || !c->mask) return XIVO_HIP_ERR_INVALID;
-  AbsorbArgs a;
+  AbsorbArgs a{};
   a.poses = c->poses; a.groups = c->groups; a.feats = c->feats; a.mask = c->mask; a.err = c->err; a.strideErr = c->Np;
   a.lay = c->lay; a.F = c->F; a.Fmax = c->Fmax; a.batch = B; a.counter = c->absorb_count; a.status = c->status;
   StageTimer st(c, ST_OTHER, 0.0);
@@ -1278,7 +1278,7 @@ int xivo_hip_edit_batch(xivo_hip_ctx* c, int F, int n_ops, const xivo_edit_op* o
   HIP_TRY(hipMemcpyAsync(d + bytes_ops, wg_filter.data(), (size_t)n_wg * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d + bytes_ops + (size_t)n_wg * sizeof(int), wg_begin.data(), (size_t)(n_wg + 1) * sizeof(int),
                          hipMemcpyHostToDevice, c->stream));
-  EditArgs a;
+  EditArgs a{};
   a.ops = (const xivo_edit_op*)d; a.wg_filter = (const int*)(d + bytes_ops); a.wg_begin = a.wg_filter + n_wg;
   a.P = c->P; a.strideP = c->sP; a.ldp = c->Np; a.Np = c->Np; a.lay = L;
   a.poses = c->poses; a.groups = c->groups; a.feats = c->feats; a.Fmax = c->Fmax;
@@ -1375,7 +1375,7 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   HIP_TRY(hipMemcpyAsync(dQi, o->Qimu, 144 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(dQm, o->Qmodel, 529 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(dImu, imu, (size_t)nb * n_imu * sizeof(xivo_imu_in), hipMemcpyHostToDevice, c->stream));
-  PropStateArgs a;
+  PropStateArgs a{};
   a.poses = c->poses + b0; a.imu = dImu; a.n_imu = n_imu; a.Qimu = dQi; a.Qmodel = dQm;
   a.g[0] = o->g[0]; a.g[1] = o->g[1]; a.g[2] = o->g[2]; a.method = o->method; a.stepsize = o->stepsize;
   a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
