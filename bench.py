@@ -247,6 +247,9 @@ def main():
                 groups[b, g_]["Rsb"], groups[b, g_]["Tsb"] = cmaj(sc["gR"][b, g_]), sc["gT"][b, g_]
             feats["x"][b] = sc["x"][b]; feats["ref_sind"][b] = sc["ref"][b]; feats["sind"][b] = sc["sind"][b]
         M = 2 * F + 7 * args.oos
+        if args.oos > 0:
+            from xivo_amd.lib import FLAG_DENSE_H
+            flags |= FLAG_DENSE_H       # OOS rows are dense over the group blocks: stack the dense rows right away
         ctx = Context(N, M, B, device=device, flags=flags)
         ctx.set_layout(N, 23, ng, 23 + 6 * ng, nf, synth.EQUI)
         rngP = np.random.default_rng(3000 + rank)

@@ -893,7 +893,6 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
   __shared__ double sHf[OOS_R][3];
   __shared__ double sHx[OOS_R][12];   // per row: [Wg(3) Tg(3) Wbc(3) Tbc(3)]
   __shared__ double sInn[OOS_R];
-  __shared__ double sLU[3][OOS_R];
   __shared__ double sA[OOS_R][OOS_R]; // kernel basis, 2k x dimker
   __shared__ int sQ[OOS_R];
   __shared__ int sRank;
@@ -941,65 +940,113 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
   }
   __syncthreads();
 
-  // FullPivLU of Hf^T (3 x 2k) by lane 0
-  if (lane == 0) {
-    const int rows = 3, cols = R2, size = rows < cols ? rows : cols;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < cols; ++j) sLU[i][j] = sHf[j][i];
-    int colsT[3] = {0, 1, 2};
-    int nonzero = size;
+  // FullPivLU of Hf^T (3 x 2k) and its kernel (Eigen FullPivLU.h:446-534, 619-699; helpers.cpp:15-16), one lane per
+  // column of Hf^T with the column's three entries in registers: the pivot search is a wave arg-max that keeps the
+  // FIRST maximum of Eigen's column-major scan (smaller column, then smaller row), row swaps are register selects,
+  // column swaps and the broadcasts of the pivot column are lane shuffles. Every arithmetic operation is the one the
+  // serial algorithm performs on that element, so the basis equals Eigen's to rounding.
+  {
+    const int cols = R2;
+    const bool incol = lane < cols;
+    double c0 = incol ? sHf[lane][0] : 0.0, c1 = incol ? sHf[lane][1] : 0.0, c2 = incol ? sHf[lane][2] : 0.0;
+    int q = lane;                     // m_q: position -> original column, built from the column transpositions
+    int nonzero = 3;
     double maxpivot = 0.0;
-    for (int kk = 0; kk < size; ++kk) {
-      // biggest |.| in the bottom-right corner; Eigen's maxCoeff visitor scans
-      // column-major and keeps the FIRST maximum
-      int br = kk, bc = kk; double big = -1.0;
-      for (int j = kk; j < cols; ++j)
-        for (int i = kk; i < rows; ++i) {
-          const double s = fabs(sLU[i][j]);
-          if (s > big) { big = s; br = i; bc = j; }
+    int colsT0 = 0, colsT1 = 1, colsT2 = 2;
+    bool live = true;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      if (!live) continue;
+      // biggest |.| of the bottom-right corner: per lane over rows kk..2 (first maximum), then over lanes j >= kk
+      double best = -1.0; int bi = kk;
+      if (incol && lane >= kk) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (i < kk) continue;
+          const double sv = fabs(i == 0 ? c0 : (i == 1 ? c1 : c2));
+          if (sv > best) { best = sv; bi = i; }
         }
-      if (big == 0.0) {
-        nonzero = kk;
-        for (int i = kk; i < size; ++i) colsT[i] = i;
-        break;
       }
+      int bj = lane;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o), oj = __shfl_xor(bj, o);
+        if (ob > best || (ob == best && oj < bj)) { best = ob; bi = oi; bj = oj; }
+      }
+      const double big = best; const int br = bi, bc = bj;     // wave-uniform
+      if (big == 0.0) { nonzero = kk; live = false; continue; }   // the rest of the corner is exactly zero (FullPivLU.h:486-494)
       if (big > maxpivot) maxpivot = big;
-      colsT[kk] = bc;
-      if (kk != br) for (int j = 0; j < cols; ++j) { const double t = sLU[kk][j]; sLU[kk][j] = sLU[br][j]; sLU[br][j] = t; }
-      if (kk != bc) for (int i = 0; i < rows; ++i) { const double t = sLU[i][kk]; sLU[i][kk] = sLU[i][bc]; sLU[i][bc] = t; }
-      if (kk < rows - 1) for (int i = kk + 1; i < rows; ++i) sLU[i][kk] /= sLU[kk][kk];
-      if (kk < size - 1)
-        for (int i = kk + 1; i < rows; ++i)
-          for (int j = kk + 1; j < cols; ++j) sLU[i][j] -= sLU[i][kk] * sLU[kk][j];
-    }
-    // m_q: identity with transposition (k, colsT[k]) applied on the right, k ascending
-    for (int j = 0; j < cols; ++j) sQ[j] = j;
-    for (int kk = 0; kk < size; ++kk) { const int t = sQ[kk]; sQ[kk] = sQ[colsT[kk]]; sQ[colsT[kk]] = t; }
-    // rank with Eigen's default threshold eps * diagonalSize (FullPivLU.h threshold())
-    const double thr = maxpivot * (2.220446049250313e-16 * size);
-    int piv[3]; int p = 0;
-    for (int i = 0; i < nonzero; ++i) if (fabs(sLU[i][i]) > thr) piv[p++] = i;
-    const int rank = p, dimker = cols - rank;
-    sRank = rank;
-    // trapezoid m (rank x cols), FullPivLU.h:660-672
-    double m[3][OOS_R];
-    for (int i = 0; i < rank; ++i) {
-      for (int j = 0; j < cols; ++j) m[i][j] = (j < i) ? 0.0 : sLU[piv[i]][j];
-    }
-    for (int i = 0; i < rank; ++i) for (int j = 0; j < i; ++j) m[i][j] = 0.0;
-    for (int i = 0; i < rank; ++i)
-      if (piv[i] != i) for (int r = 0; r < rank; ++r) { const double t = m[r][i]; m[r][i] = m[r][piv[i]]; m[r][piv[i]] = t; }
-    // upper-triangular solve m[:, :rank] X = m[:, rank:]
-    for (int c = rank; c < cols; ++c)
-      for (int i = rank - 1; i >= 0; --i) {
-        double s = m[i][c];
-        for (int j = i + 1; j < rank; ++j) s -= m[i][j] * m[j][c];
-        m[i][c] = s / m[i][i];
+      if (kk == 0) colsT0 = bc; else if (kk == 1) colsT1 = bc; else colsT2 = bc;
+      // rows kk <-> br in every column
+      if (br != kk) {
+        double& a_ = kk == 0 ? c0 : (kk == 1 ? c1 : c2);
+        if (br == 1) { const double t = a_; a_ = c1; c1 = t; }
+        else if (br == 2) { const double t = a_; a_ = c2; c2 = t; }
       }
-    for (int i = rank - 1; i >= 0; --i)
-      if (piv[i] != i) for (int r = 0; r < rank; ++r) { const double t = m[r][i]; m[r][i] = m[r][piv[i]]; m[r][piv[i]] = t; }
-    for (int i = 0; i < rank; ++i) for (int c = 0; c < dimker; ++c) sA[sQ[i]][c] = -m[i][rank + c];
-    for (int i = rank; i < cols; ++i) for (int c = 0; c < dimker; ++c) sA[sQ[i]][c] = 0.0;
-    for (int c = 0; c < dimker; ++c) sA[sQ[rank + c]][c] = 1.0;
+      // columns kk <-> bc
+      if (bc != kk) {
+        const int src = lane == kk ? bc : (lane == bc ? kk : lane);
+        c0 = __shfl(c0, src); c1 = __shfl(c1, src); c2 = __shfl(c2, src);
+        q = __shfl(q, src);
+      }
+      // multipliers in column kk, then the rank-1 update of the corner
+      const double pk0 = __shfl(c0, kk), pk1 = __shfl(c1, kk), pk2 = __shfl(c2, kk);    // column kk as it is now
+      const double piv = kk == 0 ? pk0 : (kk == 1 ? pk1 : pk2);
+      double l1 = 0.0, l2 = 0.0;        // multipliers of rows 1, 2 (those below kk)
+      if (kk == 0) { l1 = pk1 / piv; l2 = pk2 / piv; if (lane == 0) { c1 = l1; c2 = l2; } }
+      else if (kk == 1) { l2 = pk2 / piv; if (lane == 1) c2 = l2; }
+      if (lane > kk) {
+        const double top = kk == 0 ? c0 : (kk == 1 ? c1 : c2);     // sLU[kk][j]
+        if (kk == 0) { c1 -= l1 * top; c2 -= l2 * top; }
+        else if (kk == 1) { c2 -= l2 * top; }
+      }
+    }
+    (void)colsT0; (void)colsT1; (void)colsT2;
+    if (incol) sQ[lane] = q;
+    // rank with Eigen's default threshold eps * diagonalSize (FullPivLU.h threshold())
+    const double thr = maxpivot * (2.220446049250313e-16 * 3);
+    const double d0 = __shfl(c0, 0), d1 = __shfl(c1, 1), d2 = __shfl(c2, 2);
+    int piv[3]; int np = 0;
+    if (0 < nonzero && fabs(d0) > thr) piv[np++] = 0;
+    if (1 < nonzero && fabs(d1) > thr) piv[np++] = 1;
+    if (2 < nonzero && fabs(d2) > thr) piv[np++] = 2;
+    const int rank = np, dimker = cols - rank;
+    const int p0 = rank > 0 ? piv[0] : 0, p1 = rank > 1 ? piv[1] : 0, p2 = rank > 2 ? piv[2] : 0;
+    if (lane == 0) sRank = rank;
+    // trapezoid m (rank x cols): row i = row piv[i] of the LU with its strictly lower part zeroed (FullPivLU.h:660-672)
+    auto rowsel = [&](int r) -> double { return r == 0 ? c0 : (r == 1 ? c1 : c2); };
+    double m0 = rank > 0 ? rowsel(p0) : 0.0;
+    double m1 = rank > 1 ? (lane < 1 ? 0.0 : rowsel(p1)) : 0.0;
+    double m2 = rank > 2 ? (lane < 2 ? 0.0 : rowsel(p2)) : 0.0;
+    auto swap_cols = [&](int ca, int cb) {
+      if (ca == cb) return;
+      const int src = lane == ca ? cb : (lane == cb ? ca : lane);
+      m0 = __shfl(m0, src); m1 = __shfl(m1, src); m2 = __shfl(m2, src);
+    };
+    if (rank > 0) swap_cols(0, p0);
+    if (rank > 1) swap_cols(1, p1);
+    if (rank > 2) swap_cols(2, p2);
+    // upper-triangular solve m[:, :rank] X = m[:, rank:], one lane per right-hand side
+    const double u00 = __shfl(m0, 0), u01 = __shfl(m0, 1), u02 = __shfl(m0, 2), u11 = __shfl(m1, 1), u12 = __shfl(m1, 2), u22 = __shfl(m2, 2);
+    if (lane >= rank && incol) {
+      if (rank == 3) { m2 = m2 / u22; m1 = (m1 - u12 * m2) / u11; m0 = ((m0 - u01 * m1) - u02 * m2) / u00; }
+      else if (rank == 2) { m1 = m1 / u11; m0 = (m0 - u01 * m1) / u00; }
+      else if (rank == 1) { m0 = m0 / u00; }
+    }
+    if (rank > 2) swap_cols(2, p2);
+    if (rank > 1) swap_cols(1, p1);
+    if (rank > 0) swap_cols(0, p0);
+    __syncthreads();                              // sQ complete
+    // dst.row(q[i]) = -m.row(i).tail(dimker), rows q[rank..] zero, then the identity block (FullPivLU.h:690-697)
+    if (incol && lane >= rank) {
+      const int c = lane - rank;
+      for (int j = 0; j < cols; ++j) sA[j][c] = 0.0;
+      if (rank > 0) sA[sQ[0]][c] = -m0;
+      if (rank > 1) sA[sQ[1]][c] = -m1;
+      if (rank > 2) sA[sQ[2]][c] = -m2;
+      sA[sQ[lane]][c] = 1.0;
+    }
+    (void)dimker;
   }
   __syncthreads();
 
@@ -1635,26 +1682,32 @@ __global__ __launch_bounds__(256) void oos_compress_kernel(OosCompressArgs a) {
     if (tid == 0) a.rows_out[filt] = rows;
     return;
   }
-  __shared__ double scol[4][RW];   // column j of this wave's rows, broadcast source (LDS broadcast instead of RW v_readlane
-                                   // pairs: those landed in ~100 SGPRs at once and spilled)
+  // Per column (= per reflection) the work of a wave is two passes over its RW register rows: the dot products
+  // v^T A[:, c] and the rank-1 update. Everything that depends on the row index relative to the pivot row is folded
+  // into the broadcast vector the owner lane publishes in LDS (zero above the pivot row, x_p - alpha at it), so both
+  // passes are ds_read (broadcast) + v_fma per row, nothing else: the kernel is bound by VALU issue.
+  __shared__ double scol[4][RW];
+  __shared__ double salpha[64 * CPL];
+  __shared__ int spivrow[64 * CPL];
+  for (int c = tid; c < 64 * CPL; c += 256) spivrow[c] = -1;
+  __syncthreads();
   int p = 0;   // pivot row = number of reflections applied so far
   for (int j = 0; j < ncand && p < rows; ++j) {
     const int jl = j & 63, jq = j >> 6;
-    // pivot row relative to this wave's first row, kept in a VECTOR register on purpose: as a scalar, the compiler
-    // hoists the 2 RW row predicates of the unrolled loops into SGPRs and spills them
+    // pivot row relative to this wave's first row, in a VECTOR register on purpose (a scalar one makes the compiler
+    // keep the RW row predicates of the unrolled loop as 64-bit lane masks in SGPRs, which spill)
     int pl;
     asm volatile("v_mov_b32 %0, %1" : "=v"(pl) : "s"(p - wave * RW));
-    // the owner lane publishes column j; squared norm from the pivot row down + the pivot element
-    if (lane == jl) {
+    if (lane == jl) {    // the owner lane publishes column j masked to the rows >= p, its squared norm, the pivot element
       double s = 0.0, x0 = 0.0;
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         if (q != jq) continue;
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) {
-          const double e = v[q][rr];
+          const double e = rr >= pl ? v[q][rr] : 0.0;
           scol[wave][rr] = e;
-          if (rr >= pl) s = fma(e, e, s);
+          s = fma(e, e, s);
           if (rr == pl) x0 = e;
         }
       }
@@ -1662,22 +1715,19 @@ __global__ __launch_bounds__(256) void oos_compress_kernel(OosCompressArgs a) {
     }
     __syncthreads();
     const double stot = ssum[0] + ssum[1] + ssum[2] + ssum[3];
-    const double xp = spiv[p / RW];       // the wave that owns row p
-    if (stot == 0.0) { __syncthreads(); continue; }       // nothing below the pivot row in this column
+    const double xp = spiv[p / RW];       // from the wave that owns row p
+    if (stot == 0.0) { __syncthreads(); continue; }       // nothing from the pivot row down in this column: no reflection
     const double nrm = sqrt(stot);
     const double alpha = xp > 0.0 ? -nrm : nrm;
     const double beta = 1.0 / (stot - xp * alpha);        // H = I - beta v v^T, v = x - alpha e_p
-    // dot products v^T A[:, c] over this wave's rows
+    if (wave == p / RW && lane == jl) { scol[wave][p % RW] = xp - alpha; salpha[j] = alpha; spivrow[j] = p; }
+    __syncthreads();
     double dot[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) dot[q] = 0.0;
-    int pl2;   // a fresh copy per loop: shared predicates would be kept as 2 RW 64-bit lane masks in SGPRs
-    asm volatile("v_mov_b32 %0, %1" : "=v"(pl2) : "v"(pl));
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
-      double vr = scol[wave][rr];
-      if (rr == pl2) vr -= alpha;
-      if (rr < pl2) vr = 0.0;
+      const double vr = scol[wave][rr];
 #pragma unroll
       for (int q = 0; q < CPL; ++q) dot[q] = fma(vr, v[q][rr], dot[q]);
     }
@@ -1690,23 +1740,17 @@ __global__ __launch_bounds__(256) void oos_compress_kernel(OosCompressArgs a) {
       const int c = lane + 64 * q;
       w[q] = beta * (sdot[0][c] + sdot[1][c] + sdot[2][c] + sdot[3][c]);
     }
-    int pl3;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(pl3) : "v"(pl));
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
-      double vr = scol[wave][rr];
-      if (rr == pl3) vr -= alpha;
-      if (rr < pl3) vr = 0.0;
+      const double vr = scol[wave][rr];
 #pragma unroll
-      for (int q = 0; q < CPL; ++q) {
-        double e = fma(-vr, w[q], v[q][rr]);
-        if (q == jq && lane == jl && rr >= pl3) e = rr == pl3 ? alpha : 0.0;    // the reflected column, exactly
-        v[q][rr] = e;
-      }
+      for (int q = 0; q < CPL; ++q) v[q][rr] = fma(-vr, w[q], v[q][rr]);
     }
     ++p;
   }
-  // rows [0, p): the triangular factor; rows [p, rows): exactly neutral
+  __syncthreads();
+  // rows [0, p): the triangular factor - the reflected columns exactly (alpha on the pivot, zero below it; the
+  // arithmetic leaves rounding-level residue there); rows [p, rows): exactly neutral
   int pl;
   asm volatile("v_mov_b32 %0, %1" : "=v"(pl) : "s"(p - wave * RW));
 #pragma unroll
@@ -1714,12 +1758,17 @@ __global__ __launch_bounds__(256) void oos_compress_kernel(OosCompressArgs a) {
     const int jj = lane + 64 * q;
     if (jj < ncand) {
       const int col = col_of(jj);
+      const int prow = spivrow[jj];                       // -1: never a pivot column (zero from its turn on)
+      const double al = prow >= 0 ? salpha[jj] : 0.0;
+      int prl;                                            // pivot row of this column relative to the wave's rows
+      asm volatile("v_mov_b32 %0, %1" : "=v"(prl) : "v"(prow - wave * RW));
       double* hd = H + (a.row0 + wave * RW) + (long)col * a.mb.ldh;
       double* ht = HT + col + (long)(a.row0 + wave * RW) * a.mb.ldht;
 #pragma unroll
       for (int rr = 0; rr < RW; ++rr) {
         if (rr < nloc) {
-          const double x = rr < pl ? v[q][rr] : 0.0;
+          double x = rr < pl ? v[q][rr] : 0.0;
+          if (prow >= 0 && rr >= prl) x = rr == prl ? al : 0.0;
           hd[rr] = x;
           *ht = x;
         }
