@@ -44,21 +44,39 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // (XIVO_HIP_FLAG_FP32_COV: BASELINE.json config 4, covariance products only). Operands stay fp64 in HBM
 // and are rounded to fp32 when they are written to LDS; results are widened on store.
 template <typename CT> struct Cx;
+// fp64 products run on v_mfma_f64_4x4x4_4b_f64 by default: on gfx950 it sustains 72 TFLOP/s against 49 for
+// v_mfma_f64_16x16x4_f64 (scripts/mfma_probe.hip, measured on the MI355X). One 16x16x4 step becomes four 4x4x4
+// instructions, m = 0..3: lane group blk (= (lane & 15) >> 2) multiplies the B column block blk (the operand register
+// the 16x16x4 form uses, unchanged) with the A row block (blk + m) & 3 - the A fragment read from LDS rotated by 4 m
+// lanes within its 16-lane row. Operand layout (measured, scripts/mfma44_layout.hip): A / B lane = 16 k + 4 blk + i|j,
+// D lane = 16 i + 4 blk + j. Accumulator component m of lane (lg, li) then holds
+//   C[I0 + 4 (((li >> 2) + m) & 3) + (li & 3)][J0 + 4 (li >> 2) + lg];
+// tiles are converted from / to the 16x16x4 accumulator layout through a per-wave LDS pad around the main loop, so
+// prologue and epilogue are shared. -DXIVO_MFMA44=0 builds the 16x16x4 form (A/B).
+#ifndef XIVO_MFMA44
+#define XIVO_MFMA44 1
+#endif
 template <> struct Cx<double> {
   typedef d4 acc_t; typedef d2 pair_t;
   static __device__ __forceinline__ acc_t zero() { return d4{0.0, 0.0, 0.0, 0.0}; }
   static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ double mfma44(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
   // C/D row of accumulator register r for lane group lg (cdna_hip_programming.md section 3: f64 differs)
   static __device__ __forceinline__ int crow(int lg, int r) { return lg + 4 * r; }
   static __device__ __forceinline__ pair_t cvt(d2 v) { return v; }
 };
 template <> struct Cx<float> {
   typedef f4 acc_t; typedef f2 pair_t;
+  static __device__ __forceinline__ float mfma44(float, float, float c) { return c; }   // never used: fp32 keeps 16x16x4
   static __device__ __forceinline__ acc_t zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
   static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ int crow(int lg, int r) { return 4 * lg + r; }
   static __device__ __forceinline__ pair_t cvt(d2 v) { return pair_t{(float)v[0], (float)v[1]}; }
 };
+
+// wave tiles whose 4x4x4 form fits the 256-VGPR budget without spilling (measured with -Rpass-analysis): up to 16
+// accumulator slots, except the 3x5 / 5x3 shapes
+constexpr bool mf44_tile(int wm, int wn) { return XIVO_MFMA44 && wm * wn <= 16 && wm * wn != 15; }
 
 // FAST: the tile is interior (every 16x16 block in range and wanted), so slot activity is a
 // compile-time property - for strip tiles together with the compile-time wave index WAVE - and
@@ -116,6 +134,26 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   // (loaded after the main loop, when the staging registers are dead) instead of being rounded
   // to fp32 here.
   constexpr bool LATE_MSUB = sizeof(CT) == 4;
+  constexpr bool MF44 = mf44_tile(WM, WN) && sizeof(CT) == 8;
+  // 16x16x4 accumulator layout <-> 4x4x4 accumulator layout of one 16x16 block through this wave's LDS pad
+  // (pad element (i, j) of the block at j * 17 + i; same-wave LDS writes and reads are ordered)
+  double* Tcv = smem_raw + (threadIdx.x >> 6) * (16 * 17);
+  auto to_mf44 = [&](acc_t v) -> acc_t {      // v[r] = C[li][lg + 4 r]  ->  component m as documented above
+    acc_t o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tcv[(lg + 4 * r) * 17 + li] = (double)v[r];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) o[m] = (CT)Tcv[(4 * (li >> 2) + lg) * 17 + 4 * (((li >> 2) + m) & 3) + (li & 3)];
+    return o;
+  };
+  auto from_mf44 = [&](acc_t v) -> acc_t {
+    acc_t o;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) Tcv[(4 * (li >> 2) + lg) * 17 + 4 * (((li >> 2) + m) & 3) + (li & 3)] = (double)v[m];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (CT)Tcv[(lg + 4 * r) * 17 + li];
+    return o;
+  };
   acc_t acc[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
@@ -131,8 +169,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
         if (g.McolScale) v *= g.McolScale[(long)filt * g.strideMcol + j];
         acc[q][r] = (CT)v;
       }
+      if (MF44) acc[q] = to_mf44(acc[q]);
     }
   }
+  if (MF44 && !LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT)) __syncthreads();   // the pads overlap the k-panels
 
   const int steps0 = (g.seg[0].K + BK - 1) / BK;
   const int steps1 = g.nseg > 1 ? (g.seg[1].K + BK - 1) / BK : 0;
@@ -244,15 +284,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     if (t + 1 < nsteps) load_global(t + 1);
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
-      CT a[NA], bb[NB];
+      if constexpr (MF44) {
+        CT bb[NB];
 #pragma unroll
-      for (int x = 0; x < NA; ++x) a[x] = As[(4 * s + lg) * LDAS + 16 * arow(x) + li];
+        for (int x = 0; x < NB; ++x) bb[x] = Bs[(4 * s + lg) * LDBS + 16 * bcol(x) + li];
 #pragma unroll
-      for (int x = 0; x < NB; ++x) bb[x] = Bs[(4 * s + lg) * LDBS + 16 * bcol(x) + li];
+        for (int m = 0; m < 4; ++m) {       // one rotation of the A fragments at a time: NA live registers, not 4 NA
+          CT a[NA];
 #pragma unroll
-      for (int q = 0; q < NS; ++q) {
-        if (is_on(q))
-          acc[q] = Cx<CT>::mfma(bb[slot_b(q)], a[slot_a(q)], acc[q]);
+          for (int x = 0; x < NA; ++x) a[x] = As[(4 * s + lg) * LDAS + 16 * arow(x) + ((li + 4 * m) & 15)];
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            if (is_on(q)) acc[q][m] = Cx<CT>::mfma44(bb[slot_b(q)], a[slot_a(q)], acc[q][m]);
+          }
+        }
+      } else {
+        CT a[NA], bb[NB];
+#pragma unroll
+        for (int x = 0; x < NA; ++x) a[x] = As[(4 * s + lg) * LDAS + 16 * arow(x) + li];
+#pragma unroll
+        for (int x = 0; x < NB; ++x) bb[x] = Bs[(4 * s + lg) * LDBS + 16 * bcol(x) + li];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          if (is_on(q))
+            acc[q] = Cx<CT>::mfma(bb[slot_b(q)], a[slot_a(q)], acc[q]);
+        }
       }
     }
     __syncthreads();
@@ -293,6 +349,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     if (!is_on(q)) continue;
     const int I0 = m0 + 16 * arow(slot_a(q)), J0 = n0 + 16 * bcol(slot_b(q));
     const int i = I0 + li;
+    if (MF44) acc[q] = from_mf44(acc[q]);
     double v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -432,7 +489,8 @@ void gemm_pick_tile(int Mp, int Np, int lower_only, int* WM, int* WN) {
   for (const auto& c : cand) {
     const long pr = ((Mp + 32 * c[0] - 1) / (32 * c[0])) * 32L * c[0];
     const long pc = ((Np + 32 * c[1] - 1) / (32 * c[1])) * 32L * c[1];
-    const double cost = (double)pr * pc * (1.0 + 0.5 * (1.0 / c[0] + 1.0 / c[1]));
+    // tiles that run the 4x4x4 form issue 1.45x the flops per cycle (72 vs 49 TFLOP/s)
+    const double cost = (double)pr * pc * (1.0 + 0.5 * (1.0 / c[0] + 1.0 / c[1])) * (mf44_tile(c[0], c[1]) ? 1.0 : 1.45);
     if (best_cost < 0 || cost < best_cost || (cost == best_cost && c[0] * c[1] > bw * bn)) {
       best_cost = cost; bw = c[0]; bn = c[1];
     }
