@@ -44,8 +44,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // (XIVO_HIP_FLAG_FP32_COV: BASELINE.json config 4, covariance products only). Operands stay fp64 in HBM
 // and are rounded to fp32 when they are written to LDS; results are widened on store.
 template <typename CT> struct Cx;
-// fp64 products run on v_mfma_f64_4x4x4_4b_f64 by default: on gfx950 it sustains 72 TFLOP/s against 49 for
-// v_mfma_f64_16x16x4_f64 (scripts/mfma_probe.hip, measured on the MI355X). One 16x16x4 step becomes four 4x4x4
+// Optional (-DXIVO_MFMA44=1, off by default): fp64 products on v_mfma_f64_4x4x4_4b_f64. In a pure issue-rate probe
+// (scripts/mfma_probe.hip) it sustains 72 TFLOP/s on the MI355X against 49 for v_mfma_f64_16x16x4_f64, but in this
+// kernel it measured SLOWER (dense (KH-I)P 2.96 vs 2.20 ms per 4096 filters, T 6.93 vs 6.64 ms per 16384): 2.5x the
+// LDS fragment reads per flop with their latency exposed at 2 waves per SIMD, and 185 instead of 168 VGPRs for the
+// 128x64 tile (2 instead of 3 workgroups per CU). Kept for a future software-pipelined version. One 16x16x4 step becomes four 4x4x4
 // instructions, m = 0..3: lane group blk (= (lane & 15) >> 2) multiplies the B column block blk (the operand register
 // the 16x16x4 form uses, unchanged) with the A row block (blk + m) & 3 - the A fragment read from LDS rotated by 4 m
 // lanes within its 16-lane row. Operand layout (measured, scripts/mfma44_layout.hip): A / B lane = 16 k + 4 blk + i|j,
@@ -54,7 +57,10 @@ template <typename CT> struct Cx;
 // tiles are converted from / to the 16x16x4 accumulator layout through a per-wave LDS pad around the main loop, so
 // prologue and epilogue are shared. -DXIVO_MFMA44=0 builds the 16x16x4 form (A/B).
 #ifndef XIVO_MFMA44
-#define XIVO_MFMA44 1
+#define XIVO_MFMA44 0
+#endif
+#ifndef XIVO_NT_STORE
+#define XIVO_NT_STORE 0     // A/B: non-temporal stores of the output tile
 #endif
 template <> struct Cx<double> {
   typedef d4 acc_t; typedef d2 pair_t;
@@ -366,7 +372,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     for (int r = 0; r < 4; ++r) {
       const int jl = Cx<CT>::crow(lg, r);
       const int j = J0 + jl;
-      if (!g.lower_only || i >= j) Cb[i + (long)j * g.ldc] = v[r];
+      if (!g.lower_only || i >= j) {
+#if XIVO_NT_STORE
+        __builtin_nontemporal_store(v[r], &Cb[i + (long)j * g.ldc]);     // the output is not read again by this kernel
+#else
+        Cb[i + (long)j * g.ldc] = v[r];
+#endif
+      }
       if (need_t) Tw[jl * 17 + li] = v[r];   // T[j_local][i_local]
     }
     if (need_t) {
@@ -378,7 +390,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       for (int r = 0; r < 4; ++r) {
         const double t = Tw[li * 17 + lg + 4 * r];   // element (i2 = I0 + lg + 4r, j2 = J0 + li)
         const int i2 = I0 + lg + 4 * r, j2 = J0 + li;
+#if XIVO_NT_STORE
+        if (g.lower_only && !g.no_mirror && i2 > j2) __builtin_nontemporal_store(t, &Cb[j2 + (long)i2 * g.ldc]);
+#else
         if (g.lower_only && !g.no_mirror && i2 > j2) Cb[j2 + (long)i2 * g.ldc] = t;
+#endif
         if (C2b) C2b[j2 + (long)i2 * g.ldc2] = t;
       }
     }
