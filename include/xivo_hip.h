@@ -289,6 +289,17 @@ typedef struct {
 int xivo_hip_subfilter_update(xivo_hip_ctx* ctx, int b0, int nb, int n, xivo_subfilter_feat* feats,
                               const xivo_subfilter_opts* opts);
 
+/* Criteria::CandidateComparison (src/options.cpp:34-61): the order in which candidates enter the state
+ * (std::sort of src/manager.cpp:375-376,420-421,499-500). feats [nb x n] as returned by xivo_hip_subfilter_update;
+ * strict = 0: Criteria::Candidate passes, 1: Criteria::CandidateStrict. order_out [nb x n]: indices of the passing
+ * candidates of each filter, best first, padded with -1; n_out [nb] their number. The comparison is reproduced AS
+ * CODED: FeatureStatus first (READY before INITIALIZING), then Feature::score() = -P(2,2) - the value it computes from
+ * `comparison_score_type` is never used (:41-60). score_out (optional, [nb x n]) returns that value anyway:
+ * score_type 0 "DepthUncertainty" -P(2,2); 1 "CovarianceDiagNorm" -|diag P|; 2 "CovarianceDiagNormPlusOutlierCount"
+ * -(|diag P| + outlier_counter). Host arithmetic only. */
+int xivo_hip_candidate_order(const xivo_subfilter_feat* feats, int nb, int n, int strict, int score_type,
+                             int* order_out, int* n_out, double* score_out);
+
 /* ---- Estimator::Propagate on the device-resident state ----
  * For filters [b0, b0 + nb): integrates the nominal motion state (Rsb, Tsb, Vsb, bg, ba, Rsg of the resident
  * xivo_pose_in, xivo_hip_set_scene) over dt with RK4Step (src/rk4.cpp:35-103) or PrinceDormandStep

@@ -752,6 +752,22 @@ def candidate_flags(x, status, outlier_counter, zmin=0.05, zmax=5.0, max_subfilt
     return (status in (FEAT_READY, FEAT_INITIALIZING)) and ok, status == FEAT_READY and ok
 
 
+def candidate_scores(P, outlier_counter):
+    """the three `comparison_score_type` values Criteria::CandidateComparison computes (src/options.cpp:42-56):
+    DepthUncertainty, CovarianceDiagNorm, CovarianceDiagNormPlusOutlierCount."""
+    P = np.asarray(P)
+    dn = float(np.linalg.norm(np.diag(P)))
+    return -1.0 * float(P[2, 2]), -1.0 * dn, -1.0 * (dn + outlier_counter)
+
+
+def candidate_before(status1, P1, status2, P2):
+    """Criteria::CandidateComparison(f1, f2) as coded (src/options.cpp:58-60): status as integer (READY = 2 >
+    INITIALIZING = 1, src/core.h:190-199), then Feature::score() - the score of `comparison_score_type` is unused."""
+    s1 = 2 if status1 == FEAT_READY else 1
+    s2 = 2 if status2 == FEAT_READY else 1
+    return (s1 > s2) or (s1 == s2 and feature_score(P1) > feature_score(P2))
+
+
 def feature_score(P):
     """Feature::score(), src/feature.cpp:133-142: confidence in depth."""
     return -float(np.asarray(P)[2, 2])

@@ -89,3 +89,38 @@ def test_host_library_exports_the_batch_estimator(built):
                  "xivo_batch_book", "xivo_batch_stats", "xivo_batch_ctx", "xivo_host_selftest_update_step"):
         assert hasattr(host, name), name
     assert batch.batch_cfg_dtype.itemsize == 5600      # struct xivo_batch_cfg (host/batch_estimator.cpp)
+
+
+def test_candidate_comparison_order_matches_the_reference_as_coded():
+    """Criteria::CandidateComparison (src/options.cpp:34-61): status first, then Feature::score() = -P(2,2); the score of
+    `comparison_score_type` is computed but never used. Host-only entry point: runs without a GPU."""
+    import functools
+    import numpy as np
+    import xivo_oracle as orc
+    from xivo_amd.lib import candidate_order, subfilter_dtype
+    rng = np.random.default_rng(0)
+    nb, n = 3, 17
+    f = np.zeros((nb, n), dtype=subfilter_dtype)
+    for b in range(nb):
+        for i in range(n):
+            A = rng.normal(size=(3, 3)); P = A @ A.T * 1e-2
+            f[b, i]["P"] = P.T.reshape(-1)
+            f[b, i]["status"] = rng.integers(0, 2)
+            f[b, i]["outlier_counter"] = rng.choice([0.0, 0.005, 0.5])
+            ready = f[b, i]["status"] == orc.FEAT_READY
+            ok = rng.random() < 0.8
+            f[b, i]["candidate"] = (1 if ok else 0) | (2 if (ok and ready) else 0)
+    for strict in (False, True):
+        order, cnt, score = candidate_order(f, strict=strict, score_type=2)
+        for b in range(nb):
+            passing = [i for i in range(n) if f[b, i]["candidate"] & (2 if strict else 1)]
+            Pm = lambda i: f[b, i]["P"].reshape(3, 3).T
+            cmp = lambda a, c: -1 if orc.candidate_before(f[b, a]["status"], Pm(a), f[b, c]["status"], Pm(c)) else (
+                1 if orc.candidate_before(f[b, c]["status"], Pm(c), f[b, a]["status"], Pm(a)) else 0)
+            exp = sorted(passing, key=functools.cmp_to_key(cmp))          # stable, like the entry point
+            assert cnt[b] == len(passing) and order[b, :cnt[b]].tolist() == exp and (order[b, cnt[b]:] == -1).all()
+            for i in range(n):
+                assert abs(score[b, i] - orc.candidate_scores(Pm(i), f[b, i]["outlier_counter"])[2]) < 1e-15
+    s0 = candidate_order(f, score_type=0)[2]; s1 = candidate_order(f, score_type=1)[2]
+    assert abs(s0[1, 3] - orc.candidate_scores(f[1, 3]["P"].reshape(3, 3).T, 0)[0]) < 1e-15
+    assert abs(s1[1, 3] - orc.candidate_scores(f[1, 3]["P"].reshape(3, 3).T, 0)[1]) < 1e-15

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <cmath>
 #include <new>
 #include <vector>
 
@@ -1221,6 +1223,35 @@ int xivo_hip_subfilter_update(xivo_hip_ctx* c, int b0, int nb, int n, xivo_subfi
   }
   HIP_TRY(hipMemcpyAsync(feats, c->sub, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+// Criteria::CandidateComparison (src/options.cpp:34-61) and the selection order of SelectAndAddNewFeatures /
+// AddFeaturesToState-style loops (src/manager.cpp:364-376,417-421): host arithmetic on the array
+// xivo_hip_subfilter_update returned - no device work.
+int xivo_hip_candidate_order(const xivo_subfilter_feat* feats, int nb, int n, int strict, int score_type, int* order_out,
+                             int* n_out, double* score_out) {
+  if (!feats || nb < 0 || n <= 0 || !order_out || !n_out || score_type < 0 || score_type > 2) return XIVO_HIP_ERR_INVALID;
+  for (int b = 0; b < nb; ++b) {
+    const xivo_subfilter_feat* f = feats + (size_t)b * n;
+    std::vector<int> idx;
+    for (int i = 0; i < n; ++i) {
+      if (score_out) {
+        const double dn = sqrt(f[i].P[0] * f[i].P[0] + f[i].P[4] * f[i].P[4] + f[i].P[8] * f[i].P[8]);   // P().diagonal().norm()
+        score_out[(size_t)b * n + i] = score_type == 0 ? -1.0 * f[i].P[8] : (score_type == 1 ? -1.0 * dn : -1.0 * (dn + f[i].outlier_counter));
+      }
+      if (f[i].candidate & (strict ? 2 : 1)) idx.push_back(i);
+    }
+    // as coded, the comparison ignores the score it has just computed from comparison_score_type and orders by
+    // status, then Feature::score() = -P(2,2) (options.cpp:60); FeatureStatus READY = 2 > INITIALIZING = 1 (core.h:190-199).
+    // std::sort leaves the order of equivalent elements unspecified: here ties keep the list order.
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c2) {
+      const int s1 = f[a].status == XIVO_FEAT_READY ? 2 : 1, s2 = f[c2].status == XIVO_FEAT_READY ? 2 : 1;
+      return (s1 > s2) || (s1 == s2 && -f[a].P[8] > -f[c2].P[8]);
+    });
+    n_out[b] = (int)idx.size();
+    for (int i = 0; i < n; ++i) order_out[(size_t)b * n + i] = i < (int)idx.size() ? idx[i] : -1;
+  }
   return XIVO_HIP_OK;
 }
 

@@ -119,6 +119,7 @@ _SIGS = {
                         C.c_void_p],
     "xivo_hip_qr": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "xivo_hip_subfilter_update": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "xivo_hip_candidate_order": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_edit_batch": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_set_pixels": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_get_scene": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -169,6 +170,19 @@ def load_library():
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def candidate_order(feats, strict=False, score_type=0):
+    """Criteria::CandidateComparison order (src/options.cpp:34-61) of a [nb, n] subfilter_dtype array: returns
+    (order [nb, n] padded with -1, count [nb], score [nb, n] of `score_type`). Host arithmetic, no GPU needed."""
+    lib = load_library()
+    feats = np.ascontiguousarray(feats, dtype=subfilter_dtype)
+    nb, n = feats.shape
+    order = np.full((nb, n), -1, dtype=np.int32); cnt = np.zeros(nb, dtype=np.int32); score = np.zeros((nb, n))
+    rc = lib.xivo_hip_candidate_order(_ptr(feats), nb, n, int(strict), int(score_type), _ptr(order), _ptr(cnt), _ptr(score))
+    if rc != 0:
+        raise XivoHipError(rc, lib.xivo_hip_strerror(rc).decode())
+    return order, cnt, score
 
 
 def _ptr(a):
