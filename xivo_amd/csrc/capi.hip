@@ -53,6 +53,7 @@ struct xivo_hip_ctx {
   long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0, sA = 0;   // sA: A buffer, max(N x N, N x M)
   int M = 0, Mp = 0;  // rows currently staged
   int chunk = 0;      // filters per pipeline pass (0 = whole batch)
+  int chol_variant[32] = {0};   // per factor size (blocks): 0 = not calibrated yet, 1 / 2 = CholArgs::variant picked on this node
   // G-level
   xivo_layout lay{};
   xivo_cam cam{};
@@ -499,6 +500,35 @@ int xivo_hip_set_measurements_device(xivo_hip_ctx* c, int b0, int nb, int M, con
   return stage_measurements(c, b0, nb, M, dH, strideH, ldh, dInn, strideInn, dR, strideR);
 }
 
+// Big batches: which Cholesky kernel is faster depends on the node (the register kernel is ~170 KB of straight-line
+// code and loses 2.6x on nodes with slow instruction fetch, wins 20 % elsewhere - DESIGN.md). Timed once per factor
+// size on a scratch copy of the first batch's S (the A buffer is free at that point), then remembered.
+static int chol_pick(xivo_hip_ctx* c, const double* S, int Mp, int lds, int B) {
+  const int nb = Mp / 16;
+  if (B < 512 || nb > 12 || getenv("XIVO_HIP_CHOL_WAVE") || getenv("XIVO_HIP_CHOL_REG") || getenv("XIVO_HIP_NO_AUTOTUNE")) return 0;
+  if (c->chol_variant[nb]) return c->chol_variant[nb];
+  const int nt = B < 2048 ? B : 2048;            // a sample is enough
+  float best = 0.f; int pick = 1;
+  for (int v = 1; v <= 2; ++v) {
+    float ms_min = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+      if (hipMemcpyAsync(c->A, S, (size_t)nt * c->sS * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return 0;
+      CholArgs a{}; a.S = c->A; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = c->invD; a.strideInvD = c->sInvD;
+      a.status = c->status; a.batch = nt; a.variant = v;
+      hipEventRecord(c->t0, c->stream);
+      if (launch_chol_f64(a, c->stream)) return 0;
+      hipEventRecord(c->t1, c->stream);
+      if (hipEventSynchronize(c->t1) != hipSuccess) return 0;
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, c->t0, c->t1);
+      if (rep > 0 && ms < ms_min) ms_min = ms;      // first repetition = warm-up (code fetch)
+    }
+    if (v == 1 || ms_min < best) { best = ms_min; pick = v; }
+  }
+  c->chol_variant[nb] = pick;
+  return pick;
+}
+
 // One pass of the update pipeline over filters [b0, b0 + B).
 struct GateParams { int F; double R, thresh, mult; int min_inliers; };
 
@@ -563,8 +593,8 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   {
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B;
-    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
+    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B);
+    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
@@ -661,8 +691,8 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   {  // S = L L^T
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B;
-    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
+    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B);
+    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }

@@ -751,7 +751,8 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   // (A looped twin of the register kernel - runtime column loop, constant subscripts under uniform guards, 25 KB -
   //  keeps all 21 blocks live around the diagonal code and spills: 1.42 ms / 102 us. Not kept.)
   static const bool reg_always = getenv("XIVO_HIP_CHOL_REG") != nullptr;   // A/B knob
-  if (!old_kernel && nb <= 12 && (g.batch < 512 || reg_always)) {
+  const bool want_reg = g.variant == 2 || (g.variant == 0 && (g.batch < 512 || reg_always));
+  if (!old_kernel && nb <= 12 && g.variant != 1 && want_reg) {
     const int mirror = nb > 11 ? 1 : 0;   // only the streamed solve (nb >= 12) reads the mirrored upper triangle
     const bool many = g.batch >= 512;
     if (nb <= 4) hipLaunchKernelGGL((chol_reg_f64_kernel<4, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
@@ -789,9 +790,10 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   return (int)hipErrorInvalidValue;
 }
 
-void chol_kernel_label(int Mp, int batch, char* buf, size_t n) {
+void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
   const int nb = Mp / 16;
-  if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12 || (batch >= 512 && !getenv("XIVO_HIP_CHOL_REG"))) snprintf(buf, n, "chol_f64_kernel");
+  const bool reg = variant == 2 || (variant == 0 && (batch < 512 || getenv("XIVO_HIP_CHOL_REG")));
+  if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12 || variant == 1 || !reg) snprintf(buf, n, "chol_f64_kernel");
   else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)), (nb > 8 && batch >= 512) ? 3 : 2);
 }
 

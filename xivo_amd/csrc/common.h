@@ -85,9 +85,10 @@ struct CholArgs {
   long strideInvD;
   int* status;      // per filter: 0 ok, else 1 + first non-positive pivot index
   int batch;
+  int variant;      // 0: size heuristic; 1: one wave per filter (chol_f64_kernel); 2: four waves, factor in registers
 };
 int launch_chol_f64(const CholArgs& args, hipStream_t stream);
-void chol_kernel_label(int Mp, int batch, char* buf, size_t n);
+void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant = 0);
 
 struct TrsmArgs {
   const double* LU;    // from chol: L lower, L^T upper
