@@ -509,18 +509,22 @@ static int chol_pick(xivo_hip_ctx* c, const double* S, int Mp, int lds, int B) {
   if (c->chol_variant[nb]) return c->chol_variant[nb];
   const int nt = B < 2048 ? B : 2048;            // a sample is enough
   float best = 0.f; int pick = 1;
+  hipEvent_t e0, e1;                              // own events: the context's pair may be timing the caller's region
+  if (hipEventCreate(&e0) != hipSuccess) return 0;
+  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return 0; }
+  struct Guard { hipEvent_t a, b; ~Guard() { hipEventDestroy(a); hipEventDestroy(b); } } guard{e0, e1};
   for (int v = 1; v <= 2; ++v) {
     float ms_min = 1e30f;
     for (int rep = 0; rep < 2; ++rep) {
       if (hipMemcpyAsync(c->A, S, (size_t)nt * c->sS * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return 0;
       CholArgs a{}; a.S = c->A; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = c->invD; a.strideInvD = c->sInvD;
       a.status = c->status; a.batch = nt; a.variant = v;
-      hipEventRecord(c->t0, c->stream);
+      hipEventRecord(e0, c->stream);
       if (launch_chol_f64(a, c->stream)) return 0;
-      hipEventRecord(c->t1, c->stream);
-      if (hipEventSynchronize(c->t1) != hipSuccess) return 0;
+      hipEventRecord(e1, c->stream);
+      if (hipEventSynchronize(e1) != hipSuccess) return 0;
       float ms = 0.f;
-      hipEventElapsedTime(&ms, c->t0, c->t1);
+      hipEventElapsedTime(&ms, e0, e1);
       if (rep > 0 && ms < ms_min) ms_min = ms;      // first repetition = warm-up (code fetch)
     }
     if (v == 1 || ms_min < best) { best = ms_min; pick = v; }
