@@ -384,6 +384,24 @@ def main():
                  "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof_m.items() if v["launches"]}}
         ctx.set_flags(flags)
 
+    # ---- third figure (opt-in library mode, NOT the headline): XIVO_HIP_FLAG_SYMMETRIC_FORM - P+ = P - W^T W with
+    # W = L^-1 (H P), forward substitution only; equal to the Joseph form for the optimal gain, checked below
+    symm = None
+    if not args.no_mixed and sparse_path and args.level == "S":
+        from xivo_amd.lib import FLAG_SYMMETRIC_FORM
+        ctx.set_flags(base_flags | FLAG_SYMMETRIC_FORM)
+        ctx.restore_P()
+        dt_s, _, prof_s = timed(min(args.warmup, 2))
+        dt_s = max_over_ranks(dist, dt_s)
+        symm = {"value": world * B * args.steps / dt_s, "ms_per_step": dt_s / args.steps * 1e3,
+                "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof_s.items() if v["launches"]},
+                "what": "XIVO_HIP_FLAG_SYMMETRIC_FORM: S = L L^T, W = L^-1 (H P) (forward substitution only), dx = W^T L^-1 inn, "
+                        "P+ = P - W^T W - the value of the Joseph expression for the optimal gain, all fp64; opt-in, the "
+                        "reference codes the Joseph form (= `value`)"}
+        if not args.no_parity_check and rank == 0:
+            symm["parity_check"] = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating)
+        ctx.set_flags(flags)
+
     # ---- parity at the benchmarked batch: one step from the initial P, filters spread over the launch
     # (first / last, both sides of an XCD group of 8, mid batch) against the oracle - checker only, outside the timing
     parity = None
@@ -486,6 +504,8 @@ def main():
                        "not_spd_filters": int((status != 0).sum())},
             "value_mixed": mixed["value"] if mixed else None,
             "mixed": mixed,
+            "value_symmetric_form": symm["value"] if symm else None,
+            "symmetric_form": symm,
             "per_rank_updates_per_s": per_rank,
             "per_rank_min_max": [min(per_rank), max(per_rank)],
             "parity_check": parity,

@@ -80,7 +80,16 @@ enum {
    * By default that correction PRODUCT runs on the fp32 MFMA (G itself - a cancellation - and -T stay
    * fp64): its rounding adds <= 1e-7 |G K^T| to P+, orders of magnitude below the fp64 rounding of -T.
    * This flag keeps the correction product in fp64 as well. */
-  XIVO_HIP_FLAG_FP64_CORR = 128u
+  XIVO_HIP_FLAG_FP64_CORR = 128u,
+  /* Symmetric ("square-root") form of the gain and covariance: S = L L^T, W = L^-1 (H P) by forward substitution only,
+   *   dx = W^T (L^-1 inn),   P+ = P - W^T W
+   * - what the Joseph expression of src/estimator.cpp:1276-1287 evaluates to for the optimal gain K = P H^T S^-1 (its
+   * correction term (K S - P H^T) K^T vanishes identically), without the backward substitution, the gain residual and
+   * the second N x N x M product: about 55 % of the device time of the default. The result is symmetric by
+   * construction and its rounding error scales with cond(L) = sqrt(cond(S)). Opt-in: the reference codes the Joseph
+   * form and the default reproduces that expression; parity of this mode against the reference is tested to the same
+   * tolerances (1e-6 on P, 1e-8 on dx), including an ill-conditioned S. */
+  XIVO_HIP_FLAG_SYMMETRIC_FORM = 256u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,

@@ -362,3 +362,65 @@ def test_ill_conditioned_innovation_covariance(built, flags):
         assert rel_fro(err[b], e_ref) < 1e-6     # dx inherits cond(S) * eps from ANY solver; 1e-8 is for cond ~ 1e3
         w = np.linalg.eigvalsh(Pn[b])
         assert w.min() > -1e-9 * w.max()
+
+
+# ---------------------------------------------------------------- XIVO_HIP_FLAG_SYMMETRIC_FORM
+SYM_CASES = [(150, 50), (250, 80), (400, 150), (203, 30), (37, 3), (100, 192), (600, 20)]
+
+
+@pytest.mark.parametrize("N,F", SYM_CASES)
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+def test_symmetric_form_matches_the_reference_update(built, N, F, kind):
+    """P+ = P - W^T W, dx = W^T L^-1 inn with W = L^-1 (H P): what the Joseph form of estimator.cpp:1276-1287 evaluates to
+    for the optimal gain, without the backward solve and the correction product. Same tolerances as the default."""
+    from xivo_amd.lib import FLAG_SYMMETRIC_FORM
+    B = 4
+    P, H, inn, dR = synth.s_level(N, F, B, seed=N * 3 + F, dense=kind == "dense")
+    with Context(N, 2 * F, B, flags=FLAG_SYMMETRIC_FORM) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+        assert (ctx.get_status() == 0).all()
+    for b in range(B):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+        assert np.array_equal(Pn[b], Pn[b].T)
+
+
+def test_symmetric_form_gated_ill_conditioned_and_not_spd(built):
+    from xivo_amd.lib import FLAG_SYMMETRIC_FORM
+    # gating in front of it (the bench's step)
+    N, F, B = 250, 80, 3
+    P, H, inn, dR = _gating_case(N, F, B, 41)
+    with Context(N, 2 * F, B, flags=FLAG_SYMMETRIC_FORM) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
+        ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5)
+        mask, _ = ctx.get_gate(F)
+        err = ctx.get_err(); Pn = ctx.download_P()
+    for b in range(B):
+        m, _ = _oracle_gate(P[b], H[b], inn[b], 2.25, 5.991, 1.1, 5)
+        assert np.array_equal(mask[b], m) and not m.all()
+        rows = np.repeat(m, 2)
+        e_ref, P_ref, _ = orc.update_joseph(H[b][rows], P[b], inn[b][rows], dR[b][rows])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+    # cond(S) ~ 1e7: the error of this form scales with cond(L) = sqrt(cond(S))
+    N, F, B = 150, 40, 3
+    rng = np.random.default_rng(3)
+    _, H, inn, _ = synth.s_level(N, F, B, seed=5)
+    H *= 0.05
+    P = np.empty((B, N, N))
+    for b in range(B):
+        Q, _ = np.linalg.qr(rng.normal(size=(N, N)))
+        P[b] = (Q * np.logspace(-8, 0, N)) @ Q.T
+        P[b] = 0.5 * (P[b] + P[b].T)
+    dR = np.full((B, 2 * F), 1e-6)
+    dR[1, 7] = -1e12                           # and one filter whose S is not positive definite: prior kept, reported
+    with Context(N, 2 * F, B, flags=FLAG_SYMMETRIC_FORM) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        st = ctx.get_status(check=False)
+        err = ctx.get_err(); Pn = ctx.download_P()
+    assert st[1] != 0 and st[0] == 0 and st[2] == 0 and np.array_equal(Pn[1], P[1])
+    for b in (0, 2):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < 1e-6
+        w = np.linalg.eigvalsh(Pn[b])
+        assert w.min() > -1e-9 * w.max()

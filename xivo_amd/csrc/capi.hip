@@ -40,6 +40,7 @@ struct xivo_hip_ctx {
   double *P = nullptr, *Psnap = nullptr, *H = nullptr, *HT = nullptr, *HP = nullptr, *PHT = nullptr, *S = nullptr;
   double *K = nullptr, *A = nullptr, *T = nullptr, *invD = nullptr, *inn = nullptr, *diagR = nullptr;
   double *err = nullptr, *staging = nullptr, *scratch = nullptr;
+  double *neg1 = nullptr, *yvec = nullptr;   // symmetric form: a vector of -1 (operand scale), y = L^-1 inn per filter
   int* status = nullptr;
   // row-pair compressed H (ell.h) + host mirror of the per-filter "does not fit" flag
   EllBuffers ell{};
@@ -233,6 +234,7 @@ struct GemmExtra {
   int a_f32 = 0;   // first operand stored as float
   int no_mirror = 0;
   const int* skip = nullptr;   // per-filter status: non-zero = leave the output of that filter untouched
+  const double* scale0 = nullptr;   // per-k scale of the first segment's B operand (same vector for every filter)
 };
 
 int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0, long sA0, int lda0,
@@ -241,7 +243,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
          const GemmExtra& x) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
-  g.seg[0] = GemmSeg{A0, B0, nullptr, sA0, sB0, 0, lda0, ldb0, K0, x.a_f32};
+  g.seg[0] = GemmSeg{A0, B0, x.scale0, sA0, sB0, 0, lda0, ldb0, K0, x.a_f32};
   g.nseg = 1;
   if (A1) {
     g.seg[1] = GemmSeg{A1, B1, scale1, sA1, sB1, sScale1, lda1, ldb1, K1, 0};
@@ -291,7 +293,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
-                  c->staging, c->scratch, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
+                  c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
                   c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -325,6 +327,11 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   A(&c->S, B * c->sS); A(&c->K, B * c->sK); A(&c->A, B * c->sA); A(&c->T, B * c->sP);
   A(&c->invD, B * c->sInvD); A(&c->inn, B * Mp); A(&c->diagR, B * Mp); A(&c->err, B * Np);
   A(&c->status, B); A(&c->scratch, B * Np);
+  A(&c->neg1, Mp); A(&c->yvec, B * Mp);
+  if (rc == XIVO_HIP_OK) {
+    std::vector<double> m1(Mp, -1.0);
+    if (hipMemcpy(c->neg1, m1.data(), Mp * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
+  }
   c->ell.pairs_max = (int)(Mp / 2);
   A(&c->ell.idx, B * c->ell.stride_idx()); A(&c->ell.val, B * c->ell.stride_val()); A(&c->ell.nc, B); A(&c->ell.pw, B); A(&c->ell.over, B);
   c->ell_over_h.assign(B, 1); c->ell_nc_h.assign(B, ELL_CW); c->ell_pw_h.assign(B, ELL_PW);
@@ -536,6 +543,34 @@ static int chol_pick(xivo_hip_ctx* c, const double* S, int Mp, int lds, int B) {
 // One pass of the update pipeline over filters [b0, b0 + B).
 struct GateParams { int F; double R, thresh, mult; int min_inliers; };
 
+// XIVO_HIP_FLAG_SYMMETRIC_FORM: gain and covariance in the symmetric "square-root" form. With S = L L^T and
+// W = L^-1 (H P) (forward substitution only):  K (H P) = W^T W,  dx = K inn = W^T (L^-1 inn),  P+ = P - W^T W.
+// This is the covariance the Joseph form of src/estimator.cpp:1276-1287 evaluates to for the optimal gain (the Joseph
+// correction term vanishes identically), computed without the backward substitution, the residual G and the second
+// N x N x M product; its rounding error grows with cond(L) = sqrt(cond(S)), not cond(S). Opt-in: the reference codes
+// the Joseph form, which stays the default.
+static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, double* invD, double* PHT, double* K, double* P,
+                            const double* inn, int Mp, int Np, bool full) {
+  double* y = c->yvec + (long)b0 * c->Mpmax;
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "fwd_vec_kernel");
+    if (launch_fwd_vec(S, c->sS, lds, invD, c->sInvD, inn, c->Mpmax, y, c->Mpmax, Mp, B, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  {
+    TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
+    a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
+    a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
+    a.batch = B; a.fwd_only = 1; a.y = y; a.strideY = c->Mpmax;
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
+    StageTimer st(c, ST_TRSM, 1.0 * Mp * Mp * Np * B, label, 8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
+    if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+  }
+  // P+ = P - W^T W in place: accumulators start at +P (read before anything of the tile is stored), B operand scaled by -1
+  GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
+  x.scale0 = c->neg1; x.skip = c->status + b0;
+  return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
+}
+
 // Sparse-H pipeline (ell.h): H P, S and T H^T skip the structural zeros of H on the vector ALU; the
 // factorisation, the gain and the two N x N x M covariance products stay on the MFMA kernels.
 //   HP = H P (+ P H^T)            ell_mul<HP>      estimator.cpp:1259
@@ -602,6 +637,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
+  if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
   {
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
@@ -700,6 +736,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
   }
+  if ((c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) && !f32) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;

@@ -167,6 +167,38 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
   if (lane == 0) g.status[filt] = bad;
 }
 
+// y = L^-1 inn, one wave per filter: block row k after block row k - 1; the lanes split the dot products of the 16
+// rows over the columns already solved (4 lanes per row, strided), then inv(L_kk) (16 x 16, kept by the factorisation)
+// finishes the block. 160^2 / 2 multiply-adds per filter - negligible next to the matrix solve.
+__global__ __launch_bounds__(64) void fwd_vec_kernel(const double* __restrict__ LUall, long strideLU, int ldlu,
+                                                     const double* __restrict__ invDall, long strideInvD,
+                                                     const double* __restrict__ innall, long strideInn, double* __restrict__ yall,
+                                                     long strideY, int Mp, int batch) {
+  __shared__ double sy[4][384];                          // y of the wave's filter (LDS: same-wave write -> read is ordered)
+  const int wv = threadIdx.x >> 6;
+  const int filt = blockIdx.x * (blockDim.x >> 6) + wv;
+  if (filt >= batch) return;
+  const int lane = threadIdx.x & 63, r = lane & 15, part = lane >> 4;
+  const double* L = LUall + (long)filt * strideLU;
+  const double* invD = invDall + (long)filt * strideInvD;
+  const double* inn = innall + (long)filt * strideInn;
+  double* y = yall + (long)filt * strideY;
+  double* ys = sy[wv];
+  const int nb = Mp / 16;
+  for (int k = 0; k < nb; ++k) {
+    double acc = 0.0;
+    for (int c = part; c < 16 * k; c += 4) acc = fma(L[(16 * k + r) + (long)c * ldlu], ys[c], acc);
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    const double rhs = inn[16 * k + r] - acc;             // valid in every lane (all four parts hold the sum)
+    // y_k = inv(L_kk) rhs: row r of the inverse (column-major 16 x 16) against the 16 right-hand sides
+    double out = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) out = fma(invD[(long)k * 512 + r + 16 * c], __shfl(rhs, c), out);
+    if (part == 0) { ys[16 * k + r] = out; y[16 * k + r] = out; }
+  }
+}
+
 template <class F, int... Js>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Js...>) {
   (f(std::integral_constant<int, Js>{}), ...);
@@ -403,7 +435,7 @@ __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
   // backward: L^T K^T = Y
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
-    if (k < nb) {
+    if (k < nb && !g.fwd_only) {
       d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s = 0; s < 4; ++s) t = mfma(invD[(long)k * 512 + 256 + li + (4 * s + lg) * 16], X[k][s], t);
@@ -421,7 +453,7 @@ __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
 
   // K[(c0+li), m] = X[m-block][..];  dx[c0+li] = sum_m K * inn
   double* __restrict__ K = g.K + (long)filt * g.strideK;
-  const double* __restrict__ inn = g.inn + (long)filt * g.strideInn;
+  const double* __restrict__ inn = g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn;
   double part = 0.0;
 #pragma unroll
   for (int i = 0; i < NBM; ++i) {
@@ -516,7 +548,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   // backward: L^T K^T = Y
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
-    if (k < nb) {
+    if (k < nb && !g.fwd_only) {
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
       d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -534,7 +566,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   }
 
   double* __restrict__ K = g.K + (long)filt * g.strideK;
-  const double* __restrict__ inn = g.inn + (long)filt * g.strideInn;
+  const double* __restrict__ inn = g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn;
   double part = 0.0;
 #pragma unroll
   for (int i = 0; i < NBM; ++i) {
@@ -651,12 +683,14 @@ __global__ __launch_bounds__(512) void trsm_stream_f64_kernel(TrsmArgs g) {
   }
   // ---- backward: L^T K^T = Y  (panels of column k of the upper triangle = rows of L^T)
   __syncthreads();
-  panel_load(nb - 1, false);
-  panel_store(nb - 1, false, buf0);
+  if (!g.fwd_only) {
+    panel_load(nb - 1, false);
+    panel_store(nb - 1, false, buf0);
+  }
   int par = 0;
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
-    if (k < nb) {
+    if (k < nb && !g.fwd_only) {
       __syncthreads();
       const double* cur = par ? buf1 : buf0;
       double* nxt = par ? buf0 : buf1;
@@ -678,7 +712,7 @@ __global__ __launch_bounds__(512) void trsm_stream_f64_kernel(TrsmArgs g) {
   }
   if (!live) return;
   double* __restrict__ K = g.K + (long)filt * g.strideK;
-  const double* __restrict__ inn = g.inn + (long)filt * g.strideInn;
+  const double* __restrict__ inn = g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn;
   double part = 0.0;
 #pragma unroll
   for (int i = 0; i < NBM; ++i) {
@@ -788,6 +822,14 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   if (nb <= 19) return launch_trsm_t<19>(g, stream);
   if (nb <= 24) return launch_trsm_t<24>(g, stream);
   return (int)hipErrorInvalidValue;
+}
+
+int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD, long strideInvD, const double* inn, long strideInn,
+                   double* y, long strideY, int Mp, int batch, hipStream_t stream) {
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(fwd_vec_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, LU, strideLU, ldlu, invD, strideInvD, inn, strideInn,
+                     y, strideY, Mp, batch);
+  return (int)hipGetLastError();
 }
 
 void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {

@@ -108,8 +108,14 @@ struct TrsmArgs {
   long strideErr;
   int Mp, Np;
   int batch;
+  int fwd_only;        // 1: stop after the forward substitution: K receives W^T = (L^-1 HP)^T and dx = W^T y with
+  const double* y;     //    y = L^-1 inn [Mp] (launch_fwd_vec) - the symmetric form P+ = P - W^T W needs no more
+  long strideY;
 };
 int launch_trsm_f64(const TrsmArgs& args, hipStream_t stream);
+// y = L^-1 inn for every filter (one wave each): the forward substitution of the innovation vector
+int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD, long strideInvD, const double* inn, long strideInn,
+                   double* y, long strideY, int Mp, int batch, hipStream_t stream);
 void trsm_kernel_label(int Mp, char* buf, size_t n);
 
 }  // namespace xivo_hip
