@@ -266,6 +266,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
                                   (x.msub ? outs : 0.0) + (double)rows * cols + (x.C2 ? (double)rows * cols : 0.0));
   StageTimer st(c, stage, flops, label, bytes);
   const int rc = sym ? launch_gemm_sym_f64(g, c->stream) : launch_gemm_nt_f64(g, c->stream);
+  if (rc != 0 && debug_on()) fprintf(stderr, "xivo_hip: gemm launch (%s) -> %s\n", label, hipGetErrorString((hipError_t)rc));
   return rc == 0 ? XIVO_HIP_OK : XIVO_HIP_ERR_HIP;
 }
 
@@ -554,7 +555,7 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
   double* y = c->yvec + (long)b0 * c->Mpmax;
   {
     StageTimer st(c, ST_OTHER, 0.0, "fwd_vec_kernel");
-    if (launch_fwd_vec(S, c->sS, lds, invD, c->sInvD, inn, c->Mpmax, y, c->Mpmax, Mp, B, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_fwd_vec(S, c->sS, lds, invD, c->sInvD, inn, c->Mpmax, y, c->Mpmax, Mp, B, c->stream));
   }
   {
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
@@ -563,7 +564,7 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
     a.batch = B; a.fwd_only = 1; a.y = y; a.strideY = c->Mpmax;
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
     StageTimer st(c, ST_TRSM, 1.0 * Mp * Mp * Np * B, label, 8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
-    if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
   }
   // P+ = P - W^T W in place: accumulators start at +P (read before anything of the tile is stored), B operand scaled by -1
   GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
 // y = L^-1 inn, one wave per filter: block row k after block row k - 1; the lanes split the dot products of the 16
 // rows over the columns already solved (4 lanes per row, strided), then inv(L_kk) (16 x 16, kept by the factorisation)
 // finishes the block. 160^2 / 2 multiply-adds per filter - negligible next to the matrix solve.
-__global__ __launch_bounds__(64) void fwd_vec_kernel(const double* __restrict__ LUall, long strideLU, int ldlu,
+__global__ __launch_bounds__(256) void fwd_vec_kernel(const double* __restrict__ LUall, long strideLU, int ldlu,
                                                      const double* __restrict__ invDall, long strideInvD,
                                                      const double* __restrict__ innall, long strideInn, double* __restrict__ yall,
                                                      long strideY, int Mp, int batch) {
