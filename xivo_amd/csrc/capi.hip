@@ -263,7 +263,8 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   char label[64] = "gemm_sym_f64_kernel";
   if (!sym) gemm_kernel_label(g, label, sizeof(label));
   const double bytes = 8.0 * B * ((double)rows * K0 * (x.a_f32 ? 0.5 : 1.0) + (double)cols * K0 + (A1 ? ((double)rows + cols) * K1 : 0.0) +
-                                  (x.msub ? outs : 0.0) + (double)rows * cols + (x.C2 ? (double)rows * cols : 0.0));
+                                  (x.msub ? outs : 0.0) + (double)rows * cols + (x.C2 ? (double)rows * cols : 0.0))
+                       - (A0 == B0 ? 8.0 * B * (double)cols * K0 : 0.0);   // a symmetric product reads its one operand once
   StageTimer st(c, stage, flops, label, bytes);
   const int rc = sym ? launch_gemm_sym_f64(g, c->stream) : launch_gemm_nt_f64(g, c->stream);
   if (rc != 0 && debug_on()) fprintf(stderr, "xivo_hip: gemm launch (%s) -> %s\n", label, hipGetErrorString((hipError_t)rc));
@@ -566,9 +567,10 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
     StageTimer st(c, ST_TRSM, 1.0 * Mp * Mp * Np * B, label, 8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
   }
-  // P+ = P - W^T W in place: accumulators start at +P (read before anything of the tile is stored), B operand scaled by -1
-  GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
-  x.scale0 = c->neg1; x.skip = c->status + b0;
+  // P+ = P - W^T W in place: the accumulators start at -P (every tile reads its part of P before it stores anything)
+  // and the result is negated on the way out
+  GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
+  x.skip = c->status + b0;
   return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
 }
 

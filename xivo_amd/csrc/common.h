@@ -37,6 +37,7 @@ enum GemmEpilogue : int {
   EPI_SUB_IDENT = 2,  // C[i][i] -= 1            (KH - I,       estimator.cpp:1276-1279)
   EPI_SUB_MAT = 3,    // C = acc - Msub          (T = K(HP) - P,  estimator.cpp:1280)
   EPI_ADD_MAT = 4,    // C = acc + Msub          (Phi P Phi^T + Q)
+  EPI_RSUB_MAT = 5,   // C = Msub - acc          (P+ = P - W^T W, the symmetric form)
 };
 
 struct GemmArgs {

@@ -164,10 +164,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     acc[q] = Cx<CT>::zero();
-    if (!LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT) && is_on(q)) {
+    if (!LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT || g.epilogue == EPI_RSUB_MAT) && is_on(q)) {
       const double* Ms = g.Msub + (long)filt * g.strideMsub;
       const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
-      const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;
+      const double sgn = g.epilogue == EPI_ADD_MAT ? 1.0 : -1.0;      // RSUB: acc - Msub here, negated in the epilogue
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = J0 + Cx<CT>::crow(lg, r);
@@ -178,7 +178,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       if (MF44) acc[q] = to_mf44(acc[q]);
     }
   }
-  if (MF44 && !LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT)) __syncthreads();   // the pads overlap the k-panels
+  if (MF44 && !LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT || g.epilogue == EPI_RSUB_MAT)) __syncthreads();   // the pads overlap the k-panels
 
   const int steps0 = (g.seg[0].K + BK - 1) / BK;
   const int steps1 = g.nseg > 1 ? (g.seg[1].K + BK - 1) / BK : 0;
@@ -361,6 +361,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     for (int r = 0; r < 4; ++r) {
       const int j = J0 + Cx<CT>::crow(lg, r);
       v[r] = (double)acc[q][r];
+      if (!LATE_MSUB && g.epilogue == EPI_RSUB_MAT) v[r] = -v[r];
       if (late_ms) v[r] += msring[LATE_MSUB ? q % MSD : 0][r];
       if (g.epilogue == EPI_ADD_DIAG) {
         if (i == j) v[r] += dg[i];
@@ -545,7 +546,7 @@ static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
   // accumulators initialised from memory (T = K(HP) - P): the 64 extra loads per lane sit in the
   // tile prologue; the narrower 128x64 tile (3 instead of 2 workgroups per CU) hides them
   // (measured 0.54 vs 0.72 ms per 1024 filters at N=250)
-  if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
+  if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT || a.epilogue == EPI_RSUB_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
       !getenv("XIVO_HIP_TILE"))
     wn = 2;
   *wm_out = wm; *wn_out = wn;
