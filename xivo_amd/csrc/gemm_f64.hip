@@ -139,7 +139,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   // fp32 products keep Msub in fp64: it is added to the widened accumulators in the epilogue
   // (loaded after the main loop, when the staging registers are dead) instead of being rounded
   // to fp32 here.
-  constexpr bool LATE_MSUB = sizeof(CT) == 4;
+#ifndef XIVO_LATE_MSUB_F64
+#define XIVO_LATE_MSUB_F64 0   // A/B: fp64 products also fetch Msub through the epilogue ring instead of initialising the accumulators
+#endif
+  constexpr bool LATE_MSUB = sizeof(CT) == 4 || XIVO_LATE_MSUB_F64;
   constexpr bool MF44 = mf44_tile(WM, WN) && sizeof(CT) == 8;
   // 16x16x4 accumulator layout <-> 4x4x4 accumulator layout of one 16x16 block through this wave's LDS pad
   // (pad element (i, j) of the block at j * 17 + i; same-wave LDS writes and reads are ordered)
@@ -324,11 +327,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   // the stores (holding all of it would cost 128 VGPRs and the third workgroup per CU)
   constexpr int MSD = 4;
   double msring[LATE_MSUB ? MSD : 1][4];
-  const bool late_ms = LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT);
+  const bool late_ms = LATE_MSUB && (g.epilogue == EPI_SUB_MAT || g.epilogue == EPI_ADD_MAT || g.epilogue == EPI_RSUB_MAT);
   auto load_ms = [&](int q) {
     if (q >= NS || !is_on(q)) return;
     const double* Ms = g.Msub + (long)filt * g.strideMsub;
-    const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;
+    const double sgn = g.epilogue == EPI_SUB_MAT ? -1.0 : 1.0;       // RSUB: + Msub, the accumulator is negated below
     const int i = m0 + 16 * arow(slot_a(q)) + li, J0 = n0 + 16 * bcol(slot_b(q));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -361,7 +364,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     for (int r = 0; r < 4; ++r) {
       const int j = J0 + Cx<CT>::crow(lg, r);
       v[r] = (double)acc[q][r];
-      if (!LATE_MSUB && g.epilogue == EPI_RSUB_MAT) v[r] = -v[r];
+      if (g.epilogue == EPI_RSUB_MAT) v[r] = -v[r];
       if (late_ms) v[r] += msring[LATE_MSUB ? q % MSD : 0][r];
       if (g.epilogue == EPI_ADD_DIAG) {
         if (i == j) v[r] += dg[i];
