@@ -1,0 +1,48 @@
+"""bench.py end to end on the GPU box at a small batch: one JSON line with the contract's keys, the three precision
+figures, the in-bench parity check, roofline and the per-stage times (the hand-over stage inside the timed step)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "512", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_default_line(built):
+    d = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["unit"] == "updates/s" and d["value"] > 0
+    assert "workload" in d["config"] and "precision" in d["config"] and "hand_over" in d["config"]
+    assert d["config"]["pipeline"].startswith("sparse-H") and d["config"]["not_spd_filters"] == 0
+    # the three modes, slowest to fastest at this size, each with its own figure
+    assert d["value_mixed"] > 0 and d["value_symmetric_form"] > d["value"]
+    assert d["parity_check"]["ok"] and d["parity_check"]["rel_fro_P_max"] < 1e-6 and d["parity_check"]["inlier_masks_equal"]
+    assert d["symmetric_form"]["parity_check"]["ok"]
+    st = d["stage_ms_per_step"]
+    assert st["stack_H"] > 0 and st["gemm_AP"] > 0 and st["trsm_gain"] > 0      # hand-over is a timed stage
+    assert "gemm_AP" not in d["symmetric_form"]["stage_ms_per_step"]            # no T pass in the symmetric form
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["kernel"] and r["avg_launch_ms"] > 0
+    assert len(d["per_rank_updates_per_s"]) == 1
+
+
+def test_feature_level_and_config3_lines(built):
+    d = _run("--level", "G", "--ransac")
+    assert d["value"] > 0 and "OnePointRANSAC" in d["config"]["workload"]
+    d = _run("--level", "G", "--oos", "20")
+    assert d["value"] > 0 and "QR-compressed" in d["config"]["workload"] and d["config"]["pipeline"] == "dense as-coded"
