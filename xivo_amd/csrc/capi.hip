@@ -375,7 +375,7 @@ int xivo_hip_upload_P(xivo_hip_ctx* c, int b0, int nb, const double* P, long str
   if (rc) return rc;
   rc = h2d_packed(c, c->staging, P, nb, N, N, stride, ld);
   if (rc) return rc;
-  if (launch_unpack_P(c->staging, c->P + (long)b0 * c->sP, N, c->Np, c->Np, c->sP, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY((hipError_t)launch_unpack_P(c->staging, c->P + (long)b0 * c->sP, N, c->Np, c->Np, c->sP, nb, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // host buffer is only borrowed for the call
   return XIVO_HIP_OK;
 }
@@ -388,7 +388,7 @@ int xivo_hip_download_P(xivo_hip_ctx* c, int b0, int nb, double* P, long stride,
   const int N = c->N;
   int rc = ensure_staging(c, (size_t)nb * N * N);
   if (rc) return rc;
-  if (launch_pack_P(c->P + (long)b0 * c->sP, c->staging, N, c->Np, c->sP, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY((hipError_t)launch_pack_P(c->P + (long)b0 * c->sP, c->staging, N, c->Np, c->sP, nb, c->stream));
   rc = d2h_packed(c, P, c->staging, nb, N, N, stride, ld);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -437,7 +437,7 @@ int xivo_hip_p_set_block3(xivo_hip_ctx* c, int b, int off, const double* P3) {
 int xivo_hip_p_diag(xivo_hip_ctx* c, int b, double* out) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b, 1) || !out) return XIVO_HIP_ERR_INVALID;
-  if (launch_p_diag(c->P + (long)b * c->sP, c->Np, c->N, c->scratch, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY((hipError_t)launch_p_diag(c->P + (long)b * c->sP, c->Np, c->N, c->scratch, c->stream));
   HIP_TRY(hipMemcpyAsync(out, c->scratch, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return XIVO_HIP_OK;
@@ -516,7 +516,10 @@ static int chol_pick(xivo_hip_ctx* c, const double* S, int Mp, int lds, int B) {
   const int nb = Mp / 16;
   if (B < 512 || nb > 12 || getenv("XIVO_HIP_CHOL_WAVE") || getenv("XIVO_HIP_CHOL_REG") || getenv("XIVO_HIP_NO_AUTOTUNE")) return 0;
   if (c->chol_variant[nb]) return c->chol_variant[nb];
-  const int nt = B < 2048 ? B : 2048;            // a sample is enough
+  int nt = B < 2048 ? B : 2048;                  // a sample is enough
+  const long fit = (long)c->Bmax * c->sA / c->sS;   // ... and it has to fit the scratch copy (S can be larger than A: M > N)
+  if (fit < nt) nt = (int)fit;
+  if (nt < 256) return 0;
   float best = 0.f; int pick = 1;
   hipEvent_t e0, e1;                              // own events: the context's pair may be timing the caller's region
   if (hipEventCreate(&e0) != hipSuccess) return 0;
@@ -610,7 +613,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
     char label[64]; ell_kernel_label(ELL_HP, a, label, sizeof(label));
     StageTimer st(c, ST_HP, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
-    if (launch_ell_mul(ELL_HP, a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_ell_mul(ELL_HP, a, c->stream));
   }
   {
     EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
@@ -618,7 +621,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max;
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
     StageTimer st(c, ST_S, nnz_flops * Mp * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
-    if (launch_ell_mul(ELL_S, a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_ell_mul(ELL_S, a, c->stream));
   }
   if (gate) {
     GateEllArgs a{}; a.ell = e;
@@ -631,14 +634,14 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
     StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
     c->gate_sparse_last = 0;
-    if (launch_gate_ell(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_gate_ell(a, c->stream));
   }
   {
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B);
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
-    if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
   }
   if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
   {
@@ -649,7 +652,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
     StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
-    if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
   }
   {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
      // triangle is computed and mirrored (XIVO_HIP_FLAG_FULL_PNEW: all of it)
@@ -669,7 +672,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     const int gmode = g_f32 ? ELL_GF : ELL_G;
     char label[64]; ell_kernel_label(gmode, a, label, sizeof(label));
     StageTimer st(c, ST_KH, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (g_f32 ? 1.5 : 2.0) * Np * Mp));
-    if (launch_ell_mul(gmode, a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_ell_mul(gmode, a, c->stream));
   }
   {  // P+ = G K^T - T   (lower triangle + mirror)
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
@@ -724,7 +727,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.ell = c->ell; a.have_ell = 0;
     StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
     c->gate_sparse_last = 0;
-    if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_gate_dense(a, c->stream));
   }
   {  // S = HP * H^T + diag(R)  (estimator.cpp:1259-1263); lower triangle + mirror
     GemmExtra x; x.epi = EPI_ADD_DIAG; x.diag = diagR; x.sDiag = c->Mpmax; x.lower_only = full ? 0 : 1;
@@ -737,7 +740,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B);
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
-    if (launch_chol_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
   }
   if ((c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) && !f32) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
@@ -748,7 +751,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
     StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
-    if (launch_trsm_f64(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
   }
   if (c->flags & XIVO_HIP_FLAG_REASSOC) {
     {  // T = K (HP) - P
@@ -916,7 +919,7 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
   {
     StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
     c->gate_sparse_last = 0;
-    if (launch_gate_dense(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_gate_dense(a, c->stream));
   }
   if (mask_out) HIP_TRY(hipMemcpyAsync(mask_out, c->mask, (size_t)B * F, hipMemcpyDeviceToHost, c->stream));
   if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, c->dist, (size_t)B * F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1094,7 +1097,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   a.rows_out = c->oos_rows;
   {
     StageTimer st(c, ST_OTHER, 0.0);
-    if (launch_oos(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_oos(a, c->stream));
   }
   if (rows_out) HIP_TRY(hipMemcpyAsync(rows_out, c->oos_rows, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1140,7 +1143,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   a.keep = c->rs_keep; a.chi = c->rs_chi; a.n_rejected = c->rs_nrej; a.batch = B;
   {
     StageTimer st(c, ST_OTHER, 0.0, "ransac_select_kernel");
-    if (launch_ransac_select(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_ransac_select(a, c->stream));
   }
   // the low-innovation set as select found it (filters with nothing to update get an all-neutral stacking mask)
   HIP_TRY(hipMemcpyAsync(c->rs_lowkeep, c->rs_low, (size_t)B * c->Fmax, hipMemcpyDeviceToDevice, c->stream));
@@ -1150,7 +1153,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   HIP_TRY(hipMemcpyAsync(c->groups_rs, c->groups, (size_t)B * ng * sizeof(xivo_group_in), hipMemcpyDeviceToDevice, c->stream));
   {
     StageTimer st(c, ST_OTHER, 0.0, "ransac_zero_kernel");
-    if (launch_ransac_zero(a, c->P, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_ransac_zero(a, c->P, c->stream));
   }
   // partial update: H_ rows = the full J() of the low-innovation inliers (:326 - no FillJacobianBlock), R_ on the diagonal
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
@@ -1168,13 +1171,13 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
     ab.lay = c->lay; ab.F = c->F; ab.Fmax = c->Fmax; ab.batch = B; ab.counter = nullptr; ab.status = c->status;
     ab.group_mask = absorb_groups ? c->rs_gmask : nullptr;
     StageTimer st(c, ST_OTHER, 0.0, "absorb_error_kernel");
-    if (launch_absorb_error(ab, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_absorb_error(ab, c->stream));
   }
   rc = xivo_hip_jacobians_instate(c, B);                                   // :348 at the updated state
   if (rc) return rc;
   {
     StageTimer st(c, ST_OTHER, 0.0, "ransac_rescue_kernel");
-    if (launch_ransac_rescue(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_ransac_rescue(a, c->stream));
   }
   // RestoreState + Jacobians at the original state (:383-387)
   HIP_TRY(hipMemcpyAsync(c->P, c->Prs, (size_t)B * c->sP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1253,7 +1256,7 @@ static int givens_impl(xivo_hip_ctx* c, int nb, int rows, int nx, int nf, double
   a.batch = nb; a.qr = qr;
   {
     StageTimer st(c, ST_OTHER, 0.0, "givens_kernel");
-    if (launch_givens(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_givens(a, c->stream));
   }
   HIP_TRY(hipMemcpyAsync(x, dx, ex * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(Hx, dHx, ehx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1389,7 +1392,7 @@ int xivo_hip_edit_batch(xivo_hip_ctx* c, int F, int n_ops, const xivo_edit_op* o
   a.poses = c->poses; a.groups = c->groups; a.feats = c->feats; a.Fmax = c->Fmax;
   {
     StageTimer st(c, ST_OTHER, 0.0, "edit_batch_kernel");
-    if (launch_edit_batch(a, n_wg, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_edit_batch(a, n_wg, c->stream));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors above are pageable staging
   return XIVO_HIP_OK;
@@ -1406,7 +1409,7 @@ int xivo_hip_set_pixels(xivo_hip_ctx* c, int b0, int nb, int F, const double* xp
   if (rc) return rc;
   c->F = F;
   HIP_TRY(hipMemcpyAsync(c->staging, xp, (size_t)nb * F * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  if (launch_set_pixels(c->feats + (size_t)b0 * c->Fmax, c->Fmax, F, c->staging, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+  HIP_TRY((hipError_t)launch_set_pixels(c->feats + (size_t)b0 * c->Fmax, c->Fmax, F, c->staging, nb, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));   // xp is borrowed host memory
   return XIVO_HIP_OK;
 }
@@ -1486,13 +1489,13 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
   {
     StageTimer st(c, ST_PROP_STATE, 0.0, "propagate_state_kernel");
-    if (launch_propagate_state(a, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_propagate_state(a, c->stream));
   }
   {
     // tail: reads and writes the 23 rows and 23 columns of P that change (+ Phi, P_mm)
     StageTimer st(c, ST_PROP_TAIL, 0.0, "propagate_cov_fixed_kernel<23>",
                   (double)nb * (4.0 * 23 * c->N + 2.0 * 529) * sizeof(double));
-    if (launch_propagate_cov(c->P, c->sP, c->Np, c->N, c->Np, 23, dPhi, dPmm, b0, nb, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_propagate_cov(c->P, c->sP, c->Np, c->N, c->Np, 23, dPhi, dPmm, b0, nb, c->stream));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));   // imu / opts are borrowed host memory
   return XIVO_HIP_OK;
@@ -1582,9 +1585,9 @@ int xivo_hip_bench_mfma_peak(xivo_hip_ctx* c, double* out4) {
   double res[2][2];
   for (int mode = 0; mode < 2; ++mode) {
     const int blocks = mode == 0 ? 256 * 8 : 256;
-    if (launch_mfma_peak(c->scratch, 10, blocks, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_mfma_peak(c->scratch, 10, blocks, c->stream));
     HIP_TRY(hipEventRecord(c->t0, c->stream));
-    if (launch_mfma_peak(c->scratch, iters, blocks, c->stream)) return XIVO_HIP_ERR_HIP;
+    HIP_TRY((hipError_t)launch_mfma_peak(c->scratch, iters, blocks, c->stream));
     HIP_TRY(hipEventRecord(c->t1, c->stream));
     HIP_TRY(hipEventSynchronize(c->t1));
     float ms = 0.f;
