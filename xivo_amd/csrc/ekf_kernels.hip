@@ -426,10 +426,18 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   double* HT = a.mb.HT + (long)filt * a.mb.strideHT;
   // H_.setZero(total_size, N) (update.cpp:130)
   if (a.write_dense) {
-    for (int n = 0; n < a.Np; ++n)
-      for (int m = tid; m < a.Mp; m += 256) H[m + (long)n * a.mb.ldh] = 0.0;
-    for (int m = 0; m < a.Mp; ++m)
-      for (int n = tid; n < a.Np; n += 256) HT[n + (long)m * a.mb.ldht] = 0.0;
+    if (a.mb.ldh == a.Mp && a.mb.ldht == a.Np) {
+      // both copies are contiguous Mp x Np blocks (multiples of 16 doubles): one flat pass of 16-byte stores each
+      d2* h2 = reinterpret_cast<d2*>(H);
+      d2* t2 = reinterpret_cast<d2*>(HT);
+      const long n2 = (long)a.Mp * a.Np / 2;
+      for (long e = tid; e < n2; e += 256) { h2[e] = d2{0.0, 0.0}; t2[e] = d2{0.0, 0.0}; }
+    } else {
+      for (int n = 0; n < a.Np; ++n)
+        for (int m = tid; m < a.Mp; m += 256) H[m + (long)n * a.mb.ldh] = 0.0;
+      for (int m = 0; m < a.Mp; ++m)
+        for (int n = tid; n < a.Np; n += 256) HT[n + (long)m * a.mb.ldht] = 0.0;
+    }
   }
   double* inn = a.mb.inn + (long)filt * a.mb.strideInn;
   double* dR = a.mb.diagR + (long)filt * a.mb.strideR;
