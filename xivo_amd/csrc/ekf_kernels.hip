@@ -1070,15 +1070,32 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
     if (lane < dimker && row < a.Mp) {
       double rr = 0.0;
       for (int j = 0; j < R2; ++j) rr += sA[j][lane] * sInn[j];
+      // the rows arrive zero-filled (stack). The camera-extrinsics columns collect a term from every observation: summed
+      // in registers, stored once. A group block belongs to one observation - a plain store - unless the feature was
+      // seen twice from the same group; only then the read-modify-write that a general accumulation needs.
+      bool dup = false;
+      for (int o1 = 0; o1 < k; ++o1)
+        for (int o2 = o1 + 1; o2 < k; ++o2) dup = dup || ft.group_sind[o1] == ft.group_sind[o2];
+      double ex[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       for (int ob = 0; ob < k; ++ob) {
         const int goff = a.lay.group_begin + 6 * ft.group_sind[ob];
-        for (int c = 0; c < 12; ++c) {
-          const double v = sA[2 * ob][lane] * sHx[2 * ob][c] + sA[2 * ob + 1][lane] * sHx[2 * ob + 1][c];
-          const int col = c < 6 ? goff + c : (c < 9 ? 15 + (c - 6) : 18 + (c - 9));
-          const double nv = H[row + (long)col * a.mb.ldh] + v;
-          H[row + (long)col * a.mb.ldh] = nv;
-          HT[col + (long)row * a.mb.ldht] = nv;
+        const double a0 = sA[2 * ob][lane], a1 = sA[2 * ob + 1][lane];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double v = a0 * sHx[2 * ob][c] + a1 * sHx[2 * ob + 1][c];
+          const int col = goff + c;
+          if (dup) v += H[row + (long)col * a.mb.ldh];
+          H[row + (long)col * a.mb.ldh] = v;
+          HT[col + (long)row * a.mb.ldht] = v;
         }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ex[c] += a0 * sHx[2 * ob][6 + c] + a1 * sHx[2 * ob + 1][6 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int col = 15 + c;                       // Index::Wbc (15..17), Index::Tbc (18..20)
+        H[row + (long)col * a.mb.ldh] = ex[c];
+        HT[col + (long)row * a.mb.ldht] = ex[c];
       }
       inn[row] = rr;
       dR[row] = a.Roos;
