@@ -349,3 +349,32 @@ def test_cpp_batch_estimator_equals_python_runner_under_rejections(built):
         assert np.abs(py["Tsb"] - cp["Tsb"]).max() < 1e-9
     finally:
         py["backend"].close(); cp["estimator"].close()
+
+
+def test_sequences_with_one_point_ransac_python_and_cpp_hosts_agree(built):
+    """cfg use_1pt_RANSAC: Estimator::OutlierRejection runs MH gating and then OnePointRANSAC (src/manager.cpp:629-650).
+    Both hosts drive xivo_hip_one_point_ransac between gating and the update; with a threshold of 0.4 px most frames have
+    high-innovation features, so the partial update / rescue paths run every frame. Same slot books, same trajectories,
+    and the filter still tracks ground truth."""
+    B = 3
+    cfg = sequence.SequenceConfig(use_1pt_RANSAC=True, ransac_thresh=0.4, ransac_Chi2=5.89)
+    mk = lambda: ([pcw.RandomPCW(seed=80 + b) for b in range(B)],
+                  [pcw.TrajectorySim("trefoil" if b % 2 else "lissajous", seed=700 + b) for b in range(B)])
+    w1, s1 = mk()
+    py = sequence.run_pcw(sequence.HipBackend, cfg, w1, s1, total_time=1.0)
+    w2, s2 = mk()
+    cp = sequence.run_pcw_cpp(cfg, w2, s2, total_time=1.0)
+    w3, s3 = mk()
+    plain = sequence.run_pcw(sequence.HipBackend, sequence.SequenceConfig(), w3, s3, total_time=1.0)
+    try:
+        for b in range(B):
+            fid, fref, gref = cp["estimator"].book(b)
+            bk = py["runner"].books[b]
+            assert list(fid) == bk.feat_id and list(fref) == bk.feat_ref and list(gref) == bk.group_refs
+        assert np.abs(py["Tsb"] - cp["Tsb"]).max() < 1e-9
+        ate = [formats.ate_rmse(py["Tsb"][:, b], py["gt_Tsb"][:, b], align=False) for b in range(B)]
+        assert max(ate) < 0.08, ate
+        # RANSAC really changed something (features were rejected that plain MH gating keeps)
+        assert py["runner"].n_rejected > plain["runner"].n_rejected
+    finally:
+        py["backend"].close(); cp["estimator"].close(); plain["backend"].close()

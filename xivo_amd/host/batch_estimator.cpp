@@ -193,7 +193,17 @@ void BatchEstimator::VisualMeasPointCloud(double t, const int* off, const int64_
   Check(xivo_hip_set_pixels(ctx_, 0, B_, F, xp_.data()), "set_pixels");
   // --- measurement update on the tracked in-state features (src/manager.cpp:72-104), ragged over the filters
   const double R = cfg_.visual_meas_std * cfg_.visual_meas_std;
-  Check(xivo_hip_filter_update(ctx_, B_, R, cfg_.MH_thresh, cfg_.MH_adjust_factor, cfg_.min_inliers, cfg_.use_MH_gating), "filter_update");
+  if (cfg_.use_1pt_RANSAC) {
+    // Estimator::OutlierRejection with use_1pt_RANSAC (src/manager.cpp:629-650): MH gating, OnePointRANSAC on its inliers,
+    // the update on what it keeps. (No gauge group / previous-frame group list in this simplified life cycle.)
+    Check(xivo_hip_jacobians_instate(ctx_, B_), "jacobians_instate");
+    Check(xivo_hip_mh_gate(ctx_, B_, R, cfg_.MH_thresh, cfg_.MH_adjust_factor, cfg_.use_MH_gating ? cfg_.min_inliers : (1 << 30), nullptr, nullptr), "mh_gate");
+    Check(xivo_hip_one_point_ransac(ctx_, B_, R, cfg_.ransac_thresh, cfg_.ransac_Chi2, nullptr, nullptr, nullptr, nullptr, nullptr), "one_point_ransac");
+    Check(xivo_hip_stack(ctx_, B_, R), "stack");
+    Check(xivo_hip_update_joseph(ctx_, B_), "update_joseph");
+  } else {
+    Check(xivo_hip_filter_update(ctx_, B_, R, cfg_.MH_thresh, cfg_.MH_adjust_factor, cfg_.min_inliers, cfg_.use_MH_gating), "filter_update");
+  }
   Check(xivo_hip_get_gate(ctx_, B_, F, mask_.data(), nullptr), "get_gate");
   // a filter whose S was not positive definite keeps its prior P and absorbs nothing (the device skips both); it is
   // counted and reported here - the reference's pivoted LDL^T cannot fail, so there is no reference behaviour to mirror
@@ -276,6 +286,8 @@ struct xivo_batch_cfg {   // flat mirror of xivo::hip::BatchConfig
   int min_inliers, min_new_features, fix_group_block, disable_MH_gating;   // cfg use_MH_gating = false
   double initial_std_x, initial_std_y, initial_std_z, min_depth, max_depth;
   xivo_prop_opts prop;
+  int use_1pt_RANSAC, pad_;                  // cfg use_1pt_RANSAC, 1pt_RANSAC_thresh, 1pt_RANSAC_Chi2 (src/estimator.cpp:130-134)
+  double ransac_thresh, ransac_Chi2;
 };
 
 int xivo_batch_create(const xivo_batch_cfg* c, int B, int device, const xivo_pose_in* poses0, const double* P0, void** out) {
@@ -285,6 +297,7 @@ int xivo_batch_create(const xivo_batch_cfg* c, int B, int device, const xivo_pos
     cfg.visual_meas_std = c->visual_meas_std; cfg.MH_thresh = c->MH_thresh; cfg.MH_adjust_factor = c->MH_adjust_factor;
     cfg.min_inliers = c->min_inliers; cfg.min_new_features = c->min_new_features; cfg.fix_group_block = c->fix_group_block;
     cfg.use_MH_gating = c->disable_MH_gating ? 0 : 1;
+    cfg.use_1pt_RANSAC = c->use_1pt_RANSAC; cfg.ransac_thresh = c->ransac_thresh; cfg.ransac_Chi2 = c->ransac_Chi2;
     cfg.initial_std_x = c->initial_std_x; cfg.initial_std_y = c->initial_std_y; cfg.initial_std_z = c->initial_std_z;
     cfg.min_depth = c->min_depth; cfg.max_depth = c->max_depth; cfg.prop = c->prop;
     *out = new xivo::hip::BatchEstimator(cfg, B, device, poses0, P0);

@@ -30,6 +30,8 @@ struct BatchConfig {
   double MH_thresh = 5.991, MH_adjust_factor = 1.1;
   int min_inliers = 5;
   int use_MH_gating = 1;                            // cfg use_MH_gating (src/estimator.cpp:364)
+  int use_1pt_RANSAC = 0;                           // cfg use_1pt_RANSAC: OnePointRANSAC between gating and the update
+  double ransac_thresh = 5.0, ransac_Chi2 = 5.89;   // 1pt_RANSAC_thresh / 1pt_RANSAC_Chi2 (src/estimator.cpp:132-134)
   double initial_std_x = 1.0, initial_std_y = 1.0, initial_std_z = 0.1;   // pixels, pixels, log-depth (estimator.cpp:349-353)
   double min_depth = 0.05, max_depth = 10.0;
   int min_new_features = 3;                         // open a new group only when this many feature slots are free
