@@ -248,8 +248,11 @@ def main():
             feats["x"][b] = sc["x"][b]; feats["ref_sind"][b] = sc["ref"][b]; feats["sind"][b] = sc["sind"][b]
         M = 2 * F + 7 * args.oos
         if args.oos > 0:
-            from xivo_amd.lib import FLAG_DENSE_H
-            flags |= FLAG_DENSE_H       # OOS rows are dense over the group blocks: stack the dense rows right away
+            from xivo_amd.lib import FLAG_DENSE_H, FLAG_REASSOC
+            # OOS rows are dense over the group blocks: stack the dense rows right away; the re-associated dense
+            # pipeline (T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T: the same Joseph expression, contractions over
+            # M instead of N) never reads H^T, so that copy is not written at all
+            flags |= FLAG_DENSE_H | FLAG_REASSOC
         ctx = Context(N, M, B, device=device, flags=flags)
         ctx.set_layout(N, 23, ng, 23 + 6 * ng, nf, synth.EQUI)
         rngP = np.random.default_rng(3000 + rank)

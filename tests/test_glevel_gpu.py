@@ -196,8 +196,8 @@ def test_propagation_tail(built):
         assert rel_fro(got[b], exp[b]) < 1e-14
 
 
-@pytest.mark.parametrize("compress", [False, True])
-def test_config3_full_size_instate_plus_oos(built, compress):
+@pytest.mark.parametrize("compress,flags", [(False, 0), (True, 0), (True, 64 | 16)])
+def test_config3_full_size_instate_plus_oos(built, compress, flags):
     """BASELINE.json config 3 at full size: N=251 (8 groups, 60 in-state features -> 120 rows)
     + 20 OOS features seen from k=5 groups (7 projected rows each -> 140 rows), M=260.
     compress: the 140 OOS rows (non-zero only over the 6 extrinsics + 48 group columns) are replaced by the 54-row
@@ -205,7 +205,8 @@ def test_config3_full_size_instate_plus_oos(built, compress):
     src/helpers.cpp:77-101): M = 174; K, dx, P+ are unchanged to rounding."""
     cam = synth.PINHOLE
     ng, nf, F, B, n_oos, k = 8, 60, 60, 2, 20, 5
-    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 6, cam, M_max=2 * F + n_oos * (2 * k - 3))
+    # flags 64 | 16 = DENSE_H | REASSOC: dense rows stacked at once, re-associated dense pipeline, no H^T copy kept
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 6, cam, M_max=2 * F + n_oos * (2 * k - 3), flags=flags)
     assert lay.N == 251
     rng = np.random.default_rng(19)
     oos = np.zeros((B, n_oos), dtype=oos_dtype)

@@ -149,6 +149,12 @@ int collect_profile(xivo_hip_ctx* c) {
   return XIVO_HIP_OK;
 }
 
+// the transposed dense copy H^T is read by the as-coded K H - I product and the dense-row gate only; with the
+// re-associated dense pipeline forced (DENSE_H | REASSOC) nobody reads it and the G-level producers skip writing it
+static bool skip_HT(const xivo_hip_ctx* c) {
+  return (c->flags & XIVO_HIP_FLAG_DENSE_H) && (c->flags & XIVO_HIP_FLAG_REASSOC) && !(c->flags & XIVO_HIP_FLAG_FP32_COV);
+}
+
 MeasBuffers meas_buffers(xivo_hip_ctx* c) {
   MeasBuffers mb;
   mb.H = c->H; mb.strideH = c->sH; mb.ldh = c->Mpmax;
@@ -1022,6 +1028,7 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
 static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigned char* mask_override = nullptr, int full_rows = 0) {
   StackArgs a{};
   a.sb = scene_buffers(c); a.lay = c->lay; a.mb = meas_buffers(c);
+  if (skip_HT(c)) a.mb.HT = nullptr;
   if (mask_override) a.sb.mask = mask_override;
   a.Mp = c->Mpmax; a.Np = c->Np; a.batch = B; a.R = R;
   a.fix_group_block = (full_rows || (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK)) ? 1 : 0;
@@ -1093,6 +1100,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   OosArgs a{};
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
   a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
+  if (skip_HT(c)) a.mb.HT = nullptr;
   c->oos_row0 = c->M; c->oos_R = Roos;
   a.rows_out = c->oos_rows;
   {
@@ -1204,6 +1212,7 @@ int xivo_hip_compress_oos(xivo_hip_ctx* c, int B, double trigger_ratio, int* row
     return XIVO_HIP_ERR_INVALID;
   OosCompressArgs a{};
   a.lay = c->lay; a.mb = meas_buffers(c); a.row0 = c->oos_row0; a.rows = c->oos_rows; a.rows_out = c->oos_rows;
+  if (skip_HT(c)) a.mb.HT = nullptr;
   a.ratio = trigger_ratio; a.Roos = c->oos_R; a.batch = B;
   int rc;
   {

@@ -426,17 +426,20 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   double* HT = a.mb.HT + (long)filt * a.mb.strideHT;
   // H_.setZero(total_size, N) (update.cpp:130)
   if (a.write_dense) {
+    // (a.mb.HT == nullptr: the consumer never reads the transposed copy - the re-associated dense pipeline)
     if (a.mb.ldh == a.Mp && a.mb.ldht == a.Np) {
       // both copies are contiguous Mp x Np blocks (multiples of 16 doubles): one flat pass of 16-byte stores each
       d2* h2 = reinterpret_cast<d2*>(H);
       d2* t2 = reinterpret_cast<d2*>(HT);
       const long n2 = (long)a.Mp * a.Np / 2;
-      for (long e = tid; e < n2; e += 256) { h2[e] = d2{0.0, 0.0}; t2[e] = d2{0.0, 0.0}; }
+      if (a.mb.HT) for (long e = tid; e < n2; e += 256) { h2[e] = d2{0.0, 0.0}; t2[e] = d2{0.0, 0.0}; }
+      else for (long e = tid; e < n2; e += 256) h2[e] = d2{0.0, 0.0};
     } else {
       for (int n = 0; n < a.Np; ++n)
         for (int m = tid; m < a.Mp; m += 256) H[m + (long)n * a.mb.ldh] = 0.0;
-      for (int m = 0; m < a.Mp; ++m)
-        for (int n = tid; n < a.Np; n += 256) HT[n + (long)m * a.mb.ldht] = 0.0;
+      if (a.mb.HT)
+        for (int m = 0; m < a.Mp; ++m)
+          for (int n = tid; n < a.Np; n += 256) HT[n + (long)m * a.mb.ldht] = 0.0;
     }
   }
   double* inn = a.mb.inn + (long)filt * a.mb.strideInn;
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
           const double v = J[i * 21 + 3 * src + o];
           if (!a.write_dense) continue;
           H[(2 * f + i) + (long)col * a.mb.ldh] = v;
-          HT[col + (long)(2 * f + i) * a.mb.ldht] = v;
+          if (a.mb.HT) HT[col + (long)(2 * f + i) * a.mb.ldht] = v;
         }
       }
     }
@@ -1086,7 +1089,7 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
           const int col = goff + c;
           if (dup) v += H[row + (long)col * a.mb.ldh];
           H[row + (long)col * a.mb.ldh] = v;
-          HT[col + (long)row * a.mb.ldht] = v;
+          if (a.mb.HT) HT[col + (long)row * a.mb.ldht] = v;
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) ex[c] += a0 * sHx[2 * ob][6 + c] + a1 * sHx[2 * ob + 1][6 + c];
@@ -1095,7 +1098,7 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
       for (int c = 0; c < 6; ++c) {
         const int col = 15 + c;                       // Index::Wbc (15..17), Index::Tbc (18..20)
         H[row + (long)col * a.mb.ldh] = ex[c];
-        HT[col + (long)row * a.mb.ldht] = ex[c];
+        if (a.mb.HT) HT[col + (long)row * a.mb.ldht] = ex[c];
       }
       inn[row] = rr;
       dR[row] = a.Roos;
@@ -1795,7 +1798,7 @@ __global__ __launch_bounds__(256) void oos_compress_kernel(OosCompressArgs a) {
           double x = rr < pl ? v[q][rr] : 0.0;
           if (prow >= 0 && rr >= prl) x = rr == prl ? al : 0.0;
           hd[rr] = x;
-          *ht = x;
+          if (a.mb.HT) *ht = x;
         }
         ht += a.mb.ldht;
       }

@@ -39,7 +39,10 @@ struct MeasCompressArgs {
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void meas_compress_kernel(MeasCompressArgs a) {
-  constexpr int UNR = 16;
+#ifndef XIVO_COMPRESS_UNR
+#define XIVO_COMPRESS_UNR 16
+#endif
+  constexpr int UNR = XIVO_COMPRESS_UNR;       // 16-byte loads in flight per thread (32 measured within noise of 16)
   extern __shared__ __attribute__((aligned(16))) double csh[];
   // LDS: lst_v[ELL_W][list_ld] d2 | lst_n[ELL_W][list_ld] int | occw[nw][Np] int | cslot[Np] int
   const int filt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void meas_compress_kernel(MeasCompressArgs a) 
         ++cnt;
       }
     }
-    if (lane < UNR && n0 + lane < a.Np) occw[wave * a.Np + n0 + lane] = mycount;
+    if (lane < UNR && n0 + lane < a.Np) occw[wave * a.Np + n0 + lane] = mycount;   // UNR <= 64
   }
   for (int n = a.N + (UNR - a.N % UNR) % UNR + tid; n < a.Np; n += blockDim.x)   // pad columns never visited above
     for (int w = 0; w < nw; ++w) occw[w * a.Np + n] = 0;
