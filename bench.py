@@ -135,9 +135,20 @@ def parity_check(ctx, step, B, uniq, F, P, H, inn, dR, gate, no_gating):
             u = b % uniq
             d = orc.mh_distances(H[u].reshape(F, 2, -1), P[u], inn[u].reshape(F, 2), R)
             mask_equal = mask_equal and bool(np.array_equal(gm[b], orc.mh_gate(d, th, mult, min_inl)[0]))
-    ok = worst_P < 1e-6 and worst_dx < 1e-8 and mask_equal
+    # every filter of the batch against its twin: the synthetic inputs repeat with period `uniq`, the kernels are
+    # deterministic, so filter b must equal filter b % uniq BIT FOR BIT - dx of all B filters, P of 64 spread over the
+    # launch (an indexing error anywhere in the 64 GB of strides shows up here)
+    err_all = ctx.get_err(b0=0, nb=B)
+    twins_dx = bool(np.array_equal(err_all, err_all[np.arange(B) % uniq]))
+    rng = np.random.default_rng(7)
+    twins_P = True
+    for b in sorted(set(int(x) for x in rng.integers(uniq, B, size=64))) if B > uniq else []:
+        twins_P = twins_P and bool(np.array_equal(ctx.download_P(b0=b, nb=1)[0], ctx.download_P(b0=b % uniq, nb=1)[0]))
+    ok = worst_P < 1e-6 and worst_dx < 1e-8 and mask_equal and twins_dx and twins_P
     out = {"ok": bool(ok), "filters": picks, "rel_fro_P_max": worst_P, "rel_dx_max": worst_dx,
-           "inlier_masks_equal": mask_equal, "tol": {"P": 1e-6, "dx": 1e-8}, "checker": "oracle/xivo_oracle.py"}
+           "inlier_masks_equal": mask_equal, "all_filters_dx_equal_their_twin_bitwise": twins_dx,
+           "sampled_64_filters_P_equal_their_twin_bitwise": twins_P,
+           "tol": {"P": 1e-6, "dx": 1e-8}, "checker": "oracle/xivo_oracle.py"}
     if not ok:
         raise AssertionError(f"bench parity check failed: {out}")
     return out
