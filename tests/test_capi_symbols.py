@@ -88,7 +88,8 @@ def test_host_library_exports_the_batch_estimator(built):
     for name in ("xivo_batch_create", "xivo_batch_destroy", "xivo_batch_imu", "xivo_batch_visual", "xivo_batch_poses",
                  "xivo_batch_book", "xivo_batch_stats", "xivo_batch_ctx", "xivo_host_selftest_update_step"):
         assert hasattr(host, name), name
-    assert batch.batch_cfg_dtype.itemsize == 5600      # struct xivo_batch_cfg (host/batch_estimator.cpp)
+    # the numpy mirror of struct xivo_batch_cfg (host/batch_estimator.cpp) has the size the C++ side compiled
+    assert batch.batch_cfg_dtype.itemsize == host.xivo_batch_cfg_size() == 5624
 
 
 def test_candidate_comparison_order_matches_the_reference_as_coded():

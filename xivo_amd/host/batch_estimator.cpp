@@ -329,6 +329,7 @@ void xivo_batch_stats(void* h, long* n_updates, long* n_rejected, double* host_s
   auto* e = static_cast<xivo::hip::BatchEstimator*>(h);
   *n_updates = e->n_updates(); *n_rejected = e->n_rejected(); *host_seconds = e->host_seconds();
 }
+int xivo_batch_cfg_size(void) { return (int)sizeof(xivo_batch_cfg); }   // checked against the ctypes mirror (tests)
 long xivo_batch_not_spd(void* h) { return static_cast<xivo::hip::BatchEstimator*>(h)->n_not_spd(); }
 void* xivo_batch_ctx(void* h) { return static_cast<xivo::hip::BatchEstimator*>(h)->ctx(); }
 
