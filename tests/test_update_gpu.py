@@ -328,11 +328,15 @@ def test_profile_reports_kernels_bytes_and_path(built):
             prof = ctx.profile_get()
             assert ctx.last_path() == path
         assert prof["gemm_HP"]["kernel"] == hp_kernel
-        for st in ("gemm_HP", "gemm_S", "chol_S", "trsm_gain", "gemm_AP", "gemm_Pnew"):
+        # sparse pipeline: T = K(HP) - P is formed by the solve kernel on the gain in its registers - no stand-alone product
+        stages = ("gemm_HP", "gemm_S", "chol_S", "trsm_gain", "gemm_Pnew") + (() if path == 1 else ("gemm_AP",))
+        for st in stages:
             assert prof[st]["launches"] == 1 and prof[st]["ms"] > 0 and prof[st]["kernel"]
             assert prof[st]["bytes_per_launch"] > 0 and prof[st]["flops_per_launch"] > 0
+        if path == 1:
+            assert prof["gemm_AP"]["launches"] == 0
         assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<10")   # B = 16: the latency kernel
-        assert prof["trsm_gain"]["kernel"] == "trsm_lds_f64_kernel<10>"
+        assert prof["trsm_gain"]["kernel"] == ("trsm_lds_f64_kernel<10,true>" if path == 1 else "trsm_lds_f64_kernel<10,false>")
 
 
 @pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])

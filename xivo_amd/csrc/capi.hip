@@ -650,20 +650,27 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
   }
   if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
+  const bool t_full = full || getenv("XIVO_HIP_T_FULL");
+  bool t_done = false;
   {
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
-    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label,
-                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
+    // the solve goes on to T = K (HP) - P with the gain still in its registers (lower triangle + mirror)
+    const bool t_here = !t_full && trsm_forms_T(Mp, Np);
+    if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
+    t_done = t_here;
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), t_here);
+    const double t_outs = 0.5 * Np * (Np + 1.0);
+    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (t_here ? 2.0 * t_outs * Mp : 0.0)) * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (t_here ? t_outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
   }
-  {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
+  if (!t_done) {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
      // triangle is computed and mirrored (XIVO_HIP_FLAG_FULL_PNEW: all of it)
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.fp32 = f32;
-    x.lower_only = (full || getenv("XIVO_HIP_T_FULL")) ? 0 : 1;
+    x.lower_only = t_full ? 0 : 1;
     rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               T, c->sP, Np, x);
     if (rc) return rc;

@@ -477,7 +477,14 @@ __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
 // forward AND the backward substitution is a conflict-free ds_read_b64 (blocks are
 // stored column-major with a leading dimension of 17 so that both L_ik and its
 // transpose read without bank conflicts). No barrier after the initial copy.
-template <int NBM>
+// TF: the workgroup goes on to form T = K (HP) - P (estimator.cpp:1280, the left product distributed over
+// the H P already at hand) while K^T sits in its registers in exactly the A-operand layout of the MFMA: wave w
+// owns state rows 16w..16w+15 of K. Once the factor is dead the LDS takes the B operands - P H^T again, 8
+// column blocks at a time, each block stored as the 4 nb registers a wave would hold of it, lane-contiguous
+// (conflict-free ds_read_b64) - and wave w forms the 16 x 16 tiles (w, j) for the j cyclically below it
+// (every unordered pair of blocks once: 8 or 9 tiles per wave), accumulators starting at -P, and writes each
+// tile and its mirror. K is never read back and H P is read once more instead of 1.5 times by the tiled GEMM.
+template <int NBM, bool TF>
 __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr int BLK = 16 * 17;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
@@ -522,8 +529,9 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     }
   }
   __syncthreads();
-  if (!live) return;
+  if (!TF && !live) return;
 
+  if (live) {
   // forward: L Y = HP
 #pragma unroll
   for (int k = 0; k < NBM; ++k) {
@@ -582,6 +590,101 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   part += __shfl_xor(part, 16);
   part += __shfl_xor(part, 32);
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
+  }
+  if (!TF) return;
+
+  // ---- T = K (HP) - P
+  const int nwl = g.Np / 16;                       // live waves = 16-row blocks of T (Np <= 256 here)
+  const int jbp = g.t_jbp;                         // column blocks per phase: their operands fill one LDS buffer
+  const int nph = (nwl + jbp - 1) / jbp;
+  double* __restrict__ T = g.T + (long)filt * g.strideT;
+  const double* __restrict__ Pm = g.Pm + (long)filt * g.stridePm;
+  const int w = c0 >> 4;
+  const int bufsz = jbp * nb * 256;                // doubles per LDS buffer (two of them)
+  // Operands of phase p straight from global memory into LDS (no registers, asynchronous): one instruction moves
+  // 8 rows m x 16 columns j of P H^T (16 bytes per lane) to 128 consecutive doubles, so that block (jl, m, j) sits at
+  // jl nb 256 + 16 m + j - for the MFMA step (mb, r) that is (4 mb + r) 64 + lane: lane-contiguous reads.
+  auto issue = [&](int p) {
+    const int jb0 = p * jbp, nj = min(jbp, nwl - jb0);
+    double* buf = sL + (p & 1) * bufsz;
+    for (int q = wave; q < nj * 2 * nb; q += 16) {
+      const int jl = q / (2 * nb), t = q - jl * 2 * nb;
+      const double* src = PHT + (16 * (jb0 + jl) + 2 * (lane & 7)) + (long)(8 * t + (lane >> 3)) * g.ldpht;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + jl * nb * 256 + t * 128), 16, 0, 0);
+    }
+  };
+  // my tiles of a phase: block j with (w - j) mod nwl in 0..nwl/2 (the antipodal pair goes to the higher wave)
+  auto my_tiles = [&](int p) -> unsigned {
+    unsigned todo = 0;
+    if (!live || p >= nph) return todo;
+    const int jb0 = p * jbp, nj = min(jbp, nwl - jb0);
+    for (int jl = 0; jl < nj; ++jl) {
+      int d = w - (jb0 + jl);
+      if (d < 0) d += nwl;
+      if (2 * d < nwl || (2 * d == nwl && w > jb0 + jl)) todo |= 1u << jl;
+    }
+    return todo;
+  };
+  // A tile is formed in the orientation that makes its lower-triangle position (a, b), a >= b, lane-contiguous in a:
+  // blocks below the diagonal (and the diagonal one) swap the two MFMA operands - the tile comes out transposed,
+  // lanes along the row index - blocks above it stand for their mirror image. -P is read there (the lower triangle of
+  // P, as the stand-alone product does), T(a, b) and its mirror T(b, a) are written.
+  auto load_p = [&](int jb, d4& acc) {
+    const int a = 16 * (jb <= w ? w : jb) + li, b = 16 * (jb <= w ? jb : w) + lg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Pm[a + (long)(b + 4 * r) * g.ldpm];   // (negated where it is consumed: no wait here)
+  };
+  __syncthreads();                                 // the factor is dead
+  issue(0);
+  unsigned todo = my_tiles(0);
+  d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
+  if (todo) load_p(__builtin_ctz(todo), nxt);
+  for (int p = 0; p < nph; ++p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // phase p landed for every wave; the other buffer is free again
+    const int jb0 = p * jbp;
+    const double* buf = sL + (p & 1) * bufsz;
+    bool fetch = p + 1 < nph;                      // phase p + 1 is requested once the first tile has its -P (so that
+    while (todo) {                                 // the wait on those loads does not sit behind the new requests)
+      const int jl = __builtin_ctz(todo);
+      todo &= todo - 1;
+      const int jb = jb0 + jl;
+      d4 acc = -nxt;
+      if (fetch) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); issue(p + 1); fetch = false; }
+      if (todo) load_p(jb0 + __builtin_ctz(todo), nxt);
+      const double* Bop = buf + jl * nb * 256 + lane;
+      if (jb <= w) {
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma(Bop[(mb * 4 + r) * 64], X[mb][r], acc);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma(X[mb][r], Bop[(mb * 4 + r) * 64], acc);
+          }
+        }
+      }
+      const int a = 16 * (jb <= w ? w : jb) + li, b = 16 * (jb <= w ? jb : w) + lg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bb = b + 4 * r;
+        if (jb != w || a >= bb) {                  // diagonal tile: the lower triangle is authoritative
+          T[a + (long)bb * g.ldt] = acc[r];
+          if (a != bb) T[bb + (long)a * g.ldt] = acc[r];
+        }
+      }
+    }
+    if (fetch) issue(p + 1);
+    todo = my_tiles(p + 1);
+    if (todo) load_p((p + 1) * jbp + __builtin_ctz(todo), nxt);
+  }
 }
 
 // Streaming variant for factors that do not fit LDS (M > 176): the workgroup (8 waves = 128
@@ -745,20 +848,33 @@ int launch_trsm_stream_t(const TrsmArgs& g, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int NBM>
-int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
+template <int NBM, bool TF>
+int launch_trsm_lds_tf(const TrsmArgs& g_in, hipStream_t stream) {
+  TrsmArgs g = g_in;
   const int nb = g.Mp / 16;
   const int chunks = (g.Np + 255) / 256;
   const int grid = ((g.batch + 7) / 8) * 8 * chunks;
-  const size_t lds = (size_t)nb * (nb + 1) / 2 * 16 * 17 * sizeof(double);
+  size_t lds = (size_t)nb * (nb + 1) / 2 * 16 * 17 * sizeof(double);
+  if (TF) {   // the T phase re-uses all of the LDS for its B operands: nb * 2 KB per column block
+    lds = 160 * 1024;
+    g.t_jbp = (int)(lds / 2 / ((size_t)nb * 4 * 64 * sizeof(double)));   // two buffers
+    if (g.t_jbp > 16) g.t_jbp = 16;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_lds_f64_kernel<NBM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_lds_f64_kernel<NBM, TF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((trsm_lds_f64_kernel<NBM>), dim3(grid), dim3(1024), lds, stream, g);
+  hipLaunchKernelGGL((trsm_lds_f64_kernel<NBM, TF>), dim3(grid), dim3(1024), lds, stream, g);
   return (int)hipGetLastError();
+}
+template <int NBM>
+int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
+  if constexpr (NBM <= 10) {   // (11 block rows: the T phase spills at the 128-register budget of 16 waves)
+    if (g.T && !g.fwd_only && trsm_forms_T(g.Mp, g.Np)) return launch_trsm_lds_tf<NBM, true>(g, stream);
+  }
+  return launch_trsm_lds_tf<NBM, false>(g, stream);
 }
 
 template <int NBM>
@@ -801,6 +917,11 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+bool trsm_forms_T(int Mp, int Np) {
+  static const bool off = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: T as a stand-alone product
+  return !off && Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
+}
+
 int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
   const int nb = g.Mp / 16;
@@ -839,10 +960,10 @@ void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
   else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)), (nb > 8 && batch >= 512) ? 3 : 2);
 }
 
-void trsm_kernel_label(int Mp, char* buf, size_t n) {
+void trsm_kernel_label(int Mp, char* buf, size_t n, bool forms_T) {
   const int nb = Mp / 16;
   const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
-  if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11));
+  if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%s>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T ? "true" : "false");
   else if (!no_stream) snprintf(buf, n, "trsm_stream_f64_kernel<%d>", nb <= 14 ? 14 : (nb <= 19 ? 19 : 24));
   else snprintf(buf, n, "trsm_f64_kernel");
 }

@@ -112,12 +112,23 @@ struct TrsmArgs {
   int fwd_only;        // 1: stop after the forward substitution: K receives W^T = (L^-1 HP)^T and dx = W^T y with
   const double* y;     //    y = L^-1 inn [Mp] (launch_fwd_vec) - the symmetric form P+ = P - W^T W needs no more
   long strideY;
+  // T = K (HP) - P formed on the gain while it is still in registers (estimator.cpp:1280 distributed over HP):
+  // lower triangle authoritative + mirror, as the stand-alone product writes it. nullptr: not wanted.
+  double* T;
+  long strideT;
+  int ldt;
+  const double* Pm;    // the prior covariance [Np x Np]
+  long stridePm;
+  int ldpm;
+  int t_jbp;           // (set by the launcher) column blocks per LDS phase
 };
 int launch_trsm_f64(const TrsmArgs& args, hipStream_t stream);
+// whether launch_trsm_f64 forms T itself for these shapes (whole factor in LDS, one column chunk per filter)
+bool trsm_forms_T(int Mp, int Np);
 // y = L^-1 inn for every filter (one wave each): the forward substitution of the innovation vector
 int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD, long strideInvD, const double* inn, long strideInn,
                    double* y, long strideY, int Mp, int batch, hipStream_t stream);
-void trsm_kernel_label(int Mp, char* buf, size_t n);
+void trsm_kernel_label(int Mp, char* buf, size_t n, bool forms_T = false);
 
 }  // namespace xivo_hip
 
