@@ -572,9 +572,15 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B; a.fwd_only = 1; a.y = y; a.strideY = c->Mpmax;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
-    StageTimer st(c, ST_TRSM, 1.0 * Mp * Mp * Np * B, label, 8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
+    // the solve kernel goes on to P+ = P - W^T W in place, W^T still in its registers (blocks exchanged through LDS)
+    const bool p_here = !full && trsm_forms_T(Mp, Np);
+    if (p_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.skip_status = c->status + b0; }
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), p_here);
+    const double outs = 0.5 * Np * (Np + 1.0);
+    StageTimer st(c, ST_TRSM, (1.0 * Mp * Mp * Np + (p_here ? 2.0 * outs * Mp : 0.0)) * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (p_here ? outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
+    if (p_here) return XIVO_HIP_OK;
   }
   // P+ = P - W^T W in place: the accumulators start at -P (every tile reads its part of P before it stores anything)
   // and the result is negated on the way out
@@ -687,7 +693,17 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     StageTimer st(c, ST_KH, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (g_f32 ? 1.5 : 2.0) * Np * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(gmode, a, c->stream));
   }
-  {  // P+ = G K^T - T   (lower triangle + mirror)
+  if (!g_f32 && !full && pnew_reg_supported(Mp, Np)) {
+    // P+ = G K^T - T, all fp64: rows of G in registers, blocks of K through LDS, one workgroup per filter
+    PnewRegArgs a{}; a.G = G; a.strideG = c->sA; a.ldg = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
+    a.T = T; a.strideT = c->sP; a.ldt = Np; a.P = P; a.strideP = c->sP; a.ldp = Np;
+    a.skip_status = c->status + b0; a.Mp = Mp; a.Np = Np; a.batch = B;
+    char label[64]; pnew_reg_kernel_label(Mp, label, sizeof(label));
+    const double outs = 0.5 * Np * (Np + 1.0);
+    StageTimer st(c, ST_PNEW, 2.0 * outs * Mp * B, label, 8.0 * B * (2.0 * Np * Mp + outs + (double)Np * Np));
+    HIP_TRY((hipError_t)launch_pnew_reg_f64(a, c->stream));
+    rc = XIVO_HIP_OK;
+  } else {  // P+ = G K^T - T   (lower triangle + mirror)
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
     x.fp32 = (c->flags & XIVO_HIP_FLAG_FP64_CORR) ? 0 : 1;   // correction product on the fp32 MFMA, T added in fp64
     x.a_f32 = g_f32 ? 1 : 0;

@@ -477,6 +477,120 @@ __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
 // forward AND the backward substitution is a conflict-free ds_read_b64 (blocks are
 // stored column-major with a leading dimension of 17 so that both L_ik and its
 // transpose read without bank conflicts). No barrier after the initial copy.
+// Symmetric [16 nwl x 16 nwl] result  Out = A Src^T - Minit  formed tile by tile from register-resident rows:
+// wave w holds rows 16w..16w+15 of A as X[mb][r] = A[16w + li, 16 mb + lg + 4 r] - the MFMA operand layout - and the
+// rows of Src [16 nwl x 16 nb, leading dimension ldsrc over the row index] arrive in LDS, jbp row blocks per phase,
+// double-buffered. Wave w forms the tiles (w, j) for the blocks j cyclically below it ((w - j) mod nwl in 0..nwl/2,
+// the antipodal pair going to the higher wave: every unordered pair of blocks once, 8 or 9 tiles per wave at nwl = 16),
+// accumulators starting at -Minit, and writes each tile to its lower-triangle position and the mirror image.
+// All 16 waves of the workgroup must call it (barriers); `sL` = the whole 160 KB of LDS.
+// SRC_REGS: Src = A itself (a symmetric rank-k product, P - W^T W): the wave that owns a block copies its registers
+// into the LDS buffer - nothing is read back from memory. NEG_OUT: Out = Minit - A Src^T.
+template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false>
+__device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* sL, const double* __restrict__ Src, int ldsrc,
+                                                    const double* __restrict__ Minit, int ldm, double* __restrict__ Out, int ldo,
+                                                    int nb, int nwl, int jbp, bool live, int w, int wave, int lane) {
+  const int li = lane & 15, lg = lane >> 4;
+  const int nph = (nwl + jbp - 1) / jbp;
+  const int bufsz = jbp * nb * 256;                // doubles per LDS buffer (two of them)
+  // Operands of phase p straight from global memory into LDS (no registers, asynchronous): one instruction moves
+  // 8 columns m x 16 rows j of Src (16 bytes per lane) to 128 consecutive doubles, so that block (jl, m, j) sits at
+  // jl nb 256 + 16 m + j - for the MFMA step (mb, r) that is (4 mb + r) 64 + lane: lane-contiguous reads.
+  auto issue = [&](int p) {
+    const int jb0 = p * jbp, nj = min(jbp, nwl - jb0);
+    double* buf = sL + (p & 1) * bufsz;
+    if (SRC_REGS) {
+      if (live && w >= jb0 && w < jb0 + nj) {
+        double* dst = buf + (w - jb0) * nb * 256 + lane;
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(mb * 4 + r) * 64] = X[mb][r];
+          }
+        }
+      }
+      return;
+    }
+    for (int q = wave; q < nj * 2 * nb; q += 16) {
+      const int jl = q / (2 * nb), t = q - jl * 2 * nb;
+      const double* src = Src + (16 * (jb0 + jl) + 2 * (lane & 7)) + (long)(8 * t + (lane >> 3)) * ldsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + jl * nb * 256 + t * 128), 16, 0, 0);
+    }
+  };
+  auto my_tiles = [&](int p) -> unsigned {
+    unsigned todo = 0;
+    if (!live || p >= nph) return todo;
+    const int jb0 = p * jbp, nj = min(jbp, nwl - jb0);
+    for (int jl = 0; jl < nj; ++jl) {
+      int d = w - (jb0 + jl);
+      if (d < 0) d += nwl;
+      if (2 * d < nwl || (2 * d == nwl && w > jb0 + jl)) todo |= 1u << jl;
+    }
+    return todo;
+  };
+  // A tile is formed in the orientation that makes its lower-triangle position (a, b), a >= b, lane-contiguous in a:
+  // blocks below the diagonal (and the diagonal one) swap the two MFMA operands - the tile comes out transposed,
+  // lanes along the row index - blocks above it stand for their mirror image. Minit is read there (its lower
+  // triangle, as the stand-alone product does), Out(a, b) and its mirror Out(b, a) are written.
+  auto load_m = [&](int jb, d4& acc) {
+    const int a = 16 * (jb <= w ? w : jb) + li, b = 16 * (jb <= w ? jb : w) + lg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Minit[a + (long)(b + 4 * r) * ldm];   // (negated where it is consumed: no wait here)
+  };
+  issue(0);
+  unsigned todo = my_tiles(0);
+  d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
+  if (todo) load_m(__builtin_ctz(todo), nxt);
+  for (int p = 0; p < nph; ++p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // phase p landed for every wave; the other buffer is free again
+    const int jb0 = p * jbp;
+    const double* buf = sL + (p & 1) * bufsz;
+    bool fetch = p + 1 < nph;                      // phase p + 1 is requested once the first tile has its -Minit (so that
+    while (todo) {                                 // the wait on those loads does not sit behind the new requests)
+      const int jl = __builtin_ctz(todo);
+      todo &= todo - 1;
+      const int jb = jb0 + jl;
+      d4 acc = -nxt;
+      if (fetch) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); issue(p + 1); fetch = false; }
+      if (todo) load_m(jb0 + __builtin_ctz(todo), nxt);
+      const double* Bop = buf + jl * nb * 256 + lane;
+      if (jb <= w) {
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma(Bop[(mb * 4 + r) * 64], X[mb][r], acc);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma(X[mb][r], Bop[(mb * 4 + r) * 64], acc);
+          }
+        }
+      }
+      const int a = 16 * (jb <= w ? w : jb) + li, b = 16 * (jb <= w ? jb : w) + lg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bb = b + 4 * r;
+        if (jb != w || a >= bb) {                  // diagonal tile: the lower triangle is authoritative
+          const double v = NEG_OUT ? -acc[r] : acc[r];
+          Out[a + (long)bb * ldo] = v;
+          if (a != bb) Out[bb + (long)a * ldo] = v;
+        }
+      }
+    }
+    if (fetch) issue(p + 1);
+    todo = my_tiles(p + 1);
+    if (todo) load_m((p + 1) * jbp + __builtin_ctz(todo), nxt);
+  }
+}
+
 // TF: the workgroup goes on to form T = K (HP) - P (estimator.cpp:1280, the left product distributed over
 // the H P already at hand) while K^T sits in its registers in exactly the A-operand layout of the MFMA: wave w
 // owns state rows 16w..16w+15 of K. Once the factor is dead the LDS takes the B operands - P H^T again, 8
@@ -593,98 +707,48 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   }
   if (!TF) return;
 
-  // ---- T = K (HP) - P
-  const int nwl = g.Np / 16;                       // live waves = 16-row blocks of T (Np <= 256 here)
-  const int jbp = g.t_jbp;                         // column blocks per phase: their operands fill one LDS buffer
-  const int nph = (nwl + jbp - 1) / jbp;
-  double* __restrict__ T = g.T + (long)filt * g.strideT;
-  const double* __restrict__ Pm = g.Pm + (long)filt * g.stridePm;
-  const int w = c0 >> 4;
-  const int bufsz = jbp * nb * 256;                // doubles per LDS buffer (two of them)
-  // Operands of phase p straight from global memory into LDS (no registers, asynchronous): one instruction moves
-  // 8 rows m x 16 columns j of P H^T (16 bytes per lane) to 128 consecutive doubles, so that block (jl, m, j) sits at
-  // jl nb 256 + 16 m + j - for the MFMA step (mb, r) that is (4 mb + r) 64 + lane: lane-contiguous reads.
-  auto issue = [&](int p) {
-    const int jb0 = p * jbp, nj = min(jbp, nwl - jb0);
-    double* buf = sL + (p & 1) * bufsz;
-    for (int q = wave; q < nj * 2 * nb; q += 16) {
-      const int jl = q / (2 * nb), t = q - jl * 2 * nb;
-      const double* src = PHT + (16 * (jb0 + jl) + 2 * (lane & 7)) + (long)(8 * t + (lane >> 3)) * g.ldpht;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(buf + jl * nb * 256 + t * 128), 16, 0, 0);
-    }
-  };
-  // my tiles of a phase: block j with (w - j) mod nwl in 0..nwl/2 (the antipodal pair goes to the higher wave)
-  auto my_tiles = [&](int p) -> unsigned {
-    unsigned todo = 0;
-    if (!live || p >= nph) return todo;
-    const int jb0 = p * jbp, nj = min(jbp, nwl - jb0);
-    for (int jl = 0; jl < nj; ++jl) {
-      int d = w - (jb0 + jl);
-      if (d < 0) d += nwl;
-      if (2 * d < nwl || (2 * d == nwl && w > jb0 + jl)) todo |= 1u << jl;
-    }
-    return todo;
-  };
-  // A tile is formed in the orientation that makes its lower-triangle position (a, b), a >= b, lane-contiguous in a:
-  // blocks below the diagonal (and the diagonal one) swap the two MFMA operands - the tile comes out transposed,
-  // lanes along the row index - blocks above it stand for their mirror image. -P is read there (the lower triangle of
-  // P, as the stand-alone product does), T(a, b) and its mirror T(b, a) are written.
-  auto load_p = [&](int jb, d4& acc) {
-    const int a = 16 * (jb <= w ? w : jb) + li, b = 16 * (jb <= w ? jb : w) + lg;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = Pm[a + (long)(b + 4 * r) * g.ldpm];   // (negated where it is consumed: no wait here)
-  };
-  __syncthreads();                                 // the factor is dead
-  issue(0);
-  unsigned todo = my_tiles(0);
-  d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
-  if (todo) load_p(__builtin_ctz(todo), nxt);
-  for (int p = 0; p < nph; ++p) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                               // phase p landed for every wave; the other buffer is free again
-    const int jb0 = p * jbp;
-    const double* buf = sL + (p & 1) * bufsz;
-    bool fetch = p + 1 < nph;                      // phase p + 1 is requested once the first tile has its -P (so that
-    while (todo) {                                 // the wait on those loads does not sit behind the new requests)
-      const int jl = __builtin_ctz(todo);
-      todo &= todo - 1;
-      const int jb = jb0 + jl;
-      d4 acc = -nxt;
-      if (fetch) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); issue(p + 1); fetch = false; }
-      if (todo) load_p(jb0 + __builtin_ctz(todo), nxt);
-      const double* Bop = buf + jl * nb * 256 + lane;
-      if (jb <= w) {
-#pragma unroll
-        for (int mb = 0; mb < NBM; ++mb) {
-          if (mb < nb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = mfma(Bop[(mb * 4 + r) * 64], X[mb][r], acc);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int mb = 0; mb < NBM; ++mb) {
-          if (mb < nb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = mfma(X[mb][r], Bop[(mb * 4 + r) * 64], acc);
-          }
-        }
-      }
-      const int a = 16 * (jb <= w ? w : jb) + li, b = 16 * (jb <= w ? jb : w) + lg;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int bb = b + 4 * r;
-        if (jb != w || a >= bb) {                  // diagonal tile: the lower triangle is authoritative
-          T[a + (long)bb * g.ldt] = acc[r];
-          if (a != bb) T[bb + (long)a * g.ldt] = acc[r];
-        }
-      }
-    }
-    if (fetch) issue(p + 1);
-    todo = my_tiles(p + 1);
-    if (todo) load_p((p + 1) * jbp + __builtin_ctz(todo), nxt);
+  __syncthreads();                                 // the factor is dead: the LDS takes the operands
+  if (g.fwd_only) {
+    // ---- symmetric form: P+ = P - W^T W in place, W^T = the forward-substituted columns still in registers
+    if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
+    double* Pio = g.T + (long)filt * g.strideT;
+    sym_tiles_from_regs<NBM, true, true>(X, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
+    return;
   }
+  // ---- T = K (HP) - P
+  sym_tiles_from_regs<NBM>(X, sL, PHT, g.ldpht, g.Pm + (long)filt * g.stridePm, g.ldpm, g.T + (long)filt * g.strideT, g.ldt,
+                           nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
+}
+
+// P+ = G K^T - T (estimator.cpp:1280-1287 re-associated) with the rows of G in registers: the same tile walk as the T
+// phase above, one workgroup per filter, wave w holding rows 16w..16w+15 of G and the blocks of K arriving in LDS. For a
+// pair of blocks (a, b) the wave that owns it forms EITHER entry (a, b) = G_a K_b^T OR (b, a) = G_b K_a^T of the as-coded
+// product - they differ by the rounding of the solve - and writes it to both positions. Replaces the tiled GEMM
+// (HBM-bound: every panel read 1.5 times) for the all-fp64 correction product.
+template <int NBM>
+__global__ __launch_bounds__(1024) void pnew_reg_f64_kernel(PnewRegArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double sL[];
+  const int bidx = blockIdx.x;
+  const int filt = (bidx >> 3) * 8 + (bidx & 7);
+  if (filt >= g.batch) return;
+  if (g.skip_status && g.skip_status[filt] != 0) return;   // S was not positive definite: P stays the prior
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int nb = g.Mp / 16;
+  const int c0 = wave * 16;
+  const bool live = c0 < g.Np;
+  const double* __restrict__ G = g.G + (long)filt * g.strideG;
+  d4 X[NBM];
+#pragma unroll
+  for (int i = 0; i < NBM; ++i) {
+    X[i] = d4{0.0, 0.0, 0.0, 0.0};
+    if (live && i < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[i][r] = G[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldg];
+    }
+  }
+  sym_tiles_from_regs<NBM>(X, sL, g.K + (long)filt * g.strideK, g.ldk, g.T + (long)filt * g.strideT, g.ldt,
+                           g.P + (long)filt * g.strideP, g.ldp, nb, g.Np / 16, g.jbp, live, wave, wave, lane);
 }
 
 // Streaming variant for factors that do not fit LDS (M > 176): the workgroup (8 waves = 128
@@ -872,7 +936,7 @@ int launch_trsm_lds_tf(const TrsmArgs& g_in, hipStream_t stream) {
 template <int NBM>
 int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
   if constexpr (NBM <= 10) {   // (11 block rows: the T phase spills at the 128-register budget of 16 waves)
-    if (g.T && !g.fwd_only && trsm_forms_T(g.Mp, g.Np)) return launch_trsm_lds_tf<NBM, true>(g, stream);
+    if (g.T && trsm_forms_T(g.Mp, g.Np)) return launch_trsm_lds_tf<NBM, true>(g, stream);
   }
   return launch_trsm_lds_tf<NBM, false>(g, stream);
 }
@@ -916,6 +980,38 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
   return (int)hipGetLastError();
 }
+
+bool pnew_reg_supported(int Mp, int Np) {
+  static const bool off = getenv("XIVO_HIP_NO_PNEW_REG") != nullptr;   // A/B knob: the tiled GEMM instead
+  return !off && Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
+}
+
+template <int NBM>
+static int launch_pnew_reg_t(const PnewRegArgs& g_in, hipStream_t stream) {
+  PnewRegArgs g = g_in;
+  const int nb = g.Mp / 16;
+  const size_t lds = 160 * 1024;
+  g.jbp = (int)(lds / 2 / ((size_t)nb * 4 * 64 * sizeof(double)));
+  if (g.jbp > 16) g.jbp = 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pnew_reg_f64_kernel<NBM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((pnew_reg_f64_kernel<NBM>), dim3(((g.batch + 7) / 8) * 8), dim3(1024), lds, stream, g);
+  return (int)hipGetLastError();
+}
+
+int launch_pnew_reg_f64(const PnewRegArgs& g, hipStream_t stream) {
+  if (g.batch <= 0) return 0;
+  const int nb = g.Mp / 16;
+  if (nb <= 6) return launch_pnew_reg_t<6>(g, stream);
+  if (nb <= 10) return launch_pnew_reg_t<10>(g, stream);
+  return (int)hipErrorInvalidValue;
+}
+
+void pnew_reg_kernel_label(int Mp, char* buf, size_t n) { snprintf(buf, n, "pnew_reg_f64_kernel<%d>", Mp / 16 <= 6 ? 6 : 10); }
 
 bool trsm_forms_T(int Mp, int Np) {
   static const bool off = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: T as a stand-alone product

@@ -114,15 +114,37 @@ struct TrsmArgs {
   long strideY;
   // T = K (HP) - P formed on the gain while it is still in registers (estimator.cpp:1280 distributed over HP):
   // lower triangle authoritative + mirror, as the stand-alone product writes it. nullptr: not wanted.
-  double* T;
+  double* T;           // (fwd_only: the covariance itself, updated in place: P+ = P - W^T W)
   long strideT;
   int ldt;
+  const int* skip_status;   // fwd_only: per filter, non-zero = leave P untouched
   const double* Pm;    // the prior covariance [Np x Np]
   long stridePm;
   int ldpm;
   int t_jbp;           // (set by the launcher) column blocks per LDS phase
 };
 int launch_trsm_f64(const TrsmArgs& args, hipStream_t stream);
+// P+ = G K^T - T with the rows of G in registers (one workgroup per filter; see chol_trsm.hip)
+struct PnewRegArgs {
+  const double* G;     // [Np x Mp] col-major
+  long strideG;
+  int ldg;
+  const double* K;     // [Np x Mp] col-major
+  long strideK;
+  int ldk;
+  const double* T;     // [Np x Np] symmetric
+  long strideT;
+  int ldt;
+  double* P;           // out [Np x Np]
+  long strideP;
+  int ldp;
+  const int* skip_status;   // per filter: non-zero = leave P untouched
+  int Mp, Np, batch;
+  int jbp;             // (set by the launcher)
+};
+bool pnew_reg_supported(int Mp, int Np);
+int launch_pnew_reg_f64(const PnewRegArgs& args, hipStream_t stream);
+void pnew_reg_kernel_label(int Mp, char* buf, size_t n);
 // whether launch_trsm_f64 forms T itself for these shapes (whole factor in LDS, one column chunk per filter)
 bool trsm_forms_T(int Mp, int Np);
 // y = L^-1 inn for every filter (one wave each): the forward substitution of the innovation vector
