@@ -1653,6 +1653,389 @@ __global__ __launch_bounds__(256, NS == 4 ? 3 : 2) void propagate_state_kernel(P
   }
 }
 
+// ---------------------------------------------------------------- propagation, one wave per filter
+// The workgroup kernel above spends its time in barriers between phases that keep a few dozen lanes busy. Here ONE
+// wave owns a filter: nothing waits on another wave, the phases follow each other in program order, and what only
+// ever belongs to one lane leaves the LDS:
+//  * element e = lane + 64 m (m < 9) of every 23 x 23 matrix is handled by the same lane in the tableau sums, the
+//    stage combination and the + Qmodel step, so P_mm and the stage derivatives PK_q live in registers (the stage
+//    loop is unrolled: PK_q is a named register set and the tableau a compile-time constant whose zeros cost nothing);
+//  * LDS (28 KB RK4 / 34 KB Dormand-Prince: 5 / 4 filters per CU) keeps what crosses lanes: P0, the F products,
+//    the FK_q, the transition;
+//  * the nominal pre-pass is vectorised over the stages: lane q < NS composes stage q, lane NS the sub-step itself
+//    (the same ComposeMotion code with its own sample time, step and velocity; a stage of step 0 composes with the
+//    identity, exactly), each lane forming the tableau-weighted velocity from the stage velocities it recomputes.
+// Arithmetic per element is that of the workgroup kernel (same ascending-k / ascending-q sums).
+template <int NS> struct RkConst;
+template <> struct RkConst<4> {
+  static constexpr double a[4][3] = {{0, 0, 0}, {0.5, 0, 0}, {0, 0.5, 0}, {0, 0, 1.0}};
+  static constexpr double c_step[4] = {0.0, 0.5, 0.5, 1.0};
+  static constexpr double c_imu[4] = {0.0, 0.5, 0.5, 0.5};
+  static constexpr double b[4] = {1 / 6.0, 2 / 6.0, 2 / 6.0, 1 / 6.0};
+};
+template <> struct RkConst<7> {
+  static constexpr double a[7][6] = {{0},
+                                     {2 / 9.0},
+                                     {1 / 12.0, 3 / 12.0},
+                                     {55 / 324.0, -75 / 324.0, 200 / 324.0},
+                                     {83 / 330.0, -195 / 330.0, 305 / 330.0, 27 / 330.0},
+                                     {-19 / 28.0, 63 / 28.0, 4 / 28.0, -108 / 28.0, 88 / 28.0},
+                                     {38 / 400.0, 0.0, 240 / 400.0, -243 / 400.0, 330 / 400.0, 35 / 400.0}};
+  static constexpr double c_step[7] = {0.0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1.0, 1.0};
+  static constexpr double c_imu[7] = {0.0, 2 / 9.0, 3 / 9.0, 5 / 9.0, 6 / 9.0, 1.0, 1.0};
+  static constexpr double b[7] = {0.0862, 0.0, 0.6660, -0.7857, 0.9570, 0.0965, -0.0200};
+};
+
+template <int NS>
+__global__ __launch_bounds__(64) void propagate_state_wave_kernel(PropStateArgs a) {
+  constexpr int NM = 23, NN = NM * NM, FR = 9, NF = FR * NM, EL = 9, FL = 4;   // EL / FL: elements of a 23 x 23 / 9 x 23 matrix per lane
+  using TB = RkConst<NS>;
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x, filt = blockIdx.x;
+  const RkTableau& tab = kTableau[NS == 4 ? 0 : 1];
+  double* P0 = sm;
+  double* S1 = P0 + NN;        // 23 x 23 scratch whose rows >= 9 stay zero: sum a_q FK_q, later I + FK h
+  double* FPs = S1 + NN;       // [9 x 23]  F P0   ([i + 9 j])
+  double* PFs = FPs + NF;      // [23 x 9]  P0 F^T ([i + 23 j])
+  double* GQG = PFs + NF;      // [12 x 12] support of G Q G^T
+  double* Q = GQG + 144;
+  double* GQc = Q + 144;       // [12 x 12] the non-zero rows of G Q
+  double* zero = GQc + 144;    // one 0.0 + pad
+  double* nom = zero + 2;      // nominal state + IMU sample (layout of the workgroup kernel)
+  double* Jms = nom + 36;      // [NS][4][3 x 3]
+  double* F9 = Jms + NS * 36;  // [9 x 23] dense non-zero rows of F of the current stage
+  double* FKs = F9 + NF;       // [NS][9 x 23]
+  double* PhiA = FKs + NS * NF;
+
+  const double* Pg = a.P + (long)filt * a.strideP;
+  // Lanes past the end of a matrix repeat its last element (clamped index): no predicates in the loops, the copies
+  // hold identical values and only the owner stores at the end.
+  double Pmm[EL], PK[NS][EL];
+  int off[EL];                 // LDS offsets of the three terms of PK(e), 11 bits each... packed as 8-bit offsets into FPs / PFs / GQG (255: absent)
+#pragma unroll
+  for (int m = 0; m < EL; ++m) {
+    const int e = min(lane + 64 * m, NN - 1), i = e % NM, j = e / NM;
+    const int ci = i < 3 ? i : ((i >= 6 && i < 15) ? i - 3 : -1), cj = j < 3 ? j : ((j >= 6 && j < 15) ? j - 3 : -1);
+    Pmm[m] = Pg[i + (long)j * a.ldp];
+    off[m] = (i < FR ? i + FR * j : 255) | ((j < FR ? i + NM * j : 255) << 8) | (((ci >= 0 && cj >= 0) ? ci + 12 * cj : 255) << 16);
+    S1[e] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) PK[q][m] = 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < FL; ++u) {
+    const int f = min(lane + 64 * u, NF - 1);
+    const int i = f % FR, j = f / FR;
+    PhiA[f] = i == j ? 1.0 : 0.0;
+    F9[f] = (i < 3 && j == 9 + i) ? -1.0 : ((i >= 3 && i < 6 && j == 3 + i) ? 1.0 : 0.0);   // dWsb/dbg = -I, dTsb/dVsb = I
+#pragma unroll
+    for (int q = 0; q < NS; ++q) FKs[q * NF + f] = 0.0;
+  }
+  if (lane == 0) zero[0] = 0.0;
+  for (int e = lane; e < 144; e += 64) {
+    const double q = a.Qimu[e];
+    Q[e] = q;
+    const int r = e % 12;      // rows of G Q that do not depend on the state: Wsb rows = -Q[0:3,:], bg / ba rows = Q[6:12,:]
+    if (r < 3) GQc[e] = -q;
+    else if (r >= 6) GQc[e] = q;
+  }
+  double* Phi = PhiA;
+  xivo_pose_in& pose = a.poses[filt];
+  const V3 gv{{a.g[0], a.g[1], a.g[2]}};
+  if (lane == 0) {
+    const V3 Rg0 = m3_mulv(m3_from_colmajor(pose.Rsg), gv);   // Rsg g (estimator.cpp:609)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) nom[3 * i + j] = pose.Rsb[i + 3 * j];
+      nom[9 + i] = pose.Tsb[i]; nom[12 + i] = pose.Vsb[i]; nom[15 + i] = pose.bg[i]; nom[18 + i] = pose.ba[i];
+      nom[21 + i] = Rg0.v[i];
+    }
+  }
+  __syncthreads();   // (one wave: orders the LDS traffic, no waiting)
+
+  const xivo_imu_in* imu_f = a.imu + (long)filt * a.n_imu;
+  const int c3 = lane < 3 ? lane : 0;
+  double n_g = imu_f[0].gyro[c3], n_a = imu_f[0].accel[c3], n_sg = imu_f[0].slope_gyro[c3], n_sa = imu_f[0].slope_accel[c3];
+  double n_dt = imu_f[0].dt;
+  for (int smp = 0; smp < a.n_imu; ++smp) {
+    if (lane < 3) { nom[24 + lane] = n_g; nom[27 + lane] = n_a; nom[30 + lane] = n_sg; nom[33 + lane] = n_sa; }
+    const double dt = n_dt;
+    if (smp + 1 < a.n_imu) {
+      const xivo_imu_in& nx = imu_f[smp + 1];
+      n_g = nx.gyro[c3]; n_a = nx.accel[c3]; n_sg = nx.slope_gyro[c3]; n_sa = nx.slope_accel[c3]; n_dt = nx.dt;
+    }
+    __syncthreads();
+    double total = 0.0;
+    // fixed sub-stepping with the half-step tail trick (rk4.cpp:13-32, princedormand.cpp:62-81)
+    while (total < dt || a.stepsize < 0) {
+      double h = a.stepsize;
+      if (a.stepsize < 0) h = dt;
+      else if (total + h > dt) h = dt - total;
+      else if (total + h + 0.5 * h > dt) h = 0.5 * h;
+
+      {  // -- nominal pre-pass: lane q < NS = stage q, lane NS = the sub-step itself
+        MotionRegs X0; V3 Rg;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) X0.Rsb.m[i][j] = nom[3 * i + j];
+          X0.Tsb.v[i] = nom[9 + i]; X0.Vsb.v[i] = nom[12 + i]; X0.bg.v[i] = nom[15 + i]; X0.ba.v[i] = nom[18 + i];
+          Rg.v[i] = nom[21 + i];
+        }
+        V3 g0, a0, sg, sa;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { g0.v[i] = nom[24 + i]; a0.v[i] = nom[27 + i]; sg.v[i] = nom[30 + i]; sa.v[i] = nom[33 + i]; }
+        // the tableau-weighted velocity: K_q = Vsb of stage q's ComposeMotion (estimator.cpp:609)
+        V3 Kt{{0, 0, 0}};
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const double tq = TB::c_imu[q] * h, dq = TB::c_step[q] * h;
+          V3 ac;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) ac.v[i] = (a0.v[i] + sa.v[i] * tq) - X0.ba.v[i];
+          const V3 Ra = m3_mulv(X0.Rsb, ac);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            double kq = X0.Vsb.v[i];
+            if (q > 0) kq += (Ra.v[i] + Rg.v[i]) * dq;
+            Kt.v[i] += TB::b[q] * kq;
+          }
+        }
+        const bool is_step = lane == NS;
+        const int st = lane < NS ? lane : 0;
+        const double ti = is_step ? h : tab.c_imu[st] * h;
+        const double ds = is_step ? h : tab.c_step[st] * h;
+        V3 gi, ai, V;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          gi.v[i] = g0.v[i] + sg.v[i] * ti; ai.v[i] = a0.v[i] + sa.v[i] * ti;
+          V.v[i] = is_step ? Kt.v[i] : 0.0;   // the a_ij-weighted velocities of a stage only move Tsb, which no Jacobian reads
+        }
+        compose_motion_dev(X0, V, gi, ai, ds, Rg);
+        // ComputeMotionJacobianAt (estimator.cpp:615-704): the blocks of F and G
+        V3 gc, ac;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { gc.v[i] = gi.v[i] - X0.bg.v[i]; ac.v[i] = ai.v[i] - X0.ba.v[i]; }
+        const M3 w_dW_dW = m3_neg(hat(gc));
+        const M3 w_dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));
+        const M3 w_dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));
+        const M3 w_nR = m3_neg(X0.Rsb);
+        if (lane < NS) {
+          double* Jm = Jms + st * 36;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              Jm[3 * i + j] = w_dW_dW.m[i][j]; Jm[9 + 3 * i + j] = w_dV_dW.m[i][j];
+              Jm[18 + 3 * i + j] = w_nR.m[i][j]; Jm[27 + 3 * i + j] = w_dV_dWsg.m[i][j];
+            }
+        } else if (is_step) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) nom[3 * i + j] = X0.Rsb.m[i][j];
+            nom[9 + i] = X0.Tsb.v[i]; nom[12 + i] = X0.Vsb.v[i];
+            nom[24 + i] = gi.v[i]; nom[27 + i] = ai.v[i];   // rk4.cpp:27-28: the next sub-step starts from the interpolated sample
+          }
+        }
+      }
+      __syncthreads();
+
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const double* Jm = Jms + st * 36;
+        // -- phase A: P0 = Pmm + (sum_q a_q PK_q) h, S = sum_q a_q FK_q (rows < 9), the stage's entries of F, Vsb rows of G Q
+#pragma unroll
+        for (int m = 0; m < EL; ++m) {
+          const int e = min(lane + 64 * m, NN - 1);
+          double sp = 0.0;
+#pragma unroll
+          for (int q = 0; q < st; ++q)
+            if (TB::a[st][q] != 0.0) sp += TB::a[st][q] * PK[q][m];
+          P0[e] = Pmm[m] + sp * h;
+        }
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+          const int f = min(lane + 64 * u, NF - 1);
+          double sf = 0.0;
+#pragma unroll
+          for (int q = 0; q < st; ++q)
+            if (TB::a[st][q] != 0.0) sf += TB::a[st][q] * FKs[q * NF + f];
+          S1[(f % FR) + NM * (f / FR)] = sf;
+        }
+        if (lane < 33) {                                            // the stage's 33 state-dependent entries of F
+          const int l = lane, blk = l < 27 ? l / 9 : 3, m = l - 9 * blk;
+          const int i = blk < 3 ? m / 3 : m / 2, j = blk < 3 ? m % 3 : m % 2;
+          const int row = blk == 0 ? i : 6 + i, col = blk < 2 ? j : (blk == 2 ? 12 + j : 21 + j);
+          F9[row + FR * col] = Jm[9 * blk + 3 * i + j];
+        } else if (lane < 45) {                                     // (G Q)[Vsb_i, l] = sum_k -Rsb[i][k] Q[3 + k, l]
+          const int l = lane - 33;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v = fma(Jm[18 + 3 * i + k], Q[(3 + k) + 12 * l], v);
+            GQc[(3 + i) + 12 * l] = v;
+          }
+        }
+        __syncthreads();
+
+        // -- phase B: the structured products (the published 3 x 3 blocks once into registers)
+        M3 dW_dW, dV_dW, nR, dV_dWsg;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            dW_dW.m[i][j] = Jm[3 * i + j]; dV_dW.m[i][j] = Jm[9 + 3 * i + j];
+            nR.m[i][j] = Jm[18 + 3 * i + j]; dV_dWsg.m[i][j] = Jm[27 + 3 * i + j];
+          }
+        {
+          // lanes 0..22: column j of F P0, lanes 32..54: column j of F S and from it FK of the stage
+          const bool fk_task = lane >= 32;
+          const int j = fk_task ? lane - 32 : lane;
+          if (j < NM) {
+            const double* M = (fk_task ? S1 : P0) + NM * j;
+            double o[9];
+            const double m0 = M[0], m1 = M[1], m2 = M[2], m12 = M[12], m13 = M[13], m14 = M[14], m21 = M[21], m22 = M[22];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {                           // Wsb rows: k = 0..2 (dW/dW), k = 9 + i (-1)
+              double v = fma(dW_dW.m[i][0], m0, 0.0);
+              v = fma(dW_dW.m[i][1], m1, v);
+              v = fma(dW_dW.m[i][2], m2, v);
+              o[i] = fma(-1.0, M[9 + i], v);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) o[3 + i] = fma(1.0, M[6 + i], 0.0);   // Tsb rows: k = 6 + i (1)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {                           // Vsb rows: k = 0..2, 12..14, 21..22
+              double v = fma(dV_dW.m[i][0], m0, 0.0);
+              v = fma(dV_dW.m[i][1], m1, v);
+              v = fma(dV_dW.m[i][2], m2, v);
+              v = fma(nR.m[i][0], m12, v);
+              v = fma(nR.m[i][1], m13, v);
+              v = fma(nR.m[i][2], m14, v);
+              v = fma(dV_dWsg.m[i][0], m21, v);
+              o[6 + i] = fma(dV_dWsg.m[i][1], m22, v);
+            }
+            if (fk_task) {                                          // FK_st = F + F S h
+#pragma unroll
+              for (int i = 0; i < FR; ++i) FKs[st * NF + i + FR * j] = F9[i + FR * j] + o[i] * h;
+            } else {
+#pragma unroll
+              for (int i = 0; i < FR; ++i) FPs[i + FR * j] = o[i];
+            }
+          }
+        }
+        if (lane < NM) {                                            // (P0 F^T)[i, 0..8] = sum_k P0[i, k] F[j, k]
+          const int i = lane;
+          const double p0 = P0[i], p1 = P0[i + NM], p2 = P0[i + NM * 2];
+          const double p12 = P0[i + NM * 12], p13 = P0[i + NM * 13], p14 = P0[i + NM * 14];
+          const double p21 = P0[i + NM * 21], p22 = P0[i + NM * 22];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            double v = fma(p0, dW_dW.m[j][0], 0.0);
+            v = fma(p1, dW_dW.m[j][1], v);
+            v = fma(p2, dW_dW.m[j][2], v);
+            PFs[i + NM * j] = fma(P0[i + NM * (9 + j)], -1.0, v);
+            PFs[i + NM * (3 + j)] = fma(P0[i + NM * (6 + j)], 1.0, 0.0);
+            double w = fma(p0, dV_dW.m[j][0], 0.0);
+            w = fma(p1, dV_dW.m[j][1], w);
+            w = fma(p2, dV_dW.m[j][2], w);
+            w = fma(p12, nR.m[j][0], w);
+            w = fma(p13, nR.m[j][1], w);
+            w = fma(p14, nR.m[j][2], w);
+            w = fma(p21, dV_dWsg.m[j][0], w);
+            PFs[i + NM * (6 + j)] = fma(p22, dV_dWsg.m[j][1], w);
+          }
+        } else if (lane >= 32 && lane < 44) {                       // (G Q G^T)[r, :] on the 12 x 12 support
+          const int r = lane - 32;
+          const double g3 = GQc[r + 12 * 3], g4 = GQc[r + 12 * 4], g5 = GQc[r + 12 * 5];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            GQG[r + 12 * j] = fma(GQc[r + 12 * j], -1.0, 0.0);     // Wsb columns: G[Wsb_j, j] = -1
+            double v = fma(g3, nR.m[j][0], 0.0);                    // Vsb columns: G[Vsb_j, 3..5] = -Rsb[j][:]
+            v = fma(g4, nR.m[j][1], v);
+            GQG[r + 12 * (3 + j)] = fma(g5, nR.m[j][2], v);
+            GQG[r + 12 * (6 + j)] = GQc[r + 12 * (6 + j)];          // bg, ba columns: +1
+            GQG[r + 12 * (9 + j)] = GQc[r + 12 * (9 + j)];
+          }
+        }
+        __syncthreads();
+
+        // -- phase C: PK_st = F P0 + P0 F^T + G Q G^T
+#pragma unroll
+        for (int m = 0; m < EL; ++m) {
+          const int o1 = off[m] & 255, o2 = (off[m] >> 8) & 255, o3 = (off[m] >> 16) & 255;
+          const double t1 = o1 == 255 ? 0.0 : FPs[o1], t2 = o2 == 255 ? 0.0 : PFs[o2], t3 = o3 == 255 ? 0.0 : GQG[o3];
+          PK[st][m] = (t1 + t2) + t3;
+        }
+        // (phase A of the next stage writes P0 / S1 / F9 / GQc, which phase B above has finished reading; FPs / PFs / GQG are
+        //  rewritten by the next phase B only, after the reads just issued - program order within the one wave)
+      }
+      // combine the stages
+#pragma unroll
+      for (int m = 0; m < EL; ++m) {
+        double pk = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+          if (TB::b[q] != 0.0) pk += TB::b[q] * PK[q][m];
+        Pmm[m] += pk * h;                              // rk4.cpp:92-93
+      }
+#pragma unroll
+      for (int u = 0; u < FL; ++u) {
+        const int f = min(lane + 64 * u, NF - 1);
+        const int i = f % FR, j = f / FR;
+        double fk = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+          if (TB::b[q] != 0.0) fk += TB::b[q] * FKs[q * NF + f];
+        S1[i + NM * j] = (i == j ? 1.0 : 0.0) + fk * h;     // rows < 9 of Phi_step = I + FK h
+      }
+      __syncthreads();
+      {                                                // Phi <- Phi_step Phi (rows >= 9 of both are identity rows), in place:
+        double pv[FL];                                 // every lane has read its column before any lane writes
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+          const int f = min(lane + 64 * u, NF - 1);
+          const int i = f % FR, j = f / FR;
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < FR; ++k) v = fma(S1[i + NM * k], Phi[k + FR * j], v);
+          const double tail = fma(S1[i + NM * j], 1.0, v);
+          pv[u] = j >= FR ? tail : v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < FL; ++u) Phi[min(lane + 64 * u, NF - 1)] = pv[u];
+      }
+      __syncthreads();
+      total += h;
+      if (a.stepsize < 0) break;
+    }
+#pragma unroll
+    for (int m = 0; m < EL; ++m) Pmm[m] += a.Qmodel[min(lane + 64 * m, NN - 1)];   // P_mm += Qmodel (estimator.cpp:590), per Propagate
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < EL; ++m) {
+    const int e = lane + 64 * m;
+    if (e < NN) a.Pmm_out[(long)filt * NN + e] = Pmm[m];
+  }
+  for (int e = lane; e < NN; e += 64) {
+    const int i = e % NM, j = e / NM;
+    a.Phi_out[(long)filt * NN + e] = i < FR ? Phi[i + FR * j] : (i == j ? 1.0 : 0.0);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pose.Tsb[i] = nom[9 + i]; pose.Vsb[i] = nom[12 + i];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pose.Rsb[i + 3 * j] = nom[3 * i + j];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- measurement compression of the OOS rows
 // use_compression_ / compression_trigger_ratio_ (src/estimator.h:399-402) and xivo::QR (src/helpers.cpp:77-101, "QR-based
 // measurement compression") are parsed / defined but never run by the reference's pipeline. Here the block of
@@ -2077,8 +2460,21 @@ static int launch_propagate_state_ns(const PropStateArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(propagate_state_kernel<NS>, dim3(a.batch), dim3(256), lds, s, a);
   CHECK_LAUNCH();
 }
+template <int NS>
+static int launch_propagate_state_wave(const PropStateArgs& a, hipStream_t s) {
+  // LDS: P0, S1, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, nominal state, F9, two transition buffers, per stage 36
+  // Jacobian entries + FK: RK4 28 KB (5 filters per CU), Dormand-Prince 34 KB (4)
+  const size_t lds = (size_t)(2 * 529 + 4 * 207 + 3 * 144 + 2 + 36 + NS * (36 + 207)) * sizeof(double);
+  hipLaunchKernelGGL(propagate_state_wave_kernel<NS>, dim3(a.batch), dim3(64), lds, s, a);
+  CHECK_LAUNCH();
+}
+bool propagate_uses_wave_kernel() {
+  static const bool wg = getenv("XIVO_HIP_PROP_WG") != nullptr;   // A/B knob: the four-wave workgroup kernel
+  return !wg;
+}
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s) {
   if (a.batch <= 0) return 0;
+  if (propagate_uses_wave_kernel()) return a.method ? launch_propagate_state_wave<7>(a, s) : launch_propagate_state_wave<4>(a, s);
   return a.method ? launch_propagate_state_ns<7>(a, s) : launch_propagate_state_ns<4>(a, s);
 }
 int launch_mfma_peak(double* sink, int iters, int blocks, hipStream_t s) {
