@@ -336,7 +336,7 @@ def test_profile_reports_kernels_bytes_and_path(built):
         if path == 1:
             assert prof["gemm_AP"]["launches"] == 0
         assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<10")   # B = 16: the latency kernel
-        assert prof["trsm_gain"]["kernel"] == ("trsm_lds_f64_kernel<10,true>" if path == 1 else "trsm_lds_f64_kernel<10,false>")
+        assert prof["trsm_gain"]["kernel"] == ("trsm_lds_f64_kernel<10,1>" if path == 1 else "trsm_lds_f64_kernel<10,0>")
 
 
 @pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])

@@ -575,7 +575,7 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
     // the solve kernel goes on to P+ = P - W^T W in place, W^T still in its registers (blocks exchanged through LDS)
     const bool p_here = !full && trsm_forms_T(Mp, Np);
     if (p_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.skip_status = c->status + b0; }
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), p_here);
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), p_here ? 2 : 0);
     const double outs = 0.5 * Np * (Np + 1.0);
     StageTimer st(c, ST_TRSM, (1.0 * Mp * Mp * Np + (p_here ? 2.0 * outs * Mp : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (p_here ? outs + (double)Np * Np : 0.0)));
@@ -667,7 +667,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     const bool t_here = !t_full && trsm_forms_T(Mp, Np);
     if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), t_here);
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), t_here ? 1 : 0);
     const double t_outs = 0.5 * Np * (Np + 1.0);
     StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (t_here ? 2.0 * t_outs * Mp : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (t_here ? t_outs + (double)Np * Np : 0.0)));

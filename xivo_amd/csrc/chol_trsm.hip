@@ -598,7 +598,7 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* 
 // (conflict-free ds_read_b64) - and wave w forms the 16 x 16 tiles (w, j) for the j cyclically below it
 // (every unordered pair of blocks once: 8 or 9 tiles per wave), accumulators starting at -P, and writes each
 // tile and its mirror. K is never read back and H P is read once more instead of 1.5 times by the tiled GEMM.
-template <int NBM, bool TF>
+template <int NBM, int TF>
 __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr int BLK = 16 * 17;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   if (!TF) return;
 
   __syncthreads();                                 // the factor is dead: the LDS takes the operands
-  if (g.fwd_only) {
+  if (TF == 2) {
     // ---- symmetric form: P+ = P - W^T W in place, W^T = the forward-substituted columns still in registers
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
     double* Pio = g.T + (long)filt * g.strideT;
@@ -912,7 +912,7 @@ int launch_trsm_stream_t(const TrsmArgs& g, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int NBM, bool TF>
+template <int NBM, int TF>
 int launch_trsm_lds_tf(const TrsmArgs& g_in, hipStream_t stream) {
   TrsmArgs g = g_in;
   const int nb = g.Mp / 16;
@@ -936,9 +936,9 @@ int launch_trsm_lds_tf(const TrsmArgs& g_in, hipStream_t stream) {
 template <int NBM>
 int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
   if constexpr (NBM <= 10) {   // (11 block rows: the T phase spills at the 128-register budget of 16 waves)
-    if (g.T && trsm_forms_T(g.Mp, g.Np)) return launch_trsm_lds_tf<NBM, true>(g, stream);
+    if (g.T && trsm_forms_T(g.Mp, g.Np)) return g.fwd_only ? launch_trsm_lds_tf<NBM, 2>(g, stream) : launch_trsm_lds_tf<NBM, 1>(g, stream);
   }
-  return launch_trsm_lds_tf<NBM, false>(g, stream);
+  return launch_trsm_lds_tf<NBM, 0>(g, stream);
 }
 
 template <int NBM>
@@ -1056,10 +1056,10 @@ void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
   else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)), (nb > 8 && batch >= 512) ? 3 : 2);
 }
 
-void trsm_kernel_label(int Mp, char* buf, size_t n, bool forms_T) {
+void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T) {
   const int nb = Mp / 16;
   const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
-  if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%s>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T ? "true" : "false");
+  if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
   else if (!no_stream) snprintf(buf, n, "trsm_stream_f64_kernel<%d>", nb <= 14 ? 14 : (nb <= 19 ? 19 : 24));
   else snprintf(buf, n, "trsm_f64_kernel");
 }

@@ -150,7 +150,7 @@ bool trsm_forms_T(int Mp, int Np);
 // y = L^-1 inn for every filter (one wave each): the forward substitution of the innovation vector
 int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD, long strideInvD, const double* inn, long strideInn,
                    double* y, long strideY, int Mp, int batch, hipStream_t stream);
-void trsm_kernel_label(int Mp, char* buf, size_t n, bool forms_T = false);
+void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T = 0);   // forms_T: 0 solve only, 1 + T = K(HP) - P, 2 + P - W^T W (symmetric form)
 
 }  // namespace xivo_hip
 
