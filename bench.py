@@ -8,7 +8,8 @@ fp64, XIVO row sparsity, inputs resident in HBM before the timed region. Every
 step hands the dense H / inn / diagR of every filter over again (H changes with
 every camera frame, src/update.cpp:129-138): the dense -> row-pair compression is
 inside the timed step. `value` is the ALL-fp64 rate (XIVO_HIP_FLAG_FP64_CORR); the
-rate with the Joseph correction product on the fp32 MFMA is reported next to it.
+library's default mode is timed next to it (`value_mixed`: the same all-fp64 kernels
+at this size, the fp32 correction product only where the in-solve update does not apply).
 
 `python bench.py --gpus N` without a launcher spawns its N ranks itself.
 
@@ -395,7 +396,11 @@ def main():
         dt_m, gpu_ms_m, prof_m = timed(min(args.warmup, 2))
         dt_m = max_over_ranks(dist, dt_m)
         mixed = {"value": world * B * args.steps / dt_m, "ms_per_step": dt_m / args.steps * 1e3,
-                 "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof_m.items() if v["launches"]}}
+                 "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof_m.items() if v["launches"]},
+                 # whether this run really took another code path than `value`: at sizes the in-solve covariance update
+                 # holds (N <= 256, M <= 160) the library is all fp64 in its default mode too
+                 "same_kernels_as_value": {k: v["kernel"] for k, v in prof_m.items() if v["launches"]} ==
+                                          {k: v["kernel"] for k, v in prof.items() if v["launches"]}}
         ctx.set_flags(flags)
 
     # ---- third figure (opt-in library mode, NOT the headline): XIVO_HIP_FLAG_SYMMETRIC_FORM - P+ = P - W^T W with
@@ -511,9 +516,10 @@ def main():
                                      "every step, inside the timed region (stage stack_H)") if args.level == "S" else
                                     "Jacobians -> compressed rows on device every step",
                        "precision": {"value": "all fp64: storage, every product, factorisation, solve (XIVO_HIP_FLAG_FP64_CORR)",
-                                     "value_mixed": "library default: identical, except the Joseph correction product G K^T "
-                                                    "(G = T H^T + K R = O(eps cond(S)) residual) on v_mfma_f32_16x16x4_f32; "
-                                                    "G itself and -T stay fp64"},
+                                     "value_mixed": "library default (no flag): the same all-fp64 kernels wherever the in-solve "
+                                                    "covariance update applies (N <= 256, M <= 160; see mixed.same_kernels_as_value); "
+                                                    "elsewhere the Joseph correction product G K^T (G = O(eps cond(S)) residual) runs "
+                                                    "on v_mfma_f32_16x16x4_f32 with G itself and -T in fp64"},
                        "gpu_event_ms_per_step": gpu_ms / args.steps,
                        "not_spd_filters": int((status != 0).sum())},
             "value_mixed": mixed["value"] if mixed else None,

@@ -51,7 +51,9 @@ def test_full_pnew_flag_equals_mirrored(built):
         with Context(N, 2 * F, B, flags=flags) as ctx:
             ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
             outs.append(ctx.download_P())
-    assert rel_fro(outs[0], outs[1]) < 1e-13
+    # default: the expanded Joseph expression formed inside the solve kernel; FULL_PNEW: the re-associated expression
+    # from the stand-alone products, every entry computed - two rounding-level re-orderings of the same update
+    assert rel_fro(outs[0], outs[1]) < 1e-11
 
 
 def test_upload_download_roundtrip_bit_exact(built):
@@ -294,7 +296,7 @@ def test_sparse_path_with_structural_zero_in_common_column(built):
             assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
 
 
-@pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (400, 150)])
+@pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (400, 150), (203, 30), (37, 3), (64, 8), (100, 1)])   # odd / even block counts, both register-kernel widths
 def test_fp32_correction_product_is_invisible(built, N, F):
     """Sparse-H pipeline: P+ = -T + G K^T with the correction product G K^T on the fp32 MFMA (default) vs in
     fp64 (XIVO_HIP_FLAG_FP64_CORR). G is the O(eps) residual of the gain equation, so the two agree to ~1e-15
@@ -328,15 +330,16 @@ def test_profile_reports_kernels_bytes_and_path(built):
             prof = ctx.profile_get()
             assert ctx.last_path() == path
         assert prof["gemm_HP"]["kernel"] == hp_kernel
-        # sparse pipeline: T = K(HP) - P is formed by the solve kernel on the gain in its registers - no stand-alone product
-        stages = ("gemm_HP", "gemm_S", "chol_S", "trsm_gain", "gemm_Pnew") + (() if path == 1 else ("gemm_AP",))
+        # sparse pipeline: the solve kernel carries the whole covariance update on the gain in its registers - no stand-alone
+        # T / G / P+ kernels
+        stages = ("gemm_HP", "gemm_S", "chol_S", "trsm_gain") + (() if path == 1 else ("gemm_AP", "gemm_Pnew"))
         for st in stages:
             assert prof[st]["launches"] == 1 and prof[st]["ms"] > 0 and prof[st]["kernel"]
             assert prof[st]["bytes_per_launch"] > 0 and prof[st]["flops_per_launch"] > 0
         if path == 1:
-            assert prof["gemm_AP"]["launches"] == 0
+            assert prof["gemm_AP"]["launches"] == 0 and prof["gemm_KH_I"]["launches"] == 0 and prof["gemm_Pnew"]["launches"] == 0
         assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<10")   # B = 16: the latency kernel
-        assert prof["trsm_gain"]["kernel"] == ("trsm_lds_f64_kernel<10,1>" if path == 1 else "trsm_lds_f64_kernel<10,0>")
+        assert prof["trsm_gain"]["kernel"] == ("trsm_lds_f64_kernel<10,3>" if path == 1 else "trsm_lds_f64_kernel<10,0>")
 
 
 @pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])

@@ -663,15 +663,20 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
-    // the solve goes on to T = K (HP) - P with the gain still in its registers (lower triangle + mirror)
+    // the solve goes on to the whole covariance update in place with the gain still in its registers (expanded Joseph
+    // form; T and G never exist in memory) - or, with XIVO_HIP_NO_JOSEPH_IN_SOLVE, to T = K (HP) - P only
     const bool t_here = !t_full && trsm_forms_T(Mp, Np);
-    if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
+    static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;   // A/B knob
+    const bool all_here = t_here && !no_joseph;   // (both precision modes: it is all fp64 and faster than the fp32 correction product)
+    if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = 1; a.skip_status = c->status + b0; }
+    else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), t_here ? 1 : 0);
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? 3 : (t_here ? 1 : 0));
     const double t_outs = 0.5 * Np * (Np + 1.0);
-    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (t_here ? 2.0 * t_outs * Mp : 0.0)) * B, label,
+    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (t_here ? 2.0 * t_outs * Mp : 0.0) + (all_here ? 2.0 * Mp * Mp * Np : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (t_here ? t_outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
+    if (all_here) return XIVO_HIP_OK;
   }
   if (!t_done) {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
      // triangle is computed and mirrored (XIVO_HIP_FLAG_FULL_PNEW: all of it)
@@ -1520,7 +1525,9 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   a.g[0] = o->g[0]; a.g[1] = o->g[1]; a.g[2] = o->g[2]; a.method = o->method; a.stepsize = o->stepsize;
   a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
   {
-    StageTimer st(c, ST_PROP_STATE, 0.0, "propagate_state_kernel");
+    char plabel[64];
+    snprintf(plabel, sizeof(plabel), "%s<%d>", propagate_uses_wave_kernel() ? "propagate_state_wave_kernel" : "propagate_state_kernel", a.method ? 7 : 4);
+    StageTimer st(c, ST_PROP_STATE, 0.0, plabel);
     HIP_TRY((hipError_t)launch_propagate_state(a, c->stream));
   }
   {

@@ -630,6 +630,16 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     sL[t * BLK + r + 17 * c] = v[0];
     sL[t * BLK + r + 1 + 17 * c] = v[1];
   }
+  double* sD = sL + nblk * BLK;                        // TF == 3: the diagonal blocks L_kk themselves (upper triangle zeroed)
+  if (TF == 3) {
+    for (int e = tid; e < nb * 128; e += 1024) {
+      const int k = e >> 7, w = e & 127;
+      const int r = (w & 7) * 2, c = w >> 3;
+      const d2 v = *reinterpret_cast<const d2*>(LU + (16 * k + r) + (long)(16 * k + c) * ld);
+      sD[k * BLK + r + 17 * c] = r >= c ? v[0] : 0.0;
+      sD[k * BLK + r + 1 + 17 * c] = r + 1 >= c ? v[1] : 0.0;
+    }
+  }
   const int c0 = chunk * 256 + wave * 16;
   const bool live = c0 < g.Np;
 
@@ -704,10 +714,65 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   part += __shfl_xor(part, 16);
   part += __shfl_xor(part, 32);
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
+
+  if (TF == 3) {
+    // ---- the whole covariance update on the gain in registers (expanded Joseph form, see the launcher's comment):
+    //   V^T = L^T K^T (in place, ascending block rows), then L V^T (in place, descending) = (K L L^T)^T,
+    //   Z^T = 2 P H^T - K L L^T  [= P H^T - G,  G = K (L L^T) - P H^T the residual of the gain equation]
+#pragma unroll
+    for (int j = 0; j < NBM; ++j) {
+      if (j < nb) {
+        const double* Dj = sD + j * BLK;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = mfma(Dj[(4 * s2 + lg) + 17 * li], X[j][s2], acc);                 // (L_jj)^T
+#pragma unroll
+        for (int i = j + 1; i < NBM; ++i) {
+          if (i < nb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+              acc = mfma(sL[(i * (i + 1) / 2 + j) * BLK + (4 * s2 + lg) + 17 * li], X[i][s2], acc);            // (L_ij)^T
+          }
+        }
+        X[j] = acc;
+      }
+    }
+#pragma unroll
+    for (int i = NBM - 1; i >= 0; --i) {
+      if (i < nb) {
+        const double* Di = sD + i * BLK;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = mfma(Di[li + 17 * (4 * s2 + lg)], X[i][s2], acc);                 // L_ii
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2)
+            acc = mfma(sL[(i * (i + 1) / 2 + k) * BLK + li + 17 * (4 * s2 + lg)], X[k][s2], acc);              // L_ik
+        }
+        X[i] = acc;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) {
+      if (i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[i][r] = fma(2.0, PHT[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldpht], -X[i][r]);
+      }
+    }
+  }
   }
   if (!TF) return;
 
   __syncthreads();                                 // the factor is dead: the LDS takes the operands
+  if (TF == 3) {
+    // ---- P+ = P - Z^T K^T in place: rows of Z^T in registers, blocks of the gain just written arrive through LDS
+    if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
+    double* Pio = g.T + (long)filt * g.strideT;
+    sym_tiles_from_regs<NBM, false, true>(X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+                                          live, c0 >> 4, wave, lane);
+    return;
+  }
   if (TF == 2) {
     // ---- symmetric form: P+ = P - W^T W in place, W^T = the forward-substituted columns still in registers
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
@@ -936,7 +1001,8 @@ int launch_trsm_lds_tf(const TrsmArgs& g_in, hipStream_t stream) {
 template <int NBM>
 int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
   if constexpr (NBM <= 10) {   // (11 block rows: the T phase spills at the 128-register budget of 16 waves)
-    if (g.T && trsm_forms_T(g.Mp, g.Np)) return g.fwd_only ? launch_trsm_lds_tf<NBM, 2>(g, stream) : launch_trsm_lds_tf<NBM, 1>(g, stream);
+    if (g.T && trsm_forms_T(g.Mp, g.Np))
+      return g.fwd_only ? launch_trsm_lds_tf<NBM, 2>(g, stream) : (g.joseph ? launch_trsm_lds_tf<NBM, 3>(g, stream) : launch_trsm_lds_tf<NBM, 1>(g, stream));
   }
   return launch_trsm_lds_tf<NBM, 0>(g, stream);
 }

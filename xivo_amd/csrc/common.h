@@ -117,7 +117,8 @@ struct TrsmArgs {
   double* T;           // (fwd_only: the covariance itself, updated in place: P+ = P - W^T W)
   long strideT;
   int ldt;
-  const int* skip_status;   // fwd_only: per filter, non-zero = leave P untouched
+  const int* skip_status;   // fwd_only / joseph: per filter, non-zero = leave P untouched
+  int joseph;          // 1: T is the covariance itself and receives the whole Joseph update in place (expanded form, chol_trsm.hip)
   const double* Pm;    // the prior covariance [Np x Np]
   long stridePm;
   int ldpm;

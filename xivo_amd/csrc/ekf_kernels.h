@@ -87,6 +87,7 @@ struct PropStateArgs {
   int batch;
 };
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s);
+bool propagate_uses_wave_kernel();   // one wave per filter (default) or the four-wave workgroup kernel (XIVO_HIP_PROP_WG)
 
 // xivo::Givens / xivo::QR (helpers.cpp:27-101), one wave per problem, in place
 struct GivensArgs {
