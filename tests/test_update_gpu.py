@@ -431,3 +431,57 @@ def test_symmetric_form_gated_ill_conditioned_and_not_spd(built):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < 1e-6
         w = np.linalg.eigvalsh(Pn[b])
         assert w.min() > -1e-9 * w.max()
+
+
+_KNOB_SNIPPET = r"""
+import sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/oracle"); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import xivo_oracle as orc
+from helpers import rel_fro
+from xivo_amd import synth
+from xivo_amd.lib import Context, FLAG_FP64_CORR, FLAG_PROFILE
+out = {{}}
+for (N, F) in [(250, 80), (203, 30), (37, 3)]:
+    P, H, inn, dR = synth.s_level(N, F, 3, seed=5)
+    for flags in (0, FLAG_FP64_CORR):
+        with Context(N, 2 * F, 3, flags=flags | FLAG_PROFILE) as ctx:
+            ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+            Pn = ctx.download_P(); err = ctx.get_err(); prof = ctx.profile_get()
+        worst_P = worst_dx = 0.0
+        for b in range(3):
+            e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+            worst_P = max(worst_P, rel_fro(Pn[b], P_ref)); worst_dx = max(worst_dx, rel_fro(err[b], e_ref))
+        out["%d,%d,%d" % (N, F, flags)] = dict(P=worst_P, dx=worst_dx, sym=bool(all(np.array_equal(Pn[b], Pn[b].T) for b in range(3))),
+                                               kernels={{k: v["kernel"] for k, v in prof.items() if v["launches"]}})
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("knob", ["XIVO_HIP_NO_JOSEPH_IN_SOLVE", "XIVO_HIP_NO_TRSM_T", "XIVO_HIP_NO_PNEW_REG"])
+def test_fallback_pipelines_behind_the_knobs(built, knob):
+    """The kernels the default path no longer launches at these sizes - T inside the solve kernel, the compressed-row G,
+    P+ with the rows of G in registers, the tiled T / P+ products - stay selectable (A/B knobs, read once per process:
+    hence the subprocess) and are what bigger shapes fall back to. Same tolerances against the oracle."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env[knob] = "1"
+    if knob == "XIVO_HIP_NO_PNEW_REG":
+        env["XIVO_HIP_NO_JOSEPH_IN_SOLVE"] = "1"
+    r = subprocess.run([sys.executable, "-c", _KNOB_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    for key, v in res.items():
+        assert v["P"] < 1e-10 and v["dx"] < 1e-10 and v["sym"], (key, v)
+        k = v["kernels"]
+        assert "gemm_Pnew" in k and "gemm_KH_I" in k, (key, k)           # the stand-alone tail ran
+        if knob == "XIVO_HIP_NO_TRSM_T":
+            assert "gemm_AP" in k and k["trsm_gain"].endswith(",0>")
+        else:
+            assert "gemm_AP" not in k and k["trsm_gain"].endswith(",1>")
+    # which P+ kernel: registers (all fp64, unless knocked out) or the tiled product
+    from xivo_amd.lib import FLAG_FP64_CORR
+    k64 = res["250,80,%d" % FLAG_FP64_CORR]["kernels"]["gemm_Pnew"]
+    k32 = res["250,80,0"]["kernels"]["gemm_Pnew"]
+    assert k32.startswith("gemm_nt_f64_kernel") and "float" in k32
+    assert k64.startswith("gemm_nt_f64_kernel" if knob == "XIVO_HIP_NO_PNEW_REG" else "pnew_reg_f64_kernel")
