@@ -398,7 +398,7 @@ def main():
         mixed = {"value": world * B * args.steps / dt_m, "ms_per_step": dt_m / args.steps * 1e3,
                  "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof_m.items() if v["launches"]},
                  # whether this run really took another code path than `value`: at sizes the in-solve covariance update
-                 # holds (N <= 256, M <= 160) the library is all fp64 in its default mode too
+                 # holds (N <= 256, M <= 176) the library is all fp64 in its default mode too
                  "same_kernels_as_value": {k: v["kernel"] for k, v in prof_m.items() if v["launches"]} ==
                                           {k: v["kernel"] for k, v in prof.items() if v["launches"]}}
         ctx.set_flags(flags)
@@ -517,7 +517,7 @@ def main():
                                     "Jacobians -> compressed rows on device every step",
                        "precision": {"value": "all fp64: storage, every product, factorisation, solve (XIVO_HIP_FLAG_FP64_CORR)",
                                      "value_mixed": "library default (no flag): the same all-fp64 kernels wherever the in-solve "
-                                                    "covariance update applies (N <= 256, M <= 160; see mixed.same_kernels_as_value); "
+                                                    "covariance update applies (N <= 256, M <= 176; see mixed.same_kernels_as_value); "
                                                     "elsewhere the Joseph correction product G K^T (G = O(eps cond(S)) residual) runs "
                                                     "on v_mfma_f32_16x16x4_f32 with G itself and -T in fp64"},
                        "gpu_event_ms_per_step": gpu_ms / args.steps,

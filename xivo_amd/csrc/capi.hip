@@ -782,10 +782,17 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label));
-    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label,
-                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
+    // re-associated pipeline: the whole covariance update inside the solve kernel, as in the sparse pipeline (it
+    // needs the factor, P H^T and P only - nothing of H's structure)
+    static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
+    const bool all_here = (c->flags & XIVO_HIP_FLAG_REASSOC) && !f32 && !full && !no_joseph && trsm_forms_T(Mp, Np);
+    if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = 1; a.skip_status = c->status + b0; }
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? 3 : 0);
+    const double t_outs = 0.5 * Np * (Np + 1.0);
+    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (all_here ? 2.0 * t_outs * Mp + 2.0 * Mp * Mp * Np : 0.0)) * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (all_here ? t_outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
+    if (all_here) return XIVO_HIP_OK;
   }
   if (c->flags & XIVO_HIP_FLAG_REASSOC) {
     {  // T = K (HP) - P

@@ -624,20 +624,23 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     while ((i + 1) * (i + 2) / 2 <= t) ++i;            // block row of slot t (nb <= 24: a few iterations)
     const int k = t - i * (i + 1) / 2;
     const int r = (w & 7) * 2, c = w >> 3;             // rows r, r+1 of column c
-    d2 v;
-    if (i == k) v = *reinterpret_cast<const d2*>(invD + (long)k * 512 + r + 16 * c);
-    else v = *reinterpret_cast<const d2*>(LU + (16 * i + r) + (long)(16 * k + c) * ld);
+    d2 v = *reinterpret_cast<const d2*>(LU + (16 * i + r) + (long)(16 * k + c) * ld);
+    if (i == k) {   // diagonal slot: inv(L_kk) in the lower triangle; TF == 3 keeps L_kk^T above it and the diagonal of L_kk
+                    // in the pad row: one slot serves the solve and the two triangular products
+      const d2 iv = *reinterpret_cast<const d2*>(invD + (long)k * 512 + r + 16 * c);
+      if (TF != 3) v = iv;
+      else {        // (the strictly lower part of L_kk read transposed: the factorisation need not have mirrored it)
+        v[0] = r >= c ? iv[0] : LU[(16 * k + c) + (long)(16 * k + r) * ld];
+        v[1] = r + 1 >= c ? iv[1] : LU[(16 * k + c) + (long)(16 * k + r + 1) * ld];
+      }
+    }
     sL[t * BLK + r + 17 * c] = v[0];
     sL[t * BLK + r + 1 + 17 * c] = v[1];
   }
-  double* sD = sL + nblk * BLK;                        // TF == 3: the diagonal blocks L_kk themselves (upper triangle zeroed)
   if (TF == 3) {
-    for (int e = tid; e < nb * 128; e += 1024) {
-      const int k = e >> 7, w = e & 127;
-      const int r = (w & 7) * 2, c = w >> 3;
-      const d2 v = *reinterpret_cast<const d2*>(LU + (16 * k + r) + (long)(16 * k + c) * ld);
-      sD[k * BLK + r + 17 * c] = r >= c ? v[0] : 0.0;
-      sD[k * BLK + r + 1 + 17 * c] = r + 1 >= c ? v[1] : 0.0;
+    for (int e = tid; e < nb * 16; e += 1024) {
+      const int k = e >> 4, c = e & 15;
+      sL[(k * (k + 1) / 2 + k) * BLK + 16 + 17 * c] = LU[(16 * k + c) + (long)(16 * k + c) * ld];
     }
   }
   const int c0 = chunk * 256 + wave * 16;
@@ -663,7 +666,11 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
       d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) t = mfma(Dk[li + 17 * (4 * s + lg)], X[k][s], t);
+      for (int s = 0; s < 4; ++s) {
+        double a = Dk[li + 17 * (4 * s + lg)];
+        if (TF == 3) a = li >= 4 * s + lg ? a : 0.0;      // (the slot's upper triangle belongs to L_kk^T)
+        t = mfma(a, X[k][s], t);
+      }
       X[k] = t;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -684,7 +691,11 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
       d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) t = mfma(Dk[(4 * s + lg) + 17 * li], X[k][s], t);
+      for (int s = 0; s < 4; ++s) {
+        double a = Dk[(4 * s + lg) + 17 * li];
+        if (TF == 3) a = 4 * s + lg >= li ? a : 0.0;
+        t = mfma(a, X[k][s], t);
+      }
       X[k] = t;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -722,10 +733,14 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
 #pragma unroll
     for (int j = 0; j < NBM; ++j) {
       if (j < nb) {
-        const double* Dj = sD + j * BLK;
+        const double* Dj = sL + (j * (j + 1) / 2 + j) * BLK;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) acc = mfma(Dj[(4 * s2 + lg) + 17 * li], X[j][s2], acc);                 // (L_jj)^T
+        for (int s2 = 0; s2 < 4; ++s2) {                                                                      // (L_jj)^T:
+          const int kk = 4 * s2 + lg;                                                                         // element (li, kk) = L_jj(kk, li)
+          const double a = Dj[kk > li ? li + 17 * kk : 16 + 17 * li];
+          acc = mfma(kk >= li ? a : 0.0, X[j][s2], acc);
+        }
 #pragma unroll
         for (int i = j + 1; i < NBM; ++i) {
           if (i < nb) {
@@ -740,10 +755,14 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
 #pragma unroll
     for (int i = NBM - 1; i >= 0; --i) {
       if (i < nb) {
-        const double* Di = sD + i * BLK;
+        const double* Di = sL + (i * (i + 1) / 2 + i) * BLK;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) acc = mfma(Di[li + 17 * (4 * s2 + lg)], X[i][s2], acc);                 // L_ii
+        for (int s2 = 0; s2 < 4; ++s2) {                                                                      // L_ii:
+          const int kk = 4 * s2 + lg;                                                                         // element (li, kk), stored transposed
+          const double a = Di[li > kk ? kk + 17 * li : 16 + 17 * li];
+          acc = mfma(li >= kk ? a : 0.0, X[i][s2], acc);
+        }
 #pragma unroll
         for (int k = 0; k < i; ++k) {
 #pragma unroll
@@ -1000,7 +1019,7 @@ int launch_trsm_lds_tf(const TrsmArgs& g_in, hipStream_t stream) {
 }
 template <int NBM>
 int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
-  if constexpr (NBM <= 10) {   // (11 block rows: the T phase spills at the 128-register budget of 16 waves)
+  {
     if (g.T && trsm_forms_T(g.Mp, g.Np))
       return g.fwd_only ? launch_trsm_lds_tf<NBM, 2>(g, stream) : (g.joseph ? launch_trsm_lds_tf<NBM, 3>(g, stream) : launch_trsm_lds_tf<NBM, 1>(g, stream));
   }
@@ -1081,7 +1100,7 @@ void pnew_reg_kernel_label(int Mp, char* buf, size_t n) { snprintf(buf, n, "pnew
 
 bool trsm_forms_T(int Mp, int Np) {
   static const bool off = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: T as a stand-alone product
-  return !off && Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
+  return !off && Mp / 16 <= 11 && Np <= 256 && Np % 16 == 0;   // the factor fits the LDS and one workgroup covers every column
 }
 
 int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
