@@ -601,6 +601,9 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* 
 template <int NBM, int TF>
 __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr int BLK = 16 * 17;
+  // TF == 3 needs the diagonal blocks L_kk next to their inverses: in slots of their own while the LDS has room (<= 10
+  // block rows), else packed into the unused upper triangle + pad row of the inverse's slot (a few selects per read)
+  constexpr bool PACK = TF == 3 && NBM > 10;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
   const int chunks = (g.Np + 255) / 256;
   const int b = blockIdx.x;
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     if (i == k) {   // diagonal slot: inv(L_kk) in the lower triangle; TF == 3 keeps L_kk^T above it and the diagonal of L_kk
                     // in the pad row: one slot serves the solve and the two triangular products
       const d2 iv = *reinterpret_cast<const d2*>(invD + (long)k * 512 + r + 16 * c);
-      if (TF != 3) v = iv;
+      if (!PACK) v = iv;
       else {        // (the strictly lower part of L_kk read transposed: the factorisation need not have mirrored it)
         v[0] = r >= c ? iv[0] : LU[(16 * k + c) + (long)(16 * k + r) * ld];
         v[1] = r + 1 >= c ? iv[1] : LU[(16 * k + c) + (long)(16 * k + r + 1) * ld];
@@ -637,10 +640,19 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     sL[t * BLK + r + 17 * c] = v[0];
     sL[t * BLK + r + 1 + 17 * c] = v[1];
   }
-  if (TF == 3) {
+  double* sD = sL + nblk * BLK;                        // TF == 3, !PACK: the diagonal blocks L_kk in slots of their own (upper triangle zeroed)
+  if (PACK) {
     for (int e = tid; e < nb * 16; e += 1024) {
       const int k = e >> 4, c = e & 15;
       sL[(k * (k + 1) / 2 + k) * BLK + 16 + 17 * c] = LU[(16 * k + c) + (long)(16 * k + c) * ld];
+    }
+  } else if (TF == 3) {
+    for (int e = tid; e < nb * 128; e += 1024) {
+      const int k = e >> 7, w = e & 127;
+      const int r = (w & 7) * 2, c = w >> 3;
+      const d2 v = *reinterpret_cast<const d2*>(LU + (16 * k + r) + (long)(16 * k + c) * ld);
+      sD[k * BLK + r + 17 * c] = r >= c ? v[0] : 0.0;
+      sD[k * BLK + r + 1 + 17 * c] = r + 1 >= c ? v[1] : 0.0;
     }
   }
   const int c0 = chunk * 256 + wave * 16;
@@ -668,7 +680,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         double a = Dk[li + 17 * (4 * s + lg)];
-        if (TF == 3) a = li >= 4 * s + lg ? a : 0.0;      // (the slot's upper triangle belongs to L_kk^T)
+        if (PACK) a = li >= 4 * s + lg ? a : 0.0;         // (the slot's upper triangle belongs to L_kk^T)
         t = mfma(a, X[k][s], t);
       }
       X[k] = t;
@@ -693,7 +705,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         double a = Dk[(4 * s + lg) + 17 * li];
-        if (TF == 3) a = 4 * s + lg >= li ? a : 0.0;
+        if (PACK) a = 4 * s + lg >= li ? a : 0.0;
         t = mfma(a, X[k][s], t);
       }
       X[k] = t;
@@ -733,13 +745,17 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
 #pragma unroll
     for (int j = 0; j < NBM; ++j) {
       if (j < nb) {
-        const double* Dj = sL + (j * (j + 1) / 2 + j) * BLK;
+        const double* Dj = PACK ? sL + (j * (j + 1) / 2 + j) * BLK : sD + j * BLK;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {                                                                      // (L_jj)^T:
           const int kk = 4 * s2 + lg;                                                                         // element (li, kk) = L_jj(kk, li)
-          const double a = Dj[kk > li ? li + 17 * kk : 16 + 17 * li];
-          acc = mfma(kk >= li ? a : 0.0, X[j][s2], acc);
+          if (PACK) {
+            const double a = Dj[kk > li ? li + 17 * kk : 16 + 17 * li];
+            acc = mfma(kk >= li ? a : 0.0, X[j][s2], acc);
+          } else {
+            acc = mfma(Dj[kk + 17 * li], X[j][s2], acc);
+          }
         }
 #pragma unroll
         for (int i = j + 1; i < NBM; ++i) {
@@ -755,13 +771,17 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
 #pragma unroll
     for (int i = NBM - 1; i >= 0; --i) {
       if (i < nb) {
-        const double* Di = sL + (i * (i + 1) / 2 + i) * BLK;
+        const double* Di = PACK ? sL + (i * (i + 1) / 2 + i) * BLK : sD + i * BLK;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {                                                                      // L_ii:
-          const int kk = 4 * s2 + lg;                                                                         // element (li, kk), stored transposed
-          const double a = Di[li > kk ? kk + 17 * li : 16 + 17 * li];
-          acc = mfma(li >= kk ? a : 0.0, X[i][s2], acc);
+          const int kk = 4 * s2 + lg;                                                                         // element (li, kk), stored transposed when packed
+          if (PACK) {
+            const double a = Di[li > kk ? kk + 17 * li : 16 + 17 * li];
+            acc = mfma(li >= kk ? a : 0.0, X[i][s2], acc);
+          } else {
+            acc = mfma(Di[li + 17 * kk], X[i][s2], acc);
+          }
         }
 #pragma unroll
         for (int k = 0; k < i; ++k) {
