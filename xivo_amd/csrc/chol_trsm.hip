@@ -222,6 +222,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 // with one barrier between A and C and one after C.
 // MINB = workgroups per CU the register budget is cut for: 3 (168 VGPRs, a few spills) is faster for thousands of
 // factors (0.67 vs 0.75 ms / 4096 at M = 160), 2 (212 VGPRs) for a single one (76 vs 82 us)
+// Barrier for exchanges that go through LDS only: __syncthreads() also drains the vector-memory counter, i.e. waits
+// until every global store issued so far is acknowledged - microseconds per barrier that nothing here depends on.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NB, int MINB>
 __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror) {
   constexpr int RW = (NB + 3) / 4;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
 #pragma unroll
       for (int k = 0; k < j; ++k) *reinterpret_cast<d4*>(&sRow[(k * 64 + lane) * 4]) = L[jj][k];
     }
-    __syncthreads();
+    lds_barrier();
     if (wave == owner)
       for (int e = lane; e < 512; e += 64) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
 #pragma unroll
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
         }
       }
     }
-    __syncthreads();   // sInv / sRow are rewritten by the next owner
+    lds_barrier();     // sInv / sRow are rewritten by the next owner
     }
   });
   if (tid == 0) g.status[filt] = sBad;

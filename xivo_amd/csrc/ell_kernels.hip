@@ -416,7 +416,9 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
         else out[(long)m * a.ldo] = fma(K[(long)m * a.ldk], dR[m], acc);
       }
     }
-    __syncthreads();   // the slab is overwritten by the next step
+    // the slab is overwritten by the next step. LDS-only barrier: __syncthreads() would also wait for the output stores
+    // just issued and for the next slab's prefetch loads to land
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
 
