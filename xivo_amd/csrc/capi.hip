@@ -638,7 +638,8 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   if (gate) {
     GateEllArgs a{}; a.ell = e;
     a.H = c->dense_valid ? c->H + (long)b0 * c->sH : nullptr; a.strideH = c->sH; a.ldh = ldh;
-    a.HT = c->dense_valid ? c->HT + (long)b0 * c->sHT : nullptr; a.strideHT = c->sHT; a.ldht = Np; a.HP = HP; a.PHT = PHT;
+    a.HT = c->dense_valid ? c->HT + (long)b0 * c->sHT : nullptr; a.strideHT = c->sHT; a.ldht = Np; a.PHT = PHT;
+    a.HP = nullptr;   // H P [Mp x Np] has no reader behind this point (S is formed already, the solve reads P H^T)
     a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
     a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
     a.F = gate->F; a.Np = Np; a.batch = B;

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
   }
   double* H = a.H ? a.H + (long)filt * a.strideH : nullptr;       // dense copies, when they are materialised
   double* HT = a.HT ? a.HT + (long)filt * a.strideHT : nullptr;
-  double* HP = a.HP + (long)filt * a.strideH;
+  double* HP = a.HP ? a.HP + (long)filt * a.strideH : nullptr;
   for (int f = 0; f < a.F; ++f) {
     if (sdist[f] < th) continue;
     for (int n = tid; n < a.Np; n += nt) {
@@ -488,8 +488,10 @@ __global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
       }
       PHT[n + (long)(2 * f) * a.ldht] = 0.0;
       PHT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
-      HP[2 * f + (long)n * a.ldh] = 0.0;          // read by the gather form of ELL_S only
-      HP[2 * f + 1 + (long)n * a.ldh] = 0.0;
+      if (HP) {                                   // (strided: 2 Np scattered 8-byte stores per rejected feature)
+        HP[2 * f + (long)n * a.ldh] = 0.0;
+        HP[2 * f + 1 + (long)n * a.ldh] = 0.0;
+      }
     }
     if (Sm) {
       for (int jx = tid; jx < a.Mp; jx += nt) {
