@@ -528,7 +528,7 @@ int launch_meas_compress(const double* H, long strideH, int ldh, const double* i
   a.inn_out = inn_out; a.strideInnOut = strideInnOut; a.R_out = R_out; a.strideROut = strideROut;
   const int nt = ((a.pairs_clear + 63) / 64) * 64;
   if (nt > 256) return (int)hipErrorInvalidValue;
-  a.list_ld = (nt + 3) & ~3;
+  a.list_ld = (a.pairs_clear + 3) & ~3;   // only threads that own a pair ever touch the lists: 45 instead of 72 KB at 80 pairs, 3 workgroups per CU
   const size_t lds = (size_t)ELL_W * a.list_ld * (sizeof(d2) + sizeof(int)) + (size_t)(nt / 64 + 1) * Np * sizeof(int);
   // 16-byte loads need an even leading dimension / stride and an aligned base
   const bool aligned = (ldh % 2 == 0) && (strideH % 2 == 0) && ((reinterpret_cast<uintptr_t>(H) & 15u) == 0) && (M % 2 == 0);
