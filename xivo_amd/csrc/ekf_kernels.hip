@@ -1696,8 +1696,7 @@ __global__ __launch_bounds__(64) void propagate_state_wave_kernel(PropStateArgs 
   double* P0 = sm;
   double* S1 = P0 + NN;        // 23 x 23 scratch whose rows >= 9 stay zero: sum a_q FK_q, later I + FK h
   double* FPs = S1 + NN;       // [9 x 23]  F P0   ([i + 9 j])
-  double* PFs = FPs + NF;      // [23 x 9]  P0 F^T ([i + 23 j])
-  double* GQG = PFs + NF;      // [12 x 12] support of G Q G^T
+  double* GQG = FPs + NF;      // [12 x 12] support of G Q G^T
   double* Q = GQG + 144;
   double* GQc = Q + 144;       // [12 x 12] the non-zero rows of G Q
   double* zero = GQc + 144;    // one 0.0 + pad
@@ -1711,13 +1710,13 @@ __global__ __launch_bounds__(64) void propagate_state_wave_kernel(PropStateArgs 
   // Lanes past the end of a matrix repeat its last element (clamped index): no predicates in the loops, the copies
   // hold identical values and only the owner stores at the end.
   double Pmm[EL], PK[NS][EL];
-  int off[EL];                 // LDS offsets of the three terms of PK(e), 11 bits each... packed as 8-bit offsets into FPs / PFs / GQG (255: absent)
+  int off[EL];                 // the three terms of PK(e) as packed 8-bit offsets into FPs / FPs (transposed entry) / GQG (255: absent)
 #pragma unroll
   for (int m = 0; m < EL; ++m) {
     const int e = min(lane + 64 * m, NN - 1), i = e % NM, j = e / NM;
     const int ci = i < 3 ? i : ((i >= 6 && i < 15) ? i - 3 : -1), cj = j < 3 ? j : ((j >= 6 && j < 15) ? j - 3 : -1);
     Pmm[m] = Pg[i + (long)j * a.ldp];
-    off[m] = (i < FR ? i + FR * j : 255) | ((j < FR ? i + NM * j : 255) << 8) | (((ci >= 0 && cj >= 0) ? ci + 12 * cj : 255) << 16);
+    off[m] = (i < FR ? i + FR * j : 255) | ((j < FR ? j + FR * i : 255) << 8) | (((ci >= 0 && cj >= 0) ? ci + 12 * cj : 255) << 16);   // F P0, (F P0)^T, G Q G^T
     S1[e] = 0.0;
 #pragma unroll
     for (int q = 0; q < NS; ++q) PK[q][m] = 0.0;
@@ -1927,28 +1926,9 @@ __global__ __launch_bounds__(64) void propagate_state_wave_kernel(PropStateArgs 
             }
           }
         }
-        if (lane < NM) {                                            // (P0 F^T)[i, 0..8] = sum_k P0[i, k] F[j, k]
-          const int i = lane;
-          const double p0 = P0[i], p1 = P0[i + NM], p2 = P0[i + NM * 2];
-          const double p12 = P0[i + NM * 12], p13 = P0[i + NM * 13], p14 = P0[i + NM * 14];
-          const double p21 = P0[i + NM * 21], p22 = P0[i + NM * 22];
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            double v = fma(p0, dW_dW.m[j][0], 0.0);
-            v = fma(p1, dW_dW.m[j][1], v);
-            v = fma(p2, dW_dW.m[j][2], v);
-            PFs[i + NM * j] = fma(P0[i + NM * (9 + j)], -1.0, v);
-            PFs[i + NM * (3 + j)] = fma(P0[i + NM * (6 + j)], 1.0, 0.0);
-            double w = fma(p0, dV_dW.m[j][0], 0.0);
-            w = fma(p1, dV_dW.m[j][1], w);
-            w = fma(p2, dV_dW.m[j][2], w);
-            w = fma(p12, nR.m[j][0], w);
-            w = fma(p13, nR.m[j][1], w);
-            w = fma(p14, nR.m[j][2], w);
-            w = fma(p21, dV_dWsg.m[j][0], w);
-            PFs[i + NM * (6 + j)] = fma(p22, dV_dWsg.m[j][1], w);
-          }
-        } else if (lane >= 32 && lane < 44) {                       // (G Q G^T)[r, :] on the 12 x 12 support
+        // (P0 F^T is not formed: P0 is symmetric - P_mm and every stage derivative are, bit for bit but for the
+        //  rounding-level asymmetry of G Q G^T - so (P0 F^T)[i][j] = (F P0)[j][i], the same products summed in the same order)
+        if (lane >= 32 && lane < 44) {                              // (G Q G^T)[r, :] on the 12 x 12 support
           const int r = lane - 32;
           const double g3 = GQc[r + 12 * 3], g4 = GQc[r + 12 * 4], g5 = GQc[r + 12 * 5];
 #pragma unroll
@@ -1967,7 +1947,7 @@ __global__ __launch_bounds__(64) void propagate_state_wave_kernel(PropStateArgs 
 #pragma unroll
         for (int m = 0; m < EL; ++m) {
           const int o1 = off[m] & 255, o2 = (off[m] >> 8) & 255, o3 = (off[m] >> 16) & 255;
-          const double t1 = o1 == 255 ? 0.0 : FPs[o1], t2 = o2 == 255 ? 0.0 : PFs[o2], t3 = o3 == 255 ? 0.0 : GQG[o3];
+          const double t1 = o1 == 255 ? 0.0 : FPs[o1], t2 = o2 == 255 ? 0.0 : FPs[o2], t3 = o3 == 255 ? 0.0 : GQG[o3];
           PK[st][m] = (t1 + t2) + t3;
         }
         // (phase A of the next stage writes P0 / S1 / F9 / GQc, which phase B above has finished reading; FPs / PFs / GQG are
@@ -2464,7 +2444,7 @@ template <int NS>
 static int launch_propagate_state_wave(const PropStateArgs& a, hipStream_t s) {
   // LDS: P0, S1, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, nominal state, F9, two transition buffers, per stage 36
   // Jacobian entries + FK: RK4 28 KB (5 filters per CU), Dormand-Prince 34 KB (4)
-  const size_t lds = (size_t)(2 * 529 + 4 * 207 + 3 * 144 + 2 + 36 + NS * (36 + 207)) * sizeof(double);
+  const size_t lds = (size_t)(2 * 529 + 3 * 207 + 3 * 144 + 2 + 36 + NS * (36 + 207)) * sizeof(double);
   hipLaunchKernelGGL(propagate_state_wave_kernel<NS>, dim3(a.batch), dim3(64), lds, s, a);
   CHECK_LAUNCH();
 }
