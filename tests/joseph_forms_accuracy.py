@@ -6,7 +6,7 @@ expression (estimator.cpp:1257-1288 in numpy longdouble, 64-bit mantissa), as co
   reassoc    XIVO_HIP_NO_JOSEPH_IN_SOLVE=1: T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T from stand-alone kernels
   symmetric  XIVO_HIP_FLAG_SYMMETRIC_FORM: P - W^T W
   as_coded_device  XIVO_HIP_FLAG_DENSE_H: the as-coded product sequence (A = KH - I, A P A^T + K R K^T) on the device
-Prints one JSON object; run on a GPU box:  python scripts/joseph_forms_accuracy.py"""
+Prints one JSON object; run on a GPU box:  python tests/joseph_forms_accuracy.py"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
