@@ -46,7 +46,8 @@ int launch_ell_to_dense(EllBuffers e, double* H, long strideH, int ldh, double* 
 // out[x + ldo * m] = sum_slots val[m][slot] * Src[x + lds * idx[m][slot]]  (+ epilogue), x in [0, X)
 enum EllMode : int {
   ELL_HP = 0,   // Src = P (symmetric): out = P H^T [Np x Mp], out2 = H P [Mp x Np]      (estimator.cpp:1259)
-  ELL_S = 1,    // Src = P H^T [Np x Mp] (tile form) or HP [Mp x Np] (gather form): out = S = (HP) H^T + diag(R)
+  ELL_S = 1,    // Src = P H^T [Np x Mp] (tile form) or HP [Mp x Np] (gather form): out = S = (HP) H^T + diag(R); the tile form
+                // writes the lower triangle + the 64 x 64 diagonal squares only (nothing reads the rest of the symmetric S)
                 //                                                                 (estimator.cpp:1259-1263)
   ELL_G = 2,    // Src = T  [Np x Np] : out = T H^T + K diag(R)  [Np x Mp]               (re-associated :1280-1287)
   ELL_GF = 3,   // ELL_G with the result stored as float (slab form only; strideOut / ldo in float elements)

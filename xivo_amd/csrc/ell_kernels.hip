@@ -392,8 +392,11 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
     double cm[CWU];
 #pragma unroll
     for (int t = 0; t < CWU; ++t) cm[t] = slab(idx0[t]);
+    // S is symmetric and every reader (gating, both Cholesky kernels) takes its lower triangle + the diagonal blocks: lane
+    // = row x of S, pair p = columns 2p, 2p + 1 - the pairs to the right of this slab's 64 x 64 diagonal square are skipped
+    const int p_end = MODE == ELL_S ? min(pairs, (sidx * XC + XC) / 2) : pairs;
 #pragma unroll UNR
-    for (int p = wave; p < pairs; p += NW) {
+    for (int p = wave; p < p_end; p += NW) {
       ell_cint* pi = idx0 + (long)p * ELL_W + ELL_CW;
       const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT;
       double sv[PWU];
