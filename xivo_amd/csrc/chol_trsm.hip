@@ -18,6 +18,16 @@
 //   (row = (lane>>4) + 4*reg, col = lane&15) is exactly the B-operand layout of
 //   the four k-slices of the next MFMA, so forward and backward substitution
 //   chain with no data movement at all; dx = K*inn falls out as a lane reduce.
+// chol_reg_f64_kernel : four waves per filter, the factor in registers (M <= 192).
+// trsm_lds_f64_kernel<NBM, TF> : one workgroup of 16 waves per filter, the whole factor in LDS; beyond the solve it
+//   carries, on the gain still in its registers (which is also the A-operand layout),
+//     TF = 1  T = K (HP) - P                                   (estimator.cpp:1276-1280, re-associated pipeline)
+//     TF = 2  P+ = P - W^T W after the forward substitution    (symmetric form)
+//     TF = 3  the whole Joseph update in its expanded form     (estimator.cpp:1276-1287; the default up to M = 176)
+//   through sym_tiles_from_regs: symmetric N x N x M products with one operand in registers and the other arriving
+//   in LDS by global_load_lds (or from the owner waves' registers), every unordered pair of 16-row blocks once.
+// pnew_reg_f64_kernel : P+ = G K^T - T by the same walk with the rows of G loaded into the registers.
+// trsm_stream_f64_kernel : factors beyond the LDS (M > 176), panel by panel.
 #include <stdlib.h>
 
 #include "common.h"
