@@ -71,25 +71,34 @@ enum {
   /* By default the update exploits the row sparsity of H: when every row pair of every filter of the
    * call has at most 16 columns shared by most pairs + 12 private non-zero columns (true for the stacked
    * in-state Jacobians of src/update.cpp:129-138: 21 per pair), H P, S and the H-products of the
-   * covariance stage skip the structural zeros (exact: the skipped terms are 0 * x) and the covariance
-   * stage uses the re-associated Joseph expression above. A denser H (OOS rows, arbitrary input) takes the
-   * as-coded dense path automatically. This flag forces the dense as-coded path for any H. */
+   * covariance stage skip the structural zeros (exact: the skipped terms are 0 * x). The covariance stage
+   * evaluates the Joseph expression in its expanded form inside the solve kernel (N <= 256, M <= 176; see
+   * XIVO_HIP_FLAG_STANDALONE_TAIL) or in the re-associated form above. A denser H (OOS rows, arbitrary input)
+   * takes the as-coded dense path automatically. This flag forces the dense as-coded path for any H. */
   XIVO_HIP_FLAG_DENSE_H = 64u,
-  /* In the sparse-H pipeline P+ = -T + G K^T with -T = P - K(HP) (fp64) and the Joseph correction
+  /* Re-associated form of the sparse-H pipeline (stand-alone kernels: shapes beyond N = 256 / M = 176, or
+   * XIVO_HIP_FLAG_STANDALONE_TAIL): P+ = -T + G K^T with -T = P - K(HP) (fp64) and the Joseph correction
    * G K^T, G = T H^T + K R, which is O(eps * cond(S)) relative to P because K is the gain of this very S.
    * By default that correction PRODUCT runs on the fp32 MFMA (G itself - a cancellation - and -T stay
    * fp64): its rounding adds <= 1e-7 |G K^T| to P+, orders of magnitude below the fp64 rounding of -T.
-   * This flag keeps the correction product in fp64 as well. */
+   * This flag keeps the correction product in fp64 as well. (The in-solve update is all fp64 either way.) */
   XIVO_HIP_FLAG_FP64_CORR = 128u,
   /* Symmetric ("square-root") form of the gain and covariance: S = L L^T, W = L^-1 (H P) by forward substitution only,
    *   dx = W^T (L^-1 inn),   P+ = P - W^T W
    * - what the Joseph expression of src/estimator.cpp:1276-1287 evaluates to for the optimal gain K = P H^T S^-1 (its
    * correction term (K S - P H^T) K^T vanishes identically), without the backward substitution, the gain residual and
-   * the second N x N x M product: about 55 % of the device time of the default. The result is symmetric by
+   * the second N x N x M product: about 80 % of the device time of the default. The result is symmetric by
    * construction and its rounding error scales with cond(L) = sqrt(cond(S)). Opt-in: the reference codes the Joseph
    * form and the default reproduces that expression; parity of this mode against the reference is tested to the same
    * tolerances (1e-6 on P, 1e-8 on dx), including an ill-conditioned S. */
-  XIVO_HIP_FLAG_SYMMETRIC_FORM = 256u
+  XIVO_HIP_FLAG_SYMMETRIC_FORM = 256u,
+  /* Sparse-H and re-associated dense pipelines, N <= 256 and M <= 176: by default the solve kernel carries the whole
+   * covariance update on the gain still in its registers - the Joseph expression expanded for the computed gain,
+   *   P+ = P - K Z,  Z = 2 H P - L L^T K^T   (= P - K(HP) - (K(HP))^T + K S K^T with one triangle of K(HP) kept),
+   * T and G never reaching memory. This flag selects the round-1 tail instead: T = K(HP) - P, G = T H^T + K R,
+   * P+ = G K^T - T from stand-alone kernels - 0.8 x the speed, 5 x closer to the as-coded fp64 result (both lose
+   * digits in proportion to cond(S) and meet the 1e-6 / 1e-8 tolerances by orders of magnitude: DESIGN.md 1a). */
+  XIVO_HIP_FLAG_STANDALONE_TAIL = 512u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,

@@ -3,7 +3,7 @@
 expression (estimator.cpp:1257-1288 in numpy longdouble, 64-bit mantissa), as cond(S) grows:
   oracle     the as-coded fp64 sequence on the CPU (oracle/xivo_oracle.py)
   in_solve   library default: expanded form on the gain in registers (trsm_lds_f64_kernel<.,3>)
-  reassoc    XIVO_HIP_NO_JOSEPH_IN_SOLVE=1: T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T from stand-alone kernels
+  reassoc    XIVO_HIP_FLAG_STANDALONE_TAIL: T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T from stand-alone kernels
   symmetric  XIVO_HIP_FLAG_SYMMETRIC_FORM: P - W^T W
   as_coded_device  XIVO_HIP_FLAG_DENSE_H: the as-coded product sequence (A = KH - I, A P A^T + K R K^T) on the device
 Prints one JSON object; run on a GPU box:  python tests/joseph_forms_accuracy.py"""
@@ -77,7 +77,8 @@ if __name__ == "__main__":
         return json.loads(r.stdout.strip().splitlines()[-1])
 
     from xivo_amd.lib import FLAG_DENSE_H
-    runs = {"in_solve": child(0, {}), "reassoc": child(0, {"XIVO_HIP_NO_JOSEPH_IN_SOLVE": "1"}),
+    from xivo_amd.lib import FLAG_STANDALONE_TAIL
+    runs = {"in_solve": child(0, {}), "reassoc": child(FLAG_STANDALONE_TAIL, {}),
             "symmetric": child(FLAG_SYMMETRIC_FORM, {}), "as_coded_device": child(FLAG_DENSE_H, {})}
     rel = lambda a, b: float(np.linalg.norm((a - b).astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
     table = []

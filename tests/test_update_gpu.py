@@ -485,3 +485,27 @@ def test_fallback_pipelines_behind_the_knobs(built, knob):
     k32 = res["250,80,0"]["kernels"]["gemm_Pnew"]
     assert k32.startswith("gemm_nt_f64_kernel") and "float" in k32
     assert k64.startswith("gemm_nt_f64_kernel" if knob == "XIVO_HIP_NO_PNEW_REG" else "pnew_reg_f64_kernel")
+
+
+@pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (203, 30), (37, 3)])
+def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
+    """XIVO_HIP_FLAG_STANDALONE_TAIL: the covariance update from stand-alone kernels (re-associated expression) instead of
+    inside the solve kernel (expanded expression). Two rounding-level re-orderings of the same update: they agree with each
+    other and with the oracle far inside the tolerances, dx is identical (the gain is the same solve)."""
+    from xivo_amd.lib import FLAG_STANDALONE_TAIL, FLAG_PROFILE
+    B = 3
+    P, H, inn, dR = synth.s_level(N, F, B, seed=17)
+    outs, errs, kern = [], [], []
+    for flags in (0, FLAG_STANDALONE_TAIL):
+        with Context(N, 2 * F, B, flags=flags | FLAG_PROFILE) as ctx:
+            ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+            assert ctx.last_path() == 1
+            outs.append(ctx.download_P()); errs.append(ctx.get_err())
+            kern.append({k: v["kernel"] for k, v in ctx.profile_get().items() if v["launches"]})
+    assert kern[0]["trsm_gain"].endswith(",3>") and "gemm_Pnew" not in kern[0]
+    assert kern[1]["trsm_gain"].endswith(",1>") and "gemm_Pnew" in kern[1] and "gemm_KH_I" in kern[1]
+    assert np.array_equal(errs[0], errs[1])
+    assert rel_fro(outs[0], outs[1]) < 1e-11
+    for b in range(B):
+        _, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(outs[0][b], P_ref) < 1e-10 and rel_fro(outs[1][b], P_ref) < 1e-10

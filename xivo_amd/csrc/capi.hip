@@ -668,7 +668,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     // form; T and G never exist in memory) - or, with XIVO_HIP_NO_JOSEPH_IN_SOLVE, to T = K (HP) - P only
     const bool t_here = !t_full && trsm_forms_T(Mp, Np);
     static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;   // A/B knob
-    const bool all_here = t_here && !no_joseph;   // (both precision modes: it is all fp64 and faster than the fp32 correction product)
+    const bool all_here = t_here && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);   // (both precision modes: all fp64 and faster than the fp32 correction product)
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = 1; a.skip_status = c->status + b0; }
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
@@ -786,7 +786,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     // re-associated pipeline: the whole covariance update inside the solve kernel, as in the sparse pipeline (it
     // needs the factor, P H^T and P only - nothing of H's structure)
     static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
-    const bool all_here = (c->flags & XIVO_HIP_FLAG_REASSOC) && !f32 && !full && !no_joseph && trsm_forms_T(Mp, Np);
+    const bool all_here = (c->flags & XIVO_HIP_FLAG_REASSOC) && !f32 && !full && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL) && trsm_forms_T(Mp, Np);
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = 1; a.skip_status = c->status + b0; }
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? 3 : 0);
     const double t_outs = 0.5 * Np * (Np + 1.0);
