@@ -98,7 +98,12 @@ enum {
    * T and G never reaching memory. This flag selects the round-1 tail instead: T = K(HP) - P, G = T H^T + K R,
    * P+ = G K^T - T from stand-alone kernels - 0.8 x the speed, 5 x closer to the as-coded fp64 result (both lose
    * digits in proportion to cond(S) and meet the 1e-6 / 1e-8 tolerances by orders of magnitude: DESIGN.md 1a). */
-  XIVO_HIP_FLAG_STANDALONE_TAIL = 512u
+  XIVO_HIP_FLAG_STANDALONE_TAIL = 512u,
+  /* In-solve covariance update (N <= 256, M <= 176): the round-2 evaluation P+ = P - K (2 H P - L L^T K^T) - two
+   * triangular products on the gain to rebuild S K^T - instead of the default whitened evaluation of the same Joseph
+   * expression, P+ = P - (W - D)^T (W + D) with W = L^-1 H P and D = W - L^T K^T taken from the backward substitution's
+   * own partial sums. Same tolerances; 1.3 x the MFMA work. A/B knob. */
+  XIVO_HIP_FLAG_EXPANDED_JOSEPH = 1024u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,

@@ -339,7 +339,7 @@ def test_profile_reports_kernels_bytes_and_path(built):
         if path == 1:
             assert prof["gemm_AP"]["launches"] == 0 and prof["gemm_KH_I"]["launches"] == 0 and prof["gemm_Pnew"]["launches"] == 0
         assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<10")   # B = 16: the latency kernel
-        assert prof["trsm_gain"]["kernel"] == ("trsm_lds_f64_kernel<10,3>" if path == 1 else "trsm_lds_f64_kernel<10,0>")
+        assert prof["trsm_gain"]["kernel"] == ("trsm_lds_f64_kernel<10,4>" if path == 1 else "trsm_lds_f64_kernel<10,0>")
 
 
 @pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])
@@ -490,7 +490,7 @@ def test_fallback_pipelines_behind_the_knobs(built, knob):
 @pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (203, 30), (37, 3)])
 def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
     """XIVO_HIP_FLAG_STANDALONE_TAIL: the covariance update from stand-alone kernels (re-associated expression) instead of
-    inside the solve kernel (expanded expression). Two rounding-level re-orderings of the same update: they agree with each
+    inside the solve kernel (whitened expression). Two rounding-level re-orderings of the same update: they agree with each
     other and with the oracle far inside the tolerances, dx is identical (the gain is the same solve)."""
     from xivo_amd.lib import FLAG_STANDALONE_TAIL, FLAG_PROFILE
     B = 3
@@ -502,10 +502,64 @@ def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
             assert ctx.last_path() == 1
             outs.append(ctx.download_P()); errs.append(ctx.get_err())
             kern.append({k: v["kernel"] for k, v in ctx.profile_get().items() if v["launches"]})
-    assert kern[0]["trsm_gain"].endswith(",3>") and "gemm_Pnew" not in kern[0]
+    assert kern[0]["trsm_gain"].endswith(",4>") and "gemm_Pnew" not in kern[0]
     assert kern[1]["trsm_gain"].endswith(",1>") and "gemm_Pnew" in kern[1] and "gemm_KH_I" in kern[1]
-    assert np.array_equal(errs[0], errs[1])
+    assert rel_fro(errs[0], errs[1]) < 1e-13      # same solve; the in-solve variant sums dx = K inn block by block as the gain appears
     assert rel_fro(outs[0], outs[1]) < 1e-11
     for b in range(B):
         _, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
         assert rel_fro(outs[0][b], P_ref) < 1e-10 and rel_fro(outs[1][b], P_ref) < 1e-10
+
+
+# ---------------------------------------------------------------- the two in-solve evaluations of the Joseph expression
+@pytest.mark.parametrize("N,F", [(250, 80), (250, 88), (150, 50), (203, 30), (37, 3), (64, 8), (100, 1), (256, 72)])
+def test_whitened_and_expanded_in_solve_forms_agree(built, N, F):
+    """Default: P+ = P - (W - D)^T (W + D) (W = L^-1 H P from the stash, D = the backward substitution's own residual);
+    XIVO_HIP_FLAG_EXPANDED_JOSEPH: P+ = P - K (2 H P - L L^T K^T), the round-2 evaluation. Both are the Joseph expression of
+    src/estimator.cpp:1276-1287 for the computed gain with S = L L^T; they agree with each other and with the oracle far
+    inside the tolerances. (250, 88): M = 176, eleven block rows - the packed-diagonal instantiation."""
+    from xivo_amd.lib import FLAG_EXPANDED_JOSEPH, FLAG_PROFILE
+    B = 9                                    # more than one XCD group of 8
+    P, H, inn, dR = synth.s_level(N, F, B, seed=23)
+    outs, errs, kern = [], [], []
+    for flags in (0, FLAG_EXPANDED_JOSEPH):
+        with Context(N, 2 * F, B, flags=flags | FLAG_PROFILE) as ctx:
+            ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+            assert ctx.last_path() == 1 and (ctx.get_status() == 0).all()
+            outs.append(ctx.download_P()); errs.append(ctx.get_err())
+            kern.append(ctx.profile_get()["trsm_gain"]["kernel"])
+    assert kern[0].endswith(",4>") and kern[1].endswith(",3>")
+    assert rel_fro(errs[0], errs[1]) < 1e-13
+    assert rel_fro(outs[0], outs[1]) < 1e-11
+    for b in range(B):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        for o, e in zip(outs, errs):
+            assert rel_fro(o[b], P_ref) < 1e-10 and rel_fro(e[b], e_ref) < TOL_DX
+            assert np.array_equal(o[b], o[b].T)
+
+
+def test_whitened_form_ill_conditioned_and_not_spd(built):
+    """cond(S) ~ 1e7 plus one filter whose S is indefinite: tolerances as for every other evaluation, the indefinite filter
+    keeps its prior bit for bit, the smallest eigenvalue of P+ stays at rounding level."""
+    N, F, B = 150, 40, 4
+    rng = np.random.default_rng(31)
+    _, H, inn, _ = synth.s_level(N, F, B, seed=6)
+    H *= 0.05
+    P = np.empty((B, N, N))
+    for b in range(B):
+        Q, _ = np.linalg.qr(rng.normal(size=(N, N)))
+        P[b] = (Q * np.logspace(-8, 0, N)) @ Q.T
+        P[b] = 0.5 * (P[b] + P[b].T)
+    dR = np.full((B, 2 * F), 1e-6)
+    dR[2, :] = -1e3
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        st = ctx.get_status(check=False)
+        err = ctx.get_err(); Pn = ctx.download_P()
+    assert st[2] != 0 and (st[[0, 1, 3]] == 0).all()
+    assert np.array_equal(Pn[2], P[2])
+    for b in (0, 1, 3):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < 1e-6
+        w = np.linalg.eigvalsh(Pn[b])
+        assert w.min() > -1e-9 * w.max()

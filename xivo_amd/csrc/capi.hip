@@ -49,6 +49,7 @@ struct xivo_hip_ctx {
   // dense H / H^T of the stacked rows: written eagerly by set_measurements, lazily after xivo_hip_stack
   bool dense_valid = true;
   bool dense_from_ell = false;   // the stacked rows came in through set_measurements (compressed rows are the source)
+  bool ht_valid = true;          // the transposed dense copy H^T matches H (false after a producer skipped it: skip_HT)
   double stack_R = 0.0; int stack_B = 0;
   size_t staging_elems = 0;
   long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0, sA = 0;   // sA: A buffer, max(N x N, N x M)
@@ -281,6 +282,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
 
 static int ensure_gate_buffers(xivo_hip_ctx* c, int F);
 static int ensure_dense(xivo_hip_ctx* c);
+static int ensure_HT(xivo_hip_ctx* c);
 
 extern "C" {
 
@@ -669,12 +671,16 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     const bool t_here = !t_full && trsm_forms_T(Mp, Np);
     static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;   // A/B knob
     const bool all_here = t_here && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);   // (both precision modes: all fp64 and faster than the fp32 correction product)
-    if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = 1; a.skip_status = c->status + b0; }
+    const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;   // 2: whitened form (default), 1: P - K(2HP - L L^T K^T)
+    if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? 3 : (t_here ? 1 : 0));
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : 0));
     const double t_outs = 0.5 * Np * (Np + 1.0);
-    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (t_here ? 2.0 * t_outs * Mp : 0.0) + (all_here ? 2.0 * Mp * Mp * Np : 0.0)) * B, label,
+    // algorithmic flops: the two triangular solves (M^2 N each), the symmetric N x N x M product (lower triangle), and for
+    // the expanded form the two triangular products of K L L^T; the whitened form's residual blocks are 2 * 16 * M * N
+    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (t_here ? 2.0 * t_outs * Mp : 0.0) +
+                               (all_here ? (jform == 2 ? 32.0 * Mp * Np : 2.0 * Mp * Mp * Np) : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (t_here ? t_outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
     if (all_here) return XIVO_HIP_OK;
@@ -751,6 +757,8 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (rc) return rc;
   }
   if (gate) {  // Estimator::MHGating on the rows just multiplied (update.cpp:60-96): S_f = (HP)_f H_f^T + R
+    rc = ensure_HT(c);   // the gate reads (and neutralises) the transposed rows
+    if (rc) return rc;
     GateDenseArgs a{};
     a.H = H; a.strideH = c->sH; a.ldh = ldh; a.HP = HP; a.strideHP = c->sH; a.ldhp = ldh;
     a.Hw = c->H + (long)b0 * c->sH; a.HTw = c->HT + (long)b0 * c->sHT; a.strideHT = c->sHT; a.ldht = Np;
@@ -787,10 +795,11 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     // needs the factor, P H^T and P only - nothing of H's structure)
     static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
     const bool all_here = (c->flags & XIVO_HIP_FLAG_REASSOC) && !f32 && !full && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL) && trsm_forms_T(Mp, Np);
-    if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = 1; a.skip_status = c->status + b0; }
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? 3 : 0);
+    const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
+    if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : 0);
     const double t_outs = 0.5 * Np * (Np + 1.0);
-    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (all_here ? 2.0 * t_outs * Mp + 2.0 * Mp * Mp * Np : 0.0)) * B, label,
+    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (all_here ? 2.0 * t_outs * Mp + (jform == 2 ? 32.0 * Mp * Np : 2.0 * Mp * Mp * Np) : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (all_here ? t_outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
     if (all_here) return XIVO_HIP_OK;
@@ -816,6 +825,8 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     }
     return rc;
   }
+  rc = ensure_HT(c);
+  if (rc) return rc;
   {  // A = K * H - I  (estimator.cpp:1276-1279)
     GemmExtra x; x.epi = EPI_SUB_IDENT; x.fp32 = f32;
     rc = gemm(c, ST_KH, B, Np, Np, K, c->sK, Np, HT, c->sHT, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
@@ -944,6 +955,8 @@ int xivo_hip_mh_gate_dense(xivo_hip_ctx* c, int B, int F, double R, double mh_th
   if (rc) return rc;
   rc = ensure_dense(c);
   if (rc) return rc;
+  rc = ensure_HT(c);
+  if (rc) return rc;
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
   {
     GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
@@ -1064,7 +1077,8 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
 static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigned char* mask_override = nullptr, int full_rows = 0) {
   StackArgs a{};
   a.sb = scene_buffers(c); a.lay = c->lay; a.mb = meas_buffers(c);
-  if (skip_HT(c)) a.mb.HT = nullptr;
+  if (skip_HT(c)) { a.mb.HT = nullptr; if (write_dense) c->ht_valid = false; }
+  else if (write_dense) c->ht_valid = true;
   if (mask_override) a.sb.mask = mask_override;
   a.Mp = c->Mpmax; a.Np = c->Np; a.batch = B; a.R = R;
   a.fix_group_block = (full_rows || (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK)) ? 1 : 0;
@@ -1072,6 +1086,16 @@ static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigne
   a.ell = c->ell; a.emit_ell = 1; a.write_dense = write_dense;
   StageTimer st(c, ST_STACK, 0.0, "stack_kernel");
   return launch_stack(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+}
+
+// the transposed dense copy: every G-level producer may have skipped it (skip_HT decides when H is PRODUCED, on the flags
+// of that moment); a consumer that needs it - the dense-row gate, the as-coded K H - I - rebuilds it from H here
+static int ensure_HT(xivo_hip_ctx* c) {
+  if (c->ht_valid) return XIVO_HIP_OK;
+  StageTimer st(c, ST_STACK, 0.0, "transpose_H_kernel");
+  if (launch_transpose_H(c->H, c->sH, c->Mpmax, c->HT, c->sHT, c->Np, c->Mpmax, c->Np, c->Bmax, c->stream)) return XIVO_HIP_ERR_HIP;
+  c->ht_valid = true;
+  return XIVO_HIP_OK;
 }
 
 // the dense copies of the stacked rows, for the consumers that need them (dense pipeline, OOS rows, get_H)
@@ -1136,7 +1160,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   OosArgs a{};
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
   a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
-  if (skip_HT(c)) a.mb.HT = nullptr;
+  if (skip_HT(c)) { a.mb.HT = nullptr; c->ht_valid = false; }
   c->oos_row0 = c->M; c->oos_R = Roos;
   a.rows_out = c->oos_rows;
   {
@@ -1248,7 +1272,7 @@ int xivo_hip_compress_oos(xivo_hip_ctx* c, int B, double trigger_ratio, int* row
     return XIVO_HIP_ERR_INVALID;
   OosCompressArgs a{};
   a.lay = c->lay; a.mb = meas_buffers(c); a.row0 = c->oos_row0; a.rows = c->oos_rows; a.rows_out = c->oos_rows;
-  if (skip_HT(c)) a.mb.HT = nullptr;
+  if (skip_HT(c)) { a.mb.HT = nullptr; c->ht_valid = false; }
   a.ratio = trigger_ratio; a.Roos = c->oos_R; a.batch = B;
   int rc;
   {

@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
 // All 16 waves of the workgroup must call it (barriers); `sL` = the whole 160 KB of LDS.
 // SRC_REGS: Src = A itself (a symmetric rank-k product, P - W^T W): the wave that owns a block copies its registers
 // into the LDS buffer - nothing is read back from memory. NEG_OUT: Out = Minit - A Src^T.
-template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false>
+// FIXUP: Src arrives by DMA as usual and the wave that owns a block then replaces it in LDS by 2 Src - A (its registers):
+// the whitened Joseph form needs (W - D)^T (W + D) with only W in memory (see TF == 4 below).
+template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false, bool FIXUP = false>
 __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* sL, const double* __restrict__ Src, int ldsrc,
                                                     const double* __restrict__ Minit, int ldm, double* __restrict__ Out, int ldo,
                                                     int nb, int nwl, int jbp, bool live, int w, int wave, int lane) {
@@ -564,6 +566,19 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* 
     __syncthreads();                               // phase p landed for every wave; the other buffer is free again
     const int jb0 = p * jbp;
     const double* buf = sL + (p & 1) * bufsz;
+    if (FIXUP) {
+      if (live && w >= jb0 && w < jb0 + min(jbp, nwl - jb0)) {
+        double* dst = sL + (p & 1) * bufsz + (w - jb0) * nb * 256 + lane;
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(mb * 4 + r) * 64] = fma(2.0, dst[(mb * 4 + r) * 64], -X[mb][r]);
+          }
+        }
+      }
+      lds_barrier();
+    }
     bool fetch = p + 1 < nph;                      // phase p + 1 is requested once the first tile has its -Minit (so that
     while (todo) {                                 // the wait on those loads does not sit behind the new requests)
       const int jl = __builtin_ctz(todo);
@@ -619,7 +634,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr int BLK = 16 * 17;
   // TF == 3 needs the diagonal blocks L_kk next to their inverses: in slots of their own while the LDS has room (<= 10
   // block rows), else packed into the unused upper triangle + pad row of the inverse's slot (a few selects per read)
-  constexpr bool PACK = TF == 3 && NBM > 10;
+  constexpr bool PACK = (TF == 3 || TF == 4) && NBM > 10;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
   const int chunks = (g.Np + 255) / 256;
   const int b = blockIdx.x;
@@ -662,7 +677,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       const int k = e >> 4, c = e & 15;
       sL[(k * (k + 1) / 2 + k) * BLK + 16 + 17 * c] = LU[(16 * k + c) + (long)(16 * k + c) * ld];
     }
-  } else if (TF == 3) {
+  } else if (TF == 3 || TF == 4) {
     for (int e = tid; e < nb * 128; e += 1024) {
       const int k = e >> 7, w = e & 127;
       const int r = (w & 7) * 2, c = w >> 3;
@@ -712,6 +727,20 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       }
     }
   }
+  double* __restrict__ K = g.K + (long)filt * g.strideK;
+  const double* __restrict__ inn = g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn;
+  double part = 0.0;
+  if (TF == 4) {
+    // the forward-substituted columns W^T = (L^-1 H P)^T leave for the stash (the K buffer: the gain itself is never
+    // stored by this variant) - the backward substitution below destroys them and the covariance update needs them again
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) {
+      if (i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) K[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldk] = X[i][r];
+      }
+    }
+  }
   // backward: L^T K^T = Y
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
@@ -724,7 +753,29 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
         if (PACK) a = 4 * s + lg >= li ? a : 0.0;
         t = mfma(a, X[k][s], t);
       }
-      X[k] = t;
+      if (TF == 4) {
+        // D_k = B_k - L_kk^T K^T_k, B_k = W_k - sum_{i>k} L_ik^T K^T_i the right-hand side this step just consumed: the
+        // residual of the backward substitution, i.e. W_k - (L^T K^T)_k evaluated with the partial sums already at hand
+        // (both evaluations of L^T K^T carry the same rounding bound); it replaces the gain block, whose last uses -
+        // the updates of the rows above and dx - are right here
+        const double* Lk = PACK ? Dk : sD + k * BLK;
+        d4 dk = X[k];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const int kk = 4 * s2 + lg;                                        // (L_kk)^T element (li, kk) = L_kk(kk, li)
+          if (PACK) {
+            const double a = Lk[kk > li ? li + 17 * kk : 16 + 17 * li];
+            dk = mfma(kk >= li ? -a : 0.0, t[s2], dk);
+          } else {
+            dk = mfma(-Lk[kk + 17 * li], t[s2], dk);
+          }
+        }
+        X[k] = dk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fma(t[r], inn[16 * k + lg + 4 * r], part);
+      } else {
+        X[k] = t;
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -736,23 +787,37 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     }
   }
 
-  double* __restrict__ K = g.K + (long)filt * g.strideK;
-  const double* __restrict__ inn = g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn;
-  double part = 0.0;
+  if (TF != 4) {
 #pragma unroll
-  for (int i = 0; i < NBM; ++i) {
-    if (i < nb) {
+    for (int i = 0; i < NBM; ++i) {
+      if (i < nb) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 16 * i + lg + 4 * r;
-        K[(c0 + li) + (long)m * g.ldk] = X[i][r];
-        part = fma(X[i][r], inn[m], part);
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * i + lg + 4 * r;
+          K[(c0 + li) + (long)m * g.ldk] = X[i][r];
+          part = fma(X[i][r], inn[m], part);
+        }
       }
     }
   }
   part += __shfl_xor(part, 16);
   part += __shfl_xor(part, 32);
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
+
+  if (TF == 4) {
+    // X = D. The covariance update is the Joseph expression for the gain just computed, in the whitened coordinates
+    // of the factor (S = L L^T, H P = L W, V = L^T K^T = W - D):
+    //   P+ = P - K(HP) - (K(HP))^T + K S K^T = P - V^T W - W^T V + V^T V = P - (W - D)^T (W + D) + (W^T D - D^T W),
+    // whose antisymmetric last term vanishes in the lower-triangle + mirror evaluation every pipeline here uses. The
+    // rows of V^T = (W - D)^T become the register operand (own stash read back), W + D the LDS operand (below).
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) {
+      if (i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[i][r] = K[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldk] - X[i][r];
+      }
+    }
+  }
 
   if (TF == 3) {
     // ---- the whole covariance update on the gain in registers (expanded Joseph form, see the launcher's comment):
@@ -826,6 +891,14 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     double* Pio = g.T + (long)filt * g.strideT;
     sym_tiles_from_regs<NBM, false, true>(X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
                                           live, c0 >> 4, wave, lane);
+    return;
+  }
+  if (TF == 4) {
+    // ---- P+ = P - (W - D)^T (W + D) in place: W arrives from the stash by DMA, the owner waves turn it into W + D
+    if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
+    double* Pio = g.T + (long)filt * g.strideT;
+    sym_tiles_from_regs<NBM, false, true, true>(X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+                                                live, c0 >> 4, wave, lane);
     return;
   }
   if (TF == 2) {
@@ -1057,7 +1130,9 @@ template <int NBM>
 int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
   {
     if (g.T && trsm_forms_T(g.Mp, g.Np))
-      return g.fwd_only ? launch_trsm_lds_tf<NBM, 2>(g, stream) : (g.joseph ? launch_trsm_lds_tf<NBM, 3>(g, stream) : launch_trsm_lds_tf<NBM, 1>(g, stream));
+      return g.fwd_only ? launch_trsm_lds_tf<NBM, 2>(g, stream)
+                        : (g.joseph == 2 ? launch_trsm_lds_tf<NBM, 4>(g, stream)
+                                         : (g.joseph ? launch_trsm_lds_tf<NBM, 3>(g, stream) : launch_trsm_lds_tf<NBM, 1>(g, stream)));
   }
   return launch_trsm_lds_tf<NBM, 0>(g, stream);
 }

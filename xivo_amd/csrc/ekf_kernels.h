@@ -23,6 +23,9 @@ int launch_unpack_meas(const double* rawH, long strideRaw, int ldraw, const int*
                        int M, int Mp, int N, int Np, int batch, hipStream_t s);
 
 // P edits
+// H^T rebuilt from the dense H of every filter (the G-level producers may skip writing it: capi.hip skip_HT)
+int launch_transpose_H(const double* H, long strideH, int ldh, double* HT, long strideHT, int ldht, int Mp, int Np, int batch,
+                       hipStream_t s);
 int launch_p_zero_rc(double* P, int ldp, int Np, int off, int len, hipStream_t s);
 int launch_p_copy_rc(double* P, int ldp, int Np, int dst, int src, int len, hipStream_t s);
 int launch_p_diag(const double* P, int ldp, int N, double* out, hipStream_t s);

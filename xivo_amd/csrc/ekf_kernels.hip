@@ -2331,6 +2331,27 @@ int launch_unpack_meas(const double* rawH, long strideRaw, int ldraw, const int*
   hipLaunchKernelGGL(unpack_meas_kernel, grid, dim3(256), 0, s, rawH, strideRaw, ldraw, only_if, mb, M, Mp, N, Np);
   CHECK_LAUNCH();
 }
+// H^T [Np x Mp, ldht] from the dense H [Mp x Np, ldh] of every filter: the transposed copy is optional for the G-level
+// producers (capi.hip: skip_HT) and rebuilt here when a consumer turns up after all. 32 x 32 tiles through LDS so that
+// both sides move 256-byte runs.
+__global__ __launch_bounds__(256) void transpose_H_kernel(const double* __restrict__ Hall, long strideH, int ldh,
+                                                         double* __restrict__ HTall, long strideHT, int ldht, int Mp, int Np) {
+  __shared__ double t[32][33];
+  const double* H = Hall + (long)blockIdx.z * strideH;
+  double* HT = HTall + (long)blockIdx.z * strideHT;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    t[j][tx] = (m0 + tx < Mp && n0 + j < Np) ? H[(m0 + tx) + (long)(n0 + j) * ldh] : 0.0;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (n0 + tx < Np && m0 + j < Mp) HT[(n0 + tx) + (long)(m0 + j) * ldht] = t[tx][j];
+}
+int launch_transpose_H(const double* H, long strideH, int ldh, double* HT, long strideHT, int ldht, int Mp, int Np, int batch,
+                       hipStream_t s) {
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(transpose_H_kernel, dim3((Mp + 31) / 32, (Np + 31) / 32, batch), dim3(256), 0, s, H, strideH, ldh, HT, strideHT, ldht, Mp, Np);
+  CHECK_LAUNCH();
+}
 int launch_p_zero_rc(double* P, int ldp, int Np, int off, int len, hipStream_t s) {
   hipLaunchKernelGGL(p_zero_rc_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, P, ldp, Np, off, len);
   CHECK_LAUNCH();

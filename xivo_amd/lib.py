@@ -16,6 +16,7 @@ FLAG_DENSE_H = 64
 FLAG_FP64_CORR = 128
 FLAG_SYMMETRIC_FORM = 256
 FLAG_STANDALONE_TAIL = 512
+FLAG_EXPANDED_JOSEPH = 1024
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
 
