@@ -132,3 +132,37 @@ def test_gated_update_after_device_handover_is_repeatable(built):
         keep = np.repeat(res[0][2][b], 2)
         e_ref, P_ref, _ = orc.update_joseph(H[b][keep], P[b], inn[b][keep], dR[b][keep])
         assert rel_fro(res[0][0][b], P_ref) < TOL_P and rel_fro(res[0][1][b], e_ref) < TOL_DX
+
+
+_NOCOMPRESS_SNIPPET = r"""
+import sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/oracle"); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import xivo_oracle as orc
+from helpers import rel_fro
+from xivo_amd import synth
+from xivo_amd.lib import Context
+N, F, B = 150, 50, 3
+P, H, inn, dR = synth.s_level(N, F, B, seed=9)
+with Context(N, 2 * F + 20, B) as ctx:      # allocated rows beyond M: the neutral padding is exercised too
+    ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+    path = ctx.last_path(); Pn = ctx.download_P(); err = ctx.get_err(); Hb, innb, dRb = ctx.get_H(1)
+w = 0.0
+for b in range(B):
+    e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+    w = max(w, rel_fro(Pn[b], P_ref), rel_fro(err[b], e_ref))
+print(json.dumps(dict(path=path, worst=w, H_equal=bool(np.array_equal(Hb, H[1])), inn_equal=bool(np.array_equal(innb, inn[1])))))
+"""
+
+
+def test_handover_without_compression_takes_the_dense_pipeline(built):
+    """When the LDS lists of the compression kernel cannot hold a shape (very wide states) the hand-over keeps every
+    filter's dense rows and the update takes the dense pipeline. The shape limit is far away (N > ~2800 at M = 384), so
+    the same path is forced here with XIVO_HIP_NO_COMPRESS."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["XIVO_HIP_NO_COMPRESS"] = "1"
+    r = subprocess.run([sys.executable, "-c", _NOCOMPRESS_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["path"] == 0 and d["worst"] < 1e-9 and d["H_equal"] and d["inn_equal"], d

@@ -317,6 +317,27 @@ def test_imu_feeder_skips_repeated_and_old_timestamps():
     assert recs.shape == (2, 1) and np.all(np.isfinite(recs["slope_gyro"])) and np.all(recs["dt"] > 0)
 
 
+def test_imu_feeder_mixed_per_filter_clocks():
+    """Filters of one batch may sit at different times: a message that is new for one filter and a repeat for another must
+    advance the first and leave the second untouched - finite slopes, zero-length record (the reference returns per
+    estimator when dt == 0, src/estimator.cpp:550-555)."""
+    import numpy as np
+    from xivo_amd.sequence import ImuFeeder
+    f = ImuFeeder(2, 0.0, np.zeros((2, 3)), np.zeros((2, 3)))
+    f.t = np.array([0.0, 0.01])                                    # filter 1 is already at t = 0.01
+    f.imu(0.01, np.ones((2, 3)), 2 * np.ones((2, 3)))
+    rec = f.take()
+    assert np.all(np.isfinite(rec["slope_gyro"])) and np.all(np.isfinite(rec["slope_accel"]))
+    assert np.allclose(rec["dt"][:, 0], [0.01, 0.0])
+    assert np.allclose(f.slope_gyro[0], 100.0) and np.allclose(f.slope_gyro[1], 0.0)
+    assert np.allclose(f.last_gyro[0], 1.0) and np.allclose(f.last_gyro[1], 0.0)
+    assert np.allclose(f.t, 0.01)
+    f.t = np.array([0.01, 0.02])
+    f.visual(0.015)                                                # camera frame: filter 1 is past it, nothing to propagate
+    rec = f.take()
+    assert np.allclose(rec["dt"][:, 0], [0.005, 0.0]) and np.allclose(f.t, [0.015, 0.02])
+
+
 def test_oracle_absorb_error_enforces_so3_every_50_calls():
     """State::operator+= (src/core.h:154-162): every kEnforceSO3Freq = 50 absorbs Rsb / Rbc are re-normalised and the z
     component of log(Rsg) is zeroed - composing xy-only increments builds up a z rotation at second order."""

@@ -563,3 +563,41 @@ def test_whitened_form_ill_conditioned_and_not_spd(built):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < 1e-6
         w = np.linalg.eigvalsh(Pn[b])
         assert w.min() > -1e-9 * w.max()
+
+
+_CHOL_SNIPPET = r"""
+import sys, json, hashlib
+sys.path.insert(0, {root!r})
+import numpy as np
+from xivo_amd import synth
+from xivo_amd.lib import Context
+out = {{}}
+for (N, F) in [(150, 50), (250, 80), (100, 96)]:
+    B = 520                                   # >= 512: the size class where the pick matters
+    P, H, inn, dR = synth.s_level(N, F, 8, seed=41)
+    idx = np.arange(B) % 8
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P[idx]); ctx.set_measurements(H[idx], inn[idx], dR[idx]); ctx.update_joseph()
+        Pn = ctx.download_P(); err = ctx.get_err()
+    out["%d,%d" % (N, F)] = [hashlib.sha256(Pn.tobytes()).hexdigest(), hashlib.sha256(err.tobytes()).hexdigest()]
+print(json.dumps(out))
+"""
+
+
+def test_cholesky_kernels_are_bit_identical(built):
+    """The one-wave and the four-wave register Cholesky run the same arithmetic in the same order (pivot_scale, two
+    accumulators per block product, inverse rows scaled by 1 / sqrt(pivot)): whichever of them a node picks for big batches
+    (chol_pick times both once), P+ and dx come out bit for bit the same - across nodes, ranks and runs."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for knob in ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG", None):
+        env = dict(os.environ)
+        for k in ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG"):
+            env.pop(k, None)
+        if knob:
+            env[knob] = "1"
+        r = subprocess.run([sys.executable, "-c", _CHOL_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1] == res[2], res

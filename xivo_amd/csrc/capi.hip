@@ -56,6 +56,7 @@ struct xivo_hip_ctx {
   int M = 0, Mp = 0;  // rows currently staged
   int chunk = 0;      // filters per pipeline pass (0 = whole batch)
   int chol_variant[32] = {0};   // per factor size (blocks): 0 = not calibrated yet, 1 / 2 = CholArgs::variant picked on this node
+  int* tune_status = nullptr;   // scratch status of the calibration runs (never the caller's)
   // G-level
   xivo_layout lay{};
   xivo_cam cam{};
@@ -305,7 +306,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
-                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf};
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->tune_status};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
@@ -465,6 +466,15 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   c->M = M; c->Mp = round_up16(M);
   EllBuffers e = c->ell;
   e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.pw += b0; e.over += b0;
+  if (!meas_compress_fits(c->Mpmax, c->Np) || getenv("XIVO_HIP_NO_COMPRESS")) {
+    // the compression kernel's LDS lists do not fit this shape: every filter keeps its dense rows and takes the dense pipeline
+    StageTimer st(c, ST_STACK, 0.0, "unpack_meas_kernel", 8.0 * nb * (3.0 * M * N + 4.0 * M));
+    HIP_TRY((hipError_t)launch_meas_vectors(dInn, strideInn, dR, strideR, M, c->Mpmax, e, mb.inn, mb.strideInn, mb.diagR, mb.strideR, nb, c->stream));
+    HIP_TRY((hipError_t)launch_unpack_meas(dH, strideH, ldh, nullptr, mb, M, c->Mpmax, N, c->Np, nb, c->stream));
+    for (int b = b0; b < b0 + nb; ++b) { c->ell_over_h[b] = 1; c->ell_nc_h[b] = ELL_CW; c->ell_pw_h[b] = ELL_PW + 1; }
+    c->dense_valid = true; c->dense_from_ell = true; c->ht_valid = true;
+    return XIVO_HIP_OK;
+  }
   {
     StageTimer st(c, ST_STACK, 0.0, "meas_compress_kernel", 8.0 * nb * ((double)M * N + 4.0 * M) + (double)nb * c->ell.pairs_max * ELL_W * 20.0);
     // clear up to the allocated row count so stale rows of a previous, larger M vanish
@@ -479,7 +489,7 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   for (int b = b0; b < b0 + nb && !any_over; ++b) any_over = c->ell_over_h[b] != 0;
   if (debug_on()) fprintf(stderr, "xivo_hip: hand-over b0=%d nb=%d M=%d any_over=%d nc0=%d pw0=%d\n", b0, nb, M, (int)any_over, c->ell_nc_h[b0], c->ell_pw_h[b0]);
   if (any_over) HIP_TRY((hipError_t)launch_unpack_meas(dH, strideH, ldh, e.over, mb, M, c->Mpmax, N, c->Np, nb, c->stream));
-  c->dense_valid = false; c->dense_from_ell = true;
+  c->dense_valid = false; c->dense_from_ell = true; c->ht_valid = true;   // (ensure_dense rebuilds H and H^T together)
   return XIVO_HIP_OK;
 }
 
@@ -519,15 +529,24 @@ int xivo_hip_set_measurements_device(xivo_hip_ctx* c, int b0, int nb, int M, con
 
 // Big batches: which Cholesky kernel is faster depends on the node (the register kernel is ~170 KB of straight-line
 // code and loses 2.6x on nodes with slow instruction fetch, wins 20 % elsewhere - DESIGN.md). Timed once per factor
-// size on a scratch copy of the first batch's S (the A buffer is free at that point), then remembered.
+// size on scratch copies (S -> the A buffer, inverse blocks -> the T buffer, status -> a buffer of its own: all free or
+// private at that point; nothing of the caller's batch is touched), then remembered. The two kernels run the same
+// arithmetic in the same order (chol_trsm.hip: pivot_scale) and give bit-identical factors, so the pick changes the
+// time of a step and never its result: two nodes, two ranks or two runs agree bit for bit whatever they pick
+// (tests/test_update_gpu.py::test_cholesky_kernels_are_bit_identical). The timing costs one host synchronisation, once
+// per context and factor size; XIVO_HIP_NO_AUTOTUNE=1 skips it (then: the four-wave register kernel).
 static int chol_pick(xivo_hip_ctx* c, const double* S, int Mp, int lds, int B) {
   const int nb = Mp / 16;
-  if (B < 512 || nb > 12 || getenv("XIVO_HIP_CHOL_WAVE") || getenv("XIVO_HIP_CHOL_REG") || getenv("XIVO_HIP_NO_AUTOTUNE")) return 0;
+  if (B < 512 || nb > 12 || getenv("XIVO_HIP_CHOL_WAVE") || getenv("XIVO_HIP_CHOL_REG")) return 0;
+  if (getenv("XIVO_HIP_NO_AUTOTUNE")) return 2;
   if (c->chol_variant[nb]) return c->chol_variant[nb];
   int nt = B < 2048 ? B : 2048;                  // a sample is enough
-  const long fit = (long)c->Bmax * c->sA / c->sS;   // ... and it has to fit the scratch copy (S can be larger than A: M > N)
+  const long fit = (long)c->Bmax * c->sA / c->sS;   // ... and it has to fit the scratch copies (S can be larger than A: M > N)
   if (fit < nt) nt = (int)fit;
-  if (nt < 256) return 0;
+  const long fit2 = (long)c->Bmax * c->sP / c->sInvD;
+  if (fit2 < nt) nt = (int)fit2;
+  if (nt < 256) return 2;
+  if (!c->tune_status && dev_alloc(&c->tune_status, (size_t)c->Bmax) != XIVO_HIP_OK) return 2;
   float best = 0.f; int pick = 1;
   hipEvent_t e0, e1;                              // own events: the context's pair may be timing the caller's region
   if (hipEventCreate(&e0) != hipSuccess) return 0;
@@ -537,8 +556,8 @@ static int chol_pick(xivo_hip_ctx* c, const double* S, int Mp, int lds, int B) {
     float ms_min = 1e30f;
     for (int rep = 0; rep < 2; ++rep) {
       if (hipMemcpyAsync(c->A, S, (size_t)nt * c->sS * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return 0;
-      CholArgs a{}; a.S = c->A; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = c->invD; a.strideInvD = c->sInvD;
-      a.status = c->status; a.batch = nt; a.variant = v;
+      CholArgs a{}; a.S = c->A; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = c->T; a.strideInvD = c->sInvD;
+      a.status = c->tune_status; a.batch = nt; a.variant = v;
       hipEventRecord(e0, c->stream);
       if (launch_chol_f64(a, c->stream)) return 0;
       hipEventRecord(e1, c->stream);
@@ -1186,6 +1205,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
 int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_thresh, double ransac_chi2,
                               const int* gauge_group, const unsigned long long* absorb_groups,
                               unsigned char* inlier_mask_out, double* chi2_out, int* n_rejected_out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0 || !c->mask || !c->poses) return XIVO_HIP_ERR_INVALID;
   if (c->lay.n_groups > 64) return XIVO_HIP_ERR_UNSUPPORTED;
   const size_t Bm = c->Bmax, ng = c->lay.n_groups;
@@ -1228,6 +1248,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   for (int b = 0; b < B; ++b) { c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12; c->ell_pw_h[b] = 9; }
   const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
   c->dense_valid = dense != 0; c->dense_from_ell = true; c->stack_R = R; c->stack_B = B;
+  c->oos_row0 = -1;   // the partial stacking replaces the rows of any earlier xivo_hip_oos_project (as xivo_hip_stack does)
   int rc = stack_impl(c, B, R, dense, c->rs_low, 1);
   if (rc) return rc;
   rc = xivo_hip_update_joseph(c, B);
@@ -1268,6 +1289,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
 // has more than trigger_ratio times as many rows as non-zero columns, it is replaced by the triangular factor of its QR
 // decomposition (oos_compress_kernel) and the row count of the stacked measurement shrinks accordingly.
 int xivo_hip_compress_oos(xivo_hip_ctx* c, int B, double trigger_ratio, int* rows_out) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->oos_row0 < 0 || !c->oos_rows || B != c->oos_nb || !(trigger_ratio >= 1.0))
     return XIVO_HIP_ERR_INVALID;
   OosCompressArgs a{};

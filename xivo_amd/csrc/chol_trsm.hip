@@ -49,6 +49,20 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// d = sqrt(p) and rd = 1 / sqrt(p) of a pivot: hardware estimate + two Newton steps, d = p * rd with one correction - no
+// sqrt / divide in the serial chain. BOTH Cholesky kernels use this routine and the same operand order everywhere else
+// (two accumulators over the k-slices of a block product, inverse rows scaled by rd), so that they produce the SAME bits:
+// which of them a node runs faster (chol_pick in capi.hip) then changes the time, never the result.
+__device__ __forceinline__ void pivot_scale(double p, double& d, double& rd) {
+#pragma clang fp contract(off)
+  rd = __builtin_amdgcn_rsq(p);
+  const double hx = 0.5 * p;
+  rd = rd * __builtin_fma(-(hx * rd), rd, 1.5);
+  rd = rd * __builtin_fma(-(hx * rd), rd, 1.5);
+  d = p * rd;
+  d = __builtin_fma(__builtin_fma(-d, d, p), 0.5 * rd, d);
+}
+
 // One wave64 per filter (no cross-wave barriers; many filters resident per CU so
 // the serial 16x16 diagonal factorisations of different filters overlap).
 __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
 
     // ---- 2. factor the 16x16 diagonal block in registers (row li per lane), invert it
     {
-      double x[16];
+      double x[16], rdv[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) x[c] = S[(16 * j + li) + (long)(16 * j + c) * ld] - sP[li * 17 + c];
 #pragma unroll
@@ -96,8 +110,9 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
           if (!bad) bad = 1 + 16 * j + c;
           dcc = 1.0;
         }
-        const double d = sqrt(dcc);
-        const double rd = 1.0 / d;
+        double d, rd;
+        pivot_scale(dcc, d, rd);
+        rdv[c] = rd;
         x[c] = (li == c) ? d : x[c] * rd;
 #pragma unroll
         for (int q = c + 1; q < 16; ++q) {
@@ -115,8 +130,7 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
           const double lik = readlane_d(x[k], i);
           acc = fma(-lik, y[k], acc);
         }
-        const double lii = readlane_d(x[i], i);
-        y[i] = acc / lii;
+        y[i] = acc * rdv[i];
       }
       if (lg == 0) {
 #pragma unroll
@@ -137,7 +151,9 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
     for (int i = j + 1; i < nb; i += 2) {
       const bool two = (i + 1 < nb);
       const int i2 = two ? i + 1 : i;
+      // (k-slices 0, 2 and 1, 3 in separate accumulators, summed at the end: the register kernel's order)
       d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
+      d4 accA1 = d4{0.0, 0.0, 0.0, 0.0}, accB1 = d4{0.0, 0.0, 0.0, 0.0};
       for (int k = 0; k < j; ++k) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -145,15 +161,15 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
           const double a = S[(16 * j + li) + col];
           const double b1 = S[(16 * i + li) + col];
           const double b2 = S[(16 * i2 + li) + col];
-          accA = mfma(a, b1, accA);
-          accB = mfma(a, b2, accB);
+          if (s & 1) { accA1 = mfma(a, b1, accA1); accB1 = mfma(a, b2, accB1); }
+          else { accA = mfma(a, b1, accA); accB = mfma(a, b2, accB); }
         }
       }
       d4 rhsA, rhsB;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        rhsA[r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] - accA[r];
-        rhsB[r] = S[(16 * i2 + li) + (long)(16 * j + lg + 4 * r) * ld] - accB[r];
+        rhsA[r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] - (accA[r] + accA1[r]);
+        rhsB[r] = S[(16 * i2 + li) + (long)(16 * j + lg + 4 * r) * ld] - (accB[r] + accB1[r]);
       }
       d4 outA = d4{0.0, 0.0, 0.0, 0.0}, outB = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -311,13 +327,8 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
           if (!bad) bad = 1 + 16 * j + c;
           dcc = 1.0;
         }
-        // rd = dcc^-1/2: hardware estimate + two Newton steps; d = dcc * rd with one correction
-        double rd = __builtin_amdgcn_rsq(dcc);
-        const double hx = 0.5 * dcc;
-        rd = rd * fma(-hx * rd, rd, 1.5);
-        rd = rd * fma(-hx * rd, rd, 1.5);
-        double d = dcc * rd;
-        d = fma(fma(-d, d, dcc), 0.5 * rd, d);
+        double d, rd;
+        pivot_scale(dcc, d, rd);
         rdv[c] = rd;
         if (lg == lgc) x[rc] = (li == c) ? d : x[rc] * rd;
         const double lqc = __shfl(x[rc], li + 16 * lgc);            // L[my row][c]

@@ -39,6 +39,12 @@ struct EllBuffers {
 int launch_meas_compress(const double* H, long strideH, int ldh, const double* inn, long strideInn,
                          const double* diagR, long strideR, int M, int N, int Np, int Mp_clear, EllBuffers e,
                          double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s);
+// whether the per-workgroup LDS lists of launch_meas_compress fit the 160 KiB of a CU for these shapes; when they do not
+// (N beyond ~2800 at the largest M) the hand-over marks every filter "does not fit" instead (launch_meas_vectors: inn /
+// diagR padded, over = 1) and the caller unpacks the dense rows: the dense pipeline has no such limit
+bool meas_compress_fits(int Mp_clear, int Np);
+int launch_meas_vectors(const double* inn, long strideInn, const double* diagR, long strideR, int M, int Mp_clear, EllBuffers e,
+                        double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s);
 // dense padded H / H^T of the filters that fit the compressed form (over = 0), rebuilt from it
 int launch_ell_to_dense(EllBuffers e, double* H, long strideH, int ldh, double* HT, long strideHT, int ldht, int Mp,
                         int Np, int batch, hipStream_t s);

@@ -144,6 +144,19 @@ __global__ __launch_bounds__(256) void meas_compress_kernel(MeasCompressArgs a) 
   if (tid == 0) a.ell.pw[filt] = s_pw;
 }
 
+// Hand-over without compression (the LDS lists of meas_compress_kernel do not fit: very wide states): every filter is
+// marked "does not fit" and takes the dense pipeline; inn / diagR get the same neutral padding.
+__global__ __launch_bounds__(256) void meas_vectors_kernel(const double* __restrict__ inn, long strideInn, const double* __restrict__ diagR,
+                                                          long strideR, int M, int Mp_clear, EllBuffers e, double* __restrict__ inn_out,
+                                                          long strideInnOut, double* __restrict__ R_out, long strideROut) {
+  const int filt = blockIdx.x;
+  for (int m = threadIdx.x; m < Mp_clear; m += blockDim.x) {
+    inn_out[(long)filt * strideInnOut + m] = m < M ? inn[(long)filt * strideInn + m] : 0.0;
+    R_out[(long)filt * strideROut + m] = m < M ? diagR[(long)filt * strideR + m] : 1.0;
+  }
+  if (threadIdx.x == 0) { e.over[filt] = 1; e.nc[filt] = ELL_CW; e.pw[filt] = ELL_PW + 1; }
+}
+
 // Dense H / H^T (padded, both zero filled) of the filters whose rows fit the compressed form, rebuilt from it
 // on demand (dense pipeline, xivo_hip_get_H); filters with over = 1 already hold their dense rows.
 __global__ __launch_bounds__(256) void ell_to_dense_kernel(EllBuffers e, double* Hall, long strideH, int ldh,
@@ -546,6 +559,23 @@ int launch_meas_compress(const double* H, long strideH, int ldh, const double* i
   if (lds > (size_t)(160 * 1024 - 256)) return (int)hipErrorInvalidValue;
   if (aligned) hipLaunchKernelGGL(meas_compress_kernel<true>, dim3(batch), dim3(nt), lds, s, a);
   else hipLaunchKernelGGL(meas_compress_kernel<false>, dim3(batch), dim3(nt), lds, s, a);
+  CHECK_LAUNCH();
+}
+
+static size_t meas_compress_lds(int Mp_clear, int Np) {
+  const int pairs_clear = Mp_clear / 2;
+  const int nt = ((pairs_clear + 63) / 64) * 64;
+  const int list_ld = (pairs_clear + 3) & ~3;
+  return (size_t)ELL_W * list_ld * (sizeof(d2) + sizeof(int)) + (size_t)(nt / 64 + 1) * Np * sizeof(int);
+}
+bool meas_compress_fits(int Mp_clear, int Np) {
+  return Mp_clear / 2 <= 256 && meas_compress_lds(Mp_clear, Np) <= (size_t)(160 * 1024 - 256);
+}
+int launch_meas_vectors(const double* inn, long strideInn, const double* diagR, long strideR, int M, int Mp_clear, EllBuffers e,
+                        double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s) {
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(meas_vectors_kernel, dim3(batch), dim3(256), 0, s, inn, strideInn, diagR, strideR, M, Mp_clear, e, inn_out,
+                     strideInnOut, R_out, strideROut);
   CHECK_LAUNCH();
 }
 

@@ -46,18 +46,25 @@ class ImuFeeder:
                 import warnings
                 warnings.warn("IMU message older than the filter time: skipped")
             return
+        # per-filter clocks: a filter whose dt <= 0 returns early like the reference's estimator (its last_ / slope_ / time
+        # stay untouched and its record is a zero-length step, which xivo_hip_propagate integrates as the identity)
+        go = dt > 0
         rec = np.zeros(self.t.shape[0], dtype=L.imu_dtype)
-        self.slope_gyro = (gyro - self.last_gyro) / dt[:, None]
-        self.slope_accel = (accel - self.last_accel) / dt[:, None]
+        gyro = np.broadcast_to(np.asarray(gyro, dtype=float), self.last_gyro.shape)
+        accel = np.broadcast_to(np.asarray(accel, dtype=float), self.last_accel.shape)
+        safe = np.where(go, dt, 1.0)[:, None]
+        self.slope_gyro = np.where(go[:, None], (gyro - self.last_gyro) / safe, self.slope_gyro)
+        self.slope_accel = np.where(go[:, None], (accel - self.last_accel) / safe, self.slope_accel)
         rec["gyro"], rec["accel"] = self.last_gyro, self.last_accel
-        rec["slope_gyro"], rec["slope_accel"], rec["dt"] = self.slope_gyro, self.slope_accel, dt
-        self.last_gyro, self.last_accel = np.array(gyro, dtype=float), np.array(accel, dtype=float)
-        self.t = np.full_like(self.t, t)
+        rec["slope_gyro"], rec["slope_accel"], rec["dt"] = self.slope_gyro, self.slope_accel, np.where(go, dt, 0.0)
+        self.last_gyro = np.where(go[:, None], gyro, self.last_gyro)
+        self.last_accel = np.where(go[:, None], accel, self.last_accel)
+        self.t = np.where(go, t, self.t)
         self.pending.append(rec)
 
     def visual(self, t):
         """camera message at time t (visual_meas == true branch, :568-575); dt == 0 propagates nothing (:550-555)"""
-        dt = t - self.t
+        dt = np.maximum(t - self.t, 0.0)      # (a filter already at or past t propagates nothing: zero-length record)
         if np.all(dt == 0):
             return
         rec = np.zeros(self.t.shape[0], dtype=L.imu_dtype)
@@ -65,7 +72,7 @@ class ImuFeeder:
         rec["slope_gyro"], rec["slope_accel"], rec["dt"] = self.slope_gyro, self.slope_accel, dt
         self.last_gyro = self.last_gyro + self.slope_gyro * dt[:, None]
         self.last_accel = self.last_accel + self.slope_accel * dt[:, None]
-        self.t = np.full_like(self.t, t)
+        self.t = np.maximum(self.t, t)
         self.pending.append(rec)
 
     def take(self):
