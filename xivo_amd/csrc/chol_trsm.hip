@@ -34,6 +34,14 @@
 #include <utility>
 #include <stdio.h>
 
+// XIVO_ABL: timing-only ablations of trsm_lds_f64_kernel<., 4> (scripts/ablate_solve.sh builds one library per value; the
+// results are WRONG for any value but 0): 1 stop after the substitutions, 2 skip the substitutions, 3 no fix-up pass /
+// barrier, 4 no stores of P+, 5 no dx accumulation in the backward loop, 6 no stash write / read-back, 7 no loads of the P
+// tiles, 8 no operand DMA, 9 LDS-only barrier at the phase start (no vmcnt drain), 10 two row blocks per phase
+#ifndef XIVO_ABL
+#define XIVO_ABL 0
+#endif
+
 namespace xivo_hip {
 
 namespace {
@@ -47,6 +55,21 @@ __device__ __forceinline__ double readlane_d(double v, int srclane) {
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Buffer addressing for the per-filter matrices of the one-workgroup-per-filter kernels: a 128-bit resource per matrix in
+// SGPRs, ONE 32-bit per-lane byte offset that every access of that matrix shares, and the block / column part of the
+// address as a wave-uniform scalar offset - instead of a 64-bit address pair per access in VGPRs (the solve kernel lives
+// on exactly 128 VGPRs) and 64-bit vector arithmetic in the MFMA stream.
+typedef unsigned int bufu2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, 0);
 }
 
 // d = sqrt(p) and rd = 1 / sqrt(p) of a pivot: hardware estimate + two Newton steps, d = p * rd with one correction - no
@@ -541,7 +564,7 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* 
       }
       return;
     }
-    for (int q = wave; q < nj * 2 * nb; q += 16) {
+    for (int q = wave; q < (XIVO_ABL == 8 ? 0 : nj * 2 * nb); q += 16) {
       const int jl = q / (2 * nb), t = q - jl * 2 * nb;
       const double* src = Src + (16 * (jb0 + jl) + 2 * (lane & 7)) + (long)(8 * t + (lane >> 3)) * ldsrc;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -563,21 +586,28 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* 
   // blocks below the diagonal (and the diagonal one) swap the two MFMA operands - the tile comes out transposed,
   // lanes along the row index - blocks above it stand for their mirror image. Minit is read there (its lower
   // triangle, as the stand-alone product does), Out(a, b) and its mirror Out(b, a) are written.
+  const __amdgpu_buffer_rsrc_t rM = buf_rsrc(Minit), rO = buf_rsrc(Out);
+  const unsigned vM = (unsigned)(li + lg * ldm) * 8u;              // element (li, lg) of a 16 x 16 block of Minit
+  const unsigned vO = (unsigned)(li + lg * ldo) * 8u, vOt = (unsigned)(lg + li * ldo) * 8u;   // ... of Out, and of its mirror image
   auto load_m = [&](int jb, d4& acc) {
-    const int a = 16 * (jb <= w ? w : jb) + li, b = 16 * (jb <= w ? jb : w) + lg;
+    const int ba = jb <= w ? w : jb, bb = jb <= w ? jb : w;       // block (ba, bb), ba >= bb
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = Minit[a + (long)(b + 4 * r) * ldm];   // (negated where it is consumed: no wait here)
+    for (int r = 0; r < 4; ++r)
+      acc[r] = XIVO_ABL == 7 ? 1.0 : buf_ld(rM, vM, (unsigned)(16 * ba + (16 * bb + 4 * r) * ldm) * 8u);   // (negated where it is consumed: no wait here)
   };
   issue(0);
   unsigned todo = my_tiles(0);
   d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
   if (todo) load_m(__builtin_ctz(todo), nxt);
   for (int p = 0; p < nph; ++p) {
+    if (XIVO_ABL == 9) lds_barrier();
+    else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                               // phase p landed for every wave; the other buffer is free again
+    }
     const int jb0 = p * jbp;
     const double* buf = sL + (p & 1) * bufsz;
-    if (FIXUP) {
+    if (FIXUP && XIVO_ABL != 3) {
       if (live && w >= jb0 && w < jb0 + min(jbp, nwl - jb0)) {
         double* dst = sL + (p & 1) * bufsz + (w - jb0) * nb * 256 + lane;
 #pragma unroll
@@ -616,14 +646,15 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* 
           }
         }
       }
-      const int a = 16 * (jb <= w ? w : jb) + li, b = 16 * (jb <= w ? jb : w) + lg;
+      const int ba = jb <= w ? w : jb, bbk = jb <= w ? jb : w;
+      const int a = 16 * ba + li, b = 16 * bbk + lg;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int bb = b + 4 * r;
-        if (jb != w || a >= bb) {                  // diagonal tile: the lower triangle is authoritative
+        if ((jb != w || a >= bb) && !(XIVO_ABL == 4 && acc[r] != 12345.678)) {   // diagonal tile: the lower triangle is authoritative
           const double v = NEG_OUT ? -acc[r] : acc[r];
-          Out[a + (long)bb * ldo] = v;
-          if (a != bb) Out[bb + (long)a * ldo] = v;
+          buf_st(v, rO, vO, (unsigned)(16 * ba + (16 * bbk + 4 * r) * ldo) * 8u);
+          if (a != bb) buf_st(v, rO, vOt, (unsigned)(16 * bbk + 4 * r + 16 * ba * ldo) * 8u);
         }
       }
     }
@@ -661,6 +692,24 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   const double* __restrict__ PHT = g.PHT + (long)filt * g.stridePHT;
   const long ld = g.ldlu;
 
+  // the right-hand sides first: their loads are in flight while the factor is copied (one workgroup per CU - nothing else
+  // would hide the latency of either)
+  const int c0 = chunk * 256 + wave * 16;
+  const bool live = c0 < g.Np;
+  const __amdgpu_buffer_rsrc_t rPHT = buf_rsrc(PHT), rK = buf_rsrc(g.K + (long)filt * g.strideK),
+                               rInn = buf_rsrc(g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn);
+  const unsigned vPHT = (unsigned)((c0 + li) + lg * g.ldpht) * 8u;   // element (c0 + li, lg) of P H^T; + (16 i + 4 r) ldpht as a scalar offset
+  const unsigned vK = (unsigned)((c0 + li) + lg * g.ldk) * 8u;
+  d4 X[NBM];
+#pragma unroll
+  for (int i = 0; i < NBM; ++i) {
+    X[i] = d4{0.0, 0.0, 0.0, 0.0};
+    if (live && i < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[i][r] = buf_ld(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u);
+    }
+  }
+
   // cooperative copy: block (i,k), i >= k at slot i(i+1)/2 + k
   const int nblk = nb * (nb + 1) / 2;
   for (int e = tid; e < nblk * 128; e += 1024) {      // 128 = 256 elements / 2 per thread-load
@@ -697,18 +746,6 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       sD[k * BLK + r + 1 + 17 * c] = r + 1 >= c ? v[1] : 0.0;
     }
   }
-  const int c0 = chunk * 256 + wave * 16;
-  const bool live = c0 < g.Np;
-
-  d4 X[NBM];
-#pragma unroll
-  for (int i = 0; i < NBM; ++i) {
-    X[i] = d4{0.0, 0.0, 0.0, 0.0};
-    if (live && i < nb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X[i][r] = PHT[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldpht];
-    }
-  }
   __syncthreads();
   if (!TF && !live) return;
 
@@ -716,7 +753,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   // forward: L Y = HP
 #pragma unroll
   for (int k = 0; k < NBM; ++k) {
-    if (k < nb) {
+    if (k < nb && !(TF == 4 && XIVO_ABL == 2)) {
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
       d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -738,25 +775,33 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       }
     }
   }
-  double* __restrict__ K = g.K + (long)filt * g.strideK;
-  const double* __restrict__ inn = g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn;
   double part = 0.0;
-  if (TF == 4) {
+  if (TF == 4 && XIVO_ABL != 6) {
     // the forward-substituted columns W^T = (L^-1 H P)^T leave for the stash (the K buffer: the gain itself is never
     // stored by this variant) - the backward substitution below destroys them and the covariance update needs them again
 #pragma unroll
     for (int i = 0; i < NBM; ++i) {
       if (i < nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) K[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldk] = X[i][r];
+        for (int r = 0; r < 4; ++r) buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);
       }
     }
   }
   // backward: L^T K^T = Y
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
-    if (k < nb && !g.fwd_only) {
+    if (k < nb && !g.fwd_only && !(TF == 4 && XIVO_ABL == 2)) {
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
+      // TF == 4: W_k comes back from the stash while this step's MFMAs run (requested here, used at the end of the step;
+      // the last block row has not been touched yet: it is still in X)
+      d4 wk = d4{0.0, 0.0, 0.0, 0.0};
+      if (TF == 4) {
+        if (k == nb - 1) wk = X[k];
+        else if (XIVO_ABL != 6) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wk[r] = buf_ld(rK, vK, (unsigned)((16 * k + 4 * r) * g.ldk) * 8u);
+        }
+      }
       d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -770,20 +815,18 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
         // (both evaluations of L^T K^T carry the same rounding bound); it replaces the gain block, whose last uses -
         // the updates of the rows above and dx - are right here
         const double* Lk = PACK ? Dk : sD + k * BLK;
-        d4 dk = X[k];
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
           const int kk = 4 * s2 + lg;                                        // (L_kk)^T element (li, kk) = L_kk(kk, li)
           if (PACK) {
             const double a = Lk[kk > li ? li + 17 * kk : 16 + 17 * li];
-            dk = mfma(kk >= li ? -a : 0.0, t[s2], dk);
+            X[k] = mfma(kk >= li ? -a : 0.0, t[s2], X[k]);
           } else {
-            dk = mfma(-Lk[kk + 17 * li], t[s2], dk);
+            X[k] = mfma(-Lk[kk + 17 * li], t[s2], X[k]);
           }
         }
-        X[k] = dk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part = fma(t[r], inn[16 * k + lg + 4 * r], part);
+        for (int r = 0; r < 4; ++r) part = fma(t[r], XIVO_ABL == 5 ? 1.0 : buf_ld(rInn, (unsigned)lg * 8u, (unsigned)(16 * k + 4 * r) * 8u), part);
       } else {
         X[k] = t;
       }
@@ -795,6 +838,8 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
           X[i] = mfma(-a, t[s], X[i]);
         }
       }
+      // TF == 4: V_k = W_k - D_k, the row block of V^T = (W - D)^T - the register operand of the covariance product below
+      if (TF == 4) X[k] = wk - X[k];
     }
   }
 
@@ -804,9 +849,8 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       if (i < nb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = 16 * i + lg + 4 * r;
-          K[(c0 + li) + (long)m * g.ldk] = X[i][r];
-          part = fma(X[i][r], inn[m], part);
+          if (TF != 2) buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);   // (the symmetric form keeps W^T in registers: nothing reads it back)
+          part = fma(X[i][r], buf_ld(rInn, (unsigned)lg * 8u, (unsigned)(16 * i + 4 * r) * 8u), part);
         }
       }
     }
@@ -815,20 +859,11 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   part += __shfl_xor(part, 32);
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
 
-  if (TF == 4) {
-    // X = D. The covariance update is the Joseph expression for the gain just computed, in the whitened coordinates
-    // of the factor (S = L L^T, H P = L W, V = L^T K^T = W - D):
-    //   P+ = P - K(HP) - (K(HP))^T + K S K^T = P - V^T W - W^T V + V^T V = P - (W - D)^T (W + D) + (W^T D - D^T W),
-    // whose antisymmetric last term vanishes in the lower-triangle + mirror evaluation every pipeline here uses. The
-    // rows of V^T = (W - D)^T become the register operand (own stash read back), W + D the LDS operand (below).
-#pragma unroll
-    for (int i = 0; i < NBM; ++i) {
-      if (i < nb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X[i][r] = K[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldk] - X[i][r];
-      }
-    }
-  }
+  // TF == 4: X = V now. The covariance update is the Joseph expression for the gain just computed, in the whitened
+  // coordinates of the factor (S = L L^T, H P = L W, V = L^T K^T = W - D):
+  //   P+ = P - K(HP) - (K(HP))^T + K S K^T = P - V^T W - W^T V + V^T V = P - (W - D)^T (W + D) + (W^T D - D^T W),
+  // whose antisymmetric last term drops out of the lower-triangle + mirror evaluation every pipeline here uses. The rows
+  // of V^T = (W - D)^T are the register operand, W + D = 2 W - V the LDS operand (below).
 
   if (TF == 3) {
     // ---- the whole covariance update on the gain in registers (expanded Joseph form, see the launcher's comment):
@@ -888,7 +923,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     for (int i = 0; i < NBM; ++i) {
       if (i < nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) X[i][r] = fma(2.0, PHT[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldpht], -X[i][r]);
+        for (int r = 0; r < 4; ++r) X[i][r] = fma(2.0, buf_ld(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u), -X[i][r]);
       }
     }
   }
@@ -907,6 +942,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   if (TF == 4) {
     // ---- P+ = P - (W - D)^T (W + D) in place: W arrives from the stash by DMA, the owner waves turn it into W + D
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
+    if (XIVO_ABL == 1) return;
     double* Pio = g.T + (long)filt * g.strideT;
     sym_tiles_from_regs<NBM, false, true, true>(X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
                                                 live, c0 >> 4, wave, lane);
@@ -1127,6 +1163,7 @@ int launch_trsm_lds_tf(const TrsmArgs& g_in, hipStream_t stream) {
     lds = 160 * 1024;
     g.t_jbp = (int)(lds / 2 / ((size_t)nb * 4 * 64 * sizeof(double)));   // two buffers
     if (g.t_jbp > 16) g.t_jbp = 16;
+    if (XIVO_ABL == 10) g.t_jbp = 2;
   }
   static bool attr_set = false;
   if (!attr_set) {
