@@ -7,9 +7,10 @@ Workload = BASELINE.json's metric point: state dim 250, 80 features (M = 160),
 fp64, XIVO row sparsity, inputs resident in HBM before the timed region. Every
 step hands the dense H / inn / diagR of every filter over again (H changes with
 every camera frame, src/update.cpp:129-138): the dense -> row-pair compression is
-inside the timed step. `value` is the ALL-fp64 rate (XIVO_HIP_FLAG_FP64_CORR); the
-library's default mode is timed next to it (`value_mixed`: the same all-fp64 kernels
-at this size, the fp32 correction product only where the in-solve update does not apply).
+inside the timed step. `value` is the library's default mode: every product in fp64
+(no fp32 instruction runs unless XIVO_HIP_FLAG_FP32_CORR / _FP32_COV ask for one);
+`value_mixed` times the opt-in fp32 correction product next to it (the same all-fp64
+kernels wherever the in-solve covariance update applies).
 
 `python bench.py --gpus N` without a launcher spawns its N ranks itself.
 
@@ -54,6 +55,7 @@ def cpu_baseline(N, F, seconds=12.0):
     if ref is not None:
         fn = lambda b: ref.update_joseph(H[b], P[b], inn[b], dR[b])
         kind, what, cores = "port", "oracle/_ref: Eigen-3.3.9 expression-faithful driver of estimator.cpp:1257-1288, -O3, 1 thread", 1
+        flags = ref_binding.build_flags()
     else:
         import xivo_oracle as orc
         try:
@@ -63,6 +65,7 @@ def cpu_baseline(N, F, seconds=12.0):
             pass
         fn = lambda b: orc.update_joseph(H[b], P[b], inn[b], dR[b])
         kind, what, cores = "port", "oracle/xivo_oracle.py numpy restatement, BLAS pinned to 1 thread", 1
+        flags = "numpy " + np.__version__ + " (LAPACK / BLAS of the wheel)"
     fn(0)
     n = 0
     t0 = time.perf_counter()
@@ -71,7 +74,7 @@ def cpu_baseline(N, F, seconds=12.0):
         n += 1
     dt = time.perf_counter() - t0
     out = {"value": n / dt, "unit": "updates/s", "cores": cores, "kind": kind,
-           "sample": f"{n} updates of (N={N}, M={M}) in {dt:.1f}s; {what}"}
+           "sample": f"{n} updates of (N={N}, M={M}) in {dt:.1f}s; {what}", "flags": flags}
     # mode (ii) of BASELINE.md section 3: one independent filter per host core on all cores
     try:
         import multiprocessing as mp
@@ -155,6 +158,43 @@ def parity_check(ctx, step, B, uniq, F, P, H, inn, dR, gate, no_gating):
     return out
 
 
+def parity_last_step(ctx, n_steps, B, uniq, F, P, H, inn, dR, gate, no_gating):
+    """The state the TIMED loop left behind (n_steps updates of the resident covariance with the same measurements, warm-up
+    included) against the oracle applying the same n_steps updates one after the other - gating re-evaluated on the shrinking
+    covariance every time. Catches anything that only goes wrong after the first step (stale buffers, state carried between
+    launches). 4 filters spread over the launch; same tolerances as the one-step check."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import xivo_oracle as orc
+    R, th, mult, min_inl = gate
+    picks = sorted({b for b in (0, B // 2 + 3, B - 9, B - 1) if 0 <= b < B})
+    worst_P = worst_dx = 0.0
+    mask_equal = True
+    gm = ctx.get_gate(F, B)[0] if (not no_gating and F > min_inl) else None
+    for b in picks:
+        u = b % uniq
+        Pc = P[u].copy()
+        e_ref = None
+        for _ in range(n_steps):
+            rows = np.ones(2 * F, dtype=bool)
+            if gm is not None:
+                d = orc.mh_distances(H[u].reshape(F, 2, -1), Pc, inn[u].reshape(F, 2), R)
+                m = orc.mh_gate(d, th, mult, min_inl)[0]
+                rows = np.repeat(m, 2)
+            e_ref, Pc, _ = orc.update_joseph(H[u][rows], Pc, inn[u][rows], dR[u][rows])
+        if gm is not None:
+            mask_equal = mask_equal and bool(np.array_equal(gm[b], m))
+        Pn = ctx.download_P(b0=b, nb=1)[0]
+        err = ctx.get_err(b0=b, nb=1)[0]
+        worst_P = max(worst_P, float(np.linalg.norm(Pn - Pc) / np.linalg.norm(Pc)))
+        worst_dx = max(worst_dx, float(np.linalg.norm(err - e_ref) / np.linalg.norm(e_ref)))
+    ok = worst_P < 1e-6 and worst_dx < 1e-8 and mask_equal
+    out = {"ok": bool(ok), "updates_in_a_row": n_steps, "filters": picks, "rel_fro_P_max": worst_P, "rel_dx_max": worst_dx,
+           "inlier_masks_equal": mask_equal, "tol": {"P": 1e-6, "dx": 1e-8}}
+    if not ok:
+        raise AssertionError(f"bench parity check after the last timed step failed: {out}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,8 +260,13 @@ def main():
             dist.barrier()
         dt = max_over_ranks(dist, dt_rank)
         per_rank = gather_over_ranks(dist, args.batch * args.steps / dt_rank)
+        from xivo_amd.shard import bind_rank, gather_objects
+        aff = bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), None, None)
+        per_rank_parity = gather_objects(dist, {"rank": rank, "ok": None, "skipped": "dry run: no device work"})
+        per_rank_aff = gather_objects(dist, {k: aff.get(k) for k in ("numa_node", "n_cpus", "bound", "omp_threads")})
         if rank == 0:
             print(json.dumps({"metric": "EKF updates/sec (state dim 250, 80 feats) @1 GPU; % MFMA roofline", "dry_run": True,
+                              "per_rank_parity": per_rank_parity, "per_rank_affinity": per_rank_aff,
                               "value": None, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                               "per_rank_updates_per_s": per_rank, "ranks_reporting": len(per_rank)}))
@@ -231,16 +276,20 @@ def main():
         return
 
     from xivo_amd import synth
-    from xivo_amd.lib import Context, FLAG_PROFILE, FLAG_FP64_CORR, load_library
+    from xivo_amd.lib import Context, FLAG_PROFILE, FLAG_FP32_CORR, load_library
 
     # one rank per GPU; the modulo only matters when more ranks than GPUs are launched (smoke-testing the
     # N>1 path on a 1-GPU box) - on the 8-GPU node it is the identity
     ndev = max(1, load_library().xivo_hip_device_count())
     device = local_rank % ndev
+    # one rank per GPU: stay on the cores (and the memory) of the GPU's NUMA node, size the C++ host side's OpenMP team to
+    # this rank's share of the cores
+    from xivo_amd.shard import bind_rank, gather_objects
+    affinity = bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), ndev, load_library().xivo_hip_device_numa_node)
     N, F, B = args.state_dim, args.features, args.batch
     R_VIS, MH_THRESH, MH_MULT, MIN_INL = 2.25, 5.991, 1.1, 5   # cfg/tumvi_cam0.json / estimator.cpp:366-369
     base_flags = (0 if args.no_profile else FLAG_PROFILE) | args.flags
-    flags = base_flags | FLAG_FP64_CORR      # headline: every product in fp64
+    flags = base_flags                       # headline = library default: every product in fp64
     uniq = min(B, 64)
     if args.level == "G":
         # layout-faithful scene (SURVEY 8d "G-level"): 8 groups, 60 in-state features -> N = 23 + 48 + 180 = 251
@@ -381,17 +430,24 @@ def main():
         dt_rank_ = time.perf_counter() - t0
         return dt_rank_, gpu_ms_, (ctx.profile_get() if (flags & FLAG_PROFILE) else {})
 
-    # ---- headline: every product of the update in fp64 (XIVO_HIP_FLAG_FP64_CORR)
+    # ---- headline: the library default - every product of the update in fp64
     dt_rank, gpu_ms, prof = timed(args.warmup)
     dt = max_over_ranks(dist, dt_rank)
     per_rank = gather_over_ranks(dist, B * args.steps / dt_rank)
     status = ctx.get_status(check=False)
     sparse_path = ctx.last_path() == 1
+    # the state the timed loop left behind against the oracle doing the same number of updates in a row (every rank, its
+    # own filters)
+    parity_last = None
+    if args.level == "S" and not args.no_parity_check:
+        parity_last = parity_last_step(ctx, args.warmup + args.steps, B, uniq, F, P, H, inn, dR,
+                                       (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating)
 
-    # ---- second figure: default library mode - the Joseph correction product G K^T on the fp32 MFMA
+    # ---- second figure: opt-in XIVO_HIP_FLAG_FP32_CORR - the Joseph correction product G K^T on the fp32 MFMA (only
+    # where the re-associated stand-alone tail runs: beyond N = 256 / M = 176)
     mixed = None
-    if not args.no_mixed and sparse_path and not (args.flags & FLAG_FP64_CORR):
-        ctx.set_flags(base_flags)
+    if not args.no_mixed and sparse_path and not (args.flags & FLAG_FP32_CORR):
+        ctx.set_flags(base_flags | FLAG_FP32_CORR)
         ctx.restore_P()
         dt_m, gpu_ms_m, prof_m = timed(min(args.warmup, 2))
         dt_m = max_over_ranks(dist, dt_m)
@@ -417,15 +473,22 @@ def main():
                 "what": "XIVO_HIP_FLAG_SYMMETRIC_FORM: S = L L^T, W = L^-1 (H P) (forward substitution only), dx = W^T L^-1 inn, "
                         "P+ = P - W^T W - the value of the Joseph expression for the optimal gain, all fp64; opt-in, the "
                         "reference codes the Joseph form (= `value`)"}
-        if not args.no_parity_check and rank == 0:
+        if not args.no_parity_check:
             symm["parity_check"] = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating)
         ctx.set_flags(flags)
 
     # ---- parity at the benchmarked batch: one step from the initial P, filters spread over the launch
     # (first / last, both sides of an XCD group of 8, mid batch) against the oracle - checker only, outside the timing
     parity = None
-    if args.level == "S" and not args.no_parity_check and rank == 0:
+    if args.level == "S" and not args.no_parity_check:      # every rank checks its own GPU's results
         parity = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating)
+    per_rank_parity = gather_objects(dist, {"rank": rank, "device": device,
+                                            "ok": None if parity is None else bool(parity["ok"] and (parity_last or {"ok": True})["ok"]),
+                                            "rel_fro_P_max": None if parity is None else parity["rel_fro_P_max"],
+                                            "rel_dx_max": None if parity is None else parity["rel_dx_max"],
+                                            "last_step_rel_fro_P_max": None if parity_last is None else parity_last["rel_fro_P_max"]})
+    per_rank_aff = gather_objects(dist, {k: affinity.get(k) for k in ("numa_node", "n_cpus", "bound", "omp_threads", "error")
+                                         if affinity.get(k) is not None})
 
     peak_meas = ctx.bench_mfma_peak() if rank == 0 else None
 
@@ -495,7 +558,12 @@ def main():
                         "pipeline_algorithmic_gbs": sum(v["bytes_per_launch"] * v["launches"] for v in prof.values())
                                                     / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
                         "pipeline_f_alg_tflops": f_alg(N, M) * value / world / 1e12,
-                        "pipeline_frac": f_alg(N, M) * value / world / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+                        "pipeline_frac": f_alg(N, M) * value / world / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                        "pipeline_frac_note": "F_alg = the reference's AS-CODED dense flop count (BASELINE.md 2: 4N^3 + 8MN^2 + 4M^2N + M^3/3) "
+                                              "times updates/s over the fp64 matrix peak. It can exceed 1: the device path does not execute "
+                                              "that work (H's 18 of N columns, symmetric halves, no KH - I and no N^3 product); `frac` above "
+                                              "is the dominant kernel's own algorithmic flops (true N, M - not the padded sizes) over its "
+                                              "measured time"}
         out = {
             "metric": "EKF updates/sec (state dim 250, 80 feats) @1 GPU; % MFMA roofline",
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -515,8 +583,8 @@ def main():
                        "hand_over": ("dense H/inn/diagR (column-major, resident in HBM) -> row-pair compressed rows, "
                                      "every step, inside the timed region (stage stack_H)") if args.level == "S" else
                                     "Jacobians -> compressed rows on device every step",
-                       "precision": {"value": "all fp64: storage, every product, factorisation, solve (XIVO_HIP_FLAG_FP64_CORR)",
-                                     "value_mixed": "library default (no flag): the same all-fp64 kernels wherever the in-solve "
+                       "precision": {"value": "library default = all fp64: storage, every product, factorisation, solve",
+                                     "value_mixed": "opt-in XIVO_HIP_FLAG_FP32_CORR: the same all-fp64 kernels wherever the in-solve "
                                                     "covariance update applies (N <= 256, M <= 176; see mixed.same_kernels_as_value); "
                                                     "elsewhere the Joseph correction product G K^T (G = O(eps cond(S)) residual) runs "
                                                     "on v_mfma_f32_16x16x4_f32 with G itself and -T in fp64"},
@@ -529,6 +597,9 @@ def main():
             "per_rank_updates_per_s": per_rank,
             "per_rank_min_max": [min(per_rank), max(per_rank)],
             "parity_check": parity,
+            "parity_check_last_timed_step": parity_last,
+            "per_rank_parity": per_rank_parity,
+            "per_rank_affinity": per_rank_aff,
             "roofline": roofline,
             "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
         }

@@ -76,12 +76,8 @@ enum {
    * XIVO_HIP_FLAG_STANDALONE_TAIL) or in the re-associated form above. A denser H (OOS rows, arbitrary input)
    * takes the as-coded dense path automatically. This flag forces the dense as-coded path for any H. */
   XIVO_HIP_FLAG_DENSE_H = 64u,
-  /* Re-associated form of the sparse-H pipeline (stand-alone kernels: shapes beyond N = 256 / M = 176, or
-   * XIVO_HIP_FLAG_STANDALONE_TAIL): P+ = -T + G K^T with -T = P - K(HP) (fp64) and the Joseph correction
-   * G K^T, G = T H^T + K R, which is O(eps * cond(S)) relative to P because K is the gain of this very S.
-   * By default that correction PRODUCT runs on the fp32 MFMA (G itself - a cancellation - and -T stay
-   * fp64): its rounding adds <= 1e-7 |G K^T| to P+, orders of magnitude below the fp64 rounding of -T.
-   * This flag keeps the correction product in fp64 as well. (The in-solve update is all fp64 either way.) */
+  /* Accepted and ignored (round 3): every product is fp64 unless XIVO_HIP_FLAG_FP32_CORR / XIVO_HIP_FLAG_FP32_COV ask
+   * for an fp32 one. (Rounds 1-2: this flag kept the Joseph correction product of the re-associated form in fp64.) */
   XIVO_HIP_FLAG_FP64_CORR = 128u,
   /* Symmetric ("square-root") form of the gain and covariance: S = L L^T, W = L^-1 (H P) by forward substitution only,
    *   dx = W^T (L^-1 inn),   P+ = P - W^T W
@@ -103,7 +99,14 @@ enum {
    * triangular products on the gain to rebuild S K^T - instead of the default whitened evaluation of the same Joseph
    * expression, P+ = P - (W - D)^T (W + D) with W = L^-1 H P and D = W - L^T K^T taken from the backward substitution's
    * own partial sums. Same tolerances; 1.3 x the MFMA work. A/B knob. */
-  XIVO_HIP_FLAG_EXPANDED_JOSEPH = 1024u
+  XIVO_HIP_FLAG_EXPANDED_JOSEPH = 1024u,
+  /* Opt-in, re-associated form of the sparse-H pipeline only (stand-alone kernels: shapes beyond N = 256 / M = 176, or
+   * XIVO_HIP_FLAG_STANDALONE_TAIL): P+ = -T + G K^T with -T = P - K(HP) (fp64) and the Joseph correction G K^T,
+   * G = T H^T + K R, which is O(eps * cond(S)) relative to P because K is the gain of this very S. With this flag that
+   * correction PRODUCT runs on the fp32 MFMA (G itself - a cancellation - and -T stay fp64): its rounding adds
+   * <= 1e-7 |G K^T| to P+, orders of magnitude below the fp64 rounding of -T. Without it (the default since round 3)
+   * no fp32 instruction takes part in an update. */
+  XIVO_HIP_FLAG_FP32_CORR = 2048u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,
@@ -171,6 +174,10 @@ const char* xivo_hip_strerror(int status);
 int xivo_hip_sync(xivo_hip_ctx* ctx);
 /* number of visible HIP devices (0 if none / on error) */
 int xivo_hip_device_count(void);
+/* NUMA node of the host cores / memory closest to `device` (from the sysfs entry of its PCI function), -1 if unknown.
+ * The reference runs one estimator per process (src/estimator.cpp:26); with one process per GPU the launcher uses this to
+ * keep each rank's host side (hand-over staging, BatchEstimator's OpenMP team) on its GPU's socket. */
+int xivo_hip_device_numa_node(int device);
 int xivo_hip_set_flags(xivo_hip_ctx* ctx, unsigned flags);
 
 /* ---- covariance residency (Estimator::P_, src/estimator.h:423; a17) --- */

@@ -225,4 +225,20 @@ def load():
     if not os.path.exists(path):
         raise FileNotFoundError("oracle/_ref not built (needs /root/reference; run oracle/ref/Makefile)")
     _REF = Ref(path)
+    _REF.path = path
     return _REF
+
+
+def build_flags():
+    """The exact compiler line of the loaded oracle/_ref variant (oracle/ref/Makefile), for bench.py's cpu_baseline.flags."""
+    ref = load()
+    march = "x86-64-v4" if ref.path.endswith("_v4.so") else "x86-64-v3"
+    flags = "-std=c++17 -O3 -DNDEBUG -DEIGEN_INITIALIZE_MATRICES_BY_ZERO -DSOPHUS_USE_BASIC_LOGGING -fPIC -shared"
+    try:
+        for line in open(os.path.join(_HERE, "ref", "Makefile")):
+            if line.startswith("FLAGS ="):
+                flags = line.split("=", 1)[1].strip().rstrip("\\").strip()
+    except OSError:
+        pass
+    return (f"g++ {flags} -march={march} (Eigen 3.3.9 + Sophus from the reference tree; the reference's own build uses "
+            "-O3 -march=native -DNDEBUG, CMakeLists.txt:25-26,32 - a native build cannot travel to another host CPU)")

@@ -118,3 +118,36 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     assert len(out["per_rank_updates_per_s"]) == 2
     # the job time is the slower rank's (rank 1 sleeps twice as long per step in the dry path)
     assert out["ms_per_step"] >= 2.0
+    # self-verifying multi-rank line: one parity record and one affinity record per rank, gathered on rank 0
+    assert [p["rank"] for p in out["per_rank_parity"]] == [0, 1]
+    aff = out["per_rank_affinity"]
+    assert len(aff) == 2 and all(a["bound"] and a["omp_threads"] >= 1 for a in aff)
+    assert sum(a["n_cpus"] for a in aff) <= (os.cpu_count() or 1)        # the ranks share the cores, they do not overlap
+
+
+def test_eight_rank_dry_run_and_affinity_plan(tmp_path):
+    """The 8-GPU launch of BASELINE config 5, as far as a CPU box can take it: eight ranks rendezvous, every rank reports,
+    ranks > 0 log to files; and the core plan for a two-socket node (GPUs 0-3 on node 0, 4-7 on node 1)."""
+    import json
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    from xivo_amd.shard import plan_affinity
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    node_cpus = {0: list(range(0, 96)), 1: list(range(96, 192))}
+    plans = [plan_affinity(r, 8, nodes, node_cpus, list(range(192))) for r in range(8)]
+    assert all(len(p["cpus"]) == 24 and p["ranks_on_node"] == 4 for p in plans)
+    assert all(set(plans[r]["cpus"]) <= set(node_cpus[nodes[r]]) for r in range(8))
+    allc = [c for p in plans for c in p["cpus"]]
+    assert len(allc) == len(set(allc)) == 192                             # disjoint and complete
+    unknown = plan_affinity(3, 8, [-1] * 8, {}, list(range(64)))
+    assert unknown["numa_node"] == -1 and unknown["cpus"] == list(range(24, 32))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["XIVO_RANK_LOG_DIR"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and len(out["per_rank_parity"]) == 8 and len(out["per_rank_affinity"]) == 8
+    assert sorted(f for f in os.listdir(tmp_path)) == [f"rank{i}.log" for i in range(1, 8)]

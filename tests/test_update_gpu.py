@@ -298,14 +298,14 @@ def test_sparse_path_with_structural_zero_in_common_column(built):
 
 @pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (400, 150), (203, 30), (37, 3), (64, 8), (100, 1)])   # odd / even block counts, both register-kernel widths
 def test_fp32_correction_product_is_invisible(built, N, F):
-    """Sparse-H pipeline: P+ = -T + G K^T with the correction product G K^T on the fp32 MFMA (default) vs in
-    fp64 (XIVO_HIP_FLAG_FP64_CORR). G is the O(eps) residual of the gain equation, so the two agree to ~1e-15
+    """Sparse-H pipeline, re-associated form: P+ = -T + G K^T with the correction product G K^T on the fp32 MFMA
+    (XIVO_HIP_FLAG_FP32_CORR, opt-in since round 3) vs in fp64 (default). G is the O(eps) residual of the gain equation, so the two agree to ~1e-15
     relative and both sit at the fp64 rounding level from the oracle - far inside TOL_P."""
-    from xivo_amd.lib import FLAG_FP64_CORR
+    from xivo_amd.lib import FLAG_FP32_CORR, FLAG_STANDALONE_TAIL
     B = 3
     P, H, inn, dR = synth.s_level(N, F, B, seed=91)
     outs = []
-    for flags in (0, FLAG_FP64_CORR):
+    for flags in (FLAG_FP32_CORR | FLAG_STANDALONE_TAIL, FLAG_STANDALONE_TAIL):
         with Context(N, 2 * F, B, flags=flags) as ctx:
             ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
             assert ctx.last_path() == 1
@@ -440,11 +440,11 @@ import numpy as np
 import xivo_oracle as orc
 from helpers import rel_fro
 from xivo_amd import synth
-from xivo_amd.lib import Context, FLAG_FP64_CORR, FLAG_PROFILE
+from xivo_amd.lib import Context, FLAG_FP32_CORR, FLAG_PROFILE
 out = {{}}
 for (N, F) in [(250, 80), (203, 30), (37, 3)]:
     P, H, inn, dR = synth.s_level(N, F, 3, seed=5)
-    for flags in (0, FLAG_FP64_CORR):
+    for flags in (FLAG_FP32_CORR, 0):
         with Context(N, 2 * F, 3, flags=flags | FLAG_PROFILE) as ctx:
             ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
             Pn = ctx.download_P(); err = ctx.get_err(); prof = ctx.profile_get()
@@ -480,9 +480,9 @@ def test_fallback_pipelines_behind_the_knobs(built, knob):
         else:
             assert "gemm_AP" not in k and k["trsm_gain"].endswith(",1>")
     # which P+ kernel: registers (all fp64, unless knocked out) or the tiled product
-    from xivo_amd.lib import FLAG_FP64_CORR
-    k64 = res["250,80,%d" % FLAG_FP64_CORR]["kernels"]["gemm_Pnew"]
-    k32 = res["250,80,0"]["kernels"]["gemm_Pnew"]
+    from xivo_amd.lib import FLAG_FP32_CORR
+    k64 = res["250,80,0"]["kernels"]["gemm_Pnew"]
+    k32 = res["250,80,%d" % FLAG_FP32_CORR]["kernels"]["gemm_Pnew"]
     assert k32.startswith("gemm_nt_f64_kernel") and "float" in k32
     assert k64.startswith("gemm_nt_f64_kernel" if knob == "XIVO_HIP_NO_PNEW_REG" else "pnew_reg_f64_kernel")
 

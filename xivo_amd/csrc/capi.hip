@@ -359,6 +359,22 @@ int xivo_hip_device_count(void) {
   return n;
 }
 
+// NUMA node of the host memory / cores next to `device` (sysfs of its PCI function), -1 when unknown: the launcher binds
+// one rank per GPU to that node's cores (xivo_amd/shard.py) - eight ranks of an 8-GPU node must not pile up on socket 0
+int xivo_hip_device_numa_node(int device) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return -1;
+  for (char* q = bdf; *q; ++q) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+
 int xivo_hip_sync(xivo_hip_ctx* c) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c) return XIVO_HIP_ERR_INVALID;
@@ -597,9 +613,9 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
     const bool p_here = !full && trsm_forms_T(Mp, Np);
     if (p_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.skip_status = c->status + b0; }
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label), p_here ? 2 : 0);
-    const double outs = 0.5 * Np * (Np + 1.0);
-    StageTimer st(c, ST_TRSM, (1.0 * Mp * Mp * Np + (p_here ? 2.0 * outs * Mp : 0.0)) * B, label,
-                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (p_here ? outs + (double)Np * Np : 0.0)));
+    const double outs = 0.5 * Np * (Np + 1.0), Nf = c->N, Mf = c->M;
+    StageTimer st(c, ST_TRSM, (1.0 * Mf * Mf * Nf + (p_here ? Nf * (Nf + 1.0) * Mf : 0.0)) * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + (p_here ? 1.0 : 2.0) * Np * Mp + (p_here ? outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
     if (p_here) return XIVO_HIP_OK;
   }
@@ -639,13 +655,15 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   for (int b = b0; b < b0 + B; ++b) nc_max = c->ell_nc_h[b] > nc_max ? c->ell_nc_h[b] : nc_max;
   int pw_max = 1;
   for (int b = b0; b < b0 + B; ++b) pw_max = c->ell_pw_h[b] > pw_max ? c->ell_pw_h[b] : pw_max;
-  const double nnz_flops = 2.0 * Mp * 21.0;   // per contiguous-index value: 21 structural non-zeros per row
+  // algorithmic flops are counted on the TRUE sizes N, M (the padded Np, Mp only size the launches and the bytes)
+  const double Nf = c->N, Mf = c->M;
+  const double nnz_flops = 2.0 * Mf * 21.0;   // per contiguous-index value: 21 structural non-zeros per row
   int rc;
   {
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
     a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
     char label[64]; ell_kernel_label(ELL_HP, a, label, sizeof(label));
-    StageTimer st(c, ST_HP, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
+    StageTimer st(c, ST_HP, nnz_flops * Nf * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_HP, a, c->stream));
   }
   {
@@ -653,7 +671,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max;
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
-    StageTimer st(c, ST_S, nnz_flops * Mp * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
+    StageTimer st(c, ST_S, nnz_flops * Mf * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_S, a, c->stream));
   }
   if (gate) {
@@ -674,7 +692,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B);
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
-    StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
+    StageTimer st(c, ST_CHOL, Mf * Mf * Mf / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
   }
   if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
@@ -695,12 +713,14 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : 0));
-    const double t_outs = 0.5 * Np * (Np + 1.0);
-    // algorithmic flops: the two triangular solves (M^2 N each), the symmetric N x N x M product (lower triangle), and for
-    // the expanded form the two triangular products of K L L^T; the whitened form's residual blocks are 2 * 16 * M * N
-    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (t_here ? 2.0 * t_outs * Mp : 0.0) +
-                               (all_here ? (jform == 2 ? 32.0 * Mp * Np : 2.0 * Mp * Mp * Np) : 0.0)) * B, label,
-                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (t_here ? t_outs + (double)Np * Np : 0.0)));
+    const double t_outs = 0.5 * Np * (Np + 1.0), t_outs_f = 0.5 * Nf * (Nf + 1.0);
+    // algorithmic flops (true N, M): the two triangular solves (M^2 N each), the symmetric N x N x M product (lower
+    // triangle), and for the expanded form the two triangular products of K L L^T; the whitened form's residual blocks
+    // are 2 * 16 * M * N. Algorithmic bytes: the factor, P H^T once, P's lower triangle in, P out (the gain is not stored)
+    StageTimer st(c, ST_TRSM, (2.0 * Mf * Mf * Nf + (t_here ? 2.0 * t_outs_f * Mf : 0.0) +
+                               (all_here ? (jform == 2 ? 32.0 * Mf * Nf : 2.0 * Mf * Mf * Nf) : 0.0)) * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + (all_here && jform == 2 ? 1.0 : 2.0) * Np * Mp +
+                             (t_here ? t_outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
     if (all_here) return XIVO_HIP_OK;
   }
@@ -717,7 +737,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sA; a.ldo = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
     // G only ever feeds the fp32 correction product: keep it in HBM as float (slab form only)
-    g_f32 = !(c->flags & XIVO_HIP_FLAG_FP64_CORR) && ell_uses_slab_form(a);
+    g_f32 = (c->flags & XIVO_HIP_FLAG_FP32_CORR) && ell_uses_slab_form(a);
     if (g_f32) a.strideOut = 2 * c->sA;
     const int gmode = g_f32 ? ELL_GF : ELL_G;
     char label[64]; ell_kernel_label(gmode, a, label, sizeof(label));
@@ -736,7 +756,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     rc = XIVO_HIP_OK;
   } else {  // P+ = G K^T - T   (lower triangle + mirror)
     GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
-    x.fp32 = (c->flags & XIVO_HIP_FLAG_FP64_CORR) ? 0 : 1;   // correction product on the fp32 MFMA, T added in fp64
+    x.fp32 = (c->flags & XIVO_HIP_FLAG_FP32_CORR) ? 1 : 0;   // opt-in: correction product on the fp32 MFMA, T added in fp64
     x.a_f32 = g_f32 ? 1 : 0;
     x.skip = c->status + b0;   // S not positive definite: P of that filter stays the prior (reported through xivo_hip_get_status)
     rc = gemm(c, ST_PNEW, B, Np, Np, G, g_f32 ? 2 * c->sA : c->sA, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,

@@ -2300,7 +2300,11 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters)
   const long long t0 = clock64();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    // accumulators pinned to VGPRs: left to itself the compiler parks the accumulators of a small kernel like this one in
+    // AGPRs, and v_mfma_f64_16x16x4_f64 with an AGPR destination issues at 50 TFLOP/s instead of 77 on this part
+    // (scripts/mfma_agpr_probe.hip) - rounds 1 and 2 took that for the instruction's ceiling. The update kernels keep
+    // their accumulators in VGPRs (checked in the ISA), so 77 TFLOP/s = 98 % of the datasheet is the ceiling that applies.
+    for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
   }
   double s = 0.0;
 #pragma unroll

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 #include <string>
@@ -15,8 +16,18 @@ namespace xivo {
 namespace hip {
 
 namespace {
-// a microsecond of book-keeping per filter: a handful of threads is all the loop can use (256 made it 8x slower)
-constexpr int kThreads = 8;
+// a microsecond of book-keeping per filter: a handful of threads is all the loop can use (256 made it 8x slower) - and
+// with one process per GPU never more than this rank's share of the host cores: the launcher (xivo_amd/shard.py:bind_rank)
+// sets OMP_NUM_THREADS = min(8, cores / ranks)
+static int team_size() {
+  static const int n = [] {
+    const char* e = std::getenv("OMP_NUM_THREADS");
+    const int v = e ? std::atoi(e) : 8;
+    return v < 1 ? 1 : (v > 8 ? 8 : v);
+  }();
+  return n;
+}
+#define kThreads team_size()
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }

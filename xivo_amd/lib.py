@@ -17,6 +17,7 @@ FLAG_FP64_CORR = 128
 FLAG_SYMMETRIC_FORM = 256
 FLAG_STANDALONE_TAIL = 512
 FLAG_EXPANDED_JOSEPH = 1024
+FLAG_FP32_CORR = 2048
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
 
@@ -139,7 +140,8 @@ _SIGS = {
     "xivo_hip_bench_mfma_peak": [C.c_void_p, C.POINTER(C.c_double)],
 }
 # every symbol include/xivo_hip.h declares (tests check the library exports them all)
-ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile", "xivo_hip_device_count"])
+ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile", "xivo_hip_device_count",
+                                        "xivo_hip_device_numa_node"])
 
 
 def load_library():
@@ -159,6 +161,8 @@ def load_library():
         fn.restype = C.c_int
     lib.xivo_hip_device_count.argtypes = []
     lib.xivo_hip_device_count.restype = C.c_int
+    lib.xivo_hip_device_numa_node.argtypes = [C.c_int]
+    lib.xivo_hip_device_numa_node.restype = C.c_int
     lib.xivo_hip_destroy.argtypes = [C.c_void_p]
     lib.xivo_hip_destroy.restype = None
     lib.xivo_hip_strerror.argtypes = [C.c_int]
