@@ -16,6 +16,12 @@ CASES = [  # (N, F) -> M = 2F ; BASELINE.json configs + TUM-VI default build + r
     (176, 88),    # Mp = Np = 176: the largest single-workgroup triangle of the block-list kernel
     (192, 96),    # first size that falls back to strip tiles / the streamed solve
     (600, 20),    # source too wide for the LDS slab: gather form of the compressed-row kernels
+    # states wider than one workgroup / factors beyond the LDS: whitened outputs (V^T, Y^T) from the chunked or streamed
+    # solve + one tiled product P - V^T Y (round 3; before: T, G, P+ from three stand-alone kernels)
+    (300, 60),    # two 256-column chunks, factor in LDS (10 block rows)
+    (300, 88),    # ... eleven block rows: streamed instead of the LDS kernel
+    (512, 128),   # M = 256: sixteen block rows, streamed; four 128-column chunks
+    (848, 125),   # the reference's largest contemplated build (125 features, 75 groups: src/CMakeLists.txt:27-28)
 ]
 
 

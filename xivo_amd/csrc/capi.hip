@@ -697,7 +697,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
   const bool t_full = full || getenv("XIVO_HIP_T_FULL");
-  bool t_done = false;
+  bool t_done = false, wh_out = false;
   {
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
@@ -709,10 +709,17 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;   // A/B knob
     const bool all_here = t_here && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);   // (both precision modes: all fp64 and faster than the fp32 correction product)
     const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;   // 2: whitened form (default), 1: P - K(2HP - L L^T K^T)
+    // shapes one workgroup does not hold (N > 256 or M > 176): the same whitened evaluation with the product outside the
+    // solve kernel - V^T = (W - D)^T and Y^T = (W + D)^T leave the (chunked / streamed) solve, P+ = P - V^T Y is one tiled
+    // symmetric product. Replaces T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T (two products and a pass over T) there.
+    static const bool no_trsm_t = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: the round-1 stand-alone tail for every shape
+    wh_out = !t_here && !t_full && jform == 2 && !no_joseph && !no_trsm_t &&
+             !(c->flags & (XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_FP32_CORR));
+    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; }
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : 0));
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : (wh_out ? 5 : 0)));
     const double t_outs = 0.5 * Np * (Np + 1.0), t_outs_f = 0.5 * Nf * (Nf + 1.0);
     // algorithmic flops (true N, M): the two triangular solves (M^2 N each), the symmetric N x N x M product (lower
     // triangle), and for the expanded form the two triangular products of K L L^T; the whitened form's residual blocks
@@ -723,6 +730,10 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
                              (t_here ? t_outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
     if (all_here) return XIVO_HIP_OK;
+  }
+  if (wh_out) {   // P+ = P - V^T Y in place (V^T in the K buffer, Y^T in the G buffer), lower triangle + mirror
+    GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
+    return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, G, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
   }
   if (!t_done) {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
      // triangle is computed and mirrored (XIVO_HIP_FLAG_FULL_PNEW: all of it)
@@ -825,6 +836,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
   }
   if ((c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) && !f32) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
+  bool wh_out = false;
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
@@ -835,13 +847,20 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
     const bool all_here = (c->flags & XIVO_HIP_FLAG_REASSOC) && !f32 && !full && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL) && trsm_forms_T(Mp, Np);
     const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
+    wh_out = (c->flags & XIVO_HIP_FLAG_REASSOC) && !all_here && !f32 && !full && !no_joseph && jform == 2 &&
+             !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);
+    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; }
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : 0);
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (wh_out ? 5 : 0));
     const double t_outs = 0.5 * Np * (Np + 1.0);
     StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (all_here ? 2.0 * t_outs * Mp + (jform == 2 ? 32.0 * Mp * Np : 2.0 * Mp * Mp * Np) : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (all_here ? t_outs + (double)Np * Np : 0.0)));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
     if (all_here) return XIVO_HIP_OK;
+  }
+  if (wh_out) {   // P+ = P - V^T Y in place, as in the sparse pipeline
+    GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
+    return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, c->A + (long)b0 * c->sA, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
   }
   if (c->flags & XIVO_HIP_FLAG_REASSOC) {
     {  // T = K (HP) - P

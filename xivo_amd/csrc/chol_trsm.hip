@@ -676,7 +676,9 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr int BLK = 16 * 17;
   // TF == 3 needs the diagonal blocks L_kk next to their inverses: in slots of their own while the LDS has room (<= 10
   // block rows), else packed into the unused upper triangle + pad row of the inverse's slot (a few selects per read)
-  constexpr bool PACK = (TF == 3 || TF == 4) && NBM > 10;
+  constexpr bool T4 = TF == 4 || TF == 5;   // whitened Joseph form; TF == 5: its outputs V^T, Y^T for a product outside the kernel
+  constexpr bool WOUT = TF == 5;
+  constexpr bool PACK = (TF == 3 || T4) && NBM > 10;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
   const int chunks = (g.Np + 255) / 256;
   const int b = blockIdx.x;
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       const int k = e >> 4, c = e & 15;
       sL[(k * (k + 1) / 2 + k) * BLK + 16 + 17 * c] = LU[(16 * k + c) + (long)(16 * k + c) * ld];
     }
-  } else if (TF == 3 || TF == 4) {
+  } else if (TF == 3 || T4) {
     for (int e = tid; e < nb * 128; e += 1024) {
       const int k = e >> 7, w = e & 127;
       const int r = (w & 7) * 2, c = w >> 3;
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   // forward: L Y = HP
 #pragma unroll
   for (int k = 0; k < NBM; ++k) {
-    if (k < nb && !(TF == 4 && XIVO_ABL == 2)) {
+    if (k < nb && !(T4 && XIVO_ABL == 2)) {
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
       d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     }
   }
   double part = 0.0;
-  if (TF == 4 && XIVO_ABL != 6) {
+  if (T4 && XIVO_ABL != 6) {
     // the forward-substituted columns W^T = (L^-1 H P)^T leave for the stash (the K buffer: the gain itself is never
     // stored by this variant) - the backward substitution below destroys them and the covariance update needs them again
 #pragma unroll
@@ -790,12 +792,12 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   // backward: L^T K^T = Y
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
-    if (k < nb && !g.fwd_only && !(TF == 4 && XIVO_ABL == 2)) {
+    if (k < nb && !g.fwd_only && !(T4 && XIVO_ABL == 2)) {
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
       // TF == 4: W_k comes back from the stash while this step's MFMAs run (requested here, used at the end of the step;
       // the last block row has not been touched yet: it is still in X)
       d4 wk = d4{0.0, 0.0, 0.0, 0.0};
-      if (TF == 4) {
+      if (T4) {
         if (k == nb - 1) wk = X[k];
         else if (XIVO_ABL != 6) {
 #pragma unroll
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
         if (PACK) a = 4 * s + lg >= li ? a : 0.0;
         t = mfma(a, X[k][s], t);
       }
-      if (TF == 4) {
+      if (T4) {
         // D_k = B_k - L_kk^T K^T_k, B_k = W_k - sum_{i>k} L_ik^T K^T_i the right-hand side this step just consumed: the
         // residual of the backward substitution, i.e. W_k - (L^T K^T)_k evaluated with the partial sums already at hand
         // (both evaluations of L^T K^T carry the same rounding bound); it replaces the gain block, whose last uses -
@@ -839,11 +841,20 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
         }
       }
       // TF == 4: V_k = W_k - D_k, the row block of V^T = (W - D)^T - the register operand of the covariance product below
-      if (TF == 4) X[k] = wk - X[k];
+      // (or, for states wider than one workgroup, of the tiled product outside: then Y_k = W_k + D_k leaves for g.Yout here)
+      if (T4) {
+        if (WOUT) {
+          const __amdgpu_buffer_rsrc_t rY = buf_rsrc(g.Yout + (long)filt * g.strideY2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) buf_st(wk[r] + X[k][r], rY, (unsigned)((c0 + li) + lg * g.ldy2) * 8u, (unsigned)((16 * k + 4 * r) * g.ldy2) * 8u);
+        }
+        X[k] = wk - X[k];
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
-  if (TF != 4) {
+  if (!T4) {
 #pragma unroll
     for (int i = 0; i < NBM; ++i) {
       if (i < nb) {
@@ -939,7 +950,19 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
                                           live, c0 >> 4, wave, lane);
     return;
   }
-  if (TF == 4) {
+  if (T4) {
+    if (WOUT) {   // whitened outputs only: V^T replaces the stash, the covariance product runs outside (tiled)
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < NBM; ++i) {
+          if (i < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);
+          }
+        }
+      }
+      return;
+    }
     // ---- P+ = P - (W - D)^T (W + D) in place: W arrives from the stash by DMA, the owner waves turn it into W + D
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
     if (XIVO_ABL == 1) return;
@@ -991,16 +1014,20 @@ __global__ __launch_bounds__(1024) void pnew_reg_f64_kernel(PnewRegArgs g) {
                            g.P + (long)filt * g.strideP, g.ldp, nb, g.Np / 16, g.jbp, live, wave, wave, lane);
 }
 
-// Streaming variant for factors that do not fit LDS (M > 176): the workgroup (8 waves = 128
-// right-hand-side columns, X in registers as above) walks the block columns of L; the column panel
-// of step k+1 - inv(L_kk) plus the blocks L_ik, i > k (forward) or L_ki^T, i < k (backward, read
-// from the mirrored upper triangle) - is fetched global -> registers while step k's MFMAs run and
-// lands in the other half of a double-buffered LDS panel; one barrier per step.
-template <int NBM>
+// Streaming variant for factors that do not fit LDS (M > 176) and for states wider than one workgroup (N > 256): the
+// workgroup (8 waves = 128 right-hand-side columns, X in registers as above) walks the block columns of L. The column
+// panel of step k+1 - inv(L_kk) plus the blocks L_ik, i > k (forward) or L_ki^T, i < k (backward, read from the mirrored
+// upper triangle) - travels global -> LDS by DMA (global_load_lds: no registers; round 2 staged it through 20 VGPRs per
+// thread and the <19> instantiation spilled 1227 of them) while step k's MFMAs run, into the other half of a
+// double-buffered panel; one barrier per step. Blocks sit in LDS as the DMA delivers them - column-major 16 x 16,
+// unpadded - which is conflict-free for every read here (the backward pass reads the mirrored copy, never a transpose).
+// WH = 1: whitened outputs for the covariance update outside the kernel (tiled product P - V^T Y):
+//   after the forward pass W^T goes to the stash (g.K), the backward pass reads W_k back one step before it needs it,
+//   forms D_k = B_k - L_kk^T K^T_k in place and leaves Y_k = W_k + D_k in g.Yout, V_k = W_k - D_k in g.K; dx as usual.
+template <int NBM, int WH>
 __global__ __launch_bounds__(512) void trsm_stream_f64_kernel(TrsmArgs g) {
-  constexpr int BLK = 16 * 17;
-  constexpr int PL = (NBM * 128 + 511) / 512;          // d2 loads per thread per panel
-  extern __shared__ __attribute__((aligned(16))) double sL[];   // [2][NBM][16 x 17]
+  extern __shared__ __attribute__((aligned(16))) double sL[];   // [2][NBM + 1][256]
+  constexpr int PSZ = (NBM + 1) * 256;
   const int chunks = (g.Np + 127) / 128;
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
@@ -1012,10 +1039,15 @@ __global__ __launch_bounds__(512) void trsm_stream_f64_kernel(TrsmArgs g) {
   const int nb = g.Mp / 16;
   const double* __restrict__ LU = g.LU + (long)filt * g.strideLU;
   const double* __restrict__ invD = g.invD + (long)filt * g.strideInvD;
-  const double* __restrict__ PHT = g.PHT + (long)filt * g.stridePHT;
   const long ld = g.ldlu;
   const int c0 = chunk * 128 + wave * 16;
   const bool live = c0 < g.Np;
+  const __amdgpu_buffer_rsrc_t rPHT = buf_rsrc(g.PHT + (long)filt * g.stridePHT), rK = buf_rsrc(g.K + (long)filt * g.strideK),
+                               rInn = buf_rsrc(g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn),
+                               rY = buf_rsrc(WH ? g.Yout + (long)filt * g.strideY2 : g.K);
+  const unsigned vPHT = (unsigned)((live ? c0 + li : 0) + lg * g.ldpht) * 8u;
+  const unsigned vK = (unsigned)((live ? c0 + li : 0) + lg * g.ldk) * 8u;
+  const unsigned vY = WH ? (unsigned)((live ? c0 + li : 0) + lg * g.ldy2) * 8u : 0u;
 
   d4 X[NBM];
 #pragma unroll
@@ -1023,133 +1055,154 @@ __global__ __launch_bounds__(512) void trsm_stream_f64_kernel(TrsmArgs g) {
     X[i] = d4{0.0, 0.0, 0.0, 0.0};
     if (live && i < nb) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) X[i][r] = PHT[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldpht];
+      for (int r = 0; r < 4; ++r) X[i][r] = buf_ld(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u);
     }
   }
 
-  // panel of step k: slot j holds block (row-block j of the column); forward: j >= k, backward: j <= k.
-  // slot k itself holds inv(L_kk) (forward) / inv(L_kk)^T (backward). All blocks are read with the
-  // lane index contiguous (the upper triangle holds L^T) and stored [row + 17 * col].
-  d2 pr[PL];
-  auto panel_load = [&](int k, bool fwd) {
-    const int j0 = fwd ? k : 0, nj = fwd ? nb - k : k + 1;
-#pragma unroll
-    for (int u = 0; u < PL; ++u) {
-      const int e = tid + 512 * u;
-      d2 v = d2{0.0, 0.0};
-      if (e < nj * 128) {
-        const int j = j0 + (e >> 7), w = e & 127;
-        const int r = (w & 7) * 2, c = w >> 3;
-        if (j == k) v = *reinterpret_cast<const d2*>(invD + (long)k * 512 + (fwd ? 0 : 256) + r + 16 * c);
-        else v = *reinterpret_cast<const d2*>(LU + (16 * j + r) + (long)(16 * k + c) * ld);
-      }
-      pr[u] = v;
-    }
-  };
-  auto panel_store = [&](int k, bool fwd, double* buf) {
-    const int j0 = fwd ? k : 0, nj = fwd ? nb - k : k + 1;
-#pragma unroll
-    for (int u = 0; u < PL; ++u) {
-      const int e = tid + 512 * u;
-      if (e < nj * 128) {
-        const int j = j0 + (e >> 7), w = e & 127;
-        const int r = (w & 7) * 2, c = w >> 3;
-        buf[j * BLK + r + 17 * c] = pr[u][0];
-        buf[j * BLK + r + 1 + 17 * c] = pr[u][1];
-      }
+  // panel of step k: slot j holds block (j, k) of the stored factor (lower triangle: L_jk, j > k; mirrored upper triangle:
+  // L_kj^T, j < k); slot k holds inv(L_kk) (forward) or its transpose (backward); backward + WH: slot nb holds the diagonal
+  // block L_kk itself (stored symmetric: L below, L^T above - masked on read)
+  auto issue_panel = [&](int k, bool fwd, double* buf) {
+    const int j0 = fwd ? k : 0, nj = (fwd ? nb - k : k + 1) + ((WH && !fwd) ? 1 : 0);
+    for (int q = wave; q < nj * 2; q += 8) {
+      int j = j0 + (q >> 1);
+      const int h = q & 1;
+      const bool extra = WH && !fwd && (q >> 1) == nj - 1;
+      const double* src;
+      if (extra) { j = nb; src = LU + (16 * k + 2 * (lane & 7)) + (long)(16 * k + 8 * h + (lane >> 3)) * ld; }
+      else if (j == k) src = invD + (long)k * 512 + (fwd ? 0 : 256) + h * 128 + 2 * lane;
+      else src = LU + (16 * j + 2 * (lane & 7)) + (long)(16 * k + 8 * h + (lane >> 3)) * ld;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + j * 256 + h * 128), 16, 0, 0);
     }
   };
   double* buf0 = sL;
-  double* buf1 = sL + NBM * BLK;
+  double* buf1 = sL + PSZ;
 
   // ---- forward: L Y = HP
-  panel_load(0, true);
-  panel_store(0, true, buf0);
+  issue_panel(0, true, buf0);
 #pragma unroll
   for (int k = 0; k < NBM; ++k) {
     if (k < nb) {
-      __syncthreads();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                              // panel k landed for everybody; the other buffer is free again
       const double* cur = (k & 1) ? buf1 : buf0;
-      double* nxt = (k & 1) ? buf0 : buf1;
-      if (k + 1 < nb) panel_load(k + 1, true);
+      if (k + 1 < nb) issue_panel(k + 1, true, (k & 1) ? buf0 : buf1);
       if (live) {
         d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) t = mfma(cur[k * BLK + li + 17 * (4 * s + lg)], X[k][s], t);
+        for (int s = 0; s < 4; ++s) t = mfma(cur[k * 256 + li + 16 * (4 * s + lg)], X[k][s], t);
         X[k] = t;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
           for (int i = k + 1; i < NBM; ++i) {
-            if (i < nb) X[i] = mfma(-cur[i * BLK + li + 17 * (4 * s + lg)], t[s], X[i]);
+            if (i < nb) X[i] = mfma(-cur[i * 256 + li + 16 * (4 * s + lg)], t[s], X[i]);
           }
         }
       }
-      if (k + 1 < nb) panel_store(k + 1, true, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double part = 0.0;
+  if (WH && live) {     // W^T to the stash: the backward pass destroys it and the covariance update needs it again
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) {
+      if (i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // ---- backward: L^T K^T = Y  (panels of column k of the upper triangle = rows of L^T)
   __syncthreads();
-  if (!g.fwd_only) {
-    panel_load(nb - 1, false);
-    panel_store(nb - 1, false, buf0);
-  }
+  if (!g.fwd_only) issue_panel(nb - 1, false, buf0);
   int par = 0;
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
     if (k < nb && !g.fwd_only) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const double* cur = par ? buf1 : buf0;
-      double* nxt = par ? buf0 : buf1;
+      if (k > 0) issue_panel(k - 1, false, par ? buf0 : buf1);
       par ^= 1;
-      if (k > 0) panel_load(k - 1, false);
       if (live) {
+        d4 wk = d4{0.0, 0.0, 0.0, 0.0};
+        if (WH) {
+          if (k == nb - 1) wk = X[k];
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wk[r] = buf_ld(rK, vK, (unsigned)((16 * k + 4 * r) * g.ldk) * 8u);
+          }
+        }
         d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) t = mfma(cur[k * BLK + li + 17 * (4 * s + lg)], X[k][s], t);
-        X[k] = t;
+        for (int s = 0; s < 4; ++s) t = mfma(cur[k * 256 + li + 16 * (4 * s + lg)], X[k][s], t);
+        if (WH) {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {          // D_k = B_k - L_kk^T K^T_k; (L_kk)^T element (li, kk) = L_kk(kk, li), zero for kk < li
+            const int kk = 4 * s2 + lg;
+            const double a = cur[nb * 256 + li + 16 * kk];   // the diagonal block is stored symmetric: (li, kk) = (kk, li)
+            X[k] = mfma(kk >= li ? -a : 0.0, t[s2], X[k]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part = fma(t[r], buf_ld(rInn, (unsigned)lg * 8u, (unsigned)(16 * k + 4 * r) * 8u), part);
+        } else {
+          X[k] = t;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
-          for (int i = 0; i < k; ++i) X[i] = mfma(-cur[i * BLK + li + 17 * (4 * s + lg)], t[s], X[i]);
+          for (int i = 0; i < k; ++i) X[i] = mfma(-cur[i * 256 + li + 16 * (4 * s + lg)], t[s], X[i]);
+        }
+        if (WH) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) buf_st(wk[r] + X[k][r], rY, vY, (unsigned)((16 * k + 4 * r) * g.ldy2) * 8u);   // Y_k = W_k + D_k
+          X[k] = wk - X[k];                                                                                          // V_k = W_k - D_k
         }
       }
-      if (k > 0) panel_store(k - 1, false, nxt);
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every step's stash / inn loads to the top)
     }
   }
   if (!live) return;
-  double* __restrict__ K = g.K + (long)filt * g.strideK;
-  const double* __restrict__ inn = g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn;
-  double part = 0.0;
 #pragma unroll
   for (int i = 0; i < NBM; ++i) {
     if (i < nb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = 16 * i + lg + 4 * r;
-        K[(c0 + li) + (long)m * g.ldk] = X[i][r];
-        part = fma(X[i][r], inn[m], part);
+        buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);
+        if (!WH) part = fma(X[i][r], buf_ld(rInn, (unsigned)lg * 8u, (unsigned)(16 * i + 4 * r) * 8u), part);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   part += __shfl_xor(part, 16);
   part += __shfl_xor(part, 32);
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
 }
 
-template <int NBM>
+template <int NBM, int WH>
 int launch_trsm_stream_t(const TrsmArgs& g, hipStream_t stream) {
   const int chunks = (g.Np + 127) / 128;
   const int grid = ((g.batch + 7) / 8) * 8 * chunks;
-  const size_t lds = (size_t)2 * NBM * 16 * 17 * sizeof(double);
+  const size_t lds = (size_t)2 * (NBM + 1) * 256 * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_stream_f64_kernel<NBM>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_stream_f64_kernel<NBM, WH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((trsm_stream_f64_kernel<NBM>), dim3(grid), dim3(512), lds, stream, g);
+  hipLaunchKernelGGL((trsm_stream_f64_kernel<NBM, WH>), dim3(grid), dim3(512), lds, stream, g);
   return (int)hipGetLastError();
+}
+// Block-row capacities the streamed kernel is instantiated for. Register allocation of the fully unrolled substitution
+// is erratic from one capacity to the next (spilled VGPRs, hipcc 7.2: plain 14: 0, 16: 0, 18: 4801, 19: 6353, 20: 5019,
+// 22: 10, 24: 26; whitened 14: 0, 16: 35, 19: 12, 20: 47, 22: 74, 24: 806 - scripts/resource_usage.sh), so each variant
+// uses the capacities that compile clean.
+static int stream_capacity(int nb, bool whitened) {
+  if (nb <= 14) return 14;
+  if (whitened) return nb <= 19 ? 19 : (nb <= 22 ? 22 : 24);
+  return nb <= 16 ? 16 : (nb <= 22 ? 22 : 24);
 }
 
 template <int NBM, int TF>
@@ -1176,6 +1229,7 @@ int launch_trsm_lds_tf(const TrsmArgs& g_in, hipStream_t stream) {
 }
 template <int NBM>
 int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
+  if (g.Yout && !g.fwd_only) return launch_trsm_lds_tf<NBM, 5>(g, stream);   // whitened outputs, any number of column chunks
   {
     if (g.T && trsm_forms_T(g.Mp, g.Np))
       return g.fwd_only ? launch_trsm_lds_tf<NBM, 2>(g, stream)
@@ -1211,7 +1265,8 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   static const bool reg_always = getenv("XIVO_HIP_CHOL_REG") != nullptr;   // A/B knob
   const bool want_reg = g.variant == 2 || (g.variant == 0 && (g.batch < 512 || reg_always));
   if (!old_kernel && nb <= 12 && g.variant != 1 && want_reg) {
-    const int mirror = nb > 11 ? 1 : 0;   // only the streamed solve (nb >= 12) reads the mirrored upper triangle
+    const int mirror = nb > 10 ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
+                                          // whitened outputs leave the kernel (launch_trsm_f64)
     const bool many = g.batch >= 512;
     if (nb <= 4) hipLaunchKernelGGL((chol_reg_f64_kernel<4, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     else if (nb <= 8) hipLaunchKernelGGL((chol_reg_f64_kernel<8, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
@@ -1268,13 +1323,22 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   // whole factor in LDS (nb(nb+1)/2 blocks of 16x17 doubles) when it fits 160 KiB
   if (nb <= 6) return launch_trsm_lds_t<6>(g, stream);
   if (nb <= 10) return launch_trsm_lds_t<10>(g, stream);
-  if (nb <= 11) return launch_trsm_lds_t<11>(g, stream);
+  // (eleven block rows with the whitened outputs leaving the kernel: that instantiation spills 700 VGPRs - streamed instead)
+  if (nb <= 11 && !(g.Yout && !g.fwd_only)) return launch_trsm_lds_t<11>(g, stream);
   // larger factors: stream the factor through a double-buffered LDS panel
   static const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;   // A/B knob
-  if (!no_stream) {
-    if (nb <= 14) return launch_trsm_stream_t<14>(g, stream);
-    if (nb <= 19) return launch_trsm_stream_t<19>(g, stream);
-    if (nb <= 24) return launch_trsm_stream_t<24>(g, stream);
+  if (!no_stream && nb <= 24) {
+    const bool wh = g.Yout && !g.fwd_only;
+    switch (stream_capacity(nb, wh) * 2 + (wh ? 1 : 0)) {
+      case 14 * 2: return launch_trsm_stream_t<14, 0>(g, stream);
+      case 14 * 2 + 1: return launch_trsm_stream_t<14, 1>(g, stream);
+      case 16 * 2: return launch_trsm_stream_t<16, 0>(g, stream);
+      case 19 * 2 + 1: return launch_trsm_stream_t<19, 1>(g, stream);
+      case 22 * 2: return launch_trsm_stream_t<22, 0>(g, stream);
+      case 22 * 2 + 1: return launch_trsm_stream_t<22, 1>(g, stream);
+      case 24 * 2: return launch_trsm_stream_t<24, 0>(g, stream);
+      default: return launch_trsm_stream_t<24, 1>(g, stream);
+    }
   }
   if (nb <= 4) return launch_trsm_t<4>(g, stream);
   if (nb <= 7) return launch_trsm_t<7>(g, stream);
@@ -1304,7 +1368,7 @@ void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T) {
   const int nb = Mp / 16;
   const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
   if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
-  else if (!no_stream) snprintf(buf, n, "trsm_stream_f64_kernel<%d>", nb <= 14 ? 14 : (nb <= 19 ? 19 : 24));
+  else if (!no_stream) snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
   else snprintf(buf, n, "trsm_f64_kernel");
 }
 

@@ -123,6 +123,12 @@ struct TrsmArgs {
   long stridePm;
   int ldpm;
   int t_jbp;           // (set by the launcher) column blocks per LDS phase
+  // whitened outputs for a covariance update OUTSIDE the solve kernel (shapes one workgroup does not hold: N > 256 or
+  // M > 176): K receives V^T = (W - D)^T instead of the gain, Yout receives Y^T = (W + D)^T, both [Np x Mp]; then
+  // P+ = P - V^T Y as a tiled symmetric product (the Joseph expression for the computed gain, chol_trsm.hip TF == 4)
+  double* Yout;
+  long strideY2;
+  int ldy2;
 };
 int launch_trsm_f64(const TrsmArgs& args, hipStream_t stream);
 // P+ = G K^T - T with the rows of G in registers (one workgroup per filter; see chol_trsm.hip)
