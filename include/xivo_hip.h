@@ -106,7 +106,13 @@ enum {
    * correction PRODUCT runs on the fp32 MFMA (G itself - a cancellation - and -T stay fp64): its rounding adds
    * <= 1e-7 |G K^T| to P+, orders of magnitude below the fp64 rounding of -T. Without it (the default since round 3)
    * no fp32 instruction takes part in an update. */
-  XIVO_HIP_FLAG_FP32_CORR = 2048u
+  XIVO_HIP_FLAG_FP32_CORR = 2048u,
+  /* By default a filter whose innovation covariance the un-pivoted Cholesky cannot factor (S indefinite / not positive
+   * definite) is updated the reference's way after all: Eigen's diagonally pivoted L D L^T solve (src/estimator.cpp:1266)
+   * and the as-coded Joseph form, on that filter only (ldlt_fallback.hip); xivo_hip_get_ldlt_used tells which filters took
+   * that route and their status reads 0. With this flag such a filter keeps its prior covariance bit for bit, absorbs
+   * nothing, and xivo_hip_get_status reports it (the behaviour of rounds 1-2). */
+  XIVO_HIP_FLAG_NO_LDLT_FALLBACK = 4096u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,
@@ -222,6 +228,9 @@ int xivo_hip_get_err(xivo_hip_ctx* ctx, int b0, int nb, double* err, long stride
 /* per-filter factorisation status of the last update (0 = ok) ; returns
  * XIVO_HIP_ERR_NOT_SPD if any is non-zero */
 int xivo_hip_get_status(xivo_hip_ctx* ctx, int b0, int nb, int* status);
+/* used[i] = 1 if the last update of filter b0 + i ran the pivoted L D L^T fallback (S was not positive definite; the
+ * reference's S.ldlt().solve, src/estimator.cpp:1266, handles that case silently), 0 otherwise */
+int xivo_hip_get_ldlt_used(xivo_hip_ctx* ctx, int b0, int nb, int* used);
 /* Estimator::MHGating numeric core on dense rows (src/update.cpp:60-96):
  * rows 2f,2f+1 of the staged H are feature f's J. Writes the inlier mask and
  * Mahalanobis distances; rejected rows are then neutralised in the staged

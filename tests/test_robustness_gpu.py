@@ -1,13 +1,14 @@
-"""Behaviour outside the happy path: an innovation covariance that is not positive definite (the device factors with an
-un-pivoted Cholesky where the reference uses Eigen's pivoted LDL^T, src/estimator.cpp:1266) must be reported, must not
-destroy the covariance of that filter, and must not be absorbed into its state."""
+"""Behaviour outside the happy path: an innovation covariance that is not positive definite. The batched pipelines factor
+with an un-pivoted Cholesky where the reference uses Eigen's diagonally pivoted L D L^T (src/estimator.cpp:1266), which
+never fails. Default (round 3): such a filter is updated the reference's way by the device fallback (ldlt_fallback.hip).
+With XIVO_HIP_FLAG_NO_LDLT_FALLBACK it is reported, keeps its covariance and is not absorbed into the state."""
 import numpy as np
 import pytest
 
 import xivo_oracle as orc
 from helpers import rel_fro, TOL_P, TOL_DX
 from xivo_amd import synth
-from xivo_amd.lib import Context, FLAG_DENSE_H
+from xivo_amd.lib import Context, FLAG_DENSE_H, FLAG_NO_LDLT_FALLBACK, FLAG_SYMMETRIC_FORM, FLAG_EXPANDED_JOSEPH
 
 pytestmark = pytest.mark.gpu
 
@@ -17,16 +18,78 @@ def test_not_spd_filter_keeps_its_prior_and_is_reported(built, flags):
     N, F, B = 150, 50, 4
     P, H, inn, dR = synth.s_level(N, F, B, seed=17)
     dR[2, 10] = -1e12               # S of filter 2 gets a large negative diagonal entry: not positive definite
-    with Context(N, 2 * F, B, flags=flags) as ctx:
+    with Context(N, 2 * F, B, flags=flags | FLAG_NO_LDLT_FALLBACK) as ctx:
         ctx.upload_P(P)
         ctx.set_measurements(H, inn, dR)
         ctx.update_joseph()
         st = ctx.get_status(check=False)
         Pn, err = ctx.download_P(), ctx.get_err()
+        assert not ctx.get_ldlt_used().any()
         with pytest.raises(Exception):
             ctx.get_status()                       # the C ABI returns XIVO_HIP_ERR_NOT_SPD
     assert st[2] != 0 and (np.delete(st, 2) == 0).all()
     assert np.array_equal(Pn[2], P[2])             # the prior survives bit for bit
     for b in (0, 1, 3):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+def _indefinite_cases(N, F, B, seed):
+    """A covariance that lost its definiteness (R stays positive: the reference takes sqrt(R), src/estimator.cpp:1283):
+    filter 1: three eigenvalues of P flipped to large negative values (S indefinite); filter 3: P negated (S negative
+    definite up to R); the others regular."""
+    P, H, inn, dR = synth.s_level(N, F, B, seed=seed)
+    w, Q = np.linalg.eigh(P[1])
+    w[-3:] *= -1.0
+    P[1] = (Q * w) @ Q.T
+    P[1] = 0.5 * (P[1] + P[1].T)
+    P[3] = -P[3]
+    return P, H, inn, dR
+
+
+@pytest.mark.parametrize("flags", [0, FLAG_DENSE_H, FLAG_SYMMETRIC_FORM, FLAG_EXPANDED_JOSEPH])
+@pytest.mark.parametrize("N,F", [(150, 50), (64, 8), (300, 60)])
+def test_indefinite_S_is_updated_like_the_reference(built, N, F, flags):
+    """The reference's S.ldlt().solve(H P) + Joseph form goes through for ANY symmetric non-singular S. The device does the
+    same for the filters its Cholesky rejects: P+ and dx equal the oracle's (LU solve + as-coded Joseph form), and - where
+    oracle/_ref is present - Eigen's own pivoted L D L^T on the same inputs; the regular filters of the batch are not
+    affected, the status reads 0 and xivo_hip_get_ldlt_used names the filters that took the fallback."""
+    B = 5
+    P, H, inn, dR = _indefinite_cases(N, F, B, seed=300 + N)
+    with Context(N, 2 * F, B, flags=flags) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        st = ctx.get_status(check=False); used = ctx.get_ldlt_used()
+        Pn, err = ctx.download_P(), ctx.get_err()
+    assert (st == 0).all() and used.tolist() == [0, 1, 0, 1, 0]
+    try:
+        import ref_binding
+        ref = ref_binding.load()
+    except Exception:
+        ref = None
+    for b in range(B):
+        S = H[b] @ P[b] @ H[b].T + np.diag(dR[b])
+        if b in (1, 3):
+            assert np.linalg.eigvalsh(S).min() < 0
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < (TOL_DX if b not in (1, 3) else 1e-7)
+        assert np.array_equal(Pn[b], Pn[b].T)
+        if ref is not None and b in (1, 3):
+            e_e, P_e = ref.update_joseph(H[b], P[b], inn[b], dR[b])[:2]
+            assert rel_fro(Pn[b], P_e) < TOL_P and rel_fro(err[b], e_e) < 1e-7
+
+
+def test_fallback_flag_is_per_update(built):
+    """xivo_hip_get_ldlt_used describes the LAST update: a filter that needed the fallback once and whose next update is
+    regular again (fresh covariance) reads 0 afterwards."""
+    N, F, B = 64, 8, 3
+    P, H, inn, dR = synth.s_level(N, F, B, seed=5)
+    Pbad = P.copy(); Pbad[2] = -Pbad[2]
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(Pbad); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        assert ctx.get_ldlt_used().tolist() == [0, 0, 1] and (ctx.get_status(check=False) == 0).all()
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        assert ctx.get_ldlt_used().tolist() == [0, 0, 0]
+        Pn, err = ctx.download_P(), ctx.get_err()
+    for b in range(B):
         e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX

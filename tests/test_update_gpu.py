@@ -111,7 +111,8 @@ def test_not_spd_is_reported_not_fatal(built):
     N, F, B = 64, 8, 2
     P, H, inn, dR = synth.s_level(N, F, B, seed=5)
     dR[1, :] = -1e9  # S = HPH^T + R becomes indefinite for filter 1
-    with Context(N, 2 * F, B) as ctx:
+    from xivo_amd.lib import FLAG_NO_LDLT_FALLBACK      # (default: the pivoted L D L^T fallback updates it, tests/test_robustness_gpu.py)
+    with Context(N, 2 * F, B, flags=FLAG_NO_LDLT_FALLBACK) as ctx:
         ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
         st = ctx.get_status(check=False)
         assert st[0] == 0 and st[1] != 0
@@ -427,7 +428,8 @@ def test_symmetric_form_gated_ill_conditioned_and_not_spd(built):
         P[b] = 0.5 * (P[b] + P[b].T)
     dR = np.full((B, 2 * F), 1e-6)
     dR[1, 7] = -1e12                           # and one filter whose S is not positive definite: prior kept, reported
-    with Context(N, 2 * F, B, flags=FLAG_SYMMETRIC_FORM) as ctx:
+    from xivo_amd.lib import FLAG_NO_LDLT_FALLBACK
+    with Context(N, 2 * F, B, flags=FLAG_SYMMETRIC_FORM | FLAG_NO_LDLT_FALLBACK) as ctx:
         ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
         st = ctx.get_status(check=False)
         err = ctx.get_err(); Pn = ctx.download_P()
@@ -558,7 +560,8 @@ def test_whitened_form_ill_conditioned_and_not_spd(built):
         P[b] = 0.5 * (P[b] + P[b].T)
     dR = np.full((B, 2 * F), 1e-6)
     dR[2, :] = -1e3
-    with Context(N, 2 * F, B) as ctx:
+    from xivo_amd.lib import FLAG_NO_LDLT_FALLBACK
+    with Context(N, 2 * F, B, flags=FLAG_NO_LDLT_FALLBACK) as ctx:
         ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
         st = ctx.get_status(check=False)
         err = ctx.get_err(); Pn = ctx.download_P()

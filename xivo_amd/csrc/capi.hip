@@ -57,6 +57,7 @@ struct xivo_hip_ctx {
   int chunk = 0;      // filters per pipeline pass (0 = whole batch)
   int chol_variant[32] = {0};   // per factor size (blocks): 0 = not calibrated yet, 1 / 2 = CholArgs::variant picked on this node
   int* tune_status = nullptr;   // scratch status of the calibration runs (never the caller's)
+  int* ldlt_used = nullptr;     // per filter: 1 = the last update went through the pivoted L D L^T fallback
   // G-level
   xivo_layout lay{};
   xivo_cam cam{};
@@ -306,7 +307,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
-                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->tune_status};
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->tune_status, c->ldlt_used};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
@@ -337,7 +338,7 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   A(&c->P, B * c->sP); A(&c->H, B * c->sH); A(&c->HT, B * c->sHT); A(&c->HP, B * c->sH); A(&c->PHT, B * c->sK);
   A(&c->S, B * c->sS); A(&c->K, B * c->sK); A(&c->A, B * c->sA); A(&c->T, B * c->sP);
   A(&c->invD, B * c->sInvD); A(&c->inn, B * Mp); A(&c->diagR, B * Mp); A(&c->err, B * Np);
-  A(&c->status, B); A(&c->scratch, B * Np);
+  A(&c->status, B); A(&c->ldlt_used, B); A(&c->scratch, B * Np);
   A(&c->neg1, Mp); A(&c->yvec, B * Mp);
   if (rc == XIVO_HIP_OK) {
     std::vector<double> m1(Mp, -1.0);
@@ -776,7 +777,36 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   return rc;
 }
 
+static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GateParams* gate);
+
+// One pass of the update over filters [b0, b0 + B), then the device answer to a filter whose S the un-pivoted Cholesky
+// could not factor: Eigen's diagonally pivoted L D L^T (what src/estimator.cpp:1266 runs for EVERY filter) and the
+// as-coded Joseph update, on exactly those filters (ldlt_fallback.hip). Every pipeline leaves the covariance of such a
+// filter untouched and its status set, so the fallback starts from the prior.
 static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams* gate = nullptr) {
+  HIP_TRY(hipMemsetAsync(c->ldlt_used + b0, 0, (size_t)B * sizeof(int), c->stream));
+  int rc = update_joseph_range_impl(c, b0, B, gate);
+  if (rc || (c->flags & XIVO_HIP_FLAG_NO_LDLT_FALLBACK)) return rc;
+  LdltFallbackArgs a{};
+  a.status = c->status + b0; a.used = c->ldlt_used + b0;
+  a.ell = c->ell; a.ell.idx += (long)b0 * a.ell.stride_idx(); a.ell.val += (long)b0 * a.ell.stride_val();
+  a.ell.nc += b0; a.ell.pw += b0; a.ell.over += b0;
+  a.H = c->H + (long)b0 * c->sH; a.strideH = c->sH; a.ldh = c->Mpmax; a.use_dense = c->last_path == 0 ? 1 : 0;
+  a.PHT = c->PHT + (long)b0 * c->sK; a.stridePHT = c->sK; a.ldpht = c->Np;
+  a.S = c->S + (long)b0 * c->sS; a.strideS = c->sS; a.lds = c->Mpmax;
+  a.K = c->K + (long)b0 * c->sK; a.strideK = c->sK; a.ldk = c->Np;
+  a.A = c->A + (long)b0 * c->sA; a.strideA = c->sA; a.lda = c->Np;
+  a.T = c->T + (long)b0 * c->sP; a.strideT = c->sP; a.ldt = c->Np;
+  a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np;
+  a.inn = c->inn + (long)b0 * c->Mpmax; a.strideInn = c->Mpmax; a.diagR = c->diagR + (long)b0 * c->Mpmax; a.strideR = c->Mpmax;
+  a.err = c->err + (long)b0 * c->Np; a.strideErr = c->Np;
+  a.N = c->N; a.M = c->M; a.batch = B;
+  StageTimer st(c, ST_OTHER, 0.0, "ldlt_fallback_kernel");
+  HIP_TRY((hipError_t)launch_ldlt_fallback(a, c->stream));
+  return XIVO_HIP_OK;
+}
+
+static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GateParams* gate) {
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
   const double* H = c->H + (long)b0 * c->sH;
   const double* HT = c->HT + (long)b0 * c->sHT;
@@ -972,6 +1002,15 @@ int xivo_hip_get_err(xivo_hip_ctx* c, int b0, int nb, double* err, long stride) 
   if (nb == 0) return XIVO_HIP_OK;
   return d2h_rows(c, err, (size_t)stride * sizeof(double), c->err + (long)b0 * c->Np, (size_t)c->Np * sizeof(double),
                   (size_t)c->N * sizeof(double), nb);
+}
+
+int xivo_hip_get_ldlt_used(xivo_hip_ctx* c, int b0, int nb, int* used) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (bad_range(c, b0, nb) || !used) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipMemcpyAsync(used, c->ldlt_used + b0, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
 }
 
 int xivo_hip_get_status(xivo_hip_ctx* c, int b0, int nb, int* status) {

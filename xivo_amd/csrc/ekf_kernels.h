@@ -165,4 +165,25 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
 
 int launch_mfma_peak(double* sink, int iters, int blocks, hipStream_t s);
 
+// Diagonally pivoted L D L^T fallback (Eigen's S.ldlt().solve of src/estimator.cpp:1266) + the as-coded Joseph update for
+// the filters whose status is non-zero (ldlt_fallback.hip); clears their status and sets used[filt]
+}  // namespace xivo_hip
+#include "ell.h"
+namespace xivo_hip {
+struct LdltFallbackArgs {
+  int* status; int* used;
+  EllBuffers ell; const double* H; long strideH; int ldh; int use_dense;
+  const double* PHT; long stridePHT; int ldpht;
+  double* S; long strideS; int lds;
+  double* K; long strideK; int ldk;
+  double* A; long strideA; int lda;     // scratch: I - K H
+  double* T; long strideT; int ldt;     // scratch: (I - K H) P
+  double* P; long strideP; int ldp;
+  const double* inn; long strideInn;
+  const double* diagR; long strideR;
+  double* err; long strideErr;
+  int N, M, batch;
+};
+int launch_ldlt_fallback(const LdltFallbackArgs& a, hipStream_t s);
+
 }  // namespace xivo_hip

@@ -18,6 +18,7 @@ FLAG_SYMMETRIC_FORM = 256
 FLAG_STANDALONE_TAIL = 512
 FLAG_EXPANDED_JOSEPH = 1024
 FLAG_FP32_CORR = 2048
+FLAG_NO_LDLT_FALLBACK = 4096
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
 
@@ -138,6 +139,7 @@ _SIGS = {
     "xivo_hip_profile_get": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                              C.POINTER(C.c_int), C.POINTER(C.c_double)],
     "xivo_hip_bench_mfma_peak": [C.c_void_p, C.POINTER(C.c_double)],
+    "xivo_hip_get_ldlt_used": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
 }
 # every symbol include/xivo_hip.h declares (tests check the library exports them all)
 ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile", "xivo_hip_device_count",
@@ -324,6 +326,13 @@ class Context:
         rc = self.lib.xivo_hip_get_status(self.h, b0, nb, _ptr(out))
         if check:
             self._check(rc)
+        return out
+
+    def get_ldlt_used(self, b0=0, nb=None):
+        """1 for every filter whose last update ran the pivoted L D L^T fallback (S not positive definite)"""
+        nb = self.batch - b0 if nb is None else nb
+        out = np.zeros(nb, dtype=np.int32)
+        self._check(self.lib.xivo_hip_get_ldlt_used(self.h, b0, nb, _ptr(out)))
         return out
 
     def mh_gate_dense(self, F, R, thresh, mult, min_inliers, B=None):
