@@ -23,11 +23,13 @@
 //   carries, on the gain still in its registers (which is also the A-operand layout),
 //     TF = 1  T = K (HP) - P                                   (estimator.cpp:1276-1280, re-associated pipeline)
 //     TF = 2  P+ = P - W^T W after the forward substitution    (symmetric form)
-//     TF = 3  the whole Joseph update in its expanded form     (estimator.cpp:1276-1287; the default up to M = 176)
+//     TF = 3  the whole Joseph update in its expanded form     (estimator.cpp:1276-1287; round-2 default, XIVO_HIP_FLAG_EXPANDED_JOSEPH)
+//     TF = 4  the whole Joseph update in its whitened form     P+ = P - (W - D)^T (W + D)   (round 3: the default up to M = 176)
+//     TF = 5  the whitened outputs V^T, Y^T for a tiled product outside the kernel (N > 256)
 //   through sym_tiles_from_regs: symmetric N x N x M products with one operand in registers and the other arriving
 //   in LDS by global_load_lds (or from the owner waves' registers), every unordered pair of 16-row blocks once.
 // pnew_reg_f64_kernel : P+ = G K^T - T by the same walk with the rows of G loaded into the registers.
-// trsm_stream_f64_kernel : factors beyond the LDS (M > 176), panel by panel.
+// trsm_stream_f64_kernel<NB, WH> : factors beyond the LDS (M > 176), panel by panel (DMA panels); WH = 1: whitened outputs.
 #include <stdlib.h>
 
 #include "common.h"
