@@ -1027,7 +1027,8 @@ __global__ __launch_bounds__(1024) void pnew_reg_f64_kernel(PnewRegArgs g) {
 //   after the forward pass W^T goes to the stash (g.K), the backward pass reads W_k back one step before it needs it,
 //   forms D_k = B_k - L_kk^T K^T_k in place and leaves Y_k = W_k + D_k in g.Yout, V_k = W_k - D_k in g.K; dx as usual.
 template <int NBM, int WH>
-__global__ __launch_bounds__(512) void trsm_stream_f64_kernel(TrsmArgs g) {
+// (second launch bound = waves per SIMD the register budget is cut for: 8-wave workgroups -> 3 / 2 / 1 workgroups per CU)
+__global__ __launch_bounds__(512, NBM <= 4 ? 6 : (NBM <= 8 ? 4 : 2)) void trsm_stream_f64_kernel(TrsmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [2][NBM + 1][256]
   constexpr int PSZ = (NBM + 1) * 256;
   const int chunks = (g.Np + 127) / 128;
@@ -1202,6 +1203,7 @@ int launch_trsm_stream_t(const TrsmArgs& g, hipStream_t stream) {
 // 22: 10, 24: 26; whitened 14: 0, 16: 35, 19: 12, 20: 47, 22: 74, 24: 806 - scripts/resource_usage.sh), so each variant
 // uses the capacities that compile clean.
 static int stream_capacity(int nb, bool whitened) {
+  if (whitened && nb <= 8) return nb <= 4 ? 4 : (nb <= 6 ? 6 : 8);   // small factors: two workgroups per CU (XIVO_HIP_SMALL_STREAM)
   if (nb <= 14) return 14;
   if (whitened) return nb <= 19 ? 19 : (nb <= 22 ? 22 : 24);
   return nb <= 16 ? 16 : (nb <= 22 ? 22 : 24);
@@ -1267,7 +1269,8 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   static const bool reg_always = getenv("XIVO_HIP_CHOL_REG") != nullptr;   // A/B knob
   const bool want_reg = g.variant == 2 || (g.variant == 0 && (g.batch < 512 || reg_always));
   if (!old_kernel && nb <= 12 && g.variant != 1 && want_reg) {
-    const int mirror = nb > 10 ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
+    static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
+    const int mirror = (nb > 10 || small_stream) ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
                                           // whitened outputs leave the kernel (launch_trsm_f64)
     const bool many = g.batch >= 512;
     if (nb <= 4) hipLaunchKernelGGL((chol_reg_f64_kernel<4, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
@@ -1316,12 +1319,22 @@ void pnew_reg_kernel_label(int Mp, char* buf, size_t n) { snprintf(buf, n, "pnew
 
 bool trsm_forms_T(int Mp, int Np) {
   static const bool off = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: T as a stand-alone product
+  static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;   // A/B knob: small factors take the whitened-outputs path
+  if (small_stream && Mp / 16 <= 8) return false;
   return !off && Mp / 16 <= 11 && Np <= 256 && Np % 16 == 0;   // the factor fits the LDS and one workgroup covers every column
 }
 
 int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
   const int nb = g.Mp / 16;
+  // A/B knob (round 3 experiment): small factors with the whitened outputs through the streamed kernel - 8-wave workgroups of
+  // 128 columns, two or more per CU, instead of one 16-wave workgroup per filter
+  static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
+  if (small_stream && g.Yout && !g.fwd_only && nb <= 8) {
+    if (nb <= 4) return launch_trsm_stream_t<4, 1>(g, stream);
+    if (nb <= 6) return launch_trsm_stream_t<6, 1>(g, stream);
+    return launch_trsm_stream_t<8, 1>(g, stream);
+  }
   // whole factor in LDS (nb(nb+1)/2 blocks of 16x17 doubles) when it fits 160 KiB
   if (nb <= 6) return launch_trsm_lds_t<6>(g, stream);
   if (nb <= 10) return launch_trsm_lds_t<10>(g, stream);
@@ -1369,7 +1382,9 @@ void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
 void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T) {
   const int nb = Mp / 16;
   const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
-  if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
+  static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
+  if (small_stream && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
+  else if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
   else if (!no_stream) snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
   else snprintf(buf, n, "trsm_f64_kernel");
 }
