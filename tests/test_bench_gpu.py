@@ -33,6 +33,10 @@ def test_default_line(built):
     assert d["value_mixed"] > 0 and d["value_symmetric_form"] > d["value"]
     assert d["parity_check"]["ok"] and d["parity_check"]["rel_fro_P_max"] < 1e-6 and d["parity_check"]["inlier_masks_equal"]
     assert d["symmetric_form"]["parity_check"]["ok"]
+    # round 3: the state the timed loop left behind is checked too, every rank reports its own checks and its core binding
+    assert d["parity_check_last_timed_step"]["ok"] and d["parity_check_last_timed_step"]["updates_in_a_row"] == 3
+    assert [p["ok"] for p in d["per_rank_parity"]] == [True] and len(d["per_rank_affinity"]) == 1
+    assert "pipeline_frac_note" in d["roofline"] and d["config"]["precision"]["value"].startswith("library default = all fp64")
     st = d["stage_ms_per_step"]
     assert st["stack_H"] > 0 and st["trsm_gain"] > 0 and st["gemm_HP"] > 0      # hand-over is a timed stage
     assert not ({"gemm_AP", "gemm_KH_I", "gemm_Pnew"} & set(st))                # the covariance update lives in the solve kernel

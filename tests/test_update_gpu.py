@@ -610,3 +610,23 @@ def test_cholesky_kernels_are_bit_identical(built):
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert res[0] == res[1] == res[2], res
+
+
+@pytest.mark.parametrize("N,F", [(150, 50), (250, 80), (37, 3), (400, 150)])
+def test_update_matches_the_eigen_driver_directly(built, N, F):
+    """Same inputs through the HIP path and through oracle/_ref - the reference's own Eigen 3.3.9 / LDLT arithmetic compiled
+    from the reference tree (the prebuilt library travels to the GPU box) - without the numpy oracle in between:
+    UpdateJosephForm line for line (src/estimator.cpp:1257-1288) on one side, the device pipeline on the other."""
+    try:
+        import ref_binding
+        ref = ref_binding.load()
+    except Exception as e:
+        pytest.skip(f"oracle/_ref not available here: {e}")
+    B = 3
+    P, H, inn, dR = synth.s_level(N, F, B, seed=7 * N + F)
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+    for b in range(B):
+        e_ref, P_ref = ref.update_joseph(H[b], P[b], inn[b], dR[b])[:2]
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX

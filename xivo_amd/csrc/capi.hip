@@ -667,27 +667,35 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     StageTimer st(c, ST_HP, nnz_flops * Nf * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_HP, a, c->stream));
   }
+  GateEllArgs ga{};
+  if (gate) {
+    ga.ell = e;
+    ga.H = c->dense_valid ? c->H + (long)b0 * c->sH : nullptr; ga.strideH = c->sH; ga.ldh = ldh;
+    ga.HT = c->dense_valid ? c->HT + (long)b0 * c->sHT : nullptr; ga.strideHT = c->sHT; ga.ldht = Np; ga.PHT = PHT;
+    ga.HP = nullptr;   // H P [Mp x Np] has no reader behind this point (S is formed already, the solve reads P H^T)
+    ga.inn = inn; ga.strideInn = c->Mpmax; ga.diagR = diagR; ga.strideR = c->Mpmax;
+    ga.mask = c->mask + (long)b0 * gate->F; ga.dist = c->dist + (long)b0 * gate->F;
+    ga.F = gate->F; ga.Np = Np; ga.batch = B;
+    ga.S = S; ga.strideS = c->sS; ga.lds = lds; ga.Mp = Mp; ga.from_S = 1;   // distances from the diagonal blocks of S
+    ga.R = gate->R; ga.thresh = gate->thresh; ga.mult = gate->mult; ga.min_inliers = gate->min_inliers;
+  }
+  int gate_done = 0;
   {
     EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max;
+    // A/B knob (measured slower, off by default): the gate in the tail of the S kernel - S + gate 2.88 ms fused vs 2.30 + 0.36
+    // as two kernels per 16384 filters: the tail runs at one 8-wave workgroup per CU where the stand-alone gate fills the chip
+    static const bool fuse = getenv("XIVO_HIP_GATE_IN_S") != nullptr;
+    if (gate && fuse) { a.gate = ga; a.gate_here = 1; a.gate_done = &gate_done; }
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
     StageTimer st(c, ST_S, nnz_flops * Mf * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_S, a, c->stream));
   }
-  if (gate) {
-    GateEllArgs a{}; a.ell = e;
-    a.H = c->dense_valid ? c->H + (long)b0 * c->sH : nullptr; a.strideH = c->sH; a.ldh = ldh;
-    a.HT = c->dense_valid ? c->HT + (long)b0 * c->sHT : nullptr; a.strideHT = c->sHT; a.ldht = Np; a.PHT = PHT;
-    a.HP = nullptr;   // H P [Mp x Np] has no reader behind this point (S is formed already, the solve reads P H^T)
-    a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
-    a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
-    a.F = gate->F; a.Np = Np; a.batch = B;
-    a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.from_S = 1;   // distances from the diagonal blocks of S
-    a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
+  if (gate) c->gate_sparse_last = 0;
+  if (gate && !gate_done) {
     StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
-    c->gate_sparse_last = 0;
-    HIP_TRY((hipError_t)launch_gate_ell(a, c->stream));
+    HIP_TRY((hipError_t)launch_gate_ell(ga, c->stream));
   }
   {
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;

@@ -1275,6 +1275,7 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
     const bool many = g.batch >= 512;
     if (nb <= 4) hipLaunchKernelGGL((chol_reg_f64_kernel<4, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     else if (nb <= 8) hipLaunchKernelGGL((chol_reg_f64_kernel<8, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
+    else if (nb <= 10 && many && getenv("XIVO_HIP_CHOL_MINB4")) hipLaunchKernelGGL((chol_reg_f64_kernel<10, 4>), dim3(g.batch), dim3(256), 0, stream, g, mirror);   // A/B knob
     else if (nb <= 10 && many) hipLaunchKernelGGL((chol_reg_f64_kernel<10, 3>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     else if (nb <= 10) hipLaunchKernelGGL((chol_reg_f64_kernel<10, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
     else if (many) hipLaunchKernelGGL((chol_reg_f64_kernel<12, 3>), dim3(g.batch), dim3(256), 0, stream, g, mirror);

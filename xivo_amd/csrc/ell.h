@@ -58,29 +58,6 @@ enum EllMode : int {
   ELL_G = 2,    // Src = T  [Np x Np] : out = T H^T + K diag(R)  [Np x Mp]               (re-associated :1280-1287)
   ELL_GF = 3,   // ELL_G with the result stored as float (slab form only; strideOut / ldo in float elements)
 };
-struct EllMulArgs {
-  EllBuffers ell;
-  const double* Src; long strideSrc; int ldsrc;
-  int cols;     // number of source columns a slot index can name (Np)
-  const double* SrcAlt; long strideSrcAlt; int ldsrcAlt;   // ELL_S: H P [Mp x Np] for the gather fallback (may be null if the tile form fits)
-  double* out; long strideOut; int ldo;
-  double* out2; long strideOut2; int ldo2;      // ELL_HP only
-  const double* diagR; long strideR;            // ELL_S, ELL_G
-  const double* K; long strideK; int ldk;       // ELL_G
-  int X;        // extent of the contiguous index (Np for HP/G, Mp for S)
-  int Mp;       // rows of H in use (multiple of 16)
-  int slabs_per_wg; // set by the launcher (slab form): consecutive slabs one workgroup streams
-  int rb_per_wg; // set by the launcher: 16-row blocks one workgroup walks
-  int nc_max;   // upper bound of nc over the filters of the launch (host mirror)
-  int pw_max;   // upper bound of pw (0 = unknown -> ELL_PW)
-  int batch;
-};
-int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s);
-// name of the kernel instantiation launch_ell_mul runs for these arguments
-void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n);
-// true when launch_ell_mul will run the slab-in-LDS form for these arguments
-bool ell_uses_slab_form(const EllMulArgs& a);
-
 // Estimator::MHGating numeric core (src/update.cpp:60-96) on the ELL rows: S_f = H_f (P H_f^T) + R I2
 // from the already formed P H^T, threshold relaxation, then neutralisation of the rejected pairs
 // (ELL values, H / H^T / HP / P H^T rows = 0, inn = 0, diagR = 1).
@@ -98,6 +75,34 @@ struct GateEllArgs {
   // off its diagonal and the rows / columns of the rejected pairs are then decoupled in place (0, unit diagonal)
   double* S; long strideS; int lds; int Mp; int from_S;
 };
+struct EllMulArgs {
+  EllBuffers ell;
+  const double* Src; long strideSrc; int ldsrc;
+  int cols;     // number of source columns a slot index can name (Np)
+  const double* SrcAlt; long strideSrcAlt; int ldsrcAlt;   // ELL_S: H P [Mp x Np] for the gather fallback (may be null if the tile form fits)
+  double* out; long strideOut; int ldo;
+  double* out2; long strideOut2; int ldo2;      // ELL_HP only
+  const double* diagR; long strideR;            // ELL_S, ELL_G
+  const double* K; long strideK; int ldk;       // ELL_G
+  int X;        // extent of the contiguous index (Np for HP/G, Mp for S)
+  int Mp;       // rows of H in use (multiple of 16)
+  int slabs_per_wg; // set by the launcher (slab form): consecutive slabs one workgroup streams
+  int rb_per_wg; // set by the launcher: 16-row blocks one workgroup walks
+  int nc_max;   // upper bound of nc over the filters of the launch (host mirror)
+  int pw_max;   // upper bound of pw (0 = unknown -> ELL_PW)
+  int batch;
+  // ELL_S only: run the gate (src/update.cpp:60-96, gate.from_S semantics) in the tail of the S kernel when one workgroup
+  // forms the whole S of its filter (big batches); *gate_done tells the caller whether that happened (else: launch_gate_ell)
+  GateEllArgs gate;
+  int gate_here;
+  int* gate_done;
+};
+int launch_ell_mul(int mode, const EllMulArgs& a, hipStream_t s);
+// name of the kernel instantiation launch_ell_mul runs for these arguments
+void ell_kernel_label(int mode, const EllMulArgs& a, char* buf, size_t n);
+// true when launch_ell_mul will run the slab-in-LDS form for these arguments
+bool ell_uses_slab_form(const EllMulArgs& a);
+
 int launch_gate_ell(const GateEllArgs& a, hipStream_t s);
 
 }  // namespace xivo_hip

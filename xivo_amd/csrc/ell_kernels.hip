@@ -248,6 +248,102 @@ __global__ __launch_bounds__(256) void ell_mul_kernel(EllMulArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- gating on ELL rows
+// (device function: the stand-alone kernel below, and the tail of the S kernel when one workgroup owns a whole filter)
+__device__ __forceinline__ void gate_ell_body(const GateEllArgs& a, int filt, double* sdist /* LDS: F doubles + 1 */) {
+  const int nt = blockDim.x, nwv = nt >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int* __restrict__ idx = a.ell.idx + (long)filt * a.ell.stride_idx();
+  double* val = a.ell.val + (long)filt * a.ell.stride_val();
+  double* PHT = a.PHT + (long)filt * a.strideHT;
+  double* inn = a.inn + (long)filt * a.strideInn;
+  double* Sm = a.from_S ? a.S + (long)filt * a.strideS : nullptr;
+  if (a.from_S) {
+    const double* dr0 = a.diagR + (long)filt * a.strideR;
+    for (int f = tid; f < a.F; f += nt) {
+      const double s00 = Sm[2 * f + (long)(2 * f) * a.lds] - dr0[2 * f] + a.R;
+      const double s10 = Sm[2 * f + 1 + (long)(2 * f) * a.lds];
+      const double s11 = Sm[2 * f + 1 + (long)(2 * f + 1) * a.lds] - dr0[2 * f + 1] + a.R;
+      sdist[f] = mh_dist_2x2(s00, s10, s11, inn[2 * f], inn[2 * f + 1]);
+    }
+  }
+  // one wave per feature, one lane per slot: the 2 x 28 gathers of a feature are one round trip
+  for (int f = wave; f < (a.from_S ? 0 : a.F); f += nwv) {
+    const double* c0 = PHT + (long)(2 * f) * a.ldht;      // P J0^T
+    const double* c1 = c0 + a.ldht;                       // P J1^T
+    double s00 = 0, s10 = 0, s11 = 0;
+    if (lane < ELL_W) {
+      const int k = idx[(long)f * ELL_W + lane];
+      const double v0 = val[((long)f * ELL_W + lane) * 2], v1 = val[((long)f * ELL_W + lane) * 2 + 1];
+      const double p0 = c0[k], p1 = c1[k];
+      s00 = v0 * p0; s10 = v1 * p0; s11 = v1 * p1;
+    }
+    s00 = wave_sum(s00); s10 = wave_sum(s10); s11 = wave_sum(s11);
+    if (lane == 0) sdist[f] = mh_dist_2x2(s00 + a.R, s10, s11 + a.R, inn[2 * f], inn[2 * f + 1]);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const double th = relax_threshold(sdist, a.F, a.thresh, a.mult, a.min_inliers, lane);
+    if (lane == 0) sdist[a.F] = th;
+  }
+  __syncthreads();
+  const double th = sdist[a.F];
+  for (int f = tid; f < a.F; f += nt) {
+    const bool in = sdist[f] < th;
+    a.mask[(long)filt * a.F + f] = in ? 1 : 0;
+    a.dist[(long)filt * a.F + f] = sdist[f];
+    if (!in) {
+      inn[2 * f] = 0.0; inn[2 * f + 1] = 0.0;
+      double* dr = a.diagR + (long)filt * a.strideR;
+      dr[2 * f] = 1.0; dr[2 * f + 1] = 1.0;
+      for (int t = 0; t < 2 * ELL_W; ++t) val[(long)f * ELL_W * 2 + t] = 0.0;
+    }
+  }
+  double* H = a.H ? a.H + (long)filt * a.strideH : nullptr;       // dense copies, when they are materialised
+  double* HT = a.HT ? a.HT + (long)filt * a.strideHT : nullptr;
+  double* HP = a.HP ? a.HP + (long)filt * a.strideH : nullptr;
+  for (int f = 0; f < a.F; ++f) {
+    if (sdist[f] < th) continue;
+    for (int n = tid; n < a.Np; n += nt) {
+      if (H) {
+        H[2 * f + (long)n * a.ldh] = 0.0;
+        H[2 * f + 1 + (long)n * a.ldh] = 0.0;
+        HT[n + (long)(2 * f) * a.ldht] = 0.0;
+        HT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
+      }
+      PHT[n + (long)(2 * f) * a.ldht] = 0.0;
+      PHT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
+      if (HP) {                                   // (strided: 2 Np scattered 8-byte stores per rejected feature)
+        HP[2 * f + (long)n * a.ldh] = 0.0;
+        HP[2 * f + 1 + (long)n * a.ldh] = 0.0;
+      }
+    }
+    if (Sm) {
+      for (int jx = tid; jx < a.Mp; jx += nt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = 2 * f + i;
+          Sm[r + (long)jx * a.lds] = 0.0;
+          Sm[jx + (long)r * a.lds] = 0.0;
+        }
+      }
+    }
+  }
+  if (Sm) {
+    __syncthreads();
+    for (int f = tid; f < a.F; f += nt) {
+      if (sdist[f] < th) continue;
+      Sm[2 * f + (long)(2 * f) * a.lds] = 1.0;
+      Sm[2 * f + 1 + (long)(2 * f + 1) * a.lds] = 1.0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
+  extern __shared__ double sdist[];  // F doubles + 1; 256 threads for a big batch, 1024 when few filters must finish fast
+  gate_ell_body(a, blockIdx.x, sdist);
+}
+
 // ---------------------------------------------------------------- slab-in-LDS variant
 // The gather form above re-fetches a source column once per row pair that names it (a group block is
 // shared by the features anchored to it, and the 12 pose columns by everybody): ~4x the size of the
@@ -436,97 +532,11 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
     // just issued and for the next slab's prefetch loads to land
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-}
-
-// ---------------------------------------------------------------- gating on ELL rows
-__global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
-  const int nt = blockDim.x, nwv = nt >> 6;   // 256 threads for a big batch, 1024 when few filters must finish fast
-  const int filt = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  extern __shared__ double sdist[];  // F doubles + 1
-  const int* __restrict__ idx = a.ell.idx + (long)filt * a.ell.stride_idx();
-  double* val = a.ell.val + (long)filt * a.ell.stride_val();
-  double* PHT = a.PHT + (long)filt * a.strideHT;
-  double* inn = a.inn + (long)filt * a.strideInn;
-  double* Sm = a.from_S ? a.S + (long)filt * a.strideS : nullptr;
-  if (a.from_S) {
-    const double* dr0 = a.diagR + (long)filt * a.strideR;
-    for (int f = tid; f < a.F; f += nt) {
-      const double s00 = Sm[2 * f + (long)(2 * f) * a.lds] - dr0[2 * f] + a.R;
-      const double s10 = Sm[2 * f + 1 + (long)(2 * f) * a.lds];
-      const double s11 = Sm[2 * f + 1 + (long)(2 * f + 1) * a.lds] - dr0[2 * f + 1] + a.R;
-      sdist[f] = mh_dist_2x2(s00, s10, s11, inn[2 * f], inn[2 * f + 1]);
-    }
-  }
-  // one wave per feature, one lane per slot: the 2 x 28 gathers of a feature are one round trip
-  for (int f = wave; f < (a.from_S ? 0 : a.F); f += nwv) {
-    const double* c0 = PHT + (long)(2 * f) * a.ldht;      // P J0^T
-    const double* c1 = c0 + a.ldht;                       // P J1^T
-    double s00 = 0, s10 = 0, s11 = 0;
-    if (lane < ELL_W) {
-      const int k = idx[(long)f * ELL_W + lane];
-      const double v0 = val[((long)f * ELL_W + lane) * 2], v1 = val[((long)f * ELL_W + lane) * 2 + 1];
-      const double p0 = c0[k], p1 = c1[k];
-      s00 = v0 * p0; s10 = v1 * p0; s11 = v1 * p1;
-    }
-    s00 = wave_sum(s00); s10 = wave_sum(s10); s11 = wave_sum(s11);
-    if (lane == 0) sdist[f] = mh_dist_2x2(s00 + a.R, s10, s11 + a.R, inn[2 * f], inn[2 * f + 1]);
-  }
-  __syncthreads();
-  if (wave == 0) {
-    const double th = relax_threshold(sdist, a.F, a.thresh, a.mult, a.min_inliers, lane);
-    if (lane == 0) sdist[a.F] = th;
-  }
-  __syncthreads();
-  const double th = sdist[a.F];
-  for (int f = tid; f < a.F; f += nt) {
-    const bool in = sdist[f] < th;
-    a.mask[(long)filt * a.F + f] = in ? 1 : 0;
-    a.dist[(long)filt * a.F + f] = sdist[f];
-    if (!in) {
-      inn[2 * f] = 0.0; inn[2 * f + 1] = 0.0;
-      double* dr = a.diagR + (long)filt * a.strideR;
-      dr[2 * f] = 1.0; dr[2 * f + 1] = 1.0;
-      for (int t = 0; t < 2 * ELL_W; ++t) val[(long)f * ELL_W * 2 + t] = 0.0;
-    }
-  }
-  double* H = a.H ? a.H + (long)filt * a.strideH : nullptr;       // dense copies, when they are materialised
-  double* HT = a.HT ? a.HT + (long)filt * a.strideHT : nullptr;
-  double* HP = a.HP ? a.HP + (long)filt * a.strideH : nullptr;
-  for (int f = 0; f < a.F; ++f) {
-    if (sdist[f] < th) continue;
-    for (int n = tid; n < a.Np; n += nt) {
-      if (H) {
-        H[2 * f + (long)n * a.ldh] = 0.0;
-        H[2 * f + 1 + (long)n * a.ldh] = 0.0;
-        HT[n + (long)(2 * f) * a.ldht] = 0.0;
-        HT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
-      }
-      PHT[n + (long)(2 * f) * a.ldht] = 0.0;
-      PHT[n + (long)(2 * f + 1) * a.ldht] = 0.0;
-      if (HP) {                                   // (strided: 2 Np scattered 8-byte stores per rejected feature)
-        HP[2 * f + (long)n * a.ldh] = 0.0;
-        HP[2 * f + 1 + (long)n * a.ldh] = 0.0;
-      }
-    }
-    if (Sm) {
-      for (int jx = tid; jx < a.Mp; jx += nt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int r = 2 * f + i;
-          Sm[r + (long)jx * a.lds] = 0.0;
-          Sm[jx + (long)r * a.lds] = 0.0;
-        }
-      }
-    }
-  }
-  if (Sm) {
-    __syncthreads();
-    for (int f = tid; f < a.F; f += nt) {
-      if (sdist[f] < th) continue;
-      Sm[2 * f + (long)(2 * f) * a.lds] = 1.0;
-      Sm[2 * f + 1 + (long)(2 * f + 1) * a.lds] = 1.0;
-    }
+  // Estimator::MHGating on the S just formed (update.cpp:60-96), when this workgroup wrote all of it: the 2 x 2 blocks S_f
+  // sit on its diagonal; saves a launch and the pass that would re-fetch them
+  if (MODE == ELL_S && a.gate_here) {
+    __syncthreads();                      // every store of S by this workgroup is acknowledged before anybody reads it back
+    gate_ell_body(a.gate, filt, tile);
   }
 }
 
@@ -604,6 +614,8 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
   const int grid = ((a.batch + 7) / 8) * 8 * wgs;
+  if (!(MODE == ELL_S && wgs == 1)) a.gate_here = 0;      // the gate rides along only when one workgroup forms the whole S of its filter
+  if (a_in.gate_done) *a_in.gate_done = a.gate_here;
   hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU>), dim3(grid), dim3(ell_tile_threads(MODE, CWU, XC, PWU)), lds, s, a);
   return (int)hipGetLastError();
 }
