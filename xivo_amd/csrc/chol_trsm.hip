@@ -714,40 +714,75 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     }
   }
 
-  // cooperative copy: block (i,k), i >= k at slot i(i+1)/2 + k
+  // cooperative copy: block (i,k), i >= k at slot i(i+1)/2 + k. The loads of a thread are requested four at a time before
+  // the first of them is consumed (compile-time trip count): the loop used to wait for each of its ~7 round trips in turn,
+  // on a CU that has nothing else to run meanwhile. (All of them at once would spill: the right-hand sides are in flight.)
   const int nblk = nb * (nb + 1) / 2;
-  for (int e = tid; e < nblk * 128; e += 1024) {      // 128 = 256 elements / 2 per thread-load
-    const int t = e >> 7, w = e & 127;
-    int i = 0;
-    while ((i + 1) * (i + 2) / 2 <= t) ++i;            // block row of slot t (nb <= 24: a few iterations)
-    const int k = t - i * (i + 1) / 2;
-    const int r = (w & 7) * 2, c = w >> 3;             // rows r, r+1 of column c
-    d2 v = *reinterpret_cast<const d2*>(LU + (16 * i + r) + (long)(16 * k + c) * ld);
-    if (i == k) {   // diagonal slot: inv(L_kk) in the lower triangle; TF == 3 keeps L_kk^T above it and the diagonal of L_kk
-                    // in the pad row: one slot serves the solve and the two triangular products
-      const d2 iv = *reinterpret_cast<const d2*>(invD + (long)k * 512 + r + 16 * c);
-      if (!PACK) v = iv;
-      else {        // (the strictly lower part of L_kk read transposed: the factorisation need not have mirrored it)
-        v[0] = r >= c ? iv[0] : LU[(16 * k + c) + (long)(16 * k + r) * ld];
-        v[1] = r + 1 >= c ? iv[1] : LU[(16 * k + c) + (long)(16 * k + r + 1) * ld];
+  constexpr bool DIAG = !PACK && (TF == 3 || T4);                    // the diagonal blocks L_kk in slots of their own
+  constexpr int CPY = (NBM * (NBM + 1) / 2 * 128 + 1023) / 1024;     // d2 loads per thread: factor ...
+  constexpr int CPD = DIAG ? (NBM * 128 + 1023) / 1024 : 0;         // ... + diagonal blocks
+  constexpr int CPB = 4;                                              // loads in flight per thread
+  double* sD = sL + nblk * BLK;                                       // (upper triangle zeroed)
+#pragma unroll
+  for (int u0 = 0; u0 < CPY + CPD; u0 += CPB) {
+    d2 cv[CPB], cu[CPB];
+#pragma unroll
+    for (int q = 0; q < CPB; ++q) {
+      const int u = u0 + q;
+      cv[q] = d2{0.0, 0.0}; cu[q] = d2{0.0, 0.0};
+      if (u < CPY) {
+        const int e = tid + 1024 * u;
+        if (e < nblk * 128) {
+          const int t = e >> 7, w = e & 127;
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= t) ++i;            // block row of slot t (nb <= 24: a few iterations)
+          const int k = t - i * (i + 1) / 2;
+          const int r = (w & 7) * 2, c = w >> 3;             // rows r, r+1 of column c
+          cv[q] = *reinterpret_cast<const d2*>(i != k ? LU + (16 * i + r) + (long)(16 * k + c) * ld : invD + (long)k * 512 + r + 16 * c);
+          if (PACK && i == k) { cu[q][0] = LU[(16 * k + c) + (long)(16 * k + r) * ld]; cu[q][1] = LU[(16 * k + c) + (long)(16 * k + r + 1) * ld]; }
+        }
+      } else if (u < CPY + CPD) {
+        const int e = tid + 1024 * (u - CPY);
+        if (e < nb * 128) {
+          const int k = e >> 7, w = e & 127;
+          cv[q] = *reinterpret_cast<const d2*>(LU + (16 * k + (w & 7) * 2) + (long)(16 * k + (w >> 3)) * ld);
+        }
       }
     }
-    sL[t * BLK + r + 17 * c] = v[0];
-    sL[t * BLK + r + 1 + 17 * c] = v[1];
+#pragma unroll
+    for (int q = 0; q < CPB; ++q) {
+      const int u = u0 + q;
+      if (u < CPY) {
+        const int e = tid + 1024 * u;
+        if (e < nblk * 128) {
+          const int t = e >> 7, w = e & 127;
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= t) ++i;
+          const int k = t - i * (i + 1) / 2;
+          const int r = (w & 7) * 2, c = w >> 3;
+          d2 v = cv[q];
+          // diagonal slot: inv(L_kk) in the lower triangle; packed: L_kk^T above it (the strictly lower part of L_kk read
+          // transposed: the factorisation need not have mirrored it) and the diagonal of L_kk in the pad row
+          if (PACK && i == k) { v[0] = r >= c ? v[0] : cu[q][0]; v[1] = r + 1 >= c ? v[1] : cu[q][1]; }
+          sL[t * BLK + r + 17 * c] = v[0];
+          sL[t * BLK + r + 1 + 17 * c] = v[1];
+        }
+      } else if (u < CPY + CPD) {
+        const int e = tid + 1024 * (u - CPY);
+        if (e < nb * 128) {
+          const int k = e >> 7, w = e & 127;
+          const int r = (w & 7) * 2, c = w >> 3;
+          sD[k * BLK + r + 17 * c] = r >= c ? cv[q][0] : 0.0;
+          sD[k * BLK + r + 1 + 17 * c] = r + 1 >= c ? cv[q][1] : 0.0;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  double* sD = sL + nblk * BLK;                        // TF == 3, !PACK: the diagonal blocks L_kk in slots of their own (upper triangle zeroed)
   if (PACK) {
     for (int e = tid; e < nb * 16; e += 1024) {
       const int k = e >> 4, c = e & 15;
       sL[(k * (k + 1) / 2 + k) * BLK + 16 + 17 * c] = LU[(16 * k + c) + (long)(16 * k + c) * ld];
-    }
-  } else if (TF == 3 || T4) {
-    for (int e = tid; e < nb * 128; e += 1024) {
-      const int k = e >> 7, w = e & 127;
-      const int r = (w & 7) * 2, c = w >> 3;
-      const d2 v = *reinterpret_cast<const d2*>(LU + (16 * k + r) + (long)(16 * k + c) * ld);
-      sD[k * BLK + r + 17 * c] = r >= c ? v[0] : 0.0;
-      sD[k * BLK + r + 1 + 17 * c] = r + 1 >= c ? v[1] : 0.0;
     }
   }
   __syncthreads();
