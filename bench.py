@@ -216,6 +216,9 @@ def main():
                     help="level G only (BASELINE config 3): this many out-of-state (MSCKF) features, each seen from 5 in-state "
                          "groups, are null-space projected (src/oos.cpp) and appended: 7 rows each, M = 120 + 7 n")
     ap.add_argument("--no-compression", action="store_true", help="--oos: keep all 7 n projected rows (no QR measurement compression)")
+    ap.add_argument("--oos-dense", action="store_true",
+                    help="--oos: every row dense and the re-associated dense pipeline (XIVO_HIP_FLAG_DENSE_H | REASSOC, the round-2 path) "
+                         "instead of mixed stacking (in-state rows row-pair compressed, only the OOS block dense)")
     ap.add_argument("--ransac", action="store_true",
                     help="level G only: OnePointRANSAC (src/update.cpp:213-393) between MH gating and the update - backup, "
                          "partial update on the low-innovation set, absorb, re-Jacobians, chi-square rescue, restore")
@@ -308,13 +311,12 @@ def main():
                 groups[b, g_]["Rsb"], groups[b, g_]["Tsb"] = cmaj(sc["gR"][b, g_]), sc["gT"][b, g_]
             feats["x"][b] = sc["x"][b]; feats["ref_sind"][b] = sc["ref"][b]; feats["sind"][b] = sc["sind"][b]
         M = 2 * F + 7 * args.oos
-        if args.oos > 0:
+        if args.oos > 0 and args.oos_dense:
             from xivo_amd.lib import FLAG_DENSE_H, FLAG_REASSOC
-            # OOS rows are dense over the group blocks: stack the dense rows right away; the re-associated dense
-            # pipeline (T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T: the same Joseph expression, contractions over
-            # M instead of N) never reads H^T, so that copy is not written at all
+            # every row dense right away; the re-associated dense pipeline never reads H^T, so that copy is not written
             flags |= FLAG_DENSE_H | FLAG_REASSOC
-        ctx = Context(N, M, B, device=device, flags=flags)
+        # (--oos: 16 spare rows - mixed stacking pads the OOS block to 16 rows behind the 2F in-state rows)
+        ctx = Context(N, M + (16 if args.oos > 0 else 0), B, device=device, flags=flags)
         ctx.set_layout(N, 23, ng, 23 + 6 * ng, nf, synth.EQUI)
         rngP = np.random.default_rng(3000 + rank)
         A_ = rngP.uniform(-1, 1, size=(uniq, N, N))
@@ -578,8 +580,8 @@ def main():
                                    ("UpdateJosephForm only" if args.no_gating else "MH gating + UpdateJosephForm") +
                                    f": state dim {N}, {F} features (M={M}), XIVO row sparsity, P/H/inn/R resident in HBM",
                        "filters_per_gpu": B, "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
-                       "pipeline": "sparse-H (row-pair compressed H, re-associated Joseph form)" if sparse_path
-                                   else "dense as-coded",
+                       "pipeline": ("sparse-H (row-pair compressed H, whitened in-solve Joseph form" +
+                                    ("; OOS block dense: mixed stacking)" if oos_on else ")")) if sparse_path else "dense as-coded",
                        "hand_over": ("dense H/inn/diagR (column-major, resident in HBM) -> row-pair compressed rows, "
                                      "every step, inside the timed region (stage stack_H)") if args.level == "S" else
                                     "Jacobians -> compressed rows on device every step",

@@ -50,4 +50,6 @@ def test_feature_level_and_config3_lines(built):
     d = _run("--level", "G", "--ransac")
     assert d["value"] > 0 and "OnePointRANSAC" in d["config"]["workload"]
     d = _run("--level", "G", "--oos", "20")
-    assert d["value"] > 0 and "QR-compressed" in d["config"]["workload"] and d["config"]["pipeline"] == "dense as-coded"
+    assert d["value"] > 0 and "QR-compressed" in d["config"]["workload"] and "mixed stacking" in d["config"]["pipeline"]
+    d = _run("--level", "G", "--oos", "20", "--oos-dense")
+    assert d["value"] > 0 and d["config"]["pipeline"] == "dense as-coded"

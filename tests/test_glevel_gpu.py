@@ -205,8 +205,10 @@ def test_config3_full_size_instate_plus_oos(built, compress, flags):
     src/helpers.cpp:77-101): M = 174; K, dx, P+ are unchanged to rounding."""
     cam = synth.PINHOLE
     ng, nf, F, B, n_oos, k = 8, 60, 60, 2, 20, 5
-    # flags 64 | 16 = DENSE_H | REASSOC: dense rows stacked at once, re-associated dense pipeline, no H^T copy kept
-    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 6, cam, M_max=2 * F + n_oos * (2 * k - 3), flags=flags)
+    # flags 64 | 16 = DENSE_H | REASSOC: dense rows stacked at once, re-associated dense pipeline, no H^T copy kept.
+    # flags 0 (round 3): mixed stacking - the in-state rows stay row-pair compressed, only the OOS block is dense (the 16
+    # spare rows of the allocation are what the 16-row-padded OOS block needs behind row 120)
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 6, cam, M_max=2 * F + n_oos * (2 * k - 3) + 16, flags=flags)
     assert lay.N == 251
     rng = np.random.default_rng(19)
     oos = np.zeros((B, n_oos), dtype=oos_dtype)
@@ -247,6 +249,7 @@ def test_config3_full_size_instate_plus_oos(built, compress, flags):
                 # the retained energy of the residual: ||Q1^T r|| <= ||r||
                 assert np.linalg.norm(ic[120:]) <= np.linalg.norm(if_[120:]) * (1 + 1e-12)
         ctx.update_joseph()
+        assert ctx.last_path() == (0 if flags else 1)        # mixed stacking runs the sparse pipeline
         err = ctx.get_err(); Pn = ctx.download_P()
         assert (ctx.get_status() == 0).all()
     assert rows.tolist() == [140] * B

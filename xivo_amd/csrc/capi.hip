@@ -50,6 +50,10 @@ struct xivo_hip_ctx {
   bool dense_valid = true;
   bool dense_from_ell = false;   // the stacked rows came in through set_measurements (compressed rows are the source)
   bool ht_valid = true;          // the transposed dense copy H^T matches H (false after a producer skipped it: skip_HT)
+  // mixed stacking (round 3): in-state rows [0, mixed_row0) exist in the row-pair compressed form only, the OOS rows
+  // appended by xivo_hip_oos_project from row mixed_row0 on in the dense buffer only; -1: not in that mode
+  int mixed_row0 = -1;
+  bool h_clean = true;           // every row of the dense H buffer the mixed mode has not written itself is zero
   double stack_R = 0.0; int stack_B = 0;
   size_t staging_elems = 0;
   long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0, sA = 0;   // sA: A buffer, max(N x N, N x M)
@@ -489,7 +493,7 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
     HIP_TRY((hipError_t)launch_meas_vectors(dInn, strideInn, dR, strideR, M, c->Mpmax, e, mb.inn, mb.strideInn, mb.diagR, mb.strideR, nb, c->stream));
     HIP_TRY((hipError_t)launch_unpack_meas(dH, strideH, ldh, nullptr, mb, M, c->Mpmax, N, c->Np, nb, c->stream));
     for (int b = b0; b < b0 + nb; ++b) { c->ell_over_h[b] = 1; c->ell_nc_h[b] = ELL_CW; c->ell_pw_h[b] = ELL_PW + 1; }
-    c->dense_valid = true; c->dense_from_ell = true; c->ht_valid = true;
+    c->dense_valid = true; c->dense_from_ell = true; c->ht_valid = true; c->mixed_row0 = -1; c->h_clean = false;
     return XIVO_HIP_OK;
   }
   {
@@ -507,6 +511,7 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   if (debug_on()) fprintf(stderr, "xivo_hip: hand-over b0=%d nb=%d M=%d any_over=%d nc0=%d pw0=%d\n", b0, nb, M, (int)any_over, c->ell_nc_h[b0], c->ell_pw_h[b0]);
   if (any_over) HIP_TRY((hipError_t)launch_unpack_meas(dH, strideH, ldh, e.over, mb, M, c->Mpmax, N, c->Np, nb, c->stream));
   c->dense_valid = false; c->dense_from_ell = true; c->ht_valid = true;   // (ensure_dense rebuilds H and H^T together)
+  c->mixed_row0 = -1; if (any_over) c->h_clean = false;
   return XIVO_HIP_OK;
 }
 
@@ -660,12 +665,27 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   const double Nf = c->N, Mf = c->M;
   const double nnz_flops = 2.0 * Mf * 21.0;   // per contiguous-index value: 21 structural non-zeros per row
   int rc;
+  // mixed stacking: rows [0, mr0) of H are the compressed in-state rows, rows [mr0, M) the dense OOS rows appended by
+  // xivo_hip_oos_project (non-zero over the extrinsics + group columns only: src/oos.cpp:74-88). The in-state rows keep the
+  // sparse walk below; the OOS block goes through two small MFMA products (rows padded to 16 from mr0 on).
+  const int mr0 = c->mixed_row0;
+  const int Mp_ell = mr0 >= 0 ? round_up16(mr0) : Mp;
+  const int oos_pad = mr0 >= 0 ? round_up16(Mp - mr0) : 0;
+  // the OOS rows are zero beyond the extrinsics and group columns (the mode clears and writes nothing else there): the two
+  // products of the OOS block contract over the leading oos_k state columns only
+  const int oos_k = (mr0 >= 0 && c->have_layout) ? std::min(Np, round_up16(c->lay.group_begin + 6 * c->lay.n_groups)) : Np;
   {
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
-    a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
+    a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp_ell; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
     char label[64]; ell_kernel_label(ELL_HP, a, label, sizeof(label));
     StageTimer st(c, ST_HP, nnz_flops * Nf * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_HP, a, c->stream));
+  }
+  if (mr0 >= 0) {   // (H P)_oos = H_oos P, with its transpose into the P H^T columns behind the in-state ones
+    const double* Hd = c->H + (long)b0 * c->sH + mr0;
+    GemmExtra x; x.C2 = PHT + (long)mr0 * Np; x.sC2 = c->sK; x.ldc2 = Np;
+    rc = gemm(c, ST_HP, B, oos_pad, Np, Hd, c->sH, ldh, P, c->sP, Np, oos_k, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, HP + mr0, c->sH, ldh, x);
+    if (rc) return rc;
   }
   GateEllArgs ga{};
   if (gate) {
@@ -683,7 +703,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   {
     EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
-    a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max;
+    a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp_ell; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max;
     // A/B knob (measured slower, off by default): the gate in the tail of the S kernel - S + gate 2.88 ms fused vs 2.30 + 0.36
     // as two kernels per 16384 filters: the tail runs at one 8-wave workgroup per CU where the stand-alone gate fills the chip
     static const bool fuse = getenv("XIVO_HIP_GATE_IN_S") != nullptr;
@@ -691,6 +711,13 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
     StageTimer st(c, ST_S, nnz_flops * Mf * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_S, a, c->stream));
+  }
+  if (mr0 >= 0) {   // the OOS x OOS block of S (the OOS x in-state block came out of the walk above: rows of S run over all M)
+    const double* Hd = c->H + (long)b0 * c->sH + mr0;
+    GemmExtra x; x.epi = EPI_ADD_DIAG; x.diag = diagR + mr0; x.sDiag = c->Mpmax; x.lower_only = 1;
+    rc = gemm(c, ST_S, B, oos_pad, oos_pad, HP + mr0, c->sH, ldh, Hd, c->sH, ldh, oos_k, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
+              S + mr0 + (long)mr0 * lds, c->sS, lds, x);
+    if (rc) return rc;
   }
   if (gate) c->gate_sparse_last = 0;
   if (gate && !gate_done) {
@@ -800,6 +827,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   a.ell = c->ell; a.ell.idx += (long)b0 * a.ell.stride_idx(); a.ell.val += (long)b0 * a.ell.stride_val();
   a.ell.nc += b0; a.ell.pw += b0; a.ell.over += b0;
   a.H = c->H + (long)b0 * c->sH; a.strideH = c->sH; a.ldh = c->Mpmax; a.use_dense = c->last_path == 0 ? 1 : 0;
+  a.mixed_row0 = c->last_path == 1 ? c->mixed_row0 : -1;
   a.PHT = c->PHT + (long)b0 * c->sK; a.stridePHT = c->sK; a.ldpht = c->Np;
   a.S = c->S + (long)b0 * c->sS; a.strideS = c->sS; a.lds = c->Mpmax;
   a.K = c->K + (long)b0 * c->sK; a.strideK = c->sK; a.ldk = c->Np;
@@ -1207,6 +1235,13 @@ static int ensure_HT(xivo_hip_ctx* c) {
 static int ensure_dense(xivo_hip_ctx* c) {
   if (c->dense_valid) return XIVO_HIP_OK;
   c->dense_valid = true;
+  if (c->mixed_row0 >= 0) {   // mixed stacking: the in-state rows come from the compressed form, the OOS rows are in place
+    c->h_clean = false; c->ht_valid = false;
+    StageTimer st(c, ST_STACK, 0.0, "ell_to_dense_kernel");
+    return launch_ell_to_dense(c->ell, c->H, c->sH, c->Mpmax, nullptr, c->sHT, c->Np, c->Mpmax, c->Np, c->Bmax, c->stream, c->mixed_row0)
+               ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
+  }
+  c->h_clean = false;
   if (c->dense_from_ell) {   // S-level hand-over: the compressed rows are the source (filters that do not fit hold dense rows already)
     StageTimer st(c, ST_STACK, 0.0, "ell_to_dense_kernel");
     return launch_ell_to_dense(c->ell, c->H, c->sH, c->Mpmax, c->HT, c->sHT, c->Np, c->Mpmax, c->Np, c->Bmax, c->stream)
@@ -1226,6 +1261,7 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   // the sparse-H pipeline reads only the compressed rows: skip the 2 x Mp x Np dense zero-fill + scatter
   const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
   c->dense_valid = dense != 0; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B; c->oos_row0 = -1;
+  c->mixed_row0 = -1; if (dense) c->h_clean = false;
   return stack_impl(c, B, R, dense);
 }
 
@@ -1248,7 +1284,29 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
     if (rows > max_rows) max_rows = rows;
   }
   if (c->M + max_rows > c->Mmax) return XIVO_HIP_ERR_INVALID;
-  { int rcd = ensure_dense(c); if (rcd) return rcd; }
+  // Mixed stacking (round 3, default whenever the in-state rows were stacked in the compressed form only and nothing
+  // forces the dense pipeline): the OOS rows go to the dense buffer behind the in-state rows and the update keeps the
+  // sparse walk for the in-state rows - only the OOS block takes the MFMA products (update_sparse_range). Needs a
+  // 16-row-padded OOS block inside the allocation; otherwise (and with XIVO_HIP_FLAG_DENSE_H / _FP32_COV) every row
+  // becomes dense as before.
+  static const bool no_mixed = getenv("XIVO_HIP_NO_MIXED_OOS") != nullptr;   // A/B knob
+  const bool mixed = !no_mixed && !c->dense_valid && !c->dense_from_ell && c->oos_row0 < 0 && b0 == 0 &&
+                     !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) && (c->M % 2 == 0) &&
+                     c->M + round_up16(max_rows + 16) <= c->Mpmax && c->Np <= 512;
+  if (!mixed) { int rcd = ensure_dense(c); if (rcd) return rcd; c->mixed_row0 = -1; }
+  else {
+    // the OOS rows must start from zero: only the extrinsics and group columns are ever written there in this mode, so
+    // those are cleared (whole rows once, if anything else has used the dense buffer since it was allocated)
+    const int nz = round_up16(max_rows + 16) < c->Mpmax - c->M ? round_up16(max_rows + 16) : c->Mpmax - c->M;
+    if (!c->h_clean) {
+      HIP_TRY((hipError_t)launch_zero_rows(c->H, c->sH, c->Mpmax, 0, c->Mpmax, 0, c->Np, c->Bmax, c->stream));
+      c->h_clean = true;
+    } else {
+      HIP_TRY((hipError_t)launch_zero_rows(c->H, c->sH, c->Mpmax, c->M, nz, 15, 21, nb, c->stream));
+      HIP_TRY((hipError_t)launch_zero_rows(c->H, c->sH, c->Mpmax, c->M, nz, c->lay.group_begin, c->lay.group_begin + 6 * c->lay.n_groups, nb, c->stream));
+    }
+    c->mixed_row0 = c->M;
+  }
   if (n_oos * nb > c->oos_cap) {
     if (c->oos) hipFree(c->oos);
     c->oos = nullptr; c->oos_cap = 0;
@@ -1265,7 +1323,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   OosArgs a{};
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
   a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
-  if (skip_HT(c)) { a.mb.HT = nullptr; c->ht_valid = false; }
+  if (skip_HT(c) || mixed) { a.mb.HT = nullptr; c->ht_valid = false; }
   c->oos_row0 = c->M; c->oos_R = Roos;
   a.rows_out = c->oos_rows;
   {
@@ -1275,7 +1333,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   if (rows_out) HIP_TRY(hipMemcpyAsync(rows_out, c->oos_rows, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->M += max_rows; c->Mp = round_up16(c->M);
-  for (int b = b0; b < b0 + nb; ++b) c->ell_over_h[b] = 1;   // OOS rows are dense over the group blocks: dense path
+  if (!mixed) for (int b = b0; b < b0 + nb; ++b) c->ell_over_h[b] = 1;   // OOS rows are dense over the group blocks: dense path
   return XIVO_HIP_OK;
 }
 
@@ -1335,6 +1393,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
   c->dense_valid = dense != 0; c->dense_from_ell = true; c->stack_R = R; c->stack_B = B;
   c->oos_row0 = -1;   // the partial stacking replaces the rows of any earlier xivo_hip_oos_project (as xivo_hip_stack does)
+  c->mixed_row0 = -1; if (dense) c->h_clean = false;
   int rc = stack_impl(c, B, R, dense, c->rs_low, 1);
   if (rc) return rc;
   rc = xivo_hip_update_joseph(c, B);
@@ -1380,7 +1439,7 @@ int xivo_hip_compress_oos(xivo_hip_ctx* c, int B, double trigger_ratio, int* row
     return XIVO_HIP_ERR_INVALID;
   OosCompressArgs a{};
   a.lay = c->lay; a.mb = meas_buffers(c); a.row0 = c->oos_row0; a.rows = c->oos_rows; a.rows_out = c->oos_rows;
-  if (skip_HT(c)) { a.mb.HT = nullptr; c->ht_valid = false; }
+  if (skip_HT(c) || c->mixed_row0 >= 0) { a.mb.HT = nullptr; c->ht_valid = false; }
   a.ratio = trigger_ratio; a.Roos = c->oos_R; a.batch = B;
   int rc;
   {

@@ -173,6 +173,7 @@ namespace xivo_hip {
 struct LdltFallbackArgs {
   int* status; int* used;
   EllBuffers ell; const double* H; long strideH; int ldh; int use_dense;
+  int mixed_row0;   // >= 0: rows below it are row-pair compressed, rows from it on are dense (OOS rows behind in-state rows)
   const double* PHT; long stridePHT; int ldpht;
   double* S; long strideS; int lds;
   double* K; long strideK; int ldk;

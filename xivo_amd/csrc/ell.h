@@ -46,8 +46,11 @@ bool meas_compress_fits(int Mp_clear, int Np);
 int launch_meas_vectors(const double* inn, long strideInn, const double* diagR, long strideR, int M, int Mp_clear, EllBuffers e,
                         double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s);
 // dense padded H / H^T of the filters that fit the compressed form (over = 0), rebuilt from it
+// (Mrows >= 0: only rows [0, Mrows) are rebuilt - mixed stacking keeps dense OOS rows behind them; HT may be null)
 int launch_ell_to_dense(EllBuffers e, double* H, long strideH, int ldh, double* HT, long strideHT, int ldht, int Mp,
-                        int Np, int batch, hipStream_t s);
+                        int Np, int batch, hipStream_t s, int Mrows = -1);
+// zero rows [row0, row0 + nrows) x columns [c0, c1) of every filter's dense H
+int launch_zero_rows(double* H, long strideH, int ldh, int row0, int nrows, int c0, int c1, int batch, hipStream_t s);
 
 // out[x + ldo * m] = sum_slots val[m][slot] * Src[x + lds * idx[m][slot]]  (+ epilogue), x in [0, X)
 enum EllMode : int {

@@ -157,27 +157,34 @@ __global__ __launch_bounds__(256) void meas_vectors_kernel(const double* __restr
 
 // Dense H / H^T (padded, both zero filled) of the filters whose rows fit the compressed form, rebuilt from it
 // on demand (dense pipeline, xivo_hip_get_H); filters with over = 1 already hold their dense rows.
+// rows >= Mrows keep what they hold (mixed stacking: the dense OOS rows behind the compressed in-state rows); HT may be null.
 __global__ __launch_bounds__(256) void ell_to_dense_kernel(EllBuffers e, double* Hall, long strideH, int ldh,
-                                                           double* HTall, long strideHT, int ldht, int Mp, int Np) {
+                                                           double* HTall, long strideHT, int ldht, int Mp, int Np, int Mrows) {
   const int filt = blockIdx.x, tid = threadIdx.x;
   if (e.over[filt]) return;
   double* H = Hall + (long)filt * strideH;
-  double* HT = HTall + (long)filt * strideHT;
+  double* HT = HTall ? HTall + (long)filt * strideHT : nullptr;
   for (long i = tid; i < (long)Mp * Np; i += 256) {
-    H[(i % Mp) + (i / Mp) * ldh] = 0.0;
-    HT[(i % Np) + (i / Np) * ldht] = 0.0;
+    if ((i % Mp) < Mrows) H[(i % Mp) + (i / Mp) * ldh] = 0.0;
+    if (HT && (i / Np) < Mrows) HT[(i % Np) + (i / Np) * ldht] = 0.0;
   }
   __syncthreads();
   const int* idx = e.idx + (long)filt * e.stride_idx();
   const double* val = e.val + (long)filt * e.stride_val();
-  for (int i = tid; i < (Mp / 2) * ELL_W; i += 256) {
+  for (int i = tid; i < (Mrows / 2) * ELL_W; i += 256) {
     const int p = i / ELL_W, n = idx[i];
     const double v0 = val[2 * (long)i], v1 = val[2 * (long)i + 1];
     if (v0 != 0.0 || v1 != 0.0) {     // unused slots name column 0 with value 0
       H[2 * p + (long)n * ldh] = v0; H[2 * p + 1 + (long)n * ldh] = v1;
-      HT[n + (long)(2 * p) * ldht] = v0; HT[n + (long)(2 * p + 1) * ldht] = v1;
+      if (HT) { HT[n + (long)(2 * p) * ldht] = v0; HT[n + (long)(2 * p + 1) * ldht] = v1; }
     }
   }
+}
+
+// rows [row0, row0 + nrows) of every filter's dense H, columns [c0, c1) (all of them: c0 = 0, c1 = Np): zero
+__global__ __launch_bounds__(256) void zero_rows_kernel(double* Hall, long strideH, int ldh, int row0, int nrows, int c0, int c1) {
+  double* H = Hall + (long)blockIdx.x * strideH;
+  for (long i = threadIdx.x; i < (long)nrows * (c1 - c0); i += 256) H[row0 + (i % nrows) + (long)(c0 + i / nrows) * ldh] = 0.0;
 }
 
 // ---------------------------------------------------------------- out = H_ell (x) Src, gather form
@@ -588,9 +595,15 @@ int launch_meas_vectors(const double* inn, long strideInn, const double* diagR, 
 }
 
 int launch_ell_to_dense(EllBuffers e, double* H, long strideH, int ldh, double* HT, long strideHT, int ldht, int Mp,
-                        int Np, int batch, hipStream_t s) {
+                        int Np, int batch, hipStream_t s, int Mrows) {
   if (batch <= 0) return 0;
-  hipLaunchKernelGGL(ell_to_dense_kernel, dim3(batch), dim3(256), 0, s, e, H, strideH, ldh, HT, strideHT, ldht, Mp, Np);
+  hipLaunchKernelGGL(ell_to_dense_kernel, dim3(batch), dim3(256), 0, s, e, H, strideH, ldh, HT, strideHT, ldht, Mp, Np,
+                     Mrows < 0 ? Mp : Mrows);
+  CHECK_LAUNCH();
+}
+int launch_zero_rows(double* H, long strideH, int ldh, int row0, int nrows, int c0, int c1, int batch, hipStream_t s) {
+  if (batch <= 0 || nrows <= 0 || c1 <= c0) return 0;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(batch), dim3(256), 0, s, H, strideH, ldh, row0, nrows, c0, c1);
   CHECK_LAUNCH();
 }
 

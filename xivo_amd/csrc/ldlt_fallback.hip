@@ -23,11 +23,11 @@ namespace xivo_hip {
 namespace {
 
 struct HRow {   // row-pair compressed or dense access to one filter's H
-  const int* idx; const double* val; const double* Hd; int ldh; int N; bool dense;
+  const int* idx; const double* val; const double* Hd; int ldh; int N; bool dense; int dense_from;   // rows >= dense_from are dense
   // calls f(col, value) for every stored entry of row m (dense: every column, zeros included)
   template <class F>
   __device__ __forceinline__ void for_each(int m, F&& f) const {
-    if (dense) {
+    if (dense || m >= dense_from) {
       for (int n = 0; n < N; ++n) f(n, Hd[m + (long)n * ldh]);
     } else {
       const int p = m >> 1, h = m & 1;
@@ -57,6 +57,7 @@ __global__ __launch_bounds__(1024) void ldlt_fallback_kernel(LdltFallbackArgs a)
   H.dense = a.use_dense || a.ell.over[filt] != 0;
   H.idx = a.ell.idx + (long)filt * a.ell.stride_idx(); H.val = a.ell.val + (long)filt * a.ell.stride_val();
   H.Hd = a.H + (long)filt * a.strideH; H.ldh = a.ldh; H.N = N;
+  H.dense_from = a.mixed_row0 >= 0 ? a.mixed_row0 : (1 << 30);
 
   __shared__ int perm[512];       // transpositions (M <= 384)
   __shared__ double sred[1024];
