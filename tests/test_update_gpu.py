@@ -630,3 +630,39 @@ def test_update_matches_the_eigen_driver_directly(built, N, F):
     for b in range(B):
         e_ref, P_ref = ref.update_joseph(H[b], P[b], inn[b], dR[b])[:2]
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+def _fuzz_cases():
+    rng = np.random.default_rng(20260924)
+    from xivo_amd.lib import (FLAG_DENSE_H, FLAG_REASSOC, FLAG_SYMMETRIC_FORM, FLAG_STANDALONE_TAIL, FLAG_EXPANDED_JOSEPH,
+                              FLAG_FP32_CORR, FLAG_FULL_PNEW)
+    flag_sets = [0, 0, 0, FLAG_SYMMETRIC_FORM, FLAG_STANDALONE_TAIL, FLAG_EXPANDED_JOSEPH, FLAG_DENSE_H, FLAG_DENSE_H | FLAG_REASSOC,
+                 FLAG_FULL_PNEW, FLAG_STANDALONE_TAIL | FLAG_FP32_CORR]
+    cases = []
+    for i in range(36):
+        N = int(rng.integers(24, 420))
+        F = int(rng.integers(1, min(96, max(2, N // 3)) + 1))
+        if i % 6 == 5:
+            F = int(rng.integers(90, 150))                      # factors beyond the LDS: streamed solve
+        B = int(rng.integers(1, 10))
+        cases.append((N, F, B, flag_sets[i % len(flag_sets)], 1000 + i))
+    return cases
+
+
+@pytest.mark.parametrize("N,F,B,flags,seed", _fuzz_cases())
+def test_random_shapes_and_modes_match_oracle(built, N, F, B, flags, seed):
+    """Seeded random shapes (state dim 24..419, 1..149 features, 1..9 filters) through every covariance-update mode: the
+    in-solve kernels (one workgroup / chunked / streamed, whitened and expanded forms), the stand-alone tails, the symmetric
+    form, the dense pipelines. Tolerances as everywhere: 1e-6 on P (5e-5 where an fp32 product was asked for), 1e-8 on dx."""
+    from xivo_amd.lib import FLAG_FP32_CORR
+    P, H, inn, dR = synth.s_level(N, F, B, seed=seed)
+    with Context(N, 2 * F, B, flags=flags) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        assert (ctx.get_status() == 0).all() and not ctx.get_ldlt_used().any()
+        err = ctx.get_err(); Pn = ctx.download_P()
+    tol_P = 5e-5 if flags & FLAG_FP32_CORR else TOL_P
+    for b in range(B):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < tol_P and rel_fro(err[b], e_ref) < TOL_DX
+        if not flags & 4:                       # (XIVO_HIP_FLAG_FULL_PNEW computes every entry instead of lower triangle + mirror)
+            assert np.array_equal(Pn[b], Pn[b].T)
