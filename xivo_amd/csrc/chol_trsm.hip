@@ -540,8 +540,10 @@ __global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
 // into the LDS buffer - nothing is read back from memory. NEG_OUT: Out = Minit - A Src^T.
 // FIXUP: Src arrives by DMA as usual and the wave that owns a block then replaces it in LDS by 2 Src - A (its registers):
 // the whitened Joseph form needs (W - D)^T (W + D) with only W in memory (see TF == 4 below).
-template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false, bool FIXUP = false>
-__device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* sL, const double* __restrict__ Src, int ldsrc,
+// YREGS (with SRC_REGS): the LDS operand is 2 Wr - A from the owner waves' registers (short factors keep W in registers:
+// no stash, no DMA, no fix-up pass).
+template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false, bool FIXUP = false, bool YREGS = false>
+__device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4 (&Wr)[NBM], double* sL, const double* __restrict__ Src, int ldsrc,
                                                     const double* __restrict__ Minit, int ldm, double* __restrict__ Out, int ldo,
                                                     int nb, int nwl, int jbp, bool live, int w, int wave, int lane) {
   const int li = lane & 15, lg = lane >> 4;
@@ -560,7 +562,7 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], double* 
         for (int mb = 0; mb < NBM; ++mb) {
           if (mb < nb) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(mb * 4 + r) * 64] = X[mb][r];
+            for (int r = 0; r < 4; ++r) dst[(mb * 4 + r) * 64] = YREGS ? fma(2.0, Wr[mb][r], -X[mb][r]) : X[mb][r];
           }
         }
       }
@@ -680,6 +682,8 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   // block rows), else packed into the unused upper triangle + pad row of the inverse's slot (a few selects per read)
   constexpr bool T4 = TF == 4 || TF == 5;   // whitened Joseph form; TF == 5: its outputs V^T, Y^T for a product outside the kernel
   constexpr bool WOUT = TF == 5;
+  // short factors (M <= 96): W stays in registers next to the working copy - no stash, no read-back, no DMA of the operand
+  constexpr bool KEEPW = T4 && NBM <= 6;
   constexpr bool PACK = (TF == 3 || T4) && NBM > 10;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
   const int chunks = (g.Np + 255) / 256;
@@ -713,6 +717,9 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       for (int r = 0; r < 4; ++r) X[i][r] = buf_ld(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u);
     }
   }
+  d4 Wk[KEEPW ? NBM : 1];                           // (KEEPW) the forward-substituted columns, kept next to the working copy
+#pragma unroll
+  for (int i = 0; i < (KEEPW ? NBM : 1); ++i) Wk[i] = d4{0.0, 0.0, 0.0, 0.0};
 
   // cooperative copy: block (i,k), i >= k at slot i(i+1)/2 + k. The loads of a thread are requested four at a time before
   // the first of them is consumed (compile-time trip count): the loop used to wait for each of its ~7 round trips in turn,
@@ -815,7 +822,11 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     }
   }
   double part = 0.0;
-  if (T4 && XIVO_ABL != 6) {
+  if (KEEPW) {
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) Wk[i] = X[i];
+  }
+  if (T4 && !KEEPW && XIVO_ABL != 6) {
     // the forward-substituted columns W^T = (L^-1 H P)^T leave for the stash (the K buffer: the gain itself is never
     // stored by this variant) - the backward substitution below destroys them and the covariance update needs them again
 #pragma unroll
@@ -834,7 +845,8 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       // TF == 4: W_k comes back from the stash while this step's MFMAs run (requested here, used at the end of the step;
       // the last block row has not been touched yet: it is still in X)
       d4 wk = d4{0.0, 0.0, 0.0, 0.0};
-      if (T4) {
+      if (KEEPW) wk = Wk[k];
+      else if (T4) {
         if (k == nb - 1) wk = X[k];
         else if (XIVO_ABL != 6) {
 #pragma unroll
@@ -983,7 +995,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     // ---- P+ = P - Z^T K^T in place: rows of Z^T in registers, blocks of the gain just written arrive through LDS
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
     double* Pio = g.T + (long)filt * g.strideT;
-    sym_tiles_from_regs<NBM, false, true>(X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+    sym_tiles_from_regs<NBM, false, true>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
                                           live, c0 >> 4, wave, lane);
     return;
   }
@@ -1004,19 +1016,21 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
     if (XIVO_ABL == 1) return;
     double* Pio = g.T + (long)filt * g.strideT;
-    sym_tiles_from_regs<NBM, false, true, true>(X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
-                                                live, c0 >> 4, wave, lane);
+    if constexpr (KEEPW) sym_tiles_from_regs<NBM, true, true, false, true>(X, Wk, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+                                                                 live, c0 >> 4, wave, lane);
+    else sym_tiles_from_regs<NBM, false, true, true>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+                                                     live, c0 >> 4, wave, lane);
     return;
   }
   if (TF == 2) {
     // ---- symmetric form: P+ = P - W^T W in place, W^T = the forward-substituted columns still in registers
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
     double* Pio = g.T + (long)filt * g.strideT;
-    sym_tiles_from_regs<NBM, true, true>(X, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
+    sym_tiles_from_regs<NBM, true, true>(X, X, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
     return;
   }
   // ---- T = K (HP) - P
-  sym_tiles_from_regs<NBM>(X, sL, PHT, g.ldpht, g.Pm + (long)filt * g.stridePm, g.ldpm, g.T + (long)filt * g.strideT, g.ldt,
+  sym_tiles_from_regs<NBM>(X, X, sL, PHT, g.ldpht, g.Pm + (long)filt * g.stridePm, g.ldpm, g.T + (long)filt * g.strideT, g.ldt,
                            nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
 }
 
@@ -1047,7 +1061,7 @@ __global__ __launch_bounds__(1024) void pnew_reg_f64_kernel(PnewRegArgs g) {
       for (int r = 0; r < 4; ++r) X[i][r] = G[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldg];
     }
   }
-  sym_tiles_from_regs<NBM>(X, sL, g.K + (long)filt * g.strideK, g.ldk, g.T + (long)filt * g.strideT, g.ldt,
+  sym_tiles_from_regs<NBM>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, g.T + (long)filt * g.strideT, g.ldt,
                            g.P + (long)filt * g.strideP, g.ldp, nb, g.Np / 16, g.jbp, live, wave, wave, lane);
 }
 
@@ -1372,6 +1386,8 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
     return launch_trsm_stream_t<8, 1>(g, stream);
   }
   // whole factor in LDS (nb(nb+1)/2 blocks of 16x17 doubles) when it fits 160 KiB
+  // (a four-block-row instantiation of the whitened form for the TUM-VI build's 30 features spills 1232 VGPRs - hipcc 7.2;
+  //  six block rows serve M <= 96)
   if (nb <= 6) return launch_trsm_lds_t<6>(g, stream);
   if (nb <= 10) return launch_trsm_lds_t<10>(g, stream);
   // (eleven block rows with the whitened outputs leaving the kernel: that instantiation spills 700 VGPRs - streamed instead)
