@@ -1,4 +1,6 @@
 #!/bin/bash
+# SQ counter passes (wave cycles / waits / instruction mix / LDS conflicts) of the bench command, one counter group per run;
+# summary printed per kernel. DESIGN.md 3.2 quotes these for trsm_lds_f64_kernel<10,4>.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_sq; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp
