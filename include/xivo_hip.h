@@ -112,7 +112,13 @@ enum {
    * and the as-coded Joseph form, on that filter only (ldlt_fallback.hip); xivo_hip_get_ldlt_used tells which filters took
    * that route and their status reads 0. With this flag such a filter keeps its prior covariance bit for bit, absorbs
    * nothing, and xivo_hip_get_status reports it (the behaviour of rounds 1-2). */
-  XIVO_HIP_FLAG_NO_LDLT_FALLBACK = 4096u
+  XIVO_HIP_FLAG_NO_LDLT_FALLBACK = 4096u,
+  /* By default an update of at most 64 filters (one estimator is the reference's own use) takes the latency route of the
+   * default pipeline: the solve on 128-column workgroups of the streamed kernel, the covariance product P - V^T Y on
+   * 64 x 64 tiles - the same whitened Joseph evaluation spread over tens of CUs instead of one CU per filter (B = 1,
+   * N = 250, M = 160: solve + product 0.07 instead of 0.13 ms). With this flag every batch size runs the kernels sized for
+   * thousands of filters (one workgroup per filter, whole update inside the solve kernel). */
+  XIVO_HIP_FLAG_THROUGHPUT_ROUTE = 8192u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,

@@ -6,7 +6,7 @@ import pytest
 import xivo_oracle as orc
 from helpers import rel_fro, TOL_P, TOL_DX
 from xivo_amd import synth
-from xivo_amd.lib import Context, FLAG_FULL_PNEW, FLAG_DENSE_H
+from xivo_amd.lib import Context, FLAG_FULL_PNEW, FLAG_DENSE_H, FLAG_THROUGHPUT_ROUTE
 
 pytestmark = pytest.mark.gpu
 
@@ -26,14 +26,18 @@ CASES = [  # (N, F) -> M = 2F ; BASELINE.json configs + TUM-VI default build + r
 
 
 @pytest.mark.parametrize("N,F", CASES)
-@pytest.mark.parametrize("kind", ["sparse", "dense", "sparse_forced_dense"])
+@pytest.mark.parametrize("kind", ["sparse", "dense", "sparse_forced_dense", "sparse_throughput_route"])
 def test_update_joseph_matches_oracle(built, N, F, kind):
     """kind: XIVO row sparsity -> sparse-H pipeline (ell.h); dense H -> as-coded dense pipeline picked
-    automatically; the same sparse H with XIVO_HIP_FLAG_DENSE_H -> as-coded dense pipeline."""
+    automatically; the same sparse H with XIVO_HIP_FLAG_DENSE_H -> as-coded dense pipeline. Five filters take the latency
+    route where it exists (M <= 224: streamed solve + tiled product); sparse_throughput_route: the same update on the
+    kernels sized for thousands of filters (XIVO_HIP_FLAG_THROUGHPUT_ROUTE: one workgroup per filter, update inside the solve)."""
     B = 5
     dense = kind == "dense"
     P, H, inn, dR = synth.s_level(N, F, B, seed=N * 7 + F, dense=dense)
-    with Context(N, 2 * F, B, flags=FLAG_DENSE_H if kind == "sparse_forced_dense" else 0) as ctx:
+    flags = {"sparse_forced_dense": FLAG_DENSE_H, "sparse_throughput_route": FLAG_THROUGHPUT_ROUTE}.get(kind, 0)
+    kind = "sparse" if kind == "sparse_throughput_route" else kind
+    with Context(N, 2 * F, B, flags=flags) as ctx:
         ctx.upload_P(P)
         ctx.set_measurements(H, inn, dR)
         ctx.update_joseph()
@@ -323,11 +327,14 @@ def test_fp32_correction_product_is_invisible(built, N, F):
         assert rel_fro(outs[0][b], P_ref) < 1e-10
 
 
-def test_profile_reports_kernels_bytes_and_path(built):
+@pytest.mark.parametrize("B", [16, 96])
+def test_profile_reports_kernels_bytes_and_path(built, B):
     """What bench.py builds its roofline from: per-stage kernel names (as rocprofv3 spells them, minus spaces),
-    algorithmic flops / bytes and which pipeline ran."""
+    algorithmic flops / bytes and which pipeline ran. B = 16 takes the latency route (at most 64 filters: the solve on
+    128-column workgroups of the streamed kernel + the tiled product), B = 96 one workgroup per filter."""
     from xivo_amd.lib import FLAG_PROFILE
-    N, F, B = 250, 80, 16
+    N, F = 250, 80
+    latency = B <= 64
     P, H, inn, dR = synth.s_level(N, F, B, seed=1)
     for flags, path, hp_kernel in ((FLAG_PROFILE, 1, "ell_tile_kernel<0,12,64,9>"),
                                    (FLAG_PROFILE | FLAG_DENSE_H, 0, "gemm_nt_f64_kernel<5,4,double>")):
@@ -338,15 +345,20 @@ def test_profile_reports_kernels_bytes_and_path(built):
             assert ctx.last_path() == path
         assert prof["gemm_HP"]["kernel"] == hp_kernel
         # sparse pipeline: the solve kernel carries the whole covariance update on the gain in its registers - no stand-alone
-        # T / G / P+ kernels
-        stages = ("gemm_HP", "gemm_S", "chol_S", "trsm_gain") + (() if path == 1 else ("gemm_AP", "gemm_Pnew"))
+        # T / G / P+ kernels (latency route: the whitened outputs leave the solve and one tiled product follows)
+        tail = ("gemm_Pnew",) if latency and path == 1 else (() if path == 1 else ("gemm_AP", "gemm_Pnew"))
+        stages = ("gemm_HP", "gemm_S", "chol_S", "trsm_gain") + tail
         for st in stages:
             assert prof[st]["launches"] == 1 and prof[st]["ms"] > 0 and prof[st]["kernel"]
             assert prof[st]["bytes_per_launch"] > 0 and prof[st]["flops_per_launch"] > 0
         if path == 1:
-            assert prof["gemm_AP"]["launches"] == 0 and prof["gemm_KH_I"]["launches"] == 0 and prof["gemm_Pnew"]["launches"] == 0
-        assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<10")   # B = 16: the latency kernel
-        assert prof["trsm_gain"]["kernel"] == ("trsm_lds_f64_kernel<10,4>" if path == 1 else "trsm_lds_f64_kernel<10,0>")
+            assert prof["gemm_AP"]["launches"] == 0 and prof["gemm_KH_I"]["launches"] == 0
+            assert prof["gemm_Pnew"]["launches"] == (1 if latency else 0)
+        assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<10")   # B < 512: the latency kernel
+        if path == 1:
+            assert prof["trsm_gain"]["kernel"] == ("trsm_stream_f64_kernel<14,1>" if latency else "trsm_lds_f64_kernel<10,4>")
+        else:
+            assert prof["trsm_gain"]["kernel"] == "trsm_lds_f64_kernel<10,0>"
 
 
 @pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])
@@ -504,7 +516,7 @@ def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
     B = 3
     P, H, inn, dR = synth.s_level(N, F, B, seed=17)
     outs, errs, kern = [], [], []
-    for flags in (0, FLAG_STANDALONE_TAIL):
+    for flags in (FLAG_THROUGHPUT_ROUTE, FLAG_STANDALONE_TAIL):
         with Context(N, 2 * F, B, flags=flags | FLAG_PROFILE) as ctx:
             ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
             assert ctx.last_path() == 1
@@ -530,13 +542,15 @@ def test_whitened_and_expanded_in_solve_forms_agree(built, N, F):
     B = 9                                    # more than one XCD group of 8
     P, H, inn, dR = synth.s_level(N, F, B, seed=23)
     outs, errs, kern = [], [], []
-    for flags in (0, FLAG_EXPANDED_JOSEPH):
+    for flags in (FLAG_THROUGHPUT_ROUTE, FLAG_EXPANDED_JOSEPH, 0):
         with Context(N, 2 * F, B, flags=flags | FLAG_PROFILE) as ctx:
             ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
             assert ctx.last_path() == 1 and (ctx.get_status() == 0).all()
             outs.append(ctx.download_P()); errs.append(ctx.get_err())
             kern.append(ctx.profile_get()["trsm_gain"]["kernel"])
-    assert kern[0].endswith(",4>") and kern[1].endswith(",3>")
+    # nine filters without a flag: the latency route - the same whitened evaluation from the streamed solve + tiled product
+    assert kern[0].endswith(",4>") and kern[1].endswith(",3>") and kern[2].startswith("trsm_stream_f64_kernel<")
+    assert rel_fro(errs[0], errs[2]) < 1e-13 and rel_fro(outs[0], outs[2]) < 1e-11
     assert rel_fro(errs[0], errs[1]) < 1e-13
     assert rel_fro(outs[0], outs[1]) < 1e-11
     for b in range(B):
@@ -546,9 +560,11 @@ def test_whitened_and_expanded_in_solve_forms_agree(built, N, F):
             assert np.array_equal(o[b], o[b].T)
 
 
-def test_whitened_form_ill_conditioned_and_not_spd(built):
+@pytest.mark.parametrize("route", [FLAG_THROUGHPUT_ROUTE, 0])
+def test_whitened_form_ill_conditioned_and_not_spd(built, route):
     """cond(S) ~ 1e7 plus one filter whose S is indefinite: tolerances as for every other evaluation, the indefinite filter
-    keeps its prior bit for bit, the smallest eigenvalue of P+ stays at rounding level."""
+    keeps its prior bit for bit, the smallest eigenvalue of P+ stays at rounding level. Both routes of the whitened form
+    (in-solve update; streamed solve + tiled product for few filters)."""
     N, F, B = 150, 40, 4
     rng = np.random.default_rng(31)
     _, H, inn, _ = synth.s_level(N, F, B, seed=6)
@@ -561,7 +577,7 @@ def test_whitened_form_ill_conditioned_and_not_spd(built):
     dR = np.full((B, 2 * F), 1e-6)
     dR[2, :] = -1e3
     from xivo_amd.lib import FLAG_NO_LDLT_FALLBACK
-    with Context(N, 2 * F, B, flags=FLAG_NO_LDLT_FALLBACK) as ctx:
+    with Context(N, 2 * F, B, flags=FLAG_NO_LDLT_FALLBACK | route) as ctx:
         ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
         st = ctx.get_status(check=False)
         err = ctx.get_err(); Pn = ctx.download_P()
@@ -636,7 +652,7 @@ def _fuzz_cases():
     rng = np.random.default_rng(20260924)
     from xivo_amd.lib import (FLAG_DENSE_H, FLAG_REASSOC, FLAG_SYMMETRIC_FORM, FLAG_STANDALONE_TAIL, FLAG_EXPANDED_JOSEPH,
                               FLAG_FP32_CORR, FLAG_FULL_PNEW)
-    flag_sets = [0, 0, 0, FLAG_SYMMETRIC_FORM, FLAG_STANDALONE_TAIL, FLAG_EXPANDED_JOSEPH, FLAG_DENSE_H, FLAG_DENSE_H | FLAG_REASSOC,
+    flag_sets = [0, FLAG_THROUGHPUT_ROUTE, FLAG_THROUGHPUT_ROUTE, FLAG_SYMMETRIC_FORM, FLAG_STANDALONE_TAIL, FLAG_EXPANDED_JOSEPH, FLAG_DENSE_H, FLAG_DENSE_H | FLAG_REASSOC,
                  FLAG_FULL_PNEW, FLAG_STANDALONE_TAIL | FLAG_FP32_CORR]
     cases = []
     for i in range(36):
@@ -652,8 +668,8 @@ def _fuzz_cases():
 @pytest.mark.parametrize("N,F,B,flags,seed", _fuzz_cases())
 def test_random_shapes_and_modes_match_oracle(built, N, F, B, flags, seed):
     """Seeded random shapes (state dim 24..419, 1..149 features, 1..9 filters) through every covariance-update mode: the
-    in-solve kernels (one workgroup / chunked / streamed, whitened and expanded forms), the stand-alone tails, the symmetric
-    form, the dense pipelines. Tolerances as everywhere: 1e-6 on P (5e-5 where an fp32 product was asked for), 1e-8 on dx."""
+    in-solve kernels (one workgroup / chunked / streamed, whitened and expanded forms), the latency route (no flag: at most
+    nine filters here), the stand-alone tails, the symmetric form, the dense pipelines. Tolerances as everywhere: 1e-6 on P (5e-5 where an fp32 product was asked for), 1e-8 on dx."""
     from xivo_amd.lib import FLAG_FP32_CORR
     P, H, inn, dR = synth.s_level(N, F, B, seed=seed)
     with Context(N, 2 * F, B, flags=flags) as ctx:

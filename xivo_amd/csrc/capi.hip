@@ -248,6 +248,7 @@ struct GemmExtra {
   int no_mirror = 0;
   const int* skip = nullptr;   // per-filter status: non-zero = leave the output of that filter untouched
   const double* scale0 = nullptr;   // per-k scale of the first segment's B operand (same vector for every filter)
+  int small_tiles = 0;   // symmetric output on 64 x 64 tiles (latency route)
 };
 
 int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0, long sA0, int lda0,
@@ -267,7 +268,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   g.diag = x.diag; g.strideDiag = x.sDiag; g.Msub = x.msub; g.strideMsub = x.sMsub; g.ldmsub = x.ldmsub;
   g.McolScale = x.mcol; g.strideMcol = x.sMcol;
   g.epilogue = x.epi; g.lower_only = x.lower_only; g.no_mirror = x.no_mirror; g.batch = B; g.fp32 = x.fp32;
-  g.skip_status = x.skip;
+  g.skip_status = x.skip; g.small_tiles = x.small_tiles;
   // algorithmic flops of the product: a symmetric output needs its lower triangle only
   const double outs = x.lower_only ? 0.5 * rows * (cols + 1.0) : (double)rows * cols;
   const double flops = 2.0 * outs * (double)(K0 + (A1 ? K1 : 0)) * B;
@@ -285,6 +286,15 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
 }
 
 }  // namespace
+
+// An update of few filters takes the latency route (chol_trsm.hip, trsm_latency_route) when the pipeline would evaluate the
+// whitened Joseph form anyway: streamed solve with the whitened outputs + the tiled product P - V^T Y on small tiles.
+static bool latency_route(const xivo_hip_ctx* c, int Mp, int B, bool full) {
+  static const bool knobs = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") || getenv("XIVO_HIP_NO_TRSM_T") || getenv("XIVO_HIP_T_FULL");
+  const unsigned other = XIVO_HIP_FLAG_THROUGHPUT_ROUTE | XIVO_HIP_FLAG_EXPANDED_JOSEPH | XIVO_HIP_FLAG_STANDALONE_TAIL |
+                         XIVO_HIP_FLAG_FP32_CORR | XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_FP32_COV;
+  return !full && !knobs && !(c->flags & other) && trsm_latency_route(Mp, B);
+}
 
 static int ensure_gate_buffers(xivo_hip_ctx* c, int F);
 static int ensure_dense(xivo_hip_ctx* c);
@@ -724,9 +734,10 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
     HIP_TRY((hipError_t)launch_gate_ell(ga, c->stream));
   }
+  const bool lat = latency_route(c, Mp, B, full);
   {
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B);
+    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B); a.latency = lat;
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
     StageTimer st(c, ST_CHOL, Mf * Mf * Mf / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
@@ -741,7 +752,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     a.batch = B;
     // the solve goes on to the whole covariance update in place with the gain still in its registers (expanded Joseph
     // form; T and G never exist in memory) - or, with XIVO_HIP_NO_JOSEPH_IN_SOLVE, to T = K (HP) - P only
-    const bool t_here = !t_full && trsm_forms_T(Mp, Np);
+    const bool t_here = !t_full && !lat && trsm_forms_T(Mp, Np);
     static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;   // A/B knob
     const bool all_here = t_here && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);   // (both precision modes: all fp64 and faster than the fp32 correction product)
     const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;   // 2: whitened form (default), 1: P - K(2HP - L L^T K^T)
@@ -751,11 +762,11 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     static const bool no_trsm_t = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: the round-1 stand-alone tail for every shape
     wh_out = !t_here && !t_full && jform == 2 && !no_joseph && !no_trsm_t &&
              !(c->flags & (XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_FP32_CORR));
-    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; }
+    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; }
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : (wh_out ? 5 : 0)));
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : (wh_out ? 5 : 0)), lat);
     const double t_outs = 0.5 * Np * (Np + 1.0), t_outs_f = 0.5 * Nf * (Nf + 1.0);
     // algorithmic flops (true N, M): the two triangular solves (M^2 N each), the symmetric N x N x M product (lower
     // triangle), and for the expanded form the two triangular products of K L L^T; the whitened form's residual blocks
@@ -769,6 +780,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   if (wh_out) {   // P+ = P - V^T Y in place (V^T in the K buffer, Y^T in the G buffer), lower triangle + mirror
     GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
+    x.small_tiles = lat;
     return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, G, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
   }
   if (!t_done) {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
@@ -894,9 +906,10 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
               S, c->sS, lds, x);
     if (rc) return rc;
   }
+  const bool lat = (c->flags & XIVO_HIP_FLAG_REASSOC) && latency_route(c, Mp, B, full);
   {  // S = L L^T
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B);
+    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B); a.latency = lat;
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
@@ -911,13 +924,13 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
     // re-associated pipeline: the whole covariance update inside the solve kernel, as in the sparse pipeline (it
     // needs the factor, P H^T and P only - nothing of H's structure)
     static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
-    const bool all_here = (c->flags & XIVO_HIP_FLAG_REASSOC) && !f32 && !full && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL) && trsm_forms_T(Mp, Np);
+    const bool all_here = (c->flags & XIVO_HIP_FLAG_REASSOC) && !f32 && !full && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL) && !lat && trsm_forms_T(Mp, Np);
     const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
     wh_out = (c->flags & XIVO_HIP_FLAG_REASSOC) && !all_here && !f32 && !full && !no_joseph && jform == 2 &&
              !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);
-    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; }
+    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; }
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (wh_out ? 5 : 0));
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (wh_out ? 5 : 0), lat);
     const double t_outs = 0.5 * Np * (Np + 1.0);
     StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (all_here ? 2.0 * t_outs * Mp + (jform == 2 ? 32.0 * Mp * Np : 2.0 * Mp * Mp * Np) : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (all_here ? t_outs + (double)Np * Np : 0.0)));
@@ -926,6 +939,7 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
   }
   if (wh_out) {   // P+ = P - V^T Y in place, as in the sparse pipeline
     GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
+    x.small_tiles = lat;
     return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, c->A + (long)b0 * c->sA, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
   }
   if (c->flags & XIVO_HIP_FLAG_REASSOC) {

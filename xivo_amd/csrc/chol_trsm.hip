@@ -1319,7 +1319,7 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   const bool want_reg = g.variant == 2 || (g.variant == 0 && (g.batch < 512 || reg_always));
   if (!old_kernel && nb <= 12 && g.variant != 1 && want_reg) {
     static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
-    const int mirror = (nb > 10 || small_stream) ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
+    const int mirror = (nb > 10 || small_stream || g.latency) ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
                                           // whitened outputs leave the kernel (launch_trsm_f64)
     const bool many = g.batch >= 512;
     if (nb <= 4) hipLaunchKernelGGL((chol_reg_f64_kernel<4, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
@@ -1367,6 +1367,15 @@ int launch_pnew_reg_f64(const PnewRegArgs& g, hipStream_t stream) {
 
 void pnew_reg_kernel_label(int Mp, char* buf, size_t n) { snprintf(buf, n, "pnew_reg_f64_kernel<%d>", Mp / 16 <= 6 ? 6 : 10); }
 
+// Few filters (fewer one-per-filter workgroups than a quarter of the CUs): the solve spreads over 128-column workgroups of
+// the streamed kernel and the covariance product over the tiles of the stand-alone GEMM, instead of one CU per filter doing
+// all 13 000 MFMAs of an update by itself (87 us at the issue rate for N = 250, M = 160). The caller (capi.hip) combines this
+// with the pipeline's own conditions and XIVO_HIP_FLAG_THROUGHPUT_ROUTE; XIVO_HIP_NO_LATENCY_ROUTE: A/B knob.
+bool trsm_latency_route(int Mp, int batch) {
+  static const bool off = getenv("XIVO_HIP_NO_LATENCY_ROUTE") != nullptr;
+  return !off && Mp / 16 <= 14 && batch <= 64;
+}
+
 bool trsm_forms_T(int Mp, int Np) {
   static const bool off = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: T as a stand-alone product
   static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;   // A/B knob: small factors take the whitened-outputs path
@@ -1380,11 +1389,12 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   // A/B knob (round 3 experiment): small factors with the whitened outputs through the streamed kernel - 8-wave workgroups of
   // 128 columns, two or more per CU, instead of one 16-wave workgroup per filter
   static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
-  if (small_stream && g.Yout && !g.fwd_only && nb <= 8) {
+  if ((small_stream || g.latency) && g.Yout && !g.fwd_only && nb <= 8) {
     if (nb <= 4) return launch_trsm_stream_t<4, 1>(g, stream);
     if (nb <= 6) return launch_trsm_stream_t<6, 1>(g, stream);
     return launch_trsm_stream_t<8, 1>(g, stream);
   }
+  if (g.latency && g.Yout && !g.fwd_only && nb <= 14) return launch_trsm_stream_t<14, 1>(g, stream);
   // whole factor in LDS (nb(nb+1)/2 blocks of 16x17 doubles) when it fits 160 KiB
   // (a four-block-row instantiation of the whitened form for the TUM-VI build's 30 features spills 1232 VGPRs - hipcc 7.2;
   //  six block rows serve M <= 96)
@@ -1431,11 +1441,12 @@ void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
   else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)), (nb > 8 && batch >= 512) ? 3 : 2);
 }
 
-void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T) {
+void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T, bool latency) {
   const int nb = Mp / 16;
   const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
   static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
-  if (small_stream && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
+  if (latency && forms_T == 5 && nb <= 14) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
+  else if (small_stream && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
   else if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
   else if (!no_stream) snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
   else snprintf(buf, n, "trsm_f64_kernel");

@@ -61,6 +61,7 @@ struct GemmArgs {
   int lower_only;      // 1: skip tiles strictly above the diagonal and mirror-store
   int no_mirror;       // with lower_only: store the lower triangle only (the reader knows the matrix is symmetric)
   int batch;
+  int small_tiles;     // lower_only: 64 x 64 tiles (few filters: more workgroups per output)
   int tiles_m, tiles_n;
   int fp32;            // 1: fp32 MFMA with fp32 accumulation for this product (operands/results stay fp64 in HBM)
   const int* skip_status;  // optional [batch]: filters with a non-zero entry are left untouched (S not positive definite:
@@ -87,6 +88,7 @@ struct CholArgs {
   int* status;      // per filter: 0 ok, else 1 + first non-positive pivot index
   int batch;
   int variant;      // 0: size heuristic; 1: one wave per filter (chol_f64_kernel); 2: four waves, factor in registers
+  int latency;      // the solve behind it takes the latency route (streamed kernel: reads the mirrored upper triangle)
 };
 int launch_chol_f64(const CholArgs& args, hipStream_t stream);
 void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant = 0);
@@ -109,6 +111,7 @@ struct TrsmArgs {
   long strideErr;
   int Mp, Np;
   int batch;
+  int latency;         // with Yout: the latency route (trsm_latency_route) - streamed kernel whatever the factor's size
   int fwd_only;        // 1: stop after the forward substitution: K receives W^T = (L^-1 HP)^T and dx = W^T y with
   const double* y;     //    y = L^-1 inn [Mp] (launch_fwd_vec) - the symmetric form P+ = P - W^T W needs no more
   long strideY;
@@ -154,10 +157,11 @@ int launch_pnew_reg_f64(const PnewRegArgs& args, hipStream_t stream);
 void pnew_reg_kernel_label(int Mp, char* buf, size_t n);
 // whether launch_trsm_f64 forms T itself for these shapes (whole factor in LDS, one column chunk per filter)
 bool trsm_forms_T(int Mp, int Np);
+bool trsm_latency_route(int Mp, int batch);   // few filters: streamed solve on 128-column workgroups + tiled product
 // y = L^-1 inn for every filter (one wave each): the forward substitution of the innovation vector
 int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD, long strideInvD, const double* inn, long strideInn,
                    double* y, long strideY, int Mp, int batch, hipStream_t stream);
-void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T = 0);   // forms_T: 0 solve only, 1 + T = K(HP) - P, 2 + P - W^T W (symmetric form)
+void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T = 0, bool latency = false);   // forms_T: 0 solve only, 1 + T = K(HP) - P, 2 + P - W^T W (symmetric form)
 
 }  // namespace xivo_hip
 

@@ -552,6 +552,9 @@ static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
   if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT || a.epilogue == EPI_RSUB_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
       !getenv("XIVO_HIP_TILE"))
     wn = 2;
+  // few filters (the latency route of the update, chol_trsm.hip): 64 x 64 tiles - ten workgroups per symmetric 256 x 256
+  // output instead of three, on a chip that is empty anyway
+  if (a.small_tiles && a.lower_only && a.Mp > 64 && !a.fp32) { wm = 2; wn = 2; }
   *wm_out = wm; *wn_out = wn;
 }
 
