@@ -610,22 +610,28 @@ print(json.dumps(out))
 
 
 def test_cholesky_kernels_are_bit_identical(built):
-    """The one-wave and the four-wave register Cholesky run the same arithmetic in the same order (pivot_scale, two
-    accumulators per block product, inverse rows scaled by 1 / sqrt(pivot)): whichever of them a node picks for big batches
-    (chol_pick times both once), P+ and dx come out bit for bit the same - across nodes, ranks and runs."""
+    """The one-wave and the four-wave register Cholesky run the same arithmetic in the same order (factor_invert_diag on
+    the matrix pipe, pivot_scale, two accumulators per block product): whichever kernel and whichever instantiation of the
+    register kernel runs (three workgroups per CU / two, look-ahead on the diagonal update or not, blocks of S requested up
+    front or per block column, the opt-in timing of XIVO_HIP_AUTOTUNE), P+ and dx come out bit for bit the same - across
+    nodes, ranks, runs and batch sizes."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    knobs = ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG", "XIVO_HIP_CHOL_LOOKAHEAD", "XIVO_HIP_CHOL_NO_LOOKAHEAD",
+             "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE")
     res = []
-    for knob in ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG", None):
+    for knob in (("XIVO_HIP_CHOL_WAVE",), (), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
+                 ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS"), ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_NO_LOOKAHEAD"),
+                 ("XIVO_HIP_AUTOTUNE",)):
         env = dict(os.environ)
-        for k in ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG"):
+        for k in knobs:
             env.pop(k, None)
-        if knob:
-            env[knob] = "1"
+        for k in knob:
+            env[k] = "1"
         r = subprocess.run([sys.executable, "-c", _CHOL_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert res[0] == res[1] == res[2], res
+    assert all(r == res[0] for r in res[1:]), res
 
 
 @pytest.mark.parametrize("N,F", [(150, 50), (250, 80), (37, 3), (400, 150)])

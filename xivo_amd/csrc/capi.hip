@@ -559,18 +559,19 @@ int xivo_hip_set_measurements_device(xivo_hip_ctx* c, int b0, int nb, int M, con
   return stage_measurements(c, b0, nb, M, dH, strideH, ldh, dInn, strideInn, dR, strideR);
 }
 
-// Big batches: which Cholesky kernel is faster depends on the node (the register kernel is ~170 KB of straight-line
-// code and loses 2.6x on nodes with slow instruction fetch, wins 20 % elsewhere - DESIGN.md). Timed once per factor
-// size on scratch copies (S -> the A buffer, inverse blocks -> the T buffer, status -> a buffer of its own: all free or
-// private at that point; nothing of the caller's batch is touched), then remembered. The two kernels run the same
-// arithmetic in the same order (chol_trsm.hip: pivot_scale) and give bit-identical factors, so the pick changes the
-// time of a step and never its result: two nodes, two ranks or two runs agree bit for bit whatever they pick
-// (tests/test_update_gpu.py::test_cholesky_kernels_are_bit_identical). The timing costs one host synchronisation, once
-// per context and factor size; XIVO_HIP_NO_AUTOTUNE=1 skips it (then: the four-wave register kernel).
+// Which Cholesky kernel a big batch runs. Default (round 3): the four-wave register kernel, for every node and every batch
+// - deterministic, no host synchronisation inside the update call. (Rounds 1-2 timed both kernels once per factor size
+// because the register kernel, then 170-200 KB of straight-line code, lost 2.6x on nodes with slow instruction fetch; with
+// the diagonal blocks factored on the matrix pipe it is a quarter of that size and 1.6x faster than the one-wave kernel,
+// and the 2048-factor sample of the timing picked the slower kernel on the first node it was tried on.) XIVO_HIP_AUTOTUNE=1
+// brings the timing back: once per factor size on scratch copies (S -> the A buffer, inverse blocks -> the T buffer, status
+// -> a buffer of its own), then remembered. Either way the two kernels run the same arithmetic in the same order
+// (chol_f64.hip: factor_invert_diag, pivot_scale) and give bit-identical factors, so the pick changes the time of a step
+// and never its result (tests/test_update_gpu.py::test_cholesky_kernels_are_bit_identical).
 static int chol_pick(xivo_hip_ctx* c, const double* S, int Mp, int lds, int B) {
   const int nb = Mp / 16;
   if (B < 512 || nb > 12 || getenv("XIVO_HIP_CHOL_WAVE") || getenv("XIVO_HIP_CHOL_REG")) return 0;
-  if (getenv("XIVO_HIP_NO_AUTOTUNE")) return 2;
+  if (!getenv("XIVO_HIP_AUTOTUNE") || getenv("XIVO_HIP_NO_AUTOTUNE")) return 2;
   if (c->chol_variant[nb]) return c->chol_variant[nb];
   int nt = B < 2048 ? B : 2048;                  // a sample is enough
   const long fit = (long)c->Bmax * c->sA / c->sS;   // ... and it has to fit the scratch copies (S can be larger than A: M > N)

@@ -1,0 +1,392 @@
+// Batched SPD factorisation S = L L^T for the EKF measurement update (gfx950 / MI355X): the factor behind
+// `K_.transpose() = S_.ldlt().solve(H_ * P_)` (/root/reference/src/estimator.cpp:1265-1267). The reference uses Eigen's
+// pivoted LDL^T; S = HPH^T + R is SPD, so an un-pivoted blocked Cholesky is the same linear map up to rounding (a filter
+// whose S is not SPD is flagged and answered by ldlt_fallback.hip). The solve kernels are in chol_trsm.hip.
+//
+// chol_f64_kernel : one wave64 per filter, left-looking, 16x16 blocks (the v_mfma_f64_16x16x4_f64 tile); its explicit
+//   inverse of every diagonal block is kept so every panel / triangular-solve step is an MFMA.
+//   Output: L in the lower triangle, L^T mirrored into the upper triangle.
+// chol_reg_f64_kernel : four waves per filter, the factor in registers (M <= 192).
+// Both factor and invert a diagonal block with the SAME routine (factor_invert_diag) and use the same operand order
+// everywhere else, so they produce the same bits: which of them a node runs faster changes the time, never the result.
+#include <stdlib.h>
+#include <stdio.h>
+
+#include "mfma_util.h"
+
+namespace xivo_hip {
+
+namespace {
+
+
+// d = sqrt(p) and rd = 1 / sqrt(p) of a pivot: hardware estimate + two Newton steps, d = p * rd with one correction - no
+// sqrt / divide in the serial chain. BOTH Cholesky kernels use this routine and the same operand order everywhere else
+// (two accumulators over the k-slices of a block product, inverse rows scaled by rd), so that they produce the SAME bits:
+// which of them a node runs faster (chol_pick in capi.hip) then changes the time, never the result.
+__device__ __forceinline__ void pivot_scale(double p, double& d, double& rd) {
+#pragma clang fp contract(off)
+  rd = __builtin_amdgcn_rsq(p);
+  const double hx = 0.5 * p;
+  rd = rd * __builtin_fma(-(hx * rd), rd, 1.5);
+  rd = rd * __builtin_fma(-(hx * rd), rd, 1.5);
+  d = p * rd;
+  d = __builtin_fma(__builtin_fma(-d, d, p), 0.5 * rd, d);
+}
+
+// Factor AND invert one 16x16 diagonal block, held by one wave in the C/D layout of v_mfma_f64_16x16x4_f64:
+// x[r] of lane (li, lg) is X[li][lg + 4 r] on entry (X symmetric up to rounding; only X[i][c], i >= c, is consumed - the
+// same elements the round-2 routines read). On return x[r] = L[li][lg + 4 r] (for lg + 4 r <= li) and
+// y[r] = inv(L)[lg + 4 r][li].
+// Column c of the right-looking factorisation, and column c of the forward substitution L Y = I, are RANK-ONE updates:
+//   X[i][p] -= L[i][c] L[p][c]   (i, p > c)            Y[i][j] -= L[i][c] Y[c][j]   (i > c)
+// and both run on the matrix pipe with no cross-lane traffic at all: in the C/D layout "column c of L" is the register
+// x[c >> 2] of the lanes lg == (c & 3), indexed by li - which is the A (and B) operand of k-slice (c & 3) as it stands - and
+// row c of Y is y[c >> 2] of the same lanes. The three other k-slices are fed exact zeros, so every element receives exactly
+// one fused multiply-add per column, in ascending column order: the arithmetic of the round-2 routines (v_readlane /
+// ds_bpermute broadcasts + v_fma, ~2200 instructions and 7.8 us per block on a lone wave) in ~40 instructions per column.
+// What is left in the serial chain per column: one v_readlane pair (the pivot), pivot_scale, one multiply, one MFMA.
+__device__ __forceinline__ void factor_invert_diag(d4& x, d4& y, int& bad, const int row0, const int li, const int lg) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) y[r] = (lg + 4 * r == li) ? 1.0 : 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int lgc = c & 3, rc = c >> 2;
+    double dcc = readlane_d(x[rc], c + 16 * lgc);
+    if (!(dcc > 0.0)) {
+      if (!bad) bad = 1 + row0 + c;
+      dcc = 1.0;
+    }
+    double d, rd;
+    pivot_scale(dcc, d, rd);
+    const bool own = (lg == lgc);
+    const double lc = x[rc] * rd;            // L[li][c] in the lanes lg == lgc
+    const double yc = y[rc] * rd;            // row c of inv(L): final
+    if (own) { x[rc] = (li == c) ? d : lc; y[rc] = yc; }
+    if (c < 15) {
+      const bool below = own && li > c;
+      const double bl = below ? lc : 0.0;
+      const double al = -bl;
+      const double by = own ? yc : 0.0;
+      x = mfma(al, bl, x);
+      y = mfma(al, by, y);
+    }
+  }
+}
+
+
+// One wave64 per filter (no cross-wave barriers; many filters resident per CU so
+// the serial 16x16 diagonal factorisations of different filters overlap).
+__global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
+  const int filt = blockIdx.x;
+  if (filt >= g.batch) return;
+  double* S = g.S + (long)filt * g.strideS;
+  double* invD = g.invD + (long)filt * g.strideInvD;
+  const long ld = g.lds;
+  const int nb = g.Mp / 16;
+  const int lane = threadIdx.x;
+  const int li = lane & 15, lg = lane >> 4;
+
+  __shared__ double sInv[2][256];
+  int bad = 0;
+
+  for (int j = 0; j < nb; ++j) {
+    // ---- 1. diagonal block update: sum_{k<j} L_jk L_jk^T (two accumulators for ILP)
+    // ---- 2. factor + invert the 16x16 diagonal block in the accumulator layout (factor_invert_diag)
+    {
+      d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+      for (int k = 0; k < j; ++k) {
+        const double a0 = S[(16 * j + li) + (long)(16 * k + 0 + lg) * ld];
+        const double a1 = S[(16 * j + li) + (long)(16 * k + 4 + lg) * ld];
+        const double a2 = S[(16 * j + li) + (long)(16 * k + 8 + lg) * ld];
+        const double a3 = S[(16 * j + li) + (long)(16 * k + 12 + lg) * ld];
+        acc0 = mfma(a0, a0, acc0);
+        acc1 = mfma(a1, a1, acc1);
+        acc0 = mfma(a2, a2, acc0);
+        acc1 = mfma(a3, a3, acc1);
+      }
+      d4 x, y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = S[(16 * j + li) + (long)(16 * j + lg + 4 * r) * ld] - (acc0[r] + acc1[r]);
+      factor_invert_diag(x, y, bad, 16 * j, li, lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = lg + 4 * r;
+        if (c <= li) {
+          S[(16 * j + li) + (long)(16 * j + c) * ld] = x[r];
+          S[(16 * j + c) + (long)(16 * j + li) * ld] = x[r];
+        }
+        sInv[0][c + li * 16] = y[r];   // inv(L)(c, li)
+        sInv[1][li + c * 16] = y[r];   // inv(L)^T(li, c)
+      }
+    }
+    __syncthreads();
+    for (int e = lane; e < 512; e += 64) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
+
+    // ---- 3. panel: L_ij^T = inv(L_jj) * (S_ij^T - sum_k L_jk L_ik^T), i > j; two rows in flight
+    for (int i = j + 1; i < nb; i += 2) {
+      const bool two = (i + 1 < nb);
+      const int i2 = two ? i + 1 : i;
+      // (k-slices 0, 2 and 1, 3 in separate accumulators, summed at the end: the register kernel's order)
+      d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
+      d4 accA1 = d4{0.0, 0.0, 0.0, 0.0}, accB1 = d4{0.0, 0.0, 0.0, 0.0};
+      for (int k = 0; k < j; ++k) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const long col = (long)(16 * k + 4 * s + lg) * ld;
+          const double a = S[(16 * j + li) + col];
+          const double b1 = S[(16 * i + li) + col];
+          const double b2 = S[(16 * i2 + li) + col];
+          if (s & 1) { accA1 = mfma(a, b1, accA1); accB1 = mfma(a, b2, accB1); }
+          else { accA = mfma(a, b1, accA); accB = mfma(a, b2, accB); }
+        }
+      }
+      d4 rhsA, rhsB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        rhsA[r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] - (accA[r] + accA1[r]);
+        rhsB[r] = S[(16 * i2 + li) + (long)(16 * j + lg + 4 * r) * ld] - (accB[r] + accB1[r]);
+      }
+      d4 outA = d4{0.0, 0.0, 0.0, 0.0}, outB = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double iv = sInv[0][li + (4 * s + lg) * 16];
+        outA = mfma(iv, rhsA[s], outA);
+        outB = mfma(iv, rhsB[s], outB);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] = outA[r];   // L(i-block, j-block)
+        S[(16 * j + lg + 4 * r) + (long)(16 * i + li) * ld] = outA[r];   // L^T mirrored to upper
+        if (two) {
+          S[(16 * i2 + li) + (long)(16 * j + lg + 4 * r) * ld] = outB[r];
+          S[(16 * j + lg + 4 * r) + (long)(16 * i2 + li) * ld] = outB[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) g.status[filt] = bad;
+}
+
+// Register-resident variant for factors of at most NB <= 12 block rows (M <= 192): one workgroup of
+// four waves per filter, wave w owns the block rows i = w (mod 4) and keeps every L_ik it has produced
+// in registers, in the MFMA operand layout (the C layout of L_ik^T, see above, IS that layout). S is
+// read from HBM exactly once and L written once; the left-looking kernel above re-reads L_ik from
+// global for every later column (3x the bytes of S with thousands of filters in flight: it was
+// HBM-bound at 4.8 TB/s) and runs its whole dependency chain in one wave (178 us for one filter).
+// Per block column j (owner wave = j mod 4):
+//   A  owner : diagonal update sum_k L_jk L_jk^T from its registers; factor + invert the 16x16 block
+//              spread over all 64 lanes (column broadcasts by ds_bpermute, no sqrt / divide in the
+//              chain) -> LDS / global; publishes the row panel L_jk, k < j, in LDS
+//   C  all   : own rows i > j:  L_ij^T = inv(L_jj) (S_ij^T - sum_k L_jk L_ik^T), kept + stored
+// with one barrier between A and C and one after C.
+// MINB = workgroups per CU the register budget is cut for: 3 (168 VGPRs, a few spills) is faster for thousands of
+// factors (0.67 vs 0.75 ms / 4096 at M = 160), 2 (212 VGPRs) for a single one (76 vs 82 us)
+
+template <int NB, int MINB, bool PRE, bool UPFRONT>
+__global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror) {
+  constexpr int RW = (NB + 3) / 4;
+  const int filt = blockIdx.x;
+  if (filt >= g.batch) return;
+  double* S = g.S + (long)filt * g.strideS;
+  double* invD = g.invD + (long)filt * g.strideInvD;
+  const long ld = g.lds;
+  const int nb = g.Mp / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+
+  __shared__ double sInv[2][256];
+  __shared__ __attribute__((aligned(16))) double sRow[(NB - 1) * 256];   // [k][lane][4]
+  __shared__ int sBad;
+  if (tid == 0) sBad = 0;
+
+  d4 L[RW][NB];   // L[ii][k] = block (i = wave + 4 ii, k); only k < i is ever touched
+  // the diagonal blocks this wave will factor, fetched up front (their latency would otherwise sit in
+  // the serial chain of every column): x-layout, element r = S[row li][col lg + 4 r] of block (jd, jd)
+  d4 sdiag[RW];
+#pragma unroll
+  for (int ii = 0; ii < RW; ++ii) {
+    const int jd = wave + 4 * ii;
+    if (jd < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sdiag[ii][r] = S[(16 * jd + li) + (long)(16 * jd + lg + 4 * r) * ld];
+    }
+  }
+
+  // UPFRONT: every block of S this wave will turn into a block of L is requested here, into the register block that will
+  // hold the result - one memory latency per factor instead of one per block column (on this ISA loads and stores
+  // share vmcnt and retire in order, so a load issued in column j also waits for the stores of column j - 1)
+  if (UPFRONT) {
+#pragma unroll
+    for (int ii = 0; ii < RW; ++ii) {
+      const int i = wave + 4 * ii;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        if (k < 4 * ii + 3 && k < i && i < nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) L[ii][k][r] = S[(16 * i + li) + (long)(16 * k + lg + 4 * r) * ld];
+        }
+      }
+    }
+  }
+  d4 pre0 = d4{0.0, 0.0, 0.0, 0.0}, pre1 = d4{0.0, 0.0, 0.0, 0.0};   // partial diagonal update of the NEXT column's owner
+  // compile-time column index: every L[][] subscript below is a constant, so the factor stays in registers
+  static_for<NB>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (j < nb) {
+    constexpr int owner = j & 3, jj = j >> 2;
+    // S_ij for the rows this wave will finish in phase C (in flight across phases A and B)
+    d4 sreg[RW];
+#pragma unroll
+    for (int ii = 0; ii < RW; ++ii) {
+      const int i = wave + 4 * ii;
+      if (!UPFRONT && 4 * ii + 3 > j && i > j && i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sreg[ii][r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld];
+      }
+    }
+    // diagonal block in the 64-lane layout x[r] = X[row li][col lg + 4 r] - which is what the MFMA
+    // accumulators of the (symmetric) update already are, so no transpose through LDS
+    d4 x;
+    if (wave == owner) {
+      // the terms k < j - 1 of the diagonal update were formed while column j - 1 was being factored (below): only the
+      // block row produced by column j - 1 itself is still in the serial chain (same operands, same order)
+      d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+      if (PRE) { acc0 = pre0; acc1 = pre1; }
+#pragma unroll
+      for (int k = (PRE && j > 0) ? j - 1 : 0; k < j; ++k) {
+        const d4 a = L[jj][k];
+        acc0 = mfma(a[0], a[0], acc0);
+        acc1 = mfma(a[1], a[1], acc1);
+        acc0 = mfma(a[2], a[2], acc0);
+        acc1 = mfma(a[3], a[3], acc1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = sdiag[jj][r] - (acc0[r] + acc1[r]);
+    }
+    if (PRE && j + 1 < NB && j + 1 < nb && wave == ((j + 1) & 3)) {   // next column's owner, idle until the barrier: sum_{k<j} L_{j+1,k} L_{j+1,k}^T
+      pre0 = d4{0.0, 0.0, 0.0, 0.0}; pre1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < j; ++k) {
+        const d4 a = L[(j + 1) >> 2][k];
+        pre0 = mfma(a[0], a[0], pre0);
+        pre1 = mfma(a[1], a[1], pre1);
+        pre0 = mfma(a[2], a[2], pre0);
+        pre1 = mfma(a[3], a[3], pre1);
+      }
+    }
+    if (wave == owner) {
+      int bad = 0;
+      d4 y;
+      factor_invert_diag(x, y, bad, 16 * j, li, lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = lg + 4 * r;
+        if (c <= li) {
+          S[(16 * j + li) + (long)(16 * j + c) * ld] = x[r];
+          S[(16 * j + c) + (long)(16 * j + li) * ld] = x[r];
+        }
+        sInv[0][c + li * 16] = y[r];   // inv(L)(c, li)
+        sInv[1][li + c * 16] = y[r];   // inv(L)^T(li, c)
+      }
+      if (bad && lane == 0 && sBad == 0) sBad = bad;
+      // publish the row panel of block row j
+#pragma unroll
+      for (int k = 0; k < j; ++k) *reinterpret_cast<d4*>(&sRow[(k * 64 + lane) * 4]) = L[jj][k];
+    }
+    lds_barrier();
+    if (wave == owner)
+      for (int e = lane; e < 512; e += 64) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
+#pragma unroll
+    for (int ii = 0; ii < RW; ++ii) {
+      const int i = wave + 4 * ii;
+      if (4 * ii + 3 > j && i > j && i < nb) {
+        d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+          if (k < 4 * ii + 3) {
+            const d4 a = *reinterpret_cast<const d4*>(&sRow[(k * 64 + lane) * 4]);
+            const d4 bb = L[ii][k];
+            accA = mfma(a[0], bb[0], accA);
+            accB = mfma(a[1], bb[1], accB);
+            accA = mfma(a[2], bb[2], accA);
+            accB = mfma(a[3], bb[3], accB);
+          }
+        }
+        d4 rhs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rhs[r] = (UPFRONT ? L[ii][j][r] : sreg[ii][r]) - (accA[r] + accB[r]);
+        d4 out = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) out = mfma(sInv[0][li + (4 * s4 + lg) * 16], rhs[s4], out);
+        L[ii][j] = out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] = out[r];                 // L(i-block, j-block)
+          if (mirror) S[(16 * j + lg + 4 * r) + (long)(16 * i + li) * ld] = out[r];     // L^T for the streamed solve
+        }
+      }
+    }
+    lds_barrier();     // sInv / sRow are rewritten by the next owner
+    }
+  });
+  if (tid == 0) g.status[filt] = sBad;
+}
+
+}  // namespace
+
+int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
+  if (g.batch <= 0) return 0;
+  static const bool old_kernel = getenv("XIVO_HIP_CHOL_WAVE") != nullptr;   // A/B knob: one wave per filter
+  const int nb = g.Mp / 16;
+  // Round 3 (factor_invert_diag on the matrix pipe): the register kernel is ~11 500 instructions at ten block rows (it
+  // was ~45 000: 170-200 KB of straight-line code that lost 2.6x on nodes with slow instruction fetch) and is the
+  // default for every batch size it holds. Measured at M = 160: one factor 48 us (round 2: 80), 16384 factors
+  // 1.63 ms (register kernel, three workgroups per CU, no look-ahead) against 2.59 ms for the one-wave kernel and
+  // 2.3-2.4 ms for either kernel before. The one-wave kernel serves factors beyond twelve block rows.
+  const bool want_reg = g.variant == 2 || g.variant == 0;
+  if (!old_kernel && nb <= 12 && g.variant != 1 && want_reg) {
+    static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
+    const int mirror = (nb > 10 || small_stream || g.latency) ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
+                                          // whitened outputs leave the kernel (launch_trsm_f64)
+    static const bool minb2 = getenv("XIVO_HIP_CHOL_MINB2") != nullptr;   // A/B knob: the small-batch instantiation for every batch
+    const bool many = g.batch >= 512 && !minb2;
+    // Two instantiations per size, same bits (tests/test_update_gpu.py::test_cholesky_kernels_are_bit_identical):
+    //   few factors  (< 512): two workgroups per CU (up to 256 VGPRs), every block of S requested up front, the next
+    //                owner forms its diagonal update while the current block column is factored - 48 us per factor;
+    //   many factors: three workgroups per CU (168 VGPRs), blocks of S requested per block column, no look-ahead - the
+    //                look-ahead's 16 accumulator registers spill there (1.98 against 1.63 ms per 16384 factors), the
+    //                up-front loads need 248.
+    // A/B knobs: XIVO_HIP_CHOL_LOOKAHEAD / _NO_LOOKAHEAD and XIVO_HIP_CHOL_LAZY_LOADS force one behaviour for every batch.
+    static const bool no_pre = getenv("XIVO_HIP_CHOL_NO_LOOKAHEAD") != nullptr;
+    static const bool force_pre = getenv("XIVO_HIP_CHOL_LOOKAHEAD") != nullptr;
+    static const bool lazy = getenv("XIVO_HIP_CHOL_LAZY_LOADS") != nullptr;
+    const int mode = (no_pre || (many && !force_pre)) ? 0 : ((lazy || many) ? 1 : 2);
+#define CHOL_REG_LAUNCH(NB_, MINB_)                                                                                                     \
+  do {                                                                                                                                  \
+    if (mode == 0) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, false, false>), dim3(g.batch), dim3(256), 0, stream, g, mirror);   \
+    else if (mode == 1) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, true, false>), dim3(g.batch), dim3(256), 0, stream, g, mirror); \
+    else hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, true, true>), dim3(g.batch), dim3(256), 0, stream, g, mirror);             \
+  } while (0)
+    if (nb <= 4) CHOL_REG_LAUNCH(4, 2);
+    else if (nb <= 8) CHOL_REG_LAUNCH(8, 2);
+    else if (nb <= 10 && many && getenv("XIVO_HIP_CHOL_MINB4")) CHOL_REG_LAUNCH(10, 4);   // A/B knob
+    else if (nb <= 10 && many) CHOL_REG_LAUNCH(10, 3);
+    else if (nb <= 10) CHOL_REG_LAUNCH(10, 2);
+    else if (many) CHOL_REG_LAUNCH(12, 3);
+    else CHOL_REG_LAUNCH(12, 2);
+#undef CHOL_REG_LAUNCH
+    return (int)hipGetLastError();
+  }
+  hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
+  return (int)hipGetLastError();
+}
+
+void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
+  const int nb = Mp / 16;
+  if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12 || variant == 1) snprintf(buf, n, "chol_f64_kernel");
+  else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)),
+                (nb > 8 && batch >= 512 && !getenv("XIVO_HIP_CHOL_MINB2")) ? 3 : 2);
+}
+
+}  // namespace xivo_hip

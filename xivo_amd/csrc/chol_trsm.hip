@@ -32,8 +32,7 @@
 // trsm_stream_f64_kernel<NB, WH> : factors beyond the LDS (M > 176), panel by panel (DMA panels); WH = 1: whitened outputs.
 #include <stdlib.h>
 
-#include "common.h"
-#include <utility>
+#include "mfma_util.h"
 #include <stdio.h>
 
 // XIVO_ABL: timing-only ablations of trsm_lds_f64_kernel<., 4> (scripts/ablate_solve.sh builds one library per value; the
@@ -48,17 +47,6 @@ namespace xivo_hip {
 
 namespace {
 
-__device__ __forceinline__ double readlane_d(double v, int srclane) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, srclane);
-  hi = __builtin_amdgcn_readlane(hi, srclane);
-  return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-
 // Buffer addressing for the per-filter matrices of the one-workgroup-per-filter kernels: a 128-bit resource per matrix in
 // SGPRs, ONE 32-bit per-lane byte offset that every access of that matrix shares, and the block / column part of the
 // address as a wave-uniform scalar offset - instead of a 64-bit address pair per access in VGPRs (the solve kernel lives
@@ -72,150 +60,6 @@ __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff
 }
 __device__ __forceinline__ void buf_st(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, 0);
-}
-
-// d = sqrt(p) and rd = 1 / sqrt(p) of a pivot: hardware estimate + two Newton steps, d = p * rd with one correction - no
-// sqrt / divide in the serial chain. BOTH Cholesky kernels use this routine and the same operand order everywhere else
-// (two accumulators over the k-slices of a block product, inverse rows scaled by rd), so that they produce the SAME bits:
-// which of them a node runs faster (chol_pick in capi.hip) then changes the time, never the result.
-__device__ __forceinline__ void pivot_scale(double p, double& d, double& rd) {
-#pragma clang fp contract(off)
-  rd = __builtin_amdgcn_rsq(p);
-  const double hx = 0.5 * p;
-  rd = rd * __builtin_fma(-(hx * rd), rd, 1.5);
-  rd = rd * __builtin_fma(-(hx * rd), rd, 1.5);
-  d = p * rd;
-  d = __builtin_fma(__builtin_fma(-d, d, p), 0.5 * rd, d);
-}
-
-// One wave64 per filter (no cross-wave barriers; many filters resident per CU so
-// the serial 16x16 diagonal factorisations of different filters overlap).
-__global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
-  const int filt = blockIdx.x;
-  if (filt >= g.batch) return;
-  double* S = g.S + (long)filt * g.strideS;
-  double* invD = g.invD + (long)filt * g.strideInvD;
-  const long ld = g.lds;
-  const int nb = g.Mp / 16;
-  const int lane = threadIdx.x;
-  const int li = lane & 15, lg = lane >> 4;
-
-  __shared__ double sP[16 * 17];
-  __shared__ double sInv[2][256];
-  int bad = 0;
-
-  for (int j = 0; j < nb; ++j) {
-    // ---- 1. diagonal block update: sum_{k<j} L_jk L_jk^T (two accumulators for ILP)
-    {
-      d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
-      for (int k = 0; k < j; ++k) {
-        const double a0 = S[(16 * j + li) + (long)(16 * k + 0 + lg) * ld];
-        const double a1 = S[(16 * j + li) + (long)(16 * k + 4 + lg) * ld];
-        const double a2 = S[(16 * j + li) + (long)(16 * k + 8 + lg) * ld];
-        const double a3 = S[(16 * j + li) + (long)(16 * k + 12 + lg) * ld];
-        acc0 = mfma(a0, a0, acc0);
-        acc1 = mfma(a1, a1, acc1);
-        acc0 = mfma(a2, a2, acc0);
-        acc1 = mfma(a3, a3, acc1);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sP[li * 17 + lg + 4 * r] = acc0[r] + acc1[r];
-    }
-    __syncthreads();
-
-    // ---- 2. factor the 16x16 diagonal block in registers (row li per lane), invert it
-    {
-      double x[16], rdv[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) x[c] = S[(16 * j + li) + (long)(16 * j + c) * ld] - sP[li * 17 + c];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        double dcc = readlane_d(x[c], c);
-        if (!(dcc > 0.0)) {
-          if (!bad) bad = 1 + 16 * j + c;
-          dcc = 1.0;
-        }
-        double d, rd;
-        pivot_scale(dcc, d, rd);
-        rdv[c] = rd;
-        x[c] = (li == c) ? d : x[c] * rd;
-#pragma unroll
-        for (int q = c + 1; q < 16; ++q) {
-          const double lqc = readlane_d(x[c], q);
-          x[q] = fma(-x[c], lqc, x[q]);
-        }
-      }
-      // inverse: lane jj solves L y = e_jj
-      double y[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double acc = (li == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) {
-          const double lik = readlane_d(x[k], i);
-          acc = fma(-lik, y[k], acc);
-        }
-        y[i] = acc * rdv[i];
-      }
-      if (lg == 0) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          if (c <= li) {
-            S[(16 * j + li) + (long)(16 * j + c) * ld] = x[c];
-            S[(16 * j + c) + (long)(16 * j + li) * ld] = x[c];
-          }
-          sInv[0][c + li * 16] = y[c];   // inv(L)(c, li)
-          sInv[1][li + c * 16] = y[c];   // inv(L)^T(li, c)
-        }
-      }
-    }
-    __syncthreads();
-    for (int e = lane; e < 512; e += 64) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
-
-    // ---- 3. panel: L_ij^T = inv(L_jj) * (S_ij^T - sum_k L_jk L_ik^T), i > j; two rows in flight
-    for (int i = j + 1; i < nb; i += 2) {
-      const bool two = (i + 1 < nb);
-      const int i2 = two ? i + 1 : i;
-      // (k-slices 0, 2 and 1, 3 in separate accumulators, summed at the end: the register kernel's order)
-      d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
-      d4 accA1 = d4{0.0, 0.0, 0.0, 0.0}, accB1 = d4{0.0, 0.0, 0.0, 0.0};
-      for (int k = 0; k < j; ++k) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const long col = (long)(16 * k + 4 * s + lg) * ld;
-          const double a = S[(16 * j + li) + col];
-          const double b1 = S[(16 * i + li) + col];
-          const double b2 = S[(16 * i2 + li) + col];
-          if (s & 1) { accA1 = mfma(a, b1, accA1); accB1 = mfma(a, b2, accB1); }
-          else { accA = mfma(a, b1, accA); accB = mfma(a, b2, accB); }
-        }
-      }
-      d4 rhsA, rhsB;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        rhsA[r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] - (accA[r] + accA1[r]);
-        rhsB[r] = S[(16 * i2 + li) + (long)(16 * j + lg + 4 * r) * ld] - (accB[r] + accB1[r]);
-      }
-      d4 outA = d4{0.0, 0.0, 0.0, 0.0}, outB = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double iv = sInv[0][li + (4 * s + lg) * 16];
-        outA = mfma(iv, rhsA[s], outA);
-        outB = mfma(iv, rhsB[s], outB);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] = outA[r];   // L(i-block, j-block)
-        S[(16 * j + lg + 4 * r) + (long)(16 * i + li) * ld] = outA[r];   // L^T mirrored to upper
-        if (two) {
-          S[(16 * i2 + li) + (long)(16 * j + lg + 4 * r) * ld] = outB[r];
-          S[(16 * j + lg + 4 * r) + (long)(16 * i2 + li) * ld] = outB[r];
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (lane == 0) g.status[filt] = bad;
 }
 
 // y = L^-1 inn, one wave per filter: block row k after block row k - 1; the lanes split the dot products of the 16
@@ -248,191 +92,6 @@ __global__ __launch_bounds__(256) void fwd_vec_kernel(const double* __restrict__
     for (int c = 0; c < 16; ++c) out = fma(invD[(long)k * 512 + r + 16 * c], __shfl(rhs, c), out);
     if (part == 0) { ys[16 * k + r] = out; y[16 * k + r] = out; }
   }
-}
-
-template <class F, int... Js>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Js...>) {
-  (f(std::integral_constant<int, Js>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
-// Register-resident variant for factors of at most NB <= 12 block rows (M <= 192): one workgroup of
-// four waves per filter, wave w owns the block rows i = w (mod 4) and keeps every L_ik it has produced
-// in registers, in the MFMA operand layout (the C layout of L_ik^T, see above, IS that layout). S is
-// read from HBM exactly once and L written once; the left-looking kernel above re-reads L_ik from
-// global for every later column (3x the bytes of S with thousands of filters in flight: it was
-// HBM-bound at 4.8 TB/s) and runs its whole dependency chain in one wave (178 us for one filter).
-// Per block column j (owner wave = j mod 4):
-//   A  owner : diagonal update sum_k L_jk L_jk^T from its registers; factor + invert the 16x16 block
-//              spread over all 64 lanes (column broadcasts by ds_bpermute, no sqrt / divide in the
-//              chain) -> LDS / global; publishes the row panel L_jk, k < j, in LDS
-//   C  all   : own rows i > j:  L_ij^T = inv(L_jj) (S_ij^T - sum_k L_jk L_ik^T), kept + stored
-// with one barrier between A and C and one after C.
-// MINB = workgroups per CU the register budget is cut for: 3 (168 VGPRs, a few spills) is faster for thousands of
-// factors (0.67 vs 0.75 ms / 4096 at M = 160), 2 (212 VGPRs) for a single one (76 vs 82 us)
-// Barrier for exchanges that go through LDS only: __syncthreads() also drains the vector-memory counter, i.e. waits
-// until every global store issued so far is acknowledged - microseconds per barrier that nothing here depends on.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int NB, int MINB>
-__global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror) {
-  constexpr int RW = (NB + 3) / 4;
-  const int filt = blockIdx.x;
-  if (filt >= g.batch) return;
-  double* S = g.S + (long)filt * g.strideS;
-  double* invD = g.invD + (long)filt * g.strideInvD;
-  const long ld = g.lds;
-  const int nb = g.Mp / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lg = lane >> 4;
-
-  __shared__ double sInv[2][256];
-  __shared__ __attribute__((aligned(16))) double sRow[(NB - 1) * 256];   // [k][lane][4]
-  __shared__ int sBad;
-  if (tid == 0) sBad = 0;
-
-  d4 L[RW][NB];   // L[ii][k] = block (i = wave + 4 ii, k); only k < i is ever touched
-  // the diagonal blocks this wave will factor, fetched up front (their latency would otherwise sit in
-  // the serial chain of every column): x-layout, element r = S[row li][col lg + 4 r] of block (jd, jd)
-  d4 sdiag[RW];
-#pragma unroll
-  for (int ii = 0; ii < RW; ++ii) {
-    const int jd = wave + 4 * ii;
-    if (jd < nb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sdiag[ii][r] = S[(16 * jd + li) + (long)(16 * jd + lg + 4 * r) * ld];
-    }
-  }
-
-  // compile-time column index: every L[][] subscript below is a constant, so the factor stays in registers
-  static_for<NB>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    if (j < nb) {
-    constexpr int owner = j & 3, jj = j >> 2;
-    // S_ij for the rows this wave will finish in phase C (in flight across phases A and B)
-    d4 sreg[RW];
-#pragma unroll
-    for (int ii = 0; ii < RW; ++ii) {
-      const int i = wave + 4 * ii;
-      if (4 * ii + 3 > j && i > j && i < nb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sreg[ii][r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld];
-      }
-    }
-    // diagonal block in the 64-lane layout x[r] = X[row li][col lg + 4 r] - which is what the MFMA
-    // accumulators of the (symmetric) update already are, so no transpose through LDS
-    d4 x;
-    if (wave == owner) {
-      d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int k = 0; k < j; ++k) {
-        const d4 a = L[jj][k];
-        acc0 = mfma(a[0], a[0], acc0);
-        acc1 = mfma(a[1], a[1], acc1);
-        acc0 = mfma(a[2], a[2], acc0);
-        acc1 = mfma(a[3], a[3], acc1);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) x[r] = sdiag[jj][r] - (acc0[r] + acc1[r]);
-    }
-    if (wave == owner) {
-      int bad = 0;
-      double rdv[16];   // 1 / L_cc (wave-uniform)
-      // right-looking Cholesky of the 16x16 block: step c broadcasts column c with ds_bpermute
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int lgc = c & 3, rc = c >> 2;
-        double dcc = readlane_d(x[rc], c + 16 * lgc);
-        if (!(dcc > 0.0)) {
-          if (!bad) bad = 1 + 16 * j + c;
-          dcc = 1.0;
-        }
-        double d, rd;
-        pivot_scale(dcc, d, rd);
-        rdv[c] = rd;
-        if (lg == lgc) x[rc] = (li == c) ? d : x[rc] * rd;
-        const double lqc = __shfl(x[rc], li + 16 * lgc);            // L[my row][c]
-#pragma unroll
-        for (int r = rc; r < 4; ++r) {
-          const int p = lg + 4 * r;                                  // my column
-          const double lpc = __shfl(x[rc], p + 16 * lgc);            // L[p][c]
-          if (p > c && li > c) x[r] = fma(-lqc, lpc, x[r]);
-        }
-      }
-      // inverse: lane li solves L y = e_li; L[i][k] is a readlane away, 1 / L[i][i] is rdv[i]
-      double y[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double acc = (li == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) {
-          const double lik = readlane_d(x[k >> 2], i + 16 * (k & 3));
-          acc = fma(-lik, y[k], acc);
-        }
-        y[i] = acc * rdv[i];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = lg + 4 * r;
-        if (c <= li) {
-          S[(16 * j + li) + (long)(16 * j + c) * ld] = x[r];
-          S[(16 * j + c) + (long)(16 * j + li) * ld] = x[r];
-        }
-      }
-      if (lg == 0) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          sInv[0][c + li * 16] = y[c];   // inv(L)(c, li)
-          sInv[1][li + c * 16] = y[c];   // inv(L)^T(li, c)
-        }
-      }
-      if (bad && lane == 0 && sBad == 0) sBad = bad;
-      // publish the row panel of block row j
-#pragma unroll
-      for (int k = 0; k < j; ++k) *reinterpret_cast<d4*>(&sRow[(k * 64 + lane) * 4]) = L[jj][k];
-    }
-    lds_barrier();
-    if (wave == owner)
-      for (int e = lane; e < 512; e += 64) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
-#pragma unroll
-    for (int ii = 0; ii < RW; ++ii) {
-      const int i = wave + 4 * ii;
-      if (4 * ii + 3 > j && i > j && i < nb) {
-        d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < j; ++k) {
-          if (k < 4 * ii + 3) {
-            const d4 a = *reinterpret_cast<const d4*>(&sRow[(k * 64 + lane) * 4]);
-            const d4 bb = L[ii][k];
-            accA = mfma(a[0], bb[0], accA);
-            accB = mfma(a[1], bb[1], accB);
-            accA = mfma(a[2], bb[2], accA);
-            accB = mfma(a[3], bb[3], accB);
-          }
-        }
-        d4 rhs;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rhs[r] = sreg[ii][r] - (accA[r] + accB[r]);
-        d4 out = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) out = mfma(sInv[0][li + (4 * s4 + lg) * 16], rhs[s4], out);
-        L[ii][j] = out;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld] = out[r];                 // L(i-block, j-block)
-          if (mirror) S[(16 * j + lg + 4 * r) + (long)(16 * i + li) * ld] = out[r];     // L^T for the streamed solve
-        }
-      }
-    }
-    lds_barrier();     // sInv / sRow are rewritten by the next owner
-    }
-  });
-  if (tid == 0) g.status[filt] = sBad;
 }
 
 template <int NBM, int WPE>
@@ -1303,38 +962,6 @@ int launch_trsm_t(const TrsmArgs& g, hipStream_t stream) {
 
 }  // namespace
 
-int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
-  if (g.batch <= 0) return 0;
-  static const bool old_kernel = getenv("XIVO_HIP_CHOL_WAVE") != nullptr;   // A/B knob: one wave per filter
-  const int nb = g.Mp / 16;
-  // measured at M = 160: one factor 78 us (one-wave kernel 178 us); 4096 factors 0.75 ms (0.76 ms), with a third
-  // of the HBM traffic
-  // The register kernel is 170-200 KB of straight-line code executed once per factor. On some MI355X nodes of the
-  // pool it runs 2.6x slower (1.77 vs 0.67 ms per 4096 factors; the large-code GEMM variants lose ~10 % on the same
-  // nodes, the small looping kernels nothing), which makes it a liability for throughput: big batches use the
-  // compact one-wave kernel (0.71-0.76 / 0.80 ms on fast / slow nodes), small ones the register kernel (76 vs 178 us).
-  // (A looped twin of the register kernel - runtime column loop, constant subscripts under uniform guards, 25 KB -
-  //  keeps all 21 blocks live around the diagonal code and spills: 1.42 ms / 102 us. Not kept.)
-  static const bool reg_always = getenv("XIVO_HIP_CHOL_REG") != nullptr;   // A/B knob
-  const bool want_reg = g.variant == 2 || (g.variant == 0 && (g.batch < 512 || reg_always));
-  if (!old_kernel && nb <= 12 && g.variant != 1 && want_reg) {
-    static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
-    const int mirror = (nb > 10 || small_stream || g.latency) ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
-                                          // whitened outputs leave the kernel (launch_trsm_f64)
-    const bool many = g.batch >= 512;
-    if (nb <= 4) hipLaunchKernelGGL((chol_reg_f64_kernel<4, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
-    else if (nb <= 8) hipLaunchKernelGGL((chol_reg_f64_kernel<8, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
-    else if (nb <= 10 && many && getenv("XIVO_HIP_CHOL_MINB4")) hipLaunchKernelGGL((chol_reg_f64_kernel<10, 4>), dim3(g.batch), dim3(256), 0, stream, g, mirror);   // A/B knob
-    else if (nb <= 10 && many) hipLaunchKernelGGL((chol_reg_f64_kernel<10, 3>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
-    else if (nb <= 10) hipLaunchKernelGGL((chol_reg_f64_kernel<10, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
-    else if (many) hipLaunchKernelGGL((chol_reg_f64_kernel<12, 3>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
-    else hipLaunchKernelGGL((chol_reg_f64_kernel<12, 2>), dim3(g.batch), dim3(256), 0, stream, g, mirror);
-    return (int)hipGetLastError();
-  }
-  hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
-  return (int)hipGetLastError();
-}
-
 bool pnew_reg_supported(int Mp, int Np) {
   static const bool off = getenv("XIVO_HIP_NO_PNEW_REG") != nullptr;   // A/B knob: the tiled GEMM instead
   return !off && Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
@@ -1432,13 +1059,6 @@ int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD
   hipLaunchKernelGGL(fwd_vec_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, LU, strideLU, ldlu, invD, strideInvD, inn, strideInn,
                      y, strideY, Mp, batch);
   return (int)hipGetLastError();
-}
-
-void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
-  const int nb = Mp / 16;
-  const bool reg = variant == 2 || (variant == 0 && (batch < 512 || getenv("XIVO_HIP_CHOL_REG")));
-  if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12 || variant == 1 || !reg) snprintf(buf, n, "chol_f64_kernel");
-  else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)), (nb > 8 && batch >= 512) ? 3 : 2);
 }
 
 void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T, bool latency) {
