@@ -1,19 +1,30 @@
-mkdir -p gpurun_out/s2
-run() { tag=$1; shift; env "$@" timeout 120 python bench.py $ARGS --no-cpu-baseline --no-mixed > gpurun_out/s2/$tag.json 2> gpurun_out/s2/$tag.err; }
+#!/bin/bash
+# A/B of the Cholesky instantiations on ONE box (nodes of the pool differ): default library (k-slice loop inside
+# factor_invert_diag) against a build with all sixteen columns unrolled (-DXIVO_CHOL_UNROLL16=1 -> libxivo_hip_u16.so).
+O=gpurun_out/s3; mkdir -p $O
+run() { tag=$1; shift; env "$@" timeout 120 python bench.py $ARGS --no-cpu-baseline --no-mixed > $O/$tag.json 2> $O/$tag.err; }
+U16=XIVO_HIP_LIBRARY=$PWD/xivo_amd/libxivo_hip_u16.so
 ARGS="--steps 6 --warmup 2"
-run wave XIVO_HIP_CHOL_WAVE=1
-run reg3 XIVO_HIP_CHOL_REG=1
-run reg3_nopre XIVO_HIP_CHOL_REG=1 XIVO_HIP_CHOL_NO_LOOKAHEAD=1
-run reg2_up XIVO_HIP_CHOL_REG=1 XIVO_HIP_CHOL_MINB2=1
-run reg2_lazy XIVO_HIP_CHOL_REG=1 XIVO_HIP_CHOL_MINB2=1 XIVO_HIP_CHOL_LAZY_LOADS=1
+run a_loop A=1
+run a_u16 $U16
+run a_loop_pre XIVO_HIP_CHOL_LOOKAHEAD=1
+run a_u16_pre $U16 XIVO_HIP_CHOL_LOOKAHEAD=1
+run a_wave XIVO_HIP_CHOL_WAVE=1
+run a_loop2 A=1
+run a_u16_2 $U16
+run a_minb2 XIVO_HIP_CHOL_MINB2=1
 ARGS="--batch 1 --steps 200 --warmup 20"
-run lat_up A=1
-run lat_lazy XIVO_HIP_CHOL_LAZY_LOADS=1
+run b1_loop A=1
+run b1_u16 $U16
 ARGS="--batch 64 --steps 100 --warmup 10"
-run lat64_up A=1
+run b64_loop A=1
+run b64_u16 $U16
+ARGS="--batch 1024 --steps 50 --warmup 10"
+run b1024_loop A=1
+run b1024_u16 $U16
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob("gpurun_out/s2/*.json")):
+for f in sorted(glob.glob("gpurun_out/s3/*.json")):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1])
         s=d.get("stage_ms_per_step",{})

@@ -14,6 +14,10 @@
 
 #include "mfma_util.h"
 
+#ifndef XIVO_CHOL_UNROLL16
+#define XIVO_CHOL_UNROLL16 0
+#endif
+
 namespace xivo_hip {
 
 namespace {
@@ -48,21 +52,32 @@ __device__ __forceinline__ void pivot_scale(double p, double& d, double& rd) {
 __device__ __forceinline__ void factor_invert_diag(d4& x, d4& y, int& bad, const int row0, const int li, const int lg) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) y[r] = (lg + 4 * r == li) ? 1.0 : 0.0;
+  // columns c = 4 rc + lgc: the register index rc is unrolled, the k-slice lgc is a run-time loop (the lane selects of
+  // v_readlane and the lane masks are scalar values anyway) - a quarter of the code of sixteen unrolled columns. The register
+  // kernel is straight-line code executed once per factor; its size is what the instruction fetch of a CU pair sees
+  // (64 KB of instruction cache): ten block columns of sixteen unrolled columns each were 76 KB and ran 1.6x slower on
+  // some nodes of the pool than on others.
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const int lgc = c & 3, rc = c >> 2;
-    double dcc = readlane_d(x[rc], c + 16 * lgc);
-    if (!(dcc > 0.0)) {
-      if (!bad) bad = 1 + row0 + c;
-      dcc = 1.0;
-    }
-    double d, rd;
-    pivot_scale(dcc, d, rd);
-    const bool own = (lg == lgc);
-    const double lc = x[rc] * rd;            // L[li][c] in the lanes lg == lgc
-    const double yc = y[rc] * rd;            // row c of inv(L): final
-    if (own) { x[rc] = (li == c) ? d : lc; y[rc] = yc; }
-    if (c < 15) {
+  for (int rc = 0; rc < 4; ++rc) {
+#if XIVO_CHOL_UNROLL16     // A/B build (scripts/ab_chol.sh): all sixteen columns unrolled
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+    for (int lgc = 0; lgc < 4; ++lgc) {
+      const int c = 4 * rc + lgc;
+      double dcc = readlane_d(x[rc], c + 16 * lgc);
+      if (!(dcc > 0.0)) {
+        if (!bad) bad = 1 + row0 + c;
+        dcc = 1.0;
+      }
+      double d, rd;
+      pivot_scale(dcc, d, rd);
+      const bool own = (lg == lgc);
+      const double lc = x[rc] * rd;            // L[li][c] in the lanes lg == lgc
+      const double yc = y[rc] * rd;            // row c of inv(L): final
+      if (own) { x[rc] = (li == c) ? d : lc; y[rc] = yc; }
+      // (column 15 has no rows below it: its two products are exact zeros)
       const bool below = own && li > c;
       const double bl = below ? lc : 0.0;
       const double al = -bl;
@@ -72,7 +87,6 @@ __device__ __forceinline__ void factor_invert_diag(d4& x, d4& y, int& bad, const
     }
   }
 }
-
 
 // One wave64 per filter (no cross-wave barriers; many filters resident per CU so
 // the serial 16x16 diagonal factorisations of different filters overlap).
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[r] = sdiag[jj][r] - (acc0[r] + acc1[r]);
     }
-    if (PRE && j + 1 < NB && j + 1 < nb && wave == ((j + 1) & 3)) {   // next column's owner, idle until the barrier: sum_{k<j} L_{j+1,k} L_{j+1,k}^T
+    if constexpr (PRE && j + 1 < NB) if (j + 1 < nb && wave == ((j + 1) & 3)) {   // next column's owner, idle until the barrier: sum_{k<j} L_{j+1,k} L_{j+1,k}^T
       pre0 = d4{0.0, 0.0, 0.0, 0.0}; pre1 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int k = 0; k < j; ++k) {

@@ -1,24 +1,15 @@
-// Batched SPD factorisation and gain solve for the EKF measurement update.
+// Batched gain solve (and, inside it, the covariance update) for the EKF measurement update.
 //
 // Replaces `K_.transpose() = S_.ldlt().solve(H_ * P_)` and `err_ = K_ * inn_`
-// (/root/reference/src/estimator.cpp:1265-1267). The reference uses Eigen's
-// pivoted LDL^T; S = HPH^T + R is SPD, so an un-pivoted blocked Cholesky is the
-// same linear map up to rounding (tests assert 1e-8 on dx, 1e-6 on P).
+// (/root/reference/src/estimator.cpp:1265-1267) once S = L L^T is factored (chol_f64.hip: the reference uses Eigen's
+// pivoted LDL^T; S = HPH^T + R is SPD, so an un-pivoted blocked Cholesky is the same linear map up to rounding - tests
+// assert 1e-8 on dx, 1e-6 on P).
 //
-// chol_f64_kernel : one wave64 per filter, left-looking, 16x16 blocks (the
-//   v_mfma_f64_16x16x4_f64 tile). The diagonal block is factored in registers
-//   (row per lane, v_readlane broadcasts); its explicit inverse is kept so every
-//   panel / triangular-solve step is an MFMA. The factorisation is latency
-//   bound, so throughput comes from many filters resident per CU, not from
-//   widening one filter.
-//   Output: L in the lower triangle, L^T mirrored into the upper triangle (so
-//   the backward solve also reads its A operand with the lane index contiguous).
 // trsm_f64_kernel : each wave64 owns 16 right-hand-side columns and keeps the
 //   whole Mp x 16 solution in accumulator registers. The f64 MFMA C/D layout
 //   (row = (lane>>4) + 4*reg, col = lane&15) is exactly the B-operand layout of
 //   the four k-slices of the next MFMA, so forward and backward substitution
 //   chain with no data movement at all; dx = K*inn falls out as a lane reduce.
-// chol_reg_f64_kernel : four waves per filter, the factor in registers (M <= 192).
 // trsm_lds_f64_kernel<NBM, TF> : one workgroup of 16 waves per filter, the whole factor in LDS; beyond the solve it
 //   carries, on the gain still in its registers (which is also the A-operand layout),
 //     TF = 1  T = K (HP) - P                                   (estimator.cpp:1276-1280, re-associated pipeline)
