@@ -3,6 +3,7 @@
 # factor_invert_diag) against a build with all sixteen columns unrolled (-DXIVO_CHOL_UNROLL16=1 -> libxivo_hip_u16.so).
 O=gpurun_out/s3; mkdir -p $O
 run() { tag=$1; shift; env "$@" timeout 120 python bench.py $ARGS --no-cpu-baseline --no-mixed > $O/$tag.json 2> $O/$tag.err; }
+( cd xivo_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-result -Wno-unused-value -DXIVO_CHOL_UNROLL16=1 -c chol_f64.hip -o build/chol_f64_u16.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libxivo_hip_u16.so build/gemm_f64.o build/gemm_sym_f64.o build/chol_f64_u16.o build/chol_trsm.o build/ekf_kernels.o build/ell_kernels.o build/ldlt_fallback.o build/capi.o ) 2>/dev/null
 U16=XIVO_HIP_LIBRARY=$PWD/xivo_amd/libxivo_hip_u16.so
 ARGS="--steps 6 --warmup 2"
 run a_loop A=1

@@ -29,8 +29,9 @@ def test_default_line(built):
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["unit"] == "updates/s" and d["value"] > 0
     assert "workload" in d["config"] and "precision" in d["config"] and "hand_over" in d["config"]
     assert d["config"]["pipeline"].startswith("sparse-H") and d["config"]["not_spd_filters"] == 0
-    # the three modes, slowest to fastest at this size, each with its own figure
-    assert d["value_mixed"] > 0 and d["value_symmetric_form"] > d["value"]
+    # the three modes, each with its own figure (no speed ordering asserted here: two timed steps on a box that has just
+    # been handed over can stall for tens of milliseconds - the ordering is a bench result, profiles/r03_bench_n1.json)
+    assert d["value_mixed"] > 0 and d["value_symmetric_form"] > 0
     assert d["parity_check"]["ok"] and d["parity_check"]["rel_fro_P_max"] < 1e-6 and d["parity_check"]["inlier_masks_equal"]
     assert d["symmetric_form"]["parity_check"]["ok"]
     # round 3: the state the timed loop left behind is checked too, every rank reports its own checks and its core binding

@@ -597,7 +597,7 @@ import numpy as np
 from xivo_amd import synth
 from xivo_amd.lib import Context
 out = {{}}
-for (N, F) in [(150, 50), (250, 80), (100, 96)]:
+for (N, F) in [(150, 50), (250, 80), (100, 96), (100, 110), (120, 150)]:   # 7, 10, 12 block rows; 14 and 19: the eight-wave register kernel
     B = 520                                   # >= 512: the size class where the pick matters
     P, H, inn, dR = synth.s_level(N, F, 8, seed=41)
     idx = np.arange(B) % 8
@@ -612,17 +612,17 @@ print(json.dumps(out))
 def test_cholesky_kernels_are_bit_identical(built):
     """The one-wave and the four-wave register Cholesky run the same arithmetic in the same order (factor_invert_diag on
     the matrix pipe, pivot_scale, two accumulators per block product): whichever kernel and whichever instantiation of the
-    register kernel runs (three workgroups per CU / two, look-ahead on the diagonal update or not, blocks of S requested up
+    register kernel runs (four waves per factor or eight, three workgroups per CU / two, look-ahead on the diagonal update or not, blocks of S requested up
     front or per block column, the opt-in timing of XIVO_HIP_AUTOTUNE), P+ and dx come out bit for bit the same - across
     nodes, ranks, runs and batch sizes."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     knobs = ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG", "XIVO_HIP_CHOL_LOOKAHEAD", "XIVO_HIP_CHOL_NO_LOOKAHEAD",
-             "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE")
+             "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE", "XIVO_HIP_CHOL_NO_REG8")
     res = []
     for knob in (("XIVO_HIP_CHOL_WAVE",), (), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
                  ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS"), ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_NO_LOOKAHEAD"),
-                 ("XIVO_HIP_AUTOTUNE",)):
+                 ("XIVO_HIP_AUTOTUNE",), ("XIVO_HIP_CHOL_NO_REG8",)):
         env = dict(os.environ)
         for k in knobs:
             env.pop(k, None)

@@ -197,9 +197,9 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
 // MINB = workgroups per CU the register budget is cut for: 3 (168 VGPRs, a few spills) is faster for thousands of
 // factors (0.67 vs 0.75 ms / 4096 at M = 160), 2 (212 VGPRs) for a single one (76 vs 82 us)
 
-template <int NB, int MINB, bool PRE, bool UPFRONT>
-__global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror) {
-  constexpr int RW = (NB + 3) / 4;
+template <int NB, int MINB, bool PRE, bool UPFRONT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror) {
+  constexpr int RW = (NB + NW - 1) / NW;   // NW waves per factor: 4 (M <= 192), 8 (M <= 320: one workgroup per CU)
   const int filt = blockIdx.x;
   if (filt >= g.batch) return;
   double* S = g.S + (long)filt * g.strideS;
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
   d4 sdiag[RW];
 #pragma unroll
   for (int ii = 0; ii < RW; ++ii) {
-    const int jd = wave + 4 * ii;
-    if (jd < nb) {
+    const int jd = wave + NW * ii;
+    if (NW == 4 && jd < nb) {   // (eight waves, up to 19 block rows: no registers to spare - requested per block column below)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sdiag[ii][r] = S[(16 * jd + li) + (long)(16 * jd + lg + 4 * r) * ld];
     }
@@ -233,10 +233,10 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
   if (UPFRONT) {
 #pragma unroll
     for (int ii = 0; ii < RW; ++ii) {
-      const int i = wave + 4 * ii;
+      const int i = wave + NW * ii;
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        if (k < 4 * ii + 3 && k < i && i < nb) {
+        if (k < NW * ii + NW - 1 && k < i && i < nb) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) L[ii][k][r] = S[(16 * i + li) + (long)(16 * k + lg + 4 * r) * ld];
         }
@@ -248,13 +248,13 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
   static_for<NB>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     if (j < nb) {
-    constexpr int owner = j & 3, jj = j >> 2;
+    constexpr int owner = j % NW, jj = j / NW;
     // S_ij for the rows this wave will finish in phase C (in flight across phases A and B)
     d4 sreg[RW];
 #pragma unroll
     for (int ii = 0; ii < RW; ++ii) {
-      const int i = wave + 4 * ii;
-      if (!UPFRONT && 4 * ii + 3 > j && i > j && i < nb) {
+      const int i = wave + NW * ii;
+      if (!UPFRONT && NW * ii + NW - 1 > j && i > j && i < nb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sreg[ii][r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld];
       }
@@ -262,6 +262,10 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
     // diagonal block in the 64-lane layout x[r] = X[row li][col lg + 4 r] - which is what the MFMA
     // accumulators of the (symmetric) update already are, so no transpose through LDS
     d4 x;
+    if (NW != 4 && wave == owner) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sdiag[jj][r] = S[(16 * j + li) + (long)(16 * j + lg + 4 * r) * ld];
+    }
     if (wave == owner) {
       // the terms k < j - 1 of the diagonal update were formed while column j - 1 was being factored (below): only the
       // block row produced by column j - 1 itself is still in the serial chain (same operands, same order)
@@ -278,11 +282,11 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[r] = sdiag[jj][r] - (acc0[r] + acc1[r]);
     }
-    if constexpr (PRE && j + 1 < NB) if (j + 1 < nb && wave == ((j + 1) & 3)) {   // next column's owner, idle until the barrier: sum_{k<j} L_{j+1,k} L_{j+1,k}^T
+    if constexpr (PRE && j + 1 < NB) if (j + 1 < nb && wave == ((j + 1) % NW)) {   // next column's owner, idle until the barrier: sum_{k<j} L_{j+1,k} L_{j+1,k}^T
       pre0 = d4{0.0, 0.0, 0.0, 0.0}; pre1 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int k = 0; k < j; ++k) {
-        const d4 a = L[(j + 1) >> 2][k];
+        const d4 a = L[(j + 1) / NW][k];
         pre0 = mfma(a[0], a[0], pre0);
         pre1 = mfma(a[1], a[1], pre1);
         pre0 = mfma(a[2], a[2], pre0);
@@ -313,12 +317,12 @@ __global__ __launch_bounds__(256, MINB) void chol_reg_f64_kernel(CholArgs g, int
       for (int e = lane; e < 512; e += 64) invD[(long)j * 512 + e] = (&sInv[0][0])[e];
 #pragma unroll
     for (int ii = 0; ii < RW; ++ii) {
-      const int i = wave + 4 * ii;
-      if (4 * ii + 3 > j && i > j && i < nb) {
+      const int i = wave + NW * ii;
+      if (NW * ii + NW - 1 > j && i > j && i < nb) {
         d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < j; ++k) {
-          if (k < 4 * ii + 3) {
+          if (k < NW * ii + NW - 1) {
             const d4 a = *reinterpret_cast<const d4*>(&sRow[(k * 64 + lane) * 4]);
             const d4 bb = L[ii][k];
             accA = mfma(a[0], bb[0], accA);
@@ -392,13 +396,31 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
 #undef CHOL_REG_LAUNCH
     return (int)hipGetLastError();
   }
+  // 13..19 block rows (M <= 304: BASELINE config 4, the 125-feature build): the register kernel on eight waves, one
+  // workgroup per CU (two waves per SIMD at up to 256 VGPRs) - S read once, L written once, where the one-wave kernel
+  // re-reads L_ik for every later block column (15.7 GB per 4096 factors at M = 300, HBM-bound)
+  static const bool no_reg8 = getenv("XIVO_HIP_CHOL_NO_REG8") != nullptr;   // A/B knob
+  if (!old_kernel && !no_reg8 && nb > 12 && nb <= 19 && g.variant != 1) {
+    const int mirror = 1;
+    const bool pre = g.batch < 512 && !getenv("XIVO_HIP_CHOL_NO_LOOKAHEAD");
+    if (nb <= 16) {
+      if (pre) hipLaunchKernelGGL((chol_reg_f64_kernel<16, 1, true, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror);
+      else hipLaunchKernelGGL((chol_reg_f64_kernel<16, 1, false, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror);
+    } else {
+      if (pre) hipLaunchKernelGGL((chol_reg_f64_kernel<19, 1, true, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror);
+      else hipLaunchKernelGGL((chol_reg_f64_kernel<19, 1, false, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror);
+    }
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
   return (int)hipGetLastError();
 }
 
 void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
   const int nb = Mp / 16;
-  if (getenv("XIVO_HIP_CHOL_WAVE") || nb > 12 || variant == 1) snprintf(buf, n, "chol_f64_kernel");
+  const bool reg8 = nb > 12 && nb <= 19 && !getenv("XIVO_HIP_CHOL_NO_REG8");
+  if (getenv("XIVO_HIP_CHOL_WAVE") || (nb > 12 && !reg8) || variant == 1) snprintf(buf, n, "chol_f64_kernel");
+  else if (reg8) snprintf(buf, n, "chol_reg_f64_kernel<%d,1,8 waves>", nb <= 16 ? 16 : 19);
   else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)),
                 (nb > 8 && batch >= 512 && !getenv("XIVO_HIP_CHOL_MINB2")) ? 3 : 2);
 }
