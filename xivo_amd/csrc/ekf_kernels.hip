@@ -368,13 +368,14 @@ __device__ __forceinline__ double feature_chi2(const double* P, int ldp, const x
   return mh_dist_2x2(s00, s10, s11, inn[0], inn[1]);
 }
 
-// One workgroup per filter; a wave64 per feature computes S = J P J^T + R I2
+// One workgroup per filter (4 waves; 16 for fewer than 256 filters - latency); a wave64 per feature computes S = J P J^T + R I2
 // from the 21 x 21 sub-block of P the feature touches (J is structurally
 // sparse), reduces it across lanes, and the 2x2 LLT gives the Mahalanobis
 // distance. Then one wave runs the threshold-relaxation loop.
-__global__ __launch_bounds__(256) void gate_sparse_kernel(GateArgs a) {
+__global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
   const int filt = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = blockDim.x, nw = nt >> 6;   // 4 waves per filter for a big batch, 16 when few filters must finish fast
   extern __shared__ double sdist[];
   const SceneBuffers& sb = a.sb;
   const double* P = a.P + (long)filt * a.strideP;
@@ -385,14 +386,14 @@ __global__ __launch_bounds__(256) void gate_sparse_kernel(GateArgs a) {
   __syncthreads();
   {
     int cnt = 0;
-    for (int f = tid; f < sb.F; f += 256) cnt += sb.feats[(long)filt * sb.Fmax + f].sind >= 0 ? 1 : 0;
+    for (int f = tid; f < sb.F; f += nt) cnt += sb.feats[(long)filt * sb.Fmax + f].sind >= 0 ? 1 : 0;
     if (cnt) atomicAdd(&s_present, cnt);
   }
   __syncthreads();
   const int present = s_present;
   const bool gating = a.use_gating && present > a.min_inliers;
   if (gating) {
-    for (int f = wave; f < sb.F; f += 4) {
+    for (int f = wave; f < sb.F; f += nw) {
       const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
       if (ft.sind < 0) { if (lane == 0) sdist[f] = __builtin_inf(); continue; }
       const double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void gate_sparse_kernel(GateArgs a) {
     __syncthreads();
   }
   const double th = gating ? sdist[sb.F] : 0.0;
-  for (int f = tid; f < sb.F; f += 256) {
+  for (int f = tid; f < sb.F; f += nt) {
     const bool here = sb.feats[(long)filt * sb.Fmax + f].sind >= 0;
     const bool in = gating ? (sdist[f] < th) : here;
     sb.mask[(long)filt * sb.Fmax + f] = in ? 1 : 0;
@@ -2381,7 +2382,7 @@ int launch_jac_instate(const SceneBuffers& sb, const xivo_layout& lay, const xiv
   CHECK_LAUNCH();
 }
 int launch_gate_sparse(const GateArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(gate_sparse_kernel, dim3(a.batch), dim3(256), (a.sb.F + 1) * sizeof(double), s, a);
+  hipLaunchKernelGGL(gate_sparse_kernel, dim3(a.batch), dim3(a.batch < 256 ? 1024 : 256), (a.sb.F + 1) * sizeof(double), s, a);
   CHECK_LAUNCH();
 }
 int launch_stack(const StackArgs& a, hipStream_t s) {
