@@ -368,6 +368,48 @@ __device__ __forceinline__ double feature_chi2(const double* P, int ldp, const x
   return mh_dist_2x2(s00, s10, s11, inn[0], inn[1]);
 }
 
+// The same value with the gathers of P issued as seven wave-wide loads instead of twenty-one: the wave parks the 21 x 21
+// sub-block (element e = a + 21 b in lane e mod 64) and the two rows of J in its own LDS scratch, then lane (a, c) forms
+// (P J^T)(a, c) from LDS in the same ascending-b order - bit for bit the result of feature_chi2. The gate kernel was bound by
+// the number of 8-byte gather instructions a CU's address unit retires (42 per feature, two thirds of them duplicates between
+// the c = 0 and c = 1 lanes), not by memory latency. scratch: 441 + 42 doubles per wave.
+__device__ __forceinline__ double feature_chi2_lds(const double* P, int ldp, const xivo_layout& lay, const xivo_feat_in& ft,
+                                                   const double* J, const double* inn, double R, int lane, double* scratch) {
+  double* sP = scratch;          // [a + 21 b]
+  double* sJ = scratch + 441;    // [c * 21 + b]
+  double pv[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int e = lane + 64 * k;
+    const int ea = e < 441 ? e % 21 : 0, eb = e < 441 ? e / 21 : 0;
+    pv[k] = P[jcol(lay, ft, ea) + (long)jcol(lay, ft, eb) * ldp];
+  }
+  const double jmine = lane < 42 ? J[lane] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int e = lane + 64 * k;
+    if (e < 441) sP[e] = pv[k];
+  }
+  if (lane < 42) sJ[lane] = jmine;
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are done (one wave, no barrier needed)
+  __builtin_amdgcn_wave_barrier();
+  double v = 0.0;
+  const int ra = lane % 21, rc = lane / 21;
+  if (lane < 42) {
+#pragma unroll
+    for (int b = 0; b < 21; ++b) v = fma(sP[ra + 21 * b], sJ[rc * 21 + b], v);
+  }
+  const double j0 = lane < 42 ? sJ[ra] : 0.0, j1 = lane < 42 ? sJ[21 + ra] : 0.0;
+  __builtin_amdgcn_wave_barrier();      // (the next feature's writes stay behind these reads: program order within the wave)
+  double s00 = (lane < 21) ? j0 * v : 0.0;
+  double s10 = (lane < 21) ? j1 * v : 0.0;
+  double s11 = (lane >= 21 && lane < 42) ? j1 * v : 0.0;
+  s00 = wave_sum(s00) + R;
+  s10 = wave_sum(s10);
+  s11 = wave_sum(s11) + R;
+  return mh_dist_2x2(s00, s10, s11, inn[0], inn[1]);
+}
+
 // One workgroup per filter (4 waves; 16 for fewer than 256 filters - latency); a wave64 per feature computes S = J P J^T + R I2
 // from the 21 x 21 sub-block of P the feature touches (J is structurally
 // sparse), reduces it across lanes, and the 2x2 LLT gives the Mahalanobis
@@ -384,9 +426,19 @@ __global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
   __shared__ int s_present;
   if (tid == 0) s_present = 0;
   __syncthreads();
+  // the two slot indices of every entry, parked in LDS by this pass: the per-feature loop below then starts its gathers of
+  // P and J right away instead of behind a load of the entry (two dependent memory round trips per feature, fifteen
+  // features per wave one after the other, were what the kernel's time was)
+  int* s_slot = reinterpret_cast<int*>(sdist + sb.F + 1);   // [2 F]: sind, ref_sind
+  double* s_scr = sdist + sb.F + 1 + (2 * sb.F + 1) / 2 + (long)wave * 484;   // per wave: feature_chi2_lds scratch
   {
     int cnt = 0;
-    for (int f = tid; f < sb.F; f += nt) cnt += sb.feats[(long)filt * sb.Fmax + f].sind >= 0 ? 1 : 0;
+    for (int f = tid; f < sb.F; f += nt) {
+      const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+      const int si = ft.sind, rs = ft.ref_sind;
+      s_slot[2 * f] = si; s_slot[2 * f + 1] = rs;
+      cnt += si >= 0 ? 1 : 0;
+    }
     if (cnt) atomicAdd(&s_present, cnt);
   }
   __syncthreads();
@@ -394,11 +446,12 @@ __global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
   const bool gating = a.use_gating && present > a.min_inliers;
   if (gating) {
     for (int f = wave; f < sb.F; f += nw) {
-      const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
+      xivo_feat_in ft;                      // only the slots are read by feature_chi2 / jcol
+      ft.sind = s_slot[2 * f]; ft.ref_sind = s_slot[2 * f + 1];
       if (ft.sind < 0) { if (lane == 0) sdist[f] = __builtin_inf(); continue; }
       const double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
       const double* inn = sb.finn + ((long)filt * sb.Fmax + f) * 2;
-      const double d = feature_chi2(P, a.ldp, a.lay, ft, J, inn, a.R, lane);
+      const double d = feature_chi2_lds(P, a.ldp, a.lay, ft, J, inn, a.R, lane, s_scr);
       if (lane == 0) sdist[f] = d;
     }
     __syncthreads();
@@ -410,7 +463,7 @@ __global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
   }
   const double th = gating ? sdist[sb.F] : 0.0;
   for (int f = tid; f < sb.F; f += nt) {
-    const bool here = sb.feats[(long)filt * sb.Fmax + f].sind >= 0;
+    const bool here = s_slot[2 * f] >= 0;
     const bool in = gating ? (sdist[f] < th) : here;
     sb.mask[(long)filt * sb.Fmax + f] = in ? 1 : 0;
     sb.dist[(long)filt * sb.Fmax + f] = (gating && here) ? sdist[f] : 0.0;
@@ -480,33 +533,26 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   int* eidx = a.ell.idx + (long)filt * a.ell.stride_idx();
   double* eval = a.ell.val + (long)filt * a.ell.stride_val();
   if (tid == 0) { a.ell.nc[filt] = 12; a.ell.over[filt] = 0; a.ell.pw[filt] = a.fix_group_block ? 9 : 6; }
-  for (int p = tid; p < a.Mp / 2; p += 256) {
-    int* pi = eidx + (long)p * ELL_W;
-    double* pv = eval + (long)p * ELL_W * 2;
+  // one thread per (pair, slot): consecutive threads write consecutive 16-byte value slots / 4-byte index slots (a thread
+  // per pair wrote 84 scalars 448 bytes apart from its neighbour's: 0.32 ms per 4096 filters, bound by the store count)
+  const d2 zero2 = d2{0.0, 0.0};
+  for (int e = tid; e < (a.Mp / 2) * ELL_W; e += 256) {
+    const int p = e / ELL_W, t = e % ELL_W;
     const bool on = p < sb.F && sb.mask[(long)filt * sb.Fmax + p];
     const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + (p < sb.F ? p : 0)];
     const double* J = sb.J + ((long)filt * sb.Fmax + (p < sb.F ? p : 0)) * 42;
-    for (int t = 0; t < ELL_CW; ++t) {
-      pi[t] = t < 12 ? jcol(a.lay, ft, t) : 0;
-      pv[2 * t] = (on && t < 12) ? J[t] : 0.0;
-      pv[2 * t + 1] = (on && t < 12) ? J[21 + t] : 0.0;
+    int idx = 0, c = -1;        // c: compact-J column whose two values fill the slot
+    if (t < 12) { idx = jcol(a.lay, ft, t); if (on) c = t; }
+    else if (t >= ELL_CW && on) {
+      const int k = t - ELL_CW;
+      if (a.fix_group_block) { if (k < 9) { idx = jcol(a.lay, ft, 12 + k); c = 12 + k; } }
+      // Feature::FillJacobianBlock as coded: the group-rotation block is overwritten by the group-translation block
+      // (feature.cpp:675-676): columns of block 4 carry the values of block 5, block 5 contributes no slots
+      else if (k < 3) { idx = jcol(a.lay, ft, 12 + k); c = 15 + k; }
+      else if (k < 6) { idx = jcol(a.lay, ft, 15 + k); c = 15 + k; }
     }
-    int t = ELL_CW;
-    if (on) {
-      for (int b = 4; b < 7; ++b) {
-        int src = b;
-        if (!a.fix_group_block) {
-          if (b == 4) src = 5;
-          else if (b == 5) continue;
-        }
-        for (int o = 0; o < 3; ++o, ++t) {
-          pi[t] = jcol(a.lay, ft, 3 * b + o);
-          pv[2 * t] = J[3 * src + o];
-          pv[2 * t + 1] = J[21 + 3 * src + o];
-        }
-      }
-    }
-    for (; t < ELL_W; ++t) { pi[t] = 0; pv[2 * t] = 0.0; pv[2 * t + 1] = 0.0; }
+    eidx[e] = idx;
+    reinterpret_cast<d2*>(eval)[e] = c >= 0 ? d2{J[c], J[21 + c]} : zero2;
   }
 }
 
@@ -2382,7 +2428,12 @@ int launch_jac_instate(const SceneBuffers& sb, const xivo_layout& lay, const xiv
   CHECK_LAUNCH();
 }
 int launch_gate_sparse(const GateArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(gate_sparse_kernel, dim3(a.batch), dim3(a.batch < 256 ? 1024 : 256), (a.sb.F + 1) * sizeof(double), s, a);
+  int nt = a.batch < 256 ? 1024 : 256;
+  // distances + threshold | slot indices | per-wave scratch of feature_chi2_lds (64 KB without an opt-in: fewer waves if F is large)
+  auto lds_of = [&](int t) { return ((size_t)(a.sb.F + 1) + (2 * a.sb.F + 1) / 2 + (size_t)(t / 64) * 484) * sizeof(double); };
+  while (nt > 64 && lds_of(nt) > 65536) nt /= 2;
+  const size_t lds = lds_of(nt);
+  hipLaunchKernelGGL(gate_sparse_kernel, dim3(a.batch), dim3(nt), lds, s, a);
   CHECK_LAUNCH();
 }
 int launch_stack(const StackArgs& a, hipStream_t s) {
