@@ -346,33 +346,12 @@ __device__ __forceinline__ int jcol(const xivo_layout& lay, const xivo_feat_in& 
 }
 
 // res^T (J P J^T + R I2)^-1 res of one feature by one wave64 (src/update.cpp:60-70, :352-356): the 21 x 21 sub-block of
-// P the full row J touches, reduced across lanes, 2x2 LLT. The value is valid in every lane.
-__device__ __forceinline__ double feature_chi2(const double* P, int ldp, const xivo_layout& lay, const xivo_feat_in& ft,
-                                               const double* J, const double* inn, double R, int lane) {
-  double v = 0.0;
-  const int ra = lane % 21, rc = lane / 21;  // lanes 0..41 active: (P J^T)(a, c)
-  if (lane < 42) {
-    const int ia = jcol(lay, ft, ra);
-    for (int b = 0; b < 21; ++b) {
-      const int ib = jcol(lay, ft, b);
-      v = fma(P[ia + (long)ib * ldp], J[rc * 21 + b], v);
-    }
-  }
-  const double j0 = lane < 42 ? J[ra] : 0.0, j1 = lane < 42 ? J[21 + ra] : 0.0;
-  double s00 = (lane < 21) ? j0 * v : 0.0;
-  double s10 = (lane < 21) ? j1 * v : 0.0;
-  double s11 = (lane >= 21 && lane < 42) ? j1 * v : 0.0;
-  s00 = wave_sum(s00) + R;
-  s10 = wave_sum(s10);
-  s11 = wave_sum(s11) + R;
-  return mh_dist_2x2(s00, s10, s11, inn[0], inn[1]);
-}
-
-// The same value with the gathers of P issued as seven wave-wide loads instead of twenty-one: the wave parks the 21 x 21
-// sub-block (element e = a + 21 b in lane e mod 64) and the two rows of J in its own LDS scratch, then lane (a, c) forms
-// (P J^T)(a, c) from LDS in the same ascending-b order - bit for bit the result of feature_chi2. The gate kernel was bound by
-// the number of 8-byte gather instructions a CU's address unit retires (42 per feature, two thirds of them duplicates between
-// the c = 0 and c = 1 lanes), not by memory latency. scratch: 441 + 42 doubles per wave.
+// P the full row J touches, lane (a, c) forming (P J^T)(a, c) in ascending b, reduced across lanes, 2x2 LLT. The value is
+// valid in every lane. The gathers of P are issued as seven wave-wide loads: the wave parks the sub-block (element
+// e = a + 21 b in lane e mod 64) and the two rows of J in its own LDS scratch and reads its operands from there. (The first
+// version had every lane (a, c) gather its 21 elements itself - 42 gather instructions per feature, half of them duplicates
+// between the c = 0 and c = 1 lanes - and the gate kernel was bound by the number of 8-byte gathers a CU's address unit
+// retires, not by memory latency: 0.40 -> 0.28 ms per 4096 filters x 60 features, same bits.) scratch: 441 + 42 doubles.
 __device__ __forceinline__ double feature_chi2_lds(const double* P, int ldp, const xivo_layout& lay, const xivo_feat_in& ft,
                                                    const double* J, const double* inn, double R, int lane, double* scratch) {
   double* sP = scratch;          // [a + 21 b]
@@ -2316,6 +2295,7 @@ __global__ __launch_bounds__(256) void ransac_rescue_kernel(RansacArgs a) {
   const double* P = a.P + (long)filt * a.strideP;
   const int state = a.state[filt];
   __shared__ int s_rej;
+  __shared__ double s_scr[4][484];   // feature_chi2_lds: the 21 x 21 sub-block of P and the two rows of J, per wave
   if (tid == 0) s_rej = 0;
   __syncthreads();
   for (int f = wave; f < sb.F; f += 4) {
@@ -2325,7 +2305,7 @@ __global__ __launch_bounds__(256) void ransac_rescue_kernel(RansacArgs a) {
     double d = 0.0;
     bool keep = mh;
     if (mh && state != 0 && !a.low_keep[e]) {
-      d = feature_chi2(P, a.ldp, a.lay, ft, sb.J + e * 42, sb.finn + e * 2, a.R, lane);
+      d = feature_chi2_lds(P, a.ldp, a.lay, ft, sb.J + e * 42, sb.finn + e * 2, a.R, lane, s_scr[wave]);
       keep = d < a.chi2;
       if (!keep && lane == 0) atomicAdd(&s_rej, 1);
     }
