@@ -45,6 +45,8 @@ struct xivo_hip_ctx {
   // row-pair compressed H (ell.h) + host mirror of the per-filter "does not fit" flag
   EllBuffers ell{};
   std::vector<int> ell_over_h, ell_nc_h, ell_pw_h;
+  int* ell_flags_h = nullptr;   // pinned, device-mapped [Bmax][3]: over / nc / pw as the hand-over kernel leaves them
+  int* ell_flags_d = nullptr;   // its device alias
   int last_path = 0;
   // dense H / H^T of the stacked rows: written eagerly by set_measurements, lazily after xivo_hip_stack
   bool dense_valid = true;
@@ -323,6 +325,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
                   c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->tune_status, c->ldlt_used};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
   if (c->t1) hipEventDestroy(c->t1);
@@ -361,6 +364,15 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
   c->ell.pairs_max = (int)(Mp / 2);
   A(&c->ell.idx, B * c->ell.stride_idx()); A(&c->ell.val, B * c->ell.stride_val()); A(&c->ell.nc, B); A(&c->ell.pw, B); A(&c->ell.over, B);
   c->ell_over_h.assign(B, 1); c->ell_nc_h.assign(B, ELL_CW); c->ell_pw_h.assign(B, ELL_PW);
+  // the hand-over kernel mirrors its three per-filter flags into host-mapped pinned memory: the host picks the kernel
+  // instantiations from them after one stream synchronisation. (Three device-to-host copies into pageable vectors cost
+  // 85 us of idle GPU per call - a third of a B = 1 step.) If the mapping is refused the copies are used.
+  if (rc == XIVO_HIP_OK && hipHostMalloc(reinterpret_cast<void**>(&c->ell_flags_h), (size_t)B * 3 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->ell_flags_d), c->ell_flags_h, 0) != hipSuccess) {
+      hipHostFree(c->ell_flags_h); c->ell_flags_h = nullptr; c->ell_flags_d = nullptr;
+    }
+  } else c->ell_flags_h = nullptr;
+  if (getenv("XIVO_HIP_NO_MAPPED_FLAGS") && c->ell_flags_h) { hipHostFree(c->ell_flags_h); c->ell_flags_h = nullptr; c->ell_flags_d = nullptr; }   // A/B knob
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t0) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t1) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc != XIVO_HIP_OK) { xivo_hip_destroy(c); return rc; }
@@ -510,12 +522,19 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
     StageTimer st(c, ST_STACK, 0.0, "meas_compress_kernel", 8.0 * nb * ((double)M * N + 4.0 * M) + (double)nb * c->ell.pairs_max * ELL_W * 20.0);
     // clear up to the allocated row count so stale rows of a previous, larger M vanish
     HIP_TRY((hipError_t)launch_meas_compress(dH, strideH, ldh, dInn, strideInn, dR, strideR, M, N, c->Np, c->Mpmax, e, mb.inn,
-                                             mb.strideInn, mb.diagR, mb.strideR, nb, c->stream));
+                                             mb.strideInn, mb.diagR, mb.strideR, nb, c->stream,
+                                             c->ell_flags_d ? c->ell_flags_d + 3 * (long)b0 : nullptr));
   }
-  HIP_TRY(hipMemcpyAsync(c->ell_over_h.data() + b0, e.over, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->ell_nc_h.data() + b0, e.nc, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->ell_pw_h.data() + b0, e.pw, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->ell_flags_h) {
+    HIP_TRY(hipStreamSynchronize(c->stream));     // kernel end = system-scope release: the mirrored flags are in host memory
+    const int* f = c->ell_flags_h + 3 * (long)b0;
+    for (int b = 0; b < nb; ++b) { c->ell_over_h[b0 + b] = f[3 * b]; c->ell_nc_h[b0 + b] = f[3 * b + 1]; c->ell_pw_h[b0 + b] = f[3 * b + 2]; }
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->ell_over_h.data() + b0, e.over, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ell_nc_h.data() + b0, e.nc, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ell_pw_h.data() + b0, e.pw, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   bool any_over = false;
   for (int b = b0; b < b0 + nb && !any_over; ++b) any_over = c->ell_over_h[b] != 0;
   if (debug_on()) fprintf(stderr, "xivo_hip: hand-over b0=%d nb=%d M=%d any_over=%d nc0=%d pw0=%d\n", b0, nb, M, (int)any_over, c->ell_nc_h[b0], c->ell_pw_h[b0]);

@@ -38,7 +38,10 @@ struct EllBuffers {
 // and copies inn / diagR into the padded working vectors (rows [M, Mp_clear) neutral).
 int launch_meas_compress(const double* H, long strideH, int ldh, const double* inn, long strideInn,
                          const double* diagR, long strideR, int M, int N, int Np, int Mp_clear, EllBuffers e,
-                         double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s);
+                         double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s,
+                         int* host_flags = nullptr /* device alias of pinned host memory, [batch][3] = over, nc, pw: the kernel
+                                                      mirrors the three per-filter flags there so that the host reads them
+                                                      after ONE stream synchronisation, without device-to-host copies */);
 // whether the per-workgroup LDS lists of launch_meas_compress fit the 160 KiB of a CU for these shapes; when they do not
 // (N beyond ~2800 at the largest M) the hand-over marks every filter "does not fit" instead (launch_meas_vectors: inn /
 // diagR padded, over = 1) and the caller unpacks the dense rows: the dense pipeline has no such limit

@@ -35,6 +35,7 @@ struct MeasCompressArgs {
   double* inn_out; long strideInnOut;
   double* R_out; long strideROut;
   int list_ld;                           // pairs rounded up to a multiple of 4 (LDS list row length)
+  int* host_flags;                       // [batch][3] mirror of over / nc / pw in host-mapped memory (or null)
 };
 
 // UNR = 16-byte loads in flight per thread: 16 (32 measured within noise of 16 at 16384 filters; 48 for a single filter -
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(256) void meas_compress_kernel(MeasCompressArgs a) 
   int* occw = lst_n + ELL_W * a.list_ld;
   int* cslot = occw + nw * a.Np;
   __shared__ int ccols[ELL_CW];
-  __shared__ int s_nc, s_pw, s_ne[4];
+  __shared__ int s_nc, s_pw, s_over, s_ne[4];
   const double* __restrict__ H = a.H + (long)filt * a.strideH;
-  if (tid == 0) { s_pw = 0; a.ell.over[filt] = 0; }
+  if (tid == 0) { s_pw = 0; s_over = 0; }
   const bool mine = tid < pairs;
   const bool second = 2 * tid + 1 < a.M;          // M odd: the last pair has one row only
   const double* __restrict__ hp = H + (mine ? 2 * tid : 0);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void meas_compress_kernel(MeasCompressArgs a) 
       if (!((cmask >> t) & 1u)) pv[t] = d2{0.0, 0.0};
     }
     for (int t = pos; t < ELL_PW; ++t) { pi[ELL_CW + t] = 0; pv[ELL_CW + t] = d2{0.0, 0.0}; }
-    if (pos > ELL_PW) a.ell.over[filt] = 1;
+    if (pos > ELL_PW) s_over = 1;
     atomicMax(&s_pw, pos);
   }
   for (int m = tid; m < 2 * a.pairs_clear; m += blockDim.x) {
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(256) void meas_compress_kernel(MeasCompressArgs a) 
     a.R_out[(long)filt * a.strideROut + m] = m < a.M ? a.diagR[(long)filt * a.strideR + m] : 1.0;
   }
   __syncthreads();
-  if (tid == 0) a.ell.pw[filt] = s_pw;
+  if (tid == 0) {
+    a.ell.pw[filt] = s_pw; a.ell.over[filt] = s_over;
+    if (a.host_flags) { a.host_flags[3 * filt] = s_over; a.host_flags[3 * filt + 1] = s_nc; a.host_flags[3 * filt + 2] = s_pw; }
+  }
 }
 
 // Hand-over without compression (the LDS lists of meas_compress_kernel do not fit: very wide states): every filter is
@@ -551,9 +555,11 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
 
 int launch_meas_compress(const double* H, long strideH, int ldh, const double* inn, long strideInn,
                          const double* diagR, long strideR, int M, int N, int Np, int Mp_clear, EllBuffers e,
-                         double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s) {
+                         double* inn_out, long strideInnOut, double* R_out, long strideROut, int batch, hipStream_t s,
+                         int* host_flags) {
   if (batch <= 0) return 0;
   MeasCompressArgs a;
+  a.host_flags = host_flags;
   a.H = H; a.strideH = strideH; a.ldh = ldh; a.inn = inn; a.strideInn = strideInn; a.diagR = diagR; a.strideR = strideR;
   a.M = M; a.N = N; a.Np = Np; a.pairs_clear = Mp_clear / 2; a.ell = e;
   a.inn_out = inn_out; a.strideInnOut = strideInnOut; a.R_out = R_out; a.strideROut = strideROut;
