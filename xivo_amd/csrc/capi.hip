@@ -851,9 +851,12 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
 // as-coded Joseph update, on exactly those filters (ldlt_fallback.hip). Every pipeline leaves the covariance of such a
 // filter untouched and its status set, so the fallback starts from the prior.
 static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams* gate = nullptr) {
-  HIP_TRY(hipMemsetAsync(c->ldlt_used + b0, 0, (size_t)B * sizeof(int), c->stream));
   int rc = update_joseph_range_impl(c, b0, B, gate);
-  if (rc || (c->flags & XIVO_HIP_FLAG_NO_LDLT_FALLBACK)) return rc;
+  if (rc || (c->flags & XIVO_HIP_FLAG_NO_LDLT_FALLBACK)) {   // no fallback launch: clear the flags of this call here
+    HIP_TRY(hipMemsetAsync(c->ldlt_used + b0, 0, (size_t)B * sizeof(int), c->stream));
+    return rc;
+  }
+  // (the fallback kernel writes ldlt_used of EVERY filter of the range: 0 where the Cholesky succeeded, 1 where it stepped in)
   LdltFallbackArgs a{};
   a.status = c->status + b0; a.used = c->ldlt_used + b0;
   a.ell = c->ell; a.ell.idx += (long)b0 * a.ell.stride_idx(); a.ell.val += (long)b0 * a.ell.stride_val();

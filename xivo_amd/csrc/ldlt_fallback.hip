@@ -41,7 +41,10 @@ struct HRow {   // row-pair compressed or dense access to one filter's H
 
 __global__ __launch_bounds__(1024) void ldlt_fallback_kernel(LdltFallbackArgs a) {
   const int filt = blockIdx.x;
-  if (a.status[filt] == 0) return;
+  if (a.status[filt] == 0) {      // factored: nothing to do - but this launch is also what clears the "used" flag of the call
+    if (threadIdx.x == 0) a.used[filt] = 0;   // (a separate memset in front of every update cost a dispatch: 10 us of a B = 1 step)
+    return;
+  }
   const int tid = threadIdx.x, nt = blockDim.x;
   const int N = a.N, M = a.M;
   double* S = a.S + (long)filt * a.strideS;
