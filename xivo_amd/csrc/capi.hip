@@ -729,7 +729,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     ga.S = S; ga.strideS = c->sS; ga.lds = lds; ga.Mp = Mp; ga.from_S = 1;   // distances from the diagonal blocks of S
     ga.R = gate->R; ga.thresh = gate->thresh; ga.mult = gate->mult; ga.min_inliers = gate->min_inliers;
   }
-  int gate_done = 0;
+  int gate_done = 0, diag_done = 0;
   {
     EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
@@ -738,6 +738,9 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     // as two kernels per 16384 filters: the tail runs at one 8-wave workgroup per CU where the stand-alone gate fills the chip
     static const bool fuse = getenv("XIVO_HIP_GATE_IN_S") != nullptr;
     if (gate && fuse) { a.gate = ga; a.gate_here = 1; a.gate_done = &gate_done; }
+    // the 2 x 2 diagonal blocks of S once more, compact (the T buffer is free until the solve): what the gate reads
+    static const bool no_sdiag = getenv("XIVO_HIP_NO_SDIAG") != nullptr;   // A/B knob: the gate reads them off S
+    if (gate && !fuse && !no_sdiag && mr0 < 0 && (long)2 * Mp <= c->sP) { a.diag_out = c->T + (long)b0 * c->sP; a.strideDiag = c->sP; a.diag_done = &diag_done; }
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
     StageTimer st(c, ST_S, nnz_flops * Mf * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_S, a, c->stream));
@@ -751,6 +754,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   if (gate) c->gate_sparse_last = 0;
   if (gate && !gate_done) {
+    if (diag_done) { ga.Sdiag = c->T + (long)b0 * c->sP; ga.strideSdiag = c->sP; }
     StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
     HIP_TRY((hipError_t)launch_gate_ell(ga, c->stream));
   }

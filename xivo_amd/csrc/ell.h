@@ -80,6 +80,10 @@ struct GateEllArgs {
   // from_S: S = H P H^T + diag(R) of ALL candidate rows is already formed (ell<S>); the 2x2 blocks S_f are read
   // off its diagonal and the rows / columns of the rejected pairs are then decoupled in place (0, unit diagonal)
   double* S; long strideS; int lds; int Mp; int from_S;
+  // from_S, optional: the 2 x 2 diagonal blocks of S as the S kernel left them, [pair][row in block][column in block]
+  // (32 contiguous bytes per feature instead of three cache lines 2 lds doubles apart: the gate's reads of S were 3.9 M
+  // random 64-byte fetches per 16384 filters); same values bit for bit. null: read them off S.
+  const double* Sdiag; long strideSdiag;
 };
 struct EllMulArgs {
   EllBuffers ell;
@@ -88,6 +92,8 @@ struct EllMulArgs {
   const double* SrcAlt; long strideSrcAlt; int ldsrcAlt;   // ELL_S: H P [Mp x Np] for the gather fallback (may be null if the tile form fits)
   double* out; long strideOut; int ldo;
   double* out2; long strideOut2; int ldo2;      // ELL_HP only
+  double* diag_out; long strideDiag;            // ELL_S, tile form with 64-wide slabs only: compact copy of the 2 x 2 diagonal blocks (or null)
+  int* diag_done;                               // host: set to 1 by the launcher when the launch writes diag_out
   const double* diagR; long strideR;            // ELL_S, ELL_G
   const double* K; long strideK; int ldk;       // ELL_G
   int X;        // extent of the contiguous index (Np for HP/G, Mp for S)

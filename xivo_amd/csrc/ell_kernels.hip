@@ -270,9 +270,10 @@ __device__ __forceinline__ void gate_ell_body(const GateEllArgs& a, int filt, do
   if (a.from_S) {
     const double* dr0 = a.diagR + (long)filt * a.strideR;
     for (int f = tid; f < a.F; f += nt) {
-      const double s00 = Sm[2 * f + (long)(2 * f) * a.lds] - dr0[2 * f] + a.R;
-      const double s10 = Sm[2 * f + 1 + (long)(2 * f) * a.lds];
-      const double s11 = Sm[2 * f + 1 + (long)(2 * f + 1) * a.lds] - dr0[2 * f + 1] + a.R;
+      const double* sd = a.Sdiag ? a.Sdiag + (long)filt * a.strideSdiag + 4 * f : nullptr;   // [row in block][column in block]
+      const double s00 = (sd ? sd[0] : Sm[2 * f + (long)(2 * f) * a.lds]) - dr0[2 * f] + a.R;
+      const double s10 = sd ? sd[2] : Sm[2 * f + 1 + (long)(2 * f) * a.lds];
+      const double s11 = (sd ? sd[3] : Sm[2 * f + 1 + (long)(2 * f + 1) * a.lds]) - dr0[2 * f + 1] + a.R;
       sdist[f] = mh_dist_2x2(s00, s10, s11, inn[2 * f], inn[2 * f + 1]);
     }
   }
@@ -532,7 +533,11 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
         const int m = 2 * p + i;
         const double acc = i ? a1 : a0;
         if (MODE == ELL_HP) out[(long)m * a.ldo] = acc;
-        else if (MODE == ELL_S) out[(long)m * a.ldo] = acc + (x == m ? dR[m] : 0.0);
+        else if (MODE == ELL_S) {
+          const double sv_ = acc + (x == m ? dR[m] : 0.0);
+          out[(long)m * a.ldo] = sv_;
+          if (XC == 64 && a.diag_out && (x >> 1) == p) a.diag_out[(long)filt * a.strideDiag + 4 * p + 2 * (x & 1) + i] = sv_;
+        }
         else if (MODE == ELL_GF) outf[(long)m * a.ldo] = (float)fma(K[(long)m * a.ldk], dR[m], acc);
         else out[(long)m * a.ldo] = fma(K[(long)m * a.ldk], dR[m], acc);
       }
@@ -631,6 +636,8 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
   const int grid = ((a.batch + 7) / 8) * 8 * wgs;
+  if (!(MODE == ELL_S && XC == 64)) a.diag_out = nullptr;
+  if (a_in.diag_done) *a_in.diag_done = a.diag_out ? 1 : 0;
   if (!(MODE == ELL_S && wgs == 1)) a.gate_here = 0;      // the gate rides along only when one workgroup forms the whole S of its filter
   if (a_in.gate_done) *a_in.gate_done = a.gate_here;
   hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU>), dim3(grid), dim3(ell_tile_threads(MODE, CWU, XC, PWU)), lds, s, a);
@@ -681,6 +688,7 @@ static int launch_ell_tile_m(const EllMulArgs& a, hipStream_t s, bool* done) {
 
 int launch_ell_mul(int mode, const EllMulArgs& a_in, hipStream_t s) {
   if (a_in.batch <= 0) return 0;
+  if (a_in.diag_done) *a_in.diag_done = 0;      // only the tile form with 64-wide slabs writes the compact diagonal blocks
   EllMulArgs a = a_in;
   {
     {
