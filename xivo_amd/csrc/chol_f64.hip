@@ -359,9 +359,10 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
   const int nb = g.Mp / 16;
   // Round 3 (factor_invert_diag on the matrix pipe): the register kernel is ~11 500 instructions at ten block rows (it
   // was ~45 000: 170-200 KB of straight-line code that lost 2.6x on nodes with slow instruction fetch) and is the
-  // default for every batch size it holds. Measured at M = 160: one factor 48 us (round 2: 80), 16384 factors
-  // 1.63 ms (register kernel, three workgroups per CU, no look-ahead) against 2.59 ms for the one-wave kernel and
-  // 2.3-2.4 ms for either kernel before. The one-wave kernel serves factors beyond twelve block rows.
+  // default for every batch size it holds; the k-slice loop of factor_invert_diag then brought it to 42 KB. Measured at
+  // M = 160: one factor 48-52 us (round 2: 80), 16384 factors 1.6-1.7 ms (register kernel, three workgroups per CU, no
+  // look-ahead) against 2.4-2.6 ms for the one-wave kernel and 2.3-2.4 ms for either kernel before. Thirteen to nineteen
+  // block rows run the same kernel on eight waves (below); the one-wave kernel serves what is left (M > 304).
   const bool want_reg = g.variant == 2 || g.variant == 0;
   if (!old_kernel && nb <= 12 && g.variant != 1 && want_reg) {
     static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
