@@ -109,7 +109,7 @@ def _cpu_worker(arg):
     return n, time.perf_counter() - t0
 
 
-def parity_check(ctx, step, B, uniq, F, P, H, inn, dR, gate, no_gating):
+def parity_check(ctx, step, B, uniq, F, P, H, inn, dR, gate, no_gating, tol_P=1e-6):
     """Runs ONE step from the initial covariance and compares P+ / dx of 8 filters spread over the batch with the
     oracle (numpy restatement of src/update.cpp:60-96 + src/estimator.cpp:1257-1288) on the same inputs.
     Tolerances = BASELINE.json north_star: 1e-6 relative Frobenius on P, 1e-8 on dx."""
@@ -148,17 +148,15 @@ def parity_check(ctx, step, B, uniq, F, P, H, inn, dR, gate, no_gating):
     twins_P = True
     for b in sorted(set(int(x) for x in rng.integers(uniq, B, size=64))) if B > uniq else []:
         twins_P = twins_P and bool(np.array_equal(ctx.download_P(b0=b, nb=1)[0], ctx.download_P(b0=b % uniq, nb=1)[0]))
-    ok = worst_P < 1e-6 and worst_dx < 1e-8 and mask_equal and twins_dx and twins_P
+    ok = worst_P < tol_P and worst_dx < 1e-8 and mask_equal and twins_dx and twins_P
     out = {"ok": bool(ok), "filters": picks, "rel_fro_P_max": worst_P, "rel_dx_max": worst_dx,
            "inlier_masks_equal": mask_equal, "all_filters_dx_equal_their_twin_bitwise": twins_dx,
            "sampled_64_filters_P_equal_their_twin_bitwise": twins_P,
-           "tol": {"P": 1e-6, "dx": 1e-8}, "checker": "oracle/xivo_oracle.py"}
-    if not ok:
-        raise AssertionError(f"bench parity check failed: {out}")
-    return out
+           "tol": {"P": tol_P, "dx": 1e-8}, "checker": "oracle/xivo_oracle.py"}
+    return out      # (a failure is raised by main() AFTER the ranks have exchanged their results: no rank left in a collective)
 
 
-def parity_last_step(ctx, n_steps, B, uniq, F, P, H, inn, dR, gate, no_gating):
+def parity_last_step(ctx, n_steps, B, uniq, F, P, H, inn, dR, gate, no_gating, tol_P=1e-6):
     """The state the TIMED loop left behind (n_steps updates of the resident covariance with the same measurements, warm-up
     included) against the oracle applying the same n_steps updates one after the other - gating re-evaluated on the shrinking
     covariance every time. Catches anything that only goes wrong after the first step (stale buffers, state carried between
@@ -187,12 +185,135 @@ def parity_last_step(ctx, n_steps, B, uniq, F, P, H, inn, dR, gate, no_gating):
         err = ctx.get_err(b0=b, nb=1)[0]
         worst_P = max(worst_P, float(np.linalg.norm(Pn - Pc) / np.linalg.norm(Pc)))
         worst_dx = max(worst_dx, float(np.linalg.norm(err - e_ref) / np.linalg.norm(e_ref)))
-    ok = worst_P < 1e-6 and worst_dx < 1e-8 and mask_equal
+    ok = worst_P < tol_P and worst_dx < 1e-8 and mask_equal
     out = {"ok": bool(ok), "updates_in_a_row": n_steps, "filters": picks, "rel_fro_P_max": worst_P, "rel_dx_max": worst_dx,
-           "inlier_masks_equal": mask_equal, "tol": {"P": 1e-6, "dx": 1e-8}}
-    if not ok:
-        raise AssertionError(f"bench parity check after the last timed step failed: {out}")
+           "inlier_masks_equal": mask_equal, "tol": {"P": tol_P, "dx": 1e-8}}
     return out
+
+
+def parity_glevel(ctx, step, B, uniq, P0, tol_P=1e-6):
+    """Feature-level runs (--level G, BASELINE config 3): ONE step from the initial covariance, then UpdateJosephForm of
+    the oracle on the rows the device stacked (xivo_hip_get_H: in-state rows after gating - rejected features are neutral
+    rows -, projected / compressed OOS rows, inn, diagR) against the device's P+ and dx, 4 filters spread over the launch.
+    What this pins inside the bench is a1 at this shape and batch; the kernels that BUILD the rows (Jacobians, gating,
+    stacking, OOS projection, QR compression) are pinned against the oracle by tests/test_glevel_gpu.py."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import xivo_oracle as orc
+    ctx.restore_P()
+    step()
+    picks = sorted({b for b in (0, B // 2 + 3, B - 9, B - 1) if 0 <= b < B})
+    worst_P = worst_dx = 0.0
+    for b in picks:
+        Hd, innd, dRd = ctx.get_H(b)
+        e_ref, P_ref, _ = orc.update_joseph(Hd, P0[b % uniq], innd, dRd)
+        Pn = ctx.download_P(b0=b, nb=1)[0]
+        err = ctx.get_err(b0=b, nb=1)[0]
+        worst_P = max(worst_P, float(np.linalg.norm(Pn - P_ref) / np.linalg.norm(P_ref)))
+        worst_dx = max(worst_dx, float(np.linalg.norm(err - e_ref) / np.linalg.norm(e_ref)))
+    return {"ok": bool(worst_P < tol_P and worst_dx < 1e-8), "filters_checked_vs_oracle": picks, "rel_fro_P_max": worst_P,
+            "rel_dx_max": worst_dx, "rows": int(Hd.shape[0]), "tol": {"P": tol_P, "dx": 1e-8},
+            "checker": "oracle/xivo_oracle.py update_joseph on the rows the device stacked (xivo_hip_get_H)"}
+
+
+def dropin_block(shapes=((203, 30), (250, 80)), n_calls=300):
+    """Wall time of the LITERAL drop-in call - xivo::hip::Estimator::UpdateJosephForm() through libxivo_host.so with P_, H_,
+    inn_, diagR_ in pageable host memory, one estimator (the reference is one singleton filter per process,
+    src/estimator.cpp:26; callers src/update.cpp:141, :332) - median over n_calls calls, beside oracle/_ref's ms per update
+    on the same host cores, parity of the returned P_ / err_ against the oracle. mode 0 = the one-call entry
+    (xivo_hip_update_joseph_host: P_ in place, H_ compressed while staged, one synchronisation), 1 = the six general calls
+    of rounds 1-3, 2 = one call with the prior already resident (no upload of P_)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import xivo_oracle as orc
+    from xivo_amd import synth
+    host = C.CDLL(os.path.join(ROOT, "xivo_amd", "libxivo_host.so"))
+    try:
+        import ref_binding
+        ref = ref_binding.load()
+    except Exception:
+        ref = None
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = []
+    for N, F in shapes:
+        M = 2 * F
+        P, H, inn, dR = synth.s_level(N, F, 1, seed=4321 + N)
+        Pf, Hf = np.asfortranarray(P[0]), np.asfortranarray(H[0])
+        e_ref, P_ref, _ = orc.update_joseph(H[0], P[0], inn[0], dR[0])
+        row = {"N": N, "M": M, "calls": n_calls,
+               "what": "Estimator::UpdateJosephForm() via libxivo_host.so, members in pageable host memory, B = 1"}
+        for mode, key in ((0, "ms_per_update"), (1, "ms_per_update_six_call_sequence_r03"), (2, "ms_per_update_prior_resident")):
+            ms = np.zeros(n_calls); Pout = np.zeros((N, N), order="F"); err = np.zeros(N); msg = C.create_string_buffer(256)
+            rc = host.xivo_host_time_update_joseph(N, M, p(Pf), p(Hf), p(inn[0].copy()), p(dR[0].copy()), n_calls, mode, C.c_uint(0),
+                                                   p(ms), p(Pout), p(err), msg, 256)
+            if rc != 0:
+                row[key] = None; row["error"] = msg.value.decode(); continue
+            tail = ms[n_calls // 10:]
+            row[key] = float(np.median(tail))
+            if mode == 0:
+                row["p10_p90_ms"] = [float(np.percentile(tail, 10)), float(np.percentile(tail, 90))]
+                rp = float(np.linalg.norm(Pout - P_ref) / np.linalg.norm(P_ref)); re_ = float(np.linalg.norm(err - e_ref) / np.linalg.norm(e_ref))
+                row["parity"] = {"ok": bool(rp < 1e-6 and re_ < 1e-8), "rel_fro_P": rp, "rel_dx": re_, "tol": {"P": 1e-6, "dx": 1e-8}}
+        if ref is not None:
+            t = []
+            for _ in range(3):
+                ref.update_joseph(H[0], P[0], inn[0], dR[0])
+            n_ref = max(10, min(200, int(2.0 / max(1e-4, 5.65e-3 * (N / 250.0) ** 3))))
+            for _ in range(n_ref):
+                t0 = time.perf_counter(); ref.update_joseph(H[0], P[0], inn[0], dR[0]); t.append(time.perf_counter() - t0)
+            row["cpu_ref_ms_per_update"] = float(np.median(t) * 1e3)
+            row["cpu_ref"] = f"oracle/_ref (Eigen 3.3.9, 1 thread), median of {n_ref} calls on this host"
+            if row.get("ms_per_update"):
+                row["speedup_vs_cpu_ref"] = row["cpu_ref_ms_per_update"] / row["ms_per_update"]
+        out.append(row)
+    return out
+
+
+# the other BASELINE.json configurations (and the S-level variants SURVEY 8d asks for), each run by this same script in a
+# child process after the headline loop - fewer steps, no CPU baseline; one entry of the `configs` array each
+SUB_CONFIGS = [
+    ("config2 (N=150, 50 features, M=100), fp64", ["--state-dim", "150", "--features", "50", "--steps", "8", "--warmup", "2"]),
+    ("config3 (N=251: 60 in-state features + 20 OOS features null-space projected, QR-compressed), fp64, 4096 filters",
+     ["--level", "G", "--oos", "20", "--batch", "4096", "--steps", "8", "--warmup", "2"]),
+    ("config4 (N=400, 150 features, M=300), fp64 (library default), 4096 filters",
+     ["--state-dim", "400", "--features", "150", "--batch", "4096", "--steps", "5", "--warmup", "2"]),
+    ("config4 as written: fp32 MFMA covariance products (XIVO_HIP_FLAG_FP32_COV, tolerance 5e-5 on P), 4096 filters",
+     ["--state-dim", "400", "--features", "150", "--batch", "4096", "--steps", "4", "--warmup", "1", "--flags", "32", "--tol-P", "5e-5"]),
+    ("TUM-VI size (N=203, 30 features, M=60), fp64, 8192 filters",
+     ["--state-dim", "203", "--features", "30", "--batch", "8192", "--steps", "8", "--warmup", "2"]),
+    ("metric point, dense as-coded pipeline (XIVO_HIP_FLAG_DENSE_H | REASSOC = --flags 80: H treated as dense, pure-GEMM variant of SURVEY 8d), 8192 filters",
+     ["--flags", "80", "--batch", "8192", "--steps", "5", "--warmup", "2"]),
+    ("metric point, B = 1 (one estimator, inputs resident in HBM)", ["--batch", "1", "--steps", "200", "--warmup", "20"]),
+]
+
+
+def configs_block(device_budget_s=200.0):
+    import subprocess
+    rows = []
+    t_all = time.perf_counter()
+    for name, extra in SUB_CONFIGS:
+        if time.perf_counter() - t_all > device_budget_s:
+            rows.append({"name": name, "skipped": "time budget of the default run used up"})
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sub", "--no-cpu-baseline", "--no-mixed"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=150)
+            line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+            d = json.loads(line[-1]) if line else None
+        except Exception as e:   # a secondary shape must never take the headline line down
+            r, d = None, None
+            rows.append({"name": name, "error": repr(e)[:300]}); continue
+        if d is None:
+            rows.append({"name": name, "error": (r.stderr or "")[-400:], "returncode": r.returncode}); continue
+        par = d.get("parity_check") or {}
+        roof = d.get("roofline") or {}
+        rows.append({"name": name, "args": " ".join(extra), "value": d["value"], "unit": "updates/s", "ms_per_step": d["ms_per_step"],
+                     "filters": d["config"]["filters_per_gpu"], "steps": d["steps"], "pipeline": d["config"].get("pipeline"),
+                     "parity": {"ok": par.get("ok"), "rel_fro_P_max": par.get("rel_fro_P_max"), "rel_dx_max": par.get("rel_dx_max"),
+                                "inlier_masks_equal": par.get("inlier_masks_equal"), "tol": par.get("tol"), "checker": par.get("checker")},
+                     "dominant_kernel": roof.get("kernel"), "frac": roof.get("frac"), "bound": roof.get("bound"),
+                     "stage_ms_per_step": d.get("stage_ms_per_step"), "wall_s": time.perf_counter() - t0})
+    return rows
 
 
 def main():
@@ -229,6 +350,10 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="extra XIVO_HIP_FLAG_* bits (A/B knobs)")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-mixed", action="store_true", help="skip the second timed loop (fp32 correction product)")
+    ap.add_argument("--sub", action="store_true", help="child run of the `configs` array: no configs / dropin blocks of its own")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` array (the other BASELINE configurations, child runs)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the `dropin` block (wall time of the one-estimator drop-in call)")
+    ap.add_argument("--tol-P", type=float, default=1e-6, help="parity tolerance on P (1e-6 = north_star; the fp32 flag states 5e-5)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction path only, no device work (CPU-box test of --gpus N)")
     args = ap.parse_args()
@@ -443,7 +568,9 @@ def main():
     parity_last = None
     if args.level == "S" and not args.no_parity_check:
         parity_last = parity_last_step(ctx, args.warmup + args.steps, B, uniq, F, P, H, inn, dR,
-                                       (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating)
+                                       (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating,
+                                       # a stated non-default tolerance (fp32 products) is per update: it adds up over the updates in a row
+                                       tol_P=args.tol_P if args.tol_P == 1e-6 else args.tol_P * (args.warmup + args.steps))
 
     # ---- second figure: opt-in XIVO_HIP_FLAG_FP32_CORR - the Joseph correction product G K^T on the fp32 MFMA (only
     # where the re-associated stand-alone tail runs: beyond N = 256 / M = 176)
@@ -476,21 +603,33 @@ def main():
                         "P+ = P - W^T W - the value of the Joseph expression for the optimal gain, all fp64; opt-in, the "
                         "reference codes the Joseph form (= `value`)"}
         if not args.no_parity_check:
-            symm["parity_check"] = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating)
+            symm["parity_check"] = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating, args.tol_P)
         ctx.set_flags(flags)
 
     # ---- parity at the benchmarked batch: one step from the initial P, filters spread over the launch
     # (first / last, both sides of an XCD group of 8, mid batch) against the oracle - checker only, outside the timing
     parity = None
     if args.level == "S" and not args.no_parity_check:      # every rank checks its own GPU's results
-        parity = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating)
+        parity = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating, args.tol_P)
+    elif args.level == "G" and not args.no_parity_check and not frame and not args.ransac:
+        parity = parity_glevel(ctx, step, B, uniq, P, args.tol_P)
     per_rank_parity = gather_objects(dist, {"rank": rank, "device": device,
-                                            "ok": None if parity is None else bool(parity["ok"] and (parity_last or {"ok": True})["ok"]),
+                                            "ok": None if parity is None else all(q["ok"] for q in (parity, parity_last, (symm or {}).get("parity_check")) if q is not None),
                                             "rel_fro_P_max": None if parity is None else parity["rel_fro_P_max"],
                                             "rel_dx_max": None if parity is None else parity["rel_dx_max"],
                                             "last_step_rel_fro_P_max": None if parity_last is None else parity_last["rel_fro_P_max"]})
     per_rank_aff = gather_objects(dist, {k: affinity.get(k) for k in ("numa_node", "n_cpus", "bound", "omp_threads", "error")
                                          if affinity.get(k) is not None})
+
+    failed = [q for q in (parity, parity_last, (symm or {}).get("parity_check")) if q is not None and not q["ok"]]
+    if any(pr.get("ok") is False for pr in per_rank_parity):    # (the same list on every rank: all of them leave together)
+        # every rank has delivered its result to the gather above, so nobody is left waiting in a collective
+        sys.stderr.write(f"bench parity check FAILED (rank {rank}): {failed} per_rank={per_rank_parity}\n")
+        ctx.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
 
     peak_meas = ctx.bench_mfma_peak() if rank == 0 else None
 
@@ -608,6 +747,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, F)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        headline_default = (world == 1 and not args.sub and args.level == "S" and args.state_dim == 250 and args.features == 80
+                            and args.flags == 0 and not args.no_gating)
+        if headline_default and not args.no_dropin:
+            try:
+                out["dropin"] = dropin_block()
+            except Exception as e:   # never let a secondary block break the bench line
+                out["dropin"] = {"error": repr(e)[:300]}
+        if headline_default and not args.no_configs:
+            ctx.close()              # the child runs need the HBM this context holds
+            out["configs"] = configs_block()
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

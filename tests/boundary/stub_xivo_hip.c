@@ -42,4 +42,15 @@ int xivo_hip_download_P(xivo_hip_ctx* c, int b0, int nb, double* P, long stride,
   return XIVO_HIP_OK;
 }
 int xivo_hip_get_status(xivo_hip_ctx* c, int b0, int nb, int* status) { (void)b0; (void)nb; *status = 0; c->calls |= 32; return XIVO_HIP_OK; }
+/* the one-call plumbing entry (round 4): every argument of the six calls above arrives at once */
+int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, int ldh, const double* inn, const double* diagR,
+                                double* P, int ldp, double* err_out, unsigned mode) {
+  if (b != 0 || ldh != M || ldp != c->N || mode != 0 || !H || !diagR || !P || !err_out) return XIVO_HIP_ERR_INVALID;
+  c->M = M;
+  for (int n = 0; n < c->N; ++n) err_out[n] = 0.0;
+  for (int m = 0; m < M; ++m) err_out[m % c->N] += inn[m];
+  c->calls |= 64;                 /* P is left alone: "updated in place" */
+  return XIVO_HIP_OK;
+}
+int xivo_hip_host_register(xivo_hip_ctx* c, void* p, size_t bytes) { (void)p; (void)bytes; c->calls |= 128; return XIVO_HIP_OK; }
 int stub_calls(void) { return g_ctx.calls; }

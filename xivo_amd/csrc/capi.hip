@@ -93,6 +93,12 @@ struct xivo_hip_ctx {
   xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
   std::vector<char> hstage;                        // host staging of d2h_rows
   void* edit_buf = nullptr; size_t edit_cap = 0;   // device copy of the ops of xivo_hip_edit_batch
+  // one-filter plumbing call (xivo_hip_update_joseph_host): page-locked, device-mapped staging block owned by the context,
+  // the caller's registered (page-locked in place) buffers, scratch of the host-side row compression
+  char* pin_h = nullptr; char* pin_d = nullptr; size_t pin_bytes = 0;
+  struct HostReg { const char* h; size_t bytes; char* d; };
+  std::vector<HostReg> host_regs;
+  struct HostCompressScratch { std::vector<int> cnt, occ, cslot, n; std::vector<double> v; } hc;
   size_t sub_cap = 0;
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -326,6 +332,8 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
                   c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->tune_status, c->ldlt_used};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
+  if (c->pin_h) hipHostFree(c->pin_h);
+  for (auto& r : c->host_regs) hipHostUnregister(const_cast<char*>(r.h));
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
   if (c->t1) hipEventDestroy(c->t1);
@@ -1098,6 +1106,221 @@ int xivo_hip_get_status(xivo_hip_ctx* c, int b0, int nb, int* status) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (int i = 0; i < nb; ++i) if (status[i]) return XIVO_HIP_ERR_NOT_SPD;
   return XIVO_HIP_OK;
+}
+
+// ------------------------------------------------------------------ one-filter plumbing call
+// Estimator::UpdateJosephForm() as the reference calls it (src/update.cpp:141, :332): members in host memory in, members in
+// host memory out, ONE call, ONE host synchronisation. See include/xivo_hip.h.
+int xivo_hip_host_register(xivo_hip_ctx* c, void* p, size_t bytes) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (!c || !p || bytes == 0) return XIVO_HIP_ERR_INVALID;
+  for (auto& r : c->host_regs) if (r.h == (const char*)p && r.bytes >= bytes) return XIVO_HIP_OK;
+  if (hipHostRegister(p, bytes, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return XIVO_HIP_ERR_HIP; }
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) { hipHostUnregister(p); (void)hipGetLastError(); return XIVO_HIP_ERR_HIP; }
+  c->host_regs.push_back({(const char*)p, bytes, (char*)d});
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_host_unregister(xivo_hip_ctx* c, void* p) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (!c || !p) return XIVO_HIP_ERR_INVALID;
+  for (size_t i = 0; i < c->host_regs.size(); ++i) {
+    if (c->host_regs[i].h != (const char*)p) continue;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipHostUnregister(p);
+    c->host_regs.erase(c->host_regs.begin() + (long)i);
+    return XIVO_HIP_OK;
+  }
+  return XIVO_HIP_ERR_INVALID;
+}
+
+// device alias of a host range the caller registered (null: not registered - the range is staged through the context's block)
+static char* host_alias(const xivo_hip_ctx* c, const void* p, size_t bytes) {
+  const char* q = (const char*)p;
+  for (const auto& r : c->host_regs) if (q >= r.h && q + bytes <= r.h + r.bytes) return r.d + (q - r.h);
+  return nullptr;
+}
+
+// Row-pair compression of ONE dense H_ on the host: the arithmetic-free format conversion meas_compress_kernel does for a
+// batch (ell_kernels.hip - same lists, same common-column rule, same slot order, so the rows are those the device would have
+// built, bit for bit), done while the matrix is staged: the host has to touch every byte of H_ once anyway, and the
+// compressed rows are 1/7 of it. Returns over (1: the rows do not fit the compressed form).
+static int host_compress(xivo_hip_ctx::HostCompressScratch& sc, const double* H, int ldh, int M, int N, int pairs_clear, int* idx,
+                         double* val, int* nc_out, int* pw_out) {
+  const int pairs = (M + 1) / 2;
+  sc.cnt.assign(pairs_clear, 0); sc.occ.assign(N, 0); sc.cslot.assign(N, 0);
+  sc.n.resize((size_t)pairs_clear * ELL_W); sc.v.resize((size_t)pairs_clear * ELL_W * 2);
+  int* cnt = sc.cnt.data(); int* occ = sc.occ.data(); int* cslot = sc.cslot.data();
+  int* ln = sc.n.data(); double* lv = sc.v.data();
+  const int Me = M & ~1;                            // rows covered by complete pairs
+  for (int n = 0; n < N; ++n) {
+    const double* col = H + (size_t)n * ldh;
+    const uint64_t* cb = reinterpret_cast<const uint64_t*>(col);
+    int m = 0;
+    for (; m + 8 <= Me; m += 8) {                   // four pairs at a time: all-zero runs (most of H_) cost one test
+      const uint64_t any = cb[m] | cb[m + 1] | cb[m + 2] | cb[m + 3] | cb[m + 4] | cb[m + 5] | cb[m + 6] | cb[m + 7];
+      if ((any << 1) == 0) continue;                // +0.0 / -0.0 only
+      for (int q = m; q < m + 8; q += 2) {
+        const double v0 = col[q], v1 = col[q + 1];
+        if (v0 != 0.0 || v1 != 0.0) {
+          const int p = q >> 1;
+          if (cnt[p] < ELL_W) { ln[p * ELL_W + cnt[p]] = n; lv[2 * (p * ELL_W + cnt[p])] = v0; lv[2 * (p * ELL_W + cnt[p]) + 1] = v1; }
+          ++cnt[p]; ++occ[n];
+        }
+      }
+    }
+    for (; m < M; m += 2) {
+      const double v0 = col[m], v1 = m + 1 < M ? col[m + 1] : 0.0;
+      if (v0 != 0.0 || v1 != 0.0) {
+        const int p = m >> 1;
+        if (cnt[p] < ELL_W) { ln[p * ELL_W + cnt[p]] = n; lv[2 * (p * ELL_W + cnt[p])] = v0; lv[2 * (p * ELL_W + cnt[p]) + 1] = v1; }
+        ++cnt[p]; ++occ[n];
+      }
+    }
+  }
+  int ne = 0;
+  for (int p = 0; p < pairs; ++p) ne += cnt[p] > 0;
+  int ccols[ELL_CW] = {0};
+  int flagged = 0;
+  for (int n = 0; n < N; ++n) {                     // columns used by more than half of the non-empty pairs, ascending
+    if (ne > 0 && 2 * occ[n] > ne) {
+      if (flagged < ELL_CW) { cslot[n] = flagged + 1; ccols[flagged] = n; }
+      ++flagged;
+    }
+  }
+  const int nc = flagged < ELL_CW ? flagged : ELL_CW;
+  int pw = 0, over = 0;
+  for (int p = 0; p < pairs_clear; ++p) {
+    int* pi = idx + (size_t)p * ELL_W;
+    double* pv = val + (size_t)p * ELL_W * 2;
+    for (int t = 0; t < ELL_W; ++t) { pi[t] = t < nc ? ccols[t] : 0; pv[2 * t] = 0.0; pv[2 * t + 1] = 0.0; }
+    int pos = 0;
+    const int walk = cnt[p] < ELL_W ? cnt[p] : ELL_W;
+    for (int k = 0; k < walk; ++k) {
+      const int n = ln[p * ELL_W + k];
+      const double v0 = lv[2 * (p * ELL_W + k)], v1 = lv[2 * (p * ELL_W + k) + 1];
+      const int cs = cslot[n];
+      if (cs) { pv[2 * (cs - 1)] = v0; pv[2 * (cs - 1) + 1] = v1; }
+      else {
+        if (pos < ELL_PW) { pi[ELL_CW + pos] = n; pv[2 * (ELL_CW + pos)] = v0; pv[2 * (ELL_CW + pos) + 1] = v1; }
+        ++pos;
+      }
+    }
+    if (cnt[p] > ELL_W) pos = ELL_PW + 1;           // more than 28 non-zero columns cannot fit
+    if (pos > ELL_PW) over = 1;
+    if (pos > pw) pw = pos;
+  }
+  *nc_out = nc; *pw_out = pw;
+  return over;
+}
+
+// test hook (no device, no context): the host-side row compression on its own, for the CPU test that pins it to the format
+// of ell.h / meas_compress_kernel. idx [pairs_clear][28], val [pairs_clear][28][2]; returns over.
+int xivo_hip_selftest_host_compress(const double* H, int ldh, int M, int N, int pairs_clear, int* idx, double* val, int* nc, int* pw) {
+  if (!H || !idx || !val || !nc || !pw || M <= 0 || N <= 0 || ldh < M || 2 * pairs_clear < M) return XIVO_HIP_ERR_INVALID;
+  xivo_hip_ctx::HostCompressScratch sc;
+  return host_compress(sc, H, ldh, M, N, pairs_clear, idx, val, nc, pw);
+}
+
+int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, int ldh, const double* inn,
+                                const double* diagR, double* P, int ldp, double* err_out, unsigned mode) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  const bool p_up = !(mode & XIVO_HIP_HOST_P_RESIDENT), p_down = !(mode & XIVO_HIP_HOST_KEEP_P);
+  if (bad_range(c, b, 1) || !H || !inn || !diagR || !err_out || M <= 0 || M > c->Mmax || ldh < M ||
+      ((p_up || p_down) && (!P || ldp < c->N)))
+    return XIVO_HIP_ERR_INVALID;
+  const int N = c->N, Np = c->Np, pairs_clear = c->Mpmax / 2;
+  // the staged block: compressed rows | inn | diagR | flags | P in | P out | err | status
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const size_t o_idx = 0, o_val = al(o_idx + (size_t)pairs_clear * ELL_W * sizeof(int)),
+               o_inn = al(o_val + (size_t)pairs_clear * ELL_W * 2 * sizeof(double)), o_R = al(o_inn + (size_t)c->Mpmax * sizeof(double)),
+               o_flags = al(o_R + (size_t)c->Mpmax * sizeof(double)), o_Pin = al(o_flags + 4 * sizeof(int)),
+               o_Pout = al(o_Pin + (size_t)N * N * sizeof(double)), o_err = al(o_Pout + (size_t)N * N * sizeof(double)),
+               o_st = al(o_err + (size_t)N * sizeof(double)), total = al(o_st + 4 * sizeof(int));
+  if (!c->pin_h) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->pin_h), total, hipHostMallocMapped) != hipSuccess) { c->pin_h = nullptr; (void)hipGetLastError(); return XIVO_HIP_ERR_NOMEM; }
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->pin_d), c->pin_h, 0) != hipSuccess || !c->pin_d) {
+      hipHostFree(c->pin_h); c->pin_h = nullptr; c->pin_d = nullptr; (void)hipGetLastError(); return XIVO_HIP_ERR_HIP;
+    }
+    c->pin_bytes = total;
+  }
+  // the row-pair compressed rows, built while H_ is staged; an H_ that does not fit them (dense rows, stacked OOS rows) or a
+  // context pinned to the dense / fp32 pipelines takes the general entry points - same results, more crossings
+  int nc = 0, pw = 0, over = 1;
+  static const bool no_compress = getenv("XIVO_HIP_NO_COMPRESS") != nullptr;
+  const bool want_ell = !no_compress && !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) && meas_compress_fits(c->Mpmax, Np);
+  if (want_ell)
+    over = host_compress(c->hc, H, ldh, M, N, pairs_clear, reinterpret_cast<int*>(c->pin_h + o_idx),
+                         reinterpret_cast<double*>(c->pin_h + o_val), &nc, &pw);
+  if (over) {
+    int rc = XIVO_HIP_OK;
+    if (p_up) rc = xivo_hip_upload_P(c, b, 1, P, (long)ldp * N, ldp);
+    if (!rc) rc = xivo_hip_set_measurements(c, b, 1, M, H, (long)ldh * N, ldh, inn, M, diagR, M);
+    if (!rc) rc = update_joseph_range(c, b, 1);
+    if (rc) return rc;
+    int st = 0;
+    rc = xivo_hip_get_status(c, b, 1, &st);
+    if (rc) return rc;
+    rc = xivo_hip_get_err(c, b, 1, err_out, N);
+    if (!rc && p_down) rc = xivo_hip_download_P(c, b, 1, P, (long)ldp * N, ldp);
+    return rc;
+  }
+  double* s_inn = reinterpret_cast<double*>(c->pin_h + o_inn);
+  double* s_R = reinterpret_cast<double*>(c->pin_h + o_R);
+  for (int m = 0; m < c->Mpmax; ++m) { s_inn[m] = m < M ? inn[m] : 0.0; s_R[m] = m < M ? diagR[m] : 1.0; }
+  int* s_flags = reinterpret_cast<int*>(c->pin_h + o_flags);
+  s_flags[0] = nc; s_flags[1] = pw; s_flags[2] = 0;
+  // P_: in place when the caller registered it (xivo_hip_host_register), else through the block
+  const size_t p_span = ((size_t)(N - 1) * ldp + N) * sizeof(double);
+  char* p_alias = (p_up || p_down) ? host_alias(c, P, p_span) : nullptr;
+  DropinInArgs ia{};
+  if (p_up) {
+    if (p_alias) { ia.Psrc = reinterpret_cast<const double*>(p_alias); ia.ldps = ldp; }
+    else {
+      double* sp = reinterpret_cast<double*>(c->pin_h + o_Pin);
+      if (ldp == N) memcpy(sp, P, (size_t)N * N * sizeof(double));
+      else for (int j = 0; j < N; ++j) memcpy(sp + (size_t)j * N, P + (size_t)j * ldp, (size_t)N * sizeof(double));
+      ia.Psrc = reinterpret_cast<const double*>(c->pin_d + o_Pin); ia.ldps = N;
+    }
+  }
+  ia.P = c->P + (long)b * c->sP; ia.N = N; ia.Np = Np; ia.ldp = Np;
+  ia.block = c->pin_d; ia.off_idx = (int)o_idx; ia.off_val = (int)o_val; ia.off_inn = (int)o_inn; ia.off_R = (int)o_R; ia.off_flags = (int)o_flags;
+  ia.pairs_clear = pairs_clear; ia.Mpmax = c->Mpmax;
+  ia.idx = c->ell.idx + (long)b * c->ell.stride_idx(); ia.val = c->ell.val + (long)b * c->ell.stride_val();
+  ia.inn = c->inn + (long)b * c->Mpmax; ia.diagR = c->diagR + (long)b * c->Mpmax;
+  ia.nc = c->ell.nc + b; ia.pw = c->ell.pw + b; ia.over = c->ell.over + b;
+  {
+    StageTimer st(c, ST_STACK, 0.0, "dropin_in_kernel", (p_up ? 8.0 * N * N : 0.0) + (double)pairs_clear * ELL_W * 20.0 + 16.0 * c->Mpmax);
+    HIP_TRY((hipError_t)launch_dropin_in(ia, c->stream));
+  }
+  // what stage_measurements leaves behind for the pipeline
+  c->M = M; c->Mp = round_up16(M);
+  c->ell_over_h[b] = 0; c->ell_nc_h[b] = nc; c->ell_pw_h[b] = pw;
+  c->dense_valid = false; c->dense_from_ell = true; c->ht_valid = true; c->mixed_row0 = -1;
+  int rc = update_joseph_range(c, b, 1);
+  if (rc) return rc;
+  DropinOutArgs oa{};
+  oa.P = c->P + (long)b * c->sP; oa.N = N; oa.ldp = Np;
+  if (p_down) {
+    if (p_alias) { oa.Pdst = reinterpret_cast<double*>(p_alias); oa.ldpd = ldp; }
+    else { oa.Pdst = reinterpret_cast<double*>(c->pin_d + o_Pout); oa.ldpd = N; }
+  }
+  oa.err = c->err + (long)b * Np; oa.err_dst = reinterpret_cast<double*>(c->pin_d + o_err);
+  oa.status = c->status + b; oa.ldlt_used = c->ldlt_used + b; oa.flags_dst = reinterpret_cast<int*>(c->pin_d + o_st);
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "dropin_out_kernel", (p_down ? 8.0 * N * N : 0.0) + 8.0 * N);
+    HIP_TRY((hipError_t)launch_dropin_out(oa, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));        // the one synchronisation of the call: kernel end = system-scope release
+  const int* s_st = reinterpret_cast<const int*>(c->pin_h + o_st);
+  memcpy(err_out, c->pin_h + o_err, (size_t)N * sizeof(double));
+  if (p_down && !p_alias) {
+    const double* sp = reinterpret_cast<const double*>(c->pin_h + o_Pout);
+    if (ldp == N) memcpy(P, sp, (size_t)N * N * sizeof(double));
+    else for (int j = 0; j < N; ++j) memcpy(P + (size_t)j * ldp, sp + (size_t)j * N, (size_t)N * sizeof(double));
+  }
+  return s_st[0] ? XIVO_HIP_ERR_NOT_SPD : XIVO_HIP_OK;
 }
 
 static int ensure_gate_buffers(xivo_hip_ctx* c, int F) {

@@ -11,6 +11,25 @@ int launch_unpack_P(const double* raw, double* P, int N, int Np, int ldp, long s
                     hipStream_t s);
 int launch_pack_P(const double* P, double* raw, int N, int ldp, long strideP, int batch, hipStream_t s);
 
+// One-filter plumbing call (dropin.hip, capi.hip: xivo_hip_update_joseph_host): the boundary kernels address page-locked
+// host memory directly. `block` = the staged compressed rows of the filter: ints idx[pairs_clear][ELL_W] at off_idx,
+// doubles val[pairs_clear][ELL_W][2] at off_val, inn[Mpmax] at off_inn, diagR[Mpmax] at off_R, ints {nc, pw, over} at off_flags.
+struct DropinInArgs {
+  const double* Psrc; int ldps;          // host-mapped N x N covariance (null: the device copy is current)
+  double* P; int N, Np, ldp;             // the filter's padded device covariance
+  const void* block; int off_idx, off_val, off_inn, off_R, off_flags;
+  int pairs_clear, Mpmax;
+  int* idx; double* val; double* inn; double* diagR; int* nc; int* pw; int* over;   // the filter's device buffers
+};
+struct DropinOutArgs {
+  const double* P; int N, ldp;           // the filter's padded device covariance
+  double* Pdst; int ldpd;                // host-mapped destination (null: P stays on the device)
+  const double* err; double* err_dst;    // dx [N]
+  const int* status; const int* ldlt_used; int* flags_dst;   // -> {status, ldlt_used}
+};
+int launch_dropin_in(const DropinInArgs& a, hipStream_t s);
+int launch_dropin_out(const DropinOutArgs& a, hipStream_t s);
+
 // raw H (M x N, ld = M), inn (M), diagR (M)  ->  padded H (Mp x Np, ld ldh),
 // H^T (Np x Mp, ld ldht), inn (Mp, zero pad), diagR (Mp, pad = 1)
 struct MeasBuffers {

@@ -1,6 +1,7 @@
 // Implementation of the reference-shaped adapter (estimator_hip.h) over the C ABI.
 #include "estimator_hip.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -22,9 +23,21 @@ Estimator::Estimator(const xivo_layout& layout, const xivo_cam& cam, int max_fea
   P_.setZero(layout.N, layout.N);
   err_.setZero(layout.N);
   groups_.assign(layout.n_groups, nullptr);
+  PinP();
 }
 
 Estimator::~Estimator() { xivo_hip_destroy(ctx_); }
+
+// P_ keeps its storage for the life of the estimator (a fixed-size member in the reference, src/estimator.h:423): page-lock
+// it in place once so that UpdateJosephForm's two crossings of P_ need no staging copy. Re-checked per call (a resize moves
+// the storage); if the registration is refused the call stages through the context's own block - slower, same result.
+void Estimator::PinP() {
+  if (pinned_P_ == P_.data() && pinned_P_bytes_ == sizeof(number_t) * (size_t)P_.rows() * P_.cols()) return;
+  if (pinned_P_) xivo_hip_host_unregister(ctx_, pinned_P_);
+  pinned_P_ = nullptr; pinned_P_bytes_ = 0;
+  const size_t bytes = sizeof(number_t) * (size_t)P_.rows() * P_.cols();
+  if (bytes && xivo_hip_host_register(ctx_, P_.data(), bytes) == XIVO_HIP_OK) { pinned_P_ = P_.data(); pinned_P_bytes_ = bytes; }
+}
 
 void Feature::FillJacobianBlock(MatX& H, int offset) const {
   const xivo_layout& lay = owner_->layout();
@@ -44,30 +57,52 @@ void Feature::FillJacobianBlock(MatX& H, int offset) const {
   copy3(foff, foff);                                   // :677
 }
 
+// uploads P_ if the device copy is not known to be current (resident flows call it after editing P_ on the host)
+void Estimator::SyncDeviceP() {
+  if (device_P_current_) return;
+  const int N = lay_.N;
+  Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "upload_P");
+  device_P_current_ = true;
+}
+
 void Estimator::UpdateJosephForm() {
   const int N = lay_.N, M = H_.rows();
   if (H_.cols() != N || inn_.size() != M || diagR_.size() != M || P_.rows() != N)
     throw std::invalid_argument("UpdateJosephForm: inconsistent sizes");
-  Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "upload_P");
-  Check(xivo_hip_set_measurements(ctx_, 0, 1, M, H_.data(), (long)M * N, M, inn_.data(), M, diagR_.data(), M),
-        "set_measurements");
-  Check(xivo_hip_update_joseph(ctx_, 1), "update_joseph");
   err_.setZero(N);
-  int st = 0;
-  const int rc = xivo_hip_get_status(ctx_, 0, 1, &st);
-  if (rc == XIVO_HIP_ERR_NOT_SPD) {
-    // S = HPH^T + R was not positive definite. The reference's pivoted LDL^T (src/estimator.cpp:1266) cannot fail, so
-    // there is no behaviour to mirror; the device left its P untouched (the final product skips such a filter) and the
-    // host copy P_ - still the prior, nothing has been downloaded - stays authoritative: the measurement is dropped
-    // (err_ = 0), counted, and the filter carries on. BackupState/RestoreState (src/estimator.cpp:1410-1449) is not needed.
-    ++num_not_spd_;
-    last_update_ok_ = false;
+  if (legacy_plumbing_) {   // the six-call sequence of rounds 1-3 (kept for A/B timing: tests, bench.py `dropin`)
+    Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "upload_P");
+    Check(xivo_hip_set_measurements(ctx_, 0, 1, M, H_.data(), (long)M * N, M, inn_.data(), M, diagR_.data(), M),
+          "set_measurements");
+    Check(xivo_hip_update_joseph(ctx_, 1), "update_joseph");
+    int st = 0;
+    const int rc = xivo_hip_get_status(ctx_, 0, 1, &st);
+    if (rc == XIVO_HIP_ERR_NOT_SPD) { ++num_not_spd_; last_update_ok_ = false; return; }
+    Check(rc, "get_status");
+    last_update_ok_ = true;
+    Check(xivo_hip_get_err(ctx_, 0, 1, err_.data(), N), "get_err");
+    Check(xivo_hip_download_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "download_P");
+    device_P_current_ = true;
     return;
   }
-  Check(rc, "get_status");
+  // ONE call, one host synchronisation: P_ read and written in place by the device (page-locked above), H_ scanned once
+  // on the host and handed over as row-pair compressed rows, err_ and the status come back with P_
+  PinP();
+  const unsigned mode = (trust_device_P_ && device_P_current_) ? XIVO_HIP_HOST_P_RESIDENT : 0u;
+  const int rc = xivo_hip_update_joseph_host(ctx_, 0, M, H_.data(), M, inn_.data(), diagR_.data(), P_.data(), N, err_.data(), mode);
+  if (rc == XIVO_HIP_ERR_NOT_SPD) {
+    // only with XIVO_HIP_FLAG_NO_LDLT_FALLBACK (by default the device runs the reference's pivoted L D L^T for such a
+    // filter and the status reads OK): S = HPH^T + R was not positive definite, the device left its P - and so P_ - the
+    // prior; the measurement is dropped (err_ = 0), counted, and the filter carries on
+    err_.setZero(N);
+    ++num_not_spd_;
+    last_update_ok_ = false;
+    device_P_current_ = true;
+    return;
+  }
+  Check(rc, "update_joseph_host");
   last_update_ok_ = true;
-  Check(xivo_hip_get_err(ctx_, 0, 1, err_.data(), N), "get_err");
-  Check(xivo_hip_download_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "download_P");
+  device_P_current_ = true;
 }
 
 void Estimator::ComputeInstateJacobians() {
@@ -116,7 +151,8 @@ std::vector<FeaturePtr> Estimator::MHGating() {
   std::vector<FeaturePtr> inliers;
   num_mh_rejected_ = 0;
   if (F == 0) return inliers;
-  Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "upload_P");
+  if (!(trust_device_P_ && device_P_current_)) Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "upload_P");
+  device_P_current_ = true;
   std::vector<unsigned char> mask(F);
   std::vector<double> dist(F);
   Check(xivo_hip_mh_gate(ctx_, 1, R_, MH_thresh_, MH_thresh_multipler_, min_required_inliers_, mask.data(), dist.data()),
@@ -284,6 +320,7 @@ std::vector<FeaturePtr> Estimator::OnePointRANSAC(const std::vector<FeaturePtr>&
       if (!low[i]) zero_rc(P_, lay_.feature_begin + 3 * mh_inliers[i]->sind(), 3);
     for (Group* g : active)                                             // :311-317
       if (!has(groups_low, g)) zero_rc(P_, lay_.group_begin + 6 * g->sind(), 6);
+    device_P_current_ = false;                                          // P_ was edited on the host just above
     H_.setZero(2 * n_low, size); inn_.setZero(2 * n_low); diagR_.resize(2 * n_low);
     int c = 0;
     for (int i = 0; i < n; ++i) {
@@ -302,7 +339,8 @@ std::vector<FeaturePtr> Estimator::OnePointRANSAC(const std::vector<FeaturePtr>&
   for (int i = 0; i < n; ++i) if (!low[i]) hi.push_back(mh_inliers[i]);
   instate_features_ = hi;
   ComputeInstateJacobians();
-  Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)size * size, size), "upload_P");
+  if (!(trust_device_P_ && device_P_current_)) Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)size * size, size), "upload_P");
+  device_P_current_ = true;
   std::vector<unsigned char> mask(hi.size());
   std::vector<double> dist(hi.size());
   Check(xivo_hip_mh_gate(ctx_, 1, R_, ransac_Chi2_, 1.0, 0, mask.data(), dist.data()), "mh_gate");
@@ -317,6 +355,7 @@ std::vector<FeaturePtr> Estimator::OnePointRANSAC(const std::vector<FeaturePtr>&
     ++h;
   }
   // RestoreState + re-compute Jacobians at the original state (:383-387)
+  device_P_current_ = false;
   P_ = P0; Rsb_ = Rsb0; Rbc_ = Rbc0; Rsg_ = Rsg0; Tsb_ = Tsb0; Vsb_ = Vsb0; bg_ = bg0; ba_ = ba0; Tbc_ = Tbc0;
   for (size_t g = 0; g < groups_.size(); ++g) if (groups_[g]) *groups_[g] = g0[g];
   for (int i = 0; i < n; ++i) mh_inliers[i]->x_ = x0[i];
@@ -502,6 +541,7 @@ void Estimator::Propagate(bool visual_meas, number_t dt) {
   Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "upload_P");
   Check(xivo_hip_propagate_cov(ctx_, 0, 1, NM, PhiAcc.v, Pmm.v), "propagate_cov");
   Check(xivo_hip_download_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "download_P");
+  device_P_current_ = true;
 }
 
 }  // namespace hip
@@ -699,6 +739,43 @@ extern "C" int xivo_host_selftest_sequence(const xivo_layout* lay, const xivo_ca
     std::memcpy(state30 + 15, est.bg_.data(), 24); std::memcpy(state30 + 18, est.ba_.data(), 24); std::memcpy(state30 + 21, est.Rsg_.data(), 72);
     for (int g = 0; g < lay->n_groups; ++g) { std::memcpy(groups_io[g].Rsb, gs[g].Rsb_.data(), 72); std::memcpy(groups_io[g].Tsb, gs[g].Tsb_.data(), 24); }
     for (int i = 0; i < F; ++i) std::memcpy(feats_io[i].x, fs[i].x_.data(), 24);
+    return 0;
+  } catch (const std::exception& e) {
+    if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }
+    return -1;
+  }
+}
+
+// Wall time of the literal drop-in call: xivo::hip::Estimator::UpdateJosephForm() with P_, H_, inn_, diagR_ in pageable
+// host memory (what a caller at src/update.cpp:141 sees), one estimator, `n_calls` calls each from the same prior
+// (P_ is restored on the host between calls, outside the timed region; a copy into P_ is a host edit, so the call uploads
+// it again). mode: 0 = the one-call path (default of the adapter), 1 = the six-call sequence of rounds 1-3, 2 = one-call
+// path with trust_device_P_ and KEEP-style residency (no upload when the device copy is current: the prior is restored
+// with an explicit upload outside the timing). ms_out[n_calls] = per-call wall time; P_out / err_out = result of the last call.
+extern "C" int xivo_host_time_update_joseph(int N, int M, const double* P0, const double* H, const double* inn, const double* diagR,
+                                            int n_calls, int mode, unsigned flags, double* ms_out, double* P_out, double* err_out,
+                                            char* msg, int msg_len) {
+  using namespace xivo::hip;
+  try {
+    xivo_layout lay{N, 23, 1, 29, (N - 29) / 3 > 0 ? (N - 29) / 3 : 1};
+    xivo_cam cam{}; cam.model = XIVO_CAM_PINHOLE; cam.fx = cam.fy = 500; cam.cx = cam.cy = 250; cam.rows = cam.cols = 500;
+    Estimator est(lay, cam, (M + 1) / 2, flags);
+    est.legacy_plumbing_ = mode == 1;
+    est.trust_device_P_ = mode == 2;
+    est.H_.setZero(M, N); std::memcpy(est.H_.data(), H, sizeof(double) * (size_t)M * N);
+    est.inn_.setZero(M); std::memcpy(est.inn_.data(), inn, sizeof(double) * M);
+    est.diagR_.setZero(M); std::memcpy(est.diagR_.data(), diagR, sizeof(double) * M);
+    for (int it = 0; it < n_calls; ++it) {
+      std::memcpy(est.P_.data(), P0, sizeof(double) * (size_t)N * N);
+      est.InvalidateDeviceP();
+      if (mode == 2) est.SyncDeviceP();               // resident flow: the prior is on the device already
+      const auto t0 = std::chrono::steady_clock::now();
+      est.UpdateJosephForm();
+      const auto t1 = std::chrono::steady_clock::now();
+      ms_out[it] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    }
+    std::memcpy(P_out, est.P_.data(), sizeof(double) * (size_t)N * N);
+    std::memcpy(err_out, est.err_.data(), sizeof(double) * N);
     return 0;
   } catch (const std::exception& e) {
     if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }

@@ -188,11 +188,23 @@ class Estimator {
   std::vector<number_t> ransac_chi2_;      // chi-square distances of the rescue step (for tests/diagnostics)
   // host edits of P_ stay plain host code on the authoritative host copy
 
+  // UpdateJosephForm crosses PCIe with P_ twice per call. trust_device_P_ = true lets it skip the upload when the device
+  // copy is known to be current (the last adapter call that moved P_ was an upload or a download and nothing has edited
+  // P_ on the host since); host code that edits P_ (AddGroupToState, RemoveFeatureFromState, ... - SURVEY a17) then calls
+  // InvalidateDeviceP(). Off by default: P_ is a public member, as in the reference, and the adapter cannot see writes to it.
+  bool trust_device_P_ = false;
+  void InvalidateDeviceP() { device_P_current_ = false; }
+  void SyncDeviceP();                      // uploads P_ unless the device copy is known to be current
+  bool legacy_plumbing_ = false;           // UpdateJosephForm through the six general calls of rounds 1-3 (A/B timing)
+
   const xivo_layout& layout() const { return lay_; }
   unsigned flags() const { return flags_; }
 
  private:
   void Check(int status, const char* what) const;
+  void PinP();
+  number_t* pinned_P_ = nullptr; size_t pinned_P_bytes_ = 0;
+  bool device_P_current_ = false;
   xivo_hip_ctx* ctx_ = nullptr;
   xivo_layout lay_;
   xivo_cam cam_;

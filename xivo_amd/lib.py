@@ -141,7 +141,13 @@ _SIGS = {
                              C.POINTER(C.c_int), C.POINTER(C.c_double)],
     "xivo_hip_bench_mfma_peak": [C.c_void_p, C.POINTER(C.c_double)],
     "xivo_hip_get_ldlt_used": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "xivo_hip_update_joseph_host": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_uint],
+    "xivo_hip_host_register": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "xivo_hip_host_unregister": [C.c_void_p, C.c_void_p],
+    "xivo_hip_selftest_host_compress": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
 }
+HOST_P_RESIDENT, HOST_KEEP_P = 1, 2
 # every symbol include/xivo_hip.h declares (tests check the library exports them all)
 ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile", "xivo_hip_device_count",
                                         "xivo_hip_device_numa_node"])
@@ -314,6 +320,28 @@ class Context:
 
     def update_joseph(self, B=None):
         self._check(self.lib.xivo_hip_update_joseph(self.h, self.batch if B is None else B))
+
+    def update_joseph_host(self, H, inn, diagR, P_cm, b=0, mode=0, check=True):
+        """The one-call plumbing entry (xivo_hip_update_joseph_host): H [M, N] row-major here (transposed to Eigen's
+        column-major), P_cm a column-major N x N float64 array updated IN PLACE (pass the same array every call to keep its
+        address - register it with host_register to avoid the staging copy). Returns (err, rc)."""
+        H = np.asarray(H, dtype=np.float64)
+        M, N = H.shape
+        assert N == self.N and P_cm is None or (P_cm.dtype == np.float64 and P_cm.flags["F_CONTIGUOUS"])
+        Hc = _f64(H.T)
+        inn = _f64(inn); dR = _f64(diagR)
+        err = np.empty(self.N)
+        rc = self.lib.xivo_hip_update_joseph_host(self.h, b, M, _ptr(Hc), M, _ptr(inn), _ptr(dR),
+                                                  None if P_cm is None else _ptr(P_cm), self.N, _ptr(err), mode)
+        if check:
+            self._check(rc)
+        return err, rc
+
+    def host_register(self, a):
+        return self.lib.xivo_hip_host_register(self.h, _ptr(a), a.nbytes)
+
+    def host_unregister(self, a):
+        return self.lib.xivo_hip_host_unregister(self.h, _ptr(a))
 
     def get_err(self, b0=0, nb=None):
         nb = self.batch - b0 if nb is None else nb
