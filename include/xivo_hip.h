@@ -243,9 +243,8 @@ int xivo_hip_get_ldlt_used(xivo_hip_ctx* ctx, int b0, int nb, int* used);
  * update_joseph / get_status / get_err / download_P (four synchronisations, three staged copies) for the drop-in binding
  * of INTEGRATION.md section 3. The dense H_ is scanned once on the host while it is staged and crosses PCIe as row-pair
  * compressed rows (the same rows the batched hand-over builds on the device, bit for bit); an H_ without XIVO's row
- * structure takes the general entry points inside this call (same results). P_ is read and written in place by the
- * device when the caller registered its buffer (xivo_hip_host_register - Estimator::P_ keeps its address for the life of
- * the estimator), else through the context's page-locked block. Returns XIVO_HIP_ERR_NOT_SPD exactly when
+ * structure takes the general entry points inside this call (same results). P_ crosses through the context's page-locked
+ * block (one host copy each way; the boundary kernels address the block directly). Returns XIVO_HIP_ERR_NOT_SPD exactly when
  * xivo_hip_get_status would (only with XIVO_HIP_FLAG_NO_LDLT_FALLBACK); P and err_out are then the prior / undefined.
  * The context's staged row count becomes M.
  *   mode: XIVO_HIP_HOST_P_RESIDENT  the device copy of P (filter b) is current - P_ is not uploaded (no host edit since
@@ -256,12 +255,6 @@ int xivo_hip_get_ldlt_used(xivo_hip_ctx* ctx, int b0, int nb, int* used);
 #define XIVO_HIP_HOST_KEEP_P 2u
 int xivo_hip_update_joseph_host(xivo_hip_ctx* ctx, int b, int M, const double* H, int ldh, const double* inn,
                                 const double* diagR, double* P, int ldp, double* err_out, unsigned mode);
-/* Page-lock a host buffer of the caller in place and map it into the device's address space (hipHostRegister), so that
- * xivo_hip_update_joseph_host reads / writes it directly instead of staging it: meant for Estimator::P_
- * (src/estimator.h:423), whose storage is fixed for the life of the estimator. The buffer must stay allocated until
- * xivo_hip_host_unregister or xivo_hip_destroy. Failure (XIVO_HIP_ERR_HIP) is harmless: the call then stages. */
-int xivo_hip_host_register(xivo_hip_ctx* ctx, void* p, size_t bytes);
-int xivo_hip_host_unregister(xivo_hip_ctx* ctx, void* p);
 /* Test hook (needs neither a device nor a context): the host-side row-pair compression xivo_hip_update_joseph_host applies
  * to H_ while staging it - idx [pairs_clear][28] / val [pairs_clear][28][2] in the layout of the batched hand-over
  * (xivo_hip_set_measurements_device), *nc common slots, *pw private slots; returns 1 when the rows do not fit, else 0. */

@@ -52,5 +52,4 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
   c->calls |= 64;                 /* P is left alone: "updated in place" */
   return XIVO_HIP_OK;
 }
-int xivo_hip_host_register(xivo_hip_ctx* c, void* p, size_t bytes) { (void)p; (void)bytes; c->calls |= 128; return XIVO_HIP_OK; }
 int stub_calls(void) { return g_ctx.calls; }

@@ -94,10 +94,8 @@ struct xivo_hip_ctx {
   std::vector<char> hstage;                        // host staging of d2h_rows
   void* edit_buf = nullptr; size_t edit_cap = 0;   // device copy of the ops of xivo_hip_edit_batch
   // one-filter plumbing call (xivo_hip_update_joseph_host): page-locked, device-mapped staging block owned by the context,
-  // the caller's registered (page-locked in place) buffers, scratch of the host-side row compression
+  // scratch of the host-side row compression
   char* pin_h = nullptr; char* pin_d = nullptr; size_t pin_bytes = 0;
-  struct HostReg { const char* h; size_t bytes; char* d; };
-  std::vector<HostReg> host_regs;
   struct HostCompressScratch { std::vector<int> cnt, occ, cslot, n; std::vector<double> v; } hc;
   size_t sub_cap = 0;
   // timing
@@ -333,7 +331,6 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
   if (c->pin_h) hipHostFree(c->pin_h);
-  for (auto& r : c->host_regs) hipHostUnregister(const_cast<char*>(r.h));
   for (auto& ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
   if (c->t0) hipEventDestroy(c->t0);
   if (c->t1) hipEventDestroy(c->t1);
@@ -1111,37 +1108,6 @@ int xivo_hip_get_status(xivo_hip_ctx* c, int b0, int nb, int* status) {
 // ------------------------------------------------------------------ one-filter plumbing call
 // Estimator::UpdateJosephForm() as the reference calls it (src/update.cpp:141, :332): members in host memory in, members in
 // host memory out, ONE call, ONE host synchronisation. See include/xivo_hip.h.
-int xivo_hip_host_register(xivo_hip_ctx* c, void* p, size_t bytes) {
-  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
-  if (!c || !p || bytes == 0) return XIVO_HIP_ERR_INVALID;
-  for (auto& r : c->host_regs) if (r.h == (const char*)p && r.bytes >= bytes) return XIVO_HIP_OK;
-  if (hipHostRegister(p, bytes, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return XIVO_HIP_ERR_HIP; }
-  void* d = nullptr;
-  if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) { hipHostUnregister(p); (void)hipGetLastError(); return XIVO_HIP_ERR_HIP; }
-  c->host_regs.push_back({(const char*)p, bytes, (char*)d});
-  return XIVO_HIP_OK;
-}
-
-int xivo_hip_host_unregister(xivo_hip_ctx* c, void* p) {
-  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
-  if (!c || !p) return XIVO_HIP_ERR_INVALID;
-  for (size_t i = 0; i < c->host_regs.size(); ++i) {
-    if (c->host_regs[i].h != (const char*)p) continue;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    hipHostUnregister(p);
-    c->host_regs.erase(c->host_regs.begin() + (long)i);
-    return XIVO_HIP_OK;
-  }
-  return XIVO_HIP_ERR_INVALID;
-}
-
-// device alias of a host range the caller registered (null: not registered - the range is staged through the context's block)
-static char* host_alias(const xivo_hip_ctx* c, const void* p, size_t bytes) {
-  const char* q = (const char*)p;
-  for (const auto& r : c->host_regs) if (q >= r.h && q + bytes <= r.h + r.bytes) return r.d + (q - r.h);
-  return nullptr;
-}
-
 // Row-pair compression of ONE dense H_ on the host: the arithmetic-free format conversion meas_compress_kernel does for a
 // batch (ell_kernels.hip - same lists, same common-column rule, same slot order, so the rows are those the device would have
 // built, bit for bit), done while the matrix is staged: the host has to touch every byte of H_ once anyway, and the
@@ -1271,18 +1237,16 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
   for (int m = 0; m < c->Mpmax; ++m) { s_inn[m] = m < M ? inn[m] : 0.0; s_R[m] = m < M ? diagR[m] : 1.0; }
   int* s_flags = reinterpret_cast<int*>(c->pin_h + o_flags);
   s_flags[0] = nc; s_flags[1] = pw; s_flags[2] = 0;
-  // P_: in place when the caller registered it (xivo_hip_host_register), else through the block
-  const size_t p_span = ((size_t)(N - 1) * ldp + N) * sizeof(double);
-  char* p_alias = (p_up || p_down) ? host_alias(c, P, p_span) : nullptr;
+  // P_ crosses through the context's page-locked block: one host copy each way (~9 us per 500 KB), the boundary kernels
+  // read / write the block over PCIe. (Page-locking the caller's own P_ in place - hipHostRegister - saved 18 us per call
+  // and was dropped: with large pageable copies elsewhere in the process the runtime's own pinning of recycled heap
+  // addresses left the device faulting on the registered pages, scripts/register_stress.py)
   DropinInArgs ia{};
   if (p_up) {
-    if (p_alias) { ia.Psrc = reinterpret_cast<const double*>(p_alias); ia.ldps = ldp; }
-    else {
-      double* sp = reinterpret_cast<double*>(c->pin_h + o_Pin);
-      if (ldp == N) memcpy(sp, P, (size_t)N * N * sizeof(double));
-      else for (int j = 0; j < N; ++j) memcpy(sp + (size_t)j * N, P + (size_t)j * ldp, (size_t)N * sizeof(double));
-      ia.Psrc = reinterpret_cast<const double*>(c->pin_d + o_Pin); ia.ldps = N;
-    }
+    double* sp = reinterpret_cast<double*>(c->pin_h + o_Pin);
+    if (ldp == N) memcpy(sp, P, (size_t)N * N * sizeof(double));
+    else for (int j = 0; j < N; ++j) memcpy(sp + (size_t)j * N, P + (size_t)j * ldp, (size_t)N * sizeof(double));
+    ia.Psrc = reinterpret_cast<const double*>(c->pin_d + o_Pin); ia.ldps = N;
   }
   ia.P = c->P + (long)b * c->sP; ia.N = N; ia.Np = Np; ia.ldp = Np;
   ia.block = c->pin_d; ia.off_idx = (int)o_idx; ia.off_val = (int)o_val; ia.off_inn = (int)o_inn; ia.off_R = (int)o_R; ia.off_flags = (int)o_flags;
@@ -1302,10 +1266,7 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
   if (rc) return rc;
   DropinOutArgs oa{};
   oa.P = c->P + (long)b * c->sP; oa.N = N; oa.ldp = Np;
-  if (p_down) {
-    if (p_alias) { oa.Pdst = reinterpret_cast<double*>(p_alias); oa.ldpd = ldp; }
-    else { oa.Pdst = reinterpret_cast<double*>(c->pin_d + o_Pout); oa.ldpd = N; }
-  }
+  if (p_down) { oa.Pdst = reinterpret_cast<double*>(c->pin_d + o_Pout); oa.ldpd = N; }
   oa.err = c->err + (long)b * Np; oa.err_dst = reinterpret_cast<double*>(c->pin_d + o_err);
   oa.status = c->status + b; oa.ldlt_used = c->ldlt_used + b; oa.flags_dst = reinterpret_cast<int*>(c->pin_d + o_st);
   {
@@ -1315,7 +1276,7 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
   HIP_TRY(hipStreamSynchronize(c->stream));        // the one synchronisation of the call: kernel end = system-scope release
   const int* s_st = reinterpret_cast<const int*>(c->pin_h + o_st);
   memcpy(err_out, c->pin_h + o_err, (size_t)N * sizeof(double));
-  if (p_down && !p_alias) {
+  if (p_down) {
     const double* sp = reinterpret_cast<const double*>(c->pin_h + o_Pout);
     if (ldp == N) memcpy(P, sp, (size_t)N * N * sizeof(double));
     else for (int j = 0; j < N; ++j) memcpy(P + (size_t)j * ldp, sp + (size_t)j * N, (size_t)N * sizeof(double));

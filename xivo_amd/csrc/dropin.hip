@@ -2,9 +2,8 @@
 //
 // The reference's Estimator::UpdateJosephForm (/root/reference/src/estimator.cpp:1257-1288) works on members that live
 // in host memory: P_, H_, inn_, diagR_ in, err_ and P_ out. A drop-in keeps that contract, so every call crosses PCIe
-// twice. Both crossings are done by a kernel that addresses host memory directly (page-locked and mapped: the caller's
-// own P_ once it is registered, or the context's pinned staging block) - no DMA descriptors, no extra launches, no
-// host synchronisation before the last kernel has finished:
+// twice. Both crossings are done by a kernel that addresses host memory directly (the context's page-locked, device-mapped
+// staging block) - no DMA descriptors, no extra launches, no host synchronisation before the last kernel has finished:
 //   dropin_in_kernel   host P_ (N x N, ld = ldps)        -> padded device P (zero pad)          [skipped when P is resident]
 //                      host block of compressed rows      -> the filter's row-pair compressed H, inn, diagR, nc / pw / over
 //   dropin_out_kernel  device P -> host P_ ; device err_ -> host ; factorisation status + fallback flag -> host

@@ -23,21 +23,9 @@ Estimator::Estimator(const xivo_layout& layout, const xivo_cam& cam, int max_fea
   P_.setZero(layout.N, layout.N);
   err_.setZero(layout.N);
   groups_.assign(layout.n_groups, nullptr);
-  PinP();
 }
 
 Estimator::~Estimator() { xivo_hip_destroy(ctx_); }
-
-// P_ keeps its storage for the life of the estimator (a fixed-size member in the reference, src/estimator.h:423): page-lock
-// it in place once so that UpdateJosephForm's two crossings of P_ need no staging copy. Re-checked per call (a resize moves
-// the storage); if the registration is refused the call stages through the context's own block - slower, same result.
-void Estimator::PinP() {
-  if (pinned_P_ == P_.data() && pinned_P_bytes_ == sizeof(number_t) * (size_t)P_.rows() * P_.cols()) return;
-  if (pinned_P_) xivo_hip_host_unregister(ctx_, pinned_P_);
-  pinned_P_ = nullptr; pinned_P_bytes_ = 0;
-  const size_t bytes = sizeof(number_t) * (size_t)P_.rows() * P_.cols();
-  if (bytes && xivo_hip_host_register(ctx_, P_.data(), bytes) == XIVO_HIP_OK) { pinned_P_ = P_.data(); pinned_P_bytes_ = bytes; }
-}
 
 void Feature::FillJacobianBlock(MatX& H, int offset) const {
   const xivo_layout& lay = owner_->layout();
@@ -85,9 +73,8 @@ void Estimator::UpdateJosephForm() {
     device_P_current_ = true;
     return;
   }
-  // ONE call, one host synchronisation: P_ read and written in place by the device (page-locked above), H_ scanned once
-  // on the host and handed over as row-pair compressed rows, err_ and the status come back with P_
-  PinP();
+  // ONE call, one host synchronisation: P_ through the context's page-locked block, H_ scanned once on the host and
+  // handed over as row-pair compressed rows, err_ and the status come back with P_
   const unsigned mode = (trust_device_P_ && device_P_current_) ? XIVO_HIP_HOST_P_RESIDENT : 0u;
   const int rc = xivo_hip_update_joseph_host(ctx_, 0, M, H_.data(), M, inn_.data(), diagR_.data(), P_.data(), N, err_.data(), mode);
   if (rc == XIVO_HIP_ERR_NOT_SPD) {

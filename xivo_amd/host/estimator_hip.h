@@ -45,6 +45,7 @@ using ::xivo::Mat3;
 #else
 using number_t = double;  // common/alias.h:11
 
+
 struct VecX {
   std::vector<number_t> v;
   VecX() = default;
@@ -202,8 +203,6 @@ class Estimator {
 
  private:
   void Check(int status, const char* what) const;
-  void PinP();
-  number_t* pinned_P_ = nullptr; size_t pinned_P_bytes_ = 0;
   bool device_P_current_ = false;
   xivo_hip_ctx* ctx_ = nullptr;
   xivo_layout lay_;

@@ -143,8 +143,6 @@ _SIGS = {
     "xivo_hip_get_ldlt_used": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_update_joseph_host": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_uint],
-    "xivo_hip_host_register": [C.c_void_p, C.c_void_p, C.c_size_t],
-    "xivo_hip_host_unregister": [C.c_void_p, C.c_void_p],
     "xivo_hip_selftest_host_compress": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
 }
 HOST_P_RESIDENT, HOST_KEEP_P = 1, 2
@@ -323,8 +321,7 @@ class Context:
 
     def update_joseph_host(self, H, inn, diagR, P_cm, b=0, mode=0, check=True):
         """The one-call plumbing entry (xivo_hip_update_joseph_host): H [M, N] row-major here (transposed to Eigen's
-        column-major), P_cm a column-major N x N float64 array updated IN PLACE (pass the same array every call to keep its
-        address - register it with host_register to avoid the staging copy). Returns (err, rc)."""
+        column-major), P_cm a column-major N x N float64 array updated IN PLACE. Returns (err, rc)."""
         H = np.asarray(H, dtype=np.float64)
         M, N = H.shape
         assert N == self.N and P_cm is None or (P_cm.dtype == np.float64 and P_cm.flags["F_CONTIGUOUS"])
@@ -336,12 +333,6 @@ class Context:
         if check:
             self._check(rc)
         return err, rc
-
-    def host_register(self, a):
-        return self.lib.xivo_hip_host_register(self.h, _ptr(a), a.nbytes)
-
-    def host_unregister(self, a):
-        return self.lib.xivo_hip_host_unregister(self.h, _ptr(a))
 
     def get_err(self, b0=0, nb=None):
         nb = self.batch - b0 if nb is None else nb
