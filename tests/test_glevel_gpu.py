@@ -196,7 +196,10 @@ def test_propagation_tail(built):
         assert rel_fro(got[b], exp[b]) < 1e-14
 
 
-@pytest.mark.parametrize("compress,flags", [(False, 0), (True, 0), (True, 64 | 16)])
+# 512 / 4 / 2048 / 1024 = STANDALONE_TAIL / FULL_PNEW / FP32_CORR / EXPANDED_JOSEPH with OOS rows stacked: flags that route the
+# sparse pipeline to its stand-alone tail, whose G = T H^T + K R walks compressed rows that - with mixed stacking - hold the
+# in-state rows only: such a call takes the dense pipeline instead (round 4; it used to return a silently wrong P+)
+@pytest.mark.parametrize("compress,flags", [(False, 0), (True, 0), (True, 64 | 16), (True, 512), (False, 4), (False, 2048), (True, 1024)])
 def test_config3_full_size_instate_plus_oos(built, compress, flags):
     """BASELINE.json config 3 at full size: N=251 (8 groups, 60 in-state features -> 120 rows)
     + 20 OOS features seen from k=5 groups (7 projected rows each -> 140 rows), M=260.
@@ -249,7 +252,9 @@ def test_config3_full_size_instate_plus_oos(built, compress, flags):
                 # the retained energy of the residual: ||Q1^T r|| <= ||r||
                 assert np.linalg.norm(ic[120:]) <= np.linalg.norm(if_[120:]) * (1 + 1e-12)
         ctx.update_joseph()
-        assert ctx.last_path() == (0 if flags else 1)        # mixed stacking runs the sparse pipeline
+        # mixed stacking runs the sparse pipeline - unless a flag asks for its stand-alone tail (512, 4, 2048: dense pipeline);
+        # the expanded in-solve form (1024) needs nothing of H behind the solve and stays on the sparse route
+        assert ctx.last_path() == (1 if flags in (0, 1024) else 0)
         err = ctx.get_err(); Pn = ctx.download_P()
         assert (ctx.get_status() == 0).all()
     assert rows.tolist() == [140] * B

@@ -93,3 +93,24 @@ def test_fallback_flag_is_per_update(built):
     for b in range(B):
         e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+@pytest.mark.parametrize("flags", [0, FLAG_DENSE_H])
+def test_non_finite_input_keeps_the_prior_and_the_failure_signal(built, flags):
+    """A NaN measurement noise / innovation: the Cholesky flags the NaN pivot like a negative one, the L D L^T fallback
+    then sees non-finite arithmetic - that filter keeps its covariance bit for bit, dx = 0, its status stays non-zero and
+    xivo_hip_get_ldlt_used reads 0 (Eigen would hand the NaNs on; the caller's only failure signal must survive)."""
+    N, F, B = 100, 20, 4
+    P, H, inn, dR = synth.s_level(N, F, B, seed=23)
+    dR[1, 7] = np.nan              # S of filter 1 is poisoned
+    P[3] = -P[3]; inn[3, 5] = np.inf   # filter 3 needs the fallback (S negative definite) and its dx cannot be finite
+    with Context(N, 2 * F, B, flags=flags) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+        st = ctx.get_status(check=False); used = ctx.get_ldlt_used()
+        Pn, err = ctx.download_P(), ctx.get_err()
+    assert st[1] != 0 and st[3] != 0 and st[0] == 0 and st[2] == 0 and used.tolist() == [0, 0, 0, 0]
+    for b in (1, 3):
+        assert np.array_equal(Pn[b], P[b]) and not err[b].any()
+    for b in (0, 2):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX

@@ -61,6 +61,7 @@ struct xivo_hip_ctx {
   long sP = 0, sH = 0, sHT = 0, sS = 0, sK = 0, sInvD = 0, sA = 0;   // sA: A buffer, max(N x N, N x M)
   int M = 0, Mp = 0;  // rows currently staged
   int chunk = 0;      // filters per pipeline pass (0 = whole batch)
+  int call_batch = 0; // filters of the whole update call being walked in chunks (0: not chunked)
   int chol_variant[32] = {0};   // per factor size (blocks): 0 = not calibrated yet, 1 / 2 = CholArgs::variant picked on this node
   int* tune_status = nullptr;   // scratch status of the calibration runs (never the caller's)
   int* ldlt_used = nullptr;     // per filter: 1 = the last update went through the pivoted L D L^T fallback
@@ -295,7 +296,10 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
 
 // An update of few filters takes the latency route (chol_trsm.hip, trsm_latency_route) when the pipeline would evaluate the
 // whitened Joseph form anyway: streamed solve with the whitened outputs + the tiled product P - V^T Y on small tiles.
+// (B = the filters of this pass; with the batch walked in chunks - XIVO_HIP_CHUNK - the decision is made on the WHOLE call's
+// batch, c->call_batch: chunks of <= 64 filters of a large batch must not take the few-filter kernels)
 static bool latency_route(const xivo_hip_ctx* c, int Mp, int B, bool full) {
+  if (c->call_batch > B) B = c->call_batch;
   static const bool knobs = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") || getenv("XIVO_HIP_NO_TRSM_T") || getenv("XIVO_HIP_T_FULL");
   const unsigned other = XIVO_HIP_FLAG_THROUGHPUT_ROUTE | XIVO_HIP_FLAG_EXPANDED_JOSEPH | XIVO_HIP_FLAG_STANDALONE_TAIL |
                          XIVO_HIP_FLAG_FP32_CORR | XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_FP32_COV;
@@ -886,6 +890,25 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   return XIVO_HIP_OK;
 }
 
+// Whether update_sparse_range would finish with the stand-alone tail (T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T) for
+// these shapes, flags and knobs - i.e. neither the in-solve covariance update nor the whitened outputs + tiled product nor
+// the symmetric form applies. The tail's G walks the row-pair compressed rows of ALL of H; with mixed stacking (in-state
+// rows compressed, OOS rows dense) those hold the in-state rows only, so such a call must not take the sparse route.
+// (Mirrors the decisions inside update_sparse_range; keep the two in step.)
+static bool sparse_route_ends_in_standalone_tail(const xivo_hip_ctx* c, int Mp, int Np, int B) {
+  if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return false;
+  static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr, no_trsm_t = getenv("XIVO_HIP_NO_TRSM_T") != nullptr,
+                    t_full_env = getenv("XIVO_HIP_T_FULL") != nullptr;
+  const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0, t_full = full || t_full_env;
+  const bool lat = latency_route(c, Mp, B, full);
+  const bool t_here = !t_full && !lat && trsm_forms_T(Mp, Np);
+  const bool all_here = t_here && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);
+  const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
+  const bool wh_out = !t_here && !t_full && jform == 2 && !no_joseph && !no_trsm_t &&
+                      !(c->flags & (XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_FP32_CORR));
+  return !all_here && !wh_out;
+}
+
 static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GateParams* gate) {
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
   const double* H = c->H + (long)b0 * c->sH;
@@ -906,6 +929,9 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
   // the fp32 covariance mode (config 4) is defined on the as-coded products: dense path
   bool sparse = !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV));
   for (int b = b0; sparse && b < b0 + B; ++b) sparse = c->ell_over_h[b] == 0;
+  // mixed stacking + a flag / knob that routes to the stand-alone tail: every row dense, dense pipeline (ensure_dense below
+  // rebuilds the in-state rows from their compressed form next to the OOS rows already in place)
+  if (sparse && c->mixed_row0 >= 0 && sparse_route_ends_in_standalone_tail(c, Mp, Np, B)) sparse = false;
   c->last_path = sparse ? 1 : 0;
   if (sparse) return update_sparse_range(c, b0, B, gate);
   rc = ensure_dense(c);
@@ -1027,11 +1053,13 @@ int xivo_hip_update_joseph(xivo_hip_ctx* c, int B) {
   // (HP, PH^T, S, K, A, T: ~2.7 MB per filter at N=250/M=160) stay resident in the
   // 256 MiB Infinity Cache between consecutive kernels instead of round-tripping HBM.
   const int chunk = c->chunk > 0 ? c->chunk : B;
+  c->call_batch = chunk < B ? B : 0;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = B - b0 < chunk ? B - b0 : chunk;
     int rc = update_joseph_range(c, b0, nb);
-    if (rc) return rc;
+    if (rc) { c->call_batch = 0; return rc; }
   }
+  c->call_batch = 0;
   return XIVO_HIP_OK;
 }
 
@@ -1046,11 +1074,13 @@ int xivo_hip_update_dense_gated(xivo_hip_ctx* c, int B, int F, double R, double 
   // Estimator::OutlierRejection only gates when F > min_required_inliers_ (src/manager.cpp:635)
   const GateParams* g = F > min_inliers ? &gp : nullptr;
   const int chunk = c->chunk > 0 ? c->chunk : B;
+  c->call_batch = chunk < B ? B : 0;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = B - b0 < chunk ? B - b0 : chunk;
     rc = update_joseph_range(c, b0, nb, g);
-    if (rc) return rc;
+    if (rc) { c->call_batch = 0; return rc; }
   }
+  c->call_batch = 0;
   return XIVO_HIP_OK;
 }
 

@@ -1021,9 +1021,11 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   // (eleven block rows with the whitened outputs leaving the kernel: that instantiation spills 700 VGPRs - streamed instead)
   if (nb <= 11 && !(g.Yout && !g.fwd_only)) return launch_trsm_lds_t<11>(g, stream);
   // larger factors: stream the factor through a double-buffered LDS panel
-  static const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;   // A/B knob
-  if (!no_stream && nb <= 24) {
-    const bool wh = g.Yout && !g.fwd_only;
+  // A/B knob (per-wave L2 reads instead of the streamed panel). Ignored when the whitened outputs are wanted: only the streamed
+  // kernel writes them, and a caller that then forms P - V^T Y from an unwritten Y would be silently wrong.
+  static const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
+  const bool wh = g.Yout && !g.fwd_only;
+  if ((!no_stream || wh) && nb <= 24) {
     switch (stream_capacity(nb, wh) * 2 + (wh ? 1 : 0)) {
       case 14 * 2: return launch_trsm_stream_t<14, 0>(g, stream);
       case 14 * 2 + 1: return launch_trsm_stream_t<14, 1>(g, stream);
@@ -1059,7 +1061,7 @@ void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T, bool latency) {
   if (latency && forms_T == 5 && nb <= 14) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
   else if (small_stream && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
   else if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
-  else if (!no_stream) snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
+  else if (!no_stream || forms_T >= 4) snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
   else snprintf(buf, n, "trsm_f64_kernel");
 }
 

@@ -14,7 +14,9 @@
 //   5  the Joseph update as coded:  A = I - K H,  P+ = A P A^T + K R K^T  (estimator.cpp:1276-1287) - exact for ANY
 //      gain, which is the point of that form when S is not what the filter assumed
 // The status of a filter that went through here is cleared and ldlt_used[filt] set, so AbsorbError and the caller treat
-// it as the reference would: updated.
+// it as the reference would: updated. EXCEPT when the arithmetic is not finite (a NaN / Inf measurement, R or covariance:
+// the Cholesky flags a NaN pivot like a negative one): Eigen would hand the NaNs on, here the filter keeps its prior
+// covariance, its dx is zeroed, its status stays non-zero and ldlt_used reads 0 - the caller's only failure signal is kept.
 #include "ell.h"
 #include "ekf_kernels.h"
 
@@ -66,6 +68,9 @@ __global__ __launch_bounds__(1024) void ldlt_fallback_kernel(LdltFallbackArgs a)
   __shared__ double sred[1024];
   __shared__ int sidx[1024];
   __shared__ double sD[512];
+  __shared__ int s_bad;           // a pivot or an entry of dx is not finite
+  if (tid == 0) s_bad = 0;
+  const double dmax = 1.7976931348623157e308;
 
   // ---- 1. S = H (P H^T) + diag(R), every entry
   for (long e = tid; e < (long)M * M; e += nt) {
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(1024) void ldlt_fallback_kernel(LdltFallbackArgs a)
     }
     __syncthreads();
     const double dkk = S[k + k * ld];
-    if (tid == 0) sD[k] = dkk;
+    if (tid == 0) { sD[k] = dkk; if (!(fabs(dkk) <= dmax)) s_bad = 1; }
     const bool valid = fabs(dkk) > 0.0;
     for (int i = k + 1 + tid; i < M; i += nt) S[i + k * ld] = valid ? S[i + k * ld] / dkk : S[i + k * ld];
     __syncthreads();
@@ -148,8 +153,14 @@ __global__ __launch_bounds__(1024) void ldlt_fallback_kernel(LdltFallbackArgs a)
     double dx = 0.0;
     for (int m = 0; m < M; ++m) dx = fma(K[n + (long)m * a.ldk], inn[m], dx);
     a.err[(long)filt * a.strideErr + n] = dx;
+    if (!(fabs(dx) <= dmax)) s_bad = 1;   // (every writer stores the same value)
   }
   __syncthreads();
+  if (s_bad) {   // not finite: prior covariance kept, nothing to absorb, status stays as the factorisation left it
+    for (int n = tid; n < N; n += nt) a.err[(long)filt * a.strideErr + n] = 0.0;
+    if (tid == 0) a.used[filt] = 0;
+    return;
+  }
 
   // ---- 5. A = I - K H (row n per thread: no write conflicts), T = A P, P+ = T A^T + K R K^T
   for (int n = tid; n < N; n += nt) {
