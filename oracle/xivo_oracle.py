@@ -50,15 +50,78 @@ class Layout:
 # ----------------------------------------------------------------------------
 # a1: Estimator::UpdateJosephForm (src/estimator.cpp:1257-1288)
 # ----------------------------------------------------------------------------
-def update_joseph(H, P, inn, diagR):
+def ldlt_eigen(A):
+    """Eigen 3.3.9 `LDLT<MatrixXd, Lower>::compute` = internal::ldlt_inplace<Lower>::unblocked
+    (/root/reference/thirdparty/eigen/Eigen/src/Cholesky/LDLT.h:291-404), the factorisation behind
+    `S_.ldlt()` (src/estimator.cpp:1266): diagonal pivoting on the largest remaining |diagonal| (first index wins a tie,
+    as maxCoeff), lower triangle only, a zero pivot is left undivided (:364-376). Returns (mat, transpositions):
+    strict lower part of mat = L (unit diagonal), diagonal of mat = D."""
+    mat = np.array(A, dtype=np.float64)
+    n = mat.shape[0]
+    tr = np.arange(n)
+    if n <= 1:
+        return mat, tr
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(np.diag(mat)[k:])))          # :318-320
+        tr[k] = p
+        if p != k:                                                  # :323-339, lower triangle only
+            mat[[k, p], :k] = mat[[p, k], :k]
+            mat[p + 1:, [k, p]] = mat[p + 1:, [p, k]]
+            mat[k, k], mat[p, p] = mat[p, p], mat[k, k]
+            for i in range(k + 1, p):
+                mat[i, k], mat[p, i] = mat[p, i], mat[i, k]
+        rs = n - k - 1
+        if k > 0:                                                   # :350-356
+            temp = np.diag(mat)[:k] * mat[k, :k]
+            mat[k, k] -= mat[k, :k] @ temp
+            if rs > 0:
+                mat[k + 1:, k] -= mat[k + 1:, :k] @ temp
+        akk = mat[k, k]
+        valid = abs(akk) > 0.0                                      # :362-363
+        if k == 0 and not valid:                                    # :365-376: the whole diagonal is zero
+            return mat, np.arange(n)
+        if rs > 0 and valid:
+            mat[k + 1:, k] /= akk                                   # :378-379
+    return mat, tr
+
+
+def ldlt_solve_eigen(mat, tr, B):
+    """LDLT::_solve_impl (LDLT.h:561-600): x = P^T L^-T D^+ L^-1 P b with the pseudo-inverse of D at Eigen's tolerance
+    1 / highest() (a pivot of exactly zero - or denormal - drops its component instead of dividing)."""
+    X = np.array(B, dtype=np.float64)
+    n = mat.shape[0]
+    for k in range(n):                                              # dst = P b
+        if tr[k] != k:
+            X[[k, tr[k]]] = X[[tr[k], k]]
+    L = np.tril(mat, -1) + np.eye(n)
+    for i in range(n):                                              # L^-1 (unit lower)
+        X[i] -= L[i, :i] @ X[:i]
+    d = np.diag(mat)
+    tol = 1.0 / np.finfo(np.float64).max
+    for i in range(n):                                              # D^+
+        X[i] = X[i] / d[i] if abs(d[i]) > tol else 0.0
+    for i in range(n - 1, -1, -1):                                  # L^-T
+        X[i] -= L[i + 1:, i] @ X[i + 1:]
+    for k in range(n - 1, -1, -1):                                  # P^T
+        if tr[k] != k:
+            X[[k, tr[k]]] = X[[tr[k], k]]
+    return X
+
+
+def update_joseph(H, P, inn, diagR, solver="lu"):
     """Returns (err, P_new, K_scaled). Expression order as the reference:
     S=(H P) H^T; +R; K^T = S^-1 (H P); err = K inn; A = K H - I;
-    P = (A P) A^T; K *= sqrt(R) column-wise; P += K K^T."""
+    P = (A P) A^T; K *= sqrt(R) column-wise; P += K K^T.
+    solver = "lu" (LAPACK, any non-singular S) or "ldlt" (the restatement of Eigen's pivoted L D L^T above: what the
+    reference runs, and the only one of the two that is defined for a singular S - zero pivots drop their component)."""
     H = np.asarray(H, dtype=np.float64)
     P = np.asarray(P, dtype=np.float64)
     S = (H @ P) @ H.T                                   # :1259
     S[np.diag_indices_from(S)] += diagR                 # :1261-1263
-    Kt = np.linalg.solve(S, H @ P)                      # :1266 (Eigen: pivoted LDL^T)
+    if solver == "ldlt":
+        Kt = ldlt_solve_eigen(*ldlt_eigen(S), H @ P)    # :1266, S_.ldlt().solve(H_ * P_) as Eigen evaluates it
+    else:
+        Kt = np.linalg.solve(S, H @ P)                  # :1266 (Eigen: pivoted LDL^T)
     K = Kt.T
     err = K @ inn                                       # :1267
     A = K @ H                                           # :1276

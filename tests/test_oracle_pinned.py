@@ -191,6 +191,43 @@ def test_live_update_joseph_vs_ref(N, F):
     assert rel(e2, e1) < 1e-9 and rel(P2, P1) < 1e-11
 
 
+@pytest.mark.parametrize("case", ["spd", "indefinite", "negative_definite", "zero_pivots", "asymmetric_P"])
+def test_ldlt_restatement_vs_eigen_ldlt(case):
+    """orc.ldlt_eigen / ldlt_solve_eigen (Eigen 3.3.9 LDLT.h:291-404, :561-600 restated) inside UpdateJosephForm against the
+    real `S_.ldlt().solve(H_ * P_)` of oracle/_ref: positive definite, indefinite and negative definite S, an S with exactly
+    zero pivots (two all-zero measurement rows with R = 0: Eigen leaves a zero pivot undivided and its solve drops the
+    component - the update equals the one without those rows), and a P_ that is not symmetric (the reference never
+    re-symmetrises; it reads P_ as stored)."""
+    ref = _ref()
+    N, F = 100, 20
+    P, H, inn, dR = synth.s_level(N, F, 1, seed=41)
+    P, H, inn, dR = P[0], H[0], inn[0], dR[0]
+    if case == "indefinite":
+        w, Q = np.linalg.eigh(P); w[-3:] *= -1.0; P = (Q * w) @ Q.T; P = 0.5 * (P + P.T)
+    elif case == "negative_definite":
+        P = -P
+    elif case == "zero_pivots":
+        H[6:8] = 0.0; dR[6:8] = 0.0
+    elif case == "asymmetric_P":
+        rng = np.random.default_rng(3)
+        P = P + 1e-3 * np.triu(rng.standard_normal((N, N)), 1) * np.abs(P).mean()
+    S = (H @ P) @ H.T + np.diag(dR)
+    if case == "indefinite":
+        assert np.linalg.eigvalsh(0.5 * (S + S.T)).min() < 0 < np.linalg.eigvalsh(0.5 * (S + S.T)).max()
+    e1, P1 = ref.update_joseph(H, P, inn, dR)[:2]
+    e2, P2, _ = orc.update_joseph(H, P, inn, dR, solver="ldlt")
+    assert rel(e2, e1) < 1e-11 and rel(P2, P1) < 1e-12
+    if case == "zero_pivots":
+        mat, tr = orc.ldlt_eigen(S)
+        assert (np.diag(mat) == 0.0).sum() == 2
+        keep = np.ones(2 * F, dtype=bool); keep[6:8] = False
+        e3, P3, _ = orc.update_joseph(H[keep], P, inn[keep], dR[keep])
+        assert rel(e1, e3) < 1e-11 and rel(P1, P3) < 1e-12
+    elif case != "asymmetric_P":   # (an asymmetric P_ makes S asymmetric: Eigen's L D L^T reads its lower triangle, LU all of it)
+        e3, P3, _ = orc.update_joseph(H, P, inn, dR)          # the LAPACK-LU oracle the parity tests use
+        assert rel(e3, e1) < 1e-10 and rel(P3, P1) < 1e-11
+
+
 def test_live_fullpivlu_random_shapes():
     ref = _ref()
     rng = np.random.default_rng(5)

@@ -1273,9 +1273,8 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
   // addresses left the device faulting on the registered pages, scripts/register_stress.py)
   DropinInArgs ia{};
   if (p_up) {
-    double* sp = reinterpret_cast<double*>(c->pin_h + o_Pin);
-    if (ldp == N) memcpy(sp, P, (size_t)N * N * sizeof(double));
-    else for (int j = 0; j < N; ++j) memcpy(sp + (size_t)j * N, P + (size_t)j * ldp, (size_t)N * sizeof(double));
+    double* sp = reinterpret_cast<double*>(c->pin_h + o_Pin);   // (the lower triangle is all the device reads: p_unpack_device.h)
+    for (int j = 0; j < N; ++j) memcpy(sp + (size_t)j * N + j, P + (size_t)j * ldp + j, (size_t)(N - j) * sizeof(double));
     ia.Psrc = reinterpret_cast<const double*>(c->pin_d + o_Pin); ia.ldps = N;
   }
   ia.P = c->P + (long)b * c->sP; ia.N = N; ia.Np = Np; ia.ldp = Np;

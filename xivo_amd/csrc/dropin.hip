@@ -4,27 +4,24 @@
 // in host memory: P_, H_, inn_, diagR_ in, err_ and P_ out. A drop-in keeps that contract, so every call crosses PCIe
 // twice. Both crossings are done by a kernel that addresses host memory directly (the context's page-locked, device-mapped
 // staging block) - no DMA descriptors, no extra launches, no host synchronisation before the last kernel has finished:
-//   dropin_in_kernel   host P_ (N x N, ld = ldps)        -> padded device P (zero pad)          [skipped when P is resident]
+//   dropin_in_kernel   host P_ (N x N, ld = ldps; its lower triangle, mirrored) -> padded device P  [skipped when P is resident]
 //                      host block of compressed rows      -> the filter's row-pair compressed H, inn, diagR, nc / pw / over
 //   dropin_out_kernel  device P -> host P_ ; device err_ -> host ; factorisation status + fallback flag -> host
 // The dense H_ itself never crosses: the host scans it once while staging it (it has to touch every byte anyway) and
 // stages the row-pair compressed rows (ell.h) instead - 43 KB for 320 KB at N = 250 / M = 160.
 #include "ekf_kernels.h"
+#include "p_unpack_device.h"
 
 namespace xivo_hip {
 
 namespace {
 
 __global__ __launch_bounds__(256) void dropin_in_kernel(DropinInArgs a) {
-  const int nPb = a.Psrc ? (a.Np * a.Np + 255) / 256 : 0;
+  __shared__ double tile[kPUnpackTile][kPUnpackTile + 1];
+  const int nPb = a.Psrc ? p_unpack_pairs(a.Np) : 0;
   const int blk = blockIdx.x;
-  if (blk < nPb) {
-    const int e = blk * 256 + threadIdx.x;
-    if (e >= a.Np * a.Np) return;
-    const int i = e % a.Np, j = e / a.Np;
-    double v = 0.0;
-    if (i < a.N && j < a.N) v = a.Psrc[i + (long)j * a.ldps];
-    a.P[i + (long)j * a.ldp] = v;
+  if (blk < nPb) {   // lower triangle of the host matrix authoritative, read once (p_unpack_device.h): half of P_ crosses PCIe
+    p_unpack_tile_pair(a.Psrc, a.ldps, a.N, a.P, a.ldp, a.Np, blk, tile);
     return;
   }
   // the staged block, segment by segment (every segment starts 16-byte aligned on both sides)
@@ -60,7 +57,7 @@ __global__ __launch_bounds__(256) void dropin_out_kernel(DropinOutArgs a) {
 }  // namespace
 
 int launch_dropin_in(const DropinInArgs& a, hipStream_t s) {
-  const int nPb = a.Psrc ? (a.Np * a.Np + 255) / 256 : 0;
+  const int nPb = a.Psrc ? p_unpack_pairs(a.Np) : 0;
   hipLaunchKernelGGL(dropin_in_kernel, dim3(nPb + 4), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }

@@ -19,21 +19,19 @@
 #include "ekf_kernels.h"
 #include "camera_device.h"
 #include "gate_device.h"
+#include "p_unpack_device.h"
 
 namespace xivo_hip {
 
 namespace {
 
 // ---------------------------------------------------------------- pack/unpack
-__global__ void unpack_P_kernel(const double* __restrict__ raw, double* __restrict__ P, int N, int Np,
-                                int ldp, long strideP) {
+// (lower triangle of the host matrix authoritative: p_unpack_device.h)
+__global__ __launch_bounds__(256) void unpack_P_kernel(const double* __restrict__ raw, double* __restrict__ P, int N, int Np,
+                                                      int ldp, long strideP) {
+  __shared__ double tile[kPUnpackTile][kPUnpackTile + 1];
   const int f = blockIdx.y;
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long)Np * Np) return;
-  const int i = (int)(e % Np), j = (int)(e / Np);
-  double v = 0.0;
-  if (i < N && j < N) v = raw[(long)f * N * N + i + (long)j * N];
-  P[(long)f * strideP + i + (long)j * ldp] = v;
+  p_unpack_tile_pair(raw + (long)f * N * N, N, N, P + (long)f * strideP, ldp, Np, blockIdx.x, tile);
 }
 
 __global__ void pack_P_kernel(const double* __restrict__ P, double* __restrict__ raw, int N, int ldp,
@@ -2347,7 +2345,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters)
 
 int launch_unpack_P(const double* raw, double* P, int N, int Np, int ldp, long strideP, int batch,
                     hipStream_t s) {
-  dim3 grid((unsigned)(((long)Np * Np + 255) / 256), batch);
+  dim3 grid((unsigned)p_unpack_pairs(Np), batch);
   hipLaunchKernelGGL(unpack_P_kernel, grid, dim3(256), 0, s, raw, P, N, Np, ldp, strideP);
   CHECK_LAUNCH();
 }
