@@ -193,6 +193,10 @@ int xivo_hip_device_numa_node(int device);
 int xivo_hip_set_flags(xivo_hip_ctx* ctx, unsigned flags);
 
 /* ---- covariance residency (Estimator::P_, src/estimator.h:423; a17) --- */
+/* P: nb column-major N x N matrices, `stride` elements apart, leading dimension ld. The LOWER triangle of each uploaded
+ * matrix is authoritative: the device state is its exact mirror (every pipeline treats P as symmetric; the reference never
+ * re-symmetrises P_, src/estimator.cpp:1280-1287, so its triangles differ by rounding - a symmetric matrix round-trips bit
+ * for bit, a rounding-level asymmetry stays inside the parity tolerances, tests/test_robustness_gpu.py). */
 int xivo_hip_upload_P(xivo_hip_ctx* ctx, int b0, int nb, const double* P, long stride, int ld);
 int xivo_hip_download_P(xivo_hip_ctx* ctx, int b0, int nb, double* P, long stride, int ld);
 /* BackupState / RestoreState P part (src/estimator.cpp:1413-1414,1434-1435) */
