@@ -210,6 +210,85 @@ class Ref:
         return np.ascontiguousarray(R)
 
 
+class RefX:
+    """oracle/_ref/libxivo_refx_n<N>_*.so: the reference's OWN TEXT of UpdateJosephForm, MHGating, FilterUpdate (+
+    FillJacobianBlock, AbsorbError), RK4Step / PrinceDormandStep (+ ComposeMotion, ComputeMotionJacobianAt), cut out of
+    /root/reference/src at build time (oracle/ref/extract_reference.py) and compiled as member functions of shim classes
+    (oracle/ref/xivo_refx.cpp). One library per compile-time state size."""
+
+    def __init__(self, path):
+        self.path = path
+        self.lib = C.CDLL(path)
+        for f in ("refx_full_size", "refx_group_begin", "refx_feature_begin", "refx_mh_gating"):
+            getattr(self.lib, f).restype = C.c_int
+        self.N = self.lib.refx_full_size()
+        self.group_begin, self.feature_begin = self.lib.refx_group_begin(), self.lib.refx_feature_begin()
+
+    def update_joseph(self, H, P, inn, diagR):
+        M, N = H.shape
+        err = np.empty(N); Pout = np.empty((N, N), order="F")
+        self.lib.refx_update_joseph(C.c_int(N), C.c_int(M), _p(_F(H)), _p(_F(P)), _p(np.ascontiguousarray(inn, dtype=np.float64)),
+                                    _p(np.ascontiguousarray(diagR, dtype=np.float64)), _p(err), _p(Pout))
+        return err, np.ascontiguousarray(Pout)
+
+    def _Jc(self, J):
+        F, _, N = J.shape
+        assert N == self.N, (N, self.N)
+        return np.ascontiguousarray(np.stack([_F(J[i]).reshape(-1, order="F") for i in range(F)]))
+
+    def mh_gating(self, J, inn, P, R, thresh, mult, min_inliers, status=None):
+        """Estimator::MHGating as extracted. J [F, 2, N], inn [F, 2]. Returns (inlier indices in order, status after,
+        num_mh_rejected_, number of features handed to DestroyFeatures)."""
+        F = J.shape[0]
+        st = np.full(F, 3, dtype=np.int32) if status is None else np.ascontiguousarray(status, dtype=np.int32).copy()
+        idx = np.full(F, -1, dtype=np.int32); nrej = C.c_int(); ndes = C.c_int()
+        n = self.lib.refx_mh_gating(C.c_int(F), _p(self._Jc(J)), _p(np.ascontiguousarray(inn, dtype=np.float64)), _p(_F(P)),
+                                    C.c_double(R), C.c_double(thresh), C.c_double(mult), C.c_int(min_inliers), _p(st), _p(idx),
+                                    C.byref(nrej), C.byref(ndes))
+        return idx[:n].copy(), st, nrej.value, ndes.value
+
+    def filter_update(self, J, inn, ref_sind, sind, R, P, X, Rbc, Tbc, x):
+        """Estimator::FilterUpdate as extracted (stacking through Feature::FillJacobianBlock, UpdateJosephForm,
+        AbsorbError). X: oracle MotionState; x [F, 3]. Returns (H, err before the absorb, P+, Rsb, Tsb, Vsb, bg, ba, Rsg, x+)."""
+        F = J.shape[0]
+        st = np.ascontiguousarray(np.concatenate([_F(X.Rsb).reshape(-1, order="F"), X.Tsb, X.Vsb, X.bg, X.ba,
+                                                  _F(X.Rsg).reshape(-1, order="F")]), dtype=np.float64)
+        Pf = _F(P).copy(order="F"); xs = np.ascontiguousarray(x, dtype=np.float64).copy()
+        H = np.zeros((2 * F, self.N), order="F"); err = np.zeros(self.N)
+        self.lib.refx_filter_update(C.c_int(F), _p(self._Jc(J)), _p(np.ascontiguousarray(inn, dtype=np.float64)),
+                                    _p(np.ascontiguousarray(ref_sind, dtype=np.int32)), _p(np.ascontiguousarray(sind, dtype=np.int32)),
+                                    C.c_double(R), _p(Pf), _p(st), _p(_F(Rbc)), _p(np.ascontiguousarray(Tbc, dtype=np.float64)), _p(xs),
+                                    _p(H), _p(err))
+        return (np.ascontiguousarray(H), err, np.ascontiguousarray(Pf), st[0:9].reshape(3, 3).T.copy(), st[9:12].copy(), st[12:15].copy(),
+                st[15:18].copy(), st[18:21].copy(), st[21:30].reshape(3, 3).T.copy(), xs)
+
+    def integrator_step(self, method, X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec):
+        """Estimator::RK4Step / PrinceDormandStep as extracted. Returns (Rsb, Tsb, Vsb, P_new)."""
+        assert P.shape[0] == self.N
+        st = np.ascontiguousarray(np.concatenate([_F(X.Rsb).reshape(-1, order="F"), X.Tsb, X.Vsb, X.bg, X.ba,
+                                                  _F(X.Rsg).reshape(-1, order="F")]), dtype=np.float64)
+        Pf = _F(P).copy(order="F")
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (gyro0, accel0, slope_gyro, slope_accel, g_vec)]
+        self.lib.refx_integrator_step(C.c_int(1 if method == "RK4" else 0), _p(st), _p(Pf), _p(keep[0]), _p(keep[1]), _p(keep[2]),
+                                      _p(keep[3]), C.c_double(dt), _p(_F(Qimu)), _p(keep[4]))
+        return st[0:9].reshape(3, 3).T.copy(), st[9:12].copy(), st[12:15].copy(), np.ascontiguousarray(Pf)
+
+
+_REFX = {}
+
+
+def loadx(N=203):
+    """The extracted-text library compiled for state size N (203 or 251); raises FileNotFoundError if it was never built."""
+    if N in _REFX:
+        return _REFX[N]
+    for v in (("v4", "v3") if _has_avx512() else ("v3",)):
+        path = os.path.join(_HERE, "_ref", f"libxivo_refx_n{N}_{v}.so")
+        if os.path.exists(path):
+            _REFX[N] = RefX(path)
+            return _REFX[N]
+    raise FileNotFoundError(f"oracle/_ref/libxivo_refx_n{N}_*.so not built (needs /root/reference; run oracle/ref/Makefile)")
+
+
 _REF = None
 
 

@@ -451,3 +451,180 @@ def test_golden_update_joseph_at_baseline_sizes(tag):
     assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), G2[f"ujb_{tag}_sha"]), "synthetic input generator drifted"
     err, Pn, _ = orc.update_joseph(H[0], P[0], inn[0], dR[0])
     assert rel(err, G2[f"ujb_{tag}_err"]) < 1e-9 and rel(Pn, G2[f"ujb_{tag}_Pn"]) < 1e-11
+
+
+# ---- round 4 pins: the reference's OWN TEXT compiled (oracle/ref/extract_reference.py -> oracle/ref/xivo_refx.cpp) -------------
+def _refx(N):
+    try:
+        import ref_binding
+        return ref_binding.loadx(N)
+    except (FileNotFoundError, OSError):
+        pytest.skip("oracle/_ref extracted libraries not built")
+
+
+def test_extracted_build_layout_constants():
+    """the extracted src/core.h:40-105 computes the layout itself: default build N = 203, 8 groups / 60 features N = 251"""
+    x = _refx(203)
+    assert (x.N, x.group_begin, x.feature_begin) == (203, 23, 23 + 6 * 15)
+    y = _refx(251)
+    assert (y.N, y.group_begin, y.feature_begin) == (251, 23, 23 + 6 * 8)
+    lay = orc.Layout(8, 60)
+    assert (lay.N, lay.group_begin, lay.feature_begin) == (y.N, y.group_begin, y.feature_begin)
+
+
+@pytest.mark.parametrize("N,F", [(203, 30), (250, 80), (150, 50), (64, 8)])
+def test_extracted_update_joseph_form_equals_the_retyped_driver_bit_for_bit(N, F):
+    """Estimator::UpdateJosephForm: the text of src/estimator.cpp:1257-1288 compiled as is == the line-by-line retyping
+    of oracle/ref/xivo_ref.cpp, BIT FOR BIT (same Eigen expressions on the same dynamic types) - and hence the numpy
+    oracle's distance to either is the same number."""
+    ref, x = _ref(), _refx(203)
+    P, H, inn, dR = synth.s_level(N, F, 2, seed=5 + N)
+    for b in range(2):
+        e1, P1 = ref.update_joseph(H[b], P[b], inn[b], dR[b])
+        e2, P2 = x.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert np.array_equal(e1, e2) and np.array_equal(P1, P2)
+        e3, P3, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        assert rel(e3, e2) < 1e-9 and rel(P3, P2) < 1e-11
+    # an indefinite S and zero pivots go through Eigen's pivoted L D L^T in both
+    Pn = -P[0]
+    assert all(np.array_equal(a, b_) for a, b_ in zip(ref.update_joseph(H[0], Pn, inn[0], dR[0]), x.update_joseph(H[0], Pn, inn[0], dR[0])))
+
+
+@pytest.mark.parametrize("N,cam", [(203, "pinhole"), (251, "equi")])
+def test_extracted_mh_gating_whole_function(N, cam):
+    """Estimator::MHGating, src/update.cpp:50-116 as extracted (distances through the fixed-size 2 x kFullSize J of
+    src/feature.h:281, the relaxation loop, the status / DestroyFeatures bookkeeping) vs the oracle: same inlier list in the
+    same order, the same accumulated num_mh_rejected_ (the counting quirk of :87), REJECTED_BY_FILTER exactly on the others,
+    a GAUGE feature keeps its status when it is an inlier; and the retyped distances agree to rounding."""
+    x, ref = _refx(N), _ref()
+    ng, nf = (15, 30) if N == 203 else (8, 60)
+    lay = orc.Layout(ng, nf)
+    assert lay.N == N
+    from scene_util import scene_arrays, oracle_jacobians, spd
+    for seed in range(3):
+        sc = synth.g_level(ng, nf, nf, 1, seed=400 + seed, cam=CAMS[cam])
+        poses, groups, feats, xp = scene_arrays(sc, CAMS[cam])
+        if seed == 1:
+            xp[0, [2, 7, 11]] += 40.0                       # three outliers
+        if seed == 2:
+            xp[0, 3:] += np.linspace(6, 60, nf - 3)[:, None]   # almost everything wild: the threshold has to relax
+        P = spd(N, 50 + seed) * 1e-4
+        Js, inns, _ = oracle_jacobians(sc, CAMS[cam], lay, xp, 0)
+        d = orc.mh_distances(Js, P, inns, 2.25)
+        m, nrej, _ = orc.mh_gate(d, 5.991, 1.1, 5)
+        status = np.full(nf, 3, dtype=np.int32); status[0] = 7      # feature 0 fixes the gauge
+        idx, st_after, nrej_x, ndes = x.mh_gating(Js, inns, P, 2.25, 5.991, 1.1, 5, status)
+        assert idx.tolist() == np.nonzero(m)[0].tolist() and nrej_x == nrej and ndes == int((~m).sum())
+        assert all(st_after[i] == (4 if not m[i] else (7 if i == 0 else 3)) for i in range(nf))
+        assert rel(ref.mh_distances(Js, P, inns, 2.25), d) < 1e-10
+    assert (~m).sum() > 0
+
+
+@pytest.mark.parametrize("N", [203, 251])
+def test_extracted_filter_update_stacking_quirk_update_and_absorb(N):
+    """Estimator::FilterUpdate (src/update.cpp:120-153) as extracted - Feature::FillJacobianBlock (src/feature.cpp:658-684,
+    incl. the :675-676 overwrite of the group block), UpdateJosephForm, AbsorbError (src/estimator.cpp:875-921 with
+    State::operator+= of src/core.h:135-165 and Feature::UpdateState) - vs the oracle's stack_measurements / update_joseph /
+    absorb_error: H identical entry for entry (a copy), dx 1e-9, P 1e-11, the retracted state and the features 1e-12."""
+    x = _refx(N)
+    ng, nf = (15, 30) if N == 203 else (8, 60)
+    lay = orc.Layout(ng, nf)
+    from scene_util import scene_arrays, oracle_jacobians, spd
+    sc = synth.g_level(ng, nf, nf, 1, seed=77, cam=synth.RADTAN)
+    poses, groups, feats, xp = scene_arrays(sc, synth.RADTAN)
+    P = spd(N, 9) * 1e-4
+    Js, inns, _ = oracle_jacobians(sc, synth.RADTAN, lay, xp, 0)
+    X = orc.MotionState(sc["Rsb"][0], sc["Tsb"][0], [0.1, -0.2, 0.05], [0.01, 0.0, -0.01], [0.02, 0.01, 0.0], orc.so3_exp([0.01, -0.02, 0.0]))
+    Hx, err_x, Px, Rsb, Tsb, Vsb, bg, ba, Rsg, xs = x.filter_update(Js, inns, sc["ref"][0], sc["sind"][0], 2.25, P, X, sc["Rbc"][0],
+                                                                     sc["Tbc"][0], sc["x"][0])
+    H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][0], sc["sind"][0], lay, 2.25)
+    assert np.array_equal(Hx, H)                             # the as-coded stacking incl. the overwrite quirk
+    goff = lay.group_begin + 6 * int(sc["ref"][0][0])
+    assert np.abs(Hx[0:2, goff:goff + 3]).max() > 0 and not Hx[0:2, goff + 3:goff + 6].any()
+    e_ref, P_ref, _ = orc.update_joseph(H, P, inn, dR)
+    assert rel(e_ref, err_x) < 1e-9 and rel(P_ref, Px) < 1e-11
+    st = dict(Rsb=X.Rsb.copy(), Tsb=X.Tsb.copy(), Vsb=X.Vsb.copy(), bg=X.bg.copy(), ba=X.ba.copy(), Rbc=sc["Rbc"][0].copy(),
+              Tbc=sc["Tbc"][0].copy(), Rsg=X.Rsg.copy(), gR=sc["gR"][0].copy(), gT=sc["gT"][0].copy(), x=sc["x"][0].copy(), sind=sc["sind"][0])
+    orc.absorb_error(st, err_x, lay, [], range(nf))
+    assert np.abs(st["Rsb"] - Rsb).max() < 1e-12 and np.abs(st["Tsb"] - Tsb).max() < 1e-12 and np.abs(st["Vsb"] - Vsb).max() < 1e-12
+    assert np.abs(st["bg"] - bg).max() < 1e-12 and np.abs(st["ba"] - ba).max() < 1e-12 and np.abs(st["Rsg"] - Rsg).max() < 1e-12
+    assert np.abs(st["x"] - xs).max() < 1e-12
+
+
+@pytest.mark.parametrize("N", [203, 251])
+def test_extracted_integrator_steps_vs_retyped_and_oracle(N):
+    """Estimator::RK4Step (src/rk4.cpp:35-103) and PrinceDormandStep (src/princedormand.cpp:85-221) as extracted - with the
+    reference's SPARSE F_ / G_ (src/estimator.h:467-470; the retyping uses dense matrices: same sums, the sparse products
+    skip the structural zeros) and the compile-time block sizes - vs the retyped driver and the oracle's tableau form:
+    state 1e-13, P 1e-13 relative (measured ~1e-16)."""
+    x, ref = _refx(N), _ref()
+    rng = np.random.default_rng(19 + N)
+    for k in range(3):
+        A = rng.uniform(-1, 1, size=(N, N)); P = A @ A.T / N * 1e-3 + 1e-6 * np.eye(N)
+        X = orc.MotionState(orc.so3_exp(rng.normal(size=3) * 0.4), rng.normal(size=3), rng.normal(size=3),
+                            rng.normal(size=3) * 0.01, rng.normal(size=3) * 0.05, orc.so3_exp([0.02, -0.01, 0.0]))
+        gy, ac = rng.normal(size=3) * (1 + 3 * k), np.array([0.2, -0.1, 9.7]) + rng.normal(size=3)
+        sg, sa = rng.normal(size=3) * 5, rng.normal(size=3)
+        Qi = np.diag(rng.uniform(1e-6, 1e-3, 12)); gv = np.array([0.0, 0.0, -9.8]); dt = 0.001 * (1 + k)
+        for method, tab, fn in (("PD", orc.PD_TABLEAU, ref.pd_step), ("RK4", orc.RK4_TABLEAU, ref.rk4_step)):
+            Rx, Tx, Vx, Px = x.integrator_step(method, X, P, gy, ac, sg, sa, dt, Qi, gv)
+            R1, T1, V1, P1 = fn(X, P, gy, ac, sg, sa, dt, Qi, gv)
+            assert np.abs(Rx - R1).max() < 1e-15 and np.abs(Tx - T1).max() < 1e-15 and np.abs(Vx - V1).max() < 1e-15
+            assert rel(Px, P1) < 1e-13
+            Xn, Pn = orc.integrator_step(X, P, gy, ac, sg, sa, dt, Qi, gv, tab)
+            assert np.abs(Xn.Rsb - Rx).max() < 1e-13 and np.abs(Xn.Tsb - Tx).max() < 1e-14 and np.abs(Xn.Vsb - Vx).max() < 1e-13
+            assert rel(Pn, Px) < 1e-13
+
+
+# ---- golden_v3.npz: outputs of the extracted reference build (tests/golden/make_golden_v3.py); runs without oracle/_ref ----
+G3 = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v3.npz"))
+
+
+def _g3_mod():
+    """the generator's input builders (seeded scenes), so test and fixture share one definition of the inputs"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_v3", os.path.join(os.path.dirname(__file__), "golden", "make_golden_v3.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_golden_v3_mh_gating(seed):
+    m = _g3_mod()
+    Js, inns, P, status = m.gating_scene(seed)
+    assert np.array_equal(m.digest(Js, inns, P), G3[f"gate_{seed}_in_sha"]), "input generator drifted"
+    d = orc.mh_distances(Js, P, inns, 2.25)
+    mask, nrej, _ = orc.mh_gate(d, 5.991, 1.1, 5)
+    assert np.nonzero(mask)[0].tolist() == G3[f"gate_{seed}_inliers"].tolist()
+    assert [nrej, int((~mask).sum())] == G3[f"gate_{seed}_nrej"].tolist()
+    want = np.where(mask, 3, 4); want[0] = 7 if mask[0] else 4
+    assert want.tolist() == G3[f"gate_{seed}_status"].tolist()
+
+
+def test_golden_v3_filter_update():
+    m = _g3_mod()
+    sc, lay, Js, inns, P, X = m.filter_update_scene()
+    assert np.array_equal(m.digest(Js, inns, P, X.Rsb, sc["x"][0]), G3["fu_in_sha"]), "input generator drifted"
+    H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][0], sc["sind"][0], lay, 2.25)
+    Hg = np.zeros_like(H); Hg[G3["fu_H_nz_rows"], G3["fu_H_nz_cols"]] = G3["fu_H_nz_vals"]
+    assert np.array_equal(H, Hg)
+    e, Pn, _ = orc.update_joseph(H, P, inn, dR)
+    assert rel(e, G3["fu_err"]) < 1e-9 and rel(Pn, G3["fu_P"]) < 1e-11
+    st = dict(Rsb=X.Rsb.copy(), Tsb=X.Tsb.copy(), Vsb=X.Vsb.copy(), bg=X.bg.copy(), ba=X.ba.copy(), Rbc=sc["Rbc"][0].copy(),
+              Tbc=sc["Tbc"][0].copy(), Rsg=X.Rsg.copy(), gR=sc["gR"][0].copy(), gT=sc["gT"][0].copy(), x=sc["x"][0].copy(), sind=sc["sind"][0])
+    orc.absorb_error(st, G3["fu_err"], lay, [], range(m.NF))
+    got = np.concatenate([st["Rsb"].reshape(-1), st["Tsb"], st["Vsb"], st["bg"], st["ba"], st["Rsg"].reshape(-1)])
+    assert np.abs(got - G3["fu_state"]).max() < 1e-12 and np.abs(st["x"] - G3["fu_x"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("k", [0, 1])
+@pytest.mark.parametrize("method", ["RK4", "PD"])
+def test_golden_v3_integrator_steps(k, method):
+    m = _g3_mod()
+    X, P, gy, ac, sg, sa, dt, Qi, gv = m.step_inputs(k)
+    assert np.array_equal(m.digest(P, X.Rsb, X.Tsb, gy, ac, sg, sa, Qi), G3[f"step_{k}_in_sha"]), "input generator drifted"
+    Xn, Pn = orc.integrator_step(X, P, gy, ac, sg, sa, dt, Qi, gv, orc.RK4_TABLEAU if method == "RK4" else orc.PD_TABLEAU)
+    got = np.concatenate([Xn.Rsb.reshape(-1), Xn.Tsb, Xn.Vsb])
+    assert np.abs(got - G3[f"step_{k}_{method}_state"]).max() < 1e-13
+    assert rel(Pn[:23, :], G3[f"step_{k}_{method}_Prows"]) < 1e-13 and np.array_equal(Pn[23:, 23:], P[23:, 23:])
