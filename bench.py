@@ -47,15 +47,27 @@ def cpu_baseline(N, F, seconds=12.0):
     from xivo_amd import synth
     P, H, inn, dR = synth.s_level(N, F, 2, seed=12345)
     M = 2 * F
+    ref, extracted = None, False
     try:
         import ref_binding
-        ref = ref_binding.load()
+        try:      # the reference's own text of UpdateJosephForm, compiled (round 4: oracle/ref/extract_reference.py + xivo_refx.cpp)
+            ref = ref_binding.loadx(203); extracted = True
+        except Exception:
+            ref = ref_binding.load()
     except Exception:
         ref = None
     if ref is not None:
         fn = lambda b: ref.update_joseph(H[b], P[b], inn[b], dR[b])
-        kind, what, cores = "port", "oracle/_ref: Eigen-3.3.9 expression-faithful driver of estimator.cpp:1257-1288, -O3, 1 thread", 1
-        flags = ref_binding.build_flags()
+        if extracted:
+            kind, cores = "reference", 1
+            what = ("oracle/_ref extracted build: the text of Estimator::UpdateJosephForm (src/estimator.cpp:1257-1288) cut out of the "
+                    "reference tree at build time and compiled against its own Eigen 3.3.9 with its own optimisation level (-O3 -DNDEBUG), 1 thread "
+                    "(the reference runs one estimator per thread); bit-identical to the retyped driver")
+            flags = "-O3 -DNDEBUG -march=x86-64-" + ("v4" if ref.path.endswith("_v4.so") else "v3") + \
+                    " (the reference's CMake uses -march=native, which cannot travel to another host CPU)"
+        else:
+            kind, what, cores = "port", "oracle/_ref: Eigen-3.3.9 expression-faithful driver of estimator.cpp:1257-1288, -O3, 1 thread", 1
+            flags = ref_binding.build_flags()
     else:
         import xivo_oracle as orc
         try:
@@ -95,7 +107,10 @@ def _cpu_worker(arg):
     P, H, inn, dR = synth.s_level(N, F, 1, seed=4242)
     try:
         import ref_binding
-        ref = ref_binding.load()
+        try:
+            ref = ref_binding.loadx(203)
+        except Exception:
+            ref = ref_binding.load()
         fn = lambda: ref.update_joseph(H[0], P[0], inn[0], dR[0])
     except Exception:
         import xivo_oracle as orc
@@ -229,7 +244,10 @@ def dropin_block(shapes=((203, 30), (250, 80)), n_calls=300):
     host = C.CDLL(os.path.join(ROOT, "xivo_amd", "libxivo_host.so"))
     try:
         import ref_binding
-        ref = ref_binding.load()
+        try:
+            ref = ref_binding.loadx(203)       # the reference's own text of UpdateJosephForm, compiled (any N: dynamic members)
+        except Exception:
+            ref = ref_binding.load()
     except Exception:
         ref = None
     p = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -261,7 +279,8 @@ def dropin_block(shapes=((203, 30), (250, 80)), n_calls=300):
             for _ in range(n_ref):
                 t0 = time.perf_counter(); ref.update_joseph(H[0], P[0], inn[0], dR[0]); t.append(time.perf_counter() - t0)
             row["cpu_ref_ms_per_update"] = float(np.median(t) * 1e3)
-            row["cpu_ref"] = f"oracle/_ref (Eigen 3.3.9, 1 thread), median of {n_ref} calls on this host"
+            row["cpu_ref"] = (f"oracle/_ref ({'extracted text of src/estimator.cpp:1257-1288' if isinstance(ref, ref_binding.RefX) else 'retyped driver'}, "
+                              f"Eigen 3.3.9, 1 thread), median of {n_ref} calls on this host")
             if row.get("ms_per_update"):
                 row["speedup_vs_cpu_ref"] = row["cpu_ref_ms_per_update"] / row["ms_per_update"]
         out.append(row)
