@@ -34,6 +34,34 @@
 #define XIVO_ABL 0
 #endif
 
+// XIVO_TRACE (scripts/build_variant.sh trace "-DXIVO_TRACE=1"; scripts/trace_solve.py reads it back): shader-clock stamps inside
+// trsm_lds_f64_kernel<., 4> of every 64th workgroup - wave 0 at the phase boundaries of the kernel (XTR / XTRP), every wave
+// inside the product phases (XTR2: behind the fix-up, behind each tile's MFMA chain, behind each tile's stores). Timing
+// only, results unchanged; compiled out by default. Where the kernel's time goes: DESIGN.md 3.0.
+#ifndef XIVO_TRACE
+#define XIVO_TRACE 0
+#endif
+#if XIVO_TRACE
+__device__ unsigned long long xivo_trace_buf[512 * 32];
+__device__ unsigned long long xivo_trace2_buf[128 * 16 * 4 * 16];   // [workgroup][wave][phase][slot]
+#define XTR(i) do { if (T4 && !WOUT && threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 512) \
+    xivo_trace_buf[(blockIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XTRP(i) do { if (FIXUP && threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 512) \
+    xivo_trace_buf[(blockIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XTR2(ph, slot) do { if (FIXUP && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 128 && (ph) < 4 && (slot) < 16) \
+    xivo_trace2_buf[(((blockIdx.x >> 6) * 16 + (threadIdx.x >> 6)) * 4 + (ph)) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int xivo_hip_debug_read_trace(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xivo_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+extern "C" int xivo_hip_debug_read_trace2(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xivo_trace2_buf), (size_t)n * sizeof(unsigned long long));
+}
+#else
+#define XTR(i) do {} while (0)
+#define XTRP(i) do {} while (0)
+#define XTR2(ph, slot) do {} while (0)
+#endif
+
 namespace xivo_hip {
 
 namespace {
@@ -254,11 +282,16 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
   d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
   if (todo) load_m(__builtin_ctz(todo), nxt);
   for (int p = 0; p < nph; ++p) {
+    XTRP(8 + 3 * p);
     if (XIVO_ABL == 9) lds_barrier();
     else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XTRP(9 + 3 * p);
     __syncthreads();                               // phase p landed for every wave; the other buffer is free again
     }
+    XTRP(10 + 3 * p);
+    XTR2(p, 0);
+    int tslot = 2;
     const int jb0 = p * jbp;
     const double* buf = sL + (p & 1) * bufsz;
     if (FIXUP && XIVO_ABL != 3) {
@@ -274,6 +307,7 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
       }
       lds_barrier();
     }
+    XTR2(p, 1);
     bool fetch = p + 1 < nph;                      // phase p + 1 is requested once the first tile has its -Minit (so that
     while (todo) {                                 // the wait on those loads does not sit behind the new requests)
       const int jl = __builtin_ctz(todo);
@@ -300,6 +334,7 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
           }
         }
       }
+      XTR2(p, tslot); ++tslot;
       const int ba = jb <= w ? w : jb, bbk = jb <= w ? jb : w;
       const int a = 16 * ba + li, b = 16 * bbk + lg;
 #pragma unroll
@@ -311,11 +346,14 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
           if (a != bb) buf_st(v, rO, vOt, (unsigned)(16 * bbk + 4 * r + 16 * ba * ldo) * 8u);
         }
       }
+      XTR2(p, tslot); ++tslot;
     }
+    XTR2(p, 14);
     if (fetch) issue(p + 1);
     todo = my_tiles(p + 1);
     if (todo) load_m((p + 1) * jbp + __builtin_ctz(todo), nxt);
   }
+  XTRP(8 + 3 * nph);
 }
 
 // TF: the workgroup goes on to form T = K (HP) - P (estimator.cpp:1280, the left product distributed over
@@ -350,6 +388,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   const double* __restrict__ PHT = g.PHT + (long)filt * g.stridePHT;
   const long ld = g.ldlu;
 
+  XTR(0);
   // the right-hand sides first: their loads are in flight while the factor is copied (one workgroup per CU - nothing else
   // would hide the latency of either)
   const int c0 = chunk * 256 + wave * 16;
@@ -442,7 +481,9 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       sL[(k * (k + 1) / 2 + k) * BLK + 16 + 17 * c] = LU[(16 * k + c) + (long)(16 * k + c) * ld];
     }
   }
+  XTR(1);
   __syncthreads();
+  XTR(2);
   if (!TF && !live) return;
 
   if (live) {
@@ -471,6 +512,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       }
     }
   }
+  XTR(3);
   double part = 0.0;
   if (KEEPW) {
 #pragma unroll
@@ -487,6 +529,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       }
     }
   }
+  XTR(4);
   // backward: L^T K^T = Y
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
@@ -640,7 +683,9 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   }
   if (!TF) return;
 
+  XTR(5);
   __syncthreads();                                 // the factor is dead: the LDS takes the operands
+  XTR(6);
   if (TF == 3) {
     // ---- P+ = P - Z^T K^T in place: rows of Z^T in registers, blocks of the gain just written arrive through LDS
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
