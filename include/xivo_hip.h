@@ -290,6 +290,38 @@ int xivo_hip_set_scene(xivo_hip_ctx* ctx, int b0, int nb, int F,
 int xivo_hip_jacobians_instate(xivo_hip_ctx* ctx, int B);
 /* compact per-feature result: J blocks 2x21 ([Wsb Tsb Wbc Tbc Wg Tg x], row-major 2 x 21) + inn (2) */
 int xivo_hip_get_jacobians(xivo_hip_ctx* ctx, int b0, int nb, double* J2x21, double* inn2);
+/* ---- online-calibration builds (measurement side) ---------------------------------------------------------------
+ * The reference's USE_ONLINE_TEMPORAL_CALIB / USE_ONLINE_IMU_CALIB / USE_ONLINE_CAMERA_CALIB builds (src/CMakeLists.txt:13-15)
+ * put a camera-IMU time offset td, the gyro calibration Cg (9) / accel calibration Ca (6) and up to 9 camera intrinsics
+ * into the state (src/core.h:49-83) and give Feature::ComputeJacobian four more blocks (src/feature.cpp:592-609, :611-618,
+ * :632-651): d/dtd (2 x 1), d/dCg (2 x 9), d/dbg (2 x 3, at Index::bg) and d/d(intrinsics) (2 x Camera::dim()), which
+ * Feature::FillJacobianBlock stacks as well (:664-670, :679-683). xivo_hip_set_calib switches those blocks on for the
+ * context: xivo_hip_jacobians_instate then also fills them (xivo_hip_get_jacobians_calib), xivo_hip_stack /
+ * xivo_hip_filter_update stack them - as dense rows: such a row pair has up to 34 columns that every feature shares, more
+ * than the 16 common slots of the row-pair compressed form - and gate / update through the dense pipeline, whose MH gating
+ * uses the whole row as the reference's f->J() does. Slots as the reference's Index enum / kCameraBegin would number them
+ * (the caller's xivo_layout already counts them in N, group_begin, feature_begin); -1 / 0 = that block is not in the build.
+ * NOT covered: the motion-side blocks of those builds (Cg / Ca columns of the motion Jacobian, src/estimator.cpp:674-688,
+ * a 24..39-dimensional motion state in xivo_hip_propagate) and the retraction of td / Cg / Ca / the intrinsics in
+ * xivo_hip_absorb_error - the caller absorbs those components of dx on the host (src/estimator.cpp:879-889). */
+typedef struct {
+  int td;         /* Index::td, or -1 (no USE_ONLINE_TEMPORAL_CALIB: then neither the td, nor the Cg, nor the bg block exists) */
+  int Cg;         /* Index::Cg (9 columns), or -1 (no USE_ONLINE_IMU_CALIB); needs td >= 0                                   */
+  int cam_begin;  /* kCameraBegin                                                                                              */
+  int cam_dim;    /* Camera::dim(): 4 pinhole (fx fy cx cy), 5 atan (+ w), 9 radtan (+ p1 p2 k1 k2 k3), 8 equidistant
+                     (+ k0..k3); 0 = no USE_ONLINE_CAMERA_CALIB                                                               */
+} xivo_calib_layout;
+typedef struct {   /* per filter, what Estimator::ComputeInstateJacobians hands down (src/update.cpp:27-28) */
+  double gyro[3];  /* last_gyro_ (raw measurement)        */
+  double Cg[9];    /* imu_.Cg(), column-major             */
+  double td;       /* X_.td                               */
+} xivo_calib_in;
+/* layout == NULL switches the calibration blocks off again (default build) */
+int xivo_hip_set_calib(xivo_hip_ctx* ctx, const xivo_calib_layout* layout);
+int xivo_hip_set_calib_state(xivo_hip_ctx* ctx, int b0, int nb, const xivo_calib_in* calib /* nb */);
+/* the calibration blocks of the last xivo_hip_jacobians_instate, per feature 2 x 22 row-major:
+ * [ td (1) | Cg (9) | bg (3) | intrinsics (9, the first cam_dim in use) ]; blocks that are switched off read 0 */
+int xivo_hip_get_jacobians_calib(xivo_hip_ctx* ctx, int b0, int nb, double* Jc2x22);
 /* Estimator::MHGating (src/update.cpp:50-116) on the compact Jacobians (full
  * J row, as the reference gates with f->J()). */
 int xivo_hip_mh_gate(xivo_hip_ctx* ctx, int B, double R, double mh_thresh, double mh_mult,

@@ -28,6 +28,9 @@ PIECES = [
     ("absorb_error_vec", "src/estimator.cpp", r"^void Estimator::AbsorbError\(const VecX &err\) \{", "block"),
     ("absorb_error", "src/estimator.cpp", r"^void Estimator::AbsorbError\(\) \{", "block"),
     ("so3xr3", "src/group.h", r"^struct SO3xR3 \{", "block"),
+    ("jacobian_cache", "src/jac.h", r"^struct JacobianCache \{", "block"),
+    ("feature_xc", "src/feature.cpp", r"^Vec3 Feature::Xc\(Mat3 \*J\) \{", "block"),
+    ("compute_jacobian", "src/feature.cpp", r"^void Feature::ComputeJacobian\(", "block"),
     ("fill_jacobian_block", "src/feature.cpp", r"^void Feature::FillJacobianBlock\(", "block"),
 ]
 

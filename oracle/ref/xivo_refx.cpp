@@ -26,13 +26,41 @@
 
 #include "Eigen/Cholesky"
 #include "Eigen/Sparse"
+#include "camera_atan.h"
+#include "camera_equidist.h"
+#include "camera_pinhole.h"
+#include "camera_radtan.h"
+#include "project.h"     // project, unproject_logz (common/project.h)
 #include "rodrigues.h"   // dAB_dA, dAB_dB, dA_dAu (common/rodrigues.h)
 
 namespace xivo {
 
+// stand-in for CameraManager (src/camera_manager.h:25-118 needs jsoncpp + glog to construct): the same dispatch onto the
+// reference's own camera classes, configured by the extern "C" wrappers below
+struct RefCamCfg { int model; int rows, cols; double fx, fy, cx, cy; double d[5]; };
+class Camera {
+ public:
+  static Camera* instance() { static Camera c; return &c; }
+  RefCamCfg cfg{0, 480, 640, 500, 500, 320, 240, {0, 0, 0, 0, 0}};
+  int dim() const { return cfg.model == 0 ? 4 : (cfg.model == 1 ? 5 : (cfg.model == 2 ? 9 : 8)); }
+  template <typename Derived>
+  Eigen::Matrix<typename Derived::Scalar, 2, 1> Project(const Eigen::MatrixBase<Derived>& xc, Eigen::Matrix<typename Derived::Scalar, 2, 2>* jac = nullptr,
+                                                        Eigen::Matrix<typename Derived::Scalar, 2, -1>* jacc = nullptr) const {
+    const RefCamCfg& c = cfg;
+    switch (c.model) {   // src/camera_manager.h:33-49
+      case 0: return PinholeCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy).Project(xc, jac, jacc);
+      case 1: return ATANCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy, c.d[0]).Project(xc, jac, jacc);
+      case 2: return RadialTangentialCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy, c.d[0], c.d[1], c.d[2], c.d[3], c.d[4]).Project(xc, jac, jacc);
+      default: return EquidistantCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy, c.d[0], c.d[1], c.d[2], c.d[3]).Project(xc, jac, jacc);
+    }
+  }
+  template <class V> void UpdateState(const V&) {}   // (src/estimator.cpp:888: the intrinsics live in the camera object; not modelled)
+};
+
 #include "extracted/core_index_state.inc"
 #include "extracted/feature_status.inc"
 #include "extracted/so3xr3.inc"
+#include "extracted/jacobian_cache.inc"
 
 using Vec6 = Eigen::Matrix<number_t, 6, 1>;
 
@@ -40,6 +68,8 @@ class RefGroup {   // the members of Group (src/group.h:41-107) the extracted bo
  public:
   int id() const { return id_; }
   int sind() const { return sind_; }
+  const SO3& Rsb() const { return X_.Rsb; }        // src/group.h:66-67
+  const Vec3& Tsb() const { return X_.Tsb; }
   void UpdateState(const Vec6& dX) { X_ += dX; }   // src/group.h:75
   int id_ = 0, sind_ = -1;
   SO3xR3 X_;
@@ -58,16 +88,27 @@ class RefFeature {   // the members of Feature (src/feature.h:74-284) the extrac
   GroupPtr ref() const { return ref_; }
   void UpdateState(const Vec3& dx) { x_ += dx; }                          // src/feature.h:220
   void FillJacobianBlock(MatX& H, int offset);                            // src/feature.cpp:658-684 (extracted below)
+  void ComputeJacobian(const Mat3& Rsb, const Vec3& Tsb, const Mat3& Rbc, const Vec3& Tbc, const Vec3& gyro, const Mat3& Cg,
+                       const Vec3& bg, const Vec3& Vsb, number_t td);    // src/feature.cpp:542-656 (extracted below)
+  Vec3 Xc(Mat3* J = nullptr);                                             // src/feature.cpp:98-105 (extracted below)
+  const Vec2& back() const { return back_; }                              // (the last tracked pixel, src/feature.h)
+  static JacobianCache cache_;                                            // src/feature.h / feature.cpp:20: process-wide static
   Eigen::Matrix<number_t, 2, kFullSize> J_;                               // src/feature.h:281
-  Vec2 inn_;
-  Vec3 x_;
+  Vec2 inn_, back_;
+  Vec3 x_, Xc_;
   FeatureStatus status_ = FeatureStatus::INSTATE;
   int id_ = 0, sind_ = -1;
   GroupPtr ref_ = nullptr;
 };
 using FeaturePtr = RefFeature*;
 
-struct RefImu { Mat3 Ca_ = Mat3::Identity(), Cg_ = Mat3::Identity(); const Mat3& Ca() const { return Ca_; } const Mat3& Cg() const { return Cg_; } };
+JacobianCache RefFeature::cache_;
+struct RefImu {
+  Mat3 Ca_ = Mat3::Identity(), Cg_ = Mat3::Identity();
+  const Mat3& Ca() const { return Ca_; }
+  const Mat3& Cg() const { return Cg_; }
+  template <class V> void UpdateState(const V&) {}   // (src/estimator.cpp:883: Ca / Cg live in the IMU object; not modelled)
+};
 struct RefTimer { void Tick(const char*) {} void Tock(const char*) {} };
 
 class RefEstimator {   // the members of Estimator (src/estimator.h:387-575) the extracted bodies touch, same names and types
@@ -107,6 +148,8 @@ class RefEstimator {   // the members of Estimator (src/estimator.h:387-575) the
 #include "extracted/update_joseph_form.inc"
 #include "extracted/mh_gating.inc"
 #include "extracted/fill_jacobian_block.inc"
+#include "extracted/feature_xc.inc"
+#include "extracted/compute_jacobian.inc"
 #include "extracted/filter_update.inc"
 #include "extracted/absorb_error_vec.inc"
 #include "extracted/absorb_error.inc"
@@ -142,6 +185,46 @@ void store_state(const State& X, double* s) {
 extern "C" {
 
 int refx_full_size(void) { return kFullSize; }
+int refx_motion_size(void) { return kMotionSize; }
+// slots of the online-calibration builds as the extracted enum Index numbers them (-1 / 0: not in this build)
+int refx_index_td(void) {
+#ifdef USE_ONLINE_TEMPORAL_CALIB
+  return Index::td;
+#else
+  return -1;
+#endif
+}
+int refx_index_Cg(void) {
+#ifdef USE_ONLINE_IMU_CALIB
+  return Index::Cg;
+#else
+  return -1;
+#endif
+}
+int refx_camera_begin(void) { return kCameraBegin; }
+int refx_max_camera_intrinsics(void) { return kMaxCameraIntrinsics; }
+
+// Feature::ComputeJacobian + Feature::FillJacobianBlock as extracted, in whatever build this library is (default, or the
+// online-calibration defines). 3 x 3 inputs column-major. Outputs: J (2 x kFullSize column-major), inn (2), and the two rows
+// FillJacobianBlock stacks from it (Hrow, 2 x kFullSize column-major).
+void refx_compute_jacobian(const double* x, const double* xp_meas, const double* Rsbr, const double* Tsbr, const double* Rsb,
+                           const double* Tsb, const double* Rbc, const double* Tbc, const double* gyro, const double* Cg,
+                           const double* bg, const double* Vsb, double td, const RefCamCfg* cam, int ref_sind, int sind,
+                           double* J_out, double* inn_out, double* Hrow_out) {
+  Camera::instance()->cfg = *cam;
+  RefGroup g; g.sind_ = ref_sind;
+  g.X_.Rsb = SO3(Eigen::Quaterniond(Mat3(Eigen::Map<const Mat3>(Rsbr)))); g.X_.Tsb = Eigen::Map<const Vec3>(Tsbr);
+  RefFeature f; f.ref_ = &g; f.sind_ = sind;
+  f.x_ = Eigen::Map<const Vec3>(x); f.back_ = Eigen::Map<const Vec2>(xp_meas);
+  const Mat3 Rsb_ = Eigen::Map<const Mat3>(Rsb), Rbc_ = Eigen::Map<const Mat3>(Rbc), Cg_ = Eigen::Map<const Mat3>(Cg);
+  f.ComputeJacobian(Rsb_, Eigen::Map<const Vec3>(Tsb), Rbc_, Eigen::Map<const Vec3>(Tbc), Eigen::Map<const Vec3>(gyro), Cg_,
+                    Eigen::Map<const Vec3>(bg), Eigen::Map<const Vec3>(Vsb), td);
+  (Eigen::Map<Eigen::Matrix<number_t, 2, kFullSize>>(J_out)) = f.J();
+  inn_out[0] = f.inn()(0); inn_out[1] = f.inn()(1);
+  MatX H = MatX::Zero(2, kFullSize);
+  f.FillJacobianBlock(H, 0);
+  (MapMatW(Hrow_out, 2, kFullSize)) = H;
+}
 int refx_group_begin(void) { return kGroupBegin; }
 int refx_feature_begin(void) { return kFeatureBegin; }
 

@@ -262,6 +262,29 @@ class RefX:
         return (np.ascontiguousarray(H), err, np.ascontiguousarray(Pf), st[0:9].reshape(3, 3).T.copy(), st[9:12].copy(), st[12:15].copy(),
                 st[15:18].copy(), st[18:21].copy(), st[21:30].reshape(3, 3).T.copy(), xs)
 
+    def calib_slots(self):
+        """(td, Cg, cam_begin, max camera intrinsics, kMotionSize) of this build as the extracted enum Index numbers them"""
+        for f in ("refx_index_td", "refx_index_Cg", "refx_camera_begin", "refx_max_camera_intrinsics", "refx_motion_size"):
+            getattr(self.lib, f).restype = C.c_int
+        return (self.lib.refx_index_td(), self.lib.refx_index_Cg(), self.lib.refx_camera_begin(),
+                self.lib.refx_max_camera_intrinsics(), self.lib.refx_motion_size())
+
+    def compute_jacobian(self, x, xp_meas, Rsbr, Tsbr, Rsb, Tsb, Rbc, Tbc, cam, ref_sind, sind, gyro=(0, 0, 0), Cg=None,
+                         bg=(0, 0, 0), Vsb=(0, 0, 0), td=0.0):
+        """Feature::ComputeJacobian + FillJacobianBlock as extracted (this library's build: default or online calibration).
+        Returns (J [2, N], inn [2], the two stacked rows [2, N])."""
+        N = self.N
+        J = np.zeros((2, N), order="F"); inn = np.zeros(2); Hrow = np.zeros((2, N), order="F")
+        v = lambda a: _p(np.ascontiguousarray(a, dtype=np.float64))
+        Cgm = np.eye(3) if Cg is None else np.asarray(Cg, float)
+        c = _cam(cam)
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, xp_meas, Tsbr, Tsb, Tbc, gyro, bg, Vsb)]
+        mats = [_F(Rsbr), _F(Rsb), _F(Rbc), _F(Cgm)]
+        self.lib.refx_compute_jacobian(_p(keep[0]), _p(keep[1]), _p(mats[0]), _p(keep[2]), _p(mats[1]), _p(keep[3]), _p(mats[2]),
+                                       _p(keep[4]), _p(keep[5]), _p(mats[3]), _p(keep[6]), _p(keep[7]), C.c_double(td), C.byref(c),
+                                       C.c_int(int(ref_sind)), C.c_int(int(sind)), _p(J), _p(inn), _p(Hrow))
+        return np.ascontiguousarray(J), inn, np.ascontiguousarray(Hrow)
+
     def integrator_step(self, method, X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec):
         """Estimator::RK4Step / PrinceDormandStep as extracted. Returns (Rsb, Tsb, Vsb, P_new)."""
         assert P.shape[0] == self.N
@@ -278,11 +301,12 @@ _REFX = {}
 
 
 def loadx(N=203):
-    """The extracted-text library compiled for state size N (203 or 251); raises FileNotFoundError if it was never built."""
+    """The extracted-text library compiled for state size N (203 or 251), or N = "calib": the default sizes with the
+    reference's three online-calibration defines (N = 228); raises FileNotFoundError if it was never built."""
     if N in _REFX:
         return _REFX[N]
     for v in (("v4", "v3") if _has_avx512() else ("v3",)):
-        path = os.path.join(_HERE, "_ref", f"libxivo_refx_n{N}_{v}.so")
+        path = os.path.join(_HERE, "_ref", f"libxivo_refx_calib_{v}.so" if N == "calib" else f"libxivo_refx_n{N}_{v}.so")
         if os.path.exists(path):
             _REFX[N] = RefX(path)
             return _REFX[N]

@@ -37,7 +37,10 @@ K_MOTION = 23
 class Layout:
     """kGroupBegin / kFeatureBegin / kFullSize (src/core.h:87-105) as run-time values."""
 
-    def __init__(self, n_groups, n_features, N=None, group_begin=K_MOTION):
+    def __init__(self, n_groups, n_features, N=None, group_begin=K_MOTION, td=-1, Cg=-1, cam_begin=0, cam_dim=0):
+        # online-calibration builds (src/core.h:49-83): slots of td / Cg (Ca follows Cg) / the camera intrinsics, -1 / 0 = absent;
+        # calib_layout() below derives them and group_begin the way the reference's Index enum does
+        self.td, self.Cg, self.cam_begin, self.cam_dim = td, Cg, cam_begin, cam_dim
         self.group_begin = group_begin
         self.n_groups = n_groups
         self.feature_begin = group_begin + 6 * n_groups
@@ -45,6 +48,22 @@ class Layout:
         full = self.feature_begin + 3 * n_features
         self.N = full if N is None else N   # N > full: trailing zero slots (estimator.cpp:757-759)
         assert self.N >= full
+
+
+def calib_layout(n_groups, n_features, temporal=True, imu=True, camera_dim=9):
+    """Layout of an online-calibration build exactly as src/core.h:40-105 numbers it: Index::td = Wsg + 2 (temporal),
+    Cg = td + 1 (or Wsg + 2), Ca = Cg + 9, End = kMotionSize; kCameraBegin = kMotionSize, kMaxCameraIntrinsics = 9 with
+    USE_ONLINE_CAMERA_CALIB (camera_dim = Camera::dim() of the model: the slots in use), kGroupBegin behind them."""
+    nxt = WSG + 2
+    td = Cg = -1
+    if temporal:
+        td = nxt; nxt += 1
+    if imu:
+        Cg = nxt; nxt += 15
+    motion = nxt
+    cam_begin = motion
+    group_begin = motion + (9 if camera_dim > 0 else 0)
+    return Layout(n_groups, n_features, group_begin=group_begin, td=td, Cg=Cg, cam_begin=cam_begin, cam_dim=camera_dim)
 
 
 # ----------------------------------------------------------------------------
@@ -259,6 +278,60 @@ def camera_project(cam, xc):
     raise ValueError("unknown camera model")
 
 
+def camera_project_jacc(cam, xc):
+    """d(xp)/d(intrinsics) of the USE_ONLINE_CAMERA_CALIB builds, [2, dim] in each model's own parameter order:
+    pinhole fx fy cx cy (camera_pinhole.h:31-35); atan + w (camera_atan.h:62-91); radtan + p1 p2 k1 k2 k3
+    (camera_radtan.h:78-96); equidistant + k0..k3 (camera_equidist.h:80-94)."""
+    fx, fy = cam["fx"], cam["fy"]
+    x, y = float(xc[0]), float(xc[1])
+    model = cam["model"]
+    d = cam.get("d", [])
+    if model == CAM_PINHOLE:
+        return np.array([[x, 0, 1, 0], [0, y, 0, 1.0]])
+    if model == CAM_EQUI:
+        k0, k1, k2, k3 = d[:4]
+        n = math.sqrt(x * x + y * y)
+        th = math.atan2(n, 1.0); phi = math.atan2(y, x)
+        th2 = th * th; th3 = th2 * th; th5 = th3 * th2; th7 = th5 * th2; th9 = th7 * th2
+        r = th + k0 * th3 + k1 * th5 + k2 * th7 + k3 * th9
+        c, s_ = math.cos(phi), math.sin(phi)
+        J = np.zeros((2, 8))
+        J[0, 0] = r * c; J[0, 2] = 1; J[1, 1] = r * s_; J[1, 3] = 1
+        dr_dk = np.array([th3, th5, th7, th9])
+        J[0, 4:] = fx * c * dr_dk; J[1, 4:] = fy * s_ * dr_dk
+        return J
+    if model == CAM_RADTAN:
+        p1, p2, k1, k2, k3 = d[:5]
+        t2 = x * x; t3 = y * y; t6 = p1 * x * 2.0; t7 = p2 * y * 2.0; t8 = t2 * 3.0; t9 = t3 * 3.0
+        t10 = t6 * y; t11 = t7 * x; t12 = t2 + t3; t13 = t3 + t8; t14 = t2 + t9
+        t15 = t12 * t12; t16 = t12 * t12 * t12; t17 = k1 * t12; t18 = k2 * t15; t19 = k3 * t16
+        t20 = p1 * t14; t21 = p2 * t13; t28 = t17 + t18 + t19 + 1.0
+        t29 = t28 * x; t30 = t28 * y; t31 = t10 + t21 + t29; t32 = t11 + t20 + t30
+        J = np.zeros((2, 9))
+        J[0, 0] = t31; J[0, 2] = 1.0; J[0, 4] = fx * x * y * 2.0; J[0, 5] = fx * t13
+        J[0, 6] = fx * t12 * x; J[0, 7] = fx * t15 * x; J[0, 8] = fx * t16 * x
+        J[1, 1] = t32; J[1, 3] = 1.0; J[1, 4] = fy * t14; J[1, 5] = fy * x * y * 2.0
+        J[1, 6] = fy * t12 * y; J[1, 7] = fy * t15 * y; J[1, 8] = fy * t16 * y
+        return J
+    if model == CAM_ATAN:
+        w = d[0]
+        invw = 1.0 / w; w2 = 2.0 * math.tan(w * 0.5)
+        R = math.sqrt(x * x + y * y)
+        J = np.zeros((2, 5))
+        if R < 0.0001 or w == 0:
+            J[0, 0] = x; J[0, 2] = 1; J[1, 1] = y; J[1, 3] = 1
+            return J
+        f = invw * math.atan(w2 * R) / R
+        J[0, 0] = f * x; J[0, 2] = 1; J[1, 1] = f * y; J[1, 3] = 1
+        df_dinvw = math.atan(w2 * R) / R; dinvw_dw = -invw * invw
+        df_datan = invw / R; datan_dw2R = 1 / (1 + (w2 * R) * (w2 * R)); dw2R_dw2 = R
+        dw2_dw = (1 / math.cos(w * 0.5)) ** 2
+        df_dw = df_dinvw * dinvw_dw + df_datan * datan_dw2R * dw2R_dw2 * dw2_dw
+        J[0, 4] = fx * x * df_dw; J[1, 4] = fy * y * df_dw
+        return J
+    raise ValueError("unknown camera model")
+
+
 def project(Xc):
     """common/project.h:11-24"""
     X, Y, Z = Xc
@@ -275,8 +348,10 @@ def unproject_logz(x):
 # a4: Feature::ComputeJacobian (src/feature.cpp:542-656)
 # ----------------------------------------------------------------------------
 def compute_jacobian(x, xp_meas, Rsbr, Tsbr, Rsb, Tsb, Rbc, Tbc, cam, layout, ref_sind, sind,
-                     return_cache=False):
-    """Returns (J [2 x N], inn [2], blocks [7,2,3]) for one in-state feature."""
+                     return_cache=False, calib=None):
+    """Returns (J [2 x N], inn [2], blocks [7,2,3]) for one in-state feature.
+    calib = dict(gyro, Cg, bg, Vsb, td) with a layout from calib_layout(): the online-calibration builds' blocks as well
+    (src/feature.cpp:592-609, :611-618, :632-651); then also returns Jc [2, 22] = [td | Cg 9 | bg 3 | intrinsics 9] last."""
     Rsb_t, Rbc_t = Rsb.T, Rbc.T
     Xc, dXc_dx = unproject_logz(x)                       # :555 (Xc(&cache_.dXc_dx), feature.cpp:98-105)
     Xbr = Rbc @ Xc + Tbc                                 # :556
@@ -311,6 +386,29 @@ def compute_jacobian(x, xp_meas, Rsbr, Tsbr, Rsb, Tsb, Rbc, Tbc, cam, layout, re
     for b, off in enumerate([WSB, TSB, WBC, TBC, goff, goff + 3, foff]):
         J[:, off:off + 3] = blocks[b]
     inn = np.asarray(xp_meas, dtype=np.float64) - xp     # :654
+    if calib is not None:
+        Jc = np.zeros((2, 22))
+        if layout.td >= 0:
+            gyro = np.asarray(calib["gyro"], float); Cg = np.asarray(calib["Cg"], float)
+            gyro_calib = Cg @ gyro - np.asarray(calib["bg"], float)                             # :593
+            dXcn_dtd = -Rbc_t @ (hat(gyro_calib) @ Rsb_t @ (Xs - Tsb) + Rsb_t @ np.asarray(calib["Vsb"], float))   # :594-595
+            dXcn_dW = Rbc_t @ hat(Rsb_t @ (Xs - Tsb)) * calib["td"]                             # :598-599 (dAB_dB<3,1>(A) = A)
+            J[:, layout.td] = dxp_dXcn @ dXcn_dtd                                               # :632
+            Jc[:, 0] = J[:, layout.td]
+            if layout.Cg >= 0:
+                dW_dCg = np.zeros((3, 9))
+                for i in range(3):
+                    dW_dCg[i, 3 * i:3 * i + 3] = gyro                                           # :601-604
+                J[:, layout.Cg:layout.Cg + 9] = dxp_dXcn @ (dXcn_dW @ dW_dCg)                   # :605, :634
+                Jc[:, 1:10] = J[:, layout.Cg:layout.Cg + 9]
+            J[:, BG:BG + 3] = dxp_dXcn @ (-dXcn_dW)                                             # :607, :636
+            Jc[:, 10:13] = J[:, BG:BG + 3]
+        if layout.cam_dim > 0:
+            jacc = camera_project_jacc(cam, xcn)                                                # :611-614
+            dim = layout.cam_dim
+            J[:, layout.cam_begin:layout.cam_begin + dim] = jacc[:, :dim]                       # :647-651
+            Jc[:, 13:13 + dim] = jacc[:, :dim]
+        return J, inn, blocks, Jc
     if return_cache:
         cache = dict(Xc=Xc, Xbr=Xbr, Xs=Xs, Xb=Xb, Xcn=Xcn, dXcn_dWsb=dXcn_dWsb, dXcn_dTsb=dXcn_dTsb,
                      dXcn_dWbc=dXcn_dWbc, dXcn_dTbc=dXcn_dTbc, dXcn_dWsbr=dXcn_dWsbr,
@@ -334,6 +432,14 @@ def fill_jacobian_block(H, row, J, layout, ref_sind, sind, fix_group_block=False
     else:
         H[row:row + 2, goff:goff + 3] = J[:, goff + 3:goff + 6]      # :676 (the quirk)
     H[row:row + 2, foff:foff + 3] = J[:, foff:foff + 3]              # :677
+    if getattr(layout, "td", -1) >= 0:                               # :664-670 (USE_ONLINE_TEMPORAL_CALIB [+ _IMU_CALIB])
+        H[row:row + 2, layout.td] = J[:, layout.td]
+        if layout.Cg >= 0:
+            H[row:row + 2, layout.Cg:layout.Cg + 9] = J[:, layout.Cg:layout.Cg + 9]
+        H[row:row + 2, BG:BG + 3] = J[:, BG:BG + 3]
+    if getattr(layout, "cam_dim", 0) > 0:                            # :679-683 (USE_ONLINE_CAMERA_CALIB)
+        cb, dim = layout.cam_begin, layout.cam_dim
+        H[row:row + 2, cb:cb + dim] = J[:, cb:cb + dim]
 
 
 def stack_measurements(Js, inns, ref_sinds, sinds, layout, R, fix_group_block=False):

@@ -628,3 +628,62 @@ def test_golden_v3_integrator_steps(k, method):
     got = np.concatenate([Xn.Rsb.reshape(-1), Xn.Tsb, Xn.Vsb])
     assert np.abs(got - G3[f"step_{k}_{method}_state"]).max() < 1e-13
     assert rel(Pn[:23, :], G3[f"step_{k}_{method}_Prows"]) < 1e-13 and np.array_equal(Pn[23:, 23:], P[23:, 23:])
+
+
+# ---- Feature::ComputeJacobian as extracted: default build and the three online-calibration defines ---------------------------
+CAM_DIM = {"pinhole": 4, "atan": 5, "radtan": 9, "equi": 8}
+
+
+def _calib_case(cam, seed, i):
+    """one in-state feature of a 15-group / 30-feature scene + the quantities the calibration blocks need"""
+    sc = synth.g_level(15, 30, 30, 1, seed=seed, cam=cam)
+    rng = np.random.default_rng(1000 * seed + i)
+    r = int(sc["ref"][0][i])
+    cal = dict(gyro=rng.normal(size=3) * 0.5, Cg=np.eye(3) + 0.01 * rng.normal(size=(3, 3)), bg=rng.normal(size=3) * 0.01,
+               Vsb=rng.normal(size=3), td=0.013)
+    xp = np.array([300.0, 200.0]) + rng.normal(size=2) * 20
+    args = (sc["x"][0][i], xp, sc["gR"][0][r], sc["gT"][0][r], sc["Rsb"][0], sc["Tsb"][0], sc["Rbc"][0], sc["Tbc"][0])
+    return args, r, int(sc["sind"][0][i]), cal
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_extracted_compute_jacobian_default_build(name):
+    """Feature::ComputeJacobian + FillJacobianBlock, the TEXT of src/feature.cpp:542-684 compiled in the default build, vs
+    the oracle: J, inn and the stacked rows (incl. the :675-676 overwrite) - this pins a4 to the reference itself."""
+    x = _refx(203)
+    lay = orc.Layout(15, 30)
+    worst = 0.0
+    for i in range(0, 30, 3):
+        args, r, sind, cal = _calib_case(CAMS[name], 5, i)
+        J, inn, _ = orc.compute_jacobian(*args, CAMS[name], lay, r, sind)
+        Jx, innx, Hx = x.compute_jacobian(*args, CAMS[name], r, sind, gyro=cal["gyro"], Cg=cal["Cg"], bg=cal["bg"], Vsb=cal["Vsb"], td=cal["td"])
+        H = np.zeros((2, lay.N)); orc.fill_jacobian_block(H, 0, J, lay, r, sind)
+        worst = max(worst, np.abs(J - Jx).max() / np.abs(Jx).max(), np.abs(inn - innx).max(), np.abs(H - Hx).max() / np.abs(Hx).max())
+    assert worst < 1e-12
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_extracted_compute_jacobian_online_calibration_build(name):
+    """The same text compiled with -DUSE_ONLINE_TEMPORAL_CALIB -DUSE_ONLINE_IMU_CALIB -DUSE_ONLINE_CAMERA_CALIB
+    (src/CMakeLists.txt:13-15): kMotionSize 39, N = 228; the extracted enum Index gives the slots, the oracle's calib_layout
+    derives the same ones; the td / Cg / bg / intrinsics blocks of J and of the stacked rows agree to 1e-12."""
+    try:
+        import ref_binding
+        x = ref_binding.loadx("calib")
+    except (FileNotFoundError, OSError):
+        pytest.skip("oracle/_ref calibration build not built")
+    lay = orc.calib_layout(15, 30, True, True, CAM_DIM[name])
+    td, Cg, cam_begin, max_cam, motion = x.calib_slots()
+    assert (lay.N, lay.group_begin, lay.feature_begin, lay.td, lay.Cg, lay.cam_begin) == (x.N, x.group_begin, x.feature_begin, td, Cg, cam_begin)
+    assert (max_cam, motion) == (9, 39)
+    worst = 0.0
+    for i in range(0, 30, 3):
+        args, r, sind, cal = _calib_case(CAMS[name], 7, i)
+        J, inn, _, Jc = orc.compute_jacobian(*args, CAMS[name], lay, r, sind, calib=cal)
+        Jx, innx, Hx = x.compute_jacobian(*args, CAMS[name], r, sind, gyro=cal["gyro"], Cg=cal["Cg"], bg=cal["bg"], Vsb=cal["Vsb"], td=cal["td"])
+        H = np.zeros((2, lay.N)); orc.fill_jacobian_block(H, 0, J, lay, r, sind)
+        worst = max(worst, np.abs(J - Jx).max() / np.abs(Jx).max(), np.abs(inn - innx).max(), np.abs(H - Hx).max() / np.abs(Hx).max())
+        assert np.abs(Jx[:, td]).max() > 0 and np.abs(Jx[:, Cg:Cg + 9]).max() > 0 and np.abs(Jx[:, 9:12]).max() > 0
+        assert (np.abs(Jx[:, cam_begin:cam_begin + 9]).sum(0) > 0).sum() == CAM_DIM[name]
+        assert np.array_equal(Jc[:, 0], J[:, td]) and np.array_equal(Jc[:, 13:13 + CAM_DIM[name]], J[:, cam_begin:cam_begin + CAM_DIM[name]])
+    assert worst < 1e-12

@@ -69,6 +69,11 @@ struct xivo_hip_ctx {
   xivo_layout lay{};
   xivo_cam cam{};
   bool have_layout = false;
+  // online-calibration builds, measurement side (xivo_hip_set_calib): extra Jacobian blocks, dense stacking
+  bool calib_on = false;
+  xivo_calib_layout cl{-1, -1, 0, 0};
+  xivo_calib_in* calib = nullptr;   // [Bmax]
+  double* Jc = nullptr;             // [Bmax x Fmax x 44]
   int Fmax = 0, F = 0;
   xivo_pose_in* poses = nullptr;
   int* absorb_count = nullptr;   // State::counter of every filter (src/core.h:120-122)
@@ -183,6 +188,8 @@ SceneBuffers scene_buffers(xivo_hip_ctx* c) {
   sb.poses = c->poses; sb.groups = c->groups; sb.feats = c->feats;
   sb.J = c->J; sb.finn = c->finn; sb.mask = c->mask; sb.dist = c->dist;
   sb.Fmax = c->Fmax; sb.F = c->F;
+  sb.calib = c->calib_on ? c->calib : nullptr; sb.Jc = c->calib_on ? c->Jc : nullptr; sb.cl = c->cl;
+  if (!c->calib_on) sb.cl = xivo_calib_layout{-1, -1, 0, 0};
   return sb;
 }
 
@@ -331,7 +338,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
-                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->tune_status, c->ldlt_used};
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->tune_status, c->ldlt_used, c->calib, c->Jc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
   if (c->pin_h) hipHostFree(c->pin_h);
@@ -1316,15 +1323,16 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
 static int ensure_gate_buffers(xivo_hip_ctx* c, int F) {
   if (F <= c->Fmax && c->mask) return XIVO_HIP_OK;
   const int Fm = F > c->Mpmax / 2 ? F : c->Mpmax / 2;
-  void* olds[] = {c->feats, c->J, c->finn, c->dist, c->mask};
+  void* olds[] = {c->feats, c->J, c->finn, c->dist, c->mask, c->Jc};
   for (void* p : olds) if (p) hipFree(p);
-  c->feats = nullptr; c->J = nullptr; c->finn = nullptr; c->dist = nullptr; c->mask = nullptr;
+  c->feats = nullptr; c->J = nullptr; c->finn = nullptr; c->dist = nullptr; c->mask = nullptr; c->Jc = nullptr;
   const size_t B = c->Bmax;
   int rc = dev_alloc(&c->feats, B * Fm);
   if (!rc) rc = dev_alloc(&c->J, B * Fm * 42);
   if (!rc) rc = dev_alloc(&c->finn, B * Fm * 2);
   if (!rc) rc = dev_alloc(&c->dist, B * Fm);
   if (!rc) rc = dev_alloc(&c->mask, B * Fm);
+  if (!rc && c->calib_on) rc = dev_alloc(&c->Jc, B * Fm * 44);
   if (!rc && !c->rows_instate) rc = dev_alloc(&c->rows_instate, B);
   // every entry starts absent (sind = -1) and masked out until a scene / edit writes it
   if (!rc && hipMemsetAsync(c->feats, 0xFF, B * Fm * sizeof(xivo_feat_in), c->stream) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
@@ -1437,6 +1445,38 @@ int xivo_hip_get_jacobians(xivo_hip_ctx* c, int b0, int nb, double* J, double* i
   return XIVO_HIP_OK;
 }
 
+int xivo_hip_set_calib(xivo_hip_ctx* c, const xivo_calib_layout* layout) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (!c || !c->have_layout) return XIVO_HIP_ERR_INVALID;
+  if (!layout) { c->calib_on = false; c->cl = xivo_calib_layout{-1, -1, 0, 0}; return XIVO_HIP_OK; }
+  const xivo_calib_layout& l = *layout;
+  const int N = c->N;
+  if (l.td >= N || (l.Cg >= 0 && (l.td < 0 || l.Cg + 9 > N)) || l.cam_dim < 0 || l.cam_dim > 9 ||
+      (l.cam_dim > 0 && (l.cam_begin < 0 || l.cam_begin + l.cam_dim > N)))
+    return XIVO_HIP_ERR_INVALID;
+  if (!c->calib) { int rc = dev_alloc(&c->calib, (size_t)c->Bmax); if (rc) return rc; }
+  if (!c->Jc && c->Fmax > 0) { int rc = dev_alloc(&c->Jc, (size_t)c->Bmax * c->Fmax * 44); if (rc) return rc; }
+  c->cl = l;
+  c->calib_on = l.td >= 0 || l.cam_dim > 0;
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_set_calib_state(xivo_hip_ctx* c, int b0, int nb, const xivo_calib_in* calib) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (bad_range(c, b0, nb) || !calib || !c->calib) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipMemcpyAsync(c->calib + b0, calib, (size_t)nb * sizeof(xivo_calib_in), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));    // host buffer is only borrowed for the call
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_get_jacobians_calib(xivo_hip_ctx* c, int b0, int nb, double* Jc) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (bad_range(c, b0, nb) || c->F <= 0 || !Jc || !c->calib_on || !c->Jc) return XIVO_HIP_ERR_INVALID;
+  const size_t F = c->F, Fm = c->Fmax;
+  return d2h_rows(c, Jc, F * 44 * sizeof(double), c->Jc + (size_t)b0 * Fm * 44, Fm * 44 * sizeof(double), F * 44 * sizeof(double), nb);
+}
+
 static int gate_impl(xivo_hip_ctx* c, int B, double R, double th, double mult, int min_inl, int use_gating) {
   GateArgs a{};
   a.sb = scene_buffers(c); a.lay = c->lay; a.P = c->P; a.strideP = c->sP; a.ldp = c->Np;
@@ -1450,6 +1490,9 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
                      unsigned char* mask_out, double* dist_out) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
+  // (online-calibration builds gate on the whole stacked row inside xivo_hip_filter_update; the compact 21-column gate
+  //  would ignore the td / Cg / bg / intrinsics blocks)
+  if (c->calib_on) return XIVO_HIP_ERR_UNSUPPORTED;
   int rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
   if (rc) return rc;
   const size_t F = c->F, Fm = c->Fmax;
@@ -1509,11 +1552,11 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
   for (int b = 0; b < B; ++b) {
-    c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12;
+    c->ell_over_h[b] = c->calib_on ? 1 : 0; c->ell_nc_h[b] = 12;   // (calibration blocks: up to 34 shared columns - dense rows)
     c->ell_pw_h[b] = (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK) ? 9 : 6;   // group block(s) + feature block
   }
   // the sparse-H pipeline reads only the compressed rows: skip the 2 x Mp x Np dense zero-fill + scatter
-  const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
+  const int dense = ((c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) || c->calib_on) ? 1 : 0;
   c->dense_valid = dense != 0; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B; c->oos_row0 = -1;
   c->mixed_row0 = -1; if (dense) c->h_clean = false;
   return stack_impl(c, B, R, dense);
@@ -1605,7 +1648,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
                               unsigned char* inlier_mask_out, double* chi2_out, int* n_rejected_out) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0 || !c->mask || !c->poses) return XIVO_HIP_ERR_INVALID;
-  if (c->lay.n_groups > 64) return XIVO_HIP_ERR_UNSUPPORTED;
+  if (c->lay.n_groups > 64 || c->calib_on) return XIVO_HIP_ERR_UNSUPPORTED;
   const size_t Bm = c->Bmax, ng = c->lay.n_groups;
   if (!c->Prs || c->rs_Fmax != c->Fmax) {
     void* olds[] = {c->rs_low, c->rs_lowkeep, c->rs_keep, c->rs_chi};
@@ -1720,6 +1763,40 @@ int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, d
   if (rc) return rc;
   // Estimator::OutlierRejection only gates when F > min_required_inliers_ (src/manager.cpp:635)
   const int gate = use_gating && c->F > min_inliers;
+  if (c->calib_on) {
+    // online-calibration builds: the gate needs the WHOLE row J() incl. the td / Cg / bg / intrinsics blocks (update.cpp:60-70),
+    // which is not the row FillJacobianBlock stacks (the :675-676 overwrite): every present feature is stacked once as its
+    // full J() (dense rows), gated on (J P) J^T + R by the dense-row gate, then the inliers are stacked as coded and updated
+    rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 0);
+    if (rc) return rc;
+    if (gate) {
+      c->M = 2 * c->F; c->Mp = round_up16(c->M);
+      c->dense_valid = true; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B; c->oos_row0 = -1; c->mixed_row0 = -1; c->h_clean = false;
+      rc = stack_impl(c, B, R, 1, nullptr, /*full_rows=*/1);
+      if (rc) return rc;
+      rc = ensure_HT(c);
+      if (rc) return rc;
+      const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
+      {
+        GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
+        rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, c->HP, c->sH, ldh, x);
+        if (rc) return rc;
+      }
+      GateDenseArgs a{};
+      a.H = c->H; a.strideH = c->sH; a.ldh = ldh; a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh;
+      a.Hw = c->H; a.HTw = c->HT; a.strideHT = c->sHT; a.ldht = Np; a.HPw = nullptr; a.PHTw = nullptr; a.PHTr = c->PHT;
+      a.inn = c->inn; a.strideInn = c->Mpmax; a.diagR = c->diagR; a.strideR = c->Mpmax;
+      a.mask = c->mask; a.dist = c->dist; a.F = c->F; a.Np = Np; a.batch = B; a.mask_ld = c->Fmax;   // (the stride xivo_hip_stack reads the mask with)
+      a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;
+      a.ell = c->ell; a.have_ell = 0;
+      StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
+      c->gate_sparse_last = 1;
+      HIP_TRY((hipError_t)launch_gate_dense(a, c->stream));
+    }
+    rc = xivo_hip_stack(c, B, R);
+    if (rc) return rc;
+    return xivo_hip_update_joseph(c, B);
+  }
   rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, gate);
   if (rc) return rc;
   rc = xivo_hip_stack(c, B, R);

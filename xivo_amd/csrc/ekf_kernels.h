@@ -58,10 +58,11 @@ struct GateDenseArgs {
   const double* PHTr;                                // (HP)^T = P H^T of the candidate rows [Np x Mp]
   double* inn; long strideInn;
   double* diagR; long strideR;
-  unsigned char* mask; double* dist;            // [batch x F]
+  unsigned char* mask; double* dist;            // [batch x F]  (row stride mask_ld when it is set)
   int F, Np, batch;
   double R, thresh, mult; int min_inliers;
   EllBuffers ell; int have_ell;                 // also zero the rejected pairs of the compressed form (ell.h)
+  int mask_ld;                                  // 0: rows of mask / dist are F entries apart
 };
 int launch_gate_dense(const GateDenseArgs& a, hipStream_t s);
 
@@ -75,6 +76,10 @@ struct SceneBuffers {
   unsigned char* mask;           // [batch x Fmax]
   double* dist;                  // [batch x Fmax]
   int Fmax, F;
+  // online-calibration builds (include/xivo_hip.h, xivo_hip_set_calib): null / td = -1, cam_dim = 0 when switched off
+  const xivo_calib_in* calib;    // [batch]
+  double* Jc;                    // [batch x Fmax x 44]  (2 x 22 row-major: td | Cg 9 | bg 3 | intrinsics 9)
+  xivo_calib_layout cl;
 };
 int launch_jac_instate(const SceneBuffers& sb, const xivo_layout& lay, const xivo_cam& cam, int batch,
                        hipStream_t s);

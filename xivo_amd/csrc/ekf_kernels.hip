@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
   const double th = sdist[a.F];
   for (int f = tid; f < a.F; f += 256) {
     const bool in = sdist[f] < th;
-    a.mask[(long)filt * a.F + f] = in ? 1 : 0;
-    a.dist[(long)filt * a.F + f] = sdist[f];
+    a.mask[(long)filt * (a.mask_ld ? a.mask_ld : a.F) + f] = in ? 1 : 0;
+    a.dist[(long)filt * (a.mask_ld ? a.mask_ld : a.F) + f] = sdist[f];
     if (!in) {
       inn[2 * f] = 0.0; inn[2 * f + 1] = 0.0;
       double* dr = a.diagR + (long)filt * a.strideR;
@@ -257,6 +257,7 @@ __global__ void jac_instate_kernel(SceneBuffers sb, xivo_layout lay, xivo_cam ca
     for (int i = 0; i < 42; ++i) J0[i] = 0.0;
     sb.finn[((long)filt * sb.Fmax + f) * 2] = 0.0;
     sb.finn[((long)filt * sb.Fmax + f) * 2 + 1] = 0.0;
+    if (sb.Jc) { double* Jc0 = sb.Jc + ((long)filt * sb.Fmax + f) * 44; for (int i = 0; i < 44; ++i) Jc0[i] = 0.0; }
     return;
   }
   const xivo_group_in& grp = sb.groups[(long)filt * lay.n_groups + ft.ref_sind];
@@ -307,6 +308,61 @@ __global__ void jac_instate_kernel(SceneBuffers sb, xivo_layout lay, xivo_cam ca
 
   double xp[2], dxp_dXcn[2][3];
   project_pixel(cam, Xcn, xp, dxp_dXcn);
+
+  if (sb.Jc) {   // online-calibration builds: the td / Cg / bg / intrinsics blocks (feature.cpp:592-609, :611-618, :632-651)
+    double* Jc = sb.Jc + ((long)filt * sb.Fmax + f) * 44;
+    for (int i = 0; i < 44; ++i) Jc[i] = 0.0;
+    if (sb.cl.td >= 0) {
+      const xivo_calib_in& cb = sb.calib[filt];
+      const M3 Cg = m3_from_colmajor(cb.Cg);
+      const V3 gyro{{cb.gyro[0], cb.gyro[1], cb.gyro[2]}};
+      V3 gyro_calib = m3_mulv(Cg, gyro);                                   // :593  Cg * gyro - bg
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gyro_calib.v[i] -= pose.bg[i];
+      const V3 Vsb{{pose.Vsb[0], pose.Vsb[1], pose.Vsb[2]}};
+      // dXcn_dtd = -Rbc_t * (hat(gyro_calib) * Rsb_t * (Xs - Tsb) + Rsb_t * Vsb)          :594-595
+      const V3 u1 = m3_mulv(m3_mul(hat(gyro_calib), Rsb_t), dXs);
+      const V3 u2 = m3_mulv(Rsb_t, Vsb);
+      V3 u;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) u.v[i] = u1.v[i] + u2.v[i];
+      const V3 dXcn_dtd = m3_mulv(m3_neg(Rbc_t), u);
+      // dXcn_dW = dAB_dB<3,1>(Rbc_t * hat(Rsb_t * (Xs - Tsb)) * td) = that 3 x 3 matrix     :598-599
+      M3 dXcn_dW = m3_mul(Rbc_t, hat(m3_mulv(Rsb_t, dXs)));
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dXcn_dW.m[i][j] *= cb.td;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        Jc[i * 22 + 0] = dxp_dXcn[i][0] * dXcn_dtd.v[0] + dxp_dXcn[i][1] * dXcn_dtd.v[1] + dxp_dXcn[i][2] * dXcn_dtd.v[2];   // :632
+        double jw[3];                                                      // dxp_dXcn * dXcn_dW
+#pragma unroll
+        for (int j = 0; j < 3; ++j) jw[j] = dxp_dXcn[i][0] * dXcn_dW.m[0][j] + dxp_dXcn[i][1] * dXcn_dW.m[1][j] + dxp_dXcn[i][2] * dXcn_dW.m[2][j];
+        // dXcn_dCg = dXcn_dW * dW_dCg, dW_dCg row k = gyro at columns 3k..3k+2 (:601-605): column 3k + j = dXcn_dW[:, k] * gyro[j]
+        if (sb.cl.Cg >= 0)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              double acc = 0.0;                                            // (the product as Eigen forms it: dxp_dXcn * (dXcn_dW * dW_dCg))
+#pragma unroll
+              for (int q = 0; q < 3; ++q) acc += dxp_dXcn[i][q] * (dXcn_dW.m[q][k] * gyro.v[j]);
+              Jc[i * 22 + 1 + 3 * k + j] = acc;
+            }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Jc[i * 22 + 10 + j] = -jw[j];          // dXcn_dbg = -dXcn_dW (:607, :636)
+      }
+    }
+    if (sb.cl.cam_dim > 0) {                                               // :611-618, :647-651
+      double xq[2], Jq[2][2], jacc[2][9];
+      const double xcn0 = Xcn.v[0] / Xcn.v[2], xcn1 = Xcn.v[1] / Xcn.v[2];
+      camera_project_jacc(cam, xcn0, xcn1, xq, Jq, jacc);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < sb.cl.cam_dim && j < 9; ++j) Jc[i * 22 + 13 + j] = jacc[i][j];
+    }
+  }
 
   double blk[7][2][3];
   m23_mul(dxp_dXcn, dXcn_dWsb, blk[0]);
@@ -500,6 +556,21 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
         }
       }
     }
+    if (sb.Jc && a.write_dense) {   // online-calibration builds: Feature::FillJacobianBlock :664-670, :679-683
+      const double* Jc = sb.Jc + ((long)filt * sb.Fmax + f) * 44;
+      auto put = [&](int col, int i, double v) {
+        H[(2 * f + i) + (long)col * a.mb.ldh] = v;
+        if (a.mb.HT) HT[col + (long)(2 * f + i) * a.mb.ldht] = v;
+      };
+      for (int i = 0; i < 2; ++i) {
+        if (sb.cl.td >= 0) {
+          put(sb.cl.td, i, Jc[i * 22]);
+          if (sb.cl.Cg >= 0) for (int j = 0; j < 9; ++j) put(sb.cl.Cg + j, i, Jc[i * 22 + 1 + j]);
+          for (int j = 0; j < 3; ++j) put(9 + j, i, Jc[i * 22 + 10 + j]);          // Index::bg
+        }
+        for (int j = 0; j < sb.cl.cam_dim && j < 9; ++j) put(sb.cl.cam_begin + j, i, Jc[i * 22 + 13 + j]);
+      }
+    }
     inn[2 * f] = fi[0]; inn[2 * f + 1] = fi[1];      // update.cpp:136
     dR[2 * f] = a.R; dR[2 * f + 1] = a.R;            // update.cpp:137
   }
@@ -509,7 +580,7 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   // group and feature blocks the private ones (ell.h)
   int* eidx = a.ell.idx + (long)filt * a.ell.stride_idx();
   double* eval = a.ell.val + (long)filt * a.ell.stride_val();
-  if (tid == 0) { a.ell.nc[filt] = 12; a.ell.over[filt] = 0; a.ell.pw[filt] = a.fix_group_block ? 9 : 6; }
+  if (tid == 0) { a.ell.nc[filt] = 12; a.ell.over[filt] = sb.Jc ? 1 : 0; a.ell.pw[filt] = a.fix_group_block ? 9 : 6; }   // (calibration blocks: dense rows only)
   // one thread per (pair, slot): consecutive threads write consecutive 16-byte value slots / 4-byte index slots (a thread
   // per pair wrote 84 scalars 448 bytes apart from its neighbour's: 0.32 ms per 4096 filters, bound by the store count)
   const d2 zero2 = d2{0.0, 0.0};

@@ -143,9 +143,20 @@ _SIGS = {
     "xivo_hip_get_ldlt_used": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_update_joseph_host": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_uint],
+    "xivo_hip_set_calib": [C.c_void_p, C.c_void_p],
+    "xivo_hip_set_calib_state": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "xivo_hip_get_jacobians_calib": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_selftest_host_compress": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
 }
 HOST_P_RESIDENT, HOST_KEEP_P = 1, 2
+
+
+class CalibLayout(C.Structure):
+    _fields_ = [("td", C.c_int), ("Cg", C.c_int), ("cam_begin", C.c_int), ("cam_dim", C.c_int)]
+
+
+calib_dtype = np.dtype([("gyro", "f8", 3), ("Cg", "f8", 9), ("td", "f8")])
+assert calib_dtype.itemsize == 104
 # every symbol include/xivo_hip.h declares (tests check the library exports them all)
 ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile", "xivo_hip_device_count",
                                         "xivo_hip_device_numa_node"])
@@ -318,6 +329,25 @@ class Context:
 
     def update_joseph(self, B=None):
         self._check(self.lib.xivo_hip_update_joseph(self.h, self.batch if B is None else B))
+
+    # ---- online-calibration builds (measurement side) ----------------------------
+    def set_calib(self, td=-1, Cg=-1, cam_begin=0, cam_dim=0):
+        """switch the td / Cg / bg / intrinsics Jacobian blocks on (td = Cg = -1 and cam_dim = 0: off)"""
+        if td < 0 and cam_dim == 0:
+            self._check(self.lib.xivo_hip_set_calib(self.h, None))
+        else:
+            cl = CalibLayout(td, Cg, cam_begin, cam_dim)
+            self._check(self.lib.xivo_hip_set_calib(self.h, C.byref(cl)))
+
+    def set_calib_state(self, calib, b0=0):
+        calib = np.ascontiguousarray(calib, dtype=calib_dtype)
+        self._check(self.lib.xivo_hip_set_calib_state(self.h, b0, calib.shape[0], _ptr(calib)))
+
+    def get_jacobians_calib(self, b0=0, nb=None, F=None):
+        nb = self.batch - b0 if nb is None else nb
+        out = np.empty((nb, F, 2, 22))
+        self._check(self.lib.xivo_hip_get_jacobians_calib(self.h, b0, nb, _ptr(out)))
+        return out
 
     def update_joseph_host(self, H, inn, diagR, P_cm, b=0, mode=0, check=True):
         """The one-call plumbing entry (xivo_hip_update_joseph_host): H [M, N] row-major here (transposed to Eigen's
