@@ -687,3 +687,31 @@ def test_extracted_compute_jacobian_online_calibration_build(name):
         assert (np.abs(Jx[:, cam_begin:cam_begin + 9]).sum(0) > 0).sum() == CAM_DIM[name]
         assert np.array_equal(Jc[:, 0], J[:, td]) and np.array_equal(Jc[:, 13:13 + CAM_DIM[name]], J[:, cam_begin:cam_begin + CAM_DIM[name]])
     assert worst < 1e-12
+
+
+# ---- golden_v4.npz: ComputeJacobian / FillJacobianBlock of the extracted builds (default + online calibration) ----------------
+G4 = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v4.npz"))
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+@pytest.mark.parametrize("build", ["default", "calib"])
+def test_golden_v4_compute_jacobian(build, name):
+    """the oracle against stored outputs of the reference's own text (runs without oracle/_ref)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_v4", os.path.join(os.path.dirname(__file__), "golden", "make_golden_v4.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    lay = orc.calib_layout(15, 30, True, True, CAM_DIM[name]) if build == "calib" else orc.Layout(15, 30)
+    L = G4[f"{build}_layout"]
+    assert [lay.N, lay.group_begin, lay.feature_begin] == L[:3].tolist()
+    if build == "calib":
+        assert [lay.td, lay.Cg, lay.cam_begin] == L[3:6].tolist() and L[6:8].tolist() == [9, 39]
+    for i in (0, 11, 29):
+        args, r, sind, cal = m.case(CAMS[name], 7, i)
+        res = orc.compute_jacobian(*args, CAMS[name], lay, r, sind, calib=cal if build == "calib" else None)
+        J, inn = res[0], res[1]
+        H = np.zeros((2, lay.N)); orc.fill_jacobian_block(H, 0, J, lay, r, sind)
+        k = f"{build}_{name}_{i}"
+        for M_, cols, vals in ((J, G4[k + "_Jcols"], G4[k + "_J"]), (H, G4[k + "_Hcols"], G4[k + "_H"])):
+            assert np.nonzero(np.abs(M_).sum(0))[0].tolist() == cols.tolist()
+            assert np.abs(M_[:, cols] - vals).max() / np.abs(vals).max() < 1e-12
+        assert np.abs(inn - G4[k + "_inn"]).max() < 1e-10
