@@ -295,9 +295,13 @@ SUB_CONFIGS = [
      ["--level", "G", "--oos", "20", "--batch", "4096", "--steps", "8", "--warmup", "2"]),
     ("config4 (N=400, 150 features, M=300), fp64 (library default), 4096 filters",
      ["--state-dim", "400", "--features", "150", "--batch", "4096", "--steps", "5", "--warmup", "2"]),
-    ("config4 as written: fp32 MFMA covariance products (XIVO_HIP_FLAG_FP32_COV, tolerance 5e-5 on P), 4096 filters",
-     ["--state-dim", "400", "--features", "150", "--batch", "4096", "--steps", "4", "--warmup", "1", "--flags", "32", "--tol-P", "5e-5",
-      "--no-last-step-parity"]),   # (dx of a LATER update inherits the fp32 covariance of the earlier ones: the flag's tolerance is per update)
+    ("config4 as written: fp32 MFMA with stated tolerance (XIVO_HIP_FLAG_FP32_WHITENED: the whitened operands V^T, Y^T leave the fp64 "
+     "solve as float, P - V^T Y on v_mfma_f32_16x16x4_f32; tolerance 5e-5 on P, dx unchanged), 4096 filters",
+     ["--state-dim", "400", "--features", "150", "--batch", "4096", "--steps", "5", "--warmup", "2", "--flags", "16384", "--tol-P", "5e-5",
+      "--no-last-step-parity"]),   # (dx of a LATER update inherits the fp32 rounding of the earlier covariances: the tolerance is per update)
+    ("config4, the round-1 reading of 'fp32 MFMA': the three as-coded dense covariance products on the fp32 MFMA (XIVO_HIP_FLAG_FP32_COV), 4096 filters",
+     ["--state-dim", "400", "--features", "150", "--batch", "4096", "--steps", "3", "--warmup", "1", "--flags", "32", "--tol-P", "5e-5",
+      "--no-last-step-parity"]),
     ("TUM-VI size (N=203, 30 features, M=60), fp64, 8192 filters",
      ["--state-dim", "203", "--features", "30", "--batch", "8192", "--steps", "8", "--warmup", "2"]),
     ("metric point, dense AS-CODED pipeline (XIVO_HIP_FLAG_DENSE_H = --flags 64: H treated as dense, every product of "

@@ -107,6 +107,13 @@ enum {
    * <= 1e-7 |G K^T| to P+, orders of magnitude below the fp64 rounding of -T. Without it (the default since round 3)
    * no fp32 instruction takes part in an update. */
   XIVO_HIP_FLAG_FP32_CORR = 2048u,
+  /* Opt-in (round 4; BASELINE config 4 "fp32 MFMA with stated tolerance"), shapes whose covariance product runs outside the
+   * solve kernel (N > 256 or M > 176): the whitened outputs V^T = (W - D)^T and Y^T = (W + D)^T leave the fp64 solve as
+   * FLOAT and P+ = P - V^T Y runs on v_mfma_f32_16x16x4_f32 (fp32 accumulation over M, subtracted from P in fp64): half
+   * the operand bytes of a product that is HBM-bound, twice the matrix rate. Everything else (S, the factorisation, both
+   * substitutions, dx) stays fp64: dx is unchanged, P+ carries the rounding of the float operands, <= 5e-5 relative
+   * Frobenius (measured ~1e-7). Shapes the in-solve update holds are not affected. */
+  XIVO_HIP_FLAG_FP32_WHITENED = 16384u,
   /* By default a filter whose innovation covariance the un-pivoted Cholesky cannot factor (S indefinite / not positive
    * definite) is updated the reference's way after all: Eigen's diagonally pivoted L D L^T solve (src/estimator.cpp:1266)
    * and the as-coded Joseph form, on that filter only (ldlt_fallback.hip); xivo_hip_get_ldlt_used tells which filters took

@@ -692,3 +692,30 @@ def test_random_shapes_and_modes_match_oracle(built, N, F, B, flags, seed):
         assert rel_fro(Pn[b], P_ref) < tol_P and rel_fro(err[b], e_ref) < TOL_DX
         if not flags & 4:                       # (XIVO_HIP_FLAG_FULL_PNEW computes every entry instead of lower triangle + mirror)
             assert np.array_equal(Pn[b], Pn[b].T)
+
+
+@pytest.mark.parametrize("N,F,flags", [(400, 150, 0), (300, 60, 0), (512, 64, 0), (400, 150, 64 | 16), (251, 100, 0)])
+def test_fp32_whitened_operands_beyond_one_workgroup(built, N, F, flags):
+    """XIVO_HIP_FLAG_FP32_WHITENED (round 4; BASELINE config 4 "fp32 MFMA with stated tolerance"): for shapes whose product
+    runs outside the solve kernel the whitened operands V^T, Y^T leave the fp64 solve as float and P - V^T Y runs on
+    v_mfma_f32_16x16x4_f32. dx is untouched (1e-8: everything up to the gain is fp64), P+ within the stated 5e-5 (measured
+    ~1e-7: the float rounding of the operands), same status; sparse and dense re-associated pipelines."""
+    from xivo_amd.lib import FLAG_FP32_WHITENED
+    B = 3
+    P, H, inn, dR = synth.s_level(N, F, B, seed=900 + N + F)
+    out = {}
+    for fl in (flags, flags | FLAG_FP32_WHITENED):
+        with Context(N, 2 * F, B, flags=fl) as ctx:
+            ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
+            assert (ctx.get_status() == 0).all()
+            out[fl] = (ctx.get_err(), ctx.download_P())
+    worst = 0.0
+    for b in range(B):
+        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
+        e32, P32 = out[flags | FLAG_FP32_WHITENED][0][b], out[flags | FLAG_FP32_WHITENED][1][b]
+        assert rel_fro(e32, e_ref) < TOL_DX and rel_fro(P32, P_ref) < TOL_P_FP32
+        assert np.array_equal(e32, out[flags][0][b])                 # dx: the very same fp64 arithmetic
+        worst = max(worst, rel_fro(P32, P_ref))
+        assert np.array_equal(P32, P32.T)
+    assert worst > 1e-12                                             # (it really took the float path)
+    print("fp32 whitened operands: worst rel. Frobenius error on P+ = %.2e at N=%d M=%d" % (worst, N, 2 * F))

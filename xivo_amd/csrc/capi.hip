@@ -259,6 +259,7 @@ struct GemmExtra {
   int lower_only = 0;
   int fp32 = 0;
   int a_f32 = 0;   // first operand stored as float
+  int b_f32 = 0;   // second operand stored as float
   int no_mirror = 0;
   const int* skip = nullptr;   // per-filter status: non-zero = leave the output of that filter untouched
   const double* scale0 = nullptr;   // per-k scale of the first segment's B operand (same vector for every filter)
@@ -271,10 +272,10 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
          const GemmExtra& x) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
-  g.seg[0] = GemmSeg{A0, B0, x.scale0, sA0, sB0, 0, lda0, ldb0, K0, x.a_f32};
+  g.seg[0] = GemmSeg{A0, B0, x.scale0, sA0, sB0, 0, lda0, ldb0, K0, x.a_f32, x.b_f32};
   g.nseg = 1;
   if (A1) {
-    g.seg[1] = GemmSeg{A1, B1, scale1, sA1, sB1, sScale1, lda1, ldb1, K1, 0};
+    g.seg[1] = GemmSeg{A1, B1, scale1, sA1, sB1, sScale1, lda1, ldb1, K1, 0, 0};
     g.nseg = 2;
   }
   g.C = C; g.strideC = sC; g.ldc = ldc; g.Mp = rows; g.Np = cols;
@@ -290,7 +291,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
                    (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG) && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
   char label[64] = "gemm_sym_f64_kernel";
   if (!sym) gemm_kernel_label(g, label, sizeof(label));
-  const double bytes = 8.0 * B * ((double)rows * K0 * (x.a_f32 ? 0.5 : 1.0) + (double)cols * K0 + (A1 ? ((double)rows + cols) * K1 : 0.0) +
+  const double bytes = 8.0 * B * ((double)rows * K0 * (x.a_f32 ? 0.5 : 1.0) + (double)cols * K0 * (x.b_f32 ? 0.5 : 1.0) + (A1 ? ((double)rows + cols) * K1 : 0.0) +
                                   (x.msub ? outs : 0.0) + (double)rows * cols + (x.C2 ? (double)rows * cols : 0.0))
                        - (A0 == B0 ? 8.0 * B * (double)cols * K0 : 0.0);   // a symmetric product reads its one operand once
   StageTimer st(c, stage, flops, label, bytes);
@@ -784,7 +785,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
   const bool t_full = full || getenv("XIVO_HIP_T_FULL");
-  bool t_done = false, wh_out = false;
+  bool t_done = false, wh_out = false, wh_f32 = false;
   {
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
@@ -802,7 +803,8 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     static const bool no_trsm_t = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: the round-1 stand-alone tail for every shape
     wh_out = !t_here && !t_full && jform == 2 && !no_joseph && !no_trsm_t &&
              !(c->flags & (XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_FP32_CORR));
-    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; }
+    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; a.out_f32 = (c->flags & XIVO_HIP_FLAG_FP32_WHITENED) ? 1 : 0; }
+    wh_f32 = wh_out && a.out_f32;
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
@@ -821,6 +823,11 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   if (wh_out) {   // P+ = P - V^T Y in place (V^T in the K buffer, Y^T in the G buffer), lower triangle + mirror
     GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
     x.small_tiles = lat;
+    if (wh_f32) {   // XIVO_HIP_FLAG_FP32_WHITENED: both operands left the solve as float (Y^T at float 0, V^T at float Np Mp of G)
+      x.fp32 = 1; x.a_f32 = 1; x.b_f32 = 1;
+      const double* Vf = reinterpret_cast<const double*>(reinterpret_cast<const float*>(G) + (long)Np * Mp);
+      return gemm(c, ST_PNEW, B, Np, Np, Vf, 2 * c->sA, Np, G, 2 * c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
+    }
     return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, G, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
   }
   if (!t_done) {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
@@ -980,7 +987,7 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
   }
   if ((c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) && !f32) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
-  bool wh_out = false;
+  bool wh_out = false, wh_f32 = false;
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
@@ -993,7 +1000,8 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
     const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
     wh_out = (c->flags & XIVO_HIP_FLAG_REASSOC) && !all_here && !f32 && !full && !no_joseph && jform == 2 &&
              !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);
-    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; }
+    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; a.out_f32 = (c->flags & XIVO_HIP_FLAG_FP32_WHITENED) ? 1 : 0; }
+    wh_f32 = wh_out && a.out_f32;
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (wh_out ? 5 : 0), lat);
     const double t_outs = 0.5 * Np * (Np + 1.0);
@@ -1005,6 +1013,12 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
   if (wh_out) {   // P+ = P - V^T Y in place, as in the sparse pipeline
     GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
     x.small_tiles = lat;
+    if (wh_f32) {
+      x.fp32 = 1; x.a_f32 = 1; x.b_f32 = 1;
+      const double* Gb = c->A + (long)b0 * c->sA;
+      const double* Vf = reinterpret_cast<const double*>(reinterpret_cast<const float*>(Gb) + (long)Np * Mp);
+      return gemm(c, ST_PNEW, B, Np, Np, Vf, 2 * c->sA, Np, Gb, 2 * c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
+    }
     return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, c->A + (long)b0 * c->sA, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
   }
   if (c->flags & XIVO_HIP_FLAG_REASSOC) {

@@ -77,6 +77,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+__device__ __forceinline__ void buf_st_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
 __device__ __forceinline__ void buf_st(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, 0);
 }
@@ -905,7 +908,10 @@ __global__ __launch_bounds__(512, NBM <= 4 ? 6 : (NBM <= 8 ? 4 : 2)) void trsm_s
         }
         if (WH) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) buf_st(wk[r] + X[k][r], rY, vY, (unsigned)((16 * k + 4 * r) * g.ldy2) * 8u);   // Y_k = W_k + D_k
+          for (int r = 0; r < 4; ++r) {                                                                              // Y_k = W_k + D_k
+            if (g.out_f32) buf_st_f32((float)(wk[r] + X[k][r]), rY, vY >> 1, (unsigned)((16 * k + 4 * r) * g.ldy2) * 4u);
+            else buf_st(wk[r] + X[k][r], rY, vY, (unsigned)((16 * k + 4 * r) * g.ldy2) * 8u);
+          }
           X[k] = wk - X[k];                                                                                          // V_k = W_k - D_k
         }
       }
@@ -918,7 +924,10 @@ __global__ __launch_bounds__(512, NBM <= 4 ? 6 : (NBM <= 8 ? 4 : 2)) void trsm_s
     if (i < nb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);
+        // (float outputs: V^T goes behind Y^T in the Yout buffer - the K buffer still holds the fp64 stash other column
+        //  chunks of this filter may be reading back)
+        if (WH && g.out_f32) buf_st_f32((float)X[i][r], rY, vY >> 1, (unsigned)(g.Np * g.Mp + (16 * i + 4 * r) * g.ldy2) * 4u);
+        else buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);
         if (!WH) part = fma(X[i][r], buf_ld(rInn, (unsigned)lg * 8u, (unsigned)(16 * i + 4 * r) * 8u), part);
       }
     }
@@ -1058,6 +1067,7 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
     return launch_trsm_stream_t<8, 1>(g, stream);
   }
   if (g.latency && g.Yout && !g.fwd_only && nb <= 14) return launch_trsm_stream_t<14, 1>(g, stream);
+  if (g.out_f32 && g.Yout && !g.fwd_only && nb <= 14) return launch_trsm_stream_t<14, 1>(g, stream);   // (only the streamed kernel writes float outputs)
   // whole factor in LDS (nb(nb+1)/2 blocks of 16x17 doubles) when it fits 160 KiB
   // (a four-block-row instantiation of the whitened form for the TUM-VI build's 30 features spills 1232 VGPRs - hipcc 7.2;
   //  six block rows serve M <= 96)

@@ -29,6 +29,7 @@ struct GemmSeg {
   long strideA, strideB, strideScale;  // per-filter strides (elements)
   int lda, ldb, K;      // K multiple of 16
   int a_f32;            // 1: A is stored as float (same lda / stride in ELEMENTS) - fp32 products only
+  int b_f32;            // 1: B likewise
 };
 
 enum GemmEpilogue : int {
@@ -132,6 +133,10 @@ struct TrsmArgs {
   double* Yout;
   long strideY2;
   int ldy2;
+  // out_f32 (with Yout, streamed kernel only): the whitened outputs leave as FLOAT, both into the Yout buffer - Y^T at float
+  // element 0, V^T at float element Np * Mp (leading dimension ldy2, in floats) - for a product on the fp32 MFMA
+  // (XIVO_HIP_FLAG_FP32_WHITENED); K keeps the fp64 stash of W only
+  int out_f32;
 };
 int launch_trsm_f64(const TrsmArgs& args, hipStream_t stream);
 // P+ = G K^T - T with the rows of G in registers (one workgroup per filter; see chol_trsm.hip)

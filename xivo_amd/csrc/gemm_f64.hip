@@ -199,14 +199,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   const double* segA = nullptr;
   const double* segB = nullptr;
   const double* segS = nullptr;
-  int seg_lda = 0, seg_ldb = 0, seg_K = 0, seg_af32 = 0;
+  int seg_lda = 0, seg_ldb = 0, seg_K = 0, seg_af32 = 0, seg_bf32 = 0;
   auto setup_seg = [&](int sidx) {
     const GemmSeg& sg = g.seg[sidx];
     segA = sg.A + (long)filt * sg.strideA;
     segB = sg.B + (long)filt * sg.strideB;
     segS = sg.scale ? sg.scale + (long)filt * sg.strideScale : nullptr;
-    seg_lda = sg.lda; seg_ldb = sg.ldb; seg_K = sg.K; seg_af32 = sg.a_f32;
+    seg_lda = sg.lda; seg_ldb = sg.ldb; seg_K = sg.K; seg_af32 = sg.a_f32; seg_bf32 = sg.b_f32;
     if (sizeof(CT) == 4 && sg.a_f32) segA = reinterpret_cast<const double*>(reinterpret_cast<const float*>(sg.A) + (long)filt * sg.strideA);
+    if (sizeof(CT) == 4 && sg.b_f32) segB = reinterpret_cast<const double*>(reinterpret_cast<const float*>(sg.B) + (long)filt * sg.strideB);
     okA = 0; okB = 0;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
@@ -231,7 +232,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   // Issue only: nothing below consumes the loaded registers, so the loads stay in flight
   // under the MFMA block; masking (row validity, k-tail) and the optional per-k scale are
   // applied in store_lds, one k-step later.
-  int pend_k0 = 0, pend_K = 0, pend_af32 = 0;
+  int pend_k0 = 0, pend_K = 0, pend_af32 = 0, pend_bf32 = 0;
   const double* pend_S = nullptr;
   auto load_global = [&](int t) {
     if (t == 0) setup_seg(0);
@@ -240,7 +241,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     const bool tail = k0 + BK > seg_K;            // only the last, partial k-step of a segment
     const double* Ab = segA + (long)k0 * seg_lda;
     const double* Bb = segB + (long)k0 * seg_ldb;
-    pend_k0 = k0; pend_K = seg_K; pend_S = segS; pend_af32 = seg_af32;
+    pend_k0 = k0; pend_K = seg_K; pend_S = segS; pend_af32 = seg_af32; pend_bf32 = seg_bf32;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int k = (tid + 256 * r) / (16 * WM);
@@ -257,7 +258,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
     for (int r = 0; r < RB; ++r) {
       const int k = (tid + 256 * r) / (16 * WN);
       const bool kin = !tail || (k0 + k < seg_K);
-      rb[r] = *reinterpret_cast<const d2*>(Bb + (kin ? eoffB[r] : eoffB[r] - k * seg_ldb));
+      const long eo = kin ? eoffB[r] : eoffB[r] - k * seg_ldb;
+      if (sizeof(CT) == 4 && seg_bf32) rb[r][0] = *reinterpret_cast<const double*>(reinterpret_cast<const float*>(segB) + (long)k0 * seg_ldb + eo);
+      else rb[r] = *reinterpret_cast<const d2*>(Bb + eo);
     }
   };
 
@@ -280,6 +283,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
       const int idx = tid + 256 * r;
       const int k = idx / (16 * WN), p = idx % (16 * WN);
       const bool keep = ((okB >> r) & 1u) && (!tail || pend_k0 + k < pend_K);
+      if (sizeof(CT) == 4 && pend_bf32) {                // B kept in HBM as float: the pair's bits as they are (no per-k scale in this mode)
+        *reinterpret_cast<double*>(Bs + k * LDBS + 2 * p) = keep ? rb[r][0] : 0.0;
+        continue;
+      }
       d2 v = keep ? rb[r] : d2{0.0, 0.0};
       if (pend_S) v *= pend_S[pend_k0 + k < pend_K ? pend_k0 + k : pend_K - 1];
       *reinterpret_cast<pair_t*>(Bs + k * LDBS + 2 * p) = Cx<CT>::cvt(v);

@@ -19,6 +19,7 @@ FLAG_STANDALONE_TAIL = 512
 FLAG_EXPANDED_JOSEPH = 1024
 FLAG_FP32_CORR = 2048
 FLAG_NO_LDLT_FALLBACK = 4096
+FLAG_FP32_WHITENED = 16384  # N > 256 / M > 176: V^T, Y^T as float, P - V^T Y on the fp32 MFMA
 FLAG_THROUGHPUT_ROUTE = 8192    # every batch size on the kernels sized for thousands of filters (default: <= 64 filters take the latency route)
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
