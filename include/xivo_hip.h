@@ -308,24 +308,36 @@ int xivo_hip_get_jacobians(xivo_hip_ctx* ctx, int b0, int nb, double* J2x21, dou
  * than the 16 common slots of the row-pair compressed form - and gate / update through the dense pipeline, whose MH gating
  * uses the whole row as the reference's f->J() does. Slots as the reference's Index enum / kCameraBegin would number them
  * (the caller's xivo_layout already counts them in N, group_begin, feature_begin); -1 / 0 = that block is not in the build.
- * NOT covered: the motion-side blocks of those builds (Cg / Ca columns of the motion Jacobian, src/estimator.cpp:674-688,
- * a 24..39-dimensional motion state in xivo_hip_propagate) and the retraction of td / Cg / Ca / the intrinsics in
- * xivo_hip_absorb_error - the caller absorbs those components of dx on the host (src/estimator.cpp:879-889). */
+ * Motion side of those builds: xivo_hip_propagate_calib (below, next to xivo_hip_propagate) integrates the
+ * kMotionSize = 24 / 38 / 39-dimensional motion block with the Cg / Ca columns of ComputeMotionJacobianAt
+ * (src/estimator.cpp:626-638, :674-688) and imu_.Cg() / imu_.Ca() in ComposeMotion (:603-604); xivo_hip_absorb_error
+ * then also retracts td, Cg, Ca and the intrinsics (src/core.h:150-152, src/estimator.cpp:879-890, src/imu.cpp:7-21,
+ * common/camera_autocalib.h) of the resident per-filter calibration state below. */
 typedef struct {
   int td;         /* Index::td, or -1 (no USE_ONLINE_TEMPORAL_CALIB: then neither the td, nor the Cg, nor the bg block exists) */
-  int Cg;         /* Index::Cg (9 columns), or -1 (no USE_ONLINE_IMU_CALIB); needs td >= 0                                   */
+  int Cg;         /* Index::Cg (9 columns; Ca's 6 follow at Cg + 9), or -1 (no USE_ONLINE_IMU_CALIB); the measurement-side
+                     Cg / bg blocks need td >= 0 (they are nested in the temporal block, src/feature.cpp:592-609)              */
   int cam_begin;  /* kCameraBegin                                                                                              */
   int cam_dim;    /* Camera::dim(): 4 pinhole (fx fy cx cy), 5 atan (+ w), 9 radtan (+ p1 p2 k1 k2 k3), 8 equidistant
                      (+ k0..k3); 0 = no USE_ONLINE_CAMERA_CALIB                                                               */
 } xivo_calib_layout;
-typedef struct {   /* per filter, what Estimator::ComputeInstateJacobians hands down (src/update.cpp:27-28) */
+typedef struct {   /* per filter: what Estimator::ComputeInstateJacobians hands down (src/update.cpp:27-28) + the rest of the
+                      calibration state that AbsorbError retracts */
   double gyro[3];  /* last_gyro_ (raw measurement)        */
   double Cg[9];    /* imu_.Cg(), column-major             */
   double td;       /* X_.td                               */
+  double Ca[9];    /* imu_.Ca(), column-major (upper triangular, src/imu.cpp:24); identity when the build has no Ca */
+  double intr[9];  /* camera intrinsics in the order of the state slots: fx fy cx cy, then xivo_cam.d[0..4]. With
+                      cam_dim > 0 every kernel that projects (Jacobians, OOS rows, depth sub-filter) takes the filter's
+                      intrinsics from here - the context's xivo_cam only names the model; cam_dim = 0: not read */
 } xivo_calib_in;
 /* layout == NULL switches the calibration blocks off again (default build) */
 int xivo_hip_set_calib(xivo_hip_ctx* ctx, const xivo_calib_layout* layout);
 int xivo_hip_set_calib_state(xivo_hip_ctx* ctx, int b0, int nb, const xivo_calib_in* calib /* nb */);
+int xivo_hip_get_calib_state(xivo_hip_ctx* ctx, int b0, int nb, xivo_calib_in* calib_out /* nb */);
+/* only last_gyro_ of every filter (what changes from frame to frame; td / Cg / Ca / intr are state and stay as AbsorbError
+ * left them): gyro3 = nb x 3 doubles */
+int xivo_hip_set_calib_gyro(xivo_hip_ctx* ctx, int b0, int nb, const double* gyro3);
 /* the calibration blocks of the last xivo_hip_jacobians_instate, per feature 2 x 22 row-major:
  * [ td (1) | Cg (9) | bg (3) | intrinsics (9, the first cam_dim in use) ]; blocks that are switched off read 0 */
 int xivo_hip_get_jacobians_calib(xivo_hip_ctx* ctx, int b0, int nb, double* Jc2x22);
@@ -433,6 +445,13 @@ typedef struct {
 /* imu: [nb][n_imu] - the n_imu samples of each filter since its last call (one Estimator::Propagate each, in order);
  * their transitions are accumulated on chip and the O(23 N) cross-covariance tail is applied once. */
 int xivo_hip_propagate(xivo_hip_ctx* ctx, int b0, int nb, int n_imu, const xivo_imu_in* imu, const xivo_prop_opts* opts);
+/* The same for an online-calibration build (xivo_hip_set_calib with td >= 0 or Cg >= 0): kMotionSize = Index::End
+ * (src/core.h:40-75) = Cg + 15, or td + 1 without the IMU calibration; ComposeMotion with the resident imu_.Cg() / imu_.Ca()
+ * (xivo_calib_in), the motion Jacobian with the dWsb/dCg and dVsb/dCa blocks (src/estimator.cpp:626-638, :674-688), the tail
+ * over motion_size rows / columns. Qmodel: motion_size x motion_size, column-major (opts->Qmodel is not read).
+ * xivo_hip_propagate itself refuses such a context (XIVO_HIP_ERR_UNSUPPORTED): its motion block is the default build's 23. */
+int xivo_hip_propagate_calib(xivo_hip_ctx* ctx, int b0, int nb, int n_imu, const xivo_imu_in* imu, const xivo_prop_opts* opts,
+                             const double* Qmodel);
 
 /* ---- orthonormal Givens elimination and QR measurement compression ----
  * Batched xivo::Givens (src/helpers.cpp:48-75) and xivo::QR (src/helpers.cpp:78-101) on host arrays, nb
@@ -497,7 +516,7 @@ int xivo_hip_set_pixels(xivo_hip_ctx* ctx, int b0, int nb, int F, const double* 
 
 /* ---- covariance propagation tail (src/rk4.cpp:92-102, src/estimator.cpp:590) */
 /* P_mm <- Pmm_new ; P_ms <- Phi P_ms ; P_sm <- P_sm Phi^T. Phi and Pmm_new
- * are nm x nm (nm = 23 = kMotionSize), one pair per filter. */
+ * are nm x nm (nm = kMotionSize: 23, or up to 40 for the online-calibration builds), one pair per filter. */
 int xivo_hip_propagate_cov(xivo_hip_ctx* ctx, int b0, int nb, int nm, const double* Phi,
                            const double* Pmm_new);
 

@@ -27,6 +27,7 @@ PIECES = [
     ("filter_update", "src/update.cpp", r"^void Estimator::FilterUpdate\(\)", "block"),
     ("absorb_error_vec", "src/estimator.cpp", r"^void Estimator::AbsorbError\(const VecX &err\) \{", "block"),
     ("absorb_error", "src/estimator.cpp", r"^void Estimator::AbsorbError\(\) \{", "block"),
+    ("imu_state_plus", "src/imu.cpp", r"^void IMUState::operator\+=\(const Tangent &dX\) \{", "block"),
     ("so3xr3", "src/group.h", r"^struct SO3xR3 \{", "block"),
     ("jacobian_cache", "src/jac.h", r"^struct JacobianCache \{", "block"),
     ("feature_xc", "src/feature.cpp", r"^Vec3 Feature::Xc\(Mat3 \*J\) \{", "block"),

@@ -54,7 +54,13 @@ class Camera {
       default: return EquidistantCamera<double>(c.rows, c.cols, c.fx, c.fy, c.cx, c.cy, c.d[0], c.d[1], c.d[2], c.d[3]).Project(xc, jac, jacc);
     }
   }
-  template <class V> void UpdateState(const V&) {}   // (src/estimator.cpp:888: the intrinsics live in the camera object; not modelled)
+  // CameraManager::UpdateState (src/camera_manager.h:91-101) -> A_*Camera::UpdateState (common/camera_autocalib.h:34-47, :78-84,
+  // :107-116, :145-157): every parameter += its component, in the order fx fy cx cy + the model's distortion parameters
+  // (= cfg.d's order). Restated here (those classes pull in component.h / jsoncpp).
+  template <class V> void UpdateState(const V& dX) {
+    cfg.fx += dX(0); cfg.fy += dX(1); cfg.cx += dX(2); cfg.cy += dX(3);
+    for (int k = 4; k < dim(); ++k) cfg.d[k - 4] += dX(k);
+  }
 };
 
 #include "extracted/core_index_state.inc"
@@ -103,11 +109,23 @@ class RefFeature {   // the members of Feature (src/feature.h:74-284) the extrac
 using FeaturePtr = RefFeature*;
 
 JacobianCache RefFeature::cache_;
+// IMUState (src/imu.h:12-27: Ca, Cg and the 15-dimensional Tangent) with the reference's own operator+= (src/imu.cpp:7-21,
+// extracted below); the IMU object around it (src/imu.h:29-46) reduced to the accessors the extracted bodies call
+#ifndef CHECK
+#define CHECK(c) if (!(c)) abort()
+#endif
+struct IMUState {
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+  Mat3 Ca = Mat3::Identity(), Cg = Mat3::Identity();
+  using Tangent = Eigen::Matrix<number_t, 15, 1>;
+  void operator+=(const Tangent& dX);
+};
+#include "extracted/imu_state_plus.inc"
 struct RefImu {
-  Mat3 Ca_ = Mat3::Identity(), Cg_ = Mat3::Identity();
-  const Mat3& Ca() const { return Ca_; }
-  const Mat3& Cg() const { return Cg_; }
-  template <class V> void UpdateState(const V&) {}   // (src/estimator.cpp:883: Ca / Cg live in the IMU object; not modelled)
+  IMUState X_;
+  const Mat3& Ca() const { return X_.Ca; }
+  const Mat3& Cg() const { return X_.Cg; }
+  void UpdateState(const IMUState::Tangent& dX) { X_ += dX; }     // src/imu.h:34
 };
 struct RefTimer { void Tick(const char*) {} void Tock(const char*) {} };
 
@@ -297,17 +315,52 @@ void refx_filter_update(int F, const double* J, const double* inn, const int* re
 }
 
 // Estimator::RK4Step / PrinceDormandStep as extracted (with ComposeMotion, ComputeMotionJacobianAt), N = kFullSize
-void refx_integrator_step(int use_rk4, double* state30_io, double* P_io, const double* gyro0, const double* accel0,
-                          const double* slope_gyro, const double* slope_accel, double dt, const double* Qimu, const double* g) {
+// Cg / Ca: imu_.Cg() / imu_.Ca(), column-major, may be null (identity)
+void refx_integrator_step_calib(int use_rk4, double* state30_io, double* P_io, const double* gyro0, const double* accel0,
+                                const double* slope_gyro, const double* slope_accel, double dt, const double* Qimu, const double* g,
+                                const double* Cg, const double* Ca) {
   const int N = kFullSize;
   RefEstimator e;
   load_state(e.X_, state30_io);
+  if (Cg) e.imu_.X_.Cg = Eigen::Map<const Mat3>(Cg);
+  if (Ca) e.imu_.X_.Ca = Eigen::Map<const Mat3>(Ca);
   e.P_ = MapMat(P_io, N, N); e.Qimu_ = MapMat(Qimu, 12, 12); e.g_ = Eigen::Map<const Vec3>(g);
   e.slope_gyro_ = Eigen::Map<const Vec3>(slope_gyro); e.slope_accel_ = Eigen::Map<const Vec3>(slope_accel);
   const Vec3 gy = Eigen::Map<const Vec3>(gyro0), ac = Eigen::Map<const Vec3>(accel0);
   if (use_rk4) e.RK4Step(gy, ac, dt); else e.PrinceDormandStep(gy, ac, dt);
   store_state(e.X_, state30_io);
   (MapMatW(P_io, N, N)) = e.P_;
+}
+void refx_integrator_step(int use_rk4, double* state30_io, double* P_io, const double* gyro0, const double* accel0,
+                          const double* slope_gyro, const double* slope_accel, double dt, const double* Qimu, const double* g) {
+  refx_integrator_step_calib(use_rk4, state30_io, P_io, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g, nullptr, nullptr);
+}
+
+int refx_index_Ca(void) {
+#ifdef USE_ONLINE_IMU_CALIB
+  return Index::Ca;
+#else
+  return -1;
+#endif
+}
+
+// Estimator::AbsorbError(err) as extracted, motion part only (no groups / features in the lists): State::operator+= incl. td,
+// IMUState::operator+= (as extracted) for Ca / Cg, the camera intrinsics. td / Cg / Ca (column-major) / cam are in-out.
+void refx_absorb_motion_calib(double* state30_io, const double* Rbc_in, const double* Tbc_in, double* Rbc_out, double* Tbc_out,
+                              double* td_io, double* Cg_io, double* Ca_io, RefCamCfg* cam_io, const double* err) {
+  RefEstimator e;
+  load_state(e.X_, state30_io);
+  e.X_.Rbc = SO3(Eigen::Quaterniond(Mat3(Eigen::Map<const Mat3>(Rbc_in)))); e.X_.Tbc = Eigen::Map<const Vec3>(Tbc_in);
+  e.X_.td = *td_io;
+  e.imu_.X_.Cg = Eigen::Map<const Mat3>(Cg_io); e.imu_.X_.Ca = Eigen::Map<const Mat3>(Ca_io);
+  Camera::instance()->cfg = *cam_io;
+  const VecX ev = MapVec(err, kFullSize);
+  e.AbsorbError(ev);
+  store_state(e.X_, state30_io);
+  (Eigen::Map<Mat3>(Rbc_out)) = e.X_.Rbc.matrix(); (Eigen::Map<Vec3>(Tbc_out)) = e.X_.Tbc;
+  *td_io = e.X_.td;
+  (Eigen::Map<Mat3>(Cg_io)) = e.imu_.Cg(); (Eigen::Map<Mat3>(Ca_io)) = e.imu_.Ca();
+  *cam_io = Camera::instance()->cfg;
 }
 
 }  // extern "C"

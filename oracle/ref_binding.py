@@ -285,16 +285,40 @@ class RefX:
                                        C.c_int(int(ref_sind)), C.c_int(int(sind)), _p(J), _p(inn), _p(Hrow))
         return np.ascontiguousarray(J), inn, np.ascontiguousarray(Hrow)
 
-    def integrator_step(self, method, X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec):
-        """Estimator::RK4Step / PrinceDormandStep as extracted. Returns (Rsb, Tsb, Vsb, P_new)."""
+    def integrator_step(self, method, X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, Cg=None, Ca=None):
+        """Estimator::RK4Step / PrinceDormandStep as extracted (imu_.Cg() / imu_.Ca() = Cg / Ca, identity when None; in the
+        online-calibration build the motion Jacobian also carries the Cg / Ca columns, src/estimator.cpp:674-688).
+        Returns (Rsb, Tsb, Vsb, P_new)."""
         assert P.shape[0] == self.N
         st = np.ascontiguousarray(np.concatenate([_F(X.Rsb).reshape(-1, order="F"), X.Tsb, X.Vsb, X.bg, X.ba,
                                                   _F(X.Rsg).reshape(-1, order="F")]), dtype=np.float64)
         Pf = _F(P).copy(order="F")
         keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (gyro0, accel0, slope_gyro, slope_accel, g_vec)]
-        self.lib.refx_integrator_step(C.c_int(1 if method == "RK4" else 0), _p(st), _p(Pf), _p(keep[0]), _p(keep[1]), _p(keep[2]),
-                                      _p(keep[3]), C.c_double(dt), _p(_F(Qimu)), _p(keep[4]))
+        mats = [_F(np.eye(3) if Cg is None else Cg), _F(np.eye(3) if Ca is None else Ca)]
+        self.lib.refx_integrator_step_calib(C.c_int(1 if method == "RK4" else 0), _p(st), _p(Pf), _p(keep[0]), _p(keep[1]), _p(keep[2]),
+                                            _p(keep[3]), C.c_double(dt), _p(_F(Qimu)), _p(keep[4]), _p(mats[0]), _p(mats[1]))
         return st[0:9].reshape(3, 3).T.copy(), st[9:12].copy(), st[12:15].copy(), np.ascontiguousarray(Pf)
+
+    def index_Ca(self):
+        self.lib.refx_index_Ca.restype = C.c_int
+        return self.lib.refx_index_Ca()
+
+    def absorb_motion_calib(self, X, Rbc, Tbc, td, Cg, Ca, cam, err):
+        """Estimator::AbsorbError(err) as extracted on the motion state + td + IMU calibration + camera intrinsics (no groups /
+        features listed). Returns dict(Rsb, Tsb, Vsb, bg, ba, Rsg, Rbc, Tbc, td, Cg, Ca, cam)."""
+        st = np.ascontiguousarray(np.concatenate([_F(X.Rsb).reshape(-1, order="F"), X.Tsb, X.Vsb, X.bg, X.ba,
+                                                  _F(X.Rsg).reshape(-1, order="F")]), dtype=np.float64)
+        Rbo = np.zeros((3, 3), order="F"); Tbo = np.zeros(3)
+        tdv = C.c_double(td); Cgf = _F(Cg).copy(order="F"); Caf = _F(Ca).copy(order="F")
+        c = _cam(cam)
+        keep = [np.ascontiguousarray(Tbc, dtype=np.float64), np.ascontiguousarray(err, dtype=np.float64), _F(Rbc)]
+        assert keep[1].shape[0] == self.N
+        self.lib.refx_absorb_motion_calib(_p(st), _p(keep[2]), _p(keep[0]), _p(Rbo), _p(Tbo), C.byref(tdv), _p(Cgf), _p(Caf), C.byref(c),
+                                          _p(keep[1]))
+        camo = dict(cam); camo.update(fx=c.fx, fy=c.fy, cx=c.cx, cy=c.cy, d=[c.d[i] for i in range(len(cam.get("d", [])))])
+        return dict(Rsb=st[0:9].reshape(3, 3).T.copy(), Tsb=st[9:12].copy(), Vsb=st[12:15].copy(), bg=st[15:18].copy(),
+                    ba=st[18:21].copy(), Rsg=st[21:30].reshape(3, 3).T.copy(), Rbc=np.ascontiguousarray(Rbo), Tbc=Tbo, td=tdv.value,
+                    Cg=np.ascontiguousarray(Cgf), Ca=np.ascontiguousarray(Caf), cam=camo)
 
 
 _REFX = {}

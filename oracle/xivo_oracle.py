@@ -41,6 +41,8 @@ class Layout:
         # online-calibration builds (src/core.h:49-83): slots of td / Cg (Ca follows Cg) / the camera intrinsics, -1 / 0 = absent;
         # calib_layout() below derives them and group_begin the way the reference's Index enum does
         self.td, self.Cg, self.cam_begin, self.cam_dim = td, Cg, cam_begin, cam_dim
+        self.Ca = Cg + 9 if Cg >= 0 else -1
+        self.motion_size = Cg + 15 if Cg >= 0 else (td + 1 if td >= 0 else K_MOTION)   # Index::End = kMotionSize
         self.group_begin = group_begin
         self.n_groups = n_groups
         self.feature_begin = group_begin + 6 * n_groups
@@ -621,12 +623,15 @@ def oos_jacobian(Xs, obs, groups_R, groups_T, Rbc, Tbc, cam, layout):
 # a12/a14: covariance part of RK4Step (src/rk4.cpp:35-103) and
 # ComputeMotionJacobianAt (src/estimator.cpp:615-704), default build
 # ----------------------------------------------------------------------------
-def motion_jacobian(Rsb, bg, ba, gyro, accel, g_vec, Cg=None, Ca=None):
+def motion_jacobian(Rsb, bg, ba, gyro, accel, g_vec, Cg=None, Ca=None, layout=None):
+    """layout (online-calibration builds): F, G get layout.motion_size rows and, under USE_ONLINE_IMU_CALIB, the blocks
+    dWsb/dCg and dVsb/dCa of src/estimator.cpp:626-638, :674-688."""
     Cg = np.eye(3) if Cg is None else Cg
     Ca = np.eye(3) if Ca is None else Ca
+    nm = K_MOTION if layout is None else layout.motion_size
     gyro_calib = Cg @ gyro - bg
     accel_calib = Ca @ accel - ba
-    F = np.zeros((K_MOTION, K_MOTION)); G = np.zeros((K_MOTION, 12))
+    F = np.zeros((nm, nm)); G = np.zeros((nm, 12))
     dW_dW = -hat(gyro_calib)
     dV_dW = -Rsb @ hat(accel_calib)
     dV_dba = -Rsb
@@ -639,6 +644,30 @@ def motion_jacobian(Rsb, bg, ba, gyro, accel, g_vec, Cg=None, Ca=None):
             F[VSB + i, BA + j] = dV_dba[i, j]
             if j < 2:
                 F[VSB + i, WSG + j] = dV_dWsg[i, j]
+    if layout is not None and layout.Cg >= 0:
+        # :626-631 dWsb_dCg: row i carries the RAW gyro sample at columns 3 i .. 3 i + 2
+        dWsb_dCg = np.zeros((3, 9))
+        for i in range(3):
+            dWsb_dCg[i, 3 * i:3 * i + 3] = gyro
+        # :633-636 dV_dCa = dAB_dA<3,3>(accel) * dAB_dB<3,3>(Rsb) * dA_dAu<3>() with the index conventions of
+        # common/rodrigues.h:143-165 (D(p N + n, n M + m) += B(m, p)), :208-227 (D(p N + n, m P + p) = A(n, m)), :26-37
+        dV_dRCa = np.zeros((3, 9))
+        for n in range(3):
+            for m in range(3):
+                dV_dRCa[0 * 3 + n, n * 3 + m] += accel[m]
+        dRCa_dCafm = np.zeros((9, 9))
+        for n in range(3):
+            for pp in range(3):
+                for m in range(3):
+                    dRCa_dCafm[pp * 3 + n, m * 3 + pp] = Rsb[n, m]
+        dCafm_dCa = np.zeros((9, 6))
+        idx = 0
+        for i in range(3):
+            for j in range(i, 3):
+                dCafm_dCa[i * 3 + j, idx] = 1; idx += 1
+        dV_dCa = dV_dRCa @ dRCa_dCafm @ dCafm_dCa
+        F[WSB:WSB + 3, layout.Cg:layout.Cg + 9] = dWsb_dCg          # :674-679
+        F[VSB:VSB + 3, layout.Ca:layout.Ca + 6] = dV_dCa            # :680-684
     for j in range(3):
         G[WSB + j, j] = -1; G[BG + j, 6 + j] = 1; G[BA + j, 9 + j] = 1
         for i in range(3):
@@ -741,10 +770,10 @@ PD_TABLEAU = dict(
     b=[0.0862, 0.0, 0.6660, -0.7857, 0.9570, 0.0965, -0.0200])       # princedormand.cpp:195-200
 
 
-def integrator_step(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, Cg=None, Ca=None):
+def integrator_step(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, Cg=None, Ca=None, layout=None):
     """One RK4Step (rk4.cpp:35-103) / PrinceDormandStep (princedormand.cpp:85-221).
-    Returns (X_new, P_new)."""
-    nm = K_MOTION
+    Returns (X_new, P_new). layout: an online-calibration build's (kMotionSize = layout.motion_size)."""
+    nm = K_MOTION if layout is None else layout.motion_size
     Pmm = P[:nm, :nm]
     Ks, FKs, PKs = [], [], []
     for i in range(len(tab["b"])):
@@ -753,7 +782,7 @@ def integrator_step(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_ve
         if i > 0:
             V = sum(a * K for a, K in zip(tab["a"][i], Ks))
             compose_motion(X0, V, ga[:3], ga[3:], tab["c_step"][i] * dt, g_vec, Cg, Ca)
-        F, G = motion_jacobian(X0.Rsb, X0.bg, X0.ba, ga[:3], ga[3:], g_vec, Cg, Ca)
+        F, G = motion_jacobian(X0.Rsb, X0.bg, X0.ba, ga[:3], ga[3:], g_vec, Cg, Ca, layout)
         Ks.append(X0.Vsb.copy())
         if i == 0:
             FK = F.copy(); P0 = Pmm.copy()
@@ -771,10 +800,10 @@ def integrator_step(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_ve
     return Xn, Pn
 
 
-def integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, stepsize=0.002, Cg=None, Ca=None):
+def integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, stepsize=0.002, Cg=None, Ca=None, layout=None):
     """Fixed sub-stepping with the half-step tail trick (rk4.cpp:13-32, princedormand.cpp:62-81)."""
     if stepsize < 0:
-        return integrator_step(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, Cg, Ca)
+        return integrator_step(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, Cg, Ca, layout)
     total = 0.0
     gyro, accel = np.array(gyro0, float), np.array(accel0, float)
     while total < dt:
@@ -783,20 +812,22 @@ def integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab
             h = dt - total
         elif total + h + 0.5 * h > dt:
             h = 0.5 * h
-        X, P = integrator_step(X, P, gyro, accel, slope_gyro, slope_accel, h, Qimu, g_vec, tab, Cg, Ca)
+        X, P = integrator_step(X, P, gyro, accel, slope_gyro, slope_accel, h, Qimu, g_vec, tab, Cg, Ca, layout)
         gyro = gyro + slope_gyro * h
         accel = accel + slope_accel * h
         total += h
     return X, P
 
 
-def propagate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, Qmodel, g_vec, method="RK4", stepsize=0.002):
+def propagate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, Qmodel, g_vec, method="RK4", stepsize=0.002,
+              Cg=None, Ca=None, layout=None):
     """Estimator::Propagate's integration + P_mm += Qmodel (estimator.cpp:580-590); the IMU
-    slope bookkeeping of :556-575 is the caller's."""
+    slope bookkeeping of :556-575 is the caller's. layout / Cg / Ca: online-calibration builds (Qmodel kMotionSize square)."""
     tab = RK4_TABLEAU if method == "RK4" else PD_TABLEAU
-    X, P = integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, stepsize)
+    X, P = integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, stepsize, Cg, Ca, layout)
     P = P.copy()
-    P[:K_MOTION, :K_MOTION] += Qmodel
+    nm = K_MOTION if layout is None else layout.motion_size
+    P[:nm, :nm] += Qmodel
     return X, P
 
 
@@ -858,6 +889,22 @@ def absorb_error(st, err, layout, upd_groups, upd_feats):
     st["Rbc"] = st["Rbc"] @ so3_exp(err[WBC:WBC + 3])
     st["Tbc"] = st["Tbc"] + err[TBC:TBC + 3]
     st["Rsg"] = st["Rsg"] @ so3_exp(np.array([err[WSG], err[WSG + 1], 0.0]))
+    if getattr(layout, "td", -1) >= 0:                             # core.h:150-152 (USE_ONLINE_TEMPORAL_CALIB)
+        st["td"] = st["td"] + err[layout.td]
+    if getattr(layout, "Cg", -1) >= 0:                             # estimator.cpp:879-884 -> IMUState::operator+= (src/imu.cpp:7-21):
+        k = layout.Ca                                              # Ca's upper triangle row by row, then Cg row by row
+        for i in range(3):
+            for j in range(i, 3):
+                st["Ca"][i, j] += err[k]; k += 1
+        for i in range(3):
+            for j in range(3):
+                st["Cg"][i, j] += err[layout.Cg + 3 * i + j]
+    if getattr(layout, "cam_dim", 0) > 0:                          # estimator.cpp:886-890 -> A_*Camera::UpdateState
+        cam = st["cam"]                                            # (common/camera_autocalib.h): fx fy cx cy, then d in its own order
+        cam["fx"] += err[layout.cam_begin]; cam["fy"] += err[layout.cam_begin + 1]
+        cam["cx"] += err[layout.cam_begin + 2]; cam["cy"] += err[layout.cam_begin + 3]
+        for k in range(4, layout.cam_dim):
+            cam["d"][k - 4] += err[layout.cam_begin + k]
     st["counter"] = st.get("counter", 0) + 1                       # core.h:154-162
     if st["counter"] % ENFORCE_SO3_FREQ == 0:
         st["Rsb"] = quat_to_rot(rot_to_quat(st["Rsb"]))

@@ -1,7 +1,10 @@
-"""Online-calibration builds, measurement side (xivo_hip_set_calib): the td / Cg / bg / intrinsics blocks of
+"""Online-calibration builds (xivo_hip_set_calib). Measurement side: the td / Cg / bg / intrinsics blocks of
 Feature::ComputeJacobian (src/feature.cpp:592-609, :611-618, :632-651), their stacking by Feature::FillJacobianBlock
-(:664-670, :679-683), MH gating on the whole row and the update - against the oracle, whose calibration blocks are pinned
-to the reference's own text compiled with the three defines (tests/test_oracle_pinned.py)."""
+(:664-670, :679-683), MH gating on the whole row and the update. Motion side: Estimator::Propagate with the 24 / 38 / 39-
+dimensional motion block (ComposeMotion with imu_.Cg() / imu_.Ca(), the dWsb/dCg and dVsb/dCa columns of
+ComputeMotionJacobianAt, src/estimator.cpp:598-704) and AbsorbError's retraction of td / Cg / Ca / the intrinsics
+(src/estimator.cpp:875-890). All against the oracle, whose calibration code is pinned to the reference's own text
+compiled with the three defines (tests/test_oracle_pinned.py)."""
 import numpy as np
 import pytest
 
@@ -9,7 +12,7 @@ import xivo_oracle as orc
 from helpers import rel_fro, TOL_P, TOL_DX
 from scene_util import scene_arrays, spd
 from xivo_amd import synth
-from xivo_amd.lib import Context, calib_dtype
+from xivo_amd.lib import Context, calib_dtype, cam_intr, imu_dtype
 
 pytestmark = pytest.mark.gpu
 CAMS = {"pinhole": synth.PINHOLE, "equi": synth.EQUI, "radtan": synth.RADTAN, "atan": synth.ATAN}
@@ -30,6 +33,7 @@ def setup(name, temporal, imu, camera, B=3, ng=6, nf=14, seed=3):
                    Vsb=rng.normal(size=3), td=0.01 + 0.005 * b)
         poses[b]["Vsb"], poses[b]["bg"] = cal["Vsb"], cal["bg"]
         calib[b]["gyro"], calib[b]["Cg"], calib[b]["td"] = cal["gyro"], cal["Cg"].T.reshape(-1), cal["td"]
+        calib[b]["Ca"], calib[b]["intr"] = np.eye(3).reshape(-1), cam_intr(cam)
         cals.append(cal)
     ctx = Context(lay.N, 2 * nf, B)
     ctx.set_layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf, cam)
@@ -114,3 +118,173 @@ def test_calibration_off_again_and_unsupported_entries(built):
         ctx.upload_P(np.array([spd(lay.N, 5 + b) * 1e-4 for b in range(3)]))
         ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)
         assert ctx.last_path() == 1                                                             # compressed rows, sparse pipeline
+
+
+# ---- motion side ---------------------------------------------------------------------------------------------------------
+def motion_setup(temporal, imu_cal, camera_dim, B=3, ng=4, nf=8, seed=5, cam=synth.RADTAN):
+    lay = orc.calib_layout(ng, nf, temporal, imu_cal, camera_dim)
+    sc = synth.g_level(ng, nf, nf, B, seed=seed, cam=cam)
+    poses, groups, feats, xp = scene_arrays(sc, cam)
+    rng = np.random.default_rng(seed + 100)
+    calib = np.zeros(B, dtype=calib_dtype)
+    st, Cgs, Cas = [], [], []
+    for b in range(B):
+        X = orc.MotionState(sc["Rsb"][b], sc["Tsb"][b], rng.normal(size=3) * 0.5, rng.normal(size=3) * 0.01,
+                            rng.normal(size=3) * 0.05, orc.so3_exp(np.array([0.02, -0.03, 0.0])))
+        st.append(X)
+        poses[b]["Vsb"] = X.Vsb; poses[b]["bg"] = X.bg; poses[b]["ba"] = X.ba; poses[b]["Rsg"] = X.Rsg.T.reshape(-1)
+        Cg = np.eye(3) + 0.02 * rng.normal(size=(3, 3)) if imu_cal else np.eye(3)
+        Ca = np.triu(np.eye(3) + 0.02 * rng.normal(size=(3, 3))) if imu_cal else np.eye(3)
+        Cgs.append(Cg); Cas.append(Ca)
+        calib[b]["gyro"] = rng.normal(size=3) * 0.3; calib[b]["Cg"] = Cg.T.reshape(-1); calib[b]["Ca"] = Ca.T.reshape(-1)
+        calib[b]["td"] = 0.004 * (b + 1); calib[b]["intr"] = cam_intr(cam)
+    ctx = Context(lay.N, 2 * nf, B)
+    ctx.set_layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf, cam)
+    ctx.set_calib(lay.td, lay.Cg, lay.cam_begin, lay.cam_dim)
+    return lay, sc, poses, groups, feats, calib, st, Cgs, Cas, ctx
+
+
+@pytest.mark.parametrize("method", ["RK4", "PrinceDormand"])
+@pytest.mark.parametrize("temporal,imu_cal,camera_dim,motion", [(True, True, 9, 39), (True, False, 0, 24), (False, True, 0, 38),
+                                                                (True, True, 0, 39)])
+def test_propagate_with_calibration_columns(built, method, temporal, imu_cal, camera_dim, motion):
+    """Two IMU samples per filter (sub-stepping incl. the half-step tail), kMotionSize = 39 / 24 / 38: nominal state and P
+    against the oracle run sample by sample."""
+    lay, sc, poses, groups, feats, calib, st, Cgs, Cas, ctx = motion_setup(temporal, imu_cal, camera_dim)
+    assert lay.motion_size == motion
+    B, N, K = poses.shape[0], lay.N, 2
+    rng = np.random.default_rng(31)
+    P = np.array([spd(N, 70 + b) * 1e-3 for b in range(B)])
+    imu = np.zeros((B, K), dtype=imu_dtype)
+    imu["gyro"] = rng.normal(size=(B, K, 3)) * 0.3; imu["accel"] = rng.normal(size=(B, K, 3)) + np.array([0, 0, 9.8])
+    imu["slope_gyro"] = rng.normal(size=(B, K, 3)) * 5.0; imu["slope_accel"] = rng.normal(size=(B, K, 3)) * 20.0
+    imu["dt"] = (0.0047 * (1.0 + 0.1 * np.arange(B)))[:, None]
+    Qi = np.diag(rng.uniform(1e-6, 1e-4, 12)); A = rng.normal(size=(motion, motion)) * 1e-4; Qm = A @ A.T
+    g = np.array([0.0, 0.0, -9.796])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        with pytest.raises(RuntimeError):
+            ctx.propagate(imu, Qi, np.eye(23), g)            # the 23-dimensional entry refuses a calibration context
+        ctx.propagate_calib(imu, Qi, Qm, g, method=method, stepsize=0.002)
+        Pn = ctx.download_P()
+        pose_d, _, _ = ctx.get_scene()
+    for b in range(B):
+        Xr, Pr = st[b], P[b]
+        for k in range(K):
+            Xr, Pr = orc.propagate(Xr, Pr, imu["gyro"][b, k], imu["accel"][b, k], imu["slope_gyro"][b, k], imu["slope_accel"][b, k],
+                                   float(imu["dt"][b, k]), Qi, Qm, g, method=method, stepsize=0.002, Cg=Cgs[b], Ca=Cas[b], layout=lay)
+        assert rel_fro(Pn[b], Pr) < 1e-11
+        assert np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - Xr.Rsb).max() < 1e-12
+        assert np.abs(pose_d[b]["Tsb"] - Xr.Tsb).max() < 1e-12 and np.abs(pose_d[b]["Vsb"] - Xr.Vsb).max() < 1e-12
+        if imu_cal:   # the Cg / Ca columns are really in the Jacobian the oracle integrated
+            F1, _ = orc.motion_jacobian(st[b].Rsb, st[b].bg, st[b].ba, imu["gyro"][b, 0], imu["accel"][b, 0], g, Cgs[b], Cas[b], lay)
+            assert np.abs(F1[0:3, lay.Cg:lay.Cg + 9]).max() > 0.01 and np.abs(F1[6:9, lay.Ca:lay.Ca + 6]).max() > 1.0
+
+
+def test_absorb_error_retracts_the_calibration_state(built):
+    """xivo_hip_absorb_error on an online-calibration context: td, Ca's upper triangle, Cg, the nine radtan intrinsics move by
+    their dx components (src/core.h:150-152, src/imu.cpp:7-21, common/camera_autocalib.h:34-47); the Jacobians that follow use
+    the filter's own intrinsics."""
+    cam = synth.RADTAN
+    lay, sc, poses, groups, feats, calib, st, Cgs, Cas, ctx = motion_setup(True, True, 9, cam=cam)
+    B, N, F = poses.shape[0], lay.N, feats.shape[1]
+    rng = np.random.default_rng(8)
+    xp = np.array([[feats[b][i]["xp"] for i in range(F)] for b in range(B)])
+    with ctx:
+        ctx.upload_P(np.array([spd(N, 90 + b) * 1e-6 for b in range(B)]))
+        ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=False)
+        dx = ctx.get_err()
+        ctx.absorb_error()
+        cal_d = ctx.get_calib_state()
+        pose_d, _, feat_d = ctx.get_scene()
+        ctx.jacobians_instate()
+        J21, inn = ctx.get_jacobians()
+    for b in range(B):
+        sto = dict(Rsb=sc["Rsb"][b].copy(), Tsb=sc["Tsb"][b].copy(), Vsb=st[b].Vsb.copy(), bg=st[b].bg.copy(), ba=st[b].ba.copy(),
+                   Rbc=sc["Rbc"][b].copy(), Tbc=sc["Tbc"][b].copy(), Rsg=st[b].Rsg.copy(), td=float(calib[b]["td"]), Cg=Cgs[b].copy(),
+                   Ca=Cas[b].copy(), cam=dict(cam, d=list(cam["d"])), gR=sc["gR"][b].copy(), gT=sc["gT"][b].copy(),
+                   x=sc["x"][b].copy(), sind=sc["sind"][b])
+        orc.absorb_error(sto, dx[b], lay, range(lay.n_groups), range(F))
+        assert abs(cal_d[b]["td"] - sto["td"]) < 1e-15 and abs(dx[b][lay.td]) > 0
+        assert np.abs(cal_d[b]["Cg"].reshape(3, 3).T - sto["Cg"]).max() < 1e-15
+        assert np.abs(cal_d[b]["Ca"].reshape(3, 3).T - sto["Ca"]).max() < 1e-15
+        assert np.abs(np.tril(cal_d[b]["Ca"].reshape(3, 3).T, -1)).max() == 0
+        assert np.abs(cal_d[b]["intr"] - cam_intr(sto["cam"])).max() < 1e-12
+        assert np.abs(cal_d[b]["intr"] - cam_intr(cam)).max() > 0
+        assert np.abs(pose_d[b]["Tsb"] - sto["Tsb"]).max() < 1e-12
+        # the next linearisation projects with the filter's retracted intrinsics
+        cal = dict(gyro=calib[b]["gyro"], Cg=sto["Cg"], bg=sto["bg"], Vsb=sto["Vsb"], td=sto["td"])
+        for i in range(0, F, 3):
+            r = int(sc["ref"][b][i])
+            J, inn_o, _, _ = orc.compute_jacobian(sto["x"][i], xp[b][i], sto["gR"][r], sto["gT"][r], sto["Rsb"], sto["Tsb"], sto["Rbc"],
+                                                  sto["Tbc"], sto["cam"], lay, r, int(sc["sind"][b][i]), calib=cal)
+            assert np.abs(inn[b][i] - inn_o).max() < 1e-8
+
+
+def test_resident_loop_online_calibration(built):
+    """Three frames of Propagate -> ComputeInstateJacobians -> MHGating -> FilterUpdate -> AbsorbError of the full
+    online-calibration build (kMotionSize 39 + 9 radtan intrinsics), everything resident: P, the nominal state, td / Cg / Ca /
+    the intrinsics; only the IMU samples and last_gyro_ cross the boundary. Against the oracle run frame by frame."""
+    cam = synth.RADTAN
+    lay, sc, poses, groups, feats, calib, st, Cgs, Cas, ctx = motion_setup(True, True, 9, B=2, ng=5, nf=12, seed=9, cam=cam)
+    B, N, F, G = poses.shape[0], lay.N, feats.shape[1], lay.n_groups
+    rng = np.random.default_rng(17)
+    nm = lay.motion_size
+    P0 = np.array([spd(N, 40 + b) * 1e-6 for b in range(B)])
+    Qi = np.diag(rng.uniform(1e-6, 1e-4, 12)); A = rng.normal(size=(nm, nm)) * 1e-5; Qm = A @ A.T
+    g = np.array([0.0, 0.0, -9.796])
+    xp = np.array([[feats[b][i]["xp"] for i in range(F)] for b in range(B)])
+    frames = []
+    for k in range(3):
+        imu = np.zeros((B, 2), dtype=imu_dtype)
+        imu["gyro"] = rng.normal(size=(B, 2, 3)) * 0.05; imu["accel"] = rng.normal(size=(B, 2, 3)) * 0.1 + np.array([0, 0, 9.8])
+        imu["slope_gyro"] = rng.normal(size=(B, 2, 3)); imu["slope_accel"] = rng.normal(size=(B, 2, 3))
+        imu["dt"] = 0.0025
+        frames.append((imu, rng.normal(size=(B, 3)) * 0.3))
+    with ctx:
+        ctx.upload_P(P0); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        masks = []
+        for imu, gyro in frames:
+            ctx.set_calib_gyro(gyro)
+            ctx.propagate_calib(imu, Qi, Qm, g, method="PrinceDormand", stepsize=0.002)
+            ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)
+            assert (ctx.get_status() == 0).all()
+            masks.append(ctx.get_gate(F, B)[0].astype(bool))
+            ctx.absorb_error()
+        Pn = ctx.download_P(); cal_d = ctx.get_calib_state(); pose_d, grp_d, feat_d = ctx.get_scene()
+    for b in range(B):
+        s = dict(Rsb=sc["Rsb"][b].copy(), Tsb=sc["Tsb"][b].copy(), Vsb=st[b].Vsb.copy(), bg=st[b].bg.copy(), ba=st[b].ba.copy(),
+                 Rbc=sc["Rbc"][b].copy(), Tbc=sc["Tbc"][b].copy(), Rsg=st[b].Rsg.copy(), td=float(calib[b]["td"]), Cg=Cgs[b].copy(),
+                 Ca=Cas[b].copy(), cam=dict(cam, d=list(cam["d"])), gR=sc["gR"][b].copy(), gT=sc["gT"][b].copy(), x=sc["x"][b].copy(),
+                 sind=sc["sind"][b])
+        P = P0[b]
+        for k, (imu, gyro) in enumerate(frames):
+            X = orc.MotionState(s["Rsb"], s["Tsb"], s["Vsb"], s["bg"], s["ba"], s["Rsg"])
+            for j in range(2):
+                X, P = orc.propagate(X, P, imu["gyro"][b, j], imu["accel"][b, j], imu["slope_gyro"][b, j], imu["slope_accel"][b, j], 0.0025,
+                                     Qi, Qm, g, method="PrinceDormand", stepsize=0.002, Cg=s["Cg"], Ca=s["Ca"], layout=lay)
+            s["Rsb"], s["Tsb"], s["Vsb"] = X.Rsb, X.Tsb, X.Vsb
+            cal = dict(gyro=gyro[b], Cg=s["Cg"], bg=s["bg"], Vsb=s["Vsb"], td=s["td"])
+            Js, inns = [], []
+            for i in range(F):
+                r = int(sc["ref"][b][i])
+                J, inn, _, _ = orc.compute_jacobian(s["x"][i], xp[b][i], s["gR"][r], s["gT"][r], s["Rsb"], s["Tsb"], s["Rbc"], s["Tbc"],
+                                                    s["cam"], lay, r, int(sc["sind"][b][i]), calib=cal)
+                Js.append(J); inns.append(inn)
+            Js, inns = np.array(Js), np.array(inns)
+            m, _, _ = orc.mh_gate(orc.mh_distances(Js, P, inns, R_VIS), MH, MULT, 5)
+            assert np.array_equal(masks[k][b], m)
+            idx = np.nonzero(m)[0]
+            H, inn, dR = orc.stack_measurements(Js[idx], inns[idx], sc["ref"][b][idx], sc["sind"][b][idx], lay, R_VIS)
+            e, P, _ = orc.update_joseph(H, P, inn, dR)
+            orc.absorb_error(s, e, lay, range(G), idx)
+        assert rel_fro(Pn[b], P) < TOL_P
+        assert np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - s["Rsb"]).max() < 1e-9 and np.abs(pose_d[b]["Tsb"] - s["Tsb"]).max() < 1e-9
+        assert np.abs(pose_d[b]["Vsb"] - s["Vsb"]).max() < 1e-9 and np.abs(pose_d[b]["bg"] - s["bg"]).max() < 1e-9
+        assert abs(cal_d[b]["td"] - s["td"]) < 1e-9 and np.abs(cal_d[b]["Cg"].reshape(3, 3).T - s["Cg"]).max() < 1e-9
+        assert np.abs(cal_d[b]["Ca"].reshape(3, 3).T - s["Ca"]).max() < 1e-9
+        assert np.abs(cal_d[b]["intr"] - cam_intr(s["cam"])).max() < 1e-6
+        assert np.abs(cal_d[b]["intr"] - cam_intr(cam)).max() > 1e-9 and abs(cal_d[b]["td"] - calib[b]["td"]) > 1e-12
+        for i in range(F):
+            assert np.abs(feat_d[b][i]["x"] - s["x"][i]).max() < 1e-8

@@ -715,3 +715,79 @@ def test_golden_v4_compute_jacobian(build, name):
             assert np.nonzero(np.abs(M_).sum(0))[0].tolist() == cols.tolist()
             assert np.abs(M_[:, cols] - vals).max() / np.abs(vals).max() < 1e-12
         assert np.abs(inn - G4[k + "_inn"]).max() < 1e-10
+
+
+# ---- motion side of the online-calibration builds: golden_v5.npz + the extracted build live ------------------------------------
+G5 = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v5.npz"))
+
+
+def _v5():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_v5", os.path.join(os.path.dirname(__file__), "golden", "make_golden_v5.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def _oracle_calib_step(c, method, lay):
+    tab = orc.RK4_TABLEAU if method == "RK4" else orc.PD_TABLEAU
+    return orc.integrator_step(c["X"].copy(), c["P"], c["gy"], c["ac"], c["sg"], c["sa"], 0.004, c["Qimu"], c["g"], tab, c["Cg"], c["Ca"], lay)
+
+
+def _oracle_calib_absorb(c, m, lay):
+    X = c["X"]
+    st = dict(Rsb=X.Rsb.copy(), Tsb=X.Tsb.copy(), Vsb=X.Vsb.copy(), bg=X.bg.copy(), ba=X.ba.copy(), Rbc=c["Rbc"].copy(), Tbc=c["Tbc"].copy(),
+              Rsg=X.Rsg.copy(), td=c["td"], Cg=c["Cg"].copy(), Ca=c["Ca"].copy(), cam=dict(m.CAM, d=list(m.CAM["d"])),
+              gR=np.zeros((0, 3, 3)), gT=np.zeros((0, 3)), x=np.zeros((0, 3)), sind=[])
+    orc.absorb_error(st, c["err"], lay, [], [])
+    return st
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_golden_v5_calibration_motion_side(seed):
+    """the oracle's 39-dimensional integrator step and calibration absorb against stored outputs of the reference's own text
+    compiled with the three online-calibration defines (runs without oracle/_ref)"""
+    m = _v5()
+    lay = orc.calib_layout(15, 30, True, True, 9)
+    assert (lay.N, lay.motion_size, lay.Ca) == (m.N, m.NM, 33)
+    c = m.case(seed)
+    for method in ("RK4", "PrinceDormand"):
+        Xo, Po = _oracle_calib_step(c, method, lay)
+        k = f"s{seed}_{method}"
+        assert np.abs(Xo.Rsb - G5[k + "_Rsb"]).max() < 1e-14 and np.abs(Xo.Tsb - G5[k + "_Tsb"]).max() < 1e-14
+        assert np.abs(Xo.Vsb - G5[k + "_Vsb"]).max() < 1e-14
+        assert np.linalg.norm(Po[:m.NM] - G5[k + "_Ptop"]) / np.linalg.norm(G5[k + "_Ptop"]) < 1e-14
+        assert np.abs(c["w"] @ Po[m.NM:, :m.NM] - G5[k + "_Pleft_w"]).max() / np.abs(G5[k + "_Pleft_w"]).max() < 1e-13
+        # the Cg / Ca columns matter: the same step without them (default-build Jacobian in the 39 slots) is measurably different
+        lay0 = orc.calib_layout(15, 30, True, False, 9); lay0.motion_size = lay.motion_size
+        _, P0 = _oracle_calib_step(c, method, lay0)
+        assert np.linalg.norm(P0[:m.NM] - G5[k + "_Ptop"]) / np.linalg.norm(G5[k + "_Ptop"]) > 1e-9
+    st = _oracle_calib_absorb(c, m, lay)
+    k = f"s{seed}_absorb"
+    for name in ("Rsb", "Tsb", "Vsb", "bg", "ba", "Rsg", "Rbc", "Tbc", "Cg", "Ca"):
+        assert np.abs(st[name] - G5[f"{k}_{name}"]).max() < 1e-15, name
+    assert abs(st["td"] - G5[k + "_td"][0]) < 1e-17
+    intr = np.array([st["cam"]["fx"], st["cam"]["fy"], st["cam"]["cx"], st["cam"]["cy"]] + list(st["cam"]["d"]))
+    assert np.abs(intr - G5[k + "_intr"]).max() < 1e-13
+
+
+def test_extracted_calibration_build_motion_side_live():
+    """the same against the library itself when it is here (a fresh seed)"""
+    try:
+        import ref_binding
+        x = ref_binding.loadx("calib")
+    except (FileNotFoundError, OSError):
+        pytest.skip("oracle/_ref calibration build not built")
+    m = _v5()
+    lay = orc.calib_layout(15, 30, True, True, 9)
+    assert x.index_Ca() == lay.Ca and x.calib_slots()[4] == lay.motion_size
+    c = m.case(9)
+    for method in ("RK4", "PrinceDormand"):
+        R, T, V, Pn = x.integrator_step(method, c["X"], c["P"], c["gy"], c["ac"], c["sg"], c["sa"], 0.004, c["Qimu"], c["g"], c["Cg"], c["Ca"])
+        Xo, Po = _oracle_calib_step(c, method, lay)
+        assert np.abs(R - Xo.Rsb).max() < 1e-14 and np.abs(T - Xo.Tsb).max() < 1e-14 and np.abs(V - Xo.Vsb).max() < 1e-14
+        assert np.linalg.norm(Pn - Po) / np.linalg.norm(Pn) < 1e-14
+    o = x.absorb_motion_calib(c["X"], c["Rbc"], c["Tbc"], c["td"], c["Cg"], c["Ca"], m.CAM, c["err"])
+    st = _oracle_calib_absorb(c, m, lay)
+    for name in ("Rsb", "Tsb", "Vsb", "bg", "ba", "Rsg", "Rbc", "Tbc", "Cg", "Ca"):
+        assert np.abs(st[name] - o[name]).max() < 1e-15, name
+    assert st["td"] == o["td"]

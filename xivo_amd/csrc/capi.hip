@@ -70,7 +70,8 @@ struct xivo_hip_ctx {
   xivo_cam cam{};
   bool have_layout = false;
   // online-calibration builds, measurement side (xivo_hip_set_calib): extra Jacobian blocks, dense stacking
-  bool calib_on = false;
+  bool calib_on = false;       // measurement side of an online-calibration build (td / Cg / bg / intrinsics blocks)
+  bool calib_motion = false;   // motion side: kMotionSize > 23 (xivo_hip_propagate_calib)
   xivo_calib_layout cl{-1, -1, 0, 0};
   xivo_calib_in* calib = nullptr;   // [Bmax]
   double* Jc = nullptr;             // [Bmax x Fmax x 44]
@@ -1462,16 +1463,19 @@ int xivo_hip_get_jacobians(xivo_hip_ctx* c, int b0, int nb, double* J, double* i
 int xivo_hip_set_calib(xivo_hip_ctx* c, const xivo_calib_layout* layout) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout) return XIVO_HIP_ERR_INVALID;
-  if (!layout) { c->calib_on = false; c->cl = xivo_calib_layout{-1, -1, 0, 0}; return XIVO_HIP_OK; }
+  if (!layout) { c->calib_on = false; c->calib_motion = false; c->cl = xivo_calib_layout{-1, -1, 0, 0}; return XIVO_HIP_OK; }
   const xivo_calib_layout& l = *layout;
   const int N = c->N;
-  if (l.td >= N || (l.Cg >= 0 && (l.td < 0 || l.Cg + 9 > N)) || l.cam_dim < 0 || l.cam_dim > 9 ||
+  if (l.td >= N || (l.Cg >= 0 && l.Cg + 15 > N) || l.cam_dim < 0 || l.cam_dim > 9 ||
       (l.cam_dim > 0 && (l.cam_begin < 0 || l.cam_begin + l.cam_dim > N)))
     return XIVO_HIP_ERR_INVALID;
+  // slots as src/core.h:40-75 numbers them: td right behind Wsg, Cg behind td (or Wsg), the intrinsics behind the motion block
+  if ((l.td >= 0 && l.td != 23) || (l.Cg >= 0 && l.Cg != (l.td >= 0 ? 24 : 23))) return XIVO_HIP_ERR_INVALID;
   if (!c->calib) { int rc = dev_alloc(&c->calib, (size_t)c->Bmax); if (rc) return rc; }
   if (!c->Jc && c->Fmax > 0) { int rc = dev_alloc(&c->Jc, (size_t)c->Bmax * c->Fmax * 44); if (rc) return rc; }
   c->cl = l;
-  c->calib_on = l.td >= 0 || l.cam_dim > 0;
+  c->calib_on = l.td >= 0 || l.cam_dim > 0;       // measurement side: blocks beyond the default build's (the Cg / bg blocks sit inside the td block)
+  c->calib_motion = l.td >= 0 || l.Cg >= 0;       // motion side: kMotionSize > 23
   return XIVO_HIP_OK;
 }
 
@@ -1481,6 +1485,26 @@ int xivo_hip_set_calib_state(xivo_hip_ctx* c, int b0, int nb, const xivo_calib_i
   if (nb == 0) return XIVO_HIP_OK;
   HIP_TRY(hipMemcpyAsync(c->calib + b0, calib, (size_t)nb * sizeof(xivo_calib_in), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));    // host buffer is only borrowed for the call
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_set_calib_gyro(xivo_hip_ctx* c, int b0, int nb, const double* gyro3) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (bad_range(c, b0, nb) || !gyro3 || !c->calib) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  static_assert(offsetof(xivo_calib_in, gyro) == 0, "gyro leads xivo_calib_in");
+  HIP_TRY(hipMemcpy2DAsync(c->calib + b0, sizeof(xivo_calib_in), gyro3, 3 * sizeof(double), 3 * sizeof(double), (size_t)nb,
+                           hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return XIVO_HIP_OK;
+}
+
+int xivo_hip_get_calib_state(xivo_hip_ctx* c, int b0, int nb, xivo_calib_in* calib) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (bad_range(c, b0, nb) || !calib || !c->calib) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  HIP_TRY(hipMemcpyAsync(calib, c->calib + b0, (size_t)nb * sizeof(xivo_calib_in), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return XIVO_HIP_OK;
 }
 
@@ -1633,6 +1657,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   }
   OosArgs a{};
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
+  a.calib = c->calib_on ? c->calib : nullptr; a.cam_dim = c->calib_on ? c->cl.cam_dim : 0;
   a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
   if (skip_HT(c) || mixed) { a.mb.HT = nullptr; c->ht_valid = false; }
   c->oos_row0 = c->M; c->oos_R = Roos;
@@ -1876,7 +1901,7 @@ int xivo_hip_subfilter_update(xivo_hip_ctx* c, int b0, int nb, int n, xivo_subfi
   {
     StageTimer st(c, ST_OTHER, 0.0, "subfilter_kernel");
     if (launch_subfilter(c->sub, n, c->poses + b0, c->groups + (size_t)b0 * c->lay.n_groups, c->lay.n_groups, c->cam,
-                         *opts, nb, c->stream))
+                         *opts, nb, c->stream, c->calib_on ? c->calib + b0 : nullptr, c->calib_on ? c->cl.cam_dim : 0))
       return XIVO_HIP_ERR_HIP;
   }
   HIP_TRY(hipMemcpyAsync(feats, c->sub, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1919,6 +1944,7 @@ int xivo_hip_absorb_error(xivo_hip_ctx* c, int B) {
   AbsorbArgs a{};
   a.poses = c->poses; a.groups = c->groups; a.feats = c->feats; a.mask = c->mask; a.err = c->err; a.strideErr = c->Np;
   a.lay = c->lay; a.F = c->F; a.Fmax = c->Fmax; a.batch = B; a.counter = c->absorb_count; a.status = c->status;
+  a.calib = (c->calib_on || c->calib_motion) ? c->calib : nullptr; a.cl = c->cl;
   StageTimer st(c, ST_OTHER, 0.0);
   return launch_absorb_error(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
@@ -2031,7 +2057,7 @@ int xivo_hip_get_H(xivo_hip_ctx* c, int b, int* M_out, double* H, int ldh, doubl
 // ------------------------------------------------------------------ propagation tail
 int xivo_hip_propagate_cov(xivo_hip_ctx* c, int b0, int nb, int nm, const double* Phi, const double* Pmm) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
-  if (bad_range(c, b0, nb) || nm <= 0 || nm > 32 || nm > c->N || !Phi || !Pmm) return XIVO_HIP_ERR_INVALID;
+  if (bad_range(c, b0, nb) || nm <= 0 || nm > 40 || nm > c->N || !Phi || !Pmm) return XIVO_HIP_ERR_INVALID;
   if (nb == 0) return XIVO_HIP_OK;
   const size_t per = (size_t)nm * nm;
   int rc = ensure_staging(c, 2 * per * nb);
@@ -2051,6 +2077,7 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || !imu || !o || n_imu <= 0 || c->N < 23 || c->lay.group_begin < 23)
     return XIVO_HIP_ERR_INVALID;
+  if (c->calib_motion) return XIVO_HIP_ERR_UNSUPPORTED;   // kMotionSize > 23: xivo_hip_propagate_calib
   if (nb == 0) return XIVO_HIP_OK;
   for (size_t b = 0; b < (size_t)nb * n_imu; ++b)
     if (!(imu[b].dt > 0.0) || (o->stepsize >= 0 && o->stepsize < 1e-6)) return XIVO_HIP_ERR_INVALID;
@@ -2081,6 +2108,46 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
     HIP_TRY((hipError_t)launch_propagate_cov(c->P, c->sP, c->Np, c->N, c->Np, 23, dPhi, dPmm, b0, nb, c->stream));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));   // imu / opts are borrowed host memory
+  return XIVO_HIP_OK;
+}
+
+// Estimator::Propagate of an online-calibration build (kMotionSize = 24 / 38 / 39): propagate_state_calib_kernel + the
+// run-time-nm tail
+int xivo_hip_propagate_calib(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_imu_in* imu, const xivo_prop_opts* o,
+                             const double* Qmodel) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || !imu || !o || !Qmodel || n_imu <= 0 || !c->calib_motion || !c->calib)
+    return XIVO_HIP_ERR_INVALID;
+  const int nm = c->cl.Cg >= 0 ? c->cl.Cg + 15 : c->cl.td + 1;
+  if (nm > 40 || c->N < nm || c->lay.group_begin < nm) return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  for (size_t b = 0; b < (size_t)nb * n_imu; ++b)
+    if (!(imu[b].dt > 0.0) || (o->stepsize >= 0 && o->stepsize < 1e-6)) return XIVO_HIP_ERR_INVALID;
+  const size_t per = (size_t)nm * nm;
+  const size_t imu_d = ((size_t)nb * n_imu * sizeof(xivo_imu_in) + 7) / 8;      // in doubles
+  int rc = ensure_staging(c, 2 * per * nb + 144 + per + imu_d);
+  if (rc) return rc;
+  double* dPhi = c->staging; double* dPmm = dPhi + per * nb; double* dQi = dPmm + per * nb; double* dQm = dQi + 144;
+  xivo_imu_in* dImu = reinterpret_cast<xivo_imu_in*>(dQm + per);
+  HIP_TRY(hipMemcpyAsync(dQi, o->Qimu, 144 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(dQm, Qmodel, per * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(dImu, imu, (size_t)nb * n_imu * sizeof(xivo_imu_in), hipMemcpyHostToDevice, c->stream));
+  PropStateArgs a{};
+  a.poses = c->poses + b0; a.imu = dImu; a.n_imu = n_imu; a.Qimu = dQi; a.Qmodel = dQm;
+  a.g[0] = o->g[0]; a.g[1] = o->g[1]; a.g[2] = o->g[2]; a.method = o->method; a.stepsize = o->stepsize;
+  a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
+  a.nm = nm; a.iCg = c->cl.Cg; a.calib = c->calib + b0;
+  {
+    char plabel[64];
+    snprintf(plabel, sizeof(plabel), "propagate_state_calib_kernel<%d>", a.method ? 7 : 4);
+    StageTimer st(c, ST_PROP_STATE, 0.0, plabel);
+    HIP_TRY((hipError_t)launch_propagate_state_calib(a, c->stream));
+  }
+  {
+    StageTimer st(c, ST_PROP_TAIL, 0.0, "propagate_cov_kernel", (double)nb * (4.0 * nm * c->N + 2.0 * per) * sizeof(double));
+    HIP_TRY((hipError_t)launch_propagate_cov(c->P, c->sP, c->Np, c->N, c->Np, nm, dPhi, dPmm, b0, nb, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));   // imu / opts / Qmodel are borrowed host memory
   return XIVO_HIP_OK;
 }
 

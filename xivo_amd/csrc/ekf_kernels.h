@@ -100,7 +100,8 @@ int launch_stack(const StackArgs& a, hipStream_t s);
 
 // Feature::SubfilterUpdate + candidate tests (feature.cpp:246-297, options.cpp:10-33)
 int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses, const xivo_group_in* groups,
-                     int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s);
+                     int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s,
+                     const xivo_calib_in* calib = nullptr, int cam_dim = 0);
 
 // Estimator::Propagate state + covariance stages (rk4.cpp, princedormand.cpp, estimator.cpp:598-704): one wave per
 // filter; writes the accumulated transition Phi and the new P_mm (23 x 23 each, column-major) for the tail kernel
@@ -110,10 +111,14 @@ struct PropStateArgs {
   const double* Qimu; const double* Qmodel;         // device copies
   double g[3]; int method; double stepsize;
   const double* P; long strideP; int ldp;           // resident covariance (offset to b0)
-  double* Phi_out; double* Pmm_out;                 // [nb][529]
+  double* Phi_out; double* Pmm_out;                 // [nb][529] ([nb][nm * nm] for the calibration kernel)
   int batch;
+  // online-calibration builds (launch_propagate_state_calib): motion size, slot of Cg (-1: none; Ca follows at + 9), the
+  // resident calibration state (offset to b0); Qmodel is nm x nm
+  int nm, iCg; const xivo_calib_in* calib;
 };
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s);
+int launch_propagate_state_calib(const PropStateArgs& a, hipStream_t s);
 bool propagate_uses_wave_kernel();   // one wave per filter (default) or the four-wave workgroup kernel (XIVO_HIP_PROP_WG)
 
 // xivo::Givens / xivo::QR (helpers.cpp:27-101), one wave per problem, in place
@@ -130,6 +135,7 @@ struct AbsorbArgs {
   const int* status;   // [batch] factorisation status of the update that produced err: non-zero -> nothing is absorbed, err <- 0
   const unsigned long long* group_mask;   // optional [batch]: bit g = group slot g is in instate_groups_ (null: every slot)
   int* counter;   // [batch] State::counter (core.h:120-122): absorbs so far, drives the periodic SO3 re-normalisation
+  xivo_calib_in* calib; xivo_calib_layout cl;   // online-calibration builds: td / Cg / Ca / intrinsics retracted too (null: default build)
 };
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s);
 
@@ -165,6 +171,7 @@ struct OosArgs {
   const xivo_oos_in* feats; int n_oos;          // [batch x n_oos]
   const xivo_pose_in* poses; const xivo_group_in* groups;
   xivo_layout lay; xivo_cam cam; MeasBuffers mb;
+  const xivo_calib_in* calib; int cam_dim;   // online camera calibration: per-filter intrinsics (null / 0: the context's camera)
   int row0;            // first free row (after the in-state rows)
   int Mp, Np, batch; double Roos;
   int* rows_out;       // [batch]

@@ -242,14 +242,28 @@ __device__ __forceinline__ void project_pixel(const xivo_cam& cam, const V3& Xcn
     for (int j = 0; j < 3; ++j) dxp_dXcn[i][j] = Jc[i][0] * d[0][j] + Jc[i][1] * d[1][j];
 }
 
+// Online camera calibration (USE_ONLINE_CAMERA_CALIB): the intrinsics are state, one set per filter, resident in
+// xivo_calib_in::intr (fx fy cx cy d[0..4] - the order of the state slots); the context's xivo_cam names the model
+__device__ __forceinline__ xivo_cam filter_cam(const xivo_cam& cam, const xivo_calib_in* calib, int cam_dim, int filt) {
+  xivo_cam c = cam;
+  if (calib && cam_dim > 0) {
+    const double* p = calib[filt].intr;
+    c.fx = p[0]; c.fy = p[1]; c.cx = p[2]; c.cy = p[3];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c.d[k] = p[4 + k];
+  }
+  return c;
+}
+
 // ---------------------------------------------------------------- in-state Jacobian
 // One thread per (filter, feature). Output J is 2 x 21 row-major with block
 // order [Wsb Tsb Wbc Tbc Wsbr Tsbr x] (the 7 structural non-zero blocks of
 // Feature::J_, feature.cpp:623-645).
-__global__ void jac_instate_kernel(SceneBuffers sb, xivo_layout lay, xivo_cam cam, int batch) {
+__global__ void jac_instate_kernel(SceneBuffers sb, xivo_layout lay, xivo_cam cam_ctx, int batch) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= batch * sb.F) return;
   const int filt = t / sb.F, f = t % sb.F;
+  const xivo_cam cam = filter_cam(cam_ctx, sb.calib, sb.cl.cam_dim, filt);
   const xivo_pose_in& pose = sb.poses[filt];
   const xivo_feat_in& ft = sb.feats[(long)filt * sb.Fmax + f];
   if (ft.sind < 0) {   // absent entry (ragged batches): no Jacobian, no innovation
@@ -608,11 +622,12 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
 // One thread per (filter, feature): every product below is 3x3 / 2x3 / 2x2 and is written in the
 // reference's association order (feature.cpp:246-297).
 __global__ void subfilter_kernel(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses,
-                                 const xivo_group_in* groups, int n_groups, xivo_cam cam, xivo_subfilter_opts o,
-                                 int batch) {
+                                 const xivo_group_in* groups, int n_groups, xivo_cam cam_ctx, xivo_subfilter_opts o,
+                                 int batch, const xivo_calib_in* calib, int cam_dim) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= batch * n) return;
   const int filt = t / n;
+  const xivo_cam cam = filter_cam(cam_ctx, calib, cam_dim, filt);
   xivo_subfilter_feat& f = feats[t];
   const xivo_pose_in& pose = poses[filt];
   const xivo_group_in& grp = groups[(long)filt * n_groups + f.ref_sind];
@@ -958,6 +973,18 @@ __global__ __launch_bounds__(256) void absorb_error_kernel(AbsorbArgs a) {
     for (int i = 0; i < 3; ++i) {
       X.Tsb[i] += err[3 + i]; X.Vsb[i] += err[6 + i]; X.bg[i] += err[9 + i]; X.ba[i] += err[12 + i]; X.Tbc[i] += err[18 + i];
     }
+    if (a.calib) {                                       // online-calibration builds
+      xivo_calib_in& cb = a.calib[filt];
+      if (a.cl.td >= 0) cb.td += err[a.cl.td];           // core.h:150-152
+      if (a.cl.Cg >= 0) {                                // estimator.cpp:879-884 -> IMUState::operator+= (imu.cpp:7-21): Ca's upper
+        int k = a.cl.Cg + 9;                             // triangle row by row, then Cg row by row (both stored column-major)
+        for (int i = 0; i < 3; ++i)
+          for (int j = i; j < 3; ++j) cb.Ca[i + 3 * j] += err[k++];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) cb.Cg[i + 3 * j] += err[a.cl.Cg + 3 * i + j];
+      }
+      for (int k = 0; k < a.cl.cam_dim && k < 9; ++k) cb.intr[k] += err[a.cl.cam_begin + k];   // estimator.cpp:886-890
+    }
     if (a.counter && ++a.counter[filt] % 50 == 0) {      // kEnforceSO3Freq (core.h:111,154-162)
       rot_normalize(X.Rsb);
       rot_normalize(X.Rbc);
@@ -1028,7 +1055,7 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
     for (int i = 0; i < 3; ++i) d.v[i] = Xb.v[i] - pose.Tbc[i];
     const V3 Xcn = m3_mulv(Rbc_t, d);
     double xp[2], dxp_dXcn[2][3];
-    project_pixel(a.cam, Xcn, xp, dxp_dXcn);
+    project_pixel(filter_cam(a.cam, a.calib, a.cam_dim, filt), Xcn, xp, dxp_dXcn);
     double t1[2][3], out[2][3];
     m23_mul(dxp_dXcn, Rbc_t, t1);                 // dxp_dXcn * dXcn_dXb
     m23_mul(t1, Rsb_t, out);                      // * dXb_dXs -> Hf        (oos.cpp:74-75)
@@ -1214,7 +1241,7 @@ __global__ __launch_bounds__(256) void propagate_cov_kernel(double* Pall, long s
   extern __shared__ double sPhi[];  // nm*nm, column-major
   for (int e = tid; e < nm * nm; e += 256) sPhi[e] = Phi[e];
   __syncthreads();
-  constexpr int MAXM = 32;
+  constexpr int MAXM = 40;
   for (int j = nm + tid; j < N; j += 256) {
     double col[MAXM], row[MAXM];
     for (int k = 0; k < nm; ++k) { col[k] = P[k + (long)j * ldp]; row[k] = P[j + (long)k * ldp]; }
@@ -1735,6 +1762,315 @@ __global__ __launch_bounds__(256, NS == 4 ? 3 : 2) void propagate_state_kernel(P
   // results for the tail kernel; nominal state back
   for (int e = lane; e < NN; e += NT) {
     const int i = e % NM, j = e / NM;
+    a.Pmm_out[(long)filt * NN + e] = Pmm[e];
+    a.Phi_out[(long)filt * NN + e] = i < FR ? Phi[i + FR * j] : (i == j ? 1.0 : 0.0);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pose.Tsb[i] = nom[9 + i]; pose.Vsb[i] = nom[12 + i];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pose.Rsb[i + 3 * j] = nom[3 * i + j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- propagation, online-calibration builds
+// The reference's USE_ONLINE_TEMPORAL_CALIB / USE_ONLINE_IMU_CALIB builds (src/core.h:49-75) carry td, Cg (9) and Ca (6) in the
+// motion block: kMotionSize = 24 / 38 / 39, ComposeMotion uses imu_.Cg() / imu_.Ca() (estimator.cpp:603-604) and
+// ComputeMotionJacobianAt adds dWsb/dCg (:626-631, :674-679) and dVsb/dCa (:633-636, :680-684). The rows of F that are not
+// identically zero are still the nine of Wsb / Tsb / Vsb, so the products keep the shape of the default-build kernel above -
+// F P0 is 9 x nm, P0 F^T is nm x 9, FK_q has nine rows, G Q G^T the same 12 x 12 support - but the nine rows are held DENSE
+// (nm columns each, structural zeros multiplied through: 0 * x adds +0.0 in the same ascending-k sums) and nm is a run-time
+// value. One workgroup of 256 threads per filter, everything in LDS (153 KB for nm = 39 with the seven Dormand-Prince
+// stages: one workgroup per CU). Not a tuned kernel: these builds are off the metric path.
+__device__ __forceinline__ void compose_motion_calib_dev(MotionRegs& X, const V3& V, const V3& gyro, const V3& accel, double dt,
+                                                         const V3& Rg, const M3& Cg, const M3& Ca) {
+  const V3 cg = m3_mulv(Cg, gyro), ca = m3_mulv(Ca, accel);
+  V3 gc, ac;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { gc.v[i] = cg.v[i] - X.bg.v[i]; ac.v[i] = ca.v[i] - X.ba.v[i]; }   // :603-604
+  const V3 Ra = m3_mulv(X.Rsb, ac);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    X.Tsb.v[i] += V.v[i] * dt;                                   // :608
+    X.Vsb.v[i] += (Ra.v[i] + Rg.v[i]) * dt;                      // :609
+  }
+  X.Rsb = m3_mul(X.Rsb, so3_exp_small(gc.v[0] * dt, gc.v[1] * dt, gc.v[2] * dt));   // :610
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void propagate_state_calib_kernel(PropStateArgs a) {
+  constexpr int NT = 256, FR = 9, JS = 60;   // JS: doubles per stage of published Jacobian blocks
+  const int nm = a.nm, NN = nm * nm, NF = FR * nm, iCg = a.iCg, iCa = iCg >= 0 ? iCg + 9 : -1;
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x, filt = blockIdx.x;
+  const RkTableau& tab = kTableau[NS == 4 ? 0 : 1];
+  double* Pmm = sm;              // P_mm at the start of the sub-step
+  double* P0 = Pmm + NN;
+  double* PKs = P0 + NN;         // [NS][nm x nm]
+  double* PhiA = PKs + NS * NN;  // rows < 9 of the accumulated transition ([i + 9 j]; the other rows stay identity rows)
+  double* PhiB = PhiA + NF;
+  double* S1 = PhiB + NF;        // [9 x nm] sum a_q FK_q, later rows < 9 of I + FK h
+  double* F9 = S1 + NF;          // [9 x nm] the non-zero rows of F of the current stage, dense
+  double* FPs = F9 + NF;         // [9 x nm]  F P0
+  double* PFs = FPs + NF;        // [nm x 9]  P0 F^T ([i + nm j])
+  double* FKs = PFs + NF;        // [NS][9 x nm]
+  double* GQG = FKs + NS * NF;   // [12 x 12] support of G Q G^T: rows / cols (Wsb, Vsb, bg, ba)
+  double* Q = GQG + 144;
+  double* GQc = Q + 144;         // [12 x 12] the non-zero rows of G Q
+  double* nom = GQc + 144;       // Rsb[9] row-major, Tsb, Vsb, bg, ba, Rsg g (3 each: 9..23), gyro, accel, slope_gyro, slope_accel
+                                 // (24..35), Cg[9], Ca[9] row-major (36..53)
+  double* sKs = nom + 64;        // [NS][3] stage velocities
+  double* Jms = sKs + 24;        // [NS][JS]: dW/dW, dV/dW, -Rsb, dV/dWsg (3 x 3 row-major each), raw gyro (3), dV/dCa (3 x 6)
+
+  const double* Pg = a.P + (long)filt * a.strideP;
+  for (int e = lane; e < NN; e += NT) Pmm[e] = Pg[(e % nm) + (long)(e / nm) * a.ldp];
+  for (int e = lane; e < NF; e += NT) PhiA[e] = (e % FR) == (e / FR) ? 1.0 : 0.0;
+  for (int e = lane; e < NS * NF; e += NT) FKs[e] = 0.0;        // finite values under the tableau's zero coefficients
+  for (int e = lane; e < NS * NN; e += NT) PKs[e] = 0.0;
+  double* Phi = PhiA;
+  double* PhiN = PhiB;
+  for (int e = lane; e < 144; e += NT) {
+    const double q = a.Qimu[e];
+    Q[e] = q;
+    const int r = e % 12;     // rows of G Q that do not depend on the state: Wsb = -Q[0:3,:], bg = Q[6:9,:], ba = Q[9:12,:]
+    if (r < 3) GQc[e] = -q;
+    else if (r >= 6) GQc[e] = q;
+  }
+  xivo_pose_in& pose = a.poses[filt];
+  const V3 gv{{a.g[0], a.g[1], a.g[2]}};
+  if (lane == 0) {
+    const V3 Rg0 = m3_mulv(m3_from_colmajor(pose.Rsg), gv);
+    const xivo_calib_in& cb = a.calib[filt];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        nom[3 * i + j] = pose.Rsb[i + 3 * j];
+        nom[36 + 3 * i + j] = iCg >= 0 ? cb.Cg[i + 3 * j] : (i == j ? 1.0 : 0.0);
+        nom[45 + 3 * i + j] = iCg >= 0 ? cb.Ca[i + 3 * j] : (i == j ? 1.0 : 0.0);
+      }
+      nom[9 + i] = pose.Tsb[i]; nom[12 + i] = pose.Vsb[i]; nom[15 + i] = pose.bg[i]; nom[18 + i] = pose.ba[i];
+      nom[21 + i] = Rg0.v[i];
+    }
+  }
+  auto load_nominal = [&](MotionRegs& X, V3& Rg, M3& Cg, M3& Ca) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { X.Rsb.m[i][j] = nom[3 * i + j]; Cg.m[i][j] = nom[36 + 3 * i + j]; Ca.m[i][j] = nom[45 + 3 * i + j]; }
+      X.Tsb.v[i] = nom[9 + i]; X.Vsb.v[i] = nom[12 + i]; X.bg.v[i] = nom[15 + i]; X.ba.v[i] = nom[18 + i];
+      Rg.v[i] = nom[21 + i];
+    }
+  };
+  __syncthreads();
+
+  const xivo_imu_in* imu_f = a.imu + (long)filt * a.n_imu;
+  for (int smp = 0; smp < a.n_imu; ++smp) {
+    if (lane < 3) {
+      nom[24 + lane] = imu_f[smp].gyro[lane]; nom[27 + lane] = imu_f[smp].accel[lane];
+      nom[30 + lane] = imu_f[smp].slope_gyro[lane]; nom[33 + lane] = imu_f[smp].slope_accel[lane];
+    }
+    const double dt = imu_f[smp].dt;
+    __syncthreads();
+    double total = 0.0;
+    while (total < dt || a.stepsize < 0) {     // rk4.cpp:13-32, princedormand.cpp:62-81
+      double h = a.stepsize;
+      if (a.stepsize < 0) h = dt;
+      else if (total + h > dt) h = dt - total;
+      else if (total + h + 0.5 * h > dt) h = 0.5 * h;
+
+      // -- nominal pre-pass: thread st evaluates stage st (ComposeMotion + ComputeMotionJacobianAt, estimator.cpp:598-704)
+      if (lane < NS) {
+        const int st = lane;
+        MotionRegs X0; V3 Rg; M3 Cg, Ca;
+        load_nominal(X0, Rg, Cg, Ca);
+        const double ti = tab.c_imu[st] * h;
+        V3 gi, ai;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { gi.v[i] = nom[24 + i] + nom[30 + i] * ti; ai.v[i] = nom[27 + i] + nom[33 + i] * ti; }
+        if (st > 0) {
+          const V3 V0{{0, 0, 0}};   // the a_ij-weighted velocities only move Tsb, which no Jacobian reads
+          compose_motion_calib_dev(X0, V0, gi, ai, tab.c_step[st] * h, Rg, Cg, Ca);
+        }
+        const V3 cg = m3_mulv(Cg, gi), ca = m3_mulv(Ca, ai);
+        V3 gc, ac;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { gc.v[i] = cg.v[i] - X0.bg.v[i]; ac.v[i] = ca.v[i] - X0.ba.v[i]; }
+        const M3 w_dW_dW = m3_neg(hat(gc));
+        const M3 w_dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));
+        const M3 w_dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));
+        const M3 w_nR = m3_neg(X0.Rsb);
+        double* Jm = Jms + st * JS;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          sKs[3 * st + i] = X0.Vsb.v[i];
+          Jm[36 + i] = gi.v[i];                                  // :626-631: the RAW gyro sample fills dWsb/dCg
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            Jm[3 * i + j] = w_dW_dW.m[i][j]; Jm[9 + 3 * i + j] = w_dV_dW.m[i][j];
+            Jm[18 + 3 * i + j] = w_nR.m[i][j]; Jm[27 + 3 * i + j] = w_dV_dWsg.m[i][j];
+          }
+        }
+        // :633-636 dV_dCa = dAB_dA<3,3>(accel) dAB_dB<3,3>(Rsb) dA_dAu<3>() with the index conventions of common/rodrigues.h
+        // (:143-165 row index p N + n against :208-227 row index p N + n of a COLUMN-major vec): what survives is
+        // dV_dCa(n, u(m, n)) = (Rsb^T accel)(m) for m <= n, u = the upper-triangle counter of dA_dAu (row by row)
+        V3 w;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v = fma(ai.v[k], X0.Rsb.m[k][m], v);
+          w.v[m] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 18; ++e) Jm[39 + e] = 0.0;
+        {
+          int u = 0;
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int n = m; n < 3; ++n) { Jm[39 + 6 * n + u] = w.v[m]; ++u; }
+        }
+      }
+      __syncthreads();
+      // the sub-step of the nominal state itself
+      if (lane == 0) {
+        MotionRegs X; V3 Rg; M3 Cg, Ca;
+        load_nominal(X, Rg, Cg, Ca);
+        V3 ge, ae, Kt{{0, 0, 0}};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ge.v[i] = nom[24 + i] + nom[30 + i] * h; ae.v[i] = nom[27 + i] + nom[33 + i] * h; }
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Kt.v[i] += tab.b[q] * sKs[3 * q + i];
+        compose_motion_calib_dev(X, Kt, ge, ae, h, Rg, Cg, Ca);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) nom[3 * i + j] = X.Rsb.m[i][j];
+          nom[9 + i] = X.Tsb.v[i]; nom[12 + i] = X.Vsb.v[i];
+          nom[24 + i] = ge.v[i]; nom[27 + i] = ae.v[i];   // rk4.cpp:27-28: the next sub-step starts from the interpolated sample
+        }
+      }
+      auto phase_a = [&](int st) {   // P0 = Pmm + (sum a_q PK_q) h, S = sum a_q FK_q, this stage's F rows and G Q rows
+        const double* Jm = Jms + st * JS;
+        for (int e = lane; e < NN; e += NT) {
+          double sp = 0.0;
+#pragma unroll
+          for (int q = 0; q < NS - 1; ++q) sp += tab.a[st][q] * PKs[q * NN + e];
+          P0[e] = Pmm[e] + sp * h;
+        }
+        for (int e = lane; e < NF; e += NT) {
+          double sf = 0.0;
+#pragma unroll
+          for (int q = 0; q < NS - 1; ++q) sf += tab.a[st][q] * FKs[q * NF + e];
+          S1[e] = sf;
+          const int i = e % FR, j = e / FR;
+          double f = 0.0;
+          if (i < 3) {                                            // Wsb rows
+            if (j < 3) f = Jm[3 * i + j];
+            else if (j == 9 + i) f = -1.0;
+            else if (iCg >= 0 && j >= iCg + 3 * i && j < iCg + 3 * i + 3) f = Jm[36 + (j - iCg - 3 * i)];
+          } else if (i < 6) {                                     // Tsb rows
+            if (j == 3 + i) f = 1.0;
+          } else {                                                // Vsb rows
+            const int r = i - 6;
+            if (j < 3) f = Jm[9 + 3 * r + j];
+            else if (j >= 12 && j < 15) f = Jm[18 + 3 * r + (j - 12)];
+            else if (j == 21 || j == 22) f = Jm[27 + 3 * r + (j - 21)];
+            else if (iCa >= 0 && j >= iCa && j < iCa + 6) f = Jm[39 + 6 * r + (j - iCa)];
+          }
+          F9[e] = f;
+        }
+        if (lane >= 224 && lane < 236) {                          // (G Q)[Vsb_i, l] = sum_k -Rsb[i][k] Q[3 + k, l]
+          const int l = lane - 224;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v = fma(Jm[18 + 3 * i + k], Q[(3 + k) + 12 * l], v);
+            GQc[(3 + i) + 12 * l] = v;
+          }
+        }
+      };
+      phase_a(0);
+      __syncthreads();
+      for (int st = 0; st < NS; ++st) {
+        const double* Jm = Jms + st * JS;
+        // -- phase B: F P0, FK_st = F + F S h, P0 F^T, G Q G^T
+        for (int e = lane; e < NF; e += NT) {
+          const int i = e % FR, j = e / FR;
+          double fp = 0.0, fs = 0.0;
+          for (int k = 0; k < nm; ++k) fp = fma(F9[i + FR * k], P0[k + nm * j], fp);
+#pragma unroll
+          for (int k = 0; k < FR; ++k) fs = fma(F9[i + FR * k], S1[k + FR * j], fs);   // rows >= 9 of S are zero
+          FPs[e] = fp;
+          FKs[st * NF + e] = F9[e] + fs * h;
+        }
+        for (int e = lane; e < NF; e += NT) {
+          const int i = e % nm, j = e / nm;                       // (P0 F^T)[i, j < 9]
+          double pf = 0.0;
+          for (int k = 0; k < nm; ++k) pf = fma(P0[i + nm * k], F9[j + FR * k], pf);
+          PFs[e] = pf;
+        }
+        if (lane < 144) {
+          const int r = lane % 12, cidx = lane / 12;
+          double v;
+          if (cidx < 3) v = fma(GQc[r + 12 * cidx], -1.0, 0.0);
+          else if (cidx < 6) {
+            v = fma(GQc[r + 12 * 3], Jm[18 + 3 * (cidx - 3) + 0], 0.0);
+            v = fma(GQc[r + 12 * 4], Jm[18 + 3 * (cidx - 3) + 1], v);
+            v = fma(GQc[r + 12 * 5], Jm[18 + 3 * (cidx - 3) + 2], v);
+          } else v = GQc[r + 12 * cidx];
+          GQG[r + 12 * cidx] = v;
+        }
+        __syncthreads();
+        // -- phase C: PK_st = F P0 + P0 F^T + G Q G^T, then phase A of the next stage
+        for (int e = lane; e < NN; e += NT) {
+          const int i = e % nm, j = e / nm;
+          const int ci = i < 3 ? i : ((i >= 6 && i < 15) ? i - 3 : -1), cj = j < 3 ? j : ((j >= 6 && j < 15) ? j - 3 : -1);
+          const double fp = i < FR ? FPs[i + FR * j] : 0.0, pf = j < FR ? PFs[i + nm * j] : 0.0;
+          const double gq = (ci >= 0 && cj >= 0) ? GQG[ci + 12 * cj] : 0.0;
+          PKs[st * NN + e] = (fp + pf) + gq;
+        }
+        __syncthreads();
+        if (st + 1 < NS) { phase_a(st + 1); __syncthreads(); }
+      }
+      // combine the stages
+      for (int e = lane; e < NN; e += NT) {
+        double pk = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) pk += tab.b[q] * PKs[q * NN + e];
+        Pmm[e] += pk * h;                              // rk4.cpp:92-93
+      }
+      for (int e = lane; e < NF; e += NT) {
+        double fk = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) fk += tab.b[q] * FKs[q * NF + e];
+        S1[e] = ((e % FR) == (e / FR) ? 1.0 : 0.0) + fk * h;    // rows < 9 of Phi_step = I + FK h
+      }
+      __syncthreads();
+      for (int e = lane; e < NF; e += NT) {            // Phi <- Phi_step Phi (rows >= 9 of both are identity rows)
+        const int i = e % FR, j = e / FR;
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < FR; ++k) v = fma(S1[i + FR * k], Phi[k + FR * j], v);
+        if (j >= FR) v = fma(S1[i + FR * j], 1.0, v);
+        PhiN[e] = v;
+      }
+      { double* t = Phi; Phi = PhiN; PhiN = t; }
+      __syncthreads();
+      total += h;
+      if (a.stepsize < 0) break;
+    }
+    for (int e = lane; e < NN; e += NT) Pmm[e] += a.Qmodel[e];   // estimator.cpp:590, per Propagate
+    __syncthreads();
+  }
+  for (int e = lane; e < NN; e += NT) {
+    const int i = e % nm, j = e / nm;
     a.Pmm_out[(long)filt * NN + e] = Pmm[e];
     a.Phi_out[(long)filt * NN + e] = i < FR ? Phi[i + FR * j] : (i == j ? 1.0 : 0.0);
   }
@@ -2490,11 +2826,12 @@ int launch_stack(const StackArgs& a, hipStream_t s) {
   CHECK_LAUNCH();
 }
 int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses, const xivo_group_in* groups,
-                     int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s) {
+                     int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s, const xivo_calib_in* calib,
+                     int cam_dim) {
   const int tot = batch * n;
   if (tot <= 0) return 0;
   hipLaunchKernelGGL(subfilter_kernel, dim3((tot + 127) / 128), dim3(128), 0, s, feats, n, poses, groups, n_groups, cam,
-                     o, batch);
+                     o, batch, calib, cam_dim);
   CHECK_LAUNCH();
 }
 int launch_givens(const GivensArgs& a, hipStream_t s) {
@@ -2543,7 +2880,7 @@ int launch_oos(const OosArgs& a, hipStream_t s) {
 int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm, const double* Phi,
                          const double* Pmm, int b0, int nb, hipStream_t s) {
   (void)Np;
-  if (nm > 32) return (int)hipErrorInvalidValue;
+  if (nm > 40) return (int)hipErrorInvalidValue;
   if (nm == 23) {
     hipLaunchKernelGGL(propagate_cov_fixed_kernel<23>, dim3(nb), dim3(256), 0, s, P, strideP, ldp, N, Phi, Pmm, b0);
     CHECK_LAUNCH();
@@ -2574,6 +2911,29 @@ static int launch_propagate_state_wave(const PropStateArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(propagate_state_wave_kernel<NS>, dim3(a.batch), dim3(64), lds, s, a);
   CHECK_LAUNCH();
 }
+size_t propagate_calib_lds(int nm, int ns) {
+  const size_t NN = (size_t)nm * nm, NF = 9 * (size_t)nm;
+  return ((2 + ns) * NN + (6 + ns) * NF + 432 + 64 + 24 + (size_t)ns * 60) * sizeof(double);
+}
+template <int NS>
+static int launch_propagate_state_calib_ns(const PropStateArgs& a, hipStream_t s) {
+  const size_t lds = propagate_calib_lds(a.nm, NS);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_calib_kernel<NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(propagate_state_calib_kernel<NS>, dim3(a.batch), dim3(256), lds, s, a);
+  return (int)hipGetLastError();
+}
+int launch_propagate_state_calib(const PropStateArgs& a, hipStream_t s) {
+  if (a.batch <= 0) return 0;
+  if (a.nm < 23 || a.nm > 40 || !a.calib) return (int)hipErrorInvalidValue;
+  return a.method ? launch_propagate_state_calib_ns<7>(a, s) : launch_propagate_state_calib_ns<4>(a, s);
+}
+
 bool propagate_uses_wave_kernel() {
   static const bool wg = getenv("XIVO_HIP_PROP_WG") != nullptr;   // A/B knob: the four-wave workgroup kernel
   return !wg;

@@ -147,6 +147,9 @@ _SIGS = {
     "xivo_hip_set_calib": [C.c_void_p, C.c_void_p],
     "xivo_hip_set_calib_state": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_get_jacobians_calib": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "xivo_hip_get_calib_state": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "xivo_hip_set_calib_gyro": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "xivo_hip_propagate_calib": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "xivo_hip_selftest_host_compress": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
 }
 HOST_P_RESIDENT, HOST_KEEP_P = 1, 2
@@ -156,8 +159,14 @@ class CalibLayout(C.Structure):
     _fields_ = [("td", C.c_int), ("Cg", C.c_int), ("cam_begin", C.c_int), ("cam_dim", C.c_int)]
 
 
-calib_dtype = np.dtype([("gyro", "f8", 3), ("Cg", "f8", 9), ("td", "f8")])
-assert calib_dtype.itemsize == 104
+calib_dtype = np.dtype([("gyro", "f8", 3), ("Cg", "f8", 9), ("td", "f8"), ("Ca", "f8", 9), ("intr", "f8", 9)])
+assert calib_dtype.itemsize == 248
+
+
+def cam_intr(cam):
+    """xivo_calib_in::intr of a camera dict: fx fy cx cy, then the distortion parameters in xivo_cam.d's order"""
+    d = list(cam.get("d", [])) + [0.0] * 5
+    return np.array([cam["fx"], cam["fy"], cam["cx"], cam["cy"]] + d[:5], dtype=np.float64)
 # every symbol include/xivo_hip.h declares (tests check the library exports them all)
 ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile", "xivo_hip_device_count",
                                         "xivo_hip_device_numa_node"])
@@ -334,7 +343,7 @@ class Context:
     # ---- online-calibration builds (measurement side) ----------------------------
     def set_calib(self, td=-1, Cg=-1, cam_begin=0, cam_dim=0):
         """switch the td / Cg / bg / intrinsics Jacobian blocks on (td = Cg = -1 and cam_dim = 0: off)"""
-        if td < 0 and cam_dim == 0:
+        if td < 0 and Cg < 0 and cam_dim == 0:
             self._check(self.lib.xivo_hip_set_calib(self.h, None))
         else:
             cl = CalibLayout(td, Cg, cam_begin, cam_dim)
@@ -343,6 +352,16 @@ class Context:
     def set_calib_state(self, calib, b0=0):
         calib = np.ascontiguousarray(calib, dtype=calib_dtype)
         self._check(self.lib.xivo_hip_set_calib_state(self.h, b0, calib.shape[0], _ptr(calib)))
+
+    def set_calib_gyro(self, gyro, b0=0):
+        gyro = np.ascontiguousarray(gyro, dtype=np.float64).reshape(-1, 3)
+        self._check(self.lib.xivo_hip_set_calib_gyro(self.h, b0, gyro.shape[0], _ptr(gyro)))
+
+    def get_calib_state(self, b0=0, nb=None):
+        nb = self.batch - b0 if nb is None else nb
+        out = np.zeros(nb, dtype=calib_dtype)
+        self._check(self.lib.xivo_hip_get_calib_state(self.h, b0, nb, _ptr(out)))
+        return out
 
     def get_jacobians_calib(self, b0=0, nb=None, F=None):
         nb = self.batch - b0 if nb is None else nb
@@ -536,6 +555,19 @@ class Context:
         o["Qmodel"] = np.asarray(Qmodel, dtype=np.float64).T.reshape(-1)
         o["g"] = g; o["method"] = 0 if method == "RK4" else 1; o["stepsize"] = stepsize
         self._check(self.lib.xivo_hip_propagate(self.h, b0, imu.shape[0], imu.shape[1], _ptr(imu), _ptr(o)))
+
+    def propagate_calib(self, imu, Qimu, Qmodel, g, method="RK4", stepsize=0.002, b0=0):
+        """Estimator::Propagate of an online-calibration build (set_calib with td >= 0 or Cg >= 0): Qmodel is
+        kMotionSize x kMotionSize (numpy row-major); the resident calibration state supplies Cg / Ca."""
+        imu = np.ascontiguousarray(imu, dtype=imu_dtype)
+        if imu.ndim == 1:
+            imu = imu[:, None]
+        imu = np.ascontiguousarray(imu)
+        o = np.zeros(1, dtype=prop_opts_dtype)
+        o["Qimu"] = np.asarray(Qimu, dtype=np.float64).T.reshape(-1)
+        o["g"] = g; o["method"] = 0 if method == "RK4" else 1; o["stepsize"] = stepsize
+        Qm = np.ascontiguousarray(np.asarray(Qmodel, dtype=np.float64).T)
+        self._check(self.lib.xivo_hip_propagate_calib(self.h, b0, imu.shape[0], imu.shape[1], _ptr(imu), _ptr(o), _ptr(Qm)))
 
     def absorb_error(self, B=None):
         self._check(self.lib.xivo_hip_absorb_error(self.h, self.batch if B is None else B))
