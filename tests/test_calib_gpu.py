@@ -108,12 +108,32 @@ def test_filter_update_with_calibration_columns(built, name):
     assert rejected >= 2
 
 
-def test_calibration_off_again_and_unsupported_entries(built):
-    cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup("pinhole", True, True, True)
+def test_stand_alone_gate_and_calibration_off_again(built):
+    """xivo_hip_mh_gate on a calibration context gates on the whole row too (then stack + update as separate calls);
+    1-pt RANSAC is not built for these builds; set_calib() switches back to the default build."""
+    cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup("equi", True, True, True, B=3, ng=6, nf=14, seed=4)
+    feats["xp"][2, [1, 5]] += 50.0; xp[2, [1, 5]] += 50.0
+    B, F = 3, feats.shape[1]
+    P = np.array([spd(lay.N, 5 + b) * 1e-4 for b in range(B)])
     with ctx:
-        ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
         ctx.jacobians_instate()
-        assert ctx.lib.xivo_hip_mh_gate(ctx.h, 3, 2.25, 5.991, 1.1, 5, None, None) == -5      # gate on the compact 21 columns: not in this mode
+        mask, dist = ctx.mh_gate(R_VIS, MH, MULT, 5)
+        ctx.stack(R_VIS); ctx.update_joseph()
+        err = ctx.get_err(); Pn = ctx.download_P()
+        assert ctx.lib.xivo_hip_one_point_ransac(ctx.h, B, 2.25, 1.0, 5.991, None, None, None, None, None) == -5
+        rej = 0
+        for b in range(B):
+            Js, inns, _ = oracle_rows(sc, cam, lay, xp, cals, b)
+            d = orc.mh_distances(Js, P[b], inns, R_VIS)
+            m, _, _ = orc.mh_gate(d, MH, MULT, 5)
+            assert np.array_equal(mask[b], m) and rel_fro(dist[b], d) < 1e-9
+            rej += int((~m).sum())
+            idx = np.nonzero(m)[0]
+            H, inn, dR = orc.stack_measurements(Js[idx], inns[idx], sc["ref"][b][idx], sc["sind"][b][idx], lay, R_VIS)
+            e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+            assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+        assert rej >= 2
         ctx.set_calib()                                                                         # default build again
         ctx.upload_P(np.array([spd(lay.N, 5 + b) * 1e-4 for b in range(3)]))
         ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)

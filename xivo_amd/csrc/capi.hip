@@ -1524,14 +1524,47 @@ static int gate_impl(xivo_hip_ctx* c, int B, double R, double th, double mult, i
   return launch_gate_sparse(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 
+// Estimator::MHGating of an online-calibration build: the gate needs the WHOLE row J() incl. the td / Cg / bg / intrinsics
+// blocks (update.cpp:60-70), which is not the row FillJacobianBlock stacks (the :675-676 overwrite): every present feature is
+// stacked once as its full J() (dense rows) and gated on (J P) J^T + R by the dense-row gate. gate = 0: every present feature
+// is an inlier (Estimator::OutlierRejection does not gate F <= min_required_inliers_, src/manager.cpp:635).
+static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigned char* mask_override, int full_rows);
+static int calib_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double mh_mult, int min_inliers, int gate) {
+  int rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 0);
+  if (rc) return rc;
+  if (gate) {
+    c->M = 2 * c->F; c->Mp = round_up16(c->M);
+    c->dense_valid = true; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B; c->oos_row0 = -1; c->mixed_row0 = -1; c->h_clean = false;
+    rc = stack_impl(c, B, R, 1, nullptr, /*full_rows=*/1);
+    if (rc) return rc;
+    rc = ensure_HT(c);
+    if (rc) return rc;
+    const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
+    {
+      GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
+      rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, c->HP, c->sH, ldh, x);
+      if (rc) return rc;
+    }
+    GateDenseArgs a{};
+    a.H = c->H; a.strideH = c->sH; a.ldh = ldh; a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh;
+    a.Hw = c->H; a.HTw = c->HT; a.strideHT = c->sHT; a.ldht = Np; a.HPw = nullptr; a.PHTw = nullptr; a.PHTr = c->PHT;
+    a.inn = c->inn; a.strideInn = c->Mpmax; a.diagR = c->diagR; a.strideR = c->Mpmax;
+    a.mask = c->mask; a.dist = c->dist; a.F = c->F; a.Np = Np; a.batch = B; a.mask_ld = c->Fmax;   // (the stride xivo_hip_stack reads the mask with)
+    a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;
+    a.ell = c->ell; a.have_ell = 0;
+    StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
+    c->gate_sparse_last = 1;
+    HIP_TRY((hipError_t)launch_gate_dense(a, c->stream));
+  }
+  return XIVO_HIP_OK;
+}
+
 int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double mh_mult, int min_inliers,
                      unsigned char* mask_out, double* dist_out) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
-  // (online-calibration builds gate on the whole stacked row inside xivo_hip_filter_update; the compact 21-column gate
-  //  would ignore the td / Cg / bg / intrinsics blocks)
-  if (c->calib_on) return XIVO_HIP_ERR_UNSUPPORTED;
-  int rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
+  // (online-calibration builds: the compact 21-column gate would ignore the td / Cg / bg / intrinsics blocks)
+  int rc = c->calib_on ? calib_gate(c, B, R, mh_thresh, mh_mult, min_inliers, 1) : gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
   if (rc) return rc;
   const size_t F = c->F, Fm = c->Fmax;
   if (mask_out) { rc = d2h_rows(c, mask_out, F, c->mask, Fm, F, B); if (rc) return rc; }
@@ -1806,32 +1839,8 @@ int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, d
     // online-calibration builds: the gate needs the WHOLE row J() incl. the td / Cg / bg / intrinsics blocks (update.cpp:60-70),
     // which is not the row FillJacobianBlock stacks (the :675-676 overwrite): every present feature is stacked once as its
     // full J() (dense rows), gated on (J P) J^T + R by the dense-row gate, then the inliers are stacked as coded and updated
-    rc = gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 0);
+    rc = calib_gate(c, B, R, mh_thresh, mh_mult, min_inliers, gate);
     if (rc) return rc;
-    if (gate) {
-      c->M = 2 * c->F; c->Mp = round_up16(c->M);
-      c->dense_valid = true; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B; c->oos_row0 = -1; c->mixed_row0 = -1; c->h_clean = false;
-      rc = stack_impl(c, B, R, 1, nullptr, /*full_rows=*/1);
-      if (rc) return rc;
-      rc = ensure_HT(c);
-      if (rc) return rc;
-      const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
-      {
-        GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
-        rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, c->HP, c->sH, ldh, x);
-        if (rc) return rc;
-      }
-      GateDenseArgs a{};
-      a.H = c->H; a.strideH = c->sH; a.ldh = ldh; a.HP = c->HP; a.strideHP = c->sH; a.ldhp = ldh;
-      a.Hw = c->H; a.HTw = c->HT; a.strideHT = c->sHT; a.ldht = Np; a.HPw = nullptr; a.PHTw = nullptr; a.PHTr = c->PHT;
-      a.inn = c->inn; a.strideInn = c->Mpmax; a.diagR = c->diagR; a.strideR = c->Mpmax;
-      a.mask = c->mask; a.dist = c->dist; a.F = c->F; a.Np = Np; a.batch = B; a.mask_ld = c->Fmax;   // (the stride xivo_hip_stack reads the mask with)
-      a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;
-      a.ell = c->ell; a.have_ell = 0;
-      StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
-      c->gate_sparse_last = 1;
-      HIP_TRY((hipError_t)launch_gate_dense(a, c->stream));
-    }
     rc = xivo_hip_stack(c, B, R);
     if (rc) return rc;
     return xivo_hip_update_joseph(c, B);
