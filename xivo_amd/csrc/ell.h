@@ -21,6 +21,7 @@
 namespace xivo_hip {
 
 constexpr int ELL_CW = 16, ELL_PW = 12, ELL_W = ELL_CW + ELL_PW;
+constexpr int ELL_PIW = 12;   // 16-bit private slot indices per pair in the LDS copy of the slab kernels (24 bytes: 8-byte aligned rows)
 
 struct EllBuffers {
   int* idx;        // [batch][pairs_max][ELL_W]

@@ -368,6 +368,12 @@ __global__ __launch_bounds__(1024) void gate_ell_kernel(GateEllArgs a) {
 // LDS: slab[cols][XC] doubles, element (k, x) at k * XC + (x ^ (k & 15)) - the XOR keeps both the
 // row-wise loads and the transposing load of ELL_S (lanes = k) conflict-free without a pad column;
 // then ops[pairs][CWU + ELL_PW][2].
+#ifndef XIVO_ELL_HP_PF
+#define XIVO_ELL_HP_PF 0   // A/B: P H^T with 8 waves and the next slab prefetched into registers under the walk
+#endif
+#ifndef XIVO_ELL_ABL
+#define XIVO_ELL_ABL 0   // timing-only ablations of ell_tile_kernel (scripts/build_variant.sh): 1 no pair walk, 2 no slab loads, 3 no output stores
+#endif
 typedef __attribute__((address_space(4))) const double ell_cdouble;
 typedef __attribute__((address_space(4))) const int ell_cint;
 
@@ -376,7 +382,20 @@ typedef __attribute__((address_space(4))) const int ell_cint;
 // prefetch variant (next slab fetched into registers under the pair walk): the hot configuration only
 constexpr bool ell_tile_pf(int mode, int cwu, int xc, int pwu) {
   // (tried for the P H^T and G instantiations too, at 8 waves / 256 VGPRs: 0.83 -> 0.92 and 0.88 -> 1.79 ms)
-  return xc == 64 && cwu == 12 && mode == ELL_S && pwu >= 0;
+  return xc == 64 && cwu == 12 && (mode == ELL_S || (XIVO_ELL_HP_PF && mode == ELL_HP && pwu == 9)) && pwu >= 0;
+}
+// raw buffer access: one 32-bit per-lane offset + a scalar offset per access, no 64-bit address registers per store
+typedef unsigned ell_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ell_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ void ell_buf_st(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ell_u2, v), r, voff, soff, 0);
+}
+
+// matrix-core walk (see the kernel): the hot instantiations
+constexpr bool ell_tile_mf(int mode, int cwu, int xc, int pwu) {
+  return xc == 64 && cwu == 12 && pwu == 9 && (mode == ELL_HP || mode == ELL_S);
 }
 constexpr int ell_tile_threads(int mode, int cwu, int xc, int pwu) {
   return (mode == ELL_S || ell_tile_pf(mode, cwu, xc, pwu)) ? 512 : 1024;
@@ -407,12 +426,23 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
   const int cols = a.cols;
   const int pairs = a.Mp / 2;
   double* ops = tile + (long)cols * XC;
+  // the private slot indices of every pair, 16 bits each, ELL_PIW per pair (24 bytes: three 8-byte broadcast reads). As
+  // scalar loads they cost the walk most of its time: one scalar-cache miss per pair (9 KB of indices per filter, the cache
+  // is shared between CUs), and SMEM shares lgkmcnt with the LDS - every wait for an index drained the LDS reads of the
+  // other pair in flight too (walk alone, 16384 filters: P H^T 1.91 ms, S 1.77 ms).
+  unsigned short* pidx = reinterpret_cast<unsigned short*>(ops + (long)pairs * NSLOT * 2);
   {  // coefficients of every pair of the filter: coalesced 16-byte loads -> LDS, once per workgroup
     const d2* __restrict__ gv = reinterpret_cast<const d2*>(a.ell.val + (long)filt * a.ell.stride_val());
     for (int e = tid; e < pairs * NSLOT; e += NT) {
       const int p = e / NSLOT, t = e % NSLOT;
       *reinterpret_cast<d2*>(ops + 2 * e) = gv[p * ELL_W + (t < CWU ? t : ELL_CW + (t - CWU))];
     }
+    const int* __restrict__ gi = a.ell.idx + (long)filt * a.ell.stride_idx();
+    for (int e = tid; e < pairs * ELL_PIW; e += NT) {
+      const int p = e / ELL_PIW, t = e % ELL_PIW;
+      pidx[e] = t < PWU ? (unsigned short)gi[p * ELL_W + ELL_CW + t] : (unsigned short)0;
+    }
+    if (tid < ELL_CW) pidx[pairs * ELL_PIW + tid] = (unsigned short)gi[tid];   // the common slots (the same in every pair)
   }
   // The slab of step s+1 is fetched into registers while the pairs are walked over the slab of step s
   // (one workgroup per CU owns the LDS, so nothing else would hide the HBM latency of the next slab).
@@ -431,7 +461,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
         const bool ok = x0 + jj < a.X;
         const double* __restrict__ col = Src + (long)(x0 + (ok ? jj : 0)) * a.ldsrc;
 #pragma unroll
-        for (int u = 0; u < KU; ++u) { const int k = lane + 64 * u; r[q * KU + u] = (ok && k < cols) ? col[k] : 0.0; }
+        for (int u = 0; u < KU; ++u) { const int k = lane + 64 * u; r[q * KU + u] = (XIVO_ELL_ABL != 2 && ok && k < cols) ? col[k] : 0.0; }
       }
     } else {
       // uniform 64-bit base (+ u * step, scalar) and one 32-bit per-lane byte offset: no per-load address VGPRs.
@@ -445,7 +475,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
 #pragma unroll
       for (int u = 0; u < RN; ++u) {
         double v = 0.0;
-        if (u < nu) v = *reinterpret_cast<const double*>(base + (size_t)u * step + voff);
+        if (XIVO_ELL_ABL != 2 && u < nu) v = *reinterpret_cast<const double*>(base + (size_t)u * step + voff);
         r[u] = ok ? v : 0.0;
       }
     }
@@ -495,7 +525,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
       const double* __restrict__ row = Src + x0 + (ok ? xq : 0);
       for (int k0 = 0; k0 < cols; k0 += (NT / XC) * 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = k0 + kq + (NT / XC) * u; r[u] = (ok && k < cols) ? row[(long)k * a.ldsrc] : 0.0; }
+        for (int u = 0; u < 8; ++u) { const int k = k0 + kq + (NT / XC) * u; r[u] = (XIVO_ELL_ABL != 2 && ok && k < cols) ? row[(long)k * a.ldsrc] : 0.0; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int k = k0 + kq + (NT / XC) * u; if (k < cols) tile[k * XC + (xq ^ (k & 15))] = r[u]; }
       }
@@ -503,6 +533,109 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
     __syncthreads();
     if (PF && sidx + 1 < s_end) fetch(sidx + 1);
 
+    if constexpr (ell_tile_mf(MODE, CWU, XC, PWU)) {
+      // ---- walk, matrix-core form (the hot instantiations: 12 common + 9 private slots, 64-wide slabs) --------------------
+      // The scalar-coefficient walk below is bound by the LDS: every coefficient pair reaches its 64 lanes as a 16-byte
+      // broadcast read that costs the LDS return path the full 1 KB (8 clocks), 21 of them per row pair and wave - 1.9 of
+      // the 2.8 ms of P H^T and 1.8 of the 2.3 ms of S per 16384 filters were the walk, not the slab traffic. Here a wave
+      // takes 8 row pairs x 64 slab columns at a time:
+      //  * the 12 common columns are a dense product (16 rows x 12) (12 x 64): three v_mfma_f64_16x16x4_f64 per 16-column
+      //    block, the B operand = the slab rows the common slots name (12 registers per lane and slab, as before), the A
+      //    operand = the coefficients, one 8-byte per-lane read per k-step;
+      //  * MFMA row lg + 4 r of the tile stands for row (r & 1) of pair p0 + lg + 4 (r >> 1): both rows of a pair sit in
+      //    the same lane, so the private part keeps one slab gather per (pair, slot, column block) for both rows, and its
+      //    coefficient reads serve four pairs per instruction (lane groups lg read different pairs) instead of one.
+      // LDS time per 8 pairs x 64 columns: 72 gathers + 18 coefficient reads + 3 operand reads, ~450 clocks against ~1630.
+      const int li = lane & 15, lg = lane >> 4;
+      const unsigned short* cidx = pidx + pairs * ELL_PIW;
+      int ck[3];                                                        // slab rows the common slots 4 s + lg name
+#pragma unroll
+      for (int s = 0; s < 3; ++s) ck[s] = cidx[4 * s + lg];
+      const int x0 = sidx * XC;
+      const __amdgpu_buffer_rsrc_t rO = ell_rsrc(a.out + (long)filt * a.strideOut);
+      const unsigned vO = (unsigned)(2 * lg * a.ldo + li) * 8u;          // row 2 lg, column li of a tile; the rest of the address is wave-uniform
+      double dRc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (MODE == ELL_S) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (x0 + 16 * c + li < a.X) dRc[c] = a.diagR[(long)filt * a.strideR + x0 + 16 * c + li];
+      }
+      // (S: the row-pair blocks to the right of this slab's diagonal square are skipped - lower triangle + diagonal blocks)
+      const int rb_end = XIVO_ELL_ABL == 1 ? 0 : (MODE == ELL_S ? min(pairs / 8, 4 * (sidx + 1)) : pairs / 8);
+      const int pa = (li & 3) + 4 * (li >> 3), ra = (li >> 2) & 1;     // A operand: MFMA row li = pair pa, row ra of it
+      for (int rb = wave; rb < rb_end; rb += NW) {
+        const int p0 = 8 * rb;
+        d4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+        // the private slots first (plain FMAs into the zeroed tile), the dense common part on top of them: the other way
+        // round the scheduler hoists every LDS read of the private part above the MFMA chain it depends on - and spills
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int p = p0 + lg + 4 * q;
+          const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT + CWU;
+          const unsigned short* pkp = pidx + p * ELL_PIW;
+          static_assert(PWU % 3 == 0, "three slots per step");
+#pragma unroll 1
+          for (int t0 = 0; t0 < PWU; t0 += 3) {
+            // three slots per step, their 12 gathers in flight together (the scheduler, left alone, serialises them in the
+            // second half-tile - one LDS round trip per gather)
+            d2 v[3]; double g[3][4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              v[u] = pv[t0 + u];
+              const int k = (int)pkp[t0 + u];
+              const double* trow = tile + k * XC;
+              const int sw = k & 15;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) g[u][c] = trow[(16 * c + li) ^ sw];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                acc[c][2 * q] = fma(v[u][0], g[u][c], acc[c][2 * q]);
+                acc[c][2 * q + 1] = fma(v[u][1], g[u][c], acc[c][2 * q + 1]);
+              }
+            }
+          }
+        }
+        {
+          // (the B operand is re-read from the slab per tile, 12 reads: held across the private part its 24 registers made
+          //  the scheduler serialise that part's gathers)
+          double av[3], cb[3][4];
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            av[s] = ops[((long)(p0 + pa) * NSLOT + 4 * s + lg) * 2 + ra];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cb[s][c] = tile[ck[s] * XC + ((16 * c + li) ^ (ck[s] & 15))];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], cb[s][c], acc[c], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int x = x0 + 16 * c + li;
+          if (x >= a.X || (XIVO_ELL_ABL == 3 && acc[c][0] != 12345.678)) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pp = p0 + lg + 4 * (r >> 1), i = r & 1, m = 2 * pp + i;
+            const unsigned sO = (unsigned)((2 * p0 + 8 * (r >> 1) + i) * a.ldo + x0 + 16 * c) * 8u;
+            if (MODE == ELL_HP) ell_buf_st(acc[c][r], rO, vO, sO);
+            else {
+              const double sv_ = acc[c][r] + (x == m ? dRc[c] : 0.0);
+              ell_buf_st(sv_, rO, vO, sO);
+              if (a.diag_out && (x >> 1) == pp) a.diag_out[(long)filt * a.strideDiag + 4 * pp + 2 * (x & 1) + i] = sv_;
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      continue;
+    }
     const int x = sidx * XC + xx;
     const bool live = x < a.X;
     const double* __restrict__ K = a.K + (long)filt * a.strideK + (live ? x : 0);
@@ -513,20 +646,32 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
     for (int t = 0; t < CWU; ++t) cm[t] = slab(idx0[t]);
     // S is symmetric and every reader (gating, both Cholesky kernels) takes its lower triangle + the diagonal blocks: lane
     // = row x of S, pair p = columns 2p, 2p + 1 - the pairs to the right of this slab's 64 x 64 diagonal square are skipped
-    const int p_end = MODE == ELL_S ? min(pairs, (sidx * XC + XC) / 2) : pairs;
+    const int p_end = XIVO_ELL_ABL == 1 ? 0 : (MODE == ELL_S ? min(pairs, (sidx * XC + XC) / 2) : pairs);
+    // ELL_S: lane = row x of S adds R to its own diagonal element only - one vector load per slab instead of a scalar
+    // load (and an lgkmcnt drain) per stored row
+    double dRx = 0.0;
+    if (MODE == ELL_S && live) dRx = a.diagR[(long)filt * a.strideR + x];
 #pragma unroll UNR
     for (int p = wave; p < p_end; p += NW) {
-      ell_cint* pi = idx0 + (long)p * ELL_W + ELL_CW;
       const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT;
+      unsigned pk[ELL_PIW];
+      {
+        const uint2* pq = reinterpret_cast<const uint2*>(pidx + p * ELL_PIW);   // wave-uniform address: broadcast reads
+#pragma unroll
+        for (int u = 0; u < ELL_PIW / 4; ++u) {
+          const uint2 q = pq[u];
+          pk[4 * u] = q.x & 0xffffu; pk[4 * u + 1] = q.x >> 16; pk[4 * u + 2] = q.y & 0xffffu; pk[4 * u + 3] = q.y >> 16;
+        }
+      }
       double sv[PWU];
 #pragma unroll
-      for (int t = 0; t < PWU; ++t) sv[t] = slab(pi[t]);
+      for (int t = 0; t < PWU; ++t) sv[t] = slab((int)pk[t]);
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll
       for (int t = 0; t < CWU; ++t) { const d2 v = pv[t]; a0 = fma(v[0], cm[t], a0); a1 = fma(v[1], cm[t], a1); }
 #pragma unroll
       for (int t = 0; t < PWU; ++t) { const d2 v = pv[CWU + t]; a0 = fma(v[0], sv[t], a0); a1 = fma(v[1], sv[t], a1); }
-      if (!live) continue;
+      if (!live || (XIVO_ELL_ABL == 3 && a0 != 12345.678)) continue;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (XC == 32 && i != half) continue;      // XC = 32: each half-wave stores its own row
@@ -534,7 +679,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
         const double acc = i ? a1 : a0;
         if (MODE == ELL_HP) out[(long)m * a.ldo] = acc;
         else if (MODE == ELL_S) {
-          const double sv_ = acc + (x == m ? dR[m] : 0.0);
+          const double sv_ = acc + (x == m ? dRx : 0.0);
           out[(long)m * a.ldo] = sv_;
           if (XC == 64 && a.diag_out && (x >> 1) == p) a.diag_out[(long)filt * a.strideDiag + 4 * p + 2 * (x & 1) + i] = sv_;
         }
@@ -648,7 +793,8 @@ static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, int* pwu, size_t* l
   static const bool no_tile = getenv("XIVO_HIP_ELL_GATHER") != nullptr;   // A/B knob: force the gather form
   *cwu = a.nc_max <= 12 ? 12 : ELL_CW;
   *pwu = (*cwu == 12 && a.pw_max > 0 && a.pw_max <= 9) ? 9 : ELL_PW;
-  const size_t ops = (size_t)(a.Mp / 2) * (*cwu + *pwu) * 2 * sizeof(double);
+  const size_t pidx = ((size_t)(a.Mp / 2) * ELL_PIW + ELL_CW) * sizeof(unsigned short);   // the private slot indices, 16 bits each, + the common ones
+  const size_t ops = (size_t)(a.Mp / 2) * (*cwu + *pwu) * 2 * sizeof(double) + pidx;
   const size_t lds64 = (size_t)a.cols * 64 * sizeof(double) + ops, lds32 = (size_t)a.cols * 32 * sizeof(double) + ops;
   const size_t cap = 160 * 1024;
   *xc = 0; *lds = 0;
@@ -656,7 +802,7 @@ static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, int* pwu, size_t* l
   if (lds64 <= cap) { *xc = 64; *lds = lds64; return; }
   // the 9-slot walk is instantiated for XC = 64 only
   *pwu = ELL_PW;
-  const size_t lds32b = (size_t)a.cols * 32 * sizeof(double) + (size_t)(a.Mp / 2) * (*cwu + ELL_PW) * 2 * sizeof(double);
+  const size_t lds32b = (size_t)a.cols * 32 * sizeof(double) + (size_t)(a.Mp / 2) * (*cwu + ELL_PW) * 2 * sizeof(double) + pidx;
   if (lds32b <= cap) { *xc = 32; *lds = lds32b; }
   (void)lds32;
 }
