@@ -395,7 +395,7 @@ __device__ __forceinline__ void ell_buf_st(double v, __amdgpu_buffer_rsrc_t r, u
 
 // matrix-core walk (see the kernel): the hot instantiations
 constexpr bool ell_tile_mf(int mode, int cwu, int xc, int pwu) {
-  return xc == 64 && cwu == 12 && pwu == 9 && (mode == ELL_HP || mode == ELL_S);
+  return (xc == 64 || xc == 32) && cwu % 4 == 0 && pwu % 3 == 0 && (mode == ELL_HP || mode == ELL_S);
 }
 constexpr int ell_tile_threads(int mode, int cwu, int xc, int pwu) {
   return (mode == ELL_S || ell_tile_pf(mode, cwu, xc, pwu)) ? 512 : 1024;
@@ -546,27 +546,30 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
       //    the same lane, so the private part keeps one slab gather per (pair, slot, column block) for both rows, and its
       //    coefficient reads serve four pairs per instruction (lane groups lg read different pairs) instead of one.
       // LDS time per 8 pairs x 64 columns: 72 gathers + 18 coefficient reads + 3 operand reads, ~450 clocks against ~1630.
+      constexpr int NC = XC / 16, KS = CWU / 4;   // 16-column blocks per slab, k-steps of the common product
       const int li = lane & 15, lg = lane >> 4;
       const unsigned short* cidx = pidx + pairs * ELL_PIW;
-      int ck[3];                                                        // slab rows the common slots 4 s + lg name
+      int ck[KS];                                                        // slab rows the common slots 4 s + lg name
 #pragma unroll
-      for (int s = 0; s < 3; ++s) ck[s] = cidx[4 * s + lg];
+      for (int s = 0; s < KS; ++s) ck[s] = cidx[4 * s + lg];
       const int x0 = sidx * XC;
       const __amdgpu_buffer_rsrc_t rO = ell_rsrc(a.out + (long)filt * a.strideOut);
       const unsigned vO = (unsigned)(2 * lg * a.ldo + li) * 8u;          // row 2 lg, column li of a tile; the rest of the address is wave-uniform
-      double dRc[4] = {0.0, 0.0, 0.0, 0.0};
+      double dRc[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) dRc[c] = 0.0;
       if (MODE == ELL_S) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (x0 + 16 * c + li < a.X) dRc[c] = a.diagR[(long)filt * a.strideR + x0 + 16 * c + li];
+        for (int c = 0; c < NC; ++c) if (x0 + 16 * c + li < a.X) dRc[c] = a.diagR[(long)filt * a.strideR + x0 + 16 * c + li];
       }
       // (S: the row-pair blocks to the right of this slab's diagonal square are skipped - lower triangle + diagonal blocks)
-      const int rb_end = XIVO_ELL_ABL == 1 ? 0 : (MODE == ELL_S ? min(pairs / 8, 4 * (sidx + 1)) : pairs / 8);
+      const int rb_end = XIVO_ELL_ABL == 1 ? 0 : (MODE == ELL_S ? min(pairs / 8, NC * (sidx + 1)) : pairs / 8);
       const int pa = (li & 3) + 4 * (li >> 3), ra = (li >> 2) & 1;     // A operand: MFMA row li = pair pa, row ra of it
       for (int rb = wave; rb < rb_end; rb += NW) {
         const int p0 = 8 * rb;
-        d4 acc[4];
+        d4 acc[NC];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < NC; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
         // the private slots first (plain FMAs into the zeroed tile), the dense common part on top of them: the other way
         // round the scheduler hoists every LDS read of the private part above the MFMA chain it depends on - and spills
 #pragma unroll
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
           for (int t0 = 0; t0 < PWU; t0 += 3) {
             // three slots per step, their 12 gathers in flight together (the scheduler, left alone, serialises them in the
             // second half-tile - one LDS round trip per gather)
-            d2 v[3]; double g[3][4];
+            d2 v[3]; double g[3][NC];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               v[u] = pv[t0 + u];
@@ -587,13 +590,13 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
               const double* trow = tile + k * XC;
               const int sw = k & 15;
 #pragma unroll
-              for (int c = 0; c < 4; ++c) g[u][c] = trow[(16 * c + li) ^ sw];
+              for (int c = 0; c < NC; ++c) g[u][c] = trow[(16 * c + li) ^ sw];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
 #pragma unroll
-              for (int c = 0; c < 4; ++c) {
+              for (int c = 0; c < NC; ++c) {
                 acc[c][2 * q] = fma(v[u][0], g[u][c], acc[c][2 * q]);
                 acc[c][2 * q + 1] = fma(v[u][1], g[u][c], acc[c][2 * q + 1]);
               }
@@ -603,21 +606,21 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
         {
           // (the B operand is re-read from the slab per tile, 12 reads: held across the private part its 24 registers made
           //  the scheduler serialise that part's gathers)
-          double av[3], cb[3][4];
+          double av[KS], cb[KS][NC];
 #pragma unroll
-          for (int s = 0; s < 3; ++s) {
+          for (int s = 0; s < KS; ++s) {
             av[s] = ops[((long)(p0 + pa) * NSLOT + 4 * s + lg) * 2 + ra];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) cb[s][c] = tile[ck[s] * XC + ((16 * c + li) ^ (ck[s] & 15))];
+            for (int c = 0; c < NC; ++c) cb[s][c] = tile[ck[s] * XC + ((16 * c + li) ^ (ck[s] & 15))];
           }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
+          for (int c = 0; c < NC; ++c) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], cb[s][c], acc[c], 0, 0, 0);
+            for (int s = 0; s < KS; ++s) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], cb[s][c], acc[c], 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
           const int x = x0 + 16 * c + li;
           if (x >= a.X || (XIVO_ELL_ABL == 3 && acc[c][0] != 12345.678)) continue;
 #pragma unroll
@@ -800,11 +803,7 @@ static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, int* pwu, size_t* l
   *xc = 0; *lds = 0;
   if (no_tile) return;
   if (lds64 <= cap) { *xc = 64; *lds = lds64; return; }
-  // the 9-slot walk is instantiated for XC = 64 only
-  *pwu = ELL_PW;
-  const size_t lds32b = (size_t)a.cols * 32 * sizeof(double) + (size_t)(a.Mp / 2) * (*cwu + ELL_PW) * 2 * sizeof(double) + pidx;
-  if (lds32b <= cap) { *xc = 32; *lds = lds32b; }
-  (void)lds32;
+  if (lds32 <= cap) { *xc = 32; *lds = lds32; }
 }
 
 bool ell_uses_slab_form(const EllMulArgs& a) {
@@ -828,6 +827,7 @@ static int launch_ell_tile_m(const EllMulArgs& a, hipStream_t s, bool* done) {
   const bool n12 = cwu == 12;
   if (xc == 64 && pwu == 9) return launch_ell_tile_t<MODE, 12, 64, 9>(a, lds, s);
   if (xc == 64) return n12 ? launch_ell_tile_t<MODE, 12, 64, ELL_PW>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 64, ELL_PW>(a, lds, s);
+  if (xc == 32 && pwu == 9) return launch_ell_tile_t<MODE, 12, 32, 9>(a, lds, s);
   if (xc == 32) return n12 ? launch_ell_tile_t<MODE, 12, 32, ELL_PW>(a, lds, s) : launch_ell_tile_t<MODE, ELL_CW, 32, ELL_PW>(a, lds, s);
   return 0;
 }
