@@ -100,6 +100,7 @@ struct EllMulArgs {
   int X;        // extent of the contiguous index (Np for HP/G, Mp for S)
   int Mp;       // rows of H in use (multiple of 16)
   int slabs_per_wg; // set by the launcher (slab form): consecutive slabs one workgroup streams
+  int persist_stride; // set by the launcher (slab form, prefetching instantiation): > 0 = a workgroup walks filters b, b + stride, ...
   int rb_per_wg; // set by the launcher: 16-row blocks one workgroup walks
   int nc_max;   // upper bound of nc over the filters of the launch (host mirror)
   int pw_max;   // upper bound of pw (0 = unknown -> ELL_PW)

@@ -389,6 +389,9 @@ typedef unsigned ell_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ell_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
+__device__ __forceinline__ double ell_buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
 __device__ __forceinline__ void ell_buf_st(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ell_u2, v), r, voff, soff, 0);
 }
@@ -401,7 +404,8 @@ constexpr int ell_tile_threads(int mode, int cwu, int xc, int pwu) {
   return (mode == ELL_S || ell_tile_pf(mode, cwu, xc, pwu)) ? 512 : 1024;
 }
 
-template <int MODE, int CWU, int XC, int PWU>
+// TALL: the prefetch registers cover more than 256 source rows (cols up to 320); the short form saves the S instantiation 16 VGPRs
+template <int MODE, int CWU, int XC, int PWU, bool TALL = true>
 __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile_kernel(EllMulArgs a) {
   constexpr int NSLOT = CWU + PWU;   // PWU: private slots actually walked (9 for XIVO's group + feature blocks)
   constexpr int NT = ell_tile_threads(MODE, CWU, XC, PWU), NW = NT / 64;
@@ -411,18 +415,18 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
   //  two modes cannot hold a slab share next to the walk without spilling - measured slower)
   constexpr bool PF = ell_tile_pf(MODE, CWU, XC, PWU);
   constexpr int UNR = (PF || (CWU == 12 && XC == 64)) ? 2 : 1;   // pairs in flight per wave (register budget)
-  constexpr int RN = PF ? (MODE == ELL_S ? 40 : 34) : 8;
+  constexpr int RN = PF ? (MODE == ELL_S ? (TALL ? 40 : 32) : 34) : 8;
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int xchunks = (a.X + XC - 1) / XC;
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;     // workgroups per filter
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
-  const int filt = (slot / wgs) * 8 + xcd;
+  int filt = (slot / wgs) * 8 + xcd;     // (persistent form: the first filter of this workgroup; then filt += a.persist_stride)
   if (filt >= a.batch) return;
   const int s_begin = (slot % wgs) * a.slabs_per_wg;
   const int s_end = min(xchunks, s_begin + a.slabs_per_wg);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const double* __restrict__ Src = a.Src + (long)filt * a.strideSrc;
+  const double* Src = a.Src + (long)filt * a.strideSrc;
   const int cols = a.cols;
   const int pairs = a.Mp / 2;
   double* ops = tile + (long)cols * XC;
@@ -431,19 +435,25 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
   // is shared between CUs), and SMEM shares lgkmcnt with the LDS - every wait for an index drained the LDS reads of the
   // other pair in flight too (walk alone, 16384 filters: P H^T 1.91 ms, S 1.77 ms).
   unsigned short* pidx = reinterpret_cast<unsigned short*>(ops + (long)pairs * NSLOT * 2);
-  {  // coefficients of every pair of the filter: coalesced 16-byte loads -> LDS, once per workgroup
-    const d2* __restrict__ gv = reinterpret_cast<const d2*>(a.ell.val + (long)filt * a.ell.stride_val());
+  auto stage_ops = [&](int f) {  // coefficients of every pair of filter f: coalesced 16-byte loads -> LDS
+    const d2* __restrict__ gv = reinterpret_cast<const d2*>(a.ell.val + (long)f * a.ell.stride_val());
     for (int e = tid; e < pairs * NSLOT; e += NT) {
       const int p = e / NSLOT, t = e % NSLOT;
       *reinterpret_cast<d2*>(ops + 2 * e) = gv[p * ELL_W + (t < CWU ? t : ELL_CW + (t - CWU))];
     }
-    const int* __restrict__ gi = a.ell.idx + (long)filt * a.ell.stride_idx();
+    const int* __restrict__ gi = a.ell.idx + (long)f * a.ell.stride_idx();
     for (int e = tid; e < pairs * ELL_PIW; e += NT) {
       const int p = e / ELL_PIW, t = e % ELL_PIW;
       pidx[e] = t < PWU ? (unsigned short)gi[p * ELL_W + ELL_CW + t] : (unsigned short)0;
     }
     if (tid < ELL_CW) pidx[pairs * ELL_PIW + tid] = (unsigned short)gi[tid];   // the common slots (the same in every pair)
-  }
+  };
+  stage_ops(filt);
+  // Persistent form (big batches of the prefetching instantiation: a.persist_stride > 0, one workgroup per CU walks filters
+  // filt, filt + stride, ...): the next filter's first slab is prefetched under the last walk of this one like any other
+  // slab, and its coefficients are staged while that prefetch is still on its way - a workgroup that owns the CU's LDS has
+  // nobody to hide the start-up of a filter (two dependent round trips before the first walk) behind. (Holding the next
+  // coefficients in registers under the last walk as well costs 24 VGPRs the S instantiation does not have: 116 spills.)
   // The slab of step s+1 is fetched into registers while the pairs are walked over the slab of step s
   // (one workgroup per CU owns the LDS, so nothing else would hide the HBM latency of the next slab).
   //   ELL_S : source = P H^T [cols x Mp], column j contiguous over the state index: slab[k][jj] = PHT[k, x0 + jj];
@@ -451,17 +461,25 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
   //   else  : source [X x cols], contiguous index first: slab[k][xx] = Src[x0 + xx, k];
   //           thread fetches xx = tid % XC, k = tid / XC + (NT / XC) u
   double r[RN];
-  auto fetch = [&](int sidx) {
+  auto fetch = [&](const double* FSrc, int sidx) {
     const int x0 = sidx * XC;
     if (MODE == ELL_S) {
+      // one buffer resource per filter, the column as a scalar offset, the row as one 32-bit per-lane offset: no 64-bit
+      // address registers (hoisted out of the slab loop they spilled, and a scratch reload waits on vmcnt - behind every
+      // prefetch load in flight)
       constexpr int KU = RN / (XC / NW);
+      const __amdgpu_buffer_rsrc_t rs = ell_rsrc(FSrc);
+      const unsigned vo = (unsigned)lane * 8u;
 #pragma unroll
       for (int q = 0; q < XC / NW; ++q) {
         const int jj = wave + NW * q;
         const bool ok = x0 + jj < a.X;
-        const double* __restrict__ col = Src + (long)(x0 + (ok ? jj : 0)) * a.ldsrc;
+        const unsigned so = (unsigned)((x0 + (ok ? jj : 0)) * a.ldsrc) * 8u;
 #pragma unroll
-        for (int u = 0; u < KU; ++u) { const int k = lane + 64 * u; r[q * KU + u] = (XIVO_ELL_ABL != 2 && ok && k < cols) ? col[k] : 0.0; }
+        for (int u = 0; u < KU; ++u) {
+          const int k = lane + 64 * u;
+          r[q * KU + u] = (XIVO_ELL_ABL != 2 && ok && k < cols) ? ell_buf_ld(rs, vo, so + (unsigned)(64 * u) * 8u) : 0.0;
+        }
       }
     } else {
       // uniform 64-bit base (+ u * step, scalar) and one 32-bit per-lane byte offset: no per-load address VGPRs.
@@ -469,7 +487,7 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
       const int xx = tid % XC, kq = tid / XC;
       const bool ok = x0 + xx < a.X;
       const unsigned voff = ((unsigned)(ok ? xx : 0) + (unsigned)kq * (unsigned)a.ldsrc) * 8u;
-      const char* base = reinterpret_cast<const char*>(Src + x0);
+      const char* base = reinterpret_cast<const char*>(FSrc + x0);
       const size_t step = (size_t)(NT / XC) * (size_t)a.ldsrc * 8u;
       const int nu = cols / (NT / XC);
 #pragma unroll
@@ -497,11 +515,15 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
   };
 
   const int xx = lane % XC, half = lane / XC;
-  ell_cint* idx0 = (ell_cint*)(a.ell.idx + (long)filt * a.ell.stride_idx());
-  ell_cdouble* dR = (ell_cdouble*)(a.diagR + (long)filt * a.strideR);
   auto slab = [&](int k) -> double { return tile[k * XC + (xx ^ (k & 15))]; };
 
-  if (PF) fetch(s_begin);
+  const int fstep = PF ? a.persist_stride : 0;
+  if (PF) fetch(Src, s_begin);
+  for (;;) {   // (one trip unless persistent)
+  ell_cint* idx0 = (ell_cint*)(a.ell.idx + (long)filt * a.ell.stride_idx());
+  ell_cdouble* dR = (ell_cdouble*)(a.diagR + (long)filt * a.strideR);
+  const int nfilt = filt + fstep;
+  const bool more = fstep > 0 && nfilt < a.batch;
   for (int sidx = s_begin; sidx < s_end; ++sidx) {
     if (PF) {
       park();
@@ -530,8 +552,14 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
         for (int u = 0; u < 8; ++u) { const int k = k0 + kq + (NT / XC) * u; if (k < cols) tile[k * XC + (xq ^ (k & 15))] = r[u]; }
       }
     }
-    __syncthreads();
-    if (PF && sidx + 1 < s_end) fetch(sidx + 1);
+    // (prefetching form: LDS-only barrier - __syncthreads() would also wait for the acknowledgement of the output stores the
+    //  walk before just issued, a round trip to memory per slab; the prefetched registers were waited for by park())
+    if (PF) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+    if (PF) {
+      if (sidx + 1 < s_end) fetch(Src, sidx + 1);
+      else if (more) fetch(a.Src + (long)nfilt * a.strideSrc, s_begin);
+    }
 
     if constexpr (ell_tile_mf(MODE, CWU, XC, PWU)) {
       // ---- walk, matrix-core form (the hot instantiations: 12 common + 9 private slots, 64-wide slabs) --------------------
@@ -572,33 +600,85 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
         for (int c = 0; c < NC; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
         // the private slots first (plain FMAs into the zeroed tile), the dense common part on top of them: the other way
         // round the scheduler hoists every LDS read of the private part above the MFMA chain it depends on - and spills
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int p = p0 + lg + 4 * q;
-          const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT + CWU;
-          const unsigned short* pkp = pidx + p * ELL_PIW;
-          static_assert(PWU % 3 == 0, "three slots per step");
-#pragma unroll 1
-          for (int t0 = 0; t0 < PWU; t0 += 3) {
-            // three slots per step, their 12 gathers in flight together (the scheduler, left alone, serialises them in the
-            // second half-tile - one LDS round trip per gather)
-            d2 v[3]; double g[3][NC];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              v[u] = pv[t0 + u];
-              const int k = (int)pkp[t0 + u];
-              const double* trow = tile + k * XC;
-              const int sw = k & 15;
-#pragma unroll
-              for (int c = 0; c < NC; ++c) g[u][c] = trow[(16 * c + li) ^ sw];
+        if constexpr (NT == 512) {   // (the 8-wave instantiations have the registers for it: 256 per wave)
+          // all slot indices of this lane's two pairs up front (packed 16-bit, 6 registers per pair): a step then waits for
+          // ONE LDS round trip - its gathers - instead of two (index, then gather); the next step's coefficients are
+          // requested before this step's FMAs
+          uint2 iq[2][ELL_PIW / 4];
+  #pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint2* pq = reinterpret_cast<const uint2*>(pidx + (p0 + lg + 4 * q) * ELL_PIW);
+  #pragma unroll
+            for (int u = 0; u < ELL_PIW / 4; ++u) iq[q][u] = pq[u];
+          }
+  #pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int p = p0 + lg + 4 * q;
+            const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT + CWU;
+            static_assert(PWU % 3 == 0, "three slots per step");
+            d2 vn[3];
+  #pragma unroll
+            for (int u = 0; u < 3; ++u) vn[u] = pv[u];
+  #pragma unroll
+            for (int t0 = 0; t0 < PWU; t0 += 3) {
+              // three slots per step, their 12 gathers in flight together (the scheduler, left alone, serialises them in the
+              // second half-tile - one LDS round trip per gather)
+              d2 v[3]; double g[3][NC];
+  #pragma unroll
+              for (int u = 0; u < 3; ++u) {
+                const int t = t0 + u;
+                v[u] = vn[u];
+                const unsigned w = (t & 2) ? iq[q][t >> 2].y : iq[q][t >> 2].x;
+                const int k = (int)((t & 1) ? (w >> 16) : (w & 0xffffu));
+                const double* trow = tile + k * XC;
+                const int sw = k & 15;
+  #pragma unroll
+                for (int c = 0; c < NC; ++c) g[u][c] = trow[(16 * c + li) ^ sw];
+              }
+              if (t0 + 3 < PWU) {
+  #pragma unroll
+                for (int u = 0; u < 3; ++u) vn[u] = pv[t0 + 3 + u];
+              }
+              __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+              for (int u = 0; u < 3; ++u) {
+  #pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                  acc[c][2 * q] = fma(v[u][0], g[u][c], acc[c][2 * q]);
+                  acc[c][2 * q + 1] = fma(v[u][1], g[u][c], acc[c][2 * q + 1]);
+                }
+              }
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-#pragma unroll
-              for (int c = 0; c < NC; ++c) {
-                acc[c][2 * q] = fma(v[u][0], g[u][c], acc[c][2 * q]);
-                acc[c][2 * q + 1] = fma(v[u][1], g[u][c], acc[c][2 * q + 1]);
+          }
+        } else {
+  #pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int p = p0 + lg + 4 * q;
+            const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT + CWU;
+            const unsigned short* pkp = pidx + p * ELL_PIW;
+            static_assert(PWU % 3 == 0, "three slots per step");
+  #pragma unroll 1
+            for (int t0 = 0; t0 < PWU; t0 += 3) {
+              // three slots per step, their 12 gathers in flight together (the scheduler, left alone, serialises them in the
+              // second half-tile - one LDS round trip per gather)
+              d2 v[3]; double g[3][NC];
+  #pragma unroll
+              for (int u = 0; u < 3; ++u) {
+                v[u] = pv[t0 + u];
+                const int k = (int)pkp[t0 + u];
+                const double* trow = tile + k * XC;
+                const int sw = k & 15;
+  #pragma unroll
+                for (int c = 0; c < NC; ++c) g[u][c] = trow[(16 * c + li) ^ sw];
+              }
+              __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+              for (int u = 0; u < 3; ++u) {
+  #pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                  acc[c][2 * q] = fma(v[u][0], g[u][c], acc[c][2 * q]);
+                  acc[c][2 * q + 1] = fma(v[u][1], g[u][c], acc[c][2 * q + 1]);
+                }
               }
             }
           }
@@ -699,6 +779,12 @@ __global__ __launch_bounds__(ell_tile_threads(MODE, CWU, XC, PWU)) void ell_tile
   if (MODE == ELL_S && a.gate_here) {
     __syncthreads();                      // every store of S by this workgroup is acknowledged before anybody reads it back
     gate_ell_body(a.gate, filt, tile);
+    if (more) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // its LDS scratch is the next slab's
+  }
+  if (!more) break;
+  stage_ops(nfilt);                       // (visible to the walk behind the barrier that follows the next park)
+  filt = nfilt;
+  Src = a.Src + (long)filt * a.strideSrc;
   }
 }
 
@@ -766,11 +852,14 @@ int launch_zero_rows(double* H, long strideH, int ldh, int row0, int nrows, int 
   CHECK_LAUNCH();
 }
 
-template <int MODE, int CWU, int XC, int PWU>
+template <int MODE, int CWU, int XC, int PWU, bool TALL = true>
 static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) {
+  if constexpr (TALL && MODE == ELL_S && ell_tile_pf(MODE, CWU, XC, PWU)) {
+    if (a_in.cols <= 256) return launch_ell_tile_t<MODE, CWU, XC, PWU, false>(a_in, lds, s);
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC, PWU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ell_tile_kernel<MODE, CWU, XC, PWU, TALL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -783,12 +872,22 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   a.slabs_per_wg = ((ell_tile_pf(MODE, CWU, XC, PWU) || MODE == ELL_HP) && a.batch >= 1024) ? xchunks : 1;
   if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
-  const int grid = ((a.batch + 7) / 8) * 8 * wgs;
+  int grid = ((a.batch + 7) / 8) * 8 * wgs;
+  // persistent form of the prefetching instantiation: one workgroup per CU (they own the LDS one at a time anyway) walks
+  // filters b, b + G, ...; G a multiple of 8 keeps a filter on the XCD its index names
+  a.persist_stride = 0;
+  static const bool no_persist = getenv("XIVO_HIP_ELL_NO_PERSIST") != nullptr;   // A/B knob
+  if (ell_tile_pf(MODE, CWU, XC, PWU) && wgs == 1 && !no_persist) {
+    static int cus = 0;
+    if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus < 8) cus = 8; }
+    const int G = cus / 8 * 8;
+    if (grid > 2 * G) { a.persist_stride = G; grid = G; }
+  }
   if (!(MODE == ELL_S && XC == 64)) a.diag_out = nullptr;
   if (a_in.diag_done) *a_in.diag_done = a.diag_out ? 1 : 0;
   if (!(MODE == ELL_S && wgs == 1)) a.gate_here = 0;      // the gate rides along only when one workgroup forms the whole S of its filter
   if (a_in.gate_done) *a_in.gate_done = a.gate_here;
-  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU>), dim3(grid), dim3(ell_tile_threads(MODE, CWU, XC, PWU)), lds, s, a);
+  hipLaunchKernelGGL((ell_tile_kernel<MODE, CWU, XC, PWU, TALL>), dim3(grid), dim3(ell_tile_threads(MODE, CWU, XC, PWU)), lds, s, a);
   return (int)hipGetLastError();
 }
 // which form / instantiation the launcher picks: xc = 64 / 32 (slab form) or 0 (gather form)
