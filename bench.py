@@ -302,6 +302,9 @@ SUB_CONFIGS = [
     ("config4, the round-1 reading of 'fp32 MFMA': the three as-coded dense covariance products on the fp32 MFMA (XIVO_HIP_FLAG_FP32_COV), 4096 filters",
      ["--state-dim", "400", "--features", "150", "--batch", "4096", "--steps", "3", "--warmup", "1", "--flags", "32", "--tol-P", "5e-5",
       "--no-last-step-parity"]),
+    ("online-calibration build (USE_ONLINE_TEMPORAL_CALIB / _IMU_CALIB / _CAMERA_CALIB: N=276, 60 features with td / Cg / bg / 8 "
+     "intrinsics blocks), feature level: Jacobians + gating on the whole row + dense re-associated update, 4096 filters",
+     ["--level", "G", "--calib", "--flags", "16", "--batch", "4096", "--steps", "5", "--warmup", "2"]),
     ("TUM-VI size (N=203, 30 features, M=60), fp64, 8192 filters",
      ["--state-dim", "203", "--features", "30", "--batch", "8192", "--steps", "8", "--warmup", "2"]),
     ("metric point, dense AS-CODED pipeline (XIVO_HIP_FLAG_DENSE_H = --flags 64: H treated as dense, every product of "
@@ -378,6 +381,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra XIVO_HIP_FLAG_* bits (A/B knobs)")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--calib", action="store_true",
+                    help="--level G: the online-calibration build's layout and Jacobian blocks (N = 276; dense pipeline)")
     ap.add_argument("--no-mixed", action="store_true", help="skip the second timed loop (fp32 correction product)")
     ap.add_argument("--sub", action="store_true", help="child run of the `configs` array: no configs / dropin blocks of its own")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` array (the other BASELINE configurations, child runs)")
@@ -452,7 +457,10 @@ def main():
     if args.level == "G":
         # layout-faithful scene (SURVEY 8d "G-level"): 8 groups, 60 in-state features -> N = 23 + 48 + 180 = 251
         ng, nf, F = 8, 60, 60
-        N = 23 + 6 * ng + 3 * nf
+        # --calib: the reference's online-calibration build (USE_ONLINE_TEMPORAL_CALIB / _IMU_CALIB / _CAMERA_CALIB): kMotionSize
+        # 39 + 9 intrinsics slots in front of the groups -> N = 276; td / Cg / bg / intrinsics blocks in every row pair
+        gb = 48 if args.calib else 23
+        N = gb + 6 * ng + 3 * nf
         uniq = min(B, 16)
         from xivo_amd.lib import pose_dtype, group_dtype, feat_dtype
         sc = synth.g_level(ng, nf, F, uniq, seed=2000 + rank, cam=synth.EQUI)
@@ -472,7 +480,18 @@ def main():
             flags |= FLAG_DENSE_H | FLAG_REASSOC
         # (--oos: 16 spare rows - mixed stacking pads the OOS block to 16 rows behind the 2F in-state rows)
         ctx = Context(N, M + (16 if args.oos > 0 else 0), B, device=device, flags=flags)
-        ctx.set_layout(N, 23, ng, 23 + 6 * ng, nf, synth.EQUI)
+        ctx.set_layout(N, gb, ng, gb + 6 * ng, nf, synth.EQUI)
+        if args.calib:
+            from xivo_amd.lib import calib_dtype, cam_intr
+            ctx.set_calib(23, 24, 39, 8)                     # Index::td, Index::Cg, kCameraBegin, Camera::dim() (equidistant)
+            rngc = np.random.default_rng(5000 + rank)
+            cal = np.zeros(uniq, dtype=calib_dtype)
+            for b in range(uniq):
+                cal[b]["gyro"] = rngc.normal(size=3) * 0.3; cal[b]["Cg"] = (np.eye(3) + 0.01 * rngc.normal(size=(3, 3))).T.reshape(-1)
+                cal[b]["td"] = 0.005; cal[b]["Ca"] = np.eye(3).reshape(-1); cal[b]["intr"] = cam_intr(synth.EQUI)
+                poses[b]["Vsb"] = rngc.normal(size=3) * 0.5; poses[b]["bg"] = rngc.normal(size=3) * 0.01
+            for b0 in range(0, B, uniq):
+                ctx.set_calib_state(cal[:min(uniq, B - b0)], b0=b0)
         rngP = np.random.default_rng(3000 + rank)
         A_ = rngP.uniform(-1, 1, size=(uniq, N, N))
         P = (A_ @ np.transpose(A_, (0, 2, 1)) / N + 1e-3 * np.eye(N)[None]) * 1e-4
