@@ -719,3 +719,30 @@ def test_fp32_whitened_operands_beyond_one_workgroup(built, N, F, flags):
         assert np.array_equal(P32, P32.T)
     assert worst > 1e-12                                             # (it really took the float path)
     print("fp32 whitened operands: worst rel. Frobenius error on P+ = %.2e at N=%d M=%d" % (worst, N, 2 * F))
+
+
+def test_persistent_slab_kernel_ragged_batch(built):
+    """1043 filters (not a multiple of 8, more than two per CU): `ell<S>` runs its persistent form - one workgroup per CU
+    walks filters b, b + 256, ... with the next filter's first slab prefetched under the last walk - and the last round is
+    ragged. Every filter must equal its twin built from the same source filter bit for bit, and the oracle on a sample;
+    gating on (two features per filter pushed out)."""
+    N, F, B, U = 250, 80, 1043, 7
+    P1, H1, inn1, dR1 = _gating_case(N, F, U, 91)
+    idx = np.arange(B) % U
+    P, H, inn, dR = P1[idx], H1[idx], inn1[idx], dR1[idx]
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
+        ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5)
+        assert ctx.last_path() == 1
+        err = ctx.get_err(); Pn = ctx.download_P(); mask = ctx.get_gate(F)[0].astype(bool)
+        assert (ctx.get_status() == 0).all()
+    for b in range(U, B):
+        assert np.array_equal(err[b], err[b - U]) and np.array_equal(mask[b], mask[b - U])
+    for b in range(U, B, 13):
+        assert np.array_equal(Pn[b], Pn[b % U])
+    for b in (0, 3, 6):
+        m, d = _oracle_gate(P[b], H[b], inn[b], 2.25, 5.991, 1.1, 5)
+        assert np.array_equal(mask[b], m) and (~m).sum() >= 2
+        rows = np.repeat(m, 2)
+        e_ref, P_ref, _ = orc.update_joseph(H[b][rows], P[b], inn[b][rows], dR[b][rows])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
