@@ -746,3 +746,31 @@ def test_persistent_slab_kernel_ragged_batch(built):
         rows = np.repeat(m, 2)
         e_ref, P_ref, _ = orc.update_joseph(H[b][rows], P[b], inn[b][rows], dR[b][rows])
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+@pytest.mark.parametrize("N,F,steps", [(100, 20, 120), (250, 80, 40)])
+def test_long_chain_of_default_form_updates_stays_psd_and_close(built, N, F, steps):
+    """The default device form P - (W - D)^T (W + D) is PSD only up to rounding, not by construction as the as-coded
+    product (I - KH) P (I - KH)^T + K R K^T is. A long chain on the resident covariance - every update shrinks P along new
+    directions, cond(S) grows step by step, no noise is added in between - must stay symmetric, positive semi-definite and
+    next to the as-coded chain of the oracle: relative distance 1e-6 at every checkpoint (the per-update tolerance, not
+    accumulated), smallest eigenvalue above -1e-12 of the largest."""
+    B = 2
+    P, _, _, _ = synth.s_level(N, F, B, seed=5)
+    Pref = P.copy()
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P)
+        for it in range(steps):
+            _, H, inn, dR = synth.s_level(N, F, B, seed=700 + it)
+            ctx.set_measurements(H, inn, dR)
+            ctx.update_joseph()
+            assert (ctx.get_status() == 0).all()
+            for b in range(B):
+                _, Pref[b], _ = orc.update_joseph(H[b], Pref[b], inn[b], dR[b])
+            if it % 20 == 19 or it == steps - 1:
+                Pn = ctx.download_P()
+                for b in range(B):
+                    assert np.array_equal(Pn[b], Pn[b].T)
+                    w = np.linalg.eigvalsh(Pn[b])
+                    assert w.min() > -1e-12 * w.max(), (it, w.min(), w.max())
+                    assert rel_fro(Pn[b], Pref[b]) < TOL_P, (it, rel_fro(Pn[b], Pref[b]))
