@@ -15,7 +15,7 @@ python - "$O" <<'PY'
 import json,glob,sys,os
 for f in sorted(glob.glob(sys.argv[1]+"/*.json")):
     try:
-        d=json.loads(open(f).read().strip().splitlines()[-1]); s=d.get("stage_ms_per_step",{})
-        print(os.path.basename(f), round(d["value"]), round(d["ms_per_step"],3), {k:round(v,3) for k,v in s.items()}, (d.get("parity_check") or {}).get("ok"), (d.get("parity_check_last_timed_step") or {}).get("ok"))
+        d=json.loads(open(f).read().strip().splitlines()[-1]); s=d.get("stage_ms",d.get("stage_ms_per_step",{}))
+        print(os.path.basename(f), round(d["value"]), round(d["ms_per_step"],3), {k:round(v,3) for k,v in s.items()}, (d.get("parity_check") or {}).get("ok"), (d.get("parity_last") or d.get("parity_check_last_timed_step") or {}).get("ok"))
     except Exception as e: print(f,"ERR",open(f.replace(".json",".err")).read()[-300:])
 PY

@@ -28,7 +28,7 @@ import json,glob
 for f in sorted(glob.glob("gpurun_out/s3/*.json")):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1])
-        s=d.get("stage_ms_per_step",{})
+        s=d.get("stage_ms",d.get("stage_ms_per_step",{}))
         print(f.split("/")[-1], round(d["value"]), round(d["ms_per_step"],4), "chol", round(s.get("chol_S",0),4), d.get("parity_check",{}).get("ok"))
     except Exception as e: print(f, "ERR", e)
 PY

@@ -11,18 +11,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
+def _run(*extra, full=True):
+    """-> the verbose record (--full-out) by default, the printed compact line with full=False."""
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "512", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "full.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "512", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline", "--full-out", path, *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        assert len(lines[0]) < 6144          # the driver keeps the last 8 KB of stdout: the whole line has to fit
+        return json.load(open(path)) if full else json.loads(lines[0])
 
 
 def test_default_line(built):
-    d = _run()
+    d = _run("--no-configs", "--no-dropin")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -45,6 +51,26 @@ def test_default_line(built):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["kernel"] and r["avg_launch_ms"] > 0
     assert len(d["per_rank_updates_per_s"]) == 1
+
+
+def test_printed_line_is_compact_and_complete(built):
+    """What the driver's 8 KB tail keeps: contract keys, roofline, parity maxima, stage times, the drop-in medians mirrored
+    into `config` as flat scalars, one short row per sub-configuration (the child runs at their own batch sizes)."""
+    d = _run(full=False)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "parity_check", "parity_last", "stage_ms", "dropin", "configs"):
+        assert k in d, k
+    assert d["parity_check"]["ok"] and d["parity_last"]["ok"] and d["parity_last"]["n"] == 3
+    assert all(len(v) <= 120 for v in d["config"].values() if isinstance(v, str))
+    assert d["config"]["dropin_ms_250_160"] > 0 and d["config"]["dropin_ok_250_160"] is True and d["config"]["dropin_ms_203_60"] > 0
+    keys = [r["k"] for r in d["configs"]]
+    assert keys[:4] == ["cfg2", "cfg3", "cfg4_f64", "cfg4_f32w"] and {"calib", "tumvi", "glevel", "ransac", "frame_rk4", "frame_pd", "b1"} <= set(keys)
+    for r in d["configs"]:
+        assert "error" not in r, r
+        assert r.get("skipped") or (r["v"] > 0 and r["ok"] in (True, None)), r
+        if r["k"] in ("cfg2", "cfg3", "cfg4_f64", "cfg4_f32w", "tumvi", "glevel", "calib"):
+            assert r["ok"] is True, r
+    assert d["config"]["cfg2_upd_s"] == [r for r in d["configs"] if r["k"] == "cfg2"][0]["v"]
 
 
 def test_feature_level_and_config3_lines(built):
