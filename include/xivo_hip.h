@@ -125,7 +125,12 @@ enum {
    * 64 x 64 tiles - the same whitened Joseph evaluation spread over tens of CUs instead of one CU per filter (B = 1,
    * N = 250, M = 160: solve + product 0.07 instead of 0.13 ms). With this flag every batch size runs the kernels sized for
    * thousands of filters (one workgroup per filter, whole update inside the solve kernel). */
-  XIVO_HIP_FLAG_THROUGHPUT_ROUTE = 8192u
+  XIVO_HIP_FLAG_THROUGHPUT_ROUTE = 8192u,
+  /* The reference's USE_INVDEPTH build (src/CMakeLists.txt:10): a feature's local state is (X/Z, Y/Z, 1/Z) instead of
+   * (X/Z, Y/Z, log Z) - Feature::Xc goes through unproject_invz (src/feature.cpp:98-105, common/project.h:31-56) and
+   * Feature::z is 1 / x(2) (:120-126). Every kernel that unprojects a feature (in-state Jacobians, depth sub-filter and its
+   * candidate depth test, loop-closure rows) follows the flag; the Jacobian block d/dx changes accordingly. */
+  XIVO_HIP_FLAG_INVDEPTH = 32768u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,
@@ -256,7 +261,8 @@ int xivo_hip_get_ldlt_used(xivo_hip_ctx* ctx, int b0, int nb, int* used);
  * compressed rows (the same rows the batched hand-over builds on the device, bit for bit); an H_ without XIVO's row
  * structure takes the general entry points inside this call (same results). P_ crosses through the context's page-locked
  * block (one host copy each way; the boundary kernels address the block directly). Returns XIVO_HIP_ERR_NOT_SPD exactly when
- * xivo_hip_get_status would (only with XIVO_HIP_FLAG_NO_LDLT_FALLBACK); P and err_out are then the prior / undefined.
+ * xivo_hip_get_status would: with XIVO_HIP_FLAG_NO_LDLT_FALLBACK for any S the Cholesky cannot factor, and without it when the
+ * pivoted L D L^T fallback met non-finite arithmetic (a NaN / Inf in P_, H_ or diagR_); P is then the prior, err_out zero.
  * The context's staged row count becomes M.
  *   mode: XIVO_HIP_HOST_P_RESIDENT  the device copy of P (filter b) is current - P_ is not uploaded (no host edit since
  *                                   the last upload / download; P may be NULL when KEEP_P is set too)
@@ -352,9 +358,27 @@ int xivo_hip_stack(xivo_hip_ctx* ctx, int B, double R);
 /* Feature::ComputeOOSJacobian (src/oos.cpp:8-89) + SlowGivens
  * (src/helpers.cpp:13-23): per feature (2k-3) projected rows appended after
  * the in-state rows with diagR = Roos. rows_out[b] = total OOS rows. feats == NULL projects the list of the
- * previous call again (it stays resident; same nb and n_oos) - for a caller that re-linearises without new tracks. */
+ * previous call again (it stays resident; same nb and n_oos) - for a caller that re-linearises without new tracks.
+ * Camera-calibration builds (cam_dim > 0): the observations are projected with the filter's own intrinsics, and - as the
+ * reference codes ComputeOOSJacobianInternal (src/oos.cpp:39-89 writes the group / Wbc / Tbc blocks only) - the rows carry NO
+ * intrinsics block; of the row builders in that file only ComputeLCJacobian has one (:125-142, xivo_hip_close_loop_stack). */
 int xivo_hip_oos_project(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xivo_oos_in* feats,
                          double Roos, int* rows_out);
+/* One loop-closure match (Estimator::CloseLoopInternal, src/update.cpp:171-212; the mapper that FINDS matches is out of
+ * scope): an in-state feature ("old_feature") re-observed by the group in slot group_sind (Graph::LastAddedGroup) at pixel xp
+ * (the observation of the new feature that was matched to it). */
+typedef struct {
+  int feat;        /* position of the old feature in the resident feature list (xivo_hip_set_scene / xivo_hip_edit_batch);
+                      its state and anchor group give Xs = Feature::Xs(gbc), src/feature.cpp:107-118; -1 = absent match */
+  int group_sind;  /* obs.g->sind()                                                                                      */
+  double xp[2];    /* obs.xp                                                                                             */
+} xivo_lc_match;
+/* Feature::ComputeLCJacobian (src/oos.cpp:92-145) for the n matches of each filter in [b0, b0 + nb) + the stacking of
+ * CloseLoopInternal (src/update.cpp:183-196: H_.setZero(2n, N), row pair 2i from match i, diagR_ = Rlc): the staged
+ * measurement of those filters becomes the 2n loop-closure rows - d xp / d (group pose, Wbc, Tbc) and, for a context with
+ * camera calibration on (xivo_hip_set_calib, cam_dim > 0), the intrinsics block of :125-142. xivo_hip_update_joseph +
+ * xivo_hip_absorb_error then complete CloseLoopInternal (:207-208). matches: host, [nb x n]. */
+int xivo_hip_close_loop_stack(xivo_hip_ctx* ctx, int b0, int nb, int n, const xivo_lc_match* matches, double Rlc);
 /* Measurement compression (use_compression_ / compression_trigger_ratio_, src/estimator.h:399-402 - parsed by the
  * reference, src/estimator.cpp:115-117, but never acted on; xivo::QR, src/helpers.cpp:77-101 "QR-based measurement
  * compression"): call after xivo_hip_oos_project. For every filter whose OOS block has more than trigger_ratio (>= 1;

@@ -33,6 +33,22 @@ PIECES = [
     ("feature_xc", "src/feature.cpp", r"^Vec3 Feature::Xc\(Mat3 \*J\) \{", "block"),
     ("compute_jacobian", "src/feature.cpp", r"^void Feature::ComputeJacobian\(", "block"),
     ("fill_jacobian_block", "src/feature.cpp", r"^void Feature::FillJacobianBlock\(", "block"),
+    # round 5: the rest of the path - OOS / loop-closure row builders, depth sub-filter, integrator outer loops, Propagate, 1-pt RANSAC
+    ("oos_jacobian_struct", "src/jac.h", r"^struct OOSJacobian \{", "block"),
+    ("observation", "src/core.h", r"^struct Observation \{", "block"),
+    ("subfilter_options", "src/options.h", r"^struct SubfilterOptions \{", "block"),
+    ("feature_xs", "src/feature.cpp", r"^Vec3 Feature::Xs\(const SE3 &gbc, Mat3 \*J\) \{", "block"),
+    ("compute_oos_jacobian", "src/oos.cpp", r"^int Feature::ComputeOOSJacobian\(", "block"),
+    ("compute_oos_jacobian_internal", "src/oos.cpp", r"^void Feature::ComputeOOSJacobianInternal\(", "block"),
+    ("compute_lc_jacobian", "src/oos.cpp", r"^void Feature::ComputeLCJacobian\(", "block"),
+    ("subfilter_update", "src/feature.cpp", r"^void Feature::SubfilterUpdate\(", "block"),
+    ("rk4", "src/rk4.cpp", r"^void Estimator::RK4\(", "block"),
+    ("prince_dormand", "src/princedormand.cpp", r"^void Estimator::PrinceDormand\(", "block"),
+    ("propagate", "src/estimator.cpp", r"^void Estimator::Propagate\(bool visual_meas\) \{", "block"),
+    ("one_point_ransac", "src/update.cpp", r"^Estimator::OnePointRANSAC\(", "block"),   # (its return type sits on the line above)
+    ("find_new_ref_group", "src/estimator.cpp", r"^GroupPtr Estimator::FindNewRefGroup\(", "block"),
+    ("backup_state", "src/estimator.cpp", r"^void Estimator::BackupState\(", "block"),
+    ("restore_state", "src/estimator.cpp", r"^void Estimator::RestoreState\(", "block"),
 ]
 
 

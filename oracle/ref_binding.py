@@ -321,16 +321,133 @@ class RefX:
                     Cg=np.ascontiguousarray(Cgf), Ca=np.ascontiguousarray(Caf), cam=camo)
 
 
+    # ---- round 5: the remaining rows of the path on the reference's own text -------------------------------------------
+    def _state30(self, X):
+        return np.ascontiguousarray(np.concatenate([_F(X.Rsb).reshape(-1, order="F"), X.Tsb, X.Vsb, X.bg, X.ba,
+                                                    _F(X.Rsg).reshape(-1, order="F")]), dtype=np.float64)
+
+    def max_group(self):
+        self.lib.refx_max_group.restype = C.c_int
+        return self.lib.refx_max_group()
+
+    def use_invdepth(self):
+        self.lib.refx_use_invdepth.restype = C.c_int
+        return bool(self.lib.refx_use_invdepth())
+
+    def feature_xs(self, x, Rsbr, Tsbr, Rbc, Tbc):
+        """Feature::Xs(gbc) as extracted (src/feature.cpp:107-118; Xc through unproject_logz / unproject_invz per build)."""
+        out = np.zeros(3)
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, Tsbr, Tbc)]
+        mats = [_F(Rsbr), _F(Rbc)]
+        self.lib.refx_feature_xs(_p(keep[0]), _p(mats[0]), _p(keep[1]), _p(mats[1]), _p(keep[2]), _p(out))
+        return out
+
+    def compute_oos_jacobian(self, x, Rsbr, Tsbr, obs, groups_R, groups_T, Rbc, Tbc, cam, min_obs=5, instate=None):
+        """Feature::ComputeOOSJacobian (+Internal, SlowGivens) as extracted, whole-buffer quirk of src/oos.cpp:28 included.
+        obs = [(g_sind, xp), ...]. Returns (rows, Hx [rows, N], inn [rows], Xs); rows = 0 below min_obs in-state observations."""
+        n = len(obs)
+        oR = np.ascontiguousarray(np.stack([_F(groups_R[g]).reshape(-1, order="F") for g, _ in obs]))
+        oT = np.ascontiguousarray(np.stack([np.asarray(groups_T[g], float) for g, _ in obs]))
+        osind = np.ascontiguousarray([g for g, _ in obs], dtype=np.int32)
+        oin = np.ascontiguousarray(np.ones(n) if instate is None else instate, dtype=np.int32)
+        oxp = np.ascontiguousarray(np.stack([np.asarray(p, float) for _, p in obs]))
+        cap = 2 * self.max_group()
+        Hx = np.zeros(cap * self.N); inn = np.zeros(cap); Xs = np.zeros(3)
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, Tsbr, Tbc)]
+        mats = [_F(Rsbr), _F(Rbc)]
+        c = _cam(cam)
+        self.lib.refx_compute_oos_jacobian.restype = C.c_int
+        rows = self.lib.refx_compute_oos_jacobian(_p(keep[0]), _p(mats[0]), _p(keep[1]), C.c_int(n), _p(oR), _p(oT), _p(osind), _p(oin), _p(oxp),
+                                                  _p(mats[1]), _p(keep[2]), C.byref(c), C.c_int(min_obs), _p(Xs), _p(Hx), _p(inn))
+        if rows <= 0:
+            return 0, np.zeros((0, self.N)), np.zeros(0), Xs
+        return rows, np.ascontiguousarray(Hx[:rows * self.N].reshape(self.N, rows).T), inn[:rows].copy(), Xs
+
+    def compute_lc_jacobian(self, x, Rsbr, Tsbr, obs_R, obs_T, obs_sind, obs_xp, Rbc, Tbc, cam):
+        """Feature::ComputeLCJacobian as extracted, one call per match on a zeroed H_ / inn_ (Estimator::CloseLoopInternal,
+        src/update.cpp:183-196). Arrays over the n matches. Returns (H [2n, N], inn [2n])."""
+        n = len(obs_sind)
+        xs = np.ascontiguousarray(x, dtype=np.float64).reshape(n, 3)
+        rR = np.ascontiguousarray(np.stack([_F(R).reshape(-1, order="F") for R in Rsbr])); rT = np.ascontiguousarray(Tsbr, dtype=np.float64).reshape(n, 3)
+        oR = np.ascontiguousarray(np.stack([_F(R).reshape(-1, order="F") for R in obs_R])); oT = np.ascontiguousarray(obs_T, dtype=np.float64).reshape(n, 3)
+        osind = np.ascontiguousarray(obs_sind, dtype=np.int32); oxp = np.ascontiguousarray(obs_xp, dtype=np.float64).reshape(n, 2)
+        H = np.zeros((2 * n, self.N), order="F"); inn = np.zeros(2 * n)
+        Rb = _F(Rbc); Tb = np.ascontiguousarray(Tbc, dtype=np.float64); c = _cam(cam)
+        self.lib.refx_compute_lc_jacobian(C.c_int(n), _p(xs), _p(rR), _p(rT), _p(oR), _p(oT), _p(osind), _p(oxp), _p(Rb), _p(Tb), C.byref(c),
+                                          _p(H), _p(inn))
+        return np.ascontiguousarray(H), inn
+
+    def subfilter_update(self, x, P, xp_meas, Rsb, Tsb, Rbc, Tbc, Rsbr, Tsbr, cam, Rtri, MH_thresh, ready_steps, init_counter,
+                         outlier_counter):
+        """Feature::SubfilterUpdate as extracted. Returns (x, P, status 0/1, init_counter, outlier_counter) like Ref's."""
+        xs = np.ascontiguousarray(x, dtype=np.float64).copy(); Pf = _F(P).copy(order="F")
+        ic = C.c_int(int(init_counter)); oc = C.c_double(float(outlier_counter)); c = _cam(cam)
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (xp_meas, Tsb, Tbc, Tsbr)]
+        mats = [_F(Rsb), _F(Rbc), _F(Rsbr)]
+        self.lib.refx_subfilter_update.restype = C.c_int
+        st = self.lib.refx_subfilter_update(_p(xs), _p(Pf), _p(keep[0]), _p(mats[0]), _p(keep[1]), _p(mats[1]), _p(keep[2]), _p(mats[2]),
+                                            _p(keep[3]), C.byref(c), C.c_double(Rtri), C.c_double(MH_thresh), C.c_int(ready_steps),
+                                            C.byref(ic), C.byref(oc))
+        return xs, np.ascontiguousarray(Pf), st, ic.value, oc.value
+
+    def propagate(self, method, X, P, last_gyro, last_accel, slope_gyro, slope_accel, dt_ns, Qimu, Qmodel, g_vec, stepsize=0.002,
+                  curr_gyro=None, curr_accel=None, Cg=None, Ca=None):
+        """Estimator::Propagate as extracted, with the outer loops Estimator::RK4 / PrinceDormand as extracted. curr_* given: an
+        IMU message (slopes computed, :559-568); else a visual message (slopes as handed in, :569-575). dt = dt_ns ns.
+        Returns dict(Rsb, Tsb, Vsb, P, last_gyro, last_accel, slope_gyro, slope_accel)."""
+        assert P.shape[0] == self.N
+        st = self._state30(X); Pf = _F(P).copy(order="F")
+        visual = curr_gyro is None
+        lg = np.ascontiguousarray(last_gyro, dtype=np.float64).copy(); la = np.ascontiguousarray(last_accel, dtype=np.float64).copy()
+        sg = np.ascontiguousarray(slope_gyro, dtype=np.float64).copy(); sa = np.ascontiguousarray(slope_accel, dtype=np.float64).copy()
+        cg = np.zeros(3) if visual else np.ascontiguousarray(curr_gyro, dtype=np.float64)
+        ca = np.zeros(3) if visual else np.ascontiguousarray(curr_accel, dtype=np.float64)
+        gv = np.ascontiguousarray(g_vec, dtype=np.float64)
+        mats = [_F(Qimu), _F(Qmodel), _F(np.eye(3) if Cg is None else Cg), _F(np.eye(3) if Ca is None else Ca)]
+        self.lib.refx_propagate.restype = C.c_int
+        rc = self.lib.refx_propagate(C.c_int(0 if method == "RK4" else 1), C.c_int(1 if visual else 0), _p(st), _p(Pf), _p(lg), _p(la), _p(cg),
+                                     _p(ca), _p(sg), _p(sa), C.c_longlong(int(dt_ns)), _p(mats[0]), _p(mats[1]), _p(gv), _p(mats[2]),
+                                     _p(mats[3]), C.c_double(stepsize))
+        if rc != 0:
+            raise RuntimeError("the extracted integrators fixed another step size earlier in this process (function-local static)")
+        return dict(Rsb=st[0:9].reshape(3, 3).T.copy(), Tsb=st[9:12].copy(), Vsb=st[12:15].copy(), P=np.ascontiguousarray(Pf),
+                    last_gyro=lg, last_accel=la, slope_gyro=sg, slope_accel=sa)
+
+    def one_point_ransac(self, X, Rbc, Tbc, P, x, xp, ref_sind, sind, gR, gT, cam, R, ransac_thresh, ransac_chi2, gauge_sind=-1,
+                         absorb_groups=None, in_update=None, status=None, ransac_prob=0.99):
+        """Estimator::OnePointRANSAC as extracted - the whole function. gR / gT: kMaxGroup poses by slot. Returns
+        dict(keep [F] bool, status [F], n_rejected, P, x, J [F, 2, N]) - P / x as the function leaves them (restored)."""
+        F = len(sind); N = self.N; G = self.max_group()
+        assert len(gR) == G
+        st = self._state30(X); Pf = _F(P).copy(order="F")
+        xs = np.ascontiguousarray(x, dtype=np.float64).copy().reshape(F, 3); xps = np.ascontiguousarray(xp, dtype=np.float64).reshape(F, 2)
+        stt = np.full(F, 3, dtype=np.int32) if status is None else np.ascontiguousarray(status, dtype=np.int32).copy()
+        gRf = np.ascontiguousarray(np.stack([_F(R_).reshape(-1, order="F") for R_ in gR])); gTf = np.ascontiguousarray(gT, dtype=np.float64).reshape(G, 3)
+        ab = (1 << G) - 1 if absorb_groups is None else int(absorb_groups)
+        iu = np.ascontiguousarray(np.zeros(F) if in_update is None else in_update, dtype=np.int32)
+        keep = np.zeros(F, dtype=np.int32); nrej = C.c_int(); J = np.zeros((F, 2 * N)); c = _cam(cam)
+        Rb = _F(Rbc); Tb = np.ascontiguousarray(Tbc, dtype=np.float64)
+        rs = np.ascontiguousarray(ref_sind, dtype=np.int32); si = np.ascontiguousarray(sind, dtype=np.int32)
+        self.lib.refx_one_point_ransac.restype = C.c_int
+        self.lib.refx_one_point_ransac(C.c_int(F), _p(xs), _p(xps), _p(rs), _p(si), _p(stt), _p(gRf), _p(gTf), _p(st), _p(Rb), _p(Tb), _p(Pf),
+                                       C.c_double(R), C.c_double(ransac_thresh), C.c_double(ransac_prob), C.c_double(ransac_chi2),
+                                       C.c_int(int(gauge_sind)), C.c_ulonglong(ab), _p(iu), C.byref(c), _p(keep), C.byref(nrej), _p(J))
+        return dict(keep=keep.astype(bool), status=stt, n_rejected=nrej.value, P=np.ascontiguousarray(Pf), x=xs,
+                    J=np.stack([J[f].reshape(N, 2).T for f in range(F)]))
+
+
 _REFX = {}
 
 
 def loadx(N=203):
     """The extracted-text library compiled for state size N (203 or 251), or N = "calib": the default sizes with the
-    reference's three online-calibration defines (N = 228); raises FileNotFoundError if it was never built."""
+    reference's three online-calibration defines (N = 228), or N = "invdepth": the 8-group / 60-feature sizes (N = 251) with
+    -DUSE_INVDEPTH; raises FileNotFoundError if it was never built."""
     if N in _REFX:
         return _REFX[N]
     for v in (("v4", "v3") if _has_avx512() else ("v3",)):
-        path = os.path.join(_HERE, "_ref", f"libxivo_refx_calib_{v}.so" if N == "calib" else f"libxivo_refx_n{N}_{v}.so")
+        name = {"calib": "calib", "invdepth": "n251inv"}.get(N, f"n{N}")
+        path = os.path.join(_HERE, "_ref", f"libxivo_refx_{name}_{v}.so")
         if os.path.exists(path):
             _REFX[N] = RefX(path)
             return _REFX[N]

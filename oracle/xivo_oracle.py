@@ -346,16 +346,73 @@ def unproject_logz(x):
     return np.array([x[0] * z, x[1] * z, z]), np.array([[z, 0, x[0] * z], [0, z, x[1] * z], [0, 0, z]])
 
 
+def unproject_invz(x):
+    """common/project.h:52-56: unproject_invz = project_invz (:31-46) applied to (X/Z, Y/Z, 1/Z)"""
+    r = x[2]
+    return (np.array([x[0] / r, x[1] / r, 1.0 / r]),
+            np.array([[1 / r, 0, -x[0] / (r * r)], [0, 1 / r, -x[1] / (r * r)], [0, 0, -1 / (r * r)]]))
+
+
+def feature_xc(x, invdepth=False):
+    """Feature::Xc (src/feature.cpp:98-105): unproject_logz, or unproject_invz in the USE_INVDEPTH build"""
+    return unproject_invz(x) if invdepth else unproject_logz(x)
+
+
+def feature_z(x, invdepth=False):
+    """Feature::z (src/feature.cpp:120-126)"""
+    return 1.0 / x[2] if invdepth else math.exp(x[2])
+
+
+def feature_xs(x, Rsbr, Tsbr, Rbc, Tbc, invdepth=False):
+    """Feature::Xs(gbc) (src/feature.cpp:107-118): gsc = ref_->gsb() * gbc; Xs = gsc * Xc"""
+    Xc, _ = feature_xc(x, invdepth)
+    return (Rsbr @ Rbc) @ Xc + (Rsbr @ Tbc + Tsbr)
+
+
+# ----------------------------------------------------------------------------
+# a9b: Feature::ComputeLCJacobian (src/oos.cpp:92-145) under the stacking of
+# Estimator::CloseLoopInternal (src/update.cpp:183-196)
+# ----------------------------------------------------------------------------
+def lc_jacobian_rows(matches, Rbc, Tbc, cam, layout, invdepth=False):
+    """matches = [dict(x, Rsbr, Tsbr: the OLD feature's state and anchor-group pose; Rsb, Tsb, g_sind: the observing group;
+    xp: the observed pixel)]. Returns (H [2n, N], inn [2n]) - H_.setZero(2n, N) then one ComputeLCJacobian per match."""
+    n = len(matches)
+    H = np.zeros((2 * n, layout.N)); inn = np.zeros(2 * n)          # update.cpp:184-186
+    Rbc_t = Rbc.T
+    for i, m in enumerate(matches):
+        Rsb_t = np.asarray(m["Rsb"]).T
+        goff = layout.group_begin + 6 * int(m["g_sind"])            # :98
+        Xb = Rsb_t @ (feature_xs(m["x"], m["Rsbr"], m["Tsbr"], Rbc, Tbc, invdepth) - m["Tsb"])   # :107
+        dXb_dTsb = -Rsb_t; dXb_dWsb = hat(Xb)                      # :109-110
+        Xcn = Rbc_t @ (Xb - Tbc)                                    # :113
+        dXcn_dXb = Rbc_t; dXcn_dTbc = -Rbc_t; dXcn_dWbc = hat(Xcn)  # :114-116
+        dXcn_dTsb = dXcn_dXb @ dXb_dTsb                             # :120
+        dXcn_dWsb = dXcn_dXb @ dXb_dWsb                             # :121
+        xcn, dxcn_dXcn = project(Xcn)                               # :123
+        xp, dxp_dxcn = camera_project(cam, xcn)                     # :125-130
+        dxp_dXcn = dxp_dxcn @ dxcn_dXcn                             # :132
+        st = 2 * i
+        H[st:st + 2, goff:goff + 3] = dxp_dXcn @ dXcn_dWsb          # :135
+        H[st:st + 2, goff + 3:goff + 6] = dxp_dXcn @ dXcn_dTsb      # :136
+        H[st:st + 2, WBC:WBC + 3] = dxp_dXcn @ dXcn_dWbc            # :137
+        H[st:st + 2, TBC:TBC + 3] = dxp_dXcn @ dXcn_dTbc            # :138
+        if getattr(layout, "cam_dim", 0) > 0:                       # :140-143 (USE_ONLINE_CAMERA_CALIB)
+            jacc = camera_project_jacc(cam, xcn)
+            H[st:st + 2, layout.cam_begin:layout.cam_begin + layout.cam_dim] = jacc[:, :layout.cam_dim]
+        inn[st:st + 2] = np.asarray(m["xp"], dtype=np.float64) - xp  # :145
+    return H, inn
+
+
 # ----------------------------------------------------------------------------
 # a4: Feature::ComputeJacobian (src/feature.cpp:542-656)
 # ----------------------------------------------------------------------------
 def compute_jacobian(x, xp_meas, Rsbr, Tsbr, Rsb, Tsb, Rbc, Tbc, cam, layout, ref_sind, sind,
-                     return_cache=False, calib=None):
+                     return_cache=False, calib=None, invdepth=False):
     """Returns (J [2 x N], inn [2], blocks [7,2,3]) for one in-state feature.
     calib = dict(gyro, Cg, bg, Vsb, td) with a layout from calib_layout(): the online-calibration builds' blocks as well
     (src/feature.cpp:592-609, :611-618, :632-651); then also returns Jc [2, 22] = [td | Cg 9 | bg 3 | intrinsics 9] last."""
     Rsb_t, Rbc_t = Rsb.T, Rbc.T
-    Xc, dXc_dx = unproject_logz(x)                       # :555 (Xc(&cache_.dXc_dx), feature.cpp:98-105)
+    Xc, dXc_dx = feature_xc(x, invdepth)                 # :555 (Xc(&cache_.dXc_dx), feature.cpp:98-105)
     Xbr = Rbc @ Xc + Tbc                                 # :556
     Xs = Rsbr @ Xbr + Tsbr                               # :557
     Xb = Rsb_t @ (Xs - Tsb)                              # :558
@@ -929,13 +986,11 @@ FEAT_INITIALIZING, FEAT_READY = 0, 1
 
 
 def subfilter_update(x, P, xp_meas, Rsb, Tsb, Rbc, Tbc, Rsbr, Tsbr, cam, Rtri=3.5, MH_thresh=5.991, ready_steps=5,
-                     init_counter=0, outlier_counter=0.0):
+                     init_counter=0, outlier_counter=0.0, invdepth=False):
     """Returns (x, P, status, init_counter, outlier_counter). 3x3 matrices row-major [i, j]."""
     x = np.asarray(x, dtype=np.float64); P = np.asarray(P, dtype=np.float64)
     init_counter += 1                                              # :256
-    z = math.exp(x[2])                                             # unproject_logz, common/project.h:80-95
-    Xc = np.array([x[0] * z, x[1] * z, z])
-    dXc_dx = np.array([[z, 0, x[0] * z], [0, z, x[1] * z], [0, 0, z]])
+    Xc, dXc_dx = feature_xc(x, invdepth)                           # :258 Xc(&dXc_dx), feature.cpp:98-105
     # gtot = (gsb * gbc)^-1 * ref.gsb * gbc  (:260)
     Rsc, Tsc = Rsb @ Rbc, Rsb @ Tbc + Tsb
     Rrc, Trc = Rsbr @ Rbc, Rsbr @ Tbc + Tsbr
@@ -961,9 +1016,9 @@ def subfilter_update(x, P, xp_meas, Rsb, Tsb, Rbc, Tbc, Rsbr, Tsbr, cam, Rtri=3.
     return x, P, status, init_counter, outlier_counter
 
 
-def candidate_flags(x, status, outlier_counter, zmin=0.05, zmax=5.0, max_subfilter_outlier=0.01):
+def candidate_flags(x, status, outlier_counter, zmin=0.05, zmax=5.0, max_subfilter_outlier=0.01, invdepth=False):
     """(Criteria::Candidate, Criteria::CandidateStrict), src/options.cpp:10-33."""
-    zed = math.exp(x[2])                                           # Feature::z(), feature.cpp:120-126
+    zed = feature_z(x, invdepth)                                   # Feature::z(), feature.cpp:120-126
     ok = outlier_counter < max_subfilter_outlier and zmin < zed < zmax
     return (status in (FEAT_READY, FEAT_INITIALIZING)) and ok, status == FEAT_READY and ok
 

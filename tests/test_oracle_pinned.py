@@ -791,3 +791,187 @@ def test_extracted_calibration_build_motion_side_live():
     for name in ("Rsb", "Tsb", "Vsb", "bg", "ba", "Rsg", "Rbc", "Tbc", "Cg", "Ca"):
         assert np.abs(st[name] - o[name]).max() < 1e-15, name
     assert st["td"] == o["td"]
+
+
+# ---- round 5: the rest of the path on the reference's own text (golden_v6.npz; tests/golden/make_golden_v6.py) --------------------
+G6 = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v6.npz"))
+
+
+def _v6():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_v6", os.path.join(os.path.dirname(__file__), "golden", "make_golden_v6.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def _lay_of(build, name):
+    if build == "calib":
+        return orc.calib_layout(15, 30, True, True, CAM_DIM[name])
+    return orc.Layout(8, 60)
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+@pytest.mark.parametrize("build", ["n251", "calib", "invdepth"])
+def test_golden_v6_loop_closure_rows(build, name):
+    """oracle lc_jacobian_rows against stored rows of the extracted Feature::ComputeLCJacobian (src/oos.cpp:92-145) in three
+    builds: default, online calibration (the intrinsics block of :140-143), USE_INVDEPTH (Xs through unproject_invz)"""
+    m = _v6()
+    sc, _, matches, _ = m.lc_case(build, CAMS[name], 3)
+    lay = _lay_of(build, name)
+    assert lay.N == int(G6[f"lc_{build}_{name}_N"][0])
+    H, inn = orc.lc_jacobian_rows(matches, sc["Rbc"][0], sc["Tbc"][0], CAMS[name], lay, invdepth=(build == "invdepth"))
+    cols = G6[f"lc_{build}_{name}_cols"]
+    assert np.nonzero(np.abs(H).sum(0))[0].tolist() == cols.tolist()
+    assert np.abs(H[:, cols] - G6[f"lc_{build}_{name}_H"]).max() / np.abs(H).max() < 1e-12
+    assert np.abs(inn - G6[f"lc_{build}_{name}_inn"]).max() < 1e-10
+    if build == "calib":       # the intrinsics block is there, and only the slots of this camera model
+        cb = lay.cam_begin
+        assert set(range(cb, cb + CAM_DIM[name])) >= {c for c in cols.tolist() if cb <= c < cb + 9} != set()
+
+
+def test_extracted_loop_closure_rows_live():
+    m = _v6()
+    for build in ("n251", "calib", "invdepth"):
+        lib = _refx({"n251": 251}.get(build, build))
+        for name in CAMS:
+            for seed in (4, 5):
+                sc, _, matches, _ = m.lc_case(build, CAMS[name], seed, n=5)
+                H, inn = lib.compute_lc_jacobian([q["x"] for q in matches], [q["Rsbr"] for q in matches], [q["Tsbr"] for q in matches],
+                                                 [q["Rsb"] for q in matches], [q["Tsb"] for q in matches], [q["g_sind"] for q in matches],
+                                                 [q["xp"] for q in matches], sc["Rbc"][0], sc["Tbc"][0], CAMS[name])
+                Ho, io = orc.lc_jacobian_rows(matches, sc["Rbc"][0], sc["Tbc"][0], CAMS[name], _lay_of(build, name), invdepth=(build == "invdepth"))
+                assert np.abs(H - Ho).max() / np.abs(H).max() < 1e-12 and np.abs(inn - io).max() < 1e-10
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_golden_v6_invdepth_jacobian_and_subfilter(name):
+    """USE_INVDEPTH build (src/feature.cpp:98-105): ComputeJacobian + FillJacobianBlock, SubfilterUpdate, Feature::z"""
+    m = _v6()
+    cam = CAMS[name]; lay = orc.Layout(8, 60)
+    sc = synth.g_level(8, 60, 60, 1, seed=9, cam=cam)
+    for i in (0, 17, 59):
+        r = int(sc["ref"][0, i]); x = m.to_invdepth(sc["x"][0, i])
+        xp = np.array([cam["cx"], cam["cy"]]) + np.array([13.0 * (i % 5) - 20, 9.0 * (i % 7) - 25])
+        J, inn, _ = orc.compute_jacobian(x, xp, sc["gR"][0, r], sc["gT"][0, r], sc["Rsb"][0], sc["Tsb"][0], sc["Rbc"][0], sc["Tbc"][0], cam, lay,
+                                         r, int(sc["sind"][0, i]), invdepth=True)
+        k = f"inv_jac_{name}_{i}"
+        cols = G6[k + "_cols"]
+        assert np.nonzero(np.abs(J).sum(0))[0].tolist() == cols.tolist()
+        assert np.abs(J[:, cols] - G6[k + "_J"]).max() / np.abs(J).max() < 1e-12 and np.abs(inn - G6[k + "_inn"]).max() < 1e-10
+        H = np.zeros((2, lay.N)); orc.fill_jacobian_block(H, 0, J, lay, r, int(sc["sind"][0, i]))
+        assert np.abs(H[:, G6[k + "_Hcols"]] - G6[k + "_H"]).max() / np.abs(H).max() < 1e-12
+        # the same point in the log-depth parametrisation: every block but d/dx is unchanged, d/dx differs by the chain rule
+        Jl, _, _ = orc.compute_jacobian(sc["x"][0, i], xp, sc["gR"][0, r], sc["gT"][0, r], sc["Rsb"][0], sc["Tsb"][0], sc["Rbc"][0], sc["Tbc"][0],
+                                        cam, lay, r, int(sc["sind"][0, i]))
+        fo = lay.feature_begin + 3 * int(sc["sind"][0, i])
+        assert np.abs(np.delete(J - Jl, np.s_[fo:fo + 3], axis=1)).max() < 1e-9 * np.abs(J).max()
+        assert np.abs(J[:, fo:fo + 2] - Jl[:, fo:fo + 2]).max() < 1e-9 * np.abs(J).max()
+        assert np.abs(J[:, fo + 2] * (-x[2]) - Jl[:, fo + 2]).max() < 1e-9 * np.abs(J).max()      # d(1/Z)/d(log Z) = -1/Z
+    c = m.sub_case(cam, 4, invdepth=True)
+    xs, Ps, st, ic, oc = orc.subfilter_update(c["x"], c["P"], c["xp"], c["Rsb"], c["Tsb"], c["Rbc"], c["Tbc"], c["Rsbr"], c["Tsbr"], cam,
+                                              3.5, 5.991, 5, c["init_counter"], c["outlier_counter"], invdepth=True)
+    g = G6[f"inv_sub_{name}"]
+    assert rel(xs, g[:3]) < 1e-10 and rel(Ps.reshape(-1), g[3:12]) < 1e-9 and [st, ic] == [int(g[12]), int(g[13])] and abs(oc - g[14]) < 1e-9 * max(1, g[14])
+    assert abs(orc.feature_z(c["x"], True) - 1.0 / c["x"][2]) == 0.0
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_golden_v6_oos_rows_and_subfilter_of_the_extracted_text(name):
+    """Feature::ComputeOOSJacobian (+Internal, SlowGivens) and Feature::SubfilterUpdate as extracted. The reference hands
+    SlowGivens the WHOLE 2 * kMaxGroup-row buffers (src/oos.cpp:28): its result = the rows this repo (and the oracle) compute
+    from the 2k live rows + exactly-zero rows, one per unused buffer row."""
+    m = _v6()
+    cam = CAMS[name]; lay = orc.Layout(8, 60)
+    sc, i, r, obs = m.oos_case(cam, 2)
+    Xs = orc.feature_xs(sc["x"][0, i], sc["gR"][0, r], sc["gT"][0, r], sc["Rbc"][0], sc["Tbc"][0])
+    assert rel(Xs, G6[f"oos_{name}_Xs"]) < 1e-14
+    Hx, rp, _ = orc.oos_jacobian(Xs, obs, sc["gR"][0], sc["gT"][0], sc["Rbc"][0], sc["Tbc"][0], cam, lay)
+    k = len(obs)
+    assert Hx.shape[0] == 2 * k - 3
+    assert int(G6[f"oos_{name}_rows"][0]) == 2 * 8 - 3                     # whole buffer: 16 rows, rank 3
+    nz, cols = G6[f"oos_{name}_nzrows"], G6[f"oos_{name}_cols"]
+    assert len(nz) == 2 * k - 3                                            # ... of which 2k - 3 are not exactly zero
+    assert np.nonzero(np.abs(Hx).sum(0))[0].tolist() == cols.tolist()
+    assert np.abs(Hx[:, cols] - G6[f"oos_{name}_Hx"]).max() / np.abs(Hx).max() < 1e-10
+    inn = G6[f"oos_{name}_inn"]
+    assert np.abs(rp - inn[nz]).max() < 1e-9 * max(1.0, np.abs(rp).max()) and np.abs(np.delete(inn, nz)).max() == 0.0
+    c = m.sub_case(cam, 4)
+    xs, Ps, st, ic, oc = orc.subfilter_update(c["x"], c["P"], c["xp"], c["Rsb"], c["Tsb"], c["Rbc"], c["Tbc"], c["Rsbr"], c["Tsbr"], cam,
+                                              3.5, 5.991, 5, c["init_counter"], c["outlier_counter"])
+    g = G6[f"sub_{name}"]
+    assert rel(xs, g[:3]) < 1e-10 and rel(Ps.reshape(-1), g[3:12]) < 1e-9 and [st, ic] == [int(g[12]), int(g[13])] and abs(oc - g[14]) < 1e-9 * max(1, g[14])
+
+
+def test_extracted_oos_and_subfilter_equal_the_retyped_driver_live():
+    """extracted text == retyped driver (oracle/ref/xivo_ref.cpp) on the same inputs: the retyping of rounds 1-4 was faithful"""
+    m = _v6()
+    ref = _ref()
+    x251 = _refx(251)
+    lay = orc.Layout(8, 60)
+    for name, cam in CAMS.items():
+        for seed in (2, 3):
+            sc, i, r, obs = m.oos_case(cam, seed, k=5 + seed % 2)
+            rows, Hx, inn, Xs = x251.compute_oos_jacobian(sc["x"][0, i], sc["gR"][0, r], sc["gT"][0, r], obs, sc["gR"][0], sc["gT"][0],
+                                                          sc["Rbc"][0], sc["Tbc"][0], cam)
+            k = len(obs)
+            Hf = np.zeros((2 * k, 3)); Hxr = np.zeros((2 * k, lay.N)); rr = np.zeros(2 * k)
+            for c_, (g, xp) in enumerate(obs):
+                hf, hx, ii = ref.oos_internal(Xs, sc["gR"][0, g], sc["gT"][0, g], sc["Rbc"][0], sc["Tbc"][0], xp, cam, lay, g)
+                Hf[2 * c_:2 * c_ + 2] = hf; Hxr[2 * c_:2 * c_ + 2] = hx; rr[2 * c_:2 * c_ + 2] = ii
+            Hxp, rp = ref.slow_givens(Hf, Hxr, rr)[:2]
+            nz = np.nonzero(np.abs(Hx).sum(1))[0]
+            assert len(nz) == 2 * k - 3 and np.abs(Hx[nz] - Hxp).max() <= 1e-13 * np.abs(Hxp).max() and np.abs(inn[nz] - rp).max() <= 1e-12 * max(1, np.abs(rp).max())
+            # below the minimum number of in-state observations: no rows (src/oos.cpp:15, :32-34)
+            assert x251.compute_oos_jacobian(sc["x"][0, i], sc["gR"][0, r], sc["gT"][0, r], obs, sc["gR"][0], sc["gT"][0], sc["Rbc"][0],
+                                             sc["Tbc"][0], cam, min_obs=k + 1)[0] == 0
+        c = m.sub_case(cam, 4)
+        a = x251.subfilter_update(c["x"], c["P"], c["xp"], c["Rsb"], c["Tsb"], c["Rbc"], c["Tbc"], c["Rsbr"], c["Tsbr"], cam, 3.5, 5.991, 5,
+                                  c["init_counter"], c["outlier_counter"])
+        b = ref.subfilter_update(c["x"], c["P"], c["xp"], c["Rsb"], c["Tsb"], c["Rbc"], c["Tbc"], c["Rsbr"], c["Tsbr"], cam, 3.5, 5.991, 5,
+                                 c["init_counter"], c["outlier_counter"])
+        # (the two drivers build their SE3 objects from the same matrices along different routes: equal to rounding, not bitwise)
+        assert rel(a[0], b[0]) < 1e-13 and rel(a[1], b[1]) < 1e-12 and list(a[2:4]) == list(b[2:4]) and abs(a[4] - b[4]) <= 1e-12 * max(1.0, b[4])
+
+
+@pytest.mark.parametrize("dt_ns", [2500000, 7000000])
+@pytest.mark.parametrize("method", ["RK4", "PrinceDormand"])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_golden_v6_propagate_with_the_integrators_outer_loops(seed, method, dt_ns):
+    """oracle.propagate against stored outputs of the extracted Estimator::Propagate -> Estimator::RK4 / PrinceDormand
+    (sub-stepping with the half-step trick, src/rk4.cpp:13-32) -> RK4Step / PrinceDormandStep, P_mm += Qmodel (:590)"""
+    m = _v6()
+    c = m.prop_case(seed)
+    X = orc.MotionState(c["X"].Rsb.copy(), c["X"].Tsb.copy(), c["X"].Vsb.copy(), c["X"].bg.copy(), c["X"].ba.copy(), c["X"].Rsg.copy())
+    X2, P2 = orc.propagate(X, c["P"], c["gy"], c["ac"], c["sg"], c["sa"], dt_ns * 1e-9, c["Qimu"], c["Qmodel"], c["g"], method=method,
+                           stepsize=0.002)[:2]
+    k = f"prop_s{seed}_{method}_{dt_ns}"
+    assert rel(X2.Rsb, G6[k + "_Rsb"]) < 1e-12 and rel(X2.Tsb, G6[k + "_Tsb"]) < 1e-12 and rel(X2.Vsb, G6[k + "_Vsb"]) < 1e-12
+    assert rel(P2[:23, :23], G6[k + "_Pmm"]) < 1e-11 and rel(P2[:23, 23:] @ c["w"], G6[k + "_Pms_w"]) < 1e-11
+    assert rel(c["w"] @ P2[23:, :23], G6[k + "_Pleft_w"]) < 1e-11
+    last = G6[k + "_last"]        # a visual message: last_gyro_ / last_accel_ advanced along the slopes (:569-575)
+    assert rel(c["gy"] + c["sg"] * (dt_ns * 1e-9), last[:3]) < 1e-14 and rel(c["ac"] + c["sa"] * (dt_ns * 1e-9), last[3:]) < 1e-14
+
+
+@pytest.mark.parametrize("tag,cam", [("pin", "pinhole"), ("rad", "radtan"), ("tmp", "equi")])
+def test_golden_v6_one_point_ransac_whole_function(tag, cam):
+    """oracle.one_point_ransac against the extracted Estimator::OnePointRANSAC (hypothesis loop on rng_, BackupState,
+    FindNewRefGroup, P zeroing, partial update + AbsorbError, Jacobians at the updated state, chi-square rescue, RestoreState,
+    Jacobians at the original state): the kept set, the rejected set (status 4 = REJECTED_BY_FILTER), the count"""
+    m = _v6()
+    c = m.ransac_case(tag)
+    sc = c["sc"]; lay = orc.Layout(c["ng"], c["nf"])
+    xp = G6[f"ransac_{tag}_xp"]
+    assert np.abs(xp - m.ransac_pixels(c, lambda cam_, xcn: orc.camera_project(cam_, xcn)[0])).max() < 1e-9
+    st = dict(Rsb=sc["Rsb"][0], Tsb=sc["Tsb"][0], Vsb=np.zeros(3), bg=np.zeros(3), ba=np.zeros(3), Rbc=sc["Rbc"][0], Tbc=sc["Tbc"][0],
+              Rsg=np.eye(3), gR=sc["gR"][0].copy(), gT=sc["gT"][0].copy(), x=sc["x"][0].copy(), sind=sc["sind"][0], ref=sc["ref"][0])
+    out = orc.one_point_ransac(st, c["P"], xp, CAMS[cam], lay, c["R"], c["thresh"], c["chi2"], c["gauge"], range(c["ng"]))
+    keep = G6[f"ransac_{tag}_keep"]
+    assert out["inliers"] == np.nonzero(keep)[0].tolist()
+    assert sorted(out["rejected"]) == np.nonzero(G6[f"ransac_{tag}_status"] == 4)[0].tolist() and len(out["rejected"]) == int(G6[f"ransac_{tag}_nrej"][0])
+    assert 0 < out["low"].sum() < c["nf"] and len(out["rejected"]) >= 1 and len(out["inliers"]) > out["low"].sum()
+    if tag == "tmp":
+        assert c["gauge"] not in set(int(sc["ref"][0, i]) for i in range(c["nf"]) if out["low"][i])
+    r = int(sc["ref"][0, 3])
+    J3 = orc.compute_jacobian(sc["x"][0, 3], xp[3], sc["gR"][0, r], sc["gT"][0, r], sc["Rsb"][0], sc["Tsb"][0], sc["Rbc"][0], sc["Tbc"][0],
+                              CAMS[cam], lay, r, int(sc["sind"][0, 3]))[0]
+    assert np.abs(J3[:, G6[f"ransac_{tag}_J3cols"]] - G6[f"ransac_{tag}_J3"]).max() / np.abs(J3).max() < 1e-12

@@ -640,14 +640,14 @@ def test_cholesky_kernels_are_bit_identical(built):
 
 @pytest.mark.parametrize("N,F", [(150, 50), (250, 80), (37, 3), (400, 150)])
 def test_update_matches_the_eigen_driver_directly(built, N, F):
-    """Same inputs through the HIP path and through oracle/_ref - the reference's own Eigen 3.3.9 / LDLT arithmetic compiled
-    from the reference tree (the prebuilt library travels to the GPU box) - without the numpy oracle in between:
-    UpdateJosephForm line for line (src/estimator.cpp:1257-1288) on one side, the device pipeline on the other."""
+    """Same inputs through the HIP path and through oracle/_ref's EXTRACTED build - the reference's own text of
+    Estimator::UpdateJosephForm (src/estimator.cpp:1257-1288) cut out of the reference tree and compiled against its Eigen
+    3.3.9 (the prebuilt library travels to the GPU box) - without the numpy oracle in between."""
     try:
         import ref_binding
-        ref = ref_binding.load()
+        ref = ref_binding.loadx(203)      # (UpdateJosephForm's members are dynamic: the N = 203 library serves any N)
     except Exception as e:
-        pytest.skip(f"oracle/_ref not available here: {e}")
+        pytest.skip(f"oracle/_ref extracted build not available here: {e}")
     B = 3
     P, H, inn, dR = synth.s_level(N, F, B, seed=7 * N + F)
     with Context(N, 2 * F, B) as ctx:

@@ -97,6 +97,7 @@ struct xivo_hip_ctx {
   double oos_R = 0.0;
   int oos_nb = 0, oos_n = 0, oos_max_rows = 0;   // shape of the resident OOS list (xivo_hip_oos_project with feats == NULL)
   int* oos_rows = nullptr;
+  void* lc_buf = nullptr; size_t lc_cap = 0;   // xivo_hip_close_loop_stack: matches | dense rows | inn | diagR
   xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
   std::vector<char> hstage;                        // host staging of d2h_rows
   void* edit_buf = nullptr; size_t edit_cap = 0;   // device copy of the ops of xivo_hip_edit_batch
@@ -191,6 +192,7 @@ SceneBuffers scene_buffers(xivo_hip_ctx* c) {
   sb.Fmax = c->Fmax; sb.F = c->F;
   sb.calib = c->calib_on ? c->calib : nullptr; sb.Jc = c->calib_on ? c->Jc : nullptr; sb.cl = c->cl;
   if (!c->calib_on) sb.cl = xivo_calib_layout{-1, -1, 0, 0};
+  sb.invdepth = (c->flags & XIVO_HIP_FLAG_INVDEPTH) ? 1 : 0;
   return sb;
 }
 
@@ -340,7 +342,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
-                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->tune_status, c->ldlt_used, c->calib, c->Jc};
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->tune_status, c->ldlt_used, c->calib, c->Jc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
   if (c->pin_h) hipHostFree(c->pin_h);
@@ -804,7 +806,10 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     static const bool no_trsm_t = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: the round-1 stand-alone tail for every shape
     wh_out = !t_here && !t_full && jform == 2 && !no_joseph && !no_trsm_t &&
              !(c->flags & (XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_FP32_CORR));
-    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; a.out_f32 = (c->flags & XIVO_HIP_FLAG_FP32_WHITENED) ? 1 : 0; }
+    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat;
+      // XIVO_HIP_FLAG_FP32_WHITENED only where the SHAPE puts the product outside the solve kernel (N > 256 or M > 176): a
+      // few-filter call of a shape the in-solve update holds takes this branch through the latency route and stays all fp64
+      a.out_f32 = ((c->flags & XIVO_HIP_FLAG_FP32_WHITENED) && !trsm_forms_T(Mp, Np)) ? 1 : 0; }
     wh_f32 = wh_out && a.out_f32;
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
@@ -1001,7 +1006,10 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
     const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
     wh_out = (c->flags & XIVO_HIP_FLAG_REASSOC) && !all_here && !f32 && !full && !no_joseph && jform == 2 &&
              !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);
-    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; a.out_f32 = (c->flags & XIVO_HIP_FLAG_FP32_WHITENED) ? 1 : 0; }
+    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat;
+      // XIVO_HIP_FLAG_FP32_WHITENED only where the SHAPE puts the product outside the solve kernel (N > 256 or M > 176): a
+      // few-filter call of a shape the in-solve update holds takes this branch through the latency route and stays all fp64
+      a.out_f32 = ((c->flags & XIVO_HIP_FLAG_FP32_WHITENED) && !trsm_forms_T(Mp, Np)) ? 1 : 0; }
     wh_f32 = wh_out && a.out_f32;
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (wh_out ? 5 : 0), lat);
@@ -1313,8 +1321,10 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
   c->M = M; c->Mp = round_up16(M);
   c->ell_over_h[b] = 0; c->ell_nc_h[b] = nc; c->ell_pw_h[b] = pw;
   c->dense_valid = false; c->dense_from_ell = true; c->ht_valid = true; c->mixed_row0 = -1;
+  // (from here on kernels that read the context's pinned block may be in flight: an early return drains the stream first,
+  //  the next call overwrites that block)
   int rc = update_joseph_range(c, b, 1);
-  if (rc) return rc;
+  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
   DropinOutArgs oa{};
   oa.P = c->P + (long)b * c->sP; oa.N = N; oa.ldp = Np;
   if (p_down) { oa.Pdst = reinterpret_cast<double*>(c->pin_d + o_Pout); oa.ldpd = N; }
@@ -1322,7 +1332,7 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
   oa.status = c->status + b; oa.ldlt_used = c->ldlt_used + b; oa.flags_dst = reinterpret_cast<int*>(c->pin_d + o_st);
   {
     StageTimer st(c, ST_OTHER, 0.0, "dropin_out_kernel", (p_down ? 8.0 * N * N : 0.0) + 8.0 * N);
-    HIP_TRY((hipError_t)launch_dropin_out(oa, c->stream));
+    if (launch_dropin_out(oa, c->stream) != 0) { (void)hipStreamSynchronize(c->stream); return XIVO_HIP_ERR_HIP; }
   }
   HIP_TRY(hipStreamSynchronize(c->stream));        // the one synchronisation of the call: kernel end = system-scope release
   const int* s_st = reinterpret_cast<const int*>(c->pin_h + o_st);
@@ -1552,6 +1562,7 @@ static int calib_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double
     a.mask = c->mask; a.dist = c->dist; a.F = c->F; a.Np = Np; a.batch = B; a.mask_ld = c->Fmax;   // (the stride xivo_hip_stack reads the mask with)
     a.R = R; a.thresh = mh_thresh; a.mult = mh_mult; a.min_inliers = min_inliers;
     a.ell = c->ell; a.have_ell = 0;
+    a.feats = c->feats; a.Fmax = c->Fmax;        // absent entries of ragged batches are no candidates (per-filter present count)
     StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
     c->gate_sparse_last = 1;
     HIP_TRY((hipError_t)launch_gate_dense(a, c->stream));
@@ -1798,6 +1809,49 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   return XIVO_HIP_OK;
 }
 
+// Estimator::CloseLoopInternal's stacking (src/update.cpp:183-196) with Feature::ComputeLCJacobian (src/oos.cpp:92-145) on the
+// resident scene: the 2n rows of every filter are built dense in a scratch block (lc_rows_kernel) and handed over like any
+// device-resident H_ (stage_measurements: row-pair compressed where they fit - group block private, extrinsics [+ intrinsics]
+// common -, so the update that follows takes the sparse pipeline). The inlier mask of the last gating pass is left alone:
+// AbsorbError after a loop closure updates in_current_ekf_update_ as the last FilterUpdate left it (src/estimator.cpp:906-912).
+int xivo_hip_close_loop_stack(xivo_hip_ctx* c, int b0, int nb, int n, const xivo_lc_match* matches, double Rlc) {
+  if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
+  if (bad_range(c, b0, nb) || !c->have_layout || !c->poses || !c->feats || n <= 0 || 2 * n > c->Mmax || !matches || !(Rlc > 0.0))
+    return XIVO_HIP_ERR_INVALID;
+  if (nb == 0) return XIVO_HIP_OK;
+  for (size_t i = 0; i < (size_t)nb * n; ++i) {
+    const xivo_lc_match& m = matches[i];
+    if (m.feat >= c->Fmax || (m.feat >= 0 && (m.group_sind < 0 || m.group_sind >= c->lay.n_groups))) return XIVO_HIP_ERR_INVALID;
+  }
+  const int M = 2 * n, N = c->N;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_m = 0, o_H = al((size_t)nb * n * sizeof(xivo_lc_match)), o_inn = al(o_H + (size_t)nb * M * N * sizeof(double)),
+               o_R = al(o_inn + (size_t)nb * M * sizeof(double)), total = al(o_R + (size_t)nb * M * sizeof(double));
+  if (total > c->lc_cap) {
+    if (c->lc_buf) hipFree(c->lc_buf);
+    c->lc_buf = nullptr; c->lc_cap = 0;
+    if (hipMalloc(&c->lc_buf, total) != hipSuccess) { (void)hipGetLastError(); return XIVO_HIP_ERR_NOMEM; }
+    c->lc_cap = total;
+  }
+  char* base = static_cast<char*>(c->lc_buf);
+  HIP_TRY(hipMemcpyAsync(base + o_m, matches, (size_t)nb * n * sizeof(xivo_lc_match), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(base + o_H, 0, (size_t)nb * M * N * sizeof(double), c->stream));     // H_.setZero(2n, N) (update.cpp:184)
+  LcArgs a{};
+  a.matches = reinterpret_cast<const xivo_lc_match*>(base + o_m); a.n = n;
+  a.poses = c->poses + b0; a.groups = c->groups + (size_t)b0 * c->lay.n_groups; a.feats = c->feats + (size_t)b0 * c->Fmax; a.Fmax = c->Fmax;
+  a.lay = c->lay; a.cam = c->cam; a.calib = c->calib_on ? c->calib + b0 : nullptr;
+  a.cl = c->calib_on ? c->cl : xivo_calib_layout{-1, -1, 0, 0}; a.invdepth = (c->flags & XIVO_HIP_FLAG_INVDEPTH) ? 1 : 0;
+  a.H = reinterpret_cast<double*>(base + o_H); a.strideH = (long)M * N; a.ldh = M;
+  a.inn = reinterpret_cast<double*>(base + o_inn); a.diagR = reinterpret_cast<double*>(base + o_R); a.strideV = M;
+  a.Rlc = Rlc; a.batch = nb;
+  {
+    StageTimer st(c, ST_OTHER, 0.0, "lc_rows_kernel");
+    HIP_TRY((hipError_t)launch_lc_rows(a, c->stream));
+  }
+  c->oos_row0 = -1;
+  return stage_measurements(c, b0, nb, M, a.H, a.strideH, a.ldh, a.inn, a.strideV, a.diagR, a.strideV);
+}
+
 // Measurement compression of the OOS rows appended by the last xivo_hip_oos_project (use_compression_ /
 // compression_trigger_ratio_, src/estimator.h:399-402; xivo::QR, src/helpers.cpp:77-101): per filter, when the block
 // has more than trigger_ratio times as many rows as non-zero columns, it is replaced by the triangular factor of its QR
@@ -1910,7 +1964,8 @@ int xivo_hip_subfilter_update(xivo_hip_ctx* c, int b0, int nb, int n, xivo_subfi
   {
     StageTimer st(c, ST_OTHER, 0.0, "subfilter_kernel");
     if (launch_subfilter(c->sub, n, c->poses + b0, c->groups + (size_t)b0 * c->lay.n_groups, c->lay.n_groups, c->cam,
-                         *opts, nb, c->stream, c->calib_on ? c->calib + b0 : nullptr, c->calib_on ? c->cl.cam_dim : 0))
+                         *opts, nb, c->stream, c->calib_on ? c->calib + b0 : nullptr, c->calib_on ? c->cl.cam_dim : 0,
+                         (c->flags & XIVO_HIP_FLAG_INVDEPTH) ? 1 : 0))
       return XIVO_HIP_ERR_HIP;
   }
   HIP_TRY(hipMemcpyAsync(feats, c->sub, bytes, hipMemcpyDeviceToHost, c->stream));

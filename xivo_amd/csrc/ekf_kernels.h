@@ -63,6 +63,7 @@ struct GateDenseArgs {
   double R, thresh, mult; int min_inliers;
   EllBuffers ell; int have_ell;                 // also zero the rejected pairs of the compressed form (ell.h)
   int mask_ld;                                  // 0: rows of mask / dist are F entries apart
+  const xivo_feat_in* feats; int Fmax;          // optional [batch x Fmax]: entries with sind < 0 are absent (ragged batches)
 };
 int launch_gate_dense(const GateDenseArgs& a, hipStream_t s);
 
@@ -80,6 +81,7 @@ struct SceneBuffers {
   const xivo_calib_in* calib;    // [batch]
   double* Jc;                    // [batch x Fmax x 44]  (2 x 22 row-major: td | Cg 9 | bg 3 | intrinsics 9)
   xivo_calib_layout cl;
+  int invdepth;                  // XIVO_HIP_FLAG_INVDEPTH: features are (X/Z, Y/Z, 1/Z) (USE_INVDEPTH build, feature.cpp:98-105)
 };
 int launch_jac_instate(const SceneBuffers& sb, const xivo_layout& lay, const xivo_cam& cam, int batch,
                        hipStream_t s);
@@ -101,7 +103,7 @@ int launch_stack(const StackArgs& a, hipStream_t s);
 // Feature::SubfilterUpdate + candidate tests (feature.cpp:246-297, options.cpp:10-33)
 int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses, const xivo_group_in* groups,
                      int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s,
-                     const xivo_calib_in* calib = nullptr, int cam_dim = 0);
+                     const xivo_calib_in* calib = nullptr, int cam_dim = 0, int invdepth = 0);
 
 // Estimator::Propagate state + covariance stages (rk4.cpp, princedormand.cpp, estimator.cpp:598-704): one wave per
 // filter; writes the accumulated transition Phi and the new P_mm (23 x 23 each, column-major) for the tail kernel
@@ -177,6 +179,17 @@ struct OosArgs {
   int* rows_out;       // [batch]
 };
 int launch_oos(const OosArgs& a, hipStream_t s);
+
+// loop-closure rows: oos.cpp:92-145 + the stacking of update.cpp:183-196
+struct LcArgs {
+  const xivo_lc_match* matches; int n;          // [batch x n]
+  const xivo_pose_in* poses; const xivo_group_in* groups; const xivo_feat_in* feats; int Fmax;
+  xivo_layout lay; xivo_cam cam; const xivo_calib_in* calib; xivo_calib_layout cl; int invdepth;
+  double* H; long strideH; int ldh;             // [batch] 2n x N column-major, zero-filled
+  double* inn; double* diagR; long strideV;     // [batch] 2n each
+  double Rlc; int batch;
+};
+int launch_lc_rows(const LcArgs& a, hipStream_t s);
 
 // measurement compression of the appended OOS rows (estimator.h:399-402, helpers.cpp:77-101)
 struct OosCompressArgs {

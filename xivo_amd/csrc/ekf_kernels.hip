@@ -101,7 +101,23 @@ __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
   // the state index contiguous), so every lane streams four contiguous columns.
   const double* PHT = a.PHTr + (long)filt * a.strideHT;
   const double* HT = a.HTw + (long)filt * a.strideHT;
+  // ragged batches (a.feats given): absent entries (sind < 0) were stacked as zero rows; they are no candidates - distance
+  // +inf, never an inlier, not counted - and a filter gates only with more than min_inliers present entries, exactly as
+  // gate_sparse_kernel does (src/manager.cpp:635)
+  __shared__ int s_present;
+  if (tid == 0) s_present = 0;
+  __syncthreads();
+  if (a.feats) {
+    int cnt = 0;
+    for (int f = tid; f < a.F; f += 256) cnt += a.feats[(long)filt * a.Fmax + f].sind >= 0 ? 1 : 0;
+    if (cnt) atomicAdd(&s_present, cnt);
+  }
+  __syncthreads();
+  const int present = a.feats ? s_present : a.F;
+  const bool gating = !a.feats || present > a.min_inliers;
   for (int f = wave; f < a.F; f += 4) {
+    const bool here = !a.feats || a.feats[(long)filt * a.Fmax + f].sind >= 0;
+    if (!here || !gating) { if (lane == 0) sdist[f] = here ? 0.0 : __builtin_inf(); continue; }
     double s00 = 0, s10 = 0, s11 = 0;
     const double* p0 = PHT + (long)(2 * f) * a.ldht;
     const double* p1 = p0 + a.ldht;
@@ -120,7 +136,8 @@ __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
   }
   __syncthreads();
   if (wave == 0) {
-    const double th = relax_threshold(sdist, a.F, a.thresh, a.mult, a.min_inliers, lane);
+    // (not gating: present entries carry 0, absent ones +inf - any positive threshold keeps exactly the present ones)
+    const double th = gating ? relax_threshold(sdist, a.F, a.thresh, a.mult, a.min_inliers, lane, present) : 1.0;
     if (lane == 0) sdist[a.F] = th;
   }
   __syncthreads();
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
   for (int f = tid; f < a.F; f += 256) {
     const bool in = sdist[f] < th;
     a.mask[(long)filt * (a.mask_ld ? a.mask_ld : a.F) + f] = in ? 1 : 0;
-    a.dist[(long)filt * (a.mask_ld ? a.mask_ld : a.F) + f] = sdist[f];
+    a.dist[(long)filt * (a.mask_ld ? a.mask_ld : a.F) + f] = (gating && sdist[f] != __builtin_inf()) ? sdist[f] : 0.0;
     if (!in) {
       inn[2 * f] = 0.0; inn[2 * f + 1] = 0.0;
       double* dr = a.diagR + (long)filt * a.strideR;
@@ -255,6 +272,28 @@ __device__ __forceinline__ xivo_cam filter_cam(const xivo_cam& cam, const xivo_c
   return c;
 }
 
+// Feature::Xc (feature.cpp:98-105): Xc and dXc/dx from the feature's local state x = (X/Z, Y/Z, log Z) through
+// unproject_logz (project.h:79-95) or, in the USE_INVDEPTH build (XIVO_HIP_FLAG_INVDEPTH), x = (X/Z, Y/Z, 1/Z) through
+// unproject_invz = project_invz (project.h:31-56). Feature::z (feature.cpp:120-126) for the depth tests.
+__device__ __forceinline__ V3 feature_unproject(const double* x, int invdepth, M3& dXc_dx) {
+  V3 Xc;
+  if (invdepth) {
+    const double r = x[2];
+    Xc.v[0] = x[0] / r; Xc.v[1] = x[1] / r; Xc.v[2] = 1.0 / r;
+    dXc_dx.m[0][0] = 1 / r; dXc_dx.m[0][1] = 0; dXc_dx.m[0][2] = -x[0] / (r * r);
+    dXc_dx.m[1][0] = 0; dXc_dx.m[1][1] = 1 / r; dXc_dx.m[1][2] = -x[1] / (r * r);
+    dXc_dx.m[2][0] = 0; dXc_dx.m[2][1] = 0; dXc_dx.m[2][2] = -1 / (r * r);
+  } else {
+    const double z = exp(x[2]);
+    Xc.v[0] = x[0] * z; Xc.v[1] = x[1] * z; Xc.v[2] = z;
+    dXc_dx.m[0][0] = z; dXc_dx.m[0][1] = 0; dXc_dx.m[0][2] = x[0] * z;
+    dXc_dx.m[1][0] = 0; dXc_dx.m[1][1] = z; dXc_dx.m[1][2] = x[1] * z;
+    dXc_dx.m[2][0] = 0; dXc_dx.m[2][1] = 0; dXc_dx.m[2][2] = z;
+  }
+  return Xc;
+}
+__device__ __forceinline__ double feature_depth(double x2, int invdepth) { return invdepth ? 1.0 / x2 : exp(x2); }
+
 // ---------------------------------------------------------------- in-state Jacobian
 // One thread per (filter, feature). Output J is 2 x 21 row-major with block
 // order [Wsb Tsb Wbc Tbc Wsbr Tsbr x] (the 7 structural non-zero blocks of
@@ -282,13 +321,9 @@ __global__ void jac_instate_kernel(SceneBuffers sb, xivo_layout lay, xivo_cam ca
   const V3 Tsb{{pose.Tsb[0], pose.Tsb[1], pose.Tsb[2]}}, Tbc{{pose.Tbc[0], pose.Tbc[1], pose.Tbc[2]}};
   const V3 Tsbr{{grp.Tsb[0], grp.Tsb[1], grp.Tsb[2]}};
 
-  // Xc = unproject_logz(x_) (project.h:79-95, feature.cpp:98-105)
-  const double z = exp(ft.x[2]);
-  const V3 Xc{{ft.x[0] * z, ft.x[1] * z, z}};
+  // Xc = this->Xc(&dXc_dx) (feature.cpp:98-105, :555)
   M3 dXc_dx;
-  dXc_dx.m[0][0] = z; dXc_dx.m[0][1] = 0; dXc_dx.m[0][2] = ft.x[0] * z;
-  dXc_dx.m[1][0] = 0; dXc_dx.m[1][1] = z; dXc_dx.m[1][2] = ft.x[1] * z;
-  dXc_dx.m[2][0] = 0; dXc_dx.m[2][1] = 0; dXc_dx.m[2][2] = z;
+  const V3 Xc = feature_unproject(ft.x, sb.invdepth, dXc_dx);
 
   // feature.cpp:556-560
   V3 Xbr = m3_mulv(Rbc, Xc);
@@ -623,7 +658,7 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
 // reference's association order (feature.cpp:246-297).
 __global__ void subfilter_kernel(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses,
                                  const xivo_group_in* groups, int n_groups, xivo_cam cam_ctx, xivo_subfilter_opts o,
-                                 int batch, const xivo_calib_in* calib, int cam_dim) {
+                                 int batch, const xivo_calib_in* calib, int cam_dim, int invdepth) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= batch * n) return;
   const int filt = t / n;
@@ -635,13 +670,9 @@ __global__ void subfilter_kernel(xivo_subfilter_feat* feats, int n, const xivo_p
   const V3 Tsb{{pose.Tsb[0], pose.Tsb[1], pose.Tsb[2]}}, Tbc{{pose.Tbc[0], pose.Tbc[1], pose.Tbc[2]}};
   const V3 Tsbr{{grp.Tsb[0], grp.Tsb[1], grp.Tsb[2]}};
   const int init_counter = f.init_counter + 1;                                   // :256
-  // Xc(&dXc_dx): unproject_logz (project.h:80-95)
-  const double z = exp(f.x[2]);
-  const V3 Xc{{f.x[0] * z, f.x[1] * z, z}};
+  // Xc(&dXc_dx) (:258; feature.cpp:98-105)
   M3 dXc_dx;
-  dXc_dx.m[0][0] = z; dXc_dx.m[0][1] = 0; dXc_dx.m[0][2] = f.x[0] * z;
-  dXc_dx.m[1][0] = 0; dXc_dx.m[1][1] = z; dXc_dx.m[1][2] = f.x[1] * z;
-  dXc_dx.m[2][0] = 0; dXc_dx.m[2][1] = 0; dXc_dx.m[2][2] = z;
+  const V3 Xc = feature_unproject(f.x, invdepth, dXc_dx);
   // gtot = (gsb * gbc)^-1 * ref.gsb * gbc   (:260)
   const M3 Rsc = m3_mul(Rsb, Rbc), Rrc = m3_mul(Rsbr, Rbc);
   V3 Tsc = m3_mulv(Rsb, Tbc), Trc = m3_mulv(Rsbr, Tbc);
@@ -721,7 +752,7 @@ __global__ void subfilter_kernel(xivo_subfilter_feat* feats, int n, const xivo_p
   }
   f.outlier_counter = outlier; f.init_counter = init_counter; f.status = status;
   // Criteria::Candidate / CandidateStrict (options.cpp:10-33), Feature::score (feature.cpp:133-142)
-  const double zed = exp(xn[2]);
+  const double zed = feature_depth(xn[2], invdepth);                              // Feature::z (feature.cpp:120-126)
   const bool ok = outlier < o.max_subfilter_outlier && zed > o.min_depth && zed < o.max_depth;
   f.candidate = (ok ? 1 : 0) | ((ok && status == XIVO_FEAT_READY) ? 2 : 0);
   f.score = -Pn.m[2][2];
@@ -1226,6 +1257,71 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
       dR[row] = a.Roos;
     }
   }
+}
+
+// ---------------------------------------------------------------- loop-closure rows
+// Feature::ComputeLCJacobian (oos.cpp:92-145) as Estimator::CloseLoopInternal drives it (update.cpp:183-196): one thread per
+// (filter, match). The OLD in-state feature's world position Xs = Feature::Xs(gbc) (feature.cpp:107-118: its own state and
+// anchor group) is re-observed as pixel xp by the group in slot group_sind: row pair 2m, 2m+1 of a zeroed H gets
+// d xp / d (Wsb_g, Tsb_g, Wbc, Tbc) [+ the intrinsics block under USE_ONLINE_CAMERA_CALIB, :125-142], inn = obs.xp - xp,
+// diagR = Rlc. No block for the old feature's own state or its anchor group: as coded. feat < 0: an absent match (ragged
+// batches) - a neutral row pair (H = 0, inn = 0, R = 1).
+__global__ void lc_rows_kernel(LcArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.batch * a.n) return;
+  const int filt = t / a.n, m = t % a.n;
+  const xivo_lc_match& mt = a.matches[t];
+  double* H = a.H + (long)filt * a.strideH;          // 2n x N column-major, ld = ldh, zero-filled by the caller
+  double* inn = a.inn + (long)filt * a.strideV;
+  double* dR = a.diagR + (long)filt * a.strideV;
+  const int r0 = 2 * m;
+  if (mt.feat < 0) { inn[r0] = 0.0; inn[r0 + 1] = 0.0; dR[r0] = 1.0; dR[r0 + 1] = 1.0; return; }
+  const xivo_pose_in& pose = a.poses[filt];
+  const xivo_feat_in& ft = a.feats[(long)filt * a.Fmax + mt.feat];
+  const xivo_group_in& gref = a.groups[(long)filt * a.lay.n_groups + ft.ref_sind];
+  const xivo_group_in& g = a.groups[(long)filt * a.lay.n_groups + mt.group_sind];
+  const xivo_cam cam = filter_cam(a.cam, a.calib, a.cl.cam_dim, filt);
+  const M3 Rbc = m3_from_colmajor(pose.Rbc), Rsbr = m3_from_colmajor(gref.Rsb), Rsb = m3_from_colmajor(g.Rsb);
+  const M3 Rsb_t = m3_t(Rsb), Rbc_t = m3_t(Rbc);
+  // Xs(gbc) = ref_->gsb() * gbc * Xc (feature.cpp:112-113)
+  M3 dXc_dx;
+  const V3 Xc = feature_unproject(ft.x, a.invdepth, dXc_dx);
+  V3 Xbr = m3_mulv(Rbc, Xc);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Xbr.v[i] += pose.Tbc[i];
+  V3 Xs = m3_mulv(Rsbr, Xbr);
+  V3 d;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { Xs.v[i] += gref.Tsb[i]; d.v[i] = Xs.v[i] - g.Tsb[i]; }
+  const V3 Xb = m3_mulv(Rsb_t, d);                              // :107
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d.v[i] = Xb.v[i] - pose.Tbc[i];
+  const V3 Xcn = m3_mulv(Rbc_t, d);                             // :113
+  double xp[2], dxp_dXcn[2][3];
+  project_pixel(cam, Xcn, xp, dxp_dXcn);                        // :123-133
+  const M3 dXcn_dTsb = m3_mul(Rbc_t, m3_neg(Rsb_t));            // :120  dXcn_dXb * dXb_dTsb
+  const M3 dXcn_dWsb = m3_mul(Rbc_t, hat(Xb));                  // :121  dXcn_dXb * dXb_dWsb
+  double blk[2][3];
+  const int goff = a.lay.group_begin + 6 * mt.group_sind;
+  auto put = [&](int col) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) H[r0 + i + (long)(col + j) * a.ldh] = blk[i][j];
+  };
+  m23_mul(dxp_dXcn, dXcn_dWsb, blk); put(goff);                 // :136
+  m23_mul(dxp_dXcn, dXcn_dTsb, blk); put(goff + 3);             // :137
+  m23_mul(dxp_dXcn, hat(Xcn), blk); put(15);                    // :138  Index::Wbc
+  m23_mul(dxp_dXcn, m3_neg(Rbc_t), blk); put(18);               // :139  Index::Tbc
+  if (a.cl.cam_dim > 0) {                                       // :141-144
+    double xq[2], Jq[2][2], jacc[2][9];
+    camera_project_jacc(cam, Xcn.v[0] / Xcn.v[2], Xcn.v[1] / Xcn.v[2], xq, Jq, jacc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < a.cl.cam_dim && j < 9; ++j) H[r0 + i + (long)(a.cl.cam_begin + j) * a.ldh] = jacc[i][j];
+  }
+  inn[r0] = mt.xp[0] - xp[0]; inn[r0 + 1] = mt.xp[1] - xp[1];   // :146
+  dR[r0] = a.Rlc; dR[r0 + 1] = a.Rlc;                           // update.cpp:193
 }
 
 // ---------------------------------------------------------------- propagation tail
@@ -2827,11 +2923,11 @@ int launch_stack(const StackArgs& a, hipStream_t s) {
 }
 int launch_subfilter(xivo_subfilter_feat* feats, int n, const xivo_pose_in* poses, const xivo_group_in* groups,
                      int n_groups, xivo_cam cam, xivo_subfilter_opts o, int batch, hipStream_t s, const xivo_calib_in* calib,
-                     int cam_dim) {
+                     int cam_dim, int invdepth) {
   const int tot = batch * n;
   if (tot <= 0) return 0;
   hipLaunchKernelGGL(subfilter_kernel, dim3((tot + 127) / 128), dim3(128), 0, s, feats, n, poses, groups, n_groups, cam,
-                     o, batch, calib, cam_dim);
+                     o, batch, calib, cam_dim, invdepth);
   CHECK_LAUNCH();
 }
 int launch_givens(const GivensArgs& a, hipStream_t s) {
@@ -2870,6 +2966,12 @@ int launch_ransac_rescue(const RansacArgs& a, hipStream_t s) {
 }
 int launch_absorb_error(const AbsorbArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(absorb_error_kernel, dim3(a.batch), dim3(256), 0, s, a);
+  CHECK_LAUNCH();
+}
+int launch_lc_rows(const LcArgs& a, hipStream_t s) {
+  const int tot = a.batch * a.n;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(lc_rows_kernel, dim3((tot + 63) / 64), dim3(64), 0, s, a);
   CHECK_LAUNCH();
 }
 int launch_oos(const OosArgs& a, hipStream_t s) {

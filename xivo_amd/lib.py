@@ -21,6 +21,7 @@ FLAG_FP32_CORR = 2048
 FLAG_NO_LDLT_FALLBACK = 4096
 FLAG_FP32_WHITENED = 16384  # N > 256 / M > 176: V^T, Y^T as float, P - V^T Y on the fp32 MFMA
 FLAG_THROUGHPUT_ROUTE = 8192    # every batch size on the kernels sized for thousands of filters (default: <= 64 filters take the latency route)
+FLAG_INVDEPTH = 32768           # USE_INVDEPTH build: features are (X/Z, Y/Z, 1/Z) (src/feature.cpp:98-105)
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
 
@@ -57,6 +58,8 @@ class _OosC(C.Structure):
 
 
 assert oos_dtype.itemsize == C.sizeof(_OosC), (oos_dtype.itemsize, C.sizeof(_OosC))
+lc_dtype = np.dtype([("feat", "i4"), ("group_sind", "i4"), ("xp", "f8", 2)])      # xivo_lc_match
+assert lc_dtype.itemsize == 24
 imu_dtype = np.dtype([("gyro", "f8", 3), ("accel", "f8", 3), ("slope_gyro", "f8", 3), ("slope_accel", "f8", 3), ("dt", "f8")])
 prop_opts_dtype = np.dtype([("Qimu", "f8", 144), ("Qmodel", "f8", 529), ("g", "f8", 3), ("method", "i4"), ("_pad", "i4"),
                             ("stepsize", "f8")])
@@ -113,6 +116,7 @@ _SIGS = {
                          C.c_void_p],
     "xivo_hip_stack": [C.c_void_p, C.c_int, C.c_double],
     "xivo_hip_oos_project": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p],
+    "xivo_hip_close_loop_stack": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double],
     "xivo_hip_compress_oos": [C.c_void_p, C.c_int, C.c_double, C.c_void_p],
     "xivo_hip_one_point_ransac": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p],
@@ -374,7 +378,8 @@ class Context:
         column-major), P_cm a column-major N x N float64 array updated IN PLACE. Returns (err, rc)."""
         H = np.asarray(H, dtype=np.float64)
         M, N = H.shape
-        assert N == self.N and P_cm is None or (P_cm.dtype == np.float64 and P_cm.flags["F_CONTIGUOUS"])
+        assert N == self.N, (N, self.N)
+        assert P_cm is None or (P_cm.dtype == np.float64 and P_cm.flags["F_CONTIGUOUS"] and P_cm.shape == (N, N))
         Hc = _f64(H.T)
         inn = _f64(inn); dR = _f64(diagR)
         err = np.empty(self.N)
@@ -479,6 +484,12 @@ class Context:
         rows = np.zeros(nb, dtype=np.int32) if want_rows else None
         self._check(self.lib.xivo_hip_oos_project(self.h, 0, nb, n_oos, ptr, Roos, _ptr(rows) if want_rows else None))
         return rows
+
+    def close_loop_stack(self, matches, Rlc, b0=0):
+        """matches: [nb, n] lc_dtype - Feature::ComputeLCJacobian rows of Estimator::CloseLoopInternal become the staged measurement"""
+        matches = np.ascontiguousarray(matches, dtype=lc_dtype)
+        nb, n = matches.shape
+        self._check(self.lib.xivo_hip_close_loop_stack(self.h, b0, nb, n, _ptr(matches), Rlc))
 
     def compress_oos(self, trigger_ratio=1.5, B=None, want_rows=True):
         """QR measurement compression of the OOS rows appended by oos_project (estimator.h:399-402)."""
