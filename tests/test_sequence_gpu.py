@@ -378,3 +378,30 @@ def test_sequences_with_one_point_ransac_python_and_cpp_hosts_agree(built):
         assert py["runner"].n_rejected > plain["runner"].n_rejected
     finally:
         py["backend"].close(); cp["estimator"].close(); plain["backend"].close()
+
+
+def test_sequences_in_the_invdepth_build_python_and_cpp_hosts_agree(built):
+    """The reference's USE_INVDEPTH build end to end (src/feature.cpp:98-105, :144-150): features initialised as
+    (x, y, 1 / z), XIVO_HIP_FLAG_INVDEPTH on the context; both hosts take the same decisions and follow ground truth.
+    initial_std_z is an inverse-depth standard deviation in this build."""
+    B = 4
+    cfg = sequence.SequenceConfig(use_invdepth=True, initial_std_z=0.05)
+    mk = lambda: ([pcw.RandomPCW(seed=60 + b) for b in range(B)],
+                  [pcw.TrajectorySim("trefoil" if b % 2 else "lissajous", seed=500 + b) for b in range(B)])
+    w1, s1 = mk()
+    py = sequence.run_pcw(sequence.HipBackend, cfg, w1, s1, total_time=1.6)
+    w2, s2 = mk()
+    cp = sequence.run_pcw_cpp(cfg, w2, s2, total_time=1.6)
+    try:
+        for b in range(B):
+            fid, fref, gref = cp["estimator"].book(b)
+            bk = py["runner"].books[b]
+            assert list(fid) == bk.feat_id and list(fref) == bk.feat_ref and list(gref) == bk.group_refs
+        assert np.abs(py["Tsb"] - cp["Tsb"]).max() < 1e-9 and np.abs(py["Wsb"] - cp["Wsb"]).max() < 1e-9
+        ate = np.array([formats.ate_rmse(py["Tsb"][:, b], py["gt_Tsb"][:, b], align=False) for b in range(B)])
+        assert np.isfinite(ate).all() and ate.max() < 0.3, ate
+        _, _, f = py["backend"].ctx.get_scene()
+        x2 = f["x"][..., 2][f["sind"] >= 0]
+        assert (x2 > 0.05).all() and (x2 < 25.0).all()          # inverse depths of points 0.05 .. 10 m away, not log depths
+    finally:
+        py["backend"].close(); cp["estimator"].close()

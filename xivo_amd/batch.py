@@ -19,7 +19,7 @@ batch_cfg_dtype = np.dtype([
     ("min_inliers", "i4"), ("min_new_features", "i4"), ("fix_group_block", "i4"), ("disable_MH_gating", "i4"),
     ("initial_std_x", "f8"), ("initial_std_y", "f8"), ("initial_std_z", "f8"), ("min_depth", "f8"), ("max_depth", "f8"),
     ("prop", L.prop_opts_dtype),
-    ("use_1pt_RANSAC", "i4"), ("_pad1", "i4"), ("ransac_thresh", "f8"), ("ransac_Chi2", "f8")])
+    ("use_1pt_RANSAC", "i4"), ("use_invdepth", "i4"), ("ransac_thresh", "f8"), ("ransac_Chi2", "f8")])
 
 
 def load_host_library():
@@ -57,6 +57,7 @@ class BatchEstimator:
         c["min_inliers"], c["min_new_features"], c["fix_group_block"] = cfg.min_inliers, cfg.min_new_features, int(cfg.fix_group_block)
         c["disable_MH_gating"] = 0 if getattr(cfg, "use_MH_gating", True) else 1
         c["use_1pt_RANSAC"] = 1 if getattr(cfg, "use_1pt_RANSAC", False) else 0
+        c["use_invdepth"] = 1 if getattr(cfg, "use_invdepth", False) else 0
         c["ransac_thresh"], c["ransac_Chi2"] = getattr(cfg, "ransac_thresh", 5.0), getattr(cfg, "ransac_Chi2", 5.89)
         c["initial_std_x"], c["initial_std_y"], c["initial_std_z"] = cfg.initial_std_x, cfg.initial_std_y, cfg.initial_std_z
         c["min_depth"], c["max_depth"] = cfg.min_depth, cfg.max_depth

@@ -49,7 +49,8 @@ BatchEstimator::BatchEstimator(const BatchConfig& cfg, int B, int device, const 
   if (cfg.cam.model != XIVO_CAM_PINHOLE)
     throw std::invalid_argument("point-cloud input initialises features with a pinhole un-projection");
   const int N = cfg.N(), F = cfg.n_features;
-  Check(xivo_hip_create(&ctx_, device, N, 2 * F, B, cfg.fix_group_block ? XIVO_HIP_FLAG_FIX_GROUP_BLOCK : 0u), "create");
+  Check(xivo_hip_create(&ctx_, device, N, 2 * F, B, (cfg.fix_group_block ? XIVO_HIP_FLAG_FIX_GROUP_BLOCK : 0u) |
+                                                     (cfg.use_invdepth ? XIVO_HIP_FLAG_INVDEPTH : 0u)), "create");
   xivo_layout lay{N, 23, cfg.n_groups, 23 + 6 * cfg.n_groups, F};
   Check(xivo_hip_set_layout(ctx_, &lay, &cfg.cam), "set_layout");
   for (int b = 0; b < B; ++b) Check(xivo_hip_upload_P(ctx_, b, 1, P0, (long)N * N, N), "upload_P");
@@ -264,7 +265,7 @@ void BatchEstimator::VisualMeasPointCloud(double t, const int* off, const int64_
       const int j = free_slots[q], k = order[q];
       const double u = meas[(size_t)k * 3], v = meas[(size_t)k * 3 + 1], z = meas[(size_t)k * 3 + 2];
       xivo_edit_op o = make_op(b, XIVO_EDIT_ADD_FEATURE, j, j, g);   // AddFeatureToState + FillCovarianceBlock
-      o.v[0] = (u - cx) / fx; o.v[1] = (v - cy) / fy; o.v[2] = std::log(z);   // Feature::Initialize (src/feature.cpp:144-150)
+      o.v[0] = (u - cx) / fx; o.v[1] = (v - cy) / fy; o.v[2] = cfg_.use_invdepth ? 1.0 / z : std::log(z);   // Feature::Initialize (src/feature.cpp:144-150)
       o.v[3] = u; o.v[4] = v;
       o.v[5] = sd[0] * sd[0]; o.v[9] = sd[1] * sd[1]; o.v[13] = sd[2] * sd[2];   // P_ = diag(std)^2 (:158-159)
       ops.push_back(o);
@@ -297,7 +298,7 @@ struct xivo_batch_cfg {   // flat mirror of xivo::hip::BatchConfig
   int min_inliers, min_new_features, fix_group_block, disable_MH_gating;   // cfg use_MH_gating = false
   double initial_std_x, initial_std_y, initial_std_z, min_depth, max_depth;
   xivo_prop_opts prop;
-  int use_1pt_RANSAC, pad_;                  // cfg use_1pt_RANSAC, 1pt_RANSAC_thresh, 1pt_RANSAC_Chi2 (src/estimator.cpp:130-134)
+  int use_1pt_RANSAC, use_invdepth;                  // cfg use_1pt_RANSAC, 1pt_RANSAC_thresh, 1pt_RANSAC_Chi2 (src/estimator.cpp:130-134)
   double ransac_thresh, ransac_Chi2;
 };
 
@@ -309,6 +310,7 @@ int xivo_batch_create(const xivo_batch_cfg* c, int B, int device, const xivo_pos
     cfg.min_inliers = c->min_inliers; cfg.min_new_features = c->min_new_features; cfg.fix_group_block = c->fix_group_block;
     cfg.use_MH_gating = c->disable_MH_gating ? 0 : 1;
     cfg.use_1pt_RANSAC = c->use_1pt_RANSAC; cfg.ransac_thresh = c->ransac_thresh; cfg.ransac_Chi2 = c->ransac_Chi2;
+    cfg.use_invdepth = c->use_invdepth;
     cfg.initial_std_x = c->initial_std_x; cfg.initial_std_y = c->initial_std_y; cfg.initial_std_z = c->initial_std_z;
     cfg.min_depth = c->min_depth; cfg.max_depth = c->max_depth; cfg.prop = c->prop;
     *out = new xivo::hip::BatchEstimator(cfg, B, device, poses0, P0);

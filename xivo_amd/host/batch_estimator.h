@@ -36,6 +36,7 @@ struct BatchConfig {
   double min_depth = 0.05, max_depth = 10.0;
   int min_new_features = 3;                         // open a new group only when this many feature slots are free
   int fix_group_block = 1;                          // XIVO_HIP_FLAG_FIX_GROUP_BLOCK (see xivo_amd/sequence.py)
+  int use_invdepth = 0;                             // the reference's USE_INVDEPTH build: features are (X/Z, Y/Z, 1/Z); initial_std_z is then an inverse-depth std
   xivo_prop_opts prop{};                            // Qimu, Qmodel, gravity, integrator, step size
   int N() const { return 23 + 6 * n_groups + 3 * n_features; }
 };

@@ -268,7 +268,7 @@ class Estimator:
 
     def InstateFeatureXc(self, n_output=None):
         x = self.InstateFeaturexc(n_output)
-        z = np.exp(x[:, 2])
+        z = 1.0 / x[:, 2] if getattr(self.cfg, "use_invdepth", False) else np.exp(x[:, 2])   # Feature::z (src/feature.cpp:120-126)
         return np.stack([x[:, 0] * z, x[:, 1] * z, z], axis=1)
 
     def InstateFeaturePositions(self, n_output=None):
@@ -277,7 +277,8 @@ class Estimator:
         Rbc, Tbc = self._R(p["Rbc"]), p["Tbc"]
         out = []
         for j in self._slots():
-            x = f["x"][j]; z = np.exp(x[2]); Xc = np.array([x[0] * z, x[1] * z, z])
+            x = f["x"][j]; z = 1.0 / x[2] if getattr(self.cfg, "use_invdepth", False) else np.exp(x[2])
+            Xc = np.array([x[0] * z, x[1] * z, z])
             r = int(f["ref_sind"][j])
             out.append(self._R(g["Rsb"][r]) @ (Rbc @ Xc + Tbc) + g["Tsb"][r])
         return np.array(out).reshape(-1, 3)[:n_output]

@@ -110,6 +110,9 @@ class SequenceConfig:
         # False = bit-faithful to the reference's stacking.
         self.fix_group_block = True
         self.min_new_features = 3       # open a new group only when at least this many feature slots are free
+        # the reference's USE_INVDEPTH build (src/CMakeLists.txt:10): features are (X/Z, Y/Z, 1/Z); initial_std_z is then an
+        # inverse-depth standard deviation
+        self.use_invdepth = False
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown option " + k)
@@ -162,6 +165,8 @@ class HipBackend:
         self.cfg, self.B, self.F = cfg, B, cfg.n_features
         if cfg.fix_group_block:
             flags |= L.FLAG_FIX_GROUP_BLOCK
+        if getattr(cfg, "use_invdepth", False):
+            flags |= L.FLAG_INVDEPTH
         self.ctx = L.Context(cfg.N, 2 * cfg.n_features, B, device=device, flags=flags)
         self.ctx.set_layout(cfg.N, 23, cfg.n_groups, 23 + 6 * cfg.n_groups, cfg.n_features, cfg.cam)
         self.ctx.upload_P(P0)
@@ -336,7 +341,7 @@ class SequenceRunner:
             ops.append(_op(b, L.EDIT_ADD_GROUP, g))
             bk.group_refs[g] = 0; bk.group_gen[g] += 1
             for j, k in zip(free, cand):
-                x = [(meas[k, 0] - cx) / fx, (meas[k, 1] - cy) / fy, np.log(meas[k, 2])]   # Feature::Initialize, feature.cpp:144-150
+                x = [(meas[k, 0] - cx) / fx, (meas[k, 1] - cy) / fy, (1.0 / meas[k, 2] if getattr(cfg, "use_invdepth", False) else np.log(meas[k, 2]))]   # Feature::Initialize, feature.cpp:144-150
                 ops.append(_op(b, L.EDIT_ADD_FEATURE, j, j, g, v=np.concatenate([x, meas[k, :2], P3])))
                 bk.feat_id[j] = int(ids[k]); bk.feat_ref[j] = g; bk.id2slot[int(ids[k])] = j
                 bk.group_refs[g] += 1
