@@ -601,7 +601,7 @@ import numpy as np
 from xivo_amd import synth
 from xivo_amd.lib import Context
 out = {{}}
-for (N, F) in [(150, 50), (250, 80), (100, 96), (100, 110), (120, 150)]:   # 7, 10, 12 block rows; 14 and 19: the eight-wave register kernel
+for (N, F) in [(150, 50), (250, 80), (203, 30), (64, 20), (100, 96), (100, 110), (120, 150)]:   # 7, 10, 4, 3, 12 block rows; 14 and 19: the eight-wave register kernel
     B = 520                                   # >= 512: the size class where the pick matters
     P, H, inn, dR = synth.s_level(N, F, 8, seed=41)
     idx = np.arange(B) % 8
@@ -618,13 +618,16 @@ def test_cholesky_kernels_are_bit_identical(built):
     the matrix pipe, pivot_scale, two accumulators per block product): whichever kernel and whichever instantiation of the
     register kernel runs (four waves per factor or eight, three workgroups per CU / two, look-ahead on the diagonal update or not, blocks of S requested up
     front or per block column, the opt-in timing of XIVO_HIP_AUTOTUNE), P+ and dx come out bit for bit the same - across
-    nodes, ranks, runs and batch sizes."""
+    nodes, ranks, runs and batch sizes. Round 5: so does the factorisation INSIDE the solve kernel (the default wherever the
+    in-solve covariance update applies; XIVO_HIP_NO_FUSED_CHOL brings the stand-alone kernels back): block row i on wave i, the
+    factor in LDS, half of the right-hand sides joining the forward substitution late - the same bits."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     knobs = ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG", "XIVO_HIP_CHOL_LOOKAHEAD", "XIVO_HIP_CHOL_NO_LOOKAHEAD",
-             "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE", "XIVO_HIP_CHOL_NO_REG8")
+             "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE", "XIVO_HIP_CHOL_NO_REG8", "XIVO_HIP_NO_FUSED_CHOL")
     res = []
-    for knob in (("XIVO_HIP_CHOL_WAVE",), (), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
+    for knob in (("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_NO_FUSED_CHOL"), (), ("XIVO_HIP_NO_FUSED_CHOL",), ("XIVO_HIP_CHOL_LOOKAHEAD", "XIVO_HIP_NO_FUSED_CHOL"),
+                 ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_NO_FUSED_CHOL"), ("XIVO_HIP_CHOL_WAVE",), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
                  ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS"), ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_NO_LOOKAHEAD"),
                  ("XIVO_HIP_AUTOTUNE",), ("XIVO_HIP_CHOL_NO_REG8",)):
         env = dict(os.environ)

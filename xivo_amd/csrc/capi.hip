@@ -779,7 +779,14 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     HIP_TRY((hipError_t)launch_gate_ell(ga, c->stream));
   }
   const bool lat = latency_route(c, Mp, B, full);
-  {
+  const bool t_full = full || getenv("XIVO_HIP_T_FULL");
+  // Round 5: where the solve kernel carries the whole whitened Joseph update (one 16-wave workgroup per filter), it also
+  // factors S itself - in LDS, under the latency of its right-hand-side loads (chol_device.h routines, the same bits as the
+  // stand-alone kernels): no Cholesky launch, L and inv(L_kk) never cross HBM. XIVO_HIP_NO_FUSED_CHOL: A/B knob.
+  static const bool no_joseph_k = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
+  const bool fuse_chol = !(c->flags & (XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_EXPANDED_JOSEPH)) &&
+                         !t_full && !lat && trsm_forms_T(Mp, Np) && !no_joseph_k && mr0 < 0 && trsm_chol_fused_supported(Mp, Np);
+  if (!fuse_chol) {
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
     a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B); a.latency = lat;
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
@@ -787,7 +794,6 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
   }
   if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
-  const bool t_full = full || getenv("XIVO_HIP_T_FULL");
   bool t_done = false, wh_out = false, wh_f32 = false;
   {
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
@@ -815,15 +821,17 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : (wh_out ? 5 : 0)), lat);
+    if (fuse_chol) { a.chol_status = c->status + b0; trsm_chol_fused_label(Mp, label, sizeof(label)); }
     const double t_outs = 0.5 * Np * (Np + 1.0), t_outs_f = 0.5 * Nf * (Nf + 1.0);
     // algorithmic flops (true N, M): the two triangular solves (M^2 N each), the symmetric N x N x M product (lower
     // triangle), and for the expanded form the two triangular products of K L L^T; the whitened form's residual blocks
     // are 2 * 16 * M * N. Algorithmic bytes: the factor, P H^T once, P's lower triangle in, P out (the gain is not stored)
-    StageTimer st(c, ST_TRSM, (2.0 * Mf * Mf * Nf + (t_here ? 2.0 * t_outs_f * Mf : 0.0) +
+    // (fused: + the M^3 / 3 flops of the factorisation; its bytes are S's lower triangle, which the factor's were)
+    StageTimer st(c, ST_TRSM, (2.0 * Mf * Mf * Nf + (t_here ? 2.0 * t_outs_f * Mf : 0.0) + (fuse_chol ? Mf * Mf * Mf / 3.0 : 0.0) +
                                (all_here ? (jform == 2 ? 32.0 * Mf * Nf : 2.0 * Mf * Mf * Nf) : 0.0)) * B, label,
-                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + (all_here && jform == 2 ? 1.0 : 2.0) * Np * Mp +
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + (fuse_chol ? 0.0 : Mp / 16 * 512.0) + (all_here && jform == 2 ? 1.0 : 2.0) * Np * Mp +
                              (t_here ? t_outs + (double)Np * Np : 0.0)));
-    HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
+    HIP_TRY((hipError_t)(fuse_chol ? launch_trsm_chol_fused(a, c->stream) : launch_trsm_f64(a, c->stream)));
     if (all_here) return XIVO_HIP_OK;
   }
   if (wh_out) {   // P+ = P - V^T Y in place (V^T in the K buffer, Y^T in the G buffer), lower triangle + mirror

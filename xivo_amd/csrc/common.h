@@ -127,6 +127,8 @@ struct TrsmArgs {
   long stridePm;
   int ldpm;
   int t_jbp;           // (set by the launcher) column blocks per LDS phase
+  // in-kernel factorisation (solve_fused.hip: LU points at S itself): receives the status chol_f64.hip would have written
+  int* chol_status;
   // whitened outputs for a covariance update OUTSIDE the solve kernel (shapes one workgroup does not hold: N > 256 or
   // M > 176): K receives V^T = (W - D)^T instead of the gain, Yout receives Y^T = (W + D)^T, both [Np x Mp]; then
   // P+ = P - V^T Y as a tiled symmetric product (the Joseph expression for the computed gain, chol_trsm.hip TF == 4)
@@ -162,6 +164,10 @@ int launch_pnew_reg_f64(const PnewRegArgs& args, hipStream_t stream);
 void pnew_reg_kernel_label(int Mp, char* buf, size_t n);
 // whether launch_trsm_f64 forms T itself for these shapes (whole factor in LDS, one column chunk per filter)
 bool trsm_forms_T(int Mp, int Np);
+// solve_fused.hip: the whitened in-solve Joseph update with the Cholesky factorisation inside the kernel (args.LU = S)
+bool trsm_chol_fused_supported(int Mp, int Np);
+int launch_trsm_chol_fused(const TrsmArgs& args, hipStream_t stream);
+void trsm_chol_fused_label(int Mp, char* buf, size_t n);
 bool trsm_latency_route(int Mp, int batch);   // few filters: streamed solve on 128-column workgroups + tiled product
 // y = L^-1 inn for every filter (one wave each): the forward substitution of the innovation vector
 int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD, long strideInvD, const double* inn, long strideInn,

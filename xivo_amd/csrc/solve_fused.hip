@@ -1,0 +1,48 @@
+// The whitened Joseph update with the Cholesky factorisation of S inside the solve kernel (trsm_lds_kernel.h, CHOL = true):
+// `K_.transpose() = S_.ldlt().solve(H_ * P_)` ... `P_ += K_ * K_.transpose()` (/root/reference/src/estimator.cpp:1265-1287)
+// in ONE kernel per filter once S is formed. A translation unit of its own: the instantiations of the solve kernel take
+// minutes to compile (chol_trsm.hip holds eighteen of them).
+#include "trsm_lds_kernel.h"
+
+namespace xivo_hip {
+
+namespace {
+
+template <int NBM>
+int launch_fused_t(const TrsmArgs& g_in, hipStream_t stream) {
+  TrsmArgs g = g_in;
+  const int nb = g.Mp / 16;
+  const int grid = ((g.batch + 7) / 8) * 8;
+  const size_t lds = 160 * 1024;
+  g.t_jbp = (int)(lds / 2 / ((size_t)nb * 4 * 64 * sizeof(double)));   // two operand buffers in the product phase
+  if (g.t_jbp > 16) g.t_jbp = 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_lds_f64_kernel<NBM, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((trsm_lds_f64_kernel<NBM, 4, true>), dim3(grid), dim3(1024), lds, stream, g);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// shapes the fused kernel holds: the whole state in one 16-wave workgroup, a factor of at most ten block rows
+bool trsm_chol_fused_supported(int Mp, int Np) {
+  static const bool off = getenv("XIVO_HIP_NO_FUSED_CHOL") != nullptr;   // A/B knob: stand-alone Cholesky + solve
+  return !off && Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
+}
+
+// g.LU = S (lower triangle + diagonal blocks), g.invD unused, g.T = the covariance (updated in place), g.joseph = 2,
+// g.chol_status = per-filter factorisation status (out)
+int launch_trsm_chol_fused(const TrsmArgs& g, hipStream_t stream) {
+  if (g.batch <= 0) return 0;
+  const int nb = g.Mp / 16;
+  if (nb <= 6) return launch_fused_t<6>(g, stream);
+  if (nb <= 10) return launch_fused_t<10>(g, stream);
+  return (int)hipErrorInvalidValue;
+}
+
+void trsm_chol_fused_label(int Mp, char* buf, size_t n) { snprintf(buf, n, "trsm_lds_f64_kernel<%d,4,true>", Mp / 16 <= 6 ? 6 : 10); }
+
+}  // namespace xivo_hip

@@ -1,0 +1,697 @@
+// The one-workgroup-per-filter solve kernel (trsm_lds_f64_kernel) and its symmetric tile walk, shared by chol_trsm.hip (every
+// TF variant on a factor that chol_f64.hip left in memory) and solve_fused.hip (the whitened Joseph update with the Cholesky
+// factorisation run inside the kernel, under the latency of its right-hand-side loads). See chol_trsm.hip for the algebra.
+#pragma once
+#include <stdlib.h>
+#include <stdio.h>
+
+#include "mfma_util.h"
+#include "chol_device.h"
+
+// XIVO_ABL: timing-only ablations of trsm_lds_f64_kernel<., 4> (scripts/ablate_solve.sh builds one library per value; the
+// results are WRONG for any value but 0): 1 stop after the substitutions, 2 skip the substitutions, 3 no fix-up pass /
+// barrier, 4 no stores of P+, 5 no dx accumulation in the backward loop, 6 no stash write / read-back, 7 no loads of the P
+// tiles, 8 no operand DMA, 9 LDS-only barrier at the phase start (no vmcnt drain), 10 two row blocks per phase
+#ifndef XIVO_ABL
+#define XIVO_ABL 0
+#endif
+
+// XIVO_TRACE (scripts/build_variant.sh trace "-DXIVO_TRACE=1"; scripts/trace_solve.py reads it back): shader-clock stamps inside
+// trsm_lds_f64_kernel<., 4> of every 64th workgroup - wave 0 at the phase boundaries of the kernel (XTR / XTRP), every wave
+// inside the product phases (XTR2: behind the fix-up, behind each tile's MFMA chain, behind each tile's stores). Timing
+// only, results unchanged; compiled out by default. Where the kernel's time goes: DESIGN.md 3.0.
+#ifndef XIVO_TRACE
+#define XIVO_TRACE 0
+#endif
+#if XIVO_TRACE
+__device__ unsigned long long xivo_trace_buf[512 * 32];
+__device__ unsigned long long xivo_trace2_buf[128 * 16 * 4 * 16];   // [workgroup][wave][phase][slot]
+#define XTR(i) do { if (T4 && !WOUT && threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 512) \
+    xivo_trace_buf[(blockIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XTRP(i) do { if (FIXUP && threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 512) \
+    xivo_trace_buf[(blockIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define XTR2(ph, slot) do { if (FIXUP && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 128 && (ph) < 4 && (slot) < 16) \
+    xivo_trace2_buf[(((blockIdx.x >> 6) * 16 + (threadIdx.x >> 6)) * 4 + (ph)) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int xivo_hip_debug_read_trace(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xivo_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+extern "C" int xivo_hip_debug_read_trace2(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xivo_trace2_buf), (size_t)n * sizeof(unsigned long long));
+}
+#else
+#define XTR(i) do {} while (0)
+#define XTRP(i) do {} while (0)
+#define XTR2(ph, slot) do {} while (0)
+#endif
+
+namespace xivo_hip {
+
+namespace {
+
+// Buffer addressing for the per-filter matrices of the one-workgroup-per-filter kernels: a 128-bit resource per matrix in
+// SGPRs, ONE 32-bit per-lane byte offset that every access of that matrix shares, and the block / column part of the
+// address as a wave-uniform scalar offset - instead of a 64-bit address pair per access in VGPRs (the solve kernel lives
+// on exactly 128 VGPRs) and 64-bit vector arithmetic in the MFMA stream.
+typedef unsigned int bufu2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, 0);
+}
+
+template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false, bool FIXUP = false, bool YREGS = false>
+__device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4 (&Wr)[NBM], double* sL, const double* __restrict__ Src, int ldsrc,
+                                                    const double* __restrict__ Minit, int ldm, double* __restrict__ Out, int ldo,
+                                                    int nb, int nwl, int jbp, bool live, int w, int wave, int lane) {
+  const int li = lane & 15, lg = lane >> 4;
+  const int nph = (nwl + jbp - 1) / jbp;
+  const int bufsz = jbp * nb * 256;                // doubles per LDS buffer (two of them)
+  // Operands of phase p straight from global memory into LDS (no registers, asynchronous): one instruction moves
+  // 8 columns m x 16 rows j of Src (16 bytes per lane) to 128 consecutive doubles, so that block (jl, m, j) sits at
+  // jl nb 256 + 16 m + j - for the MFMA step (mb, r) that is (4 mb + r) 64 + lane: lane-contiguous reads.
+  auto issue = [&](int p) {
+    const int jb0 = p * jbp, nj = min(jbp, nwl - jb0);
+    double* buf = sL + (p & 1) * bufsz;
+    if (SRC_REGS) {
+      if (live && w >= jb0 && w < jb0 + nj) {
+        double* dst = buf + (w - jb0) * nb * 256 + lane;
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(mb * 4 + r) * 64] = YREGS ? fma(2.0, Wr[mb][r], -X[mb][r]) : X[mb][r];
+          }
+        }
+      }
+      return;
+    }
+    for (int q = wave; q < (XIVO_ABL == 8 ? 0 : nj * 2 * nb); q += 16) {
+      const int jl = q / (2 * nb), t = q - jl * 2 * nb;
+      const double* src = Src + (16 * (jb0 + jl) + 2 * (lane & 7)) + (long)(8 * t + (lane >> 3)) * ldsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + jl * nb * 256 + t * 128), 16, 0, 0);
+    }
+  };
+  auto my_tiles = [&](int p) -> unsigned {
+    unsigned todo = 0;
+    if (!live || p >= nph) return todo;
+    const int jb0 = p * jbp, nj = min(jbp, nwl - jb0);
+    for (int jl = 0; jl < nj; ++jl) {
+      int d = w - (jb0 + jl);
+      if (d < 0) d += nwl;
+      if (2 * d < nwl || (2 * d == nwl && w > jb0 + jl)) todo |= 1u << jl;
+    }
+    return todo;
+  };
+  // A tile is formed in the orientation that makes its lower-triangle position (a, b), a >= b, lane-contiguous in a:
+  // blocks below the diagonal (and the diagonal one) swap the two MFMA operands - the tile comes out transposed,
+  // lanes along the row index - blocks above it stand for their mirror image. Minit is read there (its lower
+  // triangle, as the stand-alone product does), Out(a, b) and its mirror Out(b, a) are written.
+  const __amdgpu_buffer_rsrc_t rM = buf_rsrc(Minit), rO = buf_rsrc(Out);
+  const unsigned vM = (unsigned)(li + lg * ldm) * 8u;              // element (li, lg) of a 16 x 16 block of Minit
+  const unsigned vO = (unsigned)(li + lg * ldo) * 8u, vOt = (unsigned)(lg + li * ldo) * 8u;   // ... of Out, and of its mirror image
+  auto load_m = [&](int jb, d4& acc) {
+    const int ba = jb <= w ? w : jb, bb = jb <= w ? jb : w;       // block (ba, bb), ba >= bb
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      acc[r] = XIVO_ABL == 7 ? 1.0 : buf_ld(rM, vM, (unsigned)(16 * ba + (16 * bb + 4 * r) * ldm) * 8u);   // (negated where it is consumed: no wait here)
+  };
+  issue(0);
+  unsigned todo = my_tiles(0);
+  d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
+  if (todo) load_m(__builtin_ctz(todo), nxt);
+  for (int p = 0; p < nph; ++p) {
+    XTRP(8 + 3 * p);
+    if (XIVO_ABL == 9) lds_barrier();
+    else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XTRP(9 + 3 * p);
+    __syncthreads();                               // phase p landed for every wave; the other buffer is free again
+    }
+    XTRP(10 + 3 * p);
+    XTR2(p, 0);
+    int tslot = 2;
+    const int jb0 = p * jbp;
+    const double* buf = sL + (p & 1) * bufsz;
+    if (FIXUP && XIVO_ABL != 3) {
+      if (live && w >= jb0 && w < jb0 + min(jbp, nwl - jb0)) {
+        double* dst = sL + (p & 1) * bufsz + (w - jb0) * nb * 256 + lane;
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(mb * 4 + r) * 64] = fma(2.0, dst[(mb * 4 + r) * 64], -X[mb][r]);
+          }
+        }
+      }
+      lds_barrier();
+    }
+    XTR2(p, 1);
+    bool fetch = p + 1 < nph;                      // phase p + 1 is requested once the first tile has its -Minit (so that
+    while (todo) {                                 // the wait on those loads does not sit behind the new requests)
+      const int jl = __builtin_ctz(todo);
+      todo &= todo - 1;
+      const int jb = jb0 + jl;
+      d4 acc = -nxt;
+      if (fetch) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); issue(p + 1); fetch = false; }
+      if (todo) load_m(jb0 + __builtin_ctz(todo), nxt);
+      const double* Bop = buf + jl * nb * 256 + lane;
+      if (jb <= w) {
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma(Bop[(mb * 4 + r) * 64], X[mb][r], acc);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < NBM; ++mb) {
+          if (mb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma(X[mb][r], Bop[(mb * 4 + r) * 64], acc);
+          }
+        }
+      }
+      XTR2(p, tslot); ++tslot;
+      const int ba = jb <= w ? w : jb, bbk = jb <= w ? jb : w;
+      const int a = 16 * ba + li, b = 16 * bbk + lg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bb = b + 4 * r;
+        if ((jb != w || a >= bb) && !(XIVO_ABL == 4 && acc[r] != 12345.678)) {   // diagonal tile: the lower triangle is authoritative
+          const double v = NEG_OUT ? -acc[r] : acc[r];
+          buf_st(v, rO, vO, (unsigned)(16 * ba + (16 * bbk + 4 * r) * ldo) * 8u);
+          if (a != bb) buf_st(v, rO, vOt, (unsigned)(16 * bbk + 4 * r + 16 * ba * ldo) * 8u);
+        }
+      }
+      XTR2(p, tslot); ++tslot;
+    }
+    XTR2(p, 14);
+    if (fetch) issue(p + 1);
+    todo = my_tiles(p + 1);
+    if (todo) load_m((p + 1) * jbp + __builtin_ctz(todo), nxt);
+  }
+  XTRP(8 + 3 * nph);
+}
+
+// TF: the workgroup goes on to form T = K (HP) - P (estimator.cpp:1280, the left product distributed over
+// the H P already at hand) while K^T sits in its registers in exactly the A-operand layout of the MFMA: wave w
+// owns state rows 16w..16w+15 of K. Once the factor is dead the LDS takes the B operands - P H^T again, 8
+// column blocks at a time, each block stored as the 4 nb registers a wave would hold of it, lane-contiguous
+// (conflict-free ds_read_b64) - and wave w forms the 16 x 16 tiles (w, j) for the j cyclically below it
+// (every unordered pair of blocks once: 8 or 9 tiles per wave), accumulators starting at -P, and writes each
+// tile and its mirror. K is never read back and H P is read once more instead of 1.5 times by the tiled GEMM.
+// CHOL (round 5; TF == 4, NBM <= 10): LU is S = H P H^T + diag(R) itself (lower triangle + diagonal blocks, as ell<S> / the
+// gate leave it) and the kernel factors it in LDS before it solves - under the latency of its right-hand-side loads, which
+// one workgroup per CU cannot hide behind anything else (the kernel's first 33 k cycles issued no MFMA). Block row i of the
+// factor belongs to wave i: per block column j its owner (wave j) forms the diagonal update, factors and inverts the 16 x 16
+// diagonal block (factor_invert_diag), one barrier, then waves i > j form L_ij = (S_ij - sum_k L_ik L_jk^T) L_jj^-T in place.
+// Same routines and the same operand order as chol_reg_f64_kernel / chol_f64_kernel: the SAME bits, so everything
+// behind it is unchanged - but L and inv(L_kk) never travel to HBM and back (2.5 GB written + 2.4 GB read per 16384 filters)
+// and the stand-alone Cholesky launch (1.7 ms) is gone. g.chol_status receives the factorisation status.
+template <int NBM, int TF, bool CHOL = false>
+__global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
+  constexpr int BLK = 16 * 17;
+  static_assert(!CHOL || (TF == 4 && NBM <= 10), "in-kernel factorisation: whitened form, diagonal blocks in slots of their own");
+  // TF == 3 needs the diagonal blocks L_kk next to their inverses: in slots of their own while the LDS has room (<= 10
+  // block rows), else packed into the unused upper triangle + pad row of the inverse's slot (a few selects per read)
+  constexpr bool T4 = TF == 4 || TF == 5;   // whitened Joseph form; TF == 5: its outputs V^T, Y^T for a product outside the kernel
+  constexpr bool WOUT = TF == 5;
+  // short factors (M <= 96): W stays in registers next to the working copy - no stash, no read-back, no DMA of the operand
+  constexpr bool KEEPW = T4 && NBM <= 6;
+  constexpr bool PACK = (TF == 3 || T4) && NBM > 10;
+  extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
+  const int chunks = (g.Np + 255) / 256;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int filt = (slot / chunks) * 8 + xcd;
+  const int chunk = slot % chunks;
+  if (filt >= g.batch) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int nb = g.Mp / 16;
+  const double* __restrict__ LU = g.LU + (long)filt * g.strideLU;
+  const double* __restrict__ invD = g.invD + (long)filt * g.strideInvD;
+  const double* __restrict__ PHT = g.PHT + (long)filt * g.stridePHT;
+  const long ld = g.ldlu;
+
+  XTR(0);
+  // the right-hand sides first: their loads are in flight while the factor is copied (one workgroup per CU - nothing else
+  // would hide the latency of either)
+  const int c0 = chunk * 256 + wave * 16;
+  const bool live = c0 < g.Np;
+  const __amdgpu_buffer_rsrc_t rPHT = buf_rsrc(PHT), rK = buf_rsrc(g.K + (long)filt * g.strideK),
+                               rInn = buf_rsrc(g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn);
+  const unsigned vPHT = (unsigned)((c0 + li) + lg * g.ldpht) * 8u;   // element (c0 + li, lg) of P H^T; + (16 i + 4 r) ldpht as a scalar offset
+  const unsigned vK = (unsigned)((c0 + li) + lg * g.ldk) * 8u;
+  d4 X[NBM];
+  auto load_rhs = [&](int i0, int i1) {
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) {
+      if (i >= i0 && i < i1) {
+        if constexpr (CHOL) {
+          // straight-line, unconditional loads (a block row past the factor / a wave past the state re-reads a valid block,
+          // its registers are never used): with the requests inside branches the compiler's wait-count bookkeeping gives up
+          // and the first use of ANY row waits for ALL of them - the late rows included
+          const int ib = i < nb ? i : nb - 1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) X[i][r] = buf_ld(rPHT, live ? vPHT : (unsigned)(li + lg * g.ldpht) * 8u, (unsigned)((16 * ib + 4 * r) * g.ldpht) * 8u);
+        } else {
+          X[i] = d4{0.0, 0.0, 0.0, 0.0};
+          if (live && i < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[i][r] = buf_ld(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u);
+          }
+        }
+      }
+    }
+  };
+  // CHOL: S is brought into LDS first, then block rows [0, HX) of the right-hand sides are requested and the factorisation runs
+  // under them (the kernel lives on 128 VGPRs: all NBM block rows in flight leave the factorisation no registers, and a
+  // spill reload waits for every load in front of it); rows [HX, NBM) are requested when the factor is done and join the
+  // forward substitution at step HX - each row still accumulates its terms in the same order, so nothing changes bit-wise
+  constexpr int HX = CHOL ? (NBM + 1) / 2 : NBM;
+  if constexpr (!CHOL) load_rhs(0, NBM);
+  d4 Wk[KEEPW ? NBM : 1];                           // (KEEPW) the forward-substituted columns, kept next to the working copy
+#pragma unroll
+  for (int i = 0; i < (KEEPW ? NBM : 1); ++i) Wk[i] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // cooperative copy: block (i,k), i >= k at slot i(i+1)/2 + k. The loads of a thread are requested four at a time before
+  // the first of them is consumed (compile-time trip count): the loop used to wait for each of its ~7 round trips in turn,
+  // on a CU that has nothing else to run meanwhile. (All of them at once would spill: the right-hand sides are in flight.)
+  const int nblk = nb * (nb + 1) / 2;
+  constexpr bool DIAG = !PACK && (TF == 3 || T4);                    // the diagonal blocks L_kk in slots of their own
+  constexpr int CPY = (NBM * (NBM + 1) / 2 * 128 + 1023) / 1024;     // d2 loads per thread: factor ...
+  constexpr int CPD = DIAG ? (NBM * 128 + 1023) / 1024 : 0;         // ... + diagonal blocks
+  constexpr int CPB = CHOL ? CPY + CPD : 4;                           // loads in flight per thread (CHOL: all of S at once - no right-hand sides in the registers yet)
+  double* sD = sL + nblk * BLK;                                       // (upper triangle zeroed)
+#pragma unroll
+  for (int u0 = 0; u0 < CPY + CPD; u0 += CPB) {
+    d2 cv[CPB], cu[CPB];
+#pragma unroll
+    for (int q = 0; q < CPB; ++q) {
+      const int u = u0 + q;
+      cv[q] = d2{0.0, 0.0}; cu[q] = d2{0.0, 0.0};
+      if (u < CPY) {
+        const int e = tid + 1024 * u;
+        if (e < nblk * 128) {
+          const int t = e >> 7, w = e & 127;
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= t) ++i;            // block row of slot t (nb <= 24: a few iterations)
+          const int k = t - i * (i + 1) / 2;
+          const int r = (w & 7) * 2, c = w >> 3;             // rows r, r+1 of column c
+          if (!(CHOL && i == k))      // (CHOL: the diagonal slot receives inv(L_kk) from the factorisation below)
+            cv[q] = *reinterpret_cast<const d2*>(i != k ? LU + (16 * i + r) + (long)(16 * k + c) * ld : invD + (long)k * 512 + r + 16 * c);
+          if (PACK && i == k) { cu[q][0] = LU[(16 * k + c) + (long)(16 * k + r) * ld]; cu[q][1] = LU[(16 * k + c) + (long)(16 * k + r + 1) * ld]; }
+        }
+      } else if (u < CPY + CPD) {
+        const int e = tid + 1024 * (u - CPY);
+        if (e < nb * 128) {
+          const int k = e >> 7, w = e & 127;
+          cv[q] = *reinterpret_cast<const d2*>(LU + (16 * k + (w & 7) * 2) + (long)(16 * k + (w >> 3)) * ld);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CPB; ++q) {
+      const int u = u0 + q;
+      if (u < CPY) {
+        const int e = tid + 1024 * u;
+        if (e < nblk * 128) {
+          const int t = e >> 7, w = e & 127;
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= t) ++i;
+          const int k = t - i * (i + 1) / 2;
+          const int r = (w & 7) * 2, c = w >> 3;
+          d2 v = cv[q];
+          // diagonal slot: inv(L_kk) in the lower triangle; packed: L_kk^T above it (the strictly lower part of L_kk read
+          // transposed: the factorisation need not have mirrored it) and the diagonal of L_kk in the pad row
+          if (PACK && i == k) { v[0] = r >= c ? v[0] : cu[q][0]; v[1] = r + 1 >= c ? v[1] : cu[q][1]; }
+          sL[t * BLK + r + 17 * c] = v[0];
+          sL[t * BLK + r + 1 + 17 * c] = v[1];
+        }
+      } else if (u < CPY + CPD) {
+        const int e = tid + 1024 * (u - CPY);
+        if (e < nb * 128) {
+          const int k = e >> 7, w = e & 127;
+          const int r = (w & 7) * 2, c = w >> 3;
+          sD[k * BLK + r + 17 * c] = r >= c ? cv[q][0] : 0.0;
+          sD[k * BLK + r + 1 + 17 * c] = r + 1 >= c ? cv[q][1] : 0.0;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (PACK) {
+    for (int e = tid; e < nb * 16; e += 1024) {
+      const int k = e >> 4, c = e & 15;
+      sL[(k * (k + 1) / 2 + k) * BLK + 16 + 17 * c] = LU[(16 * k + c) + (long)(16 * k + c) * ld];
+    }
+  }
+  XTR(1);
+  if constexpr (CHOL) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_rhs(0, HX);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();                                 // (no vmcnt drain: the right-hand sides stay in flight)
+  } else __syncthreads();
+  XTR(2);
+  if (!TF && !live) return;
+  int chol_bad = 0;
+  if constexpr (CHOL) {
+    // ---- S = L L^T in LDS (the right-hand sides requested above are still on their way)
+    // (the launcher hands the kernel all 160 KiB as dynamic LDS: no static allocation next to it - the flag sits behind the factor)
+    int& sBad = *reinterpret_cast<int*>(sD + nb * BLK);
+    if (tid == 0) sBad = 0;                                               // (ordered before its first use by the loop's barriers)
+    const int lo = li + 17 * lg;                                          // element (li, lg) of a padded 16 x 17 block
+#pragma unroll 1
+    for (int j = 0; j < nb; ++j) {
+      const int dj = (j * (j + 1) / 2 + j) * BLK;                         // diagonal slot: inv(L_jj)
+      if (wave == j) {
+        // owner: S_jj - sum_{k<j} L_jk L_jk^T (k ascending, k-slices 0, 2 and 1, 3 in two accumulators: chol_reg's order)
+        d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+        const double* Lj = sL + (j * (j + 1) / 2) * BLK + lo;
+#pragma unroll 1
+        for (int k = 0; k < j; ++k) {
+          const double a0 = Lj[k * BLK], a1 = Lj[k * BLK + 68], a2 = Lj[k * BLK + 136], a3 = Lj[k * BLK + 204];
+          acc0 = mfma(a0, a0, acc0);
+          acc1 = mfma(a1, a1, acc1);
+          acc0 = mfma(a2, a2, acc0);
+          acc1 = mfma(a3, a3, acc1);
+        }
+        d4 x, y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = sD[j * BLK + lo + 68 * r] - (acc0[r] + acc1[r]);
+        int bad = 0;
+        factor_invert_diag(x, y, bad, 16 * j, li, lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = lg + 4 * r;
+          sD[j * BLK + li + 17 * c] = c <= li ? x[r] : 0.0;               // L_jj, upper triangle zero
+          sL[dj + c + 17 * li] = y[r];                                    // inv(L_jj)(c, li)
+        }
+        if (bad && lane == 0 && sBad == 0) sBad = bad;
+      }
+      lds_barrier();
+      if (wave > j && wave < nb) {
+        // L_ij^T = inv(L_jj) (S_ij^T - sum_{k<j} L_jk L_ik^T), i = wave, in place
+        const double* Lj = sL + (j * (j + 1) / 2) * BLK + lo;
+        double* Li = sL + (wave * (wave + 1) / 2) * BLK + lo;
+        d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int k = 0; k < j; ++k) {
+          const double a0 = Lj[k * BLK], b0 = Li[k * BLK], a1 = Lj[k * BLK + 68], b1 = Li[k * BLK + 68];
+          accA = mfma(a0, b0, accA);
+          accB = mfma(a1, b1, accB);
+          const double a2 = Lj[k * BLK + 136], b2 = Li[k * BLK + 136], a3 = Lj[k * BLK + 204], b3 = Li[k * BLK + 204];
+          accA = mfma(a2, b2, accA);
+          accB = mfma(a3, b3, accB);
+        }
+        d4 rhs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rhs[r] = Li[j * BLK + 68 * r] - (accA[r] + accB[r]);
+        d4 out = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) out = mfma(sL[dj + li + 17 * (4 * s4 + lg)], rhs[s4], out);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Li[j * BLK + 68 * r] = out[r];
+      }
+    }
+    lds_barrier();
+    chol_bad = sBad;
+    if (tid == 0 && g.chol_status) g.chol_status[filt] = chol_bad;
+    __builtin_amdgcn_sched_barrier(0);
+    load_rhs(HX, NBM);
+  }
+
+  if (live) {
+  // forward: L Y = HP
+#pragma unroll
+  for (int k = 0; k < NBM; ++k) {
+    if (k < nb && !(T4 && XIVO_ABL == 2)) {
+      if constexpr (CHOL) {
+        if (k == HX) {   // the late block rows have arrived: the terms of steps 0 .. HX - 1, in the order the steps would have added them
+#pragma unroll
+          for (int kk = 0; kk < HX; ++kk) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+              for (int i = HX; i < NBM; ++i) {
+                if (i < nb) {
+                  const double a = sL[(i * (i + 1) / 2 + kk) * BLK + li + 17 * (4 * s + lg)];
+                  X[i] = mfma(-a, X[kk][s], X[i]);
+                }
+              }
+            }
+          }
+        }
+      }
+      const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
+      d4 t = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        double a = Dk[li + 17 * (4 * s + lg)];
+        if (PACK) a = li >= 4 * s + lg ? a : 0.0;         // (the slot's upper triangle belongs to L_kk^T)
+        t = mfma(a, X[k][s], t);
+      }
+      X[k] = t;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = k + 1; i < NBM; ++i) {
+          if (i < nb && (!CHOL || k >= HX || i < HX)) {
+            const double a = sL[(i * (i + 1) / 2 + k) * BLK + li + 17 * (4 * s + lg)];
+            X[i] = mfma(-a, t[s], X[i]);
+          }
+        }
+      }
+    }
+  }
+  XTR(3);
+  double part = 0.0;
+  if (KEEPW) {
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) Wk[i] = X[i];
+  }
+  if (T4 && !KEEPW && XIVO_ABL != 6) {
+    // the forward-substituted columns W^T = (L^-1 H P)^T leave for the stash (the K buffer: the gain itself is never
+    // stored by this variant) - the backward substitution below destroys them and the covariance update needs them again
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) {
+      if (i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);
+      }
+    }
+  }
+  XTR(4);
+  // backward: L^T K^T = Y
+#pragma unroll
+  for (int k = NBM - 1; k >= 0; --k) {
+    if (k < nb && !g.fwd_only && !(T4 && XIVO_ABL == 2)) {
+      const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
+      // TF == 4: W_k comes back from the stash while this step's MFMAs run (requested here, used at the end of the step;
+      // the last block row has not been touched yet: it is still in X)
+      d4 wk = d4{0.0, 0.0, 0.0, 0.0};
+      if (KEEPW) wk = Wk[k];
+      else if (T4) {
+        if (k == nb - 1) wk = X[k];
+        else if (XIVO_ABL != 6) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wk[r] = buf_ld(rK, vK, (unsigned)((16 * k + 4 * r) * g.ldk) * 8u);
+        }
+      }
+      d4 t = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        double a = Dk[(4 * s + lg) + 17 * li];
+        if (PACK) a = 4 * s + lg >= li ? a : 0.0;
+        t = mfma(a, X[k][s], t);
+      }
+      if (T4) {
+        // D_k = B_k - L_kk^T K^T_k, B_k = W_k - sum_{i>k} L_ik^T K^T_i the right-hand side this step just consumed: the
+        // residual of the backward substitution, i.e. W_k - (L^T K^T)_k evaluated with the partial sums already at hand
+        // (both evaluations of L^T K^T carry the same rounding bound); it replaces the gain block, whose last uses -
+        // the updates of the rows above and dx - are right here
+        const double* Lk = PACK ? Dk : sD + k * BLK;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const int kk = 4 * s2 + lg;                                        // (L_kk)^T element (li, kk) = L_kk(kk, li)
+          if (PACK) {
+            const double a = Lk[kk > li ? li + 17 * kk : 16 + 17 * li];
+            X[k] = mfma(kk >= li ? -a : 0.0, t[s2], X[k]);
+          } else {
+            X[k] = mfma(-Lk[kk + 17 * li], t[s2], X[k]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fma(t[r], XIVO_ABL == 5 ? 1.0 : buf_ld(rInn, (unsigned)lg * 8u, (unsigned)(16 * k + 4 * r) * 8u), part);
+      } else {
+        X[k] = t;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+          const double a = sL[(k * (k + 1) / 2 + i) * BLK + (4 * s + lg) + 17 * li];   // (L_ki)^T
+          X[i] = mfma(-a, t[s], X[i]);
+        }
+      }
+      // TF == 4: V_k = W_k - D_k, the row block of V^T = (W - D)^T - the register operand of the covariance product below
+      // (or, for states wider than one workgroup, of the tiled product outside: then Y_k = W_k + D_k leaves for g.Yout here)
+      if (T4) {
+        if (WOUT) {
+          const __amdgpu_buffer_rsrc_t rY = buf_rsrc(g.Yout + (long)filt * g.strideY2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) buf_st(wk[r] + X[k][r], rY, (unsigned)((c0 + li) + lg * g.ldy2) * 8u, (unsigned)((16 * k + 4 * r) * g.ldy2) * 8u);
+        }
+        X[k] = wk - X[k];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  if (!T4) {
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) {
+      if (i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (TF != 2) buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);   // (the symmetric form keeps W^T in registers: nothing reads it back)
+          part = fma(X[i][r], buf_ld(rInn, (unsigned)lg * 8u, (unsigned)(16 * i + 4 * r) * 8u), part);
+        }
+      }
+    }
+  }
+  part += __shfl_xor(part, 16);
+  part += __shfl_xor(part, 32);
+  if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
+
+  // TF == 4: X = V now. The covariance update is the Joseph expression for the gain just computed, in the whitened
+  // coordinates of the factor (S = L L^T, H P = L W, V = L^T K^T = W - D):
+  //   P+ = P - K(HP) - (K(HP))^T + K S K^T = P - V^T W - W^T V + V^T V = P - (W - D)^T (W + D) + (W^T D - D^T W),
+  // whose antisymmetric last term drops out of the lower-triangle + mirror evaluation every pipeline here uses. The rows
+  // of V^T = (W - D)^T are the register operand, W + D = 2 W - V the LDS operand (below).
+
+  if (TF == 3) {
+    // ---- the whole covariance update on the gain in registers (expanded Joseph form, see the launcher's comment):
+    //   V^T = L^T K^T (in place, ascending block rows), then L V^T (in place, descending) = (K L L^T)^T,
+    //   Z^T = 2 P H^T - K L L^T  [= P H^T - G,  G = K (L L^T) - P H^T the residual of the gain equation]
+#pragma unroll
+    for (int j = 0; j < NBM; ++j) {
+      if (j < nb) {
+        const double* Dj = PACK ? sL + (j * (j + 1) / 2 + j) * BLK : sD + j * BLK;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {                                                                      // (L_jj)^T:
+          const int kk = 4 * s2 + lg;                                                                         // element (li, kk) = L_jj(kk, li)
+          if (PACK) {
+            const double a = Dj[kk > li ? li + 17 * kk : 16 + 17 * li];
+            acc = mfma(kk >= li ? a : 0.0, X[j][s2], acc);
+          } else {
+            acc = mfma(Dj[kk + 17 * li], X[j][s2], acc);
+          }
+        }
+#pragma unroll
+        for (int i = j + 1; i < NBM; ++i) {
+          if (i < nb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+              acc = mfma(sL[(i * (i + 1) / 2 + j) * BLK + (4 * s2 + lg) + 17 * li], X[i][s2], acc);            // (L_ij)^T
+          }
+        }
+        X[j] = acc;
+      }
+    }
+#pragma unroll
+    for (int i = NBM - 1; i >= 0; --i) {
+      if (i < nb) {
+        const double* Di = PACK ? sL + (i * (i + 1) / 2 + i) * BLK : sD + i * BLK;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {                                                                      // L_ii:
+          const int kk = 4 * s2 + lg;                                                                         // element (li, kk), stored transposed when packed
+          if (PACK) {
+            const double a = Di[li > kk ? kk + 17 * li : 16 + 17 * li];
+            acc = mfma(li >= kk ? a : 0.0, X[i][s2], acc);
+          } else {
+            acc = mfma(Di[li + 17 * kk], X[i][s2], acc);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2)
+            acc = mfma(sL[(i * (i + 1) / 2 + k) * BLK + li + 17 * (4 * s2 + lg)], X[k][s2], acc);              // L_ik
+        }
+        X[i] = acc;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) {
+      if (i < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[i][r] = fma(2.0, buf_ld(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u), -X[i][r]);
+      }
+    }
+  }
+  }
+  if (!TF) return;
+
+  XTR(5);
+  __syncthreads();                                 // the factor is dead: the LDS takes the operands
+  XTR(6);
+  if (TF == 3) {
+    // ---- P+ = P - Z^T K^T in place: rows of Z^T in registers, blocks of the gain just written arrive through LDS
+    if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
+    double* Pio = g.T + (long)filt * g.strideT;
+    sym_tiles_from_regs<NBM, false, true>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+                                          live, c0 >> 4, wave, lane);
+    return;
+  }
+  if (T4) {
+    if (WOUT) {   // whitened outputs only: V^T replaces the stash, the covariance product runs outside (tiled)
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < NBM; ++i) {
+          if (i < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf_st(X[i][r], rK, vK, (unsigned)((16 * i + 4 * r) * g.ldk) * 8u);
+          }
+        }
+      }
+      return;
+    }
+    // ---- P+ = P - (W - D)^T (W + D) in place: W arrives from the stash by DMA, the owner waves turn it into W + D
+    if (CHOL ? chol_bad != 0 : (g.skip_status && g.skip_status[filt] != 0)) return;   // S not positive definite: P stays the prior
+    if (XIVO_ABL == 1) return;
+    double* Pio = g.T + (long)filt * g.strideT;
+    if constexpr (KEEPW) sym_tiles_from_regs<NBM, true, true, false, true>(X, Wk, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+                                                                 live, c0 >> 4, wave, lane);
+    else sym_tiles_from_regs<NBM, false, true, true>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+                                                     live, c0 >> 4, wave, lane);
+    return;
+  }
+  if (TF == 2) {
+    // ---- symmetric form: P+ = P - W^T W in place, W^T = the forward-substituted columns still in registers
+    if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
+    double* Pio = g.T + (long)filt * g.strideT;
+    sym_tiles_from_regs<NBM, true, true>(X, X, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
+    return;
+  }
+  // ---- T = K (HP) - P
+  sym_tiles_from_regs<NBM>(X, X, sL, PHT, g.ldpht, g.Pm + (long)filt * g.stridePm, g.ldpm, g.T + (long)filt * g.strideT, g.ldt,
+                           nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
+}
+
+}  // namespace
+
+}  // namespace xivo_hip
