@@ -780,9 +780,10 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   const bool lat = latency_route(c, Mp, B, full);
   const bool t_full = full || getenv("XIVO_HIP_T_FULL");
-  // Round 5: where the solve kernel carries the whole whitened Joseph update (one 16-wave workgroup per filter), it also
-  // factors S itself - in LDS, under the latency of its right-hand-side loads (chol_device.h routines, the same bits as the
-  // stand-alone kernels): no Cholesky launch, L and inv(L_kk) never cross HBM. XIVO_HIP_NO_FUSED_CHOL: A/B knob.
+  // Round 5, opt-in (XIVO_HIP_FUSED_CHOL=1; measured slower, see solve_fused.hip): where the solve kernel carries the whole
+  // whitened Joseph update (one 16-wave workgroup per filter) it can also factor S itself - in LDS, under the latency of its
+  // right-hand-side loads (chol_device.h routines, the same bits as the stand-alone kernels): no Cholesky launch, L and
+  // inv(L_kk) never cross HBM.
   static const bool no_joseph_k = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
   const bool fuse_chol = !(c->flags & (XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_EXPANDED_JOSEPH)) &&
                          !t_full && !lat && trsm_forms_T(Mp, Np) && !no_joseph_k && mr0 < 0 && trsm_chol_fused_supported(Mp, Np);

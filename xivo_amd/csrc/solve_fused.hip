@@ -28,9 +28,14 @@ int launch_fused_t(const TrsmArgs& g_in, hipStream_t stream) {
 }  // namespace
 
 // shapes the fused kernel holds: the whole state in one 16-wave workgroup, a factor of at most ten block rows
+// OPT-IN (XIVO_HIP_FUSED_CHOL=1), measured and not adopted: per 16384 filters at (250, 160) the solve grows from 9.6 to 12.2 ms
+// while the stand-alone Cholesky it replaces costs 1.7 ms (config 2: 4.09 -> 5.83 against 0.80; TUM-VI size: 1.69 -> 2.12
+// against 0.16). The factorisation is a serial chain (ten diagonal blocks, sixteen dependent columns each) that one
+// workgroup per CU has nothing to hide behind - ~85 k cycles per filter - whereas the stand-alone kernel keeps three factors in
+// flight per CU (26.7 us of CU time per factor). Same bits either way (tests/test_update_gpu.py).
 bool trsm_chol_fused_supported(int Mp, int Np) {
-  static const bool off = getenv("XIVO_HIP_NO_FUSED_CHOL") != nullptr;   // A/B knob: stand-alone Cholesky + solve
-  return !off && Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
+  static const bool on = getenv("XIVO_HIP_FUSED_CHOL") != nullptr;
+  return on && Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
 }
 
 // g.LU = S (lower triangle + diagonal blocks), g.invD unused, g.T = the covariance (updated in place), g.joseph = 2,
