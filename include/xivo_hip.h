@@ -404,7 +404,10 @@ int xivo_hip_compress_oos(xivo_hip_ctx* ctx, int B, double trigger_ratio, int* r
  *   gauge_group   host [B]: slot of gauge_group_ptr_, -1 = none (NULL: none for every filter)
  *   absorb_groups host [B]: bit g = group slot g is in instate_groups_ when the partial update is absorbed (that list is
  *                 the previous frame's, src/manager.cpp:103); NULL = every slot
- *   inlier_mask_out / chi2_out [B x F], n_rejected_out [B]: host, any may be NULL. chi2 is 0 for features not tested. */
+ *   inlier_mask_out / chi2_out [B x F], n_rejected_out [B]: host, any may be NULL. chi2 is 0 for features not tested.
+ * Online-calibration builds (xivo_hip_set_calib): the calibration state is backed up and restored with X_
+ * (src/estimator.cpp:1421-1427, :1442-1448), the partial update runs on the whole rows J() with their td / Cg / bg / intrinsics
+ * blocks, AbsorbError retracts td / Cg / Ca / the intrinsics, and the rescue test is the whole-row chi-square of :350-356. */
 int xivo_hip_one_point_ransac(xivo_hip_ctx* ctx, int B, double R, double ransac_thresh, double ransac_chi2,
                               const int* gauge_group, const unsigned long long* absorb_groups,
                               unsigned char* inlier_mask_out, double* chi2_out, int* n_rejected_out);

@@ -1048,7 +1048,7 @@ def feature_score(P):
 # a7: Estimator::OnePointRANSAC (src/update.cpp:213-393), numeric core for one filter.
 # ----------------------------------------------------------------------------
 def one_point_ransac(st, P, xp, cam, layout, R, ransac_thresh, ransac_chi2, gauge_group, instate_groups,
-                     in_current_ekf_update=()):
+                     in_current_ekf_update=(), calib_gyro=None):
     """st as in absorb_error plus ref [F]. All F features are the MH inliers handed in.
     Returns dict(inliers=sorted feature indices kept, rejected=..., chi2={feature: distance},
     low=low-innovation mask, err=dx of the partial update, P_partial=P after it).
@@ -1056,13 +1056,18 @@ def one_point_ransac(st, P, xp, cam, layout, R, ransac_thresh, ransac_chi2, gaug
     simply {f : |xp - pred| < ransac_thresh} (pred == the prediction of ComputeJacobian)."""
     import copy
     F = len(xp)
+    # online-calibration builds: st also carries td, Cg, Ca and cam (the intrinsics are state: BackupState / AbsorbError /
+    # RestoreState move them with X_); calib_gyro = last_gyro_ (update.cpp:348-349 hands it to ComputeJacobian)
+    calib_build = getattr(layout, "td", -1) >= 0 or getattr(layout, "cam_dim", 0) > 0
 
     def jac_all(s):
         out = []
+        cal = dict(gyro=calib_gyro, Cg=s["Cg"], bg=s["bg"], Vsb=s["Vsb"], td=s["td"]) if calib_build else None
+        cm = s["cam"] if calib_build and getattr(layout, "cam_dim", 0) > 0 else cam
         for i in range(F):
             r = int(s["ref"][i])
             out.append(compute_jacobian(s["x"][i], xp[i], s["gR"][r], s["gT"][r], s["Rsb"], s["Tsb"], s["Rbc"], s["Tbc"],
-                                        cam, layout, r, int(s["sind"][i]))[:2])
+                                        cm, layout, r, int(s["sind"][i]), calib=cal)[:2])
         return out
     J0 = jac_all(st)
     low = np.array([np.linalg.norm(J0[i][1]) < ransac_thresh for i in range(F)])         # :245-249

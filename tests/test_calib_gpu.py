@@ -110,7 +110,7 @@ def test_filter_update_with_calibration_columns(built, name):
 
 def test_stand_alone_gate_and_calibration_off_again(built):
     """xivo_hip_mh_gate on a calibration context gates on the whole row too (then stack + update as separate calls);
-    1-pt RANSAC is not built for these builds; set_calib() switches back to the default build."""
+    set_calib() switches back to the default build."""
     cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup("equi", True, True, True, B=3, ng=6, nf=14, seed=4)
     feats["xp"][2, [1, 5]] += 50.0; xp[2, [1, 5]] += 50.0
     B, F = 3, feats.shape[1]
@@ -121,7 +121,6 @@ def test_stand_alone_gate_and_calibration_off_again(built):
         mask, dist = ctx.mh_gate(R_VIS, MH, MULT, 5)
         ctx.stack(R_VIS); ctx.update_joseph()
         err = ctx.get_err(); Pn = ctx.download_P()
-        assert ctx.lib.xivo_hip_one_point_ransac(ctx.h, B, 2.25, 1.0, 5.991, None, None, None, None, None) == -5
         rej = 0
         for b in range(B):
             Js, inns, _ = oracle_rows(sc, cam, lay, xp, cals, b)
@@ -138,6 +137,68 @@ def test_stand_alone_gate_and_calibration_off_again(built):
         ctx.upload_P(np.array([spd(lay.N, 5 + b) * 1e-4 for b in range(3)]))
         ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)
         assert ctx.last_path() == 1                                                             # compressed rows, sparse pipeline
+
+
+@pytest.mark.parametrize("name", ["radtan", "equi"])
+def test_one_point_ransac_of_a_calibration_build(built, name):
+    """Estimator::OnePointRANSAC (src/update.cpp:213-393) on an online-calibration context (round 5): the low-innovation
+    set, the partial update on the WHOLE rows J() incl. the td / Cg / bg / intrinsics blocks, AbsorbError of td / Cg / Ca /
+    intrinsics, Jacobians at the updated state (with the updated intrinsics), the whole-row chi-square rescue, RestoreState
+    of everything incl. the calibration state - against the oracle, whose calibration branch is pinned to the reference's
+    own text compiled with the three defines (tests/test_oracle_pinned.py)."""
+    B, ng, nf = 8, 5, 14
+    cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup(name, True, True, True, B=B, ng=ng, nf=nf, seed=31)
+    rng = np.random.default_rng(8)
+    xp = xp - sc["pix_noise"] + rng.normal(size=xp.shape) * 0.3
+    gauge = np.zeros(B, dtype=np.int32)
+    for b in range(B):
+        kind = b % 4
+        if kind in (0, 2):                                     # a few high-innovation features, one hopeless
+            far = rng.choice(nf, size=4, replace=False)
+            xp[b, far[:-1]] += rng.choice([-1, 1], size=(3, 2)) * rng.uniform(2.0, 4.0, size=(3, 2))
+            xp[b, far[-1]] += 35.0
+        elif kind == 3:                                        # nothing is low-innovation: rescue against the prior
+            xp[b] += rng.choice([-1, 1], size=(nf, 2)) * rng.uniform(2.5, 3.5, size=(nf, 2))
+        gauge[b] = -1 if kind == 2 else int(rng.integers(0, ng))
+    feats["xp"] = xp
+    P = np.array([spd(lay.N, 400 + b) * 1e-4 for b in range(B)])
+    THRESH, CHI2, R1 = 2.0, 5.89, 1.0
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        ctx.jacobians_instate()
+        mh_mask, _ = ctx.mh_gate(R1, MH, MULT, 5)
+        J0, inn0 = ctx.get_jacobians(); Jc0 = ctx.get_jacobians_calib(F=nf)
+        keep, chi, nrej = ctx.one_point_ransac(R1, THRESH, CHI2, gauge=gauge)
+        assert np.array_equal(ctx.download_P(), P)                                   # RestoreState
+        p2, g2, _ = ctx.get_scene(); c2 = ctx.get_calib_state()
+        assert np.array_equal(p2["Rsb"], poses["Rsb"]) and np.array_equal(g2["Tsb"], groups["Tsb"])
+        assert np.array_equal(c2["intr"], calib["intr"]) and np.array_equal(c2["Cg"], calib["Cg"]) and np.array_equal(c2["td"], calib["td"])
+        J1, inn1 = ctx.get_jacobians(); Jc1 = ctx.get_jacobians_calib(F=nf)
+        assert np.array_equal(J0, J1) and np.array_equal(inn0, inn1) and np.array_equal(Jc0, Jc1)
+        ctx.stack(R1); ctx.update_joseph()
+        Pn, err = ctx.download_P(), ctx.get_err()
+    seen = dict(partial=0, prior=0, rejected=0, rescued=0)
+    for b in range(B):
+        idx = np.nonzero(mh_mask[b])[0]
+        st = dict(Rsb=sc["Rsb"][b].copy(), Tsb=sc["Tsb"][b].copy(), Vsb=cals[b]["Vsb"].copy(), bg=cals[b]["bg"].copy(), ba=np.zeros(3),
+                  Rbc=sc["Rbc"][b].copy(), Tbc=sc["Tbc"][b].copy(), Rsg=np.eye(3), gR=sc["gR"][b].copy(), gT=sc["gT"][b].copy(),
+                  x=sc["x"][b][idx].copy(), sind=sc["sind"][b][idx], ref=sc["ref"][b][idx], td=cals[b]["td"], Cg=cals[b]["Cg"].copy(),
+                  Ca=np.eye(3), cam=dict(cam, d=list(cam.get("d", []))))
+        out = orc.one_point_ransac(st, P[b], xp[b][idx], cam, lay, R1, THRESH, CHI2, int(gauge[b]), range(ng), calib_gyro=cals[b]["gyro"])
+        exp = np.zeros(nf, dtype=bool); exp[idx[out["inliers"]]] = True
+        assert np.array_equal(keep[b], exp), (b, keep[b], exp)
+        assert nrej[b] == len(out["rejected"])
+        for i, d in out["chi2"].items():
+            assert abs(chi[b, idx[i]] - d) < 1e-7 * max(1.0, d), (b, i)
+        low = out["low"]
+        seen["prior"] += (not low.any()); seen["partial"] += (low.any() and not low.all())
+        seen["rejected"] += len(out["rejected"]); seen["rescued"] += len(out["inliers"]) - int(low.sum())
+        Js, inns, _ = oracle_rows(sc, cam, lay, xp, cals, b)
+        kept = np.nonzero(exp)[0]
+        H, inn, dR = orc.stack_measurements(Js[kept], inns[kept], sc["ref"][b][kept], sc["sind"][b][kept], lay, R1)
+        e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+    assert seen["partial"] >= 3 and seen["prior"] >= 1 and seen["rejected"] >= 3, seen
 
 
 # ---- motion side ---------------------------------------------------------------------------------------------------------

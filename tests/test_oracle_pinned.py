@@ -975,3 +975,31 @@ def test_golden_v6_one_point_ransac_whole_function(tag, cam):
     J3 = orc.compute_jacobian(sc["x"][0, 3], xp[3], sc["gR"][0, r], sc["gT"][0, r], sc["Rsb"][0], sc["Tsb"][0], sc["Rbc"][0], sc["Tbc"][0],
                               CAMS[cam], lay, r, int(sc["sind"][0, 3]))[0]
     assert np.abs(J3[:, G6[f"ransac_{tag}_J3cols"]] - G6[f"ransac_{tag}_J3"]).max() / np.abs(J3).max() < 1e-12
+
+
+def test_extracted_one_point_ransac_calibration_build_live():
+    """The whole OnePointRANSAC of the extracted build compiled with the three online-calibration defines (N = 228): the partial
+    update runs on the whole rows J() with their td / Cg / bg / intrinsics blocks, AbsorbError moves td / Cg / Ca / the
+    intrinsics, Backup / RestoreState carry them - the oracle's calibration branch of one_point_ransac against it."""
+    x = _refx("calib")
+    m = _v6()
+    for tag, camname in (("rad", "radtan"), ("tmp", "equi"), ("pin", "pinhole")):
+        c = m.ransac_case(tag)
+        sc = c["sc"]; cam = CAMS[camname]
+        lay = orc.calib_layout(c["ng"], c["nf"], True, True, CAM_DIM[camname])
+        assert lay.N == x.N
+        rng = np.random.default_rng(11)
+        A = rng.uniform(-1, 1, size=(lay.N, lay.N)); P = (A @ A.T / lay.N + 1e-3 * np.eye(lay.N)) * 1e-4
+        xp = m.ransac_pixels(c, lambda cam_, xcn: orc.camera_project(cam_, xcn)[0])
+        X = orc.MotionState(sc["Rsb"][0], sc["Tsb"][0], np.zeros(3), np.zeros(3), np.zeros(3), np.eye(3))
+        o = x.one_point_ransac(X, sc["Rbc"][0], sc["Tbc"][0], P, sc["x"][0], xp, sc["ref"][0], sc["sind"][0], sc["gR"][0], sc["gT"][0],
+                               cam, c["R"], c["thresh"], c["chi2"], gauge_sind=c["gauge"])
+        st = dict(Rsb=sc["Rsb"][0], Tsb=sc["Tsb"][0], Vsb=np.zeros(3), bg=np.zeros(3), ba=np.zeros(3), Rbc=sc["Rbc"][0], Tbc=sc["Tbc"][0],
+                  Rsg=np.eye(3), gR=sc["gR"][0].copy(), gT=sc["gT"][0].copy(), x=sc["x"][0].copy(), sind=sc["sind"][0], ref=sc["ref"][0],
+                  td=0.0, Cg=np.eye(3), Ca=np.eye(3), cam=dict(cam, d=list(cam.get("d", []))))
+        out = orc.one_point_ransac(st, P, xp, cam, lay, c["R"], c["thresh"], c["chi2"], c["gauge"], range(c["ng"]), calib_gyro=np.zeros(3))
+        assert out["inliers"] == np.nonzero(o["keep"])[0].tolist(), tag
+        assert sorted(out["rejected"]) == np.nonzero(o["status"] == 4)[0].tolist() and len(out["rejected"]) == o["n_rejected"]
+        assert np.array_equal(o["P"], P) and 0 < out["low"].sum() < c["nf"]
+        # the partial update really moved the calibration columns
+        assert np.abs(out["err"][lay.td]) > 0 and np.abs(out["err"][lay.cam_begin:lay.cam_begin + 4]).max() > 0

@@ -97,6 +97,7 @@ struct xivo_hip_ctx {
   double oos_R = 0.0;
   int oos_nb = 0, oos_n = 0, oos_max_rows = 0;   // shape of the resident OOS list (xivo_hip_oos_project with feats == NULL)
   int* oos_rows = nullptr;
+  xivo_calib_in* calib_rs = nullptr;            // BackupState of the calibration state (OnePointRANSAC, online-calibration builds)
   void* lc_buf = nullptr; size_t lc_cap = 0;   // xivo_hip_close_loop_stack: matches | dense rows | inn | diagR
   xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
   std::vector<char> hstage;                        // host staging of d2h_rows
@@ -342,7 +343,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
-                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->tune_status, c->ldlt_used, c->calib, c->Jc};
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->calib_rs, c->tune_status, c->ldlt_used, c->calib, c->Jc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
   if (c->pin_h) hipHostFree(c->pin_h);
@@ -1740,8 +1741,13 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
                               unsigned char* inlier_mask_out, double* chi2_out, int* n_rejected_out) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0 || !c->mask || !c->poses) return XIVO_HIP_ERR_INVALID;
-  if (c->lay.n_groups > 64 || c->calib_on) return XIVO_HIP_ERR_UNSUPPORTED;
+  if (c->lay.n_groups > 64) return XIVO_HIP_ERR_UNSUPPORTED;
   const size_t Bm = c->Bmax, ng = c->lay.n_groups;
+  // online-calibration builds: the calibration state is backed up / restored with X_ (imu_.BackupState, Camera::BackupState,
+  // src/estimator.cpp:1421-1427), the partial update stacks the whole rows J() as dense rows, AbsorbError retracts td / Cg / Ca /
+  // the intrinsics too, and the rescue test uses the whole-row distances of the dense-row gate
+  const bool cal = c->calib_on;
+  if (cal && !c->calib_rs) { int rc = dev_alloc(&c->calib_rs, Bm); if (rc) return rc; }
   if (!c->Prs || c->rs_Fmax != c->Fmax) {
     void* olds[] = {c->rs_low, c->rs_lowkeep, c->rs_keep, c->rs_chi};
     for (void* p : olds) if (p) hipFree(p);
@@ -1772,15 +1778,16 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   HIP_TRY(hipMemcpyAsync(c->Prs, c->P, (size_t)B * c->sP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->poses_rs, c->poses, (size_t)B * sizeof(xivo_pose_in), hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->groups_rs, c->groups, (size_t)B * ng * sizeof(xivo_group_in), hipMemcpyDeviceToDevice, c->stream));
+  if (cal) HIP_TRY(hipMemcpyAsync(c->calib_rs, c->calib, (size_t)B * sizeof(xivo_calib_in), hipMemcpyDeviceToDevice, c->stream));
   {
     StageTimer st(c, ST_OTHER, 0.0, "ransac_zero_kernel");
     HIP_TRY((hipError_t)launch_ransac_zero(a, c->P, c->stream));
   }
   // partial update: H_ rows = the full J() of the low-innovation inliers (:326 - no FillJacobianBlock), R_ on the diagonal
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
-  for (int b = 0; b < B; ++b) { c->ell_over_h[b] = 0; c->ell_nc_h[b] = 12; c->ell_pw_h[b] = 9; }
-  const int dense = (c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) ? 1 : 0;
-  c->dense_valid = dense != 0; c->dense_from_ell = true; c->stack_R = R; c->stack_B = B;
+  for (int b = 0; b < B; ++b) { c->ell_over_h[b] = cal ? 1 : 0; c->ell_nc_h[b] = 12; c->ell_pw_h[b] = 9; }
+  const int dense = ((c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) || cal) ? 1 : 0;
+  c->dense_valid = dense != 0; c->dense_from_ell = !cal; c->stack_R = R; c->stack_B = B;
   c->oos_row0 = -1;   // the partial stacking replaces the rows of any earlier xivo_hip_oos_project (as xivo_hip_stack does)
   c->mixed_row0 = -1; if (dense) c->h_clean = false;
   int rc = stack_impl(c, B, R, dense, c->rs_low, 1);
@@ -1793,19 +1800,50 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
     ab.poses = c->poses; ab.groups = c->groups; ab.feats = c->feats; ab.mask = nullptr; ab.err = c->err; ab.strideErr = c->Np;
     ab.lay = c->lay; ab.F = c->F; ab.Fmax = c->Fmax; ab.batch = B; ab.counter = nullptr; ab.status = c->status;
     ab.group_mask = absorb_groups ? c->rs_gmask : nullptr;
+    ab.calib = (c->calib_on || c->calib_motion) ? c->calib : nullptr; ab.cl = c->cl;
     StageTimer st(c, ST_OTHER, 0.0, "absorb_error_kernel");
     HIP_TRY((hipError_t)launch_absorb_error(ab, c->stream));
   }
   rc = xivo_hip_jacobians_instate(c, B);                                   // :348 at the updated state
   if (rc) return rc;
-  {
+  if (!cal) {
     StageTimer st(c, ST_OTHER, 0.0, "ransac_rescue_kernel");
     HIP_TRY((hipError_t)launch_ransac_rescue(a, c->stream));
+  } else {
+    // S = J P J^T + R of every MH inlier on its WHOLE row at the updated state against the partially updated P (:350-356):
+    // the rows stacked once more in full (scratch: xivo_hip_stack re-stacks the final inlier set), H P, the dense-row distances
+    c->dense_valid = true; c->dense_from_ell = false; c->h_clean = false;
+    rc = stack_impl(c, B, R, 1, nullptr, /*full_rows=*/1);
+    if (rc) return rc;
+    rc = ensure_HT(c);
+    if (rc) return rc;
+    const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax;
+    {
+      GemmExtra x; x.C2 = c->PHT; x.sC2 = c->sK; x.ldc2 = Np;
+      rc = gemm(c, ST_HP, B, Mp, Np, c->H, c->sH, ldh, c->P, c->sP, Np, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, c->HP, c->sH, ldh, x);
+      if (rc) return rc;
+    }
+    GateDenseArgs ga{};
+    ga.H = c->H; ga.strideH = c->sH; ga.ldh = ldh; ga.HP = c->HP; ga.strideHP = c->sH; ga.ldhp = ldh;
+    ga.Hw = c->H; ga.HTw = c->HT; ga.strideHT = c->sHT; ga.ldht = Np; ga.HPw = nullptr; ga.PHTw = nullptr; ga.PHTr = c->PHT;
+    ga.inn = c->inn; ga.strideInn = c->Mpmax; ga.diagR = c->diagR; ga.strideR = c->Mpmax;
+    // (scratch outputs: the mask goes to rs_low - dead once the partial update is stacked -, the distances to rs_chi, where the
+    //  decision kernel below reads them and leaves chi2 per tested feature; c->dist keeps the MH distances)
+    ga.mask = c->rs_low; ga.dist = c->rs_chi; ga.F = c->F; ga.Np = Np; ga.batch = B; ga.mask_ld = c->Fmax;
+    ga.R = R; ga.thresh = ransac_chi2; ga.mult = 1.0; ga.min_inliers = -1; ga.no_relax = 1;
+    ga.ell = c->ell; ga.have_ell = 0; ga.feats = c->feats; ga.Fmax = c->Fmax;
+    {
+      StageTimer st(c, ST_GATE, 0.0, "gate_dense_kernel");
+      HIP_TRY((hipError_t)launch_gate_dense(ga, c->stream));
+    }
+    StageTimer st(c, ST_OTHER, 0.0, "ransac_rescue_dist_kernel");
+    HIP_TRY((hipError_t)launch_ransac_rescue_dist(a, c->rs_chi, c->Fmax, c->stream));
   }
   // RestoreState + Jacobians at the original state (:383-387)
   HIP_TRY(hipMemcpyAsync(c->P, c->Prs, (size_t)B * c->sP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->poses, c->poses_rs, (size_t)B * sizeof(xivo_pose_in), hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->groups, c->groups_rs, (size_t)B * ng * sizeof(xivo_group_in), hipMemcpyDeviceToDevice, c->stream));
+  if (cal) HIP_TRY(hipMemcpyAsync(c->calib, c->calib_rs, (size_t)B * sizeof(xivo_calib_in), hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->mask, c->rs_keep, (size_t)B * c->Fmax, hipMemcpyDeviceToDevice, c->stream));
   rc = xivo_hip_jacobians_instate(c, B);
   if (rc) return rc;

@@ -64,6 +64,7 @@ struct GateDenseArgs {
   EllBuffers ell; int have_ell;                 // also zero the rejected pairs of the compressed form (ell.h)
   int mask_ld;                                  // 0: rows of mask / dist are F entries apart
   const xivo_feat_in* feats; int Fmax;          // optional [batch x Fmax]: entries with sind < 0 are absent (ragged batches)
+  int no_relax;                                 // 1: inlier <=> distance < thresh, no relaxation loop (min_inliers = -1: every filter tested)
 };
 int launch_gate_dense(const GateDenseArgs& a, hipStream_t s);
 
@@ -157,6 +158,7 @@ struct RansacArgs {
 int launch_ransac_select(const RansacArgs& a, hipStream_t s);
 int launch_ransac_zero(const RansacArgs& a, double* P, hipStream_t s);
 int launch_ransac_rescue(const RansacArgs& a, hipStream_t s);
+int launch_ransac_rescue_dist(const RansacArgs& a, const double* dist /* [batch x ld] */, int ld, hipStream_t s);
 
 // batched resident edits (xivo_hip_edit_batch): wg_filter[w] = filter of workgroup w, its ops are
 // ops[wg_begin[w] .. wg_begin[w + 1])

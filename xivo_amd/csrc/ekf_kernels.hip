@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void gate_dense_kernel(GateDenseArgs a) {
   __syncthreads();
   if (wave == 0) {
     // (not gating: present entries carry 0, absent ones +inf - any positive threshold keeps exactly the present ones)
-    const double th = gating ? relax_threshold(sdist, a.F, a.thresh, a.mult, a.min_inliers, lane, present) : 1.0;
+    // (no_relax: a plain chi-square test against thresh - the rescue pass of OnePointRANSAC, update.cpp:352-356)
+    const double th = gating ? (a.no_relax ? a.thresh : relax_threshold(sdist, a.F, a.thresh, a.mult, a.min_inliers, lane, present)) : 1.0;
     if (lane == 0) sdist[a.F] = th;
   }
   __syncthreads();
@@ -2816,6 +2817,31 @@ __global__ __launch_bounds__(256) void ransac_rescue_kernel(RansacArgs a) {
   if (tid == 0) a.n_rejected[filt] = s_rej;
 }
 
+// the same decision from distances that are already formed (online-calibration builds: the whole-row distances of the
+// dense-row gate - J() carries the td / Cg / bg / intrinsics blocks there, which the compact 21-column form does not hold)
+__global__ __launch_bounds__(256) void ransac_rescue_dist_kernel(RansacArgs a, const double* dist, int ld) {
+  const int filt = blockIdx.x, tid = threadIdx.x;
+  const SceneBuffers& sb = a.sb;
+  const int state = a.state[filt];
+  __shared__ int s_rej;
+  if (tid == 0) s_rej = 0;
+  __syncthreads();
+  for (int f = tid; f < sb.F; f += 256) {
+    const long e = (long)filt * sb.Fmax + f;
+    const bool mh = sb.mask[e] && sb.feats[e].sind >= 0;
+    double d = 0.0;
+    bool keep = mh;
+    if (mh && state != 0 && !a.low_keep[e]) {
+      d = dist[(long)filt * ld + f];
+      keep = d < a.chi2;
+      if (!keep) atomicAdd(&s_rej, 1);
+    }
+    a.keep[e] = keep ? 1 : 0; a.chi[e] = d;
+  }
+  __syncthreads();
+  if (tid == 0) a.n_rejected[filt] = s_rej;
+}
+
 // ---------------------------------------------------------------- fp64 MFMA issue-rate probe
 // Every wave issues `iters` x 8 independent v_mfma_f64_16x16x4_f64; wave 0 of
 // block 0 also reports the shader-clock cycles it spent (s_memtime), so the
@@ -2958,6 +2984,10 @@ int launch_ransac_select(const RansacArgs& a, hipStream_t s) {
 }
 int launch_ransac_zero(const RansacArgs& a, double* P, hipStream_t s) {
   hipLaunchKernelGGL(ransac_zero_kernel, dim3(a.batch), dim3(256), 0, s, a, P);
+  CHECK_LAUNCH();
+}
+int launch_ransac_rescue_dist(const RansacArgs& a, const double* dist, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(ransac_rescue_dist_kernel, dim3(a.batch), dim3(256), 0, s, a, dist, ld);
   CHECK_LAUNCH();
 }
 int launch_ransac_rescue(const RansacArgs& a, hipStream_t s) {
