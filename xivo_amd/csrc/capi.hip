@@ -824,6 +824,9 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     t_done = t_here;
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : (wh_out ? 5 : 0)), lat);
     if (fuse_chol) { a.chol_status = c->status + b0; trsm_chol_fused_label(Mp, label, sizeof(label)); }
+    // short factor on a narrow state (BASELINE config 2): ten-wave workgroups, two per CU (solve_fused.hip)
+    const bool narrow = !fuse_chol && all_here && jform == 2 && trsm_narrow_supported(Mp, Np);
+    if (narrow) trsm_narrow_label(Mp, label, sizeof(label));
     const double t_outs = 0.5 * Np * (Np + 1.0), t_outs_f = 0.5 * Nf * (Nf + 1.0);
     // algorithmic flops (true N, M): the two triangular solves (M^2 N each), the symmetric N x N x M product (lower
     // triangle), and for the expanded form the two triangular products of K L L^T; the whitened form's residual blocks
@@ -833,7 +836,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
                                (all_here ? (jform == 2 ? 32.0 * Mf * Nf : 2.0 * Mf * Mf * Nf) : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + (fuse_chol ? 0.0 : Mp / 16 * 512.0) + (all_here && jform == 2 ? 1.0 : 2.0) * Np * Mp +
                              (t_here ? t_outs + (double)Np * Np : 0.0)));
-    HIP_TRY((hipError_t)(fuse_chol ? launch_trsm_chol_fused(a, c->stream) : launch_trsm_f64(a, c->stream)));
+    HIP_TRY((hipError_t)(fuse_chol ? launch_trsm_chol_fused(a, c->stream) : (narrow ? launch_trsm_narrow(a, c->stream) : launch_trsm_f64(a, c->stream))));
     if (all_here) return XIVO_HIP_OK;
   }
   if (wh_out) {   // P+ = P - V^T Y in place (V^T in the K buffer, Y^T in the G buffer), lower triangle + mirror

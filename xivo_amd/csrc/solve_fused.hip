@@ -25,7 +25,45 @@ int launch_fused_t(const TrsmArgs& g_in, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// Short factors on narrow states: NWV-wave workgroups, MINB of them per CU (trsm_lds_kernel.h)
+// (MINB = waves per SIMD the register budget is cut for - HIP's second __launch_bounds__ argument; WGS = workgroups per CU
+//  that makes: 4 MINB / NWV)
+template <int NBM, int NWV, int MINB>
+int launch_narrow_t(const TrsmArgs& g_in, hipStream_t stream) {
+  TrsmArgs g = g_in;
+  const int nb = g.Mp / 16;
+  const int grid = ((g.batch + 7) / 8) * 8;
+  constexpr int WGS = 4 * MINB / NWV;
+  // LDS per workgroup: the factor (diagonal blocks in slots of their own) or the two operand buffers of the product
+  // phase, whichever is larger - within the CU's 160 KiB / WGS
+  const size_t cap = (size_t)(160 * 1024 / WGS) & ~(size_t)1023;
+  const size_t factor = ((size_t)nb * (nb + 1) / 2 + nb) * 16 * 17 * sizeof(double) + 64;
+  g.t_jbp = (int)(cap / 2 / ((size_t)nb * 4 * 64 * sizeof(double)));
+  if (g.t_jbp > 16) g.t_jbp = 16;
+  if (g.t_jbp < 1 || factor > cap) return (int)hipErrorInvalidValue;
+  const size_t prod = (size_t)2 * g.t_jbp * nb * 4 * 64 * sizeof(double);
+  const size_t lds = factor > prod ? factor : prod;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_lds_f64_kernel<NBM, 4, false, NWV, MINB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((trsm_lds_f64_kernel<NBM, 4, false, NWV, MINB>), dim3(grid), dim3(64 * NWV), lds, stream, g);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
+
+// shapes the narrow instantiations hold: every column of the state in one NWV-wave workgroup
+bool trsm_narrow_supported(int Mp, int Np) {
+  static const bool off = getenv("XIVO_HIP_NO_NARROW_SOLVE") != nullptr;   // A/B knob: the sixteen-wave kernel for every shape
+  return !off && Np <= 160 && Np % 16 == 0 && Mp / 16 == 7;
+}
+int launch_trsm_narrow(const TrsmArgs& g, hipStream_t stream) {
+  if (g.batch <= 0) return 0;
+  return launch_narrow_t<7, 10, 5>(g, stream);
+}
+void trsm_narrow_label(int Mp, char* buf, size_t n) { snprintf(buf, n, "trsm_lds_f64_kernel<7,4,false,10,5>"); }
 
 // shapes the fused kernel holds: the whole state in one 16-wave workgroup, a factor of at most ten block rows
 // OPT-IN (XIVO_HIP_FUSED_CHOL=1), measured and not adopted: per 16384 filters at (250, 160) the solve grows from 9.6 to 12.2 ms

@@ -66,7 +66,7 @@ __device__ __forceinline__ void buf_st(double v, __amdgpu_buffer_rsrc_t r, unsig
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, 0);
 }
 
-template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false, bool FIXUP = false, bool YREGS = false>
+template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false, bool FIXUP = false, bool YREGS = false, int NWV = 16>
 __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4 (&Wr)[NBM], double* sL, const double* __restrict__ Src, int ldsrc,
                                                     const double* __restrict__ Minit, int ldm, double* __restrict__ Out, int ldo,
                                                     int nb, int nwl, int jbp, bool live, int w, int wave, int lane) {
@@ -92,7 +92,7 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
       }
       return;
     }
-    for (int q = wave; q < (XIVO_ABL == 8 ? 0 : nj * 2 * nb); q += 16) {
+    for (int q = wave; q < (XIVO_ABL == 8 ? 0 : nj * 2 * nb); q += NWV) {
       const int jl = q / (2 * nb), t = q - jl * 2 * nb;
       const double* src = Src + (16 * (jb0 + jl) + 2 * (lane & 7)) + (long)(8 * t + (lane >> 3)) * ldsrc;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -217,9 +217,15 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
 // Same routines and the same operand order as chol_reg_f64_kernel / chol_f64_kernel: the SAME bits, so everything
 // behind it is unchanged - but L and inv(L_kk) never travel to HBM and back (2.5 GB written + 2.4 GB read per 16384 filters)
 // and the stand-alone Cholesky launch (1.7 ms) is gone. g.chol_status receives the factorisation status.
-template <int NBM, int TF, bool CHOL = false>
-__global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
+// NWV / MINB (round 5): waves per workgroup and workgroups per CU the register budget is cut for. 16 / 1 is the kernel of
+// rounds 1-4 (one workgroup owns the CU). A state of at most 16 NWV columns with a short factor leaves room for MORE THAN ONE
+// workgroup per CU (BASELINE config 2: N = 150 -> ten waves, seven block rows: 76 KB of LDS, 96 VGPRs): the memory phases
+// of one filter (right-hand sides in, covariance tiles in and out) then run under the matrix phases of another - the
+// overlap a single workgroup cannot have, because one filter's working set fills the CU at the metric point.
+template <int NBM, int TF, bool CHOL = false, int NWV = 16, int MINB = 1>
+__global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr int BLK = 16 * 17;
+  constexpr int NT = 64 * NWV;
   static_assert(!CHOL || (TF == 4 && NBM <= 10), "in-kernel factorisation: whitened form, diagonal blocks in slots of their own");
   // TF == 3 needs the diagonal blocks L_kk next to their inverses: in slots of their own while the LDS has room (<= 10
   // block rows), else packed into the unused upper triangle + pad row of the inverse's slot (a few selects per read)
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr bool KEEPW = T4 && NBM <= 6;
   constexpr bool PACK = (TF == 3 || T4) && NBM > 10;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
-  const int chunks = (g.Np + 255) / 256;
+  const int chunks = (g.Np + 16 * NWV - 1) / (16 * NWV);
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
   const int filt = (slot / chunks) * 8 + xcd;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   XTR(0);
   // the right-hand sides first: their loads are in flight while the factor is copied (one workgroup per CU - nothing else
   // would hide the latency of either)
-  const int c0 = chunk * 256 + wave * 16;
+  const int c0 = chunk * 16 * NWV + wave * 16;
   const bool live = c0 < g.Np;
   const __amdgpu_buffer_rsrc_t rPHT = buf_rsrc(PHT), rK = buf_rsrc(g.K + (long)filt * g.strideK),
                                rInn = buf_rsrc(g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn);
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
   // on a CU that has nothing else to run meanwhile. (All of them at once would spill: the right-hand sides are in flight.)
   const int nblk = nb * (nb + 1) / 2;
   constexpr bool DIAG = !PACK && (TF == 3 || T4);                    // the diagonal blocks L_kk in slots of their own
-  constexpr int CPY = (NBM * (NBM + 1) / 2 * 128 + 1023) / 1024;     // d2 loads per thread: factor ...
-  constexpr int CPD = DIAG ? (NBM * 128 + 1023) / 1024 : 0;         // ... + diagonal blocks
+  constexpr int CPY = (NBM * (NBM + 1) / 2 * 128 + NT - 1) / NT;     // d2 loads per thread: factor ...
+  constexpr int CPD = DIAG ? (NBM * 128 + NT - 1) / NT : 0;         // ... + diagonal blocks
   constexpr int CPB = CHOL ? CPY + CPD : 4;                           // loads in flight per thread (CHOL: all of S at once - no right-hand sides in the registers yet)
   double* sD = sL + nblk * BLK;                                       // (upper triangle zeroed)
 #pragma unroll
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
       const int u = u0 + q;
       cv[q] = d2{0.0, 0.0}; cu[q] = d2{0.0, 0.0};
       if (u < CPY) {
-        const int e = tid + 1024 * u;
+        const int e = tid + NT * u;
         if (e < nblk * 128) {
           const int t = e >> 7, w = e & 127;
           int i = 0;
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
           if (PACK && i == k) { cu[q][0] = LU[(16 * k + c) + (long)(16 * k + r) * ld]; cu[q][1] = LU[(16 * k + c) + (long)(16 * k + r + 1) * ld]; }
         }
       } else if (u < CPY + CPD) {
-        const int e = tid + 1024 * (u - CPY);
+        const int e = tid + NT * (u - CPY);
         if (e < nb * 128) {
           const int k = e >> 7, w = e & 127;
           cv[q] = *reinterpret_cast<const d2*>(LU + (16 * k + (w & 7) * 2) + (long)(16 * k + (w >> 3)) * ld);
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     for (int q = 0; q < CPB; ++q) {
       const int u = u0 + q;
       if (u < CPY) {
-        const int e = tid + 1024 * u;
+        const int e = tid + NT * u;
         if (e < nblk * 128) {
           const int t = e >> 7, w = e & 127;
           int i = 0;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
           sL[t * BLK + r + 1 + 17 * c] = v[1];
         }
       } else if (u < CPY + CPD) {
-        const int e = tid + 1024 * (u - CPY);
+        const int e = tid + NT * (u - CPY);
         if (e < nb * 128) {
           const int k = e >> 7, w = e & 127;
           const int r = (w & 7) * 2, c = w >> 3;
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
   }
   if (PACK) {
-    for (int e = tid; e < nb * 16; e += 1024) {
+    for (int e = tid; e < nb * 16; e += NT) {
       const int k = e >> 4, c = e & 15;
       sL[(k * (k + 1) / 2 + k) * BLK + 16 + 17 * c] = LU[(16 * k + c) + (long)(16 * k + c) * ld];
     }
@@ -653,7 +659,7 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     // ---- P+ = P - Z^T K^T in place: rows of Z^T in registers, blocks of the gain just written arrive through LDS
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
     double* Pio = g.T + (long)filt * g.strideT;
-    sym_tiles_from_regs<NBM, false, true>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+    sym_tiles_from_regs<NBM, false, true, false, false, NWV>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
                                           live, c0 >> 4, wave, lane);
     return;
   }
@@ -674,9 +680,9 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     if (CHOL ? chol_bad != 0 : (g.skip_status && g.skip_status[filt] != 0)) return;   // S not positive definite: P stays the prior
     if (XIVO_ABL == 1) return;
     double* Pio = g.T + (long)filt * g.strideT;
-    if constexpr (KEEPW) sym_tiles_from_regs<NBM, true, true, false, true>(X, Wk, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+    if constexpr (KEEPW) sym_tiles_from_regs<NBM, true, true, false, true, NWV>(X, Wk, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
                                                                  live, c0 >> 4, wave, lane);
-    else sym_tiles_from_regs<NBM, false, true, true>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
+    else sym_tiles_from_regs<NBM, false, true, true, false, NWV>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
                                                      live, c0 >> 4, wave, lane);
     return;
   }
@@ -684,11 +690,11 @@ __global__ __launch_bounds__(1024) void trsm_lds_f64_kernel(TrsmArgs g) {
     // ---- symmetric form: P+ = P - W^T W in place, W^T = the forward-substituted columns still in registers
     if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
     double* Pio = g.T + (long)filt * g.strideT;
-    sym_tiles_from_regs<NBM, true, true>(X, X, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
+    sym_tiles_from_regs<NBM, true, true, false, false, NWV>(X, X, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
     return;
   }
   // ---- T = K (HP) - P
-  sym_tiles_from_regs<NBM>(X, X, sL, PHT, g.ldpht, g.Pm + (long)filt * g.stridePm, g.ldpm, g.T + (long)filt * g.strideT, g.ldt,
+  sym_tiles_from_regs<NBM, false, false, false, false, NWV>(X, X, sL, PHT, g.ldpht, g.Pm + (long)filt * g.stridePm, g.ldpm, g.T + (long)filt * g.strideT, g.ldt,
                            nb, g.Np / 16, g.t_jbp, live, c0 >> 4, wave, lane);
 }
 
