@@ -198,7 +198,7 @@ def test_one_point_ransac_of_a_calibration_build(built, name):
         H, inn, dR = orc.stack_measurements(Js[kept], inns[kept], sc["ref"][b][kept], sc["sind"][b][kept], lay, R1)
         e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
-    assert seen["partial"] >= 3 and seen["prior"] >= 1 and seen["rejected"] >= 3, seen
+    assert seen["partial"] >= 3 and seen["prior"] >= 1 and seen["rejected"] >= 1 and seen["rescued"] >= 3, seen
 
 
 # ---- motion side ---------------------------------------------------------------------------------------------------------

@@ -621,13 +621,13 @@ def test_cholesky_kernels_are_bit_identical(built):
     nodes, ranks, runs and batch sizes. Round 5: so does the factorisation INSIDE the solve kernel (opt-in, XIVO_HIP_FUSED_CHOL:
     measured slower than the stand-alone kernels): block row i on wave i, the factor in LDS, half of the right-hand sides joining
     the forward substitution late - the same bits. And the ten-wave, two-per-CU
-    instantiation of the solve that (150, 100) takes (XIVO_HIP_NO_NARROW_SOLVE: the sixteen-wave kernel instead)."""
+    instantiation of the solve for (150, 100) (opt-in, XIVO_HIP_NARROW_SOLVE: measured slower - that shape is HBM-bound)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     knobs = ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG", "XIVO_HIP_CHOL_LOOKAHEAD", "XIVO_HIP_CHOL_NO_LOOKAHEAD",
-             "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE", "XIVO_HIP_CHOL_NO_REG8", "XIVO_HIP_FUSED_CHOL", "XIVO_HIP_NO_NARROW_SOLVE")
+             "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE", "XIVO_HIP_CHOL_NO_REG8", "XIVO_HIP_FUSED_CHOL", "XIVO_HIP_NARROW_SOLVE")
     res = []
-    for knob in (("XIVO_HIP_CHOL_WAVE",), (), ("XIVO_HIP_FUSED_CHOL",), ("XIVO_HIP_NO_NARROW_SOLVE",), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
+    for knob in (("XIVO_HIP_CHOL_WAVE",), (), ("XIVO_HIP_FUSED_CHOL",), ("XIVO_HIP_NARROW_SOLVE",), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
                  ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS"), ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_NO_LOOKAHEAD"),
                  ("XIVO_HIP_AUTOTUNE",), ("XIVO_HIP_CHOL_NO_REG8",)):
         env = dict(os.environ)

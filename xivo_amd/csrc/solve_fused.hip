@@ -54,10 +54,14 @@ int launch_narrow_t(const TrsmArgs& g_in, hipStream_t stream) {
 
 }  // namespace
 
-// shapes the narrow instantiations hold: every column of the state in one NWV-wave workgroup
+// shapes the narrow instantiations hold: every column of the state in one NWV-wave workgroup.
+// OPT-IN (XIVO_HIP_NARROW_SOLVE=1), measured and not adopted: at BASELINE config 2 (N = 150, M = 100; 16384 filters) two
+// ten-wave workgroups per CU take 4.32 ms where the sixteen-wave kernel (ten live waves, one workgroup per CU) takes 4.06 -
+// that shape is bound by HBM (about 1 MB per filter at 4 TB/s), not by the phases of a filter failing to overlap, and the
+// 80 KB of LDS per workgroup cut the product phase to two column blocks per pass. Same bits (tests/test_update_gpu.py).
 bool trsm_narrow_supported(int Mp, int Np) {
-  static const bool off = getenv("XIVO_HIP_NO_NARROW_SOLVE") != nullptr;   // A/B knob: the sixteen-wave kernel for every shape
-  return !off && Np <= 160 && Np % 16 == 0 && Mp / 16 == 7;
+  static const bool on = getenv("XIVO_HIP_NARROW_SOLVE") != nullptr;
+  return on && Np <= 160 && Np % 16 == 0 && Mp / 16 == 7;
 }
 int launch_trsm_narrow(const TrsmArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
