@@ -777,3 +777,46 @@ def test_long_chain_of_default_form_updates_stays_psd_and_close(built, N, F, ste
                     w = np.linalg.eigvalsh(Pn[b])
                     assert w.min() > -1e-12 * w.max(), (it, w.min(), w.max())
                     assert rel_fro(Pn[b], Pref[b]) < TOL_P, (it, rel_fro(Pn[b], Pref[b]))
+
+
+_GATE_SNIPPET = r"""
+import sys, json, hashlib
+sys.path.insert(0, {root!r})
+import numpy as np
+from xivo_amd import synth
+from xivo_amd.lib import Context
+out = {{}}
+for (N, F) in [(250, 80), (150, 50), (203, 30)]:
+    B = 600                                   # >= 512: the factorisation that carries the gate
+    P, H, inn, dR = synth.s_level(N, F, 8, seed=77)
+    inn[:, 4:8] *= 6.0; inn[3, 20:30] *= 9.0      # features the gate throws out (one filter with many: threshold relaxation)
+    idx = np.arange(B) % 8
+    with Context(N, 2 * F, B) as ctx:
+        ctx.upload_P(P[idx]); ctx.set_measurements(H[idx], inn[idx], dR[idx])
+        ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5, B)
+        Pn = ctx.download_P(); err = ctx.get_err(); mask, dist = ctx.get_gate(F, B)
+        st = ctx.get_status(check=False)
+    out["%d,%d" % (N, F)] = [hashlib.sha256(a.tobytes()).hexdigest() for a in (Pn, err, mask, dist, st)] + [int(mask.sum()), int(mask.size)]
+print(json.dumps(out))
+"""
+
+
+def test_gate_in_the_factorisation_prologue_is_bit_identical_to_the_gate_kernel(built):
+    """Round 5: for thousands of filters Estimator::MHGating (src/update.cpp:60-96) rides in the prologue of the Cholesky kernel
+    (chol_reg_f64_kernel<..., GATE>: distances from the compact diagonal blocks of S, relaxation, rejected pairs decoupled
+    where S is loaded). XIVO_HIP_NO_GATE_IN_CHOL brings gate_ell_kernel back as a launch of its own: masks, distances, dx and
+    P+ must be the same bits."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for knob in ((), ("XIVO_HIP_NO_GATE_IN_CHOL",)):
+        env = dict(os.environ)
+        env.pop("XIVO_HIP_NO_GATE_IN_CHOL", None)
+        for k in knob:
+            env[k] = "1"
+        r = subprocess.run([sys.executable, "-c", _GATE_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1], res
+    for k, v in res[0].items():
+        assert 0 < v[5] < v[6], (k, v)            # something was rejected, not everything

@@ -773,27 +773,42 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
               S + mr0 + (long)mr0 * lds, c->sS, lds, x);
     if (rc) return rc;
   }
-  if (gate) c->gate_sparse_last = 0;
-  if (gate && !gate_done) {
-    if (diag_done) { ga.Sdiag = c->T + (long)b0 * c->sP; ga.strideSdiag = c->sP; }
-    StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
-    HIP_TRY((hipError_t)launch_gate_ell(ga, c->stream));
-  }
   const bool lat = latency_route(c, Mp, B, full);
   const bool t_full = full || getenv("XIVO_HIP_T_FULL");
+  const int chol_variant = chol_pick(c, S, Mp, lds, B);
+  if (gate) c->gate_sparse_last = 0;
+  // Round 5: with thousands of factors the gate rides in the prologue of the factorisation (chol_f64.hip, GATE): the
+  // distances come from the compact diagonal blocks ell<S> just left, the rejected pairs are decoupled where the factor
+  // loads S - no gate launch, no extra pass over S. (Few filters, dense copies of H alive, mixed stacking: the gate kernel.)
+  CholGateArgs cg{};
+  bool gate_folded = false;
+  if (gate && !gate_done) {
+    if (diag_done) { ga.Sdiag = c->T + (long)b0 * c->sP; ga.strideSdiag = c->sP; }
+    gate_folded = diag_done && !c->dense_valid && mr0 < 0 && !lat && chol_gate_supported(Mp, B, chol_variant);
+    if (gate_folded) {
+      cg.Sdiag = ga.Sdiag; cg.strideSdiag = ga.strideSdiag; cg.inn = inn; cg.strideInn = c->Mpmax; cg.diagR = diagR; cg.strideR = c->Mpmax;
+      cg.ellval = e.val; cg.strideVal = e.stride_val(); cg.ell_w = ELL_W; cg.PHT = PHT; cg.stridePHT = c->sK; cg.ldpht = Np; cg.Np = Np;
+      cg.mask = ga.mask; cg.dist = ga.dist; cg.F = gate->F; cg.R = gate->R; cg.thresh = gate->thresh; cg.mult = gate->mult;
+      cg.min_inliers = gate->min_inliers;
+    } else {
+      StageTimer st(c, ST_GATE, 0.0, "gate_ell_kernel");
+      HIP_TRY((hipError_t)launch_gate_ell(ga, c->stream));
+    }
+  }
   // Round 5, opt-in (XIVO_HIP_FUSED_CHOL=1; measured slower, see solve_fused.hip): where the solve kernel carries the whole
   // whitened Joseph update (one 16-wave workgroup per filter) it can also factor S itself - in LDS, under the latency of its
   // right-hand-side loads (chol_device.h routines, the same bits as the stand-alone kernels): no Cholesky launch, L and
   // inv(L_kk) never cross HBM.
   static const bool no_joseph_k = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
   const bool fuse_chol = !(c->flags & (XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_EXPANDED_JOSEPH)) &&
-                         !t_full && !lat && trsm_forms_T(Mp, Np) && !no_joseph_k && mr0 < 0 && trsm_chol_fused_supported(Mp, Np);
+                         !t_full && !lat && trsm_forms_T(Mp, Np) && !no_joseph_k && mr0 < 0 && !gate_folded && trsm_chol_fused_supported(Mp, Np);
   if (!fuse_chol) {
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B); a.latency = lat;
+    a.status = c->status + b0; a.batch = B; a.variant = chol_variant; a.latency = lat;
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
+    if (gate_folded) { const size_t n = strlen(clabel); snprintf(clabel + n, sizeof(clabel) - n, "+gate"); }
     StageTimer st(c, ST_CHOL, Mf * Mf * Mf / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
-    HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
+    HIP_TRY((hipError_t)launch_chol_f64(a, c->stream, gate_folded ? &cg : nullptr));
   }
   if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
   bool t_done = false, wh_out = false, wh_f32 = false;

@@ -14,6 +14,7 @@
 
 #include "mfma_util.h"
 #include "chol_device.h"
+#include "gate_device.h"
 
 namespace xivo_hip {
 
@@ -129,8 +130,14 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
 // MINB = workgroups per CU the register budget is cut for: 3 (168 VGPRs, a few spills) is faster for thousands of
 // factors (0.67 vs 0.75 ms / 4096 at M = 160), 2 (212 VGPRs) for a single one (76 vs 82 us)
 
-template <int NB, int MINB, bool PRE, bool UPFRONT, int NW = 4>
-__global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror) {
+// GATE (round 5): Estimator::MHGating (src/update.cpp:60-96) in the prologue of the factorisation - the chi-square distances
+// from the 2 x 2 diagonal blocks of S (the compact copy ell<S> leaves), the relaxation loop, the mask; the rows / columns of
+// the rejected pairs are then decoupled WHERE S IS LOADED (0, unit diagonal - what gate_ell_kernel writes into S), their
+// inn / diagR / compressed values / P H^T columns neutralised from here. One launch and one pass over S fewer per update;
+// with three factors in flight per CU the gate's two dependent round trips hide behind the other workgroups. Same values as
+// gate_ell_kernel bit for bit (same expressions), so the factor and everything behind it are unchanged.
+template <int NB, int MINB, bool PRE, bool UPFRONT, int NW = 4, bool GATE = false>
+__global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g, int mirror, CholGateArgs gt) {
   constexpr int RW = (NB + NW - 1) / NW;   // NW waves per factor: 4 (M <= 192), 8 (M <= 320: one workgroup per CU)
   const int filt = blockIdx.x;
   if (filt >= g.batch) return;
@@ -145,6 +152,53 @@ __global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g,
   __shared__ __attribute__((aligned(16))) double sRow[(NB - 1) * 256];   // [k][lane][4]
   __shared__ int sBad;
   if (tid == 0) sBad = 0;
+  __shared__ unsigned char sRej[GATE ? 16 * NB : 1];    // 1: the row belongs to a rejected feature
+  if constexpr (GATE) {
+    static_assert(NW == 4 && !UPFRONT, "the gate rides in the many-factors instantiations");
+    double* sdist = sRow;                                // F <= 8 NB distances + the threshold: scratch until the first panel is published
+    const int F = gt.F;
+    double* inn = gt.inn + (long)filt * gt.strideInn;
+    double* dr = gt.diagR + (long)filt * gt.strideR;
+    const double* sd = gt.Sdiag + (long)filt * gt.strideSdiag;
+    for (int f = tid; f < F; f += 64 * NW) {             // (gate_ell_body, from_S with the compact diagonal blocks)
+      const double s00 = sd[4 * f] - dr[2 * f] + gt.R;
+      const double s10 = sd[4 * f + 2];
+      const double s11 = sd[4 * f + 3] - dr[2 * f + 1] + gt.R;
+      sdist[f] = mh_dist_2x2(s00, s10, s11, inn[2 * f], inn[2 * f + 1]);
+    }
+    for (int m = tid; m < 16 * NB; m += 64 * NW) sRej[m] = 0;
+    __syncthreads();
+    if (wave == 0) {
+      const double th = relax_threshold(sdist, F, gt.thresh, gt.mult, gt.min_inliers, lane);
+      if (lane == 0) sdist[F] = th;
+    }
+    __syncthreads();
+    const double th = sdist[F];
+    for (int f = tid; f < F; f += 64 * NW) {
+      const bool in = sdist[f] < th;
+      gt.mask[(long)filt * F + f] = in ? 1 : 0;
+      gt.dist[(long)filt * F + f] = sdist[f];
+      if (!in) {
+        sRej[2 * f] = 1; sRej[2 * f + 1] = 1;
+        inn[2 * f] = 0.0; inn[2 * f + 1] = 0.0;
+        dr[2 * f] = 1.0; dr[2 * f + 1] = 1.0;
+        double* val = gt.ellval + (long)filt * gt.strideVal + (long)f * gt.ell_w * 2;
+        for (int t = 0; t < 2 * gt.ell_w; ++t) val[t] = 0.0;
+      }
+    }
+    __syncthreads();
+    double* PHT = gt.PHT + (long)filt * gt.stridePHT;    // the solve's right-hand sides: columns of the rejected pairs
+    for (int f = 0; f < F; ++f) {
+      if (!sRej[2 * f]) continue;
+      for (int n = tid; n < gt.Np; n += 64 * NW) { PHT[n + (long)(2 * f) * gt.ldpht] = 0.0; PHT[n + (long)(2 * f + 1) * gt.ldpht] = 0.0; }
+    }
+    __syncthreads();                                      // sRow is scratch no longer
+  }
+  // element (row, col) of S as the gate leaves it: rows / columns of rejected pairs decoupled (gate_ell_body's in-place edit)
+  auto gated = [&](double v, int row, int col) -> double {
+    if constexpr (GATE) return (sRej[row] | sRej[col]) ? (row == col ? 1.0 : 0.0) : v;
+    else return v;
+  };
 
   d4 L[RW][NB];   // L[ii][k] = block (i = wave + 4 ii, k); only k < i is ever touched
   // the diagonal blocks this wave will factor, fetched up front (their latency would otherwise sit in
@@ -155,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g,
     const int jd = wave + NW * ii;
     if (NW == 4 && jd < nb) {   // (eight waves, up to 19 block rows: no registers to spare - requested per block column below)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sdiag[ii][r] = S[(16 * jd + li) + (long)(16 * jd + lg + 4 * r) * ld];
+      for (int r = 0; r < 4; ++r) sdiag[ii][r] = gated(S[(16 * jd + li) + (long)(16 * jd + lg + 4 * r) * ld], 16 * jd + li, 16 * jd + lg + 4 * r);
     }
   }
 
@@ -188,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g,
       const int i = wave + NW * ii;
       if (!UPFRONT && NW * ii + NW - 1 > j && i > j && i < nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sreg[ii][r] = S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld];
+        for (int r = 0; r < 4; ++r) sreg[ii][r] = gated(S[(16 * i + li) + (long)(16 * j + lg + 4 * r) * ld], 16 * i + li, 16 * j + lg + 4 * r);
       }
     }
     // diagonal block in the 64-lane layout x[r] = X[row li][col lg + 4 r] - which is what the MFMA
@@ -285,8 +339,19 @@ __global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g,
 
 }  // namespace
 
-int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
+// whether launch_chol_f64 would run an instantiation that carries the gate for this factor size / batch
+bool chol_gate_supported(int Mp, int batch, int variant) {
+  static const bool off = getenv("XIVO_HIP_NO_GATE_IN_CHOL") != nullptr;   // A/B knob: gate_ell_kernel as a launch of its own
+  const int nb = Mp / 16;
+  const bool plain_reg = !getenv("XIVO_HIP_CHOL_WAVE") && !getenv("XIVO_HIP_CHOL_MINB2") && !getenv("XIVO_HIP_CHOL_LOOKAHEAD") &&
+                         !getenv("XIVO_HIP_CHOL_MINB4");
+  return !off && plain_reg && nb <= 12 && batch >= 512 && variant != 1;
+}
+
+int launch_chol_f64(const CholArgs& g, hipStream_t stream, const CholGateArgs* gate) {
   if (g.batch <= 0) return 0;
+  const CholGateArgs nogate{};
+  if (gate && !chol_gate_supported(g.Mp, g.batch, g.variant)) return (int)hipErrorInvalidValue;
   static const bool old_kernel = getenv("XIVO_HIP_CHOL_WAVE") != nullptr;   // A/B knob: one wave per filter
   const int nb = g.Mp / 16;
   // Round 3 (factor_invert_diag on the matrix pipe): the register kernel is ~11 500 instructions at ten block rows (it
@@ -315,9 +380,10 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
     const int mode = (no_pre || (many && !force_pre)) ? 0 : ((lazy || many) ? 1 : 2);
 #define CHOL_REG_LAUNCH(NB_, MINB_)                                                                                                     \
   do {                                                                                                                                  \
-    if (mode == 0) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, false, false>), dim3(g.batch), dim3(256), 0, stream, g, mirror);   \
-    else if (mode == 1) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, true, false>), dim3(g.batch), dim3(256), 0, stream, g, mirror); \
-    else hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, true, true>), dim3(g.batch), dim3(256), 0, stream, g, mirror);             \
+    if (mode == 0 && gate) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, false, false, 4, true>), dim3(g.batch), dim3(256), 0, stream, g, mirror, *gate); \
+    else if (mode == 0) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, false, false>), dim3(g.batch), dim3(256), 0, stream, g, mirror, nogate);   \
+    else if (mode == 1) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, true, false>), dim3(g.batch), dim3(256), 0, stream, g, mirror, nogate); \
+    else hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, true, true>), dim3(g.batch), dim3(256), 0, stream, g, mirror, nogate);             \
   } while (0)
     if (nb <= 4) CHOL_REG_LAUNCH(4, 2);
     else if (nb <= 8) CHOL_REG_LAUNCH(8, 2);
@@ -337,14 +403,15 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream) {
     const int mirror = 1;
     const bool pre = g.batch < 512 && !getenv("XIVO_HIP_CHOL_NO_LOOKAHEAD");
     if (nb <= 16) {
-      if (pre) hipLaunchKernelGGL((chol_reg_f64_kernel<16, 1, true, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror);
-      else hipLaunchKernelGGL((chol_reg_f64_kernel<16, 1, false, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror);
+      if (pre) hipLaunchKernelGGL((chol_reg_f64_kernel<16, 1, true, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror, nogate);
+      else hipLaunchKernelGGL((chol_reg_f64_kernel<16, 1, false, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror, nogate);
     } else {
-      if (pre) hipLaunchKernelGGL((chol_reg_f64_kernel<19, 1, true, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror);
-      else hipLaunchKernelGGL((chol_reg_f64_kernel<19, 1, false, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror);
+      if (pre) hipLaunchKernelGGL((chol_reg_f64_kernel<19, 1, true, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror, nogate);
+      else hipLaunchKernelGGL((chol_reg_f64_kernel<19, 1, false, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror, nogate);
     }
     return (int)hipGetLastError();
   }
+  if (gate) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
   return (int)hipGetLastError();
 }

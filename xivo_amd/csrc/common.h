@@ -91,7 +91,20 @@ struct CholArgs {
   int variant;      // 0: size heuristic; 1: one wave per filter (chol_f64_kernel); 2: four waves, factor in registers
   int latency;      // the solve behind it takes the latency route (streamed kernel: reads the mirrored upper triangle)
 };
-int launch_chol_f64(const CholArgs& args, hipStream_t stream);
+// MH gating folded into the prologue of the factorisation (chol_f64.hip, GATE instantiations): what gate_ell_kernel takes,
+// minus S (the factorisation applies the decoupling of the rejected pairs where it loads S)
+struct CholGateArgs {
+  const double* Sdiag; long strideSdiag;    // compact 2 x 2 diagonal blocks of S as ell<S> leaves them, [pair][row][col]
+  double* inn; long strideInn;
+  double* diagR; long strideR;
+  double* ellval; long strideVal; int ell_w;   // compressed values of the row pairs (ell.h: [pairs][ELL_W][2])
+  double* PHT; long stridePHT; int ldpht; int Np;
+  unsigned char* mask; double* dist;        // [batch x F]
+  int F;
+  double R, thresh, mult; int min_inliers;
+};
+bool chol_gate_supported(int Mp, int batch, int variant);
+int launch_chol_f64(const CholArgs& args, hipStream_t stream, const CholGateArgs* gate = nullptr);
 void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant = 0);
 
 struct TrsmArgs {
