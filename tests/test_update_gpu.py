@@ -789,7 +789,7 @@ out = {{}}
 for (N, F) in [(250, 80), (150, 50), (203, 30)]:
     B = 600                                   # >= 512: the factorisation that carries the gate
     P, H, inn, dR = synth.s_level(N, F, 8, seed=77)
-    inn[:, 4:8] *= 6.0; inn[3, 20:30] *= 9.0      # features the gate throws out (one filter with many: threshold relaxation)
+    inn[:, 4:8] *= 400.0; inn[3, 10:2 * F - 6] *= 900.0      # features the gate throws out (filter 3: nearly all of them - threshold relaxation)
     idx = np.arange(B) % 8
     with Context(N, 2 * F, B) as ctx:
         ctx.upload_P(P[idx]); ctx.set_measurements(H[idx], inn[idx], dR[idx])
