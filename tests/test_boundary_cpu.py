@@ -42,10 +42,16 @@ def test_documented_binding_compiles_links_and_runs_against_the_reference_types(
     assert run.returncode == 0 and "calls=64 ok=1" in run.stdout, run.stdout
 
 
-def test_adapter_compiles_with_the_reference_matrix_types(tmp_path):
-    """xivo_amd/host/estimator_hip.cpp with -DXIVO_HIP_USE_EIGEN: MatX / VecX / Vec2 / Vec3 / Mat3 are common/alias.h's."""
+CALIB_DEFS = ["-DUSE_ONLINE_TEMPORAL_CALIB", "-DUSE_ONLINE_IMU_CALIB", "-DUSE_ONLINE_CAMERA_CALIB"]
+
+
+@pytest.mark.parametrize("calib", [[], CALIB_DEFS, CALIB_DEFS[:1], CALIB_DEFS[2:]])
+def test_adapter_compiles_with_the_reference_matrix_types(tmp_path, calib):
+    """xivo_amd/host/estimator_hip.cpp with -DXIVO_HIP_USE_EIGEN: MatX / VecX / Vec2 / Vec3 / Mat3 are common/alias.h's - in the
+    default build and with the reference's online-calibration defines (src/CMakeLists.txt:13-15: all three, temporal only,
+    camera only), whose GPU run is tests/test_host_adapter_gpu.py::test_online_calibration_build_of_the_cpp_adapter."""
     obj = str(tmp_path / "estimator_hip_eigen.o")
-    r = subprocess.run(["g++", "-std=c++17", "-O0", "-w", "-c", "-DXIVO_HIP_USE_EIGEN"] + DEFS + INC +
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-w", "-c", "-DXIVO_HIP_USE_EIGEN"] + calib + DEFS + INC +
                        [os.path.join(ROOT, "xivo_amd", "host", "estimator_hip.cpp"), "-o", obj],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]

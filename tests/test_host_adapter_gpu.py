@@ -208,3 +208,92 @@ def test_multi_frame_sequence_replay(built):
         assert np.abs(np.asarray(g_io[g_]["Tsb"]) - s["gT"][g_]).max() < 1e-9
     for i in range(F):
         assert np.abs(np.asarray(f_io[i]["x"]) - s["x"][i]).max() < 1e-8
+
+
+@pytest.mark.parametrize("use_ransac", [0, 1])
+def test_online_calibration_build_of_the_cpp_adapter(built, use_ransac):
+    """xivo_amd/host/estimator_hip.{h,cpp} compiled with the reference's three online-calibration defines
+    (libxivo_host_calib.so: -DUSE_ONLINE_TEMPORAL_CALIB -DUSE_ONLINE_IMU_CALIB -DUSE_ONLINE_CAMERA_CALIB): the constructor derives
+    Index::td / Cg / kCameraBegin / kMotionSize as src/core.h:40-105 numbers them and switches the context
+    (xivo_hip_set_calib); Propagate (39-dimensional motion block, device-native), ComputeInstateJacobians with the td / Cg / bg /
+    intrinsics blocks in Feature::J_, MHGating on the whole row, [OnePointRANSAC,] FilterUpdate through FillJacobianBlock with
+    those blocks, AbsorbError of td / Ca / Cg / intrinsics - the reference's UpdateStep flow, against the oracle."""
+    from xivo_amd.lib import calib_dtype, cam_intr, imu_dtype
+    lib = C.CDLL(os.path.join(ROOT, "xivo_amd", "libxivo_host_calib.so"))
+    cam = synth.RADTAN
+    ng, nf, F = 6, 16, 16
+    lay = orc.calib_layout(ng, nf, True, True, 9)
+    sc = synth.g_level(ng, nf, F, 1, seed=91, cam=cam)
+    poses, groups, feats, xp = scene_arrays(sc, cam)
+    rng = np.random.default_rng(12)
+    if use_ransac:
+        xp = xp - sc["pix_noise"] + rng.normal(size=xp.shape) * 0.3
+        xp[0, [3, 9]] += [[3.0, -2.5], [-2.8, 3.1]]; xp[0, 12] += 40.0
+    else:
+        xp[0, [3, 9]] += 60.0
+    feats["xp"] = xp
+    cal = dict(gyro=rng.normal(size=3) * 0.3, Cg=np.eye(3) + 0.01 * rng.normal(size=(3, 3)), bg=rng.normal(size=3) * 0.01,
+               Vsb=rng.normal(size=3) * 0.5, td=0.012)
+    Ca = np.triu(np.eye(3) + 0.01 * rng.normal(size=(3, 3)))
+    poses[0]["Vsb"], poses[0]["bg"], poses[0]["ba"] = cal["Vsb"], cal["bg"], rng.normal(size=3) * 0.02
+    poses[0]["Rsg"] = orc.so3_exp(np.array([0.01, -0.02, 0.0])).T.reshape(-1)
+    calib = np.zeros(1, dtype=calib_dtype)
+    calib[0]["gyro"], calib[0]["Cg"], calib[0]["td"] = cal["gyro"], cal["Cg"].T.reshape(-1), cal["td"]
+    calib[0]["Ca"], calib[0]["intr"] = Ca.T.reshape(-1), cam_intr(cam)
+    P = spd(lay.N, 7) * 1e-4
+    Pio = np.asfortranarray(P.copy())
+    err = np.zeros(lay.N); mask = np.zeros(F, dtype=np.uint8); msg = C.create_string_buffer(256); slots = np.zeros(5, dtype=np.int32)
+    clay = Layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf)
+    ccam = Cam(); ccam.model, ccam.rows, ccam.cols = cam["model"], cam["rows"], cam["cols"]
+    ccam.fx, ccam.fy, ccam.cx, ccam.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    for i, v in enumerate(cam["d"]):
+        ccam.d[i] = v
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    # one IMU sample in front of the update (visual message: slopes as handed in)
+    imu = np.zeros(1, dtype=imu_dtype)
+    imu[0]["gyro"], imu[0]["accel"] = cal["gyro"], np.array([0.2, -0.1, 9.7])
+    imu[0]["slope_gyro"], imu[0]["slope_accel"], imu[0]["dt"] = np.array([1.0, -2.0, 0.5]), np.array([0.2, 0.1, -0.3]), 0.005
+    Qi = np.asfortranarray(np.diag([1e-4] * 3 + [1e-3] * 3 + [1e-6] * 3 + [1e-5] * 3)); nm = lay.motion_size
+    Qm = np.asfortranarray(np.diag(rng.uniform(1e-9, 1e-7, nm))); gv = np.array([0.0, 0.0, -9.8])
+    R1, TH, CHI = 2.25, 2.0, 5.89
+    rc = lib.xivo_host_selftest_update_step_calib(C.byref(clay), C.byref(ccam), C.c_uint(0), F, p(poses), p(groups), p(feats), p(calib), p(Pio),
+                                                  C.c_double(R1), C.c_double(5.991), C.c_double(1.1), 5, use_ransac, C.c_double(TH),
+                                                  C.c_double(CHI), p(err), p(mask), 1, p(imu), p(Qi), p(Qm), p(gv), 0, p(slots), msg, 256)
+    assert rc == 0, msg.value
+    assert slots.tolist() == [lay.td, lay.Cg, lay.cam_begin, 9, nm] and nm == 39
+    # ---- oracle: Propagate, Jacobians at the propagated state, gating [RANSAC], update, absorb
+    X = orc.MotionState(sc["Rsb"][0], sc["Tsb"][0], cal["Vsb"], cal["bg"], np.asarray(poses[0]["ba"]).copy(), orc.so3_exp(np.array([0.01, -0.02, 0.0])))
+    Xe, Pe = orc.propagate(X, P, imu[0]["gyro"], imu[0]["accel"], imu[0]["slope_gyro"], imu[0]["slope_accel"], 0.005, Qi, Qm, gv, method="RK4",
+                           Cg=cal["Cg"], Ca=Ca, layout=lay)[:2]
+    gyro_after = imu[0]["gyro"] + imu[0]["slope_gyro"] * 0.005             # last_gyro_ advanced by the visual message (estimator.cpp:573-574)
+    cal2 = dict(gyro=gyro_after, Cg=cal["Cg"], bg=cal["bg"], Vsb=Xe.Vsb, td=cal["td"])
+    Js, inns = [], []
+    for i in range(F):
+        r = int(sc["ref"][0][i])
+        Ji, ii, _, _ = orc.compute_jacobian(sc["x"][0][i], xp[0][i], sc["gR"][0][r], sc["gT"][0][r], Xe.Rsb, Xe.Tsb, sc["Rbc"][0], sc["Tbc"][0], cam, lay,
+                                            r, int(sc["sind"][0][i]), calib=cal2)
+        Js.append(Ji); inns.append(ii)
+    Js, inns = np.array(Js), np.array(inns)
+    m, _, _ = orc.mh_gate(orc.mh_distances(Js, Pe, inns, R1), 5.991, 1.1, 5)
+    keep = m.copy()
+    if use_ransac:
+        idx = np.nonzero(m)[0]
+        st = dict(Rsb=Xe.Rsb.copy(), Tsb=Xe.Tsb.copy(), Vsb=Xe.Vsb.copy(), bg=cal["bg"].copy(), ba=np.asarray(poses[0]["ba"]).copy(), Rbc=sc["Rbc"][0].copy(),
+                  Tbc=sc["Tbc"][0].copy(), Rsg=X.Rsg.copy(), gR=sc["gR"][0].copy(), gT=sc["gT"][0].copy(), x=sc["x"][0][idx].copy(),
+                  sind=sc["sind"][0][idx], ref=sc["ref"][0][idx], td=cal["td"], Cg=cal["Cg"].copy(), Ca=Ca.copy(), cam=dict(cam, d=list(cam["d"])))
+        out = orc.one_point_ransac(st, Pe, xp[0][idx], cam, lay, R1, TH, CHI, 0, range(ng), calib_gyro=gyro_after)
+        keep = np.zeros(F, dtype=bool); keep[idx[out["inliers"]]] = True
+        assert 0 < out["low"].sum() < len(idx) and len(out["rejected"]) >= 1
+    assert np.array_equal(mask.astype(bool), keep), (mask, keep)
+    k = np.nonzero(keep)[0]
+    H, inn, dR = orc.stack_measurements(Js[k], inns[k], sc["ref"][0][k], sc["sind"][0][k], lay, R1)
+    e_ref, P_ref, _ = orc.update_joseph(H, Pe, inn, dR)
+    assert rel_fro(np.ascontiguousarray(Pio), P_ref) < TOL_P and rel_fro(err, e_ref) < TOL_DX
+    # AbsorbError: td, Ca (upper triangle, row by row), Cg (row by row), the nine RADTAN intrinsics
+    assert abs(calib[0]["td"] - (cal["td"] + e_ref[lay.td])) < 1e-12
+    Cg_new = calib[0]["Cg"].reshape(3, 3).T; Ca_new = calib[0]["Ca"].reshape(3, 3).T
+    assert np.abs(Cg_new - (cal["Cg"] + e_ref[lay.Cg:lay.Cg + 9].reshape(3, 3))).max() < 1e-12
+    dCa = np.zeros((3, 3)); dCa[np.triu_indices(3)] = e_ref[lay.Ca:lay.Ca + 6]
+    assert np.abs(Ca_new - (Ca + dCa)).max() < 1e-12
+    assert np.abs(calib[0]["intr"] - (cam_intr(cam) + e_ref[lay.cam_begin:lay.cam_begin + 9])).max() < 1e-9
+    assert np.abs(np.asarray(poses[0]["Tsb"]) - (Xe.Tsb + e_ref[3:6])).max() < 1e-9

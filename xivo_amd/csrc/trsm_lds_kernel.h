@@ -11,7 +11,8 @@
 // XIVO_ABL: timing-only ablations of trsm_lds_f64_kernel<., 4> (scripts/ablate_solve.sh builds one library per value; the
 // results are WRONG for any value but 0): 1 stop after the substitutions, 2 skip the substitutions, 3 no fix-up pass /
 // barrier, 4 no stores of P+, 5 no dx accumulation in the backward loop, 6 no stash write / read-back, 7 no loads of the P
-// tiles, 8 no operand DMA, 9 LDS-only barrier at the phase start (no vmcnt drain), 10 two row blocks per phase
+// tiles, 8 no operand DMA, 9 LDS-only barrier at the phase start (no vmcnt drain), 10 two row blocks per phase,
+// 11 = 2 + no MFMA in the product phase: the memory floor of the product's access pattern (round 5)
 #ifndef XIVO_ABL
 #define XIVO_ABL 0
 #endif
@@ -163,7 +164,9 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
       if (fetch) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])); issue(p + 1); fetch = false; }
       if (todo) load_m(jb0 + __builtin_ctz(todo), nxt);
       const double* Bop = buf + jl * nb * 256 + lane;
-      if (jb <= w) {
+      if (XIVO_ABL == 11) {   // the product phase's memory traffic alone: tile loads, operand DMA, stores - no MFMA (one LDS read per tile)
+        acc[0] += Bop[0];
+      } else if (jb <= w) {
 #pragma unroll
         for (int mb = 0; mb < NBM; ++mb) {
           if (mb < nb) {
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
   // forward: L Y = HP
 #pragma unroll
   for (int k = 0; k < NBM; ++k) {
-    if (k < nb && !(T4 && XIVO_ABL == 2)) {
+    if (k < nb && !(T4 && (XIVO_ABL == 2 || XIVO_ABL == 11))) {
       if constexpr (CHOL) {
         if (k == HX) {   // the late block rows have arrived: the terms of steps 0 .. HX - 1, in the order the steps would have added them
 #pragma unroll
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
   // backward: L^T K^T = Y
 #pragma unroll
   for (int k = NBM - 1; k >= 0; --k) {
-    if (k < nb && !g.fwd_only && !(T4 && XIVO_ABL == 2)) {
+    if (k < nb && !g.fwd_only && !(T4 && (XIVO_ABL == 2 || XIVO_ABL == 11))) {
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
       // TF == 4: W_k comes back from the stash while this step's MFMAs run (requested here, used at the end of the step;
       // the last block row has not been touched yet: it is still in X)

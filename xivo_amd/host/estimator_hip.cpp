@@ -20,6 +20,30 @@ Estimator::Estimator(const xivo_layout& layout, const xivo_cam& cam, int max_fea
     : lay_(layout), cam_(cam), flags_(flags), max_features_(max_features) {
   Check(xivo_hip_create(&ctx_, device, layout.N, 2 * max_features, 1, flags), "xivo_hip_create");
   Check(xivo_hip_set_layout(ctx_, &lay_, &cam_), "xivo_hip_set_layout");
+#if XIVO_HIP_ONLINE_CALIB
+  {  // enum Index / kMotionSize / kCameraBegin / kGroupBegin as src/core.h:40-105 numbers them under this build's defines
+    int nxt = 23;
+#ifdef USE_ONLINE_TEMPORAL_CALIB
+    cl_.td = nxt++;
+#endif
+#ifdef USE_ONLINE_IMU_CALIB
+    cl_.Cg = nxt; nxt += 15;               // Cg (9) then Ca (6)
+#endif
+    motion_ = nxt;
+    cl_.cam_begin = motion_;
+#ifdef USE_ONLINE_CAMERA_CALIB
+    cl_.cam_dim = cam.model == XIVO_CAM_PINHOLE ? 4 : (cam.model == XIVO_CAM_ATAN ? 5 : (cam.model == XIVO_CAM_RADTAN ? 9 : 8));
+    const int group_begin = motion_ + 9;   // kMaxCameraIntrinsics slots
+#else
+    const int group_begin = motion_;
+#endif
+    if (layout.group_begin != group_begin)
+      throw std::invalid_argument("Estimator: layout.group_begin does not match this build's kGroupBegin");
+    Check(xivo_hip_set_calib(ctx_, &cl_), "xivo_hip_set_calib");
+    intr_[0] = cam.fx; intr_[1] = cam.fy; intr_[2] = cam.cx; intr_[3] = cam.cy;
+    for (int k = 0; k < 5; ++k) intr_[4 + k] = cam.d[k];
+  }
+#endif
   P_.setZero(layout.N, layout.N);
   err_.setZero(layout.N);
   groups_.assign(layout.n_groups, nullptr);
@@ -43,6 +67,20 @@ void Feature::FillJacobianBlock(MatX& H, int offset) const {
   if (owner_->flags() & XIVO_HIP_FLAG_FIX_GROUP_BLOCK) copy3(goff + 3, goff + 3);
   else copy3(goff, goff + 3);                          // :676 overwrites, goff+3.. stays zero
   copy3(foff, foff);                                   // :677
+#if XIVO_HIP_ONLINE_CALIB
+  const xivo_calib_layout& cl = owner_->calib_layout();
+  auto copyn = [&](int col, int n) { for (int i = 0; i < 2; ++i) for (int j = 0; j < n; ++j) H(offset + i, col + j) = J_(i, col + j); };
+#ifdef USE_ONLINE_TEMPORAL_CALIB
+  copyn(cl.td, 1);                                     // :665
+#ifdef USE_ONLINE_IMU_CALIB
+  copyn(cl.Cg, 9);                                     // :667
+#endif
+  copyn(9, 3);                                         // Index::bg :669
+#endif
+#ifdef USE_ONLINE_CAMERA_CALIB
+  copyn(cl.cam_begin, cl.cam_dim);                     // :679-683
+#endif
+#endif
 }
 
 // uploads P_ if the device copy is not known to be current (resident flows call it after editing P_ on the host)
@@ -117,9 +155,22 @@ void Estimator::ComputeInstateJacobians() {
     fs[i].sind = f->sind_;
   }
   Check(xivo_hip_set_scene(ctx_, 0, 1, F, &pose, gs.data(), fs.data()), "set_scene");
+#if XIVO_HIP_ONLINE_CALIB
+  {  // what ComputeInstateJacobians hands down besides the poses: last_gyro_, imu_.Cg(), X_.td (src/update.cpp:27-28) + the
+     // camera's current intrinsics
+    xivo_calib_in cs{};
+    std::memcpy(cs.gyro, last_gyro_.data(), sizeof(cs.gyro)); std::memcpy(cs.Cg, Cg_.data(), sizeof(cs.Cg));
+    cs.td = td_; std::memcpy(cs.Ca, Ca_.data(), sizeof(cs.Ca)); std::memcpy(cs.intr, intr_, sizeof(cs.intr));
+    Check(xivo_hip_set_calib_state(ctx_, 0, 1, &cs), "set_calib_state");
+  }
+#endif
   Check(xivo_hip_jacobians_instate(ctx_, 1), "jacobians_instate");
   std::vector<double> J((size_t)F * 42), inn((size_t)F * 2);
   Check(xivo_hip_get_jacobians(ctx_, 0, 1, J.data(), inn.data()), "get_jacobians");
+#if XIVO_HIP_ONLINE_CALIB
+  std::vector<double> Jc((size_t)F * 44);              // per feature 2 x 22: td | Cg 9 | bg 3 | intrinsics 9
+  Check(xivo_hip_get_jacobians_calib(ctx_, 0, 1, Jc.data()), "get_jacobians_calib");
+#endif
   for (int i = 0; i < F; ++i) {
     Feature* f = instate_features_[i];
     f->owner_ = this;
@@ -130,6 +181,17 @@ void Estimator::ComputeInstateJacobians() {
       for (int r = 0; r < 2; ++r)
         for (int c = 0; c < 3; ++c) f->J_(r, offs[b] + c) = J[(size_t)i * 42 + r * 21 + 3 * b + c];
     f->inn_(0) = inn[2 * i]; f->inn_(1) = inn[2 * i + 1];
+#if XIVO_HIP_ONLINE_CALIB
+    for (int r = 0; r < 2; ++r) {                        // J_ blocks of src/feature.cpp:632-651
+      const double* q = &Jc[(size_t)i * 44 + r * 22];
+      if (cl_.td >= 0) {
+        f->J_(r, cl_.td) = q[0];
+        if (cl_.Cg >= 0) for (int c = 0; c < 9; ++c) f->J_(r, cl_.Cg + c) = q[1 + c];
+        for (int c = 0; c < 3; ++c) f->J_(r, 9 + c) = q[10 + c];                       // Index::bg
+      }
+      for (int c = 0; c < cl_.cam_dim; ++c) f->J_(r, cl_.cam_begin + c) = q[13 + c];
+    }
+#endif
   }
 }
 
@@ -238,6 +300,15 @@ void Estimator::AbsorbError() {
   for (int i = 0; i < 3; ++i) { Tsb_(i) += err_(3 + i); Vsb_(i) += err_(6 + i); bg_(i) += err_(9 + i); ba_(i) += err_(12 + i); Tbc_(i) += err_(18 + i); }
   Rbc_ = mul3(Rbc_, exp3(err_(15), err_(16), err_(17)));
   Rsg_ = mul3(Rsg_, exp3(err_(21), err_(22), 0.0));
+#if XIVO_HIP_ONLINE_CALIB
+  if (cl_.td >= 0) td_ += err_(cl_.td);                                  // src/core.h:150-152
+  if (cl_.Cg >= 0) {                                                     // estimator.cpp:879-884 -> IMUState::operator+= (src/imu.cpp:7-21)
+    int k = cl_.Cg + 9;                                                  // Index::Ca: the upper triangle row by row
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) Ca_(i, j) += err_(k++);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Cg_(i, j) += err_(cl_.Cg + 3 * i + j);
+  }
+  for (int k = 0; k < cl_.cam_dim; ++k) intr_[k] += err_(cl_.cam_begin + k);   // estimator.cpp:886-890 -> A_*Camera::UpdateState
+#endif
   if (++absorb_counter_ % 50 == 0) {   // kEnforceSO3Freq (src/core.h:111,154-162)
     number_t q[4];
     rot_to_quat(Rsb_, q); Rsb_ = quat_to_rot(q);
@@ -286,6 +357,10 @@ std::vector<FeaturePtr> Estimator::OnePointRANSAC(const std::vector<FeaturePtr>&
   std::vector<Group> g0; for (Group* g : groups_) g0.push_back(g ? *g : Group());
   std::vector<Vec3> x0; for (Feature* f : mh_inliers) x0.push_back(f->x_);
   const std::vector<FeaturePtr> instate0 = instate_features_;
+#if XIVO_HIP_ONLINE_CALIB
+  const number_t td0 = td_; const Mat3 Cg0 = Cg_, Ca0 = Ca_;           // imu_.BackupState / Camera::BackupState (estimator.cpp:1421-1427)
+  number_t intr0[9]; std::memcpy(intr0, intr_, sizeof(intr0));
+#endif
 
   std::vector<Group*> groups_low, active;
   auto has = [](const std::vector<Group*>& v, Group* g) { for (Group* q : v) if (q == g) return true; return false; };
@@ -345,6 +420,9 @@ std::vector<FeaturePtr> Estimator::OnePointRANSAC(const std::vector<FeaturePtr>&
   device_P_current_ = false;
   P_ = P0; Rsb_ = Rsb0; Rbc_ = Rbc0; Rsg_ = Rsg0; Tsb_ = Tsb0; Vsb_ = Vsb0; bg_ = bg0; ba_ = ba0; Tbc_ = Tbc0;
   for (size_t g = 0; g < groups_.size(); ++g) if (groups_[g]) *groups_[g] = g0[g];
+#if XIVO_HIP_ONLINE_CALIB
+  td_ = td0; Cg_ = Cg0; Ca_ = Ca0; std::memcpy(intr_, intr0, sizeof(intr0));
+#endif
   for (int i = 0; i < n; ++i) mh_inliers[i]->x_ = x0[i];
   instate_features_ = mh_inliers;
   ComputeInstateJacobians();
@@ -480,6 +558,48 @@ void IntegratorStep(const Tableau& tb, MState& X, M23& Pmm, M23& Phi_out, const 
 
 void Estimator::Propagate(bool visual_meas, number_t dt) {
   if (dt == 0) return;                                    // estimator.cpp:551-556
+#if XIVO_HIP_ONLINE_CALIB
+  // Online-calibration builds: kMotionSize is 24 / 38 / 39 and ComputeMotionJacobianAt carries the dWsb/dCg and dVsb/dCa columns
+  // (src/estimator.cpp:626-638, :674-688); the adapter hands the whole call to the device-native integrator
+  // (xivo_hip_propagate_calib: RK4 / Dormand-Prince with the sub-stepping of src/rk4.cpp:13-32 on the resident state).
+  {
+    xivo_imu_in s{};
+    if (!visual_meas) {                                   // :558-568
+      for (int i = 0; i < 3; ++i) { slope_accel_(i) = (curr_accel_(i) - last_accel_(i)) / dt; slope_gyro_(i) = (curr_gyro_(i) - last_gyro_(i)) / dt; }
+    }
+    std::memcpy(s.gyro, last_gyro_.data(), 24); std::memcpy(s.accel, last_accel_.data(), 24);
+    std::memcpy(s.slope_gyro, slope_gyro_.data(), 24); std::memcpy(s.slope_accel, slope_accel_.data(), 24); s.dt = dt;
+    if (!visual_meas) { last_accel_ = curr_accel_; last_gyro_ = curr_gyro_; }
+    else for (int i = 0; i < 3; ++i) { last_accel_(i) += slope_accel_(i) * dt; last_gyro_(i) += slope_gyro_(i) * dt; }   // :569-575
+    xivo_prop_opts o{};
+    if (Qimu_.rows() != 12 || Qmodel_.rows() != motion_) throw std::invalid_argument("Propagate: Qimu_ 12 x 12, Qmodel_ kMotionSize x kMotionSize");
+    std::memcpy(o.Qimu, Qimu_.data(), sizeof(o.Qimu)); std::memcpy(o.g, g_.data(), sizeof(o.g));
+    if (integration_method_ == "PrinceDormand") o.method = 1;
+    else if (integration_method_ == "RK4") o.method = 0;
+    else throw std::runtime_error("Unknown integration method");
+    o.stepsize = stepsize_;
+    xivo_pose_in pose;
+    std::memcpy(pose.Rsb, Rsb_.data(), 72); std::memcpy(pose.Tsb, Tsb_.data(), 24); std::memcpy(pose.Rbc, Rbc_.data(), 72);
+    std::memcpy(pose.Tbc, Tbc_.data(), 24); std::memcpy(pose.Vsb, Vsb_.data(), 24); std::memcpy(pose.bg, bg_.data(), 24);
+    std::memcpy(pose.ba, ba_.data(), 24); std::memcpy(pose.Rsg, Rsg_.data(), 72);
+    std::vector<xivo_group_in> gs(lay_.n_groups);
+    for (auto& g : gs) { const Mat3 I = Identity3(); std::memcpy(g.Rsb, I.data(), 72); g.Tsb[0] = g.Tsb[1] = g.Tsb[2] = 0; }
+    xivo_feat_in none{}; none.sind = -1; none.ref_sind = 0;
+    Check(xivo_hip_set_scene(ctx_, 0, 1, 1, &pose, gs.data(), &none), "set_scene");
+    xivo_calib_in cs{};
+    std::memcpy(cs.gyro, s.gyro, 24); std::memcpy(cs.Cg, Cg_.data(), 72); cs.td = td_; std::memcpy(cs.Ca, Ca_.data(), 72);
+    std::memcpy(cs.intr, intr_, sizeof(cs.intr));
+    Check(xivo_hip_set_calib_state(ctx_, 0, 1, &cs), "set_calib_state");
+    const int N = lay_.N;
+    Check(xivo_hip_upload_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "upload_P");
+    Check(xivo_hip_propagate_calib(ctx_, 0, 1, 1, &s, &o, Qmodel_.data()), "propagate_calib");
+    Check(xivo_hip_get_scene(ctx_, 0, 1, &pose, nullptr, nullptr), "get_scene");
+    std::memcpy(Rsb_.data(), pose.Rsb, 72); std::memcpy(Tsb_.data(), pose.Tsb, 24); std::memcpy(Vsb_.data(), pose.Vsb, 24);
+    Check(xivo_hip_download_P(ctx_, 0, 1, P_.data(), (long)N * N, N), "download_P");
+    device_P_current_ = true;
+    return;
+  }
+#endif
   Vec3 accel0, gyro0;
   if (!visual_meas) {                                     // :558-568
     for (int i = 0; i < 3; ++i) {
@@ -581,6 +701,76 @@ extern "C" int xivo_host_selftest_update_step(const xivo_layout* lay, const xivo
     return -1;
   }
 }
+
+#if XIVO_HIP_ONLINE_CALIB
+// The same step in an online-calibration build (libxivo_host_calib.so): calib in / out = the calibration state before the
+// step and after AbsorbError; also Propagate over one IMU sample first when n_imu = 1 (imu, Qimu 12 x 12, Qmodel kMotionSize^2).
+extern "C" int xivo_host_selftest_update_step_calib(const xivo_layout* lay, const xivo_cam* cam, unsigned flags, int F,
+                                                    xivo_pose_in* pose, const xivo_group_in* groups, const xivo_feat_in* feats,
+                                                    xivo_calib_in* calib, double* P_inout, double R, double mh_thresh, double mh_mult,
+                                                    int min_inliers, int use_ransac, double ransac_thresh, double ransac_chi2,
+                                                    double* err_out, unsigned char* inlier_mask_out, int absorb,
+                                                    const xivo_imu_in* imu, const double* Qimu, const double* Qmodel, const double* g_vec,
+                                                    int method, int* slots_out, char* msg, int msg_len) {
+  using namespace xivo::hip;
+  try {
+    Estimator est(*lay, *cam, F, flags);
+    const int N = lay->N;
+    slots_out[0] = est.calib_layout().td; slots_out[1] = est.calib_layout().Cg; slots_out[2] = est.calib_layout().cam_begin;
+    slots_out[3] = est.calib_layout().cam_dim; slots_out[4] = est.motion_size();
+    std::memcpy(est.P_.data(), P_inout, sizeof(double) * N * N);
+    std::memcpy(est.Rsb_.data(), pose->Rsb, 72); std::memcpy(est.Tsb_.data(), pose->Tsb, 24);
+    std::memcpy(est.Rbc_.data(), pose->Rbc, 72); std::memcpy(est.Tbc_.data(), pose->Tbc, 24);
+    std::memcpy(est.Vsb_.data(), pose->Vsb, 24); std::memcpy(est.bg_.data(), pose->bg, 24); std::memcpy(est.ba_.data(), pose->ba, 24);
+    std::memcpy(est.Rsg_.data(), pose->Rsg, 72);
+    std::memcpy(est.last_gyro_.data(), calib->gyro, 24); std::memcpy(est.Cg_.data(), calib->Cg, 72); est.td_ = calib->td;
+    std::memcpy(est.Ca_.data(), calib->Ca, 72); std::memcpy(est.intr_, calib->intr, sizeof(est.intr_));
+    est.R_ = R; est.MH_thresh_ = mh_thresh; est.MH_thresh_multipler_ = mh_mult; est.min_required_inliers_ = min_inliers;
+    est.ransac_thresh_ = ransac_thresh; est.ransac_Chi2_ = ransac_chi2;
+    if (imu) {
+      std::memcpy(est.last_gyro_.data(), imu->gyro, 24); std::memcpy(est.last_accel_.data(), imu->accel, 24);
+      std::memcpy(est.slope_gyro_.data(), imu->slope_gyro, 24); std::memcpy(est.slope_accel_.data(), imu->slope_accel, 24);
+      std::memcpy(est.g_.data(), g_vec, 24);
+      est.Qimu_.setZero(12, 12); std::memcpy(est.Qimu_.data(), Qimu, sizeof(double) * 144);
+      const int nm = est.motion_size();
+      est.Qmodel_.setZero(nm, nm); std::memcpy(est.Qmodel_.data(), Qmodel, sizeof(double) * nm * nm);
+      est.integration_method_ = method == 0 ? "RK4" : "PrinceDormand";
+      est.Propagate(true, imu->dt);
+    }
+    std::vector<Group> gs(lay->n_groups);
+    for (int g = 0; g < lay->n_groups; ++g) {
+      std::memcpy(gs[g].Rsb_.data(), groups[g].Rsb, 72); std::memcpy(gs[g].Tsb_.data(), groups[g].Tsb, 24);
+      gs[g].sind_ = g; est.groups_[g] = &gs[g]; est.instate_groups_.push_back(&gs[g]);
+    }
+    std::vector<Feature> fs(F);
+    for (int i = 0; i < F; ++i) {
+      std::memcpy(fs[i].x_.data(), feats[i].x, 24); std::memcpy(fs[i].back_.data(), feats[i].xp, 16);
+      fs[i].ref_ = &gs[feats[i].ref_sind]; fs[i].sind_ = feats[i].sind;
+      est.instate_features_.push_back(&fs[i]);
+    }
+    est.ComputeInstateJacobians();
+    std::vector<FeaturePtr> inliers;
+    if (est.use_MH_gating_ && (int)est.instate_features_.size() > est.min_required_inliers_) inliers = est.MHGating();
+    else inliers = est.instate_features_;
+    if (use_ransac) { est.gauge_group_ptr_ = &gs[0]; inliers = est.OnePointRANSAC(inliers); }
+    est.in_current_ekf_update_ = inliers;
+    est.FilterUpdate();
+    std::memcpy(err_out, est.err_.data(), sizeof(double) * N);
+    if (absorb) est.AbsorbError();
+    std::memcpy(P_inout, est.P_.data(), sizeof(double) * N * N);
+    for (int i = 0; i < F; ++i) inlier_mask_out[i] = 0;
+    for (FeaturePtr f : inliers) inlier_mask_out[f - &fs[0]] = 1;
+    std::memcpy(pose->Rsb, est.Rsb_.data(), 72); std::memcpy(pose->Tsb, est.Tsb_.data(), 24); std::memcpy(pose->Vsb, est.Vsb_.data(), 24);
+    std::memcpy(pose->bg, est.bg_.data(), 24); std::memcpy(pose->Rbc, est.Rbc_.data(), 72); std::memcpy(pose->Tbc, est.Tbc_.data(), 24);
+    std::memcpy(calib->Cg, est.Cg_.data(), 72); calib->td = est.td_; std::memcpy(calib->Ca, est.Ca_.data(), 72);
+    std::memcpy(calib->intr, est.intr_, sizeof(est.intr_));
+    return 0;
+  } catch (const std::exception& e) {
+    if (msg && msg_len > 0) { std::strncpy(msg, e.what(), msg_len - 1); msg[msg_len - 1] = 0; }
+    return -1;
+  }
+}
+#endif
 
 // state30 = [Rsb(9 col-major) Tsb Vsb bg ba Rsg(9)] in/out; imu18 = [last_gyro last_accel curr_gyro curr_accel slope_gyro slope_accel]
 extern "C" int xivo_host_selftest_propagate(int N, int use_rk4, int visual_meas, double dt, double stepsize, double* state30,

@@ -24,6 +24,16 @@
 
 #include "../../include/xivo_hip.h"
 
+// The reference's online-calibration builds (src/CMakeLists.txt:13-15): compile the adapter with the same defines and it
+// carries the extra state (X_.td, imu_.Cg() / Ca(), the camera intrinsics), the extra Jacobian blocks of Feature::J_ /
+// FillJacobianBlock (src/feature.cpp:592-651, :664-683), their retraction in AbsorbError (src/estimator.cpp:875-890) and
+// switches the context with xivo_hip_set_calib. (xivo_amd/host/Makefile builds libxivo_host_calib.so that way.)
+#if defined(USE_ONLINE_TEMPORAL_CALIB) || defined(USE_ONLINE_IMU_CALIB) || defined(USE_ONLINE_CAMERA_CALIB)
+#define XIVO_HIP_ONLINE_CALIB 1
+#else
+#define XIVO_HIP_ONLINE_CALIB 0
+#endif
+
 namespace xivo {
 namespace hip {
 
@@ -180,6 +190,14 @@ class Estimator {
   // rows, AbsorbError, re-Jacobians + chi-square rescue on the device, RestoreState.
   std::vector<FeaturePtr> OnePointRANSAC(const std::vector<FeaturePtr>& mh_inliers);
   number_t ransac_thresh_ = 5, ransac_Chi2_ = 5.89;        // src/estimator.cpp:132-134
+#if XIVO_HIP_ONLINE_CALIB
+  // ---- online-calibration state (src/core.h:117-130 X_.td; src/imu.h:12-27 imu_.X_; the camera's own parameters) ----
+  number_t td_ = 0;                        // X_.td
+  Mat3 Cg_ = Identity3(), Ca_ = Identity3();   // imu_.Cg(), imu_.Ca()
+  number_t intr_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // fx fy cx cy + the model's distortion parameters (the state slots' order)
+  const xivo_calib_layout& calib_layout() const { return cl_; }
+  int motion_size() const { return motion_; }   // kMotionSize of this build (24 / 38 / 39)
+#endif
   GroupPtr gauge_group_ptr_ = nullptr;
   std::vector<GroupPtr> instate_groups_;   // groups AbsorbError retracts (src/manager.cpp:103)
   int num_oneptransac_rejected_ = 0;
@@ -204,6 +222,10 @@ class Estimator {
  private:
   void Check(int status, const char* what) const;
   bool device_P_current_ = false;
+#if XIVO_HIP_ONLINE_CALIB
+  xivo_calib_layout cl_{-1, -1, 0, 0};
+  int motion_ = 23;
+#endif
   xivo_hip_ctx* ctx_ = nullptr;
   xivo_layout lay_;
   xivo_cam cam_;
