@@ -305,7 +305,7 @@ SUB_CONFIGS = [
       "--tol-dx-last", "1e-2"]),
     ("calib", "online-calibration build (USE_ONLINE_TEMPORAL_CALIB / _IMU_CALIB / _CAMERA_CALIB: N=276, 60 features with td / Cg / bg / 8 "
      "intrinsics blocks), feature level: Jacobians + gating on the whole row + update, 4096 filters",
-     ["--level", "G", "--calib", "--flags", "16", "--batch", "4096", "--steps", "5", "--warmup", "2"]),
+     ["--level", "G", "--calib", "--batch", "4096", "--steps", "5", "--warmup", "2"]),
     ("tumvi", "TUM-VI size (N=203, 30 features, M=60), fp64, 8192 filters",
      ["--state-dim", "203", "--features", "30", "--batch", "8192", "--steps", "8", "--warmup", "2"]),
     ("dense_ascoded", "metric point, dense AS-CODED pipeline (XIVO_HIP_FLAG_DENSE_H = --flags 64: H treated as dense, every product of "
@@ -464,7 +464,7 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="extra XIVO_HIP_FLAG_* bits (A/B knobs)")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--calib", action="store_true",
-                    help="--level G: the online-calibration build's layout and Jacobian blocks (N = 276; dense pipeline)")
+                    help="--level G: the online-calibration build's layout and Jacobian blocks (N = 276; compressed rows + a dense block of the calibration columns)")
     ap.add_argument("--no-mixed", action="store_true", help="skip the second timed loop (fp32 correction product)")
     ap.add_argument("--sub", action="store_true", help="child run of the `configs` array: no configs / dropin blocks of its own")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` array (the other BASELINE configurations, child runs)")

@@ -20,6 +20,17 @@ CAM_DIM = {"pinhole": 4, "atan": 5, "radtan": 9, "equi": 8}
 R_VIS, MH, MULT = 2.25, 5.991, 1.1
 
 
+@pytest.fixture(params=["lead", "dense"])
+def rows(request, monkeypatch):
+    """The two stackings of an online-calibration build: row-pair compressed rows + the leading dense block of the calibration
+    columns on the sparse pipeline (round 5, default; last_path 1), or dense rows on the dense pipeline (XIVO_HIP_CALIB_DENSE)."""
+    if request.param == "dense":
+        monkeypatch.setenv("XIVO_HIP_CALIB_DENSE", "1")
+    else:
+        monkeypatch.delenv("XIVO_HIP_CALIB_DENSE", raising=False)
+    return 0 if request.param == "dense" else 1
+
+
 def setup(name, temporal, imu, camera, B=3, ng=6, nf=14, seed=3):
     cam = CAMS[name]
     lay = orc.calib_layout(ng, nf, temporal, imu, CAM_DIM[name] if camera else 0)
@@ -53,7 +64,7 @@ def oracle_rows(sc, cam, lay, xp, cals, b):
 
 @pytest.mark.parametrize("name", list(CAMS))
 @pytest.mark.parametrize("temporal,imu,camera", [(True, True, True), (True, False, False), (False, False, True), (True, True, False)])
-def test_calibration_jacobian_blocks_and_stacking(built, name, temporal, imu, camera):
+def test_calibration_jacobian_blocks_and_stacking(built, rows, name, temporal, imu, camera):
     cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup(name, temporal, imu, camera)
     B, F = poses.shape[0], feats.shape[1]
     with ctx:
@@ -62,9 +73,9 @@ def test_calibration_jacobian_blocks_and_stacking(built, name, temporal, imu, ca
         ctx.jacobians_instate()
         J21, inn = ctx.get_jacobians()
         Jc = ctx.get_jacobians_calib(F=F)
-        ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=False)          # stacks every present feature (dense rows)
-        Hs = [ctx.get_H(b) for b in range(B)]
-        assert ctx.last_path() == 0
+        ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=False)          # stacks every present feature
+        assert ctx.last_path() == rows
+        Hs = [ctx.get_H(b) for b in range(B)]                             # (the dense copy of the rows, rebuilt on demand)
     for b in range(B):
         Js, inns, Jcs = oracle_rows(sc, cam, lay, xp, cals, b)
         assert rel_fro(Jc[b], Jcs) < 1e-12 and np.abs(inn[b] - inns).max() < 1e-9
@@ -79,8 +90,8 @@ def test_calibration_jacobian_blocks_and_stacking(built, name, temporal, imu, ca
 
 
 @pytest.mark.parametrize("name", ["pinhole", "equi", "radtan", "atan"])
-def test_filter_update_with_calibration_columns(built, name):
-    """jac -> stack (dense rows) -> MH gating on the WHOLE row (as f->J(), update.cpp:60-70) -> UpdateJosephForm, against the
+def test_filter_update_with_calibration_columns(built, rows, name):
+    """jac -> stack -> MH gating on the WHOLE row (as f->J(), update.cpp:60-70) -> UpdateJosephForm, against the
     reference flow where rejected features are not stacked: masks identical, P 1e-6, dx 1e-8 - the td / Cg / bg / intrinsics
     components of dx included (the host absorbs those, src/estimator.cpp:879-889)."""
     cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup(name, True, True, True, B=3, ng=8, nf=20, seed=11)
@@ -90,7 +101,7 @@ def test_filter_update_with_calibration_columns(built, name):
     with ctx:
         ctx.upload_P(P); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
         ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)
-        assert ctx.last_path() == 0
+        assert ctx.last_path() == rows
         err = ctx.get_err(); Pn = ctx.download_P(); mask, dist = ctx.get_gate(F, B)
         assert (ctx.get_status() == 0).all()
     rejected = 0
@@ -108,7 +119,7 @@ def test_filter_update_with_calibration_columns(built, name):
     assert rejected >= 2
 
 
-def test_stand_alone_gate_and_calibration_off_again(built):
+def test_stand_alone_gate_and_calibration_off_again(built, rows):
     """xivo_hip_mh_gate on a calibration context gates on the whole row too (then stack + update as separate calls);
     set_calib() switches back to the default build."""
     cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup("equi", True, True, True, B=3, ng=6, nf=14, seed=4)
@@ -120,6 +131,7 @@ def test_stand_alone_gate_and_calibration_off_again(built):
         ctx.jacobians_instate()
         mask, dist = ctx.mh_gate(R_VIS, MH, MULT, 5)
         ctx.stack(R_VIS); ctx.update_joseph()
+        assert ctx.last_path() == rows
         err = ctx.get_err(); Pn = ctx.download_P()
         rej = 0
         for b in range(B):

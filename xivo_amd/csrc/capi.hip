@@ -98,6 +98,9 @@ struct xivo_hip_ctx {
   int oos_nb = 0, oos_n = 0, oos_max_rows = 0;   // shape of the resident OOS list (xivo_hip_oos_project with feats == NULL)
   int* oos_rows = nullptr;
   xivo_calib_in* calib_rs = nullptr;            // BackupState of the calibration state (OnePointRANSAC, online-calibration builds)
+  // online-calibration builds on the sparse pipeline (round 5): the calibration columns of the stacked rows as a dense
+  // [Mpmax x LEAD_K] block per filter next to the row-pair compressed rows; lead_valid: the current stacking has one
+  double* Hlead = nullptr; bool lead_valid = false;
   void* lc_buf = nullptr; size_t lc_cap = 0;   // xivo_hip_close_loop_stack: matches | dense rows | inn | diagR
   xivo_subfilter_feat* sub = nullptr;   // staging of xivo_hip_subfilter_update
   std::vector<char> hstage;                        // host staging of d2h_rows
@@ -184,6 +187,14 @@ MeasBuffers meas_buffers(xivo_hip_ctx* c) {
   mb.inn = c->inn; mb.strideInn = c->Mpmax;
   mb.diagR = c->diagR; mb.strideR = c->Mpmax;
   return mb;
+}
+
+// leading state columns the calibration blocks live in: td 23, Cg 24..32, (Ca 33..38,) bg 9..11, intrinsics up to 39..47
+constexpr int LEAD_K = 48;
+static bool calib_sparse(const xivo_hip_ctx* c) {
+  const bool off = getenv("XIVO_HIP_CALIB_DENSE") != nullptr;   // A/B knob, read per call: online-calibration builds on dense rows (round 4)
+  return c->calib_on && !off && c->Hlead && c->cl.cam_begin + 9 <= LEAD_K && c->Np >= LEAD_K &&
+         !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV | XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL));
 }
 
 SceneBuffers scene_buffers(xivo_hip_ctx* c) {
@@ -343,7 +354,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
-                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->calib_rs, c->tune_status, c->ldlt_used, c->calib, c->Jc};
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->calib_rs, c->Hlead, c->tune_status, c->ldlt_used, c->calib, c->Jc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
   if (c->pin_h) hipHostFree(c->pin_h);
@@ -530,6 +541,7 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   c->M = M; c->Mp = round_up16(M);
   EllBuffers e = c->ell;
   e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.pw += b0; e.over += b0;
+  c->lead_valid = false;
   if (!meas_compress_fits(c->Mpmax, c->Np) || getenv("XIVO_HIP_NO_COMPRESS")) {
     // the compression kernel's LDS lists do not fit this shape: every filter keeps its dense rows and takes the dense pipeline
     StageTimer st(c, ST_STACK, 0.0, "unpack_meas_kernel", 8.0 * nb * (3.0 * M * N + 4.0 * M));
@@ -738,6 +750,16 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     rc = gemm(c, ST_HP, B, oos_pad, Np, Hd, c->sH, ldh, P, c->sP, Np, oos_k, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, HP + mr0, c->sH, ldh, x);
     if (rc) return rc;
   }
+  // online-calibration stacking on the sparse pipeline: the calibration columns of H live in the leading dense block
+  // L [Mp x LEAD_K] (stack_kernel): H P += L P[0:LEAD_K, :] on the MFMA product, the transpose going to P H^T as it is written
+  const bool lead = c->lead_valid && mr0 < 0;
+  const double* Ld = lead ? c->Hlead + (long)b0 * c->Mpmax * LEAD_K : nullptr;
+  const long sLd = (long)c->Mpmax * LEAD_K;
+  if (lead) {
+    GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = HP; x.sMsub = c->sH; x.ldmsub = ldh; x.C2 = PHT; x.sC2 = c->sK; x.ldc2 = Np;
+    rc = gemm(c, ST_HP, B, Mp, Np, Ld, sLd, Mp, P, c->sP, Np, LEAD_K, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, HP, c->sH, ldh, x);
+    if (rc) return rc;
+  }
   GateEllArgs ga{};
   if (gate) {
     ga.ell = e;
@@ -758,10 +780,10 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     // A/B knob (measured slower, off by default): the gate in the tail of the S kernel - S + gate 2.88 ms fused vs 2.30 + 0.36
     // as two kernels per 16384 filters: the tail runs at one 8-wave workgroup per CU where the stand-alone gate fills the chip
     static const bool fuse = getenv("XIVO_HIP_GATE_IN_S") != nullptr;
-    if (gate && fuse) { a.gate = ga; a.gate_here = 1; a.gate_done = &gate_done; }
+    if (gate && fuse && !lead) { a.gate = ga; a.gate_here = 1; a.gate_done = &gate_done; }
     // the 2 x 2 diagonal blocks of S once more, compact (the T buffer is free until the solve): what the gate reads
     static const bool no_sdiag = getenv("XIVO_HIP_NO_SDIAG") != nullptr;   // A/B knob: the gate reads them off S
-    if (gate && !fuse && !no_sdiag && mr0 < 0 && (long)2 * Mp <= c->sP) { a.diag_out = c->T + (long)b0 * c->sP; a.strideDiag = c->sP; a.diag_done = &diag_done; }
+    if (gate && !fuse && !no_sdiag && mr0 < 0 && !lead && (long)2 * Mp <= c->sP) { a.diag_out = c->T + (long)b0 * c->sP; a.strideDiag = c->sP; a.diag_done = &diag_done; }
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
     StageTimer st(c, ST_S, nnz_flops * Mf * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_S, a, c->stream));
@@ -771,6 +793,11 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     GemmExtra x; x.epi = EPI_ADD_DIAG; x.diag = diagR + mr0; x.sDiag = c->Mpmax; x.lower_only = 1;
     rc = gemm(c, ST_S, B, oos_pad, oos_pad, HP + mr0, c->sH, ldh, Hd, c->sH, ldh, oos_k, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               S + mr0 + (long)mr0 * lds, c->sS, lds, x);
+    if (rc) return rc;
+  }
+  if (lead) {   // S += L (H P)^T[0:LEAD_K, :] - the walk above covered the compressed columns of H against the complete P H^T
+    GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = S; x.sMsub = c->sS; x.ldmsub = lds; x.lower_only = 1;
+    rc = gemm(c, ST_S, B, Mp, Mp, Ld, sLd, Mp, HP, c->sH, ldh, LEAD_K, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, S, c->sS, lds, x);
     if (rc) return rc;
   }
   const bool lat = latency_route(c, Mp, B, full);
@@ -924,6 +951,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   a.ell.nc += b0; a.ell.pw += b0; a.ell.over += b0;
   a.H = c->H + (long)b0 * c->sH; a.strideH = c->sH; a.ldh = c->Mpmax; a.use_dense = c->last_path == 0 ? 1 : 0;
   a.mixed_row0 = c->last_path == 1 ? c->mixed_row0 : -1;
+  if (c->last_path == 1 && c->lead_valid) { a.lead = c->Hlead + (long)b0 * c->Mpmax * LEAD_K; a.strideLead = (long)c->Mpmax * LEAD_K; a.ldlead = c->Mp; a.lead_k = LEAD_K; }
   a.PHT = c->PHT + (long)b0 * c->sK; a.stridePHT = c->sK; a.ldpht = c->Np;
   a.S = c->S + (long)b0 * c->sS; a.strideS = c->sS; a.lds = c->Mpmax;
   a.K = c->K + (long)b0 * c->sK; a.strideK = c->sK; a.ldk = c->Np;
@@ -980,6 +1008,8 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
   // mixed stacking + a flag / knob that routes to the stand-alone tail: every row dense, dense pipeline (ensure_dense below
   // rebuilds the in-state rows from their compressed form next to the OOS rows already in place)
   if (sparse && c->mixed_row0 >= 0 && sparse_route_ends_in_standalone_tail(c, Mp, Np, B)) sparse = false;
+  // (the same for the leading dense block of an online-calibration stacking: the tail's G = T H^T walks compressed rows only)
+  if (sparse && c->lead_valid && (gate || sparse_route_ends_in_standalone_tail(c, Mp, Np, B))) sparse = false;
   c->last_path = sparse ? 1 : 0;
   if (sparse) return update_sparse_range(c, b0, B, gate);
   rc = ensure_dense(c);
@@ -1511,6 +1541,8 @@ int xivo_hip_set_calib(xivo_hip_ctx* c, const xivo_calib_layout* layout) {
   if ((l.td >= 0 && l.td != 23) || (l.Cg >= 0 && l.Cg != (l.td >= 0 ? 24 : 23))) return XIVO_HIP_ERR_INVALID;
   if (!c->calib) { int rc = dev_alloc(&c->calib, (size_t)c->Bmax); if (rc) return rc; }
   if (!c->Jc && c->Fmax > 0) { int rc = dev_alloc(&c->Jc, (size_t)c->Bmax * c->Fmax * 44); if (rc) return rc; }
+  if (!c->Hlead) { int rc = dev_alloc(&c->Hlead, (size_t)c->Bmax * c->Mpmax * LEAD_K); if (rc) return rc; }
+  c->lead_valid = false;
   c->cl = l;
   c->calib_on = l.td >= 0 || l.cam_dim > 0;       // measurement side: blocks beyond the default build's (the Cg / bg blocks sit inside the td block)
   c->calib_motion = l.td >= 0 || l.Cg >= 0;       // motion side: kMotionSize > 23
@@ -1603,7 +1635,10 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   // (online-calibration builds: the compact 21-column gate would ignore the td / Cg / bg / intrinsics blocks)
-  int rc = c->calib_on ? calib_gate(c, B, R, mh_thresh, mh_mult, min_inliers, 1) : gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
+  // (online-calibration builds: the compact gate works on the whole row too - 43 columns, gate_sparse_kernel's wide form;
+  //  XIVO_HIP_CALIB_DENSE: the dense-row gate of round 4)
+  int rc = (c->calib_on && !calib_sparse(c)) ? calib_gate(c, B, R, mh_thresh, mh_mult, min_inliers, 1)
+                                             : gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
   if (rc) return rc;
   const size_t F = c->F, Fm = c->Fmax;
   if (mask_out) { rc = d2h_rows(c, mask_out, F, c->mask, Fm, F, B); if (rc) return rc; }
@@ -1624,6 +1659,9 @@ static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigne
   a.fix_group_block = (full_rows || (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK)) ? 1 : 0;
   a.rows_instate = c->rows_instate;
   a.ell = c->ell; a.emit_ell = 1; a.write_dense = write_dense;
+  // as-coded stacking of an online-calibration build on the sparse pipeline: compressed rows + the leading dense block
+  // (full_rows - the whole-row stackings of the gate / RANSAC - stay dense rows)
+  if (!full_rows && !write_dense && calib_sparse(c)) { a.lead = c->Hlead; a.strideLead = (long)c->Mpmax * LEAD_K; a.lead_k = LEAD_K; }
   StageTimer st(c, ST_STACK, 0.0, "stack_kernel");
   return launch_stack(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
@@ -1654,6 +1692,10 @@ static int ensure_dense(xivo_hip_ctx* c) {
     return launch_ell_to_dense(c->ell, c->H, c->sH, c->Mpmax, c->HT, c->sHT, c->Np, c->Mpmax, c->Np, c->Bmax, c->stream)
                ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
   }
+  if (c->lead_valid) {   // online-calibration stacking on the sparse pipeline: dense rows carry the calibration columns themselves
+    c->lead_valid = false;
+    for (int b = 0; b < c->stack_B; ++b) c->ell_over_h[b] = 1;
+  }
   return stack_impl(c, c->stack_B, c->stack_R, 1);
 }
 
@@ -1661,12 +1703,15 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
+  const bool csp = calib_sparse(c);
   for (int b = 0; b < B; ++b) {
-    c->ell_over_h[b] = c->calib_on ? 1 : 0; c->ell_nc_h[b] = 12;   // (calibration blocks: up to 34 shared columns - dense rows)
+    // (calibration blocks: up to 34 shared columns - dense rows, or compressed rows + the leading dense block)
+    c->ell_over_h[b] = (c->calib_on && !csp) ? 1 : 0; c->ell_nc_h[b] = 12;
     c->ell_pw_h[b] = (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK) ? 9 : 6;   // group block(s) + feature block
   }
+  c->lead_valid = csp;
   // the sparse-H pipeline reads only the compressed rows: skip the 2 x Mp x Np dense zero-fill + scatter
-  const int dense = ((c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) || c->calib_on) ? 1 : 0;
+  const int dense = ((c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) || (c->calib_on && !csp)) ? 1 : 0;
   c->dense_valid = dense != 0; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B; c->oos_row0 = -1;
   c->mixed_row0 = -1; if (dense) c->h_clean = false;
   return stack_impl(c, B, R, dense);
@@ -1697,7 +1742,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   // 16-row-padded OOS block inside the allocation; otherwise (and with XIVO_HIP_FLAG_DENSE_H / _FP32_COV) every row
   // becomes dense as before.
   static const bool no_mixed = getenv("XIVO_HIP_NO_MIXED_OOS") != nullptr;   // A/B knob
-  const bool mixed = !no_mixed && !c->dense_valid && !c->dense_from_ell && c->oos_row0 < 0 && b0 == 0 &&
+  const bool mixed = !no_mixed && !c->calib_on && !c->dense_valid && !c->dense_from_ell && c->oos_row0 < 0 && b0 == 0 &&
                      !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) && (c->M % 2 == 0) &&
                      c->M + round_up16(max_rows + 16) <= c->Mpmax && c->Np <= 512;
   if (!mixed) { int rcd = ensure_dense(c); if (rcd) return rcd; c->mixed_row0 = -1; }
@@ -1804,6 +1849,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   // partial update: H_ rows = the full J() of the low-innovation inliers (:326 - no FillJacobianBlock), R_ on the diagonal
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
   for (int b = 0; b < B; ++b) { c->ell_over_h[b] = cal ? 1 : 0; c->ell_nc_h[b] = 12; c->ell_pw_h[b] = 9; }
+  c->lead_valid = false;
   const int dense = ((c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) || cal) ? 1 : 0;
   c->dense_valid = dense != 0; c->dense_from_ell = !cal; c->stack_R = R; c->stack_B = B;
   c->oos_row0 = -1;   // the partial stacking replaces the rows of any earlier xivo_hip_oos_project (as xivo_hip_stack does)
@@ -1954,8 +2000,8 @@ int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, d
   if (rc) return rc;
   // Estimator::OutlierRejection only gates when F > min_required_inliers_ (src/manager.cpp:635)
   const int gate = use_gating && c->F > min_inliers;
-  if (c->calib_on) {
-    // online-calibration builds: the gate needs the WHOLE row J() incl. the td / Cg / bg / intrinsics blocks (update.cpp:60-70),
+  if (c->calib_on && !calib_sparse(c)) {
+    // online-calibration builds (dense rows, XIVO_HIP_CALIB_DENSE): the gate needs the WHOLE row J() incl. the td / Cg / bg / intrinsics blocks (update.cpp:60-70),
     // which is not the row FillJacobianBlock stacks (the :675-676 overwrite): every present feature is stacked once as its
     // full J() (dense rows), gated on (J P) J^T + R by the dense-row gate, then the inliers are stacked as coded and updated
     rc = calib_gate(c, B, R, mh_thresh, mh_mult, min_inliers, gate);

@@ -98,6 +98,9 @@ struct StackArgs {
   int* rows_instate;   // [batch] out: 2 * F (rows reserved for in-state features)
   EllBuffers ell; int emit_ell;   // also emit the row-pair compressed form (ell.h)
   int write_dense;                // 0: only inn / diagR / ELL (the dense H, H^T are materialised on demand)
+  // online-calibration builds on the sparse pipeline: [batch] dense blocks [Mp x lead_k] (leading dimension Mp) that take the
+  // calibration columns of every row pair; null: those builds stack dense rows
+  double* lead; long strideLead; int lead_k;
 };
 int launch_stack(const StackArgs& a, hipStream_t s);
 
@@ -220,6 +223,7 @@ struct LdltFallbackArgs {
   int* status; int* used;
   EllBuffers ell; const double* H; long strideH; int ldh; int use_dense;
   int mixed_row0;   // >= 0: rows below it are row-pair compressed, rows from it on are dense (OOS rows behind in-state rows)
+  const double* lead; long strideLead; int ldlead, lead_k;   // leading dense block next to the compressed rows (online-calibration stacking), or null
   const double* PHT; long stridePHT; int ldpht;
   double* S; long strideS; int lds;
   double* K; long strideK; int ldk;

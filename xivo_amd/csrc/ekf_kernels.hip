@@ -497,6 +497,58 @@ __device__ __forceinline__ double feature_chi2_lds(const double* P, int ldp, con
 // from the 21 x 21 sub-block of P the feature touches (J is structurally
 // sparse), reduces it across lanes, and the 2x2 LLT gives the Mahalanobis
 // distance. Then one wave runs the threshold-relaxation loop.
+// Online-calibration builds: J() has 22 more columns every feature shares - td, Cg (9), bg (3), the intrinsics (9 slots) - next
+// to the 21 of the default build (src/feature.cpp:623-651): the same gather on 43 columns, two rows per lane.
+constexpr int WIDE_NC = 43, WIDE_SCR = WIDE_NC * WIDE_NC + 2 * WIDE_NC + 1;   // doubles of LDS scratch per wave (1936)
+__device__ __forceinline__ int jcol_wide(const xivo_layout& lay, const xivo_calib_layout& cl, const xivo_feat_in& ft, int c) {
+  if (c < 21) return jcol(lay, ft, c);
+  const int k = c - 21;                                   // the layout of Jc: td | Cg 9 | bg 3 | intrinsics 9
+  if (k == 0) return cl.td >= 0 ? cl.td : 0;              // (a block that is switched off carries zeros: any valid column will do)
+  if (k < 10) return cl.Cg >= 0 ? cl.Cg + (k - 1) : 0;
+  if (k < 13) return 9 + (k - 10);                        // Index::bg
+  return (k - 13) < cl.cam_dim ? cl.cam_begin + (k - 13) : 0;
+}
+__device__ __forceinline__ double feature_chi2_wide(const double* P, int ldp, const xivo_layout& lay, const xivo_calib_layout& cl,
+                                                    const xivo_feat_in& ft, const double* J, const double* Jc, const double* inn, double R,
+                                                    int lane, double* scratch) {
+  double* sP = scratch;                       // [a + 43 b]
+  double* sJ = scratch + WIDE_NC * WIDE_NC;   // [row * 43 + b]
+  for (int e0 = 0; e0 < WIDE_NC * WIDE_NC; e0 += 64 * 8) {
+    double pv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = e0 + lane + 64 * k;
+      const int ea = e < WIDE_NC * WIDE_NC ? e % WIDE_NC : 0, eb = e < WIDE_NC * WIDE_NC ? e / WIDE_NC : 0;
+      pv[k] = P[jcol_wide(lay, cl, ft, ea) + (long)jcol_wide(lay, cl, ft, eb) * ldp];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = e0 + lane + 64 * k;
+      if (e < WIDE_NC * WIDE_NC) sP[e] = pv[k];
+    }
+  }
+  if (lane < WIDE_NC) {
+    sJ[lane] = lane < 21 ? J[lane] : Jc[lane - 21];
+    sJ[WIDE_NC + lane] = lane < 21 ? J[21 + lane] : Jc[22 + lane - 21];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  double v0 = 0.0, v1 = 0.0;
+  if (lane < WIDE_NC) {
+    for (int b = 0; b < WIDE_NC; ++b) {
+      const double p = sP[lane + WIDE_NC * b];
+      v0 = fma(p, sJ[b], v0);
+      v1 = fma(p, sJ[WIDE_NC + b], v1);
+    }
+  }
+  const double j0 = lane < WIDE_NC ? sJ[lane] : 0.0, j1 = lane < WIDE_NC ? sJ[WIDE_NC + lane] : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  const double s00 = wave_sum(j0 * v0) + R;
+  const double s10 = wave_sum(j1 * v0);
+  const double s11 = wave_sum(j1 * v1) + R;
+  return mh_dist_2x2(s00, s10, s11, inn[0], inn[1]);
+}
+
 __global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
   const int filt = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -513,7 +565,7 @@ __global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
   // P and J right away instead of behind a load of the entry (two dependent memory round trips per feature, fifteen
   // features per wave one after the other, were what the kernel's time was)
   int* s_slot = reinterpret_cast<int*>(sdist + sb.F + 1);   // [2 F]: sind, ref_sind
-  double* s_scr = sdist + sb.F + 1 + (2 * sb.F + 1) / 2 + (long)wave * 484;   // per wave: feature_chi2_lds scratch
+  double* s_scr = sdist + sb.F + 1 + (2 * sb.F + 1) / 2 + (long)wave * (sb.Jc ? WIDE_SCR : 484);   // per wave: feature_chi2_lds / _wide scratch
   {
     int cnt = 0;
     for (int f = tid; f < sb.F; f += nt) {
@@ -534,7 +586,8 @@ __global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
       if (ft.sind < 0) { if (lane == 0) sdist[f] = __builtin_inf(); continue; }
       const double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
       const double* inn = sb.finn + ((long)filt * sb.Fmax + f) * 2;
-      const double d = feature_chi2_lds(P, a.ldp, a.lay, ft, J, inn, a.R, lane, s_scr);
+      const double d = sb.Jc ? feature_chi2_wide(P, a.ldp, a.lay, sb.cl, ft, J, sb.Jc + ((long)filt * sb.Fmax + f) * 44, inn, a.R, lane, s_scr)
+                             : feature_chi2_lds(P, a.ldp, a.lay, ft, J, inn, a.R, lane, s_scr);
       if (lane == 0) sdist[f] = d;
     }
     __syncthreads();
@@ -630,7 +683,29 @@ __global__ __launch_bounds__(256) void stack_kernel(StackArgs a) {
   // group and feature blocks the private ones (ell.h)
   int* eidx = a.ell.idx + (long)filt * a.ell.stride_idx();
   double* eval = a.ell.val + (long)filt * a.ell.stride_val();
-  if (tid == 0) { a.ell.nc[filt] = 12; a.ell.over[filt] = sb.Jc ? 1 : 0; a.ell.pw[filt] = a.fix_group_block ? 9 : 6; }   // (calibration blocks: dense rows only)
+  // (calibration blocks: dense rows - or, with a.lead, the "leading dense block" next to compressed rows)
+  if (tid == 0) { a.ell.nc[filt] = 12; a.ell.over[filt] = (sb.Jc && !a.lead) ? 1 : 0; a.ell.pw[filt] = a.fix_group_block ? 9 : 6; }
+  if (sb.Jc && a.lead) {
+    // Online-calibration builds on the sparse pipeline: the td / Cg / bg / intrinsics blocks of FillJacobianBlock
+    // (feature.cpp:664-670, :679-683) are columns EVERY row pair shares - more of them than the compressed form has common
+    // slots - and all lie in the leading lead_k state columns: they go into a dense [Mp x lead_k] block of their own (zero
+    // wherever the compressed rows hold the column: Wsb, Tsb, Wbc, Tbc), which the update multiplies by two skinny GEMMs
+    double* L = a.lead + (long)filt * a.strideLead;
+    for (int e = tid; e < a.Mp * a.lead_k; e += 256) {
+      const int m = e % a.Mp, k = e / a.Mp, f = m >> 1, i = m & 1;
+      double v = 0.0;
+      if (f < sb.F && sb.mask[(long)filt * sb.Fmax + f]) {
+        const double* Jc = sb.Jc + ((long)filt * sb.Fmax + f) * 44 + i * 22;
+        if (sb.cl.td >= 0) {
+          if (k == sb.cl.td) v = Jc[0];
+          else if (sb.cl.Cg >= 0 && k >= sb.cl.Cg && k < sb.cl.Cg + 9) v = Jc[1 + k - sb.cl.Cg];
+          else if (k >= 9 && k < 12) v = Jc[10 + k - 9];
+        }
+        if (k >= sb.cl.cam_begin && k < sb.cl.cam_begin + sb.cl.cam_dim) v = Jc[13 + k - sb.cl.cam_begin];
+      }
+      L[m + (long)k * a.Mp] = v;
+    }
+  }
   // one thread per (pair, slot): consecutive threads write consecutive 16-byte value slots / 4-byte index slots (a thread
   // per pair wrote 84 scalars 448 bytes apart from its neighbour's: 0.32 ms per 4096 filters, bound by the store count)
   const d2 zero2 = d2{0.0, 0.0};
@@ -2937,7 +3012,8 @@ int launch_jac_instate(const SceneBuffers& sb, const xivo_layout& lay, const xiv
 int launch_gate_sparse(const GateArgs& a, hipStream_t s) {
   int nt = a.batch < 256 ? 1024 : 256;
   // distances + threshold | slot indices | per-wave scratch of feature_chi2_lds (64 KB without an opt-in: fewer waves if F is large)
-  auto lds_of = [&](int t) { return ((size_t)(a.sb.F + 1) + (2 * a.sb.F + 1) / 2 + (size_t)(t / 64) * 484) * sizeof(double); };
+  const size_t scr = a.sb.Jc ? WIDE_SCR : 484;
+  auto lds_of = [&](int t) { return ((size_t)(a.sb.F + 1) + (2 * a.sb.F + 1) / 2 + (size_t)(t / 64) * scr) * sizeof(double); };
   while (nt > 64 && lds_of(nt) > 65536) nt /= 2;
   const size_t lds = lds_of(nt);
   hipLaunchKernelGGL(gate_sparse_kernel, dim3(a.batch), dim3(nt), lds, s, a);

@@ -26,6 +26,7 @@ namespace {
 
 struct HRow {   // row-pair compressed or dense access to one filter's H
   const int* idx; const double* val; const double* Hd; int ldh; int N; bool dense; int dense_from;   // rows >= dense_from are dense
+  const double* lead; int ldlead, lead_k;   // calibration columns of a compressed row (dense block over the leading lead_k state columns), or null
   // calls f(col, value) for every stored entry of row m (dense: every column, zeros included)
   template <class F>
   __device__ __forceinline__ void for_each(int m, F&& f) const {
@@ -36,6 +37,10 @@ struct HRow {   // row-pair compressed or dense access to one filter's H
       for (int t = 0; t < ELL_W; ++t) {
         const double v = val[((long)p * ELL_W + t) * 2 + h];
         if (v != 0.0) f(idx[(long)p * ELL_W + t], v);
+      }
+      for (int k = 0; lead && k < lead_k; ++k) {
+        const double v = lead[m + (long)k * ldlead];
+        if (v != 0.0) f(k, v);
       }
     }
   }
@@ -63,6 +68,7 @@ __global__ __launch_bounds__(1024) void ldlt_fallback_kernel(LdltFallbackArgs a)
   H.idx = a.ell.idx + (long)filt * a.ell.stride_idx(); H.val = a.ell.val + (long)filt * a.ell.stride_val();
   H.Hd = a.H + (long)filt * a.strideH; H.ldh = a.ldh; H.N = N;
   H.dense_from = a.mixed_row0 >= 0 ? a.mixed_row0 : (1 << 30);
+  H.lead = a.lead ? a.lead + (long)filt * a.strideLead : nullptr; H.ldlead = a.ldlead; H.lead_k = a.lead_k;
 
   __shared__ int perm[512];       // transpositions (M <= 384)
   __shared__ double sred[1024];
