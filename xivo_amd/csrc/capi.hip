@@ -704,6 +704,16 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
 //   T = K (HP) - P = (KH - I) P   gemm (MFMA)      estimator.cpp:1276-1280 (left product)
 //   G = T H^T + K R               ell_mul<G>
 //   P+ = G K^T - T                gemm (MFMA)      = T (KH-I)^T + K R K^T, estimator.cpp:1280-1287
+// debugging aid (XIVO_HIP_DUMP_DIR=<dir>): raw doubles of a device buffer of the first filter of the range into <dir>/<name>.f64
+static void dump_dev(xivo_hip_ctx* c, const char* name, const double* d, size_t n) {
+  const char* dir = getenv("XIVO_HIP_DUMP_DIR");
+  if (!dir || !d) return;
+  std::vector<double> h(n);
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return;
+  char path[512]; snprintf(path, sizeof(path), "%s/%s.f64", dir, name);
+  if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(double), n, f); fclose(f); }
+}
+
 static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams* gate) {
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
   double* P = c->P + (long)b0 * c->sP;
@@ -751,13 +761,15 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (rc) return rc;
   }
   // online-calibration stacking on the sparse pipeline: the calibration columns of H live in the leading dense block
-  // L [Mp x LEAD_K] (stack_kernel): H P += L P[0:LEAD_K, :] on the MFMA product, the transpose going to P H^T as it is written
-  const bool lead = c->lead_valid && mr0 < 0;
+  // L [Mp x LEAD_K] (stack_kernel): P H^T += P[:, 0:LEAD_K] L^T on the MFMA product
+  const bool lead = c->lead_valid && mr0 < 0 && !getenv("XIVO_HIP_DEBUG_SKIP_LEAD");
   const double* Ld = lead ? c->Hlead + (long)b0 * c->Mpmax * LEAD_K : nullptr;
   const long sLd = (long)c->Mpmax * LEAD_K;
+  const int ldl = c->Mpmax;   // (stack_kernel lays the block out on the allocated row count)
   if (lead) {
-    GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = HP; x.sMsub = c->sH; x.ldmsub = ldh; x.C2 = PHT; x.sC2 = c->sK; x.ldc2 = Np;
-    rc = gemm(c, ST_HP, B, Mp, Np, Ld, sLd, Mp, P, c->sP, Np, LEAD_K, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, HP, c->sH, ldh, x);
+    // (the tiled walk writes P H^T only: this product completes it in place and leaves the complete H P as its transposed copy)
+    GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = PHT; x.sMsub = c->sK; x.ldmsub = Np; x.C2 = HP; x.sC2 = c->sH; x.ldc2 = ldh;
+    rc = gemm(c, ST_HP, B, Np, Mp, P, c->sP, Np, Ld, sLd, ldl, LEAD_K, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, PHT, c->sK, Np, x);
     if (rc) return rc;
   }
   GateEllArgs ga{};
@@ -795,10 +807,17 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
               S + mr0 + (long)mr0 * lds, c->sS, lds, x);
     if (rc) return rc;
   }
-  if (lead) {   // S += L (H P)^T[0:LEAD_K, :] - the walk above covered the compressed columns of H against the complete P H^T
+  if (lead) {
+    // S += (H P)[:, 0:LEAD_K] L^T. The walk above left, in the lower triangle, S[i, j] = sum over the COMPRESSED columns k of
+    // row j of (H P)[i, k] H[j, k] with the complete H P: what is missing is the same sum over row j's calibration columns
+    // (the order of the operands matters - L (H P)^T is the transpose, and neither term is symmetric on its own)
     GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = S; x.sMsub = c->sS; x.ldmsub = lds; x.lower_only = 1;
-    rc = gemm(c, ST_S, B, Mp, Mp, Ld, sLd, Mp, HP, c->sH, ldh, LEAD_K, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, S, c->sS, lds, x);
+    rc = gemm(c, ST_S, B, Mp, Mp, HP, c->sH, ldh, Ld, sLd, ldl, LEAD_K, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, S, c->sS, lds, x);
     if (rc) return rc;
+  }
+  if (getenv("XIVO_HIP_DUMP_DIR")) {
+    dump_dev(c, "S", S, (size_t)c->sS); dump_dev(c, "PHT", PHT, (size_t)c->sK); dump_dev(c, "HP", HP, (size_t)c->sH);
+    dump_dev(c, "P", P, (size_t)c->sP); if (lead) dump_dev(c, "Hlead", Ld, (size_t)sLd);
   }
   const bool lat = latency_route(c, Mp, B, full);
   const bool t_full = full || getenv("XIVO_HIP_T_FULL");
@@ -951,7 +970,7 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   a.ell.nc += b0; a.ell.pw += b0; a.ell.over += b0;
   a.H = c->H + (long)b0 * c->sH; a.strideH = c->sH; a.ldh = c->Mpmax; a.use_dense = c->last_path == 0 ? 1 : 0;
   a.mixed_row0 = c->last_path == 1 ? c->mixed_row0 : -1;
-  if (c->last_path == 1 && c->lead_valid) { a.lead = c->Hlead + (long)b0 * c->Mpmax * LEAD_K; a.strideLead = (long)c->Mpmax * LEAD_K; a.ldlead = c->Mp; a.lead_k = LEAD_K; }
+  if (c->last_path == 1 && c->lead_valid) { a.lead = c->Hlead + (long)b0 * c->Mpmax * LEAD_K; a.strideLead = (long)c->Mpmax * LEAD_K; a.ldlead = c->Mpmax; a.lead_k = LEAD_K; }
   a.PHT = c->PHT + (long)b0 * c->sK; a.stridePHT = c->sK; a.ldpht = c->Np;
   a.S = c->S + (long)b0 * c->sS; a.strideS = c->sS; a.lds = c->Mpmax;
   a.K = c->K + (long)b0 * c->sK; a.strideK = c->sK; a.ldk = c->Np;

@@ -497,51 +497,64 @@ __device__ __forceinline__ double feature_chi2_lds(const double* P, int ldp, con
 // from the 21 x 21 sub-block of P the feature touches (J is structurally
 // sparse), reduces it across lanes, and the 2x2 LLT gives the Mahalanobis
 // distance. Then one wave runs the threshold-relaxation loop.
-// Online-calibration builds: J() has 22 more columns every feature shares - td, Cg (9), bg (3), the intrinsics (9 slots) - next
-// to the 21 of the default build (src/feature.cpp:623-651): the same gather on 43 columns, two rows per lane.
-constexpr int WIDE_NC = 43, WIDE_SCR = WIDE_NC * WIDE_NC + 2 * WIDE_NC + 1;   // doubles of LDS scratch per wave (1936)
-__device__ __forceinline__ int jcol_wide(const xivo_layout& lay, const xivo_calib_layout& cl, const xivo_feat_in& ft, int c) {
-  if (c < 21) return jcol(lay, ft, c);
-  const int k = c - 21;                                   // the layout of Jc: td | Cg 9 | bg 3 | intrinsics 9
-  if (k == 0) return cl.td >= 0 ? cl.td : 0;              // (a block that is switched off carries zeros: any valid column will do)
+// Online-calibration builds: J() has 22 more columns EVERY feature shares - td, Cg (9), bg (3), the intrinsics (9 slots) - next
+// to the 21 of the default build (src/feature.cpp:623-651); 12 of those 21 (Wsb, Tsb, Wbc, Tbc) are shared as well. The 34 x 34
+// block of P on the shared columns is therefore the same for all features of a filter: the workgroup parks it in LDS once,
+// and a feature gathers only its 9 private columns (group, feature) against the shared ones and themselves - 387 elements,
+// seven wave-wide loads as in the default build, instead of the 43 x 43 = 1849 of a gather per feature (2.0 -> 0.46 ms per 4096
+// filters x 60 features at N = 276). The sums run over the 43 columns in the order of the whole row, as before.
+constexpr int WIDE_NS = 34, WIDE_NP = 9, WIDE_NC = 43;
+constexpr int WIDE_X = WIDE_NS * WIDE_NP, WIDE_Y = WIDE_NP * WIDE_NP;         // P[shared, private] | P[private, private]
+constexpr int WIDE_SCR = WIDE_X + WIDE_Y + 2 * WIDE_NC + 1;                   // doubles of LDS scratch per wave (474)
+constexpr int WIDE_PSS = WIDE_NS * WIDE_NS;                                   // doubles of the per-filter shared block
+__device__ __forceinline__ int wide_scol(const xivo_calib_layout& cl, int s) {   // state column of shared slot s
+  if (s < 6) return s;                                    // Index::Wsb, Tsb
+  if (s < 12) return 15 + (s - 6);                        // Index::Wbc, Tbc
+  const int k = s - 12;                                   // the layout of Jc: td | Cg 9 | bg 3 | intrinsics 9
+  if (k == 0) return cl.td >= 0 ? cl.td : 0;              // (a block that is switched off carries zeros in Jc: any valid column will do)
   if (k < 10) return cl.Cg >= 0 ? cl.Cg + (k - 1) : 0;
   if (k < 13) return 9 + (k - 10);                        // Index::bg
   return (k - 13) < cl.cam_dim ? cl.cam_begin + (k - 13) : 0;
 }
 __device__ __forceinline__ double feature_chi2_wide(const double* P, int ldp, const xivo_layout& lay, const xivo_calib_layout& cl,
                                                     const xivo_feat_in& ft, const double* J, const double* Jc, const double* inn, double R,
-                                                    int lane, double* scratch) {
-  double* sP = scratch;                       // [a + 43 b]
-  double* sJ = scratch + WIDE_NC * WIDE_NC;   // [row * 43 + b]
-  for (int e0 = 0; e0 < WIDE_NC * WIDE_NC; e0 += 64 * 8) {
-    double pv[8];
+                                                    int lane, const double* sPss, double* scratch) {
+  double* X = scratch;                        // [s + 34 p] = P[shared s, private p]
+  double* Y = scratch + WIDE_X;               // [p + 9 q]
+  double* sJ = scratch + WIDE_X + WIDE_Y;     // [row * 43 + w], w in the order of the whole row: 12 common | 9 private | 22 calibration
+  auto pcol = [&](int q) -> int { return q < 6 ? lay.group_begin + 6 * ft.ref_sind + q : lay.feature_begin + 3 * ft.sind + (q - 6); };
+  double pv[7];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int e = e0 + lane + 64 * k;
-      const int ea = e < WIDE_NC * WIDE_NC ? e % WIDE_NC : 0, eb = e < WIDE_NC * WIDE_NC ? e / WIDE_NC : 0;
-      pv[k] = P[jcol_wide(lay, cl, ft, ea) + (long)jcol_wide(lay, cl, ft, eb) * ldp];
-    }
+  for (int k = 0; k < 7; ++k) {
+    const int e = lane + 64 * k;
+    int row = 0, col = 0;
+    if (e < WIDE_X) { row = wide_scol(cl, e % WIDE_NS); col = pcol(e / WIDE_NS); }
+    else if (e < WIDE_X + WIDE_Y) { const int q = e - WIDE_X; row = pcol(q % WIDE_NP); col = pcol(q / WIDE_NP); }
+    pv[k] = P[row + (long)col * ldp];
+  }
+  double j0 = 0.0, j1 = 0.0;
+  if (lane < WIDE_NC) { j0 = lane < 21 ? J[lane] : Jc[lane - 21]; j1 = lane < 21 ? J[21 + lane] : Jc[22 + lane - 21]; }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int e = e0 + lane + 64 * k;
-      if (e < WIDE_NC * WIDE_NC) sP[e] = pv[k];
-    }
+  for (int k = 0; k < 7; ++k) {
+    const int e = lane + 64 * k;
+    if (e < WIDE_X + WIDE_Y) scratch[e] = pv[k];
   }
-  if (lane < WIDE_NC) {
-    sJ[lane] = lane < 21 ? J[lane] : Jc[lane - 21];
-    sJ[WIDE_NC + lane] = lane < 21 ? J[21 + lane] : Jc[22 + lane - 21];
-  }
+  if (lane < WIDE_NC) { sJ[lane] = j0; sJ[WIDE_NC + lane] = j1; }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   double v0 = 0.0, v1 = 0.0;
   if (lane < WIDE_NC) {
-    for (int b = 0; b < WIDE_NC; ++b) {
-      const double p = sP[lane + WIDE_NC * b];
-      v0 = fma(p, sJ[b], v0);
-      v1 = fma(p, sJ[WIDE_NC + b], v1);
-    }
+    // lane a of the whole row: shared (a < 12 or a >= 21: slot a or a - 9) or private (slot a - 12)
+    const bool ash = lane < 12 || lane >= 21;
+    const int as = lane < 12 ? lane : lane - 9, ap = lane - 12;
+    const double* ps = ash ? sPss + as : X + WIDE_NS * ap;   // P[a, shared b]: step over b
+    const int ss = ash ? WIDE_NS : 1;
+    const double* pp = ash ? X + as : Y + ap;                // P[a, private b]
+    const int sp = ash ? WIDE_NS : WIDE_NP;
+    for (int b = 0; b < 12; ++b) { const double p = ps[b * ss]; v0 = fma(p, sJ[b], v0); v1 = fma(p, sJ[WIDE_NC + b], v1); }
+    for (int b = 12; b < 21; ++b) { const double p = pp[(b - 12) * sp]; v0 = fma(p, sJ[b], v0); v1 = fma(p, sJ[WIDE_NC + b], v1); }
+    for (int b = 21; b < WIDE_NC; ++b) { const double p = ps[(b - 9) * ss]; v0 = fma(p, sJ[b], v0); v1 = fma(p, sJ[WIDE_NC + b], v1); }
   }
-  const double j0 = lane < WIDE_NC ? sJ[lane] : 0.0, j1 = lane < WIDE_NC ? sJ[WIDE_NC + lane] : 0.0;
   __builtin_amdgcn_wave_barrier();
   const double s00 = wave_sum(j0 * v0) + R;
   const double s10 = wave_sum(j1 * v0);
@@ -565,7 +578,11 @@ __global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
   // P and J right away instead of behind a load of the entry (two dependent memory round trips per feature, fifteen
   // features per wave one after the other, were what the kernel's time was)
   int* s_slot = reinterpret_cast<int*>(sdist + sb.F + 1);   // [2 F]: sind, ref_sind
-  double* s_scr = sdist + sb.F + 1 + (2 * sb.F + 1) / 2 + (long)wave * (sb.Jc ? WIDE_SCR : 484);   // per wave: feature_chi2_lds / _wide scratch
+  double* s_pss = sdist + sb.F + 1 + (2 * sb.F + 1) / 2;    // online-calibration builds: P on the 34 shared columns
+  double* s_scr = s_pss + (sb.Jc ? WIDE_PSS : 0) + (long)wave * (sb.Jc ? WIDE_SCR : 484);   // per wave: feature_chi2_lds / _wide scratch
+  if (sb.Jc && a.use_gating) {
+    for (int e = tid; e < WIDE_PSS; e += nt) s_pss[e] = P[wide_scol(sb.cl, e % WIDE_NS) + (long)wide_scol(sb.cl, e / WIDE_NS) * a.ldp];
+  }
   {
     int cnt = 0;
     for (int f = tid; f < sb.F; f += nt) {
@@ -586,7 +603,7 @@ __global__ __launch_bounds__(1024) void gate_sparse_kernel(GateArgs a) {
       if (ft.sind < 0) { if (lane == 0) sdist[f] = __builtin_inf(); continue; }
       const double* J = sb.J + ((long)filt * sb.Fmax + f) * 42;
       const double* inn = sb.finn + ((long)filt * sb.Fmax + f) * 2;
-      const double d = sb.Jc ? feature_chi2_wide(P, a.ldp, a.lay, sb.cl, ft, J, sb.Jc + ((long)filt * sb.Fmax + f) * 44, inn, a.R, lane, s_scr)
+      const double d = sb.Jc ? feature_chi2_wide(P, a.ldp, a.lay, sb.cl, ft, J, sb.Jc + ((long)filt * sb.Fmax + f) * 44, inn, a.R, lane, s_pss, s_scr)
                              : feature_chi2_lds(P, a.ldp, a.lay, ft, J, inn, a.R, lane, s_scr);
       if (lane == 0) sdist[f] = d;
     }
@@ -3012,8 +3029,8 @@ int launch_jac_instate(const SceneBuffers& sb, const xivo_layout& lay, const xiv
 int launch_gate_sparse(const GateArgs& a, hipStream_t s) {
   int nt = a.batch < 256 ? 1024 : 256;
   // distances + threshold | slot indices | per-wave scratch of feature_chi2_lds (64 KB without an opt-in: fewer waves if F is large)
-  const size_t scr = a.sb.Jc ? WIDE_SCR : 484;
-  auto lds_of = [&](int t) { return ((size_t)(a.sb.F + 1) + (2 * a.sb.F + 1) / 2 + (size_t)(t / 64) * scr) * sizeof(double); };
+  const size_t scr = a.sb.Jc ? WIDE_SCR : 484, pss = a.sb.Jc ? WIDE_PSS : 0;
+  auto lds_of = [&](int t) { return ((size_t)(a.sb.F + 1) + (2 * a.sb.F + 1) / 2 + pss + (size_t)(t / 64) * scr) * sizeof(double); };
   while (nt > 64 && lds_of(nt) > 65536) nt /= 2;
   const size_t lds = lds_of(nt);
   hipLaunchKernelGGL(gate_sparse_kernel, dim3(a.batch), dim3(nt), lds, s, a);

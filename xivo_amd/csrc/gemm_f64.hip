@@ -540,6 +540,7 @@ int launch_gemm_nt_f64(const GemmArgs& a_in, hipStream_t stream) {
   if (no_strip && a.lower_only) a.lower_only = 2;
   int wm, wn;
   pick_for(a, &wm, &wn);
+  if (wm == 3 && wn == 3 && a.lower_only == 1) a.lower_only = 2;   // diagonal tiles in full on the straight-line path, stored as lower triangle + mirror
 #define XIVO_GEMM_CASE(M_, N_) \
   if (wm == M_ && wn == N_) return launch_t<M_, N_>(a, stream);
   XIVO_GEMM_CASE(2, 2) XIVO_GEMM_CASE(2, 3) XIVO_GEMM_CASE(2, 4) XIVO_GEMM_CASE(2, 5)
@@ -562,6 +563,9 @@ static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
   // few filters (the latency route of the update, chol_trsm.hip): 64 x 64 tiles - ten workgroups per symmetric 256 x 256
   // output instead of three, on a chip that is empty anyway
   if (a.small_tiles && a.lower_only && a.Mp > 64 && !a.fp32) { wm = 2; wn = 2; }
+  // symmetric outputs whose side is a multiple of 96 but not of 128 (N = 276 -> 288: the online-calibration build): 96 x 96
+  // tiles cover them without padding - 6 tiles of 96^2 instead of 6 of 128^2 over a 384-wide grid
+  else if (a.lower_only && !a.fp32 && a.Mp == a.Np && a.Mp % 96 == 0 && a.Mp % 128 != 0 && !getenv("XIVO_HIP_NO_TILE96")) { wm = 3; wn = 3; }
   *wm_out = wm; *wn_out = wn;
 }
 
