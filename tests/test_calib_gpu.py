@@ -12,7 +12,7 @@ import xivo_oracle as orc
 from helpers import rel_fro, TOL_P, TOL_DX
 from scene_util import scene_arrays, spd
 from xivo_amd import synth
-from xivo_amd.lib import Context, calib_dtype, cam_intr, imu_dtype
+from xivo_amd.lib import Context, calib_dtype, cam_intr, imu_dtype, oos_dtype
 
 pytestmark = pytest.mark.gpu
 CAMS = {"pinhole": synth.PINHOLE, "equi": synth.EQUI, "radtan": synth.RADTAN, "atan": synth.ATAN}
@@ -31,7 +31,7 @@ def rows(request, monkeypatch):
     return 0 if request.param == "dense" else 1
 
 
-def setup(name, temporal, imu, camera, B=3, ng=6, nf=14, seed=3):
+def setup(name, temporal, imu, camera, B=3, ng=6, nf=14, seed=3, M_extra=0):
     cam = CAMS[name]
     lay = orc.calib_layout(ng, nf, temporal, imu, CAM_DIM[name] if camera else 0)
     sc = synth.g_level(ng, nf, nf, B, seed=seed, cam=cam)
@@ -46,7 +46,7 @@ def setup(name, temporal, imu, camera, B=3, ng=6, nf=14, seed=3):
         calib[b]["gyro"], calib[b]["Cg"], calib[b]["td"] = cal["gyro"], cal["Cg"].T.reshape(-1), cal["td"]
         calib[b]["Ca"], calib[b]["intr"] = np.eye(3).reshape(-1), cam_intr(cam)
         cals.append(cal)
-    ctx = Context(lay.N, 2 * nf, B)
+    ctx = Context(lay.N, 2 * nf + M_extra, B)
     ctx.set_layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf, cam)
     ctx.set_calib(lay.td, lay.Cg, lay.cam_begin, lay.cam_dim)
     return cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx
@@ -149,6 +149,110 @@ def test_stand_alone_gate_and_calibration_off_again(built, rows):
         ctx.upload_P(np.array([spd(lay.N, 5 + b) * 1e-4 for b in range(3)]))
         ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)
         assert ctx.last_path() == 1                                                             # compressed rows, sparse pipeline
+
+
+@pytest.mark.parametrize("name", ["radtan", "pinhole"])
+def test_indefinite_S_of_a_calibration_stacking_takes_the_ldlt_fallback(built, rows, name):
+    """A covariance that lost its definiteness under an online-calibration stacking: the L D L^T fallback forms S from the
+    compressed rows AND the leading dense block of the calibration columns (rows == 1) or from the dense rows (rows == 0);
+    P+ and dx equal the oracle's as-coded update, the regular filters of the batch are untouched by it."""
+    cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup(name, True, True, True, B=4, ng=6, nf=14, seed=21)
+    B = 4
+    P = np.array([spd(lay.N, 300 + b) * 1e-4 for b in range(B)])
+    w, Q = np.linalg.eigh(P[1]); w[-3:] *= -1.0
+    P[1] = (Q * w) @ Q.T; P[1] = 0.5 * (P[1] + P[1].T)
+    P[3] = -P[3]
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=False)
+        assert ctx.last_path() == rows
+        st = ctx.get_status(check=False); used = ctx.get_ldlt_used()
+        Pn, err = ctx.download_P(), ctx.get_err()
+    assert (st == 0).all() and used.tolist() == [0, 1, 0, 1]
+    for b in range(B):
+        Js, inns, _ = oracle_rows(sc, cam, lay, xp, cals, b)
+        H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][b], sc["sind"][b], lay, R_VIS)
+        if b in (1, 3):
+            assert np.linalg.eigvalsh(H @ P[b] @ H.T + np.diag(dR)).min() < 0
+        e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+def test_oos_rows_behind_a_calibration_stacking(built, rows):
+    """OOS rows appended behind an online-calibration stacking: whatever form the in-state rows were stacked in, the update
+    sees dense rows that carry the calibration columns themselves (re-stacked on demand) + the OOS block, dense pipeline."""
+    ng, nf, n_oos, B = 8, 6, 3, 2
+    cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup("pinhole", True, True, True, B=B, ng=ng, nf=nf, seed=5, M_extra=3 * 13)
+    rng = np.random.default_rng(9)
+    oos = np.zeros((B, n_oos), dtype=oos_dtype)
+    obs_all = {}
+    for b in range(B):
+        for o in range(n_oos):
+            k = [5, 2, 8][o]
+            Xs = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(3, 6)])
+            gs = rng.permutation(ng)[:k]
+            oos[b, o]["Xs"] = Xs; oos[b, o]["n_obs"] = k
+            obs = []
+            for q, g in enumerate(gs):
+                _, _, inn = orc.oos_jacobian_internal(Xs, sc["gR"][b, g], sc["gT"][b, g], sc["Rbc"][b], sc["Tbc"][b], [0, 0], cam, lay, int(g))
+                pix = -inn + rng.normal(0, 1.0, 2)
+                oos[b, o]["group_sind"][q] = g; oos[b, o]["xp"][q] = pix
+                obs.append((int(g), pix))
+            obs_all[b, o] = (Xs, obs)
+    P = np.array([spd(lay.N, 40 + b) * 1e-4 for b in range(B)])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        ctx.jacobians_instate(); mask, _ = ctx.mh_gate(R_VIS, MH, MULT, 5); ctx.stack(R_VIS)
+        nrows = ctx.oos_project(oos, 3.5 ** 2)
+        ctx.update_joseph()
+        assert ctx.last_path() == 0
+        got = [ctx.get_H(b) for b in range(B)]
+        err = ctx.get_err(); Pn = ctx.download_P()
+    assert nrows.tolist() == [7 + 1 + 13] * B and mask.all()
+    for b in range(B):
+        Js, inns, _ = oracle_rows(sc, cam, lay, xp, cals, b)
+        H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][b], sc["sind"][b], lay, R_VIS)
+        for o in range(n_oos):
+            Xs, obs = obs_all[b, o]
+            Hxp, rp, _ = orc.oos_jacobian(Xs, obs, sc["gR"][b], sc["gT"][b], sc["Rbc"][b], sc["Tbc"][b], cam, lay)
+            H = np.vstack([H, Hxp]); inn = np.concatenate([inn, rp]); dR = np.concatenate([dR, np.full(len(rp), 3.5 ** 2)])
+        assert got[b][0].shape == H.shape and rel_fro(got[b][0], H) < 1e-10 and rel_fro(got[b][1], inn) < 1e-9
+        assert np.abs(H[:2 * nf, lay.td]).max() > 0 and np.abs(got[b][0][:2 * nf, lay.Cg:lay.Cg + 9]).max() > 0
+        e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+
+
+def test_gated_update_on_a_calibration_stacking_gates_the_whole_rows(built, rows):
+    """xivo_hip_update_dense_gated after xivo_hip_stack on an online-calibration context: the gate inside the update works on
+    (H P) H^T of the WHOLE stacked rows - a stacking with the leading block is re-stacked densely for it (dense pipeline)."""
+    cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx = setup("equi", True, True, True, B=3, ng=6, nf=14, seed=14)
+    feats["xp"][1, [3, 9]] += 55.0; xp[1, [3, 9]] += 55.0
+    B, F = 3, feats.shape[1]
+    P = np.array([spd(lay.N, 15 + b) * 1e-4 for b in range(B)])
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        ctx.jacobians_instate()
+        ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=False)          # (leaves every present feature in the mask)
+        ctx.upload_P(P)
+        ctx.stack(R_VIS)
+        ctx.update_dense_gated(F, R_VIS, MH, MULT, 5)
+        assert ctx.last_path() == 0
+        mask, dist = ctx.get_gate(F, B)
+        err = ctx.get_err(); Pn = ctx.download_P()
+    rej = 0
+    for b in range(B):
+        Js, inns, _ = oracle_rows(sc, cam, lay, xp, cals, b)
+        H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][b], sc["sind"][b], lay, R_VIS)
+        # the gate of the S level sees the rows AS STACKED (FillJacobianBlock's overwrite included), not J()
+        d = np.array([inn[2 * f:2 * f + 2] @ np.linalg.solve(H[2 * f:2 * f + 2] @ P[b] @ H[2 * f:2 * f + 2].T + R_VIS * np.eye(2), inn[2 * f:2 * f + 2])
+                      for f in range(F)])
+        m, _, _ = orc.mh_gate(d, MH, MULT, 5)
+        assert np.array_equal(mask[b].astype(bool), m) and rel_fro(dist[b], d) < 1e-9
+        rej += int((~m).sum())
+        keep = np.repeat(m, 2)
+        e_ref, P_ref, _ = orc.update_joseph(H[keep], P[b], inn[keep], dR[keep])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+    assert rej >= 2
 
 
 @pytest.mark.parametrize("name", ["radtan", "equi"])

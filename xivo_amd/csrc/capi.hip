@@ -271,6 +271,7 @@ struct GemmExtra {
   const double* msub = nullptr; long sMsub = 0; int ldmsub = 0;
   const double* mcol = nullptr; long sMcol = 0;
   double* C2 = nullptr; long sC2 = 0; int ldc2 = 0;
+  int c2_rows = 0;   // > 0: the transposed copy only of the leading c2_rows rows of C (the columns of C2 a consumer reads)
   int lower_only = 0;
   int fp32 = 0;
   int a_f32 = 0;   // first operand stored as float
@@ -294,7 +295,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
     g.nseg = 2;
   }
   g.C = C; g.strideC = sC; g.ldc = ldc; g.Mp = rows; g.Np = cols;
-  g.C2 = x.C2; g.strideC2 = x.sC2; g.ldc2 = x.ldc2;
+  g.C2 = x.C2; g.strideC2 = x.sC2; g.ldc2 = x.ldc2; g.c2_rows = x.c2_rows;
   g.diag = x.diag; g.strideDiag = x.sDiag; g.Msub = x.msub; g.strideMsub = x.sMsub; g.ldmsub = x.ldmsub;
   g.McolScale = x.mcol; g.strideMcol = x.sMcol;
   g.epilogue = x.epi; g.lower_only = x.lower_only; g.no_mirror = x.no_mirror; g.batch = B; g.fp32 = x.fp32;
@@ -746,11 +747,13 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   const int oos_pad = mr0 >= 0 ? round_up16(Mp - mr0) : 0;
   // the OOS rows are zero beyond the extrinsics and group columns (the mode clears and writes nothing else there): the two
   // products of the OOS block contract over the leading oos_k state columns only
+  bool walk_tiled = false;
   const int oos_k = (mr0 >= 0 && c->have_layout) ? std::min(Np, round_up16(c->lay.group_begin + 6 * c->lay.n_groups)) : Np;
   {
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
     a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp_ell; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
     char label[64]; ell_kernel_label(ELL_HP, a, label, sizeof(label));
+    walk_tiled = ell_uses_slab_form(a);   // (the same decision for ell<S> below: it depends on the shape and slot counts only)
     StageTimer st(c, ST_HP, nnz_flops * Nf * B, label, 8.0 * B * ((double)Np * Np + (double)Np * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_HP, a, c->stream));
   }
@@ -767,8 +770,10 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   const long sLd = (long)c->Mpmax * LEAD_K;
   const int ldl = c->Mpmax;   // (stack_kernel lays the block out on the allocated row count)
   if (lead) {
-    // (the tiled walk writes P H^T only: this product completes it in place and leaves the complete H P as its transposed copy)
+    // (the tiled walk writes P H^T only: this product completes it in place and leaves H P as its transposed copy - the
+    //  leading LEAD_K columns the S product below reads, or all of it where ell<S> takes the gather form, which reads H P)
     GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = PHT; x.sMsub = c->sK; x.ldmsub = Np; x.C2 = HP; x.sC2 = c->sH; x.ldc2 = ldh;
+    x.c2_rows = walk_tiled ? LEAD_K : 0;
     rc = gemm(c, ST_HP, B, Np, Mp, P, c->sP, Np, Ld, sLd, ldl, LEAD_K, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, PHT, c->sK, Np, x);
     if (rc) return rc;
   }

@@ -51,6 +51,7 @@ struct GemmArgs {
   double* C2;          // optional second output = C^T (ldc2), e.g. PH^T next to HP
   long strideC2;
   int ldc2;
+  int c2_rows;         // > 0: C2 receives only the transposed copy of rows [0, c2_rows) of C (the columns of C2 its reader needs)
   const double* diag;  // EPI_ADD_DIAG
   long strideDiag;
   const double* Msub;  // EPI_SUB_MAT / EPI_ADD_MAT operand, same shape as C

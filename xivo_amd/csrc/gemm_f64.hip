@@ -406,7 +406,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
 #else
         if (g.lower_only && !g.no_mirror && i2 > j2) Cb[j2 + (long)i2 * g.ldc] = t;
 #endif
-        if (C2b) C2b[j2 + (long)i2 * g.ldc2] = t;
+        if (C2b && (g.c2_rows == 0 || i2 < g.c2_rows)) C2b[j2 + (long)i2 * g.ldc2] = t;
       }
     }
   }
