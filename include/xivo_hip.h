@@ -315,9 +315,16 @@ int xivo_hip_get_jacobians(xivo_hip_ctx* ctx, int b0, int nb, double* J2x21, dou
  * :632-651): d/dtd (2 x 1), d/dCg (2 x 9), d/dbg (2 x 3, at Index::bg) and d/d(intrinsics) (2 x Camera::dim()), which
  * Feature::FillJacobianBlock stacks as well (:664-670, :679-683). xivo_hip_set_calib switches those blocks on for the
  * context: xivo_hip_jacobians_instate then also fills them (xivo_hip_get_jacobians_calib), xivo_hip_stack /
- * xivo_hip_filter_update stack them - as dense rows: such a row pair has up to 34 columns that every feature shares, more
- * than the 16 common slots of the row-pair compressed form - and gate / update through the dense pipeline, whose MH gating
- * uses the whole row as the reference's f->J() does. Slots as the reference's Index enum / kCameraBegin would number them
+ * xivo_hip_filter_update stack them. Such a row pair has up to 34 columns that every feature shares - more than the 16
+ * common slots of the row-pair compressed form - but all of them lie in the leading 48 state columns: the stacking is the
+ * default build's compressed rows + a dense [M x 48] block of the calibration columns, and the update takes the sparse
+ * pipeline with two skinny products on top (round 5; xivo_hip_last_path 1). MH gating uses the whole row as the reference's
+ * f->J() does (43 columns in the compact gate). Where the calibration columns do not fit the leading 48 (cam_begin + 9 > 48),
+ * under XIVO_HIP_FLAG_DENSE_H / _FP32_COV / _SYMMETRIC_FORM / _STANDALONE_TAIL, with the environment knob
+ * XIVO_HIP_CALIB_DENSE, and whenever dense rows are needed after all (OOS rows appended, xivo_hip_update_dense_gated,
+ * xivo_hip_get_H - which therefore sends the NEXT update of that stacking down the dense pipeline) the rows are (re-)stacked
+ * as dense rows and gate / update through the dense pipeline (round 4). Same results within the stated tolerances either way.
+ * Slots as the reference's Index enum / kCameraBegin would number them
  * (the caller's xivo_layout already counts them in N, group_begin, feature_begin); -1 / 0 = that block is not in the build.
  * Motion side of those builds: xivo_hip_propagate_calib (below, next to xivo_hip_propagate) integrates the
  * kMotionSize = 24 / 38 / 39-dimensional motion block with the Cg / Ca columns of ComputeMotionJacobianAt
