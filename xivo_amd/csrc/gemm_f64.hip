@@ -412,13 +412,33 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   }
 }
 
+#ifndef XIVO_GEMM33_BK
+#define XIVO_GEMM33_BK 16     // A/B: k-panel depth of the <3,3> instantiation
+#endif
 template <int WM, int WN>
 constexpr int pick_bk() {
-  return 16;   // 32 measured neutral on MI355X and costs 32 more staging VGPRs
+  return (WM == 3 && WN == 3) ? XIVO_GEMM33_BK : 16;   // 32 measured neutral on MI355X and costs 32 more staging VGPRs
 }
 
+// waves per SIMD (= workgroups per CU) the register budget of an instantiation is cut for (A/B: -DXIVO_GEMM33_WAVES etc.)
+#ifndef XIVO_GEMM33_WAVES
+#define XIVO_GEMM33_WAVES 4   // 128 VGPRs (29 spilled) -> four workgroups per CU: P - V^T Y at N = 276 2.87 -> 2.45 ms per 4096 filters (5: 342 spilled)
+#endif
+#ifndef XIVO_GEMM44F_WAVES
+#define XIVO_GEMM44F_WAVES 0
+#endif
+#ifndef XIVO_GEMM44D_WAVES
+#define XIVO_GEMM44D_WAVES 0
+#endif
 template <int WM, int WN, typename CT>
-__global__ __launch_bounds__(256, (sizeof(CT) == 4 && WM * WN <= 16) ? 3 : 2) void gemm_nt_f64_kernel(GemmArgs g) {
+constexpr int gemm_waves() {
+  if (XIVO_GEMM33_WAVES > 0 && WM == 3 && WN == 3 && sizeof(CT) == 8) return XIVO_GEMM33_WAVES;
+  if (XIVO_GEMM44F_WAVES > 0 && WM == 4 && WN == 4 && sizeof(CT) == 4) return XIVO_GEMM44F_WAVES;
+  if (XIVO_GEMM44D_WAVES > 0 && WM == 4 && WN == 4 && sizeof(CT) == 8) return XIVO_GEMM44D_WAVES;
+  return (sizeof(CT) == 4 && WM * WN <= 16) ? 3 : 2;
+}
+template <int WM, int WN, typename CT>
+__global__ __launch_bounds__(256, (gemm_waves<WM, WN, CT>())) void gemm_nt_f64_kernel(GemmArgs g) {
   constexpr int BK = pick_bk<WM, WN>();
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int LDAS = BM + 16, LDBS = BN + 16;
@@ -563,9 +583,12 @@ static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
   // few filters (the latency route of the update, chol_trsm.hip): 64 x 64 tiles - ten workgroups per symmetric 256 x 256
   // output instead of three, on a chip that is empty anyway
   if (a.small_tiles && a.lower_only && a.Mp > 64 && !a.fp32) { wm = 2; wn = 2; }
-  // symmetric outputs whose side is a multiple of 96 but not of 128 (N = 276 -> 288: the online-calibration build): 96 x 96
-  // tiles cover them without padding - 6 tiles of 96^2 instead of 6 of 128^2 over a 384-wide grid
-  else if (a.lower_only && !a.fp32 && a.Mp == a.Np && a.Mp % 96 == 0 && a.Mp % 128 != 0 && !getenv("XIVO_HIP_NO_TILE96")) { wm = 3; wn = 3; }
+  // fp64 symmetric outputs whose side is a multiple of 96 but not of 128 (N = 276 -> 288: the online-calibration build: 6
+  // tiles of 96^2 instead of 6 of 128^2 over a 384-wide grid), or beyond 256 and not a multiple of 128 (N = 400: config 4):
+  // 96 x 96 tiles on the instantiation that keeps four workgroups per CU (these products are short in K - M <= 304 - and
+  // bound by the latency of their panel loads, not by MFMA or HBM: P - V^T Y 4.05 -> 2.45 ms per 4096 filters at N = 276,
+  // 7.35 -> 6.9 ms at N = 400; the fp32 product of config 4 measured the same on either tile and keeps 128 x 128)
+  else if (a.lower_only && !a.fp32 && a.Mp == a.Np && (a.Mp % 96 == 0 || a.Mp > 256) && a.Mp % 128 != 0 && !getenv("XIVO_HIP_NO_TILE96")) { wm = 3; wn = 3; }
   *wm_out = wm; *wn_out = wn;
 }
 
