@@ -620,25 +620,55 @@ def test_cholesky_kernels_are_bit_identical(built):
     front or per block column, the opt-in timing of XIVO_HIP_AUTOTUNE), P+ and dx come out bit for bit the same - across
     nodes, ranks, runs and batch sizes. Round 5: so does the factorisation INSIDE the solve kernel (opt-in, XIVO_HIP_FUSED_CHOL:
     measured slower than the stand-alone kernels): block row i on wave i, the factor in LDS, half of the right-hand sides joining
-    the forward substitution late - the same bits. And the ten-wave, two-per-CU
-    instantiation of the solve for (150, 100) (opt-in, XIVO_HIP_NARROW_SOLVE: measured slower - that shape is HBM-bound)."""
+    the forward substitution late - the same bits. And the three forms of the solve for (150, 100): ten waves with W kept in
+    registers (default), ten waves twice per CU with the stash (XIVO_HIP_NARROW_SOLVE=1), the sixteen-wave kernel (=0)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     knobs = ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG", "XIVO_HIP_CHOL_LOOKAHEAD", "XIVO_HIP_CHOL_NO_LOOKAHEAD",
              "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE", "XIVO_HIP_CHOL_NO_REG8", "XIVO_HIP_FUSED_CHOL", "XIVO_HIP_NARROW_SOLVE")
     res = []
-    for knob in (("XIVO_HIP_CHOL_WAVE",), (), ("XIVO_HIP_FUSED_CHOL",), ("XIVO_HIP_NARROW_SOLVE",), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
+    for knob in (("XIVO_HIP_CHOL_WAVE",), (), ("XIVO_HIP_FUSED_CHOL",), ("XIVO_HIP_NARROW_SOLVE",), ("XIVO_HIP_NARROW_SOLVE=0",), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
                  ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS"), ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_NO_LOOKAHEAD"),
                  ("XIVO_HIP_AUTOTUNE",), ("XIVO_HIP_CHOL_NO_REG8",)):
         env = dict(os.environ)
         for k in knobs:
             env.pop(k, None)
         for k in knob:
-            env[k] = "1"
+            env[k.split("=")[0]] = k.split("=")[1] if "=" in k else "1"
         r = subprocess.run([sys.executable, "-c", _CHOL_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert all(r == res[0] for r in res[1:]), res
+
+
+@pytest.mark.parametrize("N,F,waves", [(150, 50, 10), (147, 49, 10), (180, 53, 12), (192, 56, 12)])
+def test_seven_block_rows_on_a_narrow_state_keep_W_in_registers(built, N, F, waves):
+    """Round 5: a factor of seven block rows (M <= 112) on a state of at most 160 / 192 columns takes the ten- / twelve-wave
+    instantiation of the solve kernel whose 170 VGPRs per wave hold the right-hand sides AND W (no stash through HBM):
+    P+ and dx against the oracle, rejected features and a non-SPD filter included."""
+    from xivo_amd.lib import FLAG_PROFILE
+    B = 70
+    P, H, inn, dR = synth.s_level(N, F, 8, seed=3 * N + F)
+    idx = np.arange(B) % 8
+    P, H, inn, dR = P[idx].copy(), H[idx].copy(), inn[idx].copy(), dR[idx].copy()
+    inn[5, 4:8] *= 300.0                                    # two features of filter 5 fail the gate
+    P[9] = -P[9]                                            # filter 9: S negative definite -> L D L^T fallback
+    with Context(N, 2 * F, B, flags=FLAG_THROUGHPUT_ROUTE | FLAG_PROFILE) as ctx:
+        ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
+        ctx.update_dense_gated(F, float(dR[0, 0]), 5.991, 1.1, 5)
+        assert ctx.last_path() == 1
+        prof = ctx.profile_get()
+        mask, _ = ctx.get_gate(F, B)
+        st = ctx.get_status(check=False); used = ctx.get_ldlt_used()
+        Pn, err = ctx.download_P(), ctx.get_err()
+    assert prof["trsm_gain"]["kernel"] == "trsm_lds_f64_kernel<7,4,false,%d,3>" % waves
+    assert (st == 0).all() and used[9] == 1 and used.sum() == 1
+    assert not mask[5, 2:4].any() and mask[5].sum() == F - 2
+    for b in (0, 3, 5, 9, 13, B - 1):
+        keep = np.repeat(mask[b].astype(bool), 2)
+        e_ref, P_ref, _ = orc.update_joseph(H[b][keep], P[b], inn[b][keep], dR[b][keep])
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+        assert np.array_equal(Pn[b], Pn[b].T)
 
 
 @pytest.mark.parametrize("N,F", [(150, 50), (250, 80), (37, 3), (400, 150)])

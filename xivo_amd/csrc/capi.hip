@@ -892,7 +892,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (fuse_chol) { a.chol_status = c->status + b0; trsm_chol_fused_label(Mp, label, sizeof(label)); }
     // short factor on a narrow state (BASELINE config 2): ten-wave workgroups, two per CU (solve_fused.hip)
     const bool narrow = !fuse_chol && all_here && jform == 2 && trsm_narrow_supported(Mp, Np);
-    if (narrow) trsm_narrow_label(Mp, label, sizeof(label));
+    if (narrow) trsm_narrow_label(Mp, Np, label, sizeof(label));
     const double t_outs = 0.5 * Np * (Np + 1.0), t_outs_f = 0.5 * Nf * (Nf + 1.0);
     // algorithmic flops (true N, M): the two triangular solves (M^2 N each), the symmetric N x N x M product (lower
     // triangle), and for the expanded form the two triangular products of K L L^T; the whitened form's residual blocks

@@ -185,7 +185,7 @@ void trsm_chol_fused_label(int Mp, char* buf, size_t n);
 // the whitened in-solve update on NWV-wave workgroups, more than one per CU (short factor, narrow state)
 bool trsm_narrow_supported(int Mp, int Np);
 int launch_trsm_narrow(const TrsmArgs& args, hipStream_t stream);
-void trsm_narrow_label(int Mp, char* buf, size_t n);
+void trsm_narrow_label(int Mp, int Np, char* buf, size_t n);
 bool trsm_latency_route(int Mp, int batch);   // few filters: streamed solve on 128-column workgroups + tiled product
 // y = L^-1 inn for every filter (one wave each): the forward substitution of the innovation vector
 int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD, long strideInvD, const double* inn, long strideInn,

@@ -54,20 +54,33 @@ int launch_narrow_t(const TrsmArgs& g_in, hipStream_t stream) {
 
 }  // namespace
 
-// shapes the narrow instantiations hold: every column of the state in one NWV-wave workgroup.
-// OPT-IN (XIVO_HIP_NARROW_SOLVE=1), measured and not adopted: at BASELINE config 2 (N = 150, M = 100; 16384 filters) two
-// ten-wave workgroups per CU take 4.32 ms where the sixteen-wave kernel (ten live waves, one workgroup per CU) takes 4.06 -
-// that shape is bound by HBM (about 1 MB per filter at 4 TB/s), not by the phases of a filter failing to overlap, and the
-// 80 KB of LDS per workgroup cut the product phase to two column blocks per pass. Same bits (tests/test_update_gpu.py).
+// shapes the narrow instantiations hold: every column of the state in one NWV-wave workgroup, a factor of seven block rows.
+// Round 5, two forms (profiles/r05_narrow_solve_ab.json; BASELINE config 2: N = 150, M = 100, 16384 filters; the sixteen-wave
+// kernel <10,4> - ten live waves, stash of W through HBM - takes 4.10 ms there):
+//   mode 2 (DEFAULT): ONE ten-wave (N <= 160) or twelve-wave (N <= 192) workgroup per CU on 170 VGPRs per wave: seven block
+//     rows of right-hand sides (56 VGPRs) AND of W (56) stay in registers - no stash, no read-back, no operand DMA (the KEEPW
+//     form the kernel already has for factors of at most six block rows on 128 VGPRs): 3.72 ms, config 2 1.96 -> 2.06 M updates/s.
+//   mode 1 (XIVO_HIP_NARROW_SOLVE=1): TWO ten-wave workgroups per CU on 96 VGPRs, stash as before - the memory phases of one
+//     filter under the matrix phases of another: 4.32 ms (that shape is bound by HBM, the second workgroup adds requests,
+//     not bandwidth; 80 KB of LDS per workgroup cut the product phase to two column blocks per pass).
+//   XIVO_HIP_NARROW_SOLVE=0: the sixteen-wave kernel. Same bits in every mode (tests/test_update_gpu.py).
+static int narrow_mode() {
+  static const int m = [] { const char* e = getenv("XIVO_HIP_NARROW_SOLVE"); return e ? (atoi(e) == 2 ? 2 : (atoi(e) == 1 ? 1 : 0)) : 2; }();
+  return m;
+}
 bool trsm_narrow_supported(int Mp, int Np) {
-  static const bool on = getenv("XIVO_HIP_NARROW_SOLVE") != nullptr;
-  return on && Np <= 160 && Np % 16 == 0 && Mp / 16 == 7;
+  const int m = narrow_mode();
+  return m != 0 && Np % 16 == 0 && Mp / 16 == 7 && Np <= (m == 2 ? 192 : 160);
 }
 int launch_trsm_narrow(const TrsmArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
-  return launch_narrow_t<7, 10, 5>(g, stream);
+  if (narrow_mode() == 1) return launch_narrow_t<7, 10, 5>(g, stream);
+  return g.Np <= 160 ? launch_narrow_t<7, 10, 3>(g, stream) : launch_narrow_t<7, 12, 3>(g, stream);
 }
-void trsm_narrow_label(int Mp, char* buf, size_t n) { snprintf(buf, n, "trsm_lds_f64_kernel<7,4,false,10,5>"); }
+void trsm_narrow_label(int Mp, int Np, char* buf, size_t n) {
+  if (narrow_mode() == 1) snprintf(buf, n, "trsm_lds_f64_kernel<7,4,false,10,5>");
+  else snprintf(buf, n, "trsm_lds_f64_kernel<7,4,false,%d,3>", Np <= 160 ? 10 : 12);
+}
 
 // shapes the fused kernel holds: the whole state in one 16-wave workgroup, a factor of at most ten block rows
 // OPT-IN (XIVO_HIP_FUSED_CHOL=1), measured and not adopted: per 16384 filters at (250, 160) the solve grows from 9.6 to 12.2 ms

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
   constexpr bool T4 = TF == 4 || TF == 5;   // whitened Joseph form; TF == 5: its outputs V^T, Y^T for a product outside the kernel
   constexpr bool WOUT = TF == 5;
   // short factors (M <= 96): W stays in registers next to the working copy - no stash, no read-back, no DMA of the operand
-  constexpr bool KEEPW = T4 && NBM <= 6;
+  // (also seven block rows on a ten- or twelve-wave workgroup that has the CU to itself: three waves per SIMD, 170 VGPRs
+  //  each - BASELINE config 2)
+  constexpr bool KEEPW = T4 && (NBM <= 6 || (NBM == 7 && NWV <= 12 && MINB <= 3));
   constexpr bool PACK = (TF == 3 || T4) && NBM > 10;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
   const int chunks = (g.Np + 16 * NWV - 1) / (16 * NWV);
