@@ -24,6 +24,13 @@
 #ifndef XIVO_TRACE
 #define XIVO_TRACE 0
 #endif
+// XIVO_TRSM_LATE (A/B, round 5): the whitened in-solve kernel on a factor from memory requests only the first half of its
+// right-hand-side block rows in front of the factor copy and the second half behind it - those rows join the forward
+// substitution at step HX with their terms in the order the steps would have added them (the mechanism the in-kernel
+// factorisation uses: same bits), so that the first forward steps run under the arrival of the late rows.
+#ifndef XIVO_TRSM_LATE
+#define XIVO_TRSM_LATE 0
+#endif
 #if XIVO_TRACE
 __device__ unsigned long long xivo_trace_buf[512 * 32];
 __device__ unsigned long long xivo_trace2_buf[128 * 16 * 4 * 16];   // [workgroup][wave][phase][slot]
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
   //  each - BASELINE config 2)
   constexpr bool KEEPW = T4 && (NBM <= 6 || (NBM == 7 && NWV <= 12 && MINB <= 3));
   constexpr bool PACK = (TF == 3 || T4) && NBM > 10;
+  constexpr bool LATE = CHOL || (XIVO_TRSM_LATE && TF == 4 && NWV == 16 && NBM > 6 && NBM <= 10);   // right-hand sides in two halves
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
   const int chunks = (g.Np + 16 * NWV - 1) / (16 * NWV);
   const int b = blockIdx.x;
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
 #pragma unroll
     for (int i = 0; i < NBM; ++i) {
       if (i >= i0 && i < i1) {
-        if constexpr (CHOL) {
+        if constexpr (LATE) {
           // straight-line, unconditional loads (a block row past the factor / a wave past the state re-reads a valid block,
           // its registers are never used): with the requests inside branches the compiler's wait-count bookkeeping gives up
           // and the first use of ANY row waits for ALL of them - the late rows included
@@ -289,8 +297,8 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
   // under them (the kernel lives on 128 VGPRs: all NBM block rows in flight leave the factorisation no registers, and a
   // spill reload waits for every load in front of it); rows [HX, NBM) are requested when the factor is done and join the
   // forward substitution at step HX - each row still accumulates its terms in the same order, so nothing changes bit-wise
-  constexpr int HX = CHOL ? (NBM + 1) / 2 : NBM;
-  if constexpr (!CHOL) load_rhs(0, NBM);
+  constexpr int HX = LATE ? (NBM + 1) / 2 : NBM;
+  if constexpr (!CHOL) load_rhs(0, HX);
   d4 Wk[KEEPW ? NBM : 1];                           // (KEEPW) the forward-substituted columns, kept next to the working copy
 #pragma unroll
   for (int i = 0; i < (KEEPW ? NBM : 1); ++i) Wk[i] = d4{0.0, 0.0, 0.0, 0.0};
@@ -373,6 +381,11 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
     load_rhs(0, HX);
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();                                 // (no vmcnt drain: the right-hand sides stay in flight)
+  } else if constexpr (LATE) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_rhs(HX, NBM);                             // the late half: on its way while forward steps 0 .. HX - 1 run
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
   } else __syncthreads();
   XTR(2);
   if (!TF && !live) return;
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
 #pragma unroll
   for (int k = 0; k < NBM; ++k) {
     if (k < nb && !(T4 && (XIVO_ABL == 2 || XIVO_ABL == 11))) {
-      if constexpr (CHOL) {
+      if constexpr (LATE) {
         if (k == HX) {   // the late block rows have arrived: the terms of steps 0 .. HX - 1, in the order the steps would have added them
 #pragma unroll
           for (int kk = 0; kk < HX; ++kk) {
@@ -478,7 +491,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int i = k + 1; i < NBM; ++i) {
-          if (i < nb && (!CHOL || k >= HX || i < HX)) {
+          if (i < nb && (!LATE || k >= HX || i < HX)) {
             const double a = sL[(i * (i + 1) / 2 + k) * BLK + li + 17 * (4 * s + lg)];
             X[i] = mfma(-a, t[s], X[i]);
           }
