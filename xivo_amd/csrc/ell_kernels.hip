@@ -109,31 +109,53 @@ __global__ __launch_bounds__(256) void meas_compress_kernel(MeasCompressArgs a) 
   }
   __syncthreads();
   const int nc = s_nc;
-  if (tid < a.pairs_clear) {
-    int* pi = a.ell.idx + (long)filt * a.ell.stride_idx() + (long)tid * ELL_W;
-    d2* pv = reinterpret_cast<d2*>(a.ell.val + (long)filt * a.ell.stride_val()) + (long)tid * ELL_W;
-    unsigned cmask = 0;
+  // pass 2 (round 5): the rows are assembled in LDS and leave as ONE flat, coalesced copy - a filter's compressed rows are
+  // contiguous in memory (pairs x 28 index slots, pairs x 28 x 16 bytes of values). Every thread used to write its own
+  // 112-byte index row and 448-byte value row slot by slot: 64 lanes x 16 bytes at a 448-byte stride per store instruction,
+  // 0.4 of the kernel's 1.4 ms per 16384 filters (ablation without the stores). The staging reuses the lists' LDS, so every
+  // thread first takes its list into registers (static indices: no scratch).
+  const int walk = cnt < ELL_W ? cnt : ELL_W;
+  d2 rv[ELL_W]; int rn[ELL_W];
+#pragma unroll
+  for (int k = 0; k < ELL_W; ++k) {
+    const bool on = k < walk;          // (cnt > 0 only for tid < pairs <= list_ld)
+    rn[k] = on ? lst_n[k * a.list_ld + tid] : 0;
+    rv[k] = on ? lst_v[k * a.list_ld + tid] : d2{0.0, 0.0};
+  }
+  __syncthreads();
+  const int stage_rows = a.pairs_clear < a.list_ld ? a.pairs_clear : a.list_ld;   // rows beyond the lists' LDS (stale rows of a larger M) are cleared in place
+  if (tid < stage_rows) {
+    int* oi = lst_n + tid * ELL_W;
+    d2* ov = lst_v + tid * ELL_W;
+#pragma unroll
+    for (int t = 0; t < ELL_CW; ++t) { oi[t] = t < nc ? ccols[t] : 0; ov[t] = d2{0.0, 0.0}; }
+#pragma unroll
+    for (int t = 0; t < ELL_PW; ++t) { oi[ELL_CW + t] = 0; ov[ELL_CW + t] = d2{0.0, 0.0}; }
     int pos = 0;
-    const int walk = cnt < ELL_W ? cnt : ELL_W;
-    for (int k = 0; k < walk; ++k) {
-      const int n = lst_n[k * a.list_ld + tid];
-      const d2 v = lst_v[k * a.list_ld + tid];
-      const int cs = cslot[n];
-      if (cs) { pv[cs - 1] = v; cmask |= 1u << (cs - 1); }
-      else {
-        if (pos < ELL_PW) { pi[ELL_CW + pos] = n; pv[ELL_CW + pos] = v; }
-        ++pos;
+#pragma unroll
+    for (int k = 0; k < ELL_W; ++k) {
+      if (k < walk) {
+        const int cs = cslot[rn[k]];
+        if (cs) ov[cs - 1] = rv[k];
+        else {
+          if (pos < ELL_PW) { oi[ELL_CW + pos] = rn[k]; ov[ELL_CW + pos] = rv[k]; }
+          ++pos;
+        }
       }
     }
     if (cnt > ELL_W) pos = ELL_PW + 1;            // list overflow: more than 28 non-zero columns cannot fit
-#pragma unroll
-    for (int t = 0; t < ELL_CW; ++t) {
-      pi[t] = t < nc ? ccols[t] : 0;
-      if (!((cmask >> t) & 1u)) pv[t] = d2{0.0, 0.0};
-    }
-    for (int t = pos; t < ELL_PW; ++t) { pi[ELL_CW + t] = 0; pv[ELL_CW + t] = d2{0.0, 0.0}; }
     if (pos > ELL_PW) s_over = 1;
     atomicMax(&s_pw, pos);
+  }
+  __syncthreads();
+  {
+    int* gi = a.ell.idx + (long)filt * a.ell.stride_idx();
+    d2* gv = reinterpret_cast<d2*>(a.ell.val + (long)filt * a.ell.stride_val());
+    for (int e = tid; e < stage_rows * ELL_W; e += blockDim.x) { gi[e] = lst_n[e]; gv[e] = lst_v[e]; }
+    for (int e = stage_rows * ELL_W + tid; e < a.pairs_clear * ELL_W; e += blockDim.x) {
+      const int t = e % ELL_W;
+      gi[e] = t < nc ? ccols[t] : 0; gv[e] = d2{0.0, 0.0};
+    }
   }
   for (int m = tid; m < 2 * a.pairs_clear; m += blockDim.x) {
     a.inn_out[(long)filt * a.strideInnOut + m] = m < a.M ? a.inn[(long)filt * a.strideInn + m] : 0.0;
