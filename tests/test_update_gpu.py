@@ -781,13 +781,14 @@ def test_persistent_slab_kernel_ragged_batch(built):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
 
 
-@pytest.mark.parametrize("N,F,steps", [(100, 20, 120), (250, 80, 40)])
-def test_long_chain_of_default_form_updates_stays_psd_and_close(built, N, F, steps):
+@pytest.mark.parametrize("N,F,steps,r_scale", [(100, 20, 120, 1.0), (250, 80, 40, 1.0), (150, 60, 30, 1.0), (250, 80, 30, 1e-3)])
+def test_long_chain_of_default_form_updates_stays_psd_and_close(built, N, F, steps, r_scale):
     """The default device form P - (W - D)^T (W + D) is PSD only up to rounding, not by construction as the as-coded
     product (I - KH) P (I - KH)^T + K R K^T is. A long chain on the resident covariance - every update shrinks P along new
     directions, cond(S) grows step by step, no noise is added in between - must stay symmetric, positive semi-definite and
     next to the as-coded chain of the oracle: relative distance 1e-6 at every checkpoint (the per-update tolerance, not
-    accumulated), smallest eigenvalue above -1e-12 of the largest."""
+    accumulated), smallest eigenvalue above -1e-12 of the largest. (150, 60): M = 120 rows against N = 150 columns - nearly as many
+    measurements as states in every update; r_scale 1e-3: measurement noise a thousand times smaller, cond(S) correspondingly larger.)"""
     B = 2
     P, _, _, _ = synth.s_level(N, F, B, seed=5)
     Pref = P.copy()
@@ -795,6 +796,7 @@ def test_long_chain_of_default_form_updates_stays_psd_and_close(built, N, F, ste
         ctx.upload_P(P)
         for it in range(steps):
             _, H, inn, dR = synth.s_level(N, F, B, seed=700 + it)
+            dR = dR * r_scale
             ctx.set_measurements(H, inn, dR)
             ctx.update_joseph()
             assert (ctx.get_status() == 0).all()
