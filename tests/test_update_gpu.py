@@ -360,7 +360,7 @@ def test_profile_reports_kernels_bytes_and_path(built, B):
             assert prof["gemm_Pnew"]["launches"] == (1 if latency else 0)
         assert prof["chol_S"]["kernel"].startswith("chol_reg_f64_kernel<10")   # B < 512: the latency kernel
         if path == 1:
-            assert prof["trsm_gain"]["kernel"] == ("trsm_stream_f64_kernel<14,1>" if latency else "trsm_lds_f64_kernel<10,4>")
+            assert prof["trsm_gain"]["kernel"] == ("trsm_stream_f64_kernel<14,1,4>" if latency else "trsm_lds_f64_kernel<10,4>")
         else:
             assert prof["trsm_gain"]["kernel"] == "trsm_lds_f64_kernel<10,0>"
 

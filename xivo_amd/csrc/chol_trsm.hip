@@ -212,12 +212,17 @@ __global__ __launch_bounds__(1024) void pnew_reg_f64_kernel(PnewRegArgs g) {
 // WH = 1: whitened outputs for the covariance update outside the kernel (tiled product P - V^T Y):
 //   after the forward pass W^T goes to the stash (g.K), the backward pass reads W_k back one step before it needs it,
 //   forms D_k = B_k - L_kk^T K^T_k in place and leaves Y_k = W_k + D_k in g.Yout, V_k = W_k - D_k in g.K; dx as usual.
-template <int NBM, int WH>
+// NWS (round 5): waves per workgroup = 16 NWS right-hand-side columns. 8 is the kernel of rounds 2-4; 4 serves the latency route
+// (<= 64 filters): one wave per SIMD, so that a wave's chain of MFMAs has the matrix pipe to itself (two waves per SIMD take
+// turns on it: the solve of ONE filter at (250, 160) issues 480 MFMAs per wave = 14 us alone, 28 us shared) and twice as
+// many CUs work on the few filters there are.
+template <int NBM, int WH, int NWS = 8>
 // (second launch bound = waves per SIMD the register budget is cut for: 8-wave workgroups -> 3 / 2 / 1 workgroups per CU)
-__global__ __launch_bounds__(512, NBM <= 4 ? 6 : (NBM <= 8 ? 4 : 2)) void trsm_stream_f64_kernel(TrsmArgs g) {
+__global__ __launch_bounds__(64 * NWS, NWS == 8 ? (NBM <= 4 ? 6 : (NBM <= 8 ? 4 : 2)) : 2) void trsm_stream_f64_kernel(TrsmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [2][NBM + 1][256]
   constexpr int PSZ = (NBM + 1) * 256;
-  const int chunks = (g.Np + 127) / 128;
+  constexpr int WCOLS = 16 * NWS;
+  const int chunks = (g.Np + WCOLS - 1) / WCOLS;
   const int b = blockIdx.x;
   const int xcd = b & 7, slot = b >> 3;
   const int filt = (slot / chunks) * 8 + xcd;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(512, NBM <= 4 ? 6 : (NBM <= 8 ? 4 : 2)) void trsm_s
   const double* __restrict__ LU = g.LU + (long)filt * g.strideLU;
   const double* __restrict__ invD = g.invD + (long)filt * g.strideInvD;
   const long ld = g.ldlu;
-  const int c0 = chunk * 128 + wave * 16;
+  const int c0 = chunk * WCOLS + wave * 16;
   const bool live = c0 < g.Np;
   const __amdgpu_buffer_rsrc_t rPHT = buf_rsrc(g.PHT + (long)filt * g.stridePHT), rK = buf_rsrc(g.K + (long)filt * g.strideK),
                                rInn = buf_rsrc(g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn),
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(512, NBM <= 4 ? 6 : (NBM <= 8 ? 4 : 2)) void trsm_s
   // block L_kk itself (stored symmetric: L below, L^T above - masked on read)
   auto issue_panel = [&](int k, bool fwd, double* buf) {
     const int j0 = fwd ? k : 0, nj = (fwd ? nb - k : k + 1) + ((WH && !fwd) ? 1 : 0);
-    for (int q = wave; q < nj * 2; q += 8) {
+    for (int q = wave; q < nj * 2; q += NWS) {
       int j = j0 + (q >> 1);
       const int h = q & 1;
       const bool extra = WH && !fwd && (q >> 1) == nj - 1;
@@ -377,18 +382,23 @@ __global__ __launch_bounds__(512, NBM <= 4 ? 6 : (NBM <= 8 ? 4 : 2)) void trsm_s
   if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
 }
 
-template <int NBM, int WH>
+template <int NBM, int WH, int NWS = 8>
 int launch_trsm_stream_t(const TrsmArgs& g, hipStream_t stream) {
-  const int chunks = (g.Np + 127) / 128;
+  const int chunks = (g.Np + 16 * NWS - 1) / (16 * NWS);
   const int grid = ((g.batch + 7) / 8) * 8 * chunks;
   const size_t lds = (size_t)2 * (NBM + 1) * 256 * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_stream_f64_kernel<NBM, WH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_stream_f64_kernel<NBM, WH, NWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((trsm_stream_f64_kernel<NBM, WH>), dim3(grid), dim3(512), lds, stream, g);
+  hipLaunchKernelGGL((trsm_stream_f64_kernel<NBM, WH, NWS>), dim3(grid), dim3(64 * NWS), lds, stream, g);
   return (int)hipGetLastError();
+}
+// the latency route on four-wave workgroups (XIVO_HIP_STREAM_WAVES=8: the eight-wave kernel, A/B)
+static bool latency_four_waves() {
+  static const bool w8 = [] { const char* e = getenv("XIVO_HIP_STREAM_WAVES"); return e && atoi(e) == 8; }();
+  return !w8;
 }
 // Block-row capacities the streamed kernel is instantiated for. Register allocation of the fully unrolled substitution
 // is erratic from one capacity to the next (spilled VGPRs, hipcc 7.2: plain 14: 0, 16: 0, 18: 4801, 19: 6353, 20: 5019,
@@ -500,6 +510,12 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   // A/B knob (round 3 experiment): small factors with the whitened outputs through the streamed kernel - 8-wave workgroups of
   // 128 columns, two or more per CU, instead of one 16-wave workgroup per filter
   static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
+  if (g.latency && !small_stream && latency_four_waves() && g.Yout && !g.fwd_only && nb <= 14) {
+    if (nb <= 4) return launch_trsm_stream_t<4, 1, 4>(g, stream);
+    if (nb <= 6) return launch_trsm_stream_t<6, 1, 4>(g, stream);
+    if (nb <= 8) return launch_trsm_stream_t<8, 1, 4>(g, stream);
+    return launch_trsm_stream_t<14, 1, 4>(g, stream);
+  }
   if ((small_stream || g.latency) && g.Yout && !g.fwd_only && nb <= 8) {
     if (nb <= 4) return launch_trsm_stream_t<4, 1>(g, stream);
     if (nb <= 6) return launch_trsm_stream_t<6, 1>(g, stream);
@@ -552,7 +568,8 @@ void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T, bool latency) {
   const int nb = Mp / 16;
   const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
   static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
-  if (latency && forms_T == 5 && nb <= 14) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
+  if (latency && forms_T == 5 && nb <= 14 && !small_stream && latency_four_waves()) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1,4>", stream_capacity(nb, true));
+  else if (latency && forms_T == 5 && nb <= 14) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
   else if (small_stream && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
   else if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
   else if (!no_stream || forms_T >= 4) snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
