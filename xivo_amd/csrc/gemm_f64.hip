@@ -412,12 +412,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int filt, con
   }
 }
 
+#ifndef XIVO_GEMM22_BK
+#define XIVO_GEMM22_BK 16     // A/B: k-panel depth of the <2,2> instantiation (64 x 64 tiles: the latency route's products)
+#endif
 #ifndef XIVO_GEMM33_BK
 #define XIVO_GEMM33_BK 16     // A/B: k-panel depth of the <3,3> instantiation
 #endif
 template <int WM, int WN>
 constexpr int pick_bk() {
-  return (WM == 3 && WN == 3) ? XIVO_GEMM33_BK : 16;   // 32 measured neutral on MI355X and costs 32 more staging VGPRs
+  return (WM == 3 && WN == 3) ? XIVO_GEMM33_BK : ((WM == 2 && WN == 2) ? XIVO_GEMM22_BK : 16);   // 32 measured neutral on MI355X and costs 32 more staging VGPRs
 }
 
 // waves per SIMD (= workgroups per CU) the register budget of an instantiation is cut for (A/B: -DXIVO_GEMM33_WAVES etc.)
