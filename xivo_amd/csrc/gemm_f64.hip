@@ -430,6 +430,9 @@ constexpr int pick_bk() {
 #ifndef XIVO_GEMM44F_WAVES
 #define XIVO_GEMM44F_WAVES 0
 #endif
+#ifndef XIVO_GEMM34D_WAVES
+#define XIVO_GEMM34D_WAVES 0
+#endif
 #ifndef XIVO_GEMM44D_WAVES
 #define XIVO_GEMM44D_WAVES 0
 #endif
@@ -438,6 +441,7 @@ constexpr int gemm_waves() {
   if (XIVO_GEMM33_WAVES > 0 && WM == 3 && WN == 3 && sizeof(CT) == 8) return XIVO_GEMM33_WAVES;
   if (XIVO_GEMM44F_WAVES > 0 && WM == 4 && WN == 4 && sizeof(CT) == 4) return XIVO_GEMM44F_WAVES;
   if (XIVO_GEMM44D_WAVES > 0 && WM == 4 && WN == 4 && sizeof(CT) == 8) return XIVO_GEMM44D_WAVES;
+  if (XIVO_GEMM34D_WAVES > 0 && WM == 3 && WN == 4 && sizeof(CT) == 8) return XIVO_GEMM34D_WAVES;
   return (sizeof(CT) == 4 && WM * WN <= 16) ? 3 : 2;
 }
 template <int WM, int WN, typename CT>
@@ -583,6 +587,16 @@ static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
   if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT || a.epilogue == EPI_RSUB_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
       !getenv("XIVO_HIP_TILE"))
     wn = 2;
+  // short contractions on a non-square output (the lead product of an online-calibration stacking: K = 48, three k-panels):
+  // all prologue (the accumulators start from the output) and epilogue - small tiles, more workgroups in flight
+  // (N = 276: <3,4> 1.20 -> <3,2> 0.85 ms per 4096 filters; <3,3> 1.0, <5,2> 1.35)
+  {
+    const int ktot = a.seg[0].K + (a.nseg > 1 ? a.seg[1].K : 0);
+    if (!a.lower_only && !a.fp32 && a.Mp != a.Np && ktot <= 64 && !getenv("XIVO_HIP_TILE_RECT")) {
+      if (a.Mp % 96 == 0) { wm = 3; wn = 2; }
+      else if (a.Mp % 64 == 0) { wm = 2; wn = 2; }
+    }
+  }
   // few filters (the latency route of the update, chol_trsm.hip): 64 x 64 tiles - ten workgroups per symmetric 256 x 256
   // output instead of three, on a chip that is empty anyway
   if (a.small_tiles && a.lower_only && a.Mp > 64 && !a.fp32) { wm = 2; wn = 2; }
