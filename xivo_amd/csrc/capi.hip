@@ -330,6 +330,14 @@ static bool latency_route(const xivo_hip_ctx* c, int Mp, int B, bool full) {
   return !full && !knobs && !(c->flags & other) && trsm_latency_route(Mp, B);
 }
 
+// States wider than one sixteen-wave workgroup (N > 256) with a factor of at most eight block rows: the whitened outputs
+// come from the streamed solve on eight-wave workgroups (N = 276, M = 120: 2.01 -> 1.39 ms per 4096 filters - the LDS kernel
+// ran a second, nearly empty workgroup per filter that copied the whole factor for two live waves). XIVO_HIP_NO_STREAM8: A/B.
+static bool stream8_shape(int Mp, int Np) {
+  static const bool off = getenv("XIVO_HIP_NO_STREAM8") != nullptr;
+  return !off && Np > 256 && Mp / 16 <= 8;
+}
+
 static int ensure_gate_buffers(xivo_hip_ctx* c, int F);
 static int ensure_dense(xivo_hip_ctx* c);
 static int ensure_HT(xivo_hip_ctx* c);
@@ -855,7 +863,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
                          !t_full && !lat && trsm_forms_T(Mp, Np) && !no_joseph_k && mr0 < 0 && !gate_folded && trsm_chol_fused_supported(Mp, Np);
   if (!fuse_chol) {
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B; a.variant = chol_variant; a.latency = lat;
+    a.status = c->status + b0; a.batch = B; a.variant = chol_variant; a.latency = lat || stream8_shape(Mp, Np);   // (the streamed solve reads the mirrored upper triangle)
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
     if (gate_folded) { const size_t n = strlen(clabel); snprintf(clabel + n, sizeof(clabel) - n, "+gate"); }
     StageTimer st(c, ST_CHOL, Mf * Mf * Mf / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
@@ -880,7 +888,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     static const bool no_trsm_t = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: the round-1 stand-alone tail for every shape
     wh_out = !t_here && !t_full && jform == 2 && !no_joseph && !no_trsm_t &&
              !(c->flags & (XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_FP32_CORR));
-    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat;
+    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; a.stream8 = (!lat && stream8_shape(Mp, Np)) ? 1 : 0;
       // XIVO_HIP_FLAG_FP32_WHITENED only where the SHAPE puts the product outside the solve kernel (N > 256 or M > 176): a
       // few-filter call of a shape the in-solve update holds takes this branch through the latency route and stays all fp64
       a.out_f32 = ((c->flags & XIVO_HIP_FLAG_FP32_WHITENED) && !trsm_forms_T(Mp, Np)) ? 1 : 0; }
@@ -888,7 +896,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
     else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
     t_done = t_here;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : (wh_out ? 5 : 0)), lat);
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : (wh_out ? 5 : 0)), lat, a.stream8 != 0);
     if (fuse_chol) { a.chol_status = c->status + b0; trsm_chol_fused_label(Mp, label, sizeof(label)); }
     // short factor on a narrow state (BASELINE config 2): ten-wave workgroups, two per CU (solve_fused.hip)
     const bool narrow = !fuse_chol && all_here && jform == 2 && trsm_narrow_supported(Mp, Np);
@@ -1069,7 +1077,7 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
   const bool lat = (c->flags & XIVO_HIP_FLAG_REASSOC) && latency_route(c, Mp, B, full);
   {  // S = L L^T
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B); a.latency = lat;
+    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B); a.latency = lat || stream8_shape(Mp, Np);
     char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
@@ -1088,13 +1096,13 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
     const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
     wh_out = (c->flags & XIVO_HIP_FLAG_REASSOC) && !all_here && !f32 && !full && !no_joseph && jform == 2 &&
              !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);
-    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat;
+    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; a.stream8 = (!lat && stream8_shape(Mp, Np)) ? 1 : 0;
       // XIVO_HIP_FLAG_FP32_WHITENED only where the SHAPE puts the product outside the solve kernel (N > 256 or M > 176): a
       // few-filter call of a shape the in-solve update holds takes this branch through the latency route and stays all fp64
       a.out_f32 = ((c->flags & XIVO_HIP_FLAG_FP32_WHITENED) && !trsm_forms_T(Mp, Np)) ? 1 : 0; }
     wh_f32 = wh_out && a.out_f32;
     if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (wh_out ? 5 : 0), lat);
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (wh_out ? 5 : 0), lat, a.stream8 != 0);
     const double t_outs = 0.5 * Np * (Np + 1.0);
     StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (all_here ? 2.0 * t_outs * Mp + (jform == 2 ? 32.0 * Mp * Np : 2.0 * Mp * Mp * Np) : 0.0)) * B, label,
                   8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (all_here ? t_outs + (double)Np * Np : 0.0)));

@@ -516,7 +516,7 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
     if (nb <= 8) return launch_trsm_stream_t<8, 1, 4>(g, stream);
     return launch_trsm_stream_t<14, 1, 4>(g, stream);
   }
-  if ((small_stream || g.latency) && g.Yout && !g.fwd_only && nb <= 8) {
+  if ((small_stream || g.latency || g.stream8) && g.Yout && !g.fwd_only && nb <= 8) {
     if (nb <= 4) return launch_trsm_stream_t<4, 1>(g, stream);
     if (nb <= 6) return launch_trsm_stream_t<6, 1>(g, stream);
     return launch_trsm_stream_t<8, 1>(g, stream);
@@ -564,13 +564,13 @@ int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD
   return (int)hipGetLastError();
 }
 
-void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T, bool latency) {
+void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T, bool latency, bool stream8) {
   const int nb = Mp / 16;
   const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
   static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
   if (latency && forms_T == 5 && nb <= 14 && !small_stream && latency_four_waves()) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1,4>", stream_capacity(nb, true));
   else if (latency && forms_T == 5 && nb <= 14) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
-  else if (small_stream && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
+  else if ((small_stream || stream8) && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
   else if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
   else if (!no_stream || forms_T >= 4) snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
   else snprintf(buf, n, "trsm_f64_kernel");

@@ -127,6 +127,8 @@ struct TrsmArgs {
   int Mp, Np;
   int batch;
   int latency;         // with Yout: the latency route (trsm_latency_route) - streamed kernel whatever the factor's size
+  int stream8;         // with Yout, at most eight block rows: the streamed kernel on eight-wave workgroups of 128 columns (states
+                       // wider than one sixteen-wave workgroup: no nearly empty second workgroup that copies the factor for two waves)
   int fwd_only;        // 1: stop after the forward substitution: K receives W^T = (L^-1 HP)^T and dx = W^T y with
   const double* y;     //    y = L^-1 inn [Mp] (launch_fwd_vec) - the symmetric form P+ = P - W^T W needs no more
   long strideY;
@@ -190,7 +192,7 @@ bool trsm_latency_route(int Mp, int batch);   // few filters: streamed solve on 
 // y = L^-1 inn for every filter (one wave each): the forward substitution of the innovation vector
 int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD, long strideInvD, const double* inn, long strideInn,
                    double* y, long strideY, int Mp, int batch, hipStream_t stream);
-void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T = 0, bool latency = false);   // forms_T: 0 solve only, 1 + T = K(HP) - P, 2 + P - W^T W (symmetric form)
+void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T = 0, bool latency = false, bool stream8 = false);   // forms_T: 0 solve only, 1 + T = K(HP) - P, 2 + P - W^T W (symmetric form)
 
 }  // namespace xivo_hip
 
