@@ -923,7 +923,8 @@ static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, int* pwu, size_t* l
   const size_t cap = 160 * 1024;
   *xc = 0; *lds = 0;
   if (no_tile) return;
-  if (lds64 <= cap) { *xc = 64; *lds = lds64; return; }
+  static const bool force32 = getenv("XIVO_HIP_ELL_XC32") != nullptr;   // A/B knob: 32-wide slabs wherever they fit
+  if (lds64 <= cap && !force32) { *xc = 64; *lds = lds64; return; }
   if (lds32 <= cap) { *xc = 32; *lds = lds32; }
 }
 
