@@ -1,7 +1,10 @@
-"""Debugging aid: the intermediate products of one online-calibration update on the sparse pipeline against numpy."""
+"""Debugging aid (not collected by pytest; lives under tests/ because it builds its scene with the tests' helpers, which use
+the oracle): the intermediate products of one online-calibration update on the sparse pipeline against numpy.
+XIVO_HIP_DUMP_DIR=<dir> python tests/debug_calib_lead.py"""
 import os, sys, tempfile
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..")); sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
 d = os.environ.get("XIVO_HIP_DUMP_DIR") or tempfile.mkdtemp(); os.makedirs(d, exist_ok=True); os.environ["XIVO_HIP_DUMP_DIR"] = d
 import test_calib_gpu as T
 from scene_util import spd
