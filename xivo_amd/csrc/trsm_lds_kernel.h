@@ -73,6 +73,14 @@ __device__ __forceinline__ void buf_st_f32(float v, __amdgpu_buffer_rsrc_t r, un
 __device__ __forceinline__ void buf_st(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, 0);
 }
+// XIVO_PNEW_NT (A/B, round 5): cache policy of the stores of P+ in the product phase (gfx942+: bit 0 sc0, bit 1 nt, bit 4 sc1) -
+// the output is not read again before the next update's P H^T kernel, 16384 filters later
+#ifndef XIVO_PNEW_NT
+#define XIVO_PNEW_NT 0
+#endif
+__device__ __forceinline__ void buf_st_out(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, XIVO_PNEW_NT);
+}
 
 template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false, bool FIXUP = false, bool YREGS = false, int NWV = 16>
 __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4 (&Wr)[NBM], double* sL, const double* __restrict__ Src, int ldsrc,
@@ -198,8 +206,8 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
         const int bb = b + 4 * r;
         if ((jb != w || a >= bb) && !(XIVO_ABL == 4 && acc[r] != 12345.678)) {   // diagonal tile: the lower triangle is authoritative
           const double v = NEG_OUT ? -acc[r] : acc[r];
-          buf_st(v, rO, vO, (unsigned)(16 * ba + (16 * bbk + 4 * r) * ldo) * 8u);
-          if (a != bb) buf_st(v, rO, vOt, (unsigned)(16 * bbk + 4 * r + 16 * ba * ldo) * 8u);
+          buf_st_out(v, rO, vO, (unsigned)(16 * ba + (16 * bbk + 4 * r) * ldo) * 8u);
+          if (a != bb) buf_st_out(v, rO, vOt, (unsigned)(16 * bbk + 4 * r + 16 * ba * ldo) * 8u);
         }
       }
       XTR2(p, tslot); ++tslot;
