@@ -67,6 +67,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+// XIVO_SOLVE_LD_NT (A/B, round 5): cache policy of the loads the kernel reads exactly once (right-hand sides, the tiles of P)
+#ifndef XIVO_SOLVE_LD_NT
+#define XIVO_SOLVE_LD_NT 0
+#endif
+__device__ __forceinline__ double buf_ld_once(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, XIVO_SOLVE_LD_NT));
+}
 __device__ __forceinline__ void buf_st_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
@@ -137,7 +144,7 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
     const int ba = jb <= w ? w : jb, bb = jb <= w ? jb : w;       // block (ba, bb), ba >= bb
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      acc[r] = XIVO_ABL == 7 ? 1.0 : buf_ld(rM, vM, (unsigned)(16 * ba + (16 * bb + 4 * r) * ldm) * 8u);   // (negated where it is consumed: no wait here)
+      acc[r] = XIVO_ABL == 7 ? 1.0 : buf_ld_once(rM, vM, (unsigned)(16 * ba + (16 * bb + 4 * r) * ldm) * 8u);   // (negated where it is consumed: no wait here)
   };
   issue(0);
   unsigned todo = my_tiles(0);
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
           X[i] = d4{0.0, 0.0, 0.0, 0.0};
           if (live && i < nb) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[i][r] = buf_ld(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u);
+            for (int r = 0; r < 4; ++r) X[i][r] = buf_ld_once(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u);
           }
         }
       }
