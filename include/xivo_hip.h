@@ -135,7 +135,13 @@ enum {
    * (X/Z, Y/Z, log Z) - Feature::Xc goes through unproject_invz (src/feature.cpp:98-105, common/project.h:31-56) and
    * Feature::z is 1 / x(2) (:120-126). Every kernel that unprojects a feature (in-state Jacobians, depth sub-filter and its
    * candidate depth test, loop-closure rows) follows the flag; the Jacobian block d/dx changes accordingly. */
-  XIVO_HIP_FLAG_INVDEPTH = 32768u
+  XIVO_HIP_FLAG_INVDEPTH = 32768u,
+  /* Round 6: shapes one workgroup holds end to end (M <= 64 with N <= 256 - the TUM-VI build; M <= 112 with N <= 192 -
+   * BASELINE config 2) run the WHOLE update - P H^T, S, the MH gate, the factorisation, both substitutions, dx and the
+   * covariance product - in one kernel per filter (fused_update.hip): nothing but P, P+ and the compressed rows crosses HBM.
+   * Same algebra as the multi-kernel pipeline (whitened Joseph evaluation, same gate expressions). This flag keeps such a
+   * shape on the multi-kernel pipeline (A/B, and the route-against-route parity tests). */
+  XIVO_HIP_FLAG_MULTI_KERNEL = 65536u
 };
 
 /* camera models implemented on device (common/camera_pinhole.h,

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "ekf_kernels.h"
 #include "ell.h"
+#include "fused_update.h"
 
 using namespace xivo_hip;
 
@@ -723,6 +724,17 @@ static void dump_dev(xivo_hip_ctx* c, const char* name, const double* d, size_t 
   if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(double), n, f); fclose(f); }
 }
 
+// Whether a pass of the sparse pipeline takes the one-kernel route (fused_update.hip): the default Joseph evaluation on
+// row-pair compressed rows only (no OOS rows, no leading calibration block), at most 12 common and 9 private slots in use,
+// a shape one workgroup holds. XIVO_HIP_NO_FUSED_UPDATE: the five-kernel pipeline (A/B).
+static bool fused_route(const xivo_hip_ctx* c, int Mp, int Np, int nc_max, int pw_max, bool full) {
+  static const bool knobs = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") || getenv("XIVO_HIP_NO_TRSM_T") || getenv("XIVO_HIP_T_FULL");
+  const unsigned other = XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_EXPANDED_JOSEPH | XIVO_HIP_FLAG_FP32_CORR |
+                         XIVO_HIP_FLAG_FP32_COV | XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_MULTI_KERNEL;
+  return !full && !knobs && !(c->flags & other) && c->mixed_row0 < 0 && !c->lead_valid && nc_max <= 12 && pw_max <= 9 &&
+         fused_update_supported(Mp, Np);
+}
+
 static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams* gate) {
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
   double* P = c->P + (long)b0 * c->sP;
@@ -757,6 +769,27 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   // products of the OOS block contract over the leading oos_k state columns only
   bool walk_tiled = false;
   const int oos_k = (mr0 >= 0 && c->have_layout) ? std::min(Np, round_up16(c->lay.group_begin + 6 * c->lay.n_groups)) : Np;
+  // Round 6: the shapes a CU holds (TUM-VI 203 / 60, BASELINE config 2 150 / 100) take ONE kernel for the whole update -
+  // P H^T, S, the gate, the factor, both substitutions and the covariance product stay in the registers and the LDS of the
+  // workgroup that owns the filter (fused_update.hip); nothing but P, P+ and the compressed rows crosses HBM.
+  if (fused_route(c, Mp, Np, nc_max, pw_max, full)) {
+    FusedArgs a{};
+    a.P = P; a.strideP = c->sP; a.ldp = Np; a.ell = e; a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
+    a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.status = c->status + b0;
+    a.Np = Np; a.Mp = Mp; a.batch = B;
+    if (gate) {
+      a.gate = 1; a.F = gate->F; a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
+      a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
+      if (c->dense_valid) { a.H = c->H + (long)b0 * c->sH; a.strideH = c->sH; a.ldh = ldh; a.HT = c->HT + (long)b0 * c->sHT; a.strideHT = c->sHT; a.ldht = Np; }
+      c->gate_sparse_last = 0;
+    }
+    char label[64]; fused_update_label(Mp, Np, label, sizeof(label));
+    const double t_outs_f = 0.5 * Nf * (Nf + 1.0);
+    StageTimer st(c, ST_TRSM, (nnz_flops * (Nf + Mf) + Mf * Mf * Mf / 3.0 + 2.0 * Mf * Mf * Nf + 32.0 * Mf * Nf + 2.0 * t_outs_f * Mf) * B, label,
+                  B * (16.0 * Np * Np + (Mp / 2) * ELL_W * 20.0));
+    HIP_TRY((hipError_t)launch_fused_update(a, c->stream));
+    return XIVO_HIP_OK;
+  }
   {
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
     a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp_ell; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;

@@ -22,6 +22,7 @@ FLAG_NO_LDLT_FALLBACK = 4096
 FLAG_FP32_WHITENED = 16384  # N > 256 / M > 176: V^T, Y^T as float, P - V^T Y on the fp32 MFMA
 FLAG_THROUGHPUT_ROUTE = 8192    # every batch size on the kernels sized for thousands of filters (default: <= 64 filters take the latency route)
 FLAG_INVDEPTH = 32768           # USE_INVDEPTH build: features are (X/Z, Y/Z, 1/Z) (src/feature.cpp:98-105)
+FLAG_MULTI_KERNEL = 65536       # keep shapes the one-kernel update holds (fused_update.hip) on the multi-kernel pipeline
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
 
