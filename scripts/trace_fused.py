@@ -32,6 +32,8 @@ names = ["0 start", "1 coefficients staged", "2 H P gathered", "3 S walked", "4 
 tick_us = 0.01   # s_memtime counts at 100 MHz
 out = {"shape": [N, F, B], "sampled_workgroups": int(len(t)), "total_us_median": float(np.median(t[:, 8] - t[:, 0]) * tick_us),
        "segments_us": {names[i]: float(np.median(t[:, i] - t[:, i - 1]) * tick_us) for i in range(1, 9)}}
+out["phase2_us"] = {"gather done -> staging barrier": float(np.median(t[:, 9] - t[:, 2]) * tick_us), "slab write + read-back": float(np.median(t[:, 10] - t[:, 9]) * tick_us),
+                    "barrier": float(np.median(t[:, 11] - t[:, 10]) * tick_us), "walk (first pass)": float(np.median(t[:, 12] - t[:, 11]) * tick_us), "rest": float(np.median(t[:, 3] - t[:, 12]) * tick_us)}
 print(json.dumps(out, indent=1))
 
 n2 = 128 * 16 * 32
@@ -48,3 +50,4 @@ if hasattr(lib, "xivo_hip_debug_read_fused_trace2") and lib.xivo_hip_debug_read_
     print("factorisation, per wave (cycles after wave 0 entered column 0): per column j: enter | owner: diagonal update done | arrive at barrier | leave barrier")
     for wv in range(min(16, (N + 15) // 16)):
         print("wave %2d:" % wv, "  ".join(" ".join("%6d" % med[wv][4 * j + q] for q in range(4)) for j in range(nb)))
+    print("pivot stamps of block column 0 (wave 0), cycles between consecutive pivots:", " ".join("%d" % v for v in np.diff(med[0][16:32])))

@@ -4,6 +4,9 @@
 #pragma once
 #include "mfma_util.h"
 
+#ifndef XIVO_CHAIN_STAMP
+#define XIVO_CHAIN_STAMP(slot) do {} while (0)   // (trace builds of the one-kernel update: shader-clock stamp per pivot)
+#endif
 #ifndef XIVO_CHOL_UNROLL16
 #define XIVO_CHOL_UNROLL16 0
 #endif
@@ -75,6 +78,69 @@ __device__ __forceinline__ void factor_invert_diag(d4& x, d4& y, int& bad, const
       y = mfma(al, by, y);
     }
   }
+}
+
+// factor_invert_diag for a chain that runs ALONE on its SIMD (round 6, the one-kernel update: one workgroup per CU, nothing
+// else to issue while the diagonal block is factored). There the sixteen pivots cost what the wave's own in-order
+// instruction stream costs: factor_invert_diag's loop body is ~50 instructions and three taken branches per pivot, and the
+// next pivot is read (v_readlane, ~30 cycles to a scalar register) from the result of the rank-one MFMA (~94 cycles from
+// issue to a VALU consumer) before pivot_scale can even start - 460 cycles per pivot measured (scripts/probes/latency_probe.hip:
+// dependent v_fma_f64 7.6, v_rsq_f64 ~18, v_readlane -> VALU 38, MFMA -> VALU -> MFMA 93 cycles per step).
+// This variant is straight-line code for all sixteen columns (compile-time lane selects, no branches), software-pipelined
+// by one pivot:
+//  * the next pivot does not wait for the matrix pipe's update of the whole block and a second pass: the two elements column
+//    c's MFMA would combine into it - X[c + 1][c] and X[c + 1][c + 1] as columns 0 .. c - 1 left them - are read once, and the
+//    pivot is formed by the same single fused multiply-add the matrix pipe applies to that element (its other k-slices are
+//    exact zeros): p' = fma(-l, l, X[c + 1][c + 1]), l = X[c + 1][c] rd;
+//  * v_rsq_f64 and the two refinement steps of pivot c + 1 are issued in front of column c's vector work (scaling, lane
+//    selects, the two MFMAs), which then fills the latency slots of that dependent chain;
+//  * the diagonal entry is L[c][c] = p rd like every other entry of the column (factor_invert_diag corrects it to the
+//    rounded square root with four more dependent operations; p rd is within 2 ulp of it, and the inverse block is built
+//    from the same rd, so L inv(L) = I holds to the same rounding either way).
+// Not bit-identical to factor_invert_diag (the diagonal entries differ in the last place): the one-kernel route is its only
+// user. One copy per kernel (its caller loops over the block columns at run time): ~700 instructions.
+__device__ __forceinline__ double chain_rsqrt(double p) {     // v_rsq_f64 (2^-24) + two Newton steps: 2 ulp (scripts/probes/rsq_probe.hip)
+#pragma clang fp contract(off)
+  double rd = __builtin_amdgcn_rsq(p);
+  const double hx = 0.5 * p;
+  rd = rd * __builtin_fma(-(hx * rd), rd, 1.5);
+  rd = rd * __builtin_fma(-(hx * rd), rd, 1.5);
+  return rd;
+}
+__device__ __forceinline__ void factor_invert_diag_chain(d4& x, d4& y, int& bad, const int row0, const int li, const int lg) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) y[r] = (lg + 4 * r == li) ? 1.0 : 0.0;
+  double p = readlane_d(x[0], 0);
+  if (!(p > 0.0)) { bad = 1 + row0; p = 1.0; }
+  double rd = chain_rsqrt(p);
+  static_for<16>([&](auto cc) {
+    constexpr int c = decltype(cc)::value, rc = c >> 2, lgc = c & 3;
+    XIVO_CHAIN_STAMP(row0 == 0 ? 16 + c : 99);
+    double rn = 0.0;
+    if constexpr (c < 15) {
+      // X[c + 1][c] lives in lane (c + 1, lg = c & 3) of register c >> 2, X[c + 1][c + 1] in lane (c + 1, (c + 1) & 3) of register (c + 1) >> 2
+      const double x10 = readlane_d(x[rc], (c + 1) + 16 * lgc);
+      const double x11 = readlane_d(x[(c + 1) >> 2], (c + 1) + 16 * ((c + 1) & 3));
+      const double l1 = x10 * rd;
+      double pn = __builtin_fma(-l1, l1, x11);
+      const bool ok = pn > 0.0;
+      if (!ok && !bad) bad = 1 + row0 + c + 1;
+      pn = ok ? pn : 1.0;
+      rn = chain_rsqrt(pn);
+    }
+    const bool own = (lg == lgc);
+    const double lc = x[rc] * rd;            // L[li][c] in the lanes lg == lgc (li == c: p rd)
+    const double yc = y[rc] * rd;            // row c of inv(L): final
+    if (own) { x[rc] = lc; y[rc] = yc; }
+    const bool below = own && li > c;
+    const double bl = below ? lc : 0.0;
+    const double al = -bl;
+    const double by = own ? yc : 0.0;
+    x = mfma(al, bl, x);
+    y = mfma(al, by, y);
+    rd = rn;
+  });
 }
 
 }  // namespace

@@ -19,6 +19,15 @@
 //   5  W = L^-1 (H P), K^T = L^-T W, dx = K inn, D = W - L^T K^T  - all in registers (trsm_lds_kernel.h, KEEPW form)
 //   6  P+ = P - (W - D)^T (W + D), lower triangle + mirror, in place (sym_tiles_from_regs)
 // HBM traffic per filter: the columns of P that H names (<= N^2), P's lower triangle, P+ out, the compressed rows.
+#include <hip/hip_runtime.h>
+#ifndef XIVO_FUSED_TRACE
+#define XIVO_FUSED_TRACE 0
+#endif
+#if XIVO_FUSED_TRACE
+__device__ unsigned long long xivo_fused_trace2_buf[128 * 16 * 32];
+#define XIVO_CHAIN_STAMP(slot) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 128 && (slot) < 32) \
+    xivo_fused_trace2_buf[((blockIdx.x >> 6) * 16 + (threadIdx.x >> 6)) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #include "trsm_lds_kernel.h"
 #include "ell.h"
 #include "gate_device.h"
@@ -36,7 +45,6 @@ extern "C" int xivo_hip_debug_read_fused_trace(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xivo_fused_trace_buf), (size_t)n * sizeof(unsigned long long));
 }
 // second level: every wave, 16 slots (the factorisation: slot 2 j / 2 j + 1 = entry / exit of column j's work of that wave)
-__device__ unsigned long long xivo_fused_trace2_buf[128 * 16 * 32];
 #define FTR2(slot) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 128 && (slot) < 32) \
     xivo_fused_trace2_buf[((blockIdx.x >> 6) * 16 + (threadIdx.x >> 6)) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int xivo_hip_debug_read_fused_trace2(unsigned long long* out, int n) {
@@ -51,6 +59,9 @@ extern "C" int xivo_hip_debug_read_fused_trace2(unsigned long long* out, int n) 
 // gathers of phase 1, 2 stop behind the factorisation, 3 no stores of P+, 4 no mirror stores, 5 no loads of the P tiles
 #ifndef XIVO_FUSED_ABL
 #define XIVO_FUSED_ABL 0
+#endif
+#ifndef XIVO_FUSED_FWD_LATE
+#define XIVO_FUSED_FWD_LATE 0   // A/B: the forward substitution behind the factorisation instead of next to it
 #endif
 #ifndef XIVO_FUSED_GVAR
 #define XIVO_FUSED_GVAR 0   // timing-only variants of the gather's address pattern (with XIVO_FUSED_ABL=1)
@@ -94,6 +105,86 @@ __device__ __forceinline__ void fu_wait3(double& r0, double& r1, double& r2, int
 __device__ __forceinline__ void fu_anchor(unsigned& a, int& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void fu_anchor(unsigned& a, int& b, double x, double y) { asm volatile("" : "+v"(a), "+v"(b) : "v"(x), "v"(y)); }
 
+// The covariance product of the one-kernel update when every column block's operand is in LDS at once (one phase) and every
+// wave owns exactly NTU tiles: tile t of wave w is block pair (w, w - t mod nwl) - for an even nwl the last one is a dummy
+// for half the waves (computed, not stored). Straight-line code: the -P tile of step t is requested PD steps ahead, and
+// nothing between a request and its use is conditional on anything but the wave index - so the compiler's wait counts are
+// exact (vmcnt(n) = the younger requests and stores). In the general loop below the requests and stores sit inside
+// `if (t < nt)` / per-lane `if` blocks: its bookkeeping gives up at every join, every wait is vmcnt(0), and each tile waits
+// for the loads just requested AND for the acknowledgement of the previous tile's stores - a full memory round trip per
+// tile, 46 k cycles for seven tiles of sixteen MFMAs. To keep the stores unconditional the diagonal tile writes ALL its
+// lanes twice: the direct pass stores the whole block (its upper half is then overwritten), the mirror pass stores the
+// transposed lower half into the upper half and, in the lower half, the direct pass's own value again.
+template <int NBM, int NTU>
+__device__ __forceinline__ void fused_product_one_phase(const d4 (&X)[NBM], const double* ybuf, double* tsc, double* Pio, int ldp, int nb, int nwl,
+                                                        int wave, int lane) {
+  constexpr int PD = 4;
+  const int li = lane & 15, lg = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rO = buf_rsrc(Pio);
+  const unsigned vM = (unsigned)(li + lg * ldp) * 8u;
+  auto block_of = [&](int t, int& jb, bool& real) {
+    jb = wave - t; if (jb < 0) jb += nwl;
+    real = 2 * t < nwl || (2 * t == nwl && wave > jb);
+  };
+  d4 ring[PD];
+  auto request = [&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    int jb; bool real; block_of(t, jb, real);
+    const int ba = jb <= wave ? wave : jb, bb = jb <= wave ? jb : wave;       // block (ba, bb), ba >= bb: P's lower triangle
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ring[t % PD][r] = XIVO_FUSED_ABL == 5 ? 1.0 : buf_ld_once(rO, vM, (unsigned)(16 * ba + (16 * bb + 4 * r) * ldp) * 8u);
+  };
+  static_for<(PD < NTU ? PD : NTU)>([&](auto tc) { request(tc); });
+  lds_barrier();                                   // every wave's operand W + D is in place
+  static_for<NTU>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    int jb; bool real; block_of(t, jb, real);
+    d4 acc = -ring[t % PD];
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    if constexpr (t + PD < NTU) request(std::integral_constant<int, t + PD>{});
+    const double* Bop = ybuf + jb * nb * 256 + lane;
+    if (jb <= wave) {
+#pragma unroll
+      for (int mb = 0; mb < NBM; ++mb) {
+        if (mb < nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma(Bop[(mb * 4 + r) * 64], X[mb][r], acc);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < NBM; ++mb) {
+        if (mb < nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma(X[mb][r], Bop[(mb * 4 + r) * 64], acc);
+        }
+      }
+    }
+    // the tile (block (ba, bbk), ba >= bbk: rows li, columns lg + 4 r) and its mirror image through the 2 KB transpose in LDS
+    // (four full 128-byte lines per store instruction instead of sixteen 32-byte pieces)
+    const int ba = jb <= wave ? wave : jb, bbk = jb <= wave ? jb : wave;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tsc[(lg + 4 * r) * 16 + (li ^ (lg + 4 * r))] = -acc[r];      // element (a = li, b = lg + 4 r)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double mv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double v = tsc[li * 16 + ((lg + 4 * r) ^ li)];                                        // element (a = lg + 4 r, b = li)
+      mv[r] = (jb != wave || lg + 4 * r > li) ? v : -acc[r];                                      // diagonal tile: the lower triangle is authoritative
+    }
+    if (t + 1 < NTU || real) {                     // (only the last step can be a dummy: nothing is counted behind it)
+      if (XIVO_FUSED_ABL != 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf_st_out(-acc[r], rO, vM, (unsigned)(16 * ba + (16 * bbk + 4 * r) * ldp) * 8u);
+      }
+      if (XIVO_FUSED_ABL != 3 && XIVO_FUSED_ABL != 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf_st_out(mv[r], rO, vM, (unsigned)(16 * bbk + (16 * ba + 4 * r) * ldp) * 8u);
+      }
+    }
+  });
+}
+
 template <int NBM, int NWV, int XC, int GD>
 __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs g) {
   constexpr int BLK = 16 * 17, CWU = FU_CWU, PWU = FU_PWU, NSLOT = FU_NSLOT, KS = CWU / 4, NC = XC / 16;
@@ -114,6 +205,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
   double* sdist = sm + map.dist;
   unsigned char* sRej = reinterpret_cast<unsigned char*>(sm + map.rej);
   int& sBad = *reinterpret_cast<int*>(sRej + Mp);
+  int& sAny = *reinterpret_cast<int*>(sRej + Mp + 4);          // the gate rejected at least one pair
   double* Pio = g.P + (long)filt * g.strideP;
   double* innG = g.inn + (long)filt * g.strideInn;
   double* dRG = g.diagR + (long)filt * g.strideR;
@@ -133,7 +225,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
     }
     if (tid < ELL_CW) pidx[pairs * ELL_PIW + tid] = (unsigned short)gi[tid];   // the common slots (the same in every pair)
     for (int m = tid; m < Mp; m += NT) { sInn[m] = innG[m]; sR[m] = dRG[m]; sRej[m] = 0; }
-    if (tid == 0) sBad = 0;
+    if (tid == 0) { sBad = 0; sAny = 0; }
   }
   __syncthreads();
   FTR(1);
@@ -243,22 +335,30 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
   // ---- 2  S = H (P H^T) + diag(R): the waves park their columns of H P as the slab of ell<S> (row k = state index,
   //         column = measurement row of the pass, XOR swizzle as in ell_tile_kernel) and walk the row pairs over it
   lds_barrier();                                   // every wave is done with its gather staging: the slab takes that LDS
+  FTR(9);
+  // (the lane coordinates of this phase pass through an empty asm: its LDS addresses depend on nothing but the lane, so the
+  //  optimiser computes them at the top of the kernel and the register allocator then spills them across the gather -
+  //  twelve dependent scratch reloads in front of the slab stores, 8 k cycles)
+  int li2 = li, lg2 = lg;
+  asm volatile("" : "+v"(li2), "+v"(lg2));
   for (int x0 = 0; x0 < Mp; x0 += XC) {
 #pragma unroll
     for (int i = 0; i < NBM; ++i) {
       if (i < nb && 16 * i >= x0 && 16 * i < x0 + XC) {
         // register r holds row 2 (lg + 4 (r >> 1)) + (r & 1) of the block (phase 1); it comes back as row 4 r + lg - the
         // accumulator layout of the substitutions. A wave reads only what it wrote itself: no barrier in between.
-        const int k = c0 + li;
+        const int k = c0 + li2;
         double* trow = tile + k * XC;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) trow[(16 * i - x0 + 2 * (lg + 4 * (r >> 1)) + (r & 1)) ^ (k & 15)] = X[i][r];
+        for (int r = 0; r < 4; ++r) trow[(16 * i - x0 + 2 * (lg2 + 4 * (r >> 1)) + (r & 1)) ^ (k & 15)] = X[i][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 4; ++r) X[i][r] = trow[(16 * i - x0 + 4 * r + lg) ^ (k & 15)];
+        for (int r = 0; r < 4; ++r) X[i][r] = trow[(16 * i - x0 + 4 * r + lg2) ^ (k & 15)];
       }
     }
+    if (x0 == 0) FTR(10);
     lds_barrier();
+    if (x0 == 0) FTR(11);
     // tasks: (row-pair block rb, 16-column block c of this pass) on or below the diagonal of S
     const int cb0 = x0 / 16, ncb = min(NC, nb - cb0);
     const unsigned short* cidx = pidx + pairs * ELL_PIW;
@@ -275,18 +375,30 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
       for (int q = 0; q < 2; ++q) {
         const int p = p0 + lg + 4 * q;
         const d2* pv = reinterpret_cast<const d2*>(ops) + (long)p * NSLOT + CWU;
-        const unsigned short* pkp = pidx + p * ELL_PIW;
-        d2 v[PWU]; double gg[PWU];
+        // all slot indices of the pair up front (packed 16-bit: three 8-byte reads): a step then waits for ONE LDS round trip -
+        // its gathers - instead of two (index, then gather)
+        uint2 iq[ELL_PIW / 4];
+        {
+          const uint2* pq = reinterpret_cast<const uint2*>(pidx + p * ELL_PIW);
 #pragma unroll
-        for (int t = 0; t < PWU; ++t) {
-          v[t] = pv[t];
-          const int k = (int)pkp[t];
-          gg[t] = tile[k * XC + ((16 * c + li) ^ (k & 15))];
+          for (int u = 0; u < ELL_PIW / 4; ++u) iq[u] = pq[u];
         }
 #pragma unroll
-        for (int t = 0; t < PWU; ++t) {
-          acc[2 * q] = fma(v[t][0], gg[t], acc[2 * q]);
-          acc[2 * q + 1] = fma(v[t][1], gg[t], acc[2 * q + 1]);
+        for (int t0 = 0; t0 < PWU; t0 += 3) {        // three slots per step (all nine at once: 54 registers, spills around the walk)
+          d2 v[3]; double gg[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            v[t] = pv[t0 + t];
+            const unsigned w = ((t0 + t) & 2) ? iq[(t0 + t) >> 2].y : iq[(t0 + t) >> 2].x;
+            const int k = (int)(((t0 + t) & 1) ? (w >> 16) : (w & 0xffffu));
+            gg[t] = tile[k * XC + ((16 * c + li) ^ (k & 15))];
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            acc[2 * q] = fma(v[t][0], gg[t], acc[2 * q]);
+            acc[2 * q + 1] = fma(v[t][1], gg[t], acc[2 * q + 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
@@ -306,6 +418,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
         dst[ml + 17 * xl] = v;
       }
     }
+    if (x0 == 0) FTR(12);
     lds_barrier();
   }
   FTR(3);
@@ -322,17 +435,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
       sdist[f] = mh_dist_2x2(s00, s10, s11, sInn[2 * f], sInn[2 * f + 1]);
     }
     lds_barrier();
-    if (wave == 0) {
-      const double th = relax_threshold(sdist, F, g.thresh, g.mult, g.min_inliers, lane);
-      if (lane == 0) sdist[F] = th;
-    }
-    lds_barrier();
-    const double th = sdist[F];
+    // (every wave runs the relaxation loop on the distances in LDS and arrives at the same threshold: one barrier fewer
+    //  than a single wave publishing it)
+    const double th = relax_threshold(sdist, F, g.thresh, g.mult, g.min_inliers, lane);
     for (int f = tid; f < F; f += NT) {
       const bool in = sdist[f] < th;
       g.mask[(long)filt * F + f] = in ? 1 : 0;
       g.dist[(long)filt * F + f] = sdist[f];
       if (!in) {
+        sAny = 1;
         sRej[2 * f] = 1; sRej[2 * f + 1] = 1;
         sInn[2 * f] = 0.0; sInn[2 * f + 1] = 0.0;
         innG[2 * f] = 0.0; innG[2 * f + 1] = 0.0;
@@ -342,34 +453,41 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
       }
     }
     lds_barrier();
-    if (g.H) {   // dense copies of the stacked rows are alive (xivo_hip_get_H, the dense fallback rows): keep them consistent
-      double* H = g.H + (long)filt * g.strideH;
-      double* HT = g.HT + (long)filt * g.strideHT;
-      for (int f = 0; f < F; ++f) {
-        if (!sRej[2 * f]) continue;
-        for (int n = tid; n < Np; n += NT) {
-          H[2 * f + (long)n * g.ldh] = 0.0; H[2 * f + 1 + (long)n * g.ldh] = 0.0;
-          HT[n + (long)(2 * f) * g.ldht] = 0.0; HT[n + (long)(2 * f + 1) * g.ldht] = 0.0;
+    if (sAny) {                                    // (the common case - every candidate passes - ends here)
+      if (g.H) {   // dense copies of the stacked rows are alive (xivo_hip_get_H, the dense fallback rows): keep them consistent
+        double* H = g.H + (long)filt * g.strideH;
+        double* HT = g.HT + (long)filt * g.strideHT;
+        for (int f = 0; f < F; ++f) {
+          if (!sRej[2 * f]) continue;
+          for (int n = tid; n < Np; n += NT) {
+            H[2 * f + (long)n * g.ldh] = 0.0; H[2 * f + 1 + (long)n * g.ldh] = 0.0;
+            HT[n + (long)(2 * f) * g.ldht] = 0.0; HT[n + (long)(2 * f + 1) * g.ldht] = 0.0;
+          }
         }
       }
-    }
-    // rows / columns of the rejected pairs decoupled in S (0, unit diagonal), their right-hand sides zeroed
-    for (int e = tid; e < (nblk + nb) * 256; e += NT) {
-      const int t = e >> 8, w = e & 255, r = w & 15, c = w >> 4;
-      int i, k;
-      if (t < nblk) { i = 0; while ((i + 1) * (i + 2) / 2 <= t) ++i; k = t - i * (i + 1) / 2; if (i == k) continue; }
-      else { i = k = t - nblk; }
-      double* blk = t < nblk ? sL + t * BLK : sD + (t - nblk) * BLK;
-      if (sRej[16 * i + r] | sRej[16 * k + c]) blk[r + 17 * c] = (i == k && r == c) ? 1.0 : 0.0;
-    }
+      // rows / columns of the rejected pairs decoupled in S (0, unit diagonal): one block per wave and trip, four elements per lane
+      for (int t = wave; t < nblk + nb; t += nw) {
+        int i, k;
+        if (t < nblk) { i = 0; while ((i + 1) * (i + 2) / 2 <= t) ++i; k = t - i * (i + 1) / 2; if (i == k) continue; }   // (a diagonal slot of the factor: receives inv(L_kk))
+        else { i = k = t - nblk; }
+        double* blk = t < nblk ? sL + t * BLK : sD + (t - nblk) * BLK;
+        const bool rr = sRej[16 * i + li] != 0;
 #pragma unroll
-    for (int i = 0; i < NBM; ++i) {
-      if (i < nb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (sRej[16 * i + 4 * r + lg]) X[i][r] = 0.0;
+        for (int r = 0; r < 4; ++r) {
+          const int c = lg + 4 * r;
+          if (rr | (sRej[16 * k + c] != 0)) blk[li + 17 * c] = (i == k && li == c) ? 1.0 : 0.0;
+        }
       }
+      // ... and their right-hand sides zeroed
+#pragma unroll
+      for (int i = 0; i < NBM; ++i) {
+        if (i < nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (sRej[16 * i + 4 * r + lg]) X[i][r] = 0.0;
+        }
+      }
+      lds_barrier();
     }
-    lds_barrier();
   }
   FTR(4);
 
@@ -397,29 +515,28 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
   };
   {
     const int lo = li + 17 * lg;
-    static_for<NBM>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if (j < nb) {
+    // look-ahead: while the owner of column j factors its diagonal block the other waves of the factor are idle - they form
+    // the partial sums that do not depend on column j: the panel's sum_{k<j} L_jk L_ik^T, and (next owner) the diagonal
+    // update's sum_{k<j} L_{j+1,k} L_{j+1,k}^T. Behind the barrier only the terms of column j itself are left in the chain.
+    // The two accumulators receive their terms in the same (ascending k) order as before: same bits.
+    d4 pre0 = d4{0.0, 0.0, 0.0, 0.0}, pre1 = d4{0.0, 0.0, 0.0, 0.0};
+    // (the block-column loop runs at run time: ONE copy of the straight-line diagonal factorisation in the kernel; the
+    //  forward steps behind it need compile-time block indices - dispatched by static_for on the run-time column)
+#pragma unroll 1
+    for (int j = 0; j < nb; ++j) {
+      {
         const int dj = (j * (j + 1) / 2 + j) * BLK;                         // diagonal slot: inv(L_jj)
         FTR2(4 * j);
+        d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
         if (wave == j) {
           __builtin_amdgcn_s_setprio(3);             // the chain of diagonal blocks is the critical path: ahead of the forward steps of the other waves
-          d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
-          const double* Lj = sL + (j * (j + 1) / 2) * BLK + lo;
-#pragma unroll 1
-          for (int k = 0; k < j; ++k) {
-            const double a0 = Lj[k * BLK], a1 = Lj[k * BLK + 68], a2 = Lj[k * BLK + 136], a3 = Lj[k * BLK + 204];
-            acc0 = mfma(a0, a0, acc0);
-            acc1 = mfma(a1, a1, acc1);
-            acc0 = mfma(a2, a2, acc0);
-            acc1 = mfma(a3, a3, acc1);
-          }
+          const d4 acc0 = pre0, acc1 = pre1;         // terms k < j - 1 formed while column j - 1 was factored, term j - 1 behind its panel step
           d4 x, y;
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[r] = sD[j * BLK + lo + 68 * r] - (acc0[r] + acc1[r]);
           int bad = 0;
           FTR2(4 * j + 1);
-          factor_invert_diag(x, y, bad, 16 * j, li, lg);
+          factor_invert_diag_chain(x, y, bad, 16 * j, li, lg);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int c = lg + 4 * r;
@@ -428,17 +545,40 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
           }
           if (bad && lane == 0 && sBad == 0) sBad = bad;
           __builtin_amdgcn_s_setprio(0);
+        } else if (wave > j && wave < nb) {
+          const double* Lj = sL + (j * (j + 1) / 2) * BLK + lo;
+          const double* Li = sL + (wave * (wave + 1) / 2) * BLK + lo;
+          // (block column j - 1 of row j was written behind the previous barrier by wave j: not before this one)
+#pragma unroll 1
+          for (int k = 0; k < j - 1; ++k) {
+            const double a0 = Lj[k * BLK], b0 = Li[k * BLK], a1 = Lj[k * BLK + 68], b1 = Li[k * BLK + 68];
+            accA = mfma(a0, b0, accA);
+            accB = mfma(a1, b1, accB);
+            const double a2 = Lj[k * BLK + 136], b2 = Li[k * BLK + 136], a3 = Lj[k * BLK + 204], b3 = Li[k * BLK + 204];
+            accA = mfma(a2, b2, accA);
+            accB = mfma(a3, b3, accB);
+          }
+          if (wave == j + 1) {                       // next owner: its diagonal update over the block columns already final
+            pre0 = d4{0.0, 0.0, 0.0, 0.0}; pre1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int k = 0; k < j; ++k) {
+              const double a0 = Li[k * BLK], a1 = Li[k * BLK + 68], a2 = Li[k * BLK + 136], a3 = Li[k * BLK + 204];
+              pre0 = mfma(a0, a0, pre0);
+              pre1 = mfma(a1, a1, pre1);
+              pre0 = mfma(a2, a2, pre0);
+              pre1 = mfma(a3, a3, pre1);
+            }
+          }
         }
         FTR2(4 * j + 2);
         lds_barrier();
         FTR2(4 * j + 3);
         if (wave > j && wave < nb) {
           if (wave == j + 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
-          const double* Lj = sL + (j * (j + 1) / 2) * BLK + lo;
           double* Li = sL + (wave * (wave + 1) / 2) * BLK + lo;
-          d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-          for (int k = 0; k < j; ++k) {
+          if (j >= 1) {
+            const int k = j - 1;
+            const double* Lj = sL + (j * (j + 1) / 2) * BLK + lo;
             const double a0 = Lj[k * BLK], b0 = Li[k * BLK], a1 = Lj[k * BLK + 68], b1 = Li[k * BLK + 68];
             accA = mfma(a0, b0, accA);
             accB = mfma(a1, b1, accB);
@@ -455,13 +595,24 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
 #pragma unroll
           for (int r = 0; r < 4; ++r) Li[j * BLK + 68 * r] = out[r];
           if (wave != j + 1) __builtin_amdgcn_s_setprio(0);     // (the next owner keeps its priority into its factorisation)
+          else {
+            // the last term of the next diagonal update, L_{j+1,j} L_{j+1,j}^T, straight from the registers it was just formed in
+            // (out[s] is element (li, lg + 4 s) of the block: the A and the B operand of k-slice s as it stands) - no LDS round trip
+            pre0 = mfma(out[0], out[0], pre0);
+            pre1 = mfma(out[1], out[1], pre1);
+            pre0 = mfma(out[2], out[2], pre0);
+            pre1 = mfma(out[3], out[3], pre1);
+          }
         }
         // (a broken factor leaves NaNs at worst: nothing of X is used then)
-        if constexpr (j >= 2) { if (wave == j) forward(std::integral_constant<int, j - 2>{}); }
-        if constexpr (j >= 1) { if (wave != j + 1 || j + 1 >= nb) forward(std::integral_constant<int, j - 1>{}); }
+        if (!XIVO_FUSED_FWD_LATE) {
+          if (wave == j) static_for<NBM>([&](auto kc) { constexpr int k = decltype(kc)::value; if (k == j - 2) forward(kc); });
+          if (wave != j + 1 || j + 1 >= nb) static_for<NBM>([&](auto kc) { constexpr int k = decltype(kc)::value; if (k == j - 1) forward(kc); });
+        }
       }
-    });
+    }
     lds_barrier();
+    if (XIVO_FUSED_FWD_LATE) static_for<NBM>([&](auto kc) { constexpr int k = decltype(kc)::value; if (k < nb - 1) forward(kc); });
   }
   const int chol_bad = sBad;
   if (tid == 0) g.status[filt] = chol_bad;
@@ -581,6 +732,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
     };
     if (!early) __syncthreads();                   // the factor is dead: the LDS takes the operands
     write_y(0);
+    if (nph == 1 && (nwl / 2 + 1 == 7 || nwl / 2 + 1 == 6)) {   // the two target shapes (13 / 10 column blocks): hand-counted waits
+      if (nwl / 2 + 1 == 7) fused_product_one_phase<NBM, 7>(X, sm, sm + g.tsc_off + wave * 256, Pio, g.ldp, nb, nwl, wave, lane);
+      else fused_product_one_phase<NBM, 6>(X, sm, sm + g.tsc_off + wave * 256, Pio, g.ldp, nb, nwl, wave, lane);
+      FTR(8);
+      FTR2(31);
+      return;
+    }
     int nt = list_tiles(my_tiles(0));
     static_for<PD>([&](auto tc) { constexpr int t = decltype(tc)::value; if (t < nt) request(jl_of[t], ring[t]); });
     for (int p = 0; p < nph; ++p) {
@@ -681,13 +839,14 @@ int launch_fused_update_t(const FusedArgs& g, hipStream_t stream) {
 
 }  // namespace
 
-// instantiations: <4, 16, 64> M <= 64 on any state one workgroup holds (128 VGPRs; <4, 16, 32>: where the 64-wide slab does not fit next to S); <7, 12, 32> M <= 112, N <= 192 (168 VGPRs)
+// instantiations (NBM, NWV, XC; x two gather depths): <4, 16, 64> M <= 64 on any state one workgroup holds (128 VGPRs; <4, 16, 32>: where the 64-wide slab does not fit next to S); <7, 12, 48> (slab in three passes; <7, 12, 32>: four, where 48 columns do not fit) M <= 112, N <= 192 (168 VGPRs)
 static int fused_pick(int Mp, int Np) {
   static const bool off = getenv("XIVO_HIP_NO_FUSED_UPDATE") != nullptr;   // A/B knob: the five-kernel pipeline
   if (off || Np % 16 || Mp % 16 || Np < 16 || Mp < 16) return 0;
   const int nb = Mp / 16, nwl = Np / 16;
   if (nb <= 4 && nwl <= 16 && (size_t)fused_lds_map(Np, Mp, 64).total * 8 <= 160 * 1024) return 1;
   if (nb <= 4 && nwl <= 16 && (size_t)fused_lds_map(Np, Mp, 32).total * 8 <= 160 * 1024) return 3;
+  if (nb <= 7 && nwl <= 12 && (size_t)fused_lds_map(Np, Mp, 48).total * 8 <= 160 * 1024) return 4;
   if (nb <= 7 && nwl <= 12 && (size_t)fused_lds_map(Np, Mp, 32).total * 8 <= 160 * 1024) return 2;
   return 0;
 }
@@ -698,13 +857,14 @@ int launch_fused_update(const FusedArgs& g, hipStream_t stream) {
     case 1: return launch_fused_update_t<4, 16, 64>(g, stream);
     case 2: return launch_fused_update_t<7, 12, 32>(g, stream);
     case 3: return launch_fused_update_t<4, 16, 32>(g, stream);
+    case 4: return launch_fused_update_t<7, 12, 48>(g, stream);
   }
   return (int)hipErrorInvalidValue;
 }
 void fused_update_label(int Mp, int Np, char* buf, size_t n) {
   const int k = fused_pick(Mp, Np);
   if (k == 1 || k == 3) snprintf(buf, n, "fused_update_f64_kernel<4,16,%d,%d>", k == 1 ? 64 : 32, fused_gather_depth(Np, Mp, k == 1 ? 64 : 32));
-  else snprintf(buf, n, "fused_update_f64_kernel<7,12,32,%d>", fused_gather_depth(Np, Mp, 32));
+  else snprintf(buf, n, "fused_update_f64_kernel<7,12,%d,%d>", k == 4 ? 48 : 32, fused_gather_depth(Np, Mp, k == 4 ? 48 : 32));
 }
 
 }  // namespace xivo_hip
