@@ -49,11 +49,15 @@ def test_fused_update_matches_oracle(built, N, F, B):
         assert set(k for k, v in prof.items() if v["launches"]) <= {"trsm_gain", "other", "stack_H"}, prof   # (stack_H: the hand-over of the measurements)
     assert (st == 0).all() and used.sum() == 0
     for b in sorted(set([0, min(5, B - 1), B - 1])):
-        d_ref = orc.mh_distances(H[b].reshape(F, 2, N), P[b], inn[b].reshape(F, 2), R)
-        m_ref = orc.mh_gate(d_ref, 5.991, 1.1, 5)[0]
-        assert np.array_equal(mask[b].astype(bool), np.asarray(m_ref).astype(bool))
-        assert np.allclose(dist[b], d_ref, rtol=1e-9, atol=0)
-        e_ref, P_ref = _gated_reference(P[b], H[b], inn[b], dR[b], mask[b])
+        if F > 5:                                   # (Estimator::OutlierRejection gates only when F > min_required_inliers_, src/manager.cpp:635)
+            d_ref = orc.mh_distances(H[b].reshape(F, 2, N), P[b], inn[b].reshape(F, 2), R)
+            m_ref = orc.mh_gate(d_ref, 5.991, 1.1, 5)[0]
+            assert np.array_equal(mask[b].astype(bool), np.asarray(m_ref).astype(bool))
+            assert np.allclose(dist[b], d_ref, rtol=1e-9, atol=0)
+            keep = mask[b]
+        else:
+            keep = np.ones(F, dtype=bool)
+        e_ref, P_ref = _gated_reference(P[b], H[b], inn[b], dR[b], keep)
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
         assert np.array_equal(Pn[b], Pn[b].T)
     if F >= 8 and B > 5:

@@ -6,7 +6,7 @@ import pytest
 import xivo_oracle as orc
 from helpers import rel_fro, TOL_P, TOL_DX
 from xivo_amd import synth
-from xivo_amd.lib import Context, FLAG_FULL_PNEW, FLAG_DENSE_H, FLAG_THROUGHPUT_ROUTE
+from xivo_amd.lib import Context, FLAG_FULL_PNEW, FLAG_DENSE_H, FLAG_THROUGHPUT_ROUTE, FLAG_MULTI_KERNEL
 
 pytestmark = pytest.mark.gpu
 
@@ -527,7 +527,8 @@ def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
             outs.append(ctx.download_P()); errs.append(ctx.get_err())
             kern.append({k: v["kernel"] for k, v in ctx.profile_get().items() if v["launches"]})
     # (the in-solve whitened form: <NBM,4>, or its ten-wave instantiation <7,4,false,10,3> for seven block rows on <= 160 columns)
-    assert (kern[0]["trsm_gain"].endswith(",4>") or ",4,false," in kern[0]["trsm_gain"]) and "gemm_Pnew" not in kern[0]
+    # (round 6: or the one-kernel update for the shapes a CU holds - the same whitened expression)
+    assert (kern[0]["trsm_gain"].endswith(",4>") or ",4,false," in kern[0]["trsm_gain"] or kern[0]["trsm_gain"].startswith("fused_update")) and "gemm_Pnew" not in kern[0]
     assert kern[1]["trsm_gain"].endswith(",1>") and "gemm_Pnew" in kern[1] and "gemm_KH_I" in kern[1]
     assert rel_fro(errs[0], errs[1]) < 1e-13      # same solve; the in-solve variant sums dx = K inn block by block as the gain appears
     assert rel_fro(outs[0], outs[1]) < 1e-11
@@ -547,7 +548,7 @@ def test_whitened_and_expanded_in_solve_forms_agree(built, N, F):
     B = 9                                    # more than one XCD group of 8
     P, H, inn, dR = synth.s_level(N, F, B, seed=23)
     outs, errs, kern = [], [], []
-    for flags in (FLAG_THROUGHPUT_ROUTE, FLAG_EXPANDED_JOSEPH, 0):
+    for flags in (FLAG_THROUGHPUT_ROUTE | FLAG_MULTI_KERNEL, FLAG_EXPANDED_JOSEPH, FLAG_MULTI_KERNEL):   # (the multi-kernel pipeline's forms; the one-kernel route: test_fused_gpu.py)
         with Context(N, 2 * F, B, flags=flags | FLAG_PROFILE) as ctx:
             ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
             assert ctx.last_path() == 1 and (ctx.get_status() == 0).all()
@@ -653,7 +654,7 @@ def test_seven_block_rows_on_a_narrow_state_keep_W_in_registers(built, N, F, wav
     idx = np.arange(B) % 8
     P, H, inn, dR = P[idx].copy(), H[idx].copy(), inn[idx].copy(), dR[idx].copy()
     inn[5, 4:8] *= 1e4                                      # two features of filter 5 fail the gate
-    with Context(N, 2 * F, B, flags=FLAG_THROUGHPUT_ROUTE | FLAG_PROFILE) as ctx:
+    with Context(N, 2 * F, B, flags=FLAG_THROUGHPUT_ROUTE | FLAG_MULTI_KERNEL | FLAG_PROFILE) as ctx:   # (round 6: these shapes default to the one-kernel update)
         ctx.upload_P(P); ctx.set_measurements(H, inn, dR)
         ctx.update_dense_gated(F, float(dR[0, 0]), 5.991, 1.1, 5)
         assert ctx.last_path() == 1
