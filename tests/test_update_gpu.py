@@ -520,15 +520,14 @@ def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
     B = 3
     P, H, inn, dR = synth.s_level(N, F, B, seed=17)
     outs, errs, kern = [], [], []
-    for flags in (FLAG_THROUGHPUT_ROUTE, FLAG_STANDALONE_TAIL):
+    for flags in (FLAG_THROUGHPUT_ROUTE | FLAG_MULTI_KERNEL, FLAG_STANDALONE_TAIL):   # (the multi-kernel pipeline's two tails)
         with Context(N, 2 * F, B, flags=flags | FLAG_PROFILE) as ctx:
             ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
             assert ctx.last_path() == 1
             outs.append(ctx.download_P()); errs.append(ctx.get_err())
             kern.append({k: v["kernel"] for k, v in ctx.profile_get().items() if v["launches"]})
     # (the in-solve whitened form: <NBM,4>, or its ten-wave instantiation <7,4,false,10,3> for seven block rows on <= 160 columns)
-    # (round 6: or the one-kernel update for the shapes a CU holds - the same whitened expression)
-    assert (kern[0]["trsm_gain"].endswith(",4>") or ",4,false," in kern[0]["trsm_gain"] or kern[0]["trsm_gain"].startswith("fused_update")) and "gemm_Pnew" not in kern[0]
+    assert (kern[0]["trsm_gain"].endswith(",4>") or ",4,false," in kern[0]["trsm_gain"]) and "gemm_Pnew" not in kern[0]
     assert kern[1]["trsm_gain"].endswith(",1>") and "gemm_Pnew" in kern[1] and "gemm_KH_I" in kern[1]
     assert rel_fro(errs[0], errs[1]) < 1e-13      # same solve; the in-solve variant sums dx = K inn block by block as the gain appears
     assert rel_fro(outs[0], outs[1]) < 1e-11
