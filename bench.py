@@ -90,18 +90,44 @@ def cpu_baseline(N, F, seconds=12.0):
     # mode (ii) of BASELINE.md section 3: one independent filter per host core on all cores
     try:
         import multiprocessing as mp
-        nproc = os.cpu_count() or 1
-        with mp.get_context("spawn").Pool(nproc) as pool:
-            res = pool.map(_cpu_worker, [(N, F, 6.0)] * nproc)
-        out["all_cores"] = {"value": sum(r[0] / r[1] for r in res), "unit": "updates/s", "cores": nproc,
-                            "sample": f"{nproc} processes x 6 s, one filter each"}
+        # the cores this process may really use (cgroup / taskset), one pinned process each - os.cpu_count() is the host's
+        # core count, not the container's (round 5 printed "256 cores" at 5.6 x one core)
+        cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+        quota = _cgroup_cpu_quota()
+        if quota is not None and quota < len(cpus):
+            cpus = cpus[:max(1, int(quota))]
+        with mp.get_context("spawn").Pool(len(cpus)) as pool:
+            res = pool.map(_cpu_worker, [(N, F, 6.0, c) for c in cpus])
+        ran = sorted({r[2] for r in res if r[2] is not None})
+        out["all_cores"] = {"value": sum(r[0] / r[1] for r in res), "unit": "updates/s", "cores": len(cpus),
+                            "pinned_to": len(ran), "cgroup_cpu_quota": quota,
+                            "sample": f"{len(cpus)} processes x 6 s, one filter each, each pinned to one core of the affinity mask"}
     except Exception as e:   # never let the reported baseline break the bench line
         out["all_cores"] = {"error": repr(e)}
     return out
 
 
+def _cgroup_cpu_quota():
+    """CPU quota of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def _cpu_worker(arg):
-    N, F, seconds = arg
+    N, F, seconds, cpu = arg
+    pinned = None
+    try:
+        os.sched_setaffinity(0, {cpu}); pinned = cpu
+    except Exception:
+        pass
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from xivo_amd import synth
     P, H, inn, dR = synth.s_level(N, F, 1, seed=4242)
@@ -121,7 +147,7 @@ def _cpu_worker(arg):
     while time.perf_counter() - t0 < seconds:
         fn()
         n += 1
-    return n, time.perf_counter() - t0
+    return n, time.perf_counter() - t0, pinned
 
 
 def parity_check(ctx, step, B, uniq, F, P, H, inn, dR, gate, no_gating, tol_P=1e-6):
@@ -230,6 +256,50 @@ def parity_glevel(ctx, step, B, uniq, P0, tol_P=1e-6):
             "checker": "oracle/xivo_oracle.py update_joseph on the rows the device stacked (xivo_hip_get_H)"}
 
 
+def parity_frame(ctx, B, uniq, P0, scene, imu, Qimu, Qmodel, grav, method, gate, no_gating, tol_P=1e-6):
+    """Whole-frame rows: ONE frame from the initial state, checked in its two halves on 3 filters spread over the launch -
+    (i) Estimator::Propagate (src/estimator.cpp:539-592: every IMU sample through the oracle's RK4 / Dormand-Prince steps,
+    nominal state and covariance) against the device's state and P behind xivo_hip_propagate, (ii) the measurement update
+    against the oracle's UpdateJosephForm on the rows the device stacked from that propagated state, with the covariance
+    the device held in front of the update."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import xivo_oracle as orc
+    poses, groups, feats = scene
+    R, th, mult, min_inl = gate
+    ctx.restore_P()
+    for b0 in range(0, B, uniq):
+        nb = min(uniq, B - b0)
+        ctx.set_scene(poses[:nb], groups[:nb], feats[:nb], b0=b0)
+    picks = sorted({b for b in (0, B // 2 + 3, B - 1) if 0 <= b < B})
+    ctx.propagate(imu, Qimu, Qmodel, grav, method=method, stepsize=0.002)
+    pose_d = ctx.get_scene()[0]
+    P_prop = {b: ctx.download_P(b0=b, nb=1)[0] for b in picks}
+    worst_prop = worst_state = 0.0
+    for b in picks:
+        u = b % uniq
+        X = orc.MotionState(poses[u]["Rsb"].reshape(3, 3).T, poses[u]["Tsb"], poses[u]["Vsb"], poses[u]["bg"], poses[u]["ba"],
+                            poses[u]["Rsg"].reshape(3, 3).T)
+        Pr = P0[u].copy()
+        for s_ in range(imu.shape[1]):
+            smp = imu[b, s_]
+            X, Pr = orc.propagate(X, Pr, smp["gyro"], smp["accel"], smp["slope_gyro"], smp["slope_accel"], float(smp["dt"]), Qimu, Qmodel, grav,
+                                  method=method, stepsize=0.002)
+        worst_prop = max(worst_prop, float(np.linalg.norm(P_prop[b] - Pr) / np.linalg.norm(Pr)))
+        worst_state = max(worst_state, float(np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - X.Rsb).max()), float(np.abs(pose_d[b]["Tsb"] - X.Tsb).max()),
+                          float(np.abs(pose_d[b]["Vsb"] - X.Vsb).max()))
+    ctx.filter_update(R, th, mult, min_inl, not no_gating, B)
+    worst_P = worst_dx = 0.0
+    for b in picks:
+        Hd, innd, dRd = ctx.get_H(b)
+        e_ref, P_ref, _ = orc.update_joseph(Hd, P_prop[b], innd, dRd)
+        worst_P = max(worst_P, float(np.linalg.norm(ctx.download_P(b0=b, nb=1)[0] - P_ref) / np.linalg.norm(P_ref)))
+        worst_dx = max(worst_dx, float(np.linalg.norm(ctx.get_err(b0=b, nb=1)[0] - e_ref) / np.linalg.norm(e_ref)))
+    ok = worst_prop < 1e-9 and worst_state < 1e-10 and worst_P < tol_P and worst_dx < 1e-8
+    return {"ok": bool(ok), "filters_checked_vs_oracle": picks, "propagate_rel_fro_P_max": worst_prop, "propagate_state_abs_max": worst_state,
+            "rel_fro_P_max": worst_P, "rel_dx_max": worst_dx, "tol": {"propagate_P": 1e-9, "propagate_state": 1e-10, "P": tol_P, "dx": 1e-8},
+            "checker": "oracle/xivo_oracle.py: propagate() per IMU sample, then update_joseph on the rows the device stacked (xivo_hip_get_H)"}
+
+
 def dropin_block(shapes=((203, 30), (250, 80)), n_calls=300):
     """Wall time of the LITERAL drop-in call - xivo::hip::Estimator::UpdateJosephForm() through libxivo_host.so with P_, H_,
     inn_, diagR_ in pageable host memory, one estimator (the reference is one singleton filter per process,
@@ -294,6 +364,9 @@ SUB_CONFIGS = [
     ("cfg2", "config2 (N=150, 50 features, M=100), fp64", ["--state-dim", "150", "--features", "50", "--steps", "8", "--warmup", "2"]),
     ("cfg3", "config3 (N=251: 60 in-state features + 20 OOS features null-space projected, QR-compressed), fp64, 4096 filters",
      ["--level", "G", "--oos", "20", "--batch", "4096", "--steps", "8", "--warmup", "2"]),
+    ("cfg3_m260", "config3 as SURVEY 8(d) states it: the same stacking WITHOUT measurement compression (the reference parses use_compression_ and "
+     "never reads it, src/estimator.cpp:115) - 120 in-state + 140 projected OOS rows, M = 260, 4096 filters",
+     ["--level", "G", "--oos", "20", "--no-compression", "--batch", "4096", "--steps", "8", "--warmup", "2"]),
     ("cfg4_f64", "config4 (N=400, 150 features, M=300), fp64 (library default), 4096 filters",
      ["--state-dim", "400", "--features", "150", "--batch", "4096", "--steps", "5", "--warmup", "2"]),
     ("cfg4_f32w", "config4 as written: fp32 MFMA with stated tolerance (XIVO_HIP_FLAG_FP32_WHITENED: the whitened operands V^T, Y^T leave the fp64 "
@@ -401,7 +474,7 @@ def compact_line(out):
     if cb:
         c["cpu_baseline"] = {"value": _r(cb["value"], 5), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                              "sample": cb["sample"][:110], "gpu_over_cpu": _r(cb.get("gpu_over_cpu")),
-                             "all_cores": {k: _r(v) for k, v in (cb.get("all_cores") or {}).items() if k in ("value", "cores", "error")}}
+                             "all_cores": {k: _r(v) for k, v in (cb.get("all_cores") or {}).items() if k in ("value", "cores", "pinned_to", "cgroup_cpu_quota", "error")}}
 
     def pc(q):
         return None if not q else {"ok": q.get("ok"), "P": _r(q.get("rel_fro_P_max"), 2), "dx": _r(q.get("rel_dx_max"), 2),
@@ -746,7 +819,12 @@ def main():
     parity = None
     if args.level == "S" and not args.no_parity_check:      # every rank checks its own GPU's results
         parity = parity_check(ctx, step, B, uniq, F, P, H, inn, dR, (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating, args.tol_P)
-    elif args.level == "G" and not args.no_parity_check and not frame and not args.ransac:
+    elif args.level == "G" and not args.no_parity_check and frame:
+        parity = parity_frame(ctx, B, uniq, P, (poses, groups, feats), imu, Qimu, Qmodel, grav, args.integrator,
+                              (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating, args.tol_P)
+    elif args.level == "G" and not args.no_parity_check:
+        # (--ransac too: OnePointRANSAC restores the state and covariance it experimented on - src/update.cpp:375-387 - so the
+        #  final update starts from the initial covariance, on the rows that survived)
         parity = parity_glevel(ctx, step, B, uniq, P, args.tol_P)
     per_rank_parity = gather_objects(dist, {"rank": rank, "device": device,
                                             "ok": None if parity is None else all(q["ok"] for q in (parity, parity_last, (symm or {}).get("parity_check")) if q is not None),
@@ -778,6 +856,30 @@ def main():
             k = k.replace(" ", "")
             return "gemm_sym_f64_kernel" if k.startswith("gemm_sym_f64_kernel") else k
 
+        def pmc_entry(table, label):
+            """The PMC record of the kernel the library names `label`: the library prints the template arguments that select
+            the instantiation (trsm_lds_f64_kernel<10,4>), rocprofv3 prints all of them, defaults included
+            (trsm_lds_f64_kernel<10, 4, false, 16, 1>) - round 5's line lost its counter fields to that. Exact name first,
+            then the unique record of the same kernel whose argument list starts with the library's."""
+            label = norm(label.split("+")[0])          # ("+gate": the gate folded into the factorisation - same kernel name)
+            if label in table:
+                return table[label]
+            base, _, args_ = label.partition("<")
+            want = args_.rstrip(">").split(",") if args_ else []
+            hits = []
+            for k, v in table.items():
+                if not isinstance(v, dict) or k.startswith("_"):
+                    continue
+                kb, _, ka = k.partition("<")
+                have = ka.rstrip(">").split(",") if ka else []
+                if kb == base and have[:len(want)] == want:
+                    hits.append((len(have), k, v))
+            if not hits:
+                return None
+            hits.sort()
+            # several instantiations share the prefix (a GATE / CHOL twin): the one that ran most in the profiled command
+            return max(hits, key=lambda h: h[2].get("launches_profiled", 0))[2]
+
         # group stages by the kernel instantiation the library reports for them (= the rocprofv3 kernel name)
         groups = {}
         for name, st in prof.items():
@@ -791,10 +893,23 @@ def main():
         pmc = {}
         try:
             import re
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_pmc_summary\.json", f))
-            if cands:
-                pmc = {norm(k): v for k, v in json.load(open(os.path.join(ROOT, "profiles", cands[-1]))).items()}
-                pmc["_file"] = "profiles/" + cands[-1]
+            # the newest committed PMC summary whose profiled command ran THIS workload (state dim / features / batch / level /
+            # flags): r06_pmc_summary.json for the headline, r06tumvi_..., r06cfg2_... for the child rows
+            def cmd_key(cmd):
+                def opt(name, default):
+                    m = re.search(name + r"\s+(\S+)", cmd)
+                    return m.group(1) if m else default
+                return (opt("--state-dim", "250"), opt("--features", "80"), opt("--batch", str(DEFAULT_BATCH)), opt("--level", "S"),
+                        opt("--flags", "0"), "--calib" in cmd, opt("--oos", "0"), opt("--propagate-samples", "0"))
+            mine = cmd_key(" ".join(sys.argv[1:]) + f" --batch {args.batch} --state-dim {args.state_dim} --features {args.features}")
+            cands = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+\w*_pmc_summary\.json", f)),
+                           key=lambda f: (int(re.match(r"r(\d+)", f).group(1)), f))
+            for f in reversed(cands):
+                rec = json.load(open(os.path.join(ROOT, "profiles", f)))
+                if cmd_key(str((rec.get("_notes") or {}).get("command", ""))) == mine:
+                    pmc = {norm(k): v for k, v in rec.items()}
+                    pmc["_file"] = "profiles/" + f
+                    break
         except Exception:
             pmc = {}
         # filters per launch of the profiled command (per-launch counters only compare at the same batch)
@@ -823,12 +938,12 @@ def main():
                         # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of the
                         # same command (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE); null if absent
                         "traffic": (lambda e: (e.get("hbm_read_bytes_per_launch", 0) + e.get("hbm_write_bytes_per_launch", 0))
-                                    if e and args.batch == pmc_batch else None)(pmc.get(norm(dom))),
+                                    if e and args.batch == pmc_batch else None)(pmc_entry(pmc, dom)),
                         "traffic_source": pmc.get("_file"),
                         # from the same PMC passes: flops the MFMA pipe really executed per launch (symmetry and
                         # K(HP) - P skip work the reference's as-coded count includes) and pipe busy %
-                        "executed_mfma_flops_per_launch": (pmc.get(norm(dom)) or {}).get("executed_mfma_f64_flops_per_launch"),
-                        "mfma_busy_pct_pmc": (pmc.get(norm(dom)) or {}).get("mfma_busy_pct"),
+                        "executed_mfma_flops_per_launch": (pmc_entry(pmc, dom) or {}).get("executed_mfma_f64_flops_per_launch"),
+                        "mfma_busy_pct_pmc": (pmc_entry(pmc, dom) or {}).get("mfma_busy_pct"),
                         "mfma_peak_measured_tflops": peak_meas,
                         # every stage's algorithmic bytes (intermediates included: they round-trip HBM between kernels)
                         "pipeline_algorithmic_gbs": sum(v["bytes_per_launch"] * v["launches"] for v in prof.values())

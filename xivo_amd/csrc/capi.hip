@@ -2338,12 +2338,19 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   {
     char plabel[64];
     snprintf(plabel, sizeof(plabel), "%s<%d>", propagate_uses_wave_kernel() ? "propagate_state_wave_kernel" : "propagate_state_kernel", a.method ? 7 : 4);
-    StageTimer st(c, ST_PROP_STATE, 0.0, plabel);
+    // algorithmic flops: per integrator sub-step and stage the 23 x 23 Lyapunov right-hand side
+    // F P + P F^T (2 * 2 * 23^3) and the transition recursion F + c F FK (2 * 23^3), as the reference codes them (dense);
+    // sub-steps as src/rk4.cpp:19-31 cuts a sample: ceil(dt / stepsize), the sample's own dt when stepsize <= 0
+    double substeps = 0.0;
+    for (int s = 0; s < n_imu; ++s) substeps += o->stepsize > 0 ? std::ceil(imu[s].dt / o->stepsize) : 1.0;
+    const double stage_flops = 6.0 * 23.0 * 23.0 * 23.0 + 2.0 * 23.0 * 12.0 * (12.0 + 23.0);
+    StageTimer st(c, ST_PROP_STATE, (double)nb * substeps * (a.method ? 7.0 : 4.0) * stage_flops, plabel,
+                  (double)nb * (3.0 * 529 + n_imu * sizeof(xivo_imu_in) / 8.0 + 60.0) * sizeof(double));
     HIP_TRY((hipError_t)launch_propagate_state(a, c->stream));
   }
   {
     // tail: reads and writes the 23 rows and 23 columns of P that change (+ Phi, P_mm)
-    StageTimer st(c, ST_PROP_TAIL, 0.0, "propagate_cov_fixed_kernel<23>",
+    StageTimer st(c, ST_PROP_TAIL, (double)nb * 2.0 * (2.0 * 23.0 * 23.0 * (c->N - 23)), "propagate_cov_fixed_kernel<23>",
                   (double)nb * (4.0 * 23 * c->N + 2.0 * 529) * sizeof(double));
     HIP_TRY((hipError_t)launch_propagate_cov(c->P, c->sP, c->Np, c->N, c->Np, 23, dPhi, dPmm, b0, nb, c->stream));
   }
