@@ -8,9 +8,8 @@ fp64, XIVO row sparsity, inputs resident in HBM before the timed region. Every
 step hands the dense H / inn / diagR of every filter over again (H changes with
 every camera frame, src/update.cpp:129-138): the dense -> row-pair compression is
 inside the timed step. `value` is the library's default mode: every product in fp64
-(no fp32 instruction runs unless XIVO_HIP_FLAG_FP32_CORR / _FP32_COV ask for one);
-`value_mixed` times the opt-in fp32 correction product next to it (the same all-fp64
-kernels wherever the in-solve covariance update applies).
+(no fp32 instruction runs unless XIVO_HIP_FLAG_FP32_WHITENED asks for one - the cfg4_f32w row);
+`value_symmetric_form` times the opt-in symmetric form next to it.
 
 `python bench.py --gpus N` without a launcher spawns its N ranks itself.
 
@@ -384,8 +383,6 @@ SUB_CONFIGS = [
     ("dense_ascoded", "metric point, dense AS-CODED pipeline (XIVO_HIP_FLAG_DENSE_H = --flags 64: H treated as dense, every product of "
      "estimator.cpp:1259-1287 a tiled MFMA GEMM - the pure-GEMM variant of SURVEY 8d), 8192 filters",
      ["--flags", "64", "--batch", "8192", "--steps", "5", "--warmup", "2"]),
-    ("dense_reassoc", "metric point, dense re-associated pipeline (--flags 80 = DENSE_H | REASSOC: dense H P and S, then the whitened in-solve update), 8192 filters",
-     ["--flags", "80", "--batch", "8192", "--steps", "5", "--warmup", "2"]),
     ("glevel", "feature-level default build (N=251, 60 features): Jacobians + MH gating + stacking + update, 4096 filters",
      ["--level", "G", "--batch", "4096", "--steps", "8", "--warmup", "2"]),
     ("ransac", "feature-level + OnePointRANSAC (src/update.cpp:213-393) between gating and the update, 4096 filters",
@@ -437,6 +434,9 @@ def configs_block(device_budget_s=240.0):
                "bound": roof.get("bound"), "P": _r(par.get("rel_fro_P_max"), 2), "dx": _r(par.get("rel_dx_max"), 2),
                "mask": par.get("inlier_masks_equal"), "lastP": _r(last.get("rel_fro_P_max"), 2), "lastdx": _r(last.get("rel_dx_max"), 2),
                "ok": (all(oks) if oks else None)}
+        tol = (last.get("tol") or {}).get("dx")
+        if tol is not None and tol != 1e-8:
+            row["tol_dx"] = tol                     # a row checked at a looser dx tolerance than the rest says so next to its "ok"
         rows.append({k: v for k, v in row.items() if v is not None or k == "ok"})
         full.append({"k": key, "name": name, "args": " ".join(extra), "wall_s": time.perf_counter() - t0, "line": d})
     return rows, full
@@ -524,9 +524,6 @@ def main():
                     help="level G only (BASELINE config 3): this many out-of-state (MSCKF) features, each seen from 5 in-state "
                          "groups, are null-space projected (src/oos.cpp) and appended: 7 rows each, M = 120 + 7 n")
     ap.add_argument("--no-compression", action="store_true", help="--oos: keep all 7 n projected rows (no QR measurement compression)")
-    ap.add_argument("--oos-dense", action="store_true",
-                    help="--oos: every row dense and the re-associated dense pipeline (XIVO_HIP_FLAG_DENSE_H | REASSOC, the round-2 path) "
-                         "instead of mixed stacking (in-state rows row-pair compressed, only the OOS block dense)")
     ap.add_argument("--ransac", action="store_true",
                     help="level G only: OnePointRANSAC (src/update.cpp:213-393) between MH gating and the update - backup, "
                          "partial update on the low-innovation set, absorb, re-Jacobians, chi-square rescue, restore")
@@ -538,7 +535,7 @@ def main():
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--calib", action="store_true",
                     help="--level G: the online-calibration build's layout and Jacobian blocks (N = 276; compressed rows + a dense block of the calibration columns)")
-    ap.add_argument("--no-mixed", action="store_true", help="skip the second timed loop (fp32 correction product)")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the second timed loop (the opt-in symmetric form)")
     ap.add_argument("--sub", action="store_true", help="child run of the `configs` array: no configs / dropin blocks of its own")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` array (the other BASELINE configurations, child runs)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the `dropin` block (wall time of the one-estimator drop-in call)")
@@ -599,7 +596,7 @@ def main():
         return
 
     from xivo_amd import synth
-    from xivo_amd.lib import Context, FLAG_PROFILE, FLAG_FP32_CORR, load_library
+    from xivo_amd.lib import Context, FLAG_PROFILE, load_library
 
     # one rank per GPU; the modulo only matters when more ranks than GPUs are launched (smoke-testing the
     # N>1 path on a 1-GPU box) - on the 8-GPU node it is the identity
@@ -634,10 +631,6 @@ def main():
                 groups[b, g_]["Rsb"], groups[b, g_]["Tsb"] = cmaj(sc["gR"][b, g_]), sc["gT"][b, g_]
             feats["x"][b] = sc["x"][b]; feats["ref_sind"][b] = sc["ref"][b]; feats["sind"][b] = sc["sind"][b]
         M = 2 * F + 7 * args.oos
-        if args.oos > 0 and args.oos_dense:
-            from xivo_amd.lib import FLAG_DENSE_H, FLAG_REASSOC
-            # every row dense right away; the re-associated dense pipeline never reads H^T, so that copy is not written
-            flags |= FLAG_DENSE_H | FLAG_REASSOC
         # (--oos: 16 spare rows - mixed stacking pads the OOS block to 16 rows behind the 2F in-state rows)
         ctx = Context(N, M + (16 if args.oos > 0 else 0), B, device=device, flags=flags)
         ctx.set_layout(N, gb, ng, gb + 6 * ng, nf, synth.EQUI)
@@ -780,23 +773,7 @@ def main():
                                        (R_VIS, MH_THRESH, MH_MULT, MIN_INL), args.no_gating,
                                        tol_P=args.tol_P, tol_dx=args.tol_dx_last)
 
-    # ---- second figure: opt-in XIVO_HIP_FLAG_FP32_CORR - the Joseph correction product G K^T on the fp32 MFMA (only
-    # where the re-associated stand-alone tail runs: beyond N = 256 / M = 176)
-    mixed = None
-    if not args.no_mixed and sparse_path and not (args.flags & FLAG_FP32_CORR):
-        ctx.set_flags(base_flags | FLAG_FP32_CORR)
-        ctx.restore_P()
-        dt_m, gpu_ms_m, prof_m = timed(min(args.warmup, 2))
-        dt_m = max_over_ranks(dist, dt_m)
-        mixed = {"value": world * B * args.steps / dt_m, "ms_per_step": dt_m / args.steps * 1e3,
-                 "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in prof_m.items() if v["launches"]},
-                 # whether this run really took another code path than `value`: at sizes the in-solve covariance update
-                 # holds (N <= 256, M <= 176) the library is all fp64 in its default mode too
-                 "same_kernels_as_value": {k: v["kernel"] for k, v in prof_m.items() if v["launches"]} ==
-                                          {k: v["kernel"] for k, v in prof.items() if v["launches"]}}
-        ctx.set_flags(flags)
-
-    # ---- third figure (opt-in library mode, NOT the headline): XIVO_HIP_FLAG_SYMMETRIC_FORM - P+ = P - W^T W with
+    # ---- second figure (opt-in library mode, NOT the headline): XIVO_HIP_FLAG_SYMMETRIC_FORM - P+ = P - W^T W with
     # W = L^-1 (H P), forward substitution only; equal to the Joseph form for the optimal gain, checked below
     symm = None
     if not args.no_mixed and sparse_path and args.level == "S":
@@ -974,15 +951,10 @@ def main():
                        "hand_over": ("dense H/inn/diagR (column-major, resident in HBM) -> row-pair compressed rows, "
                                      "every step, inside the timed region (stage stack_H)") if args.level == "S" else
                                     "Jacobians -> compressed rows on device every step",
-                       "precision": {"value": "library default = all fp64: storage, every product, factorisation, solve",
-                                     "value_mixed": "opt-in XIVO_HIP_FLAG_FP32_CORR: the same all-fp64 kernels wherever the in-solve "
-                                                    "covariance update applies (N <= 256, M <= 176; see mixed.same_kernels_as_value); "
-                                                    "elsewhere the Joseph correction product G K^T (G = O(eps cond(S)) residual) runs "
-                                                    "on v_mfma_f32_16x16x4_f32 with G itself and -T in fp64"},
+                       "precision": {"value": "library default = all fp64: storage, every product, factorisation, solve"},
+                       "route": ctx.last_route(),
                        "gpu_event_ms_per_step": gpu_ms / args.steps,
                        "not_spd_filters": int((status != 0).sum())},
-            "value_mixed": mixed["value"] if mixed else None,
-            "mixed": mixed,
             "value_symmetric_form": symm["value"] if symm else None,
             "symmetric_form": symm,
             "per_rank_updates_per_s": per_rank,

@@ -50,35 +50,15 @@ enum {
   XIVO_HIP_FLAG_FIX_GROUP_BLOCK = 1u,
   /* record HIP events around every kernel launch (per-stage timing) */
   XIVO_HIP_FLAG_PROFILE = 2u,
-  /* compute every tile of P+ instead of the lower triangle + mirror (A/B knob) */
-  XIVO_HIP_FLAG_FULL_PNEW = 4u,
-  /* symmetric products through the rectangular-tile kernel (strip-balanced 128x128
-   * tiles) instead of the block-list kernel (A/B knob) */
-  XIVO_HIP_FLAG_TILE_SYM = 8u,
-  /* Re-associated Joseph update: with T = (KH-I)P = K(HP) - P,
-   *   P+ = T (KH-I)^T + K R K^T = (T H^T + K R) K^T - T
-   * - the same expression (exact for ANY gain K, like the Joseph form it is), but KH - I
-   * is never formed and both products contract over M instead of N: 2.5x fewer flops in
-   * the covariance stage. Rounding differs from the as-coded order at the 1e-13 level
-   * (tests); opt-in because the reference codes the congruence form. */
-  XIVO_HIP_FLAG_REASSOC = 16u,
-  /* BASELINE.json config 4: the three covariance products of the Joseph update (KH - I, (KH-I)P,
-   * P+ = T A^T + K R K^T) run on the fp32 MFMA (v_mfma_f32_16x16x4_f32, 3x the fp64 issue rate) with
-   * fp32 accumulation; operands and results stay fp64 in HBM. HP, S, the factorisation, the gain and dx
-   * stay fp64 because their error is amplified by cond(S). Stated tolerance: 5e-5 relative Frobenius on
-   * P+ (measured 1.4e-5 at N=400/M=300, 5e-6 at N=250/M=160), dx unchanged (1e-8). */
-  XIVO_HIP_FLAG_FP32_COV = 32u,
   /* By default the update exploits the row sparsity of H: when every row pair of every filter of the
    * call has at most 16 columns shared by most pairs + 12 private non-zero columns (true for the stacked
    * in-state Jacobians of src/update.cpp:129-138: 21 per pair), H P, S and the H-products of the
-   * covariance stage skip the structural zeros (exact: the skipped terms are 0 * x). The covariance stage
-   * evaluates the Joseph expression in its expanded form inside the solve kernel (N <= 256, M <= 176; see
-   * XIVO_HIP_FLAG_STANDALONE_TAIL) or in the re-associated form above. A denser H (OOS rows, arbitrary input)
-   * takes the as-coded dense path automatically. This flag forces the dense as-coded path for any H. */
+   * covariance stage skip the structural zeros (exact: the skipped terms are 0 * x), and the covariance stage
+   * evaluates the Joseph expression in its whitened form, P+ = P - (W - D)^T (W + D). An H that does not
+   * compress (dense rows, arbitrary input) keeps the same evaluation on dense products for H P and S. This flag forces the
+   * AS-CODED sequence of src/estimator.cpp:1259-1287 on dense products for any H: A = K H - I, T = A P,
+   * P+ = T A^T + K R K^T (the pure-GEMM variant; 3 x the flops). */
   XIVO_HIP_FLAG_DENSE_H = 64u,
-  /* Accepted and ignored (round 3): every product is fp64 unless XIVO_HIP_FLAG_FP32_CORR / XIVO_HIP_FLAG_FP32_COV ask
-   * for an fp32 one. (Rounds 1-2: this flag kept the Joseph correction product of the re-associated form in fp64.) */
-  XIVO_HIP_FLAG_FP64_CORR = 128u,
   /* Symmetric ("square-root") form of the gain and covariance: S = L L^T, W = L^-1 (H P) by forward substitution only,
    *   dx = W^T (L^-1 inn),   P+ = P - W^T W
    * - what the Joseph expression of src/estimator.cpp:1276-1287 evaluates to for the optimal gain K = P H^T S^-1 (its
@@ -88,25 +68,12 @@ enum {
    * form and the default reproduces that expression; parity of this mode against the reference is tested to the same
    * tolerances (1e-6 on P, 1e-8 on dx), including an ill-conditioned S. */
   XIVO_HIP_FLAG_SYMMETRIC_FORM = 256u,
-  /* Sparse-H and re-associated dense pipelines, N <= 256 and M <= 176: by default the solve kernel carries the whole
-   * covariance update on the gain still in its registers - the Joseph expression expanded for the computed gain,
-   *   P+ = P - K Z,  Z = 2 H P - L L^T K^T   (= P - K(HP) - (K(HP))^T + K S K^T with one triangle of K(HP) kept),
-   * T and G never reaching memory. This flag selects the round-1 tail instead: T = K(HP) - P, G = T H^T + K R,
-   * P+ = G K^T - T from stand-alone kernels - 0.8 x the speed, 5 x closer to the as-coded fp64 result (both lose
-   * digits in proportion to cond(S) and meet the 1e-6 / 1e-8 tolerances by orders of magnitude: DESIGN.md 1a). */
+  /* Sparse-H pipeline: by default the covariance update is the whitened Joseph expression on the gain still in the solve
+   * kernel's registers (or, for wider shapes, on the whitened outputs of the solve) - T and G never reach memory. This flag
+   * selects the re-associated tail from stand-alone kernels instead: T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T
+   * (= T (KH - I)^T + K R K^T, exact for any gain like the Joseph form it is) - 0.8 x the speed, 5 x closer to the as-coded
+   * fp64 result (both lose digits in proportion to cond(S) and meet the 1e-6 / 1e-8 tolerances by orders of magnitude). */
   XIVO_HIP_FLAG_STANDALONE_TAIL = 512u,
-  /* In-solve covariance update (N <= 256, M <= 176): the round-2 evaluation P+ = P - K (2 H P - L L^T K^T) - two
-   * triangular products on the gain to rebuild S K^T - instead of the default whitened evaluation of the same Joseph
-   * expression, P+ = P - (W - D)^T (W + D) with W = L^-1 H P and D = W - L^T K^T taken from the backward substitution's
-   * own partial sums. Same tolerances; 1.3 x the MFMA work. A/B knob. */
-  XIVO_HIP_FLAG_EXPANDED_JOSEPH = 1024u,
-  /* Opt-in, re-associated form of the sparse-H pipeline only (stand-alone kernels: shapes beyond N = 256 / M = 176, or
-   * XIVO_HIP_FLAG_STANDALONE_TAIL): P+ = -T + G K^T with -T = P - K(HP) (fp64) and the Joseph correction G K^T,
-   * G = T H^T + K R, which is O(eps * cond(S)) relative to P because K is the gain of this very S. With this flag that
-   * correction PRODUCT runs on the fp32 MFMA (G itself - a cancellation - and -T stay fp64): its rounding adds
-   * <= 1e-7 |G K^T| to P+, orders of magnitude below the fp64 rounding of -T. Without it (the default since round 3)
-   * no fp32 instruction takes part in an update. */
-  XIVO_HIP_FLAG_FP32_CORR = 2048u,
   /* Opt-in (round 4; BASELINE config 4 "fp32 MFMA with stated tolerance"), shapes whose covariance product runs outside the
    * solve kernel (N > 256 or M > 176): the whitened outputs V^T = (W - D)^T and Y^T = (W + D)^T leave the fp64 solve as
    * FLOAT and P+ = P - V^T Y runs on v_mfma_f32_16x16x4_f32 (fp32 accumulation over M, subtracted from P in fp64): half
@@ -326,8 +293,7 @@ int xivo_hip_get_jacobians(xivo_hip_ctx* ctx, int b0, int nb, double* J2x21, dou
  * default build's compressed rows + a dense [M x 48] block of the calibration columns, and the update takes the sparse
  * pipeline with two skinny products on top (round 5; xivo_hip_last_path 1). MH gating uses the whole row as the reference's
  * f->J() does (43 columns in the compact gate). Where the calibration columns do not fit the leading 48 (cam_begin + 9 > 48),
- * under XIVO_HIP_FLAG_DENSE_H / _FP32_COV / _SYMMETRIC_FORM / _STANDALONE_TAIL, with the environment knob
- * XIVO_HIP_CALIB_DENSE, and whenever dense rows are needed after all (OOS rows appended, xivo_hip_update_dense_gated,
+ * under XIVO_HIP_FLAG_DENSE_H / _SYMMETRIC_FORM / _STANDALONE_TAIL, and whenever dense rows are needed after all (OOS rows appended, xivo_hip_update_dense_gated,
  * xivo_hip_get_H - which therefore sends the NEXT update of that stacking down the dense pipeline) the rows are (re-)stacked
  * as dense rows and gate / update through the dense pipeline (round 4). Same results within the stated tolerances either way.
  * Slots as the reference's Index enum / kCameraBegin would number them
@@ -585,8 +551,13 @@ int xivo_hip_bench_mfma_peak(xivo_hip_ctx* ctx, double* out4);
 /* tile the batched GEMM picks for an (rows x cols) output (symmetric = lower
  * triangle + mirror mode), for DESIGN.md/tests */
 void xivo_hip_gemm_tile(int rows, int cols, int symmetric, int* bm, int* bn);
-/* which path the last update call took: 0 = dense as-coded, 1 = sparse-H (row-pair compressed) */
+/* which rows the last update call used: 0 = dense, 1 = row-pair compressed (sparse-H) */
 int xivo_hip_last_path(xivo_hip_ctx* ctx);
+/* the route the last update pass took (round 6: the one table in capi.hip, plan_update): 0 fused (one kernel), 1 sparse rows +
+ * in-solve whitened update, 2 sparse rows + whitened outputs + tiled product, 3 sparse symmetric form, 4 sparse stand-alone tail,
+ * 5 dense as-coded, 6 dense rows + whitened update, 7 dense symmetric form; xivo_hip_route_name gives the table's name */
+int xivo_hip_last_route(xivo_hip_ctx* ctx);
+const char* xivo_hip_route_name(int route);
 /* kernel instantiation the last launch of profile stage `stage` ran (index as in xivo_hip_profile_get; needs
  * XIVO_HIP_FLAG_PROFILE), spelled as rocprofv3 --kernel-trace prints it minus spaces; "" if none */
 const char* xivo_hip_stage_kernel(xivo_hip_ctx* ctx, int stage);

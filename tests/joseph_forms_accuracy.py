@@ -3,7 +3,7 @@
 expression (estimator.cpp:1257-1288 in numpy longdouble, 64-bit mantissa), as cond(S) grows:
   oracle     the as-coded fp64 sequence on the CPU (oracle/xivo_oracle.py)
   in_solve   library default: whitened form P - (W - D)^T (W + D) inside the solve kernel (trsm_lds_f64_kernel<.,4>)
-  in_solve_expanded  XIVO_HIP_FLAG_EXPANDED_JOSEPH: P - K (2 H P - L L^T K^T) on the gain in registers (<.,3>, the round-2 default)
+  fused      the one-kernel route of round 6 at the same form (fused_update_f64_kernel); in_solve runs with XIVO_HIP_FLAG_MULTI_KERNEL
   reassoc    XIVO_HIP_FLAG_STANDALONE_TAIL: T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T from stand-alone kernels
   symmetric  XIVO_HIP_FLAG_SYMMETRIC_FORM: P - W^T W
   as_coded_device  XIVO_HIP_FLAG_DENSE_H: the as-coded product sequence (A = KH - I, A P A^T + K R K^T) on the device
@@ -79,8 +79,8 @@ if __name__ == "__main__":
 
     from xivo_amd.lib import FLAG_DENSE_H
     from xivo_amd.lib import FLAG_STANDALONE_TAIL
-    from xivo_amd.lib import FLAG_EXPANDED_JOSEPH
-    runs = {"in_solve": child(0, {}), "in_solve_expanded": child(FLAG_EXPANDED_JOSEPH, {}), "reassoc": child(FLAG_STANDALONE_TAIL, {}),
+    from xivo_amd.lib import FLAG_MULTI_KERNEL
+    runs = {"fused": child(0, {}), "in_solve": child(FLAG_MULTI_KERNEL, {}), "reassoc": child(FLAG_STANDALONE_TAIL, {}),
             "symmetric": child(FLAG_SYMMETRIC_FORM, {}), "as_coded_device": child(FLAG_DENSE_H, {})}
     rel = lambda a, b: float(np.linalg.norm((a - b).astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
     table = []

@@ -20,15 +20,18 @@ CAM_DIM = {"pinhole": 4, "atan": 5, "radtan": 9, "equi": 8}
 R_VIS, MH, MULT = 2.25, 5.991, 1.1
 
 
+_ROWS_FLAGS = {"v": 0}
+
+
 @pytest.fixture(params=["lead", "dense"])
-def rows(request, monkeypatch):
+def rows(request):
     """The two stackings of an online-calibration build: row-pair compressed rows + the leading dense block of the calibration
-    columns on the sparse pipeline (round 5, default; last_path 1), or dense rows on the dense pipeline (XIVO_HIP_CALIB_DENSE)."""
-    if request.param == "dense":
-        monkeypatch.setenv("XIVO_HIP_CALIB_DENSE", "1")
-    else:
-        monkeypatch.delenv("XIVO_HIP_CALIB_DENSE", raising=False)
-    return 0 if request.param == "dense" else 1
+    columns on the sparse pipeline (round 5, default; last_path 1), or dense rows on the dense pipeline (the round-4 stacking:
+    XIVO_HIP_FLAG_DENSE_H on the context)."""
+    from xivo_amd.lib import FLAG_DENSE_H
+    _ROWS_FLAGS["v"] = FLAG_DENSE_H if request.param == "dense" else 0
+    yield 0 if request.param == "dense" else 1
+    _ROWS_FLAGS["v"] = 0
 
 
 def setup(name, temporal, imu, camera, B=3, ng=6, nf=14, seed=3, M_extra=0):
@@ -46,7 +49,7 @@ def setup(name, temporal, imu, camera, B=3, ng=6, nf=14, seed=3, M_extra=0):
         calib[b]["gyro"], calib[b]["Cg"], calib[b]["td"] = cal["gyro"], cal["Cg"].T.reshape(-1), cal["td"]
         calib[b]["Ca"], calib[b]["intr"] = np.eye(3).reshape(-1), cam_intr(cam)
         cals.append(cal)
-    ctx = Context(lay.N, 2 * nf + M_extra, B)
+    ctx = Context(lay.N, 2 * nf + M_extra, B, flags=_ROWS_FLAGS["v"])
     ctx.set_layout(lay.N, lay.group_begin, ng, lay.feature_begin, nf, cam)
     ctx.set_calib(lay.td, lay.Cg, lay.cam_begin, lay.cam_dim)
     return cam, lay, sc, poses, groups, feats, xp, calib, cals, ctx
@@ -148,7 +151,7 @@ def test_stand_alone_gate_and_calibration_off_again(built, rows):
         ctx.set_calib()                                                                         # default build again
         ctx.upload_P(np.array([spd(lay.N, 5 + b) * 1e-4 for b in range(3)]))
         ctx.filter_update(R_VIS, MH, MULT, 5, use_gating=True)
-        assert ctx.last_path() == 1                                                             # compressed rows, sparse pipeline
+        assert ctx.last_path() == rows                           # compressed rows, sparse pipeline (dense fixture: XIVO_HIP_FLAG_DENSE_H stays forced)
 
 
 @pytest.mark.parametrize("name", ["radtan", "pinhole"])

@@ -196,10 +196,10 @@ def test_propagation_tail(built):
         assert rel_fro(got[b], exp[b]) < 1e-14
 
 
-# 512 / 4 / 2048 / 1024 = STANDALONE_TAIL / FULL_PNEW / FP32_CORR / EXPANDED_JOSEPH with OOS rows stacked: flags that route the
-# sparse pipeline to its stand-alone tail, whose G = T H^T + K R walks compressed rows that - with mixed stacking - hold the
-# in-state rows only: such a call takes the dense pipeline instead (round 4; it used to return a silently wrong P+)
-@pytest.mark.parametrize("compress,flags", [(False, 0), (True, 0), (True, 64 | 16), (True, 512), (False, 4), (False, 2048), (True, 1024)])
+# 512 = STANDALONE_TAIL with OOS rows stacked: its G = T H^T + K R walks compressed rows that - with mixed stacking - hold the
+# in-state rows only: such a call takes dense rows instead (round 4; it used to return a silently wrong P+). 64 = DENSE_H: dense rows
+# stacked at once, as-coded sequence. 256 = SYMMETRIC_FORM on the mixed stacking.
+@pytest.mark.parametrize("compress,flags", [(False, 0), (True, 0), (True, 64), (True, 512), (False, 512), (True, 256), (True, 8192)])
 def test_config3_full_size_instate_plus_oos(built, compress, flags):
     """BASELINE.json config 3 at full size: N=251 (8 groups, 60 in-state features -> 120 rows)
     + 20 OOS features seen from k=5 groups (7 projected rows each -> 140 rows), M=260.
@@ -208,7 +208,6 @@ def test_config3_full_size_instate_plus_oos(built, compress, flags):
     src/helpers.cpp:77-101): M = 174; K, dx, P+ are unchanged to rounding."""
     cam = synth.PINHOLE
     ng, nf, F, B, n_oos, k = 8, 60, 60, 2, 20, 5
-    # flags 64 | 16 = DENSE_H | REASSOC: dense rows stacked at once, re-associated dense pipeline, no H^T copy kept.
     # flags 0 (round 3): mixed stacking - the in-state rows stay row-pair compressed, only the OOS block is dense (the 16
     # spare rows of the allocation are what the 16-row-padded OOS block needs behind row 120)
     sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 6, cam, M_max=2 * F + n_oos * (2 * k - 3) + 16, flags=flags)
@@ -252,9 +251,11 @@ def test_config3_full_size_instate_plus_oos(built, compress, flags):
                 # the retained energy of the residual: ||Q1^T r|| <= ||r||
                 assert np.linalg.norm(ic[120:]) <= np.linalg.norm(if_[120:]) * (1 + 1e-12)
         ctx.update_joseph()
-        # mixed stacking runs the sparse pipeline - unless a flag asks for its stand-alone tail (512, 4, 2048: dense pipeline);
-        # the expanded in-solve form (1024) needs nothing of H behind the solve and stays on the sparse route
-        assert ctx.last_path() == (1 if flags in (0, 1024) else 0)
+        # mixed stacking runs the sparse pipeline - unless a flag asks for the stand-alone tail (512: its G = T H^T walks ALL of H)
+        # or for dense rows (64); the symmetric form (256) and the throughput route (8192) need nothing of H behind the solve
+        assert ctx.last_path() == (1 if flags in (0, 256, 8192) else 0)
+        # (flags 0 at B = 2: the latency route - whitened outputs, product by the tiled kernel; 8192 keeps the form inside the solve kernel)
+        assert ctx.last_route() == {0: "sparse_whitened", 64: "dense_ascoded", 512: "dense_whitened", 256: "sparse_symmetric", 8192: "sparse_in_solve"}[flags]
         err = ctx.get_err(); Pn = ctx.download_P()
         assert (ctx.get_status() == 0).all()
     assert rows.tolist() == [140] * B

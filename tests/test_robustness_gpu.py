@@ -8,7 +8,7 @@ import pytest
 import xivo_oracle as orc
 from helpers import rel_fro, TOL_P, TOL_DX
 from xivo_amd import synth
-from xivo_amd.lib import Context, FLAG_DENSE_H, FLAG_NO_LDLT_FALLBACK, FLAG_SYMMETRIC_FORM, FLAG_EXPANDED_JOSEPH
+from xivo_amd.lib import Context, FLAG_DENSE_H, FLAG_NO_LDLT_FALLBACK, FLAG_SYMMETRIC_FORM, FLAG_MULTI_KERNEL
 
 pytestmark = pytest.mark.gpu
 
@@ -47,7 +47,7 @@ def _indefinite_cases(N, F, B, seed):
     return P, H, inn, dR
 
 
-@pytest.mark.parametrize("flags", [0, FLAG_DENSE_H, FLAG_SYMMETRIC_FORM, FLAG_EXPANDED_JOSEPH])
+@pytest.mark.parametrize("flags", [0, FLAG_DENSE_H, FLAG_SYMMETRIC_FORM, FLAG_MULTI_KERNEL])
 @pytest.mark.parametrize("N,F", [(150, 50), (64, 8), (300, 60)])
 def test_indefinite_S_is_updated_like_the_reference(built, N, F, flags):
     """The reference's S.ldlt().solve(H P) + Joseph form goes through for ANY symmetric non-singular S. The device does the

@@ -6,7 +6,7 @@ import pytest
 import xivo_oracle as orc
 from helpers import rel_fro, TOL_P, TOL_DX
 from xivo_amd import synth
-from xivo_amd.lib import Context, FLAG_FULL_PNEW, FLAG_DENSE_H, FLAG_THROUGHPUT_ROUTE, FLAG_MULTI_KERNEL
+from xivo_amd.lib import Context, FLAG_DENSE_H, FLAG_THROUGHPUT_ROUTE, FLAG_MULTI_KERNEL
 
 pytestmark = pytest.mark.gpu
 
@@ -51,19 +51,6 @@ def test_update_joseph_matches_oracle(built, N, F, kind):
         assert rel_fro(Pn[b], P_ref) < TOL_P
         assert rel_fro(err[b], e_ref) < TOL_DX
         assert np.array_equal(Pn[b], Pn[b].T)  # lower triangle mirrored
-
-
-def test_full_pnew_flag_equals_mirrored(built):
-    N, F, B = 150, 50, 3
-    P, H, inn, dR = synth.s_level(N, F, B, seed=3)
-    outs = []
-    for flags in (0, FLAG_FULL_PNEW):
-        with Context(N, 2 * F, B, flags=flags) as ctx:
-            ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
-            outs.append(ctx.download_P())
-    # default: the expanded Joseph expression formed inside the solve kernel; FULL_PNEW: the re-associated expression
-    # from the stand-alone products, every entry computed - two rounding-level re-orderings of the same update
-    assert rel_fro(outs[0], outs[1]) < 1e-11
 
 
 def test_upload_download_roundtrip_bit_exact(built):
@@ -195,84 +182,8 @@ def test_gating_skipped_when_too_few_features(built):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
 
 
-@pytest.mark.parametrize("N,F", [(150, 50), (250, 80), (37, 3)])
-def test_reassociated_joseph_equals_as_coded(built, N, F):
-    """XIVO_HIP_FLAG_REASSOC: P+ = (T H^T + K R) K^T - T is the same expression as the Joseph
-    form; also exercised with a deliberately WRONG gain-side input (noisy H rows -> K far from
-    optimal is not constructible here, so we check against the oracle's as-coded sequence)."""
-    from xivo_amd.lib import FLAG_REASSOC
-    B = 3
-    P, H, inn, dR = synth.s_level(N, F, B, seed=N + 1)
-    with Context(N, 2 * F, B, flags=FLAG_REASSOC) as ctx:
-        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
-        err = ctx.get_err(); Pn = ctx.download_P()
-    for b in range(B):
-        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
-        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
-        assert rel_fro(Pn[b], P_ref) < 1e-10
-        assert np.linalg.eigvalsh(Pn[b]).min() > -1e-12 * np.abs(Pn[b]).max()
-
-
-def test_size_independent_properties_at_full_batch(built):
-    """Properties that need no oracle, on a full-size batch (N=250, M=160, 512 filters):
-    P+ symmetric PSD, P+ <= P in the Loewner order along H's rows (information only adds),
-    zero innovation -> zero dx, and linearity of dx in the innovation."""
-    N, F, B = 250, 80, 512
-    P1, H1, inn1, dR1 = synth.s_level(N, F, 8, seed=77)
-    tile = lambda a: np.concatenate([a] * (B // 8), axis=0)
-    P, H, dR = tile(P1), tile(H1), tile(dR1)
-    inn = tile(inn1).copy()
-    inn[1::3] *= 2.0          # every third filter: doubled innovation
-    inn[2::3] = 0.0           # every third filter: zero innovation
-    with Context(N, 2 * F, B) as ctx:
-        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
-        err = ctx.get_err(); Pn = ctx.download_P()
-        assert (ctx.get_status() == 0).all()
-    assert np.array_equal(Pn, np.transpose(Pn, (0, 2, 1)))
-    assert np.all(err[2::3] == 0.0)
-    # linearity in the innovation: filters b (x1 class, b % 3 == 0) and b2 (x2 class, b2 % 3 == 1)
-    # built from the same source filter (b % 8 == b2 % 8)
-    checked = 0
-    for b in range(0, 96, 3):
-        b2 = next(c for c in range(b + 1, B) if c % 8 == b % 8 and c % 3 == 1)
-        assert rel_fro(err[b2], 2.0 * err[b]) < 1e-12
-        checked += 1
-    assert checked == 32
-    for b in range(0, B, 61):
-        w = np.linalg.eigvalsh(Pn[b])
-        assert w.min() > -1e-12 * w.max()
-        HPH_before = np.einsum("ij,jk,ik->i", H[b], P[b], H[b]); HPH_after = np.einsum("ij,jk,ik->i", H[b], Pn[b], H[b])
-        assert np.all(HPH_after <= HPH_before * (1 + 1e-9))
-    # covariance update does not depend on the innovation
-    assert rel_fro(Pn[1], Pn[9]) < 1e-13 and rel_fro(Pn[0], Pn[8]) == 0.0
-
-
-TOL_P_FP32 = 5e-5   # stated tolerance of XIVO_HIP_FLAG_FP32_COV (config 4): relative Frobenius on P+
-
-
-@pytest.mark.parametrize("N,F,dense", [(400, 150, False), (400, 150, True), (250, 80, False), (150, 50, False), (37, 3, False)])
-def test_fp32_covariance_products_config4(built, N, F, dense):
-    """BASELINE.json config 4 (state dim 400, 150 features): the Joseph covariance products on the fp32
-    MFMA. dx must stay at the fp64 tolerance (the gain path is fp64); P+ within the stated 5e-5."""
-    from xivo_amd.lib import FLAG_FP32_COV
-    B = 3
-    P, H, inn, dR = synth.s_level(N, F, B, seed=N + 2 * F, dense=dense)
-    with Context(N, 2 * F, B, flags=FLAG_FP32_COV) as ctx:
-        ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
-        err = ctx.get_err(); Pn = ctx.download_P()
-        assert (ctx.get_status() == 0).all()
-    worst = 0.0
-    for b in range(B):
-        e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
-        assert rel_fro(err[b], e_ref) < TOL_DX
-        worst = max(worst, rel_fro(Pn[b], P_ref))
-        assert np.array_equal(Pn[b], Pn[b].T)
-    assert worst < TOL_P_FP32, worst
-    print("fp32 covariance products: worst rel. Frobenius error on P+ = %.2e at N=%d" % (worst, N))
-
-
 def test_mixed_batch_falls_back_to_dense_path(built):
-    """One filter with a dense H in the batch: the whole call takes the as-coded dense pipeline."""
+    """One filter with a dense H in the batch: the whole call takes dense rows (the whitened update on dense H P / S)."""
     N, F, B = 150, 50, 4
     P, H, inn, dR = synth.s_level(N, F, B, seed=77)
     H[2] = synth.s_level(N, F, 1, seed=78, dense=True)[1][0]
@@ -309,26 +220,6 @@ def test_sparse_path_with_structural_zero_in_common_column(built):
         for b in range(B):
             e_ref, P_ref, _ = orc.update_joseph(H2[b], P[b], inn[b], dR[b])
             assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
-
-
-@pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (400, 150), (203, 30), (37, 3), (64, 8), (100, 1)])   # odd / even block counts, both register-kernel widths
-def test_fp32_correction_product_is_invisible(built, N, F):
-    """Sparse-H pipeline, re-associated form: P+ = -T + G K^T with the correction product G K^T on the fp32 MFMA
-    (XIVO_HIP_FLAG_FP32_CORR, opt-in since round 3) vs in fp64 (default). G is the O(eps) residual of the gain equation, so the two agree to ~1e-15
-    relative and both sit at the fp64 rounding level from the oracle - far inside TOL_P."""
-    from xivo_amd.lib import FLAG_FP32_CORR, FLAG_STANDALONE_TAIL
-    B = 3
-    P, H, inn, dR = synth.s_level(N, F, B, seed=91)
-    outs = []
-    for flags in (FLAG_FP32_CORR | FLAG_STANDALONE_TAIL, FLAG_STANDALONE_TAIL):
-        with Context(N, 2 * F, B, flags=flags) as ctx:
-            ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
-            assert ctx.last_path() == 1
-            outs.append(ctx.download_P())
-    assert rel_fro(outs[0], outs[1]) < 1e-12
-    for b in range(B):
-        _, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
-        assert rel_fro(outs[0][b], P_ref) < 1e-10
 
 
 @pytest.mark.parametrize("B", [16, 96])
@@ -457,60 +348,6 @@ def test_symmetric_form_gated_ill_conditioned_and_not_spd(built):
         assert w.min() > -1e-9 * w.max()
 
 
-_KNOB_SNIPPET = r"""
-import sys, json
-sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/oracle"); sys.path.insert(0, {root!r} + "/tests")
-import numpy as np
-import xivo_oracle as orc
-from helpers import rel_fro
-from xivo_amd import synth
-from xivo_amd.lib import Context, FLAG_FP32_CORR, FLAG_PROFILE
-out = {{}}
-for (N, F) in [(250, 80), (203, 30), (37, 3)]:
-    P, H, inn, dR = synth.s_level(N, F, 3, seed=5)
-    for flags in (FLAG_FP32_CORR, 0):
-        with Context(N, 2 * F, 3, flags=flags | FLAG_PROFILE) as ctx:
-            ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
-            Pn = ctx.download_P(); err = ctx.get_err(); prof = ctx.profile_get()
-        worst_P = worst_dx = 0.0
-        for b in range(3):
-            e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
-            worst_P = max(worst_P, rel_fro(Pn[b], P_ref)); worst_dx = max(worst_dx, rel_fro(err[b], e_ref))
-        out["%d,%d,%d" % (N, F, flags)] = dict(P=worst_P, dx=worst_dx, sym=bool(all(np.array_equal(Pn[b], Pn[b].T) for b in range(3))),
-                                               kernels={{k: v["kernel"] for k, v in prof.items() if v["launches"]}})
-print(json.dumps(out))
-"""
-
-
-@pytest.mark.parametrize("knob", ["XIVO_HIP_NO_JOSEPH_IN_SOLVE", "XIVO_HIP_NO_TRSM_T", "XIVO_HIP_NO_PNEW_REG"])
-def test_fallback_pipelines_behind_the_knobs(built, knob):
-    """The kernels the default path no longer launches at these sizes - T inside the solve kernel, the compressed-row G,
-    P+ with the rows of G in registers, the tiled T / P+ products - stay selectable (A/B knobs, read once per process:
-    hence the subprocess) and are what bigger shapes fall back to. Same tolerances against the oracle."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ); env[knob] = "1"
-    if knob == "XIVO_HIP_NO_PNEW_REG":
-        env["XIVO_HIP_NO_JOSEPH_IN_SOLVE"] = "1"
-    r = subprocess.run([sys.executable, "-c", _KNOB_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    res = json.loads(r.stdout.strip().splitlines()[-1])
-    for key, v in res.items():
-        assert v["P"] < 1e-10 and v["dx"] < 1e-10 and v["sym"], (key, v)
-        k = v["kernels"]
-        assert "gemm_Pnew" in k and "gemm_KH_I" in k, (key, k)           # the stand-alone tail ran
-        if knob == "XIVO_HIP_NO_TRSM_T":
-            assert "gemm_AP" in k and k["trsm_gain"].endswith(",0>")
-        else:
-            assert "gemm_AP" not in k and k["trsm_gain"].endswith(",1>")
-    # which P+ kernel: registers (all fp64, unless knocked out) or the tiled product
-    from xivo_amd.lib import FLAG_FP32_CORR
-    k64 = res["250,80,0"]["kernels"]["gemm_Pnew"]
-    k32 = res["250,80,%d" % FLAG_FP32_CORR]["kernels"]["gemm_Pnew"]
-    assert k32.startswith("gemm_nt_f64_kernel") and "float" in k32
-    assert k64.startswith("gemm_nt_f64_kernel" if knob == "XIVO_HIP_NO_PNEW_REG" else "pnew_reg_f64_kernel")
-
-
 @pytest.mark.parametrize("N,F", [(250, 80), (150, 50), (203, 30), (37, 3)])
 def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
     """XIVO_HIP_FLAG_STANDALONE_TAIL: the covariance update from stand-alone kernels (re-associated expression) instead of
@@ -527,7 +364,7 @@ def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
             outs.append(ctx.download_P()); errs.append(ctx.get_err())
             kern.append({k: v["kernel"] for k, v in ctx.profile_get().items() if v["launches"]})
     # (the in-solve whitened form: <NBM,4>, or its ten-wave instantiation <7,4,false,10,3> for seven block rows on <= 160 columns)
-    assert (kern[0]["trsm_gain"].endswith(",4>") or ",4,false," in kern[0]["trsm_gain"]) and "gemm_Pnew" not in kern[0]
+    assert (kern[0]["trsm_gain"].endswith(",4>") or kern[0]["trsm_gain"].startswith("trsm_lds_f64_kernel<7,4,")) and "gemm_Pnew" not in kern[0]
     assert kern[1]["trsm_gain"].endswith(",1>") and "gemm_Pnew" in kern[1] and "gemm_KH_I" in kern[1]
     assert rel_fro(errs[0], errs[1]) < 1e-13      # same solve; the in-solve variant sums dx = K inn block by block as the gain appears
     assert rel_fro(outs[0], outs[1]) < 1e-11
@@ -538,26 +375,25 @@ def test_standalone_tail_flag_matches_the_in_solve_update(built, N, F):
 
 # ---------------------------------------------------------------- the two in-solve evaluations of the Joseph expression
 @pytest.mark.parametrize("N,F", [(250, 80), (250, 88), (150, 50), (203, 30), (37, 3), (64, 8), (100, 1), (256, 72)])
-def test_whitened_and_expanded_in_solve_forms_agree(built, N, F):
-    """Default: P+ = P - (W - D)^T (W + D) (W = L^-1 H P from the stash, D = the backward substitution's own residual);
-    XIVO_HIP_FLAG_EXPANDED_JOSEPH: P+ = P - K (2 H P - L L^T K^T), the round-2 evaluation. Both are the Joseph expression of
-    src/estimator.cpp:1276-1287 for the computed gain with S = L L^T; they agree with each other and with the oracle far
-    inside the tolerances. (250, 88): M = 176, eleven block rows - the packed-diagonal instantiation."""
-    from xivo_amd.lib import FLAG_EXPANDED_JOSEPH, FLAG_PROFILE
+def test_whitened_form_in_the_solve_kernel_and_on_the_latency_route_agree(built, N, F):
+    """P+ = P - (W - D)^T (W + D) (W = L^-1 H P, D = the backward substitution's own residual) - the Joseph expression of
+    src/estimator.cpp:1276-1287 for the computed gain with S = L L^T - inside the solve kernel (one workgroup per filter) and
+    from the streamed solve's whitened outputs + the tiled product (nine filters without a flag: the latency route): the two
+    agree with each other and with the oracle far inside the tolerances. (250, 88): M = 176, eleven block rows - the
+    packed-diagonal instantiation. (The multi-kernel pipeline's two executions; the one-kernel route: test_fused_gpu.py.)"""
+    from xivo_amd.lib import FLAG_PROFILE
     B = 9                                    # more than one XCD group of 8
     P, H, inn, dR = synth.s_level(N, F, B, seed=23)
-    outs, errs, kern = [], [], []
-    for flags in (FLAG_THROUGHPUT_ROUTE | FLAG_MULTI_KERNEL, FLAG_EXPANDED_JOSEPH, FLAG_MULTI_KERNEL):   # (the multi-kernel pipeline's forms; the one-kernel route: test_fused_gpu.py)
+    outs, errs, kern, routes = [], [], [], []
+    for flags in (FLAG_THROUGHPUT_ROUTE | FLAG_MULTI_KERNEL, FLAG_MULTI_KERNEL):
         with Context(N, 2 * F, B, flags=flags | FLAG_PROFILE) as ctx:
             ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
             assert ctx.last_path() == 1 and (ctx.get_status() == 0).all()
             outs.append(ctx.download_P()); errs.append(ctx.get_err())
-            kern.append(ctx.profile_get()["trsm_gain"]["kernel"])
-    # nine filters without a flag: the latency route - the same whitened evaluation from the streamed solve + tiled product
-    assert (kern[0].endswith(",4>") or ",4,false," in kern[0]) and kern[1].endswith(",3>") and kern[2].startswith("trsm_stream_f64_kernel<")
-    assert rel_fro(errs[0], errs[2]) < 1e-13 and rel_fro(outs[0], outs[2]) < 1e-11
-    assert rel_fro(errs[0], errs[1]) < 1e-13
-    assert rel_fro(outs[0], outs[1]) < 1e-11
+            kern.append(ctx.profile_get()["trsm_gain"]["kernel"]); routes.append(ctx.last_route())
+    assert routes == ["sparse_in_solve", "sparse_whitened"]
+    assert (kern[0].endswith(",4>") or kern[0].startswith("trsm_lds_f64_kernel<7,4,")) and kern[1].startswith("trsm_stream_f64_kernel<")
+    assert rel_fro(errs[0], errs[1]) < 1e-13 and rel_fro(outs[0], outs[1]) < 1e-11
     for b in range(B):
         e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
         for o, e in zip(outs, errs):
@@ -606,7 +442,7 @@ for (N, F) in [(150, 50), (250, 80), (203, 30), (64, 20), (100, 96), (100, 110),
     B = 520                                   # >= 512: the size class where the pick matters
     P, H, inn, dR = synth.s_level(N, F, 8, seed=41)
     idx = np.arange(B) % 8
-    with Context(N, 2 * F, B) as ctx:
+    with Context(N, 2 * F, B, flags=65536) as ctx:      # XIVO_HIP_FLAG_MULTI_KERNEL: the pipeline with a stand-alone factorisation
         ctx.upload_P(P[idx]); ctx.set_measurements(H[idx], inn[idx], dR[idx]); ctx.update_joseph()
         Pn = ctx.download_P(); err = ctx.get_err()
     out["%d,%d" % (N, F)] = [hashlib.sha256(Pn.tobytes()).hexdigest(), hashlib.sha256(err.tobytes()).hexdigest()]
@@ -616,30 +452,22 @@ print(json.dumps(out))
 
 def test_cholesky_kernels_are_bit_identical(built):
     """The one-wave and the four-wave register Cholesky run the same arithmetic in the same order (factor_invert_diag on
-    the matrix pipe, pivot_scale, two accumulators per block product): whichever kernel and whichever instantiation of the
-    register kernel runs (four waves per factor or eight, three workgroups per CU / two, look-ahead on the diagonal update or not, blocks of S requested up
-    front or per block column, the opt-in timing of XIVO_HIP_AUTOTUNE), P+ and dx come out bit for bit the same - across
-    nodes, ranks, runs and batch sizes. Round 5: so does the factorisation INSIDE the solve kernel (opt-in, XIVO_HIP_FUSED_CHOL:
-    measured slower than the stand-alone kernels): block row i on wave i, the factor in LDS, half of the right-hand sides joining
-    the forward substitution late - the same bits. And the three forms of the solve for (150, 100): ten waves with W kept in
-    registers (default), ten waves twice per CU with the stash (XIVO_HIP_NARROW_SOLVE=1), the sixteen-wave kernel (=0)."""
+    the matrix pipe, pivot_scale, two accumulators per block product): whichever kernel runs (XIVO_HIP_CHOL_WAVE: the one-wave
+    kernel for every size - the one A/B knob the factorisation keeps) and whichever instantiation of the register kernel
+    (four waves per factor or eight, three workgroups per CU / two), P+ and dx come out bit for bit the same - across nodes,
+    ranks, runs and batch sizes."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    knobs = ("XIVO_HIP_CHOL_WAVE", "XIVO_HIP_CHOL_REG", "XIVO_HIP_CHOL_LOOKAHEAD", "XIVO_HIP_CHOL_NO_LOOKAHEAD",
-             "XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS", "XIVO_HIP_AUTOTUNE", "XIVO_HIP_CHOL_NO_REG8", "XIVO_HIP_FUSED_CHOL", "XIVO_HIP_NARROW_SOLVE")
     res = []
-    for knob in (("XIVO_HIP_CHOL_WAVE",), (), ("XIVO_HIP_FUSED_CHOL",), ("XIVO_HIP_NARROW_SOLVE",), ("XIVO_HIP_NARROW_SOLVE=0",), ("XIVO_HIP_CHOL_LOOKAHEAD",), ("XIVO_HIP_CHOL_MINB2",),
-                 ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_LAZY_LOADS"), ("XIVO_HIP_CHOL_MINB2", "XIVO_HIP_CHOL_NO_LOOKAHEAD"),
-                 ("XIVO_HIP_AUTOTUNE",), ("XIVO_HIP_CHOL_NO_REG8",)):
+    for knob in ((), ("XIVO_HIP_CHOL_WAVE",)):
         env = dict(os.environ)
-        for k in knobs:
-            env.pop(k, None)
+        env.pop("XIVO_HIP_CHOL_WAVE", None)
         for k in knob:
-            env[k.split("=")[0]] = k.split("=")[1] if "=" in k else "1"
+            env[k] = "1"
         r = subprocess.run([sys.executable, "-c", _CHOL_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert all(r == res[0] for r in res[1:]), res
+    assert res[0] == res[1], res
 
 
 @pytest.mark.parametrize("N,F,waves", [(150, 50, 10), (147, 49, 10), (180, 53, 12), (192, 56, 12)])
@@ -661,7 +489,7 @@ def test_seven_block_rows_on_a_narrow_state_keep_W_in_registers(built, N, F, wav
         mask, _ = ctx.get_gate(F, B)
         st = ctx.get_status(check=False); used = ctx.get_ldlt_used()
         Pn, err = ctx.download_P(), ctx.get_err()
-    assert prof["trsm_gain"]["kernel"] == "trsm_lds_f64_kernel<7,4,false,%d,3>" % waves
+    assert prof["trsm_gain"]["kernel"] == "trsm_lds_f64_kernel<7,4,%d,3>" % waves
     assert (st == 0).all() and used.sum() == 0
     assert not mask[5, 2:4].any() and mask[0].all()
     for b in (0, 3, 5, 9, 13, B - 1):
@@ -691,48 +519,64 @@ def test_update_matches_the_eigen_driver_directly(built, N, F):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
 
 
-def _fuzz_cases():
+def _route_cases():
+    """Every route of plan_update (xivo_amd/csrc/capi.hip) on seeded random shapes: (flags, dense H?, filters) -> the route the
+    table names for it. Shapes: state dim 24..419, 1..149 features."""
+    from xivo_amd.lib import FLAG_DENSE_H, FLAG_SYMMETRIC_FORM, FLAG_STANDALONE_TAIL
     rng = np.random.default_rng(20260924)
-    from xivo_amd.lib import (FLAG_DENSE_H, FLAG_REASSOC, FLAG_SYMMETRIC_FORM, FLAG_STANDALONE_TAIL, FLAG_EXPANDED_JOSEPH,
-                              FLAG_FP32_CORR, FLAG_FULL_PNEW)
-    flag_sets = [0, FLAG_THROUGHPUT_ROUTE, FLAG_THROUGHPUT_ROUTE, FLAG_SYMMETRIC_FORM, FLAG_STANDALONE_TAIL, FLAG_EXPANDED_JOSEPH, FLAG_DENSE_H, FLAG_DENSE_H | FLAG_REASSOC,
-                 FLAG_FULL_PNEW, FLAG_STANDALONE_TAIL | FLAG_FP32_CORR]
+    modes = [(0, False, None), (FLAG_THROUGHPUT_ROUTE, False, None), (FLAG_MULTI_KERNEL, False, None),
+             (FLAG_MULTI_KERNEL | FLAG_THROUGHPUT_ROUTE, False, None), (FLAG_SYMMETRIC_FORM, False, "sparse_symmetric"),
+             (FLAG_STANDALONE_TAIL, False, "sparse_tail"), (FLAG_DENSE_H, False, "dense_ascoded"), (0, True, "dense_whitened"),
+             (FLAG_THROUGHPUT_ROUTE, True, "dense_whitened"), (FLAG_SYMMETRIC_FORM, True, "dense_symmetric")]
     cases = []
-    for i in range(36):
+    for i in range(40):
         N = int(rng.integers(24, 420))
         F = int(rng.integers(1, min(96, max(2, N // 3)) + 1))
         if i % 6 == 5:
             F = int(rng.integers(90, 150))                      # factors beyond the LDS: streamed solve
         B = int(rng.integers(1, 10))
-        cases.append((N, F, B, flag_sets[i % len(flag_sets)], 1000 + i))
+        fl, dense, route = modes[i % len(modes)]
+        cases.append((N, F, B, fl, dense, route, 1000 + i))
     return cases
 
 
-@pytest.mark.parametrize("N,F,B,flags,seed", _fuzz_cases())
-def test_random_shapes_and_modes_match_oracle(built, N, F, B, flags, seed):
-    """Seeded random shapes (state dim 24..419, 1..149 features, 1..9 filters) through every covariance-update mode: the
-    in-solve kernels (one workgroup / chunked / streamed, whitened and expanded forms), the latency route (no flag: at most
-    nine filters here), the stand-alone tails, the symmetric form, the dense pipelines. Tolerances as everywhere: 1e-6 on P (5e-5 where an fp32 product was asked for), 1e-8 on dx."""
-    from xivo_amd.lib import FLAG_FP32_CORR
-    P, H, inn, dR = synth.s_level(N, F, B, seed=seed)
+@pytest.mark.parametrize("N,F,B,flags,dense,route,seed", _route_cases())
+def test_every_route_of_the_plan(built, N, F, B, flags, dense, route, seed):
+    """Seeded random shapes through every route of the one table that selects them (plan_update in capi.hip): the one-kernel
+    update, the whitened form inside the solve kernel / from the whitened outputs (chunked, streamed, the latency route), the
+    stand-alone tail, the symmetric form, the as-coded dense sequence, the whitened update on dense rows. The route the
+    library reports is one the table allows for the flags; P+ 1e-6, dx 1e-8, symmetric output."""
+    P, H, inn, dR = synth.s_level(N, F, B, seed=seed, dense=dense)
     with Context(N, 2 * F, B, flags=flags) as ctx:
         ctx.upload_P(P); ctx.set_measurements(H, inn, dR); ctx.update_joseph()
         assert (ctx.get_status() == 0).all() and not ctx.get_ldlt_used().any()
         err = ctx.get_err(); Pn = ctx.download_P()
-    tol_P = 5e-5 if flags & FLAG_FP32_CORR else TOL_P
+        got = ctx.last_route()
+    if dense and N <= 28:
+        route = None                                # (a dense H of at most 28 columns still fits the compressed form)
+    if route is not None:
+        assert got == route, (got, route)
+    elif flags & FLAG_MULTI_KERNEL:
+        assert got in ("sparse_in_solve", "sparse_whitened"), got
+    else:
+        assert got in ("fused", "sparse_in_solve", "sparse_whitened"), got
+    if (flags & FLAG_THROUGHPUT_ROUTE) and got == "sparse_whitened":
+        assert N > 256 or 2 * F > 176               # only a shape one workgroup does not hold leaves the solve kernel then
     for b in range(B):
         e_ref, P_ref, _ = orc.update_joseph(H[b], P[b], inn[b], dR[b])
-        assert rel_fro(Pn[b], P_ref) < tol_P and rel_fro(err[b], e_ref) < TOL_DX
-        if not flags & 4:                       # (XIVO_HIP_FLAG_FULL_PNEW computes every entry instead of lower triangle + mirror)
-            assert np.array_equal(Pn[b], Pn[b].T)
+        assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+        assert np.array_equal(Pn[b], Pn[b].T)
 
 
-@pytest.mark.parametrize("N,F,flags", [(400, 150, 0), (300, 60, 0), (512, 64, 0), (400, 150, 64 | 16), (251, 100, 0)])
+TOL_P_FP32 = 5e-5   # stated tolerance of XIVO_HIP_FLAG_FP32_WHITENED (config 4): relative Frobenius on P+
+
+
+@pytest.mark.parametrize("N,F,flags", [(400, 150, 0), (300, 60, 0), (512, 64, 0), (251, 100, 0)])
 def test_fp32_whitened_operands_beyond_one_workgroup(built, N, F, flags):
     """XIVO_HIP_FLAG_FP32_WHITENED (round 4; BASELINE config 4 "fp32 MFMA with stated tolerance"): for shapes whose product
     runs outside the solve kernel the whitened operands V^T, Y^T leave the fp64 solve as float and P - V^T Y runs on
     v_mfma_f32_16x16x4_f32. dx is untouched (1e-8: everything up to the gain is fp64), P+ within the stated 5e-5 (measured
-    ~1e-7: the float rounding of the operands), same status; sparse and dense re-associated pipelines."""
+    ~1e-7: the float rounding of the operands), same status."""
     from xivo_amd.lib import FLAG_FP32_WHITENED
     B = 3
     P, H, inn, dR = synth.s_level(N, F, B, seed=900 + N + F)
@@ -811,44 +655,25 @@ def test_long_chain_of_default_form_updates_stays_psd_and_close(built, N, F, ste
                     assert rel_fro(Pn[b], Pref[b]) < TOL_P, (it, rel_fro(Pn[b], Pref[b]))
 
 
-_GATE_SNIPPET = r"""
-import sys, json, hashlib
-sys.path.insert(0, {root!r})
-import numpy as np
-from xivo_amd import synth
-from xivo_amd.lib import Context
-out = {{}}
-for (N, F) in [(250, 80), (150, 50), (203, 30)]:
-    B = 600                                   # >= 512: the factorisation that carries the gate
-    P, H, inn, dR = synth.s_level(N, F, 8, seed=77)
-    inn[:, 4:8] *= 400.0; inn[3, 10:2 * F - 6] *= 900.0      # features the gate throws out (filter 3: nearly all of them - threshold relaxation)
-    idx = np.arange(B) % 8
-    with Context(N, 2 * F, B) as ctx:
-        ctx.upload_P(P[idx]); ctx.set_measurements(H[idx], inn[idx], dR[idx])
-        ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5, B)
-        Pn = ctx.download_P(); err = ctx.get_err(); mask, dist = ctx.get_gate(F, B)
-        st = ctx.get_status(check=False)
-    out["%d,%d" % (N, F)] = [hashlib.sha256(a.tobytes()).hexdigest() for a in (Pn, err, mask, dist, st)] + [int(mask.sum()), int(mask.size)]
-print(json.dumps(out))
-"""
-
-
 def test_gate_in_the_factorisation_prologue_is_bit_identical_to_the_gate_kernel(built):
-    """Round 5: for thousands of filters Estimator::MHGating (src/update.cpp:60-96) rides in the prologue of the Cholesky kernel
+    """For thousands of filters Estimator::MHGating (src/update.cpp:60-96) rides in the prologue of the Cholesky kernel
     (chol_reg_f64_kernel<..., GATE>: distances from the compact diagonal blocks of S, relaxation, rejected pairs decoupled
-    where S is loaded). XIVO_HIP_NO_GATE_IN_CHOL brings gate_ell_kernel back as a launch of its own: masks, distances, dx and
-    P+ must be the same bits."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    for knob in ((), ("XIVO_HIP_NO_GATE_IN_CHOL",)):
-        env = dict(os.environ)
-        env.pop("XIVO_HIP_NO_GATE_IN_CHOL", None)
-        for k in knob:
-            env[k] = "1"
-        r = subprocess.run([sys.executable, "-c", _GATE_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert res[0] == res[1], res
-    for k, v in res[0].items():
-        assert 0 < v[5] < v[6], (k, v)            # something was rejected, not everything
+    where S is loaded); fewer than 512 filters keep gate_ell_kernel as a launch of its own (and the few-factor instantiation
+    of the factorisation): masks, distances, dx and P+ of the same filters must be the same bits either way."""
+    from xivo_amd.lib import FLAG_PROFILE
+    for (N, F) in [(250, 80), (150, 50), (203, 30)]:
+        P, H, inn, dR = synth.s_level(N, F, 8, seed=77)
+        inn[:, 4:8] *= 400.0; inn[3, 10:2 * F - 6] *= 900.0      # features the gate throws out (filter 3: nearly all of them - threshold relaxation)
+        res = []
+        for B in (600, 500):
+            idx = np.arange(B) % 8
+            with Context(N, 2 * F, B, flags=FLAG_MULTI_KERNEL | FLAG_THROUGHPUT_ROUTE | FLAG_PROFILE) as ctx:
+                ctx.upload_P(P[idx]); ctx.set_measurements(H[idx], inn[idx], dR[idx])
+                ctx.update_dense_gated(F, 2.25, 5.991, 1.1, 5, B)
+                prof = ctx.profile_get()
+                mask, dist = ctx.get_gate(F, B)
+                res.append((ctx.download_P()[:500], ctx.get_err()[:500], mask[:500].copy(), dist[:500].copy(), ctx.get_status(check=False)[:500]))
+            assert (prof["mh_gate"]["launches"] == 0) == (B == 600) and ("+gate" in prof["chol_S"]["kernel"]) == (B == 600), prof
+        for x, y in zip(res[0], res[1]):
+            assert np.array_equal(x, y)
+        assert 0 < res[0][2].sum() < res[0][2].size               # something was rejected, not everything

@@ -49,10 +49,11 @@ struct xivo_hip_ctx {
   int* ell_flags_h = nullptr;   // pinned, device-mapped [Bmax][3]: over / nc / pw as the hand-over kernel leaves them
   int* ell_flags_d = nullptr;   // its device alias
   int last_path = 0;
+  int last_route = 0;   // UpdateRoute of the last pass (xivo_hip_last_route)
   // dense H / H^T of the stacked rows: written eagerly by set_measurements, lazily after xivo_hip_stack
   bool dense_valid = true;
   bool dense_from_ell = false;   // the stacked rows came in through set_measurements (compressed rows are the source)
-  bool ht_valid = true;          // the transposed dense copy H^T matches H (false after a producer skipped it: skip_HT)
+  bool ht_valid = true;          // the transposed dense copy H^T matches H (false after a producer skipped it: mixed stacking)
   // mixed stacking (round 3): in-state rows [0, mixed_row0) exist in the row-pair compressed form only, the OOS rows
   // appended by xivo_hip_oos_project from row mixed_row0 on in the dense buffer only; -1: not in that mode
   int mixed_row0 = -1;
@@ -63,8 +64,6 @@ struct xivo_hip_ctx {
   int M = 0, Mp = 0;  // rows currently staged
   int chunk = 0;      // filters per pipeline pass (0 = whole batch)
   int call_batch = 0; // filters of the whole update call being walked in chunks (0: not chunked)
-  int chol_variant[32] = {0};   // per factor size (blocks): 0 = not calibrated yet, 1 / 2 = CholArgs::variant picked on this node
-  int* tune_status = nullptr;   // scratch status of the calibration runs (never the caller's)
   int* ldlt_used = nullptr;     // per filter: 1 = the last update went through the pivoted L D L^T fallback
   // G-level
   xivo_layout lay{};
@@ -175,12 +174,6 @@ int collect_profile(xivo_hip_ctx* c) {
   return XIVO_HIP_OK;
 }
 
-// the transposed dense copy H^T is read by the as-coded K H - I product and the dense-row gate only; with the
-// re-associated dense pipeline forced (DENSE_H | REASSOC) nobody reads it and the G-level producers skip writing it
-static bool skip_HT(const xivo_hip_ctx* c) {
-  return (c->flags & XIVO_HIP_FLAG_DENSE_H) && (c->flags & XIVO_HIP_FLAG_REASSOC) && !(c->flags & XIVO_HIP_FLAG_FP32_COV);
-}
-
 MeasBuffers meas_buffers(xivo_hip_ctx* c) {
   MeasBuffers mb;
   mb.H = c->H; mb.strideH = c->sH; mb.ldh = c->Mpmax;
@@ -192,10 +185,9 @@ MeasBuffers meas_buffers(xivo_hip_ctx* c) {
 
 // leading state columns the calibration blocks live in: td 23, Cg 24..32, (Ca 33..38,) bg 9..11, intrinsics up to 39..47
 constexpr int LEAD_K = 48;
-static bool calib_sparse(const xivo_hip_ctx* c) {
-  const bool off = getenv("XIVO_HIP_CALIB_DENSE") != nullptr;   // A/B knob, read per call: online-calibration builds on dense rows (round 4)
-  return c->calib_on && !off && c->Hlead && c->cl.cam_begin + 9 <= LEAD_K && c->Np >= LEAD_K &&
-         !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV | XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL));
+static bool calib_sparse(const xivo_hip_ctx* c) {   // (XIVO_HIP_FLAG_DENSE_H keeps the round-4 dense stacking of these builds)
+  return c->calib_on && c->Hlead && c->cl.cam_begin + 9 <= LEAD_K && c->Np >= LEAD_K &&
+         !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL));
 }
 
 SceneBuffers scene_buffers(xivo_hip_ctx* c) {
@@ -305,7 +297,7 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
   const double outs = x.lower_only ? 0.5 * rows * (cols + 1.0) : (double)rows * cols;
   const double flops = 2.0 * outs * (double)(K0 + (A1 ? K1 : 0)) * B;
   const bool sym = g.lower_only && rows == cols && gemm_sym_supported(rows) && !g.C2 && !g.fp32 &&
-                   (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG) && !(c->flags & XIVO_HIP_FLAG_TILE_SYM);
+                   (g.epilogue == EPI_NONE || g.epilogue == EPI_ADD_DIAG);
   char label[64] = "gemm_sym_f64_kernel";
   if (!sym) gemm_kernel_label(g, label, sizeof(label));
   const double bytes = 8.0 * B * ((double)rows * K0 * (x.a_f32 ? 0.5 : 1.0) + (double)cols * K0 * (x.b_f32 ? 0.5 : 1.0) + (A1 ? ((double)rows + cols) * K1 : 0.0) +
@@ -319,24 +311,66 @@ int gemm(xivo_hip_ctx* c, int stage, int B, int rows, int cols, const double* A0
 
 }  // namespace
 
-// An update of few filters takes the latency route (chol_trsm.hip, trsm_latency_route) when the pipeline would evaluate the
-// whitened Joseph form anyway: streamed solve with the whitened outputs + the tiled product P - V^T Y on small tiles.
-// (B = the filters of this pass; with the batch walked in chunks - XIVO_HIP_CHUNK - the decision is made on the WHOLE call's
-// batch, c->call_batch: chunks of <= 64 filters of a large batch must not take the few-filter kernels)
-static bool latency_route(const xivo_hip_ctx* c, int Mp, int B, bool full) {
-  if (c->call_batch > B) B = c->call_batch;
-  static const bool knobs = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") || getenv("XIVO_HIP_NO_TRSM_T") || getenv("XIVO_HIP_T_FULL");
-  const unsigned other = XIVO_HIP_FLAG_THROUGHPUT_ROUTE | XIVO_HIP_FLAG_EXPANDED_JOSEPH | XIVO_HIP_FLAG_STANDALONE_TAIL |
-                         XIVO_HIP_FLAG_FP32_CORR | XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_FP32_COV;
-  return !full && !knobs && !(c->flags & other) && trsm_latency_route(Mp, B);
-}
+// ---------------------------------------------------------------------------------------------------------------------
+// Route selection of Estimator::UpdateJosephForm (src/estimator.cpp:1257-1288), in ONE place. Every pass of the update
+// (update_joseph_range) asks plan_update() once; the pipelines below only execute what the plan says, and
+// tests/test_update_gpu.py::test_every_route_of_the_plan enumerates the routes of this table against the oracle.
+//
+//   route              | rows of H                   | gain + covariance                                   | when
+//   -------------------+-----------------------------+-----------------------------------------------------+--------------------------
+//   FUSED              | row-pair compressed         | one kernel per filter (fused_update.hip)            | M <= 64 / N <= 256 or M <= 112 / N <= 192, default form
+//   SPARSE_IN_SOLVE    | compressed (+ OOS / lead)   | whitened Joseph form inside the solve kernel        | N <= 256, M <= 176, > 64 filters
+//   SPARSE_WHITENED    | compressed (+ OOS / lead)   | whitened outputs V^T, Y^T + tiled P - V^T Y         | wider shapes; <= 64 filters (latency route)
+//   SPARSE_SYMMETRIC   | compressed                  | P - W^T W, forward substitution only                | XIVO_HIP_FLAG_SYMMETRIC_FORM
+//   SPARSE_TAIL        | compressed                  | T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T      | XIVO_HIP_FLAG_STANDALONE_TAIL
+//   DENSE_ASCODED      | dense                       | A = KH - I, T = A P, P+ = T A^T + K R K^T           | XIVO_HIP_FLAG_DENSE_H
+//   DENSE_WHITENED     | dense (H does not compress) | dense H P and S, then as SPARSE_IN_SOLVE / _WHITENED | an H without XIVO's row structure
+//   DENSE_SYMMETRIC    | dense                       | as SPARSE_SYMMETRIC                                 | SYMMETRIC_FORM on dense rows
+enum UpdateRoute : int { ROUTE_FUSED = 0, ROUTE_SPARSE_IN_SOLVE, ROUTE_SPARSE_WHITENED, ROUTE_SPARSE_SYMMETRIC, ROUTE_SPARSE_TAIL,
+                         ROUTE_DENSE_ASCODED, ROUTE_DENSE_WHITENED, ROUTE_DENSE_SYMMETRIC, ROUTE_COUNT };
+static const char* kRouteNames[ROUTE_COUNT] = {"fused", "sparse_in_solve", "sparse_whitened", "sparse_symmetric", "sparse_tail",
+                                               "dense_ascoded", "dense_whitened", "dense_symmetric"};
+struct UpdatePlan {
+  int route;
+  bool sparse;        // the rows are used in their compressed form
+  bool in_solve;      // the covariance update runs inside the solve kernel (one workgroup per filter)
+  bool latency;       // few filters: streamed solve on four-wave workgroups + the product on 64 x 64 tiles
+  bool stream8;       // N > 256 with a short factor: the streamed solve on eight-wave workgroups
+  bool f32_whitened;  // XIVO_HIP_FLAG_FP32_WHITENED applies (the product runs outside the solve kernel because of the SHAPE)
+};
 
-// States wider than one sixteen-wave workgroup (N > 256) with a factor of at most eight block rows: the whitened outputs
-// come from the streamed solve on eight-wave workgroups (N = 276, M = 120: 2.01 -> 1.39 ms per 4096 filters - the LDS kernel
-// ran a second, nearly empty workgroup per filter that copied the whole factor for two live waves). XIVO_HIP_NO_STREAM8: A/B.
-static bool stream8_shape(int Mp, int Np) {
-  static const bool off = getenv("XIVO_HIP_NO_STREAM8") != nullptr;
-  return !off && Np > 256 && Mp / 16 <= 8;
+// (B = the filters of this pass; with the batch walked in chunks - XIVO_HIP_CHUNK - the few-filter decision is made on the
+//  WHOLE call's batch, c->call_batch: chunks of <= 64 filters of a large batch must not take the few-filter kernels)
+static UpdatePlan plan_update(const xivo_hip_ctx* c, int b0, int B, bool gate) {
+  const int Np = c->Np, Mp = c->Mp;
+  const unsigned f = c->flags;
+  UpdatePlan p{};
+  bool sparse = !(f & XIVO_HIP_FLAG_DENSE_H);
+  int nc_max = 0, pw_max = 1;
+  for (int b = b0; b < b0 + B; ++b) {
+    sparse = sparse && c->ell_over_h[b] == 0;
+    nc_max = std::max(nc_max, c->ell_nc_h[b]); pw_max = std::max(pw_max, c->ell_pw_h[b]);
+  }
+  const bool extra_rows = c->mixed_row0 >= 0 || c->lead_valid;     // dense OOS rows / the leading calibration block next to the compressed rows
+  // the stand-alone tail's G = T H^T walks compressed rows of ALL of H, and the compact gate of a calibration stacking reads whole rows
+  if (sparse && extra_rows && ((f & XIVO_HIP_FLAG_STANDALONE_TAIL) || (c->lead_valid && gate))) sparse = false;
+  if (sparse && c->lead_valid && (f & XIVO_HIP_FLAG_SYMMETRIC_FORM)) sparse = false;
+  p.sparse = sparse;
+  const bool holds = trsm_forms_T(Mp, Np);                          // one workgroup per filter holds the factor and every column of the state
+  const int Ball = c->call_batch > B ? c->call_batch : B;
+  p.latency = !(f & (XIVO_HIP_FLAG_THROUGHPUT_ROUTE | XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_SYMMETRIC_FORM)) &&
+              trsm_latency_route(Mp, Ball) && (sparse || !(f & XIVO_HIP_FLAG_DENSE_H));
+  p.stream8 = !p.latency && Np > 256 && Mp / 16 <= 8;               // (N = 276, M = 120: 2.01 -> 1.39 ms per 4096 filters)
+  if (f & XIVO_HIP_FLAG_SYMMETRIC_FORM) { p.route = sparse ? ROUTE_SPARSE_SYMMETRIC : ROUTE_DENSE_SYMMETRIC; p.in_solve = holds; return p; }
+  if (!sparse && (f & XIVO_HIP_FLAG_DENSE_H)) { p.route = ROUTE_DENSE_ASCODED; return p; }
+  if (sparse && (f & XIVO_HIP_FLAG_STANDALONE_TAIL)) { p.route = ROUTE_SPARSE_TAIL; return p; }
+  if (sparse && !extra_rows && !(f & XIVO_HIP_FLAG_MULTI_KERNEL) && nc_max <= 12 && pw_max <= 9 && fused_update_supported(Mp, Np)) {
+    p.route = ROUTE_FUSED; p.latency = false; return p;
+  }
+  p.in_solve = holds && !p.latency;
+  p.f32_whitened = (f & XIVO_HIP_FLAG_FP32_WHITENED) && !holds;
+  p.route = sparse ? (p.in_solve ? ROUTE_SPARSE_IN_SOLVE : ROUTE_SPARSE_WHITENED) : ROUTE_DENSE_WHITENED;
+  return p;
 }
 
 static int ensure_gate_buffers(xivo_hip_ctx* c, int F);
@@ -364,7 +398,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
-                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->calib_rs, c->Hlead, c->tune_status, c->ldlt_used, c->calib, c->Jc};
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->calib_rs, c->Hlead, c->ldlt_used, c->calib, c->Jc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
   if (c->pin_h) hipHostFree(c->pin_h);
@@ -414,7 +448,6 @@ int xivo_hip_create(xivo_hip_ctx** out, int device, int N, int M_max, int batch_
       hipHostFree(c->ell_flags_h); c->ell_flags_h = nullptr; c->ell_flags_d = nullptr;
     }
   } else c->ell_flags_h = nullptr;
-  if (getenv("XIVO_HIP_NO_MAPPED_FLAGS") && c->ell_flags_h) { hipHostFree(c->ell_flags_h); c->ell_flags_h = nullptr; c->ell_flags_d = nullptr; }   // A/B knob
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t0) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc == XIVO_HIP_OK && hipEventCreate(&c->t1) != hipSuccess) rc = XIVO_HIP_ERR_HIP;
   if (rc != XIVO_HIP_OK) { xivo_hip_destroy(c); return rc; }
@@ -552,7 +585,9 @@ static int stage_measurements(xivo_hip_ctx* c, int b0, int nb, int M, const doub
   EllBuffers e = c->ell;
   e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.pw += b0; e.over += b0;
   c->lead_valid = false;
-  if (!meas_compress_fits(c->Mpmax, c->Np) || getenv("XIVO_HIP_NO_COMPRESS")) {
+  // (XIVO_HIP_NO_COMPRESS: test hook for the branch very wide states take - the shape limit itself is N > ~2800 at M = 384)
+  static const bool no_compress = getenv("XIVO_HIP_NO_COMPRESS") != nullptr;
+  if (!meas_compress_fits(c->Mpmax, c->Np) || no_compress) {
     // the compression kernel's LDS lists do not fit this shape: every filter keeps its dense rows and takes the dense pipeline
     StageTimer st(c, ST_STACK, 0.0, "unpack_meas_kernel", 8.0 * nb * (3.0 * M * N + 4.0 * M));
     HIP_TRY((hipError_t)launch_meas_vectors(dInn, strideInn, dR, strideR, M, c->Mpmax, e, mb.inn, mb.strideInn, mb.diagR, mb.strideR, nb, c->stream));
@@ -621,52 +656,6 @@ int xivo_hip_set_measurements_device(xivo_hip_ctx* c, int b0, int nb, int M, con
   return stage_measurements(c, b0, nb, M, dH, strideH, ldh, dInn, strideInn, dR, strideR);
 }
 
-// Which Cholesky kernel a big batch runs. Default (round 3): the four-wave register kernel, for every node and every batch
-// - deterministic, no host synchronisation inside the update call. (Rounds 1-2 timed both kernels once per factor size
-// because the register kernel, then 170-200 KB of straight-line code, lost 2.6x on nodes with slow instruction fetch; with
-// the diagonal blocks factored on the matrix pipe it is a quarter of that size and 1.6x faster than the one-wave kernel,
-// and the 2048-factor sample of the timing picked the slower kernel on the first node it was tried on.) XIVO_HIP_AUTOTUNE=1
-// brings the timing back: once per factor size on scratch copies (S -> the A buffer, inverse blocks -> the T buffer, status
-// -> a buffer of its own), then remembered. Either way the two kernels run the same arithmetic in the same order
-// (chol_f64.hip: factor_invert_diag, pivot_scale) and give bit-identical factors, so the pick changes the time of a step
-// and never its result (tests/test_update_gpu.py::test_cholesky_kernels_are_bit_identical).
-static int chol_pick(xivo_hip_ctx* c, const double* S, int Mp, int lds, int B) {
-  const int nb = Mp / 16;
-  if (B < 512 || nb > 12 || getenv("XIVO_HIP_CHOL_WAVE") || getenv("XIVO_HIP_CHOL_REG")) return 0;
-  if (!getenv("XIVO_HIP_AUTOTUNE") || getenv("XIVO_HIP_NO_AUTOTUNE")) return 2;
-  if (c->chol_variant[nb]) return c->chol_variant[nb];
-  int nt = B < 2048 ? B : 2048;                  // a sample is enough
-  const long fit = (long)c->Bmax * c->sA / c->sS;   // ... and it has to fit the scratch copies (S can be larger than A: M > N)
-  if (fit < nt) nt = (int)fit;
-  const long fit2 = (long)c->Bmax * c->sP / c->sInvD;
-  if (fit2 < nt) nt = (int)fit2;
-  if (nt < 256) return 2;
-  if (!c->tune_status && dev_alloc(&c->tune_status, (size_t)c->Bmax) != XIVO_HIP_OK) return 2;
-  float best = 0.f; int pick = 1;
-  hipEvent_t e0, e1;                              // own events: the context's pair may be timing the caller's region
-  if (hipEventCreate(&e0) != hipSuccess) return 0;
-  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return 0; }
-  struct Guard { hipEvent_t a, b; ~Guard() { hipEventDestroy(a); hipEventDestroy(b); } } guard{e0, e1};
-  for (int v = 1; v <= 2; ++v) {
-    float ms_min = 1e30f;
-    for (int rep = 0; rep < 2; ++rep) {
-      if (hipMemcpyAsync(c->A, S, (size_t)nt * c->sS * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return 0;
-      CholArgs a{}; a.S = c->A; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = c->T; a.strideInvD = c->sInvD;
-      a.status = c->tune_status; a.batch = nt; a.variant = v;
-      hipEventRecord(e0, c->stream);
-      if (launch_chol_f64(a, c->stream)) return 0;
-      hipEventRecord(e1, c->stream);
-      if (hipEventSynchronize(e1) != hipSuccess) return 0;
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, e0, e1);
-      if (rep > 0 && ms < ms_min) ms_min = ms;      // first repetition = warm-up (code fetch)
-    }
-    if (v == 1 || ms_min < best) { best = ms_min; pick = v; }
-  }
-  c->chol_variant[nb] = pick;
-  return pick;
-}
-
 // One pass of the update pipeline over filters [b0, b0 + B).
 struct GateParams { int F; double R, thresh, mult; int min_inliers; };
 
@@ -676,8 +665,8 @@ struct GateParams { int F; double R, thresh, mult; int min_inliers; };
 // correction term vanishes identically), computed without the backward substitution, the residual G and the second
 // N x N x M product; its rounding error grows with cond(L) = sqrt(cond(S)), not cond(S). Opt-in: the reference codes
 // the Joseph form, which stays the default.
-static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, double* invD, double* PHT, double* K, double* P,
-                            const double* inn, int Mp, int Np, bool full) {
+static int finish_symmetric(xivo_hip_ctx* c, const UpdatePlan& plan, int b0, int B, double* S, int lds, double* invD, double* PHT, double* K,
+                            double* P, const double* inn, int Mp, int Np) {
   double* y = c->yvec + (long)b0 * c->Mpmax;
   {
     StageTimer st(c, ST_OTHER, 0.0, "fwd_vec_kernel");
@@ -689,7 +678,7 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B; a.fwd_only = 1; a.y = y; a.strideY = c->Mpmax;
     // the solve kernel goes on to P+ = P - W^T W in place, W^T still in its registers (blocks exchanged through LDS)
-    const bool p_here = !full && trsm_forms_T(Mp, Np);
+    const bool p_here = plan.in_solve;
     if (p_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.skip_status = c->status + b0; }
     char label[64]; trsm_kernel_label(Mp, label, sizeof(label), p_here ? 2 : 0);
     const double outs = 0.5 * Np * (Np + 1.0), Nf = c->N, Mf = c->M;
@@ -700,42 +689,66 @@ static int finish_symmetric(xivo_hip_ctx* c, int b0, int B, double* S, int lds, 
   }
   // P+ = P - W^T W in place: the accumulators start at -P (every tile reads its part of P before it stores anything)
   // and the result is negated on the way out
-  GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
+  GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1;
   x.skip = c->status + b0;
   return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
 }
 
-// Sparse-H pipeline (ell.h): H P, S and T H^T skip the structural zeros of H on the vector ALU; the
-// factorisation, the gain and the two N x N x M covariance products stay on the MFMA kernels.
-//   HP = H P (+ P H^T)            ell_mul<HP>      estimator.cpp:1259
-//   [MH gating]                   gate_ell         update.cpp:60-96
-//   S = (HP) H^T + R              ell_mul<S>       estimator.cpp:1259-1263
-//   S = L L^T, K^T = S^-1 HP, dx  chol, trsm       estimator.cpp:1265-1267
-//   T = K (HP) - P = (KH - I) P   gemm (MFMA)      estimator.cpp:1276-1280 (left product)
-//   G = T H^T + K R               ell_mul<G>
-//   P+ = G K^T - T                gemm (MFMA)      = T (KH-I)^T + K R K^T, estimator.cpp:1280-1287
-// debugging aid (XIVO_HIP_DUMP_DIR=<dir>): raw doubles of a device buffer of the first filter of the range into <dir>/<name>.f64
-static void dump_dev(xivo_hip_ctx* c, const char* name, const double* d, size_t n) {
-  const char* dir = getenv("XIVO_HIP_DUMP_DIR");
-  if (!dir || !d) return;
-  std::vector<double> h(n);
-  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return;
-  char path[512]; snprintf(path, sizeof(path), "%s/%s.f64", dir, name);
-  if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(double), n, f); fclose(f); }
+// The factorisation, the gain, dx and the covariance update once P H^T and S are formed - shared by the sparse and the dense
+// whitened pipelines (they differ in how H P and S are built, not behind them):
+//   S = L L^T (gate folded into its prologue when `cg` is given)                 estimator.cpp:1266
+//   in_solve : W = L^-1 (HP), K^T = L^-T W, dx, P+ = P - (W - D)^T (W + D) inside the solve kernel  estimator.cpp:1265-1287
+//   else     : V^T, Y^T leave the (chunked / streamed) solve, P+ = P - V^T Y as one tiled symmetric product
+static int finish_whitened(xivo_hip_ctx* c, const UpdatePlan& plan, int b0, int B, double* S, int lds, double* invD, double* PHT, double* K,
+                           double* G, double* P, const double* inn, int Mp, int Np, const CholGateArgs* cg) {
+  const double Nf = c->N, Mf = c->M;
+  {
+    CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
+    a.status = c->status + b0; a.batch = B; a.latency = plan.latency || plan.stream8;   // (the streamed solve reads the mirrored upper triangle)
+    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
+    if (cg) { const size_t n = strlen(clabel); snprintf(clabel + n, sizeof(clabel) - n, "+gate"); }
+    StageTimer st(c, ST_CHOL, Mf * Mf * Mf / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
+    HIP_TRY((hipError_t)launch_chol_f64(a, c->stream, cg));
+  }
+  {
+    TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
+    a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
+    a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np; a.batch = B;
+    if (plan.in_solve) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = 2; a.skip_status = c->status + b0; }
+    else { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = plan.latency; a.stream8 = plan.stream8 ? 1 : 0; a.out_f32 = plan.f32_whitened ? 1 : 0; }
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), plan.in_solve ? 4 : 5, plan.latency, plan.stream8);
+    // seven block rows on a narrow state: the ten- / twelve-wave instantiation with W in registers (solve_fused.hip)
+    const bool narrow = plan.in_solve && trsm_narrow_supported(Mp, Np);
+    if (narrow) trsm_narrow_label(Mp, Np, label, sizeof(label));
+    const double t_outs = 0.5 * Np * (Np + 1.0), t_outs_f = 0.5 * Nf * (Nf + 1.0);
+    // algorithmic flops (true N, M): the two triangular solves (M^2 N each), the residual blocks of the whitened form
+    // (2 * 16 * M * N) and, in the solve kernel, the symmetric N x N x M product (lower triangle). Algorithmic bytes: the
+    // factor, P H^T once, P's lower triangle in, P out (the gain is not stored)
+    StageTimer st(c, ST_TRSM, (2.0 * Mf * Mf * Nf + 32.0 * Mf * Nf + (plan.in_solve ? 2.0 * t_outs_f * Mf : 0.0)) * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + (plan.in_solve ? 1.0 : 3.0) * Np * Mp + (plan.in_solve ? t_outs + (double)Np * Np : 0.0)));
+    HIP_TRY((hipError_t)(narrow ? launch_trsm_narrow(a, c->stream) : launch_trsm_f64(a, c->stream)));
+    if (plan.in_solve) return XIVO_HIP_OK;
+  }
+  // P+ = P - V^T Y in place (V^T in the K buffer, Y^T in the G buffer), lower triangle + mirror
+  GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
+  x.small_tiles = plan.latency;
+  if (plan.f32_whitened) {   // XIVO_HIP_FLAG_FP32_WHITENED: both operands left the solve as float (Y^T at float 0, V^T at float Np Mp of G)
+    x.fp32 = 1; x.a_f32 = 1; x.b_f32 = 1;
+    const double* Vf = reinterpret_cast<const double*>(reinterpret_cast<const float*>(G) + (long)Np * Mp);
+    return gemm(c, ST_PNEW, B, Np, Np, Vf, 2 * c->sA, Np, G, 2 * c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
+  }
+  return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, G, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
 }
 
-// Whether a pass of the sparse pipeline takes the one-kernel route (fused_update.hip): the default Joseph evaluation on
-// row-pair compressed rows only (no OOS rows, no leading calibration block), at most 12 common and 9 private slots in use,
-// a shape one workgroup holds. XIVO_HIP_NO_FUSED_UPDATE: the five-kernel pipeline (A/B).
-static bool fused_route(const xivo_hip_ctx* c, int Mp, int Np, int nc_max, int pw_max, bool full) {
-  static const bool knobs = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") || getenv("XIVO_HIP_NO_TRSM_T") || getenv("XIVO_HIP_T_FULL");
-  const unsigned other = XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_EXPANDED_JOSEPH | XIVO_HIP_FLAG_FP32_CORR |
-                         XIVO_HIP_FLAG_FP32_COV | XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_MULTI_KERNEL;
-  return !full && !knobs && !(c->flags & other) && c->mixed_row0 < 0 && !c->lead_valid && nc_max <= 12 && pw_max <= 9 &&
-         fused_update_supported(Mp, Np);
-}
-
-static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams* gate) {
+// Sparse-H pipelines (ell.h): H P, S and T H^T skip the structural zeros of H; the factorisation, the gain and the
+// N x N x M covariance products stay on the MFMA kernels.
+//   FUSED            everything in one kernel per filter                                     fused_update.hip
+//   otherwise        HP = H P (+ P H^T)            ell_mul<HP>                               estimator.cpp:1259
+//                    S = (HP) H^T + R              ell_mul<S>                                estimator.cpp:1259-1263
+//                    [MH gating]                   in the prologue of the factorisation / gate_ell    update.cpp:60-96
+//                    then finish_whitened / finish_symmetric, or (SPARSE_TAIL)
+//                    T = K (HP) - P, G = T H^T + K R, P+ = G K^T - T                          estimator.cpp:1276-1287 re-associated
+static int update_sparse_range(xivo_hip_ctx* c, const UpdatePlan& plan, int b0, int B, const GateParams* gate) {
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
   double* P = c->P + (long)b0 * c->sP;
   double* HP = c->HP + (long)b0 * c->sH;
@@ -747,32 +760,18 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   double* invD = c->invD + (long)b0 * c->sInvD;
   double* inn = c->inn + (long)b0 * c->Mpmax;
   double* diagR = c->diagR + (long)b0 * c->Mpmax;
-  const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0;
-  const int f32 = 0;
   EllBuffers e = c->ell;
   e.idx += (long)b0 * e.stride_idx(); e.val += (long)b0 * e.stride_val(); e.nc += b0; e.pw += b0; e.over += b0;
-  int nc_max = 0;
-  for (int b = b0; b < b0 + B; ++b) nc_max = c->ell_nc_h[b] > nc_max ? c->ell_nc_h[b] : nc_max;
-  int pw_max = 1;
-  for (int b = b0; b < b0 + B; ++b) pw_max = c->ell_pw_h[b] > pw_max ? c->ell_pw_h[b] : pw_max;
+  int nc_max = 0, pw_max = 1;
+  for (int b = b0; b < b0 + B; ++b) { nc_max = std::max(nc_max, c->ell_nc_h[b]); pw_max = std::max(pw_max, c->ell_pw_h[b]); }
   // algorithmic flops are counted on the TRUE sizes N, M (the padded Np, Mp only size the launches and the bytes)
   const double Nf = c->N, Mf = c->M;
   const double nnz_flops = 2.0 * Mf * 21.0;   // per contiguous-index value: 21 structural non-zeros per row
   int rc;
-  // mixed stacking: rows [0, mr0) of H are the compressed in-state rows, rows [mr0, M) the dense OOS rows appended by
-  // xivo_hip_oos_project (non-zero over the extrinsics + group columns only: src/oos.cpp:74-88). The in-state rows keep the
-  // sparse walk below; the OOS block goes through two small MFMA products (rows padded to 16 from mr0 on).
-  const int mr0 = c->mixed_row0;
-  const int Mp_ell = mr0 >= 0 ? round_up16(mr0) : Mp;
-  const int oos_pad = mr0 >= 0 ? round_up16(Mp - mr0) : 0;
-  // the OOS rows are zero beyond the extrinsics and group columns (the mode clears and writes nothing else there): the two
-  // products of the OOS block contract over the leading oos_k state columns only
-  bool walk_tiled = false;
-  const int oos_k = (mr0 >= 0 && c->have_layout) ? std::min(Np, round_up16(c->lay.group_begin + 6 * c->lay.n_groups)) : Np;
-  // Round 6: the shapes a CU holds (TUM-VI 203 / 60, BASELINE config 2 150 / 100) take ONE kernel for the whole update -
-  // P H^T, S, the gate, the factor, both substitutions and the covariance product stay in the registers and the LDS of the
-  // workgroup that owns the filter (fused_update.hip); nothing but P, P+ and the compressed rows crosses HBM.
-  if (fused_route(c, Mp, Np, nc_max, pw_max, full)) {
+  if (plan.route == ROUTE_FUSED) {
+    // Round 6: the shapes a CU holds (TUM-VI 203 / 60, BASELINE config 2 150 / 100) take ONE kernel for the whole update -
+    // P H^T, S, the gate, the factor, both substitutions and the covariance product stay in the registers and the LDS of the
+    // workgroup that owns the filter; nothing but P, P+ and the compressed rows crosses HBM.
     FusedArgs a{};
     a.P = P; a.strideP = c->sP; a.ldp = Np; a.ell = e; a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
     a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.status = c->status + b0;
@@ -790,6 +789,16 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     HIP_TRY((hipError_t)launch_fused_update(a, c->stream));
     return XIVO_HIP_OK;
   }
+  // mixed stacking: rows [0, mr0) of H are the compressed in-state rows, rows [mr0, M) the dense OOS rows appended by
+  // xivo_hip_oos_project (non-zero over the extrinsics + group columns only: src/oos.cpp:74-88). The in-state rows keep the
+  // sparse walk below; the OOS block goes through two small MFMA products (rows padded to 16 from mr0 on).
+  const int mr0 = c->mixed_row0;
+  const int Mp_ell = mr0 >= 0 ? round_up16(mr0) : Mp;
+  const int oos_pad = mr0 >= 0 ? round_up16(Mp - mr0) : 0;
+  // the OOS rows are zero beyond the extrinsics and group columns (the mode clears and writes nothing else there): the two
+  // products of the OOS block contract over the leading oos_k state columns only
+  bool walk_tiled = false;
+  const int oos_k = (mr0 >= 0 && c->have_layout) ? std::min(Np, round_up16(c->lay.group_begin + 6 * c->lay.n_groups)) : Np;
   {
     EllMulArgs a{}; a.ell = e; a.Src = P; a.strideSrc = c->sP; a.ldsrc = Np; a.out = PHT; a.strideOut = c->sK; a.ldo = Np;
     a.out2 = HP; a.strideOut2 = c->sH; a.ldo2 = ldh; a.X = Np; a.Mp = Mp_ell; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
@@ -806,7 +815,7 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   }
   // online-calibration stacking on the sparse pipeline: the calibration columns of H live in the leading dense block
   // L [Mp x LEAD_K] (stack_kernel): P H^T += P[:, 0:LEAD_K] L^T on the MFMA product
-  const bool lead = c->lead_valid && mr0 < 0 && !getenv("XIVO_HIP_DEBUG_SKIP_LEAD");
+  const bool lead = c->lead_valid && mr0 < 0;
   const double* Ld = lead ? c->Hlead + (long)b0 * c->Mpmax * LEAD_K : nullptr;
   const long sLd = (long)c->Mpmax * LEAD_K;
   const int ldl = c->Mpmax;   // (stack_kernel lays the block out on the allocated row count)
@@ -830,18 +839,13 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     ga.S = S; ga.strideS = c->sS; ga.lds = lds; ga.Mp = Mp; ga.from_S = 1;   // distances from the diagonal blocks of S
     ga.R = gate->R; ga.thresh = gate->thresh; ga.mult = gate->mult; ga.min_inliers = gate->min_inliers;
   }
-  int gate_done = 0, diag_done = 0;
+  int diag_done = 0;
   {
     EllMulArgs a{}; a.ell = e; a.Src = PHT; a.strideSrc = c->sK; a.ldsrc = Np; a.SrcAlt = HP; a.strideSrcAlt = c->sH; a.ldsrcAlt = ldh;
     a.out = S; a.strideOut = c->sS; a.ldo = lds; a.cols = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.X = Mp; a.Mp = Mp_ell; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max;
-    // A/B knob (measured slower, off by default): the gate in the tail of the S kernel - S + gate 2.88 ms fused vs 2.30 + 0.36
-    // as two kernels per 16384 filters: the tail runs at one 8-wave workgroup per CU where the stand-alone gate fills the chip
-    static const bool fuse = getenv("XIVO_HIP_GATE_IN_S") != nullptr;
-    if (gate && fuse && !lead) { a.gate = ga; a.gate_here = 1; a.gate_done = &gate_done; }
     // the 2 x 2 diagonal blocks of S once more, compact (the T buffer is free until the solve): what the gate reads
-    static const bool no_sdiag = getenv("XIVO_HIP_NO_SDIAG") != nullptr;   // A/B knob: the gate reads them off S
-    if (gate && !fuse && !no_sdiag && mr0 < 0 && !lead && (long)2 * Mp <= c->sP) { a.diag_out = c->T + (long)b0 * c->sP; a.strideDiag = c->sP; a.diag_done = &diag_done; }
+    if (gate && mr0 < 0 && !lead && (long)2 * Mp <= c->sP) { a.diag_out = c->T + (long)b0 * c->sP; a.strideDiag = c->sP; a.diag_done = &diag_done; }
     char label[64]; ell_kernel_label(ELL_S, a, label, sizeof(label));
     StageTimer st(c, ST_S, nnz_flops * Mf * B, label, 8.0 * B * ((double)Np * Mp + (double)Mp * Mp));
     HIP_TRY((hipError_t)launch_ell_mul(ELL_S, a, c->stream));
@@ -861,22 +865,15 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     rc = gemm(c, ST_S, B, Mp, Mp, HP, c->sH, ldh, Ld, sLd, ldl, LEAD_K, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, S, c->sS, lds, x);
     if (rc) return rc;
   }
-  if (getenv("XIVO_HIP_DUMP_DIR")) {
-    dump_dev(c, "S", S, (size_t)c->sS); dump_dev(c, "PHT", PHT, (size_t)c->sK); dump_dev(c, "HP", HP, (size_t)c->sH);
-    dump_dev(c, "P", P, (size_t)c->sP); if (lead) dump_dev(c, "Hlead", Ld, (size_t)sLd);
-  }
-  const bool lat = latency_route(c, Mp, B, full);
-  const bool t_full = full || getenv("XIVO_HIP_T_FULL");
-  const int chol_variant = chol_pick(c, S, Mp, lds, B);
   if (gate) c->gate_sparse_last = 0;
-  // Round 5: with thousands of factors the gate rides in the prologue of the factorisation (chol_f64.hip, GATE): the
-  // distances come from the compact diagonal blocks ell<S> just left, the rejected pairs are decoupled where the factor
-  // loads S - no gate launch, no extra pass over S. (Few filters, dense copies of H alive, mixed stacking: the gate kernel.)
+  // With thousands of factors the gate rides in the prologue of the factorisation (chol_f64.hip, GATE): the distances come
+  // from the compact diagonal blocks ell<S> just left, the rejected pairs are decoupled where the factor loads S - no gate
+  // launch, no extra pass over S. (Few filters, dense copies of H alive, mixed stacking: the gate kernel.)
   CholGateArgs cg{};
   bool gate_folded = false;
-  if (gate && !gate_done) {
+  if (gate) {
     if (diag_done) { ga.Sdiag = c->T + (long)b0 * c->sP; ga.strideSdiag = c->sP; }
-    gate_folded = diag_done && !c->dense_valid && mr0 < 0 && !lat && chol_gate_supported(Mp, B, chol_variant);
+    gate_folded = diag_done && !c->dense_valid && mr0 < 0 && !plan.latency && chol_gate_supported(Mp, B);
     if (gate_folded) {
       cg.Sdiag = ga.Sdiag; cg.strideSdiag = ga.strideSdiag; cg.inn = inn; cg.strideInn = c->Mpmax; cg.diagR = diagR; cg.strideR = c->Mpmax;
       cg.ellval = e.val; cg.strideVal = e.stride_val(); cg.ell_w = ELL_W; cg.PHT = PHT; cg.stridePHT = c->sK; cg.ldpht = Np; cg.Np = Np;
@@ -887,96 +884,44 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
       HIP_TRY((hipError_t)launch_gate_ell(ga, c->stream));
     }
   }
-  // Round 5, opt-in (XIVO_HIP_FUSED_CHOL=1; measured slower, see solve_fused.hip): where the solve kernel carries the whole
-  // whitened Joseph update (one 16-wave workgroup per filter) it can also factor S itself - in LDS, under the latency of its
-  // right-hand-side loads (chol_device.h routines, the same bits as the stand-alone kernels): no Cholesky launch, L and
-  // inv(L_kk) never cross HBM.
-  static const bool no_joseph_k = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
-  const bool fuse_chol = !(c->flags & (XIVO_HIP_FLAG_SYMMETRIC_FORM | XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_EXPANDED_JOSEPH)) &&
-                         !t_full && !lat && trsm_forms_T(Mp, Np) && !no_joseph_k && mr0 < 0 && !gate_folded && trsm_chol_fused_supported(Mp, Np);
-  if (!fuse_chol) {
+  if (plan.route != ROUTE_SPARSE_TAIL && plan.route != ROUTE_SPARSE_SYMMETRIC)
+    return finish_whitened(c, plan, b0, B, S, lds, invD, PHT, K, G, P, inn, Mp, Np, gate_folded ? &cg : nullptr);
+  {
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B; a.variant = chol_variant; a.latency = lat || stream8_shape(Mp, Np);   // (the streamed solve reads the mirrored upper triangle)
-    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
+    a.status = c->status + b0; a.batch = B; a.latency = 0;
+    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
     if (gate_folded) { const size_t n = strlen(clabel); snprintf(clabel + n, sizeof(clabel) - n, "+gate"); }
     StageTimer st(c, ST_CHOL, Mf * Mf * Mf / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream, gate_folded ? &cg : nullptr));
   }
-  if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
-  bool t_done = false, wh_out = false, wh_f32 = false;
+  if (plan.route == ROUTE_SPARSE_SYMMETRIC) return finish_symmetric(c, plan, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np);
+  // ---- SPARSE_TAIL (XIVO_HIP_FLAG_STANDALONE_TAIL): K^T = S^-1 (HP), dx; T = K (HP) - P; G = T H^T + K R; P+ = G K^T - T
+  const bool t_here = trsm_forms_T(Mp, Np);      // the solve forms T on the gain still in its registers
   {
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
-    a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
-    a.batch = B;
-    // the solve goes on to the whole covariance update in place with the gain still in its registers (expanded Joseph
-    // form; T and G never exist in memory) - or, with XIVO_HIP_NO_JOSEPH_IN_SOLVE, to T = K (HP) - P only
-    const bool t_here = !t_full && !lat && trsm_forms_T(Mp, Np);
-    static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;   // A/B knob
-    const bool all_here = t_here && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);   // (both precision modes: all fp64 and faster than the fp32 correction product)
-    const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;   // 2: whitened form (default), 1: P - K(2HP - L L^T K^T)
-    // shapes one workgroup does not hold (N > 256 or M > 176): the same whitened evaluation with the product outside the
-    // solve kernel - V^T = (W - D)^T and Y^T = (W + D)^T leave the (chunked / streamed) solve, P+ = P - V^T Y is one tiled
-    // symmetric product. Replaces T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T (two products and a pass over T) there.
-    static const bool no_trsm_t = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: the round-1 stand-alone tail for every shape
-    wh_out = !t_here && !t_full && jform == 2 && !no_joseph && !no_trsm_t &&
-             !(c->flags & (XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_FP32_CORR));
-    if (wh_out) { a.Yout = G; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; a.stream8 = (!lat && stream8_shape(Mp, Np)) ? 1 : 0;
-      // XIVO_HIP_FLAG_FP32_WHITENED only where the SHAPE puts the product outside the solve kernel (N > 256 or M > 176): a
-      // few-filter call of a shape the in-solve update holds takes this branch through the latency route and stays all fp64
-      a.out_f32 = ((c->flags & XIVO_HIP_FLAG_FP32_WHITENED) && !trsm_forms_T(Mp, Np)) ? 1 : 0; }
-    wh_f32 = wh_out && a.out_f32;
-    if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
-    else if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
-    t_done = t_here;
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (t_here ? 1 : (wh_out ? 5 : 0)), lat, a.stream8 != 0);
-    if (fuse_chol) { a.chol_status = c->status + b0; trsm_chol_fused_label(Mp, label, sizeof(label)); }
-    // short factor on a narrow state (BASELINE config 2): ten-wave workgroups, two per CU (solve_fused.hip)
-    const bool narrow = !fuse_chol && all_here && jform == 2 && trsm_narrow_supported(Mp, Np);
-    if (narrow) trsm_narrow_label(Mp, Np, label, sizeof(label));
+    a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np; a.batch = B;
+    if (t_here) { a.T = T; a.strideT = c->sP; a.ldt = Np; a.Pm = P; a.stridePm = c->sP; a.ldpm = Np; }
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), t_here ? 1 : 0);
     const double t_outs = 0.5 * Np * (Np + 1.0), t_outs_f = 0.5 * Nf * (Nf + 1.0);
-    // algorithmic flops (true N, M): the two triangular solves (M^2 N each), the symmetric N x N x M product (lower
-    // triangle), and for the expanded form the two triangular products of K L L^T; the whitened form's residual blocks
-    // are 2 * 16 * M * N. Algorithmic bytes: the factor, P H^T once, P's lower triangle in, P out (the gain is not stored)
-    // (fused: + the M^3 / 3 flops of the factorisation; its bytes are S's lower triangle, which the factor's were)
-    StageTimer st(c, ST_TRSM, (2.0 * Mf * Mf * Nf + (t_here ? 2.0 * t_outs_f * Mf : 0.0) + (fuse_chol ? Mf * Mf * Mf / 3.0 : 0.0) +
-                               (all_here ? (jform == 2 ? 32.0 * Mf * Nf : 2.0 * Mf * Mf * Nf) : 0.0)) * B, label,
-                  8.0 * B * (0.5 * Mp * (Mp + 1) + (fuse_chol ? 0.0 : Mp / 16 * 512.0) + (all_here && jform == 2 ? 1.0 : 2.0) * Np * Mp +
-                             (t_here ? t_outs + (double)Np * Np : 0.0)));
-    HIP_TRY((hipError_t)(fuse_chol ? launch_trsm_chol_fused(a, c->stream) : (narrow ? launch_trsm_narrow(a, c->stream) : launch_trsm_f64(a, c->stream))));
-    if (all_here) return XIVO_HIP_OK;
+    StageTimer st(c, ST_TRSM, (2.0 * Mf * Mf * Nf + (t_here ? 2.0 * t_outs_f * Mf : 0.0)) * B, label,
+                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (t_here ? t_outs + (double)Np * Np : 0.0)));
+    HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
   }
-  if (wh_out) {   // P+ = P - V^T Y in place (V^T in the K buffer, Y^T in the G buffer), lower triangle + mirror
-    GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
-    x.small_tiles = lat;
-    if (wh_f32) {   // XIVO_HIP_FLAG_FP32_WHITENED: both operands left the solve as float (Y^T at float 0, V^T at float Np Mp of G)
-      x.fp32 = 1; x.a_f32 = 1; x.b_f32 = 1;
-      const double* Vf = reinterpret_cast<const double*>(reinterpret_cast<const float*>(G) + (long)Np * Mp);
-      return gemm(c, ST_PNEW, B, Np, Np, Vf, 2 * c->sA, Np, G, 2 * c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
-    }
-    return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, G, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
-  }
-  if (!t_done) {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
-     // triangle is computed and mirrored (XIVO_HIP_FLAG_FULL_PNEW: all of it)
-    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.fp32 = f32;
-    x.lower_only = t_full ? 0 : 1;
-    rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-              T, c->sP, Np, x);
+  if (!t_here) {  // T = K (HP) - P = (HP)^T S^-1 (HP) - P: symmetric up to the rounding of the solve, so the lower
+                  // triangle is computed and mirrored
+    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1;
+    rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, T, c->sP, Np, x);
     if (rc) return rc;
   }
-  bool g_f32 = false;
   {  // G = T H^T + K diag(R)   [Np x Mp, in the A buffer]
     EllMulArgs a{}; a.ell = e; a.Src = T; a.strideSrc = c->sP; a.ldsrc = Np; a.out = G; a.strideOut = c->sA; a.ldo = Np;
     a.diagR = diagR; a.strideR = c->Mpmax; a.K = K; a.strideK = c->sK; a.ldk = Np; a.X = Np; a.Mp = Mp; a.batch = B; a.nc_max = nc_max; a.pw_max = pw_max; a.cols = Np;
-    // G only ever feeds the fp32 correction product: keep it in HBM as float (slab form only)
-    g_f32 = (c->flags & XIVO_HIP_FLAG_FP32_CORR) && ell_uses_slab_form(a);
-    if (g_f32) a.strideOut = 2 * c->sA;
-    const int gmode = g_f32 ? ELL_GF : ELL_G;
-    char label[64]; ell_kernel_label(gmode, a, label, sizeof(label));
-    StageTimer st(c, ST_KH, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + (g_f32 ? 1.5 : 2.0) * Np * Mp));
-    HIP_TRY((hipError_t)launch_ell_mul(gmode, a, c->stream));
+    char label[64]; ell_kernel_label(ELL_G, a, label, sizeof(label));
+    StageTimer st(c, ST_KH, nnz_flops * Np * B, label, 8.0 * B * ((double)Np * Np + 2.0 * Np * Mp));
+    HIP_TRY((hipError_t)launch_ell_mul(ELL_G, a, c->stream));
   }
-  if (!g_f32 && !full && pnew_reg_supported(Mp, Np)) {
+  if (pnew_reg_supported(Mp, Np)) {
     // P+ = G K^T - T, all fp64: rows of G in registers, blocks of K through LDS, one workgroup per filter
     PnewRegArgs a{}; a.G = G; a.strideG = c->sA; a.ldg = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.T = T; a.strideT = c->sP; a.ldt = Np; a.P = P; a.strideP = c->sP; a.ldp = Np;
@@ -985,16 +930,12 @@ static int update_sparse_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
     const double outs = 0.5 * Np * (Np + 1.0);
     StageTimer st(c, ST_PNEW, 2.0 * outs * Mp * B, label, 8.0 * B * (2.0 * Np * Mp + outs + (double)Np * Np));
     HIP_TRY((hipError_t)launch_pnew_reg_f64(a, c->stream));
-    rc = XIVO_HIP_OK;
-  } else {  // P+ = G K^T - T   (lower triangle + mirror)
-    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
-    x.fp32 = (c->flags & XIVO_HIP_FLAG_FP32_CORR) ? 1 : 0;   // opt-in: correction product on the fp32 MFMA, T added in fp64
-    x.a_f32 = g_f32 ? 1 : 0;
-    x.skip = c->status + b0;   // S not positive definite: P of that filter stays the prior (reported through xivo_hip_get_status)
-    rc = gemm(c, ST_PNEW, B, Np, Np, G, g_f32 ? 2 * c->sA : c->sA, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-              P, c->sP, Np, x);
+    return XIVO_HIP_OK;
   }
-  return rc;
+  // P+ = G K^T - T   (lower triangle + mirror)
+  GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1;
+  x.skip = c->status + b0;   // S not positive definite: P of that filter stays the prior (reported through xivo_hip_get_status)
+  return gemm(c, ST_PNEW, B, Np, Np, G, c->sA, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
 }
 
 static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GateParams* gate);
@@ -1031,27 +972,12 @@ static int update_joseph_range(xivo_hip_ctx* c, int b0, int B, const GateParams*
   return XIVO_HIP_OK;
 }
 
-// Whether update_sparse_range would finish with the stand-alone tail (T = K(HP) - P, G = T H^T + K R, P+ = G K^T - T) for
-// these shapes, flags and knobs - i.e. neither the in-solve covariance update nor the whitened outputs + tiled product nor
-// the symmetric form applies. The tail's G walks the row-pair compressed rows of ALL of H; with mixed stacking (in-state
-// rows compressed, OOS rows dense) those hold the in-state rows only, so such a call must not take the sparse route.
-// (Mirrors the decisions inside update_sparse_range; keep the two in step.)
-static bool sparse_route_ends_in_standalone_tail(const xivo_hip_ctx* c, int Mp, int Np, int B) {
-  if (c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) return false;
-  static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr, no_trsm_t = getenv("XIVO_HIP_NO_TRSM_T") != nullptr,
-                    t_full_env = getenv("XIVO_HIP_T_FULL") != nullptr;
-  const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0, t_full = full || t_full_env;
-  const bool lat = latency_route(c, Mp, B, full);
-  const bool t_here = !t_full && !lat && trsm_forms_T(Mp, Np);
-  const bool all_here = t_here && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);
-  const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
-  const bool wh_out = !t_here && !t_full && jform == 2 && !no_joseph && !no_trsm_t &&
-                      !(c->flags & (XIVO_HIP_FLAG_STANDALONE_TAIL | XIVO_HIP_FLAG_FP32_CORR));
-  return !all_here && !wh_out;
-}
-
 static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GateParams* gate) {
   const int Np = c->Np, Mp = c->Mp, ldh = c->Mpmax, lds = c->Mpmax;
+  const UpdatePlan plan = plan_update(c, b0, B, gate != nullptr);
+  c->last_path = plan.sparse ? 1 : 0;
+  c->last_route = plan.route;
+  if (plan.sparse) return update_sparse_range(c, plan, b0, B, gate);
   const double* H = c->H + (long)b0 * c->sH;
   const double* HT = c->HT + (long)b0 * c->sHT;
   double* P = c->P + (long)b0 * c->sP;
@@ -1064,20 +990,7 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
   double* invD = c->invD + (long)b0 * c->sInvD;
   const double* inn = c->inn + (long)b0 * c->Mpmax;
   const double* diagR = c->diagR + (long)b0 * c->Mpmax;
-  int rc;
-  const bool full = (c->flags & XIVO_HIP_FLAG_FULL_PNEW) != 0;
-  const int f32 = (c->flags & XIVO_HIP_FLAG_FP32_COV) ? 1 : 0;
-  // the fp32 covariance mode (config 4) is defined on the as-coded products: dense path
-  bool sparse = !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV));
-  for (int b = b0; sparse && b < b0 + B; ++b) sparse = c->ell_over_h[b] == 0;
-  // mixed stacking + a flag / knob that routes to the stand-alone tail: every row dense, dense pipeline (ensure_dense below
-  // rebuilds the in-state rows from their compressed form next to the OOS rows already in place)
-  if (sparse && c->mixed_row0 >= 0 && sparse_route_ends_in_standalone_tail(c, Mp, Np, B)) sparse = false;
-  // (the same for the leading dense block of an online-calibration stacking: the tail's G = T H^T walks compressed rows only)
-  if (sparse && c->lead_valid && (gate || sparse_route_ends_in_standalone_tail(c, Mp, Np, B))) sparse = false;
-  c->last_path = sparse ? 1 : 0;
-  if (sparse) return update_sparse_range(c, b0, B, gate);
-  rc = ensure_dense(c);
+  int rc = ensure_dense(c);   // (mixed stacking / a leading block: the in-state rows are rebuilt densely next to the rows already in place)
   if (rc) return rc;
   {  // HP = H * P and its transpose PH^T (estimator.cpp:1259 first product; P symmetric => B operand = P rows)
     GemmExtra x; x.C2 = PHT; x.sC2 = c->sK; x.ldc2 = Np;
@@ -1102,95 +1015,48 @@ static int update_joseph_range_impl(xivo_hip_ctx* c, int b0, int B, const GatePa
     HIP_TRY((hipError_t)launch_gate_dense(a, c->stream));
   }
   {  // S = HP * H^T + diag(R)  (estimator.cpp:1259-1263); lower triangle + mirror
-    GemmExtra x; x.epi = EPI_ADD_DIAG; x.diag = diagR; x.sDiag = c->Mpmax; x.lower_only = full ? 0 : 1;
+    GemmExtra x; x.epi = EPI_ADD_DIAG; x.diag = diagR; x.sDiag = c->Mpmax; x.lower_only = 1;
     rc = gemm(c, ST_S, B, Mp, Mp, HP, c->sH, ldh, H, c->sH, ldh, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               S, c->sS, lds, x);
     if (rc) return rc;
   }
-  const bool lat = (c->flags & XIVO_HIP_FLAG_REASSOC) && latency_route(c, Mp, B, full);
+  if (plan.route == ROUTE_DENSE_WHITENED)      // an H without XIVO's row structure: everything behind S as on the sparse pipeline
+    return finish_whitened(c, plan, b0, B, S, lds, invD, PHT, K, c->A + (long)b0 * c->sA, P, inn, Mp, Np, nullptr);
   {  // S = L L^T
     CholArgs a{}; a.S = S; a.strideS = c->sS; a.lds = lds; a.Mp = Mp; a.invD = invD; a.strideInvD = c->sInvD;
-    a.status = c->status + b0; a.batch = B; a.variant = chol_pick(c, S, Mp, lds, B); a.latency = lat || stream8_shape(Mp, Np);
-    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel), a.variant);
+    a.status = c->status + b0; a.batch = B; a.latency = 0;
+    char clabel[64]; chol_kernel_label(Mp, B, clabel, sizeof(clabel));
     StageTimer st(c, ST_CHOL, (double)Mp * Mp * Mp / 3.0 * B, clabel, 8.0 * B * ((double)Mp * (Mp + 1) + Mp / 16 * 512.0));
     HIP_TRY((hipError_t)launch_chol_f64(a, c->stream));
   }
-  if ((c->flags & XIVO_HIP_FLAG_SYMMETRIC_FORM) && !f32) return finish_symmetric(c, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np, full);
-  bool wh_out = false, wh_f32 = false;
+  if (plan.route == ROUTE_DENSE_SYMMETRIC) return finish_symmetric(c, plan, b0, B, S, lds, invD, PHT, K, P, inn, Mp, Np);
+  // ---- DENSE_ASCODED (XIVO_HIP_FLAG_DENSE_H): the products of estimator.cpp:1265-1287 as they are written
   {  // K^T = S^-1 HP ; dx = K inn  (estimator.cpp:1265-1267)
     TrsmArgs a{}; a.LU = S; a.strideLU = c->sS; a.ldlu = lds; a.invD = invD; a.strideInvD = c->sInvD;
     a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.K = K; a.strideK = c->sK; a.ldk = Np;
     a.inn = inn; a.strideInn = c->Mpmax; a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.Mp = Mp; a.Np = Np;
     a.batch = B;
-    // re-associated pipeline: the whole covariance update inside the solve kernel, as in the sparse pipeline (it
-    // needs the factor, P H^T and P only - nothing of H's structure)
-    static const bool no_joseph = getenv("XIVO_HIP_NO_JOSEPH_IN_SOLVE") != nullptr;
-    const bool all_here = (c->flags & XIVO_HIP_FLAG_REASSOC) && !f32 && !full && !no_joseph && !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL) && !lat && trsm_forms_T(Mp, Np);
-    const int jform = (c->flags & XIVO_HIP_FLAG_EXPANDED_JOSEPH) ? 1 : 2;
-    wh_out = (c->flags & XIVO_HIP_FLAG_REASSOC) && !all_here && !f32 && !full && !no_joseph && jform == 2 &&
-             !(c->flags & XIVO_HIP_FLAG_STANDALONE_TAIL);
-    if (wh_out) { a.Yout = c->A + (long)b0 * c->sA; a.strideY2 = c->sA; a.ldy2 = Np; a.latency = lat; a.stream8 = (!lat && stream8_shape(Mp, Np)) ? 1 : 0;
-      // XIVO_HIP_FLAG_FP32_WHITENED only where the SHAPE puts the product outside the solve kernel (N > 256 or M > 176): a
-      // few-filter call of a shape the in-solve update holds takes this branch through the latency route and stays all fp64
-      a.out_f32 = ((c->flags & XIVO_HIP_FLAG_FP32_WHITENED) && !trsm_forms_T(Mp, Np)) ? 1 : 0; }
-    wh_f32 = wh_out && a.out_f32;
-    if (all_here) { a.T = P; a.strideT = c->sP; a.ldt = Np; a.joseph = jform; a.skip_status = c->status + b0; }
-    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), all_here ? (jform == 2 ? 4 : 3) : (wh_out ? 5 : 0), lat, a.stream8 != 0);
-    const double t_outs = 0.5 * Np * (Np + 1.0);
-    StageTimer st(c, ST_TRSM, (2.0 * Mp * Mp * Np + (all_here ? 2.0 * t_outs * Mp + (jform == 2 ? 32.0 * Mp * Np : 2.0 * Mp * Mp * Np) : 0.0)) * B, label,
-                  8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp + (all_here ? t_outs + (double)Np * Np : 0.0)));
+    char label[64]; trsm_kernel_label(Mp, label, sizeof(label), 0);
+    StageTimer st(c, ST_TRSM, 2.0 * Mp * Mp * Np * B, label, 8.0 * B * (0.5 * Mp * (Mp + 1) + Mp / 16 * 512.0 + 2.0 * Np * Mp));
     HIP_TRY((hipError_t)launch_trsm_f64(a, c->stream));
-    if (all_here) return XIVO_HIP_OK;
-  }
-  if (wh_out) {   // P+ = P - V^T Y in place, as in the sparse pipeline
-    GemmExtra x; x.epi = EPI_RSUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = 1; x.skip = c->status + b0;
-    x.small_tiles = lat;
-    if (wh_f32) {
-      x.fp32 = 1; x.a_f32 = 1; x.b_f32 = 1;
-      const double* Gb = c->A + (long)b0 * c->sA;
-      const double* Vf = reinterpret_cast<const double*>(reinterpret_cast<const float*>(Gb) + (long)Np * Mp);
-      return gemm(c, ST_PNEW, B, Np, Np, Vf, 2 * c->sA, Np, Gb, 2 * c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
-    }
-    return gemm(c, ST_PNEW, B, Np, Np, K, c->sK, Np, c->A + (long)b0 * c->sA, c->sA, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0, P, c->sP, Np, x);
-  }
-  if (c->flags & XIVO_HIP_FLAG_REASSOC) {
-    {  // T = K (HP) - P
-      GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np;
-      rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-                T, c->sP, Np, x);
-      if (rc) return rc;
-    }
-    {  // G = T H^T + K diag(R)   [Np x Mp, kept in the (unused) A buffer]
-      GemmExtra x; x.epi = EPI_ADD_MAT; x.msub = K; x.sMsub = c->sK; x.ldmsub = Np; x.mcol = diagR; x.sMcol = c->Mpmax;
-      rc = gemm(c, ST_KH, B, Np, Mp, T, c->sP, Np, H, c->sH, ldh, Np, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-                A, c->sP, Np, x);
-      if (rc) return rc;
-    }
-    {  // P+ = G K^T - T   (lower triangle + mirror)
-      GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = T; x.sMsub = c->sP; x.ldmsub = Np; x.lower_only = full ? 0 : 1;
-      x.skip = c->status + b0;
-      rc = gemm(c, ST_PNEW, B, Np, Np, A, c->sP, Np, K, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
-                P, c->sP, Np, x);
-    }
-    return rc;
   }
   rc = ensure_HT(c);
   if (rc) return rc;
   {  // A = K * H - I  (estimator.cpp:1276-1279)
-    GemmExtra x; x.epi = EPI_SUB_IDENT; x.fp32 = f32;
+    GemmExtra x; x.epi = EPI_SUB_IDENT;
     rc = gemm(c, ST_KH, B, Np, Np, K, c->sK, Np, HT, c->sHT, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               A, c->sP, Np, x);
     if (rc) return rc;
   }
   {  // T = A * P = K * (HP) - P  (estimator.cpp:1280, left product; distributes over the already
      // formed HP, 2MN^2 instead of 2N^3 flops, same value up to rounding)
-    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np; x.fp32 = f32;
+    GemmExtra x; x.epi = EPI_SUB_MAT; x.msub = P; x.sMsub = c->sP; x.ldmsub = Np;
     rc = gemm(c, ST_AP, B, Np, Np, K, c->sK, Np, PHT, c->sK, Np, Mp, nullptr, 0, 0, nullptr, 0, 0, 0, nullptr, 0,
               T, c->sP, Np, x);
     if (rc) return rc;
   }
   {  // P = T * A^T + K diag(R) K^T  (estimator.cpp:1280-1287, fused; lower triangle + mirror)
-    GemmExtra x; x.lower_only = full ? 0 : 1; x.fp32 = f32;
+    GemmExtra x; x.lower_only = 1;
     x.skip = c->status + b0;
     rc = gemm(c, ST_PNEW, B, Np, Np, T, c->sP, Np, A, c->sP, Np, Np, K, c->sK, Np, K, c->sK, Np, Mp, diagR,
               c->Mpmax, P, c->sP, Np, x);
@@ -1238,6 +1104,8 @@ int xivo_hip_update_dense_gated(xivo_hip_ctx* c, int B, int F, double R, double 
 }
 
 int xivo_hip_last_path(xivo_hip_ctx* c) { return c ? c->last_path : -1; }
+int xivo_hip_last_route(xivo_hip_ctx* c) { return c ? c->last_route : -1; }
+const char* xivo_hip_route_name(int route) { return route >= 0 && route < ROUTE_COUNT ? kRouteNames[route] : ""; }
 
 double xivo_hip_stage_bytes(xivo_hip_ctx* c, int stage) {
   return (c && stage >= 0 && stage < ST_COUNT) ? c->stage_bytes[stage] : 0.0;
@@ -1397,8 +1265,7 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* c, int b, int M, const double* H, 
   // the row-pair compressed rows, built while H_ is staged; an H_ that does not fit them (dense rows, stacked OOS rows) or a
   // context pinned to the dense / fp32 pipelines takes the general entry points - same results, more crossings
   int nc = 0, pw = 0, over = 1;
-  static const bool no_compress = getenv("XIVO_HIP_NO_COMPRESS") != nullptr;
-  const bool want_ell = !no_compress && !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) && meas_compress_fits(c->Mpmax, Np);
+  const bool want_ell = !(c->flags & XIVO_HIP_FLAG_DENSE_H) && meas_compress_fits(c->Mpmax, Np);
   if (want_ell)
     over = host_compress(c->hc, H, ldh, M, N, pairs_clear, reinterpret_cast<int*>(c->pin_h + o_idx),
                          reinterpret_cast<double*>(c->pin_h + o_val), &nc, &pw);
@@ -1699,9 +1566,8 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
                      unsigned char* mask_out, double* dist_out) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (!c || !c->have_layout || B <= 0 || B > c->Bmax || c->F <= 0) return XIVO_HIP_ERR_INVALID;
-  // (online-calibration builds: the compact 21-column gate would ignore the td / Cg / bg / intrinsics blocks)
   // (online-calibration builds: the compact gate works on the whole row too - 43 columns, gate_sparse_kernel's wide form;
-  //  XIVO_HIP_CALIB_DENSE: the dense-row gate of round 4)
+  //  with XIVO_HIP_FLAG_DENSE_H the dense-row gate of round 4)
   int rc = (c->calib_on && !calib_sparse(c)) ? calib_gate(c, B, R, mh_thresh, mh_mult, min_inliers, 1)
                                              : gate_impl(c, B, R, mh_thresh, mh_mult, min_inliers, 1);
   if (rc) return rc;
@@ -1717,8 +1583,7 @@ int xivo_hip_mh_gate(xivo_hip_ctx* c, int B, double R, double mh_thresh, double 
 static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigned char* mask_override = nullptr, int full_rows = 0) {
   StackArgs a{};
   a.sb = scene_buffers(c); a.lay = c->lay; a.mb = meas_buffers(c);
-  if (skip_HT(c)) { a.mb.HT = nullptr; if (write_dense) c->ht_valid = false; }
-  else if (write_dense) c->ht_valid = true;
+  if (write_dense) c->ht_valid = true;
   if (mask_override) a.sb.mask = mask_override;
   a.Mp = c->Mpmax; a.Np = c->Np; a.batch = B; a.R = R;
   a.fix_group_block = (full_rows || (c->flags & XIVO_HIP_FLAG_FIX_GROUP_BLOCK)) ? 1 : 0;
@@ -1731,8 +1596,7 @@ static int stack_impl(xivo_hip_ctx* c, int B, double R, int write_dense, unsigne
   return launch_stack(a, c->stream) ? XIVO_HIP_ERR_HIP : XIVO_HIP_OK;
 }
 
-// the transposed dense copy: every G-level producer may have skipped it (skip_HT decides when H is PRODUCED, on the flags
-// of that moment); a consumer that needs it - the dense-row gate, the as-coded K H - I - rebuilds it from H here
+// the transposed dense copy: a G-level producer may have skipped it (mixed stacking); a consumer that needs it - the dense-row gate, the as-coded K H - I - rebuilds it from H here
 static int ensure_HT(xivo_hip_ctx* c) {
   if (c->ht_valid) return XIVO_HIP_OK;
   StageTimer st(c, ST_STACK, 0.0, "transpose_H_kernel");
@@ -1776,7 +1640,7 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
   }
   c->lead_valid = csp;
   // the sparse-H pipeline reads only the compressed rows: skip the 2 x Mp x Np dense zero-fill + scatter
-  const int dense = ((c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) || (c->calib_on && !csp)) ? 1 : 0;
+  const int dense = ((c->flags & XIVO_HIP_FLAG_DENSE_H) || (c->calib_on && !csp)) ? 1 : 0;
   c->dense_valid = dense != 0; c->dense_from_ell = false; c->stack_R = R; c->stack_B = B; c->oos_row0 = -1;
   c->mixed_row0 = -1; if (dense) c->h_clean = false;
   return stack_impl(c, B, R, dense);
@@ -1804,11 +1668,10 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   // Mixed stacking (round 3, default whenever the in-state rows were stacked in the compressed form only and nothing
   // forces the dense pipeline): the OOS rows go to the dense buffer behind the in-state rows and the update keeps the
   // sparse walk for the in-state rows - only the OOS block takes the MFMA products (update_sparse_range). Needs a
-  // 16-row-padded OOS block inside the allocation; otherwise (and with XIVO_HIP_FLAG_DENSE_H / _FP32_COV) every row
+  // 16-row-padded OOS block inside the allocation; otherwise (and with XIVO_HIP_FLAG_DENSE_H) every row
   // becomes dense as before.
-  static const bool no_mixed = getenv("XIVO_HIP_NO_MIXED_OOS") != nullptr;   // A/B knob
-  const bool mixed = !no_mixed && !c->calib_on && !c->dense_valid && !c->dense_from_ell && c->oos_row0 < 0 && b0 == 0 &&
-                     !(c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) && (c->M % 2 == 0) &&
+  const bool mixed = !c->calib_on && !c->dense_valid && !c->dense_from_ell && c->oos_row0 < 0 && b0 == 0 &&
+                     !(c->flags & XIVO_HIP_FLAG_DENSE_H) && (c->M % 2 == 0) &&
                      c->M + round_up16(max_rows + 16) <= c->Mpmax && c->Np <= 512;
   if (!mixed) { int rcd = ensure_dense(c); if (rcd) return rcd; c->mixed_row0 = -1; }
   else {
@@ -1841,7 +1704,7 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
   a.calib = c->calib_on ? c->calib : nullptr; a.cam_dim = c->calib_on ? c->cl.cam_dim : 0;
   a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
-  if (skip_HT(c) || mixed) { a.mb.HT = nullptr; c->ht_valid = false; }
+  if (mixed) { a.mb.HT = nullptr; c->ht_valid = false; }
   c->oos_row0 = c->M; c->oos_R = Roos;
   a.rows_out = c->oos_rows;
   {
@@ -1915,7 +1778,7 @@ int xivo_hip_one_point_ransac(xivo_hip_ctx* c, int B, double R, double ransac_th
   c->M = 2 * c->F; c->Mp = round_up16(c->M);
   for (int b = 0; b < B; ++b) { c->ell_over_h[b] = cal ? 1 : 0; c->ell_nc_h[b] = 12; c->ell_pw_h[b] = 9; }
   c->lead_valid = false;
-  const int dense = ((c->flags & (XIVO_HIP_FLAG_DENSE_H | XIVO_HIP_FLAG_FP32_COV)) || cal) ? 1 : 0;
+  const int dense = ((c->flags & XIVO_HIP_FLAG_DENSE_H) || cal) ? 1 : 0;
   c->dense_valid = dense != 0; c->dense_from_ell = !cal; c->stack_R = R; c->stack_B = B;
   c->oos_row0 = -1;   // the partial stacking replaces the rows of any earlier xivo_hip_oos_project (as xivo_hip_stack does)
   c->mixed_row0 = -1; if (dense) c->h_clean = false;
@@ -1997,7 +1860,7 @@ int xivo_hip_close_loop_stack(xivo_hip_ctx* c, int b0, int nb, int n, const xivo
   if (nb == 0) return XIVO_HIP_OK;
   for (size_t i = 0; i < (size_t)nb * n; ++i) {
     const xivo_lc_match& m = matches[i];
-    if (m.feat >= c->Fmax || (m.feat >= 0 && (m.group_sind < 0 || m.group_sind >= c->lay.n_groups))) return XIVO_HIP_ERR_INVALID;
+    if (m.feat >= c->F || (m.feat >= 0 && (m.group_sind < 0 || m.group_sind >= c->lay.n_groups))) return XIVO_HIP_ERR_INVALID;
   }
   const int M = 2 * n, N = c->N;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -2038,7 +1901,7 @@ int xivo_hip_compress_oos(xivo_hip_ctx* c, int B, double trigger_ratio, int* row
     return XIVO_HIP_ERR_INVALID;
   OosCompressArgs a{};
   a.lay = c->lay; a.mb = meas_buffers(c); a.row0 = c->oos_row0; a.rows = c->oos_rows; a.rows_out = c->oos_rows;
-  if (skip_HT(c) || c->mixed_row0 >= 0) { a.mb.HT = nullptr; c->ht_valid = false; }
+  if (c->mixed_row0 >= 0) { a.mb.HT = nullptr; c->ht_valid = false; }
   a.ratio = trigger_ratio; a.Roos = c->oos_R; a.batch = B;
   int rc;
   {
@@ -2066,7 +1929,7 @@ int xivo_hip_filter_update(xivo_hip_ctx* c, int B, double R, double mh_thresh, d
   // Estimator::OutlierRejection only gates when F > min_required_inliers_ (src/manager.cpp:635)
   const int gate = use_gating && c->F > min_inliers;
   if (c->calib_on && !calib_sparse(c)) {
-    // online-calibration builds (dense rows, XIVO_HIP_CALIB_DENSE): the gate needs the WHOLE row J() incl. the td / Cg / bg / intrinsics blocks (update.cpp:60-70),
+    // online-calibration builds on dense rows (XIVO_HIP_FLAG_DENSE_H): the gate needs the WHOLE row J() incl. the td / Cg / bg / intrinsics blocks (update.cpp:60-70),
     // which is not the row FillJacobianBlock stacks (the :675-676 overwrite): every present feature is stacked once as its
     // full J() (dense rows), gated on (J P) J^T + R by the dense-row gate, then the inliers are stacked as coded and updated
     rc = calib_gate(c, B, R, mh_thresh, mh_mult, min_inliers, gate);
@@ -2337,7 +2200,7 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
   {
     char plabel[64];
-    snprintf(plabel, sizeof(plabel), "%s<%d>", propagate_uses_wave_kernel() ? "propagate_state_wave_kernel" : "propagate_state_kernel", a.method ? 7 : 4);
+    snprintf(plabel, sizeof(plabel), "propagate_state_wave_kernel<%d>", a.method ? 7 : 4);
     // algorithmic flops: per integrator sub-step and stage the 23 x 23 Lyapunov right-hand side
     // F P + P F^T (2 * 2 * 23^3) and the transition recursion F + c F FK (2 * 23^3), as the reference codes them (dense);
     // sub-steps as src/rk4.cpp:19-31 cuts a sample: ceil(dt / stepsize), the sample's own dt when stepsize <= 0

@@ -339,20 +339,23 @@ __global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g,
 
 }  // namespace
 
+// XIVO_HIP_CHOL_WAVE (A/B, and the bit-identity test of the two factorisation kernels): the one-wave kernel for every size
+static bool chol_one_wave_forced() { static const bool on = getenv("XIVO_HIP_CHOL_WAVE") != nullptr; return on; }
+// the instantiation of the four-wave register kernel a (size, batch) takes - ONE place decides it, for the launcher, the gate
+// and the label alike: mode 0 = many factors (three workgroups per CU at >= nine block rows, blocks of S requested per block
+// column, no look-ahead: the only instantiations that carry the gate), mode 2 = few factors (two workgroups per CU, every
+// block of S requested up front, look-ahead on the diagonal update)
+static int chol_reg_mode(int batch) { return batch >= 512 ? 0 : 2; }
+
 // whether launch_chol_f64 would run an instantiation that carries the gate for this factor size / batch
-bool chol_gate_supported(int Mp, int batch, int variant) {
-  static const bool off = getenv("XIVO_HIP_NO_GATE_IN_CHOL") != nullptr;   // A/B knob: gate_ell_kernel as a launch of its own
-  const int nb = Mp / 16;
-  const bool plain_reg = !getenv("XIVO_HIP_CHOL_WAVE") && !getenv("XIVO_HIP_CHOL_MINB2") && !getenv("XIVO_HIP_CHOL_LOOKAHEAD") &&
-                         !getenv("XIVO_HIP_CHOL_MINB4");
-  return !off && plain_reg && nb <= 12 && batch >= 512 && variant != 1;
+bool chol_gate_supported(int Mp, int batch) {
+  return !chol_one_wave_forced() && Mp / 16 <= 12 && chol_reg_mode(batch) == 0;
 }
 
 int launch_chol_f64(const CholArgs& g, hipStream_t stream, const CholGateArgs* gate) {
   if (g.batch <= 0) return 0;
   const CholGateArgs nogate{};
-  if (gate && !chol_gate_supported(g.Mp, g.batch, g.variant)) return (int)hipErrorInvalidValue;
-  static const bool old_kernel = getenv("XIVO_HIP_CHOL_WAVE") != nullptr;   // A/B knob: one wave per filter
+  if (gate && !chol_gate_supported(g.Mp, g.batch)) return (int)hipErrorInvalidValue;
   const int nb = g.Mp / 16;
   // Round 3 (factor_invert_diag on the matrix pipe): the register kernel is ~11 500 instructions at ten block rows (it
   // was ~45 000: 170-200 KB of straight-line code that lost 2.6x on nodes with slow instruction fetch) and is the
@@ -360,34 +363,21 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream, const CholGateArgs* g
   // M = 160: one factor 48-52 us (round 2: 80), 16384 factors 1.6-1.7 ms (register kernel, three workgroups per CU, no
   // look-ahead) against 2.4-2.6 ms for the one-wave kernel and 2.3-2.4 ms for either kernel before. Thirteen to nineteen
   // block rows run the same kernel on eight waves (below); the one-wave kernel serves what is left (M > 304).
-  const bool want_reg = g.variant == 2 || g.variant == 0;
-  if (!old_kernel && nb <= 12 && g.variant != 1 && want_reg) {
-    static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
-    const int mirror = (nb > 10 || small_stream || g.latency) ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
-                                          // whitened outputs leave the kernel (launch_trsm_f64)
-    static const bool minb2 = getenv("XIVO_HIP_CHOL_MINB2") != nullptr;   // A/B knob: the small-batch instantiation for every batch
-    const bool many = g.batch >= 512 && !minb2;
-    // Two instantiations per size, same bits (tests/test_update_gpu.py::test_cholesky_kernels_are_bit_identical):
-    //   few factors  (< 512): two workgroups per CU (up to 256 VGPRs), every block of S requested up front, the next
-    //                owner forms its diagonal update while the current block column is factored - 48 us per factor;
-    //   many factors: three workgroups per CU (168 VGPRs), blocks of S requested per block column, no look-ahead - the
-    //                look-ahead's 16 accumulator registers spill there (1.98 against 1.63 ms per 16384 factors), the
-    //                up-front loads need 248.
-    // A/B knobs: XIVO_HIP_CHOL_LOOKAHEAD / _NO_LOOKAHEAD and XIVO_HIP_CHOL_LAZY_LOADS force one behaviour for every batch.
-    static const bool no_pre = getenv("XIVO_HIP_CHOL_NO_LOOKAHEAD") != nullptr;
-    static const bool force_pre = getenv("XIVO_HIP_CHOL_LOOKAHEAD") != nullptr;
-    static const bool lazy = getenv("XIVO_HIP_CHOL_LAZY_LOADS") != nullptr;
-    const int mode = (no_pre || (many && !force_pre)) ? 0 : ((lazy || many) ? 1 : 2);
+  // Every instantiation produces the same bits (tests/test_update_gpu.py::test_cholesky_kernels_are_bit_identical).
+  if (!chol_one_wave_forced() && nb <= 12) {
+    const int mirror = (nb > 10 || g.latency) ? 1 : 0;   // the streamed solve reads the mirrored upper triangle: nb >= 12, and nb = 11 when the
+                                                         // whitened outputs leave the kernel (launch_trsm_f64)
+    const bool many = g.batch >= 512;
+    const int mode = chol_reg_mode(g.batch);
+    if (gate && mode != 0) return (int)hipErrorInvalidValue;   // (only the mode-0 instantiations carry the gate)
 #define CHOL_REG_LAUNCH(NB_, MINB_)                                                                                                     \
   do {                                                                                                                                  \
     if (mode == 0 && gate) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, false, false, 4, true>), dim3(g.batch), dim3(256), 0, stream, g, mirror, *gate); \
     else if (mode == 0) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, false, false>), dim3(g.batch), dim3(256), 0, stream, g, mirror, nogate);   \
-    else if (mode == 1) hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, true, false>), dim3(g.batch), dim3(256), 0, stream, g, mirror, nogate); \
     else hipLaunchKernelGGL((chol_reg_f64_kernel<NB_, MINB_, true, true>), dim3(g.batch), dim3(256), 0, stream, g, mirror, nogate);             \
   } while (0)
     if (nb <= 4) CHOL_REG_LAUNCH(4, 2);
     else if (nb <= 8) CHOL_REG_LAUNCH(8, 2);
-    else if (nb <= 10 && many && getenv("XIVO_HIP_CHOL_MINB4")) CHOL_REG_LAUNCH(10, 4);   // A/B knob
     else if (nb <= 10 && many) CHOL_REG_LAUNCH(10, 3);
     else if (nb <= 10) CHOL_REG_LAUNCH(10, 2);
     else if (many) CHOL_REG_LAUNCH(12, 3);
@@ -395,13 +385,13 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream, const CholGateArgs* g
 #undef CHOL_REG_LAUNCH
     return (int)hipGetLastError();
   }
+  if (gate) return (int)hipErrorInvalidValue;
   // 13..19 block rows (M <= 304: BASELINE config 4, the 125-feature build): the register kernel on eight waves, one
   // workgroup per CU (two waves per SIMD at up to 256 VGPRs) - S read once, L written once, where the one-wave kernel
   // re-reads L_ik for every later block column (15.7 GB per 4096 factors at M = 300, HBM-bound)
-  static const bool no_reg8 = getenv("XIVO_HIP_CHOL_NO_REG8") != nullptr;   // A/B knob
-  if (!old_kernel && !no_reg8 && nb > 12 && nb <= 19 && g.variant != 1) {
+  if (!chol_one_wave_forced() && nb > 12 && nb <= 19) {
     const int mirror = 1;
-    const bool pre = g.batch < 512 && !getenv("XIVO_HIP_CHOL_NO_LOOKAHEAD");
+    const bool pre = g.batch < 512;
     if (nb <= 16) {
       if (pre) hipLaunchKernelGGL((chol_reg_f64_kernel<16, 1, true, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror, nogate);
       else hipLaunchKernelGGL((chol_reg_f64_kernel<16, 1, false, false, 8>), dim3(g.batch), dim3(512), 0, stream, g, mirror, nogate);
@@ -411,18 +401,16 @@ int launch_chol_f64(const CholArgs& g, hipStream_t stream, const CholGateArgs* g
     }
     return (int)hipGetLastError();
   }
-  if (gate) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(chol_f64_kernel, dim3(g.batch), dim3(64), 0, stream, g);
   return (int)hipGetLastError();
 }
 
-void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant) {
+void chol_kernel_label(int Mp, int batch, char* buf, size_t n) {
   const int nb = Mp / 16;
-  const bool reg8 = nb > 12 && nb <= 19 && !getenv("XIVO_HIP_CHOL_NO_REG8");
-  if (getenv("XIVO_HIP_CHOL_WAVE") || (nb > 12 && !reg8) || variant == 1) snprintf(buf, n, "chol_f64_kernel");
+  const bool reg8 = nb > 12 && nb <= 19;
+  if (chol_one_wave_forced() || (nb > 12 && !reg8)) snprintf(buf, n, "chol_f64_kernel");
   else if (reg8) snprintf(buf, n, "chol_reg_f64_kernel<%d,1,8 waves>", nb <= 16 ? 16 : 19);
-  else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)),
-                (nb > 8 && batch >= 512 && !getenv("XIVO_HIP_CHOL_MINB2")) ? 3 : 2);
+  else snprintf(buf, n, "chol_reg_f64_kernel<%d,%d>", nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : 12)), (nb > 8 && batch >= 512) ? 3 : 2);
 }
 
 }  // namespace xivo_hip

@@ -5,16 +5,13 @@
 // pivoted LDL^T; S = HPH^T + R is SPD, so an un-pivoted blocked Cholesky is the same linear map up to rounding - tests
 // assert 1e-8 on dx, 1e-6 on P).
 //
-// trsm_f64_kernel : each wave64 owns 16 right-hand-side columns and keeps the
-//   whole Mp x 16 solution in accumulator registers. The f64 MFMA C/D layout
-//   (row = (lane>>4) + 4*reg, col = lane&15) is exactly the B-operand layout of
-//   the four k-slices of the next MFMA, so forward and backward substitution
-//   chain with no data movement at all; dx = K*inn falls out as a lane reduce.
+// Every kernel here has a wave64 own 16 right-hand-side columns and keep the whole Mp x 16 solution in accumulator registers:
+// the f64 MFMA C/D layout (row = (lane>>4) + 4*reg, col = lane&15) is exactly the B-operand layout of the four k-slices of the
+// next MFMA, so forward and backward substitution chain with no data movement at all; dx = K*inn falls out as a lane reduce.
 // trsm_lds_f64_kernel<NBM, TF> : one workgroup of 16 waves per filter, the whole factor in LDS; beyond the solve it
 //   carries, on the gain still in its registers (which is also the A-operand layout),
 //     TF = 1  T = K (HP) - P                                   (estimator.cpp:1276-1280, re-associated pipeline)
 //     TF = 2  P+ = P - W^T W after the forward substitution    (symmetric form)
-//     TF = 3  the whole Joseph update in its expanded form     (estimator.cpp:1276-1287; round-2 default, XIVO_HIP_FLAG_EXPANDED_JOSEPH)
 //     TF = 4  the whole Joseph update in its whitened form     P+ = P - (W - D)^T (W + D)   (round 3: the default up to M = 176)
 //     TF = 5  the whitened outputs V^T, Y^T for a tiled product outside the kernel (N > 256)
 //   through sym_tiles_from_regs: symmetric N x N x M products with one operand in registers and the other arriving
@@ -64,93 +61,6 @@ __global__ __launch_bounds__(256) void fwd_vec_kernel(const double* __restrict__
   }
 }
 
-template <int NBM, int WPE>
-__global__ __launch_bounds__(256, WPE) void trsm_f64_kernel(TrsmArgs g) {
-  const int chunks = (g.Np + 63) / 64;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, slot = b >> 3;
-  const int filt = (slot / chunks) * 8 + xcd;
-  const int chunk = slot % chunks;
-  if (filt >= g.batch) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int c0 = chunk * 64 + wave * 16;
-  if (c0 >= g.Np) return;
-  const int nb = g.Mp / 16;
-
-  const double* __restrict__ LU = g.LU + (long)filt * g.strideLU;
-  const double* __restrict__ invD = g.invD + (long)filt * g.strideInvD;
-  const double* __restrict__ PHT = g.PHT + (long)filt * g.stridePHT;
-  const long ld = g.ldlu;
-
-  d4 X[NBM];
-#pragma unroll
-  for (int i = 0; i < NBM; ++i) {
-    X[i] = d4{0.0, 0.0, 0.0, 0.0};
-    if (i < nb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X[i][r] = PHT[(c0 + li) + (long)(16 * i + lg + 4 * r) * g.ldpht];
-    }
-  }
-
-  // forward: L Y = HP
-#pragma unroll
-  for (int k = 0; k < NBM; ++k) {
-    if (k < nb) {
-      d4 t = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) t = mfma(invD[(long)k * 512 + li + (4 * s + lg) * 16], X[k][s], t);
-      X[k] = t;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int i = k + 1; i < NBM; ++i) {
-          if (i < nb) {
-            const double a = LU[(16 * i + li) + (long)(16 * k + 4 * s + lg) * ld];
-            X[i] = mfma(-a, t[s], X[i]);
-          }
-        }
-      }
-    }
-  }
-  // backward: L^T K^T = Y
-#pragma unroll
-  for (int k = NBM - 1; k >= 0; --k) {
-    if (k < nb && !g.fwd_only) {
-      d4 t = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) t = mfma(invD[(long)k * 512 + 256 + li + (4 * s + lg) * 16], X[k][s], t);
-      X[k] = t;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int i = 0; i < k; ++i) {
-          const double a = LU[(16 * i + li) + (long)(16 * k + 4 * s + lg) * ld];
-          X[i] = mfma(-a, t[s], X[i]);
-        }
-      }
-    }
-  }
-
-  // K[(c0+li), m] = X[m-block][..];  dx[c0+li] = sum_m K * inn
-  double* __restrict__ K = g.K + (long)filt * g.strideK;
-  const double* __restrict__ inn = g.fwd_only ? g.y + (long)filt * g.strideY : g.inn + (long)filt * g.strideInn;
-  double part = 0.0;
-#pragma unroll
-  for (int i = 0; i < NBM; ++i) {
-    if (i < nb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 16 * i + lg + 4 * r;
-        K[(c0 + li) + (long)m * g.ldk] = X[i][r];
-        part = fma(X[i][r], inn[m], part);
-      }
-    }
-  }
-  part += __shfl_xor(part, 16);
-  part += __shfl_xor(part, 32);
-  if (lg == 0) g.err[(long)filt * g.strideErr + c0 + li] = part;
-}
 
 // LDS-resident variant: the workgroup (16 waves = 256 right-hand-side columns) first
 // copies the whole factor into LDS - the 45..55 lower 16x16 blocks of L, with
@@ -395,17 +305,12 @@ int launch_trsm_stream_t(const TrsmArgs& g, hipStream_t stream) {
   hipLaunchKernelGGL((trsm_stream_f64_kernel<NBM, WH, NWS>), dim3(grid), dim3(64 * NWS), lds, stream, g);
   return (int)hipGetLastError();
 }
-// the latency route on four-wave workgroups (XIVO_HIP_STREAM_WAVES=8: the eight-wave kernel, A/B)
-static bool latency_four_waves() {
-  static const bool w8 = [] { const char* e = getenv("XIVO_HIP_STREAM_WAVES"); return e && atoi(e) == 8; }();
-  return !w8;
-}
 // Block-row capacities the streamed kernel is instantiated for. Register allocation of the fully unrolled substitution
 // is erratic from one capacity to the next (spilled VGPRs, hipcc 7.2: plain 14: 0, 16: 0, 18: 4801, 19: 6353, 20: 5019,
 // 22: 10, 24: 26; whitened 14: 0, 16: 35, 19: 12, 20: 47, 22: 74, 24: 806 - scripts/resource_usage.sh), so each variant
 // uses the capacities that compile clean.
 static int stream_capacity(int nb, bool whitened) {
-  if (whitened && nb <= 8) return nb <= 4 ? 4 : (nb <= 6 ? 6 : 8);   // small factors: two workgroups per CU (XIVO_HIP_SMALL_STREAM)
+  if (whitened && nb <= 8) return nb <= 4 ? 4 : (nb <= 6 ? 6 : 8);   // small factors (latency route, eight block rows on a wide state)
   if (nb <= 14) return 14;
   if (whitened) return nb <= 19 ? 19 : (nb <= 22 ? 22 : 24);
   return nb <= 16 ? 16 : (nb <= 22 ? 22 : 24);
@@ -439,26 +344,15 @@ int launch_trsm_lds_t(const TrsmArgs& g, hipStream_t stream) {
   {
     if (g.T && trsm_forms_T(g.Mp, g.Np))
       return g.fwd_only ? launch_trsm_lds_tf<NBM, 2>(g, stream)
-                        : (g.joseph == 2 ? launch_trsm_lds_tf<NBM, 4>(g, stream)
-                                         : (g.joseph ? launch_trsm_lds_tf<NBM, 3>(g, stream) : launch_trsm_lds_tf<NBM, 1>(g, stream)));
+                        : (g.joseph ? launch_trsm_lds_tf<NBM, 4>(g, stream) : launch_trsm_lds_tf<NBM, 1>(g, stream));
   }
   return launch_trsm_lds_tf<NBM, 0>(g, stream);
-}
-
-template <int NBM>
-int launch_trsm_t(const TrsmArgs& g, hipStream_t stream) {
-  const int chunks = (g.Np + 63) / 64;
-  const int grid = ((g.batch + 7) / 8) * 8 * chunks;
-  constexpr int WPE = NBM <= 6 ? 6 : (NBM <= 10 ? 4 : (NBM <= 14 ? 3 : (NBM <= 20 ? 2 : 1)));
-  hipLaunchKernelGGL((trsm_f64_kernel<NBM, WPE>), dim3(grid), dim3(256), 0, stream, g);
-  return (int)hipGetLastError();
 }
 
 }  // namespace
 
 bool pnew_reg_supported(int Mp, int Np) {
-  static const bool off = getenv("XIVO_HIP_NO_PNEW_REG") != nullptr;   // A/B knob: the tiled GEMM instead
-  return !off && Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
+  return Mp / 16 <= 10 && Np <= 256 && Np % 16 == 0;
 }
 
 template <int NBM>
@@ -491,37 +385,27 @@ void pnew_reg_kernel_label(int Mp, char* buf, size_t n) { snprintf(buf, n, "pnew
 // Few filters (fewer one-per-filter workgroups than a quarter of the CUs): the solve spreads over 128-column workgroups of
 // the streamed kernel and the covariance product over the tiles of the stand-alone GEMM, instead of one CU per filter doing
 // all 13 000 MFMAs of an update by itself (87 us at the issue rate for N = 250, M = 160). The caller (capi.hip) combines this
-// with the pipeline's own conditions and XIVO_HIP_FLAG_THROUGHPUT_ROUTE; XIVO_HIP_NO_LATENCY_ROUTE: A/B knob.
-bool trsm_latency_route(int Mp, int batch) {
-  static const bool off = getenv("XIVO_HIP_NO_LATENCY_ROUTE") != nullptr;
-  return !off && Mp / 16 <= 14 && batch <= 64;
-}
+// with the pipeline's own conditions and XIVO_HIP_FLAG_THROUGHPUT_ROUTE.
+bool trsm_latency_route(int Mp, int batch) { return Mp / 16 <= 14 && batch <= 64; }
 
 bool trsm_forms_T(int Mp, int Np) {
-  static const bool off = getenv("XIVO_HIP_NO_TRSM_T") != nullptr;   // A/B knob: T as a stand-alone product
-  static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;   // A/B knob: small factors take the whitened-outputs path
-  if (small_stream && Mp / 16 <= 8) return false;
-  return !off && Mp / 16 <= 11 && Np <= 256 && Np % 16 == 0;   // the factor fits the LDS and one workgroup covers every column
+  return Mp / 16 <= 11 && Np <= 256 && Np % 16 == 0;   // the factor fits the LDS and one workgroup covers every column
 }
 
 int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
   const int nb = g.Mp / 16;
-  // A/B knob (round 3 experiment): small factors with the whitened outputs through the streamed kernel - 8-wave workgroups of
-  // 128 columns, two or more per CU, instead of one 16-wave workgroup per filter
-  static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
-  if (g.latency && !small_stream && latency_four_waves() && g.Yout && !g.fwd_only && nb <= 14) {
+  if (g.latency && g.Yout && !g.fwd_only && nb <= 14) {      // few filters: four-wave workgroups of 64 columns (one wave per SIMD)
     if (nb <= 4) return launch_trsm_stream_t<4, 1, 4>(g, stream);
     if (nb <= 6) return launch_trsm_stream_t<6, 1, 4>(g, stream);
     if (nb <= 8) return launch_trsm_stream_t<8, 1, 4>(g, stream);
     return launch_trsm_stream_t<14, 1, 4>(g, stream);
   }
-  if ((small_stream || g.latency || g.stream8) && g.Yout && !g.fwd_only && nb <= 8) {
+  if (g.stream8 && g.Yout && !g.fwd_only && nb <= 8) {
     if (nb <= 4) return launch_trsm_stream_t<4, 1>(g, stream);
     if (nb <= 6) return launch_trsm_stream_t<6, 1>(g, stream);
     return launch_trsm_stream_t<8, 1>(g, stream);
   }
-  if (g.latency && g.Yout && !g.fwd_only && nb <= 14) return launch_trsm_stream_t<14, 1>(g, stream);
   if (g.out_f32 && g.Yout && !g.fwd_only && nb <= 14) return launch_trsm_stream_t<14, 1>(g, stream);   // (only the streamed kernel writes float outputs)
   // whole factor in LDS (nb(nb+1)/2 blocks of 16x17 doubles) when it fits 160 KiB
   // (a four-block-row instantiation of the whitened form for the TUM-VI build's 30 features spills 1232 VGPRs - hipcc 7.2;
@@ -531,11 +415,8 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
   // (eleven block rows with the whitened outputs leaving the kernel: that instantiation spills 700 VGPRs - streamed instead)
   if (nb <= 11 && !(g.Yout && !g.fwd_only)) return launch_trsm_lds_t<11>(g, stream);
   // larger factors: stream the factor through a double-buffered LDS panel
-  // A/B knob (per-wave L2 reads instead of the streamed panel). Ignored when the whitened outputs are wanted: only the streamed
-  // kernel writes them, and a caller that then forms P - V^T Y from an unwritten Y would be silently wrong.
-  static const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
   const bool wh = g.Yout && !g.fwd_only;
-  if ((!no_stream || wh) && nb <= 24) {
+  if (nb <= 24) {
     switch (stream_capacity(nb, wh) * 2 + (wh ? 1 : 0)) {
       case 14 * 2: return launch_trsm_stream_t<14, 0>(g, stream);
       case 14 * 2 + 1: return launch_trsm_stream_t<14, 1>(g, stream);
@@ -547,12 +428,6 @@ int launch_trsm_f64(const TrsmArgs& g, hipStream_t stream) {
       default: return launch_trsm_stream_t<24, 1>(g, stream);
     }
   }
-  if (nb <= 4) return launch_trsm_t<4>(g, stream);
-  if (nb <= 7) return launch_trsm_t<7>(g, stream);
-  if (nb <= 10) return launch_trsm_t<10>(g, stream);
-  if (nb <= 14) return launch_trsm_t<14>(g, stream);
-  if (nb <= 19) return launch_trsm_t<19>(g, stream);
-  if (nb <= 24) return launch_trsm_t<24>(g, stream);
   return (int)hipErrorInvalidValue;
 }
 
@@ -566,14 +441,10 @@ int launch_fwd_vec(const double* LU, long strideLU, int ldlu, const double* invD
 
 void trsm_kernel_label(int Mp, char* buf, size_t n, int forms_T, bool latency, bool stream8) {
   const int nb = Mp / 16;
-  const bool no_stream = getenv("XIVO_HIP_TRSM_NOSTREAM") != nullptr;
-  static const bool small_stream = getenv("XIVO_HIP_SMALL_STREAM") != nullptr;
-  if (latency && forms_T == 5 && nb <= 14 && !small_stream && latency_four_waves()) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1,4>", stream_capacity(nb, true));
-  else if (latency && forms_T == 5 && nb <= 14) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
-  else if ((small_stream || stream8) && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
+  if (latency && forms_T == 5 && nb <= 14) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1,4>", stream_capacity(nb, true));
+  else if (stream8 && forms_T >= 4 && nb <= 8) snprintf(buf, n, "trsm_stream_f64_kernel<%d,1>", stream_capacity(nb, true));
   else if (nb <= 11) snprintf(buf, n, "trsm_lds_f64_kernel<%d,%d>", nb <= 6 ? 6 : (nb <= 10 ? 10 : 11), forms_T);
-  else if (!no_stream || forms_T >= 4) snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
-  else snprintf(buf, n, "trsm_f64_kernel");
+  else snprintf(buf, n, "trsm_stream_f64_kernel<%d,%d>", stream_capacity(nb, forms_T >= 4), forms_T >= 4 ? 1 : 0);
 }
 
 }  // namespace xivo_hip

@@ -89,7 +89,6 @@ struct CholArgs {
   long strideInvD;
   int* status;      // per filter: 0 ok, else 1 + first non-positive pivot index
   int batch;
-  int variant;      // 0: size heuristic; 1: one wave per filter (chol_f64_kernel); 2: four waves, factor in registers
   int latency;      // the solve behind it takes the latency route (streamed kernel: reads the mirrored upper triangle)
 };
 // MH gating folded into the prologue of the factorisation (chol_f64.hip, GATE instantiations): what gate_ell_kernel takes,
@@ -104,9 +103,9 @@ struct CholGateArgs {
   int F;
   double R, thresh, mult; int min_inliers;
 };
-bool chol_gate_supported(int Mp, int batch, int variant);
+bool chol_gate_supported(int Mp, int batch);
 int launch_chol_f64(const CholArgs& args, hipStream_t stream, const CholGateArgs* gate = nullptr);
-void chol_kernel_label(int Mp, int batch, char* buf, size_t n, int variant = 0);
+void chol_kernel_label(int Mp, int batch, char* buf, size_t n);
 
 struct TrsmArgs {
   const double* LU;    // from chol: L lower, L^T upper
@@ -138,13 +137,11 @@ struct TrsmArgs {
   long strideT;
   int ldt;
   const int* skip_status;   // fwd_only / joseph: per filter, non-zero = leave P untouched
-  int joseph;          // 1: T is the covariance itself and receives the whole Joseph update in place (expanded form, chol_trsm.hip)
+  int joseph;          // 2: T is the covariance itself and receives the whole Joseph update in place (whitened form, chol_trsm.hip)
   const double* Pm;    // the prior covariance [Np x Np]
   long stridePm;
   int ldpm;
   int t_jbp;           // (set by the launcher) column blocks per LDS phase
-  // in-kernel factorisation (solve_fused.hip: LU points at S itself): receives the status chol_f64.hip would have written
-  int* chol_status;
   // whitened outputs for a covariance update OUTSIDE the solve kernel (shapes one workgroup does not hold: N > 256 or
   // M > 176): K receives V^T = (W - D)^T instead of the gain, Yout receives Y^T = (W + D)^T, both [Np x Mp]; then
   // P+ = P - V^T Y as a tiled symmetric product (the Joseph expression for the computed gain, chol_trsm.hip TF == 4)
@@ -180,11 +177,7 @@ int launch_pnew_reg_f64(const PnewRegArgs& args, hipStream_t stream);
 void pnew_reg_kernel_label(int Mp, char* buf, size_t n);
 // whether launch_trsm_f64 forms T itself for these shapes (whole factor in LDS, one column chunk per filter)
 bool trsm_forms_T(int Mp, int Np);
-// solve_fused.hip: the whitened in-solve Joseph update with the Cholesky factorisation inside the kernel (args.LU = S)
-bool trsm_chol_fused_supported(int Mp, int Np);
-int launch_trsm_chol_fused(const TrsmArgs& args, hipStream_t stream);
-void trsm_chol_fused_label(int Mp, char* buf, size_t n);
-// the whitened in-solve update on NWV-wave workgroups, more than one per CU (short factor, narrow state)
+// the whitened in-solve update on ten- / twelve-wave workgroups with W in registers (seven block rows, narrow state: solve_fused.hip)
 bool trsm_narrow_supported(int Mp, int Np);
 int launch_trsm_narrow(const TrsmArgs& args, hipStream_t stream);
 void trsm_narrow_label(int Mp, int Np, char* buf, size_t n);

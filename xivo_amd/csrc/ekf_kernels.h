@@ -125,7 +125,6 @@ struct PropStateArgs {
 };
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s);
 int launch_propagate_state_calib(const PropStateArgs& a, hipStream_t s);
-bool propagate_uses_wave_kernel();   // one wave per filter (default) or the four-wave workgroup kernel (XIVO_HIP_PROP_WG)
 
 // xivo::Givens / xivo::QR (helpers.cpp:27-101), one wave per problem, in place
 struct GivensArgs {

@@ -1371,6 +1371,9 @@ __global__ void lc_rows_kernel(LcArgs a) {
   if (mt.feat < 0) { inn[r0] = 0.0; inn[r0 + 1] = 0.0; dR[r0] = 1.0; dR[r0 + 1] = 1.0; return; }
   const xivo_pose_in& pose = a.poses[filt];
   const xivo_feat_in& ft = a.feats[(long)filt * a.Fmax + mt.feat];
+  // a matched feature that is not in the state (a free slot of a ragged batch: sind < 0) or whose anchor slot is out of range is
+  // the caller's error, not an address: the pair stays neutral (the host checked feat / group_sind against the layout)
+  if (ft.sind < 0 || ft.ref_sind < 0 || ft.ref_sind >= a.lay.n_groups) { inn[r0] = 0.0; inn[r0 + 1] = 0.0; dR[r0] = 1.0; dR[r0 + 1] = 1.0; return; }
   const xivo_group_in& gref = a.groups[(long)filt * a.lay.n_groups + ft.ref_sind];
   const xivo_group_in& g = a.groups[(long)filt * a.lay.n_groups + mt.group_sind];
   const xivo_cam cam = filter_cam(a.cam, a.calib, a.cl.cam_dim, filt);
@@ -1578,7 +1581,8 @@ __device__ __forceinline__ void compose_motion_dev(MotionRegs& X, const V3& V, c
   X.Rsb = m3_mul(X.Rsb, so3_exp_small(gc.v[0] * dt, gc.v[1] * dt, gc.v[2] * dt));   // :610
 }
 
-// One workgroup of 256 threads per filter; the (tiny) nominal state lives in LDS. Structure exploited:
+// Structure the propagation kernels exploit (the online-calibration kernel below: one workgroup of 256 threads per filter; the default
+// build: one wave per filter, further down - same arithmetic per element):
 //  * The nominal state of stage st - ComposeMotion of the sub-step's start state with the interpolated IMU sample
 //    (rk4.cpp:49-88) - feeds the covariance stages only through Rsb(st), the bias-corrected gyro / accel and the stage
 //    velocity K_st, and none of these depends on another stage (only Tsb does, through the a_ij-weighted velocities,
@@ -1593,376 +1597,6 @@ __device__ __forceinline__ void compose_motion_dev(MotionRegs& X, const V3& V, c
 //  * NS (stages) is a template parameter: the tableau-weighted sums are unrolled, all LDS loads of a sum are in
 //    flight together, and coefficients of stages not yet computed are the tableau's zeros times finite stale values.
 // The 23 x 23 matrices live in LDS (column-major, ld 23); FK keeps its 9 non-zero rows only ([i + 9 j]).
-// Product phase by wave: waves 0..2 own the row blocks Wsb / Tsb / Vsb of F: lanes 0..22 form column j of F P0,
-// lanes 32..54 column j of F S (S = sum a_q FK_q) and from it FK of the stage; wave 3: lanes 0..22 row i of P0 F^T,
-// lanes 32..43 row r of the 12 x 12 support of G Q G^T.
-template <int NS>
-// RK4: 3 workgroups per CU (LDS 50 KB each). The kernel is bound by the latency of one workgroup's serial chain, so a
-// third resident workgroup pays for the 40 VGPRs that spill at the 168-register budget (2.47 -> 2.22 ms per 16 samples
-// x 4096 filters); Dormand-Prince (68 KB) stays at 2.
-__global__ __launch_bounds__(256, NS == 4 ? 3 : 2) void propagate_state_kernel(PropStateArgs a) {
-  constexpr int NM = 23, NN = NM * NM, NT = 256, FR = 9, NF = FR * NM;   // FR: rows of F that are not identically zero
-  extern __shared__ double sm[];
-  const int lane = threadIdx.x, filt = blockIdx.x;   // `lane`: thread index in the workgroup
-  const int wave = lane >> 6, wl = lane & 63;
-  const RkTableau& tab = kTableau[NS == 4 ? 0 : 1];
-  double* Pmm = sm;            // P_mm at the start of the sub-step
-  double* PhiA = Pmm + NN;     // rows < 9 of the accumulated transition ([i + 9 j]; the other rows stay identity rows),
-  double* PhiB = PhiA + NF;    // double buffered
-  double* P0 = PhiB + NF;
-  double* S1 = P0 + NN;        // 23 x 23 scratch whose rows >= 9 stay zero: sum a_q FK_q, later I + FK h
-  double* FPs = S1 + NN;       // [9 x 23]  F P0          ([i + 9 j])
-  double* PFs = FPs + NF;      // [23 x 9]  P0 F^T        ([i + 23 j])
-  double* GQG = PFs + NF;      // [12 x 12] support of G Q G^T: rows / cols (Wsb, Vsb, bg, ba)
-  double* Q = GQG + 144;       // 12 x 12
-  double* GQc = Q + 144;       // [12 x 12] the non-zero rows of G Q
-  double* zero = GQc + 144;    // one 0.0 (target of the structurally absent terms of phase C) + pad
-  double* nom = zero + 2;      // nominal state + IMU sample, resident in LDS between their few uses (70 VGPRs otherwise):
-                               // Rsb[9] row-major, Tsb, Vsb, bg, ba, Rsg g, gyro, accel, slope_gyro, slope_accel (3 each)
-  double* sKs = nom + 36;      // [NS][3] stage velocities
-  double* Jms = sKs + 24;      // [NS][4][3 x 3] row-major: dW/dW, dV/dW, -Rsb, dV/dWsg of every stage
-  double* F9 = Jms + NS * 36;  // [9 x 23] the non-zero rows of F of the current stage, dense ([i + 9 j]): the F term of FK = F + F S h
-  double* FKs = F9 + NF;       // [NS][9 x 23]
-  double* PKs = FKs + NS * NF; // [NS][23 x 23]
-
-  const double* Pg = a.P + (long)filt * a.strideP;
-  for (int e = lane; e < NN; e += NT) {
-    const int i = e % NM, j = e / NM;
-    Pmm[e] = Pg[i + (long)j * a.ldp];
-    S1[e] = 0.0;
-  }
-  if (lane < NF) PhiA[lane] = (lane % FR) == (lane / FR) ? 1.0 : 0.0;
-  if (lane == 0) zero[0] = 0.0;
-  double* Phi = PhiA;
-  double* PhiN = PhiB;
-  // this thread's elements e = lane + 256 m of the 23 x 23 matrices: Qmodel entries and the LDS offsets (from sm) of
-  // the three terms of PK(e) = (F P0)(e) + (P0 F^T)(e) + (G Q G^T)(e); structurally absent terms point at `zero`
-  double qm[3];
-  int oFP[3], oPF[3], oG[3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const int e = lane + NT * m, i = e % NM, j = e / NM;
-    const int ci = i < 3 ? i : ((i >= 6 && i < 15) ? i - 3 : -1), cj = j < 3 ? j : ((j >= 6 && j < 15) ? j - 3 : -1);
-    qm[m] = e < NN ? a.Qmodel[e] : 0.0;
-    oFP[m] = i < FR ? (int)(FPs - sm) + i + FR * j : (int)(zero - sm);
-    oPF[m] = j < FR ? (int)(PFs - sm) + i + NM * j : (int)(zero - sm);
-    oG[m] = (ci >= 0 && cj >= 0) ? (int)(GQG - sm) + ci + 12 * cj : (int)(zero - sm);
-  }
-  for (int e = lane; e < NS * (NF + NN); e += NT) FKs[e] = 0.0;   // finite values under the tableau's zero coefficients
-  if (lane < NF) {                                                // the constant entries of F: dWsb/dbg = -I, dTsb/dVsb = I
-    const int i = lane % FR, j = lane / FR;
-    F9[lane] = (i < 3 && j == 9 + i) ? -1.0 : ((i >= 3 && i < 6 && j == 3 + i) ? 1.0 : 0.0);
-  }
-  for (int e = lane; e < 144; e += NT) {
-    const double q = a.Qimu[e];
-    Q[e] = q;
-    // rows of G Q that do not depend on the state: Wsb rows = -Q[0:3,:], bg rows = Q[6:9,:], ba rows = Q[9:12,:]
-    const int r = e % 12;
-    if (r < 3) GQc[e] = -q;
-    else if (r >= 6) GQc[e] = q;
-  }
-  xivo_pose_in& pose = a.poses[filt];
-  const V3 gv{{a.g[0], a.g[1], a.g[2]}};
-  if (lane == 0) {
-    const V3 Rg0 = m3_mulv(m3_from_colmajor(pose.Rsg), gv);   // Rsg g (estimator.cpp:609)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) nom[3 * i + j] = pose.Rsb[i + 3 * j];
-      nom[9 + i] = pose.Tsb[i]; nom[12 + i] = pose.Vsb[i]; nom[15 + i] = pose.bg[i]; nom[18 + i] = pose.ba[i];
-      nom[21 + i] = Rg0.v[i];
-    }
-  }
-  auto load_nominal = [&](MotionRegs& X, V3& Rg) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) X.Rsb.m[i][j] = nom[3 * i + j];
-      X.Tsb.v[i] = nom[9 + i]; X.Vsb.v[i] = nom[12 + i]; X.bg.v[i] = nom[15 + i]; X.ba.v[i] = nom[18 + i];
-      Rg.v[i] = nom[21 + i];
-    }
-  };
-  __syncthreads();
-
-  // one Estimator::Propagate per IMU sample; the transitions of all samples are accumulated in Phi so that the
-  // O(23 N) cross-covariance tail runs once per call instead of once per sample
-  // lanes 0..2 carry one component each of the next IMU sample (loaded one sample ahead: its latency hides behind
-  // the integration of the current one)
-  const xivo_imu_in* imu_f = a.imu + (long)filt * a.n_imu;
-  const int c3 = lane < 3 ? lane : 0;
-  double n_g = imu_f[0].gyro[c3], n_a = imu_f[0].accel[c3], n_sg = imu_f[0].slope_gyro[c3], n_sa = imu_f[0].slope_accel[c3];
-  double n_dt = imu_f[0].dt;
-  for (int smp = 0; smp < a.n_imu; ++smp) {
-  if (lane < 3) { nom[24 + lane] = n_g; nom[27 + lane] = n_a; nom[30 + lane] = n_sg; nom[33 + lane] = n_sa; }
-  const double dt = n_dt;
-  if (smp + 1 < a.n_imu) {
-    const xivo_imu_in& nx = imu_f[smp + 1];
-    n_g = nx.gyro[c3]; n_a = nx.accel[c3]; n_sg = nx.slope_gyro[c3]; n_sa = nx.slope_accel[c3]; n_dt = nx.dt;
-  }
-  __syncthreads();
-  double total = 0.0;
-  // fixed sub-stepping with the half-step tail trick (rk4.cpp:13-32, princedormand.cpp:62-81)
-  while (total < dt || a.stepsize < 0) {
-    double h = a.stepsize;
-    if (a.stepsize < 0) h = dt;
-    else if (total + h > dt) h = dt - total;
-    else if (total + h + 0.5 * h > dt) h = 0.5 * h;
-
-    // -- nominal pre-pass: wave w evaluates stages w, w + 4
-    for (int st = wave; st < NS; st += 4) {
-      MotionRegs X0; V3 Rg;
-      load_nominal(X0, Rg);
-      const double ti = tab.c_imu[st] * h;
-      V3 gi, ai;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { gi.v[i] = nom[24 + i] + nom[30 + i] * ti; ai.v[i] = nom[27 + i] + nom[33 + i] * ti; }
-      if (st > 0) {
-        const V3 V0{{0, 0, 0}};   // the a_ij-weighted velocities only move Tsb, which no Jacobian reads
-        compose_motion_dev(X0, V0, gi, ai, tab.c_step[st] * h, Rg);
-      }
-      // ComputeMotionJacobianAt (estimator.cpp:615-704): the blocks of F and G
-      V3 gc, ac;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { gc.v[i] = gi.v[i] - X0.bg.v[i]; ac.v[i] = ai.v[i] - X0.ba.v[i]; }
-      const M3 w_dW_dW = m3_neg(hat(gc));                         // Wsb <- Wsb ; Wsb <- bg is -I
-      const M3 w_dV_dW = m3_neg(m3_mul(X0.Rsb, hat(ac)));         // Vsb <- Wsb
-      const M3 w_dV_dWsg = m3_neg(m3_mul(X0.Rsb, hat(gv)));       // Vsb <- Wsg (first 2 columns)
-      const M3 w_nR = m3_neg(X0.Rsb);                             // Vsb <- ba, and G's Vsb <- accel-noise block
-      if (wl == 0) {
-        double* Jm = Jms + st * 36;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          sKs[3 * st + i] = X0.Vsb.v[i];
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            Jm[3 * i + j] = w_dW_dW.m[i][j]; Jm[9 + 3 * i + j] = w_dV_dW.m[i][j];
-            Jm[18 + 3 * i + j] = w_nR.m[i][j]; Jm[27 + 3 * i + j] = w_dV_dWsg.m[i][j];
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // the sub-step of the nominal state itself: wave 0, while the others start on phase A of stage 0
-    if (wave == 0) {
-      MotionRegs X; V3 Rg;
-      load_nominal(X, Rg);
-      V3 ge, ae, Kt{{0, 0, 0}};
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { ge.v[i] = nom[24 + i] + nom[30 + i] * h; ae.v[i] = nom[27 + i] + nom[33 + i] * h; }
-#pragma unroll
-      for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) Kt.v[i] += tab.b[q] * sKs[3 * q + i];
-      compose_motion_dev(X, Kt, ge, ae, h, Rg);
-      if (wl == 0) {                                 // (the next readers of nom sit behind the barriers of the stage loop)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) nom[3 * i + j] = X.Rsb.m[i][j];
-          nom[9 + i] = X.Tsb.v[i]; nom[12 + i] = X.Vsb.v[i];
-          nom[24 + i] = ge.v[i]; nom[27 + i] = ae.v[i];   // rk4.cpp:27-28: the next sub-step starts from the interpolated sample
-        }
-      }
-    }
-    // phase A of stage st: S = sum_q a_q FK_q (rows < 9), P0 = Pmm + (sum_q a_q PK_q) h (rk4.cpp:49-88), Vsb rows of G Q.
-    // It runs once before the stage loop for stage 0 and otherwise fused behind phase C of the stage before, whose
-    // thread owns the same elements: two barriers per stage.
-    auto phase_a = [&](int st) {
-      const double* Jm = Jms + st * 36;
-      double aq[NS - 1];
-#pragma unroll
-      for (int q = 0; q < NS - 1; ++q) aq[q] = tab.a[st][q];
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const int e = lane + NT * m;
-        if (e < NN) {
-          double sp = 0.0;
-#pragma unroll
-          for (int q = 0; q < NS - 1; ++q) sp += aq[q] * PKs[q * NN + e];
-          P0[e] = Pmm[e] + sp * h;
-        }
-      }
-      if (lane < NF) {
-        double sf = 0.0;
-#pragma unroll
-        for (int q = 0; q < NS - 1; ++q) sf += aq[q] * FKs[q * NF + lane];
-        S1[(lane % FR) + NM * (lane / FR)] = sf;
-      }
-      if (lane >= 64 && lane < 97) {                              // the stage's 33 state-dependent entries of F into its dense rows
-        const int l = lane - 64, blk = l < 27 ? l / 9 : 3, m = l - 9 * blk;
-        const int i = blk < 3 ? m / 3 : m / 2, j = blk < 3 ? m % 3 : m % 2;
-        // blocks: dW/dW -> rows 0..2, cols 0..2 ; dV/dW -> rows 6..8, cols 0..2 ; -Rsb -> rows 6..8, cols 12..14 ; dV/dWsg -> cols 21..22
-        const int row = blk == 0 ? i : 6 + i, col = blk < 2 ? j : (blk == 2 ? 12 + j : 21 + j);
-        F9[row + FR * col] = Jm[9 * blk + 3 * i + j];
-      }
-      if (lane >= 224 && lane < 236) {                            // (G Q)[Vsb_i, l] = sum_k -Rsb[i][k] Q[3 + k, l]
-        const int l = lane - 224;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          double v = 0.0;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) v = fma(Jm[18 + 3 * i + k], Q[(3 + k) + 12 * l], v);
-          GQc[(3 + i) + 12 * l] = v;
-        }
-      }
-    };
-    phase_a(0);
-    __syncthreads();
-    for (int st = 0; st < NS; ++st) {
-      const double* Jm = Jms + st * 36;
-      auto ldm = [&](int blk) {                                   // one published 3 x 3 block into registers
-        M3 r;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) r.m[i][j] = Jm[9 * blk + 3 * i + j];
-        return r;
-      };
-
-      // -- phase B: the structured products
-      if (wave < 3) {
-        const bool fk_task = wl >= 32;
-        const int j = fk_task ? wl - 32 : wl;
-        if (j < NM) {
-          const double* M = (fk_task ? S1 : P0) + NM * j;         // column j
-          double o[3];                                            // o = (F M)[block rows, j]
-          if (wave == 0) {                                        // Wsb rows: k = 0..2 (dW/dW), k = 9 + i (-1)
-            const M3 dW_dW = ldm(0);
-            const double m0 = M[0], m1 = M[1], m2 = M[2];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              double v = fma(dW_dW.m[i][0], m0, 0.0);
-              v = fma(dW_dW.m[i][1], m1, v);
-              v = fma(dW_dW.m[i][2], m2, v);
-              o[i] = fma(-1.0, M[9 + i], v);
-            }
-          } else if (wave == 1) {                                 // Tsb rows: k = 6 + i (1)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) o[i] = fma(1.0, M[6 + i], 0.0);
-          } else {                                                // Vsb rows: k = 0..2, 12..14, 21..22
-            const M3 dV_dW = ldm(1), nR = ldm(2), dV_dWsg = ldm(3);
-            const double m0 = M[0], m1 = M[1], m2 = M[2], m12 = M[12], m13 = M[13], m14 = M[14], m21 = M[21], m22 = M[22];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              double v = fma(dV_dW.m[i][0], m0, 0.0);
-              v = fma(dV_dW.m[i][1], m1, v);
-              v = fma(dV_dW.m[i][2], m2, v);
-              v = fma(nR.m[i][0], m12, v);
-              v = fma(nR.m[i][1], m13, v);
-              v = fma(nR.m[i][2], m14, v);
-              v = fma(dV_dWsg.m[i][0], m21, v);
-              o[i] = fma(dV_dWsg.m[i][1], m22, v);
-            }
-          }
-          if (fk_task) {                                          // FK_st = F + F S h
-#pragma unroll
-            for (int i = 0; i < 3; ++i) FKs[st * NF + (3 * wave + i) + FR * j] = F9[(3 * wave + i) + FR * j] + o[i] * h;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) FPs[(3 * wave + i) + FR * j] = o[i];
-          }
-        }
-      } else if (wl < NM) {                                       // (P0 F^T)[i, 0..8] = sum_k P0[i, k] F[j, k]
-        const int i = wl;
-        const M3 dW_dW = ldm(0), dV_dW = ldm(1), nR = ldm(2), dV_dWsg = ldm(3);
-        const double p0 = P0[i], p1 = P0[i + NM], p2 = P0[i + NM * 2];
-        const double p12 = P0[i + NM * 12], p13 = P0[i + NM * 13], p14 = P0[i + NM * 14];
-        const double p21 = P0[i + NM * 21], p22 = P0[i + NM * 22];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          double v = fma(p0, dW_dW.m[j][0], 0.0);
-          v = fma(p1, dW_dW.m[j][1], v);
-          v = fma(p2, dW_dW.m[j][2], v);
-          PFs[i + NM * j] = fma(P0[i + NM * (9 + j)], -1.0, v);
-          PFs[i + NM * (3 + j)] = fma(P0[i + NM * (6 + j)], 1.0, 0.0);
-          double w = fma(p0, dV_dW.m[j][0], 0.0);
-          w = fma(p1, dV_dW.m[j][1], w);
-          w = fma(p2, dV_dW.m[j][2], w);
-          w = fma(p12, nR.m[j][0], w);
-          w = fma(p13, nR.m[j][1], w);
-          w = fma(p14, nR.m[j][2], w);
-          w = fma(p21, dV_dWsg.m[j][0], w);
-          PFs[i + NM * (6 + j)] = fma(p22, dV_dWsg.m[j][1], w);
-        }
-      }
-      if (wave == 1 && wl < 12) {                                 // (G Q G^T)[r, :] on the 12 x 12 support (wave 1's F rows are trivial)
-        const int r = wl;
-        const M3 nR = ldm(2);
-        const double g3 = GQc[r + 12 * 3], g4 = GQc[r + 12 * 4], g5 = GQc[r + 12 * 5];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          GQG[r + 12 * j] = fma(GQc[r + 12 * j], -1.0, 0.0);     // Wsb columns: G[Wsb_j, j] = -1
-          double v = fma(g3, nR.m[j][0], 0.0);                    // Vsb columns: G[Vsb_j, 3..5] = -Rsb[j][:]
-          v = fma(g4, nR.m[j][1], v);
-          GQG[r + 12 * (3 + j)] = fma(g5, nR.m[j][2], v);
-          GQG[r + 12 * (6 + j)] = GQc[r + 12 * (6 + j)];          // bg, ba columns: +1
-          GQG[r + 12 * (9 + j)] = GQc[r + 12 * (9 + j)];
-        }
-      }
-      __syncthreads();
-
-      // -- phase C: PK_st = F P0 + P0 F^T + G Q G^T, then phase A of the next stage
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const int e = lane + NT * m;
-        if (e < NN) PKs[st * NN + e] = (sm[oFP[m]] + sm[oPF[m]]) + sm[oG[m]];
-      }
-      if (st + 1 < NS) phase_a(st + 1);
-      __syncthreads();
-    }
-    // combine the stages
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int e = lane + NT * m;
-      if (e < NN) {
-        double pk = 0.0;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) pk += tab.b[q] * PKs[q * NN + e];
-        Pmm[e] += pk * h;                            // rk4.cpp:92-93
-      }
-    }
-    if (lane < NF) {
-      const int i = lane % FR, j = lane / FR;
-      double fk = 0.0;
-#pragma unroll
-      for (int q = 0; q < NS; ++q) fk += tab.b[q] * FKs[q * NF + lane];
-      S1[i + NM * j] = (i == j ? 1.0 : 0.0) + fk * h;   // rows < 9 of Phi_step = I + FK h (the others are identity rows)
-    }
-    __syncthreads();
-    if (lane < NF) {                                 // Phi <- Phi_step Phi; rows >= 9 of Phi are identity rows: their
-      const int i = lane % FR, j = lane / FR;        // terms of the k-sum are 0 except S1(i, j) * 1 at k = j
-      double v = 0.0;
-#pragma unroll
-      for (int k = 0; k < FR; ++k) v = fma(S1[i + NM * k], Phi[k + FR * j], v);
-      if (j >= FR) v = fma(S1[i + NM * j], 1.0, v);
-      PhiN[lane] = v;
-    }
-    { double* t = Phi; Phi = PhiN; PhiN = t; }       // (next read of Phi / write of S1 lies behind the pre-pass barrier)
-    total += h;
-    if (a.stepsize < 0) break;
-  }
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {                      // P_mm += Qmodel (estimator.cpp:590), per Propagate; own elements only
-    const int e = lane + NT * m;
-    if (e < NN) Pmm[e] += qm[m];
-  }
-  }
-  __syncthreads();
-  // results for the tail kernel; nominal state back
-  for (int e = lane; e < NN; e += NT) {
-    const int i = e % NM, j = e / NM;
-    a.Pmm_out[(long)filt * NN + e] = Pmm[e];
-    a.Phi_out[(long)filt * NN + e] = i < FR ? Phi[i + FR * j] : (i == j ? 1.0 : 0.0);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      pose.Tsb[i] = nom[9 + i]; pose.Vsb[i] = nom[12 + i];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) pose.Rsb[i + 3 * j] = nom[3 * i + j];
-    }
-  }
-}
 
 // ---------------------------------------------------------------- propagation, online-calibration builds
 // The reference's USE_ONLINE_TEMPORAL_CALIB / USE_ONLINE_IMU_CALIB builds (src/core.h:49-75) carry td, Cg (9) and Ca (6) in the
@@ -3115,20 +2749,6 @@ int launch_propagate_cov(double* P, long strideP, int ldp, int N, int Np, int nm
   CHECK_LAUNCH();
 }
 template <int NS>
-static int launch_propagate_state_ns(const PropStateArgs& a, hipStream_t s) {
-  // LDS: 4 matrices, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, stage velocities, per stage 36 Jacobian entries +
-  // FK (9 rows) + PK: RK4 50 KB (3 workgroups per CU), Dormand-Prince 68 KB (2)
-  const size_t lds = (size_t)(3 * 529 + 5 * 207 + 3 * 144 + 2 + 36 + 24 + NS * (36 + 207 + 529)) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_state_kernel<NS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(propagate_state_kernel<NS>, dim3(a.batch), dim3(256), lds, s, a);
-  CHECK_LAUNCH();
-}
-template <int NS>
 static int launch_propagate_state_wave(const PropStateArgs& a, hipStream_t s) {
   // LDS: P0, S1, F P0 / P0 F^T scratch, Q / GQ / GQG^T supports, nominal state, F9, two transition buffers, per stage 36
   // Jacobian entries + FK: RK4 28 KB (5 filters per CU), Dormand-Prince 34 KB (4)
@@ -3159,14 +2779,9 @@ int launch_propagate_state_calib(const PropStateArgs& a, hipStream_t s) {
   return a.method ? launch_propagate_state_calib_ns<7>(a, s) : launch_propagate_state_calib_ns<4>(a, s);
 }
 
-bool propagate_uses_wave_kernel() {
-  static const bool wg = getenv("XIVO_HIP_PROP_WG") != nullptr;   // A/B knob: the four-wave workgroup kernel
-  return !wg;
-}
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s) {
   if (a.batch <= 0) return 0;
-  if (propagate_uses_wave_kernel()) return a.method ? launch_propagate_state_wave<7>(a, s) : launch_propagate_state_wave<4>(a, s);
-  return a.method ? launch_propagate_state_ns<7>(a, s) : launch_propagate_state_ns<4>(a, s);
+  return a.method ? launch_propagate_state_wave<7>(a, s) : launch_propagate_state_wave<4>(a, s);
 }
 int launch_mfma_peak(double* sink, int iters, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, sink, iters);

@@ -892,14 +892,12 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
   // (P H^T without the prefetch too: the slot values are staged once per filter instead of once per slab,
   //  3.2 -> 2.9 ms per 16384 filters)
   a.slabs_per_wg = ((ell_tile_pf(MODE, CWU, XC, PWU) || MODE == ELL_HP) && a.batch >= 1024) ? xchunks : 1;
-  if (const char* e = getenv("XIVO_HIP_ELL_SPW")) a.slabs_per_wg = atoi(e) > 0 ? atoi(e) : a.slabs_per_wg;   // A/B knob
   const int wgs = (xchunks + a.slabs_per_wg - 1) / a.slabs_per_wg;
   int grid = ((a.batch + 7) / 8) * 8 * wgs;
   // persistent form of the prefetching instantiation: one workgroup per CU (they own the LDS one at a time anyway) walks
   // filters b, b + G, ...; G a multiple of 8 keeps a filter on the XCD its index names
   a.persist_stride = 0;
-  static const bool no_persist = getenv("XIVO_HIP_ELL_NO_PERSIST") != nullptr;   // A/B knob
-  if (ell_tile_pf(MODE, CWU, XC, PWU) && wgs == 1 && !no_persist) {
+  if (ell_tile_pf(MODE, CWU, XC, PWU) && wgs == 1) {
     static int cus = 0;
     if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus < 8) cus = 8; }
     const int G = cus / 8 * 8;
@@ -914,7 +912,6 @@ static int launch_ell_tile_t(const EllMulArgs& a_in, size_t lds, hipStream_t s) 
 }
 // which form / instantiation the launcher picks: xc = 64 / 32 (slab form) or 0 (gather form)
 static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, int* pwu, size_t* lds) {
-  static const bool no_tile = getenv("XIVO_HIP_ELL_GATHER") != nullptr;   // A/B knob: force the gather form
   *cwu = a.nc_max <= 12 ? 12 : ELL_CW;
   *pwu = (*cwu == 12 && a.pw_max > 0 && a.pw_max <= 9) ? 9 : ELL_PW;
   const size_t pidx = ((size_t)(a.Mp / 2) * ELL_PIW + ELL_CW) * sizeof(unsigned short);   // the private slot indices, 16 bits each, + the common ones
@@ -922,9 +919,7 @@ static void ell_pick(const EllMulArgs& a, int* xc, int* cwu, int* pwu, size_t* l
   const size_t lds64 = (size_t)a.cols * 64 * sizeof(double) + ops, lds32 = (size_t)a.cols * 32 * sizeof(double) + ops;
   const size_t cap = 160 * 1024;
   *xc = 0; *lds = 0;
-  if (no_tile) return;
-  static const bool force32 = getenv("XIVO_HIP_ELL_XC32") != nullptr;   // A/B knob: 32-wide slabs wherever they fit
-  if (lds64 <= cap && !force32) { *xc = 64; *lds = lds64; return; }
+  if (lds64 <= cap) { *xc = 64; *lds = lds64; return; }
   if (lds32 <= cap) { *xc = 32; *lds = lds32; }
 }
 
@@ -974,7 +969,6 @@ int launch_ell_mul(int mode, const EllMulArgs& a_in, hipStream_t s) {
   const int nrb = a.Mp / 16;
   // big batch: one workgroup per (filter, chunk) walks all row blocks; small batch: spread them
   a.rb_per_wg = (long)a.batch * xchunks >= 2048 ? nrb : ((long)a.batch * xchunks >= 512 ? (nrb + 1) / 2 : 1);
-  if (const char* e = getenv("XIVO_HIP_ELL_RB")) a.rb_per_wg = atoi(e) > 0 ? atoi(e) : a.rb_per_wg;   // A/B knob
   const int rsplit = (nrb + a.rb_per_wg - 1) / a.rb_per_wg;
   const int grid = ((a.batch + 7) / 8) * 8 * rsplit * xchunks;
   // common slots actually in use, rounded to the instantiated widths

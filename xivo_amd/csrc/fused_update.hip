@@ -841,8 +841,7 @@ int launch_fused_update_t(const FusedArgs& g, hipStream_t stream) {
 
 // instantiations (NBM, NWV, XC; x two gather depths): <4, 16, 64> M <= 64 on any state one workgroup holds (128 VGPRs; <4, 16, 32>: where the 64-wide slab does not fit next to S); <7, 12, 48> (slab in three passes; <7, 12, 32>: four, where 48 columns do not fit) M <= 112, N <= 192 (168 VGPRs)
 static int fused_pick(int Mp, int Np) {
-  static const bool off = getenv("XIVO_HIP_NO_FUSED_UPDATE") != nullptr;   // A/B knob: the five-kernel pipeline
-  if (off || Np % 16 || Mp % 16 || Np < 16 || Mp < 16) return 0;
+  if (Np % 16 || Mp % 16 || Np < 16 || Mp < 16) return 0;   // (A/B against the multi-kernel pipeline: XIVO_HIP_FLAG_MULTI_KERNEL)
   const int nb = Mp / 16, nwl = Np / 16;
   if (nb <= 4 && nwl <= 16 && (size_t)fused_lds_map(Np, Mp, 64).total * 8 <= 160 * 1024) return 1;
   if (nb <= 4 && nwl <= 16 && (size_t)fused_lds_map(Np, Mp, 32).total * 8 <= 160 * 1024) return 3;

@@ -41,7 +41,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Compute-type traits: fp64 (default, the reference's arithmetic) or fp32 MFMA with fp32 accumulation
-// (XIVO_HIP_FLAG_FP32_COV: BASELINE.json config 4, covariance products only). Operands stay fp64 in HBM
+// (XIVO_HIP_FLAG_FP32_WHITENED: BASELINE.json config 4, the whitened correction product only). Operands stay fp64 in HBM
 // and are rounded to fp32 when they are written to LDS; results are widened on store.
 template <typename CT> struct Cx;
 // Optional (-DXIVO_MFMA44=1, off by default): fp64 products on v_mfma_f64_4x4x4_4b_f64. In a pure issue-rate probe
@@ -520,14 +520,6 @@ int pick_w(int dim) {
 }  // namespace
 
 void gemm_pick_tile(int Mp, int Np, int lower_only, int* WM, int* WN) {
-  if (const char* e = getenv("XIVO_HIP_TILE_RECT")) {   // A/B knob for non-square outputs
-    int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && Mp != Np) { *WM = a; *WN = b; return; }
-  }
-  if (const char* e = getenv("XIVO_HIP_TILE")) {   // A/B knob: "wm,wn" for square outputs > 176
-    int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && Mp == Np && Mp > 176 && !lower_only) { *WM = a; *WN = b; return; }
-  }
   if (lower_only && Mp > 64) {  // symmetric output: square 128x128 tiles (strip-balanced diagonals)
     *WM = 4;
     *WN = 4;
@@ -563,8 +555,6 @@ void gemm_kernel_label(const GemmArgs& a, char* buf, size_t n) {
 
 int launch_gemm_nt_f64(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
-  static const bool no_strip = getenv("XIVO_HIP_NO_STRIP") != nullptr;   // A/B knob
-  if (no_strip && a.lower_only) a.lower_only = 2;
   int wm, wn;
   pick_for(a, &wm, &wn);
   if (wm == 3 && wn == 3 && a.lower_only == 1) a.lower_only = 2;   // diagonal tiles in full on the straight-line path, stored as lower triangle + mirror
@@ -584,15 +574,14 @@ static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
   // accumulators initialised from memory (T = K(HP) - P): the 64 extra loads per lane sit in the
   // tile prologue; the narrower 128x64 tile (3 instead of 2 workgroups per CU) hides them
   // (measured 0.54 vs 0.72 ms per 1024 filters at N=250)
-  if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT || a.epilogue == EPI_RSUB_MAT) && !a.lower_only && wm == 4 && wn == 4 &&
-      !getenv("XIVO_HIP_TILE"))
+  if ((a.epilogue == EPI_SUB_MAT || a.epilogue == EPI_ADD_MAT || a.epilogue == EPI_RSUB_MAT) && !a.lower_only && wm == 4 && wn == 4)
     wn = 2;
   // short contractions on a non-square output (the lead product of an online-calibration stacking: K = 48, three k-panels):
   // all prologue (the accumulators start from the output) and epilogue - small tiles, more workgroups in flight
   // (N = 276: <3,4> 1.20 -> <3,2> 0.85 ms per 4096 filters; <3,3> 1.0, <5,2> 1.35)
   {
     const int ktot = a.seg[0].K + (a.nseg > 1 ? a.seg[1].K : 0);
-    if (!a.lower_only && !a.fp32 && a.Mp != a.Np && ktot <= 64 && !getenv("XIVO_HIP_TILE_RECT")) {
+    if (!a.lower_only && !a.fp32 && a.Mp != a.Np && ktot <= 64) {
       if (a.Mp % 96 == 0) { wm = 3; wn = 2; }
       else if (a.Mp % 64 == 0) { wm = 2; wn = 2; }
     }
@@ -605,7 +594,7 @@ static void pick_for(const GemmArgs& a, int* wm_out, int* wn_out) {
   // 96 x 96 tiles on the instantiation that keeps four workgroups per CU (these products are short in K - M <= 304 - and
   // bound by the latency of their panel loads, not by MFMA or HBM: P - V^T Y 4.05 -> 2.45 ms per 4096 filters at N = 276,
   // 7.35 -> 6.9 ms at N = 400; the fp32 product of config 4 measured the same on either tile and keeps 128 x 128)
-  else if (a.lower_only && !a.fp32 && a.Mp == a.Np && (a.Mp % 96 == 0 || a.Mp > 256) && a.Mp % 128 != 0 && !getenv("XIVO_HIP_NO_TILE96")) { wm = 3; wn = 3; }
+  else if (a.lower_only && !a.fp32 && a.Mp == a.Np && (a.Mp % 96 == 0 || a.Mp > 256) && a.Mp % 128 != 0) { wm = 3; wn = 3; }
   *wm_out = wm; *wn_out = wn;
 }
 

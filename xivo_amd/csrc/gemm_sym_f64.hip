@@ -204,7 +204,6 @@ int launch_gemm_sym_f64(const GemmArgs& a, hipStream_t stream) {
     }
     if (ok && r == nb) { sg.n = gi; break; }
   }
-  static const int bk_env = getenv("XIVO_HIP_SYM_BK") ? atoi(getenv("XIVO_HIP_SYM_BK")) : 0;   // A/B knob
   // panel depth: 16 when <= 14 slots per wave suffice (252 VGPRs, no spills; 0.258 vs 0.273 ms for the
   // 160x160 S), else 8 (with 18 slots BK = 16 spills)
   int max_blocks0 = 0;
@@ -212,7 +211,7 @@ int launch_gemm_sym_f64(const GemmArgs& a, hipStream_t stream) {
     const int cnt = sg.r1[gi] * (sg.r1[gi] + 1) / 2 - sg.r0[gi] * (sg.r0[gi] + 1) / 2;
     if (cnt > max_blocks0) max_blocks0 = cnt;
   }
-  const int bk = bk_env ? bk_env : (max_blocks0 <= 56 ? 16 : 8);
+  const int bk = max_blocks0 <= 56 ? 16 : 8;
   int max_lds = 0;
   for (int gi = 0; gi < sg.n; ++gi) {
     const int nr = sg.r1[gi] - sg.r0[gi], nc = sg.r1[gi];

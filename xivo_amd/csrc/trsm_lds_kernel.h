@@ -1,6 +1,6 @@
 // The one-workgroup-per-filter solve kernel (trsm_lds_f64_kernel) and its symmetric tile walk, shared by chol_trsm.hip (every
-// TF variant on a factor that chol_f64.hip left in memory) and solve_fused.hip (the whitened Joseph update with the Cholesky
-// factorisation run inside the kernel, under the latency of its right-hand-side loads). See chol_trsm.hip for the algebra.
+// TF variant on a factor that chol_f64.hip left in memory), solve_fused.hip (its ten- / twelve-wave instantiations) and
+// fused_update.hip (the buffer helpers). See chol_trsm.hip for the algebra.
 #pragma once
 #include <stdlib.h>
 #include <stdio.h>
@@ -23,13 +23,6 @@
 // only, results unchanged; compiled out by default. Where the kernel's time goes: DESIGN.md 3.0.
 #ifndef XIVO_TRACE
 #define XIVO_TRACE 0
-#endif
-// XIVO_TRSM_LATE (A/B, round 5): the whitened in-solve kernel on a factor from memory requests only the first half of its
-// right-hand-side block rows in front of the factor copy and the second half behind it - those rows join the forward
-// substitution at step HX with their terms in the order the steps would have added them (the mechanism the in-kernel
-// factorisation uses: same bits), so that the first forward steps run under the arrival of the late rows.
-#ifndef XIVO_TRSM_LATE
-#define XIVO_TRSM_LATE 0
 #endif
 #if XIVO_TRACE
 __device__ unsigned long long xivo_trace_buf[512 * 32];
@@ -67,12 +60,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
-// XIVO_SOLVE_LD_NT (A/B, round 5): cache policy of the loads the kernel reads exactly once (right-hand sides, the tiles of P)
-#ifndef XIVO_SOLVE_LD_NT
-#define XIVO_SOLVE_LD_NT 0
-#endif
+// (loads the kernel reads exactly once - right-hand sides, the tiles of P: a non-temporal policy measured neutral, round 5)
 __device__ __forceinline__ double buf_ld_once(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, XIVO_SOLVE_LD_NT));
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 __device__ __forceinline__ void buf_st_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
@@ -80,13 +70,10 @@ __device__ __forceinline__ void buf_st_f32(float v, __amdgpu_buffer_rsrc_t r, un
 __device__ __forceinline__ void buf_st(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, 0);
 }
-// XIVO_PNEW_NT (A/B, round 5): cache policy of the stores of P+ in the product phase (gfx942+: bit 0 sc0, bit 1 nt, bit 4 sc1) -
-// the output is not read again before the next update's P H^T kernel, 16384 filters later
-#ifndef XIVO_PNEW_NT
-#define XIVO_PNEW_NT 0
-#endif
+// (stores of P+ in the product phase: default cache policy - nt / sc1 measured 4-11 % slower, round 5: the 32-byte pieces of the
+//  mirror stores merge into full lines in the L2 under the default policy)
 __device__ __forceinline__ void buf_st_out(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, XIVO_PNEW_NT);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bufu2, v), r, voff, soff, 0);
 }
 
 template <int NBM, bool SRC_REGS = false, bool NEG_OUT = false, bool FIXUP = false, bool YREGS = false, int NWV = 16>
@@ -234,25 +221,17 @@ __device__ __forceinline__ void sym_tiles_from_regs(const d4 (&X)[NBM], const d4
 // (conflict-free ds_read_b64) - and wave w forms the 16 x 16 tiles (w, j) for the j cyclically below it
 // (every unordered pair of blocks once: 8 or 9 tiles per wave), accumulators starting at -P, and writes each
 // tile and its mirror. K is never read back and H P is read once more instead of 1.5 times by the tiled GEMM.
-// CHOL (round 5; TF == 4, NBM <= 10): LU is S = H P H^T + diag(R) itself (lower triangle + diagonal blocks, as ell<S> / the
-// gate leave it) and the kernel factors it in LDS before it solves - under the latency of its right-hand-side loads, which
-// one workgroup per CU cannot hide behind anything else (the kernel's first 33 k cycles issued no MFMA). Block row i of the
-// factor belongs to wave i: per block column j its owner (wave j) forms the diagonal update, factors and inverts the 16 x 16
-// diagonal block (factor_invert_diag), one barrier, then waves i > j form L_ij = (S_ij - sum_k L_ik L_jk^T) L_jj^-T in place.
-// Same routines and the same operand order as chol_reg_f64_kernel / chol_f64_kernel: the SAME bits, so everything
-// behind it is unchanged - but L and inv(L_kk) never travel to HBM and back (2.5 GB written + 2.4 GB read per 16384 filters)
-// and the stand-alone Cholesky launch (1.7 ms) is gone. g.chol_status receives the factorisation status.
 // NWV / MINB (round 5): waves per workgroup and workgroups per CU the register budget is cut for. 16 / 1 is the kernel of
 // rounds 1-4 (one workgroup owns the CU). A state of at most 16 NWV columns with a short factor leaves room for MORE THAN ONE
 // workgroup per CU (BASELINE config 2: N = 150 -> ten waves, seven block rows: 76 KB of LDS, 96 VGPRs): the memory phases
 // of one filter (right-hand sides in, covariance tiles in and out) then run under the matrix phases of another - the
 // overlap a single workgroup cannot have, because one filter's working set fills the CU at the metric point.
-template <int NBM, int TF, bool CHOL = false, int NWV = 16, int MINB = 1>
+template <int NBM, int TF, int NWV = 16, int MINB = 1>
 __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g) {
   constexpr int BLK = 16 * 17;
   constexpr int NT = 64 * NWV;
-  static_assert(!CHOL || (TF == 4 && NBM <= 10), "in-kernel factorisation: whitened form, diagonal blocks in slots of their own");
-  // TF == 3 needs the diagonal blocks L_kk next to their inverses: in slots of their own while the LDS has room (<= 10
+  static_assert(TF != 3, "TF == 3 (the round-2 expanded Joseph form) was removed in round 6");
+  // the whitened form needs the diagonal blocks L_kk next to their inverses: in slots of their own while the LDS has room (<= 10
   // block rows), else packed into the unused upper triangle + pad row of the inverse's slot (a few selects per read)
   constexpr bool T4 = TF == 4 || TF == 5;   // whitened Joseph form; TF == 5: its outputs V^T, Y^T for a product outside the kernel
   constexpr bool WOUT = TF == 5;
@@ -260,8 +239,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
   // (also seven block rows on a ten- or twelve-wave workgroup that has the CU to itself: three waves per SIMD, 170 VGPRs
   //  each - BASELINE config 2)
   constexpr bool KEEPW = T4 && (NBM <= 6 || (NBM == 7 && NWV <= 12 && MINB <= 3));
-  constexpr bool PACK = (TF == 3 || T4) && NBM > 10;
-  constexpr bool LATE = CHOL || (XIVO_TRSM_LATE && TF == 4 && NWV == 16 && NBM > 6 && NBM <= 10);   // right-hand sides in two halves
+  constexpr bool PACK = T4 && NBM > 10;
   extern __shared__ __attribute__((aligned(16))) double sL[];   // [nb(nb+1)/2][16 x 17]
   const int chunks = (g.Np + 16 * NWV - 1) / (16 * NWV);
   const int b = blockIdx.x;
@@ -291,29 +269,15 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
 #pragma unroll
     for (int i = 0; i < NBM; ++i) {
       if (i >= i0 && i < i1) {
-        if constexpr (LATE) {
-          // straight-line, unconditional loads (a block row past the factor / a wave past the state re-reads a valid block,
-          // its registers are never used): with the requests inside branches the compiler's wait-count bookkeeping gives up
-          // and the first use of ANY row waits for ALL of them - the late rows included
-          const int ib = i < nb ? i : nb - 1;
+        X[i] = d4{0.0, 0.0, 0.0, 0.0};
+        if (live && i < nb) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) X[i][r] = buf_ld(rPHT, live ? vPHT : (unsigned)(li + lg * g.ldpht) * 8u, (unsigned)((16 * ib + 4 * r) * g.ldpht) * 8u);
-        } else {
-          X[i] = d4{0.0, 0.0, 0.0, 0.0};
-          if (live && i < nb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) X[i][r] = buf_ld_once(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u);
-          }
+          for (int r = 0; r < 4; ++r) X[i][r] = buf_ld_once(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u);
         }
       }
     }
   };
-  // CHOL: S is brought into LDS first, then block rows [0, HX) of the right-hand sides are requested and the factorisation runs
-  // under them (the kernel lives on 128 VGPRs: all NBM block rows in flight leave the factorisation no registers, and a
-  // spill reload waits for every load in front of it); rows [HX, NBM) are requested when the factor is done and join the
-  // forward substitution at step HX - each row still accumulates its terms in the same order, so nothing changes bit-wise
-  constexpr int HX = LATE ? (NBM + 1) / 2 : NBM;
-  if constexpr (!CHOL) load_rhs(0, HX);
+  load_rhs(0, NBM);
   d4 Wk[KEEPW ? NBM : 1];                           // (KEEPW) the forward-substituted columns, kept next to the working copy
 #pragma unroll
   for (int i = 0; i < (KEEPW ? NBM : 1); ++i) Wk[i] = d4{0.0, 0.0, 0.0, 0.0};
@@ -322,10 +286,10 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
   // the first of them is consumed (compile-time trip count): the loop used to wait for each of its ~7 round trips in turn,
   // on a CU that has nothing else to run meanwhile. (All of them at once would spill: the right-hand sides are in flight.)
   const int nblk = nb * (nb + 1) / 2;
-  constexpr bool DIAG = !PACK && (TF == 3 || T4);                    // the diagonal blocks L_kk in slots of their own
+  constexpr bool DIAG = !PACK && T4;                                  // the diagonal blocks L_kk in slots of their own
   constexpr int CPY = (NBM * (NBM + 1) / 2 * 128 + NT - 1) / NT;     // d2 loads per thread: factor ...
   constexpr int CPD = DIAG ? (NBM * 128 + NT - 1) / NT : 0;         // ... + diagonal blocks
-  constexpr int CPB = CHOL ? CPY + CPD : 4;                           // loads in flight per thread (CHOL: all of S at once - no right-hand sides in the registers yet)
+  constexpr int CPB = 4;                                              // loads in flight per thread
   double* sD = sL + nblk * BLK;                                       // (upper triangle zeroed)
 #pragma unroll
   for (int u0 = 0; u0 < CPY + CPD; u0 += CPB) {
@@ -342,8 +306,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
           while ((i + 1) * (i + 2) / 2 <= t) ++i;            // block row of slot t (nb <= 24: a few iterations)
           const int k = t - i * (i + 1) / 2;
           const int r = (w & 7) * 2, c = w >> 3;             // rows r, r+1 of column c
-          if (!(CHOL && i == k))      // (CHOL: the diagonal slot receives inv(L_kk) from the factorisation below)
-            cv[q] = *reinterpret_cast<const d2*>(i != k ? LU + (16 * i + r) + (long)(16 * k + c) * ld : invD + (long)k * 512 + r + 16 * c);
+          cv[q] = *reinterpret_cast<const d2*>(i != k ? LU + (16 * i + r) + (long)(16 * k + c) * ld : invD + (long)k * 512 + r + 16 * c);
           if (PACK && i == k) { cu[q][0] = LU[(16 * k + c) + (long)(16 * k + r) * ld]; cu[q][1] = LU[(16 * k + c) + (long)(16 * k + r + 1) * ld]; }
         }
       } else if (u < CPY + CPD) {
@@ -391,108 +354,14 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
     }
   }
   XTR(1);
-  if constexpr (CHOL) {
-    __builtin_amdgcn_sched_barrier(0);
-    load_rhs(0, HX);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();                                 // (no vmcnt drain: the right-hand sides stay in flight)
-  } else if constexpr (LATE) {
-    __builtin_amdgcn_sched_barrier(0);
-    load_rhs(HX, NBM);                             // the late half: on its way while forward steps 0 .. HX - 1 run
-    __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();
-  } else __syncthreads();
+  __syncthreads();
   XTR(2);
   if (!TF && !live) return;
-  int chol_bad = 0;
-  if constexpr (CHOL) {
-    // ---- S = L L^T in LDS (the right-hand sides requested above are still on their way)
-    // (the launcher hands the kernel all 160 KiB as dynamic LDS: no static allocation next to it - the flag sits behind the factor)
-    int& sBad = *reinterpret_cast<int*>(sD + nb * BLK);
-    if (tid == 0) sBad = 0;                                               // (ordered before its first use by the loop's barriers)
-    const int lo = li + 17 * lg;                                          // element (li, lg) of a padded 16 x 17 block
-#pragma unroll 1
-    for (int j = 0; j < nb; ++j) {
-      const int dj = (j * (j + 1) / 2 + j) * BLK;                         // diagonal slot: inv(L_jj)
-      if (wave == j) {
-        // owner: S_jj - sum_{k<j} L_jk L_jk^T (k ascending, k-slices 0, 2 and 1, 3 in two accumulators: chol_reg's order)
-        d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
-        const double* Lj = sL + (j * (j + 1) / 2) * BLK + lo;
-#pragma unroll 1
-        for (int k = 0; k < j; ++k) {
-          const double a0 = Lj[k * BLK], a1 = Lj[k * BLK + 68], a2 = Lj[k * BLK + 136], a3 = Lj[k * BLK + 204];
-          acc0 = mfma(a0, a0, acc0);
-          acc1 = mfma(a1, a1, acc1);
-          acc0 = mfma(a2, a2, acc0);
-          acc1 = mfma(a3, a3, acc1);
-        }
-        d4 x, y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = sD[j * BLK + lo + 68 * r] - (acc0[r] + acc1[r]);
-        int bad = 0;
-        factor_invert_diag(x, y, bad, 16 * j, li, lg);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = lg + 4 * r;
-          sD[j * BLK + li + 17 * c] = c <= li ? x[r] : 0.0;               // L_jj, upper triangle zero
-          sL[dj + c + 17 * li] = y[r];                                    // inv(L_jj)(c, li)
-        }
-        if (bad && lane == 0 && sBad == 0) sBad = bad;
-      }
-      lds_barrier();
-      if (wave > j && wave < nb) {
-        // L_ij^T = inv(L_jj) (S_ij^T - sum_{k<j} L_jk L_ik^T), i = wave, in place
-        const double* Lj = sL + (j * (j + 1) / 2) * BLK + lo;
-        double* Li = sL + (wave * (wave + 1) / 2) * BLK + lo;
-        d4 accA = d4{0.0, 0.0, 0.0, 0.0}, accB = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int k = 0; k < j; ++k) {
-          const double a0 = Lj[k * BLK], b0 = Li[k * BLK], a1 = Lj[k * BLK + 68], b1 = Li[k * BLK + 68];
-          accA = mfma(a0, b0, accA);
-          accB = mfma(a1, b1, accB);
-          const double a2 = Lj[k * BLK + 136], b2 = Li[k * BLK + 136], a3 = Lj[k * BLK + 204], b3 = Li[k * BLK + 204];
-          accA = mfma(a2, b2, accA);
-          accB = mfma(a3, b3, accB);
-        }
-        d4 rhs;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rhs[r] = Li[j * BLK + 68 * r] - (accA[r] + accB[r]);
-        d4 out = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) out = mfma(sL[dj + li + 17 * (4 * s4 + lg)], rhs[s4], out);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Li[j * BLK + 68 * r] = out[r];
-      }
-    }
-    lds_barrier();
-    chol_bad = sBad;
-    if (tid == 0 && g.chol_status) g.chol_status[filt] = chol_bad;
-    __builtin_amdgcn_sched_barrier(0);
-    load_rhs(HX, NBM);
-  }
-
   if (live) {
   // forward: L Y = HP
 #pragma unroll
   for (int k = 0; k < NBM; ++k) {
     if (k < nb && !(T4 && (XIVO_ABL == 2 || XIVO_ABL == 11))) {
-      if constexpr (LATE) {
-        if (k == HX) {   // the late block rows have arrived: the terms of steps 0 .. HX - 1, in the order the steps would have added them
-#pragma unroll
-          for (int kk = 0; kk < HX; ++kk) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-              for (int i = HX; i < NBM; ++i) {
-                if (i < nb) {
-                  const double a = sL[(i * (i + 1) / 2 + kk) * BLK + li + 17 * (4 * s + lg)];
-                  X[i] = mfma(-a, X[kk][s], X[i]);
-                }
-              }
-            }
-          }
-        }
-      }
       const double* Dk = sL + (k * (k + 1) / 2 + k) * BLK;
       d4 t = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -506,7 +375,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int i = k + 1; i < NBM; ++i) {
-          if (i < nb && (!LATE || k >= HX || i < HX)) {
+          if (i < nb) {
             const double a = sL[(i * (i + 1) / 2 + k) * BLK + li + 17 * (4 * s + lg)];
             X[i] = mfma(-a, t[s], X[i]);
           }
@@ -620,82 +489,12 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
   // whose antisymmetric last term drops out of the lower-triangle + mirror evaluation every pipeline here uses. The rows
   // of V^T = (W - D)^T are the register operand, W + D = 2 W - V the LDS operand (below).
 
-  if (TF == 3) {
-    // ---- the whole covariance update on the gain in registers (expanded Joseph form, see the launcher's comment):
-    //   V^T = L^T K^T (in place, ascending block rows), then L V^T (in place, descending) = (K L L^T)^T,
-    //   Z^T = 2 P H^T - K L L^T  [= P H^T - G,  G = K (L L^T) - P H^T the residual of the gain equation]
-#pragma unroll
-    for (int j = 0; j < NBM; ++j) {
-      if (j < nb) {
-        const double* Dj = PACK ? sL + (j * (j + 1) / 2 + j) * BLK : sD + j * BLK;
-        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {                                                                      // (L_jj)^T:
-          const int kk = 4 * s2 + lg;                                                                         // element (li, kk) = L_jj(kk, li)
-          if (PACK) {
-            const double a = Dj[kk > li ? li + 17 * kk : 16 + 17 * li];
-            acc = mfma(kk >= li ? a : 0.0, X[j][s2], acc);
-          } else {
-            acc = mfma(Dj[kk + 17 * li], X[j][s2], acc);
-          }
-        }
-#pragma unroll
-        for (int i = j + 1; i < NBM; ++i) {
-          if (i < nb) {
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-              acc = mfma(sL[(i * (i + 1) / 2 + j) * BLK + (4 * s2 + lg) + 17 * li], X[i][s2], acc);            // (L_ij)^T
-          }
-        }
-        X[j] = acc;
-      }
-    }
-#pragma unroll
-    for (int i = NBM - 1; i >= 0; --i) {
-      if (i < nb) {
-        const double* Di = PACK ? sL + (i * (i + 1) / 2 + i) * BLK : sD + i * BLK;
-        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {                                                                      // L_ii:
-          const int kk = 4 * s2 + lg;                                                                         // element (li, kk), stored transposed when packed
-          if (PACK) {
-            const double a = Di[li > kk ? kk + 17 * li : 16 + 17 * li];
-            acc = mfma(li >= kk ? a : 0.0, X[i][s2], acc);
-          } else {
-            acc = mfma(Di[li + 17 * kk], X[i][s2], acc);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < i; ++k) {
-#pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2)
-            acc = mfma(sL[(i * (i + 1) / 2 + k) * BLK + li + 17 * (4 * s2 + lg)], X[k][s2], acc);              // L_ik
-        }
-        X[i] = acc;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NBM; ++i) {
-      if (i < nb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X[i][r] = fma(2.0, buf_ld(rPHT, vPHT, (unsigned)((16 * i + 4 * r) * g.ldpht) * 8u), -X[i][r]);
-      }
-    }
-  }
   }
   if (!TF) return;
 
   XTR(5);
   __syncthreads();                                 // the factor is dead: the LDS takes the operands
   XTR(6);
-  if (TF == 3) {
-    // ---- P+ = P - Z^T K^T in place: rows of Z^T in registers, blocks of the gain just written arrive through LDS
-    if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
-    double* Pio = g.T + (long)filt * g.strideT;
-    sym_tiles_from_regs<NBM, false, true, false, false, NWV>(X, X, sL, g.K + (long)filt * g.strideK, g.ldk, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,
-                                          live, c0 >> 4, wave, lane);
-    return;
-  }
   if (T4) {
     if (WOUT) {   // whitened outputs only: V^T replaces the stash, the covariance product runs outside (tiled)
       if (live) {
@@ -710,7 +509,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void trsm_lds_f64_kernel(TrsmArgs g
       return;
     }
     // ---- P+ = P - (W - D)^T (W + D) in place: W arrives from the stash by DMA, the owner waves turn it into W + D
-    if (CHOL ? chol_bad != 0 : (g.skip_status && g.skip_status[filt] != 0)) return;   // S not positive definite: P stays the prior
+    if (g.skip_status && g.skip_status[filt] != 0) return;   // S not positive definite: P stays the prior
     if (XIVO_ABL == 1) return;
     double* Pio = g.T + (long)filt * g.strideT;
     if constexpr (KEEPW) sym_tiles_from_regs<NBM, true, true, false, true, NWV>(X, Wk, sL, nullptr, 0, Pio, g.ldt, Pio, g.ldt, nb, g.Np / 16, g.t_jbp,

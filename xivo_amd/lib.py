@@ -8,16 +8,9 @@ OOS_MAX_OBS = 16
 
 FLAG_FIX_GROUP_BLOCK = 1
 FLAG_PROFILE = 2
-FLAG_FULL_PNEW = 4
-FLAG_TILE_SYM = 8
-FLAG_REASSOC = 16
-FLAG_FP32_COV = 32
 FLAG_DENSE_H = 64
-FLAG_FP64_CORR = 128
 FLAG_SYMMETRIC_FORM = 256
 FLAG_STANDALONE_TAIL = 512
-FLAG_EXPANDED_JOSEPH = 1024
-FLAG_FP32_CORR = 2048
 FLAG_NO_LDLT_FALLBACK = 4096
 FLAG_FP32_WHITENED = 16384  # N > 256 / M > 176: V^T, Y^T as float, P - V^T Y on the fp32 MFMA
 FLAG_THROUGHPUT_ROUTE = 8192    # every batch size on the kernels sized for thousands of filters (default: <= 64 filters take the latency route)
@@ -123,6 +116,7 @@ _SIGS = {
                                   C.c_void_p, C.c_void_p],
     "xivo_hip_filter_update": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int],
     "xivo_hip_last_path": [C.c_void_p],
+    "xivo_hip_last_route": [C.c_void_p],
     "xivo_hip_stage_kernel": [C.c_void_p, C.c_int],
     "xivo_hip_stage_bytes": [C.c_void_p, C.c_int],
     "xivo_hip_absorb_error": [C.c_void_p, C.c_int],
@@ -174,7 +168,7 @@ def cam_intr(cam):
     return np.array([cam["fx"], cam["fy"], cam["cx"], cam["cy"]] + d[:5], dtype=np.float64)
 # every symbol include/xivo_hip.h declares (tests check the library exports them all)
 ALL_SYMBOLS = sorted(list(_SIGS) + ["xivo_hip_destroy", "xivo_hip_strerror", "xivo_hip_gemm_tile", "xivo_hip_device_count",
-                                        "xivo_hip_device_numa_node"])
+                                        "xivo_hip_device_numa_node", "xivo_hip_route_name"])
 
 
 def load_library():
@@ -200,6 +194,8 @@ def load_library():
     lib.xivo_hip_destroy.restype = None
     lib.xivo_hip_strerror.argtypes = [C.c_int]
     lib.xivo_hip_strerror.restype = C.c_char_p
+    lib.xivo_hip_route_name.argtypes = [C.c_int]
+    lib.xivo_hip_route_name.restype = C.c_char_p
     lib.xivo_hip_gemm_tile.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.xivo_hip_gemm_tile.restype = None
     lib.xivo_hip_stage_kernel.restype = C.c_char_p
@@ -521,8 +517,13 @@ class Context:
                                                     min_inliers, int(use_gating)))
 
     def last_path(self):
-        """0: dense as-coded pipeline, 1: sparse-H (row-pair compressed) pipeline."""
+        """0: dense rows, 1: sparse-H (row-pair compressed) rows."""
         return int(self.lib.xivo_hip_last_path(self.h))
+
+    def last_route(self):
+        """Name of the route the last update pass took (the table of plan_update in capi.hip): fused, sparse_in_solve,
+        sparse_whitened, sparse_symmetric, sparse_tail, dense_ascoded, dense_whitened, dense_symmetric."""
+        return self.lib.xivo_hip_route_name(int(self.lib.xivo_hip_last_route(self.h))).decode()
 
     def subfilter_update(self, feats, Rtri=3.5, MH_thresh=5.991, ready_steps=5, min_depth=0.05, max_depth=5.0,
                          max_subfilter_outlier=0.01, b0=0):
