@@ -60,6 +60,9 @@ extern "C" int xivo_hip_debug_read_fused_trace2(unsigned long long* out, int n) 
 #ifndef XIVO_FUSED_ABL
 #define XIVO_FUSED_ABL 0
 #endif
+#ifndef XIVO_FUSED_DIAG_CHAIN
+#define XIVO_FUSED_DIAG_CHAIN 0   // A/B: the sixteen-pivot chain (factor_invert_diag_chain) instead of the four-column form
+#endif
 #ifndef XIVO_FUSED_FWD_LATE
 #define XIVO_FUSED_FWD_LATE 0   // A/B: the forward substitution behind the factorisation instead of next to it
 #endif
@@ -536,7 +539,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
           for (int r = 0; r < 4; ++r) x[r] = sD[j * BLK + lo + 68 * r] - (acc0[r] + acc1[r]);
           int bad = 0;
           FTR2(4 * j + 1);
+#if XIVO_FUSED_DIAG_CHAIN
           factor_invert_diag_chain(x, y, bad, 16 * j, li, lg);
+#else
+          factor_invert_diag_blocked2<9>(x, y, bad, 16 * j, li, lg);
+#endif
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int c = lg + 4 * r;
