@@ -348,6 +348,17 @@ int xivo_hip_stack(xivo_hip_ctx* ctx, int B, double R);
  * intrinsics block; of the row builders in that file only ComputeLCJacobian has one (:125-142, xivo_hip_close_loop_stack). */
 int xivo_hip_oos_project(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xivo_oos_in* feats,
                          double Roos, int* rows_out);
+/* The same with options. XIVO_HIP_OOS_WHOLE_BUFFER reproduces src/oos.cpp:28 AS CODED: SlowGivens is handed the whole
+ * 2 * kMaxGroup-row buffers of the feature (src/jac.h:12-16), not the 2k rows ComputeOOSJacobianInternal filled, so every
+ * feature contributes 2 * kMaxGroup - 3 rows (kMaxGroup = the layout's n_groups) however many groups saw it. What the
+ * reference leaves in the rows behind 2k is unspecified (the buffers are Eigen::resize'd, never cleared); this mode defines
+ * them as zero, for which FullPivLU::kernel appends one unit vector per such row: the first 2k - 3 rows are those of the
+ * default call, the others are H = 0, inn = 0, diagR = Roos - they change M and S, not K, dx or P+. options = 0 is
+ * xivo_hip_oos_project (SURVEY 8 a9's specification: the top 2k rows). feats == NULL re-projects with the options of the
+ * call that uploaded the list. */
+#define XIVO_HIP_OOS_WHOLE_BUFFER 1u
+int xivo_hip_oos_project_ex(xivo_hip_ctx* ctx, int b0, int nb, int n_oos, const xivo_oos_in* feats,
+                            double Roos, int* rows_out, unsigned options);
 /* One loop-closure match (Estimator::CloseLoopInternal, src/update.cpp:171-212; the mapper that FINDS matches is out of
  * scope): an in-state feature ("old_feature") re-observed by the group in slot group_sind (Graph::LastAddedGroup) at pixel xp
  * (the observation of the new feature that was matched to it). */

@@ -661,13 +661,18 @@ def oos_jacobian_internal(Xs, Rsb, Tsb, Rbc, Tbc, xp_obs, cam, layout, g_sind):
     return Hf, Hx, inn
 
 
-def oos_jacobian(Xs, obs, groups_R, groups_T, Rbc, Tbc, cam, layout):
+def oos_jacobian(Xs, obs, groups_R, groups_T, Rbc, Tbc, cam, layout, whole_buffer_groups=0):
     """ComputeOOSJacobian on the 2k live rows (the reference passes the
     whole 2*kMaxGroup buffer, oos.cpp:28 - dead code there; this repo and the
     oracle project only the live rows). obs = [(g_sind, xp), ...].
-    Returns (Hx' [(2k-rank) x N], inn' [(2k-rank)], A)."""
+    Returns (Hx' [(2k-rank) x N], inn' [(2k-rank)], A).
+    whole_buffer_groups = kMaxGroup > 0: src/oos.cpp:28 AS CODED - SlowGivens gets the whole 2 kMaxGroup-row buffers
+    (src/jac.h:12-16 resizes them and nothing clears them: the rows behind 2k are taken as zero here), so
+    2 kMaxGroup - rank rows come back."""
     k = len(obs)
-    Hf = np.zeros((2 * k, 3)); Hx = np.zeros((2 * k, layout.N)); r = np.zeros(2 * k)
+    rows = 2 * whole_buffer_groups if whole_buffer_groups else 2 * k
+    assert rows >= 2 * k
+    Hf = np.zeros((rows, 3)); Hx = np.zeros((rows, layout.N)); r = np.zeros(rows)
     for c, (g, xp) in enumerate(obs):
         hf, hx, inn = oos_jacobian_internal(Xs, groups_R[g], groups_T[g], Rbc, Tbc, xp, cam, layout, g)
         Hf[2 * c:2 * c + 2] = hf; Hx[2 * c:2 * c + 2] = hx; r[2 * c:2 * c + 2] = inn

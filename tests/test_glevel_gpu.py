@@ -156,6 +156,57 @@ def test_oos_rows_match_slow_givens(built):
         assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
 
 
+def test_oos_rows_whole_buffer_mode_as_coded(built):
+    """XIVO_HIP_OOS_WHOLE_BUFFER (xivo_hip_oos_project_ex): src/oos.cpp:28 as coded hands SlowGivens the whole 2 kMaxGroup-row
+    buffers - every feature contributes 2 kMaxGroup - 3 rows. Against the oracle's FullPivLU kernel of the zero-padded
+    buffers: the same rows, inn, diagR; and the update (K, dx, P+) equals the default call's (the extra rows are zero)."""
+    cam = synth.PINHOLE
+    ng, nf, F, B, n_oos = 8, 6, 6, 2, 3
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, F, B, 5, cam, M_max=2 * F + 3 * 13)
+    rng = np.random.default_rng(9)
+    oos = np.zeros((B, n_oos), dtype=oos_dtype)
+    obs_all = {}
+    for b in range(B):
+        for o in range(n_oos):
+            k = [5, 2, 8][o]
+            Xs = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(3, 6)])
+            gs = rng.permutation(ng)[:k]
+            oos[b, o]["Xs"] = Xs; oos[b, o]["n_obs"] = k
+            obs = []
+            for q, g in enumerate(gs):
+                _, _, inn = orc.oos_jacobian_internal(Xs, sc["gR"][b, g], sc["gT"][b, g], sc["Rbc"][b], sc["Tbc"][b], [0, 0], cam, lay, int(g))
+                pix = -inn + rng.normal(0, 1.0, 2)
+                oos[b, o]["group_sind"][q] = g; oos[b, o]["xp"][q] = pix
+                obs.append((int(g), pix))
+            obs_all[b, o] = (Xs, obs)
+    P = np.array([spd(lay.N, 40 + b) * 1e-4 for b in range(B)])
+    out = {}
+    for whole in (False, True):
+        with make(ng, nf, F, B, 5, cam, M_max=2 * F + 3 * 13)[2] as c2:
+            c2.upload_P(P); c2.set_scene(poses, groups, feats)
+            c2.jacobians_instate(); c2.mh_gate(R_VIS, MH, MULT, 5); c2.stack(R_VIS)
+            rows = c2.oos_project(oos, 3.5 ** 2, whole_buffer=whole)
+            got = [c2.get_H(b) for b in range(B)]
+            c2.update_joseph()
+            out[whole] = (rows.tolist(), got, c2.get_err(), c2.download_P())
+    ctx.close()
+    assert out[False][0] == [7 + 1 + 13] * B and out[True][0] == [3 * (2 * ng - 3)] * B
+    for b in range(B):
+        Js, inns, _ = oracle_jacobians(sc, cam, lay, xp, b)
+        H, inn, dR = orc.stack_measurements(Js, inns, sc["ref"][b], sc["sind"][b], lay, R_VIS)
+        for o in range(n_oos):
+            Xs, obs = obs_all[b, o]
+            Hxp, rp, A = orc.oos_jacobian(Xs, obs, sc["gR"][b], sc["gT"][b], sc["Rbc"][b], sc["Tbc"][b], cam, lay, whole_buffer_groups=ng)
+            assert Hxp.shape[0] == 2 * ng - 3
+            H = np.vstack([H, Hxp]); inn = np.concatenate([inn, rp]); dR = np.concatenate([dR, np.full(len(rp), 3.5 ** 2)])
+        gH, ginn, gdR = out[True][1][b]
+        assert gH.shape == H.shape
+        assert rel_fro(gH, H) < 1e-10 and rel_fro(ginn, inn) < 1e-9 and np.array_equal(gdR, dR)
+        e_ref, P_ref, _ = orc.update_joseph(H, P[b], inn, dR)
+        assert rel_fro(out[True][3][b], P_ref) < TOL_P and rel_fro(out[True][2][b], e_ref) < TOL_DX
+        assert rel_fro(out[True][3][b], out[False][3][b]) < 1e-12 and rel_fro(out[True][2][b], out[False][2][b]) < 1e-10
+
+
 def test_p_edits_and_snapshot(built):
     N, B = 113, 3
     P = np.array([spd(N, 50 + b) for b in range(B)])

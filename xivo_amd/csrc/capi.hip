@@ -95,7 +95,7 @@ struct xivo_hip_ctx {
   int oos_cap = 0;
   int oos_row0 = -1;   // first row of the OOS block of the last xivo_hip_oos_project (-1: none since the last stacking)
   double oos_R = 0.0;
-  int oos_nb = 0, oos_n = 0, oos_max_rows = 0;   // shape of the resident OOS list (xivo_hip_oos_project with feats == NULL)
+  int oos_nb = 0, oos_n = 0, oos_max_rows = 0, oos_whole = 0;   // shape of the resident OOS list (xivo_hip_oos_project with feats == NULL)
   int* oos_rows = nullptr;
   xivo_calib_in* calib_rs = nullptr;            // BackupState of the calibration state (OnePointRANSAC, online-calibration builds)
   // online-calibration builds on the sparse pipeline (round 5): the calibration columns of the stacked rows as a dense
@@ -1648,10 +1648,19 @@ int xivo_hip_stack(xivo_hip_ctx* c, int B, double R) {
 
 int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_oos_in* feats, double Roos,
                          int* rows_out) {
+  return xivo_hip_oos_project_ex(c, b0, nb, n_oos, feats, Roos, rows_out, 0u);
+}
+
+int xivo_hip_oos_project_ex(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_oos_in* feats, double Roos,
+                            int* rows_out, unsigned options) {
   if (c && hipSetDevice(c->device) != hipSuccess) return XIVO_HIP_ERR_HIP;
   if (bad_range(c, b0, nb) || !c->have_layout || n_oos <= 0 || b0 != 0) return XIVO_HIP_ERR_INVALID;
+  if (options & ~XIVO_HIP_OOS_WHOLE_BUFFER) return XIVO_HIP_ERR_INVALID;
+  // XIVO_HIP_OOS_WHOLE_BUFFER (src/oos.cpp:28 as coded): SlowGivens sees the whole 2 kMaxGroup-row buffers of the feature, so
+  // every feature contributes 2 kMaxGroup - 3 rows; the rows behind its 2 k observations are zero (include/xivo_hip.h)
+  const int whole = (options & XIVO_HIP_OOS_WHOLE_BUFFER) ? 2 * c->lay.n_groups : 0;
   // feats == NULL: the list uploaded by the previous call is still resident (same nb, n_oos) - project it again
-  if (!feats && (!c->oos || c->oos_nb != nb || c->oos_n != n_oos)) return XIVO_HIP_ERR_INVALID;
+  if (!feats && (!c->oos || c->oos_nb != nb || c->oos_n != n_oos || c->oos_whole != whole)) return XIVO_HIP_ERR_INVALID;
   int max_rows = feats ? 0 : c->oos_max_rows;
   for (int b = 0; feats && b < nb; ++b) {
     int rows = 0;
@@ -1660,7 +1669,8 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
       if (f.n_obs < 2 || f.n_obs > XIVO_OOS_MAX_OBS) return XIVO_HIP_ERR_INVALID;
       for (int q = 0; q < f.n_obs; ++q)
         if (f.group_sind[q] < 0 || f.group_sind[q] >= c->lay.n_groups) return XIVO_HIP_ERR_INVALID;
-      rows += 2 * f.n_obs - 3;
+      if (whole && 2 * f.n_obs > whole) return XIVO_HIP_ERR_INVALID;     // (more observations than the reference's buffer has rows)
+      rows += whole ? whole - 3 : 2 * f.n_obs - 3;
     }
     if (rows > max_rows) max_rows = rows;
   }
@@ -1698,12 +1708,12 @@ int xivo_hip_oos_project(xivo_hip_ctx* c, int b0, int nb, int n_oos, const xivo_
   if (!c->oos_rows) { int rc = dev_alloc(&c->oos_rows, (size_t)c->Bmax); if (rc) return rc; }
   if (feats) {
     HIP_TRY(hipMemcpyAsync(c->oos, feats, (size_t)nb * n_oos * sizeof(xivo_oos_in), hipMemcpyHostToDevice, c->stream));
-    c->oos_nb = nb; c->oos_n = n_oos; c->oos_max_rows = max_rows;
+    c->oos_nb = nb; c->oos_n = n_oos; c->oos_max_rows = max_rows; c->oos_whole = whole;
   }
   OosArgs a{};
   a.feats = c->oos; a.n_oos = n_oos; a.poses = c->poses; a.groups = c->groups; a.lay = c->lay; a.cam = c->cam;
   a.calib = c->calib_on ? c->calib : nullptr; a.cam_dim = c->calib_on ? c->cl.cam_dim : 0;
-  a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos;
+  a.mb = meas_buffers(c); a.row0 = c->M; a.Mp = c->Mpmax; a.Np = c->Np; a.batch = nb; a.Roos = Roos; a.whole = whole;
   if (mixed) { a.mb.HT = nullptr; c->ht_valid = false; }
   c->oos_row0 = c->M; c->oos_R = Roos;
   a.rows_out = c->oos_rows;

@@ -181,6 +181,7 @@ struct OosArgs {
   int row0;            // first free row (after the in-state rows)
   int Mp, Np, batch; double Roos;
   int* rows_out;       // [batch]
+  int whole;           // 0, or the 2 kMaxGroup rows of the reference's per-feature buffers (XIVO_HIP_OOS_WHOLE_BUFFER)
 };
 int launch_oos(const OosArgs& a, hipStream_t s);
 

@@ -1161,10 +1161,10 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
     int r = a.row0;
     for (int q = 0; q < o; ++q) {
       const int kq = a.feats[(long)filt * a.n_oos + q].n_obs;
-      r += kq >= 2 ? 2 * kq - 3 : 0;
+      r += kq >= 2 ? (a.whole ? a.whole - 3 : 2 * kq - 3) : 0;
     }
     sRow0 = r;
-    if (o == a.n_oos - 1 && a.rows_out) a.rows_out[filt] = r + (k >= 2 ? 2 * k - 3 : 0) - a.row0;
+    if (o == a.n_oos - 1 && a.rows_out) a.rows_out[filt] = r + (k >= 2 ? (a.whole ? a.whole - 3 : 2 * k - 3) : 0) - a.row0;
   }
   // per-observation Jacobians (oos.cpp:39-89), one lane per observation
   if (lane < k) {
@@ -1348,6 +1348,18 @@ __global__ __launch_bounds__(64) void oos_kernel(OosArgs a) {
       }
       inn[row] = rr;
       dR[row] = a.Roos;
+    }
+  }
+  // src/oos.cpp:28 as coded hands SlowGivens the whole 2 kMaxGroup-row buffers: the rows behind the 2 k filled ones are zero
+  // columns of Hf^T - never a pivot, never moved by a column transposition of the three pivot steps - so FullPivLU::kernel
+  // appends one unit vector per such row behind the 2 k - 3 basis vectors above (checked against the oracle's
+  // restatement on the padded buffers, tests/test_oos_gpu.py): zero rows of H, inn = 0, diagR = Roos
+  if (a.whole && k >= 2) {
+    double* inn = a.mb.inn + (long)filt * a.mb.strideInn;
+    double* dR = a.mb.diagR + (long)filt * a.mb.strideR;
+    for (int r = nrows_res + lane; r < a.whole - 3; r += 64) {
+      const int row = sRow0 + r;
+      if (row < a.Mp) { inn[row] = 0.0; dR[row] = a.Roos; }
     }
   }
 }

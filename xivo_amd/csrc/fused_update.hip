@@ -56,7 +56,8 @@ extern "C" int xivo_hip_debug_read_fused_trace2(unsigned long long* out, int n) 
 #endif
 
 // XIVO_FUSED_ABL (timing-only ablations, scripts/build_variant.sh; results are WRONG for any value but 0): 1 stop behind the
-// gathers of phase 1, 2 stop behind the factorisation, 3 no stores of P+, 4 no mirror stores, 5 no loads of the P tiles
+// gathers of phase 1, 2 stop behind the factorisation, 3 no stores of P+, 4 no mirror stores, 5 no loads of the P tiles,
+// 6 stop in front of the factorisation, 8 no forward substitution next to the factorisation and stop behind it
 #ifndef XIVO_FUSED_ABL
 #define XIVO_FUSED_ABL 0
 #endif
@@ -493,6 +494,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
     }
   }
   FTR(4);
+  if (XIVO_FUSED_ABL == 6) {                                   // stop in front of the factorisation
+    double chk = 0.0;
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) chk += X[i][0] + X[i][1] + X[i][2] + X[i][3];
+    if (chk == 12345.678) g.err[(long)filt * g.strideErr + c0 + li] = chk;
+    return;
+  }
 
   // ---- 4  S = L L^T in LDS (trsm_lds_kernel.h, CHOL): block row i belongs to wave i. The forward substitution rides along:
   //         step k needs inv(L_kk) and the blocks L_ik below it - complete behind the barrier of column k + 1 - so every wave
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
           }
         }
         // (a broken factor leaves NaNs at worst: nothing of X is used then)
-        if (!XIVO_FUSED_FWD_LATE) {
+        if (!XIVO_FUSED_FWD_LATE && XIVO_FUSED_ABL != 8) {
           if (wave == j) static_for<NBM>([&](auto kc) { constexpr int k = decltype(kc)::value; if (k == j - 2) forward(kc); });
           if (wave != j + 1 || j + 1 >= nb) static_for<NBM>([&](auto kc) { constexpr int k = decltype(kc)::value; if (k == j - 1) forward(kc); });
         }
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
   const int chol_bad = sBad;
   if (tid == 0) g.status[filt] = chol_bad;
   FTR(5);
-  if (XIVO_FUSED_ABL == 2) {
+  if (XIVO_FUSED_ABL == 2 || XIVO_FUSED_ABL == 8) {
     double chk = 0.0;
 #pragma unroll
     for (int i = 0; i < NBM; ++i) chk += X[i][0] + X[i][1] + X[i][2] + X[i][3];

@@ -15,6 +15,7 @@ FLAG_NO_LDLT_FALLBACK = 4096
 FLAG_FP32_WHITENED = 16384  # N > 256 / M > 176: V^T, Y^T as float, P - V^T Y on the fp32 MFMA
 FLAG_THROUGHPUT_ROUTE = 8192    # every batch size on the kernels sized for thousands of filters (default: <= 64 filters take the latency route)
 FLAG_INVDEPTH = 32768           # USE_INVDEPTH build: features are (X/Z, Y/Z, 1/Z) (src/feature.cpp:98-105)
+OOS_WHOLE_BUFFER = 1             # xivo_hip_oos_project_ex options
 FLAG_MULTI_KERNEL = 65536       # keep shapes the one-kernel update holds (fused_update.hip) on the multi-kernel pipeline
 CAM_PINHOLE, CAM_ATAN, CAM_RADTAN, CAM_EQUI = 0, 1, 2, 3
 
@@ -110,6 +111,7 @@ _SIGS = {
                          C.c_void_p],
     "xivo_hip_stack": [C.c_void_p, C.c_int, C.c_double],
     "xivo_hip_oos_project": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p],
+    "xivo_hip_oos_project_ex": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_uint],
     "xivo_hip_close_loop_stack": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double],
     "xivo_hip_compress_oos": [C.c_void_p, C.c_int, C.c_double, C.c_void_p],
     "xivo_hip_one_point_ransac": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -469,8 +471,9 @@ class Context:
     def stack(self, R, B=None):
         self._check(self.lib.xivo_hip_stack(self.h, self.batch if B is None else B, R))
 
-    def oos_project(self, feats, Roos, want_rows=True):
-        """feats: [nb, n_oos] oos_dtype, or a (nb, n_oos) tuple to project the resident list of the last call again"""
+    def oos_project(self, feats, Roos, want_rows=True, whole_buffer=False):
+        """feats: [nb, n_oos] oos_dtype, or a (nb, n_oos) tuple to project the resident list of the last call again.
+        whole_buffer: XIVO_HIP_OOS_WHOLE_BUFFER - 2 * n_groups - 3 rows per feature, as src/oos.cpp:28 is coded"""
         if isinstance(feats, tuple):
             nb, n_oos = feats
             ptr = None
@@ -479,7 +482,8 @@ class Context:
             nb, n_oos = feats.shape
             ptr = _ptr(feats)
         rows = np.zeros(nb, dtype=np.int32) if want_rows else None
-        self._check(self.lib.xivo_hip_oos_project(self.h, 0, nb, n_oos, ptr, Roos, _ptr(rows) if want_rows else None))
+        self._check(self.lib.xivo_hip_oos_project_ex(self.h, 0, nb, n_oos, ptr, Roos, _ptr(rows) if want_rows else None,
+                                                     OOS_WHOLE_BUFFER if whole_buffer else 0))
         return rows
 
     def close_loop_stack(self, matches, Rlc, b0=0):
