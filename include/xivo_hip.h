@@ -463,6 +463,17 @@ typedef struct {
   double g[3];         /* gravity in the spatial frame before Rsg */
   int method;          /* 0: RK4, 1: PrinceDormand */
   double stepsize;     /* cfg integration stepsize (0.002); < 0: a single step of length dt */
+  /* cfg_["PrinceDormand"] of the step-size-controlled branch (src/princedormand.cpp:17-22, :26-60; off in every shipped
+   * configuration). control_stepsize != 0 (method 1 only, stepsize > 0) runs that branch AS CODED: PrinceDormandStep returns
+   * 0 - its error estimate is commented out (:216-220) - so every step is followed by h *= max_scale_factor, clipped to the
+   * end of the sample with the half-step rule (:53-58); a step starts from gyro0 + slope * total_step (:38-39), and the
+   * current step h is carried from one sample - and one call - to the next as the reference's function-local static does
+   * (:13; per filter here, (re)started at `stepsize` by the first controlled call of a context or a call with another
+   * stepsize). tolerance / min_scale_factor only enter through the dead err != 0 arm; attempts is read and never used (:19).
+   * All zero (the value-initialised struct of a caller that predates them): the fixed-step branch. */
+  int control_stepsize;
+  int attempts;
+  double tolerance, min_scale_factor, max_scale_factor;
 } xivo_prop_opts;
 /* imu: [nb][n_imu] - the n_imu samples of each filter since its last call (one Estimator::Propagate each, in order);
  * their transitions are accumulated on chip and the O(23 N) cross-covariance tail is applied once. */

@@ -469,6 +469,7 @@ void set_group(RefGroup& g, const double* R9, const double* T3, int sind) {
   g.X_.Rsb = so3_of(R9); g.X_.Tsb = Eigen::Map<const Vec3>(T3); g.sind_ = sind;
 }
 double g_stepsize_fixed = -12345.0;   // Estimator::RK4 / PrinceDormand read their step size ONCE per process into a function-local static
+std::map<std::string, double> g_pd_cfg;    // cfg_["PrinceDormand"] beyond "stepsize" (refx_pd_control)
 }  // namespace
 
 int refx_max_group(void) { return kMaxGroup; }
@@ -559,6 +560,15 @@ int refx_subfilter_update(double* x, double* P, const double* xp_meas, const dou
 // (src/princedormand.cpp:7-83) and their steps as extracted. dt = curr_time_ - last_time_ = dt_ns nanoseconds. The integrators
 // keep their step size in a function-local static that is read once per process: returns -1 if this process already fixed
 // another one. visual_meas = 0: slopes from (curr - last) / dt (:559-568); 1: slopes as handed in (:569-575).
+// The keys of cfg_["PrinceDormand"] that switch on the step-size-controlled branch of Estimator::PrinceDormand
+// (src/princedormand.cpp:17-22, :26-60). The extracted function reads them ONCE per process into function-local statics (and
+// keeps its current step `h` in another one): call this before the first refx_propagate of a process - the tests load a
+// private copy of this library for it.
+void refx_pd_control(int control_stepsize, double tolerance, int attempts, double min_scale_factor, double max_scale_factor) {
+  g_pd_cfg["control_stepsize"] = control_stepsize; g_pd_cfg["tolerance"] = tolerance; g_pd_cfg["attempts"] = attempts;
+  g_pd_cfg["min_scale_factor"] = min_scale_factor; g_pd_cfg["max_scale_factor"] = max_scale_factor;
+}
+
 int refx_propagate(int method, int visual_meas, double* state30_io, double* P_io, double* last_gyro_io, double* last_accel_io,
                    const double* curr_gyro, const double* curr_accel, double* slope_gyro_io, double* slope_accel_io, long long dt_ns,
                    const double* Qimu, const double* Qmodel, const double* g, const double* Cg, const double* Ca, double stepsize) {
@@ -568,6 +578,8 @@ int refx_propagate(int method, int visual_meas, double* state30_io, double* P_io
   RefEstimator e;
   RefJson ss; ss.num = stepsize;
   e.cfg_.kids["RK4"].kids["stepsize"] = ss; e.cfg_.kids["PrinceDormand"].kids["stepsize"] = ss;
+  // cfg_["PrinceDormand"]["control_stepsize"] etc. (src/princedormand.cpp:17-22), set once per process by refx_pd_control below
+  for (const auto& kv : g_pd_cfg) { RefJson v; v.num = kv.second; e.cfg_.kids["PrinceDormand"].kids[kv.first] = v; }
   e.integration_method_ = method == 0 ? "RK4" : "PrinceDormand";
   load_state(e.X_, state30_io);
   if (Cg) e.imu_.X_.Cg = Eigen::Map<const Mat3>(Cg);

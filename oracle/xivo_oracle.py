@@ -881,12 +881,58 @@ def integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab
     return X, P
 
 
+class PDControl:
+    """cfg_["PrinceDormand"] of the step-size-controlled branch (src/princedormand.cpp:17-24) plus the function-local static `h`
+    that branch carries from one call of Estimator::PrinceDormand to the next (:13, :27-33, :52)."""
+
+    def __init__(self, stepsize=0.002, tolerance=1e-3, attempts=12, min_scale_factor=0.125, max_scale_factor=4.0):
+        self.h0 = stepsize; self.h = stepsize
+        self.tolerance = tolerance; self.attempts = attempts          # (`attempts` is read and never used, :19)
+        self.min_scale_factor = min_scale_factor; self.max_scale_factor = max_scale_factor
+        self.steps = []                                               # the step lengths taken (what the reference prints, :49)
+
+
+def integrate_pd_controlled(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, ctl, Cg=None, Ca=None, layout=None):
+    """Estimator::PrinceDormand with control_stepsize = true (src/princedormand.cpp:26-60) AS CODED: PrinceDormandStep returns 0
+    (its error estimate is commented out, :216-220), so every step is followed by scale = max_scale_factor; the step starts from
+    gyro0 + slope * total_step (:38-39 - not the running sum of the fixed-step branch), and `h` survives the call."""
+    total = 0.0
+    h = ctl.h
+    if h < 1e-6:
+        h = ctl.h0
+    h = min(h, dt)
+    gyro0, accel0 = np.array(gyro0, float), np.array(accel0, float)
+    while total < dt:
+        X, P = integrator_step(X, P, gyro0 + slope_gyro * total, accel0 + slope_accel * total, slope_gyro, slope_accel, h, Qimu, g_vec,
+                               PD_TABLEAU, Cg, Ca, layout)
+        err = 0.0                                                     # :216-220
+        ctl.steps.append(h)
+        total += h
+        if err == 0.0:
+            scale = ctl.max_scale_factor
+        else:
+            scale = 0.8 * math.sqrt(math.sqrt(ctl.tolerance * h / err))
+            scale = min(max(scale, ctl.min_scale_factor), ctl.max_scale_factor)
+        h *= scale
+        if total < dt:
+            if total + h > dt:
+                h = dt - total
+            elif total + h + 0.5 * h > dt:
+                h = 0.5 * h
+    ctl.h = h
+    return X, P
+
+
 def propagate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, Qmodel, g_vec, method="RK4", stepsize=0.002,
-              Cg=None, Ca=None, layout=None):
+              Cg=None, Ca=None, layout=None, pd_control=None):
     """Estimator::Propagate's integration + P_mm += Qmodel (estimator.cpp:580-590); the IMU
     slope bookkeeping of :556-575 is the caller's. layout / Cg / Ca: online-calibration builds (Qmodel kMotionSize square)."""
     tab = RK4_TABLEAU if method == "RK4" else PD_TABLEAU
-    X, P = integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, stepsize, Cg, Ca, layout)
+    if pd_control is not None:                                        # control_stepsize = true (PDControl carries `h` between calls)
+        assert method != "RK4"
+        X, P = integrate_pd_controlled(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, pd_control, Cg, Ca, layout)
+    else:
+        X, P = integrate(X, P, gyro0, accel0, slope_gyro, slope_accel, dt, Qimu, g_vec, tab, stepsize, Cg, Ca, layout)
     P = P.copy()
     nm = K_MOTION if layout is None else layout.motion_size
     P[:nm, :nm] += Qmodel

@@ -502,6 +502,60 @@ def test_device_propagate_state_and_covariance(built, method, dt, stepsize, gyro
         assert np.array_equal(pose_d[b]["bg"], st[b].bg) and np.array_equal(pose_d[b]["ba"], st[b].ba)
 
 
+def test_device_prince_dormand_step_size_control_as_coded(built):
+    """xivo_prop_opts.control_stepsize: the step-size-controlled branch of Estimator::PrinceDormand (src/princedormand.cpp:26-60)
+    as coded - PrinceDormandStep returns 0 (:216-220), so the step grows by max_scale_factor after every step, clipped / halved
+    at the end of a sample (:53-58), started from gyro0 + slope * total_step (:38-39) and carried from sample to sample and
+    from call to call (the reference's function-local static). A chain of samples of different lengths, split over two calls
+    (three samples in one call, two in the next), per filter a different chain - against the oracle restatement that
+    tests/test_oracle_pinned.py pins to the extracted function (golden_v7), and against those stored outputs directly."""
+    import test_oracle_pinned as top
+    from xivo_amd.lib import imu_dtype
+    m7 = top._v7(); m6 = top._v6()
+    cam = synth.PINHOLE
+    B, ng, nf = 3, 15, 30                                 # the default build's sizes: N = 203, the golden chain's
+    sc, lay, ctx, poses, groups, feats, xp = make(ng, nf, nf, B, 21, cam)
+    assert lay.N == 203
+    chains = [m7.CHAIN_NS, m7.CHAIN_NS, (4000000, 2500000, 9000000, 600000, 3000000)]
+    seeds = [1, 2, 2]
+    cases = [m6.prop_case(sd) for sd in seeds]
+    for b in range(B):
+        X = cases[b]["X"]
+        poses[b]["Rsb"] = X.Rsb.T.reshape(-1); poses[b]["Tsb"] = X.Tsb
+        poses[b]["Vsb"] = X.Vsb; poses[b]["bg"] = X.bg; poses[b]["ba"] = X.ba; poses[b]["Rsg"] = X.Rsg.T.reshape(-1)
+    P = np.array([cases[b]["P"] for b in range(B)])
+    n = len(m7.CHAIN_NS)
+    imu = np.zeros((B, n), dtype=imu_dtype)
+    for b in range(B):
+        c = cases[b]
+        imu["gyro"][b] = c["gy"]; imu["accel"][b] = c["ac"]; imu["slope_gyro"][b] = c["sg"]; imu["slope_accel"][b] = c["sa"]
+        imu["dt"][b] = np.array(chains[b]) * 1e-9
+    c0 = cases[0]
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats)
+        with pytest.raises(Exception):                                     # RK4 has no such branch
+            ctx.propagate(imu[:, :1], c0["Qimu"], c0["Qmodel"], c0["g"], method="RK4", stepsize=0.002, pd_control=m7.PD_CTL)
+        ctx.propagate(imu[:, :3], c0["Qimu"], c0["Qmodel"], c0["g"], method="PrinceDormand", stepsize=0.002, pd_control=m7.PD_CTL)
+        ctx.propagate(imu[:, 3:], c0["Qimu"], c0["Qmodel"], c0["g"], method="PrinceDormand", stepsize=0.002, pd_control=m7.PD_CTL)
+        Pn = ctx.download_P()
+        pose_d, _, _ = ctx.get_scene()
+    for b in range(B):
+        c = cases[b]
+        ctl = orc.PDControl(stepsize=0.002, **m7.PD_CTL)
+        X = orc.MotionState(c["X"].Rsb.copy(), c["X"].Tsb.copy(), c["X"].Vsb.copy(), c["X"].bg.copy(), c["X"].ba.copy(), c["X"].Rsg.copy())
+        Pr = c["P"]
+        for dt_ns in chains[b]:
+            # (the same IMU sample every call - the chain of the golden file; Qimu / Qmodel / g are the first case's for every filter)
+            X, Pr = orc.propagate(X, Pr, c["gy"], c["ac"], c["sg"], c["sa"], dt_ns * 1e-9, c0["Qimu"], c0["Qmodel"], c0["g"],
+                                  method="PrinceDormand", stepsize=0.002, pd_control=ctl)[:2]
+        assert rel_fro(Pn[b], Pr) < 1e-11
+        assert np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - X.Rsb).max() < 1e-12
+        assert np.abs(pose_d[b]["Tsb"] - X.Tsb).max() < 1e-12 and np.abs(pose_d[b]["Vsb"] - X.Vsb).max() < 1e-12
+    k = f"pdc_s1_{n - 1}"                                                  # filter 0 is the stored chain of seed 1 itself
+    assert rel_fro(Pn[0][:23, :23], top.G7[k + "_Pmm"]) < 1e-10 and np.abs(pose_d[0]["Vsb"] - top.G7[k + "_Vsb"]).max() < 1e-11
+    assert rel_fro(Pn[0][:23, 23:] @ cases[0]["w"], top.G7[k + "_Pms_w"]) < 1e-10
+
+
 def test_resident_full_frame_loop(built):
     """The whole per-frame EKF loop with nothing but the IMU sample and the pixels crossing the boundary:
     Propagate -> ComputeInstateJacobians -> MHGating -> FilterUpdate -> AbsorbError, three frames, state and P

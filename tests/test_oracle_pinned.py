@@ -1003,3 +1003,57 @@ def test_extracted_one_point_ransac_calibration_build_live():
         assert np.array_equal(o["P"], P) and 0 < out["low"].sum() < c["nf"]
         # the partial update really moved the calibration columns
         assert np.abs(out["err"][lay.td]) > 0 and np.abs(out["err"][lay.cam_begin:lay.cam_begin + 4]).max() > 0
+
+
+# ---- round 6 pin: golden_v7.npz (tests/golden/make_golden_v7.py) - the step-size-controlled branch of Estimator::PrinceDormand ----
+G7 = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v7.npz"))
+
+
+def _v7():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_v7", os.path.join(os.path.dirname(__file__), "golden", "make_golden_v7.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def pd_control_chain_oracle(seed):
+    """The chain of make_golden_v7 through the oracle: (case, [(X, P) after every call], the step lengths taken)"""
+    m7 = _v7(); c = _v6().prop_case(seed)
+    ctl = orc.PDControl(stepsize=0.002, **m7.PD_CTL)
+    X = orc.MotionState(c["X"].Rsb.copy(), c["X"].Tsb.copy(), c["X"].Vsb.copy(), c["X"].bg.copy(), c["X"].ba.copy(), c["X"].Rsg.copy())
+    P = c["P"]
+    outs = []
+    for dt_ns in m7.CHAIN_NS:
+        X, P = orc.propagate(X, P, c["gy"], c["ac"], c["sg"], c["sa"], dt_ns * 1e-9, c["Qimu"], c["Qmodel"], c["g"], method="PrinceDormand",
+                             stepsize=0.002, pd_control=ctl)[:2]
+        outs.append((X, P))
+    return c, outs, ctl.steps
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_golden_v7_prince_dormand_step_size_control_as_coded(seed):
+    """oracle.integrate_pd_controlled against stored outputs of the extracted Estimator::PrinceDormand with control_stepsize = true
+    (src/princedormand.cpp:26-60): five Propagate calls in a row - the step the branch carries in a function-local static grows
+    4 x per step (PrinceDormandStep returns 0, :216-220) and is clipped / halved at the end of a sample (:53-58)."""
+    c, outs, steps = pd_control_chain_oracle(seed)
+    # (what the reference prints, :49)
+    assert np.allclose(steps, [0.002, 0.0005, 0.002, 0.005, 0.0025, 0.01, 0.002, 0.001], rtol=1e-12)
+    for i, (X, P) in enumerate(outs):
+        k = f"pdc_s{seed}_{i}"
+        assert rel(X.Rsb, G7[k + "_Rsb"]) < 1e-12 and rel(X.Tsb, G7[k + "_Tsb"]) < 1e-12 and rel(X.Vsb, G7[k + "_Vsb"]) < 1e-12
+        assert rel(P[:23, :23], G7[k + "_Pmm"]) < 1e-11 and rel(P[:23, 23:] @ c["w"], G7[k + "_Pms_w"]) < 1e-11
+
+
+def test_live_prince_dormand_step_size_control_vs_ref():
+    """The same chain on a private copy of the extracted library (fresh function-local statics), live"""
+    m7 = _v7()
+    try:
+        rx = m7.private_refx(203)
+    except (FileNotFoundError, OSError, TypeError):
+        pytest.skip("oracle/_ref not built")
+    if not hasattr(rx.lib, "refx_pd_control"):
+        pytest.skip("oracle/_ref predates refx_pd_control")
+    c, ref_outs = m7.run_chain(rx, 2)
+    _, outs, _ = pd_control_chain_oracle(2)
+    for (X, P), o in zip(outs, ref_outs):
+        assert rel(X.Rsb, o["Rsb"]) < 1e-12 and rel(X.Vsb, o["Vsb"]) < 1e-12 and rel(P[:23, :], o["P"][:23, :]) < 1e-11

@@ -95,6 +95,7 @@ struct xivo_hip_ctx {
   int oos_cap = 0;
   int oos_row0 = -1;   // first row of the OOS block of the last xivo_hip_oos_project (-1: none since the last stacking)
   double oos_R = 0.0;
+  double* pd_h = nullptr; double pd_h0 = 0.0;   // step-size-controlled Dormand-Prince: the step each filter carries (xivo_hip_propagate)
   int oos_nb = 0, oos_n = 0, oos_max_rows = 0, oos_whole = 0;   // shape of the resident OOS list (xivo_hip_oos_project with feats == NULL)
   int* oos_rows = nullptr;
   xivo_calib_in* calib_rs = nullptr;            // BackupState of the calibration state (OnePointRANSAC, online-calibration builds)
@@ -398,7 +399,7 @@ void xivo_hip_destroy(xivo_hip_ctx* c) {
   void* ptrs[] = {c->P, c->Psnap, c->H, c->HT, c->HP, c->PHT, c->S, c->K, c->A, c->T, c->invD, c->inn, c->diagR, c->err,
                   c->staging, c->scratch, c->neg1, c->yvec, c->status, c->poses, c->groups, c->feats, c->J, c->finn, c->dist,
                   c->mask, c->rows_instate, c->absorb_count, c->Prs, c->poses_rs, c->groups_rs, c->rs_low, c->rs_lowkeep, c->rs_keep,
-                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->calib_rs, c->Hlead, c->ldlt_used, c->calib, c->Jc};
+                  c->rs_zg, c->rs_gmask, c->rs_state, c->rs_gauge, c->rs_nrej, c->rs_chi, c->oos, c->oos_rows, c->ell.idx, c->ell.val, c->ell.nc, c->ell.pw, c->ell.over, c->sub, c->edit_buf, c->lc_buf, c->calib_rs, c->Hlead, c->ldlt_used, c->calib, c->Jc, c->pd_h};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ell_flags_h) hipHostFree(c->ell_flags_h);
   if (c->pin_h) hipHostFree(c->pin_h);
@@ -2195,6 +2196,15 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   for (size_t b = 0; b < (size_t)nb * n_imu; ++b)
     if (!(imu[b].dt > 0.0) || (o->stepsize >= 0 && o->stepsize < 1e-6)) return XIVO_HIP_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
+  // control_stepsize (src/princedormand.cpp:26-60): Dormand-Prince with a positive cfg step and a growth factor only
+  if (o->control_stepsize && (o->method != 1 || !(o->stepsize > 0) || !(o->max_scale_factor > 0))) return XIVO_HIP_ERR_INVALID;
+  if (o->control_stepsize && (!c->pd_h || c->pd_h0 != o->stepsize)) {
+    // the reference's function-local static `h` starts at the cfg step (:23): one per filter here
+    if (!c->pd_h) { int rcd = dev_alloc(&c->pd_h, (size_t)c->Bmax); if (rcd) return rcd; }
+    std::vector<double> h0((size_t)c->Bmax, o->stepsize);
+    HIP_TRY(hipMemcpy(c->pd_h, h0.data(), h0.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->pd_h0 = o->stepsize;
+  }
   const size_t per = 529;
   const size_t imu_d = ((size_t)nb * n_imu * sizeof(xivo_imu_in) + 7) / 8;      // in doubles
   int rc = ensure_staging(c, 2 * per * nb + 144 + 529 + imu_d);
@@ -2208,6 +2218,9 @@ int xivo_hip_propagate(xivo_hip_ctx* c, int b0, int nb, int n_imu, const xivo_im
   a.poses = c->poses + b0; a.imu = dImu; a.n_imu = n_imu; a.Qimu = dQi; a.Qmodel = dQm;
   a.g[0] = o->g[0]; a.g[1] = o->g[1]; a.g[2] = o->g[2]; a.method = o->method; a.stepsize = o->stepsize;
   a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
+  if (o->control_stepsize) {
+    a.pd_h = c->pd_h + b0; a.pd_tol = o->tolerance; a.pd_min_scale = o->min_scale_factor; a.pd_max_scale = o->max_scale_factor;
+  }
   {
     char plabel[64];
     snprintf(plabel, sizeof(plabel), "propagate_state_wave_kernel<%d>", a.method ? 7 : 4);
@@ -2240,6 +2253,7 @@ int xivo_hip_propagate_calib(xivo_hip_ctx* c, int b0, int nb, int n_imu, const x
     return XIVO_HIP_ERR_INVALID;
   const int nm = c->cl.Cg >= 0 ? c->cl.Cg + 15 : c->cl.td + 1;
   if (nm > 40 || c->N < nm || c->lay.group_begin < nm) return XIVO_HIP_ERR_INVALID;
+  if (o->control_stepsize) return XIVO_HIP_ERR_UNSUPPORTED;   // the step-size-controlled branch is built for the default motion block only
   if (nb == 0) return XIVO_HIP_OK;
   for (size_t b = 0; b < (size_t)nb * n_imu; ++b)
     if (!(imu[b].dt > 0.0) || (o->stepsize >= 0 && o->stepsize < 1e-6)) return XIVO_HIP_ERR_INVALID;

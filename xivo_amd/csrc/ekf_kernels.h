@@ -122,6 +122,9 @@ struct PropStateArgs {
   // online-calibration builds (launch_propagate_state_calib): motion size, slot of Cg (-1: none; Ca follows at + 9), the
   // resident calibration state (offset to b0); Qmodel is nm x nm
   int nm, iCg; const xivo_calib_in* calib;
+  // step-size-controlled Dormand-Prince (princedormand.cpp:26-60; default-build kernel only): the per-filter step carried between
+  // samples and calls (the reference's function-local static h), null = fixed steps
+  double* pd_h; double pd_tol, pd_min_scale, pd_max_scale;
 };
 int launch_propagate_state(const PropStateArgs& a, hipStream_t s);
 int launch_propagate_state_calib(const PropStateArgs& a, hipStream_t s);

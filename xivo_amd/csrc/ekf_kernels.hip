@@ -2023,9 +2023,17 @@ __global__ __launch_bounds__(64) void propagate_state_wave_kernel(PropStateArgs 
   const int c3 = lane < 3 ? lane : 0;
   double n_g = imu_f[0].gyro[c3], n_a = imu_f[0].accel[c3], n_sg = imu_f[0].slope_gyro[c3], n_sa = imu_f[0].slope_accel[c3];
   double n_dt = imu_f[0].dt;
+  // step-size-controlled Dormand-Prince (princedormand.cpp:26-60): the step the last sample - or the last call - left behind
+  const bool ctl = NS == 7 && a.pd_h != nullptr;
+  double hs = ctl ? a.pd_h[filt] : 0.0;
   for (int smp = 0; smp < a.n_imu; ++smp) {
     if (lane < 3) { nom[24 + lane] = n_g; nom[27 + lane] = n_a; nom[30 + lane] = n_sg; nom[33 + lane] = n_sa; }
     const double dt = n_dt;
+    const double cur_g = n_g, cur_a = n_a, cur_sg = n_sg, cur_sa = n_sa;     // (lanes 0-2: this sample as it arrived)
+    if (ctl) {
+      if (hs < 1e-6) hs = a.stepsize;        // :30-32
+      hs = fmin(hs, dt);                     // :34
+    }
     if (smp + 1 < a.n_imu) {
       const xivo_imu_in& nx = imu_f[smp + 1];
       n_g = nx.gyro[c3]; n_a = nx.accel[c3]; n_sg = nx.slope_gyro[c3]; n_sa = nx.slope_accel[c3]; n_dt = nx.dt;
@@ -2033,9 +2041,10 @@ __global__ __launch_bounds__(64) void propagate_state_wave_kernel(PropStateArgs 
     __syncthreads();
     double total = 0.0;
     // fixed sub-stepping with the half-step tail trick (rk4.cpp:13-32, princedormand.cpp:62-81)
-    while (total < dt || a.stepsize < 0) {
+    while (total < dt || (!ctl && a.stepsize < 0)) {
       double h = a.stepsize;
-      if (a.stepsize < 0) h = dt;
+      if (ctl) h = hs;
+      else if (a.stepsize < 0) h = dt;
       else if (total + h > dt) h = dt - total;
       else if (total + h + 0.5 * h > dt) h = 0.5 * h;
 
@@ -2257,12 +2266,26 @@ __global__ __launch_bounds__(64) void propagate_state_wave_kernel(PropStateArgs 
       }
       __syncthreads();
       total += h;
-      if (a.stepsize < 0) break;
+      if (ctl) {
+        const double err = 0.0;                // PrinceDormandStep returns 0: its error estimate is commented out (:216-220)
+        double scale;
+        if (err == 0.0) scale = a.pd_max_scale;                                                     // :42-43
+        else scale = fmin(fmax(0.8 * sqrt(sqrt(a.pd_tol * h / err)), a.pd_min_scale), a.pd_max_scale);   // :45-47
+        hs = h * scale;                                                                             // :51
+        if (total < dt) {                                                                           // :52-58
+          if (total + hs > dt) hs = dt - total;
+          else if (total + hs + 0.5 * hs > dt) hs = 0.5 * hs;
+        }
+        // the next step starts from gyro0 + slope * total_step (:38-39), not from the running sum of the fixed-step branch
+        if (lane < 3) { nom[24 + lane] = cur_g + cur_sg * total; nom[27 + lane] = cur_a + cur_sa * total; }
+        __syncthreads();
+      } else if (a.stepsize < 0) break;
     }
 #pragma unroll
     for (int m = 0; m < EL; ++m) Pmm[m] += a.Qmodel[min(lane + 64 * m, NN - 1)];   // P_mm += Qmodel (estimator.cpp:590), per Propagate
   }
   __syncthreads();
+  if (ctl && lane == 0) a.pd_h[filt] = hs;
 #pragma unroll
   for (int m = 0; m < EL; ++m) {
     const int e = lane + 64 * m;

@@ -57,8 +57,9 @@ lc_dtype = np.dtype([("feat", "i4"), ("group_sind", "i4"), ("xp", "f8", 2)])    
 assert lc_dtype.itemsize == 24
 imu_dtype = np.dtype([("gyro", "f8", 3), ("accel", "f8", 3), ("slope_gyro", "f8", 3), ("slope_accel", "f8", 3), ("dt", "f8")])
 prop_opts_dtype = np.dtype([("Qimu", "f8", 144), ("Qmodel", "f8", 529), ("g", "f8", 3), ("method", "i4"), ("_pad", "i4"),
-                            ("stepsize", "f8")])
-assert imu_dtype.itemsize == 104 and prop_opts_dtype.itemsize == (144 + 529 + 3) * 8 + 16
+                            ("stepsize", "f8"), ("control_stepsize", "i4"), ("attempts", "i4"), ("tolerance", "f8"),
+                            ("min_scale_factor", "f8"), ("max_scale_factor", "f8")])
+assert imu_dtype.itemsize == 104 and prop_opts_dtype.itemsize == (144 + 529 + 3) * 8 + 16 + 32
 subfilter_dtype = np.dtype([("x", "f8", 3), ("P", "f8", 9), ("xp", "f8", 2), ("outlier_counter", "f8"), ("score", "f8"),
                             ("ref_sind", "i4"), ("status", "i4"), ("init_counter", "i4"), ("candidate", "i4")])
 subfilter_opts_dtype = np.dtype([("Rtri", "f8"), ("MH_thresh", "f8"), ("ready_steps", "i4"), ("_pad", "i4"),
@@ -560,9 +561,10 @@ class Context:
         self._check(self.lib.xivo_hip_qr(self.h, nb, rows, nx, _ptr(xd), _ptr(Hxd), effective_rows, _ptr(ro)))
         return ro, xd, np.transpose(Hxd, (0, 2, 1)).copy()
 
-    def propagate(self, imu, Qimu, Qmodel, g, method="RK4", stepsize=0.002, b0=0):
+    def propagate(self, imu, Qimu, Qmodel, g, method="RK4", stepsize=0.002, b0=0, pd_control=None):
         """imu: [nb] or [nb, n_imu] array of imu_dtype (the samples since the last call, in order); Qimu 12x12,
-        Qmodel 23x23 (numpy row-major)."""
+        Qmodel 23x23 (numpy row-major). pd_control: dict(tolerance, attempts, min_scale_factor, max_scale_factor) switches on the
+        step-size-controlled branch of Estimator::PrinceDormand (src/princedormand.cpp:26-60, as coded)."""
         imu = np.ascontiguousarray(imu, dtype=imu_dtype)
         if imu.ndim == 1:
             imu = imu[:, None]
@@ -571,6 +573,10 @@ class Context:
         o["Qimu"] = np.asarray(Qimu, dtype=np.float64).T.reshape(-1)
         o["Qmodel"] = np.asarray(Qmodel, dtype=np.float64).T.reshape(-1)
         o["g"] = g; o["method"] = 0 if method == "RK4" else 1; o["stepsize"] = stepsize
+        if pd_control is not None:
+            o["control_stepsize"] = 1
+            o["tolerance"] = pd_control.get("tolerance", 1e-3); o["attempts"] = pd_control.get("attempts", 12)
+            o["min_scale_factor"] = pd_control.get("min_scale_factor", 0.125); o["max_scale_factor"] = pd_control.get("max_scale_factor", 4.0)
         self._check(self.lib.xivo_hip_propagate(self.h, b0, imu.shape[0], imu.shape[1], _ptr(imu), _ptr(o)))
 
     def propagate_calib(self, imu, Qimu, Qmodel, g, method="RK4", stepsize=0.002, b0=0):
