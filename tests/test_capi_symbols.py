@@ -89,7 +89,7 @@ def test_host_library_exports_the_batch_estimator(built):
                  "xivo_batch_book", "xivo_batch_stats", "xivo_batch_ctx", "xivo_host_selftest_update_step"):
         assert hasattr(host, name), name
     # the numpy mirror of struct xivo_batch_cfg (host/batch_estimator.cpp) has the size the C++ side compiled
-    assert batch.batch_cfg_dtype.itemsize == host.xivo_batch_cfg_size() == 5624
+    assert batch.batch_cfg_dtype.itemsize == host.xivo_batch_cfg_size() == 5656      # (round 6: + the 32 bytes of the control_stepsize fields of xivo_prop_opts)
 
 
 def test_candidate_comparison_order_matches_the_reference_as_coded():
