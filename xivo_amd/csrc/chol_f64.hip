@@ -14,6 +14,17 @@
 
 #include "mfma_util.h"
 #include "chol_device.h"
+
+// The diagonal-block step of both Cholesky kernels: the four-column form (chol_device.h, round 6; chol_S 1.95 -> 1.86 ms per 16384 at
+// M = 160, 2.65 -> 2.48 per 4096 at M = 300, 0.27 -> 0.25 at M = 120) - or, -DXIVO_CHOL_BLOCKED=0, the sixteen-column loop of rounds 3-5
+#ifndef XIVO_CHOL_BLOCKED
+#define XIVO_CHOL_BLOCKED 1
+#endif
+#if XIVO_CHOL_BLOCKED
+#define XIVO_CHOL_DIAG factor_invert_diag_blocked2<9>
+#else
+#define XIVO_CHOL_DIAG factor_invert_diag
+#endif
 #include "gate_device.h"
 
 namespace xivo_hip {
@@ -54,7 +65,7 @@ __global__ __launch_bounds__(64, 4) void chol_f64_kernel(CholArgs g) {
       d4 x, y;
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[r] = S[(16 * j + li) + (long)(16 * j + lg + 4 * r) * ld] - (acc0[r] + acc1[r]);
-      factor_invert_diag(x, y, bad, 16 * j, li, lg);
+      XIVO_CHOL_DIAG(x, y, bad, 16 * j, li, lg);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = lg + 4 * r;
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void chol_reg_f64_kernel(CholArgs g,
     if (wave == owner) {
       int bad = 0;
       d4 y;
-      factor_invert_diag(x, y, bad, 16 * j, li, lg);
+      XIVO_CHOL_DIAG(x, y, bad, 16 * j, li, lg);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = lg + 4 * r;
