@@ -64,6 +64,9 @@ extern "C" int xivo_hip_debug_read_fused_trace2(unsigned long long* out, int n) 
 #ifndef XIVO_FUSED_DIAG_CHAIN
 #define XIVO_FUSED_DIAG_CHAIN 0   // A/B: the sixteen-pivot chain (factor_invert_diag_chain) instead of the four-column form
 #endif
+#ifndef XIVO_FUSED_BALANCE
+#define XIVO_FUSED_BALANCE 1      // product tiles oriented by SIMD load at 10 / 13 column blocks (0: the cyclic rule everywhere)
+#endif
 #ifndef XIVO_FUSED_FWD_LATE
 #define XIVO_FUSED_FWD_LATE 0   // A/B: the forward substitution behind the factorisation instead of next to it
 #endif
@@ -119,16 +122,37 @@ __device__ __forceinline__ void fu_anchor(unsigned& a, int& b, double x, double 
 // tile, 46 k cycles for seven tiles of sixteen MFMAs. To keep the stores unconditional the diagonal tile writes ALL its
 // lanes twice: the direct pass stores the whole block (its upper half is then overwritten), the mirror pass stores the
 // transposed lower half into the upper half and, in the lower half, the direct pass's own value again.
-template <int NBM, int NTU>
+// Which wave forms which tile when the waves do not spread evenly over the four SIMDs (wave w runs on SIMD w % 4): ten column
+// blocks are 3 + 3 + 2 + 2 waves, thirteen 4 + 3 + 3 + 3, and with the cyclic rule above every wave forms the same number of
+// tiles - the SIMDs with one wave more set the time of the phase (18 against 12 tile slots; 28 against 21). Tile {a, b} can be
+// formed by wave a or by wave b (each holds its own row block of W - D in registers, W + D of every block is in LDS): these
+// tables orient the 45 / 78 pairs so that every SIMD forms 14 + 14 + 14 + 13 of the 55 tiles, or 23 + 23 + 23 + 22 of the 91
+// (a maximum-flow orientation, computed offline; the wave's own diagonal tile first, -1 = no tile).
+__device__ const signed char kFusedTiles10[10][8] = {
+    {0, 1, 3, 4, 5, -1, -1, -1}, {1, 2, 3, 4, 5, -1, -1, -1}, {2, 0, 3, 4, 5, 6, 8, -1}, {3, 4, 5, 6, 7, 8, 9, -1}, {4, 5, 6, 8, 9, -1, -1, -1},
+    {5, 7, 8, 9, -1, -1, -1, -1}, {6, 0, 1, 5, 7, 8, 9, -1}, {7, 0, 1, 2, 4, 8, 9, -1}, {8, 0, 1, 9, -1, -1, -1, -1}, {9, 0, 1, 2, -1, -1, -1, -1}};
+__device__ const signed char kFusedTiles13[13][8] = {
+    {0, 1, 2, 4, 6, 7, -1, -1}, {1, 2, 3, 4, 5, 6, 7, 9}, {2, 3, 4, 5, 6, 7, 8, 10}, {3, 0, 4, 5, 6, 7, 8, 10}, {4, 5, 8, 9, 10, 12, -1, -1},
+    {5, 0, 6, 7, 8, 9, 11, 12}, {6, 4, 7, 8, 9, 10, 11, 12}, {7, 4, 8, 9, 10, 11, 12, -1}, {8, 0, 1, 9, 11, 12, -1, -1}, {9, 0, 2, 3, 10, 11, 12, -1},
+    {10, 0, 1, 5, 8, 11, 12, -1}, {11, 0, 1, 2, 3, 4, 12, -1}, {12, 0, 1, 2, 3, -1, -1, -1}};
+
+// TAB = 0: the cyclic rule (tile t of wave w is the pair (w, w - t mod nwl), NTU = nwl / 2 + 1 tiles per wave, the last one a dummy
+// for half the waves of an even nwl); TAB = 10 / 13: the wave's list of the tables above, NTU of them, all real.
+template <int NBM, int NTU, int TAB = 0>
 __device__ __forceinline__ void fused_product_one_phase(const d4 (&X)[NBM], const double* ybuf, double* tsc, double* Pio, int ldp, int nb, int nwl,
                                                         int wave, int lane) {
   constexpr int PD = 4;
+  static_assert(NTU >= PD, "the prefetch ring is primed with PD tiles");
   const int li = lane & 15, lg = lane >> 4;
   const __amdgpu_buffer_rsrc_t rO = buf_rsrc(Pio);
   const unsigned vM = (unsigned)(li + lg * ldp) * 8u;
   auto block_of = [&](int t, int& jb, bool& real) {
-    jb = wave - t; if (jb < 0) jb += nwl;
-    real = 2 * t < nwl || (2 * t == nwl && wave > jb);
+    if constexpr (TAB == 10) { jb = __builtin_amdgcn_readfirstlane(kFusedTiles10[wave][t]); real = true; }
+    else if constexpr (TAB == 13) { jb = __builtin_amdgcn_readfirstlane(kFusedTiles13[wave][t]); real = true; }
+    else {
+      jb = wave - t; if (jb < 0) jb += nwl;
+      real = 2 * t < nwl || (2 * t == nwl && wave > jb);
+    }
   };
   d4 ring[PD];
   auto request = [&](auto tc) {
@@ -748,8 +772,20 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
     if (!early) __syncthreads();                   // the factor is dead: the LDS takes the operands
     write_y(0);
     if (nph == 1 && (nwl / 2 + 1 == 7 || nwl / 2 + 1 == 6)) {   // the two target shapes (13 / 10 column blocks): hand-counted waits
-      if (nwl / 2 + 1 == 7) fused_product_one_phase<NBM, 7>(X, sm, sm + g.tsc_off + wave * 256, Pio, g.ldp, nb, nwl, wave, lane);
-      else fused_product_one_phase<NBM, 6>(X, sm, sm + g.tsc_off + wave * 256, Pio, g.ldp, nb, nwl, wave, lane);
+      double* tscw = sm + g.tsc_off + wave * 256;
+      if (XIVO_FUSED_BALANCE && nwl == 10) {         // tiles oriented for 3 + 3 + 2 + 2 waves on the four SIMDs (tables above)
+        const int ntw = (wave == 2 || wave == 3 || wave == 6 || wave == 7) ? 7 : ((wave == 0 || wave == 1 || wave == 4) ? 5 : 4);
+        if (ntw == 7) fused_product_one_phase<NBM, 7, 10>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
+        else if (ntw == 5) fused_product_one_phase<NBM, 5, 10>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
+        else fused_product_one_phase<NBM, 4, 10>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
+      } else if (XIVO_FUSED_BALANCE && nwl == 13) {  // 4 + 3 + 3 + 3 waves
+        const int ntw = (wave == 12) ? 5 : ((wave & 3) == 0 ? 6 : ((wave == 7 || wave >= 9) ? 7 : 8));
+        if (ntw == 8) fused_product_one_phase<NBM, 8, 13>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
+        else if (ntw == 7) fused_product_one_phase<NBM, 7, 13>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
+        else if (ntw == 6) fused_product_one_phase<NBM, 6, 13>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
+        else fused_product_one_phase<NBM, 5, 13>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
+      } else if (nwl / 2 + 1 == 7) fused_product_one_phase<NBM, 7>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
+      else fused_product_one_phase<NBM, 6>(X, sm, tscw, Pio, g.ldp, nb, nwl, wave, lane);
       FTR(8);
       FTR2(31);
       return;
