@@ -18,7 +18,9 @@ if [ $PART = all ] || [ $PART = bench ]; then
 timeout 900 python bench.py --full-out $O/bench_full.json > $O/bench_default.json 2> $O/bench_default.err
 tail -c 300 $O/bench_default.json
 for n in 2 8; do
-HIP_VISIBLE_DEVICES=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2951$n bench.py --gpus $n --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-dropin > $O/bench_${n}ranks_on_1gpu.json 2> $O/bench_${n}ranks.err
+# (eight contexts of 16384 filters do not fit 288 GB: 4096 filters per rank there)
+B=16384; [ $n = 8 ] && B=4096
+HIP_VISIBLE_DEVICES=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2951$n bench.py --gpus $n --batch $B --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-dropin > $O/bench_${n}ranks_on_1gpu.json 2> $O/bench_${n}ranks.err
 tail -c 300 $O/bench_${n}ranks_on_1gpu.json
 done
 fi
