@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_sq; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-mixed --no-parity-check"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-mixed --no-parity-check --no-configs --no-dropin ${BENCH_ARGS:-}"
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES -d $O -o p1 --output-format csv -- $BENCH > $O/p1.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O -o p2 --output-format csv -- $BENCH > $O/p2.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH -d $O -o p3 --output-format csv -- $BENCH > $O/p3.log 2>&1
@@ -20,6 +20,6 @@ for p in ("p1","p2","p3"):
         k=r["Kernel_Name"].split("(")[0][-50:]
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[(k,r["Counter_Name"])]+=1
     for k,v in agg.items():
-        if "trsm" in k or "ell_tile" in k or "chol" in k:
+        if "trsm" in k or "ell_tile" in k or "chol" in k or "fused" in k:
             print(p, k, {c: round(val/max(1,n[(k,c)])/1e6,2) for c,val in v.items()}, "(M per dispatch)")
 PY
