@@ -93,6 +93,37 @@ def test_fused_update_against_the_multi_kernel_pipeline(built, N, F):
         assert rel_fro(out[0][0][b], out[1][0][b]) < 1e-10 and rel_fro(out[0][1][b], out[1][1][b]) < 1e-9
 
 
+@pytest.mark.parametrize("N,F", [(203, 30), (150, 50), (192, 56)])
+def test_fused_update_six_and_nine_private_slots(built, N, F):
+    """The kernel walks six private slots per row pair when no pair of the batch uses more (synth.s_level's rows: 12 common + 6
+    private columns) and nine otherwise (the in-state rows FillJacobianBlock stacks: group anchor 6 + feature 3): the same
+    batch with three more non-zero columns per pair takes the nine-slot instantiation - both against the oracle, the stage
+    label says which ran."""
+    B = 5
+    P, H, inn, dR = synth.s_level(N, F, B, seed=3 * N + F)
+    rng = np.random.default_rng(N + F)
+    H9 = H.copy()
+    for b in range(B):
+        for f in range(F):
+            free = np.nonzero(H[b, 2 * f] == 0)[0]
+            free = free[free >= 21]                             # behind the motion / extrinsics columns every pair names
+            cols = rng.choice(free, 3, replace=False)
+            for c_ in cols:
+                H9[b, 2 * f:2 * f + 2, c_] = rng.normal(size=2) * np.abs(H[b, 2 * f:2 * f + 2]).max()
+    for Hx, slots in ((H, 6), (H9, 9)):
+        with Context(N, 2 * F, B, flags=FLAG_PROFILE) as ctx:
+            ctx.upload_P(P); ctx.set_measurements(Hx, inn, dR); ctx.update_joseph()
+            label = ctx.profile_get()["trsm_gain"]["kernel"]
+            want = slots if (N, F) != (192, 56) else 9          # (the 32-column slab instantiations exist for nine slots only)
+            assert ctx.last_route() == "fused" and label.startswith("fused_update_f64_kernel") and label.endswith(",%d>" % want), label
+            assert (ctx.get_status() == 0).all()
+            Pn, err = ctx.download_P(), ctx.get_err()
+        for b in range(B):
+            e_ref, P_ref, _ = orc.update_joseph(Hx[b], P[b], inn[b], dR[b])
+            assert rel_fro(Pn[b], P_ref) < TOL_P and rel_fro(err[b], e_ref) < TOL_DX
+            assert np.array_equal(Pn[b], Pn[b].T)
+
+
 def test_fused_update_without_gate_and_chained(built):
     """xivo_hip_update_joseph (no gating) on the one-kernel route, three updates in a row on the resident covariance."""
     N, F, B = 203, 30, 6

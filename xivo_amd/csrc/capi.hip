@@ -776,14 +776,14 @@ static int update_sparse_range(xivo_hip_ctx* c, const UpdatePlan& plan, int b0, 
     FusedArgs a{};
     a.P = P; a.strideP = c->sP; a.ldp = Np; a.ell = e; a.inn = inn; a.strideInn = c->Mpmax; a.diagR = diagR; a.strideR = c->Mpmax;
     a.err = c->err + (long)b0 * Np; a.strideErr = Np; a.PHT = PHT; a.stridePHT = c->sK; a.ldpht = Np; a.status = c->status + b0;
-    a.Np = Np; a.Mp = Mp; a.batch = B;
+    a.Np = Np; a.Mp = Mp; a.batch = B; a.pw = pw_max;
     if (gate) {
       a.gate = 1; a.F = gate->F; a.R = gate->R; a.thresh = gate->thresh; a.mult = gate->mult; a.min_inliers = gate->min_inliers;
       a.mask = c->mask + (long)b0 * gate->F; a.dist = c->dist + (long)b0 * gate->F;
       if (c->dense_valid) { a.H = c->H + (long)b0 * c->sH; a.strideH = c->sH; a.ldh = ldh; a.HT = c->HT + (long)b0 * c->sHT; a.strideHT = c->sHT; a.ldht = Np; }
       c->gate_sparse_last = 0;
     }
-    char label[64]; fused_update_label(Mp, Np, label, sizeof(label));
+    char label[64]; fused_update_label(Mp, Np, pw_max, label, sizeof(label));
     const double t_outs_f = 0.5 * Nf * (Nf + 1.0);
     StageTimer st(c, ST_TRSM, (nnz_flops * (Nf + Mf) + Mf * Mf * Mf / 3.0 + 2.0 * Mf * Mf * Nf + 32.0 * Mf * Nf + 2.0 * t_outs_f * Mf) * B, label,
                   B * (16.0 * Np * Np + (Mp / 2) * ELL_W * 20.0));

@@ -18,11 +18,12 @@ struct FusedArgs {
   unsigned char* mask; double* dist;         // [batch x F]
   double* H; long strideH; int ldh;          // dense copies of the stacked rows kept consistent with the gate (or null)
   double* HT; long strideHT; int ldht;
+  int pw;                                    // widest private slot count of the batch (host copy of ell.pw): <= 6 takes the six-slot instantiation
   int jbp;                                   // (set by the launcher) column blocks per LDS phase of the product
   int tsc_off;                               // (set by the launcher) LDS offset (doubles) of the per-wave transpose scratch of the product
 };
 bool fused_update_supported(int Mp, int Np);
 int launch_fused_update(const FusedArgs& g, hipStream_t stream);
-void fused_update_label(int Mp, int Np, char* buf, size_t n);
+void fused_update_label(int Mp, int Np, int pw, char* buf, size_t n);
 
 }  // namespace xivo_hip

@@ -67,6 +67,9 @@ extern "C" int xivo_hip_debug_read_fused_trace2(unsigned long long* out, int n) 
 #ifndef XIVO_FUSED_BALANCE
 #define XIVO_FUSED_BALANCE 1      // product tiles oriented by SIMD load at 10 / 13 column blocks (0: the cyclic rule everywhere)
 #endif
+#ifndef XIVO_FUSED_TU
+#define XIVO_FUSED_TU 4
+#endif
 #ifndef XIVO_FUSED_FWD_LATE
 #define XIVO_FUSED_FWD_LATE 0   // A/B: the forward substitution behind the factorisation instead of next to it
 #endif
@@ -213,9 +216,13 @@ __device__ __forceinline__ void fused_product_one_phase(const d4 (&X)[NBM], cons
   });
 }
 
-template <int NBM, int NWV, int XC, int GD>
+// PW = private slots per row pair the kernel walks: 9 (group anchor 6 + feature 3: the in-state rows FillJacobianBlock stacks) or 6
+// for batches whose widest pair uses no more (the gather then needs 24 instead of 36 column pieces per unit - three 1 KB requests
+// instead of five - and the S walk six gathers per pair instead of nine). The LDS map keeps the 9-slot sizes either way.
+template <int NBM, int NWV, int XC, int GD, int PW>
 __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs g) {
-  constexpr int BLK = 16 * 17, CWU = FU_CWU, PWU = FU_PWU, NSLOT = FU_NSLOT, KS = CWU / 4, NC = XC / 16;
+  static_assert(PW == 9 || PW == 6, "private slots walked: a multiple of three (the S walk takes them three at a time)");
+  constexpr int BLK = 16 * 17, CWU = FU_CWU, PWU = PW, NSLOT = FU_CWU + PW, KS = CWU / 4, NC = XC / 16;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int filt = blockIdx.x;
   if (filt >= g.batch) return;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
     // wave are in flight in the (still unused) slab / factor region of the LDS; the lanes then pick their values with
     // ds_read_b64. Requests and waits are hand-placed: the DMA instructions and the empty asm statements that carry the
     // sums of the unit consumed before keep their order, s_waitcnt vmcnt(n) counts exactly the younger requests.
-    constexpr int NU = 2 * NBM, UI = 5, USZ = UI * 128;              // units; DMA instructions per unit; doubles per unit slot
+    constexpr int NU = 2 * NBM, UI = (4 * PWU + 7) / 8, USZ = UI * 128;   // units; DMA instructions per unit (eight pieces each); doubles per unit slot
     const unsigned long long pbase = reinterpret_cast<unsigned long long>(Pio);
     const fu_v4i rs = fu_v4i{(int)(unsigned)pbase, (int)(unsigned)(pbase >> 32), 0x7FFFFFFF, 0x00020000};   // (= buf_rsrc(Pio))
     const unsigned ld8 = (unsigned)g.ldp * 8u;
@@ -854,7 +861,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void fused_update_f64_kernel(FusedArgs
   FTR2(31);
 }
 
-template <int NBM, int NWV, int XC, int GD>
+template <int NBM, int NWV, int XC, int GD, int PW>
 int launch_fused_update_g(const FusedArgs& g_in, hipStream_t stream) {
   FusedArgs g = g_in;
   const int nb = g.Mp / 16, nwl = g.Np / 16;
@@ -872,20 +879,34 @@ int launch_fused_update_g(const FusedArgs& g_in, hipStream_t stream) {
   if (opbytes + tsc > lds) lds = opbytes + tsc;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_update_f64_kernel<NBM, NWV, XC, GD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_update_f64_kernel<NBM, NWV, XC, GD, PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     attr_set = true;
   }
-  hipLaunchKernelGGL((fused_update_f64_kernel<NBM, NWV, XC, GD>), dim3(g.batch), dim3(64 * nwl), lds, stream, g);
+  hipLaunchKernelGGL((fused_update_f64_kernel<NBM, NWV, XC, GD, PW>), dim3(g.batch), dim3(64 * nwl), lds, stream, g);
   return (int)hipGetLastError();
 }
 // gather staging of phase 1: two units (10 KB) per wave in flight where the slab / factor region of the LDS holds them, else one
-static int fused_gather_depth(int Np, int Mp, int XC) {
+static int fused_private_slots(int pw, int XC) { return (pw <= 6 && (XC == 64 || XC == 48)) ? 6 : 9; }
+static int fused_gather_depth(int Np, int Mp, int XC, int pws) {
   const int room = fused_lds_map(Np, Mp, XC).ops;   // doubles in front of the coefficients (live during the gather)
-  return (Np / 16) * 2 * 640 <= room ? 2 : 1;
+  const int usz = (4 * pws + 7) / 8 * 128;
+  return (Np / 16) * 2 * usz <= room ? 2 : 1;
 }
+// (slots, staging depth) of the instantiation launch_fused_update_t picks
+static void fused_variant(int Np, int Mp, int XC, int pw, int& pws, int& gd) {
+  pws = fused_private_slots(pw, XC);
+  if (pws == 6 && fused_gather_depth(Np, Mp, XC, 6) != 2) pws = 9;
+  gd = fused_gather_depth(Np, Mp, XC, pws);
+}
+// (the six-slot form is instantiated where it is used: the widest slab of either factor size with the two-unit staging)
 template <int NBM, int NWV, int XC>
 int launch_fused_update_t(const FusedArgs& g, hipStream_t stream) {
-  return fused_gather_depth(g.Np, g.Mp, XC) == 2 ? launch_fused_update_g<NBM, NWV, XC, 2>(g, stream) : launch_fused_update_g<NBM, NWV, XC, 1>(g, stream);
+  int pws, gd;
+  fused_variant(g.Np, g.Mp, XC, g.pw, pws, gd);
+  if constexpr ((NBM == 4 && XC == 64) || (NBM == 7 && XC == 48)) {
+    if (pws == 6) return launch_fused_update_g<NBM, NWV, XC, 2, 6>(g, stream);
+  }
+  return gd == 2 ? launch_fused_update_g<NBM, NWV, XC, 2, 9>(g, stream) : launch_fused_update_g<NBM, NWV, XC, 1, 9>(g, stream);
 }
 
 }  // namespace
@@ -900,21 +921,37 @@ static int fused_pick(int Mp, int Np) {
   if (nb <= 7 && nwl <= 12 && (size_t)fused_lds_map(Np, Mp, 32).total * 8 <= 160 * 1024) return 2;
   return 0;
 }
+#if XIVO_FUSED_TU != 7
 bool fused_update_supported(int Mp, int Np) { return fused_pick(Mp, Np) != 0; }
+#endif
+// Two translation units (the instantiations take minutes to compile): this file holds the M <= 64 kernels and the dispatch,
+// fused_update7.hip - which includes this file with XIVO_FUSED_TU = 7 - the M <= 112 kernels. A trace build
+// (-DXIVO_FUSED_TRACE=1) keeps everything here: its stamp buffers are device globals of ONE unit.
+#if XIVO_FUSED_TU == 7 || XIVO_FUSED_TRACE
+int launch_fused_update_k2(const FusedArgs& g, hipStream_t stream) { return launch_fused_update_t<7, 12, 32>(g, stream); }
+int launch_fused_update_k4(const FusedArgs& g, hipStream_t stream) { return launch_fused_update_t<7, 12, 48>(g, stream); }
+#else
+int launch_fused_update_k2(const FusedArgs& g, hipStream_t stream);
+int launch_fused_update_k4(const FusedArgs& g, hipStream_t stream);
+#endif
+#if XIVO_FUSED_TU != 7
 int launch_fused_update(const FusedArgs& g, hipStream_t stream) {
   if (g.batch <= 0) return 0;
   switch (fused_pick(g.Mp, g.Np)) {
     case 1: return launch_fused_update_t<4, 16, 64>(g, stream);
-    case 2: return launch_fused_update_t<7, 12, 32>(g, stream);
+    case 2: return launch_fused_update_k2(g, stream);
     case 3: return launch_fused_update_t<4, 16, 32>(g, stream);
-    case 4: return launch_fused_update_t<7, 12, 48>(g, stream);
+    case 4: return launch_fused_update_k4(g, stream);
   }
   return (int)hipErrorInvalidValue;
 }
-void fused_update_label(int Mp, int Np, char* buf, size_t n) {
+void fused_update_label(int Mp, int Np, int pw, char* buf, size_t n) {
   const int k = fused_pick(Mp, Np);
-  if (k == 1 || k == 3) snprintf(buf, n, "fused_update_f64_kernel<4,16,%d,%d>", k == 1 ? 64 : 32, fused_gather_depth(Np, Mp, k == 1 ? 64 : 32));
-  else snprintf(buf, n, "fused_update_f64_kernel<7,12,%d,%d>", k == 4 ? 48 : 32, fused_gather_depth(Np, Mp, k == 4 ? 48 : 32));
+  const int xc = (k == 1) ? 64 : (k == 4 ? 48 : 32);
+  int pws, gd;
+  fused_variant(Np, Mp, xc, pw, pws, gd);
+  snprintf(buf, n, "fused_update_f64_kernel<%s,%d,%d,%d>", (k == 1 || k == 3) ? "4,16" : "7,12", xc, gd, pws);
 }
+#endif
 
 }  // namespace xivo_hip
