@@ -253,6 +253,10 @@ int xivo_hip_update_joseph_host(xivo_hip_ctx* ctx, int b, int M, const double* H
 /* Test hook (needs neither a device nor a context): the host-side row-pair compression xivo_hip_update_joseph_host applies
  * to H_ while staging it - idx [pairs_clear][28] / val [pairs_clear][28][2] in the layout of the batched hand-over
  * (xivo_hip_set_measurements_device), *nc common slots, *pw private slots; returns 1 when the rows do not fit, else 0. */
+/* Host-only check of the tables that say which wave of the one-kernel update (csrc/fused_update.hip) forms which tile of
+ * P+ at 10 / 13 column blocks: every block pair exactly once, the counts the kernel's dispatch assumes, per_simd[4] (optional)
+ * the tiles per SIMD. 0 = consistent, -1 = no table for that size. No GPU needed. */
+int xivo_hip_selftest_fused_tiles(int column_blocks, int* per_simd);
 int xivo_hip_selftest_host_compress(const double* H, int ldh, int M, int N, int pairs_clear, int* idx, double* val, int* nc, int* pw);
 /* Estimator::MHGating numeric core on dense rows (src/update.cpp:60-96):
  * rows 2f,2f+1 of the staged H are feature f's J. Writes the inlier mask and

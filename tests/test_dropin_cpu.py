@@ -95,3 +95,17 @@ def test_rows_that_do_not_fit_are_reported(built):
     got, want = run(lib, Hs, 16), restate(Hs, 16)
     assert got[4] == want[4] and got[2:] == want[2:]
     assert lib.xivo_hip_selftest_host_compress(None, 1, 1, 1, 1, None, None, None, None) == -1
+
+
+def test_fused_update_tile_tables_cover_every_block_pair_once(built):
+    """The orientation tables of the one-kernel update's product phase (csrc/fused_update.hip, kFusedTiles10 / 13): every
+    unordered pair of column blocks is formed by exactly one wave, counts as the kernel's dispatch assumes, SIMD loads balanced
+    (14 14 14 13 of 55 tiles; 23 23 23 22 of 91). Host code only."""
+    import ctypes as C
+    from xivo_amd.lib import load_library
+    lib = load_library()
+    for nwl, want in ((10, [14, 13, 14, 14]), (13, [23, 23, 23, 22])):
+        simd = (C.c_int * 4)()
+        assert lib.xivo_hip_selftest_fused_tiles(nwl, simd) == 0
+        assert sorted(simd) == sorted(want) and sum(simd) == nwl * (nwl + 1) // 2
+    assert lib.xivo_hip_selftest_fused_tiles(12, None) == -1

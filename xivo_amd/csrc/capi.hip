@@ -1235,6 +1235,8 @@ static int host_compress(xivo_hip_ctx::HostCompressScratch& sc, const double* H,
 
 // test hook (no device, no context): the host-side row compression on its own, for the CPU test that pins it to the format
 // of ell.h / meas_compress_kernel. idx [pairs_clear][28], val [pairs_clear][28][2]; returns over.
+int xivo_hip_selftest_fused_tiles(int column_blocks, int* per_simd) { return fused_tiles_selftest(column_blocks, per_simd); }
+
 int xivo_hip_selftest_host_compress(const double* H, int ldh, int M, int N, int pairs_clear, int* idx, double* val, int* nc, int* pw) {
   if (!H || !idx || !val || !nc || !pw || M <= 0 || N <= 0 || ldh < M || 2 * pairs_clear < M) return XIVO_HIP_ERR_INVALID;
   xivo_hip_ctx::HostCompressScratch sc;

@@ -25,5 +25,6 @@ struct FusedArgs {
 bool fused_update_supported(int Mp, int Np);
 int launch_fused_update(const FusedArgs& g, hipStream_t stream);
 void fused_update_label(int Mp, int Np, int pw, char* buf, size_t n);
+int fused_tiles_selftest(int nwl, int* per_simd);
 
 }  // namespace xivo_hip

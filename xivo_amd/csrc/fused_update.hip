@@ -131,13 +131,18 @@ __device__ __forceinline__ void fu_anchor(unsigned& a, int& b, double x, double 
 // formed by wave a or by wave b (each holds its own row block of W - D in registers, W + D of every block is in LDS): these
 // tables orient the 45 / 78 pairs so that every SIMD forms 14 + 14 + 14 + 13 of the 55 tiles, or 23 + 23 + 23 + 22 of the 91
 // (a maximum-flow orientation, computed offline; the wave's own diagonal tile first, -1 = no tile).
-__device__ const signed char kFusedTiles10[10][8] = {
-    {0, 1, 3, 4, 5, -1, -1, -1}, {1, 2, 3, 4, 5, -1, -1, -1}, {2, 0, 3, 4, 5, 6, 8, -1}, {3, 4, 5, 6, 7, 8, 9, -1}, {4, 5, 6, 8, 9, -1, -1, -1},
-    {5, 7, 8, 9, -1, -1, -1, -1}, {6, 0, 1, 5, 7, 8, 9, -1}, {7, 0, 1, 2, 4, 8, 9, -1}, {8, 0, 1, 9, -1, -1, -1, -1}, {9, 0, 1, 2, -1, -1, -1, -1}};
-__device__ const signed char kFusedTiles13[13][8] = {
-    {0, 1, 2, 4, 6, 7, -1, -1}, {1, 2, 3, 4, 5, 6, 7, 9}, {2, 3, 4, 5, 6, 7, 8, 10}, {3, 0, 4, 5, 6, 7, 8, 10}, {4, 5, 8, 9, 10, 12, -1, -1},
-    {5, 0, 6, 7, 8, 9, 11, 12}, {6, 4, 7, 8, 9, 10, 11, 12}, {7, 4, 8, 9, 10, 11, 12, -1}, {8, 0, 1, 9, 11, 12, -1, -1}, {9, 0, 2, 3, 10, 11, 12, -1},
-    {10, 0, 1, 5, 8, 11, 12, -1}, {11, 0, 1, 2, 3, 4, 12, -1}, {12, 0, 1, 2, 3, -1, -1, -1}};
+#define XIVO_FUSED_TILES10 \
+    {0, 1, 3, 4, 5, -1, -1, -1}, {1, 2, 3, 4, 5, -1, -1, -1}, {2, 0, 3, 4, 5, 6, 8, -1}, {3, 4, 5, 6, 7, 8, 9, -1}, {4, 5, 6, 8, 9, -1, -1, -1}, \
+    {5, 7, 8, 9, -1, -1, -1, -1}, {6, 0, 1, 5, 7, 8, 9, -1}, {7, 0, 1, 2, 4, 8, 9, -1}, {8, 0, 1, 9, -1, -1, -1, -1}, {9, 0, 1, 2, -1, -1, -1, -1}
+#define XIVO_FUSED_TILES13 \
+    {0, 1, 2, 4, 6, 7, -1, -1}, {1, 2, 3, 4, 5, 6, 7, 9}, {2, 3, 4, 5, 6, 7, 8, 10}, {3, 0, 4, 5, 6, 7, 8, 10}, {4, 5, 8, 9, 10, 12, -1, -1}, \
+    {5, 0, 6, 7, 8, 9, 11, 12}, {6, 4, 7, 8, 9, 10, 11, 12}, {7, 4, 8, 9, 10, 11, 12, -1}, {8, 0, 1, 9, 11, 12, -1, -1}, {9, 0, 2, 3, 10, 11, 12, -1}, \
+    {10, 0, 1, 5, 8, 11, 12, -1}, {11, 0, 1, 2, 3, 4, 12, -1}, {12, 0, 1, 2, 3, -1, -1, -1}
+__device__ const signed char kFusedTiles10[10][8] = {XIVO_FUSED_TILES10};
+__device__ const signed char kFusedTiles13[13][8] = {XIVO_FUSED_TILES13};
+// (host copies for xivo_hip_selftest_fused_tiles: every block pair exactly once, the counts the kernel's dispatch assumes)
+static const signed char kFusedTiles10Host[10][8] = {XIVO_FUSED_TILES10};
+static const signed char kFusedTiles13Host[13][8] = {XIVO_FUSED_TILES13};
 
 // TAB = 0: the cyclic rule (tile t of wave w is the pair (w, w - t mod nwl), NTU = nwl / 2 + 1 tiles per wave, the last one a dummy
 // for half the waves of an even nwl); TAB = 10 / 13: the wave's list of the tables above, NTU of them, all real.
@@ -944,6 +949,35 @@ int launch_fused_update(const FusedArgs& g, hipStream_t stream) {
     case 4: return launch_fused_update_k4(g, stream);
   }
   return (int)hipErrorInvalidValue;
+}
+// The orientation tables of the product phase, checked on the host: every unordered block pair {a, b} (a == b: the diagonal tile)
+// is formed by exactly one wave, a wave's own diagonal tile comes first, the per-wave counts are the ones the kernel's dispatch
+// hard-codes, and no SIMD (wave % 4) forms more than ceil(tiles / 4) of them. Returns 0, or the number of the failed check.
+int fused_tiles_selftest(int nwl, int* per_simd /* [4] */) {
+  if (nwl != 10 && nwl != 13) return -1;
+  int seen[13][13] = {}, cnt[13] = {}, simd[4] = {};
+  for (int w = 0; w < nwl; ++w) {
+    const signed char* row = nwl == 10 ? kFusedTiles10Host[w] : kFusedTiles13Host[w];
+    if (row[0] != w) return 1;
+    bool ended = false;
+    for (int t = 0; t < 8; ++t) {
+      const int jb = row[t];
+      if (jb < 0) { ended = true; continue; }
+      if (ended || jb >= nwl) return 2;
+      const int a = w > jb ? w : jb, b = w > jb ? jb : w;
+      if (seen[a][b]++) return 3;
+      ++cnt[w]; ++simd[w & 3];
+    }
+  }
+  for (int a = 0; a < nwl; ++a) for (int b = 0; b <= a; ++b) if (seen[a][b] != 1) return 4;
+  for (int w = 0; w < nwl; ++w) {
+    const int want = nwl == 10 ? ((w == 2 || w == 3 || w == 6 || w == 7) ? 7 : ((w == 0 || w == 1 || w == 4) ? 5 : 4))
+                               : ((w == 12) ? 5 : ((w & 3) == 0 ? 6 : ((w == 7 || w >= 9) ? 7 : 8)));
+    if (cnt[w] != want) return 5;
+  }
+  const int tiles = nwl * (nwl + 1) / 2;
+  for (int q = 0; q < 4; ++q) { if (simd[q] > (tiles + 3) / 4) return 6; if (per_simd) per_simd[q] = simd[q]; }
+  return 0;
 }
 void fused_update_label(int Mp, int Np, int pw, char* buf, size_t n) {
   const int k = fused_pick(Mp, Np);

@@ -152,6 +152,7 @@ _SIGS = {
     "xivo_hip_get_calib_state": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_set_calib_gyro": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "xivo_hip_propagate_calib": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "xivo_hip_selftest_fused_tiles": [C.c_int, C.c_void_p],
     "xivo_hip_selftest_host_compress": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
 }
 HOST_P_RESIDENT, HOST_KEEP_P = 1, 2
