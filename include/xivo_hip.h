@@ -486,6 +486,7 @@ int xivo_hip_propagate(xivo_hip_ctx* ctx, int b0, int nb, int n_imu, const xivo_
  * (src/core.h:40-75) = Cg + 15, or td + 1 without the IMU calibration; ComposeMotion with the resident imu_.Cg() / imu_.Ca()
  * (xivo_calib_in), the motion Jacobian with the dWsb/dCg and dVsb/dCa blocks (src/estimator.cpp:626-638, :674-688), the tail
  * over motion_size rows / columns. Qmodel: motion_size x motion_size, column-major (opts->Qmodel is not read).
+ * opts->control_stepsize works as in xivo_hip_propagate (the step a filter carries is shared by the two entry points).
  * xivo_hip_propagate itself refuses such a context (XIVO_HIP_ERR_UNSUPPORTED): its motion block is the default build's 23. */
 int xivo_hip_propagate_calib(xivo_hip_ctx* ctx, int b0, int nb, int n_imu, const xivo_imu_in* imu, const xivo_prop_opts* opts,
                              const double* Qmodel);

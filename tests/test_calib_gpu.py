@@ -381,6 +381,44 @@ def test_propagate_with_calibration_columns(built, method, temporal, imu_cal, ca
             assert np.abs(F1[0:3, lay.Cg:lay.Cg + 9]).max() > 0.01 and np.abs(F1[6:9, lay.Ca:lay.Ca + 6]).max() > 1.0
 
 
+@pytest.mark.parametrize("temporal,imu_cal,motion", [(True, True, 39), (True, False, 24)])
+def test_propagate_calib_step_size_control_as_coded(built, temporal, imu_cal, motion):
+    """xivo_prop_opts.control_stepsize on an online-calibration context (kMotionSize 39 / 24): the step-size-controlled branch of
+    Estimator::PrinceDormand (src/princedormand.cpp:26-60) as coded - samples of different lengths, two calls, the step carried
+    per filter - against the oracle restatement (pinned to the extracted function: tests/test_oracle_pinned.py, golden_v7)."""
+    lay, sc, poses, groups, feats, calib, st, Cgs, Cas, ctx = motion_setup(temporal, imu_cal, 0)
+    assert lay.motion_size == motion
+    B, N = poses.shape[0], lay.N
+    rng = np.random.default_rng(77)
+    P = np.array([spd(N, 170 + b) * 1e-3 for b in range(B)])
+    dts = np.array([0.0025, 0.007, 0.0025, 0.012, 0.001])
+    K = len(dts)
+    imu = np.zeros((B, K), dtype=imu_dtype)
+    imu["gyro"] = rng.normal(size=(B, K, 3)) * 0.3; imu["accel"] = rng.normal(size=(B, K, 3)) + np.array([0, 0, 9.8])
+    imu["slope_gyro"] = rng.normal(size=(B, K, 3)) * 5.0; imu["slope_accel"] = rng.normal(size=(B, K, 3)) * 20.0
+    imu["dt"] = dts[None, :] * (1.0 + 0.07 * np.arange(B))[:, None]
+    Qi = np.diag(rng.uniform(1e-6, 1e-4, 12)); A = rng.normal(size=(motion, motion)) * 1e-4; Qm = A @ A.T
+    g = np.array([0.0, 0.0, -9.796])
+    ctlo = dict(tolerance=1e-3, attempts=12, min_scale_factor=0.125, max_scale_factor=4.0)
+    with ctx:
+        ctx.upload_P(P); ctx.set_scene(poses, groups, feats); ctx.set_calib_state(calib)
+        ctx.propagate_calib(imu[:, :2], Qi, Qm, g, method="PrinceDormand", stepsize=0.002, pd_control=ctlo)
+        ctx.propagate_calib(imu[:, 2:], Qi, Qm, g, method="PrinceDormand", stepsize=0.002, pd_control=ctlo)
+        Pn = ctx.download_P()
+        pose_d, _, _ = ctx.get_scene()
+    for b in range(B):
+        Xr, Pr = st[b], P[b]
+        ctl = orc.PDControl(stepsize=0.002, **ctlo)
+        for k in range(K):
+            Xr, Pr = orc.propagate(Xr, Pr, imu["gyro"][b, k], imu["accel"][b, k], imu["slope_gyro"][b, k], imu["slope_accel"][b, k],
+                                   float(imu["dt"][b, k]), Qi, Qm, g, method="PrinceDormand", stepsize=0.002, Cg=Cgs[b], Ca=Cas[b], layout=lay,
+                                   pd_control=ctl)
+        assert len(ctl.steps) > K                                       # (some sample took more than one step)
+        assert rel_fro(Pn[b], Pr) < 1e-11
+        assert np.abs(pose_d[b]["Rsb"].reshape(3, 3).T - Xr.Rsb).max() < 1e-12
+        assert np.abs(pose_d[b]["Tsb"] - Xr.Tsb).max() < 1e-12 and np.abs(pose_d[b]["Vsb"] - Xr.Vsb).max() < 1e-12
+
+
 def test_absorb_error_retracts_the_calibration_state(built):
     """xivo_hip_absorb_error on an online-calibration context: td, Ca's upper triangle, Cg, the nine radtan intrinsics move by
     their dx components (src/core.h:150-152, src/imu.cpp:7-21, common/camera_autocalib.h:34-47); the Jacobians that follow use

@@ -2255,7 +2255,13 @@ int xivo_hip_propagate_calib(xivo_hip_ctx* c, int b0, int nb, int n_imu, const x
     return XIVO_HIP_ERR_INVALID;
   const int nm = c->cl.Cg >= 0 ? c->cl.Cg + 15 : c->cl.td + 1;
   if (nm > 40 || c->N < nm || c->lay.group_begin < nm) return XIVO_HIP_ERR_INVALID;
-  if (o->control_stepsize) return XIVO_HIP_ERR_UNSUPPORTED;   // the step-size-controlled branch is built for the default motion block only
+  if (o->control_stepsize && (o->method != 1 || !(o->stepsize > 0) || !(o->max_scale_factor > 0))) return XIVO_HIP_ERR_INVALID;
+  if (o->control_stepsize && (!c->pd_h || c->pd_h0 != o->stepsize)) {   // (as in xivo_hip_propagate: the step every filter carries)
+    if (!c->pd_h) { int rcd = dev_alloc(&c->pd_h, (size_t)c->Bmax); if (rcd) return rcd; }
+    std::vector<double> h0((size_t)c->Bmax, o->stepsize);
+    HIP_TRY(hipMemcpy(c->pd_h, h0.data(), h0.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->pd_h0 = o->stepsize;
+  }
   if (nb == 0) return XIVO_HIP_OK;
   for (size_t b = 0; b < (size_t)nb * n_imu; ++b)
     if (!(imu[b].dt > 0.0) || (o->stepsize >= 0 && o->stepsize < 1e-6)) return XIVO_HIP_ERR_INVALID;
@@ -2271,6 +2277,9 @@ int xivo_hip_propagate_calib(xivo_hip_ctx* c, int b0, int nb, int n_imu, const x
   PropStateArgs a{};
   a.poses = c->poses + b0; a.imu = dImu; a.n_imu = n_imu; a.Qimu = dQi; a.Qmodel = dQm;
   a.g[0] = o->g[0]; a.g[1] = o->g[1]; a.g[2] = o->g[2]; a.method = o->method; a.stepsize = o->stepsize;
+  if (o->control_stepsize) {
+    a.pd_h = c->pd_h + b0; a.pd_tol = o->tolerance; a.pd_min_scale = o->min_scale_factor; a.pd_max_scale = o->max_scale_factor;
+  }
   a.P = c->P + (long)b0 * c->sP; a.strideP = c->sP; a.ldp = c->Np; a.Phi_out = dPhi; a.Pmm_out = dPmm; a.batch = nb;
   a.nm = nm; a.iCg = c->cl.Cg; a.calib = c->calib + b0;
   {

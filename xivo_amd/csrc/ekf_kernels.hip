@@ -1702,17 +1702,25 @@ __global__ __launch_bounds__(256) void propagate_state_calib_kernel(PropStateArg
   __syncthreads();
 
   const xivo_imu_in* imu_f = a.imu + (long)filt * a.n_imu;
+  // step-size-controlled Dormand-Prince (princedormand.cpp:26-60, as in propagate_state_wave_kernel): every thread carries the step
+  const bool ctl = NS == 7 && a.pd_h != nullptr;
+  double hs = ctl ? a.pd_h[filt] : 0.0;
   for (int smp = 0; smp < a.n_imu; ++smp) {
     if (lane < 3) {
       nom[24 + lane] = imu_f[smp].gyro[lane]; nom[27 + lane] = imu_f[smp].accel[lane];
       nom[30 + lane] = imu_f[smp].slope_gyro[lane]; nom[33 + lane] = imu_f[smp].slope_accel[lane];
     }
     const double dt = imu_f[smp].dt;
+    if (ctl) {
+      if (hs < 1e-6) hs = a.stepsize;        // :30-32
+      hs = fmin(hs, dt);                     // :34
+    }
     __syncthreads();
     double total = 0.0;
-    while (total < dt || a.stepsize < 0) {     // rk4.cpp:13-32, princedormand.cpp:62-81
+    while (total < dt || (!ctl && a.stepsize < 0)) {     // rk4.cpp:13-32, princedormand.cpp:62-81
       double h = a.stepsize;
-      if (a.stepsize < 0) h = dt;
+      if (ctl) h = hs;
+      else if (a.stepsize < 0) h = dt;
       else if (total + h > dt) h = dt - total;
       else if (total + h + 0.5 * h > dt) h = 0.5 * h;
 
@@ -1899,7 +1907,23 @@ __global__ __launch_bounds__(256) void propagate_state_calib_kernel(PropStateArg
       { double* t = Phi; Phi = PhiN; PhiN = t; }
       __syncthreads();
       total += h;
-      if (a.stepsize < 0) break;
+      if (ctl) {
+        const double err = 0.0;                // PrinceDormandStep returns 0 (:216-220)
+        double scale;
+        if (err == 0.0) scale = a.pd_max_scale;                                                     // :42-43
+        else scale = fmin(fmax(0.8 * sqrt(sqrt(a.pd_tol * h / err)), a.pd_min_scale), a.pd_max_scale);   // :45-47
+        hs = h * scale;                                                                             // :51
+        if (total < dt) {                                                                           // :52-58
+          if (total + hs > dt) hs = dt - total;
+          else if (total + hs + 0.5 * hs > dt) hs = 0.5 * hs;
+        }
+        // the next step starts from gyro0 + slope * total_step (:38-39)
+        if (lane < 3) {
+          nom[24 + lane] = imu_f[smp].gyro[lane] + imu_f[smp].slope_gyro[lane] * total;
+          nom[27 + lane] = imu_f[smp].accel[lane] + imu_f[smp].slope_accel[lane] * total;
+        }
+        __syncthreads();
+      } else if (a.stepsize < 0) break;
     }
     for (int e = lane; e < NN; e += NT) Pmm[e] += a.Qmodel[e];   // estimator.cpp:590, per Propagate
     __syncthreads();
@@ -1909,6 +1933,7 @@ __global__ __launch_bounds__(256) void propagate_state_calib_kernel(PropStateArg
     a.Pmm_out[(long)filt * NN + e] = Pmm[e];
     a.Phi_out[(long)filt * NN + e] = i < FR ? Phi[i + FR * j] : (i == j ? 1.0 : 0.0);
   }
+  if (ctl && lane == 0) a.pd_h[filt] = hs;
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {

@@ -580,7 +580,7 @@ class Context:
             o["min_scale_factor"] = pd_control.get("min_scale_factor", 0.125); o["max_scale_factor"] = pd_control.get("max_scale_factor", 4.0)
         self._check(self.lib.xivo_hip_propagate(self.h, b0, imu.shape[0], imu.shape[1], _ptr(imu), _ptr(o)))
 
-    def propagate_calib(self, imu, Qimu, Qmodel, g, method="RK4", stepsize=0.002, b0=0):
+    def propagate_calib(self, imu, Qimu, Qmodel, g, method="RK4", stepsize=0.002, b0=0, pd_control=None):
         """Estimator::Propagate of an online-calibration build (set_calib with td >= 0 or Cg >= 0): Qmodel is
         kMotionSize x kMotionSize (numpy row-major); the resident calibration state supplies Cg / Ca."""
         imu = np.ascontiguousarray(imu, dtype=imu_dtype)
@@ -590,6 +590,10 @@ class Context:
         o = np.zeros(1, dtype=prop_opts_dtype)
         o["Qimu"] = np.asarray(Qimu, dtype=np.float64).T.reshape(-1)
         o["g"] = g; o["method"] = 0 if method == "RK4" else 1; o["stepsize"] = stepsize
+        if pd_control is not None:
+            o["control_stepsize"] = 1
+            o["tolerance"] = pd_control.get("tolerance", 1e-3); o["attempts"] = pd_control.get("attempts", 12)
+            o["min_scale_factor"] = pd_control.get("min_scale_factor", 0.125); o["max_scale_factor"] = pd_control.get("max_scale_factor", 4.0)
         Qm = np.ascontiguousarray(np.asarray(Qmodel, dtype=np.float64).T)
         self._check(self.lib.xivo_hip_propagate_calib(self.h, b0, imu.shape[0], imu.shape[1], _ptr(imu), _ptr(o), _ptr(Qm)))
 
