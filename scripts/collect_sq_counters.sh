@@ -20,6 +20,6 @@ for p in ("p1","p2","p3"):
         k=r["Kernel_Name"].split("(")[0][-50:]
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[(k,r["Counter_Name"])]+=1
     for k,v in agg.items():
-        if "trsm" in k or "ell_tile" in k or "chol" in k or "fused" in k:
+        if "trsm" in k or "ell_tile" in k or "chol" in k or "fused" in k or "propagate" in k:
             print(p, k, {c: round(val/max(1,n[(k,c)])/1e6,2) for c,val in v.items()}, "(M per dispatch)")
 PY
